@@ -1,0 +1,222 @@
+/*
+ * tacex_hip.h - C ABI of libtacex_hip.so, the MI355X (gfx950) implementation of the TacEx tactile hot path.
+ *
+ * The reference (DH-Ng/TacEx) has no FFI: its hot path is PyTorch code behind the Python plugin classes
+ * GelSightSimulator / GelSightSensor.  This header is the boundary the build introduces UNDER those
+ * classes; each entry point names the reference code it replaces.  Short names:
+ *   TT = source/tacex/tacex/simulation_approaches/gpu_taxim/sim/taxim_torch.py
+ *   TS = source/tacex/tacex/simulation_approaches/gpu_taxim/taxim_sim.py
+ *   GS = source/tacex/tacex/gelsight_sensor.py
+ *   MM = source/tacex/tacex/simulation_approaches/fots/sim/marker_motion.py
+ *   FS = source/tacex/tacex/simulation_approaches/fots/fots_marker_sim.py
+ *   US/UO/UA = source/tacex_uipc/tacex_uipc/{sim/uipc_sim.py,objects/uipc_object.py,sim/uipc_attachments.py}
+ *   VT = source/tacex/tacex/simulation_approaches/fem_based/sim/tactile_sensor_sapienipc_modified.py
+ *
+ * Conventions
+ *   - plain C types only; every `*_dev` pointer is DEVICE memory owned by the caller (PyTorch, usually);
+ *   - no allocation, no synchronisation inside a compute call: work is enqueued on `stream`
+ *     (a hipStream_t passed as void*; NULL = the null stream);
+ *   - one context per device, not thread-safe per context;
+ *   - every function returns 0 on success, non-zero on error; tacex_last_error() gives the message
+ *     (the Python layer turns it into RuntimeError / ValueError like the reference's exceptions);
+ *   - images are row-major float32, batch first: height maps (B,H,W) in millimetres, RGB (B,H,W,3).
+ */
+#ifndef TACEX_HIP_H
+#define TACEX_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TACEX_MAX_LEVELS 8
+#define TACEX_ABI_VERSION 1
+
+typedef struct tacex_taxim_ctx tacex_taxim_ctx;
+typedef struct tacex_fots_ctx tacex_fots_ctx;
+typedef struct tacex_fem_ctx tacex_fem_ctx;
+
+const char* tacex_last_error(void);
+int tacex_abi_version(void);
+/* Number of HIP devices visible / name of the gcn arch of `device_id` (for loud failure messages). */
+int tacex_device_count(int* count);
+int tacex_device_arch(int device_id, char* buf, size_t buflen);
+
+/* ---------------------------------------------------------------------------------------------
+ * Taxim optical path.  Tables are HOST pointers, copied to the device once at creation
+ * (replaces TaximTorch.__init__, TT:50-130, and the lru-cached tables TT:136-164).
+ * ------------------------------------------------------------------------------------------- */
+typedef struct tacex_taxim_params {
+  int32_t height, width;        /* tactile image size H, W (TS:49-54 tactile_img_res = (W,H)) */
+  int32_t calib_height, calib_width; /* calibration size (params.json sensor.h / sensor.w: 480, 640) */
+  float pixmm;                  /* params.json sensor.pixmm (0.0295) */
+  int32_t num_bins;             /* params.json sensor.num_bins (125) */
+  float contact_scale;          /* params.json simulator.contact_scale (0.4), TT:459 */
+  int32_t n_levels;             /* pyramid levels + 1 final blur (7), TT:464-471 */
+  int32_t ksize_w[TACEX_MAX_LEVELS]; /* odd kernel widths  per level, TT:396-403 */
+  int32_t ksize_h[TACEX_MAX_LEVELS]; /* odd kernel heights per level */
+  const float* taps_w[TACEX_MAX_LEVELS]; /* normalised float32 taps, ksize_w[l] each, TT:362-366 */
+  const float* taps_h[TACEX_MAX_LEVELS];
+  const float* poly;            /* (3, num_bins, num_bins, 6) float32 = stack(grad_b,grad_g,grad_r)/255, TT:73-80 */
+  const float* gel_map;         /* (H, W) float32, mm, max == 0, TT:82-90,159-164 */
+  const float* background;      /* (3, H, W) float32 in [0,1], TT:92-94,136-137,414-430 */
+  const float* feat_x;          /* (W,) float32: linspace(0, calib_width,  W+1)[:-1], TT:139-157 */
+  const float* feat_y;          /* (H,) float32: linspace(0, calib_height, H+1)[:-1] */
+} tacex_taxim_params;
+
+int tacex_taxim_create(int device_id, const tacex_taxim_params* params, tacex_taxim_ctx** out);
+void tacex_taxim_destroy(tacex_taxim_ctx* ctx);
+
+/* Bytes of caller-provided device scratch tacex_taxim_render / tacex_taxim_deform need for B frames. */
+size_t tacex_taxim_workspace_bytes(const tacex_taxim_ctx* ctx, int num_frames);
+
+/* GS:581-593 (_get_height_map) + GS:557-579 (_get_camera_depth) + TS:115-131 (compute_indentation_depth)
+ * in one pass over the camera depth image:
+ *   hm_mm      = (isinf(depth_m) ? far_clip_m : depth_m) * 1000                       (B,Hc,Wc)
+ *   frame_min  = min over the frame of hm_mm                                           (B,)
+ *   indent_mm  = d <= gelpad_height ? (gelpad_height - d) * 1000 : 0,
+ *                d = max(frame_min/1000 - gelpad_to_camera_min_distance, 0)            (B,)  [nullable]
+ *   cam_u8     = uint8(((hm_mm - near_clip_m*1000) / (far_clip_m*1000)) * 255)  (sic)  (B,Hc,Wc) [nullable]
+ * depth_m_dev may alias hm_mm_dev. */
+int tacex_height_map_from_depth(const float* depth_m_dev, float near_clip_m, float far_clip_m,
+                                float gelpad_height_m, float gelpad_to_camera_min_distance_m,
+                                float* hm_mm_dev, float* frame_min_dev, float* indent_mm_dev,
+                                uint8_t* cam_u8_dev, int num_frames, int height, int width, void* stream);
+
+/* TS:115-131 on an existing mm height map. frame_min_dev (B,) is also written (re-used by the render). */
+int tacex_indentation_depth(const float* hm_mm_dev, float gelpad_height_m,
+                            float gelpad_to_camera_min_distance_m, float* frame_min_dev,
+                            float* indent_mm_dev, int num_frames, int height, int width, void* stream);
+
+/* Flags for tacex_taxim_render / tacex_taxim_deform */
+#define TACEX_FLAG_NO_SHIFT      1u  /* press_depth=None: use the height map as is (TT:188-189 skipped) */
+#define TACEX_FLAG_HAVE_FRAME_MIN 2u /* frame_min_dev already holds min(hm) per frame (skip that pass) */
+
+/* TaximSimulator.optical_simulation (TS:80-113) -> Taxim.render_direct (TI:153-163) ->
+ * TaximTorch._render_impl / __render no-shadow branch (TT:174-258), output already NHWC (TS:109-111).
+ *   hm_mm_dev   (B,H,W) height map in mm (H,W = ctx size)
+ *   press_dev   (B,)    press depth in mm (= indentation depth); ignored with TACEX_FLAG_NO_SHIFT
+ *   frame_min_dev (B,)  scratch/in: per-frame min of hm (see TACEX_FLAG_HAVE_FRAME_MIN)
+ *   rgb_dev     (B,H,W,3) float32 in [0,1]
+ *   z_out_dev   (B,H,W) deformed gel (mm) after the final blur, nullable      (TT:443-473 result #1)
+ *   mask_out_dev(B,H,W) uint8 shrunken contact mask, nullable                 (TT:473 result #2)
+ *   workspace_dev: tacex_taxim_workspace_bytes(ctx, B) bytes of device scratch */
+int tacex_taxim_render(tacex_taxim_ctx* ctx, const float* hm_mm_dev, const float* press_dev,
+                       float* frame_min_dev, float* rgb_dev, float* z_out_dev, uint8_t* mask_out_dev,
+                       void* workspace_dev, int num_frames, unsigned flags, void* stream);
+
+/* __get_shifted_height_map + __compute_gel_pad_deformation only (TT:432-473), as the FOTS wrapper calls
+ * them (FS:128-129). Same arguments as above without the shading. */
+int tacex_taxim_deform(tacex_taxim_ctx* ctx, const float* hm_mm_dev, const float* press_dev,
+                       float* frame_min_dev, float* z_out_dev, uint8_t* mask_out_dev,
+                       void* workspace_dev, int num_frames, unsigned flags, void* stream);
+
+/* Shading only: deformed gel (B,H,W) mm -> RGB (TT:237-258): normals, bins, polynomial, + background, clip.
+ * idx_out_dev (B,H,W,2) uint8 [idx_mag, idx_dir] is optional (parity tests). */
+int tacex_taxim_shade(tacex_taxim_ctx* ctx, const float* z_dev, float* rgb_dev, uint8_t* idx_out_dev,
+                      int num_frames, void* stream);
+
+/* torchvision resize(bilinear, antialias=True) of a batch of single-channel images, used when the camera
+ * resolution differs from the tactile resolution (TS:88-89, FS:121-122). */
+int tacex_resize_bilinear_aa(const float* src_dev, int src_h, int src_w, float* dst_dev, int dst_h,
+                             int dst_w, int num_frames, void* stream);
+
+/* Optional per-stage timing with hipEvents on the launch stream (bench.py's roofline leg).
+ * Stages: 0 = frame-min, 1..n_levels = blur levels, n_levels+1 = shade. */
+int tacex_taxim_set_profiling(tacex_taxim_ctx* ctx, int enabled);
+/* Synchronises the recorded events; returns accumulated milliseconds and launch count, then resets. */
+int tacex_taxim_read_profile(tacex_taxim_ctx* ctx, int stage, double* total_ms, int* launches);
+int tacex_taxim_num_stages(const tacex_taxim_ctx* ctx);
+const char* tacex_taxim_stage_name(const tacex_taxim_ctx* ctx, int stage);
+
+/* ---------------------------------------------------------------------------------------------
+ * FOTS marker-displacement field (MM:22-219 driven per env by FS:114-184).
+ * ------------------------------------------------------------------------------------------- */
+typedef struct tacex_fots_params {
+  int32_t height, width;          /* tactile image size */
+  int32_t num_markers_row, num_markers_col; /* 9, 11 (FSC:46-53) */
+  const int32_t* marker_x;        /* HOST (rows*cols,) initial pixel x, row-major (row, col), MM:59-76 */
+  const int32_t* marker_y;        /* HOST (rows*cols,) initial pixel y */
+  double lamb[3];                 /* [dilate, shear, twist] = [0.00125, 0.00021, 0.00038], FS:77 */
+  float mm2pix;                   /* 19.58, FSC:36 */
+  float shear_max;                /* 10 px, MM:78 */
+  float theta_max_deg;            /* 60 deg, MM:90 */
+} tacex_fots_params;
+
+int tacex_fots_create(int device_id, const tacex_fots_params* params, tacex_fots_ctx** out);
+void tacex_fots_destroy(tacex_fots_ctx* ctx);
+
+/* Per-env trajectory state (FS:101-103,168,176-177): only traj[0], traj[-1] and len(traj) are ever read
+ * (MM:177-205).  Layout of traj_state_dev: (B, 8) float32 = [len, x0, y0, th0, xl, yl, thl, pad].
+ * Bytes needed: */
+size_t tacex_fots_state_bytes(int num_envs);
+size_t tacex_fots_workspace_bytes(int num_envs);
+
+/* FS:130-182 for all envs in one go:
+ *   z_dev (B,H,W) deformed gel, mask_dev (B,H,W) uint8 (both from tacex_taxim_deform / _render),
+ *   indent_dev (B,) mm, theta_dev (B,) yaw of the indenter in the sensor frame (replaces the
+ *   FrameTransformer read-out FS:147-159), traj_state_dev in/out,
+ *   markers_dev (B,2,M,2) float32: [initial | current] x (x, y), FS:90-99. */
+int tacex_fots_markers(tacex_fots_ctx* ctx, const float* z_dev, const uint8_t* mask_dev,
+                       const float* indent_dev, const float* theta_dev, float* traj_state_dev,
+                       float* markers_dev, void* workspace_dev, int num_envs, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Gelpad FEM inner step (what libuipc's world.advance() runs for the StableNeoHookean gelpad,
+ * US:250-252, UO:442-470, UA:364-428).  Batched: `num_envs` independent copies of one tet mesh.
+ * All floating point is float64.  Parity: UNPINNED (libuipc is an un-vendored submodule); the
+ * restatement follows Smith, de Goes, Kim 2018 "Stable Neo-Hookean Flesh Simulation".
+ * ------------------------------------------------------------------------------------------- */
+typedef struct tacex_fem_params {
+  int32_t num_verts, num_tets;
+  const double* rest_positions;  /* HOST (V,3) */
+  const int32_t* tets;           /* HOST (T,4) */
+  double youngs, poisson;        /* Pa, - (UO:59,76-88: E = 0.01 MPa, nu = 0.49) */
+  double density;                /* kg/m^3 (1e3) */
+  double dt;                     /* s (US:57: 0.01) */
+  double gravity[3];             /* (0,0,-9.8) US:60 */
+  double constraint_strength_ratio; /* SoftPositionConstraint strength (UA:38: 100) */
+} tacex_fem_params;
+
+int tacex_fem_create(int device_id, const tacex_fem_params* params, tacex_fem_ctx** out);
+void tacex_fem_destroy(tacex_fem_ctx* ctx);
+size_t tacex_fem_workspace_bytes(const tacex_fem_ctx* ctx, int num_envs);
+
+/* Per-element Stable-Neo-Hookean energy, gradient (12) and Hessian (12x12, optionally PSD-projected),
+ * one tet per lane.  x_dev (B,V,3); outputs nullable: energy_dev (B,T), grad_dev (B,T,12), hess_dev (B,T,144). */
+int tacex_fem_element_terms(tacex_fem_ctx* ctx, const double* x_dev, double* energy_dev, double* grad_dev,
+                            double* hess_dev, int project_psd, int num_envs, void* stream);
+
+/* Total incremental potential per env (inertia + dt^2 * elastic + soft position constraints),
+ * wavefront-reduced: E_dev (B,).  x_tilde_dev (B,V,3) is the inertial target; constrained_dev (B,V) uint8
+ * and aim_dev (B,V,3) describe UA:364-385's animation targets (nullable = no constraints). */
+int tacex_fem_energy(tacex_fem_ctx* ctx, const double* x_dev, const double* x_tilde_dev,
+                     const uint8_t* constrained_dev, const double* aim_dev, double* E_dev,
+                     void* workspace_dev, int num_envs, void* stream);
+
+/* Assembled nodal gradient (B,V,3) of the same potential - atomics-free vertex gather over incident tets. */
+int tacex_fem_gradient(tacex_fem_ctx* ctx, const double* x_dev, const double* x_tilde_dev,
+                       const uint8_t* constrained_dev, const double* aim_dev, double* g_dev,
+                       void* workspace_dev, int num_envs, void* stream);
+
+/* One projected-Newton iteration per env: assemble (block-Jacobi preconditioned) system, matrix-free PCG
+ * (US:70-72 tol_rate), backtracking line search on the energy (US:76: max_iter 8).  x_dev is updated in place.
+ * stats_dev (B,4) float64 = [energy_before, energy_after, step_length, pcg_iterations]. */
+int tacex_fem_newton_step(tacex_fem_ctx* ctx, double* x_dev, const double* x_tilde_dev,
+                          const uint8_t* constrained_dev, const double* aim_dev, double* stats_dev,
+                          void* workspace_dev, int num_envs, int pcg_max_iter, double pcg_tol_rate,
+                          int ls_max_iter, void* stream);
+
+/* FEM-driven markers (VT:347-366): barycentric surface points -> pinhole projection.
+ *   surf_pos_dev (B,Vs,3) surface vertex positions in the CAMERA frame, tri_dev (M,3) int32 vertex ids,
+ *   weight_dev (M,3) float64, intrinsics fx,fy,cx,cy (VT:57-63: 340,325,160,125) -> uv_dev (B,M,2) float64 */
+int tacex_fem_marker_uv(const double* surf_pos_dev, const int32_t* tri_dev, const double* weight_dev,
+                        double fx, double fy, double cx, double cy, double* uv_dev, int num_envs,
+                        int num_surf_verts, int num_markers, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TACEX_HIP_H */

@@ -1,0 +1,279 @@
+"""CPU oracle for the gelpad FEM inner step (TEST INFRASTRUCTURE - never imported by the product path).
+
+PARITY UNPINNED.  In the reference this arithmetic lives inside libuipc (C++/CUDA), an un-vendored git
+submodule (`.gitmodules:1-4` -> github.com/DH-Ng/libuipc, branch `tacex`, commit not recoverable,
+`source/tacex_uipc/libuipc/` is empty), reached through `world.advance()` (tacex_uipc/sim/uipc_sim.py:250-252)
+for a gelpad declared as `StableNeoHookean` with `ElasticModuli.youngs_poisson(E, nu)` and a mass density
+(tacex_uipc/objects/uipc_object.py:442-470, defaults E = 0.01 MPa, nu = 0.49, rho = 1e3 at :59,76-88),
+driven by `SoftPositionConstraint` animation targets (tacex_uipc/sim/uipc_attachments.py:139-142,364-428).
+The reference holds no test or golden vector at this boundary (tools/test_settings.py:54-57 skips libuipc's
+tests; env_test_utils.py:62 excludes the Uipc envs), so this file restates the PUBLISHED model
+
+    Smith, de Goes, Kim 2018, "Stable Neo-Hookean Flesh Simulation", eq. 14:
+        Psi(F) = mu/2 (I_C - 3) + lambda/2 (J - alpha)^2 - mu/2 log(I_C + 1),   alpha = 1 + 3 mu / (4 lambda)
+        with the paper's reparameterisation mu = 4/3 mu_Lame, lambda = lambda_Lame + 5/6 mu_Lame,
+
+inside a backward-Euler incremental potential per environment
+
+    E(x) = 1/2 sum_v m_v |x_v - xt_v|^2 + dt^2 sum_t vol_t (Psi(F_t) - Psi(I))
+           + 1/2 s sum_{v in C} m_v |x_v - aim_v|^2          (soft position constraint, strength ratio s)
+
+and pins ITSELF with known-answer tests (tests/test_fem_oracle.py): finite-difference consistency of
+energy/gradient/Hessian, zero rest force, rigid-motion invariance, PSD projection, monotone line search.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from pathlib import Path
+
+import numpy as np
+
+
+# --------------------------------------------------------------------------------------------------
+# mesh I/O: Gmsh 2.2 ASCII (the reference ships real tet meshes under
+# source/tacex_uipc/examples/libuipc-samples/tet_meshes/*.msh; fixtures under tests/golden/ are re-saved as .npz)
+# --------------------------------------------------------------------------------------------------
+def load_msh(path: Path):
+    lines = Path(path).read_text().splitlines()
+    i = lines.index("$Nodes")
+    n = int(lines[i + 1])
+    pts = np.array([[float(v) for v in lines[i + 2 + k].split()[1:4]] for k in range(n)])
+    j = lines.index("$Elements")
+    m = int(lines[j + 1])
+    tets = []
+    for k in range(m):
+        p = lines[j + 2 + k].split()
+        if int(p[1]) == 4:  # 4-node tetrahedron
+            ntags = int(p[2])
+            tets.append([int(v) - 1 for v in p[3 + ntags : 3 + ntags + 4]])
+    return pts, np.array(tets, dtype=np.int32)
+
+
+def box_tet_mesh(nx=6, ny=8, nz=3, size=(0.02075, 0.02525, 0.0045)):
+    """Regular box split into 6 tets per cell: a gelpad-sized block (gsmini_cfg.py:22-24: 20.75 x 25.25 x 4.5 mm)."""
+    xs, ys, zs = (np.linspace(0, size[d], n + 1) for d, n in enumerate((nx, ny, nz)))
+    P = np.stack(np.meshgrid(xs, ys, zs, indexing="ij"), -1).reshape(-1, 3)
+    idx = lambda i, j, k: (i * (ny + 1) + j) * (nz + 1) + k
+    tets = []
+    for i in range(nx):
+        for j in range(ny):
+            for k in range(nz):
+                c = [idx(i + a, j + b, k + d) for a in (0, 1) for b in (0, 1) for d in (0, 1)]
+                # Kuhn split around the main diagonal c[0]-c[7]
+                for p in ((1, 3), (3, 2), (2, 6), (6, 4), (4, 5), (5, 1)):
+                    tets.append([c[0], c[p[0]], c[p[1]], c[7]])
+    return P, np.array(tets, dtype=np.int32)
+
+
+def lame_from_youngs_poisson(E: float, nu: float):
+    return E / (2 * (1 + nu)), E * nu / ((1 + nu) * (1 - 2 * nu))
+
+
+@dataclass
+class FemModel:
+    X: np.ndarray         # (V,3) rest positions
+    tets: np.ndarray      # (T,4), positively oriented
+    dm_inv: np.ndarray    # (T,3,3)
+    vol: np.ndarray       # (T,)
+    mass: np.ndarray      # (V,) lumped
+    mu: float
+    lam: float
+    alpha: float
+    psi_rest: float
+    dt: float
+    strength: float
+
+    @classmethod
+    def build(cls, X, tets, youngs=1e4, poisson=0.49, density=1e3, dt=0.01, strength=100.0):
+        X = np.asarray(X, np.float64)
+        tets = np.array(tets, dtype=np.int32)
+        Dm = np.stack([X[tets[:, 1]] - X[tets[:, 0]], X[tets[:, 2]] - X[tets[:, 0]], X[tets[:, 3]] - X[tets[:, 0]]], -1)
+        det = np.linalg.det(Dm)
+        flip = det < 0
+        tets[flip] = tets[flip][:, [0, 2, 1, 3]]  # re-orient
+        Dm = np.stack([X[tets[:, 1]] - X[tets[:, 0]], X[tets[:, 2]] - X[tets[:, 0]], X[tets[:, 3]] - X[tets[:, 0]]], -1)
+        vol = np.linalg.det(Dm) / 6.0
+        assert (vol > 0).all(), "degenerate tetrahedron"
+        mass = np.zeros(len(X))
+        np.add.at(mass, tets.reshape(-1), np.repeat(density * vol / 4.0, 4))
+        mu_l, lam_l = lame_from_youngs_poisson(youngs, poisson)
+        mu, lam = 4.0 / 3.0 * mu_l, lam_l + 5.0 / 6.0 * mu_l
+        alpha = 1.0 + 0.75 * mu / lam
+        psi_rest = 0.5 * lam * (1 - alpha) ** 2 - 0.5 * mu * np.log(4.0)
+        return cls(X, tets, np.linalg.inv(Dm), vol, mass, mu, lam, alpha, psi_rest, dt, strength)
+
+    # ---- kinematics --------------------------------------------------------------------------------
+    def deformation_gradient(self, x):
+        """x (..., V, 3) -> F (..., T, 3, 3)."""
+        t = self.tets
+        Ds = np.stack([x[..., t[:, 1], :] - x[..., t[:, 0], :], x[..., t[:, 2], :] - x[..., t[:, 0], :],
+                       x[..., t[:, 3], :] - x[..., t[:, 0], :]], -1)
+        return Ds @ self.dm_inv
+
+    @staticmethod
+    def cofactor(F):
+        f0, f1, f2 = F[..., :, 0], F[..., :, 1], F[..., :, 2]
+        return np.stack([np.cross(f1, f2), np.cross(f2, f0), np.cross(f0, f1)], -1)
+
+    # ---- element terms -----------------------------------------------------------------------------------
+    def psi(self, F):
+        Ic = (F * F).sum((-2, -1))
+        J = np.linalg.det(F)
+        return 0.5 * self.mu * (Ic - 3) + 0.5 * self.lam * (J - self.alpha) ** 2 - 0.5 * self.mu * np.log(Ic + 1) - self.psi_rest
+
+    def pk1(self, F):
+        Ic = (F * F).sum((-2, -1))[..., None, None]
+        J = np.linalg.det(F)[..., None, None]
+        return self.mu * (1 - 1 / (Ic + 1)) * F + self.lam * (J - self.alpha) * self.cofactor(F)
+
+    def dpk1(self, F, dF):
+        """Directional derivative of P (the 9x9 Hessian applied to dF)."""
+        Ic = (F * F).sum((-2, -1))[..., None, None]
+        J = np.linalg.det(F)[..., None, None]
+        C = self.cofactor(F)
+        f0, f1, f2 = F[..., :, 0], F[..., :, 1], F[..., :, 2]
+        d0, d1, d2 = dF[..., :, 0], dF[..., :, 1], dF[..., :, 2]
+        dC = np.stack([np.cross(d1, f2) + np.cross(f1, d2), np.cross(d2, f0) + np.cross(f2, d0),
+                       np.cross(d0, f1) + np.cross(f0, d1)], -1)
+        FdF = (F * dF).sum((-2, -1))[..., None, None]
+        CdF = (C * dF).sum((-2, -1))[..., None, None]
+        return (self.mu * (1 - 1 / (Ic + 1)) * dF + 2 * self.mu / (Ic + 1) ** 2 * FdF * F
+                + self.lam * CdF * C + self.lam * (J - self.alpha) * dC)
+
+    def element_energy(self, x):
+        return self.vol * self.psi(self.deformation_gradient(x))  # (..., T)
+
+    def element_gradient(self, x):
+        """(..., T, 12): gradient of vol*Psi wrt the 4 vertices (x0,x1,x2,x3), xyz fastest."""
+        F = self.deformation_gradient(x)
+        Hm = self.vol[:, None, None] * (self.pk1(F) @ np.swapaxes(self.dm_inv, -1, -2))  # columns: d/dx1..3
+        g1, g2, g3 = Hm[..., :, 0], Hm[..., :, 1], Hm[..., :, 2]
+        return np.concatenate([-(g1 + g2 + g3), g1, g2, g3], -1)
+
+    def element_hessian(self, x, project_psd=False):
+        """(..., T, 12, 12) Hessian of vol*Psi; optional projection of the 9x9 F-space Hessian onto PSD."""
+        F = self.deformation_gradient(x)
+        shp = F.shape[:-2]
+        # G: (T, 9, 12) with vec(F) row-major (i*3+m) = G @ x_e
+        T = len(self.tets)
+        G = np.zeros((T, 9, 12))
+        r = np.concatenate([-self.dm_inv.sum(-2, keepdims=True), self.dm_inv], -2)  # (T,4,3): dF[k,m]/dx[v,k] = r[v,m]
+        for v in range(4):
+            for k in range(3):
+                for m in range(3):
+                    G[:, k * 3 + m, v * 3 + k] = r[:, v, m]
+        H9 = np.zeros(shp + (9, 9))
+        for q in range(9):
+            dF = np.zeros(shp + (3, 3))
+            dF[..., q // 3, q % 3] = 1.0
+            H9[..., :, q] = self.dpk1(F, dF).reshape(shp + (9,))
+        if project_psd:
+            w, V = np.linalg.eigh(0.5 * (H9 + np.swapaxes(H9, -1, -2)))
+            H9 = (V * np.maximum(w, 0.0)[..., None, :]) @ np.swapaxes(V, -1, -2)
+        return self.vol[:, None, None] * (np.swapaxes(G, -1, -2) @ H9 @ G)
+
+    # ---- incremental potential ------------------------------------------------------------------------------
+    def energy(self, x, x_tilde, constrained=None, aim=None):
+        d = x - x_tilde
+        E = 0.5 * (self.mass[:, None] * d * d).sum((-2, -1)) + self.dt**2 * self.element_energy(x).sum(-1)
+        if constrained is not None:
+            c = x - aim
+            E = E + 0.5 * self.strength * (constrained[..., None] * self.mass[:, None] * c * c).sum((-2, -1))
+        return E
+
+    def gradient(self, x, x_tilde, constrained=None, aim=None):
+        g = self.mass[:, None] * (x - x_tilde)
+        ge = self.element_gradient(x).reshape(x.shape[:-2] + (len(self.tets), 4, 3)) * self.dt**2
+        for b in np.ndindex(x.shape[:-2]):
+            np.add.at(g[b], self.tets.reshape(-1), ge[b].reshape(-1, 3))
+        if constrained is not None:
+            g = g + self.strength * constrained[..., None] * self.mass[:, None] * (x - aim)
+        return g
+
+    def hess_vec(self, x, p, constrained=None):
+        """(M + dt^2 K + s M_c) p, matrix-free through dpk1."""
+        F = self.deformation_gradient(x)
+        dF = self.deformation_gradient(p)  # linear in p (rest offsets cancel: Ds is a difference)
+        dH = self.vol[:, None, None] * (self.dpk1(F, dF) @ np.swapaxes(self.dm_inv, -1, -2)) * self.dt**2
+        g1, g2, g3 = dH[..., :, 0], dH[..., :, 1], dH[..., :, 2]
+        ge = np.stack([-(g1 + g2 + g3), g1, g2, g3], -2)  # (..., T, 4, 3)
+        y = self.mass[:, None] * p
+        for b in np.ndindex(x.shape[:-2]):
+            np.add.at(y[b], self.tets.reshape(-1), ge[b].reshape(-1, 3))
+        if constrained is not None:
+            y = y + self.strength * constrained[..., None] * self.mass[:, None] * p
+        return y
+
+    def diag_blocks(self, x, constrained=None):
+        """(..., V, 3, 3) diagonal blocks of M + dt^2 K + s M_c (block-Jacobi preconditioner)."""
+        He = self.element_hessian(x) * self.dt**2
+        D = np.zeros(x.shape[:-2] + (len(self.X), 3, 3))
+        for b in np.ndindex(x.shape[:-2]):
+            for v in range(4):
+                np.add.at(D[b], self.tets[:, v], He[b][:, v * 3 : v * 3 + 3, v * 3 : v * 3 + 3])
+        m = self.mass * (1 if constrained is None else 1)
+        D = D + m[:, None, None] * np.eye(3)
+        if constrained is not None:
+            D = D + (self.strength * constrained * self.mass)[..., None, None] * np.eye(3)
+        return D
+
+    # ---- one Newton iteration: truncated PCG + backtracking line search (US:70-76) ----------------------------------
+    def newton_step(self, x, x_tilde, constrained=None, aim=None, pcg_max_iter=64, pcg_tol_rate=1e-3, ls_max_iter=8):
+        """Single env (x: (V,3)).  Returns (x_new, stats=[E0, E1, step, pcg_iters])."""
+        g = self.gradient(x, x_tilde, constrained, aim)
+        D = self.diag_blocks(x, constrained)
+        # fall back to the (always SPD) mass block where the elastic block is not positive definite
+        mdiag = self.mass * (1.0 + (self.strength * constrained if constrained is not None else 0.0))
+        Dinv = np.empty_like(D)
+        for v in range(len(self.X)):
+            try:
+                np.linalg.cholesky(D[v])
+                Dinv[v] = np.linalg.inv(D[v])
+            except np.linalg.LinAlgError:
+                Dinv[v] = np.eye(3) / mdiag[v]
+        prec = lambda r: np.einsum("vij,vj->vi", Dinv, r)
+        d = np.zeros_like(x)
+        r = -g
+        z = prec(r)
+        p = z.copy()
+        rz = (r * z).sum()
+        rz0 = rz
+        it = 0
+        while it < pcg_max_iter and rz > pcg_tol_rate**2 * rz0 and rz0 > 0:
+            Hp = self.hess_vec(x, p, constrained)
+            pHp = (p * Hp).sum()
+            if pHp <= 0:  # negative curvature: keep what we have (steepest-descent-like first step)
+                if it == 0:
+                    d = z.copy()
+                break
+            a = rz / pHp
+            d = d + a * p
+            r = r - a * Hp
+            z = prec(r)
+            rz_new = (r * z).sum()
+            p = z + (rz_new / rz) * p
+            rz = rz_new
+            it += 1
+        E0 = self.energy(x, x_tilde, constrained, aim)
+        step = 1.0
+        E1 = E0
+        x_new = x
+        for _ in range(ls_max_iter + 1):
+            cand = x + step * d
+            Ec = self.energy(cand, x_tilde, constrained, aim)
+            if Ec <= E0:
+                x_new, E1 = cand, Ec
+                break
+            step *= 0.5
+        else:
+            step = 0.0
+        return x_new, np.array([E0, E1, step, it])
+
+
+def marker_uv(surf_pos, tri, weight, fx=340.0, fy=325.0, cx=160.0, cy=125.0):
+    """FEM-driven markers (tactile_sensor_sapienipc_modified.py:347-366): barycentric point on a surface triangle,
+    then pinhole projection uv = (K p) / p_z.   surf_pos (B,Vs,3) camera frame, tri (M,3), weight (M,3) -> (B,M,2)."""
+    pts = (surf_pos[:, tri, :] * weight[None, :, :, None]).sum(-2)
+    u = fx * pts[..., 0] / pts[..., 2] + cx
+    v = fy * pts[..., 1] / pts[..., 2] + cy
+    return np.stack([u, v], -1)

@@ -1,0 +1,769 @@
+// Gelpad FEM inner step for MI355X (gfx950), float64, batched over independent environments.
+//
+// What libuipc's world.advance() executes for the TacEx gelpad (tacex_uipc/sim/uipc_sim.py:250-252;
+// StableNeoHookean + ElasticModuli.youngs_poisson, tacex_uipc/objects/uipc_object.py:442-470; soft position
+// constraints, tacex_uipc/sim/uipc_attachments.py:139-142,364-428).  libuipc is an un-vendored submodule, so
+// this follows the published model (Smith, de Goes, Kim 2018, eq. 14) - see oracle/fem_oracle.py, PARITY UNPINNED.
+//
+//   Psi(F) = mu/2 (Ic-3) + lam/2 (J-alpha)^2 - mu/2 log(Ic+1) - Psi(I)
+//   P      = a F + c C,         a = mu (1 - 1/(Ic+1)),  c = lam (J - alpha),  C = cof F = [f1xf2, f2xf0, f0xf1]
+//   dP[dF] = a dF + b (F:dF) F + lam (C:dF) C + c dC[dF],   b = 2 mu / (Ic+1)^2
+//   E(x)   = 1/2 sum m |x-xt|^2 + dt^2 sum vol Psi(F) + 1/2 s sum_{constrained} m |x-aim|^2
+//
+// Design (bandwidth-bound, no MFMA): one tet per lane for element terms with element-minor SoA outputs
+// (energy (B,T), grad (B,12,T), hess (B,144,T)) so every store is coalesced; nodal assembly is an atomics-free
+// vertex gather over a CSR incidence list; reductions are wave shuffles + LDS; the Newton step runs as ONE
+// workgroup per environment - matrix-free PCG (block-Jacobi preconditioned) and the backtracking line search
+// stay inside a single launch with no host round trip.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+
+#include <vector>
+
+#include "tacex_hip.h"
+#include "tacex_internal.h"
+
+namespace tacex {
+
+struct FemDev {
+  int V, T;
+  const int* tets;        // (4,T) SoA
+  const double* dminv;    // (9,T) SoA, row-major 3x3 per tet
+  const double* vol;      // (T)
+  const double* mass;     // (V)
+  const int* vt_off;      // (V+1) CSR vertex -> incident (tet*4 + local)
+  const int* vt_idx;
+  double mu, lam, alpha, psi_rest, dt, strength;
+};
+
+// ---- small dense helpers (row-major 3x3 in double[9]) ---------------------------------------------------
+__device__ __forceinline__ void cross3(const double* a, const double* b, double* o) {
+  o[0] = a[1] * b[2] - a[2] * b[1];
+  o[1] = a[2] * b[0] - a[0] * b[2];
+  o[2] = a[0] * b[1] - a[1] * b[0];
+}
+
+struct TetState {
+  double F[9], C[9];
+  double a, b, c;   // coefficients above
+  double Ic, J;
+};
+
+__device__ __forceinline__ void load_tet(const FemDev& m, int t, int v[4], double Di[9]) {
+#pragma unroll
+  for (int k = 0; k < 4; ++k) v[k] = m.tets[k * m.T + t];
+#pragma unroll
+  for (int k = 0; k < 9; ++k) Di[k] = m.dminv[k * m.T + t];
+}
+
+// F = Ds * DmInv with Ds columns (x1-x0, x2-x0, x3-x0); x points at one env's (V,3) array
+__device__ __forceinline__ void deformation_gradient(const double* x, const int v[4], const double Di[9], double F[9]) {
+  double Ds[9];
+#pragma unroll
+  for (int k = 0; k < 3; ++k)
+#pragma unroll
+    for (int i = 0; i < 3; ++i) Ds[i * 3 + k] = x[v[k + 1] * 3 + i] - x[v[0] * 3 + i];
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int mm = 0; mm < 3; ++mm)
+      F[i * 3 + mm] = Ds[i * 3 + 0] * Di[0 * 3 + mm] + Ds[i * 3 + 1] * Di[1 * 3 + mm] + Ds[i * 3 + 2] * Di[2 * 3 + mm];
+}
+
+__device__ __forceinline__ void tet_state(const FemDev& m, const double F[9], TetState& s) {
+  double f0[3] = {F[0], F[3], F[6]}, f1[3] = {F[1], F[4], F[7]}, f2[3] = {F[2], F[5], F[8]};
+  double c0[3], c1[3], c2[3];
+  cross3(f1, f2, c0);
+  cross3(f2, f0, c1);
+  cross3(f0, f1, c2);
+#pragma unroll
+  for (int i = 0; i < 3; ++i) { s.C[i * 3 + 0] = c0[i]; s.C[i * 3 + 1] = c1[i]; s.C[i * 3 + 2] = c2[i]; }
+  double Ic = 0.0;
+#pragma unroll
+  for (int k = 0; k < 9; ++k) { s.F[k] = F[k]; Ic += F[k] * F[k]; }
+  s.Ic = Ic;
+  s.J = f0[0] * c0[0] + f0[1] * c0[1] + f0[2] * c0[2];
+  s.a = m.mu * (1.0 - 1.0 / (Ic + 1.0));
+  s.b = 2.0 * m.mu / ((Ic + 1.0) * (Ic + 1.0));
+  s.c = m.lam * (s.J - m.alpha);
+}
+
+__device__ __forceinline__ double psi_of(const FemDev& m, const TetState& s) {
+  const double dj = s.J - m.alpha;
+  return 0.5 * m.mu * (s.Ic - 3.0) + 0.5 * m.lam * dj * dj - 0.5 * m.mu * log(s.Ic + 1.0) - m.psi_rest;
+}
+
+// dP = (9x9 Hessian of Psi) applied to dF
+__device__ __forceinline__ void apply_dP(const FemDev& m, const TetState& s, const double dF[9], double dP[9]) {
+  double FdF = 0.0, CdF = 0.0;
+#pragma unroll
+  for (int k = 0; k < 9; ++k) { FdF += s.F[k] * dF[k]; CdF += s.C[k] * dF[k]; }
+  const double* F = s.F;
+  double f0[3] = {F[0], F[3], F[6]}, f1[3] = {F[1], F[4], F[7]}, f2[3] = {F[2], F[5], F[8]};
+  double d0[3] = {dF[0], dF[3], dF[6]}, d1[3] = {dF[1], dF[4], dF[7]}, d2[3] = {dF[2], dF[5], dF[8]};
+  double t1[3], t2[3], e0[3], e1[3], e2[3];
+  cross3(d1, f2, t1); cross3(f1, d2, t2);
+#pragma unroll
+  for (int i = 0; i < 3; ++i) e0[i] = t1[i] + t2[i];
+  cross3(d2, f0, t1); cross3(f2, d0, t2);
+#pragma unroll
+  for (int i = 0; i < 3; ++i) e1[i] = t1[i] + t2[i];
+  cross3(d0, f1, t1); cross3(f0, d1, t2);
+#pragma unroll
+  for (int i = 0; i < 3; ++i) e2[i] = t1[i] + t2[i];
+  const double bb = s.b * FdF, ll = m.lam * CdF;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    dP[i * 3 + 0] = s.a * dF[i * 3 + 0] + bb * F[i * 3 + 0] + ll * s.C[i * 3 + 0] + s.c * e0[i];
+    dP[i * 3 + 1] = s.a * dF[i * 3 + 1] + bb * F[i * 3 + 1] + ll * s.C[i * 3 + 1] + s.c * e1[i];
+    dP[i * 3 + 2] = s.a * dF[i * 3 + 2] + bb * F[i * 3 + 2] + ll * s.C[i * 3 + 2] + s.c * e2[i];
+  }
+}
+
+// rows r_v (v = 0..3) with dF[k][m] / dx[v][k] = r_v[m]:  r_{1..3} = rows of DmInv, r_0 = -(r_1 + r_2 + r_3)
+__device__ __forceinline__ void shape_rows(const double Di[9], double r[12]) {
+#pragma unroll
+  for (int mm = 0; mm < 3; ++mm) {
+    r[3 + mm] = Di[0 * 3 + mm]; r[6 + mm] = Di[1 * 3 + mm]; r[9 + mm] = Di[2 * 3 + mm];
+    r[mm] = -(Di[0 * 3 + mm] + Di[1 * 3 + mm] + Di[2 * 3 + mm]);
+  }
+}
+
+// element gradient (12) = scale * P : dF/dx
+__device__ __forceinline__ void element_gradient(const TetState& s, const double r[12], double scale, double g[12]) {
+  double P[9];
+#pragma unroll
+  for (int k = 0; k < 9; ++k) P[k] = s.a * s.F[k] + s.c * s.C[k];
+#pragma unroll
+  for (int v = 0; v < 4; ++v)
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+      g[v * 3 + i] = scale * (P[i * 3 + 0] * r[v * 3 + 0] + P[i * 3 + 1] * r[v * 3 + 1] + P[i * 3 + 2] * r[v * 3 + 2]);
+}
+
+// cyclic Jacobi eigen-decomposition of a symmetric 9x9 (PSD-projection path only; arrays live in scratch)
+__device__ void jacobi_psd9(double* A) {
+  double V[81];
+  for (int i = 0; i < 81; ++i) V[i] = (i / 9 == i % 9) ? 1.0 : 0.0;
+  for (int sweep = 0; sweep < 12; ++sweep) {
+    double off = 0.0, dia = 0.0;
+    for (int p = 0; p < 9; ++p) {
+      dia += A[p * 9 + p] * A[p * 9 + p];
+      for (int q = p + 1; q < 9; ++q) off += A[p * 9 + q] * A[p * 9 + q];
+    }
+    if (off <= 1e-30 * (dia + 1e-300)) break;
+    for (int p = 0; p < 8; ++p)
+      for (int q = p + 1; q < 9; ++q) {
+        const double apq = A[p * 9 + q];
+        if (fabs(apq) < 1e-300) continue;
+        const double theta = (A[q * 9 + q] - A[p * 9 + p]) / (2.0 * apq);
+        const double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+        const double cs = 1.0 / sqrt(t * t + 1.0), sn = t * cs;
+        for (int k = 0; k < 9; ++k) {
+          const double akp = A[k * 9 + p], akq = A[k * 9 + q];
+          A[k * 9 + p] = cs * akp - sn * akq;
+          A[k * 9 + q] = sn * akp + cs * akq;
+        }
+        for (int k = 0; k < 9; ++k) {
+          const double apk = A[p * 9 + k], aqk = A[q * 9 + k];
+          A[p * 9 + k] = cs * apk - sn * aqk;
+          A[q * 9 + k] = sn * apk + cs * aqk;
+        }
+        for (int k = 0; k < 9; ++k) {
+          const double vkp = V[k * 9 + p], vkq = V[k * 9 + q];
+          V[k * 9 + p] = cs * vkp - sn * vkq;
+          V[k * 9 + q] = sn * vkp + cs * vkq;
+        }
+      }
+  }
+  double w[9];
+  for (int i = 0; i < 9; ++i) w[i] = A[i * 9 + i] > 0.0 ? A[i * 9 + i] : 0.0;
+  for (int i = 0; i < 9; ++i)
+    for (int j = 0; j < 9; ++j) {
+      double sacc = 0.0;
+      for (int k = 0; k < 9; ++k) sacc += V[i * 9 + k] * w[k] * V[j * 9 + k];
+      A[i * 9 + j] = sacc;
+    }
+}
+
+// ---- K17a: element terms, one tet per lane, SoA outputs ---------------------------------------------------
+template <bool PROJECT_PSD>
+__global__ __launch_bounds__(256) void fem_element_terms_kernel(FemDev m, const double* __restrict__ x,
+                                                                double* __restrict__ energy, double* __restrict__ grad,
+                                                                double* __restrict__ hess) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  const int b = blockIdx.y;
+  if (t >= m.T) return;
+  int v[4];
+  double Di[9], F[9], r[12];
+  load_tet(m, t, v, Di);
+  deformation_gradient(x + (size_t)b * m.V * 3, v, Di, F);
+  TetState s;
+  tet_state(m, F, s);
+  shape_rows(Di, r);
+  const double vol = m.vol[t];
+  const size_t T = m.T;
+  if (energy) energy[(size_t)b * T + t] = vol * psi_of(m, s);
+  if (grad) {
+    double g[12];
+    element_gradient(s, r, vol, g);
+#pragma unroll
+    for (int k = 0; k < 12; ++k) grad[((size_t)b * 12 + k) * T + t] = g[k];
+  }
+  if (!hess) return;
+  if constexpr (!PROJECT_PSD) {
+    // column j = (vertex u, component k): dF = e_k (x) r_u ; H[:, j] = vol * (dP : dF_i)
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        double dF[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, dP[9];
+        dF[k * 3 + 0] = r[u * 3 + 0]; dF[k * 3 + 1] = r[u * 3 + 1]; dF[k * 3 + 2] = r[u * 3 + 2];
+        apply_dP(m, s, dF, dP);
+        const int j = u * 3 + k;
+#pragma unroll
+        for (int w = 0; w < 4; ++w)
+#pragma unroll
+          for (int i = 0; i < 3; ++i) {
+            const double h = vol * (dP[i * 3 + 0] * r[w * 3 + 0] + dP[i * 3 + 1] * r[w * 3 + 1] + dP[i * 3 + 2] * r[w * 3 + 2]);
+            hess[((size_t)b * 144 + (w * 3 + i) * 12 + j) * T + t] = h;
+          }
+      }
+    return;
+  } else {
+  // PSD projection of the 9x9 F-space Hessian (row-major vec(F) index q = i*3 + m), then H12 = vol G^T H9+ G
+  double H9[81];
+  for (int q = 0; q < 9; ++q) {
+    double dF[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, dP[9];
+    dF[q] = 1.0;
+    apply_dP(m, s, dF, dP);
+    for (int p = 0; p < 9; ++p) H9[p * 9 + q] = dP[p];
+  }
+  for (int p = 0; p < 9; ++p)
+    for (int q = p + 1; q < 9; ++q) { const double a = 0.5 * (H9[p * 9 + q] + H9[q * 9 + p]); H9[p * 9 + q] = a; H9[q * 9 + p] = a; }
+  jacobi_psd9(H9);
+  for (int u = 0; u < 4; ++u)
+    for (int k = 0; k < 3; ++k) {
+      double dP[9];  // H9 * vec(dF_j), dF_j = e_k (x) r_u
+      for (int p = 0; p < 9; ++p)
+        dP[p] = H9[p * 9 + k * 3 + 0] * r[u * 3 + 0] + H9[p * 9 + k * 3 + 1] * r[u * 3 + 1] + H9[p * 9 + k * 3 + 2] * r[u * 3 + 2];
+      const int j = u * 3 + k;
+      for (int w = 0; w < 4; ++w)
+        for (int i = 0; i < 3; ++i) {
+          const double h = vol * (dP[i * 3 + 0] * r[w * 3 + 0] + dP[i * 3 + 1] * r[w * 3 + 1] + dP[i * 3 + 2] * r[w * 3 + 2]);
+          hess[((size_t)b * 144 + (w * 3 + i) * 12 + j) * T + t] = h;
+        }
+    }
+  }
+}
+
+// ---- block-wide sum (wave shuffle + LDS), result broadcast to all threads ------------------------------------
+__device__ __forceinline__ double block_sum(double v, double* sh /* >= 17 doubles */) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  const int wid = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  __syncthreads();  // protect sh from the previous use
+  if ((threadIdx.x & 63) == 0) sh[wid] = v;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double s = 0.0;
+    for (int w = 0; w < nw; ++w) s += sh[w];
+    sh[16] = s;
+  }
+  __syncthreads();
+  return sh[16];
+}
+
+__device__ double env_energy(const FemDev& m, const double* x, const double* xt, const uint8_t* cons, const double* aim,
+                             double* sh) {
+  double e = 0.0;
+  for (int t = threadIdx.x; t < m.T; t += blockDim.x) {
+    int v[4];
+    double Di[9], F[9];
+    load_tet(m, t, v, Di);
+    deformation_gradient(x, v, Di, F);
+    TetState s;
+    tet_state(m, F, s);
+    e += m.dt * m.dt * m.vol[t] * psi_of(m, s);
+  }
+  for (int v = threadIdx.x; v < m.V; v += blockDim.x) {
+    const double mv = m.mass[v];
+    double q = 0.0, qc = 0.0;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      const double d = x[v * 3 + i] - xt[v * 3 + i];
+      q += d * d;
+      if (cons && cons[v]) { const double c = x[v * 3 + i] - aim[v * 3 + i]; qc += c * c; }
+    }
+    e += 0.5 * mv * q + 0.5 * m.strength * mv * qc;
+  }
+  return block_sum(e, sh);
+}
+
+// per-tet gradients (scaled by dt^2) into ge (12,T) of this env
+__device__ void env_tet_gradients(const FemDev& m, const double* x, double* ge) {
+  for (int t = threadIdx.x; t < m.T; t += blockDim.x) {
+    int v[4];
+    double Di[9], F[9], r[12], g[12];
+    load_tet(m, t, v, Di);
+    deformation_gradient(x, v, Di, F);
+    TetState s;
+    tet_state(m, F, s);
+    shape_rows(Di, r);
+    element_gradient(s, r, m.dt * m.dt * m.vol[t], g);
+#pragma unroll
+    for (int k = 0; k < 12; ++k) ge[(size_t)k * m.T + t] = g[k];
+  }
+}
+
+// atomics-free nodal assembly: vertex v sums its incident tets' local rows
+__device__ __forceinline__ void gather_vertex(const FemDev& m, const double* ge, int v, double out[3]) {
+  out[0] = out[1] = out[2] = 0.0;
+  for (int e = m.vt_off[v]; e < m.vt_off[v + 1]; ++e) {
+    const int code = m.vt_idx[e];
+    const int t = code >> 2, l = code & 3;
+    out[0] += ge[(size_t)(l * 3 + 0) * m.T + t];
+    out[1] += ge[(size_t)(l * 3 + 1) * m.T + t];
+    out[2] += ge[(size_t)(l * 3 + 2) * m.T + t];
+  }
+}
+
+__global__ __launch_bounds__(512) void fem_energy_kernel(FemDev m, const double* x, const double* xt,
+                                                         const uint8_t* cons, const double* aim, double* E) {
+  __shared__ double sh[17];
+  const int b = blockIdx.x;
+  const size_t o = (size_t)b * m.V * 3;
+  const double e = env_energy(m, x + o, xt + o, cons ? cons + (size_t)b * m.V : nullptr, aim ? aim + o : nullptr, sh);
+  if (threadIdx.x == 0) E[b] = e;
+}
+
+__global__ __launch_bounds__(512) void fem_gradient_kernel(FemDev m, const double* x, const double* xt,
+                                                           const uint8_t* cons, const double* aim, double* g,
+                                                           double* ws_ge /* (B,12,T) */) {
+  const int b = blockIdx.x;
+  const size_t o = (size_t)b * m.V * 3;
+  double* ge = ws_ge + (size_t)b * 12 * m.T;
+  env_tet_gradients(m, x + o, ge);
+  __syncthreads();
+  for (int v = threadIdx.x; v < m.V; v += blockDim.x) {
+    double a[3];
+    gather_vertex(m, ge, v, a);
+    const double mv = m.mass[v];
+    const bool c = cons && cons[(size_t)b * m.V + v];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      double gi = a[i] + mv * (x[o + v * 3 + i] - xt[o + v * 3 + i]);
+      if (c) gi += m.strength * mv * (x[o + v * 3 + i] - aim[o + v * 3 + i]);
+      g[o + v * 3 + i] = gi;
+    }
+  }
+}
+
+// ---- K17b: one projected-Newton iteration per env, everything inside one workgroup -----------------------------
+// workspace per env (doubles): ge 12T | tet cache 12T (F 9, a, b, c) | hv 12T | g,r,z,p,d,Hp,xc 7*3V | Dinv 9V
+__host__ __device__ inline size_t newton_ws_doubles(int V, int T) { return (size_t)36 * T + (size_t)30 * V; }
+
+__device__ __forceinline__ bool inv3_spd(const double A[9], double Ai[9]) {
+  // Cholesky test + inverse via adjugate
+  if (!(A[0] > 0.0)) return false;
+  const double l10 = A[3] / sqrt(A[0]), l20 = A[6] / sqrt(A[0]);
+  const double d1 = A[4] - l10 * l10;
+  if (!(d1 > 0.0)) return false;
+  const double l21 = (A[7] - l20 * l10) / sqrt(d1);
+  const double d2 = A[8] - l20 * l20 - l21 * l21;
+  if (!(d2 > 0.0)) return false;
+  const double c00 = A[4] * A[8] - A[5] * A[7], c01 = A[5] * A[6] - A[3] * A[8], c02 = A[3] * A[7] - A[4] * A[6];
+  const double det = A[0] * c00 + A[1] * c01 + A[2] * c02;
+  const double id = 1.0 / det;
+  Ai[0] = c00 * id; Ai[1] = (A[2] * A[7] - A[1] * A[8]) * id; Ai[2] = (A[1] * A[5] - A[2] * A[4]) * id;
+  Ai[3] = c01 * id; Ai[4] = (A[0] * A[8] - A[2] * A[6]) * id; Ai[5] = (A[2] * A[3] - A[0] * A[5]) * id;
+  Ai[6] = c02 * id; Ai[7] = (A[1] * A[6] - A[0] * A[7]) * id; Ai[8] = (A[0] * A[4] - A[1] * A[3]) * id;
+  return true;
+}
+
+__global__ __launch_bounds__(512) void fem_newton_kernel(FemDev m, double* xg, const double* xtg, const uint8_t* consg,
+                                                         const double* aimg, double* stats, double* wsg,
+                                                         int pcg_max_iter, double pcg_tol_rate, int ls_max_iter) {
+  __shared__ double sh[17];
+  const int b = blockIdx.x;
+  const int V = m.V, T = m.T;
+  const size_t o = (size_t)b * V * 3;
+  double* x = xg + o;
+  const double* xt = xtg + o;
+  const uint8_t* cons = consg ? consg + (size_t)b * V : nullptr;
+  const double* aim = aimg ? aimg + o : nullptr;
+  double* ws = wsg + (size_t)b * newton_ws_doubles(V, T);
+  double* ge = ws;                       // (12,T) tet gradients, later diag-block scratch
+  double* tc = ws + (size_t)12 * T;      // (12,T) F(9), a, b, c
+  double* hv = ws + (size_t)24 * T;      // (12,T) per-tet H*p contributions
+  double* vg = ws + (size_t)36 * T;      // g
+  double* vr = vg + (size_t)3 * V;
+  double* vz = vr + (size_t)3 * V;
+  double* vp = vz + (size_t)3 * V;
+  double* vd = vp + (size_t)3 * V;
+  double* vHp = vd + (size_t)3 * V;
+  double* xc = vHp + (size_t)3 * V;      // line-search candidate
+  double* Dinv = xc + (size_t)3 * V;     // (V,9)
+  const double dt2 = m.dt * m.dt;
+
+  // ---- element pass: cache F and coefficients, tet gradients, diagonal 3x3 blocks (into hv as (4*9? no: 12 rows)) ----
+  // the four 3x3 diagonal blocks of the element Hessian need 36 doubles per tet: use ge+tc? they are needed later,
+  // so diagonal blocks are accumulated vertex-side from recomputed columns below (second loop) instead.
+  for (int t = threadIdx.x; t < T; t += blockDim.x) {
+    int v[4];
+    double Di[9], F[9], r[12], g[12];
+    load_tet(m, t, v, Di);
+    deformation_gradient(x, v, Di, F);
+    TetState s;
+    tet_state(m, F, s);
+    shape_rows(Di, r);
+    element_gradient(s, r, dt2 * m.vol[t], g);
+#pragma unroll
+    for (int k = 0; k < 12; ++k) ge[(size_t)k * T + t] = g[k];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) tc[(size_t)k * T + t] = F[k];
+    tc[(size_t)9 * T + t] = s.a; tc[(size_t)10 * T + t] = s.b; tc[(size_t)11 * T + t] = s.c;
+  }
+  __syncthreads();
+  // ---- nodal gradient + block-Jacobi preconditioner (vertex gather; diagonal blocks recomputed per incidence) ----
+  for (int v = threadIdx.x; v < V; v += blockDim.x) {
+    double a3[3];
+    gather_vertex(m, ge, v, a3);
+    const double mv = m.mass[v];
+    const bool c = cons && cons[v];
+    const double md = mv * (1.0 + (c ? m.strength : 0.0));
+    double D[9] = {md, 0, 0, 0, md, 0, 0, 0, md};
+    for (int e = m.vt_off[v]; e < m.vt_off[v + 1]; ++e) {
+      const int code = m.vt_idx[e];
+      const int t = code >> 2, l = code & 3;
+      double Di[9], r[12];
+#pragma unroll
+      for (int k = 0; k < 9; ++k) Di[k] = m.dminv[(size_t)k * T + t];
+      shape_rows(Di, r);
+      TetState s;
+#pragma unroll
+      for (int k = 0; k < 9; ++k) s.F[k] = tc[(size_t)k * T + t];
+      {  // cofactor from F
+        double f0[3] = {s.F[0], s.F[3], s.F[6]}, f1[3] = {s.F[1], s.F[4], s.F[7]}, f2[3] = {s.F[2], s.F[5], s.F[8]};
+        double c0[3], c1[3], c2[3];
+        cross3(f1, f2, c0); cross3(f2, f0, c1); cross3(f0, f1, c2);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) { s.C[i * 3 + 0] = c0[i]; s.C[i * 3 + 1] = c1[i]; s.C[i * 3 + 2] = c2[i]; }
+      }
+      s.a = tc[(size_t)9 * T + t]; s.b = tc[(size_t)10 * T + t]; s.c = tc[(size_t)11 * T + t];
+      const double sc = dt2 * m.vol[t];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        double dF[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, dP[9];
+        dF[k * 3 + 0] = r[l * 3 + 0]; dF[k * 3 + 1] = r[l * 3 + 1]; dF[k * 3 + 2] = r[l * 3 + 2];
+        apply_dP(m, s, dF, dP);
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+          D[i * 3 + k] += sc * (dP[i * 3 + 0] * r[l * 3 + 0] + dP[i * 3 + 1] * r[l * 3 + 1] + dP[i * 3 + 2] * r[l * 3 + 2]);
+      }
+    }
+    double Di3[9];
+    if (!inv3_spd(D, Di3)) {  // elastic block not SPD -> mass block (always SPD)
+      const double im = 1.0 / md;
+      Di3[0] = im; Di3[1] = 0; Di3[2] = 0; Di3[3] = 0; Di3[4] = im; Di3[5] = 0; Di3[6] = 0; Di3[7] = 0; Di3[8] = im;
+    }
+#pragma unroll
+    for (int k = 0; k < 9; ++k) Dinv[(size_t)v * 9 + k] = Di3[k];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      double gi = a3[i] + mv * (x[v * 3 + i] - xt[v * 3 + i]);
+      if (c) gi += m.strength * mv * (x[v * 3 + i] - aim[v * 3 + i]);
+      vg[v * 3 + i] = gi;
+      vr[v * 3 + i] = -gi;
+      vd[v * 3 + i] = 0.0;
+    }
+  }
+  __syncthreads();
+  // z = Dinv r ; p = z ; rz
+  double part = 0.0;
+  for (int v = threadIdx.x; v < V; v += blockDim.x) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      const double z = Dinv[(size_t)v * 9 + i * 3 + 0] * vr[v * 3 + 0] + Dinv[(size_t)v * 9 + i * 3 + 1] * vr[v * 3 + 1] +
+                       Dinv[(size_t)v * 9 + i * 3 + 2] * vr[v * 3 + 2];
+      vz[v * 3 + i] = z;
+      vp[v * 3 + i] = z;
+      part += vr[v * 3 + i] * z;
+    }
+  }
+  double rz = block_sum(part, sh);
+  const double rz0 = rz;
+  int it = 0;
+  while (it < pcg_max_iter && rz0 > 0.0 && rz > pcg_tol_rate * pcg_tol_rate * rz0) {
+    // ---- Hp = (M + s Mc + dt^2 K) p, matrix-free: per-tet dP[dF(p)] then vertex gather ----
+    for (int t = threadIdx.x; t < T; t += blockDim.x) {
+      int v[4];
+      double Di[9], dF[9], dP[9], r[12];
+      load_tet(m, t, v, Di);
+      deformation_gradient(vp, v, Di, dF);  // linear in p
+      TetState s;
+#pragma unroll
+      for (int k = 0; k < 9; ++k) s.F[k] = tc[(size_t)k * T + t];
+      {
+        double f0[3] = {s.F[0], s.F[3], s.F[6]}, f1[3] = {s.F[1], s.F[4], s.F[7]}, f2[3] = {s.F[2], s.F[5], s.F[8]};
+        double c0[3], c1[3], c2[3];
+        cross3(f1, f2, c0); cross3(f2, f0, c1); cross3(f0, f1, c2);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) { s.C[i * 3 + 0] = c0[i]; s.C[i * 3 + 1] = c1[i]; s.C[i * 3 + 2] = c2[i]; }
+      }
+      s.a = tc[(size_t)9 * T + t]; s.b = tc[(size_t)10 * T + t]; s.c = tc[(size_t)11 * T + t];
+      apply_dP(m, s, dF, dP);
+      shape_rows(Di, r);
+      const double sc = dt2 * m.vol[t];
+#pragma unroll
+      for (int w = 0; w < 4; ++w)
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+          hv[(size_t)(w * 3 + i) * T + t] = sc * (dP[i * 3 + 0] * r[w * 3 + 0] + dP[i * 3 + 1] * r[w * 3 + 1] + dP[i * 3 + 2] * r[w * 3 + 2]);
+    }
+    __syncthreads();
+    part = 0.0;
+    for (int v = threadIdx.x; v < V; v += blockDim.x) {
+      double a3[3];
+      gather_vertex(m, hv, v, a3);
+      const double md = m.mass[v] * (1.0 + ((cons && cons[v]) ? m.strength : 0.0));
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        const double h = a3[i] + md * vp[v * 3 + i];
+        vHp[v * 3 + i] = h;
+        part += vp[v * 3 + i] * h;
+      }
+    }
+    const double pHp = block_sum(part, sh);
+    if (!(pHp > 0.0)) {  // negative curvature: keep d (first iteration: preconditioned steepest descent)
+      if (it == 0)
+        for (int k = threadIdx.x; k < 3 * V; k += blockDim.x) vd[k] = vz[k];
+      break;
+    }
+    const double al = rz / pHp;
+    part = 0.0;
+    for (int v = threadIdx.x; v < V; v += blockDim.x) {
+      double rr[3];
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        vd[v * 3 + i] += al * vp[v * 3 + i];
+        rr[i] = vr[v * 3 + i] - al * vHp[v * 3 + i];
+        vr[v * 3 + i] = rr[i];
+      }
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        const double z = Dinv[(size_t)v * 9 + i * 3 + 0] * rr[0] + Dinv[(size_t)v * 9 + i * 3 + 1] * rr[1] + Dinv[(size_t)v * 9 + i * 3 + 2] * rr[2];
+        vz[v * 3 + i] = z;
+        part += rr[i] * z;
+      }
+    }
+    const double rz_new = block_sum(part, sh);
+    const double beta = rz_new / rz;
+    for (int k = threadIdx.x; k < 3 * V; k += blockDim.x) vp[k] = vz[k] + beta * vp[k];
+    rz = rz_new;
+    ++it;
+    __syncthreads();
+  }
+  __syncthreads();
+  // ---- backtracking line search on the incremental potential (accept the first E(x + step d) <= E(x)) ----
+  const double E0 = env_energy(m, x, xt, cons, aim, sh);
+  double step = 1.0, E1 = E0;
+  bool accepted = false;
+  for (int ls = 0; ls <= ls_max_iter; ++ls) {
+    for (int k = threadIdx.x; k < 3 * V; k += blockDim.x) xc[k] = x[k] + step * vd[k];
+    __syncthreads();
+    const double Ec = env_energy(m, xc, xt, cons, aim, sh);
+    if (Ec <= E0) { E1 = Ec; accepted = true; break; }
+    step *= 0.5;
+  }
+  if (accepted) {
+    for (int k = threadIdx.x; k < 3 * V; k += blockDim.x) x[k] = xc[k];
+  } else {
+    step = 0.0;
+  }
+  if (threadIdx.x == 0) {
+    stats[(size_t)b * 4 + 0] = E0; stats[(size_t)b * 4 + 1] = E1; stats[(size_t)b * 4 + 2] = step; stats[(size_t)b * 4 + 3] = (double)it;
+  }
+}
+
+// ---- K18: FEM-driven markers: barycentric surface point + pinhole projection (VT:347-366) ------------------------
+__global__ __launch_bounds__(128) void fem_marker_uv_kernel(const double* __restrict__ pos, const int* __restrict__ tri,
+                                                            const double* __restrict__ wgt, double fx, double fy,
+                                                            double cx, double cy, double* __restrict__ uv, int Vs, int M) {
+  const int mi = blockIdx.x * blockDim.x + threadIdx.x;
+  const int b = blockIdx.y;
+  if (mi >= M) return;
+  const double* p = pos + (size_t)b * Vs * 3;
+  double q[3] = {0, 0, 0};
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const int v = tri[mi * 3 + k];
+    const double w = wgt[mi * 3 + k];
+    q[0] += w * p[v * 3 + 0]; q[1] += w * p[v * 3 + 1]; q[2] += w * p[v * 3 + 2];
+  }
+  uv[((size_t)b * M + mi) * 2 + 0] = fx * q[0] / q[2] + cx;
+  uv[((size_t)b * M + mi) * 2 + 1] = fy * q[1] / q[2] + cy;
+}
+
+}  // namespace tacex
+
+using namespace tacex;
+
+struct tacex_fem_ctx {
+  int device = 0;
+  FemDev dev{};
+  std::vector<void*> allocs;
+};
+
+template <typename T>
+static int fem_upload(tacex_fem_ctx* c, const std::vector<T>& h, const T** out) {
+  void* p = nullptr;
+  hipError_t e = hipMalloc(&p, h.size() * sizeof(T) + 16);
+  if (e != hipSuccess) return fail_hip(e, "hipMalloc(fem table)");
+  c->allocs.push_back(p);
+  e = hipMemcpy(p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice);
+  if (e != hipSuccess) return fail_hip(e, "hipMemcpy(fem table)");
+  *out = static_cast<const T*>(p);
+  return 0;
+}
+
+extern "C" {
+
+int tacex_fem_create(int device_id, const tacex_fem_params* p, tacex_fem_ctx** out) {
+  if (!p || !out || !p->rest_positions || !p->tets) { set_error("tacex_fem_create: null argument"); return 2; }
+  const int V = p->num_verts, T = p->num_tets;
+  if (V < 4 || T < 1) { set_error("tacex_fem_create: mesh too small (V=%d, T=%d)", V, T); return 2; }
+  if (!(p->poisson > -1.0 && p->poisson < 0.5) || !(p->youngs > 0.0) || !(p->density > 0.0) || !(p->dt > 0.0)) {
+    set_error("tacex_fem_create: need youngs > 0, -1 < poisson < 0.5, density > 0, dt > 0");
+    return 2;
+  }
+  std::vector<int> tets((size_t)4 * T);
+  std::vector<double> dminv((size_t)9 * T), vol(T), mass(V, 0.0);
+  const double* X = p->rest_positions;
+  for (int t = 0; t < T; ++t) {
+    int v[4];
+    for (int k = 0; k < 4; ++k) {
+      v[k] = p->tets[t * 4 + k];
+      if (v[k] < 0 || v[k] >= V) { set_error("tacex_fem_create: tet %d has vertex index %d out of range", t, v[k]); return 2; }
+    }
+    double Dm[9], det = 0.0;
+    for (int attempt = 0; attempt < 2; ++attempt) {
+      for (int k = 0; k < 3; ++k)
+        for (int i = 0; i < 3; ++i) Dm[i * 3 + k] = X[v[k + 1] * 3 + i] - X[v[0] * 3 + i];
+      det = Dm[0] * (Dm[4] * Dm[8] - Dm[5] * Dm[7]) - Dm[1] * (Dm[3] * Dm[8] - Dm[5] * Dm[6]) + Dm[2] * (Dm[3] * Dm[7] - Dm[4] * Dm[6]);
+      if (det > 0.0) break;
+      int tmp = v[1]; v[1] = v[2]; v[2] = tmp;  // re-orient (same rule as the oracle)
+    }
+    if (!(det > 0.0)) { set_error("tacex_fem_create: tet %d is degenerate", t); return 2; }
+    const double id = 1.0 / det;
+    double inv[9] = {(Dm[4] * Dm[8] - Dm[5] * Dm[7]) * id, (Dm[2] * Dm[7] - Dm[1] * Dm[8]) * id, (Dm[1] * Dm[5] - Dm[2] * Dm[4]) * id,
+                     (Dm[5] * Dm[6] - Dm[3] * Dm[8]) * id, (Dm[0] * Dm[8] - Dm[2] * Dm[6]) * id, (Dm[2] * Dm[3] - Dm[0] * Dm[5]) * id,
+                     (Dm[3] * Dm[7] - Dm[4] * Dm[6]) * id, (Dm[1] * Dm[6] - Dm[0] * Dm[7]) * id, (Dm[0] * Dm[4] - Dm[1] * Dm[3]) * id};
+    for (int k = 0; k < 9; ++k) dminv[(size_t)k * T + t] = inv[k];
+    for (int k = 0; k < 4; ++k) tets[(size_t)k * T + t] = v[k];
+    vol[t] = det / 6.0;
+    for (int k = 0; k < 4; ++k) mass[v[k]] += p->density * vol[t] / 4.0;
+  }
+  std::vector<int> off(V + 1, 0), idx((size_t)4 * T);
+  for (int t = 0; t < T; ++t)
+    for (int k = 0; k < 4; ++k) off[tets[(size_t)k * T + t] + 1]++;
+  for (int v = 0; v < V; ++v) off[v + 1] += off[v];
+  {
+    std::vector<int> cur(off.begin(), off.end() - 1);
+    for (int t = 0; t < T; ++t)
+      for (int k = 0; k < 4; ++k) idx[cur[tets[(size_t)k * T + t]]++] = t * 4 + k;
+  }
+  hipError_t e = hipSetDevice(device_id);
+  if (e != hipSuccess) return fail_hip(e, "hipSetDevice");
+  auto* c = new tacex_fem_ctx();
+  c->device = device_id;
+  FemDev& d = c->dev;
+  d.V = V; d.T = T;
+  int rc = fem_upload(c, tets, &d.tets) | fem_upload(c, dminv, &d.dminv) | fem_upload(c, vol, &d.vol) |
+           fem_upload(c, mass, &d.mass) | fem_upload(c, off, &d.vt_off) | fem_upload(c, idx, &d.vt_idx);
+  if (rc) { tacex_fem_destroy(c); return rc; }
+  const double mu_l = p->youngs / (2.0 * (1.0 + p->poisson));
+  const double lam_l = p->youngs * p->poisson / ((1.0 + p->poisson) * (1.0 - 2.0 * p->poisson));
+  d.mu = 4.0 / 3.0 * mu_l;
+  d.lam = lam_l + 5.0 / 6.0 * mu_l;
+  d.alpha = 1.0 + 0.75 * d.mu / d.lam;
+  d.psi_rest = 0.5 * d.lam * (1.0 - d.alpha) * (1.0 - d.alpha) - 0.5 * d.mu * log(4.0);
+  d.dt = p->dt;
+  d.strength = p->constraint_strength_ratio;
+  *out = c;
+  return 0;
+}
+
+void tacex_fem_destroy(tacex_fem_ctx* c) {
+  if (!c) return;
+  (void)hipSetDevice(c->device);
+  for (void* p : c->allocs) (void)hipFree(p);
+  delete c;
+}
+
+size_t tacex_fem_workspace_bytes(const tacex_fem_ctx* c, int B) {
+  if (!c || B <= 0) return 0;
+  return (size_t)B * newton_ws_doubles(c->dev.V, c->dev.T) * sizeof(double);
+}
+
+int tacex_fem_element_terms(tacex_fem_ctx* c, const double* x, double* energy, double* grad, double* hess,
+                            int project_psd, int B, void* stream) {
+  if (!c || !x) { set_error("tacex_fem_element_terms: null argument"); return 2; }
+  if (B <= 0) return 0;
+  if (project_psd && hess)
+    hipLaunchKernelGGL(fem_element_terms_kernel<true>, dim3((c->dev.T + 255) / 256, B), dim3(256), 0, (hipStream_t)stream,
+                       c->dev, x, energy, grad, hess);
+  else
+    hipLaunchKernelGGL(fem_element_terms_kernel<false>, dim3((c->dev.T + 255) / 256, B), dim3(256), 0, (hipStream_t)stream,
+                       c->dev, x, energy, grad, hess);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : fail_hip(e, "fem_element_terms_kernel");
+}
+
+int tacex_fem_energy(tacex_fem_ctx* c, const double* x, const double* xt, const uint8_t* cons, const double* aim,
+                     double* E, void* ws, int B, void* stream) {
+  (void)ws;
+  if (!c || !x || !xt || !E) { set_error("tacex_fem_energy: null argument"); return 2; }
+  if ((cons == nullptr) != (aim == nullptr)) { set_error("tacex_fem_energy: constrained_dev and aim_dev go together"); return 2; }
+  if (B <= 0) return 0;
+  hipLaunchKernelGGL(fem_energy_kernel, dim3(B), dim3(512), 0, (hipStream_t)stream, c->dev, x, xt, cons, aim, E);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : fail_hip(e, "fem_energy_kernel");
+}
+
+int tacex_fem_gradient(tacex_fem_ctx* c, const double* x, const double* xt, const uint8_t* cons, const double* aim,
+                       double* g, void* ws, int B, void* stream) {
+  if (!c || !x || !xt || !g || !ws) { set_error("tacex_fem_gradient: null argument"); return 2; }
+  if ((cons == nullptr) != (aim == nullptr)) { set_error("tacex_fem_gradient: constrained_dev and aim_dev go together"); return 2; }
+  if (B <= 0) return 0;
+  hipLaunchKernelGGL(fem_gradient_kernel, dim3(B), dim3(512), 0, (hipStream_t)stream, c->dev, x, xt, cons, aim, g,
+                     static_cast<double*>(ws));
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : fail_hip(e, "fem_gradient_kernel");
+}
+
+int tacex_fem_newton_step(tacex_fem_ctx* c, double* x, const double* xt, const uint8_t* cons, const double* aim,
+                          double* stats, void* ws, int B, int pcg_max_iter, double pcg_tol_rate, int ls_max_iter,
+                          void* stream) {
+  if (!c || !x || !xt || !stats || !ws) { set_error("tacex_fem_newton_step: null argument"); return 2; }
+  if ((cons == nullptr) != (aim == nullptr)) { set_error("tacex_fem_newton_step: constrained_dev and aim_dev go together"); return 2; }
+  if (pcg_max_iter < 1 || ls_max_iter < 0 || !(pcg_tol_rate > 0.0)) { set_error("tacex_fem_newton_step: bad solver parameters"); return 2; }
+  if (B <= 0) return 0;
+  hipLaunchKernelGGL(fem_newton_kernel, dim3(B), dim3(512), 0, (hipStream_t)stream, c->dev, x, xt, cons, aim, stats,
+                     static_cast<double*>(ws), pcg_max_iter, pcg_tol_rate, ls_max_iter);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : fail_hip(e, "fem_newton_kernel");
+}
+
+int tacex_fem_marker_uv(const double* pos, const int32_t* tri, const double* wgt, double fx, double fy, double cx,
+                        double cy, double* uv, int B, int Vs, int M, void* stream) {
+  if (!pos || !tri || !wgt || !uv) { set_error("tacex_fem_marker_uv: null argument"); return 2; }
+  if (B <= 0 || M <= 0) return 0;
+  hipLaunchKernelGGL(fem_marker_uv_kernel, dim3((M + 127) / 128, B), dim3(128), 0, (hipStream_t)stream, pos, tri, wgt, fx, fy,
+                     cx, cy, uv, Vs, M);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : fail_hip(e, "fem_marker_uv_kernel");
+}
+
+}  // extern "C"

@@ -1,0 +1,317 @@
+// C ABI of libtacex_hip.so (include/tacex_hip.h): context management, table upload, stage sequencing.
+// No torch types, no allocation inside compute calls (tables are allocated once at *_create).
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "tacex_hip.h"
+#include "tacex_internal.h"
+
+namespace tacex {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+int fail_hip(hipError_t e, const char* what) {
+  set_error("%s: %s (%d)", what, hipGetErrorString(e), (int)e);
+  return 1;
+}
+
+}  // namespace tacex
+
+using namespace tacex;
+
+#define HIP_TRY(expr, what)                          \
+  do {                                               \
+    hipError_t _e = (expr);                          \
+    if (_e != hipSuccess) return fail_hip(_e, what); \
+  } while (0)
+
+struct tacex_taxim_ctx {
+  int device = 0;
+  int H = 0, W = 0;
+  int n_levels = 0;
+  float contact_scale = 0.4f;
+  LevelDesc levels[TACEX_MAX_LEVELS];
+  ShadeParams shade;
+  float* gel_dev = nullptr;
+  std::vector<void*> allocs;
+  // profiling
+  bool profiling = false;
+  struct Ev { hipEvent_t a, b; int stage; };
+  std::vector<Ev> events;
+  std::vector<double> stage_ms;
+  std::vector<int> stage_n;
+  std::vector<std::string> stage_names;
+};
+
+template <typename T>
+static int upload(tacex_taxim_ctx* c, const T* host, size_t n, T** dev) {
+  void* p = nullptr;
+  HIP_TRY(hipMalloc(&p, n * sizeof(T)), "hipMalloc(table)");
+  c->allocs.push_back(p);
+  HIP_TRY(hipMemcpy(p, host, n * sizeof(T), hipMemcpyHostToDevice), "hipMemcpy(table)");
+  *dev = static_cast<T*>(p);
+  return 0;
+}
+
+extern "C" {
+
+const char* tacex_last_error(void) { return g_err; }
+int tacex_abi_version(void) { return TACEX_ABI_VERSION; }
+
+int tacex_device_count(int* count) {
+  HIP_TRY(hipGetDeviceCount(count), "hipGetDeviceCount");
+  return 0;
+}
+
+int tacex_device_arch(int device_id, char* buf, size_t buflen) {
+  hipDeviceProp_t prop;
+  HIP_TRY(hipGetDeviceProperties(&prop, device_id), "hipGetDeviceProperties");
+  snprintf(buf, buflen, "%s", prop.gcnArchName);
+  return 0;
+}
+
+int tacex_taxim_create(int device_id, const tacex_taxim_params* p, tacex_taxim_ctx** out) {
+  if (!p || !out) { set_error("tacex_taxim_create: null argument"); return 2; }
+  if (p->n_levels < 1 || p->n_levels > TACEX_MAX_LEVELS) { set_error("n_levels %d out of range", p->n_levels); return 2; }
+  if (p->height < 3 || p->width < 3) { set_error("image %dx%d too small", p->height, p->width); return 2; }
+  if (p->num_bins < 2 || p->num_bins > 256) { set_error("num_bins %d out of range (2..256)", p->num_bins); return 2; }
+  for (int l = 0; l < p->n_levels; ++l) {
+    if (p->ksize_w[l] % 2 != 1 || p->ksize_h[l] % 2 != 1 || p->ksize_w[l] < 1 || p->ksize_h[l] < 1) {
+      set_error("level %d: kernel sizes must be odd and positive (%d, %d)", l, p->ksize_w[l], p->ksize_h[l]);
+      return 2;
+    }
+    // torch 'reflect' padding requires pad < dim (TT:411)
+    if ((p->ksize_w[l] - 1) / 2 >= p->width || (p->ksize_h[l] - 1) / 2 >= p->height) {
+      set_error("level %d: reflect padding (%d, %d) must be smaller than the image (%d, %d)", l,
+                (p->ksize_w[l] - 1) / 2, (p->ksize_h[l] - 1) / 2, p->width, p->height);
+      return 2;
+    }
+  }
+  HIP_TRY(hipSetDevice(device_id), "hipSetDevice");
+  auto* c = new tacex_taxim_ctx();
+  c->device = device_id;
+  c->H = p->height;
+  c->W = p->width;
+  c->n_levels = p->n_levels;
+  c->contact_scale = p->contact_scale;
+  const size_t npix = (size_t)c->H * c->W;
+  int rc = 0;
+  for (int l = 0; l < p->n_levels && !rc; ++l) {
+    c->levels[l].kw = p->ksize_w[l];
+    c->levels[l].kh = p->ksize_h[l];
+    c->levels[l].same_taps = p->ksize_w[l] == p->ksize_h[l] &&
+                             memcmp(p->taps_w[l], p->taps_h[l], sizeof(float) * p->ksize_w[l]) == 0;
+    rc |= upload(c, p->taps_w[l], (size_t)p->ksize_w[l], &c->levels[l].taps_w_dev);
+    rc |= upload(c, p->taps_h[l], (size_t)p->ksize_h[l], &c->levels[l].taps_h_dev);
+  }
+  if (!rc) rc |= upload(c, p->gel_map, npix, &c->gel_dev);
+  // polynomial table (3, nb, nb, 6) -> (nb, nb, 24): one 96-byte, 16-byte-aligned record per bin
+  const int nb = p->num_bins;
+  if (!rc) {
+    std::vector<float> poly((size_t)nb * nb * 24, 0.0f);
+    for (int ch = 0; ch < 3; ++ch)
+      for (int i = 0; i < nb; ++i)
+        for (int j = 0; j < nb; ++j)
+          for (int k = 0; k < 6; ++k)
+            poly[((size_t)i * nb + j) * 24 + (ch == 2 ? 12 : ch * 6) + k] =
+                p->poly[(((size_t)ch * nb + i) * nb + j) * 6 + k];
+    rc |= upload(c, poly.data(), poly.size(), &c->shade.poly_dev);
+  }
+  if (!rc) {  // background (3,H,W) -> (H,W,3)
+    std::vector<float> bg(npix * 3);
+    for (int ch = 0; ch < 3; ++ch)
+      for (size_t i = 0; i < npix; ++i) bg[i * 3 + ch] = p->background[ch * npix + i];
+    rc |= upload(c, bg.data(), bg.size(), &c->shade.bg_nhwc_dev);
+  }
+  if (!rc) rc |= upload(c, p->feat_x, (size_t)c->W, &c->shade.fx_dev);
+  if (!rc) rc |= upload(c, p->feat_y, (size_t)c->H, &c->shade.fy_dev);
+  if (rc) { tacex_taxim_destroy(c); return rc; }
+  c->shade.H = c->H; c->shade.W = c->W; c->shade.nb = nb;
+  c->shade.calib_h = p->calib_height; c->shade.calib_w = p->calib_width;
+  c->shade.pixmm = p->pixmm;
+  // bin widths as float32 of the python doubles (TT:243-244)
+  c->shade.x_binr = (float)(0.5 * 3.14159265358979323846 / (nb - 1));
+  c->shade.y_binr = (float)(2.0 * 3.14159265358979323846 / (nb - 1));
+  const int ns = p->n_levels + 2;
+  c->stage_ms.assign(ns, 0.0);
+  c->stage_n.assign(ns, 0);
+  c->stage_names.resize(ns);
+  c->stage_names[0] = "frame_min";
+  for (int l = 0; l < p->n_levels; ++l) {
+    char nm[64];
+    snprintf(nm, sizeof(nm), "blur_l%d_k%dx%d", l, p->ksize_w[l], p->ksize_h[l]);
+    c->stage_names[1 + l] = nm;
+  }
+  c->stage_names[ns - 1] = "shade";
+  *out = c;
+  return 0;
+}
+
+void tacex_taxim_destroy(tacex_taxim_ctx* c) {
+  if (!c) return;
+  (void)hipSetDevice(c->device);
+  for (auto& e : c->events) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
+  for (void* p : c->allocs) (void)hipFree(p);
+  delete c;
+}
+
+static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+size_t tacex_taxim_workspace_bytes(const tacex_taxim_ctx* c, int B) {
+  if (!c || B <= 0) return 0;
+  const size_t img = align_up((size_t)B * c->H * c->W * sizeof(float), 256);
+  const size_t vec = align_up((size_t)B * sizeof(float), 256);
+  return 3 * img + 3 * vec;  // Z ping, Z pong, generic-path temp; shift_a, shift_b, pdepth
+}
+
+int tacex_taxim_set_profiling(tacex_taxim_ctx* c, int enabled) {
+  if (!c) { set_error("null ctx"); return 2; }
+  c->profiling = enabled != 0;
+  return 0;
+}
+
+int tacex_taxim_num_stages(const tacex_taxim_ctx* c) { return c ? (int)c->stage_ms.size() : 0; }
+
+const char* tacex_taxim_stage_name(const tacex_taxim_ctx* c, int stage) {
+  if (!c || stage < 0 || stage >= (int)c->stage_names.size()) return "";
+  return c->stage_names[stage].c_str();
+}
+
+static void drain_events(tacex_taxim_ctx* c) {
+  for (auto& e : c->events) {
+    float ms = 0.f;
+    if (hipEventSynchronize(e.b) == hipSuccess && hipEventElapsedTime(&ms, e.a, e.b) == hipSuccess) {
+      c->stage_ms[e.stage] += ms;
+      c->stage_n[e.stage] += 1;
+    }
+    (void)hipEventDestroy(e.a);
+    (void)hipEventDestroy(e.b);
+  }
+  c->events.clear();
+}
+
+int tacex_taxim_read_profile(tacex_taxim_ctx* c, int stage, double* total_ms, int* launches) {
+  if (!c || stage < 0 || stage >= (int)c->stage_ms.size()) { set_error("bad stage"); return 2; }
+  drain_events(c);
+  if (total_ms) *total_ms = c->stage_ms[stage];
+  if (launches) *launches = c->stage_n[stage];
+  c->stage_ms[stage] = 0.0;
+  c->stage_n[stage] = 0;
+  return 0;
+}
+
+struct StageTimer {
+  tacex_taxim_ctx* c; hipStream_t st; int stage; hipEvent_t a{}, b{}; bool on;
+  StageTimer(tacex_taxim_ctx* c_, hipStream_t st_, int stage_) : c(c_), st(st_), stage(stage_), on(c_->profiling) {
+    if (on) {
+      on = hipEventCreate(&a) == hipSuccess && hipEventCreate(&b) == hipSuccess &&
+           hipEventRecord(a, st) == hipSuccess;
+    }
+  }
+  ~StageTimer() {
+    if (on && hipEventRecord(b, st) == hipSuccess) c->events.push_back({a, b, stage});
+  }
+};
+
+int tacex_height_map_from_depth(const float* depth_m, float near_m, float far_m, float gelpad_h,
+                                float gelpad_dmin, float* hm_mm, float* frame_min, float* indent_mm,
+                                uint8_t* cam_u8, int B, int H, int W, void* stream) {
+  if (!depth_m || !hm_mm || !frame_min) { set_error("tacex_height_map_from_depth: null buffer"); return 2; }
+  if (B <= 0) return 0;
+  if (((size_t)H * W) % 4 != 0 && false) { /* handled by the scalar tail */ }
+  HIP_TRY(run_frame_min(depth_m, true, hm_mm, frame_min, indent_mm, cam_u8, B, H * W, near_m, far_m, gelpad_h,
+                        gelpad_dmin, (hipStream_t)stream),
+          "frame_min_kernel<depth>");
+  return 0;
+}
+
+int tacex_indentation_depth(const float* hm_mm, float gelpad_h, float gelpad_dmin, float* frame_min,
+                            float* indent_mm, int B, int H, int W, void* stream) {
+  if (!hm_mm || !frame_min || !indent_mm) { set_error("tacex_indentation_depth: null buffer"); return 2; }
+  if (B <= 0) return 0;
+  HIP_TRY(run_frame_min(hm_mm, false, nullptr, frame_min, indent_mm, nullptr, B, H * W, 0.f, 0.f, gelpad_h,
+                        gelpad_dmin, (hipStream_t)stream),
+          "frame_min_kernel");
+  return 0;
+}
+
+static int deform_impl(tacex_taxim_ctx* c, const float* hm, const float* press, float* frame_min,
+                       float** z_final, float* z_out, uint8_t* mask_out, void* ws, int B, unsigned flags,
+                       hipStream_t st) {
+  const size_t img = align_up((size_t)B * c->H * c->W * sizeof(float), 256);
+  const size_t vec = align_up((size_t)B * sizeof(float), 256);
+  char* w = static_cast<char*>(ws);
+  float* zbuf[2] = {reinterpret_cast<float*>(w), reinterpret_cast<float*>(w + img)};
+  float* tmp = reinterpret_cast<float*>(w + 2 * img);
+  float* sa = reinterpret_cast<float*>(w + 3 * img);
+  float* sb = reinterpret_cast<float*>(w + 3 * img + vec);
+  float* pd = reinterpret_cast<float*>(w + 3 * img + 2 * vec);
+  const bool no_shift = (flags & TACEX_FLAG_NO_SHIFT) != 0;
+  if (!(flags & TACEX_FLAG_HAVE_FRAME_MIN)) {
+    StageTimer t(c, st, 0);
+    HIP_TRY(run_frame_min(hm, false, nullptr, frame_min, nullptr, nullptr, B, c->H * c->W, 0.f, 0.f, 0.f, 0.f, st),
+            "frame_min_kernel");
+  }
+  HIP_TRY(run_press_depth(frame_min, press, sa, sb, pd, B, no_shift ? 1 : 0, st), "press_depth_kernel");
+  const float* src = nullptr;
+  for (int l = 0; l < c->n_levels; ++l) {
+    const bool last = l == c->n_levels - 1;
+    float* dst = (last && z_out) ? z_out : zbuf[l & 1];
+    StageTimer t(c, st, 1 + l);
+    HIP_TRY(run_blur_level(c->levels[l], src, hm, c->gel_dev, sa, sb, pd, dst, tmp, last ? mask_out : nullptr, B,
+                           c->H, c->W, c->contact_scale, last ? 0 : 1, l == 0, st),
+            "blur level");
+    src = dst;
+  }
+  *z_final = const_cast<float*>(src);
+  return 0;
+}
+
+int tacex_taxim_deform(tacex_taxim_ctx* c, const float* hm, const float* press, float* frame_min,
+                       float* z_out, uint8_t* mask_out, void* ws, int B, unsigned flags, void* stream) {
+  if (!c || !hm || !frame_min || !z_out || !ws) { set_error("tacex_taxim_deform: null argument"); return 2; }
+  if (!press && !(flags & TACEX_FLAG_NO_SHIFT)) { set_error("tacex_taxim_deform: press_dev is null"); return 2; }
+  if (B <= 0) return 0;
+  float* zf = nullptr;
+  return deform_impl(c, hm, press, frame_min, &zf, z_out, mask_out, ws, B, flags, (hipStream_t)stream);
+}
+
+int tacex_taxim_shade(tacex_taxim_ctx* c, const float* z, float* rgb, uint8_t* idx_out, int B, void* stream) {
+  if (!c || !z || !rgb) { set_error("tacex_taxim_shade: null argument"); return 2; }
+  if (B <= 0) return 0;
+  StageTimer t(c, (hipStream_t)stream, c->n_levels + 1);
+  HIP_TRY(run_shade(c->shade, z, rgb, idx_out, B, (hipStream_t)stream), "shade_kernel");
+  return 0;
+}
+
+int tacex_taxim_render(tacex_taxim_ctx* c, const float* hm, const float* press, float* frame_min, float* rgb,
+                       float* z_out, uint8_t* mask_out, void* ws, int B, unsigned flags, void* stream) {
+  if (!c || !hm || !frame_min || !rgb || !ws) { set_error("tacex_taxim_render: null argument"); return 2; }
+  if (!press && !(flags & TACEX_FLAG_NO_SHIFT)) { set_error("tacex_taxim_render: press_dev is null"); return 2; }
+  if (B <= 0) return 0;
+  float* zf = nullptr;
+  int rc = deform_impl(c, hm, press, frame_min, &zf, z_out, mask_out, ws, B, flags, (hipStream_t)stream);
+  if (rc) return rc;
+  return tacex_taxim_shade(c, zf, rgb, nullptr, B, stream);
+}
+
+int tacex_resize_bilinear_aa(const float* src, int sh, int sw, float* dst, int dh, int dw, int B, void* stream) {
+  if (!src || !dst || sh <= 0 || sw <= 0 || dh <= 0 || dw <= 0) { set_error("tacex_resize_bilinear_aa: bad argument"); return 2; }
+  if (B <= 0) return 0;
+  HIP_TRY(run_resize_aa(src, sh, sw, dst, dh, dw, B, (hipStream_t)stream), "resize_aa_kernel");
+  return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,41 @@
+// Internal declarations shared by the HIP translation units of libtacex_hip.so (not part of the ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace tacex {
+
+struct LevelDesc {
+  int kw = 1, kh = 1;
+  bool same_taps = false;  // taps_w == taps_h element-wise (sigma_w == sigma_h): tuned band kernel eligible
+  float* taps_w_dev = nullptr;
+  float* taps_h_dev = nullptr;
+};
+
+struct ShadeParams {
+  int H = 0, W = 0, nb = 0, calib_h = 0, calib_w = 0;
+  float pixmm = 0.f, x_binr = 0.f, y_binr = 0.f;
+  float* poly_dev = nullptr;     // (nb, nb, 24)
+  float* bg_nhwc_dev = nullptr;  // (H, W, 3)
+  float* fx_dev = nullptr;       // (W,)
+  float* fy_dev = nullptr;       // (H,)
+};
+
+hipError_t run_frame_min(const float* in, bool from_depth, float* hm_out, float* fmin, float* indent,
+                         uint8_t* cam_u8, int B, int npix, float near_m, float far_m, float gelpad_h,
+                         float gelpad_dmin, hipStream_t st);
+hipError_t run_press_depth(const float* fmin, const float* press, float* sa, float* sb, float* pd, int B,
+                           int no_shift, hipStream_t st);
+hipError_t run_blur_level(const LevelDesc& lv, const float* src, const float* hm, const float* gel,
+                          const float* sa, const float* sb, const float* pd, float* dst, float* tmp,
+                          uint8_t* mask_out, int B, int H, int W, float contact_scale, int restore,
+                          bool first, hipStream_t st);
+hipError_t run_shade(const ShadeParams& sp, const float* z, float* rgb, uint8_t* idx_out, int B,
+                     hipStream_t st);
+hipError_t run_resize_aa(const float* src, int sh, int sw, float* dst, int dh, int dw, int B, hipStream_t st);
+
+// thread-local error string (tacex_last_error)
+void set_error(const char* fmt, ...);
+int fail_hip(hipError_t e, const char* what);
+
+}  // namespace tacex

@@ -1,0 +1,602 @@
+// Taxim optical path for MI355X (gfx950): frame-min / indentation depth, gel-pad deformation pyramid,
+// polynomial shading.  Written for wave64 + LDS, no CUDA compatibility layer.
+//
+// Reference semantics (file:line in /root/reference, short names as in include/tacex_hip.h):
+//   frame-min / indentation  TS:115-131, TT:432-441, TT:449
+//   deformation pyramid      TT:443-473 (blur TT:381-412, kernels TT:362-379)
+//   normals / bins / shading TT:475-503, TT:237-258, TT:139-157
+//
+// Data layout in HBM: height maps / deformed gel (B,H,W) f32 row-major; RGB (B,H,W,3) f32; per-frame
+// scalars (B,) f32.  The blur kernel works on a band of TH rows x full width per workgroup:
+//   V-pass : each thread owns 2 adjacent columns x RV rows, streams RV+K-1 rows straight from global/L2
+//            (coalesced 8 B per lane) through a register sliding window;
+//   LDS    : V-pass result stored row-pair interleaved [TH/2][pitch] of float2 (+ mirrored x-padding);
+//   H-pass : each thread owns 2 rows x RH columns, reads its window from LDS with ds_read_b128,
+//            then applies the masked restore Z[M] = J[M] and writes coalesced.
+// Both passes are "tap x window" FMA loops on float2 so the compiler can use v_pk_fma_f32.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <type_traits>
+
+#include "tacex_internal.h"
+
+namespace tacex {
+
+typedef float v2f __attribute__((ext_vector_type(2)));
+typedef float v4f __attribute__((ext_vector_type(4)));
+
+// ------------------------------------------------------------------------------------------------
+// helpers
+// ------------------------------------------------------------------------------------------------
+// compile-time loop: every index is an integral_constant, so tap indices fold to constants and the
+// "tap x window" bodies become straight-line v_pk_fma_f32 streams (a plain #pragma unroll of the
+// 76 x 16 nest is only partially honoured by the unroller).
+template <int I, int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    static_for<I + 1, N>(f);
+  }
+}
+
+__device__ __forceinline__ int reflect_idx(int i, int n) {
+  // torch 'reflect' (no edge repeat), single reflection: valid for -(n-1) <= i <= 2(n-1)
+  i = i < 0 ? -i : i;
+  return i >= n ? 2 * (n - 1) - i : i;
+}
+
+__device__ __forceinline__ float wave_min(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// XCD-aware bijective remap of the linear block id (blocks b, b+8, b+16.. share an XCD / L2):
+// consecutive logical ids land on the same XCD so a frame's bands share halo rows in one L2.
+__device__ __forceinline__ int xcd_remap(int bid, int nblocks) {
+  const int nx = 8;
+  int q = nblocks / nx, r = nblocks % nx;
+  int xcd = bid % nx, idx = bid / nx;
+  int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  return base + idx;
+}
+
+// ------------------------------------------------------------------------------------------------
+// K1: per-frame minimum (+ optional depth->mm conversion, indentation depth, uint8 camera depth)
+//      one workgroup (1024 threads) per frame; float4 loads; wave shuffle + LDS reduction.
+// ------------------------------------------------------------------------------------------------
+template <bool FROM_DEPTH>
+__global__ __launch_bounds__(1024) void frame_min_kernel(
+    const float* __restrict__ in, float* __restrict__ hm_out, float* __restrict__ fmin_out,
+    float* __restrict__ indent_out, uint8_t* __restrict__ cam_u8, int npix, float near_m, float far_m,
+    float gelpad_h, float gelpad_dmin) {
+  const int b = blockIdx.x;
+  const float* src = in + (size_t)b * npix;
+  float m = INFINITY;
+  const int n4 = npix >> 2;
+  for (int i = threadIdx.x; i < n4; i += blockDim.x) {
+    v4f v = reinterpret_cast<const v4f*>(src)[i];
+    if (FROM_DEPTH) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        float d = v[k];
+        d = isinf(d) ? far_m : d;  // GS:585-588 (clip camera values that are inf)
+        v[k] = d * 1000.0f;        // GS:590 (m -> mm)
+      }
+      reinterpret_cast<v4f*>(hm_out + (size_t)b * npix)[i] = v;
+      if (cam_u8) {
+        // GS:573-575: ((mm - near*1000) / (far*1000)) * 255 -> uint8 (divides by far, sic)
+        uchar4 u;
+        float nmm = near_m * 1000.0f, fmm = far_m * 1000.0f;
+        u.x = (uint8_t)(((v[0] - nmm) / fmm) * 255.0f);
+        u.y = (uint8_t)(((v[1] - nmm) / fmm) * 255.0f);
+        u.z = (uint8_t)(((v[2] - nmm) / fmm) * 255.0f);
+        u.w = (uint8_t)(((v[3] - nmm) / fmm) * 255.0f);
+        reinterpret_cast<uchar4*>(cam_u8 + (size_t)b * npix)[i] = u;
+      }
+    }
+    m = fminf(m, fminf(fminf(v[0], v[1]), fminf(v[2], v[3])));
+  }
+  for (int i = (n4 << 2) + threadIdx.x; i < npix; i += blockDim.x) {  // tail (npix % 4)
+    float d = src[i];
+    if (FROM_DEPTH) {
+      d = isinf(d) ? far_m : d;
+      d *= 1000.0f;
+      hm_out[(size_t)b * npix + i] = d;
+      if (cam_u8) cam_u8[(size_t)b * npix + i] = (uint8_t)(((d - near_m * 1000.0f) / (far_m * 1000.0f)) * 255.0f);
+    }
+    m = fminf(m, d);
+  }
+  __shared__ float red[16];
+  m = wave_min(m);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x < 64) {
+    float v = threadIdx.x < (blockDim.x >> 6) ? red[threadIdx.x] : INFINITY;
+    v = wave_min(v);
+    if (threadIdx.x == 0) {
+      fmin_out[b] = v;
+      if (indent_out) {
+        // TS:116-129
+        float d = v / 1000.0f - gelpad_dmin;
+        d = d < 0.0f ? 0.0f : d;
+        indent_out[b] = d <= gelpad_h ? (gelpad_h - d) * 1000.0f : 0.0f;
+      }
+    }
+  }
+}
+
+// per-frame pressing depth P = -min(S) (TT:449) from the frame minimum:
+//   shifted : S = (hm - fmin) - press  -> min(S) = (fmin - fmin) - press = -press (exact in fp32)
+//   no shift: S = hm                   -> P = -fmin
+__global__ void press_depth_kernel(const float* __restrict__ fmin, const float* __restrict__ press,
+                                   float* __restrict__ shift_a, float* __restrict__ shift_b,
+                                   float* __restrict__ pdepth, int B, int no_shift) {
+  int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  if (no_shift) {
+    shift_a[b] = 0.0f;
+    shift_b[b] = 0.0f;
+    pdepth[b] = -fmin[b];
+  } else {
+    float p = press[b];
+    shift_a[b] = fmin[b];
+    shift_b[b] = p;
+    pdepth[b] = -((fmin[b] - fmin[b]) - p);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K3/K4: one pyramid level = separable Gaussian + masked restore, band-tiled (see file header)
+// ------------------------------------------------------------------------------------------------
+struct BlurArgs {
+  const float* src;     // (B,H,W) previous level; unused when FIRST
+  const float* hm;      // (B,H,W) height map (mm)
+  const float* gel;     // (H,W)
+  const float* shift_a; // (B,) S = (hm - shift_a) - shift_b
+  const float* shift_b; // (B,)
+  const float* pdepth;  // (B,) P
+  float* dst;           // (B,H,W)
+  uint8_t* mask_out;    // (B,H,W) nullable
+  const float* taps;    // (K,)
+  int H, W, B;
+  int pitch;            // LDS row pitch in float2 units (even, == 2 mod 32)
+  int padx;             // left padding in float2 units (even, >= (K-1)/2)
+  float contact_scale;
+  int restore;          // apply Z[M] = J[M]
+};
+
+template <int K, int TH, int RV, int RH, bool FIRST, int NT>
+__global__ __launch_bounds__(NT) void blur_band_kernel(BlurArgs a) {
+  static_assert(K % 2 == 1, "odd kernel");
+  static_assert(TH % RV == 0 && RV % 2 == 0 && TH % 2 == 0, "tile shape");
+  constexpr int R = (K - 1) / 2;
+  constexpr int RUP = (R + 1) & ~1;  // R rounded up to even (16-byte aligned LDS windows)
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  v2f* mid = reinterpret_cast<v2f*>(smem_raw);
+
+  const int H = a.H, W = a.W;
+  const int nbands = (H + TH - 1) / TH;
+  const int lid = xcd_remap(blockIdx.x, gridDim.x);
+  const int frame = lid / nbands;
+  const int band = lid - frame * nbands;
+  const int by0 = band * TH;
+  const size_t fo = (size_t)frame * H * W;
+  const float* __restrict__ src = FIRST ? a.hm + fo : a.src + fo;
+  const float* __restrict__ hm = a.hm + fo;
+  const float* __restrict__ gel = a.gel;
+  const float sa = a.shift_a[frame], sb = a.shift_b[frame];
+  const float* __restrict__ taps = a.taps;
+  const int pitch = a.pitch, padx = a.padx;
+
+  // ---- V-pass: global -> registers -> LDS (row-pair interleaved) ----
+  const int ncp = W >> 1;
+  const int vitems = ncp * (TH / RV);
+  for (int it = threadIdx.x; it < vitems; it += NT) {
+    const int ch = it / ncp;
+    const int c = (it - ch * ncp) << 1;
+    const int y0 = by0 + ch * RV;
+    v2f acc[RV];
+#pragma unroll
+    for (int r = 0; r < RV; ++r) acc[r] = (v2f)(0.0f);
+    static_for<0, RV + K - 1>([&](auto jc) {
+      constexpr int j = decltype(jc)::value;
+      int yy = reflect_idx(y0 - R + j, H);
+      yy = yy < 0 ? 0 : (yy >= H ? H - 1 : yy);  // rows of a partial last band (never stored)
+      v2f x = *reinterpret_cast<const v2f*>(src + (size_t)yy * W + c);
+      if (FIRST) {  // J = min(S, gel), S = (hm - shift_a) - shift_b   (TT:441, TT:454)
+        v2f g = *reinterpret_cast<const v2f*>(gel + (size_t)yy * W + c);
+        x.x = fminf((x.x - sa) - sb, g.x);
+        x.y = fminf((x.y - sa) - sb, g.y);
+      }
+      static_for<0, RV>([&](auto rc) {
+        constexpr int r = decltype(rc)::value;
+        constexpr int t = j - r;
+        if constexpr (t >= 0 && t < K) {
+          const float w = taps[t < K - 1 - t ? t : K - 1 - t];  // symmetric taps: half the scalars
+          acc[r] += w * x;
+        }
+      });
+    });
+    const int rp0 = (ch * RV) >> 1;
+#pragma unroll
+    for (int r = 0; r < RV; r += 2) {
+      v2f* row = mid + (size_t)(rp0 + (r >> 1)) * pitch + padx;
+      v2f e0 = {acc[r].x, acc[r + 1].x};  // column c   : (row y, row y+1)
+      v2f e1 = {acc[r].y, acc[r + 1].y};  // column c+1
+      v4f q = {e0.x, e0.y, e1.x, e1.y};
+      *reinterpret_cast<v4f*>(row + c) = q;
+      // mirrored x-padding (torch 'reflect'): position -cc <- cc, position 2(W-1)-cc <- cc
+      if (c >= 1 && c <= padx) row[-c] = e0;
+      if (c + 1 <= padx) row[-(c + 1)] = e1;
+      if (c >= W - 1 - padx && c <= W - 2) row[2 * (W - 1) - c] = e0;
+      if (c + 1 >= W - 1 - padx && c + 1 <= W - 2) row[2 * (W - 1) - (c + 1)] = e1;
+    }
+  }
+  __syncthreads();
+
+  // ---- H-pass: LDS -> registers -> masked restore -> global ----
+  const float P = a.pdepth[frame];
+  const float thr = -P * a.contact_scale;  // TT:459
+  const int nseg = W / RH;
+  const int hitems = (TH >> 1) * ((nseg + 3) & ~3);
+  for (int it = threadIdx.x; it < hitems; it += NT) {
+    // lanes: 4 segments x 16 row pairs per wave keeps ds_read_b128 lane groups on distinct banks
+    const int rp = (it >> 2) % (TH >> 1);
+    const int seg = (it & 3) + ((it >> 2) / (TH >> 1)) * 4;
+    if (seg >= nseg) continue;
+    const int x0 = seg * RH;
+    const v2f* base = mid + (size_t)rp * pitch + padx + x0 - RUP;
+    v2f acc[RH];
+#pragma unroll
+    for (int r = 0; r < RH; ++r) acc[r] = (v2f)(0.0f);
+    static_for<0, (RH + 2 * RUP) / 2>([&](auto jc) {
+      constexpr int j2 = decltype(jc)::value;
+      // skip 16-byte groups that carry no tap for any output (alignment slack when R is odd)
+      v4f q = *reinterpret_cast<const v4f*>(base + 2 * j2);
+      static_for<0, 2>([&](auto hc) {
+        constexpr int h = decltype(hc)::value;
+        constexpr int j = 2 * j2 + h - (RUP - R);
+        const v2f x = h == 0 ? (v2f){q.x, q.y} : (v2f){q.z, q.w};
+        static_for<0, RH>([&](auto rc) {
+          constexpr int r = decltype(rc)::value;
+          constexpr int t = j - r;
+          if constexpr (t >= 0 && t < K) {
+            const float w = taps[t < K - 1 - t ? t : K - 1 - t];
+            acc[r] += w * x;
+          }
+        });
+      });
+    });
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int y = by0 + 2 * rp + h;
+      if (y >= H) continue;
+      const size_t ro = (size_t)y * W + x0;
+      float outv[RH];
+      uint8_t mk[RH];
+#pragma unroll
+      for (int r4 = 0; r4 < RH; r4 += 4) {
+        v4f hv = *reinterpret_cast<const v4f*>(hm + ro + r4);
+        v4f gv = *reinterpret_cast<const v4f*>(gel + ro + r4);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const float S = (hv[k] - sa) - sb;
+          const float J = fminf(S, gv[k]);
+          const bool M = ((J - gv[k]) < thr) && (S < 0.0f);  // TT:457-461
+          const float bl = h == 0 ? acc[r4 + k].x : acc[r4 + k].y;
+          outv[r4 + k] = (a.restore && M) ? J : bl;         // TT:467
+          mk[r4 + k] = M ? 1 : 0;
+        }
+      }
+#pragma unroll
+      for (int r4 = 0; r4 < RH; r4 += 4) {
+        v4f o = {outv[r4], outv[r4 + 1], outv[r4 + 2], outv[r4 + 3]};
+        *reinterpret_cast<v4f*>(a.dst + fo + ro + r4) = o;
+      }
+      if (a.mask_out) {
+#pragma unroll
+        for (int r4 = 0; r4 < RH; r4 += 4) {
+          uchar4 u = {mk[r4], mk[r4 + 1], mk[r4 + 2], mk[r4 + 3]};
+          *reinterpret_cast<uchar4*>(a.mask_out + fo + ro + r4) = u;
+        }
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// generic fallback (any odd kw, kh; any H, W): two plain passes through a temp buffer.
+// Used for resolutions whose kernel sizes have no tuned instantiation (e.g. 32x32 -> (7,9)).
+// ------------------------------------------------------------------------------------------------
+struct GenericArgs {
+  const float* src; const float* hm; const float* gel;
+  const float* shift_a; const float* shift_b; const float* pdepth;
+  float* dst; uint8_t* mask_out;
+  const float* taps; int k;
+  int H, W, B; float contact_scale; int restore; int first;
+};
+
+__global__ __launch_bounds__(256) void blur_generic_v_kernel(GenericArgs a) {  // vertical taps, src -> dst
+  const int H = a.H, W = a.W;
+  const size_t n = (size_t)a.B * H * W;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const int x = i % W;
+    const int y = (i / W) % H;
+    const int b = i / ((size_t)W * H);
+    const size_t fo = (size_t)b * H * W;
+    const int r = (a.k - 1) / 2;
+    float acc = 0.0f;
+    for (int t = 0; t < a.k; ++t) {
+      const int yy = reflect_idx(y - r + t, H);
+      float v;
+      if (a.first) {
+        const float S = (a.hm[fo + (size_t)yy * W + x] - a.shift_a[b]) - a.shift_b[b];
+        v = fminf(S, a.gel[(size_t)yy * W + x]);
+      } else {
+        v = a.src[fo + (size_t)yy * W + x];
+      }
+      acc = fmaf(a.taps[t], v, acc);
+    }
+    a.dst[i] = acc;
+  }
+}
+
+__global__ __launch_bounds__(256) void blur_generic_h_kernel(GenericArgs a) {  // horizontal taps + restore
+  const int H = a.H, W = a.W;
+  const size_t n = (size_t)a.B * H * W;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const int x = i % W;
+    const int y = (i / W) % H;
+    const int b = i / ((size_t)W * H);
+    const size_t fo = (size_t)b * H * W;
+    const int r = (a.k - 1) / 2;
+    float acc = 0.0f;
+    for (int t = 0; t < a.k; ++t) {
+      const int xx = reflect_idx(x - r + t, W);
+      acc = fmaf(a.taps[t], a.src[fo + (size_t)y * W + xx], acc);
+    }
+    const float g = a.gel[(size_t)y * W + x];
+    const float S = (a.hm[i] - a.shift_a[b]) - a.shift_b[b];
+    const float J = fminf(S, g);
+    const bool M = ((J - g) < (-a.pdepth[b] * a.contact_scale)) && (S < 0.0f);
+    a.dst[i] = (a.restore && M) ? J : acc;
+    if (a.mask_out) a.mask_out[i] = M ? 1 : 0;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K5-K10: normals -> bins -> polynomial gather -> + background -> clip -> NHWC   (one pass)
+// ------------------------------------------------------------------------------------------------
+struct ShadeArgs {
+  const float* z;      // (B,H,W) deformed gel, mm
+  const float* poly;   // (nb, nb, 24) f32: [im][id][c*6+k], padded 18 -> 24 floats (16-byte aligned rows)
+  const float* bg;     // (H,W,3) f32 (NHWC copy of the background)
+  const float* fx;     // (W,)
+  const float* fy;     // (H,)
+  float* rgb;          // (B,H,W,3)
+  uint8_t* idx_out;    // (B,H,W,2) nullable
+  int H, W, B, nb;
+  float pixmm;         // 0.0295
+  float sy, sx;        // H / calib_h, W / calib_w applied as "* H / calib_h" (TT:489-490)
+  float calib_h, calib_w;
+  float x_binr, y_binr;
+};
+
+__global__ __launch_bounds__(256) void shade_kernel(ShadeArgs a) {
+  const int H = a.H, W = a.W;
+  const int npix = H * W;
+  const int b = blockIdx.y;
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= npix) return;
+  const int y = p / W, x = p - y * W;
+  const float* __restrict__ z = a.z + (size_t)b * npix;
+  // replicate padding of the (H-2, W-2) gradient maps (TT:501-502) == evaluate at the clamped pixel
+  const int yc = min(max(y, 1), H - 2), xc = min(max(x, 1), W - 2);
+  // height in pixel units, sign flipped: z_px = -(Z / pixmm)  (TT:238-239)
+  const float top = -(z[(size_t)(yc - 1) * W + xc] / a.pixmm);
+  const float bot = -(z[(size_t)(yc + 1) * W + xc] / a.pixmm);
+  const float lef = -(z[(size_t)yc * W + xc - 1] / a.pixmm);
+  const float rig = -(z[(size_t)yc * W + xc + 1] / a.pixmm);
+  // same op order as TT:486-490: ((bot-top)/2) * H / calib_h   (no fma contraction across these)
+  const float dzdx = __fdiv_rn(__fmul_rn(__fmul_rn(__fsub_rn(bot, top), 0.5f), (float)H), a.calib_h);
+  const float dzdy = __fdiv_rn(__fmul_rn(__fmul_rn(__fsub_rn(rig, lef), 0.5f), (float)W), a.calib_w);
+  const float t = __fsqrt_rn(__fadd_rn(__fmul_rn(dzdx, dzdx), __fmul_rn(dzdy, dzdy)));
+  const float mag = atanf(t);
+  const float dir = t != 0.0f ? atan2f(__fdiv_rn(dzdx, t), __fdiv_rn(dzdy, t)) : 0.0f;  // TT:494-499
+  int im = (int)floorf(__fdiv_rn(mag, a.x_binr));                                         // TT:246
+  int id = (int)floorf(__fdiv_rn(__fadd_rn(dir, 3.14159274101257324f), a.y_binr));        // TT:247
+  im = min(max(im, 0), a.nb - 1);
+  id = min(max(id, 0), a.nb - 1);
+  const v4f* __restrict__ pc = reinterpret_cast<const v4f*>(a.poly + ((size_t)im * a.nb + id) * 24);
+  const v4f c0 = pc[0], c1 = pc[1], c2 = pc[2], c3 = pc[3], c4 = pc[4];
+  const float X = a.fx[x], Y = a.fy[y];
+  const float f0 = X * X, f1 = Y * Y, f2 = X * Y;  // TT:148-157
+  // I_c = sum_k f_k * p_{c,k}
+  const float r = ((((f0 * c0.x + f1 * c0.y) + f2 * c0.z) + X * c0.w) + Y * c1.x) + c1.y;
+  const float g = ((((f0 * c1.z + f1 * c1.w) + f2 * c2.x) + X * c2.y) + Y * c2.z) + c2.w;
+  const float bl = ((((f0 * c3.x + f1 * c3.y) + f2 * c3.z) + X * c3.w) + Y * c4.x) + c4.y;
+  const float* __restrict__ bg = a.bg + (size_t)p * 3;
+  float* __restrict__ o = a.rgb + ((size_t)b * npix + p) * 3;
+  o[0] = fminf(fmaxf(r + bg[0], 0.0f), 1.0f);   // TT:257-258
+  o[1] = fminf(fmaxf(g + bg[1], 0.0f), 1.0f);
+  o[2] = fminf(fmaxf(bl + bg[2], 0.0f), 1.0f);
+  if (a.idx_out) {
+    uint8_t* io = a.idx_out + ((size_t)b * npix + p) * 2;
+    io[0] = (uint8_t)im;
+    io[1] = (uint8_t)id;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K15: bilinear antialiased resize (separable triangle filter, PIL/torchvision semantics)
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void aa_window(int i, float scale, int n_in, int& lo, int& cnt, float& center,
+                                          float& inv) {
+  const float support = scale >= 1.0f ? scale : 1.0f;
+  inv = scale >= 1.0f ? 1.0f / scale : 1.0f;
+  center = scale * (i + 0.5f);
+  lo = max(0, (int)(center - support + 0.5f));
+  const int hi = min(n_in, (int)(center + support + 0.5f));
+  cnt = hi - lo;
+}
+
+__global__ __launch_bounds__(256) void resize_aa_kernel(const float* __restrict__ src, int sh, int sw,
+                                                       float* __restrict__ dst, int dh, int dw, int B) {
+  const size_t n = (size_t)B * dh * dw;
+  const float scy = (float)sh / dh, scx = (float)sw / dw;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const int x = i % dw;
+    const int y = (i / dw) % dh;
+    const int b = i / ((size_t)dw * dh);
+    int xl, xc, yl, yc;
+    float cx, ix, cy, iy;
+    aa_window(x, scx, sw, xl, xc, cx, ix);
+    aa_window(y, scy, sh, yl, yc, cy, iy);
+    float wys = 0.0f, acc = 0.0f;
+    for (int jy = 0; jy < yc; ++jy) {
+      const float wy = fmaxf(0.0f, 1.0f - fabsf((jy + yl - cy + 0.5f) * iy));
+      float wxs = 0.0f, rowacc = 0.0f;
+      const float* row = src + ((size_t)b * sh + (yl + jy)) * sw;
+      for (int jx = 0; jx < xc; ++jx) {
+        const float wx = fmaxf(0.0f, 1.0f - fabsf((jx + xl - cx + 0.5f) * ix));
+        rowacc = fmaf(wx, row[xl + jx], rowacc);
+        wxs += wx;
+      }
+      acc = fmaf(wy, rowacc / wxs, acc);
+      wys += wy;
+    }
+    dst[i] = acc / wys;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// host-side launchers
+// ------------------------------------------------------------------------------------------------
+static inline int lds_pitch_for(int W, int padx) {
+  int pitch = W + 2 * padx;
+  int m = ((2 - pitch) % 32 + 32) % 32;  // pitch == 2 (mod 32) float2 units -> row-pair stride of 4 banks
+  return pitch + m;
+}
+
+template <int K, int TH, int RV, int RH, bool FIRST>
+static hipError_t launch_band(const BlurArgs& a0, hipStream_t st) {
+  constexpr int NT = 320;
+  BlurArgs a = a0;
+  constexpr int R = (K - 1) / 2;
+  a.padx = (R + 1) & ~1;
+  a.pitch = lds_pitch_for(a.W, a.padx);
+  const int nbands = (a.H + TH - 1) / TH;
+  const size_t lds = (size_t)(TH / 2) * a.pitch * sizeof(v2f);
+  auto kern = blur_band_kernel<K, TH, RV, RH, FIRST, NT>;
+  static bool attr_done = false;
+  if (!attr_done && lds > 48 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(nbands * a.B), dim3(NT), lds, st, a);
+  return hipGetLastError();
+}
+
+static bool band_supported(int k, int H, int W) {
+  if (W % 16 != 0 || W < 32 || H < 2) return false;
+  if ((k - 1) / 2 >= H || ((k - 1) / 2 + 1) > W - 1) return false;
+  switch (k) {
+    case 3: case 5: case 9: case 15: case 17: case 33: case 61: return true;  // 117: generic path (TODO chunked variant)
+    default: return false;
+  }
+}
+
+static bool band_first_supported(int k) { return k == 61; }
+
+static hipError_t dispatch_band(int k, bool first, const BlurArgs& a, hipStream_t st) {
+  if (first) {
+    switch (k) {  // first pyramid level at the two tuned resolutions (320x240 / 640x480)
+      case 61: return launch_band<61, 32, 16, 16, true>(a, st);
+      default: return hipErrorInvalidValue;
+    }
+  }
+  switch (k) {
+    case 3: return launch_band<3, 32, 16, 16, false>(a, st);
+    case 5: return launch_band<5, 32, 16, 16, false>(a, st);
+    case 9: return launch_band<9, 32, 16, 16, false>(a, st);
+    case 15: return launch_band<15, 32, 16, 16, false>(a, st);
+    case 17: return launch_band<17, 32, 16, 16, false>(a, st);
+    case 33: return launch_band<33, 32, 16, 16, false>(a, st);
+    case 61: return launch_band<61, 32, 16, 16, false>(a, st);
+    default: return hipErrorInvalidValue;
+  }
+}
+
+hipError_t run_frame_min(const float* in, bool from_depth, float* hm_out, float* fmin, float* indent,
+                         uint8_t* cam_u8, int B, int npix, float near_m, float far_m, float gelpad_h,
+                         float gelpad_dmin, hipStream_t st) {
+  if (from_depth)
+    hipLaunchKernelGGL(frame_min_kernel<true>, dim3(B), dim3(1024), 0, st, in, hm_out, fmin, indent, cam_u8,
+                       npix, near_m, far_m, gelpad_h, gelpad_dmin);
+  else
+    hipLaunchKernelGGL(frame_min_kernel<false>, dim3(B), dim3(1024), 0, st, in, hm_out, fmin, indent, cam_u8,
+                       npix, near_m, far_m, gelpad_h, gelpad_dmin);
+  return hipGetLastError();
+}
+
+hipError_t run_press_depth(const float* fmin, const float* press, float* sa, float* sb, float* pd, int B,
+                           int no_shift, hipStream_t st) {
+  hipLaunchKernelGGL(press_depth_kernel, dim3((B + 255) / 256), dim3(256), 0, st, fmin, press, sa, sb, pd, B,
+                     no_shift);
+  return hipGetLastError();
+}
+
+hipError_t run_blur_level(const LevelDesc& lv, const float* src, const float* hm, const float* gel,
+                          const float* sa, const float* sb, const float* pd, float* dst, float* tmp,
+                          uint8_t* mask_out, int B, int H, int W, float contact_scale, int restore,
+                          bool first, hipStream_t st) {
+  if (lv.same_taps && band_supported(lv.kw, H, W) && (!first || band_first_supported(lv.kw))) {
+    BlurArgs a{};
+    a.src = src; a.hm = hm; a.gel = gel; a.shift_a = sa; a.shift_b = sb; a.pdepth = pd;
+    a.dst = dst; a.mask_out = mask_out; a.taps = lv.taps_w_dev; a.H = H; a.W = W; a.B = B;
+    a.contact_scale = contact_scale; a.restore = restore;
+    return dispatch_band(lv.kw, first, a, st);
+  }
+  GenericArgs g{};
+  g.hm = hm; g.gel = gel; g.shift_a = sa; g.shift_b = sb; g.pdepth = pd; g.H = H; g.W = W; g.B = B;
+  g.contact_scale = contact_scale;
+  const size_t n = (size_t)B * H * W;
+  const int grid = (int)((n + 255) / 256 < 65536 ? (n + 255) / 256 : 65536);
+  g.src = src; g.dst = tmp; g.taps = lv.taps_h_dev; g.k = lv.kh; g.first = first ? 1 : 0; g.restore = 0;
+  g.mask_out = nullptr;
+  hipLaunchKernelGGL(blur_generic_v_kernel, dim3(grid), dim3(256), 0, st, g);
+  g.src = tmp; g.dst = dst; g.taps = lv.taps_w_dev; g.k = lv.kw; g.first = 0; g.restore = restore;
+  g.mask_out = mask_out;
+  hipLaunchKernelGGL(blur_generic_h_kernel, dim3(grid), dim3(256), 0, st, g);
+  return hipGetLastError();
+}
+
+hipError_t run_shade(const ShadeParams& sp, const float* z, float* rgb, uint8_t* idx_out, int B,
+                     hipStream_t st) {
+  ShadeArgs a{};
+  a.z = z; a.poly = sp.poly_dev; a.bg = sp.bg_nhwc_dev; a.fx = sp.fx_dev; a.fy = sp.fy_dev; a.rgb = rgb;
+  a.idx_out = idx_out; a.H = sp.H; a.W = sp.W; a.B = B; a.nb = sp.nb; a.pixmm = sp.pixmm;
+  a.calib_h = (float)sp.calib_h; a.calib_w = (float)sp.calib_w;
+  a.x_binr = sp.x_binr; a.y_binr = sp.y_binr;
+  const int npix = sp.H * sp.W;
+  hipLaunchKernelGGL(shade_kernel, dim3((npix + 255) / 256, B), dim3(256), 0, st, a);
+  return hipGetLastError();
+}
+
+hipError_t run_resize_aa(const float* src, int sh, int sw, float* dst, int dh, int dw, int B, hipStream_t st) {
+  const size_t n = (size_t)B * dh * dw;
+  const int grid = (int)((n + 255) / 256 < 65536 ? (n + 255) / 256 : 65536);
+  hipLaunchKernelGGL(resize_aa_kernel, dim3(grid), dim3(256), 0, st, src, sh, sw, dst, dh, dw, B);
+  return hipGetLastError();
+}
+
+}  // namespace tacex

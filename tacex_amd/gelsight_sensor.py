@@ -1,0 +1,260 @@
+"""`GelSightSensor` - the sensor boundary, drop-in for source/tacex/tacex/gelsight_sensor.py:31-378.
+
+Same constructor, properties (`data`, `frame`, `tactile_image_shape`, `camera_resolution`,
+`indentation_depth`), `update()` / `reset()` semantics and persistent output buffers that are written in
+place.  The Isaac `TiledCamera` is replaced by an injected depth image (cfg.sensor_camera_cfg.depth_source
+or `set_camera_depth`); everything downstream of that image runs in HIP kernels.
+"""
+from __future__ import annotations
+
+from collections.abc import Sequence
+from typing import TYPE_CHECKING
+
+import torch
+
+from . import _lib
+from .gelsight_sensor_data import GelSightSensorData
+from .sensor_base import SensorBase
+from .simulation_approaches.gelsight_simulator import GelSightSimulator
+
+if TYPE_CHECKING:
+    from .gelsight_sensor_cfg import GelSightSensorCfg
+
+
+class GelSightSensor(SensorBase):
+    cfg: "GelSightSensorCfg"
+
+    def __init__(self, cfg: "GelSightSensorCfg", gelpad_obj=None):
+        self.cfg = cfg
+        self._prim_view = None
+        self.camera = None  # there is no TiledCamera here; see set_camera_depth
+        self.gelpad_obj = gelpad_obj
+        self._indentation_depth: torch.Tensor = None
+        self.optical_simulator: GelSightSimulator = None
+        self.marker_motion_simulator: GelSightSimulator = None
+        self.compute_indentation_depth_func = None
+        self._data = GelSightSensorData()
+        self._data.output = dict.fromkeys(self.cfg.data_types, None)
+        self._is_spawned = False
+        self._camera_depth_m = None
+        self._height_map_version = 0
+        # SensorBase sets _num_envs / _device, which the simulator constructors read
+        super().__init__(self.cfg)
+
+        # instantiate the simulation approaches named in the cfg (gelsight_sensor.py:59-77)
+        if self.cfg.optical_sim_cfg is not None:
+            self.optical_simulator = self.cfg.optical_sim_cfg.simulation_approach_class(
+                sensor=self, cfg=self.cfg.optical_sim_cfg
+            )
+        if self.cfg.marker_motion_sim_cfg is not None:
+            if (self.optical_simulator is not None) and (
+                self.cfg.optical_sim_cfg.simulation_approach_class
+                == self.cfg.marker_motion_sim_cfg.simulation_approach_class
+            ):
+                self.marker_motion_simulator = self.optical_simulator
+            else:
+                self.marker_motion_simulator = self.cfg.marker_motion_sim_cfg.simulation_approach_class(
+                    sensor=self, cfg=self.cfg.marker_motion_sim_cfg
+                )
+
+    # -- properties (gelsight_sensor.py:107-140) --------------------------------------------------------
+    @property
+    def data(self) -> GelSightSensorData:
+        self._update_outdated_buffers()
+        return self._data
+
+    @property
+    def frame(self) -> torch.Tensor:
+        return self._frame
+
+    @property
+    def tactile_image_shape(self) -> tuple[int, int, int]:
+        return self.cfg.optical_sim_cfg.tactile_img_res[1], self.cfg.optical_sim_cfg.tactile_img_res[0], 3
+
+    @property
+    def camera_resolution(self) -> tuple[int, int]:
+        return self.cfg.sensor_camera_cfg.resolution[0], self.cfg.sensor_camera_cfg.resolution[1]
+
+    @property
+    def indentation_depth(self):
+        """How deep objects are inside the gel pad [mm]."""
+        return self._indentation_depth
+
+    @property
+    def prim_view(self):
+        return self._prim_view
+
+    # -- depth injection (replaces TiledCamera, gelsight_sensor.py:229-263) ---------------------------------
+    def set_camera_depth(self, depth_m: torch.Tensor):
+        """Provide the camera depth image in metres: (num_envs, Hc, Wc) or (num_envs, Hc, Wc, 1), float32."""
+        if depth_m.dim() == 4:
+            depth_m = depth_m[..., 0]
+        W, H = self.camera_resolution
+        if tuple(depth_m.shape) != (self._num_envs, H, W):
+            raise RuntimeError(
+                f"camera depth has shape {tuple(depth_m.shape)}, expected ({self._num_envs}, {H}, {W}) "
+                "(num_envs, camera height, camera width)"
+            )
+        self._camera_depth_m = depth_m
+
+    def _read_camera_depth(self):
+        src = self.cfg.sensor_camera_cfg.depth_source if self.cfg.sensor_camera_cfg is not None else None
+        if src is not None:
+            self.set_camera_depth(src())
+        return self._camera_depth_m
+
+    # -- reset (gelsight_sensor.py:147-197) -----------------------------------------------------------------
+    def reset(self, env_ids: Sequence[int] | None = None):
+        if not self._is_initialized:
+            self.initialize()
+            return
+        self._reset_impl(env_ids)
+
+    def _reset_impl(self, env_ids):
+        super().reset(env_ids)
+        if env_ids is None:
+            env_ids = self._ALL_INDICES
+        self._indentation_depth[env_ids] = 0
+        self._data.output["height_map"][env_ids] = 0
+        self._height_map_version += 1
+        if "camera_depth" in self._data.output and self._data.output["camera_depth"] is not None:
+            self._data.output["camera_depth"][env_ids] = 0
+        # simulate optical/marker output without indentation, then reset the simulators (reference order,
+        # gelsight_sensor.py:182-193: the render happens BEFORE optical_simulator.reset())
+        if (self.optical_simulator is not None) and ("tactile_rgb" in self._data.output):
+            self._data.output["tactile_rgb"][:] = self.optical_simulator.optical_simulation()
+            self.optical_simulator.reset()
+        if (self.marker_motion_simulator is not None) and ("marker_motion" in self._data.output):
+            self._data.output["marker_motion"][:] = self.marker_motion_simulator.marker_motion_simulation()
+            self._data.output["init_marker_pos"] = ([0], [0])
+            self.marker_motion_simulator.reset()
+        self._frame[env_ids] = 0
+
+    # -- initialisation (gelsight_sensor.py:203-337) -----------------------------------------------------------
+    def _initialize_impl(self):
+        super()._initialize_impl()
+        if self.cfg.device is not None:
+            self._device = self.cfg.device
+        dev = torch.device(self._device)
+        if dev.type != "cuda":
+            raise _lib.TacexHipError(f"GelSightSensor needs an AMD GPU device, got '{self._device}' (no CPU fallback)")
+        _lib.require_gpu(dev.index or 0)
+        self._ALL_INDICES = torch.arange(self._num_envs, device=self._device, dtype=torch.long)
+        self._frame = torch.zeros(self._num_envs, device=self._device, dtype=torch.long)
+        self._indentation_depth = torch.zeros((self._num_envs,), device=self._device)
+        Wc, Hc = self.camera_resolution
+        self._data.output["height_map"] = torch.zeros((self._num_envs, Hc, Wc), device=self._device)
+
+        if self.optical_simulator is not None:
+            self.optical_simulator._initialize_impl()
+        if self.marker_motion_simulator is not None and self.marker_motion_simulator is not self.optical_simulator:
+            self.marker_motion_simulator._initialize_impl()
+        elif self.marker_motion_simulator is not None and not hasattr(self.marker_motion_simulator, "marker_data"):
+            self.marker_motion_simulator._initialize_impl()
+
+        if "camera_depth" in self.cfg.data_types:
+            self._data.output["camera_depth"] = torch.zeros((self._num_envs, Hc, Wc, 1), dtype=torch.uint8, device=self._device)
+        if "camera_rgb" in self.cfg.data_types:
+            self._data.output["camera_rgb"] = torch.zeros((self._num_envs, Hc, Wc, 3), device=self._device)
+        if "tactile_rgb" in self.cfg.data_types:
+            if self.cfg.optical_sim_cfg is None:
+                raise RuntimeError("data type 'tactile_rgb' needs an optical_sim_cfg")
+            W, H = self.cfg.optical_sim_cfg.tactile_img_res
+            self._data.output["tactile_rgb"] = torch.zeros((self._num_envs, H, W, 3), device=self._device)
+        if "marker_motion" in self.cfg.data_types:
+            if self.cfg.marker_motion_sim_cfg is None:
+                raise RuntimeError("data type 'marker_motion' needs a marker_motion_sim_cfg")
+            nm = self.cfg.marker_motion_sim_cfg.marker_params.num_markers
+            self._data.output["marker_motion"] = torch.zeros((self._num_envs, 2, nm, 2), device=self._device)
+
+        # how the indentation depth is computed (gelsight_sensor.py:321-329)
+        if self.cfg.compute_indentation_depth_class == "optical_sim" and self.optical_simulator is not None:
+            self.compute_indentation_depth_func = self.optical_simulator.compute_indentation_depth
+        elif self.cfg.compute_indentation_depth_class == "marker_motion_sim" and self.marker_motion_simulator is not None:
+            self.compute_indentation_depth_func = self.marker_motion_simulator.compute_indentation_depth
+        else:
+            self.compute_indentation_depth_func = None
+        self._is_initialized = True
+        self._reset_impl(None)
+
+    # -- per-step update (gelsight_sensor.py:342-378) ------------------------------------------------------------
+    def _update_buffers_impl(self, env_ids: Sequence[int]):
+        # like the reference, env_ids only selects which frame counters advance: all envs are recomputed
+        if isinstance(env_ids, slice):
+            self._frame += 1
+        else:
+            self._frame[env_ids.to(self._frame.device)] += 1
+
+        if self.compute_indentation_depth_func is not None:
+            self._get_height_map()
+            self._indentation_depth[:] = self.compute_indentation_depth_func()
+
+        if "camera_depth" in self._data.output:
+            self._get_camera_depth()
+
+        if (self.optical_simulator is not None) and ("tactile_rgb" in self.cfg.data_types):
+            res = self.optical_simulator.optical_simulation()
+            if res.data_ptr() != self._data.output["tactile_rgb"].data_ptr():
+                self._data.output["tactile_rgb"][:] = res
+
+        if (self.marker_motion_simulator is not None) and ("marker_motion" in self.cfg.data_types):
+            res = self.marker_motion_simulator.marker_motion_simulation()
+            if res.data_ptr() != self._data.output["marker_motion"].data_ptr():
+                self._data.output["marker_motion"][:] = res
+
+    # -- camera -> height map (gelsight_sensor.py:557-593) ---------------------------------------------------------
+    def _fused_targets(self):
+        """Buffers of the indentation-depth provider the fused depth kernel may fill directly."""
+        sim = None
+        if self.compute_indentation_depth_func is not None:
+            sim = getattr(self.compute_indentation_depth_func, "__self__", None)
+        if sim is not None and hasattr(sim, "_frame_min") and hasattr(sim.cfg, "gelpad_height"):
+            return sim
+        return None
+
+    def _get_height_map(self):
+        depth = self._read_camera_depth()
+        if depth is None:
+            return self._data.output["height_map"]  # no camera: keep whatever the caller wrote
+        hm = self._data.output["height_map"]
+        near, far = self.cfg.sensor_camera_cfg.clipping_range
+        sim = self._fused_targets()
+        want_u8 = "camera_depth" in self._data.output and self._data.output["camera_depth"] is not None
+        depth = depth if (depth.is_contiguous() and depth.dtype == torch.float32) else depth.float().contiguous()
+        lib = _lib.load_library()
+        B, H, W = hm.shape
+        fmin = sim._frame_min if sim is not None else self._scratch_min()
+        indent = sim._indentation_depth if sim is not None else None
+        with torch.cuda.device(hm.device):
+            rc = lib.tacex_height_map_from_depth(
+                _lib.ptr(depth), float(near), float(far),
+                float(sim.cfg.gelpad_height) if sim is not None else 0.0,
+                float(sim.cfg.gelpad_to_camera_min_distance) if sim is not None else 0.0,
+                _lib.ptr(hm), _lib.ptr(fmin), _lib.ptr(indent),
+                _lib.ptr(self._data.output["camera_depth"]) if want_u8 else 0,
+                B, H, W, _lib.current_stream_handle(hm.device))
+        _lib.check(rc, "tacex_height_map_from_depth")
+        self._height_map_version += 1
+        if sim is not None:
+            sim._frame_min_version = self._height_map_version
+            sim._indent_version = self._height_map_version
+        self._camera_depth_version = self._height_map_version
+        return hm
+
+    def _scratch_min(self):
+        if getattr(self, "_fmin_scratch", None) is None:
+            self._fmin_scratch = torch.zeros((self._num_envs,), device=self._device)
+        return self._fmin_scratch
+
+    def _get_camera_depth(self):
+        # the uint8 image is produced by the same pass as the height map; only redo it if that did not run
+        if getattr(self, "_camera_depth_version", -1) != self._height_map_version and self._read_camera_depth() is not None:
+            self._get_height_map()
+        return self._data.output["camera_depth"]
+
+    # -- debug vis: Kit UI of the reference (gelsight_sensor.py:380-555) is out of scope -----------------------------
+    def _set_debug_vis_impl(self, debug_vis: bool):
+        pass
+
+    def _debug_vis_callback(self, event):
+        pass

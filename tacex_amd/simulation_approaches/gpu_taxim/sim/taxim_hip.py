@@ -1,0 +1,303 @@
+"""`TaximHip` - the MI355X backend of the Taxim optical simulator.
+
+Counterpart of the reference's `TaximTorch` (gpu_taxim/sim/taxim_torch.py:47-503) with the same public
+surface (`render_direct`, `render`, `background_img`, `width`, `height`, `sim_params`, `sensor_params`,
+`device`, `backend_name`, taxim_impl.py:74-246).  All per-frame arithmetic runs in hand-written HIP
+kernels behind the C ABI of libtacex_hip.so; this class only prepares tables once per resolution,
+owns the scratch buffers and passes raw device pointers + the current HIP stream.
+
+There is no CPU fallback: constructing it without a visible AMD GPU raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from pathlib import Path
+from typing import Any
+
+import numpy as np
+import torch
+
+from .... import _lib
+from ....calibration import CALIB_GELSIGHT, TaximTables, build_taxim_tables, load_params
+
+
+class _ShapeCtx:
+    """Device context + host tables for one tactile resolution."""
+
+    def __init__(self, tables: TaximTables, device_index: int):
+        lib = _lib.load_library()
+        self.tables = tables
+        p = _lib.TaximParams()
+        p.height, p.width = tables.height, tables.width
+        p.calib_height, p.calib_width = tables.sensor_params.height, tables.sensor_params.width
+        p.pixmm = tables.sensor_params.pixmm
+        p.num_bins = tables.sensor_params.num_bins
+        p.contact_scale = tables.sim_params.contact_scale
+        n = len(tables.ksize_w)
+        if n > _lib.MAX_LEVELS:
+            raise ValueError(f"at most {_lib.MAX_LEVELS} blur levels are supported, got {n}")
+        p.n_levels = n
+        self._keep = []  # keep the numpy buffers alive during the create call
+
+        def fp(a):
+            a = np.ascontiguousarray(a, dtype=np.float32)
+            self._keep.append(a)
+            return a.ctypes.data_as(_lib.c_float_p)
+
+        for i in range(n):
+            p.ksize_w[i], p.ksize_h[i] = tables.ksize_w[i], tables.ksize_h[i]
+            p.taps_w[i], p.taps_h[i] = fp(tables.taps_w[i]), fp(tables.taps_h[i])
+        p.poly, p.gel_map, p.background = fp(tables.poly), fp(tables.gel_map), fp(tables.background)
+        p.feat_x, p.feat_y = fp(tables.feat_x), fp(tables.feat_y)
+        h = C.c_void_p()
+        _lib.check(lib.tacex_taxim_create(device_index, C.byref(p), C.byref(h)), "tacex_taxim_create")
+        self.handle = h
+        self._lib = lib
+        self._keep = []
+
+    def __del__(self):
+        try:
+            if getattr(self, "handle", None):
+                self._lib.tacex_taxim_destroy(self.handle)
+                self.handle = None
+        except Exception:
+            pass
+
+
+class TaximHip:
+    def __init__(
+        self,
+        calib_folder: Path = CALIB_GELSIGHT,
+        params: dict[str, dict[str, Any]] | None = None,
+        device: torch.device | str = "cuda",
+    ):
+        self._device = torch.device(device)
+        if self._device.type != "cuda":
+            raise _lib.TacexHipError(
+                f"TaximHip runs on an AMD GPU only (got device '{device}'); the reference's CPU path is not "
+                "part of this package (the CPU oracle lives under oracle/ and is test infrastructure)."
+            )
+        self._device_index = self._device.index if self._device.index is not None else torch.cuda.current_device()
+        self._device = torch.device("cuda", self._device_index)
+        self._arch = _lib.require_gpu(self._device_index)
+        self._calib_folder = Path(calib_folder)
+        self._params_override = params
+        self._sim_params, self._sensor_params = load_params(self._calib_folder, params)
+        self._ctx: dict[tuple[int, int], _ShapeCtx] = {}
+        self._ws: dict[tuple[int, int], torch.Tensor] = {}
+        self._fmin: dict[tuple[int, int], torch.Tensor] = {}
+        self._bg_full = None
+        self._lib = _lib.load_library()
+
+    # -- taxim_impl.py:204-246 ---------------------------------------------------------------------------
+    @property
+    def width(self) -> int:
+        return self._sensor_params.width
+
+    @property
+    def height(self) -> int:
+        return self._sensor_params.height
+
+    @property
+    def sim_params(self):
+        return self._sim_params
+
+    @property
+    def sensor_params(self):
+        return self._sensor_params
+
+    @property
+    def device(self) -> torch.device:
+        return self._device
+
+    @property
+    def backend_name(self) -> str:
+        return "hip"
+
+    # -- tables ------------------------------------------------------------------------------------------
+    def context(self, shape_hw: tuple[int, int]) -> _ShapeCtx:
+        shape_hw = (int(shape_hw[0]), int(shape_hw[1]))
+        ctx = self._ctx.get(shape_hw)
+        if ctx is None:
+            tables = build_taxim_tables(self._calib_folder, shape_hw, self._params_override)
+            ctx = _ShapeCtx(tables, self._device_index)
+            self._ctx[shape_hw] = ctx
+        return ctx
+
+    @property
+    def background_img(self) -> torch.Tensor:
+        """(3, calib_h, calib_w) processed background, like taxim_torch.py:132-134."""
+        if self._bg_full is None:
+            t = self.context((self.height, self.width)).tables
+            self._bg_full = torch.from_numpy(t.background_full).to(self._device)
+        return self._bg_full
+
+    def background_for(self, shape_hw: tuple[int, int]) -> torch.Tensor:
+        return torch.from_numpy(self.context(shape_hw).tables.background).to(self._device)
+
+    def gel_map_for(self, shape_hw: tuple[int, int]) -> torch.Tensor:
+        return torch.from_numpy(self.context(shape_hw).tables.gel_map).to(self._device)
+
+    # -- scratch -----------------------------------------------------------------------------------------
+    def _workspace(self, ctx: _ShapeCtx, shape_hw, B: int) -> torch.Tensor:
+        need = self._lib.tacex_taxim_workspace_bytes(ctx.handle, B)
+        ws = self._ws.get(shape_hw)
+        if ws is None or ws.numel() < need:
+            ws = torch.empty(need, dtype=torch.uint8, device=self._device)
+            self._ws[shape_hw] = ws
+        return ws
+
+    def _frame_min_buf(self, shape_hw, B: int) -> torch.Tensor:
+        fm = self._fmin.get(shape_hw)
+        if fm is None or fm.numel() < B:
+            fm = torch.empty(B, dtype=torch.float32, device=self._device)
+            self._fmin[shape_hw] = fm
+        return fm[:B]
+
+    def _check_hm(self, height_map: torch.Tensor) -> torch.Tensor:
+        if not isinstance(height_map, torch.Tensor):
+            raise TypeError("height_map must be a torch.Tensor on the GPU (use render() for NumPy input)")
+        if height_map.device != self._device:
+            raise ValueError(f"height_map is on {height_map.device}, this simulator runs on {self._device}")
+        if height_map.dim() < 2:
+            raise ValueError("height_map needs at least 2 dimensions (..., H, W)")
+        hm = height_map.reshape((-1,) + tuple(height_map.shape[-2:]))
+        if hm.dtype != torch.float32:
+            hm = hm.float()
+        return hm.contiguous()
+
+    def _press(self, press_depth, B: int):
+        if press_depth is None:
+            return None
+        if not isinstance(press_depth, torch.Tensor):
+            press_depth = torch.full((B,), float(press_depth), dtype=torch.float32, device=self._device)
+        p = press_depth.to(device=self._device, dtype=torch.float32).reshape(-1)
+        if p.numel() == 1 and B != 1:
+            p = p.expand(B)
+        if p.numel() != B:
+            raise ValueError(f"press_depth has {p.numel()} entries for {B} height maps")
+        return p.contiguous()
+
+    # -- taxim_impl.py:153-163 / taxim_torch.py:174-195 ----------------------------------------------------
+    def render_direct(
+        self,
+        height_map: torch.Tensor,
+        with_shadow: bool = True,
+        press_depth: torch.Tensor | float | None = None,
+        orig_hm_fmt: bool = False,
+        out: torch.Tensor | None = None,
+        frame_min: torch.Tensor | None = None,
+        z_out: torch.Tensor | None = None,
+        mask_out: torch.Tensor | None = None,
+    ) -> torch.Tensor:
+        """(..., H, W) mm height map -> (..., 3, H, W) RGB in [0,1] (a channel-first VIEW of an NHWC buffer).
+
+        Extra keyword arguments (not in the reference): `out` (B,H,W,3) buffer to render into,
+        `frame_min` (B,) precomputed per-frame minimum, `z_out` / `mask_out` to also return the deformed gel
+        and the shrunken contact mask of taxim_torch.py:443-473 (the FOTS wrapper needs both).
+        """
+        if with_shadow:
+            raise NotImplementedError(
+                "with_shadow=True (taxim_torch.py:260-346) is not implemented in the HIP backend yet; "
+                "every shipped TacEx cfg uses with_shadow=False"
+            )
+        batch_shape = tuple(height_map.shape[:-2])
+        hm = self._check_hm(height_map)
+        B, H, W = hm.shape
+        ctx = self.context((H, W))
+        if orig_hm_fmt:  # taxim_torch.py:185-186
+            hm = ctx.tables.gel_map_shift - hm
+        press = self._press(press_depth, B)
+        flags = 0
+        if press is None:
+            flags |= _lib.FLAG_NO_SHIFT
+        if frame_min is not None:
+            flags |= _lib.FLAG_HAVE_FRAME_MIN
+            fmin = frame_min
+        else:
+            fmin = self._frame_min_buf((H, W), B)
+        if out is None:
+            out = torch.empty((B, H, W, 3), dtype=torch.float32, device=self._device)
+        elif tuple(out.shape) != (B, H, W, 3) or not out.is_contiguous() or out.dtype != torch.float32:
+            raise ValueError("out must be a contiguous float32 (B,H,W,3) tensor")
+        ws = self._workspace(ctx, (H, W), B)
+        with torch.cuda.device(self._device):
+            stream = _lib.current_stream_handle(self._device)
+            rc = self._lib.tacex_taxim_render(
+                ctx.handle, _lib.ptr(hm), _lib.ptr(press), _lib.ptr(fmin), _lib.ptr(out), _lib.ptr(z_out),
+                _lib.ptr(mask_out), _lib.ptr(ws), B, flags, stream)
+        _lib.check(rc, "tacex_taxim_render")
+        return out.movedim(3, 1).reshape(batch_shape + (3, H, W))
+
+    def deform(self, height_map: torch.Tensor, press_depth, frame_min: torch.Tensor | None = None,
+               z_out: torch.Tensor | None = None, mask_out: torch.Tensor | None = None):
+        """__get_shifted_height_map + __compute_gel_pad_deformation (taxim_torch.py:432-473):
+        returns (deformed gel (B,H,W) f32 mm, shrunken contact mask (B,H,W) uint8)."""
+        hm = self._check_hm(height_map)
+        B, H, W = hm.shape
+        ctx = self.context((H, W))
+        press = self._press(press_depth, B)
+        flags = 0 if press is not None else _lib.FLAG_NO_SHIFT
+        if frame_min is not None:
+            flags |= _lib.FLAG_HAVE_FRAME_MIN
+            fmin = frame_min
+        else:
+            fmin = self._frame_min_buf((H, W), B)
+        if z_out is None:
+            z_out = torch.empty((B, H, W), dtype=torch.float32, device=self._device)
+        if mask_out is None:
+            mask_out = torch.empty((B, H, W), dtype=torch.uint8, device=self._device)
+        ws = self._workspace(ctx, (H, W), B)
+        with torch.cuda.device(self._device):
+            rc = self._lib.tacex_taxim_deform(
+                ctx.handle, _lib.ptr(hm), _lib.ptr(press), _lib.ptr(fmin), _lib.ptr(z_out), _lib.ptr(mask_out),
+                _lib.ptr(ws), B, flags, _lib.current_stream_handle(self._device))
+        _lib.check(rc, "tacex_taxim_deform")
+        return z_out, mask_out
+
+    def shade(self, deformed_gel: torch.Tensor, return_bins: bool = False):
+        """taxim_torch.py:237-258 on an existing deformed gel: (B,H,W) -> (B,H,W,3) [+ (B,H,W,2) uint8 bins]."""
+        z = self._check_hm(deformed_gel)
+        B, H, W = z.shape
+        ctx = self.context((H, W))
+        rgb = torch.empty((B, H, W, 3), dtype=torch.float32, device=self._device)
+        idx = torch.empty((B, H, W, 2), dtype=torch.uint8, device=self._device) if return_bins else None
+        with torch.cuda.device(self._device):
+            rc = self._lib.tacex_taxim_shade(ctx.handle, _lib.ptr(z), _lib.ptr(rgb), _lib.ptr(idx), B,
+                                             _lib.current_stream_handle(self._device))
+        _lib.check(rc, "tacex_taxim_shade")
+        return (rgb, idx) if return_bins else rgb
+
+    # -- taxim_impl.py:117-151, taxim_torch.py:166-171 ------------------------------------------------------
+    def convert_height_map(self, height_map: np.ndarray) -> torch.Tensor:
+        return torch.from_numpy(np.asarray(height_map)).to(self._device).float()
+
+    def img_to_numpy(self, img: torch.Tensor) -> np.ndarray:
+        b_dims = len(img.shape[:-3])
+        return img.permute(*range(b_dims), -2, -1, -3).cpu().numpy()
+
+    def render(self, height_map, with_shadow: bool = True, press_depth=None, orig_hm_fmt: bool = False):
+        """NumPy in -> NumPy (…,H,W,3) out; tensors are passed straight to render_direct."""
+        if isinstance(height_map, np.ndarray):
+            pd = press_depth
+            if isinstance(pd, np.ndarray):
+                pd = torch.from_numpy(pd).to(self._device).float()
+            res = self.render_direct(self.convert_height_map(height_map), with_shadow, pd, orig_hm_fmt)
+            return self.img_to_numpy(res)
+        return self.render_direct(height_map, with_shadow, press_depth, orig_hm_fmt)
+
+    __call__ = render
+
+    # -- profiling (bench.py roofline leg) --------------------------------------------------------------------
+    def set_profiling(self, shape_hw, enabled: bool):
+        ctx = self.context(shape_hw)
+        _lib.check(self._lib.tacex_taxim_set_profiling(ctx.handle, 1 if enabled else 0), "set_profiling")
+
+    def read_profile(self, shape_hw) -> dict[str, tuple[float, int]]:
+        ctx = self.context(shape_hw)
+        out = {}
+        for s in range(self._lib.tacex_taxim_num_stages(ctx.handle)):
+            ms, n = C.c_double(0), C.c_int(0)
+            _lib.check(self._lib.tacex_taxim_read_profile(ctx.handle, s, C.byref(ms), C.byref(n)), "read_profile")
+            out[self._lib.tacex_taxim_stage_name(ctx.handle, s).decode()] = (ms.value, n.value)
+        return out

@@ -1,0 +1,125 @@
+"""`TaximSimulator` - optical simulation plugin, drop-in for the reference's
+source/tacex/tacex/simulation_approaches/gpu_taxim/taxim_sim.py:20-135 (same attributes and methods),
+with the arithmetic done by libtacex_hip.so instead of PyTorch ops."""
+from __future__ import annotations
+
+from pathlib import Path
+from typing import TYPE_CHECKING
+
+import torch
+
+from ... import _lib
+from ..gelsight_simulator import GelSightSimulator
+from .sim import Taxim
+
+if TYPE_CHECKING:
+    from ...gelsight_sensor import GelSightSensor
+    from .taxim_sim_cfg import TaximSimulatorCfg
+
+
+class TaximSimulator(GelSightSimulator):
+    cfg: "TaximSimulatorCfg"
+
+    def __init__(self, sensor: "GelSightSensor", cfg: "TaximSimulatorCfg"):
+        self.sensor = sensor
+        super().__init__(sensor=sensor, cfg=cfg)
+
+    def _initialize_impl(self):
+        calib_folder = Path(self.cfg.calib_folder_path)
+        self._device = self.sensor.device if self.cfg.device is None else self.cfg.device
+        self._num_envs = self.sensor._num_envs
+        W, H = self.cfg.tactile_img_res
+        # indentation depth in mm (taxim_sim.py:43-50), on the sensor's device like the reference
+        self._indentation_depth = torch.zeros((self._num_envs,), device=self.sensor._device)
+        self.tactile_rgb_img = torch.zeros((self._num_envs, H, W, 3), device=self._device)
+        self._taxim = Taxim(calib_folder=calib_folder, device=self._device)
+        # (3,H,W) -> (H,W,3); the reference resizes the calibration-size background (taxim_sim.py:64-72),
+        # the tables already hold the same resize for the tactile resolution
+        self.background_img = self._taxim.background_for((H, W)).movedim(0, 2).contiguous()
+        self.tactile_rgb_img[:] = self.background_img
+        self.img_res = self.cfg.tactile_img_res
+        # per-frame minimum of the current height map, shared between compute_indentation_depth and the render
+        self._frame_min = torch.zeros((self._num_envs,), device=self._device)
+        self._frame_min_version = -1
+        self._indent_version = -1
+        # deformed gel + contact mask of the latest render, kept for a marker simulator (FOTS re-uses them)
+        self._keep_deformation = False
+        self._deformed_gel = None
+        self._contact_mask = None
+        self._deformation_version = -1
+        self._resized_hm = None
+
+    # -- helpers --------------------------------------------------------------------------------------
+    def request_deformation_outputs(self):
+        """A marker simulator asks the optical simulator to also keep (deformed gel, contact mask)."""
+        W, H = self.cfg.tactile_img_res
+        self._keep_deformation = True
+        self._deformed_gel = torch.zeros((self._num_envs, H, W), device=self._device)
+        self._contact_mask = torch.zeros((self._num_envs, H, W), dtype=torch.uint8, device=self._device)
+
+    def _tactile_height_map(self) -> tuple[torch.Tensor, bool]:
+        """Height map at the tactile resolution; resized with the HIP kernel if the camera differs (taxim_sim.py:88-89)."""
+        height_map = self.sensor._data.output["height_map"]
+        W, H = self.cfg.tactile_img_res
+        if (height_map.shape[1], height_map.shape[2]) == (H, W):
+            return height_map, False
+        B = height_map.shape[0]
+        if self._resized_hm is None or self._resized_hm.shape != (B, H, W):
+            self._resized_hm = torch.empty((B, H, W), dtype=torch.float32, device=self._device)
+        lib = _lib.load_library()
+        hm = height_map.contiguous()
+        with torch.cuda.device(self._resized_hm.device):
+            rc = lib.tacex_resize_bilinear_aa(_lib.ptr(hm), hm.shape[1], hm.shape[2], _lib.ptr(self._resized_hm), H, W, B,
+                                              _lib.current_stream_handle(self._resized_hm.device))
+        _lib.check(rc, "tacex_resize_bilinear_aa")
+        return self._resized_hm, True
+
+    # -- plugin interface -------------------------------------------------------------------------------
+    def optical_simulation(self):
+        """(num_envs, H, W, 3) float32 RGB in [0,1] (the reference docstring says 0..255, taxim_sim.py:83, wrongly)."""
+        height_map, resized = self._tactile_height_map()
+        have_min = (not resized) and self._frame_min_version == self.sensor._height_map_version
+        self._taxim.render_direct(
+            height_map,
+            with_shadow=self.cfg.with_shadow,
+            press_depth=self._indentation_depth,
+            orig_hm_fmt=False,
+            out=self.tactile_rgb_img,
+            frame_min=self._frame_min if have_min else None,
+            z_out=self._deformed_gel if self._keep_deformation else None,
+            mask_out=self._contact_mask if self._keep_deformation else None,
+        )
+        if self._keep_deformation:
+            self._deformation_version = self.sensor._height_map_version
+        return self.tactile_rgb_img
+
+    def compute_indentation_depth(self):
+        """taxim_sim.py:115-131 in one reduction kernel; also caches the per-frame minimum."""
+        if self._indent_version == self.sensor._height_map_version:
+            return self._indentation_depth  # already filled by the fused depth -> height-map pass of the sensor
+        height_map = self.sensor._data.output["height_map"]
+        B, H, W = height_map.shape
+        lib = _lib.load_library()
+        hm = height_map if height_map.is_contiguous() else height_map.contiguous()
+        with torch.cuda.device(hm.device):
+            rc = lib.tacex_indentation_depth(
+                _lib.ptr(hm), float(self.cfg.gelpad_height), float(self.cfg.gelpad_to_camera_min_distance),
+                _lib.ptr(self._frame_min), _lib.ptr(self._indentation_depth), B, H, W,
+                _lib.current_stream_handle(hm.device))
+        _lib.check(rc, "tacex_indentation_depth")
+        self._frame_min_version = self.sensor._height_map_version
+        self._indent_version = self.sensor._height_map_version
+        return self._indentation_depth
+
+    def reset(self):
+        self._indentation_depth = torch.zeros((self._num_envs,), device=self._device)
+        self.tactile_rgb_img[:] = self.background_img
+        self._frame_min_version = -1
+        self._indent_version = -1
+        self._deformation_version = -1
+
+    def _set_debug_vis_impl(self, debug_vis: bool):
+        pass  # Kit UI windows of the reference (taxim_sim.py:137-213) are out of scope
+
+    def _debug_vis_callback(self, event):
+        pass

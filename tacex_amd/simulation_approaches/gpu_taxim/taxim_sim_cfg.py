@@ -1,0 +1,19 @@
+from ...utils.configclass import MISSING, configclass
+from ..gelsight_simulator_cfg import GelSightSimulatorCfg
+from .taxim_sim import TaximSimulator
+
+
+@configclass
+class TaximSimulatorCfg(GelSightSimulatorCfg):
+    """Same fields as the reference's gpu_taxim/taxim_sim_cfg.py:11-36."""
+
+    simulation_approach_class: type = TaximSimulator
+    calib_folder_path: str = ""
+    device: str = "cuda"
+    with_shadow: bool = False
+    tactile_img_res: tuple = (320, 240)
+    """(width, height) of the tactile image; the camera height map is resampled if it differs."""
+    gelpad_height: float = MISSING
+    """Used for computing the indentation depth from the height map [m]."""
+    gelpad_to_camera_min_distance: float = MISSING
+    """Min distance of the camera to the gelpad [m]."""

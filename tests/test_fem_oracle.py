@@ -1,0 +1,132 @@
+"""CPU known-answer tests that pin the FEM oracle to itself (parity with libuipc is UNPINNED, see oracle/fem_oracle.py)."""
+import numpy as np
+import pytest
+
+from oracle.fem_oracle import FemModel, box_tet_mesh, marker_uv
+
+
+@pytest.fixture(scope="module")
+def meshes(golden_dir):
+    return np.load(golden_dir / "fem_meshes.npz")
+
+
+def _model(meshes, name="cube", **kw):
+    return FemModel.build(meshes[f"{name}_points"], meshes[f"{name}_tets"], **kw)
+
+
+def _rand_rot(rng):
+    q, _ = np.linalg.qr(rng.normal(size=(3, 3)))
+    return q * np.sign(np.linalg.det(q))
+
+
+def test_mesh_fixtures(meshes):
+    # simple_axle 593 nodes / 2003 tets, link 491/1499, cylinder_hole 388/1269
+    assert meshes["simple_axle_points"].shape == (593, 3) and meshes["simple_axle_tets"].shape == (2003, 4)
+    assert meshes["link_tets"].shape == (1499, 4) and meshes["cylinder_hole_tets"].shape == (1269, 4)
+    for n in ("tet", "cube", "simple_axle", "link", "cylinder_hole"):
+        m = _model(meshes, n)
+        assert (m.vol > 0).all()
+        np.testing.assert_allclose(m.mass.sum(), 1e3 * m.vol.sum(), rtol=1e-12)
+
+
+def test_rest_state_zero_force_and_energy(meshes):
+    m = _model(meshes, "simple_axle")
+    x = m.X.copy()
+    assert np.abs(m.element_energy(x)).max() < 1e-12 * m.mu * m.vol.max() + 1e-18
+    g = m.element_gradient(x)
+    assert np.abs(g).max() < 1e-9 * m.mu * np.cbrt(m.vol.max()) ** 2
+    assert np.abs(m.gradient(x, x)).max() < 1e-9 * m.mu * np.cbrt(m.vol.max()) ** 2
+
+
+def test_rigid_motion_invariance(meshes):
+    rng = np.random.default_rng(0)
+    m = _model(meshes, "link")
+    x = m.X + 0.02 * np.ptp(m.X) * rng.normal(size=m.X.shape)
+    R, t = _rand_rot(rng), rng.normal(size=3)
+    e0 = m.element_energy(x)
+    e1 = m.element_energy(x @ R.T + t)
+    np.testing.assert_allclose(e1, e0, rtol=1e-9, atol=1e-14 * np.abs(e0).max())
+    g0 = m.element_gradient(x).reshape(-1, 4, 3)
+    g1 = m.element_gradient(x @ R.T + t).reshape(-1, 4, 3)
+    np.testing.assert_allclose(g1, g0 @ R.T, rtol=1e-7, atol=1e-9 * np.abs(g0).max())
+
+
+def test_gradient_and_hessian_finite_differences(meshes):
+    rng = np.random.default_rng(1)
+    m = _model(meshes, "cube")
+    L = np.ptp(m.X)
+    x = m.X + 0.05 * L * rng.normal(size=m.X.shape)
+    xt = m.X + 0.01 * L * rng.normal(size=m.X.shape)
+    cons = (rng.random(len(m.X)) < 0.3).astype(np.float64)
+    aim = m.X + 0.02 * L * rng.normal(size=m.X.shape)
+    g = m.gradient(x, xt, cons, aim)
+    h = 1e-6 * L
+    for _ in range(5):
+        d = rng.normal(size=x.shape)
+        fd = (m.energy(x + h * d, xt, cons, aim) - m.energy(x - h * d, xt, cons, aim)) / (2 * h)
+        assert abs(fd - (g * d).sum()) <= 1e-6 * max(abs(fd), 1e-30) + 1e-12 * np.abs(g).sum()
+        Hd = m.hess_vec(x, d, cons)
+        fdH = (m.gradient(x + h * d, xt, cons, aim) - m.gradient(x - h * d, xt, cons, aim)) / (2 * h)
+        assert np.abs(fdH - Hd).max() <= 1e-5 * np.abs(Hd).max()
+    # element Hessian columns agree with finite differences of element gradients
+    He = m.element_hessian(x)
+    ge0 = m.element_gradient
+    v = 3
+    for comp in range(3):
+        dx = np.zeros_like(x)
+        dx[v, comp] = h
+        fd = (ge0(x + dx) - ge0(x - dx)) / (2 * h)  # (T,12)
+        for t in np.where((m.tets == v).any(1))[0][:4]:
+            loc = int(np.where(m.tets[t] == v)[0][0])
+            assert np.abs(fd[t] - He[t][:, loc * 3 + comp]).max() <= 1e-5 * np.abs(He[t]).max()
+    assert np.abs(He - np.swapaxes(He, -1, -2)).max() <= 1e-9 * np.abs(He).max()
+
+
+def test_psd_projection(meshes):
+    rng = np.random.default_rng(2)
+    m = _model(meshes, "cube")
+    x = m.X * np.array([0.55, 1.3, 0.7]) + 0.03 * np.ptp(m.X) * rng.normal(size=m.X.shape)  # strong compression
+    H = m.element_hessian(x)
+    Hp = m.element_hessian(x, project_psd=True)
+    w = np.linalg.eigvalsh(H)
+    wp = np.linalg.eigvalsh(Hp)
+    assert w.min() < -1e-9 * np.abs(w).max(), "test input must produce indefinite element Hessians"
+    assert wp.min() >= -1e-9 * np.abs(wp).max()
+    # already-PSD elements are unchanged
+    psd = w.min(-1) >= 0
+    if psd.any():
+        np.testing.assert_allclose(Hp[psd], H[psd], rtol=1e-9, atol=1e-12 * np.abs(H).max())
+    # rest state: projection is a no-op
+    H0 = m.element_hessian(m.X)
+    np.testing.assert_allclose(m.element_hessian(m.X, True), H0, rtol=1e-8, atol=1e-10 * np.abs(H0).max())
+
+
+def test_newton_step_monotone_and_converges():
+    X, tets = box_tet_mesh(4, 5, 2)
+    m = FemModel.build(X, tets, youngs=1e4, poisson=0.49, density=1e3, dt=0.01, strength=100.0)
+    rng = np.random.default_rng(3)
+    top = X[:, 2] > X[:, 2].max() - 1e-9
+    cons = top.astype(np.float64)
+    aim = X.copy()
+    aim[top, 2] -= 0.0008  # press the top surface down by 0.8 mm
+    x = X.copy()
+    xt = X + m.dt**2 * np.array([0, 0, -9.8])
+    E_prev = m.energy(x, xt, cons, aim)
+    for it in range(12):
+        x, st = m.newton_step(x, xt, cons, aim, pcg_max_iter=200, pcg_tol_rate=1e-4)
+        assert st[1] <= st[0] + 1e-18, "line search must not increase the energy"
+        assert abs(st[0] - E_prev) <= 1e-12 * max(abs(E_prev), 1e-30)
+        E_prev = st[1]
+    gn = np.abs(m.gradient(x, xt, cons, aim)).max()
+    g0 = np.abs(m.gradient(X, xt, cons, aim)).max()
+    assert gn < 1e-4 * g0
+    assert np.abs(x[top, 2] - aim[top, 2]).max() < 0.5 * 0.0008  # constraint pulls the surface most of the way
+
+
+def test_marker_uv_pinhole():
+    pos = np.array([[[0.0, 0.0, 0.02], [0.004, 0.0, 0.02], [0.0, 0.004, 0.02]]])
+    tri = np.array([[0, 1, 2]])
+    w = np.array([[0.2, 0.3, 0.5]])
+    uv = marker_uv(pos, tri, w)
+    p = 0.2 * pos[0, 0] + 0.3 * pos[0, 1] + 0.5 * pos[0, 2]
+    np.testing.assert_allclose(uv[0, 0], [340 * p[0] / p[2] + 160, 325 * p[1] / p[2] + 125])
