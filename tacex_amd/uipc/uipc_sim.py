@@ -1,0 +1,203 @@
+"""`UipcSim` - batched gelpad FEM stepping, counterpart of source/tacex_uipc/tacex_uipc/sim/uipc_sim.py:32-131,134-312.
+
+The reference wraps libuipc (one scene, num_envs = 1 in practice, docs/source/showcases/ball_rolling.md:23) and
+calls `world.advance(); world.retrieve()` (uipc_sim.py:250-252).  Here the Newton loop of that advance - element
+gradient/Hessian work, PCG and line search - runs in HIP for `num_envs` independent copies of the gelpad.
+Contact (IPC barrier / CCD), affine bodies and the ground of libuipc are out of scope.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import torch
+
+from .. import _lib
+from ..utils.configclass import configclass
+
+
+@configclass
+class UipcSimCfg:
+    """Field names follow uipc_sim.py:32-131 (entries that only configure out-of-scope libuipc parts are kept
+    for drop-in construction and ignored)."""
+
+    device: str = "cuda"
+    dt: float = 0.01
+    sanity_check_enable: bool = True
+    sanity_check_mode: str = "quiet"
+    workspace: str = ""
+    logger_level: str = "Error"
+    gravity: tuple = (0.0, 0.0, -9.8)
+    ground_height: float = 0.0
+    ground_normal: tuple = (0.0, 0.0, 1.0)
+
+    @configclass
+    class Newton:
+        max_iter: int = 1024
+        use_adaptive_tol: bool = False
+        velocity_tol: float = 0.05
+        """converged when max |dx| / dt <= velocity_tol [m/s]"""
+        ccd_tol: float = 1.0
+        transrate_tol: float = 0.1
+
+    newton: Newton = Newton()
+
+    @configclass
+    class LinearSystem:
+        solver: str = "linear_pcg"
+        tol_rate: float = 1e-3
+        max_iter: int = 256
+
+    linear_system: LinearSystem = LinearSystem()
+
+    @configclass
+    class LineSearch:
+        max_iter: int = 8
+        report_energy: bool = False
+
+    line_search: LineSearch = LineSearch()
+
+    @configclass
+    class Contact:
+        enable: bool = False  # no IPC contact in this build
+
+    contact: Contact = Contact()
+    collision_detection_method: str = "linear_bvh"
+    diff_sim: bool = False
+
+
+class UipcSim:
+    cfg: UipcSimCfg
+
+    def __init__(self, cfg: UipcSimCfg, num_envs: int = 1):
+        self.cfg = cfg
+        self.num_envs = int(num_envs)
+        self.uipc_objects = []
+        self._handle = None
+        self._lib = None
+        self.device = torch.device(cfg.device)
+        if self.device.type != "cuda":
+            raise _lib.TacexHipError("UipcSim needs an AMD GPU device (no CPU fallback)")
+        self._dev_index = self.device.index if self.device.index is not None else 0
+        self.last_newton_iters = 0
+
+    # -- uipc_sim.py:228-248 -------------------------------------------------------------------------------
+    def setup_sim(self, constraint_strength_ratio: float | None = None):
+        if len(self.uipc_objects) != 1:
+            raise RuntimeError("this build steps exactly one deformable object (the gelpad) per environment")
+        obj = self.uipc_objects[0]
+        _lib.require_gpu(self._dev_index)
+        lib = _lib.load_library()
+        p = _lib.FemParams()
+        p.num_verts, p.num_tets = obj.num_verts, obj.num_tets
+        p.rest_positions = obj.points.ctypes.data_as(C.POINTER(C.c_double))
+        p.tets = obj.tets.ctypes.data_as(_lib.c_int32_p)
+        p.youngs = obj.cfg.constitution_cfg.youngs_modulus * 1e6  # MPa -> Pa (uipc_object.py:452)
+        p.poisson = obj.cfg.constitution_cfg.poisson_rate
+        p.density = obj.cfg.mass_density
+        p.dt = self.cfg.dt
+        for k in range(3):
+            p.gravity[k] = self.cfg.gravity[k]
+        if constraint_strength_ratio is None:
+            ac = obj.cfg.attachment_cfg
+            constraint_strength_ratio = ac.constraint_strength_ratio if ac is not None else 100.0
+        p.constraint_strength_ratio = constraint_strength_ratio
+        h = C.c_void_p()
+        _lib.check(lib.tacex_fem_create(self._dev_index, C.byref(p), C.byref(h)), "tacex_fem_create")
+        self._handle, self._lib, self._obj = h, lib, obj
+        B, V = self.num_envs, obj.num_verts
+        dev = self.device
+        self.x = torch.from_numpy(obj.points).to(dev)[None].repeat(B, 1, 1).contiguous()  # (B,V,3) float64
+        self.v = torch.zeros_like(self.x)
+        self.x_tilde = torch.empty_like(self.x)
+        self.is_constrained = torch.zeros((B, V), dtype=torch.uint8, device=dev)
+        self.aim_position = self.x.clone()
+        self.stats = torch.zeros((B, 4), dtype=torch.float64, device=dev)
+        self._ws = torch.empty(lib.tacex_fem_workspace_bytes(h, B), dtype=torch.uint8, device=dev)
+        self._g = torch.tensor(self.cfg.gravity, dtype=torch.float64, device=dev)
+
+    def __del__(self):
+        try:
+            if self._handle:
+                self._lib.tacex_fem_destroy(self._handle)
+                self._handle = None
+        except Exception:
+            pass
+
+    def _stream(self):
+        return _lib.current_stream_handle(self.device)
+
+    # -- animation targets (uipc_attachments.py:364-385) ----------------------------------------------------------
+    def set_constraints(self, vertex_idx, aim_positions: torch.Tensor):
+        """is_constrained[idx] = 1; aim_position[idx] = aim  (aim (B,A,3))."""
+        idx = torch.as_tensor(vertex_idx, device=self.device, dtype=torch.long)
+        self.is_constrained[:, idx] = 1
+        self.aim_position[:, idx] = aim_positions.to(self.device, torch.float64)
+
+    # -- low-level entry points (thin wrappers of the C ABI) -----------------------------------------------------------
+    def element_terms(self, x=None, energy=True, gradient=True, hessian=True, project_psd=False):
+        x = self.x if x is None else x
+        B, T = x.shape[0], self._obj.num_tets
+        e = torch.empty((B, T), dtype=torch.float64, device=self.device) if energy else None
+        g = torch.empty((B, 12, T), dtype=torch.float64, device=self.device) if gradient else None
+        h = torch.empty((B, 144, T), dtype=torch.float64, device=self.device) if hessian else None
+        with torch.cuda.device(self.device):
+            rc = self._lib.tacex_fem_element_terms(self._handle, _lib.ptr(x), _lib.ptr(e), _lib.ptr(g), _lib.ptr(h),
+                                                   1 if project_psd else 0, B, self._stream())
+        _lib.check(rc, "tacex_fem_element_terms")
+        return e, g, h
+
+    def energy(self, x=None, x_tilde=None, constrained=True):
+        x = self.x if x is None else x
+        xt = self.x_tilde if x_tilde is None else x_tilde
+        E = torch.empty((x.shape[0],), dtype=torch.float64, device=self.device)
+        with torch.cuda.device(self.device):
+            rc = self._lib.tacex_fem_energy(self._handle, _lib.ptr(x), _lib.ptr(xt),
+                                            _lib.ptr(self.is_constrained) if constrained else 0,
+                                            _lib.ptr(self.aim_position) if constrained else 0, _lib.ptr(E),
+                                            _lib.ptr(self._ws), x.shape[0], self._stream())
+        _lib.check(rc, "tacex_fem_energy")
+        return E
+
+    def gradient(self, x=None, x_tilde=None, constrained=True):
+        x = self.x if x is None else x
+        xt = self.x_tilde if x_tilde is None else x_tilde
+        g = torch.empty_like(x)
+        with torch.cuda.device(self.device):
+            rc = self._lib.tacex_fem_gradient(self._handle, _lib.ptr(x), _lib.ptr(xt),
+                                              _lib.ptr(self.is_constrained) if constrained else 0,
+                                              _lib.ptr(self.aim_position) if constrained else 0, _lib.ptr(g),
+                                              _lib.ptr(self._ws), x.shape[0], self._stream())
+        _lib.check(rc, "tacex_fem_gradient")
+        return g
+
+    def newton_step(self, constrained=True):
+        with torch.cuda.device(self.device):
+            rc = self._lib.tacex_fem_newton_step(
+                self._handle, _lib.ptr(self.x), _lib.ptr(self.x_tilde),
+                _lib.ptr(self.is_constrained) if constrained else 0, _lib.ptr(self.aim_position) if constrained else 0,
+                _lib.ptr(self.stats), _lib.ptr(self._ws), self.num_envs, int(self.cfg.linear_system.max_iter),
+                float(self.cfg.linear_system.tol_rate), int(self.cfg.line_search.max_iter), self._stream())
+        _lib.check(rc, "tacex_fem_newton_step")
+        return self.stats
+
+    # -- uipc_sim.py:250-252: world.advance(); world.retrieve() ---------------------------------------------------------
+    def step(self, max_newton_iter: int | None = None, check_every: int = 4):
+        """One backward-Euler step for all envs: x_tilde = x + dt v + dt^2 g, Newton iterations, v = (x - x_n)/dt.
+        Convergence (velocity_tol, uipc_sim.py:62-66) is checked on the host only every `check_every` iterations."""
+        dt = self.cfg.dt
+        x_n = self.x.clone()
+        self.x_tilde = x_n + dt * self.v + (dt * dt) * self._g
+        n_max = self.cfg.newton.max_iter if max_newton_iter is None else max_newton_iter
+        it = 0
+        while it < n_max:
+            x_prev = self.x.clone()
+            self.newton_step()
+            it += 1
+            if it % check_every == 0 or it == n_max:
+                dx = (self.x - x_prev).abs().amax().item()
+                if dx / dt <= self.cfg.newton.velocity_tol:
+                    break
+        self.last_newton_iters = it
+        self.v = (self.x - x_n) / dt
+        return self.x

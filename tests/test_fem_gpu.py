@@ -1,0 +1,146 @@
+"""GPU tests of the gelpad FEM kernels against the CPU oracle (oracle/fem_oracle.py; parity with libuipc UNPINNED)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _sim(points, tets, B, strength=100.0, dt=0.01):
+    from tacex_amd.uipc import UipcObject, UipcObjectCfg, UipcSim, UipcSimCfg
+
+    sim = UipcSim(UipcSimCfg(device="cuda:0", dt=dt), num_envs=B)
+    UipcObject(UipcObjectCfg(mesh_points=points, mesh_tets=tets), sim)
+    sim.setup_sim(constraint_strength_ratio=strength)
+    return sim
+
+
+@pytest.fixture(scope="module")
+def meshes(golden_dir):
+    return np.load(golden_dir / "fem_meshes.npz")
+
+
+@pytest.mark.parametrize("name", ["cube", "simple_axle", "link"])
+def test_element_terms_vs_oracle(meshes, name):
+    from oracle.fem_oracle import FemModel
+
+    P, Tt = meshes[f"{name}_points"], meshes[f"{name}_tets"]
+    m = FemModel.build(P, Tt, youngs=1e4)
+    B = 3
+    rng = np.random.default_rng(0)
+    x = np.stack([m.X, m.X + 0.03 * np.ptp(m.X) * rng.normal(size=m.X.shape),
+                  m.X * np.array([0.6, 1.2, 0.8]) + 0.02 * np.ptp(m.X) * rng.normal(size=m.X.shape)])
+    sim = _sim(P, Tt, B)
+    xd = torch.from_numpy(x).cuda()
+    e, g, h = sim.element_terms(xd)
+    eo, go, ho = m.element_energy(x), m.element_gradient(x), m.element_hessian(x)
+    sc_e, sc_g, sc_h = np.abs(eo).max() + 1e-300, np.abs(go).max(), np.abs(ho).max()
+    assert np.abs(e.cpu().numpy() - eo).max() <= 1e-11 * sc_e + 1e-22
+    assert np.abs(g.cpu().numpy().transpose(0, 2, 1) - go).max() <= 1e-11 * sc_g
+    hh = h.cpu().numpy().reshape(B, 12, 12, -1).transpose(0, 3, 1, 2)
+    assert np.abs(hh - ho).max() <= 1e-11 * sc_h
+    # rest state (env 0): zero force
+    assert np.abs(g[0].cpu().numpy()).max() <= 1e-9 * sc_g
+    # PSD projection: eigenvalues >= 0, PSD elements unchanged
+    _, _, hp = sim.element_terms(xd, energy=False, gradient=False, project_psd=True)
+    hp = hp.cpu().numpy().reshape(B, 12, 12, -1).transpose(0, 3, 1, 2)
+    hpo = m.element_hessian(x, project_psd=True)
+    assert np.abs(hp - hpo).max() <= 1e-8 * sc_h
+    assert np.linalg.eigvalsh(0.5 * (hp + hp.transpose(0, 1, 3, 2))).min() >= -1e-9 * sc_h
+
+
+def test_energy_gradient_vs_oracle(meshes):
+    from oracle.fem_oracle import FemModel
+
+    P, Tt = meshes["simple_axle_points"], meshes["simple_axle_tets"]
+    m = FemModel.build(P, Tt, youngs=1e4, strength=250.0)
+    rng = np.random.default_rng(1)
+    B, L = 4, np.ptp(P)
+    x = m.X[None] + 0.02 * L * rng.normal(size=(B,) + m.X.shape)
+    xt = m.X[None] + 0.005 * L * rng.normal(size=(B,) + m.X.shape)
+    cons = (rng.random((B, len(P))) < 0.2)
+    aim = m.X[None] + 0.01 * L * rng.normal(size=(B,) + m.X.shape)
+    sim = _sim(P, Tt, B, strength=250.0)
+    sim.x = torch.from_numpy(x).cuda()
+    sim.x_tilde = torch.from_numpy(xt).cuda()
+    sim.is_constrained = torch.from_numpy(cons.astype(np.uint8)).cuda()
+    sim.aim_position = torch.from_numpy(aim).cuda()
+    for b_cons in (True, False):
+        E = sim.energy(constrained=b_cons).cpu().numpy()
+        g = sim.gradient(constrained=b_cons).cpu().numpy()
+        for b in range(B):
+            c = cons[b].astype(np.float64) if b_cons else None
+            a = aim[b] if b_cons else None
+            Eo = m.energy(x[b], xt[b], c, a)
+            go = m.gradient(x[b], xt[b], c, a)
+            assert abs(E[b] - Eo) <= 1e-11 * abs(Eo)
+            assert np.abs(g[b] - go).max() <= 1e-10 * np.abs(go).max()
+
+
+def test_newton_step_vs_oracle_and_monotone():
+    from oracle.fem_oracle import FemModel, box_tet_mesh
+
+    P, Tt = box_tet_mesh(4, 5, 2)
+    m = FemModel.build(P, Tt, youngs=1e4, strength=100.0)
+    B = 3
+    top = np.where(P[:, 2] > P[:, 2].max() - 1e-9)[0]
+    sim = _sim(P, Tt, B)
+    sim.cfg.linear_system.max_iter = 200
+    sim.cfg.linear_system.tol_rate = 1e-4
+    depths = [0.0004, 0.0008, 0.0012]
+    aim = torch.from_numpy(P[top]).cuda()[None].repeat(B, 1, 1)
+    for b, d in enumerate(depths):
+        aim[b, :, 2] -= d
+    sim.set_constraints(top, aim)
+    sim.x_tilde = sim.x + sim.cfg.dt**2 * torch.tensor([0, 0, -9.8], dtype=torch.float64, device="cuda")
+    xo = [P.copy() for _ in range(B)]
+    xt = P + m.dt**2 * np.array([0, 0, -9.8])
+    cons = np.zeros(len(P)); cons[top] = 1.0
+    E_prev = None
+    for it in range(6):
+        st = sim.newton_step().cpu().numpy().copy()
+        assert (st[:, 1] <= st[:, 0] + 1e-18).all(), "line search must not increase the energy"
+        if E_prev is not None:
+            np.testing.assert_allclose(st[:, 0], E_prev, rtol=1e-10)
+        E_prev = st[:, 1]
+        for b in range(B):
+            aim_b = P.copy(); aim_b[top, 2] -= depths[b]
+            xo[b], so = m.newton_step(xo[b], xt, cons, aim_b, pcg_max_iter=200, pcg_tol_rate=1e-4)
+            assert abs(st[b, 0] - so[0]) <= 1e-8 * abs(so[0]) + 1e-20, (it, b)
+            assert abs(st[b, 1] - so[1]) <= 1e-6 * abs(so[1]) + 1e-20, (it, b)
+            if so[0] - so[1] > 1e-7 * abs(so[0]):  # at convergence accept/reject is decided by roundoff
+                assert st[b, 2] == so[2]
+    x = sim.x.cpu().numpy()
+    for b in range(B):
+        assert np.abs(x[b] - xo[b]).max() <= 1e-6 * np.ptp(P)
+
+
+def test_step_api_and_marker_uv(meshes):
+    from oracle.fem_oracle import marker_uv
+    from tacex_amd import _lib
+    from tacex_amd.uipc import UipcObject, UipcObjectCfg
+    from tacex_amd.uipc.uipc_object import gelpad_box_mesh
+
+    P, Tt = gelpad_box_mesh(4, 5, 2)
+    sim = _sim(P, Tt, 2)
+    sim.cfg.newton.velocity_tol = 1e-3
+    bottom = np.where(P[:, 2] < 1e-12)[0]
+    sim.set_constraints(bottom, torch.from_numpy(P[bottom]).cuda()[None].repeat(2, 1, 1))
+    x = sim.step(max_newton_iter=30)
+    assert torch.isfinite(x).all()
+    assert sim.last_newton_iters <= 30
+    # gravity pulls the free top down a little, the glued bottom stays
+    free_fall = 0.5 * 9.8 * sim.cfg.dt**2 * 2  # dt^2 g
+    assert x[:, bottom, 2].abs().max() < 0.2 * free_fall  # soft constraint holds the glued face back
+    assert x[:, :, 2].max() <= P[:, 2].max() + 1e-9
+    obj = sim.uipc_objects[0]
+    tri = obj.surface_triangles()[:50]
+    rng = np.random.default_rng(0)
+    w = rng.dirichlet(np.ones(3), size=len(tri))
+    cam = x.clone(); cam[..., 2] += 0.02
+    uv = torch.empty((2, len(tri), 2), dtype=torch.float64, device="cuda")
+    lib = _lib.load_library()
+    tri_d = torch.from_numpy(tri).cuda(); w_d = torch.from_numpy(w).cuda()
+    _lib.check(lib.tacex_fem_marker_uv(cam.data_ptr(), tri_d.data_ptr(), w_d.data_ptr(), 340.0, 325.0, 160.0, 125.0,
+                                       uv.data_ptr(), 2, cam.shape[1], len(tri), torch.cuda.current_stream().cuda_stream), "uv")
+    np.testing.assert_allclose(uv.cpu().numpy(), marker_uv(cam.cpu().numpy(), tri, w), rtol=1e-12)
