@@ -122,6 +122,14 @@ int tacex_taxim_shade(tacex_taxim_ctx* ctx, const float* z_dev, float* rgb_dev, 
  * resolution differs from the tactile resolution (TS:88-89, FS:121-122). */
 int tacex_resize_bilinear_aa(const float* src_dev, int src_h, int src_w, float* dst_dev, int dst_h,
                              int dst_w, int num_frames, void* stream);
+/* Same filter on channels-last images (B,H,W,C): produces the low-resolution policy observation from the
+ * tactile RGB frame (tasks feed 32x32x3 to the policy, tacex_tasks/.../ball_rolling_tactile_rgb.py:303,318),
+ * which is what the multi-GPU observation all-gather carries. */
+int tacex_resize_bilinear_aa_nhwc(const float* src_dev, int src_h, int src_w, float* dst_dev, int dst_h,
+                                  int dst_w, int channels, int num_frames,
+                                  float* tmp_dev /* num_frames*dst_h*src_w*channels floats: separable two-pass
+                                                    (recommended for down-sampling); NULL = single pass */,
+                                  void* stream);
 
 /* Optional per-stage timing with hipEvents on the launch stream (bench.py's roofline leg).
  * Stages: 0 = frame-min, 1..n_levels = blur levels, n_levels+1 = shade. */

@@ -1,5 +1,5 @@
 import sys, time, torch
-sys.path.insert(0, '.')
+sys.path.insert(0, str(__import__('pathlib').Path(__file__).resolve().parent.parent))
 from tacex_amd.simulation_approaches.gpu_taxim.sim import Taxim
 from tacex_amd.utils.synthetic import synthetic_depth_maps
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 256

@@ -310,7 +310,15 @@ int tacex_taxim_render(tacex_taxim_ctx* c, const float* hm, const float* press, 
 int tacex_resize_bilinear_aa(const float* src, int sh, int sw, float* dst, int dh, int dw, int B, void* stream) {
   if (!src || !dst || sh <= 0 || sw <= 0 || dh <= 0 || dw <= 0) { set_error("tacex_resize_bilinear_aa: bad argument"); return 2; }
   if (B <= 0) return 0;
-  HIP_TRY(run_resize_aa(src, sh, sw, dst, dh, dw, B, (hipStream_t)stream), "resize_aa_kernel");
+  HIP_TRY(run_resize_aa(src, sh, sw, dst, dh, dw, B, 1, nullptr, (hipStream_t)stream), "resize_aa_kernel");
+  return 0;
+}
+
+int tacex_resize_bilinear_aa_nhwc(const float* src, int sh, int sw, float* dst, int dh, int dw, int channels, int B,
+                                  float* tmp, void* stream) {
+  if (!src || !dst || sh <= 0 || sw <= 0 || dh <= 0 || dw <= 0 || channels <= 0) { set_error("tacex_resize_bilinear_aa_nhwc: bad argument"); return 2; }
+  if (B <= 0) return 0;
+  HIP_TRY(run_resize_aa(src, sh, sw, dst, dh, dw, B, channels, tmp, (hipStream_t)stream), "resize_aa_kernel");
   return 0;
 }
 

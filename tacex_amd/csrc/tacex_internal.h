@@ -32,7 +32,8 @@ hipError_t run_blur_level(const LevelDesc& lv, const float* src, const float* hm
                           bool first, hipStream_t st);
 hipError_t run_shade(const ShadeParams& sp, const float* z, float* rgb, uint8_t* idx_out, int B,
                      hipStream_t st);
-hipError_t run_resize_aa(const float* src, int sh, int sw, float* dst, int dh, int dw, int B, hipStream_t st);
+hipError_t run_resize_aa(const float* src, int sh, int sw, float* dst, int dh, int dw, int B, int C, float* tmp,
+                         hipStream_t st);
 
 // thread-local error string (tacex_last_error)
 void set_error(const char* fmt, ...);

@@ -448,13 +448,16 @@ __device__ __forceinline__ void aa_window(int i, float scale, int n_in, int& lo,
 }
 
 __global__ __launch_bounds__(256) void resize_aa_kernel(const float* __restrict__ src, int sh, int sw,
-                                                       float* __restrict__ dst, int dh, int dw, int B) {
-  const size_t n = (size_t)B * dh * dw;
+                                                       float* __restrict__ dst, int dh, int dw, int B, int C) {
+  // channels-last: src (B,sh,sw,C) -> dst (B,dh,dw,C); C == 1 is the plain height-map case
+  const size_t n = (size_t)B * dh * dw * C;
   const float scy = (float)sh / dh, scx = (float)sw / dw;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-    const int x = i % dw;
-    const int y = (i / dw) % dh;
-    const int b = i / ((size_t)dw * dh);
+    const int ch = i % C;
+    const size_t pi = i / C;
+    const int x = pi % dw;
+    const int y = (pi / dw) % dh;
+    const int b = pi / ((size_t)dw * dh);
     int xl, xc, yl, yc;
     float cx, ix, cy, iy;
     aa_window(x, scx, sw, xl, xc, cx, ix);
@@ -463,13 +466,61 @@ __global__ __launch_bounds__(256) void resize_aa_kernel(const float* __restrict_
     for (int jy = 0; jy < yc; ++jy) {
       const float wy = fmaxf(0.0f, 1.0f - fabsf((jy + yl - cy + 0.5f) * iy));
       float wxs = 0.0f, rowacc = 0.0f;
-      const float* row = src + ((size_t)b * sh + (yl + jy)) * sw;
+      const float* row = src + (((size_t)b * sh + (yl + jy)) * sw) * C + ch;
       for (int jx = 0; jx < xc; ++jx) {
         const float wx = fmaxf(0.0f, 1.0f - fabsf((jx + xl - cx + 0.5f) * ix));
-        rowacc = fmaf(wx, row[xl + jx], rowacc);
+        rowacc = fmaf(wx, row[(size_t)(xl + jx) * C], rowacc);
         wxs += wx;
       }
       acc = fmaf(wy, rowacc / wxs, acc);
+      wys += wy;
+    }
+    dst[i] = acc / wys;
+  }
+}
+
+// separable two-pass variant (used when a temp buffer is given): each pass has one thread per output element and
+// a short contiguous tap window, so large down-sampling factors (320x240 -> 32x32 policy observation: 20 x 15
+// taps) stay coalesced instead of one thread walking 300 scattered taps.
+__global__ __launch_bounds__(256) void resize_aa_h_kernel(const float* __restrict__ src, int sh, int sw,
+                                                         float* __restrict__ tmp, int dw, int B, int C) {
+  const size_t n = (size_t)B * sh * dw * C;  // tmp (B,sh,dw,C)
+  const float scx = (float)sw / dw;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const int ch = i % C;
+    const size_t pi = i / C;
+    const int x = pi % dw;
+    const size_t row = pi / dw;  // b*sh + y
+    int xl, xc;
+    float cx, ix;
+    aa_window(x, scx, sw, xl, xc, cx, ix);
+    const float* r = src + (row * sw) * C + ch;
+    float wxs = 0.0f, acc = 0.0f;
+    for (int jx = 0; jx < xc; ++jx) {
+      const float wx = fmaxf(0.0f, 1.0f - fabsf((jx + xl - cx + 0.5f) * ix));
+      acc = fmaf(wx, r[(size_t)(xl + jx) * C], acc);
+      wxs += wx;
+    }
+    tmp[i] = acc / wxs;
+  }
+}
+
+__global__ __launch_bounds__(256) void resize_aa_v_kernel(const float* __restrict__ tmp, int sh, float* __restrict__ dst,
+                                                         int dh, int dw, int B, int C) {
+  const size_t n = (size_t)B * dh * dw * C;
+  const float scy = (float)sh / dh;
+  const size_t rowlen = (size_t)dw * C;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t within = i % rowlen;
+    const int y = (i / rowlen) % dh;
+    const int b = i / (rowlen * dh);
+    int yl, yc;
+    float cy, iy;
+    aa_window(y, scy, sh, yl, yc, cy, iy);
+    float wys = 0.0f, acc = 0.0f;
+    for (int jy = 0; jy < yc; ++jy) {
+      const float wy = fmaxf(0.0f, 1.0f - fabsf((jy + yl - cy + 0.5f) * iy));
+      acc = fmaf(wy, tmp[((size_t)b * sh + yl + jy) * rowlen + within], acc);
       wys += wy;
     }
     dst[i] = acc / wys;
@@ -592,10 +643,21 @@ hipError_t run_shade(const ShadeParams& sp, const float* z, float* rgb, uint8_t*
   return hipGetLastError();
 }
 
-hipError_t run_resize_aa(const float* src, int sh, int sw, float* dst, int dh, int dw, int B, hipStream_t st) {
-  const size_t n = (size_t)B * dh * dw;
+hipError_t run_resize_aa(const float* src, int sh, int sw, float* dst, int dh, int dw, int B, int C, float* tmp,
+                         hipStream_t st) {
+  if (tmp) {
+    // vertical pass first: adjacent lanes read adjacent addresses (fully coalesced) and the data shrinks by sh/dh
+    // before the channel-strided horizontal pass; tmp is (B, dh, sw, C)
+    const size_t n1 = (size_t)B * dh * sw * C, n2 = (size_t)B * dh * dw * C;
+    const int g1 = (int)((n1 + 255) / 256 < 65536 ? (n1 + 255) / 256 : 65536);
+    const int g2 = (int)((n2 + 255) / 256 < 65536 ? (n2 + 255) / 256 : 65536);
+    hipLaunchKernelGGL(resize_aa_v_kernel, dim3(g1), dim3(256), 0, st, src, sh, tmp, dh, sw, B, C);
+    hipLaunchKernelGGL(resize_aa_h_kernel, dim3(g2), dim3(256), 0, st, tmp, dh, sw, dst, dw, B, C);
+    return hipGetLastError();
+  }
+  const size_t n = (size_t)B * dh * dw * C;
   const int grid = (int)((n + 255) / 256 < 65536 ? (n + 255) / 256 : 65536);
-  hipLaunchKernelGGL(resize_aa_kernel, dim3(grid), dim3(256), 0, st, src, sh, sw, dst, dh, dw, B);
+  hipLaunchKernelGGL(resize_aa_kernel, dim3(grid), dim3(256), 0, st, src, sh, sw, dst, dh, dw, B, C);
   return hipGetLastError();
 }
 

@@ -1,0 +1,103 @@
+"""Environment sharding across the GPUs of one node + the single observation all-gather.
+
+The reference has no collectives: multi-GPU there is IsaacLab's `--distributed` flag that pins
+one process per GPU (scripts/reinforcement_learning/skrl/train.py:116-117).  Environments are independent units
+(every op of the tactile path is per-env), so the path shards by contiguous env ranges with NO data-path
+collective; the only exchange is collecting the policy observation of all shards - exactly one all-gather per
+step (RCCL over xGMI on the GPU box, `backend="nccl"`; gloo in the CPU tests).
+
+xGMI is a full mesh of point-to-point links, so an all-gather is one hop and per-link bound
+(t ~ shard_bytes / 153 GB/s): the payload is the low-resolution policy observation (+ markers, indentation),
+not the full-resolution fp32 frame (472 MB per 512-env shard would cost ~3 ms, as much as rendering it).
+"""
+from __future__ import annotations
+
+import os
+from dataclasses import dataclass
+
+import torch
+import torch.distributed as dist
+
+
+def shard_range(num_envs_total: int, rank: int, world_size: int) -> tuple[int, int]:
+    """Contiguous env range [lo, hi) of `rank`; the first `num_envs_total % world_size` ranks get one extra env."""
+    if world_size <= 0 or not (0 <= rank < world_size):
+        raise ValueError(f"bad rank/world_size {rank}/{world_size}")
+    q, r = divmod(num_envs_total, world_size)
+    lo = rank * q + min(rank, r)
+    return lo, lo + q + (1 if rank < r else 0)
+
+
+@dataclass
+class ShardInfo:
+    rank: int
+    world_size: int
+    local_rank: int
+    lo: int
+    hi: int
+
+    @property
+    def num_local(self) -> int:
+        return self.hi - self.lo
+
+
+def init_from_env(num_envs_total: int, backend: str | None = None) -> ShardInfo:
+    """Reads RANK / WORLD_SIZE / LOCAL_RANK / MASTER_* (torch.distributed.run contract); single process if unset."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", str(rank)))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(local)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    lo, hi = shard_range(num_envs_total, rank, world)
+    return ShardInfo(rank, world, local, lo, hi)
+
+
+class ObservationGather:
+    """Packs the per-shard observation pieces into ONE contiguous buffer and all-gathers it in ONE collective.
+
+    pieces: dict name -> per-env shape (without the env dim). All shards must hold the same number of envs
+    (all_gather_into_tensor needs equal sizes; use num_envs_total % world_size == 0).
+    """
+
+    def __init__(self, pieces: dict[str, tuple[int, ...]], num_local: int, world_size: int, device, dtype=torch.float32):
+        self.pieces = {k: tuple(v) for k, v in pieces.items()}
+        self.sizes = {k: int(torch.Size(v).numel()) for k, v in self.pieces.items()}
+        self.row = sum(self.sizes.values())
+        self.num_local, self.world = num_local, world_size
+        self.local = torch.zeros((num_local, self.row), device=device, dtype=dtype)
+        self.full = torch.zeros((world_size * num_local, self.row), device=device, dtype=dtype)
+        self._off = {}
+        o = 0
+        for k, n in self.sizes.items():
+            self._off[k] = o
+            o += n
+
+    def slot(self, name: str) -> torch.Tensor:
+        """(num_local, *shape) strided view into the packed send buffer (fill it in place; views cannot be
+        contiguous, so kernels write through `pack` instead when they need a dense destination)."""
+        o, n = self._off[name], self.sizes[name]
+        return self.local[:, o:o + n]
+
+    def pack(self, name: str, value: torch.Tensor):
+        self.slot(name).copy_(value.reshape(self.num_local, -1))
+
+    def payload_bytes(self) -> int:
+        return self.local.numel() * self.local.element_size()
+
+    def gather(self) -> dict[str, torch.Tensor]:
+        if self.world > 1:
+            dist.all_gather_into_tensor(self.full, self.local)  # the single collective of the step
+        else:
+            self.full.copy_(self.local)
+        out = {}
+        for k, shape in self.pieces.items():
+            o, n = self._off[k], self.sizes[k]
+            out[k] = self.full[:, o:o + n].reshape((self.full.shape[0],) + shape)
+        return out

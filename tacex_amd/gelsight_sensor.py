@@ -160,12 +160,22 @@ class GelSightSensor(SensorBase):
             if self.cfg.optical_sim_cfg is None:
                 raise RuntimeError("data type 'tactile_rgb' needs an optical_sim_cfg")
             W, H = self.cfg.optical_sim_cfg.tactile_img_res
-            self._data.output["tactile_rgb"] = torch.zeros((self._num_envs, H, W, 3), device=self._device)
+            buf = getattr(self.optical_simulator, "tactile_rgb_img", None)
+            if buf is not None and tuple(buf.shape) == (self._num_envs, H, W, 3) and buf.is_cuda:
+                # the simulator renders straight into the sensor's persistent output buffer: the reference's
+                # per-step `output["tactile_rgb"][:] = ...` (GS:375) is a 236 MB device copy at 256 envs
+                self._data.output["tactile_rgb"] = buf
+            else:
+                self._data.output["tactile_rgb"] = torch.zeros((self._num_envs, H, W, 3), device=self._device)
         if "marker_motion" in self.cfg.data_types:
             if self.cfg.marker_motion_sim_cfg is None:
                 raise RuntimeError("data type 'marker_motion' needs a marker_motion_sim_cfg")
             nm = self.cfg.marker_motion_sim_cfg.marker_params.num_markers
-            self._data.output["marker_motion"] = torch.zeros((self._num_envs, 2, nm, 2), device=self._device)
+            buf = getattr(self.marker_motion_simulator, "marker_data", None)
+            if buf is not None and tuple(buf.shape) == (self._num_envs, 2, nm, 2):
+                self._data.output["marker_motion"] = buf
+            else:
+                self._data.output["marker_motion"] = torch.zeros((self._num_envs, 2, nm, 2), device=self._device)
 
         # how the indentation depth is computed (gelsight_sensor.py:321-329)
         if self.cfg.compute_indentation_depth_class == "optical_sim" and self.optical_simulator is not None:
@@ -187,7 +197,9 @@ class GelSightSensor(SensorBase):
 
         if self.compute_indentation_depth_func is not None:
             self._get_height_map()
-            self._indentation_depth[:] = self.compute_indentation_depth_func()
+            res = self.compute_indentation_depth_func()
+            if res.data_ptr() != self._indentation_depth.data_ptr():
+                self._indentation_depth[:] = res
 
         if "camera_depth" in self._data.output:
             self._get_camera_depth()

@@ -1,0 +1,48 @@
+"""CPU: the N > 1 path - env sharding + the single observation all-gather - with world_size 2 over gloo."""
+import os
+import subprocess
+import sys
+import textwrap
+
+from conftest import REPO
+
+WORKER = textwrap.dedent(
+    """
+    import os, sys, torch
+    sys.path.insert(0, sys.argv[1])
+    import torch.distributed as dist
+    from tacex_amd.env_shard import ObservationGather, init_from_env
+    shard = init_from_env(num_envs_total=6, backend="gloo")
+    assert shard.world_size == 2 and shard.num_local == 3 and (shard.lo, shard.hi) == (3 * shard.rank, 3 * shard.rank + 3)
+    g = ObservationGather({"rgb32": (2, 2, 3), "indent": (1,)}, shard.num_local, shard.world_size, "cpu")
+    env_ids = torch.arange(shard.lo, shard.hi, dtype=torch.float32)
+    g.pack("rgb32", env_ids.view(-1, 1, 1, 1).expand(-1, 2, 2, 3))
+    g.pack("indent", env_ids * 10)
+    out = g.gather()   # exactly one collective
+    assert out["indent"].reshape(-1).tolist() == [0., 10., 20., 30., 40., 50.], out["indent"]
+    assert out["rgb32"][:, 0, 0, 0].tolist() == [0., 1., 2., 3., 4., 5.]
+    # max-over-ranks timing reduction used by bench.py
+    t = torch.tensor([1.0 + shard.rank], dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    assert float(t) == 2.0
+    dist.barrier()
+    dist.destroy_process_group()
+    print("rank", shard.rank, "ok")
+    """
+)
+
+
+def test_two_rank_gather_over_gloo(tmp_path):
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER)
+    port = 29500 + (os.getpid() % 2000)
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, str(script), str(REPO)], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.STDOUT, text=True))
+    outs = [p.communicate(timeout=120)[0] for p in procs]
+    for rank, (p, o) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, f"rank {rank} failed:\n{o}"
+        assert f"rank {rank} ok" in o

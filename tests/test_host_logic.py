@@ -1,0 +1,157 @@
+"""CPU: host-side logic of the boundary - cfg classes, SensorBase bookkeeping, calibration tables, sharding maths."""
+import numpy as np
+import pytest
+import torch
+
+from tacex_amd.calibration import (build_taxim_tables, gaussian_kernel_size, gaussian_taps, load_params,
+                                   resize_bilinear_aa_host, torch_linspace_f32)
+from tacex_amd.env_shard import ObservationGather, shard_range
+from tacex_amd.sensor_base import SensorBase, SensorBaseCfg
+from tacex_amd.utils.configclass import MISSING, configclass
+
+
+def test_rel_parameter_scaling(calib_dir):
+    """`_rel` parameters scale element 0 by the width and element 1 by the height (TI:33-47)."""
+    sim, sensor = load_params(calib_dir)
+    pw, ph = sim.deform_pyramid_sigma((240, 320))
+    assert np.allclose(pw, (15.25, 7.75, 4.0, 1.75, 1.0, 0.55)) and np.allclose(ph, (15.25, 7.75, 4.0, 1.75, 1.0, 0.55))
+    fw, fh = sim.deform_final_sigma((32, 32))
+    assert np.isclose(fw, 0.003125 * 32) and np.isclose(fh, 0.004166666666666667 * 32)
+    assert (sensor.width, sensor.height, sensor.num_bins) == (640, 480, 125)
+    with pytest.raises(AttributeError):
+        sim.not_a_parameter
+    with pytest.raises(ValueError, match="Unknown key"):
+        load_params(calib_dir, {"simulator": {"nope": 1}})
+    sim2, _ = load_params(calib_dir, {"simulator": {"contact_scale": 0.5}})
+    assert sim2.contact_scale == 0.5 and sim2.fan_angle == sim.fan_angle
+
+
+def test_tables_vs_reference_golden(calib_dir, golden_dir):
+    tb = np.load(golden_dir / "taxim_tables.npz")
+    for (H, W) in [(240, 320), (480, 640), (32, 32), (24, 32), (48, 64)]:
+        t = build_taxim_tables(calib_dir, (H, W))
+        assert t.ksize_w == tb[f"ksize_{H}x{W}"][:, 0].tolist() and t.ksize_h == tb[f"ksize_{H}x{W}"][:, 1].tolist()
+        for li in range(7):
+            np.testing.assert_allclose(t.taps_w[li], tb[f"taps_w_{H}x{W}_{li}"], rtol=0, atol=3e-8)
+            np.testing.assert_allclose(t.taps_h[li], tb[f"taps_h_{H}x{W}_{li}"], rtol=0, atol=3e-8)
+        g = np.load(golden_dir / f"taxim_{H}x{W}.npz")
+        assert np.abs(t.gel_map - g["gel"]).max() <= 1e-6
+        if "bg" in g:
+            assert np.abs(t.background - g["bg"]).max() <= 2e-6
+        assert t.poly.shape == (3, 125, 125, 6)
+    # features follow torch.linspace(0, calib, n+1)[:-1] in float32 (TT:139-157)
+    for n, end in [(240, 480), (320, 640), (32, 640), (24, 480), (48, 480)]:   # every shipped resolution: exact
+        np.testing.assert_array_equal(torch_linspace_f32(0, end, n + 1), torch.linspace(0, end, n + 1).numpy())
+    for n, end in [(77, 640), (33, 480)]:  # inexact step: torch's vectorised kernel differs by <= 1 ulp per SIMD width
+        np.testing.assert_allclose(torch_linspace_f32(0, end, n + 1), torch.linspace(0, end, n + 1).numpy(), rtol=2.4e-7)
+    assert gaussian_kernel_size(15.25) == 61 and gaussian_kernel_size(0.55) == 3
+    assert abs(gaussian_taps(4.0, 17).sum() - 1) < 1e-6
+
+
+def test_host_resize_matches_torch():
+    rng = np.random.default_rng(0)
+    x = np.cumsum(rng.normal(size=(2, 48, 64)), -1).astype(np.float32) * 0.01
+    for size in [(24, 32), (240, 320), (7, 9)]:
+        a = resize_bilinear_aa_host(x, size)
+        b = torch.nn.functional.interpolate(torch.from_numpy(x)[None], size=list(size), mode="bilinear", antialias=True)[0].numpy()
+        assert np.abs(a - b).max() < 1e-5
+
+
+def test_configclass_semantics():
+    @configclass
+    class Inner:
+        a: int = 1
+        b: list = [1, 2]
+
+    @configclass
+    class Outer:
+        inner: Inner = Inner()
+        req: float = MISSING
+        untyped = 3.5
+
+    o1, o2 = Outer(), Outer()
+    o1.inner.b.append(3)
+    assert o2.inner.b == [1, 2], "mutable defaults must not be shared"
+    assert o1.untyped == 3.5 and o1.req is MISSING
+    with pytest.raises(TypeError, match="Missing values"):
+        o1.validate()
+    o3 = o1.replace(req=2.0)
+    o3.validate()
+    assert o3.to_dict()["inner"] == {"a": 1, "b": [1, 2, 3]}
+    assert o1.copy().inner is not o1.inner
+
+
+class _Probe(SensorBase):
+    def __init__(self, cfg):
+        super().__init__(cfg)
+        self.calls = []
+
+    @property
+    def data(self):
+        self._update_outdated_buffers()
+        return self.calls
+
+    def _update_buffers_impl(self, env_ids):
+        self.calls.append(env_ids)
+
+
+def test_sensor_base_update_reset_contract():
+    s = _Probe(SensorBaseCfg(num_envs=3, update_period=0.02))
+    s.update(0.01)            # t=0.01 < period, but freshly initialised buffers are outdated
+    assert s.calls == []      # lazy: nothing until .data or force_recompute
+    _ = s.data
+    assert len(s.calls) == 1
+    s.update(0.01)            # 0.01 since last update: not outdated
+    _ = s.data
+    assert len(s.calls) == 1
+    s.update(0.01)            # 0.02 since last update (+1e-6): outdated
+    s.update(0.0, force_recompute=True)
+    assert len(s.calls) == 2
+    s.reset([1])
+    assert s._is_outdated.tolist() == [False, True, False] and float(s._timestamp[1]) == 0.0
+    _ = s.data
+    assert isinstance(s.calls[-1], torch.Tensor) and s.calls[-1].tolist() == [1]
+    with pytest.raises(ValueError):
+        _Probe(SensorBaseCfg(num_envs=1, history_length=-1))
+
+
+def test_cfg_defaults_match_reference_presets():
+    from tacex_amd import GelSightSensorCfg
+    from tacex_amd.simulation_approaches.fots import FOTSMarkerSimulatorCfg
+    from tacex_amd.simulation_approaches.fots.fots_marker_sim import FOTS_LAMB, marker_grid
+    from tacex_amd.simulation_approaches.gpu_taxim import TaximSimulatorCfg
+
+    t = TaximSimulatorCfg(gelpad_height=0.0045, gelpad_to_camera_min_distance=0.024)
+    assert t.tactile_img_res == (320, 240) and t.with_shadow is False and t.device == "cuda"
+    f = FOTSMarkerSimulatorCfg()
+    assert f.tactile_img_res == (240, 320)  # the reference default is (W,H)-swapped (FSC:24); presets override
+    assert (f.marker_params.num_markers_col, f.marker_params.num_markers_row, f.marker_params.num_markers) == (11, 9, 99)
+    assert f.mm_to_pixel == 19.58 and FOTS_LAMB == (0.00125, 0.00021, 0.00038)
+    mx, my = marker_grid(320, 240, 11, 9, 15.0, 26.0)
+    assert mx[:11].tolist() == [15, 44, 73, 102, 131, 160, 189, 218, 247, 276, 305]
+    assert my[::11].tolist() == [26, 49, 73, 96, 120, 143, 167, 190, 214]
+    s = GelSightSensorCfg()
+    assert s.data_types == ["tactile_rgb", "marker_motion", "height_map", "camera_depth", "camera_rgb"]
+    assert s.compute_indentation_depth_class == "optical_sim"
+
+
+def test_shard_ranges_cover_all_envs():
+    for total, world in [(4096, 8), (10, 3), (7, 8), (256, 1)]:
+        spans = [shard_range(total, r, world) for r in range(world)]
+        assert spans[0][0] == 0 and spans[-1][1] == total
+        assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
+        sizes = [b - a for a, b in spans]
+        assert max(sizes) - min(sizes) <= 1
+    with pytest.raises(ValueError):
+        shard_range(8, 3, 2)
+
+
+def test_observation_gather_single_process():
+    g = ObservationGather({"rgb32": (4, 4, 3), "indent": (1,), "markers": (2, 5, 2)}, num_local=3, world_size=1, device="cpu")
+    rgb = torch.arange(3 * 48, dtype=torch.float32).reshape(3, 4, 4, 3)
+    g.pack("rgb32", rgb)
+    g.pack("indent", torch.tensor([1.0, 2.0, 3.0]))
+    g.pack("markers", torch.ones(3, 2, 5, 2))
+    out = g.gather()
+    assert torch.equal(out["rgb32"], rgb) and out["indent"].reshape(-1).tolist() == [1.0, 2.0, 3.0]
+    assert g.payload_bytes() == 3 * (48 + 1 + 20) * 4

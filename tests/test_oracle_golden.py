@@ -97,3 +97,20 @@ def test_fots_oracle_vs_reference(golden_dir, calib_dir):
         assert np.abs(md[:, 1] - ref[:, 1]).max() <= 1e-4, s
         disp = np.abs(ref[:, 1] - ref[:, 0]).max()
         assert disp > 0.1  # the fixture really moves markers
+
+
+def test_torch_cpu_port_vs_reference(golden_dir, calib_dir):
+    """The bench's CPU-baseline port reproduces the reference RGB on same-bin pixels (it is the reference's own
+    algorithm incl. the FFT blur, so flat-region noise differs only through FFT library roundoff)."""
+    import torch
+
+    from oracle.taxim_torch_cpu import TaximTorchCpuPort
+
+    g = _load(golden_dir, 240, 320)
+    port = TaximTorchCpuPort(calib_dir, (240, 320))
+    rgb = port.render_direct(torch.from_numpy(g["hm"]), torch.from_numpy(g["indent"])).numpy()
+    assert rgb.shape == g["rgb"].shape
+    strong = g["grad_mag"] > 1e-3
+    d = np.abs(rgb - g["rgb"])
+    assert np.quantile(d[strong], 0.99) <= 1e-4
+    assert (d[strong] <= 1e-4).mean() >= 0.99
