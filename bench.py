@@ -197,6 +197,8 @@ def main():
                 bpf = 8 * N          # read height map, write level 0
             elif name.startswith("blur_"):
                 bpf = 12 * N         # read previous level + height map (masked restore), write level
+            elif name.startswith("tail"):
+                bpf = (20 + (5 if markers else 0)) * N  # read level + height map, write RGB (+ deformed gel + mask for FOTS)
             else:
                 bpf = 16 * N         # shade: read deformed gel, write RGB
             avg = ms / cnt

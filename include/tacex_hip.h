@@ -131,8 +131,12 @@ int tacex_resize_bilinear_aa_nhwc(const float* src_dev, int src_h, int src_w, fl
                                                     (recommended for down-sampling); NULL = single pass */,
                                   void* stream);
 
+/* Ablation / test hook: 1 (default) = trailing small-kernel levels + shading run as ONE fused LDS-tiled kernel where a
+ * tuned instantiation exists (320x240, 640x480); 0 = every level as its own kernel + separate shade kernel. */
+int tacex_taxim_set_fused_tail(tacex_taxim_ctx* ctx, int enabled);
+
 /* Optional per-stage timing with hipEvents on the launch stream (bench.py's roofline leg).
- * Stages: 0 = frame-min, 1..n_levels = blur levels, n_levels+1 = shade. */
+ * Stages: 0 = frame-min, 1..n_levels = blur levels, n_levels+1 = shade, n_levels+2 = fused tail. */
 int tacex_taxim_set_profiling(tacex_taxim_ctx* ctx, int enabled);
 /* Synchronises the recorded events; returns accumulated milliseconds and launch count, then resets. */
 int tacex_taxim_read_profile(tacex_taxim_ctx* ctx, int stage, double* total_ms, int* launches);

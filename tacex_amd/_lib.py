@@ -87,6 +87,7 @@ SIGNATURES = {
     "tacex_taxim_shade": (_i, [_vp, _vp, _vp, _vp, _i, _vp]),
     "tacex_resize_bilinear_aa": (_i, [_vp, _i, _i, _vp, _i, _i, _i, _vp]),
     "tacex_resize_bilinear_aa_nhwc": (_i, [_vp, _i, _i, _vp, _i, _i, _i, _i, _vp, _vp]),
+    "tacex_taxim_set_fused_tail": (_i, [_vp, _i]),
     "tacex_taxim_set_profiling": (_i, [_vp, _i]),
     "tacex_taxim_read_profile": (_i, [_vp, _i, C.POINTER(C.c_double), C.POINTER(C.c_int)]),
     "tacex_taxim_num_stages": (_i, [_vp]),

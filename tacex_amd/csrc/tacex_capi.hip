@@ -41,6 +41,8 @@ struct tacex_taxim_ctx {
   int device = 0;
   int H = 0, W = 0;
   int n_levels = 0;
+  int n_fused = 0;       // trailing levels handled by the fused tail kernel (+ shading)
+  bool use_tail = true;
   float contact_scale = 0.4f;
   LevelDesc levels[TACEX_MAX_LEVELS];
   ShadeParams shade;
@@ -144,7 +146,8 @@ int tacex_taxim_create(int device_id, const tacex_taxim_params* p, tacex_taxim_c
   // bin widths as float32 of the python doubles (TT:243-244)
   c->shade.x_binr = (float)(0.5 * 3.14159265358979323846 / (nb - 1));
   c->shade.y_binr = (float)(2.0 * 3.14159265358979323846 / (nb - 1));
-  const int ns = p->n_levels + 2;
+  c->n_fused = tail_levels(c->levels, c->n_levels, c->H, c->W);
+  const int ns = p->n_levels + 3;
   c->stage_ms.assign(ns, 0.0);
   c->stage_n.assign(ns, 0);
   c->stage_names.resize(ns);
@@ -154,7 +157,8 @@ int tacex_taxim_create(int device_id, const tacex_taxim_params* p, tacex_taxim_c
     snprintf(nm, sizeof(nm), "blur_l%d_k%dx%d", l, p->ksize_w[l], p->ksize_h[l]);
     c->stage_names[1 + l] = nm;
   }
-  c->stage_names[ns - 1] = "shade";
+  c->stage_names[ns - 2] = "shade";
+  c->stage_names[ns - 1] = "tail_fused";
   *out = c;
   return 0;
 }
@@ -247,9 +251,8 @@ int tacex_indentation_depth(const float* hm_mm, float gelpad_h, float gelpad_dmi
   return 0;
 }
 
-static int deform_impl(tacex_taxim_ctx* c, const float* hm, const float* press, float* frame_min,
-                       float** z_final, float* z_out, uint8_t* mask_out, void* ws, int B, unsigned flags,
-                       hipStream_t st) {
+static int pipeline_impl(tacex_taxim_ctx* c, const float* hm, const float* press, float* frame_min, float* rgb,
+                         float* z_out, uint8_t* mask_out, void* ws, int B, unsigned flags, hipStream_t st) {
   const size_t img = align_up((size_t)B * c->H * c->W * sizeof(float), 256);
   const size_t vec = align_up((size_t)B * sizeof(float), 256);
   char* w = static_cast<char*>(ws);
@@ -265,8 +268,10 @@ static int deform_impl(tacex_taxim_ctx* c, const float* hm, const float* press, 
             "frame_min_kernel");
   }
   HIP_TRY(run_press_depth(frame_min, press, sa, sb, pd, B, no_shift ? 1 : 0, st), "press_depth_kernel");
+  const int n_fused = c->use_tail ? c->n_fused : 0;
+  const int n_band = c->n_levels - n_fused;
   const float* src = nullptr;
-  for (int l = 0; l < c->n_levels; ++l) {
+  for (int l = 0; l < n_band; ++l) {
     const bool last = l == c->n_levels - 1;
     float* dst = (last && z_out) ? z_out : zbuf[l & 1];
     StageTimer t(c, st, 1 + l);
@@ -275,7 +280,18 @@ static int deform_impl(tacex_taxim_ctx* c, const float* hm, const float* press, 
             "blur level");
     src = dst;
   }
-  *z_final = const_cast<float*>(src);
+  if (n_fused > 0) {
+    // trailing small-kernel levels (+ restores) and the shading in one LDS-tiled kernel
+    StageTimer t(c, st, c->n_levels + 2);
+    HIP_TRY(run_tail(c->levels, c->n_levels, n_fused, src, hm, c->gel_dev, sa, sb, pd, z_out, mask_out, &c->shade, rgb, B,
+                     c->H, c->W, c->contact_scale, st),
+            "taxim_tail_kernel");
+    return 0;
+  }
+  if (rgb) {
+    StageTimer t(c, st, c->n_levels + 1);
+    HIP_TRY(run_shade(c->shade, src, rgb, nullptr, B, st), "shade_kernel");
+  }
   return 0;
 }
 
@@ -284,8 +300,7 @@ int tacex_taxim_deform(tacex_taxim_ctx* c, const float* hm, const float* press, 
   if (!c || !hm || !frame_min || !z_out || !ws) { set_error("tacex_taxim_deform: null argument"); return 2; }
   if (!press && !(flags & TACEX_FLAG_NO_SHIFT)) { set_error("tacex_taxim_deform: press_dev is null"); return 2; }
   if (B <= 0) return 0;
-  float* zf = nullptr;
-  return deform_impl(c, hm, press, frame_min, &zf, z_out, mask_out, ws, B, flags, (hipStream_t)stream);
+  return pipeline_impl(c, hm, press, frame_min, nullptr, z_out, mask_out, ws, B, flags, (hipStream_t)stream);
 }
 
 int tacex_taxim_shade(tacex_taxim_ctx* c, const float* z, float* rgb, uint8_t* idx_out, int B, void* stream) {
@@ -301,10 +316,14 @@ int tacex_taxim_render(tacex_taxim_ctx* c, const float* hm, const float* press, 
   if (!c || !hm || !frame_min || !rgb || !ws) { set_error("tacex_taxim_render: null argument"); return 2; }
   if (!press && !(flags & TACEX_FLAG_NO_SHIFT)) { set_error("tacex_taxim_render: press_dev is null"); return 2; }
   if (B <= 0) return 0;
-  float* zf = nullptr;
-  int rc = deform_impl(c, hm, press, frame_min, &zf, z_out, mask_out, ws, B, flags, (hipStream_t)stream);
-  if (rc) return rc;
-  return tacex_taxim_shade(c, zf, rgb, nullptr, B, stream);
+  return pipeline_impl(c, hm, press, frame_min, rgb, z_out, mask_out, ws, B, flags, (hipStream_t)stream);
+}
+
+/* test / ablation hook: 0 = run every level as its own kernel + separate shade, 1 = fused tail (default) */
+int tacex_taxim_set_fused_tail(tacex_taxim_ctx* c, int enabled) {
+  if (!c) { set_error("null ctx"); return 2; }
+  c->use_tail = enabled != 0;
+  return 0;
 }
 
 int tacex_resize_bilinear_aa(const float* src, int sh, int sw, float* dst, int dh, int dw, int B, void* stream) {

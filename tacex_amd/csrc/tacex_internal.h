@@ -35,6 +35,12 @@ hipError_t run_shade(const ShadeParams& sp, const float* z, float* rgb, uint8_t*
 hipError_t run_resize_aa(const float* src, int sh, int sw, float* dst, int dh, int dw, int B, int C, float* tmp,
                          hipStream_t st);
 
+// fused tail (taxim_tail.hip): trailing small-kernel levels + shading in one LDS-tiled kernel
+int tail_levels(const LevelDesc* lv, int n_levels, int H, int W);
+hipError_t run_tail(const LevelDesc* lv, int n_levels, int n_fused, const float* zin, const float* hm, const float* gel,
+                    const float* sa, const float* sb, const float* pd, float* z_out, uint8_t* mask_out,
+                    const ShadeParams* sp, float* rgb, int B, int H, int W, float contact_scale, hipStream_t st);
+
 // thread-local error string (tacex_last_error)
 void set_error(const char* fmt, ...);
 int fail_hip(hipError_t e, const char* what);

@@ -20,52 +20,9 @@
 #include <type_traits>
 
 #include "tacex_internal.h"
+#include "taxim_device.h"
 
 namespace tacex {
-
-typedef float v2f __attribute__((ext_vector_type(2)));
-typedef float v4f __attribute__((ext_vector_type(4)));
-
-// ------------------------------------------------------------------------------------------------
-// helpers
-// ------------------------------------------------------------------------------------------------
-// compile-time loop: every index is an integral_constant, so tap indices fold to constants and the
-// "tap x window" bodies become straight-line v_pk_fma_f32 streams (a plain #pragma unroll of the
-// 76 x 16 nest is only partially honoured by the unroller).
-template <int I, int N, typename F>
-__device__ __forceinline__ void static_for(F&& f) {
-  if constexpr (I < N) {
-    f(std::integral_constant<int, I>{});
-    static_for<I + 1, N>(f);
-  }
-}
-
-__device__ __forceinline__ int reflect_idx(int i, int n) {
-  // torch 'reflect' (no edge repeat), single reflection: valid for -(n-1) <= i <= 2(n-1)
-  i = i < 0 ? -i : i;
-  return i >= n ? 2 * (n - 1) - i : i;
-}
-
-__device__ __forceinline__ float wave_min(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o, 64));
-  return v;
-}
-__device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-  return v;
-}
-
-// XCD-aware bijective remap of the linear block id (blocks b, b+8, b+16.. share an XCD / L2):
-// consecutive logical ids land on the same XCD so a frame's bands share halo rows in one L2.
-__device__ __forceinline__ int xcd_remap(int bid, int nblocks) {
-  const int nx = 8;
-  int q = nblocks / nx, r = nblocks % nx;
-  int xcd = bid % nx, idx = bid / nx;
-  int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
-  return base + idx;
-}
 
 // ------------------------------------------------------------------------------------------------
 // K1: per-frame minimum (+ optional depth->mm conversion, indentation depth, uint8 camera depth)
@@ -173,7 +130,7 @@ struct BlurArgs {
 };
 
 template <int K, int TH, int RV, int RH, bool FIRST, int NT>
-__global__ __launch_bounds__(NT) void blur_band_kernel(BlurArgs a) {
+__global__ __launch_bounds__(NT, 3) void blur_band_kernel(BlurArgs a) {
   static_assert(K % 2 == 1, "odd kernel");
   static_assert(TH % RV == 0 && RV % 2 == 0 && TH % 2 == 0, "tile shape");
   constexpr int R = (K - 1) / 2;
@@ -196,11 +153,17 @@ __global__ __launch_bounds__(NT) void blur_band_kernel(BlurArgs a) {
   const int pitch = a.pitch, padx = a.padx;
 
   // ---- V-pass: global -> registers -> LDS (row-pair interleaved) ----
+  // The row chunk is WAVE-UNIFORM (waves [ch*wpc, (ch+1)*wpc) own chunk ch), so the reflected row index and the
+  // row base address are scalar (SALU) work; with a per-lane chunk they cost ~8 VALU instructions per streamed row,
+  // i.e. half as many again as the FMAs themselves.
   const int ncp = W >> 1;
-  const int vitems = ncp * (TH / RV);
-  for (int it = threadIdx.x; it < vitems; it += NT) {
-    const int ch = it / ncp;
-    const int c = (it - ch * ncp) << 1;
+  const int wpc = (ncp + 63) >> 6;                                        // waves per row chunk
+  const int wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int ch = wid / wpc;
+  const int cpair = (wid - ch * wpc) * 64 + (int)(threadIdx.x & 63);
+  if (ch < TH / RV && cpair < ncp) {
+    const int c = cpair << 1;
+    const unsigned coff = (unsigned)c * 4u;
     const int y0 = by0 + ch * RV;
     v2f acc[RV];
 #pragma unroll
@@ -209,11 +172,14 @@ __global__ __launch_bounds__(NT) void blur_band_kernel(BlurArgs a) {
       constexpr int j = decltype(jc)::value;
       int yy = reflect_idx(y0 - R + j, H);
       yy = yy < 0 ? 0 : (yy >= H ? H - 1 : yy);  // rows of a partial last band (never stored)
-      v2f x = *reinterpret_cast<const v2f*>(src + (size_t)yy * W + c);
+      // scalar row base + 32-bit unsigned lane offset -> global_load with an SGPR base, no per-lane 64-bit adds
+      const char* rowb = reinterpret_cast<const char*>(src + (size_t)yy * W);
+      v2f x = *reinterpret_cast<const v2f*>(rowb + coff);
       if (FIRST) {  // J = min(S, gel), S = (hm - shift_a) - shift_b   (TT:441, TT:454)
-        v2f g = *reinterpret_cast<const v2f*>(gel + (size_t)yy * W + c);
-        x.x = fminf((x.x - sa) - sb, g.x);
-        x.y = fminf((x.y - sa) - sb, g.y);
+        const char* gelb = reinterpret_cast<const char*>(gel + (size_t)yy * W);
+        const v2f g = *reinterpret_cast<const v2f*>(gelb + coff);
+        x.x = fmin_raw((x.x - sa) - sb, g.x);
+        x.y = fmin_raw((x.y - sa) - sb, g.y);
       }
       static_for<0, RV>([&](auto rc) {
         constexpr int r = decltype(rc)::value;
@@ -374,21 +340,6 @@ __global__ __launch_bounds__(256) void blur_generic_h_kernel(GenericArgs a) {  /
 // ------------------------------------------------------------------------------------------------
 // K5-K10: normals -> bins -> polynomial gather -> + background -> clip -> NHWC   (one pass)
 // ------------------------------------------------------------------------------------------------
-struct ShadeArgs {
-  const float* z;      // (B,H,W) deformed gel, mm
-  const float* poly;   // (nb, nb, 24) f32: [im][id][c*6+k], padded 18 -> 24 floats (16-byte aligned rows)
-  const float* bg;     // (H,W,3) f32 (NHWC copy of the background)
-  const float* fx;     // (W,)
-  const float* fy;     // (H,)
-  float* rgb;          // (B,H,W,3)
-  uint8_t* idx_out;    // (B,H,W,2) nullable
-  int H, W, B, nb;
-  float pixmm;         // 0.0295
-  float sy, sx;        // H / calib_h, W / calib_w applied as "* H / calib_h" (TT:489-490)
-  float calib_h, calib_w;
-  float x_binr, y_binr;
-};
-
 __global__ __launch_bounds__(256) void shade_kernel(ShadeArgs a) {
   const int H = a.H, W = a.W;
   const int npix = H * W;
@@ -399,39 +350,8 @@ __global__ __launch_bounds__(256) void shade_kernel(ShadeArgs a) {
   const float* __restrict__ z = a.z + (size_t)b * npix;
   // replicate padding of the (H-2, W-2) gradient maps (TT:501-502) == evaluate at the clamped pixel
   const int yc = min(max(y, 1), H - 2), xc = min(max(x, 1), W - 2);
-  // height in pixel units, sign flipped: z_px = -(Z / pixmm)  (TT:238-239)
-  const float top = -(z[(size_t)(yc - 1) * W + xc] / a.pixmm);
-  const float bot = -(z[(size_t)(yc + 1) * W + xc] / a.pixmm);
-  const float lef = -(z[(size_t)yc * W + xc - 1] / a.pixmm);
-  const float rig = -(z[(size_t)yc * W + xc + 1] / a.pixmm);
-  // same op order as TT:486-490: ((bot-top)/2) * H / calib_h   (no fma contraction across these)
-  const float dzdx = __fdiv_rn(__fmul_rn(__fmul_rn(__fsub_rn(bot, top), 0.5f), (float)H), a.calib_h);
-  const float dzdy = __fdiv_rn(__fmul_rn(__fmul_rn(__fsub_rn(rig, lef), 0.5f), (float)W), a.calib_w);
-  const float t = __fsqrt_rn(__fadd_rn(__fmul_rn(dzdx, dzdx), __fmul_rn(dzdy, dzdy)));
-  const float mag = atanf(t);
-  const float dir = t != 0.0f ? atan2f(__fdiv_rn(dzdx, t), __fdiv_rn(dzdy, t)) : 0.0f;  // TT:494-499
-  int im = (int)floorf(__fdiv_rn(mag, a.x_binr));                                         // TT:246
-  int id = (int)floorf(__fdiv_rn(__fadd_rn(dir, 3.14159274101257324f), a.y_binr));        // TT:247
-  im = min(max(im, 0), a.nb - 1);
-  id = min(max(id, 0), a.nb - 1);
-  const v4f* __restrict__ pc = reinterpret_cast<const v4f*>(a.poly + ((size_t)im * a.nb + id) * 24);
-  const v4f c0 = pc[0], c1 = pc[1], c2 = pc[2], c3 = pc[3], c4 = pc[4];
-  const float X = a.fx[x], Y = a.fy[y];
-  const float f0 = X * X, f1 = Y * Y, f2 = X * Y;  // TT:148-157
-  // I_c = sum_k f_k * p_{c,k}
-  const float r = ((((f0 * c0.x + f1 * c0.y) + f2 * c0.z) + X * c0.w) + Y * c1.x) + c1.y;
-  const float g = ((((f0 * c1.z + f1 * c1.w) + f2 * c2.x) + X * c2.y) + Y * c2.z) + c2.w;
-  const float bl = ((((f0 * c3.x + f1 * c3.y) + f2 * c3.z) + X * c3.w) + Y * c4.x) + c4.y;
-  const float* __restrict__ bg = a.bg + (size_t)p * 3;
-  float* __restrict__ o = a.rgb + ((size_t)b * npix + p) * 3;
-  o[0] = fminf(fmaxf(r + bg[0], 0.0f), 1.0f);   // TT:257-258
-  o[1] = fminf(fmaxf(g + bg[1], 0.0f), 1.0f);
-  o[2] = fminf(fmaxf(bl + bg[2], 0.0f), 1.0f);
-  if (a.idx_out) {
-    uint8_t* io = a.idx_out + ((size_t)b * npix + p) * 2;
-    io[0] = (uint8_t)im;
-    io[1] = (uint8_t)id;
-  }
+  shade_pixel(a, z[(size_t)(yc - 1) * W + xc], z[(size_t)(yc + 1) * W + xc], z[(size_t)yc * W + xc - 1],
+              z[(size_t)yc * W + xc + 1], x, y, b);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -536,9 +456,8 @@ static inline int lds_pitch_for(int W, int padx) {
   return pitch + m;
 }
 
-template <int K, int TH, int RV, int RH, bool FIRST>
-static hipError_t launch_band(const BlurArgs& a0, hipStream_t st) {
-  constexpr int NT = 320;
+template <int K, int TH, int RV, int RH, bool FIRST, int NT>
+static hipError_t launch_band_nt(const BlurArgs& a0, hipStream_t st) {
   BlurArgs a = a0;
   constexpr int R = (K - 1) / 2;
   a.padx = (R + 1) & ~1;
@@ -557,8 +476,19 @@ static hipError_t launch_band(const BlurArgs& a0, hipStream_t st) {
   return hipGetLastError();
 }
 
+// threads per workgroup: 64 * ceil(W/128) waves per row chunk * (TH/RV = 2) chunks
+template <int K, int TH, int RV, int RH, bool FIRST>
+static hipError_t launch_band(const BlurArgs& a, hipStream_t st) {
+  if (a.W <= 384) return launch_band_nt<K, TH, RV, RH, FIRST, 384>(a, st);
+  if constexpr (K == 33 || K == 61) {  // 640x480 levels that are not covered by the fused tail
+    if (a.W <= 640) return launch_band_nt<K, TH, RV, RH, FIRST, 640>(a, st);
+  }
+  return hipErrorInvalidValue;
+}
+
 static bool band_supported(int k, int H, int W) {
   if (W % 16 != 0 || W < 32 || H < 2) return false;
+  if (W > 384 && !(W <= 640 && (k == 33 || k == 61))) return false;
   if ((k - 1) / 2 >= H || ((k - 1) / 2 + 1) > W - 1) return false;
   switch (k) {
     case 3: case 5: case 9: case 15: case 17: case 33: case 61: return true;  // 117: generic path (TODO chunked variant)
@@ -638,6 +568,8 @@ hipError_t run_shade(const ShadeParams& sp, const float* z, float* rgb, uint8_t*
   a.idx_out = idx_out; a.H = sp.H; a.W = sp.W; a.B = B; a.nb = sp.nb; a.pixmm = sp.pixmm;
   a.calib_h = (float)sp.calib_h; a.calib_w = (float)sp.calib_w;
   a.x_binr = sp.x_binr; a.y_binr = sp.y_binr;
+  a.gsy = (float)(0.5 * sp.H / sp.calib_h / (double)sp.pixmm); a.gsx = (float)(0.5 * sp.W / sp.calib_w / (double)sp.pixmm);
+  a.inv_x_binr = (float)(1.0 / (double)sp.x_binr); a.inv_y_binr = (float)(1.0 / (double)sp.y_binr);
   const int npix = sp.H * sp.W;
   hipLaunchKernelGGL(shade_kernel, dim3((npix + 255) / 256, B), dim3(256), 0, st, a);
   return hipGetLastError();

@@ -1,0 +1,336 @@
+// Fused tail of the Taxim path: the small-kernel pyramid levels (e.g. k = 9, 5, 3 + final 5 at 320x240) with their
+// masked restores AND the shading, in ONE LDS-tiled kernel.
+//
+// Why: as separate band kernels these levels are memory-bound (12 B/px each at ~4.5 TB/s) and the shade kernel
+// re-reads the deformed gel; fused, a 64x32 output tile (+ halo = sum of radii + 2) lives in LDS across all levels,
+// HBM sees one read of the previous level + the height map and one write of RGB (+ deformed gel / mask for FOTS).
+//
+// Reference semantics per level: Z = G(Z); Z[M] = J[M]  (TT:464-467), final Z = G(Z) without restore (TT:468-471),
+// reflect padding at the IMAGE border at every level (TT:411) - reproduced by re-mirroring the out-of-image halo
+// cells of border tiles after each level; then normals/bins/polynomial/background/clip (TT:475-503, 237-258).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "tacex_internal.h"
+#include "taxim_device.h"
+
+namespace tacex {
+
+constexpr int kTailMaxLevels = 5;
+
+struct TailArgs {
+  const float* zin;      // (B,H,W) output of the last band-kernel level
+  const float* hm;       // (B,H,W)
+  const float* gel;      // (H,W)
+  const float* shift_a;  // (B,)
+  const float* shift_b;
+  const float* pdepth;
+  const float* taps[kTailMaxLevels];
+  float* z_out;          // (B,H,W) nullable
+  uint8_t* mask_out;     // (B,H,W) nullable
+  ShadeArgs sh;          // sh.rgb == nullptr -> deformation only
+  int H, W, B;
+  float contact_scale;
+};
+
+template <int... KS>
+struct TailCfg {
+  static constexpr int NL = sizeof...(KS);
+  static constexpr int K[NL] = {KS...};
+  static constexpr int sum_r() { int s = 0; for (int i = 0; i < NL; ++i) s += (K[i] - 1) / 2; return s; }
+  static constexpr int max_r() { int m = 0; for (int i = 0; i < NL; ++i) m = (K[i] - 1) / 2 > m ? (K[i] - 1) / 2 : m; return m; }
+  static constexpr int TW = 64, TH = 32;
+  static constexpr int HLY = sum_r() + 2;            // +1 central difference, +1 clamped (replicate) gradient row
+  static constexpr int HLX = (HLY + 1) & ~1;         // even -> region width stays a multiple of 4
+  static constexpr int RW = TW + 2 * HLX;            // region width  (multiple of 4)
+  static constexpr int RH = (TH + 2 * HLY + 3) & ~3; // region height (multiple of 4)
+  static constexpr int PADX = (max_r() + 3) & ~3;    // guard columns for the 16-byte window reads
+  static constexpr int PADY = max_r();               // guard rows for the vertical window
+  static constexpr int P = RW + 2 * PADX + 4;        // LDS pitch (floats); +4 staggers rows across banks
+  static constexpr int ROWS = RH + 2 * PADY;
+  // valid margin needed after level l = sum of the radii of levels l+1.. plus 2 (gradient + replicate clamp)
+  static constexpr int margin_after(int l) { int s = 2; for (int i = l + 1; i < NL; ++i) s += (K[i] - 1) / 2; return s; }
+  static constexpr size_t lds_bytes() { return (size_t)(2 * ROWS * P + RH * P) * sizeof(float) + (size_t)RH * P; }
+};
+
+template <int... KS>
+__global__ __launch_bounds__(512) void taxim_tail_kernel(TailArgs a) {
+  using C = TailCfg<KS...>;
+  constexpr int NL = C::NL, TW = C::TW, TH = C::TH, HLY = C::HLY, HLX = C::HLX, RW = C::RW, RH = C::RH;
+  constexpr int PADX = C::PADX, PADY = C::PADY, P = C::P, ROWS = C::ROWS;
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  float* bufA = reinterpret_cast<float*>(smem_raw);
+  float* bufB = bufA + ROWS * P;
+  float* bufJ = bufB + ROWS * P;                       // RH x P
+  uint8_t* bufM = reinterpret_cast<uint8_t*>(bufJ + RH * P);  // RH x P
+
+  const int H = a.H, W = a.W;
+  const int ntx = (W + TW - 1) / TW, nty = (H + TH - 1) / TH;
+  const int lid = xcd_remap(blockIdx.x, gridDim.x);
+  const int frame = lid / (ntx * nty);
+  const int tix = lid - frame * ntx * nty;
+  const int ty0 = (tix / ntx) * TH, tx0 = (tix % ntx) * TW;
+  const size_t fo = (size_t)frame * H * W;
+  const float sa = a.shift_a[frame], sb = a.shift_b[frame];
+  const float thr = -a.pdepth[frame] * a.contact_scale;  // TT:459
+  const float* __restrict__ zin = a.zin + fo;
+  const float* __restrict__ hm = a.hm + fo;
+  const int gy0 = ty0 - HLY, gx0 = tx0 - HLX;  // global coords of region cell (0,0)
+  const int tid = threadIdx.x;
+  constexpr int NT = 512;
+
+  // ---- load: previous level at REFLECTED coordinates (= its reflect padding), J and M for in-image cells ----
+  // one 4-cell group per thread and pass; all passes unrolled so every global load of the tile is in flight at once
+  {
+    constexpr int G = RW / 4;          // 16-byte groups per region row
+    constexpr int RPP = NT / G;        // region rows covered per pass
+    constexpr int NPASS = (RH + RPP - 1) / RPP;
+    const int lrow = tid / G, lx = (tid - lrow * G) * 4;
+    const int gx = gx0 + lx;
+    const bool xin = gx >= 0 && gx + 3 < W;  // whole group inside the image (W % 4 == 0, gx0 % 4 == 0)
+    int rx[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) rx[k] = min(max(reflect_idx(gx + k, W), 0), W - 1);
+    v4f zv[NPASS], hv[NPASS], gv[NPASS];
+    bool yin[NPASS];
+#pragma unroll
+    for (int ps = 0; ps < NPASS; ++ps) {
+      const int ly = ps * RPP + lrow;
+      const int gy = gy0 + ly;
+      yin[ps] = false;
+      if (lrow < RPP && ly < RH) {
+        const int ry = min(max(reflect_idx(gy, H), 0), H - 1);
+        const float* zr = zin + (size_t)ry * W;
+        if (xin) {
+          zv[ps] = *reinterpret_cast<const v4f*>(zr + gx);
+        } else {
+          zv[ps] = (v4f){zr[rx[0]], zr[rx[1]], zr[rx[2]], zr[rx[3]]};
+        }
+        yin[ps] = gy >= 0 && gy < H;
+        if (yin[ps]) {
+          if (xin) {
+            hv[ps] = *reinterpret_cast<const v4f*>(hm + (size_t)gy * W + gx);
+            gv[ps] = *reinterpret_cast<const v4f*>(a.gel + (size_t)gy * W + gx);
+          } else {  // partially outside in x: clamp the address, the cell is flagged out-of-image below
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+              const int cx = min(max(gx + k, 0), W - 1);
+              hv[ps][k] = hm[(size_t)gy * W + cx];
+              gv[ps][k] = a.gel[(size_t)gy * W + cx];
+            }
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int ps = 0; ps < NPASS; ++ps) {
+      const int ly = ps * RPP + lrow;
+      if (lrow < RPP && ly < RH) {
+        *reinterpret_cast<v4f*>(bufA + (ly + PADY) * P + PADX + lx) = zv[ps];
+        v4f Jv = (v4f)(0.0f);
+        uchar4 Mv = {0, 0, 0, 0};
+        if (yin[ps]) {
+          uint8_t mk[4];
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const bool inside = gx + k >= 0 && gx + k < W;
+            const float S = (hv[ps][k] - sa) - sb;
+            const float J = fminf(S, gv[ps][k]);
+            Jv[k] = inside ? J : 0.0f;
+            mk[k] = (inside && ((J - gv[ps][k]) < thr) && (S < 0.0f)) ? 1 : 0;  // TT:457-461
+          }
+          Mv = {mk[0], mk[1], mk[2], mk[3]};
+        }
+        *reinterpret_cast<v4f*>(bufJ + ly * P + PADX + lx) = Jv;
+        *reinterpret_cast<uchar4*>(bufM + ly * P + PADX + lx) = Mv;
+      }
+    }
+  }
+  __syncthreads();
+
+  static_for<0, NL>([&](auto lc) {
+    constexpr int l = decltype(lc)::value;
+    constexpr int K = C::K[l];
+    constexpr int R = (K - 1) / 2;
+    constexpr int R4 = (R + 3) & ~3;
+    // margin (beyond the output tile) that must still be valid AFTER this level: radii of the later levels + 2
+    constexpr int MY = C::margin_after(l), MX = MY + (HLX - HLY);
+    // V-pass output rows [VY0, VY1), H-pass rows [HY0, HY1) (= V rows +- R), columns [X0, X1) - 4-aligned supersets
+    constexpr int VY0 = (HLY - MY) & ~3, VY1 = (HLY + TH + MY + 3) & ~3;
+    constexpr int HY0 = (HLY - MY - R) < 0 ? 0 : (HLY - MY - R), HY1 = (HLY + TH + MY + R) > RH ? RH : (HLY + TH + MY + R);
+    constexpr int X0 = (HLX - MX) & ~3, X1 = (HLX + TW + MX + 3) & ~3;
+    constexpr int NXG = (X1 - X0) / 4;
+    const float* __restrict__ taps = a.taps[l];
+    if constexpr (K > 1) {
+      // ---- H-pass: bufA -> bufB, 4 consecutive x per item, window read as 16-byte groups ----
+      for (int it = tid; it < (HY1 - HY0) * NXG; it += NT) {
+        const int ly = HY0 + it / NXG, x0 = X0 + (it % NXG) * 4;
+        const float* row = bufA + (ly + PADY) * P + PADX + x0 - R4;
+        float win[4 + 2 * R4];
+        static_for<0, (4 + 2 * R4) / 4>([&](auto jc) {
+          constexpr int j = decltype(jc)::value;
+          const v4f q = *reinterpret_cast<const v4f*>(row + 4 * j);
+          win[4 * j] = q.x; win[4 * j + 1] = q.y; win[4 * j + 2] = q.z; win[4 * j + 3] = q.w;
+        });
+        v4f o = (v4f)(0.0f);
+        static_for<0, K>([&](auto tc) {
+          constexpr int t = decltype(tc)::value;
+          const float w = taps[t < K - 1 - t ? t : K - 1 - t];
+          o.x += w * win[R4 - R + t];
+          o.y += w * win[R4 - R + t + 1];
+          o.z += w * win[R4 - R + t + 2];
+          o.w += w * win[R4 - R + t + 3];
+        });
+        *reinterpret_cast<v4f*>(bufB + (ly + PADY) * P + PADX + x0) = o;
+      }
+      __syncthreads();
+      // ---- V-pass: bufB -> bufA, 4 columns x 4 rows per item, + masked restore ----
+      for (int it = tid; it < ((VY1 - VY0) / 4) * NXG; it += NT) {
+        const int ly0 = VY0 + (it / NXG) * 4, x0 = X0 + (it % NXG) * 4;
+        v4f acc[4] = {(v4f)(0.0f), (v4f)(0.0f), (v4f)(0.0f), (v4f)(0.0f)};
+        static_for<0, 4 + 2 * R>([&](auto jc) {
+          constexpr int j = decltype(jc)::value;
+          const v4f q = *reinterpret_cast<const v4f*>(bufB + (ly0 - R + j + PADY) * P + PADX + x0);
+          static_for<0, 4>([&](auto rc) {
+            constexpr int r = decltype(rc)::value;
+            constexpr int t = j - r;
+            if constexpr (t >= 0 && t < K) acc[r] += taps[t < K - 1 - t ? t : K - 1 - t] * q;
+          });
+        });
+        static_for<0, 4>([&](auto rc) {
+          constexpr int r = decltype(rc)::value;
+          v4f o = acc[r];
+          if constexpr (l < NL - 1) {  // TT:467 Z[M] = J[M]; the final blur (TT:468-471) has no restore
+            const int ci = (ly0 + r) * P + PADX + x0;
+            const v4f Jv = *reinterpret_cast<const v4f*>(bufJ + ci);
+            const uchar4 Mv = *reinterpret_cast<const uchar4*>(bufM + ci);
+            o.x = Mv.x ? Jv.x : o.x; o.y = Mv.y ? Jv.y : o.y; o.z = Mv.z ? Jv.z : o.z; o.w = Mv.w ? Jv.w : o.w;
+          }
+          *reinterpret_cast<v4f*>(bufA + (ly0 + r + PADY) * P + PADX + x0) = o;
+        });
+      }
+      __syncthreads();
+    } else if constexpr (l < NL - 1) {
+      // K == 1: the blur is the identity (single tap = 1.0) but the restore still runs
+      for (int c = tid; c < RH * RW; c += NT) {
+        const int ly = c / RW, lx = c - ly * RW;
+        if (bufM[ly * P + PADX + lx]) bufA[(ly + PADY) * P + PADX + lx] = bufJ[ly * P + PADX + lx];
+      }
+      __syncthreads();
+    }
+    if constexpr (l < NL - 1) {
+      // ---- re-mirror the out-of-image halo (reflect padding of the NEXT level's input); border tiles only ----
+      const bool border = gy0 < 0 || gx0 < 0 || gy0 + RH > H || gx0 + RW > W;
+      if (border) {
+        for (int c = tid; c < RH * RW; c += NT) {
+          const int ly = c / RW, lx = c - ly * RW;
+          const int gy = gy0 + ly, gx = gx0 + lx;
+          if (gy >= 0 && gy < H && gx >= 0 && gx < W) continue;
+          int sy = reflect_idx(gy, H) - gy0, sx = reflect_idx(gx, W) - gx0;
+          sy = min(max(sy, 0), RH - 1);  // cells beyond the needed halo of a partial tile: any in-bounds source
+          sx = min(max(sx, 0), RW - 1);
+          bufA[(ly + PADY) * P + PADX + lx] = bufA[(sy + PADY) * P + PADX + sx];
+        }
+      }
+      __syncthreads();
+    }
+  });
+
+  // ---- epilogue: 4 consecutive pixels per thread: float4 I/O for deformed gel / mask / background / RGB ----
+  static_assert((TH * TW) % (4 * NT) == 0, "epilogue strips");
+  const bool fast_w = (W % 4) == 0;
+#pragma unroll
+  for (int k = 0; k < (TH * TW) / (4 * NT); ++k) {
+    const int sidx = tid + k * NT;                 // strip index within the tile
+    const int oy = sidx / (TW / 4), ox = (sidx - oy * (TW / 4)) * 4;
+    const int gy = ty0 + oy, gx = tx0 + ox;
+    if (gy >= H || gx >= W) continue;
+    const int ly = oy + HLY, lx = ox + HLX;
+    const size_t p = (size_t)gy * W + gx;
+    const float* crow = bufA + (ly + PADY) * P + PADX + lx;
+    if (fast_w) {  // whole strip inside the image
+      if (a.z_out) *reinterpret_cast<v4f*>(a.z_out + fo + p) = *reinterpret_cast<const v4f*>(crow);
+      if (a.mask_out) *reinterpret_cast<uchar4*>(a.mask_out + fo + p) = *reinterpret_cast<const uchar4*>(bufM + ly * P + PADX + lx);
+    } else {
+      for (int i = 0; i < 4 && gx + i < W; ++i) {
+        if (a.z_out) a.z_out[fo + p + i] = crow[i];
+        if (a.mask_out) a.mask_out[fo + p + i] = bufM[ly * P + PADX + lx + i];
+      }
+    }
+    if (a.sh.rgb) {
+      // replicate padding of the gradient maps == evaluate at the clamped pixel (TT:501-502)
+      const int yc = min(max(gy, 1), H - 2) - gy0;
+      const float* rc = bufA + (yc + PADY) * P + PADX;
+      float rgb[12];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int gxi = min(gx + i, W - 1);
+        const int xc = min(max(gxi, 1), W - 2) - gx0;
+        shade_pixel_rgb(a.sh, rc[xc - P], rc[xc + P], rc[xc - 1], rc[xc + 1], gxi, gy, rgb + 3 * i);
+      }
+      float* o = a.sh.rgb + ((size_t)frame * H * W + p) * 3;
+      if (fast_w) {
+        reinterpret_cast<v4f*>(o)[0] = (v4f){rgb[0], rgb[1], rgb[2], rgb[3]};
+        reinterpret_cast<v4f*>(o)[1] = (v4f){rgb[4], rgb[5], rgb[6], rgb[7]};
+        reinterpret_cast<v4f*>(o)[2] = (v4f){rgb[8], rgb[9], rgb[10], rgb[11]};
+      } else {
+        for (int i = 0; i < 4 && gx + i < W; ++i) { o[3 * i] = rgb[3 * i]; o[3 * i + 1] = rgb[3 * i + 1]; o[3 * i + 2] = rgb[3 * i + 2]; }
+      }
+    }
+  }
+}
+
+template <int... KS>
+static hipError_t launch_tail(const TailArgs& a, hipStream_t st) {
+  using C = TailCfg<KS...>;
+  const int ntx = (a.W + C::TW - 1) / C::TW, nty = (a.H + C::TH - 1) / C::TH;
+  auto kern = taxim_tail_kernel<KS...>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)C::lds_bytes());
+    if (e != hipSuccess) return e;
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(ntx * nty * a.B), dim3(512), C::lds_bytes(), st, a);
+  return hipGetLastError();
+}
+
+// number of trailing levels the fused tail covers for this context (0 = no fused instantiation)
+int tail_levels(const LevelDesc* lv, int n_levels, int H, int W) {
+  if (H < 8 || W < 8 || W % 4 != 0) return 0;
+  auto match = [&](int n, const int* ks) {
+    if (n_levels < n) return false;
+    for (int i = 0; i < n; ++i) {
+      const LevelDesc& d = lv[n_levels - n + i];
+      if (!d.same_taps || d.kw != ks[i]) return false;
+    }
+    return true;
+  };
+  static const int k320[4] = {9, 5, 3, 5};    // 320x240 (gsmini presets, BASELINE configs 1-4)
+  static const int k640[4] = {15, 9, 5, 9};   // 640x480 (BASELINE config 5)
+  if (match(4, k320) || match(4, k640)) return 4;
+  return 0;
+}
+
+hipError_t run_tail(const LevelDesc* lv, int n_levels, int n_fused, const float* zin, const float* hm, const float* gel,
+                    const float* sa, const float* sb, const float* pd, float* z_out, uint8_t* mask_out,
+                    const ShadeParams* sp, float* rgb, int B, int H, int W, float contact_scale, hipStream_t st) {
+  TailArgs a{};
+  a.zin = zin; a.hm = hm; a.gel = gel; a.shift_a = sa; a.shift_b = sb; a.pdepth = pd; a.z_out = z_out; a.mask_out = mask_out;
+  a.H = H; a.W = W; a.B = B; a.contact_scale = contact_scale;
+  for (int i = 0; i < n_fused; ++i) a.taps[i] = lv[n_levels - n_fused + i].taps_w_dev;
+  if (sp && rgb) {
+    a.sh.poly = sp->poly_dev; a.sh.bg = sp->bg_nhwc_dev; a.sh.fx = sp->fx_dev; a.sh.fy = sp->fy_dev; a.sh.rgb = rgb;
+    a.sh.idx_out = nullptr; a.sh.H = H; a.sh.W = W; a.sh.B = B; a.sh.nb = sp->nb; a.sh.pixmm = sp->pixmm;
+    a.sh.calib_h = (float)sp->calib_h; a.sh.calib_w = (float)sp->calib_w; a.sh.x_binr = sp->x_binr; a.sh.y_binr = sp->y_binr;
+    a.sh.gsy = (float)(0.5 * H / sp->calib_h / (double)sp->pixmm); a.sh.gsx = (float)(0.5 * W / sp->calib_w / (double)sp->pixmm);
+    a.sh.inv_x_binr = (float)(1.0 / (double)sp->x_binr); a.sh.inv_y_binr = (float)(1.0 / (double)sp->y_binr);
+  }
+  const int k0 = lv[n_levels - n_fused].kw;
+  if (n_fused == 4 && k0 == 9) return launch_tail<9, 5, 3, 5>(a, st);
+  if (n_fused == 4 && k0 == 15) return launch_tail<15, 9, 5, 9>(a, st);
+  return hipErrorInvalidValue;
+}
+
+}  // namespace tacex

@@ -288,6 +288,11 @@ class TaximHip:
 
     __call__ = render
 
+    def set_fused_tail(self, shape_hw, enabled: bool):
+        """Ablation hook: run every pyramid level as its own kernel (False) or use the fused tail kernel (True, default)."""
+        ctx = self.context(shape_hw)
+        _lib.check(self._lib.tacex_taxim_set_fused_tail(ctx.handle, 1 if enabled else 0), "set_fused_tail")
+
     # -- profiling (bench.py roofline leg) --------------------------------------------------------------------
     def set_profiling(self, shape_hw, enabled: bool):
         ctx = self.context(shape_hw)
