@@ -6,8 +6,8 @@
 // HBM sees one read of the previous level + the height map and one write of RGB (+ deformed gel / mask for FOTS).
 //
 // Reference semantics per level: Z = G(Z); Z[M] = J[M]  (TT:464-467), final Z = G(Z) without restore (TT:468-471),
-// reflect padding at the IMAGE border at every level (TT:411) - reproduced by re-mirroring the out-of-image halo
-// cells of border tiles after each level; then normals/bins/polynomial/background/clip (TT:475-503, 237-258).
+// reflect padding at the IMAGE border at every level (TT:411) - reproduced by loading input, J and M at reflected
+// coordinates (a symmetric blur keeps the halo mirror-symmetric); then normals/bins/polynomial/background/clip.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -79,8 +79,12 @@ __global__ __launch_bounds__(512) void taxim_tail_kernel(TailArgs a) {
   const int tid = threadIdx.x;
   constexpr int NT = 512;
 
-  // ---- load: previous level at REFLECTED coordinates (= its reflect padding), J and M for in-image cells ----
-  // one 4-cell group per thread and pass; all passes unrolled so every global load of the tile is in flight at once
+  // ---- load: previous level, J and M, ALL at REFLECTED coordinates ----
+  // Out-of-image halo cells hold the mirror image of the in-image data (= torch 'reflect' padding, TT:411).  A
+  // symmetric kernel maps a mirror-symmetric signal to a mirror-symmetric signal, and the restore Z[M] = J[M] uses
+  // the mirrored J / M, so the halo stays the reflect padding of every later level without any re-mirroring pass
+  // (the only difference to padding each level explicitly is the summation order of the taps: float roundoff).
+  // One 4-cell group per thread and pass; all passes unrolled so every global load of the tile is in flight at once.
   {
     constexpr int G = RW / 4;          // 16-byte groups per region row
     constexpr int RPP = NT / G;        // region rows covered per pass
@@ -88,36 +92,25 @@ __global__ __launch_bounds__(512) void taxim_tail_kernel(TailArgs a) {
     const int lrow = tid / G, lx = (tid - lrow * G) * 4;
     const int gx = gx0 + lx;
     const bool xin = gx >= 0 && gx + 3 < W;  // whole group inside the image (W % 4 == 0, gx0 % 4 == 0)
-    int rx[4];
+    unsigned rxo[4];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) rx[k] = min(max(reflect_idx(gx + k, W), 0), W - 1);
+    for (int k = 0; k < 4; ++k) rxo[k] = (unsigned)min(max(reflect_idx(gx + k, W), 0), W - 1);
     v4f zv[NPASS], hv[NPASS], gv[NPASS];
-    bool yin[NPASS];
 #pragma unroll
     for (int ps = 0; ps < NPASS; ++ps) {
       const int ly = ps * RPP + lrow;
-      const int gy = gy0 + ly;
-      yin[ps] = false;
       if (lrow < RPP && ly < RH) {
-        const int ry = min(max(reflect_idx(gy, H), 0), H - 1);
-        const float* zr = zin + (size_t)ry * W;
+        const unsigned ro = (unsigned)min(max(reflect_idx(gy0 + ly, H), 0), H - 1) * (unsigned)W;
         if (xin) {
-          zv[ps] = *reinterpret_cast<const v4f*>(zr + gx);
+          zv[ps] = *reinterpret_cast<const v4f*>(zin + ro + gx);
+          hv[ps] = *reinterpret_cast<const v4f*>(hm + ro + gx);
+          gv[ps] = *reinterpret_cast<const v4f*>(a.gel + ro + gx);
         } else {
-          zv[ps] = (v4f){zr[rx[0]], zr[rx[1]], zr[rx[2]], zr[rx[3]]};
-        }
-        yin[ps] = gy >= 0 && gy < H;
-        if (yin[ps]) {
-          if (xin) {
-            hv[ps] = *reinterpret_cast<const v4f*>(hm + (size_t)gy * W + gx);
-            gv[ps] = *reinterpret_cast<const v4f*>(a.gel + (size_t)gy * W + gx);
-          } else {  // partially outside in x: clamp the address, the cell is flagged out-of-image below
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-              const int cx = min(max(gx + k, 0), W - 1);
-              hv[ps][k] = hm[(size_t)gy * W + cx];
-              gv[ps][k] = a.gel[(size_t)gy * W + cx];
-            }
+          for (int k = 0; k < 4; ++k) {
+            zv[ps][k] = zin[ro + rxo[k]];
+            hv[ps][k] = hm[ro + rxo[k]];
+            gv[ps][k] = a.gel[ro + rxo[k]];
           }
         }
       }
@@ -127,22 +120,17 @@ __global__ __launch_bounds__(512) void taxim_tail_kernel(TailArgs a) {
       const int ly = ps * RPP + lrow;
       if (lrow < RPP && ly < RH) {
         *reinterpret_cast<v4f*>(bufA + (ly + PADY) * P + PADX + lx) = zv[ps];
-        v4f Jv = (v4f)(0.0f);
-        uchar4 Mv = {0, 0, 0, 0};
-        if (yin[ps]) {
-          uint8_t mk[4];
+        v4f Jv;
+        uint8_t mk[4];
 #pragma unroll
-          for (int k = 0; k < 4; ++k) {
-            const bool inside = gx + k >= 0 && gx + k < W;
-            const float S = (hv[ps][k] - sa) - sb;
-            const float J = fminf(S, gv[ps][k]);
-            Jv[k] = inside ? J : 0.0f;
-            mk[k] = (inside && ((J - gv[ps][k]) < thr) && (S < 0.0f)) ? 1 : 0;  // TT:457-461
-          }
-          Mv = {mk[0], mk[1], mk[2], mk[3]};
+        for (int k = 0; k < 4; ++k) {
+          const float S = (hv[ps][k] - sa) - sb;
+          const float J = fmin_raw(S, gv[ps][k]);
+          Jv[k] = J;
+          mk[k] = (((J - gv[ps][k]) < thr) && (S < 0.0f)) ? 1 : 0;  // TT:457-461
         }
         *reinterpret_cast<v4f*>(bufJ + ly * P + PADX + lx) = Jv;
-        *reinterpret_cast<uchar4*>(bufM + ly * P + PADX + lx) = Mv;
+        *reinterpret_cast<uchar4*>(bufM + ly * P + PADX + lx) = (uchar4){mk[0], mk[1], mk[2], mk[3]};
       }
     }
   }
@@ -215,22 +203,6 @@ __global__ __launch_bounds__(512) void taxim_tail_kernel(TailArgs a) {
       for (int c = tid; c < RH * RW; c += NT) {
         const int ly = c / RW, lx = c - ly * RW;
         if (bufM[ly * P + PADX + lx]) bufA[(ly + PADY) * P + PADX + lx] = bufJ[ly * P + PADX + lx];
-      }
-      __syncthreads();
-    }
-    if constexpr (l < NL - 1) {
-      // ---- re-mirror the out-of-image halo (reflect padding of the NEXT level's input); border tiles only ----
-      const bool border = gy0 < 0 || gx0 < 0 || gy0 + RH > H || gx0 + RW > W;
-      if (border) {
-        for (int c = tid; c < RH * RW; c += NT) {
-          const int ly = c / RW, lx = c - ly * RW;
-          const int gy = gy0 + ly, gx = gx0 + lx;
-          if (gy >= 0 && gy < H && gx >= 0 && gx < W) continue;
-          int sy = reflect_idx(gy, H) - gy0, sx = reflect_idx(gx, W) - gx0;
-          sy = min(max(sy, 0), RH - 1);  // cells beyond the needed halo of a partial tile: any in-bounds source
-          sx = min(max(sx, 0), RW - 1);
-          bufA[(ly + PADY) * P + PADX + lx] = bufA[(sy + PADY) * P + PADX + sx];
-        }
       }
       __syncthreads();
     }

@@ -164,3 +164,22 @@ def test_fused_tail_matches_unfused_levels(taxim, shape):
     same = (idf == idu).all(-1)
     assert same.float().mean().item() > 0.995
     assert ((rf - ru).abs()[same]).max().item() <= 2e-6
+
+
+def test_policy_observation_downsample_matches_torch(taxim):
+    """(B,240,320,3) -> (B,32,32,3) antialiased bilinear (two-pass kernel) vs torch's own antialiased interpolate."""
+    from tacex_amd import _lib
+
+    lib = _lib.load_library()
+    g = torch.Generator().manual_seed(3)
+    x = torch.rand((4, 240, 320, 3), generator=g)
+    x = torch.cumsum(x, 2) / 160.0  # smooth along x so torch's float32 weight roundoff stays small
+    xd = x.cuda()
+    y = torch.empty((4, 32, 32, 3), device="cuda")
+    tmp = torch.empty((4, 32, 320, 3), device="cuda")
+    for t in (tmp, None):
+        y.zero_()
+        _lib.check(lib.tacex_resize_bilinear_aa_nhwc(xd.data_ptr(), 240, 320, y.data_ptr(), 32, 32, 3, 4,
+                                                     0 if t is None else t.data_ptr(), torch.cuda.current_stream().cuda_stream), "resize")
+        ref = torch.nn.functional.interpolate(x.movedim(3, 1), size=[32, 32], mode="bilinear", antialias=True).movedim(1, 3)
+        assert (y.cpu() - ref).abs().max() < 1e-5
