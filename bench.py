@@ -220,10 +220,15 @@ def main():
                     "pipeline_* = 16 B/px compulsory bytes of the whole Taxim path / sum of its kernels; "
                     "valu_frac = algorithmic fp32 flops / 157.3 TFLOP/s (the separable blur is VALU-heavy)",
         }
+        # HBM bytes of the dominant kernel per launch from the PMC passes (FETCH_SIZE x2 + WRITE_SIZE, collected with
+        # separate `rocprofv3 --pmc` runs and committed as profiles/pmc_traffic.json - counters cannot be read live here)
         pmc = REPO / "profiles" / "pmc_traffic.json"
-        if pmc.exists():
+        if pmc.exists() and (H, W) == (240, 320):
             try:
-                roofline["traffic"] = json.loads(pmc.read_text()).get(dom)
+                per_frame = json.loads(pmc.read_text())["per_frame_bytes"].get(dom)
+                if per_frame is not None:
+                    roofline["traffic"] = int(per_frame * B)
+                    roofline["traffic_source"] = "profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, per-frame bytes x frames per launch)"
             except Exception:
                 pass
 
