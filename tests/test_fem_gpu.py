@@ -144,3 +144,58 @@ def test_step_api_and_marker_uv(meshes):
     _lib.check(lib.tacex_fem_marker_uv(cam.data_ptr(), tri_d.data_ptr(), w_d.data_ptr(), 340.0, 325.0, 160.0, 125.0,
                                        uv.data_ptr(), 2, cam.shape[1], len(tri), torch.cuda.current_stream().cuda_stream), "uv")
     np.testing.assert_allclose(uv.cpu().numpy(), marker_uv(cam.cpu().numpy(), tri, w), rtol=1e-12)
+
+
+def test_mani_skill_marker_flow_plugin():
+    """GelSightSensor + ManiSkillSimulator (FEM-driven markers, MS:22-86 / VT:354-413) for several envs at once:
+    barycentric surface points + pinhole projection on the GPU vs the NumPy oracle; mask/pad semantics of VT:382-405."""
+    from oracle.fem_oracle import marker_uv
+    from tacex_amd import GelSightSensor, GelSightSensorCfg
+    from tacex_amd.simulation_approaches.fem_based import ManiSkillSimulatorCfg
+    from tacex_amd.simulation_approaches.fem_based.sim.tactile_sensor_uipc import gen_marker_grid, gen_marker_weight
+    from tacex_amd.uipc import UipcObject, UipcObjectCfg, UipcSim, UipcSimCfg
+    from tacex_amd.uipc.uipc_object import gelpad_box_mesh
+
+    B = 3
+    P, Tt = gelpad_box_mesh(10, 8, 3, size=(0.030, 0.018, 0.0045))
+    P = P - np.array([0.011, 0.009, 0.0])  # marker area over the camera axis
+    sim = UipcSim(UipcSimCfg(device="cuda:0"), num_envs=B)
+    gel = UipcObject(UipcObjectCfg(mesh_points=P, mesh_tets=Tt), sim)
+    sim.setup_sim()
+    cfg = GelSightSensorCfg(
+        num_envs=B, data_types=["marker_motion"], optical_sim_cfg=None,
+        marker_motion_sim_cfg=ManiSkillSimulatorCfg(device="cuda:0", camera_pos_w=(0.0, 0.0, -0.024)),
+        sensor_camera_cfg=GelSightSensorCfg.SensorCameraCfg(resolution=(320, 240)), device="cuda:0")
+    cfg.compute_indentation_depth_class = "marker_motion_sim"
+    sensor = GelSightSensor(cfg, gelpad_obj=gel)
+    sensor.compute_indentation_depth_func = None
+    sensor.initialize()
+    sensor.compute_indentation_depth_func = None
+    ms = sensor.marker_motion_simulator.marker_motion_sim
+    # deform every env differently (smooth displacement field), then read the flow through the sensor
+    x = sim.x.clone()
+    for b in range(B):
+        x[b, :, 0] += 0.0004 * (b + 1) * torch.sin(300 * x[b, :, 1])
+        x[b, :, 2] += 0.0003 * (b + 1) * torch.cos(200 * x[b, :, 0])
+    sim.x = x
+    sensor.update(0.01, force_recompute=True)
+    flow = sensor.data.output["marker_motion"].cpu().numpy()  # (B,2,128,2)
+    assert flow.shape == (B, 2, 128, 2)
+    # oracle
+    surf_ids = ms.surf_vertex_ids
+    cam = lambda v: v - np.array([0.0, 0.0, -0.024])
+    grid = gen_marker_grid()
+    tri, wgt = gen_marker_weight(grid, cam(P[surf_ids]), ms.surf_triangles)
+    init_uv = marker_uv(cam(P[surf_ids])[None].repeat(B, 0), tri, wgt)
+    curr_uv = marker_uv(cam(x.cpu().numpy()[:, surf_ids]), tri, wgt)
+    u0, v0 = init_uv[0, :, 0], init_uv[0, :, 1]
+    mask = (u0 > 5) & (u0 < 240) & (v0 > 5) & (v0 < 320)  # (sic) u vs height, v vs width (VT:382-387)
+    n = int(mask.sum())
+    assert 0 < n < 128
+    ref = np.zeros((B, 2, 128, 2))
+    ref[:, 0, :n] = init_uv[:, mask]
+    ref[:, 1, :n] = curr_uv[:, mask]
+    ref[:, :, n:] = ref[:, :, n - 1:n]  # padded by repeating the last marker
+    np.testing.assert_allclose(flow, ref, rtol=0, atol=2e-3)  # float32 output buffer of ~300 px values
+    assert np.abs(flow[:, 1] - flow[:, 0]).max() > 1.0  # markers really moved
+    assert np.abs(flow[0] - flow[2]).max() > 0.5         # per-env flows differ (the reference fills env 0 only)

@@ -155,3 +155,27 @@ def test_observation_gather_single_process():
     out = g.gather()
     assert torch.equal(out["rgb32"], rgb) and out["indent"].reshape(-1).tolist() == [1.0, 2.0, 3.0]
     assert g.payload_bytes() == 3 * (48 + 1 + 20) * 4
+
+
+def test_fem_marker_setup_vs_reference(golden_dir):
+    """Marker grid (VT:189-247) and surface-triangle / barycentric-weight search (VT:249-329) against vectors produced
+    by the reference's own functions (tests/golden/make_fem_marker_golden.py)."""
+    from tacex_amd.simulation_approaches.fem_based.sim.tactile_sensor_uipc import gen_marker_grid, gen_marker_weight
+
+    g = np.load(golden_dir / "fem_markers.npz")
+    grid = gen_marker_grid()
+    np.testing.assert_allclose(grid, g["grid"], rtol=0, atol=1e-15)
+    assert grid.shape == (91, 2)
+    idx, wgt = gen_marker_weight(grid, g["surf_cam"].astype(np.float64), g["triangles"])
+    assert idx.shape == g["tri_idx"].shape
+    # the same marker point must be reproduced; the chosen triangle can differ only for points on a shared edge
+    pts_ref = (g["surf_cam"][g["tri_idx"]] * g["weights"][..., None]).sum(1)
+    pts = (g["surf_cam"][idx] * wgt[..., None]).sum(1)
+    np.testing.assert_allclose(pts, pts_ref, atol=1e-7)
+    same = (idx == g["tri_idx"]).all(1)
+    assert same.mean() > 0.8
+    np.testing.assert_allclose(wgt[same], g["weights"][same], atol=1e-5)
+    # randomised grid: same numpy draw order as the reference
+    rs = np.random.RandomState(123)
+    grid2 = gen_marker_grid((1.8, 2.2), 0.05, (0.5, 0.4), (0.05, 0.05), rng=rs)
+    np.testing.assert_allclose(grid2, g["grid_random"], rtol=0, atol=1e-12)
