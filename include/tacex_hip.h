@@ -90,9 +90,33 @@ int tacex_indentation_depth(const float* hm_mm_dev, float gelpad_height_m,
                             float gelpad_to_camera_min_distance_m, float* frame_min_dev,
                             float* indent_mm_dev, int num_frames, int height, int width, void* stream);
 
+/* Shadow branch tables (TaximTorch.__init__ shadow calibration TT:96-126 + the per-shape parameters of TT:260-346).
+ * Optional: only needed before a render with TACEX_FLAG_WITH_SHADOW. Host pointers, copied once. */
+typedef struct tacex_shadow_params {
+  int32_t num_directions;      /* 63  (shadowDirections) */
+  int32_t num_fan_rays;        /* 4   = int(2 * fan_angle / fan_precision), TT:102 */
+  int32_t num_heights;         /* 24 */
+  int32_t num_steps;           /* 51  (longest table entry; shorter ones padded with +inf, TT:118-126) */
+  const float* fan_angles;     /* (num_directions, num_fan_rays): direction + linspace(-fan_angle, fan_angle), TT:103-105 */
+  const float* table;          /* (3, num_directions, num_heights, num_steps), RGB order, already / 255, +inf padded */
+  int32_t win_left, win_right, win_top, win_bottom; /* composite window of the two box-dilation rounds, TT:261-272 */
+  float shadow_depth_0;        /* 0.4, TT:97 */
+  float height_precision;      /* params.json simulator.height_precision (0.1) */
+  float discretize_precision;  /* params.json simulator.discretize_precision (0.1) */
+  float step_x, step_y;        /* shadow_step(shape)[1], [0] (sic: x uses the height-scaled value), TT:298-305 */
+  int32_t blur_kw, blur_kh;    /* shadow_blur_sigma kernel, TT:339-342 */
+  const float* blur_taps_w;
+  const float* blur_taps_h;
+} tacex_shadow_params;
+
+int tacex_taxim_set_shadow(tacex_taxim_ctx* ctx, const tacex_shadow_params* params);
+/* extra scratch (beyond tacex_taxim_workspace_bytes) a render with TACEX_FLAG_WITH_SHADOW needs, placed right after it */
+size_t tacex_taxim_shadow_workspace_bytes(const tacex_taxim_ctx* ctx, int num_frames);
+
 /* Flags for tacex_taxim_render / tacex_taxim_deform */
 #define TACEX_FLAG_NO_SHIFT      1u  /* press_depth=None: use the height map as is (TT:188-189 skipped) */
 #define TACEX_FLAG_HAVE_FRAME_MIN 2u /* frame_min_dev already holds min(hm) per frame (skip that pass) */
+#define TACEX_FLAG_WITH_SHADOW    4u /* render only: shadow branch TT:260-346 (needs tacex_taxim_set_shadow + extra scratch) */
 
 /* TaximSimulator.optical_simulation (TS:80-113) -> Taxim.render_direct (TI:153-163) ->
  * TaximTorch._render_impl / __render no-shadow branch (TT:174-258), output already NHWC (TS:109-111).

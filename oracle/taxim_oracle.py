@@ -203,6 +203,19 @@ class TaximOracle:
         yy, xx = np.meshgrid(ys, xs, indexing="ij")
         self.feat = np.stack([xx * xx, yy * yy, xx * yy, xx, yy, np.ones_like(xx)], -1).astype(F32)
 
+        # shadow calibration (TT:96-126): directions, fan of 4 rays around each, table padded with +inf to 51 steps,
+        # BGR -> RGB flip; the "extra empty entry" concat of the reference does not change the shape (24 heights)
+        sd = np.load(calib_dir / "shadowTable.npz", allow_pickle=True)
+        direction = sd["shadowDirections"].astype(F32)
+        fan_angle = self.p.sim["fan_angle"]
+        n_fan = int(fan_angle * 2 / self.p.sim["fan_precision"])
+        self.fan = (direction[:, None] + np.linspace(-fan_angle, fan_angle, n_fan).astype(F32)[None, :]).astype(F32)
+        tab = sd["shadowTable"][::-1]  # flip channel axis
+        maxlen = max(len(e) for e in tab.reshape(-1))
+        self.shadow_table = (np.array([list(e) + [np.inf] * (maxlen - len(e)) for e in tab.reshape(-1)], dtype=F32)
+                             .reshape(tab.shape + (maxlen,)) / F32(255))
+        self.shadow_depth_0 = 0.4
+
         self.pyr_sigmas = list(zip(*self.p.rel("deform_pyramid_sigma", (self.H, self.W))))  # [(sw, sh)]
         self.final_sigma = self.p.rel("deform_final_sigma", (self.H, self.W))
 
@@ -276,9 +289,72 @@ class TaximOracle:
             return rgb, mag, dr, im, idd
         return rgb
 
+    # -- TT:260-346 (shadow branch) ---------------------------------------------------------------------
+    @staticmethod
+    def _box_dilate_same(mask_f: np.ndarray, kh: int, kw: int) -> np.ndarray:
+        """conv2d(ones((kh,kw)), padding='same'): torch pads (k-1)//2 before and the rest after (TT:268-272)."""
+        H, W = mask_f.shape[-2:]
+        top, left = (kh - 1) // 2, (kw - 1) // 2
+        pad = [(0, 0)] * (mask_f.ndim - 2) + [(top, kh - 1 - top), (left, kw - 1 - left)]
+        mp = np.pad(mask_f, pad)
+        out = np.zeros_like(mask_f)
+        for i in range(kh):
+            for j in range(kw):
+                out += mp[..., i : i + H, j : j + W]
+        return out
+
+    def shadow_attachment_rounds(self):
+        ks = np.array(self.p.rel("shadow_attachment_kernel_size", (self.H, self.W)))  # (w, h)
+        total = np.round(ks * 2).astype(np.int_)
+        first = total // 2
+        return [np.maximum(1, first), np.maximum(1, total - first)]  # each (kw, kh)
+
+    def shade_with_shadow(self, Z: np.ndarray, M: np.ndarray) -> np.ndarray:
+        """Deformed gel (B,H,W) + shrunken contact mask -> (B,H,W,3) RGB with cast shadows."""
+        H, W = self.H, self.W
+        B = Z.shape[0]
+        Zf = np.asarray(Z, F32)
+        z_px = -(Zf / F32(self.p.pixmm))
+        mag, dr = self.normals(z_px)
+        im, idd = self.bins(mag, dr)
+        coef = self.poly[:, im, idd]
+        sim = np.moveaxis((coef * self.feat[None, None]).sum(-1, dtype=F32), 0, 1).astype(F32)  # (B,3,H,W)
+        dil = M.astype(F32)
+        for (kw, kh) in self.shadow_attachment_rounds():
+            dil = self._box_dilate_same(dil, int(kh), int(kw))
+        boundary = (dil != 0) & ~M
+        bi, yi, xi = np.nonzero(boundary)
+        norm_idx = np.floor((dr[boundary].astype(F32) + F32(math.pi)) / F32(self.p.sim["discretize_precision"])).astype(np.int64)
+        zpx = (Zf / F32(self.p.pixmm)).astype(F32)  # deformed_gel_px
+        contact_px = ((self.gel[None] - Zf) / F32(self.p.pixmm)).astype(F32)[boundary]
+        hidx = np.floor((contact_px * F32(self.p.pixmm) - F32(self.shadow_depth_0)) / F32(self.p.sim["height_precision"])).astype(np.int64) + 6
+        max_h = self.shadow_table.shape[2] - 1
+        hidx[(hidx < 0) | (hidx >= max_h)] = max_h
+        sel = self.shadow_table[:, norm_idx, hidx]  # (3,N,51)
+        thetas = self.fan[norm_idx]                 # (N,4)
+        nstep = sel.shape[-1]
+        steps = (np.arange(nstep) + 1).astype(F32)
+        step_w, step_h = self.p.rel("shadow_step", (H, W))  # (w_val, h_val); x uses [1], y uses [0] (TT:300-305)
+        sx = (xi[:, None, None].astype(F32) + (F32(step_h) * steps)[None, None, :] * np.cos(thetas)[:, :, None]).astype(F32)
+        sy = (yi[:, None, None].astype(F32) + (F32(step_w) * steps)[None, None, :] * np.sin(thetas)[:, :, None]).astype(F32)
+        sx = np.trunc(sx).astype(np.int64)
+        sy = np.trunc(sy).astype(np.int64)
+        cx, cy = np.clip(sx, 0, W - 1), np.clip(sy, 0, H - 1)
+        valid = (sx >= 0) & (sx < W) & (sy >= 0) & (sy < H) & (zpx[bi, yi, xi][:, None, None] < zpx[bi[:, None, None], cy, cx])
+        shadow = np.full((3, B * H * W), np.inf, F32)
+        n_i, f_i, s_i = np.nonzero(valid)
+        flat = (bi[n_i] * H + sy[valid]) * W + sx[valid]
+        for c in range(3):
+            np.minimum.at(shadow[c], flat, sel[c, n_i, s_i])
+        sim = np.minimum(sim, np.moveaxis(shadow.reshape(3, B, H, W), 0, 1))
+        wdt = np.float64 if self.blur_mode == "direct" else F32
+        s1 = self._blur(sim.astype(wdt), self.p.rel("shadow_blur_sigma", (H, W)))
+        s2 = self._blur(s1 + self.bg[None].astype(wdt), self.final_sigma)
+        return np.moveaxis(np.clip(s2, 0, 1), 1, -1).astype(F32)
+
     # -- TI:153-163 + TT:174-195 ----------------------------------------------------------------------
-    def render_direct(self, hm: np.ndarray, press: np.ndarray) -> np.ndarray:
-        """(B,H,W) mm height map + (B,) press depth -> (B,H,W,3) float32 RGB in [0,1] (no-shadow path)."""
+    def render_direct(self, hm: np.ndarray, press: np.ndarray, with_shadow: bool = False) -> np.ndarray:
+        """(B,H,W) mm height map + (B,) press depth -> (B,H,W,3) float32 RGB in [0,1]."""
         S = self.shifted_height_map(hm, press)
-        Z, _ = self.gel_pad_deformation(S)
-        return self.shade(Z)
+        Z, M = self.gel_pad_deformation(S)
+        return self.shade_with_shadow(Z, M) if with_shadow else self.shade(Z)

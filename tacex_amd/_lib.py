@@ -13,6 +13,7 @@ from ._build import LIB, build_library
 MAX_LEVELS = 8
 FLAG_NO_SHIFT = 1
 FLAG_HAVE_FRAME_MIN = 2
+FLAG_WITH_SHADOW = 4
 
 c_float_p = C.POINTER(C.c_float)
 c_int32_p = C.POINTER(C.c_int32)
@@ -37,6 +38,17 @@ class TaximParams(C.Structure):
         ("background", c_float_p),
         ("feat_x", c_float_p),
         ("feat_y", c_float_p),
+    ]
+
+
+class ShadowParams(C.Structure):
+    _fields_ = [
+        ("num_directions", C.c_int32), ("num_fan_rays", C.c_int32), ("num_heights", C.c_int32), ("num_steps", C.c_int32),
+        ("fan_angles", c_float_p), ("table", c_float_p),
+        ("win_left", C.c_int32), ("win_right", C.c_int32), ("win_top", C.c_int32), ("win_bottom", C.c_int32),
+        ("shadow_depth_0", C.c_float), ("height_precision", C.c_float), ("discretize_precision", C.c_float),
+        ("step_x", C.c_float), ("step_y", C.c_float),
+        ("blur_kw", C.c_int32), ("blur_kh", C.c_int32), ("blur_taps_w", c_float_p), ("blur_taps_h", c_float_p),
     ]
 
 
@@ -80,6 +92,8 @@ SIGNATURES = {
     "tacex_taxim_create": (_i, [_i, C.POINTER(TaximParams), C.POINTER(_vp)]),
     "tacex_taxim_destroy": (None, [_vp]),
     "tacex_taxim_workspace_bytes": (_sz, [_vp, _i]),
+    "tacex_taxim_set_shadow": (_i, [_vp, C.POINTER(ShadowParams)]),
+    "tacex_taxim_shadow_workspace_bytes": (_sz, [_vp, _i]),
     "tacex_height_map_from_depth": (_i, [_vp, _f, _f, _f, _f, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "tacex_indentation_depth": (_i, [_vp, _f, _f, _vp, _vp, _i, _i, _i, _vp]),
     "tacex_taxim_render": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _u, _vp]),

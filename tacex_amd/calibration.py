@@ -197,6 +197,7 @@ class TaximTables:
     background_full: np.ndarray = None  # (3, calib_h, calib_w) f32 (the reference's `background_img`)
     feat_x: np.ndarray = None
     feat_y: np.ndarray = None
+    shadow: dict = None             # shadow-branch tables (build_shadow_tables), filled on demand
 
 
 def build_taxim_tables(calib_folder: Path, shape_hw: tuple[int, int],
@@ -245,3 +246,33 @@ def build_taxim_tables(calib_folder: Path, shape_hw: tuple[int, int],
     t.feat_x = np.ascontiguousarray(torch_linspace_f32(0, cw, W + 1)[:-1])
     t.feat_y = np.ascontiguousarray(torch_linspace_f32(0, ch, H + 1)[:-1])
     return t
+
+
+def build_shadow_tables(calib_folder: Path, tables: TaximTables) -> dict:
+    """Shadow calibration (taxim_torch.py:96-126) + the per-shape parameters of the shadow branch (taxim_torch.py:260-346)."""
+    sim, H, W = tables.sim_params, tables.height, tables.width
+    sd = np.load(Path(calib_folder) / "shadowTable.npz", allow_pickle=True)
+    direction = sd["shadowDirections"].astype(F32)
+    n_fan = int(sim.fan_angle * 2 / sim.fan_precision)
+    fan = (direction[:, None] + np.linspace(-sim.fan_angle, sim.fan_angle, n_fan).astype(F32)[None, :]).astype(F32)
+    tab = sd["shadowTable"][::-1]  # BGR -> RGB (taxim_torch.py:113); the "extra empty entry" concat keeps 24 heights
+    nstep = max(len(e) for e in tab.reshape(-1))
+    table = (np.array([list(e) + [np.inf] * (nstep - len(e)) for e in tab.reshape(-1)], dtype=F32)
+             .reshape(tab.shape + (nstep,)) / F32(255))
+    # two box-dilation rounds with conv2d(padding="same") (taxim_torch.py:261-272): composite window
+    ks = np.array(sim.shadow_attachment_kernel_size((H, W)))  # (w, h)
+    total = np.round(ks * 2).astype(np.int_)
+    first = total // 2
+    rounds = [np.maximum(1, first), np.maximum(1, total - first)]
+    wl = sum(int((r[0] - 1) // 2) for r in rounds)
+    wr = sum(int(r[0] - 1 - (r[0] - 1) // 2) for r in rounds)
+    wt = sum(int((r[1] - 1) // 2) for r in rounds)
+    wb = sum(int(r[1] - 1 - (r[1] - 1) // 2) for r in rounds)
+    step_w, step_h = sim.shadow_step((H, W))
+    sbw, sbh = sim.shadow_blur_sigma((H, W))
+    kw, kh = gaussian_kernel_size(sbw), gaussian_kernel_size(sbh)
+    return dict(fan=np.ascontiguousarray(fan), table=np.ascontiguousarray(table), ndir=int(fan.shape[0]), nfan=int(n_fan),
+                nheight=int(table.shape[2]), nstep=int(nstep), win=(wl, wr, wt, wb), depth0=0.4,
+                height_precision=float(sim.height_precision), discretize_precision=float(sim.discretize_precision),
+                step_x=float(step_h), step_y=float(step_w),  # (sic) x uses shadow_step[1] = the height-scaled value
+                blur_kw=kw, blur_kh=kh, blur_taps_w=gaussian_taps(sbw, kw), blur_taps_h=gaussian_taps(sbh, kh))

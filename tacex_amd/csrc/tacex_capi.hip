@@ -46,6 +46,7 @@ struct tacex_taxim_ctx {
   float contact_scale = 0.4f;
   LevelDesc levels[TACEX_MAX_LEVELS];
   ShadeParams shade;
+  ShadowParams shadow;
   float* gel_dev = nullptr;
   std::vector<void*> allocs;
   // profiling
@@ -172,6 +173,44 @@ void tacex_taxim_destroy(tacex_taxim_ctx* c) {
 }
 
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+int tacex_taxim_set_shadow(tacex_taxim_ctx* c, const tacex_shadow_params* p) {
+  if (!c || !p || !p->fan_angles || !p->table || !p->blur_taps_w || !p->blur_taps_h) { set_error("tacex_taxim_set_shadow: null argument"); return 2; }
+  if (p->num_directions < 1 || p->num_fan_rays < 1 || p->num_heights < 2 || p->num_steps < 1 || p->blur_kw % 2 != 1 || p->blur_kh % 2 != 1) {
+    set_error("tacex_taxim_set_shadow: bad table dimensions");
+    return 2;
+  }
+  HIP_TRY(hipSetDevice(c->device), "hipSetDevice");
+  ShadowParams& s = c->shadow;
+  s.ndir = p->num_directions; s.nfan = p->num_fan_rays; s.nheight = p->num_heights; s.nstep = p->num_steps;
+  s.wl = p->win_left; s.wr = p->win_right; s.wt = p->win_top; s.wb = p->win_bottom;
+  s.depth0 = p->shadow_depth_0; s.height_prec = p->height_precision; s.disc_prec = p->discretize_precision;
+  s.step_x = p->step_x; s.step_y = p->step_y;
+  int rc = upload(c, p->fan_angles, (size_t)s.ndir * s.nfan, &s.fan_dev);
+  if (!rc) {  // (3, ndir, nh, nstep) -> (ndir, nh, nstep, 4)
+    std::vector<float> t((size_t)s.ndir * s.nheight * s.nstep * 4, 0.0f);
+    for (int ch = 0; ch < 3; ++ch)
+      for (int d = 0; d < s.ndir; ++d)
+        for (int h = 0; h < s.nheight; ++h)
+          for (int k = 0; k < s.nstep; ++k)
+            t[(((size_t)d * s.nheight + h) * s.nstep + k) * 4 + ch] = p->table[(((size_t)ch * s.ndir + d) * s.nheight + h) * s.nstep + k];
+    rc |= upload(c, t.data(), t.size(), &s.table_dev);
+  }
+  s.sblur_kw = p->blur_kw; s.sblur_kh = p->blur_kh;
+  if (!rc) rc |= upload(c, p->blur_taps_w, (size_t)p->blur_kw, &s.sblur_taps_w_dev);
+  if (!rc) rc |= upload(c, p->blur_taps_h, (size_t)p->blur_kh, &s.sblur_taps_h_dev);
+  const LevelDesc& fl = c->levels[c->n_levels - 1];  // deform_final_sigma kernel (TT:343-344)
+  s.final_kw = fl.kw; s.final_kh = fl.kh; s.final_taps_w_dev = fl.taps_w_dev; s.final_taps_h_dev = fl.taps_h_dev;
+  if (rc) return rc;
+  s.ready = true;
+  return 0;
+}
+
+size_t tacex_taxim_shadow_workspace_bytes(const tacex_taxim_ctx* c, int B) {
+  if (!c || B <= 0) return 0;
+  const size_t img = align_up((size_t)B * c->H * c->W * sizeof(float), 256);
+  return 12 * img;  // deformed gel 1, mask 1 (u8, one image slot), gdir 1, raw 3, shadow 3, tmp 3
+}
 
 size_t tacex_taxim_workspace_bytes(const tacex_taxim_ctx* c, int B) {
   if (!c || B <= 0) return 0;
@@ -316,6 +355,22 @@ int tacex_taxim_render(tacex_taxim_ctx* c, const float* hm, const float* press, 
   if (!c || !hm || !frame_min || !rgb || !ws) { set_error("tacex_taxim_render: null argument"); return 2; }
   if (!press && !(flags & TACEX_FLAG_NO_SHIFT)) { set_error("tacex_taxim_render: press_dev is null"); return 2; }
   if (B <= 0) return 0;
+  if (flags & TACEX_FLAG_WITH_SHADOW) {
+    if (!c->shadow.ready) { set_error("tacex_taxim_render: TACEX_FLAG_WITH_SHADOW needs tacex_taxim_set_shadow first"); return 2; }
+    const size_t img = align_up((size_t)B * c->H * c->W * sizeof(float), 256);
+    char* sw = static_cast<char*>(ws) + tacex_taxim_workspace_bytes(c, B);
+    float* zb = z_out ? z_out : reinterpret_cast<float*>(sw);
+    uint8_t* mb = mask_out ? mask_out : reinterpret_cast<uint8_t*>(sw + img);
+    float* gdir = reinterpret_cast<float*>(sw + 2 * img);
+    float* raw = reinterpret_cast<float*>(sw + 3 * img);
+    float* shd = reinterpret_cast<float*>(sw + 6 * img);
+    float* tmp = reinterpret_cast<float*>(sw + 9 * img);
+    int rc = pipeline_impl(c, hm, press, frame_min, nullptr, zb, mb, ws, B, flags, (hipStream_t)stream);
+    if (rc) return rc;
+    StageTimer t(c, (hipStream_t)stream, c->n_levels + 1);
+    HIP_TRY(run_shadow(c->shadow, c->shade, zb, mb, c->gel_dev, rgb, raw, shd, gdir, tmp, B, (hipStream_t)stream), "shadow branch");
+    return 0;
+  }
   return pipeline_impl(c, hm, press, frame_min, rgb, z_out, mask_out, ws, B, flags, (hipStream_t)stream);
 }
 

@@ -35,6 +35,20 @@ hipError_t run_shade(const ShadeParams& sp, const float* z, float* rgb, uint8_t*
 hipError_t run_resize_aa(const float* src, int sh, int sw, float* dst, int dh, int dw, int B, int C, float* tmp,
                          hipStream_t st);
 
+struct ShadowParams {  // shadow branch tables (taxim_shadow.hip), set by tacex_taxim_set_shadow
+  bool ready = false;
+  int ndir = 0, nfan = 0, nheight = 0, nstep = 0;
+  int wl = 0, wr = 0, wt = 0, wb = 0;
+  float depth0 = 0.4f, height_prec = 0.1f, disc_prec = 0.1f, step_x = 0.f, step_y = 0.f;
+  float* fan_dev = nullptr;     // (ndir, nfan)
+  float* table_dev = nullptr;   // (ndir, nheight, nstep, 4)
+  int sblur_kw = 1, sblur_kh = 1, final_kw = 1, final_kh = 1;
+  float* sblur_taps_w_dev = nullptr; float* sblur_taps_h_dev = nullptr;
+  float* final_taps_w_dev = nullptr; float* final_taps_h_dev = nullptr;
+};
+hipError_t run_shadow(const ShadowParams& sw, const ShadeParams& sp, const float* z, const uint8_t* mask, const float* gel,
+                      float* rgb, float* ws_raw, float* ws_shadow, float* ws_gdir, float* ws_tmp, int B, hipStream_t st);
+
 // fused tail (taxim_tail.hip): trailing small-kernel levels + shading in one LDS-tiled kernel
 int tail_levels(const LevelDesc* lv, int n_levels, int H, int W);
 hipError_t run_tail(const LevelDesc* lv, int n_levels, int n_fused, const float* zin, const float* hm, const float* gel,

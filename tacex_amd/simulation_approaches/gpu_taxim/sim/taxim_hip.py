@@ -18,7 +18,7 @@ import numpy as np
 import torch
 
 from .... import _lib
-from ....calibration import CALIB_GELSIGHT, TaximTables, build_taxim_tables, load_params
+from ....calibration import CALIB_GELSIGHT, TaximTables, build_shadow_tables, build_taxim_tables, load_params
 
 
 class _ShapeCtx:
@@ -139,8 +139,27 @@ class TaximHip:
         return torch.from_numpy(self.context(shape_hw).tables.gel_map).to(self._device)
 
     # -- scratch -----------------------------------------------------------------------------------------
-    def _workspace(self, ctx: _ShapeCtx, shape_hw, B: int) -> torch.Tensor:
+    def _ensure_shadow(self, ctx: _ShapeCtx):
+        """Upload the shadow-branch tables of this resolution once (taxim_torch.py:96-126, 260-346)."""
+        if getattr(ctx, "shadow_ready", False):
+            return
+        sh = build_shadow_tables(self._calib_folder, ctx.tables)
+        p = _lib.ShadowParams()
+        p.num_directions, p.num_fan_rays, p.num_heights, p.num_steps = sh["ndir"], sh["nfan"], sh["nheight"], sh["nstep"]
+        keep = [np.ascontiguousarray(sh[k], dtype=np.float32) for k in ("fan", "table", "blur_taps_w", "blur_taps_h")]
+        p.fan_angles, p.table = keep[0].ctypes.data_as(_lib.c_float_p), keep[1].ctypes.data_as(_lib.c_float_p)
+        p.win_left, p.win_right, p.win_top, p.win_bottom = sh["win"]
+        p.shadow_depth_0, p.height_precision, p.discretize_precision = sh["depth0"], sh["height_precision"], sh["discretize_precision"]
+        p.step_x, p.step_y = sh["step_x"], sh["step_y"]
+        p.blur_kw, p.blur_kh = sh["blur_kw"], sh["blur_kh"]
+        p.blur_taps_w, p.blur_taps_h = keep[2].ctypes.data_as(_lib.c_float_p), keep[3].ctypes.data_as(_lib.c_float_p)
+        _lib.check(self._lib.tacex_taxim_set_shadow(ctx.handle, C.byref(p)), "tacex_taxim_set_shadow")
+        ctx.shadow_ready = True
+
+    def _workspace(self, ctx: _ShapeCtx, shape_hw, B: int, with_shadow: bool = False) -> torch.Tensor:
         need = self._lib.tacex_taxim_workspace_bytes(ctx.handle, B)
+        if with_shadow:
+            need += self._lib.tacex_taxim_shadow_workspace_bytes(ctx.handle, B)
         ws = self._ws.get(shape_hw)
         if ws is None or ws.numel() < need:
             ws = torch.empty(need, dtype=torch.uint8, device=self._device)
@@ -196,11 +215,6 @@ class TaximHip:
         `frame_min` (B,) precomputed per-frame minimum, `z_out` / `mask_out` to also return the deformed gel
         and the shrunken contact mask of taxim_torch.py:443-473 (the FOTS wrapper needs both).
         """
-        if with_shadow:
-            raise NotImplementedError(
-                "with_shadow=True (taxim_torch.py:260-346) is not implemented in the HIP backend yet; "
-                "every shipped TacEx cfg uses with_shadow=False"
-            )
         batch_shape = tuple(height_map.shape[:-2])
         hm = self._check_hm(height_map)
         B, H, W = hm.shape
@@ -220,7 +234,10 @@ class TaximHip:
             out = torch.empty((B, H, W, 3), dtype=torch.float32, device=self._device)
         elif tuple(out.shape) != (B, H, W, 3) or not out.is_contiguous() or out.dtype != torch.float32:
             raise ValueError("out must be a contiguous float32 (B,H,W,3) tensor")
-        ws = self._workspace(ctx, (H, W), B)
+        if with_shadow:
+            self._ensure_shadow(ctx)
+            flags |= _lib.FLAG_WITH_SHADOW
+        ws = self._workspace(ctx, (H, W), B, with_shadow)
         with torch.cuda.device(self._device):
             stream = _lib.current_stream_handle(self._device)
             rc = self._lib.tacex_taxim_render(

@@ -199,7 +199,7 @@ def main():
     np.savez_compressed(HERE / "taxim_32x32.npz", **taxim_case(t, 32, 32, 4, 11, levels=True, shadow=True))
     np.savez_compressed(HERE / "taxim_24x32.npz", **taxim_case(t, 24, 32, 3, 12, levels=True, shadow=False))
     np.savez_compressed(HERE / "taxim_48x64.npz", **taxim_case(t, 48, 64, 4, 13, levels=True, shadow=True))
-    np.savez_compressed(HERE / "taxim_240x320.npz", **taxim_case(t, 240, 320, 5, 14, levels=True, shadow=False, n_levels_frames=2))
+    np.savez_compressed(HERE / "taxim_240x320.npz", **taxim_case(t, 240, 320, 5, 14, levels=True, shadow=True, n_levels_frames=2))
     np.savez_compressed(HERE / "taxim_480x640.npz", **taxim_case(t, 480, 640, 2, 15, levels=False, shadow=False, slim=True))
     np.savez_compressed(HERE / "fots_240x320.npz", **fots_case(t, MarkerMotion, seed=21, n=4, steps=4))
     for f in sorted(HERE.glob("*.npz")):

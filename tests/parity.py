@@ -45,3 +45,15 @@ def check_against_reference(Z, im, idd, rgb, g, frames=None, z_tol=1e-5, rgb_tol
         stats["rgb_rel_same_bin_all"] = float(err[same].max())
         assert stats["rgb_rel_same_bin_all"] <= rgb_tol, stats
     return stats
+
+
+def well_conditioned_field(im, idd, g, frames=None, radius=3):
+    """Pixels whose whole (2r+1)^2 receptive field is same-bin AND strong-gradient w.r.t. the reference: the shadow
+    branch blurs the shaded image twice (k=3 then k=5 at 320x240), which smears the reference's arbitrary flat-region
+    bins over their neighbourhood, so only such pixels are comparable with the reference's shadow output."""
+    from scipy import ndimage
+
+    sl = slice(None) if frames is None else frames
+    same = (np.asarray(im) == g["idx_mag"][sl]) & (np.asarray(idd) == g["idx_dir"][sl]) & (g["grad_mag"][sl] > 1e-3)
+    st = np.ones((2 * radius + 1, 2 * radius + 1))
+    return np.stack([ndimage.binary_erosion(same[b], structure=st) for b in range(same.shape[0])])

@@ -114,3 +114,28 @@ def test_torch_cpu_port_vs_reference(golden_dir, calib_dir):
     d = np.abs(rgb - g["rgb"])
     assert np.quantile(d[strong], 0.99) <= 1e-4
     assert (d[strong] <= 1e-4).mean() >= 0.99
+
+
+def test_shadow_branch_oracle_vs_reference(golden_dir, calib_dir):
+    """with_shadow=True (TT:260-346): boundary ring, 4-ray fan x 51 steps, scatter-min, two image blurs."""
+    from parity import well_conditioned_field
+
+    g = _load(golden_dir, 240, 320)
+    o = TaximOracle(calib_dir, (240, 320), "direct")
+    S = o.shifted_height_map(g["hm"], g["indent"])
+    Z, M = o.gel_pad_deformation(S)
+    _, mag, dr, im, idd = o.shade(Z, True)
+    rgb = o.shade_with_shadow(Z, M)
+    ok = well_conditioned_field(im, idd, g)
+    assert ok.sum() > 50000
+    d = np.abs(rgb - g["rgb_shadow"])
+    assert d[ok].max() <= 1e-5
+    # the fixture really casts shadows on comparable pixels
+    assert np.abs(g["rgb_shadow"] - g["rgb"])[ok].max() > 0.1
+    assert o.shadow_attachment_rounds()[0].tolist() == [2, 2] and o.shadow_attachment_rounds()[1].tolist() == [3, 3]
+    # small images: blur kernels degenerate to k=1, no boundary pixel casts a shadow -> identical to the plain path
+    g48 = _load(golden_dir, 48, 64)
+    o48 = TaximOracle(calib_dir, (48, 64), "direct")
+    r48 = o48.render_direct(g48["hm"], g48["indent"], with_shadow=True)
+    strong = g48["grad_mag"] > 1e-3
+    assert np.quantile(np.abs(r48 - g48["rgb_shadow"])[strong], 0.99) <= 1e-4

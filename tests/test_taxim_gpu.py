@@ -120,8 +120,6 @@ def test_resize_kernel_matches_torch():
 
 
 def test_errors_are_loud(taxim):
-    with pytest.raises(NotImplementedError):
-        taxim.render_direct(torch.zeros((1, 32, 32), device="cuda"), with_shadow=True)
     with pytest.raises(ValueError):
         taxim.render_direct(torch.zeros((1, 32, 32)), with_shadow=False)  # CPU tensor
     from tacex_amd.simulation_approaches.gpu_taxim.sim import Taxim
@@ -183,3 +181,34 @@ def test_policy_observation_downsample_matches_torch(taxim):
                                                      0 if t is None else t.data_ptr(), torch.cuda.current_stream().cuda_stream), "resize")
         ref = torch.nn.functional.interpolate(x.movedim(3, 1), size=[32, 32], mode="bilinear", antialias=True).movedim(1, 3)
         assert (y.cpu() - ref).abs().max() < 1e-5
+
+
+def test_shadow_branch_vs_reference_and_oracle(taxim, golden_dir, calib_dir):
+    """with_shadow=True (TT:260-346): ring detection, 4x51 ray march with float atomic-min, two image blurs.
+    vs the reference on pixels whose 7x7 receptive field is well conditioned, and vs the oracle everywhere except where
+    a single ray sample flips (float32 cos/sin + truncation sit on integer boundaries for a handful of samples)."""
+    from oracle.taxim_oracle import TaximOracle
+    from parity import well_conditioned_field
+
+    g = dict(np.load(golden_dir / "taxim_240x320.npz"))
+    hm = torch.from_numpy(g["hm"]).cuda()
+    indent = torch.from_numpy(g["indent"]).cuda()
+    rgb = taxim.render_direct(hm, with_shadow=True, press_depth=indent).movedim(1, 3).cpu().numpy()
+    assert rgb.shape == g["rgb_shadow"].shape and rgb.min() >= 0 and rgb.max() <= 1
+    Z, M = taxim.deform(hm, indent)
+    _, idx = taxim.shade(Z, return_bins=True)
+    idx = idx.cpu().numpy().astype(np.int64)
+    ok = well_conditioned_field(idx[..., 0], idx[..., 1], g)
+    assert ok.sum() > 50000
+    d = np.abs(rgb - g["rgb_shadow"])
+    assert np.quantile(d[ok], 0.999) <= 1e-4, np.quantile(d[ok], 0.999)
+    assert (d[ok] > 1e-3).mean() < 2e-3
+    assert np.abs(g["rgb_shadow"] - g["rgb"])[ok].max() > 0.1  # shadows are really cast there
+    o = TaximOracle(calib_dir, (240, 320), "direct")
+    ref = o.render_direct(g["hm"], g["indent"], with_shadow=True)
+    do = np.abs(rgb - ref)
+    # a bin flip (0.4 % of strong pixels) is smeared over its 7x7 neighbourhood by the two blurs
+    assert np.quantile(do, 0.99) <= 1e-4, np.quantile(do, 0.99)
+    assert (do > 1e-3).mean() < 5e-3
+    # no-contact frame: no ring -> both blurs of (flat shade + background) only
+    assert do[-1].max() <= 1e-5
