@@ -118,6 +118,11 @@ int tacex_taxim_create(int device_id, const tacex_taxim_params* p, tacex_taxim_c
                              memcmp(p->taps_w[l], p->taps_h[l], sizeof(float) * p->ksize_w[l]) == 0;
     rc |= upload(c, p->taps_w[l], (size_t)p->ksize_w[l], &c->levels[l].taps_w_dev);
     rc |= upload(c, p->taps_h[l], (size_t)p->ksize_h[l], &c->levels[l].taps_h_dev);
+    if (c->levels[l].same_taps && !rc) {
+      std::vector<float> pad((size_t)p->ksize_w[l] + 64, 0.0f);
+      for (int k = 0; k < p->ksize_w[l]; ++k) pad[16 + k] = p->taps_w[l][k];
+      rc |= upload(c, pad.data(), pad.size(), &c->levels[l].taps_pad_dev);
+    }
   }
   if (!rc) rc |= upload(c, p->gel_map, npix, &c->gel_dev);
   // polynomial table (3, nb, nb, 6) -> (nb, nb, 24): one 96-byte, 16-byte-aligned record per bin

@@ -16,6 +16,7 @@
 // Both passes are "tap x window" FMA loops on float2 so the compiler can use v_pk_fma_f32.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include <type_traits>
 
@@ -258,6 +259,157 @@ __global__ __launch_bounds__(NT, 3) void blur_band_kernel(BlurArgs a) {
           const bool M = ((J - gv[k]) < thr) && (S < 0.0f);  // TT:457-461
           const float bl = h == 0 ? acc[r4 + k].x : acc[r4 + k].y;
           outv[r4 + k] = (a.restore && M) ? J : bl;         // TT:467
+          mk[r4 + k] = M ? 1 : 0;
+        }
+      }
+#pragma unroll
+      for (int r4 = 0; r4 < RH; r4 += 4) {
+        v4f o = {outv[r4], outv[r4 + 1], outv[r4 + 2], outv[r4 + 3]};
+        *reinterpret_cast<v4f*>(a.dst + fo + ro + r4) = o;
+      }
+      if (a.mask_out) {
+#pragma unroll
+        for (int r4 = 0; r4 < RH; r4 += 4) {
+          uchar4 u = {mk[r4], mk[r4 + 1], mk[r4 + 2], mk[r4 + 3]};
+          *reinterpret_cast<uchar4*>(a.mask_out + fo + ro + r4) = u;
+        }
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// looped band kernel: same band / LDS / row-pair structure as blur_band_kernel, but the tap dimension is a RUNTIME
+// loop over groups of G streamed elements with zero-padded taps (wq[OFF + t] = w[t], 0 outside [0,K)).  Used where a
+// full compile-time unroll is not viable (k = 117 at 640x480: 2 x 16 x 117 FMAs per thread and pass).  Cost of the
+// generality: the triangular ends are computed with zero weights, (RV + K - 1 rounded up to G) / K - 1 extra FMAs
+// (+13 % at k = 117).
+// ------------------------------------------------------------------------------------------------
+constexpr int kLoopOff = 16;  // wq index of tap 0 (>= RV - 1 + 1)
+
+template <int TH, int RV, int RH, int G, bool FIRST, int NT>
+__global__ __launch_bounds__(NT, 3) void blur_band_loop_kernel(BlurArgs a, int K) {
+  static_assert(TH % RV == 0 && RV % 2 == 0 && G % 2 == 0 && RV <= kLoopOff, "tile shape");
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  v2f* mid = reinterpret_cast<v2f*>(smem_raw);
+  const int R = (K - 1) / 2, RUP = (R + 1) & ~1;
+  const int H = a.H, W = a.W;
+  const int nbands = (H + TH - 1) / TH;
+  const int lid = xcd_remap(blockIdx.x, gridDim.x);
+  const int frame = lid / nbands;
+  const int band = lid - frame * nbands;
+  const int by0 = band * TH;
+  const size_t fo = (size_t)frame * H * W;
+  const float* __restrict__ src = FIRST ? a.hm + fo : a.src + fo;
+  const float* __restrict__ hm = a.hm + fo;
+  const float* __restrict__ gel = a.gel;
+  const float sa = a.shift_a[frame], sb = a.shift_b[frame];
+  const float* __restrict__ wq = a.taps;  // zero-padded taps
+  const int pitch = a.pitch, padx = a.padx;
+
+  const int ncp = W >> 1;
+  const int wpc = (ncp + 63) >> 6;
+  const int wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int ch = wid / wpc;
+  const int cpair = (wid - ch * wpc) * 64 + (int)(threadIdx.x & 63);
+  if (ch < TH / RV && cpair < ncp) {
+    const int c = cpair << 1;
+    const unsigned coff = (unsigned)c * 4u;
+    const int y0 = by0 + ch * RV;
+    v2f acc[RV];
+#pragma unroll
+    for (int r = 0; r < RV; ++r) acc[r] = (v2f)(0.0f);
+    const int ng = (RV + K - 1 + G - 1) / G;
+#pragma unroll 1
+    for (int g = 0; g < ng; ++g) {
+      v2f xv[G];
+#pragma unroll
+      for (int i = 0; i < G; ++i) {
+        int yy = reflect_idx(y0 - R + g * G + i, H);
+        yy = yy < 0 ? 0 : (yy >= H ? H - 1 : yy);  // beyond the window / partial band: finite data, zero weight
+        const char* rowb = reinterpret_cast<const char*>(src + (size_t)yy * W);
+        v2f x = *reinterpret_cast<const v2f*>(rowb + coff);
+        if (FIRST) {
+          const char* gelb = reinterpret_cast<const char*>(gel + (size_t)yy * W);
+          const v2f gg = *reinterpret_cast<const v2f*>(gelb + coff);
+          x.x = fmin_raw((x.x - sa) - sb, gg.x);
+          x.y = fmin_raw((x.y - sa) - sb, gg.y);
+        }
+        xv[i] = x;
+      }
+      const float* wg = wq + kLoopOff + g * G;  // weight of (element i, output r) = wg[i - r]
+#pragma unroll
+      for (int i = 0; i < G; ++i)
+#pragma unroll
+        for (int r = 0; r < RV; ++r) acc[r] += wg[i - r] * xv[i];
+    }
+    const int rp0 = (ch * RV) >> 1;
+#pragma unroll
+    for (int r = 0; r < RV; r += 2) {
+      v2f* row = mid + (size_t)(rp0 + (r >> 1)) * pitch + padx;
+      v2f e0 = {acc[r].x, acc[r + 1].x};
+      v2f e1 = {acc[r].y, acc[r + 1].y};
+      v4f q = {e0.x, e0.y, e1.x, e1.y};
+      *reinterpret_cast<v4f*>(row + c) = q;
+      if (c >= 1 && c <= padx) row[-c] = e0;
+      if (c + 1 <= padx) row[-(c + 1)] = e1;
+      if (c >= W - 1 - padx && c <= W - 2) row[2 * (W - 1) - c] = e0;
+      if (c + 1 >= W - 1 - padx && c + 1 <= W - 2) row[2 * (W - 1) - (c + 1)] = e1;
+    }
+  }
+  __syncthreads();
+
+  const float P = a.pdepth[frame];
+  const float thr = -P * a.contact_scale;
+  const int nseg = W / RH;
+  const int hitems = (TH >> 1) * ((nseg + 3) & ~3);
+  const int nwin = RH + 2 * RUP;  // float2 elements of the window
+  for (int it = threadIdx.x; it < hitems; it += NT) {
+    const int rp = (it >> 2) % (TH >> 1);
+    const int seg = (it & 3) + ((it >> 2) / (TH >> 1)) * 4;
+    if (seg >= nseg) continue;
+    const int x0 = seg * RH;
+    const v2f* base = mid + (size_t)rp * pitch + padx + x0 - RUP;
+    v2f acc[RH];
+#pragma unroll
+    for (int r = 0; r < RH; ++r) acc[r] = (v2f)(0.0f);
+    const int ng = (nwin + G - 1) / G;
+    const int sh = RUP - R;  // 0 or 1: alignment slack in front of the window
+#pragma unroll 1
+    for (int g = 0; g < ng; ++g) {
+      v2f xv[G];
+#pragma unroll
+      for (int i2 = 0; i2 < G / 2; ++i2) {
+        const int j = g * G + 2 * i2;
+        v4f q = (v4f)(0.0f);
+        if (j < nwin) q = *reinterpret_cast<const v4f*>(base + j);  // never read beyond the row's window
+        xv[2 * i2] = (v2f){q.x, q.y};
+        xv[2 * i2 + 1] = (v2f){q.z, q.w};
+      }
+      const float* wg = wq + kLoopOff + g * G - sh;
+#pragma unroll
+      for (int i = 0; i < G; ++i)
+#pragma unroll
+        for (int r = 0; r < RH; ++r) acc[r] += wg[i - r] * xv[i];
+    }
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int y = by0 + 2 * rp + h;
+      if (y >= H) continue;
+      const size_t ro = (size_t)y * W + x0;
+      float outv[RH];
+      uint8_t mk[RH];
+#pragma unroll
+      for (int r4 = 0; r4 < RH; r4 += 4) {
+        v4f hv = *reinterpret_cast<const v4f*>(hm + ro + r4);
+        v4f gv = *reinterpret_cast<const v4f*>(gel + ro + r4);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const float S = (hv[k] - sa) - sb;
+          const float J = fminf(S, gv[k]);
+          const bool M = ((J - gv[k]) < thr) && (S < 0.0f);
+          const float bl = h == 0 ? acc[r4 + k].x : acc[r4 + k].y;
+          outv[r4 + k] = (a.restore && M) ? J : bl;
           mk[r4 + k] = M ? 1 : 0;
         }
       }
@@ -522,6 +674,41 @@ static hipError_t launch_band(const BlurArgs& a, hipStream_t st) {
   return hipErrorInvalidValue;
 }
 
+template <bool FIRST, int NT>
+static hipError_t launch_band_loop(const BlurArgs& a0, int K, hipStream_t st) {
+  constexpr int TH = 32, RV = 16, RH = 16, G = 12;
+  BlurArgs a = a0;
+  const int R = (K - 1) / 2;
+  a.padx = (R + 1) & ~1;
+  a.pitch = lds_pitch_for(a.W, a.padx);
+  const int nbands = (a.H + TH - 1) / TH;
+  const size_t lds = (size_t)(TH / 2) * a.pitch * sizeof(v2f);
+  auto kern = blur_band_loop_kernel<TH, RV, RH, G, FIRST, NT>;
+  static bool attr_done = false;
+  if (!attr_done && lds > 48 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(nbands * a.B), dim3(NT), lds, st, a, K);
+  return hipGetLastError();
+}
+
+// looped variant: any odd K with identical w/h taps whose mirrored padding fits the row (image >= 2 * radius)
+static int band_loop_min_k() {  // A/B hook: TACEX_BAND_LOOP_MIN_K overrides the smallest k served by the looped kernel
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("TACEX_BAND_LOOP_MIN_K");
+    v = e ? atoi(e) : 35;
+  }
+  return v;
+}
+
+static bool band_loop_supported(int k, int H, int W) {
+  const int R = (k - 1) / 2;
+  return W % 16 == 0 && W >= 32 && W <= 640 && R < H && ((R + 1) & ~1) <= W - 1 && k >= band_loop_min_k();
+}
+
 static bool band_supported(int k, int H, int W) {
   if (W % 16 != 0 || W < 32 || H < 2) return false;
   if (W > 384 && !(W <= 640 && (k == 33 || k == 61))) return false;
@@ -576,6 +763,16 @@ hipError_t run_blur_level(const LevelDesc& lv, const float* src, const float* hm
                           const float* sa, const float* sb, const float* pd, float* dst, float* tmp,
                           uint8_t* mask_out, int B, int H, int W, float contact_scale, int restore,
                           bool first, hipStream_t st) {
+  const bool unrolled_ok = band_supported(lv.kw, H, W) && (!first || band_first_supported(lv.kw));
+  if (lv.same_taps && lv.taps_pad_dev && band_loop_supported(lv.kw, H, W) && (!unrolled_ok || lv.kw >= band_loop_min_k()) &&
+      (band_loop_min_k() != 35 || !unrolled_ok)) {
+    BlurArgs a{};
+    a.src = src; a.hm = hm; a.gel = gel; a.shift_a = sa; a.shift_b = sb; a.pdepth = pd;
+    a.dst = dst; a.mask_out = mask_out; a.taps = lv.taps_pad_dev; a.H = H; a.W = W; a.B = B;
+    a.contact_scale = contact_scale; a.restore = restore;
+    if (W <= 384) return first ? launch_band_loop<true, 384>(a, lv.kw, st) : launch_band_loop<false, 384>(a, lv.kw, st);
+    return first ? launch_band_loop<true, 640>(a, lv.kw, st) : launch_band_loop<false, 640>(a, lv.kw, st);
+  }
   if (lv.same_taps && band_supported(lv.kw, H, W) && (!first || band_first_supported(lv.kw))) {
     BlurArgs a{};
     a.src = src; a.hm = hm; a.gel = gel; a.shift_a = sa; a.shift_b = sb; a.pdepth = pd;
