@@ -218,6 +218,9 @@ class TaximHip:
         batch_shape = tuple(height_map.shape[:-2])
         hm = self._check_hm(height_map)
         B, H, W = hm.shape
+        if B == 0:  # empty batch: nothing to launch
+            empty = torch.empty((0, H, W, 3), dtype=torch.float32, device=self._device) if out is None else out
+            return empty.movedim(3, 1).reshape(batch_shape + (3, H, W))
         ctx = self.context((H, W))
         if orig_hm_fmt:  # taxim_torch.py:185-186
             hm = ctx.tables.gel_map_shift - hm
