@@ -1,0 +1,44 @@
+"""FEM micro-bench (BASELINE config 4 shard: 512 envs x ~2k-tet gelpad on one MI355X): element terms + Newton step."""
+import argparse, sys, time
+from pathlib import Path
+import numpy as np, torch
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+from tacex_amd.uipc import UipcObject, UipcObjectCfg, UipcSim, UipcSimCfg
+from tacex_amd.uipc.uipc_object import gelpad_box_mesh
+
+ap = argparse.ArgumentParser(); ap.add_argument("--envs", type=int, default=512); ap.add_argument("--iters", type=int, default=10)
+a = ap.parse_args()
+P, T = gelpad_box_mesh(8, 10, 4)  # 495 verts / 1920 tets
+B = a.envs
+sim = UipcSim(UipcSimCfg(device="cuda:0"), num_envs=B)
+UipcObject(UipcObjectCfg(mesh_points=P, mesh_tets=T), sim)
+sim.setup_sim()
+top = np.where(P[:, 2] > P[:, 2].max() - 1e-9)[0]
+aim = torch.from_numpy(P[top]).cuda()[None].repeat(B, 1, 1)
+aim[:, :, 2] -= torch.linspace(0.0002, 0.0012, B, device="cuda", dtype=torch.float64)[:, None]
+sim.set_constraints(top, aim)
+sim.x_tilde = sim.x.clone()
+def timeit(fn, n):
+    fn(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(n): fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / n
+nt = B * len(T)
+for name, fn, bytes_per_tet in [
+    ("element_terms energy+grad+hess (assembled)", lambda: sim.element_terms(), 208 + 8 + 96 + 1152),
+    ("element_terms energy+grad", lambda: sim.element_terms(hessian=False), 208 + 8 + 96),
+    ("energy (line-search evaluation)", lambda: sim.energy(), 208),
+    ("gradient (vertex gather)", lambda: sim.gradient(), 208 + 96),
+]:
+    dt = timeit(fn, a.iters)
+    print(f"{name:46s} {dt*1e3:8.3f} ms  {nt/dt/1e9:7.2f} Gtet/s  {nt*bytes_per_tet/dt/1e9:8.1f} GB/s algorithmic")
+x0 = sim.x.clone()
+def newton():
+    sim.x.copy_(x0); sim.newton_step()
+dt = timeit(newton, 5)
+st = sim.stats.cpu().numpy()
+print(f"newton_step (PCG<= {sim.cfg.linear_system.max_iter}, tol {sim.cfg.linear_system.tol_rate}) {dt*1e3:8.3f} ms/iter for {B} envs; pcg iters mean {st[:,3].mean():.1f} max {st[:,3].max():.0f}; step mean {st[:,2].mean():.2f}")
+sim.x.copy_(x0)
+t0 = time.perf_counter(); sim.step(max_newton_iter=8); torch.cuda.synchronize()
+print(f"UipcSim.step (8 Newton iters cap): {(time.perf_counter()-t0)*1e3:.2f} ms, iters {sim.last_newton_iters}")
