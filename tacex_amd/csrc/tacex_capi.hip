@@ -119,6 +119,16 @@ int tacex_taxim_create(int device_id, const tacex_taxim_params* p, tacex_taxim_c
     rc |= upload(c, p->taps_w[l], (size_t)p->ksize_w[l], &c->levels[l].taps_w_dev);
     rc |= upload(c, p->taps_h[l], (size_t)p->ksize_h[l], &c->levels[l].taps_h_dev);
     if (c->levels[l].same_taps && !rc) {
+      const int K = p->ksize_w[l], ks = (32 + K) / 2;
+      std::vector<float> tl((size_t)ks * 64, 0.0f);
+      for (int kk = 0; kk < ks; ++kk)
+        for (int ln = 0; ln < 64; ++ln) {
+          const int t = 2 * kk + (ln >> 5) - (ln & 31);
+          if (t >= 0 && t < K) tl[(size_t)kk * 64 + ln] = p->taps_w[l][t];
+        }
+      rc |= upload(c, tl.data(), tl.size(), &c->levels[l].taps_mfma_dev);
+    }
+    if (c->levels[l].same_taps && !rc) {
       std::vector<float> pad((size_t)p->ksize_w[l] + 64, 0.0f);
       for (int k = 0; k < p->ksize_w[l]; ++k) pad[16 + k] = p->taps_w[l][k];
       rc |= upload(c, pad.data(), pad.size(), &c->levels[l].taps_pad_dev);

@@ -279,6 +279,176 @@ __global__ __launch_bounds__(NT, 3) void blur_band_kernel(BlurArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// MFMA band kernel: the separable Gaussian as two banded-Toeplitz matrix products on the matrix cores.
+//   V-pass: Out[32 x 32] = Tv[32 x (31+K)] * In[(31+K) x 32]   per 32-column block, straight from global/L2
+//   H-pass: Out[32 x 32] = Mid[32 x (31+K)] * Th[(31+K) x 32]  per 32-column block, Mid from LDS
+// with v_mfma_f32_32x32x2_f32: f32 in / f32 accumulate, bit-identical to a k-ordered fmaf chain, issued on the matrix
+// pipe at the f32 vector peak rate but as ONE instruction per 2048 MACs.  The VALU band kernel above spends ~2700 VALU
+// wave-instructions per 1952 packed FMAs and is issue-bound at ~20 % of the roof; here the VALU only computes row
+// indices and the masked restore.  Band waste: the 32 x (31+K) Toeplitz block carries (31+K)/K x the useful MACs
+// (1.5x at K = 61), all of it on the otherwise idle matrix pipe.
+// Per lane l the weight operand of k-step kk is w[(2 kk + (l >> 5)) - (l & 31)] (0 outside the band) for BOTH passes:
+// A[i][k] = w[k - i] with i = l & 31 in the V-pass, B[k][j] = w[k - j] with j = l & 31 in the H-pass.
+// ------------------------------------------------------------------------------------------------
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+template <int K, bool FIRST>
+__global__ __launch_bounds__(640) void blur_mfma_kernel(BlurArgs a) {
+  constexpr int TH = 32;
+  constexpr int R = (K - 1) / 2;
+  constexpr int KS = (TH + K - 1 + 1) / 2;  // k-steps of 2 input rows / columns
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  float* mid = reinterpret_cast<float*>(smem_raw);
+  const int H = a.H, W = a.W;
+  const int pitch = a.pitch, padx = a.padx;  // floats; pitch odd -> column reads of 32 rows hit 32 banks
+  const int nbands = (H + TH - 1) / TH;
+  const int lid = xcd_remap(blockIdx.x, gridDim.x);
+  const int frame = lid / nbands;
+  const int band = lid - frame * nbands;
+  const int by0 = band * TH;
+  const size_t fo = (size_t)frame * H * W;
+  const float* __restrict__ src = FIRST ? a.hm + fo : a.src + fo;
+  const float* __restrict__ hm = a.hm + fo;
+  const float* __restrict__ gel = a.gel;
+  const float sa = a.shift_a[frame], sb = a.shift_b[frame];
+  const int lane = threadIdx.x & 63;
+  const int wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int nwaves = blockDim.x >> 6;
+  const int li = lane & 31, lk = lane >> 5;
+
+  // per-lane band weights, shared by both passes
+  float wl[KS];
+  static_for<0, KS>([&](auto kc) {
+    constexpr int kk = decltype(kc)::value;
+    wl[kk] = a.taps[kk * 64 + lane];  // host-prepared per-lane band table: w[2 kk + (l >> 5) - (l & 31)] or 0
+  });
+
+  const int nblk = W >> 5;
+  // ---- V-pass ----
+  for (int blk = wid; blk < nblk; blk += nwaves) {
+    const int c0 = blk << 5;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+    // all operand loads of the block are issued before the MFMA chain (one load right in front of each MFMA
+    // serialises ~1 us of L2 latency per k-step)
+    float bv[KS], gv[FIRST ? KS : 1];
+    static_for<0, KS>([&](auto kc) {
+      constexpr int kk = decltype(kc)::value;
+      int yy = reflect_idx(by0 - R + 2 * kk + lk, H);
+      yy = yy < 0 ? 0 : (yy >= H ? H - 1 : yy);  // beyond the window / partial band: finite data, zero weight
+      const unsigned off = (unsigned)yy * (unsigned)W + (unsigned)(c0 + li);
+      bv[kk] = src[off];
+      if constexpr (FIRST) gv[kk] = gel[off];
+    });
+    static_for<0, KS>([&](auto kc) {
+      constexpr int kk = decltype(kc)::value;
+      float b = bv[kk];
+      // J = min(S, gel) (TT:441,454).  NOT fmin_raw: an inline-asm VALU write feeding an MFMA operand is invisible to
+      // the hazard recognizer (VALU write -> MFMA SrcA/B read needs wait states) and the MFMA would read a stale register
+      if constexpr (FIRST) b = fminf((b - sa) - sb, gv[kk]);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wl[kk], b, acc, 0, 0, 0);
+    });
+    // D layout: col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = (r & 3) + 8 * (r >> 2) + 4 * lk;
+      mid[row * pitch + padx + c0 + li] = acc[r];
+    }
+  }
+  __syncthreads();
+  // mirrored x-padding (torch 'reflect'): position -c <- c, position (W-1)+c <- (W-1)-c, c = 1..R
+  for (int e = threadIdx.x; e < TH * 2 * R; e += blockDim.x) {
+    const int row = e / (2 * R), q = e - row * (2 * R);
+    const int c = (q >> 1) + 1;
+    float* rp = mid + row * pitch + padx;
+    if (q & 1) rp[W - 1 + c] = rp[W - 1 - c];
+    else rp[-c] = rp[c];
+  }
+  __syncthreads();
+  // ---- H-pass + masked restore ----
+  const float thr = -a.pdepth[frame] * a.contact_scale;  // TT:459
+  for (int blk = wid; blk < nblk; blk += nwaves) {
+    const int c0 = blk << 5;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+    const float* arow = mid + li * pitch + padx + c0 - R + lk;
+    float av[KS];
+    static_for<0, KS>([&](auto kc) {
+      constexpr int kk = decltype(kc)::value;
+      // columns beyond c0 + 31 + R carry zero weights; never read beyond the padded row
+      av[kk] = (c0 - R + lk + 2 * kk < W + R) ? arow[2 * kk] : 0.0f;
+    });
+    static_for<0, KS>([&](auto kc) {
+      constexpr int kk = decltype(kc)::value;
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[kk], wl[kk], acc, 0, 0, 0);
+    });
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int y = by0 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+      if (y < H) {
+        const size_t p = (size_t)y * W + c0 + li;
+        const float g = gel[p];
+        const float S = (hm[p] - sa) - sb;
+        const float J = fmin_raw(S, g);
+        const bool M = ((J - g) < thr) && (S < 0.0f);  // TT:457-461
+        a.dst[fo + p] = (a.restore && M) ? J : acc[r];  // TT:467
+        if (a.mask_out) a.mask_out[fo + p] = M ? 1 : 0;
+      }
+    }
+  }
+}
+
+template <int K, bool FIRST>
+static hipError_t launch_mfma(const BlurArgs& a0, hipStream_t st) {
+  constexpr int TH = 32, R = (K - 1) / 2;
+  BlurArgs a = a0;
+  a.padx = R;
+  a.pitch = (a.W + 2 * R) | 1;  // odd
+  const int nbands = (a.H + TH - 1) / TH;
+  const size_t lds = (size_t)TH * a.pitch * sizeof(float);
+  const int nblk = a.W / 32;
+  const int nthreads = 64 * (nblk < 10 ? nblk : 10);
+  auto kern = blur_mfma_kernel<K, FIRST>;
+  static size_t attr_lds = 0;
+  if (lds > 48 * 1024 && lds > attr_lds) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    attr_lds = lds;
+  }
+  hipLaunchKernelGGL(kern, dim3(nbands * a.B), dim3(nthreads), lds, st, a);
+  return hipGetLastError();
+}
+
+// Experimental (round 1): correct (parity-tested) but not yet faster than the VALU band kernels - 171-211 us vs 150 us
+// for k = 61 at B = 256 although the matrix pipe itself needs only 49 us (SQ_VALU_MFMA_BUSY_CYCLES): the chains wait
+// on dword operand loads and ~2.4 k VALU instructions per wave of index / epilogue work.  Opt in: TACEX_BLUR_MFMA=1.
+static int mfma_enabled() {
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("TACEX_BLUR_MFMA"); v = e ? atoi(e) : 0; }
+  return v;
+}
+
+static bool mfma_supported(int k, bool first, int H, int W) {
+  if (!mfma_enabled() || W % 32 != 0 || W < 64 || W > 2048) return false;
+  const int R = (k - 1) / 2;
+  if (R >= H || R > W - 1) return false;
+  if (first) return k == 61;
+  return k == 61 || k == 33 || k == 17;
+}
+
+static hipError_t dispatch_mfma(int k, bool first, const BlurArgs& a, hipStream_t st) {
+  if (first) return launch_mfma<61, true>(a, st);
+  switch (k) {
+    case 61: return launch_mfma<61, false>(a, st);
+    case 33: return launch_mfma<33, false>(a, st);
+    case 17: return launch_mfma<17, false>(a, st);
+    default: return hipErrorInvalidValue;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // looped band kernel: same band / LDS / row-pair structure as blur_band_kernel, but the tap dimension is a RUNTIME
 // loop over groups of G streamed elements with zero-padded taps (wq[OFF + t] = w[t], 0 outside [0,K)).  Used where a
 // full compile-time unroll is not viable (k = 117 at 640x480: 2 x 16 x 117 FMAs per thread and pass).  Cost of the
@@ -763,6 +933,13 @@ hipError_t run_blur_level(const LevelDesc& lv, const float* src, const float* hm
                           const float* sa, const float* sb, const float* pd, float* dst, float* tmp,
                           uint8_t* mask_out, int B, int H, int W, float contact_scale, int restore,
                           bool first, hipStream_t st) {
+  if (lv.same_taps && lv.taps_mfma_dev && mfma_supported(lv.kw, first, H, W)) {
+    BlurArgs a{};
+    a.src = src; a.hm = hm; a.gel = gel; a.shift_a = sa; a.shift_b = sb; a.pdepth = pd;
+    a.dst = dst; a.mask_out = mask_out; a.taps = lv.taps_mfma_dev; a.H = H; a.W = W; a.B = B;
+    a.contact_scale = contact_scale; a.restore = restore;
+    return dispatch_mfma(lv.kw, first, a, st);
+  }
   const bool unrolled_ok = band_supported(lv.kw, H, W) && (!first || band_first_supported(lv.kw));
   if (lv.same_taps && lv.taps_pad_dev && band_loop_supported(lv.kw, H, W) && (!unrolled_ok || lv.kw >= band_loop_min_k()) &&
       (band_loop_min_k() != 35 || !unrolled_ok)) {

@@ -212,3 +212,33 @@ def test_shadow_branch_vs_reference_and_oracle(taxim, golden_dir, calib_dir):
     assert (do > 1e-3).mean() < 5e-3
     # no-contact frame: no ring -> both blurs of (flat shade + background) only
     assert do[-1].max() <= 1e-5
+
+
+def test_experimental_mfma_band_kernels_parity(calib_dir, golden_dir, tmp_path):
+    """The opt-in MFMA (v_mfma_f32_32x32x2_f32) band kernels must give the same deformation as the default path.
+    The switch is read once per process, so the MFMA run happens in a child process."""
+    import subprocess
+    import sys
+
+    from conftest import REPO
+
+    script = tmp_path / "mfma_run.py"
+    script.write_text(
+        "import sys, numpy as np, torch\n"
+        f"sys.path.insert(0, {str(REPO)!r})\n"
+        "from tacex_amd.simulation_approaches.gpu_taxim.sim import Taxim\n"
+        f"g = np.load({str(golden_dir / 'taxim_240x320.npz')!r})\n"
+        f"t = Taxim(calib_folder={str(calib_dir)!r}, backend='hip', device='cuda:0')\n"
+        "Z, M = t.deform(torch.from_numpy(g['hm']).cuda(), torch.from_numpy(g['indent']).cuda())\n"
+        "np.save(sys.argv[1], Z.cpu().numpy()); np.save(sys.argv[1] + '.m.npy', M.cpu().numpy())\n")
+    outs = {}
+    for flag in ("1", "0"):
+        out = tmp_path / f"z{flag}.npy"
+        env = dict(__import__("os").environ, TACEX_BLUR_MFMA=flag)
+        r = subprocess.run([sys.executable, str(script), str(out)], env=env, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs[flag] = (np.load(out), np.load(str(out) + ".m.npy"))
+    g = np.load(golden_dir / "taxim_240x320.npz")
+    np.testing.assert_array_equal(outs["1"][1], outs["0"][1])
+    assert np.abs(outs["1"][0] - outs["0"][0]).max() <= 2e-6
+    assert np.abs(outs["1"][0] - g["Z"]).max() <= 1e-5
