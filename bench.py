@@ -116,7 +116,8 @@ def main():
         if args.gpus > 1:
             raise SystemExit(f"--gpus {args.gpus} needs `python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py ...` "
                              f"(WORLD_SIZE={world})")
-    shard = init_from_env(args.envs_per_gpu * args.gpus, backend="nccl" if args.gpus > 1 else None)
+    shard = init_from_env(args.envs_per_gpu * args.gpus,
+                          backend="nccl" if (args.gpus > 1 or os.environ.get("TACEX_FORCE_DIST") == "1") else None)
     dev = f"cuda:{shard.local_rank}"
     torch.cuda.set_device(shard.local_rank)
     B = shard.num_local
@@ -153,8 +154,10 @@ def main():
                 obs.pack("markers", out["marker_motion"])
             obs.gather()
 
+    use_dist = dist.is_available() and dist.is_initialized()
+
     def barrier():
-        if shard.world_size > 1:
+        if use_dist:
             dist.barrier()
 
     for i in range(args.warmup):
@@ -169,7 +172,7 @@ def main():
     barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    if shard.world_size > 1:
+    if use_dist:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -259,7 +262,7 @@ def main():
         if cpu is not None:
             line["cpu_baseline"] = cpu
         print(json.dumps(line), flush=True)
-    if shard.world_size > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

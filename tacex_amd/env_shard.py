@@ -46,7 +46,8 @@ def init_from_env(num_envs_total: int, backend: str | None = None) -> ShardInfo:
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", str(rank)))
-    if world > 1 and not dist.is_initialized():
+    force = os.environ.get("TACEX_FORCE_DIST") == "1" and "RANK" in os.environ  # exercise the collective path with 1 rank
+    if (world > 1 or force) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -54,7 +55,9 @@ def init_from_env(num_envs_total: int, backend: str | None = None) -> ShardInfo:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
         if backend == "nccl":
             torch.cuda.set_device(local)
-        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+            dist.init_process_group(backend=backend, rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend=backend, rank=rank, world_size=world)
     lo, hi = shard_range(num_envs_total, rank, world)
     return ShardInfo(rank, world, local, lo, hi)
 
@@ -92,7 +95,7 @@ class ObservationGather:
         return self.local.numel() * self.local.element_size()
 
     def gather(self) -> dict[str, torch.Tensor]:
-        if self.world > 1:
+        if self.world > 1 or (dist.is_available() and dist.is_initialized()):
             dist.all_gather_into_tensor(self.full, self.local)  # the single collective of the step
         else:
             self.full.copy_(self.local)
