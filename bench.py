@@ -48,7 +48,7 @@ def parse():
     return ap.parse_args()
 
 
-def build_sensor(num_envs, H, W, markers, device):
+def build_sensor(num_envs, H, W, markers, device, obs_res=None):
     from tacex_amd import GelSightSensor, GelSightSensorCfg
     from tacex_amd.calibration import CALIB_GELSIGHT_MINI
     from tacex_amd.simulation_approaches.fots import FOTSMarkerSimulatorCfg
@@ -61,7 +61,7 @@ def build_sensor(num_envs, H, W, markers, device):
         data_types=types,
         optical_sim_cfg=TaximSimulatorCfg(calib_folder_path=str(CALIB_GELSIGHT_MINI), gelpad_height=0.0045,
                                           gelpad_to_camera_min_distance=0.024, with_shadow=False,
-                                          tactile_img_res=(W, H), device=device),
+                                          tactile_img_res=(W, H), device=device, policy_obs_res=obs_res),
         marker_motion_sim_cfg=FOTSMarkerSimulatorCfg(tactile_img_res=(W, H), device=device) if markers else None,
         device=device,
     )
@@ -121,7 +121,7 @@ def main():
     dev = f"cuda:{shard.local_rank}"
     torch.cuda.set_device(shard.local_rank)
     B = shard.num_local
-    sensor = build_sensor(B, H, W, markers, dev)
+    sensor = build_sensor(B, H, W, markers, dev, obs_res=(32, 32) if args.gather == "obs32" else None)
     # synthetic camera depth (metres), already resident in HBM; a different seed per shard
     hm_mm, _ = synthetic_depth_maps(B, H, W, seed=1 + shard.rank, device=dev)
     depth_m = (hm_mm / 1000.0).contiguous()
@@ -136,8 +136,6 @@ def main():
         if markers:
             pieces["markers"] = (2, 99, 2)
         obs = ObservationGather(pieces, B, shard.world_size, dev)
-        rgb32 = torch.empty((B, 32, 32, 3), device=dev)
-        rs_tmp = torch.empty((B, 32, W, 3), device=dev)
 
     def step(i: int):
         if markers:
@@ -145,10 +143,7 @@ def main():
         sensor.update(dt=0.01, force_recompute=True)
         if obs is not None:
             out = sensor._data.output
-            rc = lib.tacex_resize_bilinear_aa_nhwc(out["tactile_rgb"].data_ptr(), H, W, rgb32.data_ptr(), 32, 32, 3, B,
-                                                   rs_tmp.data_ptr(), torch.cuda.current_stream().cuda_stream)
-            _lib.check(rc, "tacex_resize_bilinear_aa_nhwc")
-            obs.pack("rgb32", rgb32)
+            obs.pack("rgb32", out["tactile_rgb_obs"])  # produced inside the render pass (fused into the tail kernel)
             obs.pack("indent", sensor.indentation_depth)
             if markers:
                 obs.pack("markers", out["marker_motion"])

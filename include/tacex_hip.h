@@ -131,6 +131,16 @@ int tacex_taxim_render(tacex_taxim_ctx* ctx, const float* hm_mm_dev, const float
                        float* frame_min_dev, float* rgb_dev, float* z_out_dev, uint8_t* mask_out_dev,
                        void* workspace_dev, int num_frames, unsigned flags, void* stream);
 
+/* tacex_taxim_render + the low-resolution POLICY OBSERVATION in the same pass: obs_out_dev (B,obs_h,obs_w,3) is the
+ * antialiased bilinear down-sample of the RGB frame (torchvision resize semantics, as tasks feed 32x32x3 to the policy:
+ * tacex_tasks/.../ball_rolling_tactile_rgb.py:303,318).  Where the fused tail kernel exists the horizontal half of the
+ * filter is accumulated while the frame is still in LDS (the full-resolution frame is never re-read), otherwise it falls
+ * back to the two-pass resize.  obs_scratch_dev: B * max(H * obs_w, obs_h * W) * 3 floats. */
+int tacex_taxim_render_obs(tacex_taxim_ctx* ctx, const float* hm_mm_dev, const float* press_dev, float* frame_min_dev,
+                           float* rgb_dev, float* z_out_dev, uint8_t* mask_out_dev, void* workspace_dev,
+                           float* obs_scratch_dev, float* obs_out_dev, int obs_h, int obs_w, int num_frames,
+                           unsigned flags, void* stream);
+
 /* __get_shifted_height_map + __compute_gel_pad_deformation only (TT:432-473), as the FOTS wrapper calls
  * them (FS:128-129). Same arguments as above without the shading. */
 int tacex_taxim_deform(tacex_taxim_ctx* ctx, const float* hm_mm_dev, const float* press_dev,

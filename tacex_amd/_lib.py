@@ -97,6 +97,7 @@ SIGNATURES = {
     "tacex_height_map_from_depth": (_i, [_vp, _f, _f, _f, _f, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "tacex_indentation_depth": (_i, [_vp, _f, _f, _vp, _vp, _i, _i, _i, _vp]),
     "tacex_taxim_render": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _u, _vp]),
+    "tacex_taxim_render_obs": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _u, _vp]),
     "tacex_taxim_deform": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _u, _vp]),
     "tacex_taxim_shade": (_i, [_vp, _vp, _vp, _vp, _i, _vp]),
     "tacex_resize_bilinear_aa": (_i, [_vp, _i, _i, _vp, _i, _i, _i, _vp]),

@@ -5,6 +5,7 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <algorithm>
 #include <string>
 #include <vector>
 
@@ -48,6 +49,7 @@ struct tacex_taxim_ctx {
   ShadeParams shade;
   ShadowParams shadow;
   float* gel_dev = nullptr;
+  ObsTables obs_tab{};   // filter tables of the last policy-observation size asked for (built on first use)
   std::vector<void*> allocs;
   // profiling
   bool profiling = false;
@@ -189,6 +191,54 @@ void tacex_taxim_destroy(tacex_taxim_ctx* c) {
 
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
+// Triangle-filter taps of torchvision's antialiased bilinear resize (GelSightSensor's 32 x 32 policy observation),
+// one axis: the same fp32 expressions as resize_v_kernel / the oracle's resize_bilinear_aa.
+static void obs_axis_table(int n_in, int n_out, int k, std::vector<int>& lo, std::vector<int>& cnt, std::vector<float>& sum,
+                           std::vector<float>& w) {
+  const float sc = (float)n_in / (float)n_out;
+  const float sup = sc >= 1.0f ? sc : 1.0f, inv = sc >= 1.0f ? 1.0f / sc : 1.0f;
+  lo.resize(n_out); cnt.resize(n_out); sum.resize(n_out); w.assign((size_t)n_out * k, 0.0f);
+  for (int o = 0; o < n_out; ++o) {
+    const float center = sc * ((float)o + 0.5f);
+    const int a = std::max(0, (int)(center - sup + 0.5f)), b = std::min(n_in, (int)(center + sup + 0.5f));
+    lo[o] = a; cnt[o] = b - a;
+    float s = 0.0f;
+    for (int y = a; y < b; ++y) {
+      const float t = ((float)y - center + 0.5f) * inv;
+      const float v = fmaxf(0.0f, 1.0f - fabsf(t));
+      w[(size_t)o * k + (y - a)] = v;
+      s += v;
+    }
+    sum[o] = s;
+  }
+}
+
+static int ensure_obs_tables(tacex_taxim_ctx* c, int oh, int ow) {
+  if (c->obs_tab.oh == oh && c->obs_tab.ow == ow) return 0;
+  ObsTables t{};
+  t.oh = oh; t.ow = ow;
+  t.ky = 2 * (int)ceilf((float)c->H / oh) + 2;
+  t.kx = 2 * (int)ceilf((float)c->W / ow) + 2;
+  std::vector<int> lo, cnt; std::vector<float> sum, w;
+  int *dlo, *dcnt; float *dsum, *dw;
+  obs_axis_table(c->H, oh, t.ky, lo, cnt, sum, w);
+  if (int rc = upload(c, lo.data(), lo.size(), &dlo)) return rc;
+  if (int rc = upload(c, cnt.data(), cnt.size(), &dcnt)) return rc;
+  if (int rc = upload(c, sum.data(), sum.size(), &dsum)) return rc;
+  if (int rc = upload(c, w.data(), w.size(), &dw)) return rc;
+  t.ylo = dlo; t.ycnt = dcnt; t.ysum = dsum; t.wy = dw;
+  t.ymax = *std::max_element(cnt.begin(), cnt.end());
+  obs_axis_table(c->W, ow, t.kx, lo, cnt, sum, w);
+  if (int rc = upload(c, lo.data(), lo.size(), &dlo)) return rc;
+  if (int rc = upload(c, cnt.data(), cnt.size(), &dcnt)) return rc;
+  if (int rc = upload(c, sum.data(), sum.size(), &dsum)) return rc;
+  if (int rc = upload(c, w.data(), w.size(), &dw)) return rc;
+  t.xlo = dlo; t.xcnt = dcnt; t.xsum = dsum; t.wx = dw;
+  t.xmax = *std::max_element(cnt.begin(), cnt.end());
+  c->obs_tab = t;
+  return 0;
+}
+
 int tacex_taxim_set_shadow(tacex_taxim_ctx* c, const tacex_shadow_params* p) {
   if (!c || !p || !p->fan_angles || !p->table || !p->blur_taps_w || !p->blur_taps_h) { set_error("tacex_taxim_set_shadow: null argument"); return 2; }
   if (p->num_directions < 1 || p->num_fan_rays < 1 || p->num_heights < 2 || p->num_steps < 1 || p->blur_kw % 2 != 1 || p->blur_kh % 2 != 1) {
@@ -306,7 +356,8 @@ int tacex_indentation_depth(const float* hm_mm, float gelpad_h, float gelpad_dmi
 }
 
 static int pipeline_impl(tacex_taxim_ctx* c, const float* hm, const float* press, float* frame_min, float* rgb,
-                         float* z_out, uint8_t* mask_out, void* ws, int B, unsigned flags, hipStream_t st) {
+                         float* z_out, uint8_t* mask_out, void* ws, int B, unsigned flags, hipStream_t st,
+                         float* obs_h = nullptr, float* obs = nullptr, int obs_hh = 0, int obs_w = 0) {
   const size_t img = align_up((size_t)B * c->H * c->W * sizeof(float), 256);
   const size_t vec = align_up((size_t)B * sizeof(float), 256);
   char* w = static_cast<char*>(ws);
@@ -337,15 +388,28 @@ static int pipeline_impl(tacex_taxim_ctx* c, const float* hm, const float* press
   if (n_fused > 0) {
     // trailing small-kernel levels (+ restores) and the shading in one LDS-tiled kernel
     StageTimer t(c, st, c->n_levels + 2);
-    HIP_TRY(run_tail(c->levels, c->n_levels, n_fused, src, hm, c->gel_dev, sa, sb, pd, z_out, mask_out, &c->shade, rgb, B,
-                     c->H, c->W, c->contact_scale, st),
+    // fused observation: needs down-sampling factors >= 7.5 (y) / 8 (x) (cell-count bounds of the tile) and scratch room
+    bool fuse_obs = false;
+    if (obs_h && obs && rgb) {
+      if (int rc = ensure_obs_tables(c, obs_hh, obs_w)) return rc;
+      fuse_obs = obs_fusable(c->obs_tab, c->H, c->W) &&
+                 obs_part_floats(c->H, c->W, B) <= (size_t)B * (size_t)(c->H * obs_w > obs_hh * c->W ? c->H * obs_w : obs_hh * c->W) * 3;
+    }
+    HIP_TRY(run_tail(c->levels, c->n_levels, n_fused, src, hm, c->gel_dev, sa, sb, pd, z_out, mask_out, &c->shade, rgb,
+                     fuse_obs ? obs_h : nullptr, fuse_obs ? &c->obs_tab : nullptr, B, c->H, c->W, c->contact_scale, st),
             "taxim_tail_kernel");
+    if (fuse_obs) {
+      HIP_TRY(run_obs_finish(obs_h, obs, c->obs_tab, c->H, c->W, B, st), "obs_finish_kernel");
+    } else if (obs && rgb) {  // no fusable geometry: plain two-pass down-sample of the finished frame (obs_h = scratch)
+      HIP_TRY(run_resize_aa(rgb, c->H, c->W, obs, obs_hh, obs_w, B, 3, obs_h, st), "resize_aa (observation)");
+    }
     return 0;
   }
   if (rgb) {
     StageTimer t(c, st, c->n_levels + 1);
     HIP_TRY(run_shade(c->shade, src, rgb, nullptr, B, st), "shade_kernel");
   }
+  if (obs && rgb) HIP_TRY(run_resize_aa(rgb, c->H, c->W, obs, obs_hh, obs_w, B, 3, obs_h, st), "resize_aa (observation)");
   return 0;
 }
 
@@ -387,6 +451,19 @@ int tacex_taxim_render(tacex_taxim_ctx* c, const float* hm, const float* press, 
     return 0;
   }
   return pipeline_impl(c, hm, press, frame_min, rgb, z_out, mask_out, ws, B, flags, (hipStream_t)stream);
+}
+
+/* render + low-resolution policy observation in the same pass */
+int tacex_taxim_render_obs(tacex_taxim_ctx* c, const float* hm, const float* press, float* frame_min, float* rgb,
+                           float* z_out, uint8_t* mask_out, void* ws, float* obs_scratch, float* obs_out, int obs_h,
+                           int obs_w, int B, unsigned flags, void* stream) {
+  if (!c || !hm || !frame_min || !rgb || !ws || !obs_scratch || !obs_out) { set_error("tacex_taxim_render_obs: null argument"); return 2; }
+  if (obs_h <= 0 || obs_w <= 0 || obs_h > c->H || obs_w > c->W) { set_error("tacex_taxim_render_obs: bad observation size %dx%d", obs_w, obs_h); return 2; }
+  if (!press && !(flags & TACEX_FLAG_NO_SHIFT)) { set_error("tacex_taxim_render_obs: press_dev is null"); return 2; }
+  if (flags & TACEX_FLAG_WITH_SHADOW) { set_error("tacex_taxim_render_obs: not available with TACEX_FLAG_WITH_SHADOW"); return 2; }
+  if (B <= 0) return 0;
+  return pipeline_impl(c, hm, press, frame_min, rgb, z_out, mask_out, ws, B, flags, (hipStream_t)stream, obs_scratch, obs_out,
+                       obs_h, obs_w);
 }
 
 /* test / ablation hook: 0 = run every level as its own kernel + separate shade, 1 = fused tail (default) */

@@ -53,9 +53,21 @@ hipError_t run_shadow(const ShadowParams& sw, const ShadeParams& sp, const float
 
 // fused tail (taxim_tail.hip): trailing small-kernel levels + shading in one LDS-tiled kernel
 int tail_levels(const LevelDesc* lv, int n_levels, int H, int W);
+// triangle-filter tables of the antialiased policy-observation down-sample (one entry per output row / column):
+// first source index, tap count, the un-normalised taps (stride ky / kx) and their sum - built once per (oh, ow)
+struct ObsTables {
+  const int* ylo; const int* ycnt; const float* ysum; const float* wy; int ky;
+  const int* xlo; const int* xcnt; const float* xsum; const float* wx; int kx;
+  int oh, ow;
+  int ymax, xmax;  // longest filter (taps) per axis
+};
 hipError_t run_tail(const LevelDesc* lv, int n_levels, int n_fused, const float* zin, const float* hm, const float* gel,
                     const float* sa, const float* sb, const float* pd, float* z_out, uint8_t* mask_out,
-                    const ShadeParams* sp, float* rgb, int B, int H, int W, float contact_scale, hipStream_t st);
+                    const ShadeParams* sp, float* rgb, float* obs_part, const ObsTables* obs_tab, int B, int H, int W,
+                    float contact_scale, hipStream_t st);
+hipError_t run_obs_finish(const float* part, float* obs, const ObsTables& t, int H, int W, int B, hipStream_t st);
+size_t obs_part_floats(int H, int W, int B);
+bool obs_fusable(const ObsTables& t, int H, int W);  // geometry the fused tail reduction is compiled for
 
 // thread-local error string (tacex_last_error)
 void set_error(const char* fmt, ...);

@@ -17,6 +17,10 @@
 namespace tacex {
 
 constexpr int kTailMaxLevels = 5;
+// observation cells a 64 x 32 tile can overlap when the down-sampling factor is >= 7.5 (y) / >= 8 (x): tile / scale + 3
+constexpr int kObsNRY = 8, kObsNCX = 11;
+// longest triangle filter the fused observation handles (taps per output row / column); longer ones take the two-pass resize
+constexpr int kObsKY = 16, kObsKX = 24;
 
 struct TailArgs {
   const float* zin;      // (B,H,W) output of the last band-kernel level
@@ -31,6 +35,8 @@ struct TailArgs {
   ShadeArgs sh;          // sh.rgb == nullptr -> deformation only
   int H, W, B;
   float contact_scale;
+  float* obs_part;       // nullable: per-tile partial sums of the policy observation, [tile][kObsNRY][kObsNCX][3]
+  ObsTables obs;         // filter tables of the observation (valid when obs_part != nullptr)
 };
 
 template <int... KS>
@@ -216,7 +222,13 @@ __global__ __launch_bounds__(512) void taxim_tail_kernel(TailArgs a) {
     const int sidx = tid + k * NT;                 // strip index within the tile
     const int oy = sidx / (TW / 4), ox = (sidx - oy * (TW / 4)) * 4;
     const int gy = ty0 + oy, gx = tx0 + ox;
-    if (gy >= H || gx >= W) continue;
+    if (gy >= H || gx >= W) {  // tile overhang: only the observation staging must not hold stale (possibly non-finite) data
+      if (a.obs_part && a.sh.rgb) {
+        float* sg = bufB + oy * (TW * 3) + ox * 3;
+        reinterpret_cast<v4f*>(sg)[0] = (v4f)(0.0f); reinterpret_cast<v4f*>(sg)[1] = (v4f)(0.0f); reinterpret_cast<v4f*>(sg)[2] = (v4f)(0.0f);
+      }
+      continue;
+    }
     const int ly = oy + HLY, lx = ox + HLX;
     const size_t p = (size_t)gy * W + gx;
     const float* crow = bufA + (ly + PADY) * P + PADX + lx;
@@ -240,6 +252,12 @@ __global__ __launch_bounds__(512) void taxim_tail_kernel(TailArgs a) {
         const int xc = min(max(gxi, 1), W - 2) - gx0;
         shade_pixel_rgb(a.sh, rc[xc - P], rc[xc + P], rc[xc - 1], rc[xc + 1], gxi, gy, rgb + 3 * i);
       }
+      if (a.obs_part) {  // stage the strip for the observation reduction below (bufB is free after the last V-pass)
+        float* sg = bufB + oy * (TW * 3) + ox * 3;
+        reinterpret_cast<v4f*>(sg)[0] = (v4f){rgb[0], rgb[1], rgb[2], rgb[3]};
+        reinterpret_cast<v4f*>(sg)[1] = (v4f){rgb[4], rgb[5], rgb[6], rgb[7]};
+        reinterpret_cast<v4f*>(sg)[2] = (v4f){rgb[8], rgb[9], rgb[10], rgb[11]};
+      }
       float* o = a.sh.rgb + ((size_t)frame * H * W + p) * 3;
       if (fast_w) {
         reinterpret_cast<v4f*>(o)[0] = (v4f){rgb[0], rgb[1], rgb[2], rgb[3]};
@@ -250,6 +268,135 @@ __global__ __launch_bounds__(512) void taxim_tail_kernel(TailArgs a) {
       }
     }
   }
+  // ---- policy observation (torchvision antialiased bilinear = separable triangle filter of support H/oh x W/ow):
+  //      the tile reduces its own pixels vertically, then horizontally, to the <= NRY x NCX observation cells it
+  //      overlaps and stores these PARTIAL sums (un-normalised) in its own slot of obs_part; obs_finish_kernel adds
+  //      the <= 4 partials of a cell in a fixed order.  No atomics, no memset, the full-resolution frame is not re-read.
+  if (a.obs_part && a.sh.rgb) {
+    constexpr int NRY = kObsNRY, NCX = kObsNCX, KY = kObsKY, KX = kObsKX, TWC = TW * 3;
+    static_assert(TH * TWC <= ROWS * P && NRY * TWC <= ROWS * P, "rgb staging / vertical partials must fit a ping-pong buffer");
+    static_assert(TWC % 64 == 0 && NT % 64 == 0 && (NRY * TWC) % NT == 0, "a wave stays inside one observation row in the vertical pass");
+    static_assert(KY <= TH && KX <= TW && KY % 4 == 0 && KX % 4 == 0 && NRY * KY + NCX * KX + NRY + NCX <= RH * P, "tap windows");
+    float* v1 = bufA;                  // [NRY][TWC]; the final level is dead once every strip of the epilogue is shaded
+    float* wly = bufJ;                 // [NRY][KY] taps of cell row j over the KY tile rows starting at wby[j] (0 outside its support)
+    float* wlx = wly + NRY * KY;       // [NCX][KX] same for the cell columns
+    int* wby = reinterpret_cast<int*>(wlx + NCX * KX);  // [NRY] first row of the window (tile-relative)
+    int* wbx = wby + NRY;                                // [NCX]
+    const ObsTables& T = a.obs;
+    const float scy = (float)H / (float)T.oh, scx = (float)W / (float)T.ow;
+    const int oy0 = max(0, (int)floorf(((float)ty0 - scy) / scy));
+    const int ox0 = max(0, (int)floorf(((float)tx0 - scx) / scx));
+    // J is dead after the last restore: build this tile's tap windows there.  A window is KY (KX) consecutive tile rows
+    // (columns) that cover support(cell) ^ tile, so the reductions below run fixed, fully unrolled trip counts with
+    // immediate LDS offsets - every load of an item is in flight at once instead of one latency per tap.
+    if (tid < NRY * KY) {
+      const int j = tid / KY, t = tid - j * KY, oy = oy0 + j;
+      float w = 0.0f;
+      int base = 0;
+      if (oy < T.oh) {
+        const int flo = T.ylo[oy];
+        base = min(max(flo, ty0), ty0 + TH - KY);
+        const int k = base + t - flo;  // tap index of tile row base + t
+        if (k >= 0 && k < T.ycnt[oy] && base + t < H) w = T.wy[(size_t)oy * T.ky + k];
+        base -= ty0;
+      }
+      wly[tid] = w;
+      if (t == 0) wby[j] = base;
+    }
+    if (tid < NCX * KX) {
+      const int q = tid / KX, t = tid - q * KX, ox = ox0 + q;
+      float w = 0.0f;
+      int base = 0;
+      if (ox < T.ow) {
+        const int flo = T.xlo[ox];
+        base = min(max(flo, tx0), tx0 + TW - KX);
+        const int k = base + t - flo;
+        if (k >= 0 && k < T.xcnt[ox] && base + t < W) w = T.wx[(size_t)ox * T.kx + k];
+        base -= tx0;
+      }
+      wlx[tid] = w;
+      if (t == 0) wbx[q] = base;
+    }
+    __syncthreads();
+    // vertical: item = (cell row j, column*channel xc); j is wave-uniform
+#pragma unroll
+    for (int r = 0; r < (NRY * TWC) / NT; ++r) {
+      const int it = tid + r * NT;
+      const int j = __builtin_amdgcn_readfirstlane(it / TWC), xc = it - j * TWC;
+      const float* sg = bufB + wby[j] * TWC + xc;
+      const v4f* wv = reinterpret_cast<const v4f*>(wly + j * KY);
+      float acc = 0.0f;
+      static_for<0, KY / 4>([&](auto tc) {
+        constexpr int t = decltype(tc)::value * 4;
+        const v4f w = wv[t / 4];
+        acc = fmaf(w.x, sg[t * TWC], acc);
+        acc = fmaf(w.y, sg[(t + 1) * TWC], acc);
+        acc = fmaf(w.z, sg[(t + 2) * TWC], acc);
+        acc = fmaf(w.w, sg[(t + 3) * TWC], acc);
+      });
+      v1[j * TWC + xc] = acc;
+    }
+    __syncthreads();
+    float* part = a.obs_part + (size_t)lid * (NRY * NCX * 3);  // lid = frame * tiles_per_frame + tile index
+    if (tid < NRY * NCX * 3) {  // horizontal: item = (cell row j, cell column q, channel)
+      const int ch = tid % 3, q = (tid / 3) % NCX, j = tid / (3 * NCX);
+      const float* sg = v1 + j * TWC + wbx[q] * 3 + ch;
+      const v4f* wv = reinterpret_cast<const v4f*>(wlx + q * KX);
+      float acc = 0.0f;
+      static_for<0, KX / 4>([&](auto tc) {
+        constexpr int t = decltype(tc)::value * 4;
+        const v4f w = wv[t / 4];
+        acc = fmaf(w.x, sg[t * 3], acc);
+        acc = fmaf(w.y, sg[(t + 1) * 3], acc);
+        acc = fmaf(w.z, sg[(t + 2) * 3], acc);
+        acc = fmaf(w.w, sg[(t + 3) * 3], acc);
+      });
+      part[tid] = acc;
+    }
+  }
+}
+
+// adds the per-tile partial sums of every observation cell in a fixed order and normalises by the weight sums
+__global__ __launch_bounds__(256) void obs_finish_kernel(const float* __restrict__ part, float* __restrict__ obs, ObsTables T,
+                                                        int H, int W, int B, int ntx, int nty, int TW, int TH) {
+  constexpr int NRY = kObsNRY, NCX = kObsNCX;
+  const int oh = T.oh, ow = T.ow;
+  const size_t n = (size_t)B * oh * ow * 3;
+  const float scy = (float)H / oh, scx = (float)W / ow;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const int ch = i % 3, ox = (i / 3) % ow, oy = (i / (3 * (size_t)ow)) % oh, b = i / (3 * (size_t)ow * oh);
+    const int ylo = T.ylo[oy], yhi = ylo + T.ycnt[oy], xlo = T.xlo[ox], xhi = xlo + T.xcnt[ox];
+    float acc = 0.0f;
+    for (int ty = ylo / TH; ty <= (yhi - 1) / TH; ++ty) {
+      const int oy0 = max(0, (int)floorf(((float)(ty * TH) - scy) / scy));
+      for (int tx = xlo / TW; tx <= (xhi - 1) / TW; ++tx) {
+        const int ox0 = max(0, (int)floorf(((float)(tx * TW) - scx) / scx));
+        const int j = oy - oy0, q = ox - ox0;
+        if (j < 0 || j >= NRY || q < 0 || q >= NCX) continue;  // cannot happen for the scales run_tail accepts
+        const size_t tile = ((size_t)b * nty + ty) * ntx + tx;
+        acc += part[(tile * NRY * NCX + (size_t)j * NCX + q) * 3 + ch];
+      }
+    }
+    obs[i] = acc / (T.xsum[ox] * T.ysum[oy]);
+  }
+}
+
+hipError_t run_obs_finish(const float* part, float* obs, const ObsTables& t, int H, int W, int B, hipStream_t st) {
+  const int TW = 64, TH = 32;
+  const int ntx = (W + TW - 1) / TW, nty = (H + TH - 1) / TH;
+  const size_t n = (size_t)B * t.oh * t.ow * 3;
+  const int grid = (int)((n + 255) / 256 < 65536 ? (n + 255) / 256 : 65536);
+  hipLaunchKernelGGL(obs_finish_kernel, dim3(grid), dim3(256), 0, st, part, obs, t, H, W, B, ntx, nty, TW, TH);
+  return hipGetLastError();
+}
+
+bool obs_fusable(const ObsTables& t, int H, int W) {
+  return (float)H / t.oh >= 7.5f && (float)W / t.ow >= 8.0f && t.ymax <= kObsKY && t.xmax <= kObsKX && W % 4 == 0;
+}
+
+size_t obs_part_floats(int H, int W, int B) {
+  const int ntx = (W + 63) / 64, nty = (H + 31) / 32;
+  return (size_t)B * ntx * nty * kObsNRY * kObsNCX * 3;
 }
 
 template <int... KS>
@@ -287,8 +434,11 @@ int tail_levels(const LevelDesc* lv, int n_levels, int H, int W) {
 
 hipError_t run_tail(const LevelDesc* lv, int n_levels, int n_fused, const float* zin, const float* hm, const float* gel,
                     const float* sa, const float* sb, const float* pd, float* z_out, uint8_t* mask_out,
-                    const ShadeParams* sp, float* rgb, int B, int H, int W, float contact_scale, hipStream_t st) {
+                    const ShadeParams* sp, float* rgb, float* obs_part, const ObsTables* obs_tab, int B, int H, int W,
+                    float contact_scale, hipStream_t st) {
   TailArgs a{};
+  a.obs_part = obs_tab ? obs_part : nullptr;
+  if (a.obs_part) a.obs = *obs_tab;
   a.zin = zin; a.hm = hm; a.gel = gel; a.shift_a = sa; a.shift_b = sb; a.pdepth = pd; a.z_out = z_out; a.mask_out = mask_out;
   a.H = H; a.W = W; a.B = B; a.contact_scale = contact_scale;
   for (int i = 0; i < n_fused; ++i) a.taps[i] = lv[n_levels - n_fused + i].taps_w_dev;

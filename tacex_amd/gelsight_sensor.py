@@ -167,6 +167,8 @@ class GelSightSensor(SensorBase):
                 self._data.output["tactile_rgb"] = buf
             else:
                 self._data.output["tactile_rgb"] = torch.zeros((self._num_envs, H, W, 3), device=self._device)
+            if getattr(self.optical_simulator, "policy_obs", None) is not None:
+                self._data.output["tactile_rgb_obs"] = self.optical_simulator.policy_obs
         if "marker_motion" in self.cfg.data_types:
             if self.cfg.marker_motion_sim_cfg is None:
                 raise RuntimeError("data type 'marker_motion' needs a marker_motion_sim_cfg")

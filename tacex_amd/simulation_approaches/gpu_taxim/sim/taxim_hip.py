@@ -86,6 +86,7 @@ class TaximHip:
         self._ctx: dict[tuple[int, int], _ShapeCtx] = {}
         self._ws: dict[tuple[int, int], torch.Tensor] = {}
         self._fmin: dict[tuple[int, int], torch.Tensor] = {}
+        self._obs_scratch: dict[tuple[int, int], torch.Tensor] = {}
         self._bg_full = None
         self._lib = _lib.load_library()
 
@@ -208,8 +209,12 @@ class TaximHip:
         frame_min: torch.Tensor | None = None,
         z_out: torch.Tensor | None = None,
         mask_out: torch.Tensor | None = None,
+        obs_out: torch.Tensor | None = None,
     ) -> torch.Tensor:
         """(..., H, W) mm height map -> (..., 3, H, W) RGB in [0,1] (a channel-first VIEW of an NHWC buffer).
+
+        `obs_out` (B, oh, ow, 3): additionally produce the antialiased low-resolution policy observation in the same
+        pass (fused into the tail kernel where one exists).
 
         Extra keyword arguments (not in the reference): `out` (B,H,W,3) buffer to render into,
         `frame_min` (B,) precomputed per-frame minimum, `z_out` / `mask_out` to also return the deformed gel
@@ -243,10 +248,24 @@ class TaximHip:
         ws = self._workspace(ctx, (H, W), B, with_shadow)
         with torch.cuda.device(self._device):
             stream = _lib.current_stream_handle(self._device)
-            rc = self._lib.tacex_taxim_render(
-                ctx.handle, _lib.ptr(hm), _lib.ptr(press), _lib.ptr(fmin), _lib.ptr(out), _lib.ptr(z_out),
-                _lib.ptr(mask_out), _lib.ptr(ws), B, flags, stream)
-        _lib.check(rc, "tacex_taxim_render")
+            if obs_out is not None and not with_shadow:
+                if obs_out.dim() != 4 or obs_out.shape[0] != B or obs_out.shape[3] != 3 or not obs_out.is_contiguous():
+                    raise ValueError("obs_out must be a contiguous float32 (B, oh, ow, 3) tensor")
+                oh, ow = int(obs_out.shape[1]), int(obs_out.shape[2])
+                need = B * max(H * ow, oh * W) * 3
+                sc = self._obs_scratch.get((H, W))
+                if sc is None or sc.numel() < need:
+                    sc = torch.empty(need, dtype=torch.float32, device=self._device)
+                    self._obs_scratch[(H, W)] = sc
+                rc = self._lib.tacex_taxim_render_obs(
+                    ctx.handle, _lib.ptr(hm), _lib.ptr(press), _lib.ptr(fmin), _lib.ptr(out), _lib.ptr(z_out),
+                    _lib.ptr(mask_out), _lib.ptr(ws), _lib.ptr(sc), _lib.ptr(obs_out), oh, ow, B, flags, stream)
+                _lib.check(rc, "tacex_taxim_render_obs")
+            else:
+                rc = self._lib.tacex_taxim_render(
+                    ctx.handle, _lib.ptr(hm), _lib.ptr(press), _lib.ptr(fmin), _lib.ptr(out), _lib.ptr(z_out),
+                    _lib.ptr(mask_out), _lib.ptr(ws), B, flags, stream)
+                _lib.check(rc, "tacex_taxim_render")
         return out.movedim(3, 1).reshape(batch_shape + (3, H, W))
 
     def deform(self, height_map: torch.Tensor, press_depth, frame_min: torch.Tensor | None = None,

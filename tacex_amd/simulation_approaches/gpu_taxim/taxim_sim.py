@@ -48,6 +48,10 @@ class TaximSimulator(GelSightSimulator):
         self._contact_mask = None
         self._deformation_version = -1
         self._resized_hm = None
+        self.policy_obs = None
+        if getattr(self.cfg, "policy_obs_res", None) is not None:
+            ow, oh = self.cfg.policy_obs_res
+            self.policy_obs = torch.zeros((self._num_envs, oh, ow, 3), device=self._device)
 
     # -- helpers --------------------------------------------------------------------------------------
     def request_deformation_outputs(self):
@@ -88,6 +92,7 @@ class TaximSimulator(GelSightSimulator):
             frame_min=self._frame_min if have_min else None,
             z_out=self._deformed_gel if self._keep_deformation else None,
             mask_out=self._contact_mask if self._keep_deformation else None,
+            obs_out=self.policy_obs,
         )
         if self._keep_deformation:
             self._deformation_version = self.sensor._height_map_version

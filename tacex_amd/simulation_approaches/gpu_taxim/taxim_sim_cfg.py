@@ -17,3 +17,7 @@ class TaximSimulatorCfg(GelSightSimulatorCfg):
     """Used for computing the indentation depth from the height map [m]."""
     gelpad_to_camera_min_distance: float = MISSING
     """Min distance of the camera to the gelpad [m]."""
+    policy_obs_res: tuple = None
+    """Extension (not in the reference): (width, height) of an antialiased low-resolution copy of the tactile frame
+    produced in the same pass (e.g. (32, 32), what the TacEx tasks feed to the policy); exposed as
+    `sensor.data.output["tactile_rgb_obs"]` with shape (num_envs, height, width, 3)."""
