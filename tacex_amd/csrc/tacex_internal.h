@@ -10,7 +10,7 @@ struct LevelDesc {
   bool same_taps = false;  // taps_w == taps_h element-wise (sigma_w == sigma_h): tuned band kernel eligible
   float* taps_w_dev = nullptr;
   float* taps_h_dev = nullptr;
-  float* taps_mfma_dev = nullptr; // per-lane band weights for blur_mfma_kernel: [(32 + K)/2 k-steps][64 lanes]
+  float* taps_mfma_dev = nullptr; // per-lane band weights for blur_mfma_kernel: [V | H][(16 + 2 RA)/4 k-steps][64 lanes]
   float* taps_pad_dev = nullptr;  // zero-padded taps for the looped band kernel: [16 zeros | K taps | 48 zeros]
 };
 

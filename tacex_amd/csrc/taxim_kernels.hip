@@ -128,6 +128,7 @@ struct BlurArgs {
   int padx;             // left padding in float2 units (even, >= (K-1)/2)
   float contact_scale;
   int restore;          // apply Z[M] = J[M]
+  int row0, nbands;     // MFMA kernel: first row and band count of this launch
 };
 
 template <int K, int TH, int RV, int RH, bool FIRST, int NT>
@@ -279,161 +280,231 @@ __global__ __launch_bounds__(NT, 3) void blur_band_kernel(BlurArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// MFMA band kernel: the separable Gaussian as two banded-Toeplitz matrix products on the matrix cores.
-//   V-pass: Out[32 x 32] = Tv[32 x (31+K)] * In[(31+K) x 32]   per 32-column block, straight from global/L2
-//   H-pass: Out[32 x 32] = Mid[32 x (31+K)] * Th[(31+K) x 32]  per 32-column block, Mid from LDS
-// with v_mfma_f32_32x32x2_f32: f32 in / f32 accumulate, bit-identical to a k-ordered fmaf chain, issued on the matrix
-// pipe at the f32 vector peak rate but as ONE instruction per 2048 MACs.  The VALU band kernel above spends ~2700 VALU
-// wave-instructions per 1952 packed FMAs and is issue-bound at ~20 % of the roof; here the VALU only computes row
-// indices and the masked restore.  Band waste: the 32 x (31+K) Toeplitz block carries (31+K)/K x the useful MACs
-// (1.5x at K = 61), all of it on the otherwise idle matrix pipe.
-// Per lane l the weight operand of k-step kk is w[(2 kk + (l >> 5)) - (l & 31)] (0 outside the band) for BOTH passes:
-// A[i][k] = w[k - i] with i = l & 31 in the V-pass, B[k][j] = w[k - j] with j = l & 31 in the H-pass.
+// MFMA band kernel: the separable Gaussian as two banded-Toeplitz matrix products on the matrix cores, with
+// v_mfma_f32_16x16x4_f32 (f32 in / f32 accumulate, bit-identical to a k-ordered fmaf chain, 32 cycles per 1024 MACs).
+//   band   = NTILE x 16 rows x W columns of one frame; a 16-row tile contracts over WIN = 16 + 2 RA rows / columns,
+//            RA = R rounded up to 8 (zero taps beyond R)
+//   V-pass : Out[16 x 64] = Tv[16 x WIN] * In[WIN x 64] per tile and 64-column super-block (one per wave).  In comes
+//            straight from global / L2: ONE 16-byte load per lane and k-step feeds 4 MFMAs of EVERY tile whose window
+//            holds the row (column j of block v is column c0 + 4 j + v, so the four accumulators of a lane hold 4
+//            adjacent columns -> 16-byte LDS stores).  k-step ks of lane group g = lane >> 4 contracts window row
+//            4 ks + g, so tile t uses union k-steps [4 t, 4 t + KS) with the SAME weight table.  The L2 -> L1 read
+//            amplification (16 NTILE + 2 RA) / (16 NTILE) is what bounds the k = 61 level: 5x at NTILE = 1, 3x at 2.
+//   H-pass : Out^T[16 cols x 16 rows] = Th^T * Mid^T per 16-column block, Mid from LDS.  Here k-step ks of lane group g
+//            contracts window column KS g + ks (each group walks CONSECUTIVE columns: one ds_read_b128 = four k-steps),
+//            and the transposed product leaves a lane with four consecutive columns of one row, so the masked restore
+//            and the 16-byte global stores run straight from the accumulators.
+// Band weights per lane (0 outside the band), i = lane & 15:
+//   V: wl[ks] = w[4 ks + g - RA - i + R]    H: wl[ks] = w[KS g + ks - RA - i + R]     (host tables, [2][KS][64])
+// Useful MACs / issued MACs = K / WIN (0.76 at K = 61, 0.69 at 33, 0.53 at 17).
 // ------------------------------------------------------------------------------------------------
-typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-template <int K, bool FIRST>
+template <int K, bool FIRST, int NTILE>
 __global__ __launch_bounds__(640) void blur_mfma_kernel(BlurArgs a) {
-  constexpr int TH = 32;
-  constexpr int R = (K - 1) / 2;
-  constexpr int KS = (TH + K - 1 + 1) / 2;  // k-steps of 2 input rows / columns
+  constexpr int TH = 16 * NTILE;
+  constexpr int R = (K - 1) / 2, RA = (R + 7) & ~7, WIN = 16 + 2 * RA, KS = WIN / 4;
+  constexpr int KU = KS + 4 * (NTILE - 1);  // k-steps over the union window of the band's tiles
+  constexpr int CH = 4, NCH = KU / CH;      // k-steps per software-pipeline chunk
+  static_assert(KU % CH == 0 && KS % 4 == 0, "window");
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  float* mid = reinterpret_cast<float*>(smem_raw);
-  const int H = a.H, W = a.W;
-  const int pitch = a.pitch, padx = a.padx;  // floats; pitch odd -> column reads of 32 rows hit 32 banks
-  const int nbands = (H + TH - 1) / TH;
+  float* mid = reinterpret_cast<float*>(smem_raw);  // TH x pitch, columns padded by RA on both sides
+  const int H = a.H, W = a.W, pitch = a.pitch;
   const int lid = xcd_remap(blockIdx.x, gridDim.x);
-  const int frame = lid / nbands;
-  const int band = lid - frame * nbands;
-  const int by0 = band * TH;
+  const int frame = lid / a.nbands;
+  const int band = lid - frame * a.nbands;
+  const int by0 = a.row0 + band * TH;
   const size_t fo = (size_t)frame * H * W;
   const float* __restrict__ src = FIRST ? a.hm + fo : a.src + fo;
   const float* __restrict__ hm = a.hm + fo;
   const float* __restrict__ gel = a.gel;
   const float sa = a.shift_a[frame], sb = a.shift_b[frame];
   const int lane = threadIdx.x & 63;
-  const int wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  const int nwaves = blockDim.x >> 6;
-  const int li = lane & 31, lk = lane >> 5;
+  const int wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // one 64-column super-block per wave
+  const int li = lane & 15, g = lane >> 4;
+  const int c0 = wid << 6;
 
-  // per-lane band weights, shared by both passes
-  float wl[KS];
-  static_for<0, KS>([&](auto kc) {
-    constexpr int kk = decltype(kc)::value;
-    wl[kk] = a.taps[kk * 64 + lane];  // host-prepared per-lane band table: w[2 kk + (l >> 5) - (l & 31)] or 0
-  });
-
-  const int nblk = W >> 5;
   // ---- V-pass ----
-  for (int blk = wid; blk < nblk; blk += nwaves) {
-    const int c0 = blk << 5;
-    f32x16 acc;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
-    // all operand loads of the block are issued before the MFMA chain (one load right in front of each MFMA
-    // serialises ~1 us of L2 latency per k-step)
-    float bv[KS], gv[FIRST ? KS : 1];
+  {
+    float wl[KS];
     static_for<0, KS>([&](auto kc) {
-      constexpr int kk = decltype(kc)::value;
-      int yy = reflect_idx(by0 - R + 2 * kk + lk, H);
-      yy = yy < 0 ? 0 : (yy >= H ? H - 1 : yy);  // beyond the window / partial band: finite data, zero weight
-      const unsigned off = (unsigned)yy * (unsigned)W + (unsigned)(c0 + li);
-      bv[kk] = src[off];
-      if constexpr (FIRST) gv[kk] = gel[off];
+      constexpr int ks = decltype(kc)::value;
+      wl[ks] = a.taps[ks * 64 + lane];
     });
-    static_for<0, KS>([&](auto kc) {
-      constexpr int kk = decltype(kc)::value;
-      float b = bv[kk];
-      // J = min(S, gel) (TT:441,454).  NOT fmin_raw: an inline-asm VALU write feeding an MFMA operand is invisible to
-      // the hazard recognizer (VALU write -> MFMA SrcA/B read needs wait states) and the MFMA would read a stale register
-      if constexpr (FIRST) b = fminf((b - sa) - sb, gv[kk]);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wl[kk], b, acc, 0, 0, 0);
-    });
-    // D layout: col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
+    f32x4 acc[NTILE][4];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int row = (r & 3) + 8 * (r >> 2) + 4 * lk;
-      mid[row * pitch + padx + c0 + li] = acc[r];
-    }
+    for (int t = 0; t < NTILE; ++t)
+#pragma unroll
+      for (int v = 0; v < 4; ++v) acc[t][v] = (f32x4)(0.0f);
+    const int rb = by0 - RA + g;
+    const unsigned coff = (unsigned)(c0 + 4 * li);
+    v4f xb[2][CH], gb[FIRST ? 2 : 1][FIRST ? CH : 1];
+    auto issue = [&](auto chunk_c) {
+      constexpr int chunk = decltype(chunk_c)::value;
+      static_for<0, CH>([&](auto cc) {
+        constexpr int c = decltype(cc)::value;
+        int yy = reflect_idx(rb + 4 * (chunk * CH + c), H);
+        yy = yy < 0 ? 0 : (yy >= H ? H - 1 : yy);  // zero-weight rows beyond the reflect range: any finite data
+        const unsigned off = (unsigned)yy * (unsigned)W + coff;
+        xb[chunk & 1][c] = *reinterpret_cast<const v4f*>(src + off);
+        if constexpr (FIRST) gb[chunk & 1][c] = *reinterpret_cast<const v4f*>(gel + off);
+      });
+    };
+    issue(std::integral_constant<int, 0>{});
+    static_for<0, NCH>([&](auto chunk_c) {
+      constexpr int chunk = decltype(chunk_c)::value;
+      if constexpr (chunk + 1 < NCH) issue(std::integral_constant<int, chunk + 1>{});
+      static_for<0, CH>([&](auto cc) {
+        constexpr int c = decltype(cc)::value;
+        constexpr int ku = chunk * CH + c;
+        v4f x = xb[chunk & 1][c];
+        if constexpr (FIRST) {  // J = min(S, gel), S = (hm - shift_a) - shift_b (TT:441, TT:454).  fminf, not the
+          const v4f gq = gb[chunk & 1][c];  // inline-asm fmin_raw: the hazard recognizer cannot see asm feeding an MFMA
+          x.x = fminf((x.x - sa) - sb, gq.x); x.y = fminf((x.y - sa) - sb, gq.y);
+          x.z = fminf((x.z - sa) - sb, gq.z); x.w = fminf((x.w - sa) - sb, gq.w);
+        }
+        static_for<0, NTILE>([&](auto tc) {
+          constexpr int t = decltype(tc)::value;
+          constexpr int ks = ku - 4 * t;
+          if constexpr (ks >= 0 && ks < KS) {
+            const float w = wl[ks];
+            acc[t][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(w, x.x, acc[t][0], 0, 0, 0);
+            acc[t][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(w, x.y, acc[t][1], 0, 0, 0);
+            acc[t][2] = __builtin_amdgcn_mfma_f32_16x16x4f32(w, x.z, acc[t][2], 0, 0, 0);
+            acc[t][3] = __builtin_amdgcn_mfma_f32_16x16x4f32(w, x.w, acc[t][3], 0, 0, 0);
+          }
+        });
+      });
+    });
+    // D layout: column (lane & 15), row 4 (lane >> 4) + reg.  The lanes next to the left / right image border also write
+    // the mirrored x-padding (torch 'reflect': position -c <- c, (W-1)+c <- (W-1)-c, c = 1..RA), so one barrier suffices.
+    const int cx = c0 + 4 * li;
+#pragma unroll
+    for (int t = 0; t < NTILE; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float* rowp = mid + (16 * t + 4 * g + r) * pitch + RA;
+        const float e[4] = {acc[t][0][r], acc[t][1][r], acc[t][2][r], acc[t][3][r]};
+        *reinterpret_cast<v4f*>(rowp + cx) = (v4f){e[0], e[1], e[2], e[3]};
+        if (cx <= RA) {
+#pragma unroll
+          for (int v = 0; v < 4; ++v)
+            if (cx + v >= 1 && cx + v <= RA) rowp[-(cx + v)] = e[v];
+        }
+        if (cx + 3 >= W - 1 - RA) {
+#pragma unroll
+          for (int v = 0; v < 4; ++v)
+            if (cx + v >= W - 1 - RA && cx + v <= W - 2) rowp[2 * (W - 1) - (cx + v)] = e[v];
+        }
+      }
   }
   __syncthreads();
-  // mirrored x-padding (torch 'reflect'): position -c <- c, position (W-1)+c <- (W-1)-c, c = 1..R
-  for (int e = threadIdx.x; e < TH * 2 * R; e += blockDim.x) {
-    const int row = e / (2 * R), q = e - row * (2 * R);
-    const int c = (q >> 1) + 1;
-    float* rp = mid + row * pitch + padx;
-    if (q & 1) rp[W - 1 + c] = rp[W - 1 - c];
-    else rp[-c] = rp[c];
-  }
-  __syncthreads();
-  // ---- H-pass + masked restore ----
-  const float thr = -a.pdepth[frame] * a.contact_scale;  // TT:459
-  for (int blk = wid; blk < nblk; blk += nwaves) {
-    const int c0 = blk << 5;
-    f32x16 acc;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
-    const float* arow = mid + li * pitch + padx + c0 - R + lk;
-    float av[KS];
+  // ---- H-pass + masked restore: per tile, four adjacent 16-column blocks per wave (four independent chains) ----
+  {
+    float wl[KS];
     static_for<0, KS>([&](auto kc) {
-      constexpr int kk = decltype(kc)::value;
-      // columns beyond c0 + 31 + R carry zero weights; never read beyond the padded row
-      av[kk] = (c0 - R + lk + 2 * kk < W + R) ? arow[2 * kk] : 0.0f;
+      constexpr int ks = decltype(kc)::value;
+      wl[ks] = a.taps[(KS + ks) * 64 + lane];
     });
-    static_for<0, KS>([&](auto kc) {
-      constexpr int kk = decltype(kc)::value;
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[kk], wl[kk], acc, 0, 0, 0);
-    });
+    const float thr = -a.pdepth[frame] * a.contact_scale;  // TT:459
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int y = by0 + (r & 3) + 8 * (r >> 2) + 4 * lk;
-      if (y < H) {
-        const size_t p = (size_t)y * W + c0 + li;
-        const float g = gel[p];
-        const float S = (hm[p] - sa) - sb;
-        const float J = fmin_raw(S, g);
-        const bool M = ((J - g) < thr) && (S < 0.0f);  // TT:457-461
-        a.dst[fo + p] = (a.restore && M) ? J : acc[r];  // TT:467
-        if (a.mask_out) a.mask_out[fo + p] = M ? 1 : 0;
+    for (int t = 0; t < NTILE; ++t) {
+      f32x4 acc[4];
+#pragma unroll
+      for (int n = 0; n < 4; ++n) acc[n] = (f32x4)(0.0f);
+      const float* arow = mid + (16 * t + li) * pitch + KS * g + c0;  // window column KS g + ks of block n: + 16 n
+      // restore operands: issued ahead of the MFMA chain so their latency hides behind it
+      const size_t p0 = (size_t)(by0 + 16 * t + li) * W + c0 + 4 * g;
+      v4f hv[4], gv[4];
+#pragma unroll
+      for (int n = 0; n < 4; ++n) {
+        hv[n] = *reinterpret_cast<const v4f*>(hm + p0 + 16 * n);
+        gv[n] = *reinterpret_cast<const v4f*>(gel + p0 + 16 * n);
+      }
+      static_for<0, KS / 4>([&](auto mc) {
+        constexpr int m = decltype(mc)::value;
+        v4f q[4];
+#pragma unroll
+        for (int n = 0; n < 4; ++n) q[n] = *reinterpret_cast<const v4f*>(arow + 16 * n + 4 * m);
+#pragma unroll
+        for (int n = 0; n < 4; ++n) acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(wl[4 * m], q[n].x, acc[n], 0, 0, 0);
+#pragma unroll
+        for (int n = 0; n < 4; ++n) acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(wl[4 * m + 1], q[n].y, acc[n], 0, 0, 0);
+#pragma unroll
+        for (int n = 0; n < 4; ++n) acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(wl[4 * m + 2], q[n].z, acc[n], 0, 0, 0);
+#pragma unroll
+        for (int n = 0; n < 4; ++n) acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(wl[4 * m + 3], q[n].w, acc[n], 0, 0, 0);
+      });
+#pragma unroll
+      for (int n = 0; n < 4; ++n) {
+        v4f o;
+        uint8_t mk[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const float S = (hv[n][k] - sa) - sb;
+          const float J = fminf(S, gv[n][k]);
+          const bool M = ((J - gv[n][k]) < thr) && (S < 0.0f);  // TT:457-461
+          o[k] = (a.restore && M) ? J : acc[n][k];              // TT:467
+          mk[k] = M ? 1 : 0;
+        }
+        *reinterpret_cast<v4f*>(a.dst + fo + p0 + 16 * n) = o;
+        if (a.mask_out) *reinterpret_cast<uchar4*>(a.mask_out + fo + p0 + 16 * n) = (uchar4){mk[0], mk[1], mk[2], mk[3]};
       }
     }
   }
 }
 
-template <int K, bool FIRST>
-static hipError_t launch_mfma(const BlurArgs& a0, hipStream_t st) {
-  constexpr int TH = 32, R = (K - 1) / 2;
-  BlurArgs a = a0;
-  a.padx = R;
-  a.pitch = (a.W + 2 * R) | 1;  // odd
-  const int nbands = (a.H + TH - 1) / TH;
-  const size_t lds = (size_t)TH * a.pitch * sizeof(float);
-  const int nblk = a.W / 32;
-  const int nthreads = 64 * (nblk < 10 ? nblk : 10);
-  auto kern = blur_mfma_kernel<K, FIRST>;
+template <int K, bool FIRST, int NTILE>
+static hipError_t launch_mfma_tiles(BlurArgs a, int row0, int nbands, hipStream_t st) {
+  constexpr int TH = 16 * NTILE, R = (K - 1) / 2, RA = (R + 7) & ~7;
+  a.row0 = row0;
+  a.nbands = nbands;
+  a.padx = RA;
+  a.pitch = a.W + 2 * RA + 4;  // multiple of 4 with an odd quotient: the 16 rows of a ds_read_b128 hit distinct bank groups
+  if (((a.pitch >> 2) & 1) == 0) a.pitch += 4;
+  static const size_t lds_pad = getenv("TACEX_MFMA_LDS_PAD") ? (size_t)atoi(getenv("TACEX_MFMA_LDS_PAD")) * 1024 : 0;  // occupancy A/B hook
+  const size_t lds = (size_t)TH * a.pitch * sizeof(float) + lds_pad;
+  auto kern = blur_mfma_kernel<K, FIRST, NTILE>;
   static size_t attr_lds = 0;
   if (lds > 48 * 1024 && lds > attr_lds) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     attr_lds = lds;
   }
-  hipLaunchKernelGGL(kern, dim3(nbands * a.B), dim3(nthreads), lds, st, a);
+  hipLaunchKernelGGL(kern, dim3(nbands * a.B), dim3(a.W), lds, st, a);
   return hipGetLastError();
 }
 
-// Experimental (round 1): correct (parity-tested) but not yet faster than the VALU band kernels - 171-211 us vs 150 us
-// for k = 61 at B = 256 although the matrix pipe itself needs only 49 us (SQ_VALU_MFMA_BUSY_CYCLES): the chains wait
-// on dword operand loads and ~2.4 k VALU instructions per wave of index / epilogue work.  Opt in: TACEX_BLUR_MFMA=1.
+// TACEX_MFMA_TILES (A/B hook): 16-row tiles per band, 1..3.  Default 1: taller bands cut the V-pass L2 -> L1 traffic
+// (5x -> 3x at k = 61) but measured 3-15 % slower at 256 x 320x240 (fewer, longer workgroups per CU).  Rows left over by the tall bands (H % (16 NTILE))
+// are served by a second launch of the next smaller band height.
+template <int K, bool FIRST>
+static hipError_t launch_mfma(const BlurArgs& a, hipStream_t st) {
+  static const int ntile_env = getenv("TACEX_MFMA_TILES") ? atoi(getenv("TACEX_MFMA_TILES")) : 1;
+  int done = 0;
+  hipError_t e = hipSuccess;
+  for (int nt = ntile_env < 1 ? 1 : (ntile_env > 3 ? 3 : ntile_env); nt >= 1 && done < a.H && e == hipSuccess; --nt) {
+    const int nb = (a.H - done) / (16 * nt);
+    if (nb == 0) continue;
+    if (nt == 3) e = launch_mfma_tiles<K, FIRST, 3>(a, done, nb, st);
+    else if (nt == 2) e = launch_mfma_tiles<K, FIRST, 2>(a, done, nb, st);
+    else e = launch_mfma_tiles<K, FIRST, 1>(a, done, nb, st);
+    done += nb * 16 * nt;
+  }
+  return e;
+}
+
+// TACEX_BLUR_MFMA: 1 (default) = matrix-core band kernels where compiled (k = 61 / 33 / 17), 0 = VALU band kernels only
 static int mfma_enabled() {
   static int v = -1;
-  if (v < 0) { const char* e = getenv("TACEX_BLUR_MFMA"); v = e ? atoi(e) : 0; }
+  if (v < 0) { const char* e = getenv("TACEX_BLUR_MFMA"); v = e ? atoi(e) : 1; }
   return v;
 }
 
 static bool mfma_supported(int k, bool first, int H, int W) {
-  if (!mfma_enabled() || W % 32 != 0 || W < 64 || W > 2048) return false;
+  if (!mfma_enabled() || W % 64 != 0 || W < 64 || W > 640 || H % 16 != 0) return false;
   const int R = (k - 1) / 2;
-  if (R >= H || R > W - 1) return false;
+  if (R >= H || R > W - 1 || ((R + 7) & ~7) >= W) return false;
   if (first) return k == 61;
   return k == 61 || k == 33 || k == 17;
 }
