@@ -76,60 +76,89 @@ struct ShadeArgs {
 };
 
 
-// float32 arctangent on t >= 0 (Cephes atanf scheme: two-step range reduction + degree-4 odd polynomial,
-// |error| ~ 1e-7 rad ~ 1 ulp).  The libm atanf/atan2f + IEEE-exact divisions made the shading VALU-bound
-// (~400 instructions / pixel, 75 % of the fused kernel); bins only need the angle to ~1e-6 rad (bin width 1.27e-2),
-// so results differ from libm only for pixels that sit on a bin boundary to within float roundoff.
-__device__ __forceinline__ float atan_pos(float t) {
-  const bool big = t > 2.414213562373095f;   // tan(3 pi / 8)
-  const bool mid = t > 0.4142135623730950f;  // tan(pi / 8)
-  const float x = big ? -__builtin_amdgcn_rcpf(t) : (mid ? (t - 1.0f) * __builtin_amdgcn_rcpf(t + 1.0f) : t);
-  const float y0 = big ? 1.57079632679489662f : (mid ? 0.785398163397448310f : 0.0f);
+// plain v_max_f32 (see fmin_raw)
+__device__ __forceinline__ float fmax_raw(float a, float b) {
+  float r;
+  asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+
+// atan(x) for 0 <= x <= 1: x * P(x^2), P = degree-8 minimax fit of atan(sqrt z)/sqrt z on [0,1]; |error| <= 8.1e-8 rad
+// evaluated in float32 (the reference's bins are 1.27e-2 rad wide; libm atanf is ~1 ulp = 6e-8 at pi/4).  One reduction
+// (x -> 1/x above 1) instead of the two-step Cephes scheme: the libm atanf/atan2f + IEEE divisions made the shading
+// ~400 VALU instructions / pixel; on gfx950 v_rcp/v_sqrt issue at quarter rate and v_min/v_max/v_cmp/v_cvt at half
+// rate (scripts/hip_probes/valu_rates.hip), so a reduction step costs more than the extra polynomial terms.
+__device__ __forceinline__ float atan_unit(float x) {
   const float z = x * x;
-  const float p = (((8.05374449538e-2f * z - 1.38776856032e-1f) * z + 1.99777106478e-1f) * z - 3.33329491539e-1f) * z * x + x;
-  return y0 + p;
+  float p = 0.0024566983338445425f;
+  p = fmaf(p, z, -0.01440124586224556f);
+  p = fmaf(p, z, 0.03978102654218674f);
+  p = fmaf(p, z, -0.07234838604927063f);
+  p = fmaf(p, z, 0.10498936474323273f);
+  p = fmaf(p, z, -0.14161226153373718f);
+  p = fmaf(p, z, 0.19985906779766083f);
+  p = fmaf(p, z, -0.33332598209381104f);
+  p = fmaf(p, z, 0.9999998807907104f);
+  return p * x;
+}
+
+// atan(t), t >= 0
+__device__ __forceinline__ float atan_pos(float t) {
+  const bool big = t > 1.0f;
+  const float p = atan_unit(big ? __builtin_amdgcn_rcpf(t) : t);
+  return big ? 1.57079632679489662f - p : p;
 }
 
 // atan2(y, x) for finite inputs with (x, y) != (0, 0)
 __device__ __forceinline__ float atan2_fast(float y, float x) {
   const float ax = fabsf(x), ay = fabsf(y);
-  const bool swap = ay > ax;
-  const float num = swap ? ax : ay, den = swap ? ay : ax;
-  float a = atan_pos(num * __builtin_amdgcn_rcpf(den));        // in [0, pi/4]
-  a = swap ? 1.57079632679489662f - a : a;          // in [0, pi/2]
+  float a = atan_unit(fmin_raw(ax, ay) * __builtin_amdgcn_rcpf(fmax_raw(ax, ay)));  // in [0, pi/4]
+  a = ay > ax ? 1.57079632679489662f - a : a;       // in [0, pi/2]
   a = x < 0.0f ? 3.14159265358979324f - a : a;      // in [0, pi]
-  return y < 0.0f ? -a : a;
+  return __builtin_copysignf(a, y);
 }
 
-// normals -> bins -> polynomial -> + background -> clip for ONE pixel (TT:475-503, 237-258).
-// top/bot/lef/rig are the deformed-gel values (mm) around the CLAMPED pixel (replicate padding, TT:501-502).
-__device__ __forceinline__ void shade_pixel_core(const ShadeArgs& a, float ztop, float zbot, float zlef, float zrig,
-                                                 int x, int y, float out[3], int& im_out, int& id_out) {
-  const size_t p = (size_t)y * a.W + x;
+// gradient -> (magnitude bin, direction bin)  (TT:475-499, 243-247).  top/bot/lef/rig are the deformed-gel values (mm)
+// around the CLAMPED pixel (replicate padding of the gradient maps, TT:501-502).
+__device__ __forceinline__ void shade_bins(const ShadeArgs& a, float ztop, float zbot, float zlef, float zrig, int& im,
+                                           int& id) {
   // z_px = -(Z / pixmm) (TT:238-239); dzdx = (z[y+1]-z[y-1])/2 * H / calib_h, dzdy likewise in x (TT:486-490):
   // folded into one scale per axis (a.gsy, a.gsx); note bot-top of -Z/pixmm = (ztop - zbot)/pixmm
   const float dzdx = (ztop - zbot) * a.gsy;
   const float dzdy = (zlef - zrig) * a.gsx;
-  const float t = __builtin_amdgcn_sqrtf(dzdx * dzdx + dzdy * dzdy);
+  const float t = __builtin_amdgcn_sqrtf(fmaf(dzdx, dzdx, dzdy * dzdy));
   const float mag = atan_pos(t);
   // atan2(dzdx/t, dzdy/t) == atan2(dzdx, dzdy) for t > 0; grad_dir = 0 where t == 0 (TT:494-499)
   const float dir = t != 0.0f ? atan2_fast(dzdx, dzdy) : 0.0f;
-  int im = (int)floorf(mag * a.inv_x_binr);                                   // TT:246
-  int id = (int)floorf((dir + 3.14159274101257324f) * a.inv_y_binr);          // TT:247
-  im = min(max(im, 0), a.nb - 1);
-  id = min(max(id, 0), a.nb - 1);
-  const v4f* __restrict__ pc = reinterpret_cast<const v4f*>(a.poly + ((unsigned)(im * a.nb + id)) * 24u);
+  // floor == truncation: both arguments are >= 0 (mag >= 0, dir >= -pi)                       TT:246-247
+  im = min(max((int)(mag * a.inv_x_binr), 0), a.nb - 1);
+  id = min(max((int)((dir + 3.14159274101257324f) * a.inv_y_binr), 0), a.nb - 1);
+}
+
+// I_c = sum_k f_k(X, Y) * p_{c,k}(bin), f = [X^2, Y^2, XY, X, Y, 1]  (TT:148-157, 250-255): one FMA chain per channel.
+// The table record is a 32-bit byte offset from the wave-uniform table base (no 64-bit VALU address arithmetic).
+__device__ __forceinline__ void shade_poly(const ShadeArgs& a, int im, int id, float X, float Y, float out[3]) {
+  const v4f* __restrict__ pc =
+      reinterpret_cast<const v4f*>(reinterpret_cast<const char*>(a.poly) + (unsigned)(im * a.nb + id) * 96u);
   const v4f c0 = pc[0], c1 = pc[1], c2 = pc[2], c3 = pc[3], c4 = pc[4];
-  const float X = a.fx[x], Y = a.fy[y];
-  const float f0 = X * X, f1 = Y * Y, f2 = X * Y;  // TT:148-157
-  // I_c = sum_k f_k * p_{c,k}
-  const float r = ((((f0 * c0.x + f1 * c0.y) + f2 * c0.z) + X * c0.w) + Y * c1.x) + c1.y;
-  const float g = ((((f0 * c1.z + f1 * c1.w) + f2 * c2.x) + X * c2.y) + Y * c2.z) + c2.w;
-  const float bl = ((((f0 * c3.x + f1 * c3.y) + f2 * c3.z) + X * c3.w) + Y * c4.x) + c4.y;
-  const float* __restrict__ bg = a.bg + p * 3;
-  out[0] = fminf(fmaxf(r + bg[0], 0.0f), 1.0f);   // TT:257-258
-  out[1] = fminf(fmaxf(g + bg[1], 0.0f), 1.0f);
-  out[2] = fminf(fmaxf(bl + bg[2], 0.0f), 1.0f);
+  const float f0 = X * X, f1 = Y * Y, f2 = X * Y;
+  out[0] = fmaf(f0, c0.x, fmaf(f1, c0.y, fmaf(f2, c0.z, fmaf(X, c0.w, fmaf(Y, c1.x, c1.y)))));
+  out[1] = fmaf(f0, c1.z, fmaf(f1, c1.w, fmaf(f2, c2.x, fmaf(X, c2.y, fmaf(Y, c2.z, c2.w)))));
+  out[2] = fmaf(f0, c3.x, fmaf(f1, c3.y, fmaf(f2, c3.z, fmaf(X, c3.w, fmaf(Y, c4.x, c4.y)))));
+}
+
+// normals -> bins -> polynomial -> + background -> clip for ONE pixel (TT:475-503, 237-258)
+__device__ __forceinline__ void shade_pixel_core(const ShadeArgs& a, float ztop, float zbot, float zlef, float zrig,
+                                                 int x, int y, float out[3], int& im_out, int& id_out) {
+  const unsigned p = (unsigned)y * (unsigned)a.W + (unsigned)x;
+  int im, id;
+  shade_bins(a, ztop, zbot, zlef, zrig, im, id);
+  float c[3];
+  shade_poly(a, im, id, a.fx[(unsigned)x], a.fy[(unsigned)y], c);
+  const float* __restrict__ bg = reinterpret_cast<const float*>(reinterpret_cast<const char*>(a.bg) + p * 12u);
+  out[0] = __builtin_amdgcn_fmed3f(c[0] + bg[0], 0.0f, 1.0f);   // TT:257-258
+  out[1] = __builtin_amdgcn_fmed3f(c[1] + bg[1], 0.0f, 1.0f);
+  out[2] = __builtin_amdgcn_fmed3f(c[2] + bg[2], 0.0f, 1.0f);
   im_out = im;
   id_out = id;
 }
@@ -138,6 +167,27 @@ __device__ __forceinline__ void shade_pixel_rgb(const ShadeArgs& a, float ztop, 
                                                 int y, float out[3]) {
   int im, id;
   shade_pixel_core(a, ztop, zbot, zlef, zrig, x, y, out, im, id);
+}
+
+// Four horizontally consecutive pixels (x % 4 == 0, x + 3 < W) of row y: the background (48 contiguous bytes) and the
+// four column coordinates come in as 16-byte loads instead of 12 + 4 strided dwords per lane.
+// zn[i] = {top, bottom, left, right} of pixel i.
+__device__ __forceinline__ void shade_strip4_rgb(const ShadeArgs& a, const float zn[4][4], int x, int y, float out[12]) {
+  const unsigned p = (unsigned)y * (unsigned)a.W + (unsigned)x;
+  const v4f X4 = *reinterpret_cast<const v4f*>(a.fx + (unsigned)x);
+  const float Y = a.fy[(unsigned)y];
+  const v4f* __restrict__ bgp = reinterpret_cast<const v4f*>(reinterpret_cast<const char*>(a.bg) + p * 12u);
+  const v4f b0 = bgp[0], b1 = bgp[1], b2 = bgp[2];
+  const float bg[12] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w, b2.x, b2.y, b2.z, b2.w};
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    int im, id;
+    shade_bins(a, zn[i][0], zn[i][1], zn[i][2], zn[i][3], im, id);
+    float c[3];
+    shade_poly(a, im, id, X4[i], Y, c);
+#pragma unroll
+    for (int ch = 0; ch < 3; ++ch) out[3 * i + ch] = __builtin_amdgcn_fmed3f(c[ch] + bg[3 * i + ch], 0.0f, 1.0f);  // TT:257-258
+  }
 }
 
 __device__ __forceinline__ void shade_pixel(const ShadeArgs& a, float ztop, float zbot, float zlef, float zrig, int x,

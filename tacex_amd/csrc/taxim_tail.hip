@@ -17,6 +17,9 @@
 namespace tacex {
 
 constexpr int kTailMaxLevels = 5;
+// 8 waves per workgroup, 2 per SIMD: two workgroups per CU (LDS-bound) then need 4 wave slots and <= 128 VGPRs per SIMD.
+// (640 threads measured 25 % slower: 3+3+2+2 waves per workgroup leave no room for the second workgroup's 3 on a SIMD.)
+constexpr int kTailThreads = 512;
 // observation cells a 64 x 32 tile can overlap when the down-sampling factor is >= 7.5 (y) / >= 8 (x): tile / scale + 3
 constexpr int kObsNRY = 8, kObsNCX = 11;
 // longest triangle filter the fused observation handles (taps per output row / column); longer ones take the two-pass resize
@@ -60,7 +63,7 @@ struct TailCfg {
 };
 
 template <int... KS>
-__global__ __launch_bounds__(512) void taxim_tail_kernel(TailArgs a) {
+__global__ __launch_bounds__(kTailThreads) void taxim_tail_kernel(TailArgs a) {
   using C = TailCfg<KS...>;
   constexpr int NL = C::NL, TW = C::TW, TH = C::TH, HLY = C::HLY, HLX = C::HLX, RW = C::RW, RH = C::RH;
   constexpr int PADX = C::PADX, PADY = C::PADY, P = C::P, ROWS = C::ROWS;
@@ -83,7 +86,7 @@ __global__ __launch_bounds__(512) void taxim_tail_kernel(TailArgs a) {
   const float* __restrict__ hm = a.hm + fo;
   const int gy0 = ty0 - HLY, gx0 = tx0 - HLX;  // global coords of region cell (0,0)
   const int tid = threadIdx.x;
-  constexpr int NT = 512;
+  constexpr int NT = kTailThreads;
 
   // ---- load: previous level, J and M, ALL at REFLECTED coordinates ----
   // Out-of-image halo cells hold the mirror image of the in-image data (= torch 'reflect' padding, TT:411).  A
@@ -178,20 +181,22 @@ __global__ __launch_bounds__(512) void taxim_tail_kernel(TailArgs a) {
         *reinterpret_cast<v4f*>(bufB + (ly + PADY) * P + PADX + x0) = o;
       }
       __syncthreads();
-      // ---- V-pass: bufB -> bufA, 4 columns x 4 rows per item, + masked restore ----
-      for (int it = tid; it < ((VY1 - VY0) / 4) * NXG; it += NT) {
-        const int ly0 = VY0 + (it / NXG) * 4, x0 = X0 + (it % NXG) * 4;
-        v4f acc[4] = {(v4f)(0.0f), (v4f)(0.0f), (v4f)(0.0f), (v4f)(0.0f)};
-        static_for<0, 4 + 2 * R>([&](auto jc) {
+      // ---- V-pass: bufB -> bufA, 4 columns x 2 rows per item, + masked restore ----
+      // (2-row items: ~2x the items of a 4x4 blocking, so all 10 waves carry one item instead of 4 of them carrying
+      // 16 outputs each while the rest wait at the barrier; the extra window reads are LDS-cheap)
+      for (int it = tid; it < ((VY1 - VY0) / 2) * NXG; it += NT) {
+        const int ly0 = VY0 + (it / NXG) * 2, x0 = X0 + (it % NXG) * 4;
+        v4f acc[2] = {(v4f)(0.0f), (v4f)(0.0f)};
+        static_for<0, 2 + 2 * R>([&](auto jc) {
           constexpr int j = decltype(jc)::value;
           const v4f q = *reinterpret_cast<const v4f*>(bufB + (ly0 - R + j + PADY) * P + PADX + x0);
-          static_for<0, 4>([&](auto rc) {
+          static_for<0, 2>([&](auto rc) {
             constexpr int r = decltype(rc)::value;
             constexpr int t = j - r;
             if constexpr (t >= 0 && t < K) acc[r] += taps[t < K - 1 - t ? t : K - 1 - t] * q;
           });
         });
-        static_for<0, 4>([&](auto rc) {
+        static_for<0, 2>([&](auto rc) {
           constexpr int r = decltype(rc)::value;
           v4f o = acc[r];
           if constexpr (l < NL - 1) {  // TT:467 Z[M] = J[M]; the final blur (TT:468-471) has no restore
@@ -215,11 +220,8 @@ __global__ __launch_bounds__(512) void taxim_tail_kernel(TailArgs a) {
   });
 
   // ---- epilogue: 4 consecutive pixels per thread: float4 I/O for deformed gel / mask / background / RGB ----
-  static_assert((TH * TW) % (4 * NT) == 0, "epilogue strips");
   const bool fast_w = (W % 4) == 0;
-#pragma unroll
-  for (int k = 0; k < (TH * TW) / (4 * NT); ++k) {
-    const int sidx = tid + k * NT;                 // strip index within the tile
+  for (int sidx = tid; sidx < (TH * TW) / 4; sidx += NT) {  // strip index within the tile
     const int oy = sidx / (TW / 4), ox = (sidx - oy * (TW / 4)) * 4;
     const int gy = ty0 + oy, gx = tx0 + ox;
     if (gy >= H || gx >= W) {  // tile overhang: only the observation staging must not hold stale (possibly non-finite) data
@@ -230,10 +232,10 @@ __global__ __launch_bounds__(512) void taxim_tail_kernel(TailArgs a) {
       continue;
     }
     const int ly = oy + HLY, lx = ox + HLX;
-    const size_t p = (size_t)gy * W + gx;
+    const unsigned p = (unsigned)gy * (unsigned)W + (unsigned)gx;  // 32-bit pixel offset from the wave-uniform frame bases
     const float* crow = bufA + (ly + PADY) * P + PADX + lx;
     if (fast_w) {  // whole strip inside the image
-      if (a.z_out) *reinterpret_cast<v4f*>(a.z_out + fo + p) = *reinterpret_cast<const v4f*>(crow);
+      if (a.z_out) *reinterpret_cast<v4f*>(reinterpret_cast<char*>(a.z_out + fo) + p * 4u) = *reinterpret_cast<const v4f*>(crow);
       if (a.mask_out) *reinterpret_cast<uchar4*>(a.mask_out + fo + p) = *reinterpret_cast<const uchar4*>(bufM + ly * P + PADX + lx);
     } else {
       for (int i = 0; i < 4 && gx + i < W; ++i) {
@@ -246,11 +248,21 @@ __global__ __launch_bounds__(512) void taxim_tail_kernel(TailArgs a) {
       const int yc = min(max(gy, 1), H - 2) - gy0;
       const float* rc = bufA + (yc + PADY) * P + PADX;
       float rgb[12];
+      if (fast_w) {
+        float zn[4][4];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int gxi = min(gx + i, W - 1);
-        const int xc = min(max(gxi, 1), W - 2) - gx0;
-        shade_pixel_rgb(a.sh, rc[xc - P], rc[xc + P], rc[xc - 1], rc[xc + 1], gxi, gy, rgb + 3 * i);
+        for (int i = 0; i < 4; ++i) {
+          const int xc = min(max(gx + i, 1), W - 2) - gx0;
+          zn[i][0] = rc[xc - P]; zn[i][1] = rc[xc + P]; zn[i][2] = rc[xc - 1]; zn[i][3] = rc[xc + 1];
+        }
+        shade_strip4_rgb(a.sh, zn, gx, gy, rgb);
+      } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int gxi = min(gx + i, W - 1);
+          const int xc = min(max(gxi, 1), W - 2) - gx0;
+          shade_pixel_rgb(a.sh, rc[xc - P], rc[xc + P], rc[xc - 1], rc[xc + 1], gxi, gy, rgb + 3 * i);
+        }
       }
       if (a.obs_part) {  // stage the strip for the observation reduction below (bufB is free after the last V-pass)
         float* sg = bufB + oy * (TW * 3) + ox * 3;
@@ -258,7 +270,7 @@ __global__ __launch_bounds__(512) void taxim_tail_kernel(TailArgs a) {
         reinterpret_cast<v4f*>(sg)[1] = (v4f){rgb[4], rgb[5], rgb[6], rgb[7]};
         reinterpret_cast<v4f*>(sg)[2] = (v4f){rgb[8], rgb[9], rgb[10], rgb[11]};
       }
-      float* o = a.sh.rgb + ((size_t)frame * H * W + p) * 3;
+      float* o = reinterpret_cast<float*>(reinterpret_cast<char*>(a.sh.rgb + fo * 3) + p * 12u);
       if (fast_w) {
         reinterpret_cast<v4f*>(o)[0] = (v4f){rgb[0], rgb[1], rgb[2], rgb[3]};
         reinterpret_cast<v4f*>(o)[1] = (v4f){rgb[4], rgb[5], rgb[6], rgb[7]};
@@ -275,7 +287,7 @@ __global__ __launch_bounds__(512) void taxim_tail_kernel(TailArgs a) {
   if (a.obs_part && a.sh.rgb) {
     constexpr int NRY = kObsNRY, NCX = kObsNCX, KY = kObsKY, KX = kObsKX, TWC = TW * 3;
     static_assert(TH * TWC <= ROWS * P && NRY * TWC <= ROWS * P, "rgb staging / vertical partials must fit a ping-pong buffer");
-    static_assert(TWC % 64 == 0 && NT % 64 == 0 && (NRY * TWC) % NT == 0, "a wave stays inside one observation row in the vertical pass");
+    static_assert(TWC % 64 == 0 && NT % 64 == 0, "a wave stays inside one observation row in the vertical pass");
     static_assert(KY <= TH && KX <= TW && KY % 4 == 0 && KX % 4 == 0 && NRY * KY + NCX * KX + NRY + NCX <= RH * P, "tap windows");
     float* v1 = bufA;                  // [NRY][TWC]; the final level is dead once every strip of the epilogue is shaded
     float* wly = bufJ;                 // [NRY][KY] taps of cell row j over the KY tile rows starting at wby[j] (0 outside its support)
@@ -319,9 +331,7 @@ __global__ __launch_bounds__(512) void taxim_tail_kernel(TailArgs a) {
     }
     __syncthreads();
     // vertical: item = (cell row j, column*channel xc); j is wave-uniform
-#pragma unroll
-    for (int r = 0; r < (NRY * TWC) / NT; ++r) {
-      const int it = tid + r * NT;
+    for (int it = tid; it < NRY * TWC; it += NT) {
       const int j = __builtin_amdgcn_readfirstlane(it / TWC), xc = it - j * TWC;
       const float* sg = bufB + wby[j] * TWC + xc;
       const v4f* wv = reinterpret_cast<const v4f*>(wly + j * KY);
@@ -411,7 +421,7 @@ static hipError_t launch_tail(const TailArgs& a, hipStream_t st) {
     if (e != hipSuccess) return e;
     attr_done = true;
   }
-  hipLaunchKernelGGL(kern, dim3(ntx * nty * a.B), dim3(512), C::lds_bytes(), st, a);
+  hipLaunchKernelGGL(kern, dim3(ntx * nty * a.B), dim3(kTailThreads), C::lds_bytes(), st, a);
   return hipGetLastError();
 }
 
