@@ -59,7 +59,8 @@ struct TailCfg {
   static constexpr int ROWS = RH + 2 * PADY;
   // valid margin needed after level l = sum of the radii of levels l+1.. plus 2 (gradient + replicate clamp)
   static constexpr int margin_after(int l) { int s = 2; for (int i = l + 1; i < NL; ++i) s += (K[i] - 1) / 2; return s; }
-  static constexpr size_t lds_bytes() { return (size_t)(2 * ROWS * P + RH * P) * sizeof(float) + (size_t)RH * P; }
+  static constexpr size_t obs_lds_bytes() { return (size_t)(kObsNRY * kObsKY + kObsNCX * kObsKX + kObsNRY + kObsNCX + 1) / 4 * 16 + 16; }
+  static constexpr size_t lds_bytes() { return (size_t)(2 * ROWS * P + RH * P) * sizeof(float) + (size_t)RH * P + obs_lds_bytes(); }
 };
 
 template <int... KS>
@@ -88,6 +89,14 @@ __global__ __launch_bounds__(kTailThreads) void taxim_tail_kernel(TailArgs a) {
   const int tid = threadIdx.x;
   constexpr int NT = kTailThreads;
 
+  // ---- policy observation, step 0: this tile's tap windows (see the reduction after the epilogue).  A window is KY (KX)
+  // consecutive tile rows (columns) covering support(cell) ^ tile, so the reductions run fixed, fully unrolled trip
+  // counts with immediate LDS offsets.  Built here, in its own LDS area, so that the dependent table loads overlap the
+  // tile load instead of sitting exposed between the epilogue and the reduction.
+  float* wly = reinterpret_cast<float*>(bufM + RH * P);  // [NRY][KY] taps of cell row j over the KY tile rows from wby[j]
+  float* wlx = wly + kObsNRY * kObsKY;                    // [NCX][KX] same for the cell columns
+  int* wby = reinterpret_cast<int*>(wlx + kObsNCX * kObsKX);  // [NRY] first row of the window (tile-relative)
+  int* wbx = wby + kObsNRY;                                    // [NCX]
   // ---- load: previous level, J and M, ALL at REFLECTED coordinates ----
   // Out-of-image halo cells hold the mirror image of the in-image data (= torch 'reflect' padding, TT:411).  A
   // symmetric kernel maps a mirror-symmetric signal to a mirror-symmetric signal, and the restore Z[M] = J[M] uses
@@ -122,6 +131,42 @@ __global__ __launch_bounds__(kTailThreads) void taxim_tail_kernel(TailArgs a) {
             gv[ps][k] = a.gel[ro + rxo[k]];
           }
         }
+      }
+    }
+    // (observation tap windows: issued behind the tile loads, in front of their first use)
+    if (a.obs_part && a.sh.rgb) {
+      constexpr int NRY = kObsNRY, NCX = kObsNCX, KY = kObsKY, KX = kObsKX;
+      const ObsTables& T = a.obs;
+      const float scy = (float)H / (float)T.oh, scx = (float)W / (float)T.ow;
+      const int oy0 = max(0, (int)floorf(((float)ty0 - scy) / scy));
+      const int ox0 = max(0, (int)floorf(((float)tx0 - scx) / scx));
+      if (tid < NRY * KY) {
+        const int j = tid / KY, t = tid - j * KY, oy = oy0 + j;
+        float w = 0.0f;
+        int base = 0;
+        if (oy < T.oh) {
+          const int flo = T.ylo[oy];
+          base = min(max(flo, ty0), ty0 + TH - KY);
+          const int k = base + t - flo;  // tap index of tile row base + t
+          if (k >= 0 && k < T.ycnt[oy] && base + t < H) w = T.wy[(size_t)oy * T.ky + k];
+          base -= ty0;
+        }
+        wly[tid] = w;
+        if (t == 0) wby[j] = base;
+      }
+      if (tid < NCX * KX) {
+        const int q = tid / KX, t = tid - q * KX, ox = ox0 + q;
+        float w = 0.0f;
+        int base = 0;
+        if (ox < T.ow) {
+          const int flo = T.xlo[ox];
+          base = min(max(flo, tx0), tx0 + TW - KX);
+          const int k = base + t - flo;
+          if (k >= 0 && k < T.xcnt[ox] && base + t < W) w = T.wx[(size_t)ox * T.kx + k];
+          base -= tx0;
+        }
+        wlx[tid] = w;
+        if (t == 0) wbx[q] = base;
       }
     }
 #pragma unroll
@@ -288,47 +333,8 @@ __global__ __launch_bounds__(kTailThreads) void taxim_tail_kernel(TailArgs a) {
     constexpr int NRY = kObsNRY, NCX = kObsNCX, KY = kObsKY, KX = kObsKX, TWC = TW * 3;
     static_assert(TH * TWC <= ROWS * P && NRY * TWC <= ROWS * P, "rgb staging / vertical partials must fit a ping-pong buffer");
     static_assert(TWC % 64 == 0 && NT % 64 == 0, "a wave stays inside one observation row in the vertical pass");
-    static_assert(KY <= TH && KX <= TW && KY % 4 == 0 && KX % 4 == 0 && NRY * KY + NCX * KX + NRY + NCX <= RH * P, "tap windows");
+    static_assert(KY <= TH && KX <= TW && KY % 4 == 0 && KX % 4 == 0, "tap windows");
     float* v1 = bufA;                  // [NRY][TWC]; the final level is dead once every strip of the epilogue is shaded
-    float* wly = bufJ;                 // [NRY][KY] taps of cell row j over the KY tile rows starting at wby[j] (0 outside its support)
-    float* wlx = wly + NRY * KY;       // [NCX][KX] same for the cell columns
-    int* wby = reinterpret_cast<int*>(wlx + NCX * KX);  // [NRY] first row of the window (tile-relative)
-    int* wbx = wby + NRY;                                // [NCX]
-    const ObsTables& T = a.obs;
-    const float scy = (float)H / (float)T.oh, scx = (float)W / (float)T.ow;
-    const int oy0 = max(0, (int)floorf(((float)ty0 - scy) / scy));
-    const int ox0 = max(0, (int)floorf(((float)tx0 - scx) / scx));
-    // J is dead after the last restore: build this tile's tap windows there.  A window is KY (KX) consecutive tile rows
-    // (columns) that cover support(cell) ^ tile, so the reductions below run fixed, fully unrolled trip counts with
-    // immediate LDS offsets - every load of an item is in flight at once instead of one latency per tap.
-    if (tid < NRY * KY) {
-      const int j = tid / KY, t = tid - j * KY, oy = oy0 + j;
-      float w = 0.0f;
-      int base = 0;
-      if (oy < T.oh) {
-        const int flo = T.ylo[oy];
-        base = min(max(flo, ty0), ty0 + TH - KY);
-        const int k = base + t - flo;  // tap index of tile row base + t
-        if (k >= 0 && k < T.ycnt[oy] && base + t < H) w = T.wy[(size_t)oy * T.ky + k];
-        base -= ty0;
-      }
-      wly[tid] = w;
-      if (t == 0) wby[j] = base;
-    }
-    if (tid < NCX * KX) {
-      const int q = tid / KX, t = tid - q * KX, ox = ox0 + q;
-      float w = 0.0f;
-      int base = 0;
-      if (ox < T.ow) {
-        const int flo = T.xlo[ox];
-        base = min(max(flo, tx0), tx0 + TW - KX);
-        const int k = base + t - flo;
-        if (k >= 0 && k < T.xcnt[ox] && base + t < W) w = T.wx[(size_t)ox * T.kx + k];
-        base -= tx0;
-      }
-      wlx[tid] = w;
-      if (t == 0) wbx[q] = base;
-    }
     __syncthreads();
     // vertical: item = (cell row j, column*channel xc); j is wave-uniform
     for (int it = tid; it < NRY * TWC; it += NT) {
