@@ -143,10 +143,11 @@ def main():
         sensor.update(dt=0.01, force_recompute=True)
         if obs is not None:
             out = sensor._data.output
-            obs.pack("rgb32", out["tactile_rgb_obs"])  # produced inside the render pass (fused into the tail kernel)
-            obs.pack("indent", sensor.indentation_depth)
+            vals = {"rgb32": out["tactile_rgb_obs"],  # produced inside the render pass (fused into the tail kernel)
+                    "indent": sensor.indentation_depth}
             if markers:
-                obs.pack("markers", out["marker_motion"])
+                vals["markers"] = out["marker_motion"]
+            obs.pack_all(vals)
             obs.gather()
 
     use_dist = dist.is_available() and dist.is_initialized()
@@ -247,7 +248,7 @@ def main():
                 "observation_gather": None if obs is None else {"payload": "32x32x3 f32 RGB (antialiased) + indentation"
                                                                 + (" + markers (2,99,2)" if markers else ""),
                                                                 "bytes_per_rank": obs.payload_bytes(),
-                                                                "collective": "all_gather_into_tensor x1 per step" if args.gpus > 1 else "local copy (N=1)"},
+                                                                "collective": "all_gather_into_tensor x1 per step" if (args.gpus > 1 or use_dist) else "none (N=1: the packed buffer is the observation)"},
                 "background_frame": "synthetic f0 (real dataPack.npz absent from the reference checkout)",
                 "arch": _lib.require_gpu(shard.local_rank),
             },

@@ -368,16 +368,23 @@ static int pipeline_impl(tacex_taxim_ctx* c, const float* hm, const float* press
   char* w = static_cast<char*>(ws);
   float* zbuf[2] = {reinterpret_cast<float*>(w), reinterpret_cast<float*>(w + img)};
   float* tmp = reinterpret_cast<float*>(w + 2 * img);
-  float* sa = reinterpret_cast<float*>(w + 3 * img);
-  float* sb = reinterpret_cast<float*>(w + 3 * img + vec);
-  float* pd = reinterpret_cast<float*>(w + 3 * img + 2 * vec);
+  const float* sa = reinterpret_cast<float*>(w + 3 * img);
+  const float* sb = reinterpret_cast<float*>(w + 3 * img + vec);
+  const float* pd = reinterpret_cast<float*>(w + 3 * img + 2 * vec);
   const bool no_shift = (flags & TACEX_FLAG_NO_SHIFT) != 0;
   if (!(flags & TACEX_FLAG_HAVE_FRAME_MIN)) {
     StageTimer t(c, st, 0);
     HIP_TRY(run_frame_min(hm, false, nullptr, frame_min, nullptr, nullptr, B, c->H * c->W, 0.f, 0.f, 0.f, 0.f, st),
             "frame_min_kernel");
   }
-  HIP_TRY(run_press_depth(frame_min, press, sa, sb, pd, B, no_shift ? 1 : 0, st), "press_depth_kernel");
+  if (no_shift) {  // S = hm, P = -min(hm): zeros / negated minima need their own (B,) arrays
+    HIP_TRY(run_press_depth(frame_min, press, const_cast<float*>(sa), const_cast<float*>(sb), const_cast<float*>(pd), B, 1, st),
+            "press_depth_kernel");
+  } else {
+    // S = (hm - min) - press (TT:441) and P = -min(S) = -((min - min) - press) = press (TT:449): the per-frame scalars
+    // the kernels read ARE the frame-min and press arrays - no (B,)-sized helper launch (~5 us of a ~600 us step)
+    sa = frame_min; sb = press; pd = press;
+  }
   const int n_fused = c->use_tail ? c->n_fused : 0;
   const int n_band = c->n_levels - n_fused;
   const float* src = nullptr;

@@ -75,7 +75,9 @@ class ObservationGather:
         self.row = sum(self.sizes.values())
         self.num_local, self.world = num_local, world_size
         self.local = torch.zeros((num_local, self.row), device=device, dtype=dtype)
-        self.full = torch.zeros((world_size * num_local, self.row), device=device, dtype=dtype)
+        # one rank, no process group: the "gathered" buffer IS the send buffer (no copy); otherwise the collective fills it
+        self._alias = world_size == 1 and not (dist.is_available() and dist.is_initialized())
+        self.full = self.local if self._alias else torch.zeros((world_size * num_local, self.row), device=device, dtype=dtype)
         self._off = {}
         o = 0
         for k, n in self.sizes.items():
@@ -91,13 +93,18 @@ class ObservationGather:
     def pack(self, name: str, value: torch.Tensor):
         self.slot(name).copy_(value.reshape(self.num_local, -1))
 
+    def pack_all(self, values: dict[str, torch.Tensor]):
+        """Fill the whole send buffer with ONE kernel (a concatenation along the row) instead of one strided copy per
+        piece: at 256 envs every extra launch costs ~5 us of a ~600 us step."""
+        torch.cat([values[k].reshape(self.num_local, -1) for k in self.pieces], dim=1, out=self.local)
+
     def payload_bytes(self) -> int:
         return self.local.numel() * self.local.element_size()
 
     def gather(self) -> dict[str, torch.Tensor]:
         if self.world > 1 or (dist.is_available() and dist.is_initialized()):
             dist.all_gather_into_tensor(self.full, self.local)  # the single collective of the step
-        else:
+        elif not self._alias:
             self.full.copy_(self.local)
         out = {}
         for k, shape in self.pieces.items():

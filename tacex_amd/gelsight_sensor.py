@@ -65,6 +65,11 @@ class GelSightSensor(SensorBase):
 
     @property
     def frame(self) -> torch.Tensor:
+        """Per-env update counter (gelsight_sensor.py:345).  Full-batch updates only bump a host integer (no kernel per
+        step); the tensor is materialised on read."""
+        if self._frame_pending:
+            self._frame += self._frame_pending
+            self._frame_pending = 0
         return self._frame
 
     @property
@@ -128,7 +133,7 @@ class GelSightSensor(SensorBase):
             self._data.output["marker_motion"][:] = self.marker_motion_simulator.marker_motion_simulation()
             self._data.output["init_marker_pos"] = ([0], [0])
             self.marker_motion_simulator.reset()
-        self._frame[env_ids] = 0
+        self._frame[env_ids] = -self._frame_pending  # frame == 0 once the pending full-batch increments are folded in
 
     # -- initialisation (gelsight_sensor.py:203-337) -----------------------------------------------------------
     def _initialize_impl(self):
@@ -141,6 +146,7 @@ class GelSightSensor(SensorBase):
         _lib.require_gpu(dev.index or 0)
         self._ALL_INDICES = torch.arange(self._num_envs, device=self._device, dtype=torch.long)
         self._frame = torch.zeros(self._num_envs, device=self._device, dtype=torch.long)
+        self._frame_pending = 0
         self._indentation_depth = torch.zeros((self._num_envs,), device=self._device)
         Wc, Hc = self.camera_resolution
         self._data.output["height_map"] = torch.zeros((self._num_envs, Hc, Wc), device=self._device)
@@ -186,6 +192,11 @@ class GelSightSensor(SensorBase):
             self.compute_indentation_depth_func = self.marker_motion_simulator.compute_indentation_depth
         else:
             self.compute_indentation_depth_func = None
+        # the provider fills its own (B,) buffer in the fused depth pass: share it instead of copying it every step
+        provider = getattr(self.compute_indentation_depth_func, "__self__", None)
+        buf = getattr(provider, "_indentation_depth", None)
+        if isinstance(buf, torch.Tensor) and buf.is_cuda and tuple(buf.shape) == (self._num_envs,):
+            self._indentation_depth = buf
         self._is_initialized = True
         self._reset_impl(None)
 
@@ -193,7 +204,7 @@ class GelSightSensor(SensorBase):
     def _update_buffers_impl(self, env_ids: Sequence[int]):
         # like the reference, env_ids only selects which frame counters advance: all envs are recomputed
         if isinstance(env_ids, slice):
-            self._frame += 1
+            self._frame_pending += 1
         else:
             self._frame[env_ids.to(self._frame.device)] += 1
 

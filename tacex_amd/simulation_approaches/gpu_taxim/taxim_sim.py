@@ -117,7 +117,7 @@ class TaximSimulator(GelSightSimulator):
         return self._indentation_depth
 
     def reset(self):
-        self._indentation_depth = torch.zeros((self._num_envs,), device=self._device)
+        self._indentation_depth.zero_()  # in place (taxim_sim.py:141 re-allocates): the sensor shares this buffer
         self.tactile_rgb_img[:] = self.background_img
         self._frame_min_version = -1
         self._indent_version = -1

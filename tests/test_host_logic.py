@@ -155,6 +155,10 @@ def test_observation_gather_single_process():
     out = g.gather()
     assert torch.equal(out["rgb32"], rgb) and out["indent"].reshape(-1).tolist() == [1.0, 2.0, 3.0]
     assert g.payload_bytes() == 3 * (48 + 1 + 20) * 4
+    # one-kernel packing of all pieces gives the same send buffer
+    g2 = ObservationGather({"rgb32": (4, 4, 3), "indent": (1,), "markers": (2, 5, 2)}, num_local=3, world_size=1, device="cpu")
+    g2.pack_all({"markers": torch.ones(3, 2, 5, 2), "rgb32": rgb, "indent": torch.tensor([1.0, 2.0, 3.0])})
+    assert torch.equal(g2.local, g.local)
 
 
 def test_fem_marker_setup_vs_reference(golden_dir):
