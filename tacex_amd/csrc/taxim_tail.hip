@@ -20,6 +20,14 @@ constexpr int kTailMaxLevels = 5;
 // 8 waves per workgroup, 2 per SIMD: two workgroups per CU (LDS-bound) then need 4 wave slots and <= 128 VGPRs per SIMD.
 // (640 threads measured 25 % slower: 3+3+2+2 waves per workgroup leave no room for the second workgroup's 3 on a SIMD.)
 constexpr int kTailThreads = 512;
+// true: J = min(S, gel) and the contact mask of the whole region stay in LDS across the three restores (28 KB of the
+// 80.9 KB: TWO workgroups per CU).  false: J is not cached and the mask is kept as 4 bits per 4-pixel group (54.1 KB =
+// three workgroups per CU, needs <= 80 VGPRs); the restore then re-reads hm / gel (L2 hits) for groups with a mask bit.
+// Measured at 256 x 320x240 (round 1): cached 253 us; uncached at the 128-VGPR budget (still 2 per CU) 264 us; uncached
+// at the 80-VGPR budget (3 per CU, 31 spilled VGPRs) 329 us - the third workgroup does not pay while the epilogue
+// spills, so the cached layout stays the default.
+constexpr bool kTailCacheJ = true;
+constexpr int kTailWavesPerSimd = kTailCacheJ ? 4 : 6;  // register budget: 128 / 80 VGPRs  // register budget: 128 / 80 VGPRs
 // observation cells a 64 x 32 tile can overlap when the down-sampling factor is >= 7.5 (y) / >= 8 (x): tile / scale + 3
 constexpr int kObsNRY = 8, kObsNCX = 11;
 // longest triangle filter the fused observation handles (taps per output row / column); longer ones take the two-pass resize
@@ -60,19 +68,23 @@ struct TailCfg {
   // valid margin needed after level l = sum of the radii of levels l+1.. plus 2 (gradient + replicate clamp)
   static constexpr int margin_after(int l) { int s = 2; for (int i = l + 1; i < NL; ++i) s += (K[i] - 1) / 2; return s; }
   static constexpr size_t obs_lds_bytes() { return (size_t)(kObsNRY * kObsKY + kObsNCX * kObsKX + kObsNRY + kObsNCX + 1) / 4 * 16 + 16; }
-  static constexpr size_t lds_bytes() { return (size_t)(2 * ROWS * P + RH * P) * sizeof(float) + (size_t)RH * P + obs_lds_bytes(); }
+  static constexpr size_t mask_lds_bytes() { return kTailCacheJ ? (size_t)RH * P : (((size_t)RH * (RW / 4) + 15) / 16) * 16; }
+  static constexpr size_t lds_bytes() {
+    return (size_t)(2 * ROWS * P + (kTailCacheJ ? RH * P : 0)) * sizeof(float) + mask_lds_bytes() + obs_lds_bytes();
+  }
 };
 
 template <int... KS>
-__global__ __launch_bounds__(kTailThreads) void taxim_tail_kernel(TailArgs a) {
+__global__ __launch_bounds__(kTailThreads, kTailWavesPerSimd) void taxim_tail_kernel(TailArgs a) {
   using C = TailCfg<KS...>;
   constexpr int NL = C::NL, TW = C::TW, TH = C::TH, HLY = C::HLY, HLX = C::HLX, RW = C::RW, RH = C::RH;
   constexpr int PADX = C::PADX, PADY = C::PADY, P = C::P, ROWS = C::ROWS;
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   float* bufA = reinterpret_cast<float*>(smem_raw);
   float* bufB = bufA + ROWS * P;
-  float* bufJ = bufB + ROWS * P;                       // RH x P
-  uint8_t* bufM = reinterpret_cast<uint8_t*>(bufJ + RH * P);  // RH x P
+  float* bufJ = bufB + ROWS * P;                       // RH x P (kTailCacheJ only)
+  uint8_t* bufM = reinterpret_cast<uint8_t*>(bufJ + (kTailCacheJ ? RH * P : 0));  // RH x P bytes, or RH x RW/4 nibbles
+  constexpr int MG = RW / 4;                           // mask groups per region row (!kTailCacheJ)
 
   const int H = a.H, W = a.W;
   const int ntx = (W + TW - 1) / TW, nty = (H + TH - 1) / TH;
@@ -93,7 +105,7 @@ __global__ __launch_bounds__(kTailThreads) void taxim_tail_kernel(TailArgs a) {
   // consecutive tile rows (columns) covering support(cell) ^ tile, so the reductions run fixed, fully unrolled trip
   // counts with immediate LDS offsets.  Built here, in its own LDS area, so that the dependent table loads overlap the
   // tile load instead of sitting exposed between the epilogue and the reduction.
-  float* wly = reinterpret_cast<float*>(bufM + RH * P);  // [NRY][KY] taps of cell row j over the KY tile rows from wby[j]
+  float* wly = reinterpret_cast<float*>(bufM + C::mask_lds_bytes());  // [NRY][KY] taps of cell row j over the KY tile rows from wby[j]
   float* wlx = wly + kObsNRY * kObsKY;                    // [NCX][KX] same for the cell columns
   int* wby = reinterpret_cast<int*>(wlx + kObsNCX * kObsKX);  // [NRY] first row of the window (tile-relative)
   int* wbx = wby + kObsNRY;                                    // [NCX]
@@ -183,8 +195,12 @@ __global__ __launch_bounds__(kTailThreads) void taxim_tail_kernel(TailArgs a) {
           Jv[k] = J;
           mk[k] = (((J - gv[ps][k]) < thr) && (S < 0.0f)) ? 1 : 0;  // TT:457-461
         }
-        *reinterpret_cast<v4f*>(bufJ + ly * P + PADX + lx) = Jv;
-        *reinterpret_cast<uchar4*>(bufM + ly * P + PADX + lx) = (uchar4){mk[0], mk[1], mk[2], mk[3]};
+        if constexpr (kTailCacheJ) {
+          *reinterpret_cast<v4f*>(bufJ + ly * P + PADX + lx) = Jv;
+          *reinterpret_cast<uchar4*>(bufM + ly * P + PADX + lx) = (uchar4){mk[0], mk[1], mk[2], mk[3]};
+        } else {
+          bufM[ly * MG + (lx >> 2)] = (uint8_t)(mk[0] | (mk[1] << 1) | (mk[2] << 2) | (mk[3] << 3));
+        }
       }
     }
   }
@@ -245,10 +261,33 @@ __global__ __launch_bounds__(kTailThreads) void taxim_tail_kernel(TailArgs a) {
           constexpr int r = decltype(rc)::value;
           v4f o = acc[r];
           if constexpr (l < NL - 1) {  // TT:467 Z[M] = J[M]; the final blur (TT:468-471) has no restore
-            const int ci = (ly0 + r) * P + PADX + x0;
-            const v4f Jv = *reinterpret_cast<const v4f*>(bufJ + ci);
-            const uchar4 Mv = *reinterpret_cast<const uchar4*>(bufM + ci);
-            o.x = Mv.x ? Jv.x : o.x; o.y = Mv.y ? Jv.y : o.y; o.z = Mv.z ? Jv.z : o.z; o.w = Mv.w ? Jv.w : o.w;
+            if constexpr (kTailCacheJ) {
+              const int ci = (ly0 + r) * P + PADX + x0;
+              const v4f Jv = *reinterpret_cast<const v4f*>(bufJ + ci);
+              const uchar4 Mv = *reinterpret_cast<const uchar4*>(bufM + ci);
+              o.x = Mv.x ? Jv.x : o.x; o.y = Mv.y ? Jv.y : o.y; o.z = Mv.z ? Jv.z : o.z; o.w = Mv.w ? Jv.w : o.w;
+            } else {
+              const unsigned bits = bufM[(ly0 + r) * MG + (x0 >> 2)];
+              if (bits) {  // contact pixels only: J = min(S, gel) again, from the (reflected) height map / gel in L2
+                const unsigned ro = (unsigned)min(max(reflect_idx(gy0 + ly0 + r, H), 0), H - 1) * (unsigned)W;
+                const int gx = gx0 + x0;
+                v4f hq, gq;
+                if (gx >= 0 && gx + 3 < W) {
+                  hq = *reinterpret_cast<const v4f*>(hm + ro + gx);
+                  gq = *reinterpret_cast<const v4f*>(a.gel + ro + gx);
+                } else {
+#pragma unroll
+                  for (int k = 0; k < 4; ++k) {
+                    const unsigned xo = (unsigned)min(max(reflect_idx(gx + k, W), 0), W - 1);
+                    hq[k] = hm[ro + xo];
+                    gq[k] = a.gel[ro + xo];
+                  }
+                }
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                  if (bits & (1u << k)) o[k] = fmin_raw((hq[k] - sa) - sb, gq[k]);
+              }
+            }
           }
           *reinterpret_cast<v4f*>(bufA + (ly0 + r + PADY) * P + PADX + x0) = o;
         });
@@ -256,6 +295,7 @@ __global__ __launch_bounds__(kTailThreads) void taxim_tail_kernel(TailArgs a) {
       __syncthreads();
     } else if constexpr (l < NL - 1) {
       // K == 1: the blur is the identity (single tap = 1.0) but the restore still runs
+      static_assert(kTailCacheJ, "the k == 1 restore reads the cached J");
       for (int c = tid; c < RH * RW; c += NT) {
         const int ly = c / RW, lx = c - ly * RW;
         if (bufM[ly * P + PADX + lx]) bufA[(ly + PADY) * P + PADX + lx] = bufJ[ly * P + PADX + lx];
@@ -281,11 +321,19 @@ __global__ __launch_bounds__(kTailThreads) void taxim_tail_kernel(TailArgs a) {
     const float* crow = bufA + (ly + PADY) * P + PADX + lx;
     if (fast_w) {  // whole strip inside the image
       if (a.z_out) *reinterpret_cast<v4f*>(reinterpret_cast<char*>(a.z_out + fo) + p * 4u) = *reinterpret_cast<const v4f*>(crow);
-      if (a.mask_out) *reinterpret_cast<uchar4*>(a.mask_out + fo + p) = *reinterpret_cast<const uchar4*>(bufM + ly * P + PADX + lx);
+      if (a.mask_out) {
+        uchar4 mv;
+        if constexpr (kTailCacheJ) mv = *reinterpret_cast<const uchar4*>(bufM + ly * P + PADX + lx);
+        else {
+          const unsigned bits = bufM[ly * MG + (lx >> 2)];
+          mv = (uchar4){(uint8_t)(bits & 1), (uint8_t)((bits >> 1) & 1), (uint8_t)((bits >> 2) & 1), (uint8_t)((bits >> 3) & 1)};
+        }
+        *reinterpret_cast<uchar4*>(a.mask_out + fo + p) = mv;
+      }
     } else {
       for (int i = 0; i < 4 && gx + i < W; ++i) {
         if (a.z_out) a.z_out[fo + p + i] = crow[i];
-        if (a.mask_out) a.mask_out[fo + p + i] = bufM[ly * P + PADX + lx + i];
+        if (a.mask_out) a.mask_out[fo + p + i] = kTailCacheJ ? bufM[ly * P + PADX + lx + i] : (uint8_t)((bufM[ly * MG + (lx >> 2)] >> i) & 1);
       }
     }
     if (a.sh.rgb) {
