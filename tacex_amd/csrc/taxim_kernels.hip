@@ -299,13 +299,19 @@ __global__ __launch_bounds__(NT, 3) void blur_band_kernel(BlurArgs a) {
 // Useful MACs / issued MACs = K / WIN (0.76 at K = 61, 0.69 at 33, 0.53 at 17).
 // ------------------------------------------------------------------------------------------------
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+#ifndef TACEX_MFMA_CH
+#define TACEX_MFMA_CH 4
+#endif
+#ifndef TACEX_MFMA_FENCE
+#define TACEX_MFMA_FENCE 0
+#endif
 
 template <int K, bool FIRST, int NTILE>
 __global__ __launch_bounds__(640) void blur_mfma_kernel(BlurArgs a) {
   constexpr int TH = 16 * NTILE;
   constexpr int R = (K - 1) / 2, RA = (R + 7) & ~7, WIN = 16 + 2 * RA, KS = WIN / 4;
   constexpr int KU = KS + 4 * (NTILE - 1);  // k-steps over the union window of the band's tiles
-  constexpr int CH = 4, NCH = KU / CH;      // k-steps per software-pipeline chunk
+  constexpr int CH = TACEX_MFMA_CH, NCH = KU / CH;      // k-steps per software-pipeline chunk
   static_assert(KU % CH == 0 && KS % 4 == 0, "window");
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   float* mid = reinterpret_cast<float*>(smem_raw);  // TH x pitch, columns padded by RA on both sides
@@ -313,7 +319,9 @@ __global__ __launch_bounds__(640) void blur_mfma_kernel(BlurArgs a) {
   const int lid = xcd_remap(blockIdx.x, gridDim.x);
   const int frame = lid / a.nbands;
   const int band = lid - frame * a.nbands;
-  const int by0 = a.row0 + band * TH;
+  // the last band of a frame is shifted up when TH does not divide H: its first rows recompute (identically) what the
+  // band above stores - cheaper than a second, nearly empty launch for the remainder
+  const int by0 = min(a.row0 + band * TH, H - TH);
   const size_t fo = (size_t)frame * H * W;
   const float* __restrict__ src = FIRST ? a.hm + fo : a.src + fo;
   const float* __restrict__ hm = a.hm + fo;
@@ -353,7 +361,9 @@ __global__ __launch_bounds__(640) void blur_mfma_kernel(BlurArgs a) {
     issue(std::integral_constant<int, 0>{});
     static_for<0, NCH>([&](auto chunk_c) {
       constexpr int chunk = decltype(chunk_c)::value;
+      if constexpr (TACEX_MFMA_FENCE) __builtin_amdgcn_sched_barrier(0);
       if constexpr (chunk + 1 < NCH) issue(std::integral_constant<int, chunk + 1>{});
+      if constexpr (TACEX_MFMA_FENCE) __builtin_amdgcn_sched_barrier(0);
       static_for<0, CH>([&](auto cc) {
         constexpr int c = decltype(cc)::value;
         constexpr int ku = chunk * CH + c;
@@ -476,25 +486,17 @@ static hipError_t launch_mfma_tiles(BlurArgs a, int row0, int nbands, hipStream_
 }
 
 // TACEX_MFMA_TILES (A/B hook): 16-row tiles per band, 1..3.  Default 1: taller bands cut the V-pass L2 -> L1 traffic
-// (5x -> 3x at k = 61) but measured 3-15 % slower at 256 x 320x240 (fewer, longer workgroups per CU).  Rows left over by the tall bands (H % (16 NTILE))
-// are served by a second launch of the next smaller band height.
+// (5x -> 3x at k = 61) but measured 3-8 % slower at 256 x 320x240 (fewer, longer workgroups per CU).
 template <int K, bool FIRST>
 static hipError_t launch_mfma(const BlurArgs& a, hipStream_t st) {
   static const int ntile_env = getenv("TACEX_MFMA_TILES") ? atoi(getenv("TACEX_MFMA_TILES")) : 1;
-  int done = 0;
-  hipError_t e = hipSuccess;
-  for (int nt = ntile_env < 1 ? 1 : (ntile_env > 3 ? 3 : ntile_env); nt >= 1 && done < a.H && e == hipSuccess; --nt) {
-    const int nb = (a.H - done) / (16 * nt);
-    if (nb == 0) continue;
-    if (nt == 3) e = launch_mfma_tiles<K, FIRST, 3>(a, done, nb, st);
-    else if (nt == 2) e = launch_mfma_tiles<K, FIRST, 2>(a, done, nb, st);
-    else e = launch_mfma_tiles<K, FIRST, 1>(a, done, nb, st);
-    done += nb * 16 * nt;
-  }
-  return e;
+  const int nt = ntile_env < 1 ? 1 : (ntile_env > 3 ? 3 : ntile_env);
+  if (nt == 3 && a.H >= 48) return launch_mfma_tiles<K, FIRST, 3>(a, 0, (a.H + 47) / 48, st);
+  if (nt >= 2 && a.H >= 32) return launch_mfma_tiles<K, FIRST, 2>(a, 0, (a.H + 31) / 32, st);
+  return launch_mfma_tiles<K, FIRST, 1>(a, 0, a.H / 16, st);
 }
 
-// TACEX_BLUR_MFMA: 1 (default) = matrix-core band kernels where compiled (k = 61 / 33 / 17), 0 = VALU band kernels only
+// TACEX_BLUR_MFMA: 1 (default) = matrix-core band kernels where compiled (k = 117 / 61 / 33 / 17), 0 = VALU band kernels only
 static int mfma_enabled() {
   static int v = -1;
   if (v < 0) { const char* e = getenv("TACEX_BLUR_MFMA"); v = e ? atoi(e) : 1; }
@@ -505,13 +507,14 @@ static bool mfma_supported(int k, bool first, int H, int W) {
   if (!mfma_enabled() || W % 64 != 0 || W < 64 || W > 640 || H % 16 != 0) return false;
   const int R = (k - 1) / 2;
   if (R >= H || R > W - 1 || ((R + 7) & ~7) >= W) return false;
-  if (first) return k == 61;
-  return k == 61 || k == 33 || k == 17;
+  if (first) return k == 61 || k == 117;
+  return k == 117 || k == 61 || k == 33 || k == 17;
 }
 
 static hipError_t dispatch_mfma(int k, bool first, const BlurArgs& a, hipStream_t st) {
-  if (first) return launch_mfma<61, true>(a, st);
+  if (first) return k == 117 ? launch_mfma<117, true>(a, st) : launch_mfma<61, true>(a, st);
   switch (k) {
+    case 117: return launch_mfma<117, false>(a, st);
     case 61: return launch_mfma<61, false>(a, st);
     case 33: return launch_mfma<33, false>(a, st);
     case 17: return launch_mfma<17, false>(a, st);
