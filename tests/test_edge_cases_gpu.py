@@ -141,3 +141,35 @@ def test_params_override_and_unknown_key(calib_dir):
     with pytest.raises(ValueError, match="Unknown key"):
         Taxim(calib_folder=calib_dir, params={"simulator": {"bogus": 1}}, backend="hip", device="cuda:0")
     assert t.background_img.shape == (3, 480, 640)
+
+
+def test_chunked_pipeline_is_bit_identical(calib_dir, tmp_path):
+    """Large shards are walked in chunks that re-use the same scratch images (Infinity-Cache residency).  Chunking must
+    not change a single bit of RGB, deformed gel, mask or observation (TACEX_CHUNK_FRAMES is read once per process)."""
+    import os
+    import subprocess
+    import sys
+
+    from conftest import REPO
+
+    script = tmp_path / "chunk_run.py"
+    script.write_text(
+        "import sys, numpy as np, torch\n"
+        f"sys.path.insert(0, {str(REPO)!r})\n"
+        "from tacex_amd.simulation_approaches.gpu_taxim.sim import Taxim\n"
+        "from tacex_amd.utils.synthetic import synthetic_depth_maps\n"
+        f"t = Taxim(calib_folder={str(calib_dir)!r}, backend='hip', device='cuda:0')\n"
+        "hm, ind = synthetic_depth_maps(7, 240, 320, seed=11, device='cuda')\n"
+        "z = torch.empty((7, 240, 320), device='cuda'); m = torch.empty((7, 240, 320), dtype=torch.uint8, device='cuda')\n"
+        "obs = torch.empty((7, 32, 32, 3), device='cuda')\n"
+        "rgb = t.render_direct(hm, False, ind, z_out=z, mask_out=m, obs_out=obs)\n"
+        "np.savez(sys.argv[1], rgb=rgb.cpu().numpy(), z=z.cpu().numpy(), m=m.cpu().numpy(), obs=obs.cpu().numpy())\n")
+    outs = {}
+    for chunk in ("0", "3"):
+        out = tmp_path / f"c{chunk}.npz"
+        env = dict(os.environ, TACEX_CHUNK_FRAMES=chunk)
+        r = subprocess.run([sys.executable, str(script), str(out)], env=env, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs[chunk] = np.load(out)
+    for k in ("rgb", "z", "m", "obs"):
+        np.testing.assert_array_equal(outs["0"][k], outs["3"][k])
