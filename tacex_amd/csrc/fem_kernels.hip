@@ -18,6 +18,7 @@
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include <vector>
 
@@ -587,6 +588,302 @@ __global__ __launch_bounds__(512) void fem_newton_kernel(FemDev m, double* xg, c
   }
 }
 
+// ---- K17c: the same Newton iteration with the env's state resident on the CU ------------------------------------
+// fem_newton_kernel above streams ~700 KB per env and PCG iteration through HBM / L2 (cached tet state, per-tet H*p rows,
+// seven nodal vectors): 81 us per PCG iteration for 512 envs, bandwidth-bound.  Here
+//   * thread v OWNS vertex v (V <= 512): x, r, z, p, d, H*p and the 3x3 preconditioner block live in registers;
+//   * only what tets gather at random - x and p - sits in LDS (2 x 12 KB at 495 vertices);
+//   * the tet state (F, cofactor, coefficients) is RECOMPUTED from the LDS x every iteration (~80 f64 FMAs) instead of
+//     being re-read (96 B per tet);
+//   * per-tet rows travel to their vertices through a 48 KB LDS window of 512 tets at a time; each vertex walks its CSR
+//     incidence list (sorted by tet) once per iteration, so the result is deterministic (the order differs from the
+//     streaming kernel's only by the tet renumbering of tacex_fem_create).
+// Mesh constants (tets, DmInv, vol, CSR) are the only global reads inside the PCG loop and are shared by all envs (L2).
+constexpr int kNwtThreads = 512;
+constexpr int kNwtChunk = 512;  // tets per LDS exchange window (1024 = 2 per thread measured slower: 90 spilled VGPRs)
+constexpr int kNwtTpw = kNwtChunk / kNwtThreads;
+
+// block-wide sum with ONE barrier: wave partials go to one of two alternating LDS rows and every thread adds them in the
+// same fixed order (the row written two calls ago cannot still be read: a barrier lies in between)
+__device__ __forceinline__ double block_sum1(double v, double* sh2 /* 2 x 8 doubles */, int& phase) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  double* row = sh2 + 8 * (phase & 1);
+  ++phase;
+  if ((threadIdx.x & 63) == 0) row[threadIdx.x >> 6] = v;
+  __syncthreads();
+  double s = 0.0;
+#pragma unroll
+  for (int w = 0; w < kNwtThreads / 64; ++w) s += row[w];
+  return s;
+}
+
+__device__ __forceinline__ double env_energy_lds(const FemDev& m, const double* xl, const double x3[3], const double* xt,
+                                                 bool own, bool c, const double* aim, double* sh, int& phase) {
+  double e = 0.0;
+  const double dt2 = m.dt * m.dt;
+  for (int t = threadIdx.x; t < m.T; t += blockDim.x) {
+    int v[4];
+    double Di[9], F[9];
+    load_tet(m, t, v, Di);
+    deformation_gradient(xl, v, Di, F);
+    TetState s;
+    tet_state(m, F, s);
+    e += dt2 * m.vol[t] * psi_of(m, s);
+  }
+  if (own) {
+    const int v = threadIdx.x;
+    const double mv = m.mass[v];
+    double q = 0.0, qc = 0.0;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      const double d = x3[i] - xt[v * 3 + i];
+      q += d * d;
+      if (c) { const double cc = x3[i] - aim[v * 3 + i]; qc += cc * cc; }
+    }
+    e += 0.5 * mv * q + 0.5 * m.strength * mv * qc;
+  }
+  return block_sum1(e, sh, phase);
+}
+
+__global__ __launch_bounds__(kNwtThreads) void fem_newton_lds_kernel(FemDev m, double* xg, const double* xtg,
+                                                                     const uint8_t* consg, const double* aimg, double* stats,
+                                                                     int pcg_max_iter, double pcg_tol_rate, int ls_max_iter) {
+  extern __shared__ __attribute__((aligned(16))) double nlds[];
+  constexpr int CH = kNwtChunk;
+  const int V = m.V, T = m.T, tid = threadIdx.x;
+  double* xs = nlds;            // (V,3) current x
+  double* ps = xs + 3 * V;      // (V,3) PCG direction p, later the line-search candidate
+  double* hv = ps + 3 * V;      // (12, CH) per-tet rows of the current window
+  double* sh = hv + 12 * CH;    // 2 x 8 wave partials of block_sum1 (+2 pad)
+  int* csr = reinterpret_cast<int*>(sh + 18);  // (4T) incidence codes tet * 4 + local, vertex-major: read every sweep
+  int phase = 0;  // block_sum1 row toggle
+  const int b = blockIdx.x;
+  const size_t o = (size_t)b * V * 3;
+  double* x = xg + o;
+  const double* xt = xtg + o;
+  const double* aim = aimg ? aimg + o : nullptr;
+  const bool own = tid < V;
+  const bool c = own && consg && consg[(size_t)b * V + tid];
+  const double dt2 = m.dt * m.dt;
+  const int nchunk = (T + CH - 1) / CH;
+  const int e_begin = own ? m.vt_off[tid] : 0, e_end = own ? m.vt_off[tid + 1] : 0;
+  const double mv = own ? m.mass[tid] : 0.0;
+  const double md = mv * (1.0 + (c ? m.strength : 0.0));
+
+  double x3[3] = {0, 0, 0};
+  if (own) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { x3[i] = x[tid * 3 + i]; xs[tid * 3 + i] = x3[i]; }
+  }
+  for (int k = tid; k < 4 * T; k += kNwtThreads) csr[k] = m.vt_idx[k];
+  __syncthreads();
+
+  // one sweep over the tets in windows of CH = kNwtTpw x 512: `make(v, Di, vol, rows)` fills the 12 rows of a tet (each thread
+  // owns kNwtTpw independent tets of the window), then vertex `tid` adds the rows of its incident tets inside the window
+  // (CSR entries are sorted by tet, so a cursor suffices).  The mesh constants of the NEXT window are fetched while this
+  // window is computed and gathered (they are the only global reads of the sweep).
+  auto sweep = [&](auto&& make, double acc[3]) {
+    int e = e_begin;
+    int code = e < e_end ? csr[e] : 0x7fffffff;
+    acc[0] = acc[1] = acc[2] = 0.0;
+    int vn[kNwtTpw][4];
+    double Din[kNwtTpw][9], voln[kNwtTpw];
+#pragma unroll
+    for (int u = 0; u < kNwtTpw; ++u) {
+      const int t = u * kNwtThreads + tid;
+      voln[u] = 0.0;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) vn[u][k] = 0;
+#pragma unroll
+      for (int k = 0; k < 9; ++k) Din[u][k] = 0.0;
+      if (t < T) { load_tet(m, t, vn[u], Din[u]); voln[u] = m.vol[t]; }
+    }
+    for (int j = 0; j < nchunk; ++j) {
+      int v[kNwtTpw][4];
+      double Di[kNwtTpw][9], vol[kNwtTpw];
+#pragma unroll
+      for (int u = 0; u < kNwtTpw; ++u) {
+        vol[u] = voln[u];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[u][k] = vn[u][k];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) Di[u][k] = Din[u][k];
+        const int tn = (j + 1) * CH + u * kNwtThreads + tid;
+        if (tn < T) { load_tet(m, tn, vn[u], Din[u]); voln[u] = m.vol[tn]; }
+      }
+#pragma unroll
+      for (int u = 0; u < kNwtTpw; ++u) {
+        const int tl = u * kNwtThreads + tid;
+        if (j * CH + tl < T) {
+          double rows[12];
+          make(v[u], Di[u], vol[u], rows);
+#pragma unroll
+          for (int k = 0; k < 12; ++k) hv[k * CH + tl] = rows[k];
+        }
+      }
+      __syncthreads();
+      const int tend4 = (j + 1) * CH * 4;
+      while (code < tend4) {  // `code` always holds entry e (or INT_MAX past the list): its successor is fetched while the
+        const int l = code & 3, tl = (code >> 2) - j * CH;  // rows of this entry are in flight - one LDS latency per entry
+        ++e;
+        const int nxt = e < e_end ? csr[e] : 0x7fffffff;
+        acc[0] += hv[(l * 3 + 0) * CH + tl];
+        acc[1] += hv[(l * 3 + 1) * CH + tl];
+        acc[2] += hv[(l * 3 + 2) * CH + tl];
+        code = nxt;
+      }
+      if (j + 1 < nchunk) __syncthreads();  // the window is rewritten; after the last one the caller's next barrier suffices
+    }
+  };
+
+  // ---- nodal gradient ----
+  double r3[3], d3[3] = {0, 0, 0};
+  {
+    double a3[3];
+    sweep([&](const int* v, const double* Di, double vol, double* g) {
+      double F[9], r[12];
+      deformation_gradient(xs, v, Di, F);
+      TetState s;
+      tet_state(m, F, s);
+      shape_rows(Di, r);
+      element_gradient(s, r, dt2 * vol, g);
+    }, a3);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      double gi = 0.0;
+      if (own) {
+        gi = a3[i] + mv * (x3[i] - xt[tid * 3 + i]);
+        if (c) gi += m.strength * mv * (x3[i] - aim[tid * 3 + i]);
+      }
+      r3[i] = -gi;
+    }
+  }
+  // ---- block-Jacobi preconditioner: 3x3 diagonal block of vertex tid (columns recomputed per incidence) ----
+  double Dinv[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+  if (own) {
+    double D[9] = {md, 0, 0, 0, md, 0, 0, 0, md};
+    for (int e = e_begin; e < e_end; ++e) {
+      const int code = csr[e];
+      const int t = code >> 2, l = code & 3;
+      int v[4];
+      double Di[9], F[9], r[12];
+      load_tet(m, t, v, Di);
+      deformation_gradient(xs, v, Di, F);
+      TetState s;
+      tet_state(m, F, s);
+      shape_rows(Di, r);
+      const double sc = dt2 * m.vol[t];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        double dF[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, dP[9];
+        dF[k * 3 + 0] = r[l * 3 + 0]; dF[k * 3 + 1] = r[l * 3 + 1]; dF[k * 3 + 2] = r[l * 3 + 2];
+        apply_dP(m, s, dF, dP);
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+          D[i * 3 + k] += sc * (dP[i * 3 + 0] * r[l * 3 + 0] + dP[i * 3 + 1] * r[l * 3 + 1] + dP[i * 3 + 2] * r[l * 3 + 2]);
+      }
+    }
+    if (!inv3_spd(D, Dinv)) {  // elastic block not SPD -> mass block (always SPD)
+      const double im = 1.0 / md;
+      Dinv[0] = im; Dinv[1] = 0; Dinv[2] = 0; Dinv[3] = 0; Dinv[4] = im; Dinv[5] = 0; Dinv[6] = 0; Dinv[7] = 0; Dinv[8] = im;
+    }
+  }
+  // ---- PCG ----
+  double z3[3], p3[3];
+  double part = 0.0;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    z3[i] = Dinv[i * 3 + 0] * r3[0] + Dinv[i * 3 + 1] * r3[1] + Dinv[i * 3 + 2] * r3[2];
+    p3[i] = z3[i];
+    part += r3[i] * z3[i];
+  }
+  double rz = block_sum1(part, sh, phase);
+  const double rz0 = rz;
+  int it = 0;
+  while (it < pcg_max_iter && rz0 > 0.0 && rz > pcg_tol_rate * pcg_tol_rate * rz0) {
+    if (own) {
+#pragma unroll
+      for (int i = 0; i < 3; ++i) ps[tid * 3 + i] = p3[i];
+    }
+    __syncthreads();
+    // Hp = (M + s Mc + dt^2 K) p, matrix-free: per-tet dP[dF(p)] rows, gathered per vertex
+    double a3[3];
+    sweep([&](const int* v, const double* Di, double vol, double* rows) {
+      double F[9], dF[9], dP[9], r[12];
+      deformation_gradient(xs, v, Di, F);
+      deformation_gradient(ps, v, Di, dF);  // linear in p
+      TetState s;
+      tet_state(m, F, s);
+      apply_dP(m, s, dF, dP);
+      shape_rows(Di, r);
+      const double sc = dt2 * vol;
+#pragma unroll
+      for (int w = 0; w < 4; ++w)
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+          rows[w * 3 + i] = sc * (dP[i * 3 + 0] * r[w * 3 + 0] + dP[i * 3 + 1] * r[w * 3 + 1] + dP[i * 3 + 2] * r[w * 3 + 2]);
+    }, a3);
+    double Hp3[3];
+    part = 0.0;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      Hp3[i] = own ? a3[i] + md * p3[i] : 0.0;
+      part += p3[i] * Hp3[i];
+    }
+    const double pHp = block_sum1(part, sh, phase);
+    if (!(pHp > 0.0)) {  // negative curvature: keep d (first iteration: preconditioned steepest descent)
+      if (it == 0) { d3[0] = z3[0]; d3[1] = z3[1]; d3[2] = z3[2]; }
+      break;
+    }
+    const double al = rz / pHp;
+    part = 0.0;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      d3[i] += al * p3[i];
+      r3[i] -= al * Hp3[i];
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      z3[i] = Dinv[i * 3 + 0] * r3[0] + Dinv[i * 3 + 1] * r3[1] + Dinv[i * 3 + 2] * r3[2];
+      part += r3[i] * z3[i];
+    }
+    const double rz_new = block_sum1(part, sh, phase);
+    const double beta = rz_new / rz;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) p3[i] = z3[i] + beta * p3[i];
+    rz = rz_new;
+    ++it;
+  }
+  // ---- backtracking line search on the incremental potential (accept the first E(x + step d) <= E(x)) ----
+  const double E0 = env_energy_lds(m, xs, x3, xt, own, c, aim, sh, phase);
+  double step = 1.0, E1 = E0;
+  bool accepted = false;
+  double xc3[3] = {0, 0, 0};
+  for (int ls = 0; ls <= ls_max_iter; ++ls) {
+    __syncthreads();  // every tet is done reading ps (PCG sweep or the previous candidate)
+    if (own) {
+#pragma unroll
+      for (int i = 0; i < 3; ++i) { xc3[i] = x3[i] + step * d3[i]; ps[tid * 3 + i] = xc3[i]; }
+    }
+    __syncthreads();
+    const double Ec = env_energy_lds(m, ps, xc3, xt, own, c, aim, sh, phase);
+    if (Ec <= E0) { E1 = Ec; accepted = true; break; }
+    step *= 0.5;
+  }
+  if (accepted) {
+    if (own) {
+#pragma unroll
+      for (int i = 0; i < 3; ++i) x[tid * 3 + i] = xc3[i];
+    }
+  } else {
+    step = 0.0;
+  }
+  if (tid == 0) {
+    stats[(size_t)b * 4 + 0] = E0; stats[(size_t)b * 4 + 1] = E1; stats[(size_t)b * 4 + 2] = step; stats[(size_t)b * 4 + 3] = (double)it;
+  }
+}
+
 // ---- K18: FEM-driven markers: barycentric surface point + pinhole projection (VT:347-366) ------------------------
 __global__ __launch_bounds__(128) void fem_marker_uv_kernel(const double* __restrict__ pos, const int* __restrict__ tri,
                                                             const double* __restrict__ wgt, double fx, double fy,
@@ -613,6 +910,7 @@ using namespace tacex;
 struct tacex_fem_ctx {
   int device = 0;
   FemDev dev{};
+  FemDev dev_nwt{};  // same mesh with the tets renumbered for fem_newton_lds_kernel (see tacex_fem_create)
   std::vector<void*> allocs;
 };
 
@@ -682,6 +980,31 @@ int tacex_fem_create(int device_id, const tacex_fem_params* p, tacex_fem_ctx** o
   d.V = V; d.T = T;
   int rc = fem_upload(c, tets, &d.tets) | fem_upload(c, dminv, &d.dminv) | fem_upload(c, vol, &d.vol) |
            fem_upload(c, mass, &d.mass) | fem_upload(c, off, &d.vt_off) | fem_upload(c, idx, &d.vt_idx);
+  // Renumbered copy for the LDS Newton kernel.  Its per-window vertex gather waits, in every window, for the vertex with
+  // the most incident tets IN THAT WINDOW; with a spatially coherent numbering all ~24 tets of a vertex sit in one or two
+  // windows, so each of the 4 windows costs a full-valence gather (measured: 54 % of the kernel).  Dealing the tets out
+  // round-robin spreads every vertex's tets evenly over the windows.
+  {
+    const int nwin = (T + kNwtChunk - 1) / kNwtChunk;
+    std::vector<int> order;
+    order.reserve(T);
+    for (int w = 0; w < nwin; ++w)
+      for (int t = w; t < T; t += nwin) order.push_back(t);
+    std::vector<int> tets2((size_t)4 * T), off2(off), idx2((size_t)4 * T);
+    std::vector<double> dminv2((size_t)9 * T), vol2(T);
+    for (int n = 0; n < T; ++n) {
+      const int t = order[n];
+      for (int k = 0; k < 4; ++k) tets2[(size_t)k * T + n] = tets[(size_t)k * T + t];
+      for (int k = 0; k < 9; ++k) dminv2[(size_t)k * T + n] = dminv[(size_t)k * T + t];
+      vol2[n] = vol[t];
+    }
+    std::vector<int> cur(off.begin(), off.end() - 1);
+    for (int n = 0; n < T; ++n)
+      for (int k = 0; k < 4; ++k) idx2[cur[tets2[(size_t)k * T + n]]++] = n * 4 + k;
+    c->dev_nwt = d;
+    rc = fem_upload(c, tets2, &c->dev_nwt.tets) | fem_upload(c, dminv2, &c->dev_nwt.dminv) | fem_upload(c, vol2, &c->dev_nwt.vol) |
+         fem_upload(c, idx2, &c->dev_nwt.vt_idx);
+  }
   if (rc) { tacex_fem_destroy(c); return rc; }
   const double mu_l = p->youngs / (2.0 * (1.0 + p->poisson));
   const double lam_l = p->youngs * p->poisson / ((1.0 + p->poisson) * (1.0 - 2.0 * p->poisson));
@@ -691,6 +1014,8 @@ int tacex_fem_create(int device_id, const tacex_fem_params* p, tacex_fem_ctx** o
   d.psi_rest = 0.5 * d.lam * (1.0 - d.alpha) * (1.0 - d.alpha) - 0.5 * d.mu * log(4.0);
   d.dt = p->dt;
   d.strength = p->constraint_strength_ratio;
+  c->dev_nwt.mu = d.mu; c->dev_nwt.lam = d.lam; c->dev_nwt.alpha = d.alpha; c->dev_nwt.psi_rest = d.psi_rest;
+  c->dev_nwt.dt = d.dt; c->dev_nwt.strength = d.strength;
   *out = c;
   return 0;
 }
@@ -750,6 +1075,22 @@ int tacex_fem_newton_step(tacex_fem_ctx* c, double* x, const double* xt, const u
   if ((cons == nullptr) != (aim == nullptr)) { set_error("tacex_fem_newton_step: constrained_dev and aim_dev go together"); return 2; }
   if (pcg_max_iter < 1 || ls_max_iter < 0 || !(pcg_tol_rate > 0.0)) { set_error("tacex_fem_newton_step: bad solver parameters"); return 2; }
   if (B <= 0) return 0;
+  // TACEX_FEM_NEWTON_LDS=0 selects the streaming kernel (also used when the mesh has more vertices than a workgroup has threads)
+  static const int use_lds = getenv("TACEX_FEM_NEWTON_LDS") ? atoi(getenv("TACEX_FEM_NEWTON_LDS")) : 1;
+  const size_t lds = ((size_t)6 * c->dev.V + (size_t)12 * kNwtChunk + 18) * sizeof(double) + (size_t)4 * c->dev.T * sizeof(int);
+  if (use_lds && c->dev.V <= kNwtThreads && lds <= 160 * 1024) {
+    static size_t attr_lds = 0;
+    if (lds > attr_lds) {
+      hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void*>(fem_newton_lds_kernel),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (ea != hipSuccess) return fail_hip(ea, "hipFuncSetAttribute(fem_newton_lds_kernel)");
+      attr_lds = lds;
+    }
+    hipLaunchKernelGGL(fem_newton_lds_kernel, dim3(B), dim3(kNwtThreads), lds, (hipStream_t)stream, c->dev_nwt, x, xt, cons, aim,
+                       stats, pcg_max_iter, pcg_tol_rate, ls_max_iter);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : fail_hip(e, "fem_newton_lds_kernel");
+  }
   hipLaunchKernelGGL(fem_newton_kernel, dim3(B), dim3(512), 0, (hipStream_t)stream, c->dev, x, xt, cons, aim, stats,
                      static_cast<double*>(ws), pcg_max_iter, pcg_tol_rate, ls_max_iter);
   hipError_t e = hipGetLastError();

@@ -115,6 +115,46 @@ def test_newton_step_vs_oracle_and_monotone():
         assert np.abs(x[b] - xo[b]).max() <= 1e-6 * np.ptp(P)
 
 
+def test_lds_and_streaming_newton_kernels_agree(tmp_path):
+    """The CU-resident Newton kernel (default) and the streaming one (TACEX_FEM_NEWTON_LDS=0) solve the same system; they
+    differ only in the summation order of the nodal gathers (tet renumbering).  The switch is read once per process."""
+    import os
+    import subprocess
+    import sys
+
+    from conftest import REPO
+
+    script = tmp_path / "newton_run.py"
+    script.write_text(
+        "import sys, numpy as np, torch\n"
+        f"sys.path.insert(0, {str(REPO)!r})\n"
+        "from tacex_amd.uipc import UipcObject, UipcObjectCfg, UipcSim, UipcSimCfg\n"
+        "from tacex_amd.uipc.uipc_object import gelpad_box_mesh\n"
+        "P, T = gelpad_box_mesh(8, 10, 4)\n"
+        "B = 4\n"
+        "sim = UipcSim(UipcSimCfg(device='cuda:0'), num_envs=B)\n"
+        "UipcObject(UipcObjectCfg(mesh_points=P, mesh_tets=T), sim)\n"
+        "sim.setup_sim()\n"
+        "sim.cfg.linear_system.max_iter = 60\n"
+        "top = np.where(P[:, 2] > P[:, 2].max() - 1e-9)[0]\n"
+        "aim = torch.from_numpy(P[top]).cuda()[None].repeat(B, 1, 1)\n"
+        "aim[:, :, 2] -= torch.linspace(0.0002, 0.0012, B, device='cuda', dtype=torch.float64)[:, None]\n"
+        "sim.set_constraints(top, aim); sim.x_tilde = sim.x.clone()\n"
+        "st = [sim.newton_step().cpu().numpy().copy() for _ in range(3)]\n"
+        "np.savez(sys.argv[1], x=sim.x.cpu().numpy(), st=np.stack(st))\n")
+    outs = {}
+    for flag in ("1", "0"):
+        out = tmp_path / f"n{flag}.npz"
+        r = subprocess.run([sys.executable, str(script), str(out)], env=dict(os.environ, TACEX_FEM_NEWTON_LDS=flag),
+                           capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs[flag] = np.load(out)
+    np.testing.assert_array_equal(outs["1"]["st"][..., 3], outs["0"]["st"][..., 3])  # same PCG iteration counts
+    np.testing.assert_allclose(outs["1"]["st"][..., :2], outs["0"]["st"][..., :2], rtol=1e-9)
+    scale = np.ptp(outs["0"]["x"])
+    assert np.abs(outs["1"]["x"] - outs["0"]["x"]).max() <= 1e-9 * scale
+
+
 def test_step_api_and_marker_uv(meshes):
     from oracle.fem_oracle import marker_uv
     from tacex_amd import _lib
