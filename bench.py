@@ -42,13 +42,15 @@ def parse():
     ap.add_argument("--no-markers", action="store_true", help="Taxim RGB only (skip the FOTS marker field)")
     ap.add_argument("--gather", choices=["obs32", "none"], default="obs32",
                     help="payload of the per-step observation all-gather (obs32 = 32x32x3 RGB + markers + indentation)")
+    ap.add_argument("--obs-dtype", choices=["u8", "f32"], default="u8",
+                    help="dtype of the 32x32x3 policy image in the gather payload (u8 = what a CNN policy consumes)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--cpu-baseline-seconds", type=float, default=12.0)
     return ap.parse_args()
 
 
-def build_sensor(num_envs, H, W, markers, device, obs_res=None):
+def build_sensor(num_envs, H, W, markers, device, obs_res=None, obs_dtype="float32"):
     from tacex_amd import GelSightSensor, GelSightSensorCfg
     from tacex_amd.calibration import CALIB_GELSIGHT_MINI
     from tacex_amd.simulation_approaches.fots import FOTSMarkerSimulatorCfg
@@ -61,7 +63,8 @@ def build_sensor(num_envs, H, W, markers, device, obs_res=None):
         data_types=types,
         optical_sim_cfg=TaximSimulatorCfg(calib_folder_path=str(CALIB_GELSIGHT_MINI), gelpad_height=0.0045,
                                           gelpad_to_camera_min_distance=0.024, with_shadow=False,
-                                          tactile_img_res=(W, H), device=device, policy_obs_res=obs_res),
+                                          tactile_img_res=(W, H), device=device, policy_obs_res=obs_res,
+                                          policy_obs_dtype=obs_dtype),
         marker_motion_sim_cfg=FOTSMarkerSimulatorCfg(tactile_img_res=(W, H), device=device) if markers else None,
         device=device,
     )
@@ -121,7 +124,8 @@ def main():
     dev = f"cuda:{shard.local_rank}"
     torch.cuda.set_device(shard.local_rank)
     B = shard.num_local
-    sensor = build_sensor(B, H, W, markers, dev, obs_res=(32, 32) if args.gather == "obs32" else None)
+    sensor = build_sensor(B, H, W, markers, dev, obs_res=(32, 32) if args.gather == "obs32" else None,
+                          obs_dtype="uint8" if args.obs_dtype == "u8" else "float32")
     # synthetic camera depth (metres), already resident in HBM; a different seed per shard
     hm_mm, _ = synthetic_depth_maps(B, H, W, seed=1 + shard.rank, device=dev)
     depth_m = (hm_mm / 1000.0).contiguous()
@@ -135,7 +139,8 @@ def main():
         pieces = {"rgb32": (32, 32, 3), "indent": (1,)}
         if markers:
             pieces["markers"] = (2, 99, 2)
-        obs = ObservationGather(pieces, B, shard.world_size, dev)
+        obs = ObservationGather(pieces, B, shard.world_size, dev,
+                                dtypes={"rgb32": torch.uint8} if args.obs_dtype == "u8" else None)
 
     def step(i: int):
         if markers:
@@ -245,8 +250,8 @@ def main():
                             + (" + FOTS markers (99)" if markers else "") + " via GelSightSensor.update(); BASELINE configs[1]"
                             + (" + markers" if markers else ""),
                 "envs_per_gpu": args.envs_per_gpu, "resolution": [W, H], "markers": markers,
-                "observation_gather": None if obs is None else {"payload": "32x32x3 f32 RGB (antialiased) + indentation"
-                                                                + (" + markers (2,99,2)" if markers else ""),
+                "observation_gather": None if obs is None else {"payload": f"32x32x3 {args.obs_dtype} RGB (antialiased, produced in the render pass) + f32 indentation"
+                                                                + (" + f32 markers (2,99,2)" if markers else ""),
                                                                 "bytes_per_rank": obs.payload_bytes(),
                                                                 "collective": "all_gather_into_tensor x1 per step" if (args.gpus > 1 or use_dist) else "none (N=1: the packed buffer is the observation)"},
                 "background_frame": "synthetic f0 (real dataPack.npz absent from the reference checkout)",

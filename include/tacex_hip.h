@@ -116,6 +116,7 @@ size_t tacex_taxim_shadow_workspace_bytes(const tacex_taxim_ctx* ctx, int num_fr
 /* Flags for tacex_taxim_render / tacex_taxim_deform */
 #define TACEX_FLAG_NO_SHIFT      1u  /* press_depth=None: use the height map as is (TT:188-189 skipped) */
 #define TACEX_FLAG_HAVE_FRAME_MIN 2u /* frame_min_dev already holds min(hm) per frame (skip that pass) */
+#define TACEX_FLAG_OBS_U8         8u /* render_obs only: obs_out_dev is uint8 (B,obs_h,obs_w,3) = floor(255 x + 0.5) */
 #define TACEX_FLAG_WITH_SHADOW    4u /* render only: shadow branch TT:260-346 (needs tacex_taxim_set_shadow + extra scratch) */
 
 /* TaximSimulator.optical_simulation (TS:80-113) -> Taxim.render_direct (TI:153-163) ->
@@ -135,10 +136,12 @@ int tacex_taxim_render(tacex_taxim_ctx* ctx, const float* hm_mm_dev, const float
  * antialiased bilinear down-sample of the RGB frame (torchvision resize semantics, as tasks feed 32x32x3 to the policy:
  * tacex_tasks/.../ball_rolling_tactile_rgb.py:303,318).  Where the fused tail kernel exists the horizontal half of the
  * filter is accumulated while the frame is still in LDS (the full-resolution frame is never re-read), otherwise it falls
- * back to the two-pass resize.  obs_scratch_dev: B * max(H * obs_w, obs_h * W) * 3 floats. */
+ * back to the two-pass resize.  obs_scratch_dev: B * (max(H * obs_w, obs_h * W) + obs_h * obs_w) * 3 floats.
+ * obs_out_dev is float32, or uint8 with TACEX_FLAG_OBS_U8 (the image a CNN policy consumes; a quarter of the bytes in the
+ * per-step observation all-gather). */
 int tacex_taxim_render_obs(tacex_taxim_ctx* ctx, const float* hm_mm_dev, const float* press_dev, float* frame_min_dev,
                            float* rgb_dev, float* z_out_dev, uint8_t* mask_out_dev, void* workspace_dev,
-                           float* obs_scratch_dev, float* obs_out_dev, int obs_h, int obs_w, int num_frames,
+                           float* obs_scratch_dev, void* obs_out_dev, int obs_h, int obs_w, int num_frames,
                            unsigned flags, void* stream);
 
 /* __get_shifted_height_map + __compute_gel_pad_deformation only (TT:432-473), as the FOTS wrapper calls

@@ -14,6 +14,7 @@ MAX_LEVELS = 8
 FLAG_NO_SHIFT = 1
 FLAG_HAVE_FRAME_MIN = 2
 FLAG_WITH_SHADOW = 4
+FLAG_OBS_U8 = 8
 
 c_float_p = C.POINTER(C.c_float)
 c_int32_p = C.POINTER(C.c_int32)

@@ -362,7 +362,7 @@ int tacex_indentation_depth(const float* hm_mm, float gelpad_h, float gelpad_dmi
 
 static int pipeline_chunk(tacex_taxim_ctx* c, const float* hm, const float* press, float* frame_min, float* rgb,
                           float* z_out, uint8_t* mask_out, void* ws, int B, unsigned flags, hipStream_t st,
-                          float* obs_h, float* obs, int obs_hh, int obs_w);
+                          float* obs_h, void* obs, int obs_hh, int obs_w);
 
 // Frames per pass of the pipeline: the level buffers (Z ping / pong, 4 B/px each) plus the height map of one pass should
 // stay resident in the 256 MB Infinity Cache between the kernels of the pass, so large shards are walked in chunks that
@@ -379,7 +379,7 @@ static int chunk_frames(const tacex_taxim_ctx* c, int B) {
 
 static int pipeline_impl(tacex_taxim_ctx* c, const float* hm, const float* press, float* frame_min, float* rgb,
                          float* z_out, uint8_t* mask_out, void* ws, int B, unsigned flags, hipStream_t st,
-                         float* obs_h = nullptr, float* obs = nullptr, int obs_hh = 0, int obs_w = 0) {
+                         float* obs_h = nullptr, void* obs = nullptr, int obs_hh = 0, int obs_w = 0) {
   const int cf = chunk_frames(c, B);
   if (cf >= B) return pipeline_chunk(c, hm, press, frame_min, rgb, z_out, mask_out, ws, B, flags, st, obs_h, obs, obs_hh, obs_w);
   if (!(flags & TACEX_FLAG_HAVE_FRAME_MIN)) {  // one reduction pass over the whole shard, then chunks
@@ -392,16 +392,27 @@ static int pipeline_impl(tacex_taxim_ctx* c, const float* hm, const float* press
     const int n = B - b0 < cf ? B - b0 : cf;
     int rc = pipeline_chunk(c, hm + b0 * npix, press ? press + b0 : nullptr, frame_min + b0, rgb ? rgb + b0 * npix * 3 : nullptr,
                             z_out ? z_out + b0 * npix : nullptr, mask_out ? mask_out + b0 * npix : nullptr, ws, n,
-                            flags | TACEX_FLAG_HAVE_FRAME_MIN, st, obs_h, obs ? obs + (size_t)b0 * obs_hh * obs_w * 3 : nullptr,
+                            flags | TACEX_FLAG_HAVE_FRAME_MIN, st, obs_h,
+                            obs ? static_cast<char*>(obs) + (size_t)b0 * obs_hh * obs_w * 3 * ((flags & TACEX_FLAG_OBS_U8) ? 1 : 4) : nullptr,
                             obs_hh, obs_w);
     if (rc) return rc;
   }
   return 0;
 }
 
+// two-pass antialiased down-sample of the finished frame (scratch = [resize temp | float observation when the caller wants uint8])
+static int resize_obs(tacex_taxim_ctx* c, const float* rgb, float* scratch, void* obs, bool u8, int oh, int ow, int B, hipStream_t st) {
+  const size_t tmp_floats = (size_t)B * (size_t)(c->H * ow > oh * c->W ? c->H * ow : oh * c->W) * 3;
+  float* dst = u8 ? scratch + tmp_floats : static_cast<float*>(obs);
+  HIP_TRY(run_resize_aa(rgb, c->H, c->W, dst, oh, ow, B, 3, scratch, st), "resize_aa (observation)");
+  if (u8) HIP_TRY(run_obs_to_u8(dst, static_cast<uint8_t*>(obs), (size_t)B * oh * ow * 3, st), "obs_to_u8_kernel");
+  return 0;
+}
+
 static int pipeline_chunk(tacex_taxim_ctx* c, const float* hm, const float* press, float* frame_min, float* rgb,
                           float* z_out, uint8_t* mask_out, void* ws, int B, unsigned flags, hipStream_t st,
-                          float* obs_h, float* obs, int obs_hh, int obs_w) {
+                          float* obs_h, void* obs, int obs_hh, int obs_w) {
+  const bool obs_u8 = (flags & TACEX_FLAG_OBS_U8) != 0;
   const size_t img = align_up((size_t)B * c->H * c->W * sizeof(float), 256);
   const size_t vec = align_up((size_t)B * sizeof(float), 256);
   char* w = static_cast<char*>(ws);
@@ -450,9 +461,9 @@ static int pipeline_chunk(tacex_taxim_ctx* c, const float* hm, const float* pres
                      fuse_obs ? obs_h : nullptr, fuse_obs ? &c->obs_tab : nullptr, B, c->H, c->W, c->contact_scale, st),
             "taxim_tail_kernel");
     if (fuse_obs) {
-      HIP_TRY(run_obs_finish(obs_h, obs, c->obs_tab, c->H, c->W, B, st), "obs_finish_kernel");
+      HIP_TRY(run_obs_finish(obs_h, obs, obs_u8, c->obs_tab, c->H, c->W, B, st), "obs_finish_kernel");
     } else if (obs && rgb) {  // no fusable geometry: plain two-pass down-sample of the finished frame (obs_h = scratch)
-      HIP_TRY(run_resize_aa(rgb, c->H, c->W, obs, obs_hh, obs_w, B, 3, obs_h, st), "resize_aa (observation)");
+      if (int rc = resize_obs(c, rgb, obs_h, obs, obs_u8, obs_hh, obs_w, B, st)) return rc;
     }
     return 0;
   }
@@ -460,7 +471,7 @@ static int pipeline_chunk(tacex_taxim_ctx* c, const float* hm, const float* pres
     StageTimer t(c, st, c->n_levels + 1);
     HIP_TRY(run_shade(c->shade, src, rgb, nullptr, B, st), "shade_kernel");
   }
-  if (obs && rgb) HIP_TRY(run_resize_aa(rgb, c->H, c->W, obs, obs_hh, obs_w, B, 3, obs_h, st), "resize_aa (observation)");
+  if (obs && rgb) return resize_obs(c, rgb, obs_h, obs, obs_u8, obs_hh, obs_w, B, st);
   return 0;
 }
 
@@ -506,7 +517,7 @@ int tacex_taxim_render(tacex_taxim_ctx* c, const float* hm, const float* press, 
 
 /* render + low-resolution policy observation in the same pass */
 int tacex_taxim_render_obs(tacex_taxim_ctx* c, const float* hm, const float* press, float* frame_min, float* rgb,
-                           float* z_out, uint8_t* mask_out, void* ws, float* obs_scratch, float* obs_out, int obs_h,
+                           float* z_out, uint8_t* mask_out, void* ws, float* obs_scratch, void* obs_out, int obs_h,
                            int obs_w, int B, unsigned flags, void* stream) {
   if (!c || !hm || !frame_min || !rgb || !ws || !obs_scratch || !obs_out) { set_error("tacex_taxim_render_obs: null argument"); return 2; }
   if (obs_h <= 0 || obs_w <= 0 || obs_h > c->H || obs_w > c->W) { set_error("tacex_taxim_render_obs: bad observation size %dx%d", obs_w, obs_h); return 2; }

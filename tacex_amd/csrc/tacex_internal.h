@@ -65,7 +65,8 @@ hipError_t run_tail(const LevelDesc* lv, int n_levels, int n_fused, const float*
                     const float* sa, const float* sb, const float* pd, float* z_out, uint8_t* mask_out,
                     const ShadeParams* sp, float* rgb, float* obs_part, const ObsTables* obs_tab, int B, int H, int W,
                     float contact_scale, hipStream_t st);
-hipError_t run_obs_finish(const float* part, float* obs, const ObsTables& t, int H, int W, int B, hipStream_t st);
+hipError_t run_obs_finish(const float* part, void* obs, bool u8, const ObsTables& t, int H, int W, int B, hipStream_t st);
+hipError_t run_obs_to_u8(const float* src, uint8_t* dst, size_t n, hipStream_t st);
 size_t obs_part_floats(int H, int W, int B);
 bool obs_fusable(const ObsTables& t, int H, int W);  // geometry the fused tail reduction is compiled for
 

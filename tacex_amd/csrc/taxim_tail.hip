@@ -423,7 +423,8 @@ __global__ __launch_bounds__(kTailThreads, kTailWavesPerSimd) void taxim_tail_ke
 // adds the per-tile partial sums of every observation cell in a fixed order and normalises by the weight sums.
 // One thread per (frame, cell) = 3 channels; 32-bit index arithmetic only (a 64-bit div/mod chain per element made the
 // first version 12 us for 786 K outputs).
-__global__ __launch_bounds__(256) void obs_finish_kernel(const float* __restrict__ part, float* __restrict__ obs, ObsTables T,
+template <bool U8>
+__global__ __launch_bounds__(256) void obs_finish_kernel(const float* __restrict__ part, void* __restrict__ obs_v, ObsTables T,
                                                         int H, int W, int ntx, int nty, int TW, int TH) {
   constexpr int NRY = kObsNRY, NCX = kObsNCX;
   const int oh = T.oh, ow = T.ow;
@@ -446,14 +447,33 @@ __global__ __launch_bounds__(256) void obs_finish_kernel(const float* __restrict
     }
   }
   const float nrm = T.xsum[ox] * T.ysum[oy];
-  float* o = obs + ((size_t)b * (oh * ow) + cell) * 3;
-  o[0] = a0 / nrm; o[1] = a1 / nrm; o[2] = a2 / nrm;
+  const size_t oi = ((size_t)b * (oh * ow) + cell) * 3;
+  if constexpr (U8) {  // RGB is clipped to [0,1] (TT:257-258), so is every convex combination of it
+    uint8_t* o = static_cast<uint8_t*>(obs_v) + oi;
+    o[0] = (uint8_t)(a0 / nrm * 255.0f + 0.5f); o[1] = (uint8_t)(a1 / nrm * 255.0f + 0.5f); o[2] = (uint8_t)(a2 / nrm * 255.0f + 0.5f);
+  } else {
+    float* o = static_cast<float*>(obs_v) + oi;
+    o[0] = a0 / nrm; o[1] = a1 / nrm; o[2] = a2 / nrm;
+  }
 }
 
-hipError_t run_obs_finish(const float* part, float* obs, const ObsTables& t, int H, int W, int B, hipStream_t st) {
+__global__ __launch_bounds__(256) void obs_to_u8_kernel(const float* __restrict__ src, uint8_t* __restrict__ dst, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+    dst[i] = (uint8_t)(fminf(fmaxf(src[i], 0.0f), 1.0f) * 255.0f + 0.5f);
+}
+
+hipError_t run_obs_to_u8(const float* src, uint8_t* dst, size_t n, hipStream_t st) {
+  const int grid = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
+  hipLaunchKernelGGL(obs_to_u8_kernel, dim3(grid), dim3(256), 0, st, src, dst, n);
+  return hipGetLastError();
+}
+
+hipError_t run_obs_finish(const float* part, void* obs, bool u8, const ObsTables& t, int H, int W, int B, hipStream_t st) {
   const int TW = 64, TH = 32;
   const int ntx = (W + TW - 1) / TW, nty = (H + TH - 1) / TH;
-  hipLaunchKernelGGL(obs_finish_kernel, dim3((t.oh * t.ow + 255) / 256, B), dim3(256), 0, st, part, obs, t, H, W, ntx, nty, TW, TH);
+  const dim3 grid((t.oh * t.ow + 255) / 256, B);
+  if (u8) hipLaunchKernelGGL(obs_finish_kernel<true>, grid, dim3(256), 0, st, part, obs, t, H, W, ntx, nty, TW, TH);
+  else hipLaunchKernelGGL(obs_finish_kernel<false>, grid, dim3(256), 0, st, part, obs, t, H, W, ntx, nty, TW, TH);
   return hipGetLastError();
 }
 

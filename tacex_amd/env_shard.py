@@ -67,36 +67,57 @@ class ObservationGather:
 
     pieces: dict name -> per-env shape (without the env dim). All shards must hold the same number of envs
     (all_gather_into_tensor needs equal sizes; use num_envs_total % world_size == 0).
+    dtypes: optional dict name -> torch.dtype for pieces that differ from `dtype` (e.g. a uint8 policy image next to
+    float32 markers); the buffer is then a byte buffer with every piece aligned to 8 bytes, still ONE collective.
     """
 
-    def __init__(self, pieces: dict[str, tuple[int, ...]], num_local: int, world_size: int, device, dtype=torch.float32):
+    def __init__(self, pieces: dict[str, tuple[int, ...]], num_local: int, world_size: int, device, dtype=torch.float32,
+                 dtypes: dict | None = None):
         self.pieces = {k: tuple(v) for k, v in pieces.items()}
-        self.sizes = {k: int(torch.Size(v).numel()) for k, v in self.pieces.items()}
-        self.row = sum(self.sizes.values())
-        self.num_local, self.world = num_local, world_size
-        self.local = torch.zeros((num_local, self.row), device=device, dtype=dtype)
-        # one rank, no process group: the "gathered" buffer IS the send buffer (no copy); otherwise the collective fills it
-        self._alias = world_size == 1 and not (dist.is_available() and dist.is_initialized())
-        self.full = self.local if self._alias else torch.zeros((world_size * num_local, self.row), device=device, dtype=dtype)
-        self._off = {}
+        self.dtypes = {k: (dtypes or {}).get(k, dtype) for k in self.pieces}
+        self.bytes_mode = len(set(self.dtypes.values())) > 1
+        buf_dtype = torch.uint8 if self.bytes_mode else next(iter(self.dtypes.values()), dtype)
+        isz = {k: (torch.empty((), dtype=d).element_size() if self.bytes_mode else 1) for k, d in self.dtypes.items()}
+        self.sizes = {k: int(torch.Size(v).numel()) * isz[k] for k, v in self.pieces.items()}  # buffer elements per env
+        self._off, self._cat = {}, []  # _cat: (name | None for padding, width) in buffer order
         o = 0
         for k, n in self.sizes.items():
+            if self.bytes_mode and o % 8:
+                pad = 8 - o % 8
+                self._cat.append((None, pad))
+                o += pad
             self._off[k] = o
+            self._cat.append((k, n))
             o += n
+        if self.bytes_mode and o % 8:
+            self._cat.append((None, 8 - o % 8))
+            o += 8 - o % 8
+        self.row = o
+        self.num_local, self.world = num_local, world_size
+        self.local = torch.zeros((num_local, self.row), device=device, dtype=buf_dtype)
+        # one rank, no process group: the "gathered" buffer IS the send buffer (no copy); otherwise the collective fills it
+        self._alias = world_size == 1 and not (dist.is_available() and dist.is_initialized())
+        self.full = self.local if self._alias else torch.zeros((world_size * num_local, self.row), device=device, dtype=buf_dtype)
+        self._pads = {w: torch.zeros((num_local, w), device=device, dtype=buf_dtype) for k, w in self._cat if k is None}
+
+    def _as_buf(self, name: str, value: torch.Tensor) -> torch.Tensor:
+        v = value.reshape(self.num_local, -1)
+        if v.dtype != self.dtypes[name]:
+            v = v.to(self.dtypes[name])
+        return v.contiguous().view(torch.uint8) if self.bytes_mode else v
 
     def slot(self, name: str) -> torch.Tensor:
-        """(num_local, *shape) strided view into the packed send buffer (fill it in place; views cannot be
-        contiguous, so kernels write through `pack` instead when they need a dense destination)."""
+        """(num_local, n) strided view into the packed send buffer, in the buffer's dtype (bytes in mixed-dtype mode)."""
         o, n = self._off[name], self.sizes[name]
         return self.local[:, o:o + n]
 
     def pack(self, name: str, value: torch.Tensor):
-        self.slot(name).copy_(value.reshape(self.num_local, -1))
+        self.slot(name).copy_(self._as_buf(name, value))
 
     def pack_all(self, values: dict[str, torch.Tensor]):
         """Fill the whole send buffer with ONE kernel (a concatenation along the row) instead of one strided copy per
         piece: at 256 envs every extra launch costs ~5 us of a ~600 us step."""
-        torch.cat([values[k].reshape(self.num_local, -1) for k in self.pieces], dim=1, out=self.local)
+        torch.cat([self._pads[w] if k is None else self._as_buf(k, values[k]) for k, w in self._cat], dim=1, out=self.local)
 
     def payload_bytes(self) -> int:
         return self.local.numel() * self.local.element_size()
@@ -109,5 +130,8 @@ class ObservationGather:
         out = {}
         for k, shape in self.pieces.items():
             o, n = self._off[k], self.sizes[k]
-            out[k] = self.full[:, o:o + n].reshape((self.full.shape[0],) + shape)
+            piece = self.full[:, o:o + n]
+            if self.bytes_mode:
+                piece = piece.view(self.dtypes[k])
+            out[k] = piece.reshape((self.full.shape[0],) + shape)
         return out

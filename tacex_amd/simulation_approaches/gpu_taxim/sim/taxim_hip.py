@@ -213,7 +213,7 @@ class TaximHip:
     ) -> torch.Tensor:
         """(..., H, W) mm height map -> (..., 3, H, W) RGB in [0,1] (a channel-first VIEW of an NHWC buffer).
 
-        `obs_out` (B, oh, ow, 3): additionally produce the antialiased low-resolution policy observation in the same
+        `obs_out` (B, oh, ow, 3) float32 or uint8 (= floor(255 x + 0.5)): additionally produce the antialiased low-resolution policy observation in the same
         pass (fused into the tail kernel where one exists).
 
         Extra keyword arguments (not in the reference): `out` (B,H,W,3) buffer to render into,
@@ -250,9 +250,13 @@ class TaximHip:
             stream = _lib.current_stream_handle(self._device)
             if obs_out is not None and not with_shadow:
                 if obs_out.dim() != 4 or obs_out.shape[0] != B or obs_out.shape[3] != 3 or not obs_out.is_contiguous():
-                    raise ValueError("obs_out must be a contiguous float32 (B, oh, ow, 3) tensor")
+                    raise ValueError("obs_out must be a contiguous (B, oh, ow, 3) tensor")
+                if obs_out.dtype not in (torch.float32, torch.uint8):
+                    raise ValueError("obs_out must be float32 or uint8")
                 oh, ow = int(obs_out.shape[1]), int(obs_out.shape[2])
-                need = B * max(H * ow, oh * W) * 3
+                need = B * (max(H * ow, oh * W) + oh * ow) * 3
+                if obs_out.dtype == torch.uint8:
+                    flags |= _lib.FLAG_OBS_U8
                 sc = self._obs_scratch.get((H, W))
                 if sc is None or sc.numel() < need:
                     sc = torch.empty(need, dtype=torch.float32, device=self._device)

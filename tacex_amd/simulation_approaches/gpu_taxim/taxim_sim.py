@@ -51,7 +51,8 @@ class TaximSimulator(GelSightSimulator):
         self.policy_obs = None
         if getattr(self.cfg, "policy_obs_res", None) is not None:
             ow, oh = self.cfg.policy_obs_res
-            self.policy_obs = torch.zeros((self._num_envs, oh, ow, 3), device=self._device)
+            dt = {"float32": torch.float32, "uint8": torch.uint8}[getattr(self.cfg, "policy_obs_dtype", "float32")]
+            self.policy_obs = torch.zeros((self._num_envs, oh, ow, 3), device=self._device, dtype=dt)
 
     # -- helpers --------------------------------------------------------------------------------------
     def request_deformation_outputs(self):

@@ -21,3 +21,6 @@ class TaximSimulatorCfg(GelSightSimulatorCfg):
     """Extension (not in the reference): (width, height) of an antialiased low-resolution copy of the tactile frame
     produced in the same pass (e.g. (32, 32), what the TacEx tasks feed to the policy); exposed as
     `sensor.data.output["tactile_rgb_obs"]` with shape (num_envs, height, width, 3)."""
+    policy_obs_dtype: str = "float32"
+    """"float32" (values in [0,1]) or "uint8" (floor(255 x + 0.5): the image a CNN policy consumes, a quarter of the bytes
+    in the per-step observation gather)."""

@@ -161,6 +161,23 @@ def test_observation_gather_single_process():
     assert torch.equal(g2.local, g.local)
 
 
+def test_observation_gather_mixed_dtypes():
+    """uint8 policy image next to float32 pieces: one byte buffer, 8-byte aligned pieces, same views back."""
+    pieces = {"rgb32": (4, 4, 3), "indent": (1,), "markers": (2, 5, 2)}
+    g = ObservationGather(pieces, num_local=3, world_size=1, device="cpu", dtypes={"rgb32": torch.uint8})
+    rgb = torch.arange(3 * 48, dtype=torch.uint8).reshape(3, 4, 4, 3)
+    mk = torch.arange(60, dtype=torch.float32).reshape(3, 2, 5, 2)
+    g.pack_all({"rgb32": rgb, "indent": torch.tensor([1.0, 2.0, 3.0]), "markers": mk})
+    out = g.gather()
+    assert out["rgb32"].dtype == torch.uint8 and torch.equal(out["rgb32"], rgb)
+    assert out["indent"].reshape(-1).tolist() == [1.0, 2.0, 3.0] and torch.equal(out["markers"], mk)
+    assert g.payload_bytes() == 3 * (48 + 8 + 80) and g.local.dtype == torch.uint8
+    g2 = ObservationGather(pieces, num_local=3, world_size=1, device="cpu", dtypes={"rgb32": torch.uint8})
+    for k, v in (("markers", mk), ("rgb32", rgb), ("indent", torch.tensor([1.0, 2.0, 3.0]))):
+        g2.pack(k, v)
+    assert torch.equal(g2.local, g.local)
+
+
 def test_fem_marker_setup_vs_reference(golden_dir):
     """Marker grid (VT:189-247) and surface-triangle / barycentric-weight search (VT:249-329) against vectors produced
     by the reference's own functions (tests/golden/make_fem_marker_golden.py)."""
