@@ -305,6 +305,12 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #ifndef TACEX_MFMA_FENCE
 #define TACEX_MFMA_FENCE 0
 #endif
+// H-pass contraction map: 0 = window column KS g + ks (one ds_read_b128 per four k-steps, default), 1 = 4 ks + g like the
+// V-pass (taps of every output column added in the same order; one ds_read_b32 per k-step, measured 3-5 % slower and
+// without an observable difference in the bins of flat regions)
+#ifndef TACEX_MFMA_H_CONSEC
+#define TACEX_MFMA_H_CONSEC 0
+#endif
 
 template <int K, bool FIRST, int NTILE>
 __global__ __launch_bounds__(640) void blur_mfma_kernel(BlurArgs a) {
@@ -414,7 +420,7 @@ __global__ __launch_bounds__(640) void blur_mfma_kernel(BlurArgs a) {
     float wl[KS];
     static_for<0, KS>([&](auto kc) {
       constexpr int ks = decltype(kc)::value;
-      wl[ks] = a.taps[(KS + ks) * 64 + lane];
+      wl[ks] = a.taps[((TACEX_MFMA_H_CONSEC ? 0 : KS) + ks) * 64 + lane];
     });
     const float thr = -a.pdepth[frame] * a.contact_scale;  // TT:459
 #pragma unroll
@@ -422,7 +428,6 @@ __global__ __launch_bounds__(640) void blur_mfma_kernel(BlurArgs a) {
       f32x4 acc[4];
 #pragma unroll
       for (int n = 0; n < 4; ++n) acc[n] = (f32x4)(0.0f);
-      const float* arow = mid + (16 * t + li) * pitch + KS * g + c0;  // window column KS g + ks of block n: + 16 n
       // restore operands: issued ahead of the MFMA chain so their latency hides behind it
       const size_t p0 = (size_t)(by0 + 16 * t + li) * W + c0 + 4 * g;
       v4f hv[4], gv[4];
@@ -431,20 +436,36 @@ __global__ __launch_bounds__(640) void blur_mfma_kernel(BlurArgs a) {
         hv[n] = *reinterpret_cast<const v4f*>(hm + p0 + 16 * n);
         gv[n] = *reinterpret_cast<const v4f*>(gel + p0 + 16 * n);
       }
-      static_for<0, KS / 4>([&](auto mc) {
-        constexpr int m = decltype(mc)::value;
-        v4f q[4];
+      if constexpr (TACEX_MFMA_H_CONSEC) {
+        // k-step ks of lane group g contracts window column 4 ks + g (same map, same table as the V-pass): every output
+        // column then adds its taps in the SAME order 0..K-1, so a flat input gives a bit-exactly flat output (no
+        // round-off texture for the shading to turn into noise bins).  One ds_read_b32 per block and k-step.
+        const float* arow = mid + (16 * t + li) * pitch + g + c0;
+        static_for<0, KS>([&](auto kc) {
+          constexpr int ks = decltype(kc)::value;
+          float q[4];
 #pragma unroll
-        for (int n = 0; n < 4; ++n) q[n] = *reinterpret_cast<const v4f*>(arow + 16 * n + 4 * m);
+          for (int n = 0; n < 4; ++n) q[n] = arow[16 * n + 4 * ks];
 #pragma unroll
-        for (int n = 0; n < 4; ++n) acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(wl[4 * m], q[n].x, acc[n], 0, 0, 0);
+          for (int n = 0; n < 4; ++n) acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(wl[ks], q[n], acc[n], 0, 0, 0);
+        });
+      } else {
+        const float* arow = mid + (16 * t + li) * pitch + KS * g + c0;  // window column KS g + ks of block n: + 16 n
+        static_for<0, KS / 4>([&](auto mc) {
+          constexpr int m = decltype(mc)::value;
+          v4f q[4];
 #pragma unroll
-        for (int n = 0; n < 4; ++n) acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(wl[4 * m + 1], q[n].y, acc[n], 0, 0, 0);
+          for (int n = 0; n < 4; ++n) q[n] = *reinterpret_cast<const v4f*>(arow + 16 * n + 4 * m);
 #pragma unroll
-        for (int n = 0; n < 4; ++n) acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(wl[4 * m + 2], q[n].z, acc[n], 0, 0, 0);
+          for (int n = 0; n < 4; ++n) acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(wl[4 * m], q[n].x, acc[n], 0, 0, 0);
 #pragma unroll
-        for (int n = 0; n < 4; ++n) acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(wl[4 * m + 3], q[n].w, acc[n], 0, 0, 0);
-      });
+          for (int n = 0; n < 4; ++n) acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(wl[4 * m + 1], q[n].y, acc[n], 0, 0, 0);
+#pragma unroll
+          for (int n = 0; n < 4; ++n) acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(wl[4 * m + 2], q[n].z, acc[n], 0, 0, 0);
+#pragma unroll
+          for (int n = 0; n < 4; ++n) acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(wl[4 * m + 3], q[n].w, acc[n], 0, 0, 0);
+        });
+      }
 #pragma unroll
       for (int n = 0; n < 4; ++n) {
         v4f o;
