@@ -10,6 +10,7 @@
 // coordinates (a symmetric blur keeps the halo mirror-symmetric); then normals/bins/polynomial/background/clip.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "tacex_internal.h"
 #include "taxim_device.h"
@@ -515,7 +516,12 @@ int tail_levels(const LevelDesc* lv, int n_levels, int H, int W) {
   };
   static const int k320[4] = {9, 5, 3, 5};    // 320x240 (gsmini presets, BASELINE configs 1-4)
   static const int k640[4] = {15, 9, 5, 9};   // 640x480 (BASELINE config 5)
-  if (match(4, k320) || match(4, k640)) return 4;
+  // 640x480: fusing all four levels needs a 104 x 72 region (halo 19) = 130 KB of LDS, ONE workgroup per CU and 3.7x the
+  // pixels of the tile at the first level; leaving k = 15 to a band kernel gives the 320x240 footprint (88 x 56 region,
+  // two workgroups per CU).  TACEX_TAIL_LEVELS_640=4 restores the four-level kernel (A/B hook).
+  static const int lv640 = getenv("TACEX_TAIL_LEVELS_640") ? atoi(getenv("TACEX_TAIL_LEVELS_640")) : 3;
+  if (match(4, k320)) return 4;
+  if (match(4, k640)) return lv640 == 4 ? 4 : 3;
   return 0;
 }
 
@@ -539,6 +545,7 @@ hipError_t run_tail(const LevelDesc* lv, int n_levels, int n_fused, const float*
   const int k0 = lv[n_levels - n_fused].kw;
   if (n_fused == 4 && k0 == 9) return launch_tail<9, 5, 3, 5>(a, st);
   if (n_fused == 4 && k0 == 15) return launch_tail<15, 9, 5, 9>(a, st);
+  if (n_fused == 3 && k0 == 9) return launch_tail<9, 5, 9>(a, st);
   return hipErrorInvalidValue;
 }
 
