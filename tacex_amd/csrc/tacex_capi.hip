@@ -454,7 +454,7 @@ static int pipeline_chunk(tacex_taxim_ctx* c, const float* hm, const float* pres
     bool fuse_obs = false;
     if (obs_h && obs && rgb) {
       if (int rc = ensure_obs_tables(c, obs_hh, obs_w)) return rc;
-      fuse_obs = obs_fusable(c->obs_tab, c->H, c->W) &&
+      fuse_obs = obs_fusable(c->obs_tab, c->H, c->W) && tail_obs_supported(n_fused, c->levels[c->n_levels - n_fused].kw) &&
                  obs_part_floats(c->H, c->W, B) <= (size_t)B * (size_t)(c->H * obs_w > obs_hh * c->W ? c->H * obs_w : obs_hh * c->W) * 3;
     }
     HIP_TRY(run_tail(c->levels, c->n_levels, n_fused, src, hm, c->gel_dev, sa, sb, pd, z_out, mask_out, &c->shade, rgb,

@@ -68,7 +68,8 @@ hipError_t run_tail(const LevelDesc* lv, int n_levels, int n_fused, const float*
 hipError_t run_obs_finish(const float* part, void* obs, bool u8, const ObsTables& t, int H, int W, int B, hipStream_t st);
 hipError_t run_obs_to_u8(const float* src, uint8_t* dst, size_t n, hipStream_t st);
 size_t obs_part_floats(int H, int W, int B);
-bool obs_fusable(const ObsTables& t, int H, int W);  // geometry the fused tail reduction is compiled for
+bool obs_fusable(const ObsTables& t, int H, int W);
+bool tail_obs_supported(int n_fused, int k0);  // geometry the fused tail reduction is compiled for
 
 // thread-local error string (tacex_last_error)
 void set_error(const char* fmt, ...);

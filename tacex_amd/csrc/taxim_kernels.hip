@@ -529,7 +529,7 @@ static bool mfma_supported(int k, bool first, int H, int W) {
   const int R = (k - 1) / 2;
   if (R >= H || R > W - 1 || ((R + 7) & ~7) >= W) return false;
   if (first) return k == 61 || k == 117;
-  return k == 117 || k == 61 || k == 33 || k == 17 || k == 15;
+  return k == 117 || k == 61 || k == 33 || k == 17 || k == 15 || k == 9;
 }
 
 static hipError_t dispatch_mfma(int k, bool first, const BlurArgs& a, hipStream_t st) {
@@ -540,6 +540,7 @@ static hipError_t dispatch_mfma(int k, bool first, const BlurArgs& a, hipStream_
     case 33: return launch_mfma<33, false>(a, st);
     case 17: return launch_mfma<17, false>(a, st);
     case 15: return launch_mfma<15, false>(a, st);
+    case 9: return launch_mfma<9, false>(a, st);
     default: return hipErrorInvalidValue;
   }
 }

@@ -68,6 +68,8 @@ struct TailCfg {
   static constexpr int ROWS = RH + 2 * PADY;
   // valid margin needed after level l = sum of the radii of levels l+1.. plus 2 (gradient + replicate clamp)
   static constexpr int margin_after(int l) { int s = 2; for (int i = l + 1; i < NL; ++i) s += (K[i] - 1) / 2; return s; }
+  // the fused observation stages the tile's RGB (TH x TW x 3 floats) in one ping-pong buffer
+  static constexpr bool obs_ok = TH * TW * 3 <= ROWS * P && kObsNRY * TW * 3 <= ROWS * P;
   static constexpr size_t obs_lds_bytes() { return (size_t)(kObsNRY * kObsKY + kObsNCX * kObsKX + kObsNRY + kObsNCX + 1) / 4 * 16 + 16; }
   static constexpr size_t mask_lds_bytes() { return kTailCacheJ ? (size_t)RH * P : (((size_t)RH * (RW / 4) + 15) / 16) * 16; }
   static constexpr size_t lds_bytes() {
@@ -378,9 +380,8 @@ __global__ __launch_bounds__(kTailThreads, kTailWavesPerSimd) void taxim_tail_ke
   //      the tile reduces its own pixels vertically, then horizontally, to the <= NRY x NCX observation cells it
   //      overlaps and stores these PARTIAL sums (un-normalised) in its own slot of obs_part; obs_finish_kernel adds
   //      the <= 4 partials of a cell in a fixed order.  No atomics, no memset, the full-resolution frame is not re-read.
-  if (a.obs_part && a.sh.rgb) {
+  if constexpr (C::obs_ok) if (a.obs_part && a.sh.rgb) {
     constexpr int NRY = kObsNRY, NCX = kObsNCX, KY = kObsKY, KX = kObsKX, TWC = TW * 3;
-    static_assert(TH * TWC <= ROWS * P && NRY * TWC <= ROWS * P, "rgb staging / vertical partials must fit a ping-pong buffer");
     static_assert(TWC % 64 == 0 && NT % 64 == 0, "a wave stays inside one observation row in the vertical pass");
     static_assert(KY <= TH && KX <= TW && KY % 4 == 0 && KX % 4 == 0, "tap windows");
     float* v1 = bufA;                  // [NRY][TWC]; the final level is dead once every strip of the epilogue is shaded
@@ -478,6 +479,15 @@ hipError_t run_obs_finish(const float* part, void* obs, bool u8, const ObsTables
   return hipGetLastError();
 }
 
+// whether the fused tail instantiation for (n_fused, first fused k) has room to stage the observation
+bool tail_obs_supported(int n_fused, int k0) {
+  if (n_fused == 4 && k0 == 9) return TailCfg<9, 5, 3, 5>::obs_ok;
+  if (n_fused == 4 && k0 == 15) return TailCfg<15, 9, 5, 9>::obs_ok;
+  if (n_fused == 3 && k0 == 9) return TailCfg<9, 5, 9>::obs_ok;
+  if (n_fused == 3 && k0 == 5) return TailCfg<5, 3, 5>::obs_ok;
+  return false;
+}
+
 bool obs_fusable(const ObsTables& t, int H, int W) {
   return (float)H / t.oh >= 7.5f && (float)W / t.ow >= 8.0f && t.ymax <= kObsKY && t.xmax <= kObsKX && W % 4 == 0;
 }
@@ -488,8 +498,10 @@ size_t obs_part_floats(int H, int W, int B) {
 }
 
 template <int... KS>
-static hipError_t launch_tail(const TailArgs& a, hipStream_t st) {
+static hipError_t launch_tail(const TailArgs& a0, hipStream_t st) {
   using C = TailCfg<KS...>;
+  if (!C::obs_ok && a0.obs_part) return hipErrorInvalidValue;  // callers check tail_obs_supported() first
+  TailArgs a = a0;
   const int ntx = (a.W + C::TW - 1) / C::TW, nty = (a.H + C::TH - 1) / C::TH;
   auto kern = taxim_tail_kernel<KS...>;
   static bool attr_done = false;
@@ -520,7 +532,8 @@ int tail_levels(const LevelDesc* lv, int n_levels, int H, int W) {
   // pixels of the tile at the first level; leaving k = 15 to a band kernel gives the 320x240 footprint (88 x 56 region,
   // two workgroups per CU).  TACEX_TAIL_LEVELS_640=4 restores the four-level kernel (A/B hook).
   static const int lv640 = getenv("TACEX_TAIL_LEVELS_640") ? atoi(getenv("TACEX_TAIL_LEVELS_640")) : 3;
-  if (match(4, k320)) return 4;
+  static const int lv320 = getenv("TACEX_TAIL_LEVELS_320") ? atoi(getenv("TACEX_TAIL_LEVELS_320")) : 4;
+  if (match(4, k320)) return lv320 == 3 ? 3 : 4;
   if (match(4, k640)) return lv640 == 4 ? 4 : 3;
   return 0;
 }
@@ -546,6 +559,7 @@ hipError_t run_tail(const LevelDesc* lv, int n_levels, int n_fused, const float*
   if (n_fused == 4 && k0 == 9) return launch_tail<9, 5, 3, 5>(a, st);
   if (n_fused == 4 && k0 == 15) return launch_tail<15, 9, 5, 9>(a, st);
   if (n_fused == 3 && k0 == 9) return launch_tail<9, 5, 9>(a, st);
+  if (n_fused == 3 && k0 == 5) return launch_tail<5, 3, 5>(a, st);
   return hipErrorInvalidValue;
 }
 
