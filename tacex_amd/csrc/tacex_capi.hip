@@ -142,6 +142,11 @@ int tacex_taxim_create(int device_id, const tacex_taxim_params* p, tacex_taxim_c
     }
   }
   if (!rc) rc |= upload(c, p->gel_map, npix, &c->gel_dev);
+  {
+    bool gz = true;
+    for (size_t i = 0; i < npix && gz; ++i) gz = p->gel_map[i] == 0.0f;
+    for (int l = 0; l < p->n_levels; ++l) c->levels[l].gel_zero = gz;
+  }
   // polynomial table (3, nb, nb, 6) -> (nb, nb, 24): one 96-byte, 16-byte-aligned record per bin
   const int nb = p->num_bins;
   if (!rc) {

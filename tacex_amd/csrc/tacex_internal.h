@@ -7,6 +7,7 @@ namespace tacex {
 
 struct LevelDesc {
   int kw = 1, kh = 1;
+  bool gel_zero = false;   // the context's gel map is identically 0 (GelSight Mini): kernels skip its loads
   bool same_taps = false;  // taps_w == taps_h element-wise (sigma_w == sigma_h): tuned band kernel eligible
   float* taps_w_dev = nullptr;
   float* taps_h_dev = nullptr;

@@ -312,7 +312,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define TACEX_MFMA_H_CONSEC 0
 #endif
 
-template <int K, bool FIRST, int NTILE>
+template <int K, bool FIRST, int NTILE, bool GZ>
 __global__ __launch_bounds__(640) void blur_mfma_kernel(BlurArgs a) {
   constexpr int TH = 16 * NTILE;
   constexpr int R = (K - 1) / 2, RA = (R + 7) & ~7, WIN = 16 + 2 * RA, KS = WIN / 4;
@@ -361,7 +361,7 @@ __global__ __launch_bounds__(640) void blur_mfma_kernel(BlurArgs a) {
         yy = yy < 0 ? 0 : (yy >= H ? H - 1 : yy);  // zero-weight rows beyond the reflect range: any finite data
         const unsigned off = (unsigned)yy * (unsigned)W + coff;
         xb[chunk & 1][c] = *reinterpret_cast<const v4f*>(src + off);
-        if constexpr (FIRST) gb[chunk & 1][c] = *reinterpret_cast<const v4f*>(gel + off);
+        if constexpr (FIRST) gb[chunk & 1][c] = GZ ? (v4f)(0.0f) : *reinterpret_cast<const v4f*>(gel + off);  // GZ: gel == 0 everywhere
       });
     };
     issue(std::integral_constant<int, 0>{});
@@ -434,7 +434,7 @@ __global__ __launch_bounds__(640) void blur_mfma_kernel(BlurArgs a) {
 #pragma unroll
       for (int n = 0; n < 4; ++n) {
         hv[n] = *reinterpret_cast<const v4f*>(hm + p0 + 16 * n);
-        gv[n] = *reinterpret_cast<const v4f*>(gel + p0 + 16 * n);
+        gv[n] = GZ ? (v4f)(0.0f) : *reinterpret_cast<const v4f*>(gel + p0 + 16 * n);
       }
       if constexpr (TACEX_MFMA_H_CONSEC) {
         // k-step ks of lane group g contracts window column 4 ks + g (same map, same table as the V-pass): every output
@@ -485,7 +485,7 @@ __global__ __launch_bounds__(640) void blur_mfma_kernel(BlurArgs a) {
   }
 }
 
-template <int K, bool FIRST, int NTILE>
+template <int K, bool FIRST, int NTILE, bool GZ>
 static hipError_t launch_mfma_tiles(BlurArgs a, int row0, int nbands, hipStream_t st) {
   constexpr int TH = 16 * NTILE, R = (K - 1) / 2, RA = (R + 7) & ~7;
   a.row0 = row0;
@@ -495,7 +495,7 @@ static hipError_t launch_mfma_tiles(BlurArgs a, int row0, int nbands, hipStream_
   if (((a.pitch >> 2) & 1) == 0) a.pitch += 4;
   static const size_t lds_pad = getenv("TACEX_MFMA_LDS_PAD") ? (size_t)atoi(getenv("TACEX_MFMA_LDS_PAD")) * 1024 : 0;  // occupancy A/B hook
   const size_t lds = (size_t)TH * a.pitch * sizeof(float) + lds_pad;
-  auto kern = blur_mfma_kernel<K, FIRST, NTILE>;
+  auto kern = blur_mfma_kernel<K, FIRST, NTILE, GZ>;
   static size_t attr_lds = 0;
   if (lds > 48 * 1024 && lds > attr_lds) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -506,15 +506,13 @@ static hipError_t launch_mfma_tiles(BlurArgs a, int row0, int nbands, hipStream_
   return hipGetLastError();
 }
 
-// TACEX_MFMA_TILES (A/B hook): 16-row tiles per band, 1..3.  Default 1: taller bands cut the V-pass L2 -> L1 traffic
-// (5x -> 3x at k = 61) but measured 3-8 % slower at 256 x 320x240 (fewer, longer workgroups per CU).
+// Band height: NTILE = 1 (16 rows).  Taller bands (NTILE = 2 / 3, shared V-pass loads: 3x / 2.3x instead of 5x L2 -> L1
+// read amplification at k = 61) are supported by the kernel and were measured 3-8 % SLOWER at 256 x 320x240 (fewer,
+// longer workgroups per CU), so only NTILE = 1 is instantiated.  a.gel == nullptr selects the all-zero-gel variant.
 template <int K, bool FIRST>
 static hipError_t launch_mfma(const BlurArgs& a, hipStream_t st) {
-  static const int ntile_env = getenv("TACEX_MFMA_TILES") ? atoi(getenv("TACEX_MFMA_TILES")) : 1;
-  const int nt = ntile_env < 1 ? 1 : (ntile_env > 3 ? 3 : ntile_env);
-  if (nt == 3 && a.H >= 48) return launch_mfma_tiles<K, FIRST, 3>(a, 0, (a.H + 47) / 48, st);
-  if (nt >= 2 && a.H >= 32) return launch_mfma_tiles<K, FIRST, 2>(a, 0, (a.H + 31) / 32, st);
-  return launch_mfma_tiles<K, FIRST, 1>(a, 0, a.H / 16, st);
+  if (a.gel == nullptr) return launch_mfma_tiles<K, FIRST, 1, true>(a, 0, a.H / 16, st);
+  return launch_mfma_tiles<K, FIRST, 1, false>(a, 0, a.H / 16, st);
 }
 
 // TACEX_BLUR_MFMA: 1 (default) = matrix-core band kernels where compiled (k = 117 / 61 / 33 / 17), 0 = VALU band kernels only
@@ -1032,7 +1030,8 @@ hipError_t run_blur_level(const LevelDesc& lv, const float* src, const float* hm
                           bool first, hipStream_t st) {
   if (lv.same_taps && lv.taps_mfma_dev && mfma_supported(lv.kw, first, H, W)) {
     BlurArgs a{};
-    a.src = src; a.hm = hm; a.gel = gel; a.shift_a = sa; a.shift_b = sb; a.pdepth = pd;
+    a.src = src; a.hm = hm; a.shift_a = sa; a.shift_b = sb; a.pdepth = pd;
+    a.gel = lv.gel_zero ? nullptr : gel;  // all-zero gel map (GelSight Mini): no gel loads - half of level 0's V-pass reads
     a.dst = dst; a.mask_out = mask_out; a.taps = lv.taps_mfma_dev; a.H = H; a.W = W; a.B = B;
     a.contact_scale = contact_scale; a.restore = restore;
     return dispatch_mfma(lv.kw, first, a, st);

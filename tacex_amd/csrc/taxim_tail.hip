@@ -137,13 +137,13 @@ __global__ __launch_bounds__(kTailThreads, kTailWavesPerSimd) void taxim_tail_ke
         if (xin) {
           zv[ps] = *reinterpret_cast<const v4f*>(zin + ro + gx);
           hv[ps] = *reinterpret_cast<const v4f*>(hm + ro + gx);
-          gv[ps] = *reinterpret_cast<const v4f*>(a.gel + ro + gx);
+          gv[ps] = a.gel ? *reinterpret_cast<const v4f*>(a.gel + ro + gx) : (v4f)(0.0f);  // nullptr: gel == 0
         } else {
 #pragma unroll
           for (int k = 0; k < 4; ++k) {
             zv[ps][k] = zin[ro + rxo[k]];
             hv[ps][k] = hm[ro + rxo[k]];
-            gv[ps][k] = a.gel[ro + rxo[k]];
+            gv[ps][k] = a.gel ? a.gel[ro + rxo[k]] : 0.0f;
           }
         }
       }
@@ -277,13 +277,13 @@ __global__ __launch_bounds__(kTailThreads, kTailWavesPerSimd) void taxim_tail_ke
                 v4f hq, gq;
                 if (gx >= 0 && gx + 3 < W) {
                   hq = *reinterpret_cast<const v4f*>(hm + ro + gx);
-                  gq = *reinterpret_cast<const v4f*>(a.gel + ro + gx);
+                  gq = a.gel ? *reinterpret_cast<const v4f*>(a.gel + ro + gx) : (v4f)(0.0f);
                 } else {
 #pragma unroll
                   for (int k = 0; k < 4; ++k) {
                     const unsigned xo = (unsigned)min(max(reflect_idx(gx + k, W), 0), W - 1);
                     hq[k] = hm[ro + xo];
-                    gq[k] = a.gel[ro + xo];
+                    gq[k] = a.gel ? a.gel[ro + xo] : 0.0f;
                   }
                 }
 #pragma unroll
@@ -545,7 +545,7 @@ hipError_t run_tail(const LevelDesc* lv, int n_levels, int n_fused, const float*
   TailArgs a{};
   a.obs_part = obs_tab ? obs_part : nullptr;
   if (a.obs_part) a.obs = *obs_tab;
-  a.zin = zin; a.hm = hm; a.gel = gel; a.shift_a = sa; a.shift_b = sb; a.pdepth = pd; a.z_out = z_out; a.mask_out = mask_out;
+  a.zin = zin; a.hm = hm; a.gel = lv[0].gel_zero ? nullptr : gel; a.shift_a = sa; a.shift_b = sb; a.pdepth = pd; a.z_out = z_out; a.mask_out = mask_out;
   a.H = H; a.W = W; a.B = B; a.contact_scale = contact_scale;
   for (int i = 0; i < n_fused; ++i) a.taps[i] = lv[n_levels - n_fused + i].taps_w_dev;
   if (sp && rgb) {

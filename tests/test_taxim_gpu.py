@@ -216,7 +216,7 @@ def test_shadow_branch_vs_reference_and_oracle(taxim, golden_dir, calib_dir):
 
 def test_mfma_and_valu_band_kernels_agree(calib_dir, golden_dir, tmp_path):
     """The matrix-core (v_mfma_f32_16x16x4_f32, default) and the VALU band kernels (TACEX_BLUR_MFMA=0) must give the same
-    deformation, for every band height of the MFMA kernel.  The switches are read once per process: child processes."""
+    deformation.  The switch is read once per process: child processes."""
     import subprocess
     import sys
 
@@ -232,14 +232,14 @@ def test_mfma_and_valu_band_kernels_agree(calib_dir, golden_dir, tmp_path):
         "Z, M = t.deform(torch.from_numpy(g['hm']).cuda(), torch.from_numpy(g['indent']).cuda())\n"
         "np.save(sys.argv[1], Z.cpu().numpy()); np.save(sys.argv[1] + '.m.npy', M.cpu().numpy())\n")
     outs = {}
-    for flag, tiles in (("0", "1"), ("1", "1"), ("1", "2"), ("1", "3")):
+    for flag, tiles in (("0", "1"), ("1", "1")):
         out = tmp_path / f"z{flag}{tiles}.npy"
         env = dict(__import__("os").environ, TACEX_BLUR_MFMA=flag, TACEX_MFMA_TILES=tiles)
         r = subprocess.run([sys.executable, str(script), str(out)], env=env, capture_output=True, text=True, timeout=300)
         assert r.returncode == 0, r.stderr[-2000:]
         outs[flag + tiles] = (np.load(out), np.load(str(out) + ".m.npy"))
     g = np.load(golden_dir / "taxim_240x320.npz")
-    for key in ("11", "12", "13"):
+    for key in ("11",):
         np.testing.assert_array_equal(outs[key][1], outs["01"][1])
         assert np.abs(outs[key][0] - outs["01"][0]).max() <= 2e-6
         assert np.abs(outs[key][0] - g["Z"]).max() <= 1e-5
