@@ -132,6 +132,13 @@ int tacex_taxim_render(tacex_taxim_ctx* ctx, const float* hm_mm_dev, const float
                        float* frame_min_dev, float* rgb_dev, float* z_out_dev, uint8_t* mask_out_dev,
                        void* workspace_dev, int num_frames, unsigned flags, void* stream);
 
+/* FOTS contact statistics as a by-product of the render: when a buffer is set, the fused tail kernel (where one exists:
+ * tacex_taxim_fots_partials_per_env > 0) stores one 16-byte partial {max Z, mask count, row sum, column sum} per wave and
+ * tile while the frame is in LDS; tacex_fots_markers_partials consumes them.  Only calls with num_frames <= capacity_frames
+ * write (the buffer holds capacity_frames * partials_per_env records); nullptr disables. */
+int tacex_taxim_fots_partials_per_env(const tacex_taxim_ctx* ctx);
+int tacex_taxim_set_fots_partials(tacex_taxim_ctx* ctx, void* partials_dev, int capacity_frames);
+
 /* tacex_taxim_render + the low-resolution POLICY OBSERVATION in the same pass: obs_out_dev (B,obs_h,obs_w,3) is the
  * antialiased bilinear down-sample of the RGB frame (torchvision resize semantics, as tasks feed 32x32x3 to the policy:
  * tacex_tasks/.../ball_rolling_tactile_rgb.py:303,318).  Where the fused tail kernel exists the horizontal half of the
@@ -211,6 +218,13 @@ size_t tacex_fots_workspace_bytes(int num_envs);
 int tacex_fots_markers(tacex_fots_ctx* ctx, const float* z_dev, const uint8_t* mask_dev,
                        const float* indent_dev, const float* theta_dev, float* traj_state_dev,
                        float* markers_dev, void* workspace_dev, int num_envs, void* stream);
+
+/* Same, with the per-env contact statistics (max of the deformed gel, mask centroid sums; FS:130-141) taken from the
+ * partials a tacex_taxim_render* / _deform call wrote (tacex_taxim_set_fots_partials) instead of re-reading z / mask. */
+int tacex_fots_markers_partials(tacex_fots_ctx* ctx, const float* z_dev, const uint8_t* mask_dev,
+                                const float* indent_dev, const float* theta_dev, float* traj_state_dev,
+                                float* markers_dev, void* workspace_dev, const void* partials_dev,
+                                int partials_per_env, int num_envs, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Gelpad FEM inner step (what libuipc's world.advance() runs for the StableNeoHookean gelpad,

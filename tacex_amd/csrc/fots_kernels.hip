@@ -21,13 +21,6 @@ namespace tacex {
 
 typedef float v4f __attribute__((ext_vector_type(4)));
 
-struct FotsReduce {   // per env, written by fots_reduce_kernel
-  float zmax;
-  int count;          // number of mask pixels
-  int sum_row;        // sum of row indices of mask pixels (<= 240*76800 fits int32; 480*307200 = 1.5e8 too)
-  int sum_col;
-};
-
 __global__ __launch_bounds__(1024) void fots_reduce_kernel(const float* __restrict__ z,
                                                           const uint8_t* __restrict__ mask,
                                                           FotsReduce* __restrict__ out, int H, int W) {
@@ -66,6 +59,27 @@ __global__ __launch_bounds__(1024) void fots_reduce_kernel(const float* __restri
     for (int w = 1; w < nw; ++w) { zmax = fmaxf(zmax, s_z[w]); cnt += s_c[w]; sr += s_r[w]; sc += s_k[w]; }
     out[e].zmax = zmax; out[e].count = cnt; out[e].sum_row = sr; out[e].sum_col = sc;
   }
+}
+
+// per-env statistics from the per-wave partials the fused Taxim tail kernel wrote while the frame was still in LDS
+// (n partials per env, env-major): replaces the 98 MB re-read of fots_reduce_kernel by a 5 KB one
+__global__ __launch_bounds__(64) void fots_combine_kernel(const FotsReduce* __restrict__ part, int n, FotsReduce* __restrict__ out) {
+  const int e = blockIdx.x;
+  const FotsReduce* p = part + (size_t)e * n;
+  float zmax = -INFINITY;
+  int cnt = 0, sr = 0, sc = 0;
+  for (int i = threadIdx.x; i < n; i += 64) {
+    const FotsReduce r = p[i];
+    zmax = fmaxf(zmax, r.zmax); cnt += r.count; sr += r.sum_row; sc += r.sum_col;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    zmax = fmaxf(zmax, __shfl_xor(zmax, o, 64));
+    cnt += __shfl_xor(cnt, o, 64);
+    sr += __shfl_xor(sr, o, 64);
+    sc += __shfl_xor(sc, o, 64);
+  }
+  if (threadIdx.x == 0) { out[e].zmax = zmax; out[e].count = cnt; out[e].sum_row = sr; out[e].sum_col = sc; }
 }
 
 struct FotsArgs {
@@ -266,6 +280,9 @@ void tacex_fots_destroy(tacex_fots_ctx* c) {
 size_t tacex_fots_state_bytes(int num_envs) { return num_envs > 0 ? (size_t)num_envs * 8 * sizeof(float) : 0; }
 size_t tacex_fots_workspace_bytes(int num_envs) { return num_envs > 0 ? (size_t)num_envs * sizeof(FotsReduce) : 0; }
 
+static int fots_markers_impl(tacex_fots_ctx* c, const float* z, const uint8_t* mask, const float* indent, const float* theta,
+                             float* traj_state, float* markers, void* ws, const FotsReduce* part, int npart, int B, void* stream);
+
 int tacex_fots_markers(tacex_fots_ctx* c, const float* z, const uint8_t* mask, const float* indent,
                        const float* theta, float* traj_state, float* markers, void* ws, int B, void* stream) {
   if (!c || !z || !mask || !indent || !theta || !traj_state || !markers || !ws) {
@@ -273,9 +290,27 @@ int tacex_fots_markers(tacex_fots_ctx* c, const float* z, const uint8_t* mask, c
     return 2;
   }
   if (B <= 0) return 0;
+  return fots_markers_impl(c, z, mask, indent, theta, traj_state, markers, ws, nullptr, 0, B, stream);
+}
+
+int tacex_fots_markers_partials(tacex_fots_ctx* c, const float* z, const uint8_t* mask, const float* indent,
+                                const float* theta, float* traj_state, float* markers, void* ws, const void* partials,
+                                int partials_per_env, int B, void* stream) {
+  if (!c || !z || !mask || !indent || !theta || !traj_state || !markers || !ws || !partials || partials_per_env < 1) {
+    set_error("tacex_fots_markers_partials: null argument");
+    return 2;
+  }
+  if (B <= 0) return 0;
+  return fots_markers_impl(c, z, mask, indent, theta, traj_state, markers, ws, static_cast<const FotsReduce*>(partials),
+                           partials_per_env, B, stream);
+}
+
+static int fots_markers_impl(tacex_fots_ctx* c, const float* z, const uint8_t* mask, const float* indent, const float* theta,
+                             float* traj_state, float* markers, void* ws, const FotsReduce* part, int npart, int B, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   FotsReduce* red = static_cast<FotsReduce*>(ws);
-  hipLaunchKernelGGL(fots_reduce_kernel, dim3(B), dim3(1024), 0, st, z, mask, red, c->H, c->W);
+  if (part) hipLaunchKernelGGL(fots_combine_kernel, dim3(B), dim3(64), 0, st, part, npart, red);
+  else hipLaunchKernelGGL(fots_reduce_kernel, dim3(B), dim3(1024), 0, st, z, mask, red, c->H, c->W);
   FotsArgs a{};
   a.z = z; a.mask = mask; a.indent = indent; a.theta = theta; a.traj = traj_state; a.markers = markers; a.red = red;
   a.mx = c->mx_dev; a.my = c->my_dev; a.B = B; a.H = c->H; a.W = c->W; a.nrow = c->nrow; a.ncol = c->ncol;

@@ -49,6 +49,8 @@ struct tacex_taxim_ctx {
   ShadeParams shade;
   ShadowParams shadow;
   float* gel_dev = nullptr;
+  FotsReduce* fots_part = nullptr;  // optional per-wave FOTS contact statistics written by the fused tail
+  int fots_cap = 0;                 // frames the buffer holds
   ObsTables obs_tab{};   // filter tables of the last policy-observation size asked for (built on first use)
   std::vector<void*> allocs;
   // profiling
@@ -367,7 +369,7 @@ int tacex_indentation_depth(const float* hm_mm, float gelpad_h, float gelpad_dmi
 
 static int pipeline_chunk(tacex_taxim_ctx* c, const float* hm, const float* press, float* frame_min, float* rgb,
                           float* z_out, uint8_t* mask_out, void* ws, int B, unsigned flags, hipStream_t st,
-                          float* obs_h, void* obs, int obs_hh, int obs_w);
+                          float* obs_h, void* obs, int obs_hh, int obs_w, FotsReduce* fots_part);
 
 // Frames per pass of the pipeline: the level buffers (Z ping / pong, 4 B/px each) plus the height map of one pass should
 // stay resident in the 256 MB Infinity Cache between the kernels of the pass, so large shards are walked in chunks that
@@ -386,7 +388,9 @@ static int pipeline_impl(tacex_taxim_ctx* c, const float* hm, const float* press
                          float* z_out, uint8_t* mask_out, void* ws, int B, unsigned flags, hipStream_t st,
                          float* obs_h = nullptr, void* obs = nullptr, int obs_hh = 0, int obs_w = 0) {
   const int cf = chunk_frames(c, B);
-  if (cf >= B) return pipeline_chunk(c, hm, press, frame_min, rgb, z_out, mask_out, ws, B, flags, st, obs_h, obs, obs_hh, obs_w);
+  FotsReduce* fp = (c->fots_part && B <= c->fots_cap) ? c->fots_part : nullptr;
+  const size_t fper = tail_tiles_per_frame(c->H, c->W) * kTailWavesPerTile;
+  if (cf >= B) return pipeline_chunk(c, hm, press, frame_min, rgb, z_out, mask_out, ws, B, flags, st, obs_h, obs, obs_hh, obs_w, fp);
   if (!(flags & TACEX_FLAG_HAVE_FRAME_MIN)) {  // one reduction pass over the whole shard, then chunks
     StageTimer t(c, st, 0);
     HIP_TRY(run_frame_min(hm, false, nullptr, frame_min, nullptr, nullptr, B, c->H * c->W, 0.f, 0.f, 0.f, 0.f, st),
@@ -399,7 +403,7 @@ static int pipeline_impl(tacex_taxim_ctx* c, const float* hm, const float* press
                             z_out ? z_out + b0 * npix : nullptr, mask_out ? mask_out + b0 * npix : nullptr, ws, n,
                             flags | TACEX_FLAG_HAVE_FRAME_MIN, st, obs_h,
                             obs ? static_cast<char*>(obs) + (size_t)b0 * obs_hh * obs_w * 3 * ((flags & TACEX_FLAG_OBS_U8) ? 1 : 4) : nullptr,
-                            obs_hh, obs_w);
+                            obs_hh, obs_w, fp ? fp + (size_t)b0 * fper : nullptr);
     if (rc) return rc;
   }
   return 0;
@@ -416,7 +420,7 @@ static int resize_obs(tacex_taxim_ctx* c, const float* rgb, float* scratch, void
 
 static int pipeline_chunk(tacex_taxim_ctx* c, const float* hm, const float* press, float* frame_min, float* rgb,
                           float* z_out, uint8_t* mask_out, void* ws, int B, unsigned flags, hipStream_t st,
-                          float* obs_h, void* obs, int obs_hh, int obs_w) {
+                          float* obs_h, void* obs, int obs_hh, int obs_w, FotsReduce* fots_part) {
   const bool obs_u8 = (flags & TACEX_FLAG_OBS_U8) != 0;
   const size_t img = align_up((size_t)B * c->H * c->W * sizeof(float), 256);
   const size_t vec = align_up((size_t)B * sizeof(float), 256);
@@ -463,7 +467,7 @@ static int pipeline_chunk(tacex_taxim_ctx* c, const float* hm, const float* pres
                  obs_part_floats(c->H, c->W, B) <= (size_t)B * (size_t)(c->H * obs_w > obs_hh * c->W ? c->H * obs_w : obs_hh * c->W) * 3;
     }
     HIP_TRY(run_tail(c->levels, c->n_levels, n_fused, src, hm, c->gel_dev, sa, sb, pd, z_out, mask_out, &c->shade, rgb,
-                     fuse_obs ? obs_h : nullptr, fuse_obs ? &c->obs_tab : nullptr, B, c->H, c->W, c->contact_scale, st),
+                     fuse_obs ? obs_h : nullptr, fuse_obs ? &c->obs_tab : nullptr, fots_part, B, c->H, c->W, c->contact_scale, st),
             "taxim_tail_kernel");
     if (fuse_obs) {
       HIP_TRY(run_obs_finish(obs_h, obs, obs_u8, c->obs_tab, c->H, c->W, B, st), "obs_finish_kernel");
@@ -518,6 +522,18 @@ int tacex_taxim_render(tacex_taxim_ctx* c, const float* hm, const float* press, 
     return 0;
   }
   return pipeline_impl(c, hm, press, frame_min, rgb, z_out, mask_out, ws, B, flags, (hipStream_t)stream);
+}
+
+int tacex_taxim_fots_partials_per_env(const tacex_taxim_ctx* c) {
+  if (!c || !c->use_tail || c->n_fused <= 0) return 0;
+  return (int)(tail_tiles_per_frame(c->H, c->W) * kTailWavesPerTile);
+}
+
+int tacex_taxim_set_fots_partials(tacex_taxim_ctx* c, void* partials_dev, int capacity_frames) {
+  if (!c) { set_error("tacex_taxim_set_fots_partials: null context"); return 2; }
+  c->fots_part = static_cast<FotsReduce*>(partials_dev);
+  c->fots_cap = partials_dev ? capacity_frames : 0;
+  return 0;
 }
 
 /* render + low-resolution policy observation in the same pass */

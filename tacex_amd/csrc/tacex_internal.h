@@ -15,6 +15,16 @@ struct LevelDesc {
   float* taps_pad_dev = nullptr;  // zero-padded taps for the looped band kernel: [16 zeros | K taps | 48 zeros]
 };
 
+// contact statistics FOTS needs per env (fots_marker_sim.py:130-141): max of the deformed gel, contact-mask pixel count and
+// row / column index sums.  The fused tail writes one per WAVE of every tile (no barrier, no atomics); see fots_kernels.hip.
+struct FotsReduce {
+  float zmax;
+  int count;
+  int sum_row;  // <= 480 * 307200 fits int32
+  int sum_col;
+};
+constexpr int kTailWavesPerTile = 8;
+
 struct ShadeParams {
   int H = 0, W = 0, nb = 0, calib_h = 0, calib_w = 0;
   float pixmm = 0.f, x_binr = 0.f, y_binr = 0.f;
@@ -64,8 +74,9 @@ struct ObsTables {
 };
 hipError_t run_tail(const LevelDesc* lv, int n_levels, int n_fused, const float* zin, const float* hm, const float* gel,
                     const float* sa, const float* sb, const float* pd, float* z_out, uint8_t* mask_out,
-                    const ShadeParams* sp, float* rgb, float* obs_part, const ObsTables* obs_tab, int B, int H, int W,
-                    float contact_scale, hipStream_t st);
+                    const ShadeParams* sp, float* rgb, float* obs_part, const ObsTables* obs_tab, FotsReduce* fots_part, int B,
+                    int H, int W, float contact_scale, hipStream_t st);
+size_t tail_tiles_per_frame(int H, int W);
 hipError_t run_obs_finish(const float* part, void* obs, bool u8, const ObsTables& t, int H, int W, int B, hipStream_t st);
 hipError_t run_obs_to_u8(const float* src, uint8_t* dst, size_t n, hipStream_t st);
 size_t obs_part_floats(int H, int W, int B);

@@ -48,6 +48,28 @@ __device__ __forceinline__ float wave_max(float v) {
   return v;
 }
 
+// Wave-wide inclusive scans on the VALU (DPP row shifts / broadcasts, no LDS round trips like ds_bpermute): lane 63 ends up
+// with the reduction over the wave.  Sequence of LLVM's AMDGPU atomic optimizer for wave64 on gfx9.
+#define TACEX_DPP_SCAN(v, IDENT, OP, T_AS_INT, INT_AS_T)                                                              \
+  do {                                                                                                                \
+    v = OP(v, INT_AS_T(__builtin_amdgcn_update_dpp(T_AS_INT(IDENT), T_AS_INT(v), 0x111, 0xf, 0xf, false)));           \
+    v = OP(v, INT_AS_T(__builtin_amdgcn_update_dpp(T_AS_INT(IDENT), T_AS_INT(v), 0x112, 0xf, 0xf, false)));           \
+    v = OP(v, INT_AS_T(__builtin_amdgcn_update_dpp(T_AS_INT(IDENT), T_AS_INT(v), 0x114, 0xf, 0xf, false)));           \
+    v = OP(v, INT_AS_T(__builtin_amdgcn_update_dpp(T_AS_INT(IDENT), T_AS_INT(v), 0x118, 0xf, 0xf, false)));           \
+    v = OP(v, INT_AS_T(__builtin_amdgcn_update_dpp(T_AS_INT(IDENT), T_AS_INT(v), 0x142, 0xa, 0xf, false)));           \
+    v = OP(v, INT_AS_T(__builtin_amdgcn_update_dpp(T_AS_INT(IDENT), T_AS_INT(v), 0x143, 0xc, 0xf, false)));           \
+  } while (0)
+__device__ __forceinline__ int dpp_id_int(int x) { return x; }
+__device__ __forceinline__ int dpp_add_int(int a, int b) { return a + b; }
+__device__ __forceinline__ int wave_scan_add_lane63(int v) {
+  TACEX_DPP_SCAN(v, 0, dpp_add_int, dpp_id_int, dpp_id_int);
+  return v;
+}
+__device__ __forceinline__ float wave_scan_max_lane63(float v) {
+  TACEX_DPP_SCAN(v, -INFINITY, fmaxf, __float_as_int, __int_as_float);
+  return v;
+}
+
 // XCD-aware bijective remap of the linear block id (blocks b, b+8, b+16.. share an XCD / L2):
 // consecutive logical ids land on the same XCD so a frame's bands share halo rows in one L2.
 __device__ __forceinline__ int xcd_remap(int bid, int nblocks) {

@@ -49,6 +49,7 @@ struct TailArgs {
   float contact_scale;
   float* obs_part;       // nullable: per-tile partial sums of the policy observation, [tile][kObsNRY][kObsNCX][3]
   ObsTables obs;         // filter tables of the observation (valid when obs_part != nullptr)
+  FotsReduce* fots_part; // nullable: per-wave contact statistics, [tile][kTailWavesPerTile]
 };
 
 template <int... KS>
@@ -308,6 +309,8 @@ __global__ __launch_bounds__(kTailThreads, kTailWavesPerSimd) void taxim_tail_ke
   });
 
   // ---- epilogue: 4 consecutive pixels per thread: float4 I/O for deformed gel / mask / background / RGB ----
+  float f_zmax = -INFINITY;  // FOTS contact statistics of this thread's strips (fots_part)
+  int f_cnt = 0, f_sr = 0, f_sc = 0;
   const bool fast_w = (W % 4) == 0;
   for (int sidx = tid; sidx < (TH * TW) / 4; sidx += NT) {  // strip index within the tile
     const int oy = sidx / (TW / 4), ox = (sidx - oy * (TW / 4)) * 4;
@@ -322,6 +325,24 @@ __global__ __launch_bounds__(kTailThreads, kTailWavesPerSimd) void taxim_tail_ke
     const int ly = oy + HLY, lx = ox + HLX;
     const unsigned p = (unsigned)gy * (unsigned)W + (unsigned)gx;  // 32-bit pixel offset from the wave-uniform frame bases
     const float* crow = bufA + (ly + PADY) * P + PADX + lx;
+    if (a.fots_part) {
+      uint8_t mb[4];
+      if constexpr (kTailCacheJ) {
+        const uchar4 mv = *reinterpret_cast<const uchar4*>(bufM + ly * P + PADX + lx);
+        mb[0] = mv.x; mb[1] = mv.y; mb[2] = mv.z; mb[3] = mv.w;
+      } else {
+        const unsigned bits = bufM[ly * MG + (lx >> 2)];
+        mb[0] = bits & 1; mb[1] = (bits >> 1) & 1; mb[2] = (bits >> 2) & 1; mb[3] = (bits >> 3) & 1;
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        if (gx + i < W) {
+          f_zmax = fmaxf(f_zmax, crow[i]);
+          const int m1 = mb[i] != 0;
+          f_cnt += m1; f_sr += m1 * gy; f_sc += m1 * (gx + i);
+        }
+      }
+    }
     if (fast_w) {  // whole strip inside the image
       if (a.z_out) *reinterpret_cast<v4f*>(reinterpret_cast<char*>(a.z_out + fo) + p * 4u) = *reinterpret_cast<const v4f*>(crow);
       if (a.mask_out) {
@@ -376,6 +397,17 @@ __global__ __launch_bounds__(kTailThreads, kTailWavesPerSimd) void taxim_tail_ke
       }
     }
   }
+  if (a.fots_part) {  // one record per wave: no barrier, no atomics; fots_combine_kernel adds the records of an env
+    f_zmax = wave_scan_max_lane63(f_zmax);
+    f_cnt = wave_scan_add_lane63(f_cnt);
+    f_sr = wave_scan_add_lane63(f_sr);
+    f_sc = wave_scan_add_lane63(f_sc);
+    if ((tid & 63) == 63) {
+      FotsReduce r;
+      r.zmax = f_zmax; r.count = f_cnt; r.sum_row = f_sr; r.sum_col = f_sc;
+      a.fots_part[(size_t)lid * kTailWavesPerTile + (tid >> 6)] = r;
+    }
+  }
   // ---- policy observation (torchvision antialiased bilinear = separable triangle filter of support H/oh x W/ow):
   //      the tile reduces its own pixels vertically, then horizontally, to the <= NRY x NCX observation cells it
   //      overlaps and stores these PARTIAL sums (un-normalised) in its own slot of obs_part; obs_finish_kernel adds
@@ -384,6 +416,7 @@ __global__ __launch_bounds__(kTailThreads, kTailWavesPerSimd) void taxim_tail_ke
     constexpr int NRY = kObsNRY, NCX = kObsNCX, KY = kObsKY, KX = kObsKX, TWC = TW * 3;
     static_assert(TWC % 64 == 0 && NT % 64 == 0, "a wave stays inside one observation row in the vertical pass");
     static_assert(KY <= TH && KX <= TW && KY % 4 == 0 && KX % 4 == 0, "tap windows");
+    static_assert(kTailThreads == 64 * kTailWavesPerTile, "FOTS partial records per tile");
     float* v1 = bufA;                  // [NRY][TWC]; the final level is dead once every strip of the epilogue is shaded
     __syncthreads();
     // vertical: item = (cell row j, column*channel xc); j is wave-uniform
@@ -492,6 +525,8 @@ bool obs_fusable(const ObsTables& t, int H, int W) {
   return (float)H / t.oh >= 7.5f && (float)W / t.ow >= 8.0f && t.ymax <= kObsKY && t.xmax <= kObsKX && W % 4 == 0;
 }
 
+size_t tail_tiles_per_frame(int H, int W) { return (size_t)((W + 63) / 64) * ((H + 31) / 32); }
+
 size_t obs_part_floats(int H, int W, int B) {
   const int ntx = (W + 63) / 64, nty = (H + 31) / 32;
   return (size_t)B * ntx * nty * kObsNRY * kObsNCX * 3;
@@ -540,9 +575,10 @@ int tail_levels(const LevelDesc* lv, int n_levels, int H, int W) {
 
 hipError_t run_tail(const LevelDesc* lv, int n_levels, int n_fused, const float* zin, const float* hm, const float* gel,
                     const float* sa, const float* sb, const float* pd, float* z_out, uint8_t* mask_out,
-                    const ShadeParams* sp, float* rgb, float* obs_part, const ObsTables* obs_tab, int B, int H, int W,
-                    float contact_scale, hipStream_t st) {
+                    const ShadeParams* sp, float* rgb, float* obs_part, const ObsTables* obs_tab, FotsReduce* fots_part, int B,
+                    int H, int W, float contact_scale, hipStream_t st) {
   TailArgs a{};
+  a.fots_part = fots_part;
   a.obs_part = obs_tab ? obs_part : nullptr;
   if (a.obs_part) a.obs = *obs_tab;
   a.zin = zin; a.hm = hm; a.gel = lv[0].gel_zero ? nullptr : gel; a.shift_a = sa; a.shift_b = sb; a.pdepth = pd; a.z_out = z_out; a.mask_out = mask_out;

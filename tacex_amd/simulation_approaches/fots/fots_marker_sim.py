@@ -114,9 +114,12 @@ class FOTSMarkerSimulator(GelSightSimulator):
         if self.cfg.yaw_source is not None:
             self.set_indenter_yaw(self.cfg.yaw_source())
         opt = self._optical
+        partials = None
         if opt._keep_deformation and opt._deformation_version == self.sensor._height_map_version \
                 and tuple(opt.cfg.tactile_img_res) == tuple(self.cfg.tactile_img_res):
             z, mask = opt._deformed_gel, opt._contact_mask  # same height map already deformed by the render
+            if getattr(opt, "_fots_partials_version", -1) == self.sensor._height_map_version:
+                partials = opt._fots_partials  # ... and its contact statistics came out of the same kernel
         else:
             height_map = self.sensor._data.output["height_map"]
             W, H = self.cfg.tactile_img_res
@@ -134,10 +137,16 @@ class FOTSMarkerSimulator(GelSightSimulator):
             z, mask = self._taxim.deform(height_map, self._indentation_depth, z_out=self._z, mask_out=self._mask)
         indent = self._indentation_depth.to(self._device).contiguous()
         with torch.cuda.device(self.marker_data.device):
-            rc = self._lib.tacex_fots_markers(
-                self._handle, _lib.ptr(z), _lib.ptr(mask), _lib.ptr(indent), _lib.ptr(self.theta),
-                _lib.ptr(self._traj_state), _lib.ptr(self.marker_data), _lib.ptr(self._ws), self._num_envs,
-                _lib.current_stream_handle(self.marker_data.device))
+            if partials is not None:
+                rc = self._lib.tacex_fots_markers_partials(
+                    self._handle, _lib.ptr(z), _lib.ptr(mask), _lib.ptr(indent), _lib.ptr(self.theta),
+                    _lib.ptr(self._traj_state), _lib.ptr(self.marker_data), _lib.ptr(self._ws), _lib.ptr(partials),
+                    int(partials.shape[1]), self._num_envs, _lib.current_stream_handle(self.marker_data.device))
+            else:
+                rc = self._lib.tacex_fots_markers(
+                    self._handle, _lib.ptr(z), _lib.ptr(mask), _lib.ptr(indent), _lib.ptr(self.theta),
+                    _lib.ptr(self._traj_state), _lib.ptr(self.marker_data), _lib.ptr(self._ws), self._num_envs,
+                    _lib.current_stream_handle(self.marker_data.device))
         _lib.check(rc, "tacex_fots_markers")
         return self.marker_data
 

@@ -336,6 +336,17 @@ class TaximHip:
         ctx = self.context(shape_hw)
         _lib.check(self._lib.tacex_taxim_set_fused_tail(ctx.handle, 1 if enabled else 0), "set_fused_tail")
 
+    # -- FOTS contact statistics as a by-product of the render (fused tail only) -------------------------------------
+    def fots_partials_per_env(self, shape_hw) -> int:
+        """Records per env the fused tail writes (0: no fused tail for this shape / tail disabled)."""
+        return int(self._lib.tacex_taxim_fots_partials_per_env(self.context(shape_hw).handle))
+
+    def set_fots_partials(self, shape_hw, buf: torch.Tensor | None, capacity_frames: int = 0):
+        """buf: uint8 tensor of capacity_frames * fots_partials_per_env * 16 bytes (or None to disable)."""
+        ctx = self.context(shape_hw)
+        _lib.check(self._lib.tacex_taxim_set_fots_partials(ctx.handle, _lib.ptr(buf) if buf is not None else 0,
+                                                           int(capacity_frames)), "set_fots_partials")
+
     # -- profiling (bench.py roofline leg) --------------------------------------------------------------------
     def set_profiling(self, shape_hw, enabled: bool):
         ctx = self.context(shape_hw)

@@ -47,6 +47,7 @@ class TaximSimulator(GelSightSimulator):
         self._deformed_gel = None
         self._contact_mask = None
         self._deformation_version = -1
+        self._fots_partials_version = -1
         self._resized_hm = None
         self.policy_obs = None
         if getattr(self.cfg, "policy_obs_res", None) is not None:
@@ -61,6 +62,12 @@ class TaximSimulator(GelSightSimulator):
         self._keep_deformation = True
         self._deformed_gel = torch.zeros((self._num_envs, H, W), device=self._device)
         self._contact_mask = torch.zeros((self._num_envs, H, W), dtype=torch.uint8, device=self._device)
+        # the fused tail also leaves FOTS's per-env contact statistics behind (one 16-byte record per wave and tile)
+        n = self._taxim.fots_partials_per_env((H, W))
+        self._fots_partials = torch.zeros((self._num_envs, max(n, 1), 16), dtype=torch.uint8, device=self._device)
+        self._fots_partials_version = -1
+        if n > 0:
+            self._taxim.set_fots_partials((H, W), self._fots_partials, self._num_envs)
 
     def _tactile_height_map(self) -> tuple[torch.Tensor, bool]:
         """Height map at the tactile resolution; resized with the HIP kernel if the camera differs (taxim_sim.py:88-89)."""
@@ -97,6 +104,9 @@ class TaximSimulator(GelSightSimulator):
         )
         if self._keep_deformation:
             self._deformation_version = self.sensor._height_map_version
+            W, H = self.cfg.tactile_img_res
+            n = self._taxim.fots_partials_per_env((H, W))  # 0 while the fused tail is disabled
+            self._fots_partials_version = self.sensor._height_map_version if n == self._fots_partials.shape[1] and n > 0 else -1
         return self.tactile_rgb_img
 
     def compute_indentation_depth(self):
@@ -123,6 +133,7 @@ class TaximSimulator(GelSightSimulator):
         self._frame_min_version = -1
         self._indent_version = -1
         self._deformation_version = -1
+        self._fots_partials_version = -1
 
     def _set_debug_vis_impl(self, debug_vis: bool):
         pass  # Kit UI windows of the reference (taxim_sim.py:137-213) are out of scope
