@@ -18,6 +18,13 @@
 namespace tacex {
 
 constexpr int kTailMaxLevels = 5;
+// Every barrier-separated phase of the tail costs ~2 k cycles per tile whatever its work (in-kernel clock64), so the small
+// levels trade FMAs for phases: k <= 5 levels compute the horizontal sums of their (2 + 2R) input rows per item in
+// registers and go straight to the vertical sums - same arithmetic, same order, bit-identical results, one phase less.
+#ifndef TACEX_TAIL_FUSE2D_MAXK
+#define TACEX_TAIL_FUSE2D_MAXK 5
+#endif
+constexpr int kTailFuse2dMaxK = TACEX_TAIL_FUSE2D_MAXK;
 // 8 waves per workgroup, 2 per SIMD: two workgroups per CU (LDS-bound) then need 4 wave slots and <= 128 VGPRs per SIMD.
 // (640 threads measured 25 % slower: 3+3+2+2 waves per workgroup leave no room for the second workgroup's 3 on a SIMD.)
 constexpr int kTailThreads = 512;
@@ -68,6 +75,10 @@ struct TailCfg {
   static constexpr int P = RW + 2 * PADX + 4;        // LDS pitch (floats); +4 staggers rows across banks
   static constexpr int ROWS = RH + 2 * PADY;
   // valid margin needed after level l = sum of the radii of levels l+1.. plus 2 (gradient + replicate clamp)
+  // levels with k <= kTailFuse2dMaxK run H and V in ONE phase (horizontal sums of the 2 + 2R rows an item needs stay in
+  // registers): output goes to the OTHER ping-pong buffer, so the buffer holding level l's input alternates
+  static constexpr bool fused2d(int l) { return K[l] > 1 && K[l] <= kTailFuse2dMaxK; }
+  static constexpr int in_buf(int l) { int n = 0; for (int i = 0; i < l; ++i) n += fused2d(i) ? 1 : 0; return n & 1; }
   static constexpr int margin_after(int l) { int s = 2; for (int i = l + 1; i < NL; ++i) s += (K[i] - 1) / 2; return s; }
   // the fused observation stages the tile's RGB (TH x TW x 3 floats) in one ping-pong buffer
   static constexpr bool obs_ok = TH * TW * 3 <= ROWS * P && kObsNRY * TW * 3 <= ROWS * P;
@@ -223,78 +234,102 @@ __global__ __launch_bounds__(kTailThreads, kTailWavesPerSimd) void taxim_tail_ke
     constexpr int X0 = (HLX - MX) & ~3, X1 = (HLX + TW + MX + 3) & ~3;
     constexpr int NXG = (X1 - X0) / 4;
     const float* __restrict__ taps = a.taps[l];
-    if constexpr (K > 1) {
-      // ---- H-pass: bufA -> bufB, 4 consecutive x per item, window read as 16-byte groups ----
-      for (int it = tid; it < (HY1 - HY0) * NXG; it += NT) {
-        const int ly = HY0 + it / NXG, x0 = X0 + (it % NXG) * 4;
-        const float* row = bufA + (ly + PADY) * P + PADX + x0 - R4;
-        float win[4 + 2 * R4];
-        static_for<0, (4 + 2 * R4) / 4>([&](auto jc) {
-          constexpr int j = decltype(jc)::value;
-          const v4f q = *reinterpret_cast<const v4f*>(row + 4 * j);
-          win[4 * j] = q.x; win[4 * j + 1] = q.y; win[4 * j + 2] = q.z; win[4 * j + 3] = q.w;
-        });
-        v4f o = (v4f)(0.0f);
-        static_for<0, K>([&](auto tc) {
-          constexpr int t = decltype(tc)::value;
-          const float w = taps[t < K - 1 - t ? t : K - 1 - t];
-          o.x += w * win[R4 - R + t];
-          o.y += w * win[R4 - R + t + 1];
-          o.z += w * win[R4 - R + t + 2];
-          o.w += w * win[R4 - R + t + 3];
-        });
-        *reinterpret_cast<v4f*>(bufB + (ly + PADY) * P + PADX + x0) = o;
+    float* const cur = C::in_buf(l) ? bufB : bufA;   // holds this level's input
+    float* const oth = C::in_buf(l) ? bufA : bufB;
+    auto restore_store = [&](v4f o, int row, int x0, float* dst) {
+      if constexpr (l < NL - 1) {  // TT:467 Z[M] = J[M]; the final blur (TT:468-471) has no restore
+        if constexpr (kTailCacheJ) {
+          const int ci = row * P + PADX + x0;
+          const v4f Jv = *reinterpret_cast<const v4f*>(bufJ + ci);
+          const uchar4 Mv = *reinterpret_cast<const uchar4*>(bufM + ci);
+          o.x = Mv.x ? Jv.x : o.x; o.y = Mv.y ? Jv.y : o.y; o.z = Mv.z ? Jv.z : o.z; o.w = Mv.w ? Jv.w : o.w;
+        } else {
+          const unsigned bits = bufM[row * MG + (x0 >> 2)];
+          if (bits) {  // contact pixels only: J = min(S, gel) again, from the (reflected) height map / gel in L2
+            const unsigned ro = (unsigned)min(max(reflect_idx(gy0 + row, H), 0), H - 1) * (unsigned)W;
+            const int gx = gx0 + x0;
+            v4f hq, gq;
+            if (gx >= 0 && gx + 3 < W) {
+              hq = *reinterpret_cast<const v4f*>(hm + ro + gx);
+              gq = a.gel ? *reinterpret_cast<const v4f*>(a.gel + ro + gx) : (v4f)(0.0f);
+            } else {
+#pragma unroll
+              for (int k = 0; k < 4; ++k) {
+                const unsigned xo = (unsigned)min(max(reflect_idx(gx + k, W), 0), W - 1);
+                hq[k] = hm[ro + xo];
+                gq[k] = a.gel ? a.gel[ro + xo] : 0.0f;
+              }
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+              if (bits & (1u << k)) o[k] = fmin_raw((hq[k] - sa) - sb, gq[k]);
+          }
+        }
       }
-      __syncthreads();
-      // ---- V-pass: bufB -> bufA, 4 columns x 2 rows per item, + masked restore ----
-      // (2-row items: ~2x the items of a 4x4 blocking, so all 10 waves carry one item instead of 4 of them carrying
-      // 16 outputs each while the rest wait at the barrier; the extra window reads are LDS-cheap)
+      *reinterpret_cast<v4f*>(dst + (row + PADY) * P + PADX + x0) = o;
+    };
+    // horizontal sums of 4 consecutive x of one row of `src` (window read as 16-byte groups)
+    auto hsum4 = [&](const float* src, int ly, int x0) -> v4f {
+      const float* row = src + (ly + PADY) * P + PADX + x0 - R4;
+      float win[4 + 2 * R4];
+      static_for<0, (4 + 2 * R4) / 4>([&](auto jc) {
+        constexpr int j = decltype(jc)::value;
+        const v4f q = *reinterpret_cast<const v4f*>(row + 4 * j);
+        win[4 * j] = q.x; win[4 * j + 1] = q.y; win[4 * j + 2] = q.z; win[4 * j + 3] = q.w;
+      });
+      v4f o = (v4f)(0.0f);
+      static_for<0, K>([&](auto tc) {
+        constexpr int t = decltype(tc)::value;
+        const float w = taps[t < K - 1 - t ? t : K - 1 - t];
+        o.x += w * win[R4 - R + t];
+        o.y += w * win[R4 - R + t + 1];
+        o.z += w * win[R4 - R + t + 2];
+        o.w += w * win[R4 - R + t + 3];
+      });
+      return o;
+    };
+    if constexpr (C::fused2d(l)) {
+      // ---- single phase: cur -> oth, 4 columns x 2 rows per item; the 2 + 2R horizontal row sums never leave registers ----
       for (int it = tid; it < ((VY1 - VY0) / 2) * NXG; it += NT) {
         const int ly0 = VY0 + (it / NXG) * 2, x0 = X0 + (it % NXG) * 4;
         v4f acc[2] = {(v4f)(0.0f), (v4f)(0.0f)};
         static_for<0, 2 + 2 * R>([&](auto jc) {
           constexpr int j = decltype(jc)::value;
-          const v4f q = *reinterpret_cast<const v4f*>(bufB + (ly0 - R + j + PADY) * P + PADX + x0);
+          const v4f q = hsum4(cur, ly0 - R + j, x0);
           static_for<0, 2>([&](auto rc) {
             constexpr int r = decltype(rc)::value;
             constexpr int t = j - r;
             if constexpr (t >= 0 && t < K) acc[r] += taps[t < K - 1 - t ? t : K - 1 - t] * q;
           });
         });
-        static_for<0, 2>([&](auto rc) {
-          constexpr int r = decltype(rc)::value;
-          v4f o = acc[r];
-          if constexpr (l < NL - 1) {  // TT:467 Z[M] = J[M]; the final blur (TT:468-471) has no restore
-            if constexpr (kTailCacheJ) {
-              const int ci = (ly0 + r) * P + PADX + x0;
-              const v4f Jv = *reinterpret_cast<const v4f*>(bufJ + ci);
-              const uchar4 Mv = *reinterpret_cast<const uchar4*>(bufM + ci);
-              o.x = Mv.x ? Jv.x : o.x; o.y = Mv.y ? Jv.y : o.y; o.z = Mv.z ? Jv.z : o.z; o.w = Mv.w ? Jv.w : o.w;
-            } else {
-              const unsigned bits = bufM[(ly0 + r) * MG + (x0 >> 2)];
-              if (bits) {  // contact pixels only: J = min(S, gel) again, from the (reflected) height map / gel in L2
-                const unsigned ro = (unsigned)min(max(reflect_idx(gy0 + ly0 + r, H), 0), H - 1) * (unsigned)W;
-                const int gx = gx0 + x0;
-                v4f hq, gq;
-                if (gx >= 0 && gx + 3 < W) {
-                  hq = *reinterpret_cast<const v4f*>(hm + ro + gx);
-                  gq = a.gel ? *reinterpret_cast<const v4f*>(a.gel + ro + gx) : (v4f)(0.0f);
-                } else {
-#pragma unroll
-                  for (int k = 0; k < 4; ++k) {
-                    const unsigned xo = (unsigned)min(max(reflect_idx(gx + k, W), 0), W - 1);
-                    hq[k] = hm[ro + xo];
-                    gq[k] = a.gel ? a.gel[ro + xo] : 0.0f;
-                  }
-                }
-#pragma unroll
-                for (int k = 0; k < 4; ++k)
-                  if (bits & (1u << k)) o[k] = fmin_raw((hq[k] - sa) - sb, gq[k]);
-              }
-            }
-          }
-          *reinterpret_cast<v4f*>(bufA + (ly0 + r + PADY) * P + PADX + x0) = o;
+        restore_store(acc[0], ly0, x0, oth);
+        restore_store(acc[1], ly0 + 1, x0, oth);
+      }
+      __syncthreads();
+    } else if constexpr (K > 1) {
+      // ---- H-pass: cur -> oth, 4 consecutive x per item ----
+      for (int it = tid; it < (HY1 - HY0) * NXG; it += NT) {
+        const int ly = HY0 + it / NXG, x0 = X0 + (it % NXG) * 4;
+        *reinterpret_cast<v4f*>(oth + (ly + PADY) * P + PADX + x0) = hsum4(cur, ly, x0);
+      }
+      __syncthreads();
+      // ---- V-pass: oth -> cur, 4 columns x 2 rows per item, + masked restore ----
+      // (2-row items: ~2x the items of a 4x4 blocking, so every wave carries one item instead of half of them carrying
+      // 16 outputs each while the rest wait at the barrier; the extra window reads are LDS-cheap)
+      for (int it = tid; it < ((VY1 - VY0) / 2) * NXG; it += NT) {
+        const int ly0 = VY0 + (it / NXG) * 2, x0 = X0 + (it % NXG) * 4;
+        v4f acc[2] = {(v4f)(0.0f), (v4f)(0.0f)};
+        static_for<0, 2 + 2 * R>([&](auto jc) {
+          constexpr int j = decltype(jc)::value;
+          const v4f q = *reinterpret_cast<const v4f*>(oth + (ly0 - R + j + PADY) * P + PADX + x0);
+          static_for<0, 2>([&](auto rc) {
+            constexpr int r = decltype(rc)::value;
+            constexpr int t = j - r;
+            if constexpr (t >= 0 && t < K) acc[r] += taps[t < K - 1 - t ? t : K - 1 - t] * q;
+          });
         });
+        restore_store(acc[0], ly0, x0, cur);
+        restore_store(acc[1], ly0 + 1, x0, cur);
       }
       __syncthreads();
     } else if constexpr (l < NL - 1) {
@@ -302,13 +337,15 @@ __global__ __launch_bounds__(kTailThreads, kTailWavesPerSimd) void taxim_tail_ke
       static_assert(kTailCacheJ, "the k == 1 restore reads the cached J");
       for (int c = tid; c < RH * RW; c += NT) {
         const int ly = c / RW, lx = c - ly * RW;
-        if (bufM[ly * P + PADX + lx]) bufA[(ly + PADY) * P + PADX + lx] = bufJ[ly * P + PADX + lx];
+        if (bufM[ly * P + PADX + lx]) cur[(ly + PADY) * P + PADX + lx] = bufJ[ly * P + PADX + lx];
       }
       __syncthreads();
     }
   });
 
   // ---- epilogue: 4 consecutive pixels per thread: float4 I/O for deformed gel / mask / background / RGB ----
+  float* const bufZ = C::in_buf(NL) ? bufB : bufA;  // final deformed gel of the region
+  float* const bufS = C::in_buf(NL) ? bufA : bufB;  // the other ping-pong buffer: free, stages RGB for the observation
   float f_zmax = -INFINITY;  // FOTS contact statistics of this thread's strips (fots_part)
   int f_cnt = 0, f_sr = 0, f_sc = 0;
   const bool fast_w = (W % 4) == 0;
@@ -317,14 +354,14 @@ __global__ __launch_bounds__(kTailThreads, kTailWavesPerSimd) void taxim_tail_ke
     const int gy = ty0 + oy, gx = tx0 + ox;
     if (gy >= H || gx >= W) {  // tile overhang: only the observation staging must not hold stale (possibly non-finite) data
       if (a.obs_part && a.sh.rgb) {
-        float* sg = bufB + oy * (TW * 3) + ox * 3;
+        float* sg = bufS + oy * (TW * 3) + ox * 3;
         reinterpret_cast<v4f*>(sg)[0] = (v4f)(0.0f); reinterpret_cast<v4f*>(sg)[1] = (v4f)(0.0f); reinterpret_cast<v4f*>(sg)[2] = (v4f)(0.0f);
       }
       continue;
     }
     const int ly = oy + HLY, lx = ox + HLX;
     const unsigned p = (unsigned)gy * (unsigned)W + (unsigned)gx;  // 32-bit pixel offset from the wave-uniform frame bases
-    const float* crow = bufA + (ly + PADY) * P + PADX + lx;
+    const float* crow = bufZ + (ly + PADY) * P + PADX + lx;
     if (a.fots_part) {
       uint8_t mb[4];
       if constexpr (kTailCacheJ) {
@@ -363,7 +400,7 @@ __global__ __launch_bounds__(kTailThreads, kTailWavesPerSimd) void taxim_tail_ke
     if (a.sh.rgb) {
       // replicate padding of the gradient maps == evaluate at the clamped pixel (TT:501-502)
       const int yc = min(max(gy, 1), H - 2) - gy0;
-      const float* rc = bufA + (yc + PADY) * P + PADX;
+      const float* rc = bufZ + (yc + PADY) * P + PADX;
       float rgb[12];
       if (fast_w) {
         float zn[4][4];
@@ -381,8 +418,8 @@ __global__ __launch_bounds__(kTailThreads, kTailWavesPerSimd) void taxim_tail_ke
           shade_pixel_rgb(a.sh, rc[xc - P], rc[xc + P], rc[xc - 1], rc[xc + 1], gxi, gy, rgb + 3 * i);
         }
       }
-      if (a.obs_part) {  // stage the strip for the observation reduction below (bufB is free after the last V-pass)
-        float* sg = bufB + oy * (TW * 3) + ox * 3;
+      if (a.obs_part) {  // stage the strip for the observation reduction below (the other buffer is free after the last level)
+        float* sg = bufS + oy * (TW * 3) + ox * 3;
         reinterpret_cast<v4f*>(sg)[0] = (v4f){rgb[0], rgb[1], rgb[2], rgb[3]};
         reinterpret_cast<v4f*>(sg)[1] = (v4f){rgb[4], rgb[5], rgb[6], rgb[7]};
         reinterpret_cast<v4f*>(sg)[2] = (v4f){rgb[8], rgb[9], rgb[10], rgb[11]};
@@ -417,12 +454,12 @@ __global__ __launch_bounds__(kTailThreads, kTailWavesPerSimd) void taxim_tail_ke
     static_assert(TWC % 64 == 0 && NT % 64 == 0, "a wave stays inside one observation row in the vertical pass");
     static_assert(KY <= TH && KX <= TW && KY % 4 == 0 && KX % 4 == 0, "tap windows");
     static_assert(kTailThreads == 64 * kTailWavesPerTile, "FOTS partial records per tile");
-    float* v1 = bufA;                  // [NRY][TWC]; the final level is dead once every strip of the epilogue is shaded
+    float* v1 = bufZ;                  // [NRY][TWC]; the final level is dead once every strip of the epilogue is shaded
     __syncthreads();
     // vertical: item = (cell row j, column*channel xc); j is wave-uniform
     for (int it = tid; it < NRY * TWC; it += NT) {
       const int j = __builtin_amdgcn_readfirstlane(it / TWC), xc = it - j * TWC;
-      const float* sg = bufB + wby[j] * TWC + xc;
+      const float* sg = bufS + wby[j] * TWC + xc;
       const v4f* wv = reinterpret_cast<const v4f*>(wly + j * KY);
       float acc = 0.0f;
       static_for<0, KY / 4>([&](auto tc) {
