@@ -85,6 +85,17 @@ int tacex_height_map_from_depth(const float* depth_m_dev, float near_clip_m, flo
                                 float* hm_mm_dev, float* frame_min_dev, float* indent_mm_dev,
                                 uint8_t* cam_u8_dev, int num_frames, int height, int width, void* stream);
 
+/* Height-map SOURCE: rasterise one analytic indenter per env into the height map (mm), with the per-frame
+ * minimum and the indentation depth of TS:115-131 in the same pass.  Stands in for the TiledCamera depth render
+ * (GS:229-263 -> _get_height_map GS:581-593) when the contact geometry is a primitive; 4 B/px written, nothing read.
+ * indenters_dev (B, 8) f32: [kind, cx_px, cy_px, r_px, angle_rad, press_mm, cx2_px, cy2_px]
+ *   kind 0 sphere, 1 lying cylinder (radius r/2), 2 wedge with 45 degree flanks, 3 two spheres, < 0 no contact.
+ * depth = min(gel_top_mm - press_mm + profile(x, y), far_clip_mm), profile in mm above the indenter's lowest point. */
+int tacex_height_map_from_indenters(const float* indenters_dev, float pixmm, float gel_top_mm, float far_clip_mm,
+                                    float gelpad_height_m, float gelpad_to_camera_min_distance_m, float* hm_mm_dev,
+                                    float* frame_min_dev, float* indent_mm_dev, int num_frames, int height, int width,
+                                    void* stream);
+
 /* TS:115-131 on an existing mm height map. frame_min_dev (B,) is also written (re-used by the render). */
 int tacex_indentation_depth(const float* hm_mm_dev, float gelpad_height_m,
                             float gelpad_to_camera_min_distance_m, float* frame_min_dev,

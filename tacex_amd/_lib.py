@@ -113,6 +113,7 @@ SIGNATURES = {
     "tacex_fots_state_bytes": (_sz, [_i]),
     "tacex_fots_workspace_bytes": (_sz, [_i]),
     "tacex_fots_markers": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp]),
+    "tacex_height_map_from_indenters": (_i, [_vp, _f, _f, _f, _f, _f, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "tacex_fots_markers_partials": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp]),
     "tacex_taxim_fots_partials_per_env": (_i, [_vp]),
     "tacex_taxim_set_fots_partials": (_i, [_vp, _vp, _i]),

@@ -357,6 +357,18 @@ int tacex_height_map_from_depth(const float* depth_m, float near_m, float far_m,
   return 0;
 }
 
+int tacex_height_map_from_indenters(const float* indenters, float pixmm, float gel_top_mm, float far_clip_mm, float gelpad_h,
+                                    float gelpad_dmin, float* hm_mm, float* frame_min, float* indent_mm, int B, int H, int W,
+                                    void* stream) {
+  if (!indenters || !hm_mm || !frame_min) { set_error("tacex_height_map_from_indenters: null buffer"); return 2; }
+  if (W % 4 != 0 || H <= 0 || !(pixmm > 0.0f)) { set_error("tacex_height_map_from_indenters: need W %% 4 == 0, H > 0, pixmm > 0"); return 2; }
+  if (B <= 0) return 0;
+  HIP_TRY(run_indenter_height_map(indenters, hm_mm, frame_min, indent_mm, B, H, W, pixmm, gel_top_mm, far_clip_mm, gelpad_h,
+                                  gelpad_dmin, (hipStream_t)stream),
+          "indenter_height_map_kernel");
+  return 0;
+}
+
 int tacex_indentation_depth(const float* hm_mm, float gelpad_h, float gelpad_dmin, float* frame_min,
                             float* indent_mm, int B, int H, int W, void* stream) {
   if (!hm_mm || !frame_min || !indent_mm) { set_error("tacex_indentation_depth: null buffer"); return 2; }

@@ -90,6 +90,92 @@ __global__ __launch_bounds__(1024) void frame_min_kernel(
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// K0 (height-map source): rasterise one analytic indenter per env straight into the height map, with the
+// per-frame minimum and the indentation depth in the same pass - the input-side twin of the path.  It stands in for the
+// TiledCamera depth render (GS:229-263, 581-593) when the contact geometry is a primitive: 4 B/px written, nothing read.
+// Scene model (mm, pixel coordinates): gel top at gel_top_mm from the camera, background at far_clip_mm; the lowest point
+// of the indenter is press_mm below the gel top; profile(x, y) = height of the indenter surface above its lowest point:
+//   kind 0 sphere (radius r px)            kind 1 cylinder lying in the image plane (radius r/2, axis at angle)
+//   kind 2 wedge with 45 degree flanks     kind 3 two spheres (second: centre (cx2, cy2), radius 0.6 r, 0.1 mm higher)
+//   kind < 0: no contact (far clip everywhere)
+// depth = min(gel_top - press + profile, far_clip).
+// ------------------------------------------------------------------------------------------------
+struct IndenterDesc { float kind, cx, cy, r, angle, press_mm, cx2, cy2; };
+
+__device__ __forceinline__ float indenter_profile(const IndenterDesc& d, float sn, float cs, float x, float y, float pixmm) {
+  const float dx = x - d.cx, dy = y - d.cy;
+  const int kind = (int)d.kind;
+  const float big = 1e3f;
+  if (kind == 0 || kind == 3) {
+    const float q = dx * dx + dy * dy;
+    float p = q <= d.r * d.r ? (d.r - __builtin_amdgcn_sqrtf(fmaxf(d.r * d.r - q, 0.0f))) * pixmm : big;
+    if (kind == 3) {
+      const float r2 = 0.6f * d.r, ex = x - d.cx2, ey = y - d.cy2, q2 = ex * ex + ey * ey;
+      const float p2 = q2 <= r2 * r2 ? (r2 - __builtin_amdgcn_sqrtf(fmaxf(r2 * r2 - q2, 0.0f))) * pixmm + 0.1f : big;
+      p = fminf(p, p2);
+    }
+    return p;
+  }
+  const float dn = -dx * sn + dy * cs;
+  if (kind == 1) {
+    const float rc = 0.5f * d.r;
+    return fabsf(dn) <= rc ? (rc - __builtin_amdgcn_sqrtf(fmaxf(rc * rc - dn * dn, 0.0f))) * pixmm : big;
+  }
+  const float dt = dx * cs + dy * sn;  // kind 2
+  return (fabsf(dt) <= d.r && fabsf(dn) <= 0.6f * d.r) ? fabsf(dn) * pixmm : big;
+}
+
+__global__ __launch_bounds__(1024) void indenter_height_map_kernel(const IndenterDesc* __restrict__ desc, float* __restrict__ hm_out,
+                                                                   float* __restrict__ fmin_out, float* __restrict__ indent_out,
+                                                                   int H, int W, float pixmm, float gel_top_mm, float far_clip_mm,
+                                                                   float gelpad_h, float gelpad_dmin) {
+  const int b = blockIdx.x;
+  const IndenterDesc d = desc[b];
+  const float sn = sinf(d.angle), cs = cosf(d.angle);
+  const float base = gel_top_mm - d.press_mm;
+  const bool none = d.kind < 0.0f;
+  float* out = hm_out + (size_t)b * H * W;
+  float m = INFINITY;
+  const int n4 = (H * W) >> 2;  // W % 4 == 0 (checked on the host): a group of 4 never straddles rows
+  // (x, y) of this thread's 4-pixel group advance incrementally (no integer division per group)
+  const int step_px = (int)blockDim.x << 2, step_y = step_px / W, step_x = step_px - step_y * W;
+  int y = ((int)threadIdx.x << 2) / W, x = ((int)threadIdx.x << 2) - y * W;
+  for (int i = threadIdx.x; i < n4; i += blockDim.x) {
+    v4f v;
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      v[k] = none ? far_clip_mm : fminf(base + indenter_profile(d, sn, cs, (float)(x + k), (float)y, pixmm), far_clip_mm);
+    reinterpret_cast<v4f*>(out)[i] = v;
+    m = fminf(m, fminf(fminf(v[0], v[1]), fminf(v[2], v[3])));
+    x += step_x; y += step_y;
+    if (x >= W) { x -= W; ++y; }
+  }
+  __shared__ float red[16];
+  m = wave_min(m);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x < 64) {
+    float v = threadIdx.x < (blockDim.x >> 6) ? red[threadIdx.x] : INFINITY;
+    v = wave_min(v);
+    if (threadIdx.x == 0) {
+      fmin_out[b] = v;
+      if (indent_out) {  // TS:116-129
+        float dd = v / 1000.0f - gelpad_dmin;
+        dd = dd < 0.0f ? 0.0f : dd;
+        indent_out[b] = dd <= gelpad_h ? (gelpad_h - dd) * 1000.0f : 0.0f;
+      }
+    }
+  }
+}
+
+hipError_t run_indenter_height_map(const float* desc, float* hm, float* fmin, float* indent, int B, int H, int W, float pixmm,
+                                   float gel_top_mm, float far_clip_mm, float gelpad_h, float gelpad_dmin, hipStream_t st) {
+  hipLaunchKernelGGL(indenter_height_map_kernel, dim3(B), dim3(1024), 0, st, reinterpret_cast<const IndenterDesc*>(desc), hm, fmin,
+                     indent, H, W, pixmm, gel_top_mm, far_clip_mm, gelpad_h, gelpad_dmin);
+  return hipGetLastError();
+}
+
 // per-frame pressing depth P = -min(S) (TT:449) from the frame minimum:
 //   shifted : S = (hm - fmin) - press  -> min(S) = (fmin - fmin) - press = -press (exact in fp32)
 //   no shift: S = hm                   -> P = -fmin

@@ -102,6 +102,11 @@ class GelSightSensor(SensorBase):
             )
         self._camera_depth_m = depth_m
 
+    def set_height_map_source(self, source):
+        """Fill the height map from an on-device source (e.g. `IndenterHeightMapSource`) instead of a camera depth image
+        (SURVEY 8f n1).  `source.fill(hm, frame_min, indent, gelpad_height, gelpad_to_camera_min_distance)`."""
+        self._height_map_source = source
+
     def _read_camera_depth(self):
         src = self.cfg.sensor_camera_cfg.depth_source if self.cfg.sensor_camera_cfg is not None else None
         if src is not None:
@@ -238,6 +243,19 @@ class GelSightSensor(SensorBase):
         return None
 
     def _get_height_map(self):
+        src = getattr(self, "_height_map_source", None)
+        if src is not None:  # analytic source: height map, frame minimum and indentation depth in one launch
+            hm = self._data.output["height_map"]
+            sim = self._fused_targets()
+            fmin = sim._frame_min if sim is not None else self._scratch_min()
+            src.fill(hm, fmin, sim._indentation_depth if sim is not None else None,
+                     float(sim.cfg.gelpad_height) if sim is not None else 0.0,
+                     float(sim.cfg.gelpad_to_camera_min_distance) if sim is not None else 0.0)
+            self._height_map_version += 1
+            if sim is not None:
+                sim._frame_min_version = self._height_map_version
+                sim._indent_version = self._height_map_version
+            return hm
         depth = self._read_camera_depth()
         if depth is None:
             return self._data.output["height_map"]  # no camera: keep whatever the caller wrote
