@@ -153,7 +153,7 @@ def main():
             if markers:
                 vals["markers"] = out["marker_motion"]
             obs.pack_all(vals)
-            obs.gather()
+            obs.gather_async()  # overlaps the next step's rendering; ordered before the next pack / the final sync
 
     use_dist = dist.is_available() and dist.is_initialized()
 
@@ -163,12 +163,16 @@ def main():
 
     for i in range(args.warmup):
         step(i)
+    if obs is not None:
+        obs.wait()
     torch.cuda.synchronize()
     barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(i)
+    if obs is not None:
+        obs.wait()  # the last step's collective is part of the timed region
     torch.cuda.synchronize()
     barrier()
     torch.cuda.synchronize()

@@ -112,21 +112,41 @@ class ObservationGather:
         return self.local[:, o:o + n]
 
     def pack(self, name: str, value: torch.Tensor):
+        self.wait()
         self.slot(name).copy_(self._as_buf(name, value))
 
     def pack_all(self, values: dict[str, torch.Tensor]):
         """Fill the whole send buffer with ONE kernel (a concatenation along the row) instead of one strided copy per
         piece: at 256 envs every extra launch costs ~5 us of a ~600 us step."""
+        self.wait()  # the previous step's collective still reads the send buffer
         torch.cat([self._pads[w] if k is None else self._as_buf(k, values[k]) for k, w in self._cat], dim=1, out=self.local)
 
     def payload_bytes(self) -> int:
         return self.local.numel() * self.local.element_size()
 
-    def gather(self) -> dict[str, torch.Tensor]:
+    def gather_async(self):
+        """Issue the step's collective WITHOUT stalling the compute stream: RCCL runs it on its own stream behind the
+        packing kernel, so it overlaps the next step's rendering.  `wait()` (called by `pack*` and `views`) orders the
+        compute stream behind it before the send buffer is refilled or the result is read."""
+        self.wait()
         if self.world > 1 or (dist.is_available() and dist.is_initialized()):
-            dist.all_gather_into_tensor(self.full, self.local)  # the single collective of the step
+            self._work = dist.all_gather_into_tensor(self.full, self.local, async_op=True)
         elif not self._alias:
             self.full.copy_(self.local)
+
+    def wait(self):
+        w = getattr(self, "_work", None)
+        if w is not None:
+            w.wait()
+            self._work = None
+
+    def gather(self) -> dict[str, torch.Tensor]:
+        """Blocking form: collective + views of the gathered pieces."""
+        self.gather_async()
+        return self.views()
+
+    def views(self) -> dict[str, torch.Tensor]:
+        self.wait()
         out = {}
         for k, shape in self.pieces.items():
             o, n = self._off[k], self.sizes[k]

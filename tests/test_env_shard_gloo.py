@@ -21,6 +21,15 @@ WORKER = textwrap.dedent(
     out = g.gather()   # exactly one collective
     assert out["indent"].reshape(-1).tolist() == [0., 10., 20., 30., 40., 50.], out["indent"]
     assert out["rgb32"][:, 0, 0, 0].tolist() == [0., 1., 2., 3., 4., 5.]
+    # the pipelined form bench.py uses (mixed dtypes, one byte buffer): issue, refill after the implicit wait, read views
+    g2 = ObservationGather({"rgb32": (2, 2, 3), "indent": (1,)}, shard.num_local, shard.world_size, "cpu",
+                           dtypes={"rgb32": torch.uint8})
+    for step in range(3):
+        g2.pack_all({"rgb32": (env_ids + step).to(torch.uint8).view(-1, 1, 1, 1).expand(-1, 2, 2, 3), "indent": env_ids * 10 + step})
+        g2.gather_async()
+    v = g2.views()
+    assert v["rgb32"].dtype == torch.uint8 and v["rgb32"][:, 1, 1, 2].tolist() == [2, 3, 4, 5, 6, 7]
+    assert v["indent"].reshape(-1).tolist() == [2., 12., 22., 32., 42., 52.]
     # max-over-ranks timing reduction used by bench.py
     t = torch.tensor([1.0 + shard.rank], dtype=torch.float64)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
