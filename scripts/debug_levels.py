@@ -1,3 +1,4 @@
+"""Diagnostic: per-level deformed-gel comparison HIP vs oracle with a truncated pyramid (1..3 levels).  GPU only."""
 import json, os, sys, tempfile
 from pathlib import Path
 import numpy as np, torch
