@@ -393,7 +393,9 @@ static int chunk_frames(const tacex_taxim_ctx* c, int B) {
   if (env > 0) return env < B ? env : B;
   const size_t per_frame = (size_t)3 * c->H * c->W * sizeof(float);
   const size_t n = ((size_t)240 << 20) / per_frame;
-  return (int)(n < 1 ? 1 : (n >= (size_t)B ? (size_t)B : n));
+  if (n < 1 || (size_t)B < 2 * n) return B;  // a shard barely over the budget is cheaper in one pass than in two small ones
+  const size_t nchunks = ((size_t)B + n - 1) / n;
+  return (int)(((size_t)B + nchunks - 1) / nchunks);  // equal chunks
 }
 
 static int pipeline_impl(tacex_taxim_ctx* c, const float* hm, const float* press, float* frame_min, float* rgb,
