@@ -456,21 +456,22 @@ __global__ __launch_bounds__(kTailThreads, kTailWavesPerSimd) void taxim_tail_ke
     static_assert(kTailThreads == 64 * kTailWavesPerTile, "FOTS partial records per tile");
     float* v1 = bufZ;                  // [NRY][TWC]; the final level is dead once every strip of the epilogue is shaded
     __syncthreads();
-    // vertical: item = (cell row j, column*channel xc); j is wave-uniform
-    for (int it = tid; it < NRY * TWC; it += NT) {
-      const int j = __builtin_amdgcn_readfirstlane(it / TWC), xc = it - j * TWC;
+    // vertical: item = (cell row j, 4 consecutive column*channel values): 16-byte LDS reads, one item per thread
+    static_assert(TWC % 4 == 0 && NRY * (TWC / 4) <= NT, "vertical observation items");
+    if (tid < NRY * (TWC / 4)) {
+      const int j = tid / (TWC / 4), xc = (tid - j * (TWC / 4)) * 4;
       const float* sg = bufS + wby[j] * TWC + xc;
       const v4f* wv = reinterpret_cast<const v4f*>(wly + j * KY);
-      float acc = 0.0f;
+      v4f acc = (v4f)(0.0f);
       static_for<0, KY / 4>([&](auto tc) {
         constexpr int t = decltype(tc)::value * 4;
         const v4f w = wv[t / 4];
-        acc = fmaf(w.x, sg[t * TWC], acc);
-        acc = fmaf(w.y, sg[(t + 1) * TWC], acc);
-        acc = fmaf(w.z, sg[(t + 2) * TWC], acc);
-        acc = fmaf(w.w, sg[(t + 3) * TWC], acc);
+        acc += w.x * *reinterpret_cast<const v4f*>(sg + t * TWC);
+        acc += w.y * *reinterpret_cast<const v4f*>(sg + (t + 1) * TWC);
+        acc += w.z * *reinterpret_cast<const v4f*>(sg + (t + 2) * TWC);
+        acc += w.w * *reinterpret_cast<const v4f*>(sg + (t + 3) * TWC);
       });
-      v1[j * TWC + xc] = acc;
+      *reinterpret_cast<v4f*>(v1 + j * TWC + xc) = acc;
     }
     __syncthreads();
     float* part = a.obs_part + (size_t)lid * (NRY * NCX * 3);  // lid = frame * tiles_per_frame + tile index
