@@ -275,6 +275,12 @@ int tacex_fem_gradient(tacex_fem_ctx* ctx, const double* x_dev, const double* x_
                        const uint8_t* constrained_dev, const double* aim_dev, double* g_dev,
                        void* workspace_dev, int num_envs, void* stream);
 
+/* Device-side convergence for repeated Newton launches: dx_dev (num_envs,) f64 holds max|dx| of each env's last accepted
+ * update (the caller fills it with +inf at the start of a time step); an env whose value is <= dx_tol (= velocity_tol * dt,
+ * US:62-66) returns at once from the next tacex_fem_newton_step, so extra iterations cost nothing and no host round trip
+ * is needed to stop them.  nullptr disables.  (CU-resident kernel only.) */
+int tacex_fem_set_newton_early_exit(tacex_fem_ctx* ctx, double* dx_dev, double dx_tol);
+
 /* One projected-Newton iteration per env: assemble (block-Jacobi preconditioned) system, matrix-free PCG
  * (US:70-72 tol_rate), backtracking line search on the energy (US:76: max_iter 8).  x_dev is updated in place.
  * stats_dev (B,4) float64 = [energy_before, energy_after, step_length, pcg_iterations]. */

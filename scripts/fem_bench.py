@@ -42,3 +42,8 @@ print(f"newton_step (PCG<= {sim.cfg.linear_system.max_iter}, tol {sim.cfg.linear
 sim.x.copy_(x0)
 t0 = time.perf_counter(); sim.step(max_newton_iter=8); torch.cuda.synchronize()
 print(f"UipcSim.step (8 Newton iters cap): {(time.perf_counter()-t0)*1e3:.2f} ms, iters {sim.last_newton_iters}")
+sim.x.copy_(x0); sim.v.zero_()
+def full_step():
+    sim.x.copy_(x0); sim.v.zero_(); sim.step(max_newton_iter=8)
+dt = timeit(full_step, 3)
+print(f"UipcSim.step warm (8 Newton iters cap, device-side early exit): {dt*1e3:.2f} ms, iters {sim.last_newton_iters}")

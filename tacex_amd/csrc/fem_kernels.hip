@@ -648,7 +648,8 @@ __device__ __forceinline__ double env_energy_lds(const FemDev& m, const double* 
 
 __global__ __launch_bounds__(kNwtThreads) void fem_newton_lds_kernel(FemDev m, double* xg, const double* xtg,
                                                                      const uint8_t* consg, const double* aimg, double* stats,
-                                                                     int pcg_max_iter, double pcg_tol_rate, int ls_max_iter) {
+                                                                     int pcg_max_iter, double pcg_tol_rate, int ls_max_iter,
+                                                                     double* dxg, double dx_tol) {
   extern __shared__ __attribute__((aligned(16))) double nlds[];
   constexpr int CH = kNwtChunk;
   const int V = m.V, T = m.T, tid = threadIdx.x;
@@ -659,6 +660,10 @@ __global__ __launch_bounds__(kNwtThreads) void fem_newton_lds_kernel(FemDev m, d
   int* csr = reinterpret_cast<int*>(sh + 18);  // (4T) incidence codes tet * 4 + local, vertex-major: read every sweep
   int phase = 0;  // block_sum1 row toggle
   const int b = blockIdx.x;
+  if (dxg && dxg[b] <= dx_tol) {  // this env's last update was below the Newton tolerance (uipc_sim.py:62-66): nothing to do
+    if (threadIdx.x == 0) { stats[(size_t)b * 4 + 2] = 0.0; stats[(size_t)b * 4 + 3] = 0.0; }
+    return;
+  }
   const size_t o = (size_t)b * V * 3;
   double* x = xg + o;
   const double* xt = xtg + o;
@@ -879,6 +884,20 @@ __global__ __launch_bounds__(kNwtThreads) void fem_newton_lds_kernel(FemDev m, d
   } else {
     step = 0.0;
   }
+  if (dxg) {  // max |dx| of this iteration, for the early exit of the next launch
+    double mdx = 0.0;
+    if (own && accepted) mdx = fmax(fabs(xc3[0] - x3[0]), fmax(fabs(xc3[1] - x3[1]), fabs(xc3[2] - x3[2])));
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mdx = fmax(mdx, __shfl_xor(mdx, o, 64));
+    __syncthreads();
+    if ((tid & 63) == 0) sh[tid >> 6] = mdx;
+    __syncthreads();
+    if (tid == 0) {
+      double v = 0.0;
+      for (int w = 0; w < kNwtThreads / 64; ++w) v = fmax(v, sh[w]);
+      dxg[b] = v;
+    }
+  }
   if (tid == 0) {
     stats[(size_t)b * 4 + 0] = E0; stats[(size_t)b * 4 + 1] = E1; stats[(size_t)b * 4 + 2] = step; stats[(size_t)b * 4 + 3] = (double)it;
   }
@@ -911,6 +930,8 @@ struct tacex_fem_ctx {
   int device = 0;
   FemDev dev{};
   FemDev dev_nwt{};  // same mesh with the tets renumbered for fem_newton_lds_kernel (see tacex_fem_create)
+  double* dx_dev = nullptr;  // optional (B,) last Newton update max|dx| per env: converged envs skip further iterations
+  double dx_tol = 0.0;
   std::vector<void*> allocs;
 };
 
@@ -1068,6 +1089,13 @@ int tacex_fem_gradient(tacex_fem_ctx* c, const double* x, const double* xt, cons
   return e == hipSuccess ? 0 : fail_hip(e, "fem_gradient_kernel");
 }
 
+int tacex_fem_set_newton_early_exit(tacex_fem_ctx* c, double* dx_dev, double dx_tol) {
+  if (!c) { set_error("tacex_fem_set_newton_early_exit: null context"); return 2; }
+  c->dx_dev = dx_dev;
+  c->dx_tol = dx_dev ? dx_tol : 0.0;
+  return 0;
+}
+
 int tacex_fem_newton_step(tacex_fem_ctx* c, double* x, const double* xt, const uint8_t* cons, const double* aim,
                           double* stats, void* ws, int B, int pcg_max_iter, double pcg_tol_rate, int ls_max_iter,
                           void* stream) {
@@ -1087,7 +1115,7 @@ int tacex_fem_newton_step(tacex_fem_ctx* c, double* x, const double* xt, const u
       attr_lds = lds;
     }
     hipLaunchKernelGGL(fem_newton_lds_kernel, dim3(B), dim3(kNwtThreads), lds, (hipStream_t)stream, c->dev_nwt, x, xt, cons, aim,
-                       stats, pcg_max_iter, pcg_tol_rate, ls_max_iter);
+                       stats, pcg_max_iter, pcg_tol_rate, ls_max_iter, c->dx_dev, c->dx_tol);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : fail_hip(e, "fem_newton_lds_kernel");
   }
