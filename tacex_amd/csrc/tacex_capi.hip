@@ -475,16 +475,18 @@ static int pipeline_chunk(tacex_taxim_ctx* c, const float* hm, const float* pres
     StageTimer t(c, st, c->n_levels + 2);
     // fused observation: needs down-sampling factors >= 7.5 (y) / 8 (x) (cell-count bounds of the tile) and scratch room
     bool fuse_obs = false;
+    int onry = 0, oncx = 0, oky = 0, okx = 0;
     if (obs_h && obs && rgb) {
       if (int rc = ensure_obs_tables(c, obs_hh, obs_w)) return rc;
-      fuse_obs = obs_fusable(c->obs_tab, c->H, c->W) && tail_obs_supported(n_fused, c->levels[c->n_levels - n_fused].kw) &&
-                 obs_part_floats(c->H, c->W, B) <= (size_t)B * (size_t)(c->H * obs_w > obs_hh * c->W ? c->H * obs_w : obs_hh * c->W) * 3;
+      const int k0 = c->levels[c->n_levels - n_fused].kw;
+      fuse_obs = obs_fusable(c->obs_tab, c->H, c->W, n_fused, k0) && tail_obs_geom(n_fused, k0, &onry, &oncx, &oky, &okx) &&
+                 obs_part_floats(c->H, c->W, B, onry, oncx) <= (size_t)B * (size_t)(c->H * obs_w > obs_hh * c->W ? c->H * obs_w : obs_hh * c->W) * 3;
     }
     HIP_TRY(run_tail(c->levels, c->n_levels, n_fused, src, hm, c->gel_dev, sa, sb, pd, z_out, mask_out, &c->shade, rgb,
                      fuse_obs ? obs_h : nullptr, fuse_obs ? &c->obs_tab : nullptr, fots_part, B, c->H, c->W, c->contact_scale, st),
             "taxim_tail_kernel");
     if (fuse_obs) {
-      HIP_TRY(run_obs_finish(obs_h, obs, obs_u8, c->obs_tab, c->H, c->W, B, st), "obs_finish_kernel");
+      HIP_TRY(run_obs_finish(obs_h, obs, obs_u8, c->obs_tab, c->H, c->W, B, onry, oncx, st), "obs_finish_kernel");
     } else if (obs && rgb) {  // no fusable geometry: plain two-pass down-sample of the finished frame (obs_h = scratch)
       if (int rc = resize_obs(c, rgb, obs_h, obs, obs_u8, obs_hh, obs_w, B, st)) return rc;
     }

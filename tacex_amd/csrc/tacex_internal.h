@@ -79,11 +79,12 @@ hipError_t run_tail(const LevelDesc* lv, int n_levels, int n_fused, const float*
                     const ShadeParams* sp, float* rgb, float* obs_part, const ObsTables* obs_tab, FotsReduce* fots_part, int B,
                     int H, int W, float contact_scale, hipStream_t st);
 size_t tail_tiles_per_frame(int H, int W);
-hipError_t run_obs_finish(const float* part, void* obs, bool u8, const ObsTables& t, int H, int W, int B, hipStream_t st);
+hipError_t run_obs_finish(const float* part, void* obs, bool u8, const ObsTables& t, int H, int W, int B, int nry, int ncx,
+                          hipStream_t st);
+bool tail_obs_geom(int n_fused, int k0, int* nry, int* ncx, int* ky, int* kx);
 hipError_t run_obs_to_u8(const float* src, uint8_t* dst, size_t n, hipStream_t st);
-size_t obs_part_floats(int H, int W, int B);
-bool obs_fusable(const ObsTables& t, int H, int W);
-bool tail_obs_supported(int n_fused, int k0);  // geometry the fused tail reduction is compiled for
+size_t obs_part_floats(int H, int W, int B, int nry, int ncx);
+bool obs_fusable(const ObsTables& t, int H, int W, int n_fused, int k0);  // geometry the fused tail reduction is compiled for
 
 // thread-local error string (tacex_last_error)
 void set_error(const char* fmt, ...);

@@ -37,9 +37,9 @@ constexpr int kTailThreads = 512;
 constexpr bool kTailCacheJ = true;
 constexpr int kTailWavesPerSimd = kTailCacheJ ? 4 : 6;  // register budget: 128 / 80 VGPRs  // register budget: 128 / 80 VGPRs
 // observation cells a 64 x 32 tile can overlap when the down-sampling factor is >= 7.5 (y) / >= 8 (x): tile / scale + 3
-constexpr int kObsNRY = 8, kObsNCX = 11;
+// (per tail instantiation: TailCfg::ONRY / ONCX; 8 x 11 for the 320x240 tail, 6 x 7 for the 640x480 one whose filters are longer)
 // longest triangle filter the fused observation handles (taps per output row / column); longer ones take the two-pass resize
-constexpr int kObsKY = 16, kObsKX = 24;
+// (TailCfg::OKY / OKX: 16 / 24 taps at 320x240 -> 32x32, 32 / 44 at 640x480 -> 32x32)
 
 struct TailArgs {
   const float* zin;      // (B,H,W) output of the last band-kernel level
@@ -54,7 +54,7 @@ struct TailArgs {
   ShadeArgs sh;          // sh.rgb == nullptr -> deformation only
   int H, W, B;
   float contact_scale;
-  float* obs_part;       // nullable: per-tile partial sums of the policy observation, [tile][kObsNRY][kObsNCX][3]
+  float* obs_part;       // nullable: per-tile partial sums of the policy observation, [tile][ONRY][ONCX][3]
   ObsTables obs;         // filter tables of the observation (valid when obs_part != nullptr)
   FotsReduce* fots_part; // nullable: per-wave contact statistics, [tile][kTailWavesPerTile]
 };
@@ -80,9 +80,14 @@ struct TailCfg {
   static constexpr bool fused2d(int l) { return K[l] > 1 && K[l] <= kTailFuse2dMaxK; }
   static constexpr int in_buf(int l) { int n = 0; for (int i = 0; i < l; ++i) n += fused2d(i) ? 1 : 0; return n & 1; }
   static constexpr int margin_after(int l) { int s = 2; for (int i = l + 1; i < NL; ++i) s += (K[i] - 1) / 2; return s; }
+  // fused policy observation: cells a tile may overlap (ONRY x ONCX) and longest filter (OKY / OKX taps) this instantiation
+  // is compiled for.  The three-level tail is the 640x480 one: longer filters, fewer cells per tile; sized so that the
+  // tap windows still fit beside two workgroups' buffers in the CU's LDS.
+  static constexpr bool wide_obs = (NL == 3 && K[0] == 9);
+  static constexpr int ONRY = wide_obs ? 6 : 8, ONCX = wide_obs ? 7 : 11, OKY = wide_obs ? 32 : 16, OKX = wide_obs ? 44 : 24;
   // the fused observation stages the tile's RGB (TH x TW x 3 floats) in one ping-pong buffer
-  static constexpr bool obs_ok = TH * TW * 3 <= ROWS * P && kObsNRY * TW * 3 <= ROWS * P;
-  static constexpr size_t obs_lds_bytes() { return (size_t)(kObsNRY * kObsKY + kObsNCX * kObsKX + kObsNRY + kObsNCX + 1) / 4 * 16 + 16; }
+  static constexpr bool obs_ok = TH * TW * 3 <= ROWS * P && ONRY * TW * 3 <= ROWS * P;
+  static constexpr size_t obs_lds_bytes() { return (size_t)(ONRY * OKY + ONCX * OKX + ONRY + ONCX + 1) / 4 * 16 + 16; }
   static constexpr size_t mask_lds_bytes() { return kTailCacheJ ? (size_t)RH * P : (((size_t)RH * (RW / 4) + 15) / 16) * 16; }
   static constexpr size_t lds_bytes() {
     return (size_t)(2 * ROWS * P + (kTailCacheJ ? RH * P : 0)) * sizeof(float) + mask_lds_bytes() + obs_lds_bytes();
@@ -121,9 +126,9 @@ __global__ __launch_bounds__(kTailThreads, kTailWavesPerSimd) void taxim_tail_ke
   // counts with immediate LDS offsets.  Built here, in its own LDS area, so that the dependent table loads overlap the
   // tile load instead of sitting exposed between the epilogue and the reduction.
   float* wly = reinterpret_cast<float*>(bufM + C::mask_lds_bytes());  // [NRY][KY] taps of cell row j over the KY tile rows from wby[j]
-  float* wlx = wly + kObsNRY * kObsKY;                    // [NCX][KX] same for the cell columns
-  int* wby = reinterpret_cast<int*>(wlx + kObsNCX * kObsKX);  // [NRY] first row of the window (tile-relative)
-  int* wbx = wby + kObsNRY;                                    // [NCX]
+  float* wlx = wly + C::ONRY * C::OKY;                    // [NCX][KX] same for the cell columns
+  int* wby = reinterpret_cast<int*>(wlx + C::ONCX * C::OKX);  // [NRY] first row of the window (tile-relative)
+  int* wbx = wby + C::ONRY;                                   // [NCX]
   // ---- load: previous level, J and M, ALL at REFLECTED coordinates ----
   // Out-of-image halo cells hold the mirror image of the in-image data (= torch 'reflect' padding, TT:411).  A
   // symmetric kernel maps a mirror-symmetric signal to a mirror-symmetric signal, and the restore Z[M] = J[M] uses
@@ -162,7 +167,7 @@ __global__ __launch_bounds__(kTailThreads, kTailWavesPerSimd) void taxim_tail_ke
     }
     // (observation tap windows: issued behind the tile loads, in front of their first use)
     if (a.obs_part && a.sh.rgb) {
-      constexpr int NRY = kObsNRY, NCX = kObsNCX, KY = kObsKY, KX = kObsKX;
+      constexpr int NRY = C::ONRY, NCX = C::ONCX, KY = C::OKY, KX = C::OKX;
       const ObsTables& T = a.obs;
       const float scy = (float)H / (float)T.oh, scx = (float)W / (float)T.ow;
       const int oy0 = max(0, (int)floorf(((float)ty0 - scy) / scy));
@@ -450,7 +455,7 @@ __global__ __launch_bounds__(kTailThreads, kTailWavesPerSimd) void taxim_tail_ke
   //      overlaps and stores these PARTIAL sums (un-normalised) in its own slot of obs_part; obs_finish_kernel adds
   //      the <= 4 partials of a cell in a fixed order.  No atomics, no memset, the full-resolution frame is not re-read.
   if constexpr (C::obs_ok) if (a.obs_part && a.sh.rgb) {
-    constexpr int NRY = kObsNRY, NCX = kObsNCX, KY = kObsKY, KX = kObsKX, TWC = TW * 3;
+    constexpr int NRY = C::ONRY, NCX = C::ONCX, KY = C::OKY, KX = C::OKX, TWC = TW * 3;
     static_assert(TWC % 64 == 0 && NT % 64 == 0, "a wave stays inside one observation row in the vertical pass");
     static_assert(KY <= TH && KX <= TW && KY % 4 == 0 && KX % 4 == 0, "tap windows");
     static_assert(kTailThreads == 64 * kTailWavesPerTile, "FOTS partial records per tile");
@@ -498,8 +503,7 @@ __global__ __launch_bounds__(kTailThreads, kTailWavesPerSimd) void taxim_tail_ke
 // first version 12 us for 786 K outputs).
 template <bool U8>
 __global__ __launch_bounds__(256) void obs_finish_kernel(const float* __restrict__ part, void* __restrict__ obs_v, ObsTables T,
-                                                        int H, int W, int ntx, int nty, int TW, int TH) {
-  constexpr int NRY = kObsNRY, NCX = kObsNCX;
+                                                        int H, int W, int ntx, int nty, int TW, int TH, int NRY, int NCX) {
   const int oh = T.oh, ow = T.ow;
   const int cell = blockIdx.x * blockDim.x + threadIdx.x;
   if (cell >= oh * ow) return;
@@ -541,39 +545,49 @@ hipError_t run_obs_to_u8(const float* src, uint8_t* dst, size_t n, hipStream_t s
   return hipGetLastError();
 }
 
-hipError_t run_obs_finish(const float* part, void* obs, bool u8, const ObsTables& t, int H, int W, int B, hipStream_t st) {
-  const int TW = 64, TH = 32;
-  const int ntx = (W + TW - 1) / TW, nty = (H + TH - 1) / TH;
-  const dim3 grid((t.oh * t.ow + 255) / 256, B);
-  if (u8) hipLaunchKernelGGL(obs_finish_kernel<true>, grid, dim3(256), 0, st, part, obs, t, H, W, ntx, nty, TW, TH);
-  else hipLaunchKernelGGL(obs_finish_kernel<false>, grid, dim3(256), 0, st, part, obs, t, H, W, ntx, nty, TW, TH);
-  return hipGetLastError();
-}
-
-// whether the fused tail instantiation for (n_fused, first fused k) has room to stage the observation
-bool tail_obs_supported(int n_fused, int k0) {
-  if (n_fused == 4 && k0 == 9) return TailCfg<9, 5, 3, 5>::obs_ok;
-  if (n_fused == 4 && k0 == 15) return TailCfg<15, 9, 5, 9>::obs_ok;
-  if (n_fused == 3 && k0 == 9) return TailCfg<9, 5, 9>::obs_ok;
-  if (n_fused == 3 && k0 == 5) return TailCfg<5, 3, 5>::obs_ok;
+// observation geometry of the fused tail instantiation for (n_fused, first fused k); false: no room to stage the observation
+bool tail_obs_geom(int n_fused, int k0, int* nry, int* ncx, int* ky, int* kx) {
+  auto set = [&](auto cfg) {
+    using C = decltype(cfg);
+    *nry = C::ONRY; *ncx = C::ONCX; *ky = C::OKY; *kx = C::OKX;
+    return C::obs_ok;
+  };
+  if (n_fused == 4 && k0 == 9) return set(TailCfg<9, 5, 3, 5>{});
+  if (n_fused == 4 && k0 == 15) return set(TailCfg<15, 9, 5, 9>{});
+  if (n_fused == 3 && k0 == 9) return set(TailCfg<9, 5, 9>{});
+  if (n_fused == 3 && k0 == 5) return set(TailCfg<5, 3, 5>{});
   return false;
 }
 
-bool obs_fusable(const ObsTables& t, int H, int W) {
-  return (float)H / t.oh >= 7.5f && (float)W / t.ow >= 8.0f && t.ymax <= kObsKY && t.xmax <= kObsKX && W % 4 == 0;
+hipError_t run_obs_finish(const float* part, void* obs, bool u8, const ObsTables& t, int H, int W, int B, int nry, int ncx,
+                          hipStream_t st) {
+  const int TW = 64, TH = 32;
+  const int ntx = (W + TW - 1) / TW, nty = (H + TH - 1) / TH;
+  const dim3 grid((t.oh * t.ow + 255) / 256, B);
+  if (u8) hipLaunchKernelGGL(obs_finish_kernel<true>, grid, dim3(256), 0, st, part, obs, t, H, W, ntx, nty, TW, TH, nry, ncx);
+  else hipLaunchKernelGGL(obs_finish_kernel<false>, grid, dim3(256), 0, st, part, obs, t, H, W, ntx, nty, TW, TH, nry, ncx);
+  return hipGetLastError();
+}
+
+// can the fused tail (n_fused levels, first fused k) produce this observation?  Cells per tile and filter lengths must fit
+// what the instantiation is compiled for.
+bool obs_fusable(const ObsTables& t, int H, int W, int n_fused, int k0) {
+  int nry, ncx, ky, kx;
+  if (!tail_obs_geom(n_fused, k0, &nry, &ncx, &ky, &kx) || W % 4 != 0) return false;
+  const float scy = (float)H / t.oh, scx = (float)W / t.ow;
+  return 32.0f / scy + 3.0f <= (float)nry && 64.0f / scx + 3.0f <= (float)ncx && t.ymax <= ky && t.xmax <= kx;
 }
 
 size_t tail_tiles_per_frame(int H, int W) { return (size_t)((W + 63) / 64) * ((H + 31) / 32); }
 
-size_t obs_part_floats(int H, int W, int B) {
-  const int ntx = (W + 63) / 64, nty = (H + 31) / 32;
-  return (size_t)B * ntx * nty * kObsNRY * kObsNCX * 3;
+size_t obs_part_floats(int H, int W, int B, int nry, int ncx) {
+  return (size_t)B * tail_tiles_per_frame(H, W) * nry * ncx * 3;
 }
 
 template <int... KS>
 static hipError_t launch_tail(const TailArgs& a0, hipStream_t st) {
   using C = TailCfg<KS...>;
-  if (!C::obs_ok && a0.obs_part) return hipErrorInvalidValue;  // callers check tail_obs_supported() first
+  if (!C::obs_ok && a0.obs_part) return hipErrorInvalidValue;  // callers check obs_fusable() first
   TailArgs a = a0;
   const int ntx = (a.W + C::TW - 1) / C::TW, nty = (a.H + C::TH - 1) / C::TH;
   auto kern = taxim_tail_kernel<KS...>;
