@@ -738,10 +738,10 @@ static hipError_t launch_band_nt(const BlurArgs& a0, hipStream_t st) {
 // threads per workgroup: 64 * ceil(W/128) waves per row chunk * (TH/RV = 2) chunks
 template <int K, int TH, int RV, int RH, bool FIRST>
 static hipError_t launch_band(const BlurArgs& a, hipStream_t st) {
+  // widths up to 384 only: wider frames are served by the MFMA band kernels (taxim_mfma.hip) or, with TACEX_BLUR_MFMA=0,
+  // by the looped / generic kernels - the fully unrolled k = 61 / 33 instantiations for 640 columns cost a minute of build
+  // time for a path nothing selects by default
   if (a.W <= 384) return launch_band_nt<K, TH, RV, RH, FIRST, 384>(a, st);
-  if constexpr (K == 33 || K == 61) {  // 640x480 levels that are not covered by the fused tail
-    if (a.W <= 640) return launch_band_nt<K, TH, RV, RH, FIRST, 640>(a, st);
-  }
   return hipErrorInvalidValue;
 }
 
@@ -782,7 +782,7 @@ static bool band_loop_supported(int k, int H, int W) {
 
 static bool band_supported(int k, int H, int W) {
   if (W % 16 != 0 || W < 32 || H < 2) return false;
-  if (W > 384 && !(W <= 640 && (k == 33 || k == 61))) return false;
+  if (W > 384) return false;
   if ((k - 1) / 2 >= H || ((k - 1) / 2 + 1) > W - 1) return false;
   switch (k) {
     case 3: case 5: case 9: case 15: case 17: case 33: case 61: return true;  // 117: generic path (TODO chunked variant)
