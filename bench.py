@@ -206,7 +206,10 @@ def main():
             elif name.startswith("blur_"):
                 bpf = 12 * N         # read previous level + height map (masked restore), write level
             elif name.startswith("tail"):
-                bpf = (20 + (5 if markers else 0)) * N  # read level + height map, write RGB (+ deformed gel + mask for FOTS)
+                # read level + height map, write RGB; FOTS gets the marker pixels + per-wave statistics from the same kernel
+                # (a few KB per frame), so the full deformed-gel / mask frames (5 B/px) are only stored on the fallback path
+                full_frames = markers and getattr(sensor.optical_simulator, "_fots_compact_version", -1) < 0
+                bpf = (20 + (5 if full_frames else 0)) * N
             else:
                 bpf = 16 * N         # shade: read deformed gel, write RGB
             avg = ms / cnt

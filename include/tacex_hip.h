@@ -148,6 +148,12 @@ int tacex_taxim_render(tacex_taxim_ctx* ctx, const float* hm_mm_dev, const float
  * tile while the frame is in LDS; tacex_fots_markers_partials consumes them.  Only calls with num_frames <= capacity_frames
  * write (the buffer holds capacity_frames * partials_per_env records); nullptr disables. */
 int tacex_taxim_fots_partials_per_env(const tacex_taxim_ctx* ctx);
+/* ... and the deformed gel / contact mask AT THE MARKER PIXELS only (FOTS looks nothing else up, MM:152-166): with the taps
+ * set, the fused tail also fills z_pix_dev / mask_pix_dev (capacity_frames, n_markers) and the caller may pass
+ * z_out_dev = mask_out_dev = NULL to the render - 5 B/px of stores less.  marker_x / marker_y: HOST int32 pixel positions
+ * (the FOTS marker grid); markers outside the image are skipped.  NULL buffers disable. */
+int tacex_taxim_set_fots_taps(tacex_taxim_ctx* ctx, const int32_t* marker_x, const int32_t* marker_y, int n_markers,
+                              float* z_pix_dev, uint8_t* mask_pix_dev, int capacity_frames);
 int tacex_taxim_set_fots_partials(tacex_taxim_ctx* ctx, void* partials_dev, int capacity_frames);
 
 /* tacex_taxim_render + the low-resolution POLICY OBSERVATION in the same pass: obs_out_dev (B,obs_h,obs_w,3) is the
@@ -230,6 +236,12 @@ int tacex_fots_markers(tacex_fots_ctx* ctx, const float* z_dev, const uint8_t* m
                        const float* indent_dev, const float* theta_dev, float* traj_state_dev,
                        float* markers_dev, void* workspace_dev, int num_envs, void* stream);
 
+/* With pixels_compact != 0, z_dev / mask_dev are the (num_envs, num_markers) arrays tacex_taxim_set_fots_taps fills
+ * instead of full (num_envs, H, W) frames. */
+int tacex_fots_markers_compact(tacex_fots_ctx* ctx, const float* z_pix_dev, const uint8_t* mask_pix_dev,
+                               const float* indent_dev, const float* theta_dev, float* traj_state_dev,
+                               float* markers_dev, void* workspace_dev, const void* partials_dev,
+                               int partials_per_env, int num_envs, void* stream);
 /* Same, with the per-env contact statistics (max of the deformed gel, mask centroid sums; FS:130-141) taken from the
  * partials a tacex_taxim_render* / _deform call wrote (tacex_taxim_set_fots_partials) instead of re-reading z / mask. */
 int tacex_fots_markers_partials(tacex_fots_ctx* ctx, const float* z_dev, const uint8_t* mask_dev,

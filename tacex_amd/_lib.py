@@ -117,6 +117,8 @@ SIGNATURES = {
     "tacex_fots_markers_partials": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp]),
     "tacex_taxim_fots_partials_per_env": (_i, [_vp]),
     "tacex_taxim_set_fots_partials": (_i, [_vp, _vp, _i]),
+    "tacex_taxim_set_fots_taps": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _i]),
+    "tacex_fots_markers_compact": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp]),
     "tacex_fem_create": (_i, [_i, C.POINTER(FemParams), C.POINTER(_vp)]),
     "tacex_fem_destroy": (None, [_vp]),
     "tacex_fem_workspace_bytes": (_sz, [_vp, _i]),

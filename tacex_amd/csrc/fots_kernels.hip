@@ -87,6 +87,7 @@ struct FotsArgs {
   float* traj; float* markers; const FotsReduce* red;
   const int* mx; const int* my;
   int B, H, W, nrow, ncol;
+  int compact;  // z / mask are (B, M) values at the marker pixels instead of (B, H, W) frames
   double lamb0, lamb1, lamb2;
   float mm2pix, shear_max, theta_max_rad_f;
 };
@@ -136,10 +137,11 @@ __global__ __launch_bounds__(128) void fots_marker_kernel(FotsArgs a) {
   bool hit = false;
   float hval = 0.0f;
   if (active && py >= 0 && py < a.H && px >= 0 && px < a.W) {
-    if (a.mask[fo + (size_t)py * a.W + px] == 1) {
+    const size_t pi = a.compact ? (size_t)e * M + tid : fo + (size_t)py * a.W + px;
+    if (a.mask[pi] == 1) {
       hit = true;
       // deformed' = gmax - Z (FS:130, fp32); depth = deformed' - min_env(deformed') (MM:146); /= 10 (MM:149)
-      const float dz = gmax - a.z[fo + (size_t)py * a.W + px];
+      const float dz = gmax - a.z[pi];
       const float dmin = gmax - red.zmax;
       hval = (dz - dmin) / 10.0f;
     }
@@ -281,7 +283,7 @@ size_t tacex_fots_state_bytes(int num_envs) { return num_envs > 0 ? (size_t)num_
 size_t tacex_fots_workspace_bytes(int num_envs) { return num_envs > 0 ? (size_t)num_envs * sizeof(FotsReduce) : 0; }
 
 static int fots_markers_impl(tacex_fots_ctx* c, const float* z, const uint8_t* mask, const float* indent, const float* theta,
-                             float* traj_state, float* markers, void* ws, const FotsReduce* part, int npart, int B, void* stream);
+                             float* traj_state, float* markers, void* ws, const FotsReduce* part, int npart, int B, void* stream, int compact = 0);
 
 int tacex_fots_markers(tacex_fots_ctx* c, const float* z, const uint8_t* mask, const float* indent,
                        const float* theta, float* traj_state, float* markers, void* ws, int B, void* stream) {
@@ -305,13 +307,26 @@ int tacex_fots_markers_partials(tacex_fots_ctx* c, const float* z, const uint8_t
                            partials_per_env, B, stream);
 }
 
+int tacex_fots_markers_compact(tacex_fots_ctx* c, const float* z_pix, const uint8_t* mask_pix, const float* indent,
+                               const float* theta, float* traj_state, float* markers, void* ws, const void* partials,
+                               int partials_per_env, int B, void* stream) {
+  if (!c || !z_pix || !mask_pix || !indent || !theta || !traj_state || !markers || !ws || !partials || partials_per_env < 1) {
+    set_error("tacex_fots_markers_compact: null argument");
+    return 2;
+  }
+  if (B <= 0) return 0;
+  return fots_markers_impl(c, z_pix, mask_pix, indent, theta, traj_state, markers, ws, static_cast<const FotsReduce*>(partials),
+                           partials_per_env, B, stream, 1);
+}
+
 static int fots_markers_impl(tacex_fots_ctx* c, const float* z, const uint8_t* mask, const float* indent, const float* theta,
-                             float* traj_state, float* markers, void* ws, const FotsReduce* part, int npart, int B, void* stream) {
+                             float* traj_state, float* markers, void* ws, const FotsReduce* part, int npart, int B, void* stream, int compact) {
   hipStream_t st = (hipStream_t)stream;
   FotsReduce* red = static_cast<FotsReduce*>(ws);
   if (part) hipLaunchKernelGGL(fots_combine_kernel, dim3(B), dim3(64), 0, st, part, npart, red);
   else hipLaunchKernelGGL(fots_reduce_kernel, dim3(B), dim3(1024), 0, st, z, mask, red, c->H, c->W);
   FotsArgs a{};
+  a.compact = compact;
   a.z = z; a.mask = mask; a.indent = indent; a.theta = theta; a.traj = traj_state; a.markers = markers; a.red = red;
   a.mx = c->mx_dev; a.my = c->my_dev; a.B = B; a.H = c->H; a.W = c->W; a.nrow = c->nrow; a.ncol = c->ncol;
   a.lamb0 = c->lamb[0]; a.lamb1 = c->lamb[1]; a.lamb2 = c->lamb[2];

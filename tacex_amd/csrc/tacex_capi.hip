@@ -51,6 +51,10 @@ struct tacex_taxim_ctx {
   float* gel_dev = nullptr;
   FotsReduce* fots_part = nullptr;  // optional per-wave FOTS contact statistics written by the fused tail
   int fots_cap = 0;                 // frames the buffer holds
+  FotsTaps fots_taps{};             // marker pixels per tile (tacex_taxim_set_fots_taps)
+  float* fots_pix_z = nullptr;      // (cap, M) deformed gel at the marker pixels
+  uint8_t* fots_pix_m = nullptr;    // (cap, M) contact mask at the marker pixels
+  int fots_pix_cap = 0;
   ObsTables obs_tab{};   // filter tables of the last policy-observation size asked for (built on first use)
   std::vector<void*> allocs;
   // profiling
@@ -381,7 +385,7 @@ int tacex_indentation_depth(const float* hm_mm, float gelpad_h, float gelpad_dmi
 
 static int pipeline_chunk(tacex_taxim_ctx* c, const float* hm, const float* press, float* frame_min, float* rgb,
                           float* z_out, uint8_t* mask_out, void* ws, int B, unsigned flags, hipStream_t st,
-                          float* obs_h, void* obs, int obs_hh, int obs_w, FotsReduce* fots_part);
+                          float* obs_h, void* obs, int obs_hh, int obs_w, FotsReduce* fots_part, int frame0);
 
 // Frames per pass of the pipeline: the level buffers (Z ping / pong, 4 B/px each) plus the height map of one pass should
 // stay resident in the 256 MB Infinity Cache between the kernels of the pass, so large shards are walked in chunks that
@@ -404,7 +408,7 @@ static int pipeline_impl(tacex_taxim_ctx* c, const float* hm, const float* press
   const int cf = chunk_frames(c, B);
   FotsReduce* fp = (c->fots_part && B <= c->fots_cap) ? c->fots_part : nullptr;
   const size_t fper = tail_tiles_per_frame(c->H, c->W) * kTailWavesPerTile;
-  if (cf >= B) return pipeline_chunk(c, hm, press, frame_min, rgb, z_out, mask_out, ws, B, flags, st, obs_h, obs, obs_hh, obs_w, fp);
+  if (cf >= B) return pipeline_chunk(c, hm, press, frame_min, rgb, z_out, mask_out, ws, B, flags, st, obs_h, obs, obs_hh, obs_w, fp, B <= c->fots_pix_cap ? 0 : -1);
   if (!(flags & TACEX_FLAG_HAVE_FRAME_MIN)) {  // one reduction pass over the whole shard, then chunks
     StageTimer t(c, st, 0);
     HIP_TRY(run_frame_min(hm, false, nullptr, frame_min, nullptr, nullptr, B, c->H * c->W, 0.f, 0.f, 0.f, 0.f, st),
@@ -417,7 +421,7 @@ static int pipeline_impl(tacex_taxim_ctx* c, const float* hm, const float* press
                             z_out ? z_out + b0 * npix : nullptr, mask_out ? mask_out + b0 * npix : nullptr, ws, n,
                             flags | TACEX_FLAG_HAVE_FRAME_MIN, st, obs_h,
                             obs ? static_cast<char*>(obs) + (size_t)b0 * obs_hh * obs_w * 3 * ((flags & TACEX_FLAG_OBS_U8) ? 1 : 4) : nullptr,
-                            obs_hh, obs_w, fp ? fp + (size_t)b0 * fper : nullptr);
+                            obs_hh, obs_w, fp ? fp + (size_t)b0 * fper : nullptr, B <= c->fots_pix_cap ? b0 : -1);
     if (rc) return rc;
   }
   return 0;
@@ -434,7 +438,7 @@ static int resize_obs(tacex_taxim_ctx* c, const float* rgb, float* scratch, void
 
 static int pipeline_chunk(tacex_taxim_ctx* c, const float* hm, const float* press, float* frame_min, float* rgb,
                           float* z_out, uint8_t* mask_out, void* ws, int B, unsigned flags, hipStream_t st,
-                          float* obs_h, void* obs, int obs_hh, int obs_w, FotsReduce* fots_part) {
+                          float* obs_h, void* obs, int obs_hh, int obs_w, FotsReduce* fots_part, int frame0) {
   const bool obs_u8 = (flags & TACEX_FLAG_OBS_U8) != 0;
   const size_t img = align_up((size_t)B * c->H * c->W * sizeof(float), 256);
   const size_t vec = align_up((size_t)B * sizeof(float), 256);
@@ -483,7 +487,11 @@ static int pipeline_chunk(tacex_taxim_ctx* c, const float* hm, const float* pres
                  obs_part_floats(c->H, c->W, B, onry, oncx) <= (size_t)B * (size_t)(c->H * obs_w > obs_hh * c->W ? c->H * obs_w : obs_hh * c->W) * 3;
     }
     HIP_TRY(run_tail(c->levels, c->n_levels, n_fused, src, hm, c->gel_dev, sa, sb, pd, z_out, mask_out, &c->shade, rgb,
-                     fuse_obs ? obs_h : nullptr, fuse_obs ? &c->obs_tab : nullptr, fots_part, B, c->H, c->W, c->contact_scale, st),
+                     fuse_obs ? obs_h : nullptr, fuse_obs ? &c->obs_tab : nullptr, fots_part,
+                     (frame0 >= 0 && c->fots_pix_z) ? &c->fots_taps : nullptr,
+                     (frame0 >= 0 && c->fots_pix_z) ? c->fots_pix_z + (size_t)frame0 * c->fots_taps.n_markers : nullptr,
+                     (frame0 >= 0 && c->fots_pix_m) ? c->fots_pix_m + (size_t)frame0 * c->fots_taps.n_markers : nullptr, B, c->H, c->W,
+                     c->contact_scale, st),
             "taxim_tail_kernel");
     if (fuse_obs) {
       HIP_TRY(run_obs_finish(obs_h, obs, obs_u8, c->obs_tab, c->H, c->W, B, onry, oncx, st), "obs_finish_kernel");
@@ -538,6 +546,32 @@ int tacex_taxim_render(tacex_taxim_ctx* c, const float* hm, const float* press, 
     return 0;
   }
   return pipeline_impl(c, hm, press, frame_min, rgb, z_out, mask_out, ws, B, flags, (hipStream_t)stream);
+}
+
+int tacex_taxim_set_fots_taps(tacex_taxim_ctx* c, const int32_t* marker_x, const int32_t* marker_y, int n_markers,
+                              float* z_pix_dev, uint8_t* mask_pix_dev, int capacity_frames) {
+  if (!c) { set_error("tacex_taxim_set_fots_taps: null context"); return 2; }
+  if (!z_pix_dev || !mask_pix_dev || !marker_x || !marker_y || n_markers <= 0) {  // disable
+    c->fots_pix_z = nullptr; c->fots_pix_m = nullptr; c->fots_pix_cap = 0;
+    return 0;
+  }
+  if (n_markers > 65535) { set_error("tacex_taxim_set_fots_taps: too many markers"); return 2; }
+  HIP_TRY(hipSetDevice(c->device), "hipSetDevice");
+  const int ntx = (c->W + 63) / 64, nty = (c->H + 31) / 32;
+  std::vector<int> tile((size_t)ntx * nty * kTailMaxMarkersPerTile, 0), cnt((size_t)ntx * nty, 0);
+  for (int m = 0; m < n_markers; ++m) {
+    const int x = marker_x[m], y = marker_y[m];
+    if (x < 0 || x >= c->W || y < 0 || y >= c->H) continue;  // FOTS ignores markers outside the image (MM:152-166)
+    const int t = (y / 32) * ntx + x / 64;
+    if (cnt[t] >= kTailMaxMarkersPerTile) { set_error("tacex_taxim_set_fots_taps: more than %d markers in one 64x32 tile", kTailMaxMarkersPerTile); return 2; }
+    tile[(size_t)t * kTailMaxMarkersPerTile + cnt[t]++] = (m << 16) | ((y % 32) << 8) | (x % 64);
+  }
+  int *dt = nullptr, *dc = nullptr;
+  if (int rc = upload(c, tile.data(), tile.size(), &dt)) return rc;
+  if (int rc = upload(c, cnt.data(), cnt.size(), &dc)) return rc;
+  c->fots_taps.mk_tile = dt; c->fots_taps.mk_cnt = dc; c->fots_taps.n_markers = n_markers;
+  c->fots_pix_z = z_pix_dev; c->fots_pix_m = mask_pix_dev; c->fots_pix_cap = capacity_frames;
+  return 0;
 }
 
 int tacex_taxim_fots_partials_per_env(const tacex_taxim_ctx* c) {

@@ -24,6 +24,13 @@ struct FotsReduce {
   int sum_col;
 };
 constexpr int kTailWavesPerTile = 8;
+constexpr int kTailMaxMarkersPerTile = 16;
+// FOTS marker pixels per 64 x 32 tile of the fused tail (device tables, built by tacex_taxim_set_fots_taps)
+struct FotsTaps {
+  const int* mk_tile = nullptr;  // [tiles_per_frame][kTailMaxMarkersPerTile]: marker << 16 | y_in_tile << 8 | x_in_tile
+  const int* mk_cnt = nullptr;   // [tiles_per_frame]
+  int n_markers = 0;
+};
 
 struct ShadeParams {
   int H = 0, W = 0, nb = 0, calib_h = 0, calib_w = 0;
@@ -76,8 +83,8 @@ struct ObsTables {
 };
 hipError_t run_tail(const LevelDesc* lv, int n_levels, int n_fused, const float* zin, const float* hm, const float* gel,
                     const float* sa, const float* sb, const float* pd, float* z_out, uint8_t* mask_out,
-                    const ShadeParams* sp, float* rgb, float* obs_part, const ObsTables* obs_tab, FotsReduce* fots_part, int B,
-                    int H, int W, float contact_scale, hipStream_t st);
+                    const ShadeParams* sp, float* rgb, float* obs_part, const ObsTables* obs_tab, FotsReduce* fots_part,
+                    const FotsTaps* taps, float* pix_z, uint8_t* pix_m, int B, int H, int W, float contact_scale, hipStream_t st);
 size_t tail_tiles_per_frame(int H, int W);
 hipError_t run_obs_finish(const float* part, void* obs, bool u8, const ObsTables& t, int H, int W, int B, int nry, int ncx,
                           hipStream_t st);

@@ -57,6 +57,9 @@ struct TailArgs {
   float* obs_part;       // nullable: per-tile partial sums of the policy observation, [tile][ONRY][ONCX][3]
   ObsTables obs;         // filter tables of the observation (valid when obs_part != nullptr)
   FotsReduce* fots_part; // nullable: per-wave contact statistics, [tile][kTailWavesPerTile]
+  // nullable: deformed gel / contact mask at the FOTS marker pixels only (B, M) - lets the caller drop the full-frame
+  // z_out / mask_out stores.  mk_tile[tile_in_frame][kTailMaxMarkersPerTile] = marker << 16 | ly << 8 | lx, mk_cnt[tile]
+  float* pix_z; uint8_t* pix_m; const int* mk_tile; const int* mk_cnt; int n_markers;
 };
 
 template <int... KS>
@@ -439,6 +442,18 @@ __global__ __launch_bounds__(kTailThreads, kTailWavesPerSimd) void taxim_tail_ke
       }
     }
   }
+  if (a.pix_z) {  // the few marker pixels of this tile: straight from the LDS copies of the final level and the mask
+    const int cnt = a.mk_cnt[tix];
+    if (tid < cnt) {
+      const int e = a.mk_tile[tix * kTailMaxMarkersPerTile + tid];
+      const int m = e >> 16, ly = ((e >> 8) & 0xff) + HLY, lx = (e & 0xff) + HLX;
+      uint8_t mv;
+      if constexpr (kTailCacheJ) mv = bufM[ly * P + PADX + lx];
+      else mv = (uint8_t)((bufM[ly * MG + (lx >> 2)] >> (lx & 3)) & 1);
+      a.pix_z[(size_t)frame * a.n_markers + m] = bufZ[(ly + PADY) * P + PADX + lx];
+      a.pix_m[(size_t)frame * a.n_markers + m] = mv;
+    }
+  }
   if (a.fots_part) {  // one record per wave: no barrier, no atomics; fots_combine_kernel adds the records of an env
     f_zmax = wave_scan_max_lane63(f_zmax);
     f_cnt = wave_scan_add_lane63(f_cnt);
@@ -627,10 +642,13 @@ int tail_levels(const LevelDesc* lv, int n_levels, int H, int W) {
 
 hipError_t run_tail(const LevelDesc* lv, int n_levels, int n_fused, const float* zin, const float* hm, const float* gel,
                     const float* sa, const float* sb, const float* pd, float* z_out, uint8_t* mask_out,
-                    const ShadeParams* sp, float* rgb, float* obs_part, const ObsTables* obs_tab, FotsReduce* fots_part, int B,
-                    int H, int W, float contact_scale, hipStream_t st) {
+                    const ShadeParams* sp, float* rgb, float* obs_part, const ObsTables* obs_tab, FotsReduce* fots_part,
+                    const FotsTaps* taps, float* pix_z, uint8_t* pix_m, int B, int H, int W, float contact_scale, hipStream_t st) {
   TailArgs a{};
   a.fots_part = fots_part;
+  if (taps && taps->mk_tile && pix_z && pix_m) {
+    a.pix_z = pix_z; a.pix_m = pix_m; a.mk_tile = taps->mk_tile; a.mk_cnt = taps->mk_cnt; a.n_markers = taps->n_markers;
+  }
   a.obs_part = obs_tab ? obs_part : nullptr;
   if (a.obs_part) a.obs = *obs_tab;
   a.zin = zin; a.hm = hm; a.gel = lv[0].gel_zero ? nullptr : gel; a.shift_a = sa; a.shift_b = sb; a.pdepth = pd; a.z_out = z_out; a.mask_out = mask_out;

@@ -93,7 +93,8 @@ class FOTSMarkerSimulator(GelSightSimulator):
         self.sensor._data.output["traj"] = self._traj_state
         self.theta = torch.zeros((B,), device=self._device)
         self._ws = torch.empty(max(1, lib.tacex_fots_workspace_bytes(B)), dtype=torch.uint8, device=self._device)
-        self._optical.request_deformation_outputs()
+        self._optical.request_deformation_outputs(mx, my) if tuple(self._optical.cfg.tactile_img_res) == tuple(self.cfg.tactile_img_res) \
+            else self._optical.request_deformation_outputs()
         self._z = None
         self._mask = None
 
@@ -115,6 +116,17 @@ class FOTSMarkerSimulator(GelSightSimulator):
             self.set_indenter_yaw(self.cfg.yaw_source())
         opt = self._optical
         partials = None
+        if getattr(opt, "_fots_compact_version", -1) == self.sensor._height_map_version \
+                and getattr(opt, "_fots_partials_version", -1) == self.sensor._height_map_version:
+            # the render left the marker-pixel values and the contact statistics behind: no frame is read at all
+            indent = self._indentation_depth.to(self._device).contiguous()
+            with torch.cuda.device(self.marker_data.device):
+                rc = self._lib.tacex_fots_markers_compact(
+                    self._handle, _lib.ptr(opt._pix_z), _lib.ptr(opt._pix_m), _lib.ptr(indent), _lib.ptr(self.theta),
+                    _lib.ptr(self._traj_state), _lib.ptr(self.marker_data), _lib.ptr(self._ws), _lib.ptr(opt._fots_partials),
+                    int(opt._fots_partials.shape[1]), self._num_envs, _lib.current_stream_handle(self.marker_data.device))
+            _lib.check(rc, "tacex_fots_markers_compact")
+            return self.marker_data
         if opt._keep_deformation and opt._deformation_version == self.sensor._height_map_version \
                 and tuple(opt.cfg.tactile_img_res) == tuple(self.cfg.tactile_img_res):
             z, mask = opt._deformed_gel, opt._contact_mask  # same height map already deformed by the render

@@ -347,6 +347,21 @@ class TaximHip:
         _lib.check(self._lib.tacex_taxim_set_fots_partials(ctx.handle, _lib.ptr(buf) if buf is not None else 0,
                                                            int(capacity_frames)), "set_fots_partials")
 
+    def set_fots_taps(self, shape_hw, marker_x, marker_y, z_pix: torch.Tensor | None, mask_pix: torch.Tensor | None,
+                      capacity_frames: int = 0):
+        """marker_x / marker_y: host int32 arrays (M,); z_pix (cap, M) f32 / mask_pix (cap, M) u8 device tensors the fused
+        tail fills with the deformed gel / contact mask at the marker pixels (None disables)."""
+        import numpy as np
+
+        ctx = self.context(shape_hw)
+        if z_pix is None:
+            _lib.check(self._lib.tacex_taxim_set_fots_taps(ctx.handle, 0, 0, 0, 0, 0, 0), "set_fots_taps")
+            return
+        mx = np.ascontiguousarray(marker_x, dtype=np.int32)
+        my = np.ascontiguousarray(marker_y, dtype=np.int32)
+        _lib.check(self._lib.tacex_taxim_set_fots_taps(ctx.handle, mx.ctypes.data, my.ctypes.data, int(mx.size), _lib.ptr(z_pix),
+                                                       _lib.ptr(mask_pix), int(capacity_frames)), "set_fots_taps")
+
     # -- profiling (bench.py roofline leg) --------------------------------------------------------------------
     def set_profiling(self, shape_hw, enabled: bool):
         ctx = self.context(shape_hw)

@@ -48,6 +48,7 @@ class TaximSimulator(GelSightSimulator):
         self._contact_mask = None
         self._deformation_version = -1
         self._fots_partials_version = -1
+        self._fots_compact_version = -1
         self._resized_hm = None
         self.policy_obs = None
         if getattr(self.cfg, "policy_obs_res", None) is not None:
@@ -56,12 +57,21 @@ class TaximSimulator(GelSightSimulator):
             self.policy_obs = torch.zeros((self._num_envs, oh, ow, 3), device=self._device, dtype=dt)
 
     # -- helpers --------------------------------------------------------------------------------------
-    def request_deformation_outputs(self):
-        """A marker simulator asks the optical simulator to also keep (deformed gel, contact mask)."""
+    def request_deformation_outputs(self, marker_x=None, marker_y=None):
+        """A marker simulator asks the optical simulator to also keep (deformed gel, contact mask).  With the marker
+        pixel grid (host int arrays) and a fused tail, only the values AT the markers are kept (`_pix_z`, `_pix_m`,
+        (num_envs, M)) and the 5 B/px full-frame stores are dropped; the full frames are the fallback."""
         W, H = self.cfg.tactile_img_res
         self._keep_deformation = True
         self._deformed_gel = torch.zeros((self._num_envs, H, W), device=self._device)
         self._contact_mask = torch.zeros((self._num_envs, H, W), dtype=torch.uint8, device=self._device)
+        self._pix_z = self._pix_m = None
+        self._fots_compact_version = -1
+        if marker_x is not None and self._taxim.fots_partials_per_env((H, W)) > 0:
+            M = int(len(marker_x))
+            self._pix_z = torch.zeros((self._num_envs, M), device=self._device)
+            self._pix_m = torch.zeros((self._num_envs, M), dtype=torch.uint8, device=self._device)
+            self._taxim.set_fots_taps((H, W), marker_x, marker_y, self._pix_z, self._pix_m, self._num_envs)
         # the fused tail also leaves FOTS's per-env contact statistics behind (one 16-byte record per wave and tile)
         n = self._taxim.fots_partials_per_env((H, W))
         self._fots_partials = torch.zeros((self._num_envs, max(n, 1), 16), dtype=torch.uint8, device=self._device)
@@ -91,6 +101,11 @@ class TaximSimulator(GelSightSimulator):
         """(num_envs, H, W, 3) float32 RGB in [0,1] (the reference docstring says 0..255, taxim_sim.py:83, wrongly)."""
         height_map, resized = self._tactile_height_map()
         have_min = (not resized) and self._frame_min_version == self.sensor._height_map_version
+        W, H = self.cfg.tactile_img_res
+        # marker-pixel outputs replace the full deformed-gel / mask frames while the fused tail is available
+        compact = (self._keep_deformation and getattr(self, "_pix_z", None) is not None and not self.cfg.with_shadow
+                   and self._taxim.fots_partials_per_env((H, W)) > 0)
+        full = self._keep_deformation and not compact
         self._taxim.render_direct(
             height_map,
             with_shadow=self.cfg.with_shadow,
@@ -98,13 +113,13 @@ class TaximSimulator(GelSightSimulator):
             orig_hm_fmt=False,
             out=self.tactile_rgb_img,
             frame_min=self._frame_min if have_min else None,
-            z_out=self._deformed_gel if self._keep_deformation else None,
-            mask_out=self._contact_mask if self._keep_deformation else None,
+            z_out=self._deformed_gel if full else None,
+            mask_out=self._contact_mask if full else None,
             obs_out=self.policy_obs,
         )
         if self._keep_deformation:
-            self._deformation_version = self.sensor._height_map_version
-            W, H = self.cfg.tactile_img_res
+            self._deformation_version = self.sensor._height_map_version if full else -1
+            self._fots_compact_version = self.sensor._height_map_version if compact else -1
             n = self._taxim.fots_partials_per_env((H, W))  # 0 while the fused tail is disabled
             self._fots_partials_version = self.sensor._height_map_version if n == self._fots_partials.shape[1] and n > 0 else -1
         return self.tactile_rgb_img
@@ -134,6 +149,7 @@ class TaximSimulator(GelSightSimulator):
         self._indent_version = -1
         self._deformation_version = -1
         self._fots_partials_version = -1
+        self._fots_compact_version = -1
 
     def _set_debug_vis_impl(self, debug_vis: bool):
         pass  # Kit UI windows of the reference (taxim_sim.py:137-213) are out of scope
