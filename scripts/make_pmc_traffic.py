@@ -1,10 +1,10 @@
 """Build profiles/pmc_traffic.json from two rocprofv3 --pmc passes (FETCH_SIZE and WRITE_SIZE in SEPARATE runs, as the
-MI355X guide prescribes) of `scripts/quick_bench.py 256 --iters 3 --no-profile`.
+MI355X guide prescribes) of the bench command (256 frames per launch).
 
 On the GPU box:
     cd /tmp && export TMPDIR=/tmp
-    rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/pmc_fetch -- python $GRAFT_REPO_ROOT/scripts/quick_bench.py 256 --iters 3 --no-profile
-    rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/pmc_write -- python $GRAFT_REPO_ROOT/scripts/quick_bench.py 256 --iters 3 --no-profile
+    rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/pmc_fetch -- python $GRAFT_REPO_ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-roofline
+    rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/pmc_write -- python $GRAFT_REPO_ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-roofline
 then (anywhere):  python scripts/make_pmc_traffic.py gpurun_out/pmc_fetch gpurun_out/pmc_write profiles/pmc_traffic.json
 """
 import csv, glob, json, os, sys
@@ -35,8 +35,8 @@ def collect(d, counter):
 
 fetch, write = collect(sys.argv[1], "FETCH_SIZE"), collect(sys.argv[2], "WRITE_SIZE")
 out = {
-    "_provenance": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (two separate passes) on `python scripts/quick_bench.py "
-                   "256 --iters 3 --no-profile`, MI355X; built by scripts/make_pmc_traffic.py. Counter unit KiB. FETCH_SIZE is doubled "
+    "_provenance": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (two separate passes) on `python bench.py --steps 5 --warmup 2 "
+                   "--no-cpu-baseline --no-roofline` (256 envs through GelSightSensor.update()), MI355X; built by scripts/make_pmc_traffic.py. Counter unit KiB. FETCH_SIZE is doubled "
                    "(gfx950 reports exactly 1/2 of wide coalesced streaming reads, MI355X_MICROARCH.md HBM section; check: frame_min reads "
                    "78.6 MB, counter 39.3 MB). Values are HBM bytes PER FRAME (320x240); bench.py multiplies by the frames per launch.",
     "frames_per_launch_measured": FRAMES,
