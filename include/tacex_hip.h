@@ -32,7 +32,7 @@ extern "C" {
 #endif
 
 #define TACEX_MAX_LEVELS 8
-#define TACEX_ABI_VERSION 1
+#define TACEX_ABI_VERSION 2
 
 typedef struct tacex_taxim_ctx tacex_taxim_ctx;
 typedef struct tacex_fots_ctx tacex_fots_ctx;
@@ -79,8 +79,9 @@ size_t tacex_taxim_workspace_bytes(const tacex_taxim_ctx* ctx, int num_frames);
  *   indent_mm  = d <= gelpad_height ? (gelpad_height - d) * 1000 : 0,
  *                d = max(frame_min/1000 - gelpad_to_camera_min_distance, 0)            (B,)  [nullable]
  *   cam_u8     = uint8(((hm_mm - near_clip_m*1000) / (far_clip_m*1000)) * 255)  (sic)  (B,Hc,Wc) [nullable]
- * depth_m_dev may alias hm_mm_dev. */
-int tacex_height_map_from_depth(const float* depth_m_dev, float near_clip_m, float far_clip_m,
+ * The clip range is passed as DOUBLES: the reference multiplies the Python doubles by 1000 and torch rounds the product once
+ * to float32 (GS:573-574), so cam_u8 is bit-exact.  depth_m_dev may alias hm_mm_dev. */
+int tacex_height_map_from_depth(const float* depth_m_dev, double near_clip_m, double far_clip_m,
                                 float gelpad_height_m, float gelpad_to_camera_min_distance_m,
                                 float* hm_mm_dev, float* frame_min_dev, float* indent_mm_dev,
                                 uint8_t* cam_u8_dev, int num_frames, int height, int width, void* stream);
@@ -196,6 +197,11 @@ int tacex_resize_bilinear_aa_nhwc(const float* src_dev, int src_h, int src_w, fl
  * tuned instantiation exists (320x240, 640x480); 0 = every level as its own kernel + separate shade kernel. */
 int tacex_taxim_set_fused_tail(tacex_taxim_ctx* ctx, int enabled);
 
+/* Frames one pass of the kernel sequence covers for a call with num_frames frames: large shards are walked in chunks whose
+ * level buffers stay resident in the 256 MB Infinity Cache (== num_frames when the shard is rendered in one pass).
+ * bench.py needs it to turn per-launch durations into bytes per launch. */
+int tacex_taxim_chunk_frames(const tacex_taxim_ctx* ctx, int num_frames);
+
 /* Optional per-stage timing with hipEvents on the launch stream (bench.py's roofline leg).
  * Stages: 0 = frame-min, 1..n_levels = blur levels, n_levels+1 = shade, n_levels+2 = fused tail. */
 int tacex_taxim_set_profiling(tacex_taxim_ctx* ctx, int enabled);
@@ -222,7 +228,7 @@ int tacex_fots_create(int device_id, const tacex_fots_params* params, tacex_fots
 void tacex_fots_destroy(tacex_fots_ctx* ctx);
 
 /* Per-env trajectory state (FS:101-103,168,176-177): only traj[0], traj[-1] and len(traj) are ever read
- * (MM:177-205).  Layout of traj_state_dev: (B, 8) float32 = [len, x0, y0, th0, xl, yl, thl, pad].
+ * (MM:177-205).  Layout of traj_state_dev: (B, 8) float32 = [len, x0, y0, th0, xl, yl, thl, n_contacts of the last step].
  * Bytes needed: */
 size_t tacex_fots_state_bytes(int num_envs);
 size_t tacex_fots_workspace_bytes(int num_envs);
@@ -300,6 +306,17 @@ int tacex_fem_newton_step(tacex_fem_ctx* ctx, double* x_dev, const double* x_til
                           const uint8_t* constrained_dev, const double* aim_dev, double* stats_dev,
                           void* workspace_dev, int num_envs, int pcg_max_iter, double pcg_tol_rate,
                           int ls_max_iter, void* stream);
+
+/* Attachment animation (UA:364-428: `_compute_aim_positions` + the animator callback `animate_tet` UA:365-385) for all envs:
+ *   aim_position[b, idx[a]] = R(body_quat[b]) * offsets[a] + body_pos[b];  is_constrained[b, idx[a]] = 1
+ * body_pos_dev (B,3) / body_quat_dev (B,4 wxyz) float32 pose of the rigid body the gelpad is attached to (IsaacLab root / link
+ * state), offsets_dev (A,3) float32 attachment offsets in the body frame (UA:293-297), idx_dev (A,) int32 vertex ids.
+ * The rotation is evaluated in float32 like IsaacLab's transform_points (UA:411-413) and widened to float64 on store.
+ * aim_compact_dev (B,A,3) float64 optionally receives the same positions densely (the reference's `self.aim_positions`). */
+int tacex_fem_set_attachment_targets(const float* body_pos_dev, const float* body_quat_dev, const float* offsets_dev,
+                                     const int32_t* idx_dev, double* aim_position_dev, uint8_t* is_constrained_dev,
+                                     double* aim_compact_dev, int num_envs, int num_attachment_points, int num_verts,
+                                     void* stream);
 
 /* FEM-driven markers (VT:347-366): barycentric surface points -> pinhole projection.
  *   surf_pos_dev (B,Vs,3) surface vertex positions in the CAMERA frame, tri_dev (M,3) int32 vertex ids,

@@ -277,3 +277,17 @@ def marker_uv(surf_pos, tri, weight, fx=340.0, fy=325.0, cx=160.0, cy=125.0):
     u = fx * pts[..., 0] / pts[..., 2] + cx
     v = fy * pts[..., 1] / pts[..., 2] + cy
     return np.stack([u, v], -1)
+
+
+def attachment_aim_positions(offsets, body_pos, body_quat):
+    """Attachment targets (uipc_attachments.py:387-428): IsaacLab `transform_points(offsets, pos, quat)` = R(q) offsets + pos in
+    float32, R = `matrix_from_quat` (wxyz).  offsets (A,3), body_pos (B,3), body_quat (B,4) -> (B,A,3) float64."""
+    f = np.float32
+    q = np.asarray(body_quat, f)
+    r, i, j, k = q[:, 0], q[:, 1], q[:, 2], q[:, 3]
+    two_s = f(2.0) / (q * q).sum(-1, dtype=f)
+    R = np.stack([f(1) - two_s * (j * j + k * k), two_s * (i * j - k * r), two_s * (i * k + j * r),
+                  two_s * (i * j + k * r), f(1) - two_s * (i * i + k * k), two_s * (j * k - i * r),
+                  two_s * (i * k - j * r), two_s * (j * k + i * r), f(1) - two_s * (i * i + j * j)], -1).reshape(-1, 3, 3).astype(f)
+    out = np.einsum("bij,aj->bai", R, np.asarray(offsets, f)).astype(f) + np.asarray(body_pos, f)[:, None, :]
+    return out.astype(np.float64)

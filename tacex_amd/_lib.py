@@ -11,6 +11,7 @@ from pathlib import Path
 from ._build import LIB, build_library
 
 MAX_LEVELS = 8
+ABI_VERSION = 2  # TACEX_ABI_VERSION of include/tacex_hip.h; bumped whenever a signature or struct layout changes
 FLAG_NO_SHIFT = 1
 FLAG_HAVE_FRAME_MIN = 2
 FLAG_WITH_SHADOW = 4
@@ -95,7 +96,7 @@ SIGNATURES = {
     "tacex_taxim_workspace_bytes": (_sz, [_vp, _i]),
     "tacex_taxim_set_shadow": (_i, [_vp, C.POINTER(ShadowParams)]),
     "tacex_taxim_shadow_workspace_bytes": (_sz, [_vp, _i]),
-    "tacex_height_map_from_depth": (_i, [_vp, _f, _f, _f, _f, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
+    "tacex_height_map_from_depth": (_i, [_vp, _d, _d, _f, _f, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "tacex_indentation_depth": (_i, [_vp, _f, _f, _vp, _vp, _i, _i, _i, _vp]),
     "tacex_taxim_render": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _u, _vp]),
     "tacex_taxim_render_obs": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _u, _vp]),
@@ -104,6 +105,7 @@ SIGNATURES = {
     "tacex_resize_bilinear_aa": (_i, [_vp, _i, _i, _vp, _i, _i, _i, _vp]),
     "tacex_resize_bilinear_aa_nhwc": (_i, [_vp, _i, _i, _vp, _i, _i, _i, _i, _vp, _vp]),
     "tacex_taxim_set_fused_tail": (_i, [_vp, _i]),
+    "tacex_taxim_chunk_frames": (_i, [_vp, _i]),
     "tacex_taxim_set_profiling": (_i, [_vp, _i]),
     "tacex_taxim_read_profile": (_i, [_vp, _i, C.POINTER(C.c_double), C.POINTER(C.c_int)]),
     "tacex_taxim_num_stages": (_i, [_vp]),
@@ -127,6 +129,7 @@ SIGNATURES = {
     "tacex_fem_gradient": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp]),
     "tacex_fem_newton_step": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _d, _i, _vp]),
     "tacex_fem_set_newton_early_exit": (_i, [_vp, _vp, C.c_double]),
+    "tacex_fem_set_attachment_targets": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "tacex_fem_marker_uv": (_i, [_vp, _vp, _vp, _d, _d, _d, _d, _vp, _i, _i, _i, _vp]),
 }
 
@@ -143,10 +146,17 @@ def load_library(build_if_missing: bool = True) -> C.CDLL:
     global _lib
     if _lib is not None:
         return _lib
-    if not LIB.exists():
-        if not build_if_missing:
-            raise TacexHipError(f"{LIB} is missing - run `python -m tacex_amd._build` (needs hipcc)")
-        build_library()
+    if not LIB.exists() and not build_if_missing:
+        raise TacexHipError(f"{LIB} is missing - run `python -m tacex_amd._build` (needs hipcc)")
+    if build_if_missing:
+        # a sha256 stamp compare of the sources when the library is current; rebuilds a missing OR STALE one (a library
+        # older than include/tacex_hip.h would be called with the wrong signatures)
+        try:
+            build_library()
+        except Exception as e:
+            if not LIB.exists():
+                raise TacexHipError(f"cannot build {LIB}: {e}") from e
+            raise TacexHipError(f"{LIB} is stale (sources changed) and rebuilding it failed: {e}") from e
     try:
         lib = C.CDLL(str(LIB))
     except OSError as e:  # e.g. libamdhip64 missing
@@ -161,9 +171,11 @@ def load_library(build_if_missing: bool = True) -> C.CDLL:
         fn.restype = res
         fn.argtypes = args
     global MISSING_SYMBOLS
-    MISSING_SYMBOLS = missing  # tests/test_capi_symbols.py requires this to be empty; a missing entry fails at its call site
-    if lib.tacex_abi_version() != 1:
-        raise TacexHipError("libtacex_hip.so ABI version mismatch")
+    MISSING_SYMBOLS = missing
+    if missing:
+        raise TacexHipError(f"{LIB} lacks symbols declared in include/tacex_hip.h: {missing}")
+    if lib.tacex_abi_version() != ABI_VERSION:
+        raise TacexHipError(f"libtacex_hip.so ABI version {lib.tacex_abi_version()} != {ABI_VERSION} (include/tacex_hip.h)")
     _lib = lib
     return lib
 

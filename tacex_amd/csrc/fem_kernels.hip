@@ -903,6 +903,38 @@ __global__ __launch_bounds__(kNwtThreads) void fem_newton_lds_kernel(FemDev m, d
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Attachment animation (UA:364-428): per step and env, aim = R(q) offset + p for every attached vertex, written straight into
+// the constraint arrays the Newton kernels read (`aim_position`, `is_constrained`) - the reference computes it with
+// IsaacLab's `transform_points` in float32 on the GPU, copies it to the host and hands it to libuipc's animator callback
+// (UA:365-385).  One lane per (env, attachment point); float32 rotation like the reference, widened to float64 on store.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(128) void fem_attachment_aim_kernel(const float* __restrict__ body_pos, const float* __restrict__ body_quat,
+                                                                 const float* __restrict__ offsets, const int32_t* __restrict__ idx,
+                                                                 double* __restrict__ aim, uint8_t* __restrict__ constrained,
+                                                                 double* __restrict__ aim_compact, int A, int V) {
+  const int a = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
+  if (a >= A) return;
+  const float qw = body_quat[b * 4 + 0], qx = body_quat[b * 4 + 1], qy = body_quat[b * 4 + 2], qz = body_quat[b * 4 + 3];
+  // isaaclab.utils.math.matrix_from_quat: two_s = 2 / |q|^2, rows of R
+  const float two_s = 2.0f / (qw * qw + qx * qx + qy * qy + qz * qz);
+  const float r00 = 1.0f - two_s * (qy * qy + qz * qz), r01 = two_s * (qx * qy - qz * qw), r02 = two_s * (qx * qz + qy * qw);
+  const float r10 = two_s * (qx * qy + qz * qw), r11 = 1.0f - two_s * (qx * qx + qz * qz), r12 = two_s * (qy * qz - qx * qw);
+  const float r20 = two_s * (qx * qz - qy * qw), r21 = two_s * (qy * qz + qx * qw), r22 = 1.0f - two_s * (qx * qx + qy * qy);
+  const float ox = offsets[a * 3 + 0], oy = offsets[a * 3 + 1], oz = offsets[a * 3 + 2];
+  const float x = (r00 * ox + r01 * oy + r02 * oz) + body_pos[b * 3 + 0];
+  const float y = (r10 * ox + r11 * oy + r12 * oz) + body_pos[b * 3 + 1];
+  const float z = (r20 * ox + r21 * oy + r22 * oz) + body_pos[b * 3 + 2];
+  const int v = idx[a];
+  double* o = aim + ((size_t)b * V + v) * 3;
+  o[0] = (double)x; o[1] = (double)y; o[2] = (double)z;
+  constrained[(size_t)b * V + v] = 1;
+  if (aim_compact) {
+    double* c = aim_compact + ((size_t)b * A + a) * 3;
+    c[0] = (double)x; c[1] = (double)y; c[2] = (double)z;
+  }
+}
+
 // ---- K18: FEM-driven markers: barycentric surface point + pinhole projection (VT:347-366) ------------------------
 __global__ __launch_bounds__(128) void fem_marker_uv_kernel(const double* __restrict__ pos, const int* __restrict__ tri,
                                                             const double* __restrict__ wgt, double fx, double fy,
@@ -1123,6 +1155,16 @@ int tacex_fem_newton_step(tacex_fem_ctx* c, double* x, const double* xt, const u
                      static_cast<double*>(ws), pcg_max_iter, pcg_tol_rate, ls_max_iter);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : fail_hip(e, "fem_newton_kernel");
+}
+
+int tacex_fem_set_attachment_targets(const float* body_pos, const float* body_quat, const float* offsets, const int32_t* idx,
+                                     double* aim, uint8_t* constrained, double* aim_compact, int B, int A, int V, void* stream) {
+  if (!body_pos || !body_quat || !offsets || !idx || !aim || !constrained) { set_error("tacex_fem_set_attachment_targets: null argument"); return 2; }
+  if (B <= 0 || A <= 0) return 0;
+  hipLaunchKernelGGL(fem_attachment_aim_kernel, dim3((A + 127) / 128, B), dim3(128), 0, (hipStream_t)stream, body_pos, body_quat,
+                     offsets, idx, aim, constrained, aim_compact, A, V);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : fail_hip(e, "fem_attachment_aim_kernel");
 }
 
 int tacex_fem_marker_uv(const double* pos, const int32_t* tri, const double* wgt, double fx, double fy, double cx,

@@ -129,7 +129,7 @@ __global__ __launch_bounds__(128) void fots_marker_kernel(FotsArgs a) {
 
   if (!in_contact) {  // FS:176-179: traj reset, markers = initial positions
     if (active) { out_cur[tid * 2 + 0] = (float)px; out_cur[tid * 2 + 1] = (float)py; }
-    if (tid == 0) tr[0] = 0.0f;
+    if (tid == 0) { tr[0] = 0.0f; tr[7] = 0.0f; }
     return;
   }
 
@@ -184,7 +184,8 @@ __global__ __launch_bounds__(128) void fots_marker_kernel(FotsArgs a) {
   }
   __syncthreads();  // everyone has read the old state
   if (tid == 0) {
-    tr[0] = (float)tlen; tr[1] = t0x; tr[2] = t0y; tr[3] = t0t; tr[4] = tlx; tr[5] = tly; tr[6] = tlt; tr[7] = 0.f;
+    tr[0] = (float)tlen; tr[1] = t0x; tr[2] = t0y; tr[3] = t0t; tr[4] = tlx; tr[5] = tly; tr[6] = tlt;
+    tr[7] = (float)nc;  // contacts found this step (MM:152-166), for parity checks
   }
   if (!active) return;
 

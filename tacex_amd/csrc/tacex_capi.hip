@@ -349,14 +349,14 @@ struct StageTimer {
   }
 };
 
-int tacex_height_map_from_depth(const float* depth_m, float near_m, float far_m, float gelpad_h,
+int tacex_height_map_from_depth(const float* depth_m, double near_m, double far_m, float gelpad_h,
                                 float gelpad_dmin, float* hm_mm, float* frame_min, float* indent_mm,
                                 uint8_t* cam_u8, int B, int H, int W, void* stream) {
   if (!depth_m || !hm_mm || !frame_min) { set_error("tacex_height_map_from_depth: null buffer"); return 2; }
   if (B <= 0) return 0;
-  if (((size_t)H * W) % 4 != 0 && false) { /* handled by the scalar tail */ }
-  HIP_TRY(run_frame_min(depth_m, true, hm_mm, frame_min, indent_mm, cam_u8, B, H * W, near_m, far_m, gelpad_h,
-                        gelpad_dmin, (hipStream_t)stream),
+  // GS:573-574: `clipping_range[i] * 1000` is a Python double product; torch rounds it ONCE to float32 as the scalar operand
+  HIP_TRY(run_frame_min(depth_m, true, hm_mm, frame_min, indent_mm, cam_u8, B, H * W, (float)(near_m * 1000.0), (float)far_m,
+                        (float)(far_m * 1000.0), gelpad_h, gelpad_dmin, (hipStream_t)stream),
           "frame_min_kernel<depth>");
   return 0;
 }
@@ -377,7 +377,7 @@ int tacex_indentation_depth(const float* hm_mm, float gelpad_h, float gelpad_dmi
                             float* indent_mm, int B, int H, int W, void* stream) {
   if (!hm_mm || !frame_min || !indent_mm) { set_error("tacex_indentation_depth: null buffer"); return 2; }
   if (B <= 0) return 0;
-  HIP_TRY(run_frame_min(hm_mm, false, nullptr, frame_min, indent_mm, nullptr, B, H * W, 0.f, 0.f, gelpad_h,
+  HIP_TRY(run_frame_min(hm_mm, false, nullptr, frame_min, indent_mm, nullptr, B, H * W, 0.f, 0.f, 0.f, gelpad_h,
                         gelpad_dmin, (hipStream_t)stream),
           "frame_min_kernel");
   return 0;
@@ -402,6 +402,8 @@ static int chunk_frames(const tacex_taxim_ctx* c, int B) {
   return (int)(((size_t)B + nchunks - 1) / nchunks);  // equal chunks
 }
 
+int tacex_taxim_chunk_frames(const tacex_taxim_ctx* c, int B) { return (c && B > 0) ? chunk_frames(c, B) : 0; }
+
 static int pipeline_impl(tacex_taxim_ctx* c, const float* hm, const float* press, float* frame_min, float* rgb,
                          float* z_out, uint8_t* mask_out, void* ws, int B, unsigned flags, hipStream_t st,
                          float* obs_h = nullptr, void* obs = nullptr, int obs_hh = 0, int obs_w = 0) {
@@ -411,7 +413,7 @@ static int pipeline_impl(tacex_taxim_ctx* c, const float* hm, const float* press
   if (cf >= B) return pipeline_chunk(c, hm, press, frame_min, rgb, z_out, mask_out, ws, B, flags, st, obs_h, obs, obs_hh, obs_w, fp, B <= c->fots_pix_cap ? 0 : -1);
   if (!(flags & TACEX_FLAG_HAVE_FRAME_MIN)) {  // one reduction pass over the whole shard, then chunks
     StageTimer t(c, st, 0);
-    HIP_TRY(run_frame_min(hm, false, nullptr, frame_min, nullptr, nullptr, B, c->H * c->W, 0.f, 0.f, 0.f, 0.f, st),
+    HIP_TRY(run_frame_min(hm, false, nullptr, frame_min, nullptr, nullptr, B, c->H * c->W, 0.f, 0.f, 0.f, 0.f, 0.f, st),
             "frame_min_kernel");
   }
   const size_t npix = (size_t)c->H * c->W;
@@ -451,7 +453,7 @@ static int pipeline_chunk(tacex_taxim_ctx* c, const float* hm, const float* pres
   const bool no_shift = (flags & TACEX_FLAG_NO_SHIFT) != 0;
   if (!(flags & TACEX_FLAG_HAVE_FRAME_MIN)) {
     StageTimer t(c, st, 0);
-    HIP_TRY(run_frame_min(hm, false, nullptr, frame_min, nullptr, nullptr, B, c->H * c->W, 0.f, 0.f, 0.f, 0.f, st),
+    HIP_TRY(run_frame_min(hm, false, nullptr, frame_min, nullptr, nullptr, B, c->H * c->W, 0.f, 0.f, 0.f, 0.f, 0.f, st),
             "frame_min_kernel");
   }
   if (no_shift) {  // S = hm, P = -min(hm): zeros / negated minima need their own (B,) arrays

@@ -42,7 +42,7 @@ struct ShadeParams {
 };
 
 hipError_t run_frame_min(const float* in, bool from_depth, float* hm_out, float* fmin, float* indent,
-                         uint8_t* cam_u8, int B, int npix, float near_m, float far_m, float gelpad_h,
+                         uint8_t* cam_u8, int B, int npix, float near_mm, float far_m, float far_mm, float gelpad_h,
                          float gelpad_dmin, hipStream_t st);
 hipError_t run_indenter_height_map(const float* desc, float* hm, float* fmin, float* indent, int B, int H, int W, float pixmm,
                                    float gel_top_mm, float far_clip_mm, float gelpad_h, float gelpad_dmin, hipStream_t st);

@@ -33,7 +33,7 @@ namespace tacex {
 template <bool FROM_DEPTH>
 __global__ __launch_bounds__(1024) void frame_min_kernel(
     const float* __restrict__ in, float* __restrict__ hm_out, float* __restrict__ fmin_out,
-    float* __restrict__ indent_out, uint8_t* __restrict__ cam_u8, int npix, float near_m, float far_m,
+    float* __restrict__ indent_out, uint8_t* __restrict__ cam_u8, int npix, float nmm, float far_m, float fmm,
     float gelpad_h, float gelpad_dmin) {
   const int b = blockIdx.x;
   const float* src = in + (size_t)b * npix;
@@ -50,9 +50,10 @@ __global__ __launch_bounds__(1024) void frame_min_kernel(
       }
       reinterpret_cast<v4f*>(hm_out + (size_t)b * npix)[i] = v;
       if (cam_u8) {
-        // GS:573-575: ((mm - near*1000) / (far*1000)) * 255 -> uint8 (divides by far, sic)
+        // GS:573-575: ((mm - near*1000) / (far*1000)) * 255 -> uint8 (divides by far, sic).  nmm / fmm are the Python
+        // double products rounded once to float32 on the host (what torch does with a Python scalar operand); the
+        // division is IEEE (hipcc's default correctly rounded f32 divide), so the bytes equal the reference's.
         uchar4 u;
-        float nmm = near_m * 1000.0f, fmm = far_m * 1000.0f;
         u.x = (uint8_t)(((v[0] - nmm) / fmm) * 255.0f);
         u.y = (uint8_t)(((v[1] - nmm) / fmm) * 255.0f);
         u.z = (uint8_t)(((v[2] - nmm) / fmm) * 255.0f);
@@ -68,7 +69,7 @@ __global__ __launch_bounds__(1024) void frame_min_kernel(
       d = isinf(d) ? far_m : d;
       d *= 1000.0f;
       hm_out[(size_t)b * npix + i] = d;
-      if (cam_u8) cam_u8[(size_t)b * npix + i] = (uint8_t)(((d - near_m * 1000.0f) / (far_m * 1000.0f)) * 255.0f);
+      if (cam_u8) cam_u8[(size_t)b * npix + i] = (uint8_t)(((d - nmm) / fmm) * 255.0f);
     }
     m = fminf(m, d);
   }
@@ -812,14 +813,14 @@ static hipError_t dispatch_band(int k, bool first, const BlurArgs& a, hipStream_
 }
 
 hipError_t run_frame_min(const float* in, bool from_depth, float* hm_out, float* fmin, float* indent,
-                         uint8_t* cam_u8, int B, int npix, float near_m, float far_m, float gelpad_h,
+                         uint8_t* cam_u8, int B, int npix, float near_mm, float far_m, float far_mm, float gelpad_h,
                          float gelpad_dmin, hipStream_t st) {
   if (from_depth)
     hipLaunchKernelGGL(frame_min_kernel<true>, dim3(B), dim3(1024), 0, st, in, hm_out, fmin, indent, cam_u8,
-                       npix, near_m, far_m, gelpad_h, gelpad_dmin);
+                       npix, near_mm, far_m, far_mm, gelpad_h, gelpad_dmin);
   else
     hipLaunchKernelGGL(frame_min_kernel<false>, dim3(B), dim3(1024), 0, st, in, hm_out, fmin, indent, cam_u8,
-                       npix, near_m, far_m, gelpad_h, gelpad_dmin);
+                       npix, near_mm, far_m, far_mm, gelpad_h, gelpad_dmin);
   return hipGetLastError();
 }
 

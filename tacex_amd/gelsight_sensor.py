@@ -102,6 +102,20 @@ class GelSightSensor(SensorBase):
             )
         self._camera_depth_m = depth_m
 
+    def set_height_map(self, height_map_mm: torch.Tensor):
+        """Provide the height map (mm, (num_envs, Hc, Wc)) directly instead of a camera depth image: copied into the
+        persistent `output["height_map"]` buffer; cached per-frame minima / indentation depths are invalidated."""
+        hm = self._data.output["height_map"]
+        if tuple(height_map_mm.shape) != tuple(hm.shape):
+            raise RuntimeError(f"height map has shape {tuple(height_map_mm.shape)}, expected {tuple(hm.shape)}")
+        if height_map_mm.data_ptr() != hm.data_ptr():
+            hm.copy_(height_map_mm)
+        self.mark_height_map_dirty()
+
+    def mark_height_map_dirty(self):
+        """Call after writing `output["height_map"]` in place."""
+        self._height_map_version += 1
+
     def set_height_map_source(self, source):
         """Fill the height map from an on-device source (e.g. `IndenterHeightMapSource`) instead of a camera depth image
         (SURVEY 8f n1).  `source.fill(hm, frame_min, indent, gelpad_height, gelpad_to_camera_min_distance)`."""
@@ -131,11 +145,18 @@ class GelSightSensor(SensorBase):
             self._data.output["camera_depth"][env_ids] = 0
         # simulate optical/marker output without indentation, then reset the simulators (reference order,
         # gelsight_sensor.py:182-193: the render happens BEFORE optical_simulator.reset())
+        # Per-env state of envs that are NOT being reset survives, as in the reference: its simulators' reset() only
+        # re-allocate their private indentation buffers (TS:133-135, FS:206-208); the trajectory of an env is cleared by
+        # the marker simulation itself when its indentation depth is 0 (FS:176-177), which holds for `env_ids` here.
         if (self.optical_simulator is not None) and ("tactile_rgb" in self._data.output):
-            self._data.output["tactile_rgb"][:] = self.optical_simulator.optical_simulation()
+            res = self.optical_simulator.optical_simulation()
+            if res.data_ptr() != self._data.output["tactile_rgb"].data_ptr():
+                self._data.output["tactile_rgb"][:] = res
             self.optical_simulator.reset()
         if (self.marker_motion_simulator is not None) and ("marker_motion" in self._data.output):
-            self._data.output["marker_motion"][:] = self.marker_motion_simulator.marker_motion_simulation()
+            res = self.marker_motion_simulator.marker_motion_simulation()
+            if res.data_ptr() != self._data.output["marker_motion"].data_ptr():
+                self._data.output["marker_motion"][:] = res
             self._data.output["init_marker_pos"] = ([0], [0])
             self.marker_motion_simulator.reset()
         self._frame[env_ids] = -self._frame_pending  # frame == 0 once the pending full-batch increments are folded in
@@ -258,7 +279,11 @@ class GelSightSensor(SensorBase):
             return hm
         depth = self._read_camera_depth()
         if depth is None:
-            return self._data.output["height_map"]  # no camera: keep whatever the caller wrote
+            # no camera: the caller writes output["height_map"] itself (set_height_map, or in place).  An in-place write
+            # cannot be seen from here, so every update treats the map as new: the per-frame minimum and the indentation
+            # depth are recomputed (one small reduction kernel) instead of being served from the previous map's cache.
+            self._height_map_version += 1
+            return self._data.output["height_map"]
         hm = self._data.output["height_map"]
         near, far = self.cfg.sensor_camera_cfg.clipping_range
         sim = self._fused_targets()

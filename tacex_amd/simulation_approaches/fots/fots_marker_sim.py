@@ -163,8 +163,10 @@ class FOTSMarkerSimulator(GelSightSimulator):
         return self.marker_data
 
     def reset(self):
+        """fots_marker_sim.py:206-208.  The trajectories are NOT cleared here (the reference does not either): an env's
+        trajectory restarts when the marker simulation sees its indentation depth at 0 (FS:176-177), which the sensor's
+        reset guarantees for the envs being reset; envs still in contact keep their shear / twist origin."""
         self._indentation_depth = torch.zeros((self._num_envs,), device=self._device)
-        self._traj_state.zero_()
 
     def _set_debug_vis_impl(self, debug_vis: bool):
         pass

@@ -362,6 +362,10 @@ class TaximHip:
         _lib.check(self._lib.tacex_taxim_set_fots_taps(ctx.handle, mx.ctypes.data, my.ctypes.data, int(mx.size), _lib.ptr(z_pix),
                                                        _lib.ptr(mask_pix), int(capacity_frames)), "set_fots_taps")
 
+    def chunk_frames(self, shape_hw, num_frames: int) -> int:
+        """Frames per pass of the kernel sequence for a `num_frames` call (Infinity-Cache-sized chunks)."""
+        return int(self._lib.tacex_taxim_chunk_frames(self.context(shape_hw).handle, int(num_frames)))
+
     # -- profiling (bench.py roofline leg) --------------------------------------------------------------------
     def set_profiling(self, shape_hw, enabled: bool):
         ctx = self.context(shape_hw)

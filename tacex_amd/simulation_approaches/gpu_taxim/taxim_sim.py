@@ -143,8 +143,18 @@ class TaximSimulator(GelSightSimulator):
         return self._indentation_depth
 
     def reset(self):
-        self._indentation_depth.zero_()  # in place (taxim_sim.py:141 re-allocates): the sensor shares this buffer
-        self.tactile_rgb_img[:] = self.background_img
+        """taxim_sim.py:133-135: fresh zero indentation buffer, background into the simulator's image buffer.
+
+        Both buffers may be SHARED with the sensor here (they are private copies in the reference): the sensor has
+        already zeroed the indentation depth of exactly the envs being reset (GS:163) and its `tactile_rgb` output keeps
+        the frame rendered just before this call (GS:182-183), so shared buffers are left alone - zeroing / overwriting
+        them for all envs would wipe the state of envs that are still in contact."""
+        if getattr(self.sensor, "_indentation_depth", None) is not self._indentation_depth:
+            self._indentation_depth.zero_()
+        out = getattr(self.sensor, "_data", None)
+        out = out.output.get("tactile_rgb") if out is not None and out.output else None
+        if out is None or out.data_ptr() != self.tactile_rgb_img.data_ptr():
+            self.tactile_rgb_img[:] = self.background_img
         self._frame_min_version = -1
         self._indent_version = -1
         self._deformation_version = -1

@@ -194,7 +194,8 @@ class UipcSim:
     # -- uipc_sim.py:250-252: world.advance(); world.retrieve() ---------------------------------------------------------
     def step(self, max_newton_iter: int | None = None, check_every: int = 4):
         """One backward-Euler step for all envs: x_tilde = x + dt v + dt^2 g, Newton iterations, v = (x - x_n)/dt.
-        Convergence (velocity_tol, uipc_sim.py:62-66) is checked on the host only every `check_every` iterations."""
+        Convergence (velocity_tol, uipc_sim.py:62-66) is decided per env on the device (converged envs return at once from later
+        launches); the host only reads the batch maximum every `check_every` iterations to stop launching."""
         dt = self.cfg.dt
         x_n = self.x.clone()
         self.x_tilde = x_n + dt * self.v + (dt * dt) * self._g
@@ -205,13 +206,14 @@ class UipcSim:
             self._dx = torch.empty((self.num_envs,), dtype=torch.float64, device=self.device)
         self._dx.fill_(float("inf"))
         it = 0
+        tol = float(self.cfg.newton.velocity_tol) * dt
         while it < n_max:
-            x_prev = self.x.clone()
             self.newton_step(_early_exit=True)
             it += 1
             if it % check_every == 0 or it == n_max:
-                dx = (self.x - x_prev).abs().amax().item()
-                if dx / dt <= self.cfg.newton.velocity_tol:
+                # max |dx| of every env's last accepted update is maintained by the kernel itself (B doubles): the host reads
+                # one scalar every `check_every` launches, no copy of the state and no per-iteration sync
+                if float(self._dx.max()) <= tol:
                     break
         self.last_newton_iters = it
         self.v = (self.x - x_n) / dt

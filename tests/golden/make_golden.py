@@ -129,7 +129,7 @@ def fots_case(t, MarkerMotion, seed: int, n: int, steps: int):
     )
     init = np.stack((mm.init_marker_x_pos, mm.init_marker_y_pos), -1).reshape(-1, 2)
     trajs = [[] for _ in range(n)]
-    hms, thetas, outs, indents, ncontacts = [], [], [], [], []
+    hms, thetas, outs, indents, ncontacts, csets = [], [], [], [], [], []
     for s in range(steps):
         # the indenter drifts sideways and (in the middle step, env 1) lifts off -> traj reset path
         hm = torch.roll(hm0, shifts=(2 * s, 3 * s), dims=(1, 2)).clone()
@@ -143,6 +143,7 @@ def fots_case(t, MarkerMotion, seed: int, n: int, steps: int):
         md = np.zeros((n, 2, init.shape[0], 2), np.float32)
         md[:, 0] = init
         nc = []
+        cset = np.zeros((n, init.shape[0]), np.uint8)  # contact SET: markers (row-major j * ncol + i) whose pixel is in the mask
         for e in range(n):
             if indent[e].item() > 0.0:  # fots_marker_sim.py:133-175
                 pts = torch.argwhere(M[e])
@@ -156,6 +157,7 @@ def fots_case(t, MarkerMotion, seed: int, n: int, steps: int):
                     for j in range(mm.num_markers_row):
                         if M[e].numpy()[int(mm.init_marker_y_pos[j, i]), int(mm.init_marker_x_pos[j, i])] == 1.0:
                             c += 1
+                            cset[e, j * mm.num_markers_col + i] = 1
                 nc.append(c)
                 x, y = mm.marker_sim(D[e].cpu().numpy(), M[e].cpu().numpy(), trajs[e])
             else:
@@ -168,12 +170,14 @@ def fots_case(t, MarkerMotion, seed: int, n: int, steps: int):
         outs.append(md)
         indents.append(indent.numpy())
         ncontacts.append(nc)
+        csets.append(cset)
     return {
         "hm": np.stack(hms, 0),
         "theta": np.stack(thetas, 0),
         "indent": np.stack(indents, 0),
         "marker_data": np.stack(outs, 0),
         "n_contacts": np.array(ncontacts, np.int64),
+        "contact_set": np.stack(csets, 0),
         "init_marker_pos": init.astype(np.int64),
         "marker_x_idx": mm.marker_x_idx.astype(np.int64),
         "marker_y_idx": mm.marker_y_idx.astype(np.int64),

@@ -239,3 +239,95 @@ def test_mani_skill_marker_flow_plugin():
     np.testing.assert_allclose(flow, ref, rtol=0, atol=2e-3)  # float32 output buffer of ~300 px values
     assert np.abs(flow[:, 1] - flow[:, 0]).max() > 1.0  # markers really moved
     assert np.abs(flow[0] - flow[2]).max() > 0.5         # per-env flows differ (the reference fills env 0 only)
+
+
+@pytest.mark.parametrize("nu", [0.3, 0.49])
+def test_hip_element_gradient_uniaxial_closed_form(nu):
+    """The HIP element kernel against a CLOSED FORM (not the oracle): F = diag(s,1,1) on the unit right tet gives
+    Pxx = mu (1 - 1/(s^2+3)) s + lambda (s - alpha), Pyy = Pzz = mu (1 - 1/(s^2+3)) + lambda (s - alpha) s with
+    (mu, lambda) = (4/3 mu_L, lambda_L + 5/6 mu_L) of `youngs_poisson(E, nu)`; its slope at s = 1 is Hooke's law."""
+    from tacex_amd.uipc import UipcObject, UipcObjectCfg, UipcSim, UipcSimCfg
+
+    E_mpa = 0.01
+    E = E_mpa * 1e6
+    mu_l, lam_l = E / (2 * (1 + nu)), E * nu / ((1 + nu) * (1 - 2 * nu))
+    mu, lam = 4.0 / 3.0 * mu_l, lam_l + 5.0 / 6.0 * mu_l
+    alpha = 1.0 + 0.75 * mu / lam
+    X = np.array([[0.0, 0, 0], [1, 0, 0], [0, 1, 0], [0, 0, 1]])
+    T = np.array([[0, 1, 2, 3]], dtype=np.int32)
+    stretches = [0.7, 1.0 - 1e-6, 1.0, 1.0 + 1e-6, 1.3]
+    sim = UipcSim(UipcSimCfg(device="cuda:0"), num_envs=len(stretches))
+    cfg = UipcObjectCfg(mesh_points=X, mesh_tets=T)
+    cfg.constitution_cfg.youngs_modulus, cfg.constitution_cfg.poisson_rate = E_mpa, nu
+    UipcObject(cfg, sim)
+    sim.setup_sim()
+    x = torch.from_numpy(np.stack([X * np.array([s, 1.0, 1.0]) for s in stretches])).cuda()
+    _, g, _ = sim.element_terms(x, energy=False, hessian=False)
+    g = g.cpu().numpy()[:, :, 0].reshape(len(stretches), 4, 3)  # (env, vertex, xyz)
+    P = 6.0 * np.stack([g[:, 1], g[:, 2], g[:, 3]], -1)        # Dm = I, vol = 1/6
+    for k, s in enumerate(stretches):
+        pxx = mu * (1 - 1 / (s * s + 3)) * s + lam * (s - alpha)
+        pyy = mu * (1 - 1 / (s * s + 3)) + lam * (s - alpha) * s
+        np.testing.assert_allclose(np.diag(P[k]), [pxx, pyy, pyy], rtol=1e-11, atol=1e-9 * lam_l)
+        assert np.abs(P[k] - np.diag(np.diag(P[k]))).max() <= 1e-9 * lam_l
+    dP = (P[3] - P[1]) / 2e-6
+    assert abs(dP[0, 0] - (lam_l + 2 * mu_l)) <= 1e-5 * (lam_l + 2 * mu_l)  # Hooke: lambda_L + 2 mu_L
+    assert abs(dP[1, 1] - lam_l) <= 1e-5 * (lam_l + 2 * mu_l)              # Hooke: lambda_L
+    assert np.abs(P[2]).max() <= 1e-9 * lam_l                                # rest stability at nu = 0.49
+
+
+def test_attachment_chain_aim_set_constraints_step_vs_oracle():
+    """a20 end to end for B envs with DISTINCT body poses: UipcIsaacAttachments.apply (compute_aim_positions + the animator's
+    is_constrained / aim_position writes, UA:364-428) -> UipcSim.step, against the oracle driven the same way."""
+    from oracle.fem_oracle import FemModel, attachment_aim_positions, box_tet_mesh
+    from tacex_amd.uipc import UipcIsaacAttachments, UipcIsaacAttachmentsCfg, UipcObject, UipcObjectCfg, UipcSim, UipcSimCfg
+
+    P, Tt = box_tet_mesh(4, 5, 2)
+    B = 3
+    sim = UipcSim(UipcSimCfg(device="cuda:0"), num_envs=B)
+    gel = UipcObject(UipcObjectCfg(mesh_points=P, mesh_tets=Tt), sim)
+    sim.setup_sim(constraint_strength_ratio=100.0)
+    sim.cfg.linear_system.max_iter, sim.cfg.linear_system.tol_rate = 200, 1e-4
+    # the "sensor case": a box collider hugging the back face (z = 0) of the gelpad, body frame at its centre
+    size = P.max(0) - P.min(0)
+    body_pos0 = np.array([size[0] / 2, size[1] / 2, -0.001])
+    att = UipcIsaacAttachments(UipcIsaacAttachmentsCfg(), gel, rigid_collider=("box", (size[0] / 2 + 1e-6, size[1] / 2 + 1e-6, 0.001)),
+                               rigid_pos=body_pos0)
+    back = np.where(P[:, 2] < 1e-12)[0]
+    assert sorted(att.attachment_points_idx.tolist()) == sorted(back.tolist())  # exactly the back-face vertices are attached
+    np.testing.assert_allclose(att.attachment_offsets, (P[att.attachment_points_idx] - body_pos0).astype(np.float32), atol=1e-9)
+    # distinct poses: translation + yaw / roll per env
+    ang = np.array([0.0, 0.05, -0.08])
+    quat = np.stack([np.cos(ang / 2), np.sin(ang / 2) * np.array([0, 0, 1.0]), np.zeros(3), np.sin(ang / 2) * np.array([0, 1.0, 0])], -1)
+    quat = quat / np.linalg.norm(quat, axis=1, keepdims=True)
+    pos = body_pos0[None] + np.array([[0, 0, 0], [0.0003, 0, 0.0002], [-0.0002, 0.0004, -0.0003]])
+    aim = att.apply(sim, torch.from_numpy(pos).cuda(), torch.from_numpy(quat).cuda())
+    aim_o = attachment_aim_positions(att.attachment_offsets, pos, quat)
+    assert np.abs(aim.cpu().numpy() - aim_o).max() <= 2e-7 * np.abs(aim_o).max()  # float32 rotation on both sides
+    cons = sim.is_constrained.cpu().numpy()
+    assert (cons[:, att.attachment_points_idx] == 1).all() and cons.sum() == B * len(back)
+    np.testing.assert_array_equal(sim.aim_position[:, att.attachment_points_idx].cpu().numpy(), aim.cpu().numpy())
+    # one backward-Euler step (3 Newton iterations) on the GPU and in the oracle
+    m = FemModel.build(P, Tt, youngs=1e4, strength=100.0)
+    g = np.array(sim.cfg.gravity)
+    sim.newton_kwargs = None
+    x_n = sim.x.clone()
+    sim.x_tilde = x_n + sim.cfg.dt * sim.v + sim.cfg.dt**2 * sim._g
+    for _ in range(3):
+        sim.newton_step()
+    x = sim.x.cpu().numpy()
+    c = np.zeros(len(P)); c[att.attachment_points_idx] = 1.0
+    xt = P + m.dt**2 * g
+    for b in range(B):
+        aim_b = P.copy()
+        aim_b[att.attachment_points_idx] = aim.cpu().numpy()[b]
+        xo = P.copy()
+        for _ in range(3):
+            xo, _ = m.newton_step(xo, xt, c, aim_b, pcg_max_iter=200, pcg_tol_rate=1e-4)
+        assert np.abs(x[b] - xo).max() <= 1e-6 * np.ptp(P), b
+    # and through the public step(): the attached face follows its body, envs differ
+    sim.x.copy_(x_n)
+    sim.step(max_newton_iter=6)
+    d = (sim.x[:, att.attachment_points_idx] - aim).abs().amax().item()
+    assert d < 2e-4
+    assert (sim.x[1] - sim.x[2]).abs().max().item() > 1e-4

@@ -130,3 +130,79 @@ def test_marker_uv_pinhole():
     uv = marker_uv(pos, tri, w)
     p = 0.2 * pos[0, 0] + 0.3 * pos[0, 1] + 0.5 * pos[0, 2]
     np.testing.assert_allclose(uv[0, 0], [340 * p[0] / p[2] + 160, 325 * p[1] / p[2] + 125])
+
+
+# ---- closed-form known answers that do NOT go through the oracle's own formulas ------------------------------------------------
+def _lame(E, nu):
+    return E / (2 * (1 + nu)), E * nu / ((1 + nu) * (1 - 2 * nu))
+
+
+def _unit_tet():
+    X = np.array([[0.0, 0, 0], [1, 0, 0], [0, 1, 0], [0, 0, 1]])
+    return X, np.array([[0, 1, 2, 3]], dtype=np.int32)
+
+
+@pytest.mark.parametrize("nu", [0.3, 0.49])
+def test_uniaxial_stretch_matches_linear_elasticity_closed_form(nu):
+    """Pins the `ElasticModuli.youngs_poisson(E, nu)` -> (mu, lambda) mapping (uipc_object.py:448-452) independently of the
+    oracle: for F = diag(s, 1, 1) the Stable Neo-Hookean first Piola stress must linearise at s = 1 to HOOKE's law with the Lame
+    parameters of (E, nu): dPxx/ds = lambda_L + 2 mu_L, dPyy/ds = dPzz/ds = lambda_L (Smith, de Goes, Kim 2018, section 3.4:
+    that is what the re-parameterisation mu = 4/3 mu_L, lambda = lambda_L + 5/6 mu_L is for).  A wrong mapping (e.g. passing the
+    Lame parameters through unchanged) is off by 17 % in the first and by 5/6 mu_L in the second."""
+    E = 1e4
+    mu_l, lam_l = _lame(E, nu)
+    X, T = _unit_tet()
+    m = FemModel.build(X, T, youngs=E, poisson=nu)
+    # nodal forces of the single tet under F = diag(s,1,1): f = -vol P Dm^-T; for the unit right tet Dm = I, vol = 1/6, so the
+    # force on vertex 1 (the +x one) is -(1/6) P[:,0] etc.
+    def piola(s):
+        x = X * np.array([s, 1.0, 1.0])
+        g = m.element_gradient(x)[0].reshape(4, 3)  # d(vol Psi)/dx_v
+        return 6.0 * np.stack([g[1], g[2], g[3]], -1)  # P = 6 * [g1 g2 g3] for Dm = I
+    h = 1e-6
+    dP = (piola(1 + h) - piola(1 - h)) / (2 * h)
+    assert abs(dP[0, 0] - (lam_l + 2 * mu_l)) <= 1e-6 * (lam_l + 2 * mu_l)
+    assert abs(dP[1, 1] - lam_l) <= 1e-6 * (lam_l + 2 * mu_l) and abs(dP[2, 2] - lam_l) <= 1e-6 * (lam_l + 2 * mu_l)
+    assert np.abs(dP - np.diag(np.diag(dP))).max() <= 1e-6 * lam_l
+    # finite stretch: closed form written out by hand for F = diag(s,1,1) (I_C = s^2 + 2, J = s, cof F = diag(1, s, s))
+    mu, lam = 4.0 / 3.0 * mu_l, lam_l + 5.0 / 6.0 * mu_l
+    alpha = 1.0 + 0.75 * mu / lam
+    for s in (0.7, 1.0, 1.3):
+        P = piola(s)
+        pxx = mu * (1 - 1 / (s * s + 3)) * s + lam * (s - alpha)
+        pyy = mu * (1 - 1 / (s * s + 3)) + lam * (s - alpha) * s
+        np.testing.assert_allclose(np.diag(P), [pxx, pyy, pyy], rtol=1e-12, atol=1e-9 * lam_l)
+    # rest stability (the point of the "stable" model): zero stress at F = I even at nu = 0.49
+    assert np.abs(piola(1.0)).max() <= 1e-10 * lam_l
+
+
+def test_simple_shear_closed_form():
+    """F = I + g e_x e_y^T (simple shear): I_C = 3 + g^2, J = 1 -> Pxy = mu (1 - 1/(4 + g^2)) g, and the small-strain shear modulus
+    dPxy/dg at g = 0 is mu (1 - 1/4) = 3/4 * 4/3 mu_L = mu_L = E / (2 (1 + nu))."""
+    E, nu = 1e4, 0.49
+    mu_l, lam_l = _lame(E, nu)
+    X, T = _unit_tet()
+    m = FemModel.build(X, T, youngs=E, poisson=nu)
+    def pxy(g):
+        x = X.copy()
+        x[:, 0] += g * X[:, 1]
+        gr = m.element_gradient(x)[0].reshape(4, 3)
+        return 6.0 * gr[2, 0]  # P[0,1] = d(vol Psi)/dx_2 (x component) * 6
+    h = 1e-6
+    assert abs((pxy(h) - pxy(-h)) / (2 * h) - mu_l) <= 1e-6 * mu_l
+    mu = 4.0 / 3.0 * mu_l
+    for g in (0.1, 0.5):
+        # cof F = [[1,0,0],[-g,1,0],[0,0,1]] for simple shear: its (x,y) entry is 0, so Pxy has no volumetric part
+        assert abs(pxy(g) - mu * (1 - 1 / (4 + g * g)) * g) <= 1e-11 * mu
+
+
+def test_attachment_aim_positions_closed_form():
+    """uipc_attachments.py:387-428: aim = R(q) offset + p.  90 degree yaw about z maps (1,0,0) -> (0,1,0)."""
+    from oracle.fem_oracle import attachment_aim_positions
+
+    off = np.array([[1.0, 0, 0], [0, 2.0, 0], [0, 0, 3.0]], np.float32)
+    q = np.array([[np.cos(np.pi / 4), 0, 0, np.sin(np.pi / 4)], [1, 0, 0, 0]], np.float32)
+    p = np.array([[10.0, 20, 30], [1, 2, 3]], np.float32)
+    aim = attachment_aim_positions(off, p, q)
+    np.testing.assert_allclose(aim[0], [[10, 21, 30], [8, 20, 30], [10, 20, 33]], atol=1e-5)
+    np.testing.assert_allclose(aim[1], off + p[1], atol=1e-6)
