@@ -24,7 +24,8 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, name), f"{name} declared in include/tacex_hip.h but not exported"
         assert name in _lib.SIGNATURES, f"{name} has no ctypes signature in tacex_amd/_lib.py"
     assert sorted(_lib.SIGNATURES) == declared, "ctypes table and header disagree"
-    assert lib.tacex_abi_version() == 1
+    hdr = int(re.search(r"#define\s+TACEX_ABI_VERSION\s+(\d+)", (REPO / "include" / "tacex_hip.h").read_text()).group(1))
+    assert lib.tacex_abi_version() == hdr == _lib.ABI_VERSION
 
 
 def test_argument_validation_needs_no_gpu():
