@@ -1,0 +1,24 @@
+#!/bin/bash
+# One GPU-box round trip: parity tests, the driver's bench command, a rocprofv3 kernel-trace of the headline config.
+# usage: scripts/gpu_round.sh <tag> [tests|bench|prof|pmc ...]   (default: tests bench prof)
+TAG=${1:-r02}; shift
+STEPS=${@:-tests bench prof}
+OUT=$GRAFT_REPO_ROOT/gpurun_out/$TAG
+mkdir -p $OUT
+cd $GRAFT_REPO_ROOT
+for s in $STEPS; do
+  case $s in
+    tests) timeout 1500 python -m pytest tests -m gpu -x -q > $OUT/pytest_gpu.log 2>&1; echo "pytest rc=$?" | tee -a $OUT/pytest_gpu.log; tail -5 $OUT/pytest_gpu.log ;;
+    bench) timeout 900 python bench.py > $OUT/bench.json 2> $OUT/bench.err; echo "bench rc=$?"; tail -c 600 $OUT/bench.err; head -c 1500 $OUT/bench.json ;;
+    benchq) timeout 600 python bench.py --no-sweep --no-cpu-baseline > $OUT/bench_quick.json 2> $OUT/bench_quick.err; echo "benchq rc=$?"; head -c 1200 $OUT/bench_quick.json ;;
+    prof) (cd /tmp && export TMPDIR=/tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -- python3 $GRAFT_REPO_ROOT/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-sweep > $OUT/prof.log 2>&1; echo "prof rc=$?") ;;
+    pmc) (cd /tmp && export TMPDIR=/tmp
+          timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-sweep --no-roofline > $OUT/pmc_fetch.log 2>&1; echo "pmc fetch rc=$?"
+          timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-sweep --no-roofline > $OUT/pmc_write.log 2>&1; echo "pmc write rc=$?") ;;
+    pmcsq) (cd /tmp && export TMPDIR=/tmp
+          timeout 600 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS --output-format csv -d $OUT/pmc_sq -- python3 $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-sweep --no-roofline > $OUT/pmc_sq.log 2>&1; echo "pmc sq rc=$?") ;;
+  esac
+done
+# keep the merged-back payload small: kernel stats + counter csvs only
+find $OUT -name "*.db" -delete 2>/dev/null; find $OUT -name "*_agent_info.csv" -delete 2>/dev/null
+du -sh $OUT

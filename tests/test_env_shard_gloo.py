@@ -4,6 +4,8 @@ import subprocess
 import sys
 import textwrap
 
+import pytest
+
 from conftest import REPO
 
 WORKER = textwrap.dedent(
@@ -55,3 +57,49 @@ def test_two_rank_gather_over_gloo(tmp_path):
     for rank, (p, o) in enumerate(zip(procs, outs)):
         assert p.returncode == 0, f"rank {rank} failed:\n{o}"
         assert f"rank {rank} ok" in o
+
+
+@pytest.mark.gpu
+def test_rccl_observation_gather_single_rank_child_process(tmp_path):
+    """RCCL smoke on the GPU box (the 8-GPU run must not also be the first RCCL run): a FRESH child process joins a 1-rank
+    `nccl` (= RCCL) group and drives five bench-style steps through ObservationGather.pack_all() / gather_async(); the
+    gathered views must equal the packed inputs, including the mixed uint8 / float32 byte layout."""
+    import os
+    import socket
+    import subprocess
+    import sys
+
+    from conftest import REPO
+
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    script = tmp_path / "rccl_smoke.py"
+    script.write_text(
+        "import os, sys, torch\n"
+        f"sys.path.insert(0, {str(REPO)!r})\n"
+        "import torch.distributed as dist\n"
+        "from bench import Rig\n"
+        "from tacex_amd.env_shard import init_from_env\n"
+        "shard = init_from_env(8, backend='nccl')\n"
+        "assert dist.is_initialized() and dist.get_backend() == 'nccl' and shard.world_size == 1\n"
+        "torch.cuda.set_device(0)\n"
+        "rig = Rig(8, 240, 320, 2, True, 'cuda:0', shard.world_size, seed=3)\n"
+        "assert not rig.obs._alias  # a real collective fills `full`, not an alias of the send buffer\n"
+        "for i in range(5):\n"
+        "    rig.step(i)\n"
+        "rig.finish()\n"
+        "torch.cuda.synchronize()\n"
+        "v = rig.obs.views()\n"
+        "for k, s in enumerate(rig.sensors):\n"
+        "    o = s._data.output\n"
+        "    assert torch.equal(v[f'rgb32_{k}'], o['tactile_rgb_obs']), 'rgb32'\n"
+        "    assert v[f'rgb32_{k}'].dtype == torch.uint8 and float(v[f'rgb32_{k}'].float().mean()) > 1.0\n"
+        "    assert torch.equal(v[f'markers_{k}'], o['marker_motion']), 'markers'\n"
+        "    assert torch.equal(v[f'indent_{k}'][:, 0], s.indentation_depth), 'indent'\n"
+        "dist.barrier(); dist.destroy_process_group()\n"
+        "print('RCCL_SMOKE_OK')\n")
+    env = dict(os.environ, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+               TACEX_FORCE_DIST="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "RCCL_SMOKE_OK" in r.stdout, (r.stdout[-1500:], r.stderr[-3000:])
