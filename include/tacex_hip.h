@@ -193,8 +193,10 @@ int tacex_resize_bilinear_aa_nhwc(const float* src_dev, int src_h, int src_w, fl
                                                     (recommended for down-sampling); NULL = single pass */,
                                   void* stream);
 
-/* Ablation / test hook: 1 (default) = trailing small-kernel levels + shading run as ONE fused LDS-tiled kernel where a
- * tuned instantiation exists (320x240, 640x480); 0 = every level as its own kernel + separate shade kernel. */
+/* Ablation / test hook: 1 (default) = trailing small-kernel levels + shading run as ONE fused kernel where a tuned
+ * instantiation exists (320x240, 640x480): the wave-autonomous streaming kernel (taxim_stream.hip) for plain renders, the
+ * LDS-tiled kernel (taxim_tail.hip) when the full deformed-gel / mask frames are requested; 2 = always the LDS-tiled kernel;
+ * 0 = every level as its own kernel + separate shade kernel. */
 int tacex_taxim_set_fused_tail(tacex_taxim_ctx* ctx, int enabled);
 
 /* Frames one pass of the kernel sequence covers for a call with num_frames frames: large shards are walked in chunks whose

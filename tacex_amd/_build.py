@@ -12,7 +12,7 @@ CSRC = PKG / "csrc"
 INCLUDE = PKG.parent / "include"
 LIB = PKG / "libtacex_hip.so"
 STAMP = PKG / "libtacex_hip.so.stamp"
-SOURCES = ["taxim_kernels.hip", "taxim_mfma.hip", "taxim_tail.hip", "taxim_shadow.hip", "fots_kernels.hip", "fem_kernels.hip", "tacex_capi.hip"]
+SOURCES = ["taxim_kernels.hip", "taxim_mfma.hip", "taxim_tail.hip", "taxim_stream.hip", "taxim_shadow.hip", "fots_kernels.hip", "fem_kernels.hip", "tacex_capi.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=fast", "-Wno-unused-result"]
 # A/B hook for kernel tuning macros, e.g. TACEX_EXTRA_HIPCC_FLAGS="-DTACEX_MFMA_CH=2" (part of the build digest)
 FLAGS += os.environ.get("TACEX_EXTRA_HIPCC_FLAGS", "").split()

@@ -44,6 +44,7 @@ struct tacex_taxim_ctx {
   int n_levels = 0;
   int n_fused = 0;       // trailing levels handled by the fused tail kernel (+ shading)
   bool use_tail = true;
+  bool use_stream = true;  // prefer the streaming tail where it exists (tacex_taxim_set_fused_tail(ctx, 2) forces the tiled one)
   float contact_scale = 0.4f;
   LevelDesc levels[TACEX_MAX_LEVELS];
   ShadeParams shade;
@@ -56,6 +57,13 @@ struct tacex_taxim_ctx {
   uint8_t* fots_pix_m = nullptr;    // (cap, M) contact mask at the marker pixels
   int fots_pix_cap = 0;
   ObsTables obs_tab{};   // filter tables of the last policy-observation size asked for (built on first use)
+  // host copies of the row / column filters (the streaming tail's per-row tables are derived from them)
+  std::vector<int> obs_ylo_h, obs_ycnt_h, obs_xlo_h, obs_xcnt_h;
+  std::vector<float> obs_wy_h;
+  // streaming tail: geometry + per-(observation size, segment count) tables, marker pixels as a CSR over rows
+  struct StreamObsPlan { int oh, ow, nseg; StreamPlan plan; };
+  std::vector<StreamObsPlan> stream_plans;
+  const int* mk_row_ptr = nullptr; const int* mk_x = nullptr; const int* mk_id = nullptr;
   std::vector<void*> allocs;
   // profiling
   bool profiling = false;
@@ -231,6 +239,7 @@ static void obs_axis_table(int n_in, int n_out, int k, std::vector<int>& lo, std
 
 static int ensure_obs_tables(tacex_taxim_ctx* c, int oh, int ow) {
   if (c->obs_tab.oh == oh && c->obs_tab.ow == ow) return 0;
+  HIP_TRY(hipSetDevice(c->device), "hipSetDevice");
   ObsTables t{};
   t.oh = oh; t.ow = ow;
   t.ky = 2 * (int)ceilf((float)c->H / oh) + 2;
@@ -238,6 +247,7 @@ static int ensure_obs_tables(tacex_taxim_ctx* c, int oh, int ow) {
   std::vector<int> lo, cnt; std::vector<float> sum, w;
   int *dlo, *dcnt; float *dsum, *dw;
   obs_axis_table(c->H, oh, t.ky, lo, cnt, sum, w);
+  c->obs_ylo_h = lo; c->obs_ycnt_h = cnt; c->obs_wy_h = w;
   if (int rc = upload(c, lo.data(), lo.size(), &dlo)) return rc;
   if (int rc = upload(c, cnt.data(), cnt.size(), &dcnt)) return rc;
   if (int rc = upload(c, sum.data(), sum.size(), &dsum)) return rc;
@@ -245,6 +255,7 @@ static int ensure_obs_tables(tacex_taxim_ctx* c, int oh, int ow) {
   t.ylo = dlo; t.ycnt = dcnt; t.ysum = dsum; t.wy = dw;
   t.ymax = *std::max_element(cnt.begin(), cnt.end());
   obs_axis_table(c->W, ow, t.kx, lo, cnt, sum, w);
+  c->obs_xlo_h = lo; c->obs_xcnt_h = cnt;
   if (int rc = upload(c, lo.data(), lo.size(), &dlo)) return rc;
   if (int rc = upload(c, cnt.data(), cnt.size(), &dcnt)) return rc;
   if (int rc = upload(c, sum.data(), sum.size(), &dsum)) return rc;
@@ -252,6 +263,77 @@ static int ensure_obs_tables(tacex_taxim_ctx* c, int oh, int ow) {
   t.xlo = dlo; t.xcnt = dcnt; t.xsum = dsum; t.wx = dw;
   t.xmax = *std::max_element(cnt.begin(), cnt.end());
   c->obs_tab = t;
+  return 0;
+}
+
+// Streaming-tail plan for B frames (+ an optional policy observation of oh x ow): strip / segment geometry and, for the
+// observation, the per-frame-row tables the kernel walks (which <= 3 observation rows a frame row feeds, with which weights)
+// plus the block geometry of the partial sums.  Cached per (oh, ow, nseg); obs_ready = false when the filters do not fit
+// (a frame row feeding more than 3 observation rows, i.e. down-sampling factors below 2).
+static int stream_plan(tacex_taxim_ctx* c, int n_fused, int B, int oh, int ow, const StreamPlan** out) {
+  const int k0 = c->levels[c->n_levels - n_fused].kw;
+  int nstrips = 0, strip_w = 0;
+  if (!stream_geometry(n_fused, k0, c->W, &nstrips, &strip_w)) { set_error("no streaming tail for this level set"); return 1; }
+  const int nseg = stream_segments(B, nstrips, c->H, 0);
+  for (auto& e : c->stream_plans)
+    if (e.oh == oh && e.ow == ow && e.nseg == nseg) {
+      e.plan.mk_row_ptr = c->mk_row_ptr; e.plan.mk_x = c->mk_x; e.plan.mk_id = c->mk_id; e.plan.n_markers = c->fots_taps.n_markers;
+      *out = &e.plan;
+      return 0;
+    }
+  StreamPlan p{};
+  p.nstrips = nstrips; p.strip_w = strip_w; p.nseg = nseg; p.seg_rows = (c->H + nseg - 1) / nseg;
+  if (oh > 0 && ow > 0) {
+    if (int rc = ensure_obs_tables(c, oh, ow)) return rc;
+    const int H = c->H, W = c->W, ky = c->obs_tab.ky;
+    std::vector<int> o0(H), oa(nseg), ob(nseg), q0(nstrips), nq(nstrips);
+    std::vector<float> rw((size_t)H * 3, 0.0f);
+    bool ok = true;
+    for (int r = 0; r < H && ok; ++r) {
+      int o = 0;
+      while (o < oh && r >= c->obs_ylo_h[o] + c->obs_ycnt_h[o]) ++o;
+      o0[r] = o;
+      for (int k = 0; k < 3 && o + k < oh; ++k)
+        if (r >= c->obs_ylo_h[o + k] && r < c->obs_ylo_h[o + k] + c->obs_ycnt_h[o + k])
+          rw[(size_t)r * 3 + k] = c->obs_wy_h[(size_t)(o + k) * ky + (r - c->obs_ylo_h[o + k])];
+      if (o + 3 < oh && r >= c->obs_ylo_h[o + 3]) ok = false;  // a 4th observation row overlaps this frame row
+      if (r > 0 && o0[r] < o0[r - 1]) ok = false;
+    }
+    int nrows = 0, ncols = 0;
+    for (int g = 0; g < nseg && ok; ++g) {
+      const int r0 = g * p.seg_rows, r1 = std::min(H, r0 + p.seg_rows);
+      oa[g] = o0[r0];
+      int b = oa[g];
+      while (b + 1 < oh && c->obs_ylo_h[b + 1] < r1) ++b;
+      ob[g] = std::min(b, oh - 1);
+      if (oa[g] >= oh) ok = false;
+      nrows = std::max(nrows, ob[g] - oa[g] + 1);
+    }
+    for (int s2 = 0; s2 < nstrips && ok; ++s2) {
+      const int vx0 = s2 * strip_w, vx1 = std::min(W, vx0 + strip_w);
+      int a = 0;
+      while (a < ow && c->obs_xlo_h[a] + c->obs_xcnt_h[a] <= vx0) ++a;
+      int b = a;
+      while (b + 1 < ow && c->obs_xlo_h[b + 1] < vx1) ++b;
+      if (a >= ow) ok = false;
+      q0[s2] = a; nq[s2] = b - a + 1;
+      ncols = std::max(ncols, nq[s2]);
+    }
+    if (ok) {
+      int *d_o0, *d_oa, *d_ob, *d_q0, *d_nq; float* d_rw;
+      if (int rc = upload(c, o0.data(), o0.size(), &d_o0)) return rc;
+      if (int rc = upload(c, rw.data(), rw.size(), &d_rw)) return rc;
+      if (int rc = upload(c, oa.data(), oa.size(), &d_oa)) return rc;
+      if (int rc = upload(c, ob.data(), ob.size(), &d_ob)) return rc;
+      if (int rc = upload(c, q0.data(), q0.size(), &d_q0)) return rc;
+      if (int rc = upload(c, nq.data(), nq.size(), &d_nq)) return rc;
+      p.obs = c->obs_tab; p.obs_row_o0 = d_o0; p.obs_row_w = d_rw; p.obs_seg_oa = d_oa; p.obs_seg_ob = d_ob;
+      p.obs_strip_q0 = d_q0; p.obs_strip_nq = d_nq; p.obs_nrows = nrows; p.obs_ncols = ncols; p.obs_ready = true;
+    }
+  }
+  p.mk_row_ptr = c->mk_row_ptr; p.mk_x = c->mk_x; p.mk_id = c->mk_id; p.n_markers = c->fots_taps.n_markers;
+  c->stream_plans.push_back({oh, ow, nseg, p});
+  *out = &c->stream_plans.back().plan;
   return 0;
 }
 
@@ -476,6 +558,29 @@ static int pipeline_chunk(tacex_taxim_ctx* c, const float* hm, const float* pres
             "blur level");
     src = dst;
   }
+  if (n_fused > 0 && c->use_stream && rgb && !z_out && !mask_out && stream_supported(n_fused, c->levels[c->n_levels - n_fused].kw, c->H, c->W)) {
+    // trailing small-kernel levels (+ restores), shading, observation and FOTS by-products: wave-autonomous streaming kernel
+    StageTimer t(c, st, c->n_levels + 2);
+    const bool want_obs = obs_h && obs;
+    const StreamPlan* plan = nullptr;
+    if (int rc = stream_plan(c, n_fused, B, want_obs ? obs_hh : 0, want_obs ? obs_w : 0, &plan)) return rc;
+    const size_t obs_scratch_floats = (size_t)B * (size_t)(c->H * obs_w > obs_hh * c->W ? c->H * obs_w : obs_hh * c->W) * 3;
+    const bool fuse_obs = want_obs && plan->obs_ready &&
+                          (size_t)B * plan->nstrips * plan->nseg * plan->obs_nrows * plan->obs_ncols * 3 <= obs_scratch_floats;
+    const bool pix = frame0 >= 0 && c->fots_pix_z && c->mk_row_ptr;
+    HIP_TRY(run_stream_tail(c->levels, c->n_levels, n_fused, src, hm, c->gel_dev, sa, sb, pd, &c->shade, rgb, B, c->H, c->W,
+                            c->contact_scale, *plan, fuse_obs ? obs_h : nullptr, fots_part,
+                            (int)(tail_tiles_per_frame(c->H, c->W) * kTailWavesPerTile),
+                            pix ? c->fots_pix_z + (size_t)frame0 * c->fots_taps.n_markers : nullptr,
+                            pix ? c->fots_pix_m + (size_t)frame0 * c->fots_taps.n_markers : nullptr, st),
+            "taxim_stream_kernel");
+    if (fuse_obs) {
+      HIP_TRY(run_obs_finish_stream(obs_h, obs, obs_u8, *plan, B, st), "obs_finish_stream_kernel");
+    } else if (want_obs) {
+      if (int rc = resize_obs(c, rgb, obs_h, obs, obs_u8, obs_hh, obs_w, B, st)) return rc;
+    }
+    return 0;
+  }
   if (n_fused > 0) {
     // trailing small-kernel levels (+ restores) and the shading in one LDS-tiled kernel
     StageTimer t(c, st, c->n_levels + 2);
@@ -571,6 +676,24 @@ int tacex_taxim_set_fots_taps(tacex_taxim_ctx* c, const int32_t* marker_x, const
   int *dt = nullptr, *dc = nullptr;
   if (int rc = upload(c, tile.data(), tile.size(), &dt)) return rc;
   if (int rc = upload(c, cnt.data(), cnt.size(), &dc)) return rc;
+  {  // the same markers as a CSR over frame rows (streaming tail)
+    std::vector<int> ptr(c->H + 1, 0), mx, mid;
+    for (int m = 0; m < n_markers; ++m)
+      if (marker_x[m] >= 0 && marker_x[m] < c->W && marker_y[m] >= 0 && marker_y[m] < c->H) ++ptr[marker_y[m] + 1];
+    for (int y = 0; y < c->H; ++y) ptr[y + 1] += ptr[y];
+    mx.resize(ptr[c->H] > 0 ? ptr[c->H] : 1); mid.resize(mx.size());
+    std::vector<int> fill(ptr.begin(), ptr.end() - 1);
+    for (int m = 0; m < n_markers; ++m)
+      if (marker_x[m] >= 0 && marker_x[m] < c->W && marker_y[m] >= 0 && marker_y[m] < c->H) {
+        const int e = fill[marker_y[m]]++;
+        mx[e] = marker_x[m]; mid[e] = m;
+      }
+    int *dp = nullptr, *dx = nullptr, *di = nullptr;
+    if (int rc = upload(c, ptr.data(), ptr.size(), &dp)) return rc;
+    if (int rc = upload(c, mx.data(), mx.size(), &dx)) return rc;
+    if (int rc = upload(c, mid.data(), mid.size(), &di)) return rc;
+    c->mk_row_ptr = dp; c->mk_x = dx; c->mk_id = di;
+  }
   c->fots_taps.mk_tile = dt; c->fots_taps.mk_cnt = dc; c->fots_taps.n_markers = n_markers;
   c->fots_pix_z = z_pix_dev; c->fots_pix_m = mask_pix_dev; c->fots_pix_cap = capacity_frames;
   return 0;
@@ -605,6 +728,7 @@ int tacex_taxim_render_obs(tacex_taxim_ctx* c, const float* hm, const float* pre
 int tacex_taxim_set_fused_tail(tacex_taxim_ctx* c, int enabled) {
   if (!c) { set_error("null ctx"); return 2; }
   c->use_tail = enabled != 0;
+  c->use_stream = enabled == 1;
   return 0;
 }
 

@@ -93,6 +93,30 @@ hipError_t run_obs_to_u8(const float* src, uint8_t* dst, size_t n, hipStream_t s
 size_t obs_part_floats(int H, int W, int B, int nry, int ncx);
 bool obs_fusable(const ObsTables& t, int H, int W, int n_fused, int k0);  // geometry the fused tail reduction is compiled for
 
+// streaming fused tail (taxim_stream.hip): wave-autonomous line-buffer pipeline, the default where an instantiation exists
+constexpr int kStreamMaxLevels = 5;
+constexpr int kStreamMaxSeg = 8;
+struct StreamPlan {
+  int nstrips = 0, strip_w = 0, nseg = 0, seg_rows = 0;
+  // policy observation of one (oh, ow, nseg): device tables, valid when obs_ready
+  bool obs_ready = false;
+  ObsTables obs{};
+  const int* obs_row_o0 = nullptr; const float* obs_row_w = nullptr;
+  const int* obs_strip_q0 = nullptr; const int* obs_strip_nq = nullptr;
+  const int* obs_seg_oa = nullptr; const int* obs_seg_ob = nullptr;
+  int obs_nrows = 0, obs_ncols = 0;
+  // FOTS marker pixels as a CSR over frame rows (device), nullptr when no taps are set
+  const int* mk_row_ptr = nullptr; const int* mk_x = nullptr; const int* mk_id = nullptr; int n_markers = 0;
+};
+bool stream_supported(int n_fused, int k0, int H, int W);
+bool stream_geometry(int n_fused, int k0, int W, int* nstrips, int* strip_w);
+int stream_segments(int B, int nstrips, int H, int sum_r);
+hipError_t run_stream_tail(const LevelDesc* lv, int n_levels, int n_fused, const float* zin, const float* hm, const float* gel,
+                           const float* sa, const float* sb, const float* pd, const ShadeParams* sp, float* rgb, int B, int H, int W,
+                           float contact_scale, const StreamPlan& plan, float* obs_part, FotsReduce* fots_part, int fots_stride,
+                           float* pix_z, uint8_t* pix_m, hipStream_t st);
+hipError_t run_obs_finish_stream(const float* part, void* obs, bool u8, const StreamPlan& plan, int B, hipStream_t st);
+
 // thread-local error string (tacex_last_error)
 void set_error(const char* fmt, ...);
 int fail_hip(hipError_t e, const char* what);

@@ -64,7 +64,13 @@ def gen_marker_weight(marker_pts_xy: np.ndarray, surface_pts: np.ndarray, triang
     p2 = pts[:, :2]
     idx, wgt = [], []
     for i in range(p2.shape[0]):
-        cand = face_idx[i].tolist()
+        # faces seen edge-on from the camera (side walls of the pad among the 4 nearest) have no barycentric coordinates in
+        # the image plane: the reference's np.linalg.inv raises there (VT:300-303); they are skipped instead
+        cand = [f for f in face_idx[i].tolist()
+                if abs(np.linalg.det(np.stack([surface_pts[triangles[f]][1, :2] - surface_pts[triangles[f]][0, :2],
+                                               surface_pts[triangles[f]][2, :2] - surface_pts[triangles[f]][0, :2]], axis=1))) > 1e-18]
+        if not cand:
+            raise RuntimeError(f"marker {i}: all nearest surface faces are edge-on to the camera")
         for fid in cand:
             p0, p1, q2 = surface_pts[triangles[fid]][:, :2]
             A = np.stack([p1 - p0, q2 - p0], axis=1)

@@ -331,10 +331,12 @@ class TaximHip:
 
     __call__ = render
 
-    def set_fused_tail(self, shape_hw, enabled: bool):
-        """Ablation hook: run every pyramid level as its own kernel (False) or use the fused tail kernel (True, default)."""
+    def set_fused_tail(self, shape_hw, enabled):
+        """Ablation hook: 0 / False = every pyramid level as its own kernel + separate shade; 1 / True = fused tail (default:
+        streaming kernel for plain renders, LDS-tiled kernel when full deformed-gel / mask frames are requested); 2 = always the
+        LDS-tiled kernel."""
         ctx = self.context(shape_hw)
-        _lib.check(self._lib.tacex_taxim_set_fused_tail(ctx.handle, 1 if enabled else 0), "set_fused_tail")
+        _lib.check(self._lib.tacex_taxim_set_fused_tail(ctx.handle, int(enabled)), "set_fused_tail")
 
     # -- FOTS contact statistics as a by-product of the render (fused tail only) -------------------------------------
     def fots_partials_per_env(self, shape_hw) -> int:

@@ -243,3 +243,68 @@ def test_mfma_and_valu_band_kernels_agree(calib_dir, golden_dir, tmp_path):
         np.testing.assert_array_equal(outs[key][1], outs["01"][1])
         assert np.abs(outs[key][0] - outs["01"][0]).max() <= 2e-6
         assert np.abs(outs[key][0] - g["Z"]).max() <= 1e-5
+
+
+@pytest.mark.parametrize("shape,segs", [((240, 320), "0"), ((240, 320), "3"), ((240, 320), "8"), ((480, 640), "0"), ((480, 640), "5")])
+def test_streaming_tail_matches_tiled_tail(calib_dir, tmp_path, shape, segs):
+    """The wave-autonomous streaming tail (taxim_stream.hip, default) against the LDS-tiled tail (taxim_tail.hip) through the
+    sensor boundary: RGB bit-equal (same summation order of every level, same shading code), uint8 / float policy observation
+    to round-off (different partial-sum tiling), FOTS markers bit-equal (marker-pixel values and integer contact statistics
+    are the same numbers).  Vertical segmentation (TACEX_STREAM_SEGS, read once per process) must not change a bit of RGB:
+    strips / segments only differ in how much warm-up they recompute."""
+    import os
+    import subprocess
+    import sys
+
+    from conftest import REPO
+
+    H, W = shape
+    script = tmp_path / "stream_run.py"
+    script.write_text(
+        "import sys, numpy as np, torch\n"
+        f"sys.path.insert(0, {str(REPO)!r})\n"
+        "from tacex_amd import GelSightSensor, GelSightSensorCfg\n"
+        "from tacex_amd.simulation_approaches.fots import FOTSMarkerSimulatorCfg\n"
+        "from tacex_amd.simulation_approaches.gpu_taxim import TaximSimulatorCfg\n"
+        "from tacex_amd.utils.synthetic import synthetic_depth_maps\n"
+        f"H, W, n = {H}, {W}, 6\n"
+        "mode = int(sys.argv[2])\n"
+        "res = {}\n"
+        "for dt in ('uint8', 'float32'):\n"
+        "    cfg = GelSightSensorCfg(num_envs=n, sensor_camera_cfg=GelSightSensorCfg.SensorCameraCfg(resolution=(W, H), clipping_range=(0.024, 0.029)),\n"
+        "        data_types=['tactile_rgb', 'height_map', 'marker_motion'],\n"
+        f"        optical_sim_cfg=TaximSimulatorCfg(calib_folder_path={str(calib_dir)!r}, gelpad_height=0.0045, gelpad_to_camera_min_distance=0.024,\n"
+        "            tactile_img_res=(W, H), device='cuda:0', policy_obs_res=(32, 32), policy_obs_dtype=dt),\n"
+        "        marker_motion_sim_cfg=FOTSMarkerSimulatorCfg(tactile_img_res=(W, H), device='cuda:0',\n"
+        "            marker_params=FOTSMarkerSimulatorCfg.MarkerParams(num_markers_col=11, num_markers_row=9, x0=15 * W // 320, y0=26 * H // 240)), device='cuda:0')\n"
+        "    s = GelSightSensor(cfg); s.initialize()\n"
+        "    s.optical_simulator._taxim.set_fused_tail((H, W), mode)\n"
+        "    hm, _ = synthetic_depth_maps(n, H, W, seed=99, flat_fraction=0.17)\n"
+        "    hm[0, : H // 6, : W // 6] = torch.minimum(hm[0, : H // 6, : W // 6], torch.tensor(28.0))   # contact in the image corner\n"
+        "    hm[1, -H // 8 :, W // 3 : W // 2] = 27.9                                                    # ... and on the bottom border\n"
+        "    hm[2, H // 2 - 3 : H // 2 + 3, W // 2 - 40 : W // 2 + 40] = 27.5                            # across the strip seam\n"
+        "    s.set_camera_depth((hm / 1000.0).cuda())\n"
+        "    for k in range(2):\n"
+        "        s.marker_motion_simulator.set_indenter_yaw(torch.full((n,), 0.05 * k, device='cuda:0'))\n"
+        "        s.update(0.01, force_recompute=True)\n"
+        "    o = s.data.output\n"
+        "    res['rgb'] = o['tactile_rgb'].cpu().numpy(); res['obs_' + dt] = o['tactile_rgb_obs'].cpu().numpy()\n"
+        "    res['markers'] = o['marker_motion'].cpu().numpy(); res['pix_z'] = s.optical_simulator._pix_z.cpu().numpy()\n"
+        "    res['pix_m'] = s.optical_simulator._pix_m.cpu().numpy(); res['traj'] = s.marker_motion_simulator._traj_state.cpu().numpy()\n"
+        "np.savez(sys.argv[1], **res)\n")
+    outs = {}
+    for mode in ("1", "2"):
+        out = tmp_path / f"m{mode}.npz"
+        env = dict(os.environ, TACEX_STREAM_SEGS=segs)
+        r = subprocess.run([sys.executable, str(script), str(out), mode], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-3000:]
+        outs[mode] = np.load(out)
+    a, b = outs["1"], outs["2"]
+    np.testing.assert_array_equal(a["rgb"], b["rgb"])
+    np.testing.assert_array_equal(a["pix_m"], b["pix_m"])
+    np.testing.assert_array_equal(a["pix_z"], b["pix_z"])
+    np.testing.assert_array_equal(a["traj"], b["traj"])
+    np.testing.assert_array_equal(a["markers"], b["markers"])
+    assert np.abs(a["obs_float32"] - b["obs_float32"]).max() <= 2e-6
+    assert np.abs(a["obs_uint8"].astype(int) - b["obs_uint8"].astype(int)).max() <= 1 and (a["obs_uint8"] == b["obs_uint8"]).mean() > 0.999
+    assert a["pix_m"].sum() > 0 and np.abs(a["markers"][:, 1] - a["markers"][:, 0]).max() > 0.1
