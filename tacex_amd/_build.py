@@ -16,6 +16,9 @@ SOURCES = ["taxim_kernels.hip", "taxim_mfma.hip", "taxim_tail.hip", "taxim_strea
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=fast", "-Wno-unused-result"]
 # A/B hook for kernel tuning macros, e.g. TACEX_EXTRA_HIPCC_FLAGS="-DTACEX_MFMA_CH=2" (part of the build digest)
 FLAGS += os.environ.get("TACEX_EXTRA_HIPCC_FLAGS", "").split()
+# per-file flags (part of the digest): the streaming tail is scalar f32 FMA chains - SLP packing into v_pk_fma_f32 (half rate on
+# gfx950, scripts/hip_probes/valu_rates.hip) only adds register shuffles and pushed the kernel into scratch
+FILE_FLAGS = {"taxim_stream.hip": ["-fno-slp-vectorize"]}
 
 
 def _hipcc() -> str:
@@ -31,6 +34,7 @@ def _digest() -> str:
         h.update(f.name.encode())
         h.update(f.read_bytes())
     h.update(" ".join(FLAGS).encode())
+    h.update(repr(sorted(FILE_FLAGS.items())).encode())
     return h.hexdigest()
 
 
@@ -46,7 +50,7 @@ def build_library(force: bool = False, verbose: bool = False) -> Path:
     procs = []
     for s in srcs:
         obj = objdir / (s.stem + ".o")
-        cmd = [hipcc, *FLAGS, f"-I{INCLUDE}", f"-I{CSRC}", "-c", str(s), "-o", str(obj)]
+        cmd = [hipcc, *FLAGS, *FILE_FLAGS.get(s.name, []), f"-I{INCLUDE}", f"-I{CSRC}", "-c", str(s), "-o", str(obj)]
         if verbose:
             print(" ".join(cmd))
         procs.append((s, obj, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))

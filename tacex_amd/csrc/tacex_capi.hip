@@ -61,9 +61,12 @@ struct tacex_taxim_ctx {
   std::vector<int> obs_ylo_h, obs_ycnt_h, obs_xlo_h, obs_xcnt_h;
   std::vector<float> obs_wy_h;
   // streaming tail: geometry + per-(observation size, segment count) tables, marker pixels as a CSR over rows
-  struct StreamObsPlan { int oh, ow, nseg; StreamPlan plan; };
+  struct StreamObsPlan { int oh, ow, nseg, mk_version; StreamPlan plan; };
   std::vector<StreamObsPlan> stream_plans;
-  const int* mk_row_ptr = nullptr; const int* mk_x = nullptr; const int* mk_id = nullptr;
+  std::vector<float> feat_y_h;                 // host copy of the polynomial feature y (per-row table of the streaming tail)
+  std::vector<int> mk_row_ptr_h;               // marker CSR over frame rows (host), device columns / ids below
+  const int* mk_x = nullptr; const int* mk_id = nullptr;
+  int mk_version = 0;
   std::vector<void*> allocs;
   // profiling
   bool profiling = false;
@@ -181,6 +184,7 @@ int tacex_taxim_create(int device_id, const tacex_taxim_params* p, tacex_taxim_c
   }
   if (!rc) rc |= upload(c, p->feat_x, (size_t)c->W, &c->shade.fx_dev);
   if (!rc) rc |= upload(c, p->feat_y, (size_t)c->H, &c->shade.fy_dev);
+  c->feat_y_h.assign(p->feat_y, p->feat_y + c->H);
   if (rc) { tacex_taxim_destroy(c); return rc; }
   c->shade.H = c->H; c->shade.W = c->W; c->shade.nb = nb;
   c->shade.calib_h = p->calib_height; c->shade.calib_w = p->calib_width;
@@ -266,43 +270,50 @@ static int ensure_obs_tables(tacex_taxim_ctx* c, int oh, int ow) {
   return 0;
 }
 
-// Streaming-tail plan for B frames (+ an optional policy observation of oh x ow): strip / segment geometry and, for the
-// observation, the per-frame-row tables the kernel walks (which <= 3 observation rows a frame row feeds, with which weights)
-// plus the block geometry of the partial sums.  Cached per (oh, ow, nseg); obs_ready = false when the filters do not fit
-// (a frame row feeding more than 3 observation rows, i.e. down-sampling factors below 2).
+// Streaming-tail plan for B frames (+ an optional policy observation of oh x ow): strip / segment geometry, the packed
+// per-frame-row table the kernel walks (feature y, which <= 3 observation rows the row feeds with which weights, its FOTS
+// marker range) and the block geometry of the observation partial sums.  Cached per (oh, ow, nseg, marker set);
+// obs_ready = false when the filters do not fit (a frame row feeding more than 3 observation rows, i.e. down-sampling
+// factors below 2, or column windows that exceed the per-wave LDS table).
 static int stream_plan(tacex_taxim_ctx* c, int n_fused, int B, int oh, int ow, const StreamPlan** out) {
   const int k0 = c->levels[c->n_levels - n_fused].kw;
   int nstrips = 0, strip_w = 0;
   if (!stream_geometry(n_fused, k0, c->W, &nstrips, &strip_w)) { set_error("no streaming tail for this level set"); return 1; }
   const int nseg = stream_segments(B, nstrips, c->H, 0);
   for (auto& e : c->stream_plans)
-    if (e.oh == oh && e.ow == ow && e.nseg == nseg) {
-      e.plan.mk_row_ptr = c->mk_row_ptr; e.plan.mk_x = c->mk_x; e.plan.mk_id = c->mk_id; e.plan.n_markers = c->fots_taps.n_markers;
-      *out = &e.plan;
-      return 0;
-    }
+    if (e.oh == oh && e.ow == ow && e.nseg == nseg && e.mk_version == c->mk_version) { *out = &e.plan; return 0; }
+  HIP_TRY(hipSetDevice(c->device), "hipSetDevice");
   StreamPlan p{};
   p.nstrips = nstrips; p.strip_w = strip_w; p.nseg = nseg; p.seg_rows = (c->H + nseg - 1) / nseg;
+  const int H = c->H, W = c->W;
+  std::vector<StreamRowInfo> rows(H);
+  for (int r = 0; r < H; ++r) {
+    StreamRowInfo& ri = rows[r];
+    ri.fy = c->feat_y_h[r]; ri.o0 = 0; ri.w0 = ri.w1 = ri.w2 = 0.0f; ri.pad = 0;
+    ri.mk0 = c->mk_row_ptr_h.empty() ? 0 : c->mk_row_ptr_h[r];
+    ri.mk1 = c->mk_row_ptr_h.empty() ? 0 : c->mk_row_ptr_h[r + 1];
+  }
   if (oh > 0 && ow > 0) {
     if (int rc = ensure_obs_tables(c, oh, ow)) return rc;
-    const int H = c->H, W = c->W, ky = c->obs_tab.ky;
-    std::vector<int> o0(H), oa(nseg), ob(nseg), q0(nstrips), nq(nstrips);
-    std::vector<float> rw((size_t)H * 3, 0.0f);
+    const int ky = c->obs_tab.ky;
+    std::vector<int> oa(nseg), ob(nseg), q0(nstrips), nq(nstrips);
     bool ok = true;
     for (int r = 0; r < H && ok; ++r) {
       int o = 0;
       while (o < oh && r >= c->obs_ylo_h[o] + c->obs_ycnt_h[o]) ++o;
-      o0[r] = o;
+      rows[r].o0 = o;
+      float wk[3] = {0.f, 0.f, 0.f};
       for (int k = 0; k < 3 && o + k < oh; ++k)
         if (r >= c->obs_ylo_h[o + k] && r < c->obs_ylo_h[o + k] + c->obs_ycnt_h[o + k])
-          rw[(size_t)r * 3 + k] = c->obs_wy_h[(size_t)(o + k) * ky + (r - c->obs_ylo_h[o + k])];
+          wk[k] = c->obs_wy_h[(size_t)(o + k) * ky + (r - c->obs_ylo_h[o + k])];
+      rows[r].w0 = wk[0]; rows[r].w1 = wk[1]; rows[r].w2 = wk[2];
       if (o + 3 < oh && r >= c->obs_ylo_h[o + 3]) ok = false;  // a 4th observation row overlaps this frame row
-      if (r > 0 && o0[r] < o0[r - 1]) ok = false;
+      if (r > 0 && rows[r].o0 < rows[r - 1].o0) ok = false;
     }
     int nrows = 0, ncols = 0;
     for (int g = 0; g < nseg && ok; ++g) {
       const int r0 = g * p.seg_rows, r1 = std::min(H, r0 + p.seg_rows);
-      oa[g] = o0[r0];
+      oa[g] = rows[r0].o0;
       int b = oa[g];
       while (b + 1 < oh && c->obs_ylo_h[b + 1] < r1) ++b;
       ob[g] = std::min(b, oh - 1);
@@ -319,20 +330,25 @@ static int stream_plan(tacex_taxim_ctx* c, int n_fused, int B, int oh, int ow, c
       q0[s2] = a; nq[s2] = b - a + 1;
       ncols = std::max(ncols, nq[s2]);
     }
+    const int kxp = (c->obs_tab.xmax + 3) & ~3;
+    if (ncols > stream_obs_max_cols() || ncols * kxp > stream_obs_lds_floats() || kxp > 64 * 3) ok = false;
     if (ok) {
-      int *d_o0, *d_oa, *d_ob, *d_q0, *d_nq; float* d_rw;
-      if (int rc = upload(c, o0.data(), o0.size(), &d_o0)) return rc;
-      if (int rc = upload(c, rw.data(), rw.size(), &d_rw)) return rc;
+      int *d_oa, *d_ob, *d_q0, *d_nq;
       if (int rc = upload(c, oa.data(), oa.size(), &d_oa)) return rc;
       if (int rc = upload(c, ob.data(), ob.size(), &d_ob)) return rc;
       if (int rc = upload(c, q0.data(), q0.size(), &d_q0)) return rc;
       if (int rc = upload(c, nq.data(), nq.size(), &d_nq)) return rc;
-      p.obs = c->obs_tab; p.obs_row_o0 = d_o0; p.obs_row_w = d_rw; p.obs_seg_oa = d_oa; p.obs_seg_ob = d_ob;
+      p.obs = c->obs_tab; p.obs_seg_oa = d_oa; p.obs_seg_ob = d_ob; p.obs_kxp = kxp;
       p.obs_strip_q0 = d_q0; p.obs_strip_nq = d_nq; p.obs_nrows = nrows; p.obs_ncols = ncols; p.obs_ready = true;
+    } else {
+      for (auto& ri : rows) { ri.o0 = 0; ri.w0 = ri.w1 = ri.w2 = 0.0f; }
     }
   }
-  p.mk_row_ptr = c->mk_row_ptr; p.mk_x = c->mk_x; p.mk_id = c->mk_id; p.n_markers = c->fots_taps.n_markers;
-  c->stream_plans.push_back({oh, ow, nseg, p});
+  StreamRowInfo* d_rows = nullptr;
+  if (int rc = upload(c, rows.data(), rows.size(), &d_rows)) return rc;
+  p.rows = d_rows;
+  p.mk_x = c->mk_x; p.mk_id = c->mk_id; p.n_markers = c->fots_taps.n_markers;
+  c->stream_plans.push_back({oh, ow, nseg, c->mk_version, p});
   *out = &c->stream_plans.back().plan;
   return 0;
 }
@@ -567,7 +583,7 @@ static int pipeline_chunk(tacex_taxim_ctx* c, const float* hm, const float* pres
     const size_t obs_scratch_floats = (size_t)B * (size_t)(c->H * obs_w > obs_hh * c->W ? c->H * obs_w : obs_hh * c->W) * 3;
     const bool fuse_obs = want_obs && plan->obs_ready &&
                           (size_t)B * plan->nstrips * plan->nseg * plan->obs_nrows * plan->obs_ncols * 3 <= obs_scratch_floats;
-    const bool pix = frame0 >= 0 && c->fots_pix_z && c->mk_row_ptr;
+    const bool pix = frame0 >= 0 && c->fots_pix_z && c->mk_x;
     HIP_TRY(run_stream_tail(c->levels, c->n_levels, n_fused, src, hm, c->gel_dev, sa, sb, pd, &c->shade, rgb, B, c->H, c->W,
                             c->contact_scale, *plan, fuse_obs ? obs_h : nullptr, fots_part,
                             (int)(tail_tiles_per_frame(c->H, c->W) * kTailWavesPerTile),
@@ -660,6 +676,7 @@ int tacex_taxim_set_fots_taps(tacex_taxim_ctx* c, const int32_t* marker_x, const
   if (!c) { set_error("tacex_taxim_set_fots_taps: null context"); return 2; }
   if (!z_pix_dev || !mask_pix_dev || !marker_x || !marker_y || n_markers <= 0) {  // disable
     c->fots_pix_z = nullptr; c->fots_pix_m = nullptr; c->fots_pix_cap = 0;
+    c->mk_row_ptr_h.clear(); c->mk_x = nullptr; c->mk_id = nullptr; ++c->mk_version;
     return 0;
   }
   if (n_markers > 65535) { set_error("tacex_taxim_set_fots_taps: too many markers"); return 2; }
@@ -688,11 +705,10 @@ int tacex_taxim_set_fots_taps(tacex_taxim_ctx* c, const int32_t* marker_x, const
         const int e = fill[marker_y[m]]++;
         mx[e] = marker_x[m]; mid[e] = m;
       }
-    int *dp = nullptr, *dx = nullptr, *di = nullptr;
-    if (int rc = upload(c, ptr.data(), ptr.size(), &dp)) return rc;
+    int *dx = nullptr, *di = nullptr;
     if (int rc = upload(c, mx.data(), mx.size(), &dx)) return rc;
     if (int rc = upload(c, mid.data(), mid.size(), &di)) return rc;
-    c->mk_row_ptr = dp; c->mk_x = dx; c->mk_id = di;
+    c->mk_row_ptr_h = ptr; c->mk_x = dx; c->mk_id = di; ++c->mk_version;
   }
   c->fots_taps.mk_tile = dt; c->fots_taps.mk_cnt = dc; c->fots_taps.n_markers = n_markers;
   c->fots_pix_z = z_pix_dev; c->fots_pix_m = mask_pix_dev; c->fots_pix_cap = capacity_frames;

@@ -96,18 +96,30 @@ bool obs_fusable(const ObsTables& t, int H, int W, int n_fused, int k0);  // geo
 // streaming fused tail (taxim_stream.hip): wave-autonomous line-buffer pipeline, the default where an instantiation exists
 constexpr int kStreamMaxLevels = 5;
 constexpr int kStreamMaxSeg = 8;
+// per-frame-row scalars the streaming kernel needs, packed so that ONE 32-byte scalar load per row fetches them (issued an
+// iteration ahead): polynomial feature y, the observation rows the row feeds (first row + 3 weights), its FOTS marker range
+struct StreamRowInfo {
+  float fy;
+  int o0;
+  float w0, w1, w2;
+  int mk0, mk1;  // markers mk_x / mk_id [mk0, mk1) lie in this row
+  int pad;
+};
 struct StreamPlan {
   int nstrips = 0, strip_w = 0, nseg = 0, seg_rows = 0;
   // policy observation of one (oh, ow, nseg): device tables, valid when obs_ready
   bool obs_ready = false;
   ObsTables obs{};
-  const int* obs_row_o0 = nullptr; const float* obs_row_w = nullptr;
+  const void* rows = nullptr;  // (H,) StreamRowInfo: feature y, observation rows + weights, marker range of every frame row
+  int obs_kxp = 0;             // column-filter window length (taps padded to a multiple of 4)
   const int* obs_strip_q0 = nullptr; const int* obs_strip_nq = nullptr;
   const int* obs_seg_oa = nullptr; const int* obs_seg_ob = nullptr;
   int obs_nrows = 0, obs_ncols = 0;
   // FOTS marker pixels as a CSR over frame rows (device), nullptr when no taps are set
-  const int* mk_row_ptr = nullptr; const int* mk_x = nullptr; const int* mk_id = nullptr; int n_markers = 0;
+  const int* mk_x = nullptr; const int* mk_id = nullptr; int n_markers = 0;
 };
+int stream_obs_lds_floats();
+int stream_obs_max_cols();
 bool stream_supported(int n_fused, int k0, int H, int W);
 bool stream_geometry(int n_fused, int k0, int W, int* nstrips, int* strip_w);
 int stream_segments(int B, int nstrips, int H, int sum_r);

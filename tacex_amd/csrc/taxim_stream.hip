@@ -48,36 +48,46 @@ struct StreamArgs {
   float contact_scale;
   int nstrips, strip_w;  // strips per frame, valid columns per strip
   int nseg, seg_rows;    // vertical segments per strip, rows per segment
+  const StreamRowInfo* rows;  // (H,)
   // policy observation (nullable): per (frame, strip, segment) block of partial sums [obs_nrows][obs_ncols][3]
   float* obs_part;
-  const int* obs_row_o0;    // (H,)   first observation row a frame row contributes to
-  const float* obs_row_w;   // (H,3)  its weights for rows o0, o0 + 1, o0 + 2 (0 where out of the filter support)
   const int* obs_xlo; const int* obs_xcnt; const float* obs_wx; int obs_kx;   // column filters (ObsTables)
   const int* obs_strip_q0;  // (nstrips,) first observation column a strip's valid columns touch
   const int* obs_strip_nq;  // (nstrips,) number of such columns
   const int* obs_seg_oa;    // (nseg,) first / last observation row a segment's rows touch
   const int* obs_seg_ob;
   int obs_nrows, obs_ncols; // block geometry (max over segments / strips)
+  int obs_kxp;              // column-filter taps padded to a multiple of 4 (<= kStreamObsLdsFloats / obs_ncols)
   // FOTS by-products (nullable)
   FotsReduce* fots_part;    // [frame][fots_stride]: slot strip * nseg + seg, the rest filled with identity records
   int fots_stride;
   float* pix_z; uint8_t* pix_m; int n_markers;
-  const int* mk_row_ptr;    // (H + 1,) CSR over frame rows
-  const int* mk_x;          // marker column
+  const int* mk_x;          // marker column  (CSR over rows: StreamRowInfo::mk0 / mk1)
   const int* mk_id;         // marker index
 };
 
 __device__ __forceinline__ float dpp_from_left(float v) {   // lane i receives lane i-1's value
-  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x138, 0xf, 0xf, false));
+  return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x138, 0xf, 0xf, true));  // no `old` operand to initialise
 }
 __device__ __forceinline__ float dpp_from_right(float v) {  // lane i receives lane i+1's value
-  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x130, 0xf, 0xf, false));
+  return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x130, 0xf, 0xf, true));
 }
-__device__ __forceinline__ int dpp_from_left_i(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x138, 0xf, 0xf, false); }
-__device__ __forceinline__ int dpp_from_right_i(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x130, 0xf, 0xf, false); }
+__device__ __forceinline__ int dpp_from_left_i(int v) { return __builtin_amdgcn_mov_dpp(v, 0x138, 0xf, 0xf, true); }
+__device__ __forceinline__ int dpp_from_right_i(int v) { return __builtin_amdgcn_mov_dpp(v, 0x130, 0xf, 0xf, true); }
+
+// d = w * h + a with the destination free to differ from the addend: the vertical scatter chain writes A[j] from A[j-1], and
+// hipcc's two-address v_fmac form (destination tied to the addend) costs one v_mov per partial sum and row to put the result
+// back into the loop-carried register.  volatile: the chain must run in descending j (A[j] is read before it is overwritten).
+__device__ __forceinline__ float fma_to(float w, float h, float a) {
+  float d;
+  asm volatile("v_fma_f32 %0, %1, %2, %3" : "=v"(d) : "s"(w), "v"(h), "v"(a));
+  return d;
+}
 
 // LDS traffic of ONE wave is executed in order; the fence only stops the compiler from moving accesses across it
 __device__ __forceinline__ void wave_lds_fence() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+
+typedef float v3f __attribute__((ext_vector_type(3)));
 
 template <int... KS>
 struct StreamCfg {
@@ -94,8 +104,14 @@ struct StreamCfg {
   static_assert(sum_r() - R(NL - 1) < kStreamRing, "restore ring too shallow");
 };
 
+// wave-private LDS: S ring [kStreamRing][64] float4 (.w unused) | observation staging row [64 * PX * 3] | column-filter window
+// weights [obs_ncols][obs_kxp] + window start per column [obs_ncols]
+constexpr int kStreamObsLdsFloats = 512;
+constexpr int kStreamObsMaxCols = 64;
+constexpr size_t kStreamLdsPerWave = (size_t)kStreamRing * 64 * 16 + 64 * kStreamPx * 3 * 4 + kStreamObsLdsFloats * 4 + kStreamObsMaxCols * 4;
+
 template <bool GZ, int... KS>
-__global__ __launch_bounds__(64 * kStreamWaves) void taxim_stream_kernel(StreamArgs a) {
+__global__ __launch_bounds__(64 * kStreamWaves, 2) void taxim_stream_kernel(StreamArgs a) {
   using C = StreamCfg<KS...>;
   constexpr int NL = C::NL, PX = kStreamPx, SUMR = C::sum_r(), HL = C::HL;
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -111,26 +127,53 @@ __global__ __launch_bounds__(64 * kStreamWaves) void taxim_stream_kernel(StreamA
   const int r0 = seg * a.seg_rows, r1 = min(H, r0 + a.seg_rows);  // output rows of this wave
   const int vx0 = strip * a.strip_w, vx1 = min(W, vx0 + a.strip_w);
   const int cx0 = vx0 - HL * PX;                                   // column of lane 0, pixel 0
-  // wave-private LDS: S ring [kStreamRing][64] float4 (.w unused) + one observation staging row [64 * PX * 3]
-  v4f* ring = reinterpret_cast<v4f*>(smem_raw) + wv_in_blk * (kStreamRing * 64 + (64 * PX * 3) / 4);
+  char* lds = smem_raw + (size_t)wv_in_blk * kStreamLdsPerWave;
+  v4f* ring = reinterpret_cast<v4f*>(lds);
   float* obs_row = reinterpret_cast<float*>(ring + kStreamRing * 64);
+  float* obs_wl = obs_row + 64 * PX * 3;                              // [nq][kxp] window weights
+  int* obs_xb = reinterpret_cast<int*>(obs_wl + kStreamObsLdsFloats);  // [nq] first staging pixel of the window
 
   const size_t fo = (size_t)frame * H * W;
   const float* __restrict__ zin = a.zin + fo;
   const float* __restrict__ hm = a.hm + fo;
   const float sa = a.shift_a[frame], sb = a.shift_b[frame];
   const float thr = -a.pdepth[frame] * a.contact_scale;  // TT:459
+  const bool do_rgb = a.sh.rgb != nullptr;
+  const bool do_obs = a.obs_part != nullptr && do_rgb;
+  const bool do_fots = a.fots_part != nullptr;
 
   int xg[PX];
   unsigned xo[PX];   // reflected + clamped column (loads)
+  unsigned xc[PX];   // clamped column (background / stores)
   bool valid[PX];
   float X[PX];       // polynomial feature x of the pixel (TT:139-157)
 #pragma unroll
   for (int i = 0; i < PX; ++i) {
     xg[i] = cx0 + lane * PX + i;
     xo[i] = (unsigned)min(max(reflect_idx(xg[i], W), 0), W - 1);
+    xc[i] = (unsigned)min(max(xg[i], 0), W - 1);
     valid[i] = xg[i] >= vx0 && xg[i] < vx1;
-    X[i] = a.sh.rgb ? a.sh.fx[min(max(xg[i], 0), W - 1)] : 0.0f;
+    X[i] = do_rgb ? a.sh.fx[xc[i]] : 0.0f;
+  }
+
+  // ---- policy observation set-up: this strip's column filters as fixed-length windows over the staging row ----
+  const int q0 = do_obs ? a.obs_strip_q0[strip] : 0, nq = do_obs ? a.obs_strip_nq[strip] : 0;
+  const int kxp = a.obs_kxp;
+  if (do_obs) {
+    for (int j = lane; j < nq; j += 64) {
+      const int q = q0 + j;
+      int xb = max(a.obs_xlo[q], vx0) - cx0;
+      xb = min(xb, 64 * PX - kxp);
+      obs_xb[j] = xb;
+    }
+    wave_lds_fence();
+    for (int j = lane; j < nq * kxp; j += 64) {
+      const int qi = j / kxp, t = j - qi * kxp, q = q0 + qi;
+      const int x = obs_xb[qi] + t + cx0;  // frame column of this tap
+      const int xlo = a.obs_xlo[q];
+      obs_wl[j] = (x >= xlo && x < xlo + a.obs_xcnt[q] && x >= vx0 && x < vx1) ? a.obs_wx[(size_t)q * a.obs_kx + (x - xlo)] : 0.0f;
+    }
+    wave_lds_fence();
   }
 
   // taps (wave-uniform: scalar registers)
@@ -159,61 +202,106 @@ __global__ __launch_bounds__(64 * kStreamWaves) void taxim_stream_kernel(StreamA
   for (int k = 0; k < kStreamObsActive; ++k)
 #pragma unroll
     for (int j = 0; j < PX * 3; ++j) OA[k][j] = 0.0f;
-  const bool do_obs = a.obs_part != nullptr && a.sh.rgb != nullptr;
-  int cur_o0 = do_obs ? a.obs_seg_oa[seg] : 0;
+  const int seg_oa = do_obs ? a.obs_seg_oa[seg] : 0;
   const int seg_ob = do_obs ? a.obs_seg_ob[seg] : -1;
+  int cur_o0 = seg_oa;
   float* const obs_blk = do_obs ? a.obs_part + (size_t)wv * (a.obs_nrows * a.obs_ncols * 3) : nullptr;
-  const int seg_oa = cur_o0;
 
-  auto row_off = [&](int y) -> unsigned { return (unsigned)min(max(reflect_idx(y, H), 0), H - 1) * (unsigned)W; };
+  auto row_of = [&](int y) -> int { return min(max(reflect_idx(y, H), 0), H - 1); };
 
-  // horizontal reduction of one finished (or segment-final) observation row: staged through the wave's LDS row
+  // horizontal reduction of one finished (or segment-final) observation row: staged through the wave's LDS row, every
+  // (column, channel) cell reduced by one lane over a fixed-length window (weights 0 outside the filter / the strip)
   auto obs_flush = [&](const float (&acc)[PX * 3], int o) {
     if (o < seg_oa || o > seg_ob) return;
     wave_lds_fence();
 #pragma unroll
     for (int j = 0; j < PX * 3; ++j) obs_row[lane * (PX * 3) + j] = acc[j];
     wave_lds_fence();
-    const int q0 = a.obs_strip_q0[strip], nq = a.obs_strip_nq[strip];
     for (int base = 0; base < nq * 3; base += 64) {
       const int j = base + lane;
       if (j < nq * 3) {
-        const int qi = j / 3, ch = j - qi * 3, q = q0 + qi;
-        const int xlo = a.obs_xlo[q], xhi = xlo + a.obs_xcnt[q];
-        const int xa = max(xlo, vx0), xb = min(xhi, vx1);
-        const float* wq = a.obs_wx + (size_t)q * a.obs_kx - xlo;
+        const int qi = j / 3, ch = j - qi * 3;
+        const float* sp = obs_row + obs_xb[qi] * 3 + ch;
+        const v4f* wp = reinterpret_cast<const v4f*>(obs_wl + qi * kxp);
         float s = 0.0f;
-        for (int x = xa; x < xb; ++x) s = fmaf(wq[x], obs_row[(x - cx0) * 3 + ch], s);
+#pragma unroll 3
+        for (int t = 0; t < kxp; t += 4) {
+          const v4f w4 = wp[t >> 2];
+          s = fmaf(w4.x, sp[t * 3], s);
+          s = fmaf(w4.y, sp[t * 3 + 3], s);
+          s = fmaf(w4.z, sp[t * 3 + 6], s);
+          s = fmaf(w4.w, sp[t * 3 + 9], s);
+        }
         obs_blk[((o - seg_oa) * a.obs_ncols + qi) * 3 + ch] = s;
       }
     }
     wave_lds_fence();
   };
 
-  const int ys = r0 - SUMR - 1, ye = r1 - 1 + SUMR + 1;  // input rows walked by this wave
+  // Iteration y: input row y enters level 0; the last level leaves row y - SUMR (-> Zd at the END of the iteration); the row
+  // shaded in this iteration is gs = y - SUMR - 2, whose neighbours (Zu, Zm, Zd) = rows gs-1, gs, gs+1 are complete at the
+  // START of the iteration: its bins are computed and its table / background loads issued FIRST, the levels of this iteration
+  // run under their latency, the polynomial + stores come last.
+  const int ys = r0 - SUMR - 1, ye = r1 + SUMR + 1;
   float zc[PX], hc[PX];
   {
-    const unsigned ro = row_off(ys);
+    const unsigned ro = (unsigned)row_of(ys) * (unsigned)W;
 #pragma unroll
     for (int i = 0; i < PX; ++i) { zc[i] = zin[ro + xo[i]]; hc[i] = hm[ro + xo[i]]; }
   }
+  // row scalars, fetched one iteration ahead: info of the row shaded next, marker ranges of the rows entering / leaving
+  StreamRowInfo ri_g = a.rows[row_of(ys - SUMR - 2)];
+  StreamRowInfo ri_y = a.rows[row_of(ys)];
+  StreamRowInfo ri_z = a.rows[row_of(ys - SUMR)];
   for (int y = ys; y <= ye; ++y) {
-    // ---- prefetch the next input row ----
+    // ---- prefetch the next input row and the next iteration's row scalars ----
     float zn[PX], hn[PX];
     {
-      const unsigned ro = row_off(y + 1 <= ye ? y + 1 : y);
+      const unsigned ro = (unsigned)row_of(y + 1) * (unsigned)W;
 #pragma unroll
       for (int i = 0; i < PX; ++i) { zn[i] = zin[ro + xo[i]]; hn[i] = hm[ro + xo[i]]; }
     }
+    const StreamRowInfo nri_g = a.rows[row_of(y + 1 - SUMR - 2)];
+    const StreamRowInfo nri_y = a.rows[row_of(y + 1)];
+    const StreamRowInfo nri_z = a.rows[row_of(y + 1 - SUMR)];
+
+    // ---- shading, part 1 (runs between level 0 and level 1, see below): bins of row gs, table / background loads in flight.
+    //      Replicate padding of the gradient maps (TT:501-502): rows 0 / H-1 take the gradient of rows 1 / H-2 and are emitted
+    //      together with them; columns 0 / W-1 take the bins of columns 1 / W-2. ----
+    const int gs = y - SUMR - 2;
+    const bool shade_now = do_rgb && gs >= max(r0, 1) && gs <= min(r1 - 1, H - 2);
+    v4f pc[PX][5];
+    v3f bgv[PX];
+    auto shade_part1 = [&]() {
+      if (!shade_now) return;
+      const float zl = dpp_from_left(Zm[PX - 1]), zrg = dpp_from_right(Zm[0]);
+      int code[PX];
+#pragma unroll
+      for (int i = 0; i < PX; ++i) {
+        int im, id;
+        shade_bins(a.sh, Zu[i], Zd[i], i == 0 ? zl : Zm[i - 1], i == PX - 1 ? zrg : Zm[i + 1], im, id);
+        code[i] = im * a.sh.nb + id;
+      }
+      const int cl = dpp_from_left_i(code[PX - 1]), cr = dpp_from_right_i(code[0]);
+#pragma unroll
+      for (int i = 0; i < PX; ++i) {
+        const int right = i == PX - 1 ? cr : code[i + 1], left = i == 0 ? cl : code[i - 1];
+        const int cc = xg[i] == 0 ? right : (xg[i] == W - 1 ? left : code[i]);
+        const v4f* __restrict__ pp = reinterpret_cast<const v4f*>(reinterpret_cast<const char*>(a.sh.poly) + (unsigned)cc * 96u);
+        pc[i][0] = pp[0]; pc[i][1] = pp[1]; pc[i][2] = pp[2]; pc[i][3] = pp[3]; pc[i][4] = pp[4];
+        bgv[i] = *reinterpret_cast<const v3f*>(reinterpret_cast<const char*>(a.sh.bg) + ((unsigned)gs * (unsigned)W + xc[i]) * 12u);
+      }
+    };
+
     // ---- S of this row into the ring; contact statistics of the rows this wave owns ----
     float S[PX];
 #pragma unroll
     for (int i = 0; i < PX; ++i) S[i] = (hc[i] - sa) - sb;  // TT:441
     ring[(y & (kStreamRing - 1)) * 64 + lane] = (v4f){S[0], S[1], S[2], 0.0f};
-    if (a.fots_part != nullptr && y >= r0 && y < r1) {
+    if (do_fots && y >= r0 && y < r1) {
       float gl[PX] = {0.f, 0.f, 0.f};
       if constexpr (!GZ) {
-        const unsigned ro = row_off(y);
+        const unsigned ro = (unsigned)row_of(y) * (unsigned)W;
 #pragma unroll
         for (int i = 0; i < PX; ++i) gl[i] = a.gel[ro + xo[i]];
       }
@@ -226,9 +314,10 @@ __global__ __launch_bounds__(64 * kStreamWaves) void taxim_stream_kernel(StreamA
         f_cnt += m1; f_sr += m1 * y; f_sc += m1 * xg[i];
       }
       if (a.pix_m != nullptr) {  // contact mask at the FOTS marker pixels of this row
-        for (int e = a.mk_row_ptr[y]; e < a.mk_row_ptr[y + 1]; ++e) {
-          const int d = a.mk_x[e] - cx0 - lane * PX;
-          if (d >= 0 && d < PX && a.mk_x[e] >= vx0 && a.mk_x[e] < vx1)
+        for (int e = ri_y.mk0; e < ri_y.mk1; ++e) {
+          const int mx = a.mk_x[e];
+          const int d = mx - cx0 - lane * PX;
+          if (d >= 0 && d < PX && mx >= vx0 && mx < vx1)
             a.pix_m[(size_t)frame * a.n_markers + a.mk_id[e]] = (uint8_t)(d == 0 ? mrow[0] : (d == 1 ? mrow[1] : mrow[2]));
         }
       }
@@ -240,6 +329,8 @@ __global__ __launch_bounds__(64 * kStreamWaves) void taxim_stream_kernel(StreamA
     static_for<0, NL>([&](auto lc) {
       constexpr int l = decltype(lc)::value;
       constexpr int K = C::K[l], R = C::R(l), WO = C::acc_off(l) + l, AO = C::acc_off(l);
+      // the widest window (level 0) is done: issue the shading loads of row gs now, the remaining levels run under their latency
+      if constexpr (l == (NL > 1 ? 1 : 0)) shade_part1();
       float h[PX];
       if constexpr (K == 1) {
 #pragma unroll
@@ -280,10 +371,10 @@ __global__ __launch_bounds__(64 * kStreamWaves) void taxim_stream_kernel(StreamA
       } else {
 #pragma unroll
         for (int i = 0; i < PX; ++i) {
-          out[i] = fmaf(w[WO + K - 1], h[i], A[AO + K - 2][i]);
+          out[i] = fma_to(w[WO + K - 1], h[i], A[AO + K - 2][i]);
           static_for<0, K - 2>([&](auto jc) {
             constexpr int j = K - 2 - decltype(jc)::value;  // K-2 .. 1
-            A[AO + j][i] = fmaf(w[WO + j], h[i], A[AO + j - 1][i]);
+            A[AO + j][i] = fma_to(w[WO + j], h[i], A[AO + j - 1][i]);
           });
           A[AO][i] = w[WO] * h[i];
         }
@@ -293,7 +384,7 @@ __global__ __launch_bounds__(64 * kStreamWaves) void taxim_stream_kernel(StreamA
         const v4f Sv = ring[(rr & (kStreamRing - 1)) * 64 + lane];
         float gl[PX] = {0.f, 0.f, 0.f};
         if constexpr (!GZ) {
-          const unsigned ro = row_off(rr);
+          const unsigned ro = (unsigned)row_of(rr) * (unsigned)W;
 #pragma unroll
           for (int i = 0; i < PX; ++i) gl[i] = a.gel[ro + xo[i]];
         }
@@ -307,83 +398,69 @@ __global__ __launch_bounds__(64 * kStreamWaves) void taxim_stream_kernel(StreamA
 #pragma unroll
       for (int i = 0; i < PX; ++i) cur[i] = out[i];
     });
-    // ---- cur = last-level row y - SUMR ----
-#pragma unroll
-    for (int i = 0; i < PX; ++i) { Zu[i] = Zm[i]; Zm[i] = Zd[i]; Zd[i] = cur[i]; }
-    const int zr = y - SUMR;  // row index of Zd
+    // ---- cur = last-level row zr = y - SUMR ----
+    const int zr = y - SUMR;
     if (zr >= r0 && zr < r1) {
-      if (a.fots_part != nullptr) {
+      if (do_fots) {
 #pragma unroll
         for (int i = 0; i < PX; ++i) f_zmax = valid[i] ? fmaxf(f_zmax, cur[i]) : f_zmax;
       }
       if (a.pix_z != nullptr) {
-        for (int e = a.mk_row_ptr[zr]; e < a.mk_row_ptr[zr + 1]; ++e) {
-          const int d = a.mk_x[e] - cx0 - lane * PX;
-          if (d >= 0 && d < PX && a.mk_x[e] >= vx0 && a.mk_x[e] < vx1)
+        for (int e = ri_z.mk0; e < ri_z.mk1; ++e) {
+          const int mx = a.mk_x[e];
+          const int d = mx - cx0 - lane * PX;
+          if (d >= 0 && d < PX && mx >= vx0 && mx < vx1)
             a.pix_z[(size_t)frame * a.n_markers + a.mk_id[e]] = d == 0 ? cur[0] : (d == 1 ? cur[1] : cur[2]);
         }
       }
     }
-    // ---- shading of row g = y - SUMR - 1 from (Zu, Zm, Zd) = rows g-1, g, g+1.  Replicate padding of the gradient maps
-    //      (TT:501-502): rows 0 / H-1 take the gradient of rows 1 / H-2 and are emitted together with them; columns 0 / W-1
-    //      take the bins of columns 1 / W-2. ----
-    const int g = zr - 1;
-    if (a.sh.rgb != nullptr && g >= max(r0, 1) && g <= min(r1 - 1, H - 2)) {
-      const float zl = dpp_from_left(Zm[PX - 1]), zrg = dpp_from_right(Zm[0]);
-      int code[PX];
-#pragma unroll
-      for (int i = 0; i < PX; ++i) {
-        int im, id;
-        shade_bins(a.sh, Zu[i], Zd[i], i == 0 ? zl : Zm[i - 1], i == PX - 1 ? zrg : Zm[i + 1], im, id);
-        code[i] = im | (id << 8);
-      }
-      const int cl = dpp_from_left_i(code[PX - 1]), cr = dpp_from_right_i(code[0]);
-      int codec[PX];
-#pragma unroll
-      for (int i = 0; i < PX; ++i) {
-        const int right = i == PX - 1 ? cr : code[i + 1], left = i == 0 ? cl : code[i - 1];
-        codec[i] = xg[i] == 0 ? right : (xg[i] == W - 1 ? left : code[i]);
-      }
-      // rows emitted by this iteration (ascending)
-      const int e_lo = g == 1 ? 0 : g, e_hi = g == H - 2 ? H - 1 : g;
+    // ---- shading, part 2: polynomial, background, clip, store, observation ----
+    if (shade_now) {
+      const int e_lo = gs == 1 ? 0 : gs, e_hi = gs == H - 2 ? H - 1 : gs;  // rows emitted by this iteration (ascending)
       for (int e = e_lo; e <= e_hi; ++e) {
         if (e < r0 || e >= r1) continue;
-        const float Y = a.sh.fy[e];
+        StreamRowInfo ri = ri_g;
+        if (e != gs) {  // a replicated border row: its own feature / background / observation row (twice per frame)
+          ri = a.rows[e];
+#pragma unroll
+          for (int i = 0; i < PX; ++i)
+            bgv[i] = *reinterpret_cast<const v3f*>(reinterpret_cast<const char*>(a.sh.bg) + ((unsigned)e * (unsigned)W + xc[i]) * 12u);
+        }
+        const float Y = ri.fy;
         float rgb[PX * 3];
 #pragma unroll
         for (int i = 0; i < PX; ++i) {
-          float c[3];
-          shade_poly(a.sh, codec[i] & 0xff, codec[i] >> 8, X[i], Y, c);
-          const unsigned p = (unsigned)e * (unsigned)W + (unsigned)min(max(xg[i], 0), W - 1);
-          const float* __restrict__ bg = reinterpret_cast<const float*>(reinterpret_cast<const char*>(a.sh.bg) + p * 12u);
-          rgb[3 * i + 0] = __builtin_amdgcn_fmed3f(c[0] + bg[0], 0.0f, 1.0f);  // TT:257-258
-          rgb[3 * i + 1] = __builtin_amdgcn_fmed3f(c[1] + bg[1], 0.0f, 1.0f);
-          rgb[3 * i + 2] = __builtin_amdgcn_fmed3f(c[2] + bg[2], 0.0f, 1.0f);
-          if (valid[i]) {
-            float* o = reinterpret_cast<float*>(reinterpret_cast<char*>(a.sh.rgb + fo * 3) + p * 12u);
-            o[0] = rgb[3 * i]; o[1] = rgb[3 * i + 1]; o[2] = rgb[3 * i + 2];
-          }
+          const v4f c0 = pc[i][0], c1 = pc[i][1], c2 = pc[i][2], c3 = pc[i][3], c4 = pc[i][4];
+          const float f0 = X[i] * X[i], f1 = Y * Y, f2 = X[i] * Y;
+          const float p0 = fmaf(f0, c0.x, fmaf(f1, c0.y, fmaf(f2, c0.z, fmaf(X[i], c0.w, fmaf(Y, c1.x, c1.y)))));
+          const float p1 = fmaf(f0, c1.z, fmaf(f1, c1.w, fmaf(f2, c2.x, fmaf(X[i], c2.y, fmaf(Y, c2.z, c2.w)))));
+          const float p2 = fmaf(f0, c3.x, fmaf(f1, c3.y, fmaf(f2, c3.z, fmaf(X[i], c3.w, fmaf(Y, c4.x, c4.y)))));
+          rgb[3 * i + 0] = __builtin_amdgcn_fmed3f(p0 + bgv[i].x, 0.0f, 1.0f);  // TT:257-258
+          rgb[3 * i + 1] = __builtin_amdgcn_fmed3f(p1 + bgv[i].y, 0.0f, 1.0f);
+          rgb[3 * i + 2] = __builtin_amdgcn_fmed3f(p2 + bgv[i].z, 0.0f, 1.0f);
+          if (valid[i])
+            *reinterpret_cast<v3f*>(reinterpret_cast<char*>(a.sh.rgb + fo * 3) + ((unsigned)e * (unsigned)W + xc[i]) * 12u) =
+                (v3f){rgb[3 * i], rgb[3 * i + 1], rgb[3 * i + 2]};
         }
         if (do_obs) {
-          const int o0 = a.obs_row_o0[e];
-          while (cur_o0 < o0) {  // the oldest observation row in flight got its last frame row: reduce it horizontally
+          while (cur_o0 < ri.o0) {  // the oldest observation row in flight got its last frame row: reduce it horizontally
             obs_flush(OA[0], cur_o0);
 #pragma unroll
             for (int j = 0; j < PX * 3; ++j) { OA[0][j] = OA[1][j]; OA[1][j] = OA[2][j]; OA[2][j] = 0.0f; }
             ++cur_o0;
           }
-          const float w0 = a.obs_row_w[e * 3], w1 = a.obs_row_w[e * 3 + 1], w2 = a.obs_row_w[e * 3 + 2];
 #pragma unroll
           for (int j = 0; j < PX * 3; ++j) {
-            OA[0][j] = fmaf(w0, rgb[j], OA[0][j]);
-            OA[1][j] = fmaf(w1, rgb[j], OA[1][j]);
-            OA[2][j] = fmaf(w2, rgb[j], OA[2][j]);
+            OA[0][j] = fmaf(ri.w0, rgb[j], OA[0][j]);
+            OA[1][j] = fmaf(ri.w1, rgb[j], OA[1][j]);
+            OA[2][j] = fmaf(ri.w2, rgb[j], OA[2][j]);
           }
         }
       }
     }
 #pragma unroll
-    for (int i = 0; i < PX; ++i) { zc[i] = zn[i]; hc[i] = hn[i]; }
+    for (int i = 0; i < PX; ++i) { Zu[i] = Zm[i]; Zm[i] = Zd[i]; Zd[i] = cur[i]; zc[i] = zn[i]; hc[i] = hn[i]; }
+    ri_g = nri_g; ri_y = nri_y; ri_z = nri_z;
   }
   if (do_obs) {  // observation rows still in flight at the end of the segment (another segment adds its share)
     obs_flush(OA[0], cur_o0);
@@ -391,7 +468,7 @@ __global__ __launch_bounds__(64 * kStreamWaves) void taxim_stream_kernel(StreamA
     obs_flush(OA[2], cur_o0 + 2);
     // rows of the block this segment never reached stay unwritten: the finishing kernel only reads [seg_oa, seg_ob]
   }
-  if (a.fots_part != nullptr) {  // one record per wave: no atomics; fots_combine_kernel adds the records of an env
+  if (do_fots) {  // one record per wave: no atomics; fots_combine_kernel adds the records of an env
     f_zmax = wave_scan_max_lane63(f_zmax);
     f_cnt = wave_scan_add_lane63(f_cnt);
     f_sr = wave_scan_add_lane63(f_sr);
@@ -489,7 +566,7 @@ template <int... KS>
 static hipError_t launch_stream(const StreamArgs& a, bool gel_zero, hipStream_t st) {
   const int waves = a.B * a.nstrips * a.nseg;
   const dim3 grid((waves + kStreamWaves - 1) / kStreamWaves);
-  const size_t lds = (size_t)kStreamWaves * (kStreamRing * 64 * 16 + 64 * kStreamPx * 3 * 4);
+  const size_t lds = (size_t)kStreamWaves * kStreamLdsPerWave;
   if (gel_zero) hipLaunchKernelGGL((taxim_stream_kernel<true, KS...>), grid, dim3(64 * kStreamWaves), lds, st, a);
   else hipLaunchKernelGGL((taxim_stream_kernel<false, KS...>), grid, dim3(64 * kStreamWaves), lds, st, a);
   return hipGetLastError();
@@ -509,18 +586,19 @@ hipError_t run_stream_tail(const LevelDesc* lv, int n_levels, int n_fused, const
   a.sh.gsy = (float)(0.5 * H / sp->calib_h / (double)sp->pixmm); a.sh.gsx = (float)(0.5 * W / sp->calib_w / (double)sp->pixmm);
   a.sh.inv_x_binr = (float)(1.0 / (double)sp->x_binr); a.sh.inv_y_binr = (float)(1.0 / (double)sp->y_binr);
   a.nstrips = plan.nstrips; a.strip_w = plan.strip_w; a.nseg = plan.nseg; a.seg_rows = plan.seg_rows;
+  a.rows = static_cast<const StreamRowInfo*>(plan.rows);
   if (obs_part && plan.obs_ready) {
     a.obs_part = obs_part;
-    a.obs_row_o0 = plan.obs_row_o0; a.obs_row_w = plan.obs_row_w;
+    a.obs_kxp = plan.obs_kxp;
     a.obs_xlo = plan.obs.xlo; a.obs_xcnt = plan.obs.xcnt; a.obs_wx = plan.obs.wx; a.obs_kx = plan.obs.kx;
     a.obs_strip_q0 = plan.obs_strip_q0; a.obs_strip_nq = plan.obs_strip_nq;
     a.obs_seg_oa = plan.obs_seg_oa; a.obs_seg_ob = plan.obs_seg_ob;
     a.obs_nrows = plan.obs_nrows; a.obs_ncols = plan.obs_ncols;
   }
   a.fots_part = fots_part; a.fots_stride = fots_stride;
-  if (pix_z && pix_m && plan.mk_row_ptr) {
+  if (pix_z && pix_m && plan.mk_x) {
     a.pix_z = pix_z; a.pix_m = pix_m; a.n_markers = plan.n_markers;
-    a.mk_row_ptr = plan.mk_row_ptr; a.mk_x = plan.mk_x; a.mk_id = plan.mk_id;
+    a.mk_x = plan.mk_x; a.mk_id = plan.mk_id;
   }
   const int k0 = lv[n_levels - n_fused].kw;
   switch (stream_variant(n_fused, k0)) {
@@ -540,5 +618,8 @@ hipError_t run_obs_finish_stream(const float* part, void* obs, bool u8, const St
                        plan.obs_seg_oa, plan.obs_seg_ob, plan.nstrips, plan.nseg, plan.obs_nrows, plan.obs_ncols);
   return hipGetLastError();
 }
+
+int stream_obs_lds_floats() { return kStreamObsLdsFloats; }
+int stream_obs_max_cols() { return kStreamObsMaxCols; }
 
 }  // namespace tacex
