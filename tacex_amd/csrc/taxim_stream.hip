@@ -108,7 +108,15 @@ struct StreamCfg {
 // weights [obs_ncols][obs_kxp] + window start per column [obs_ncols]
 constexpr int kStreamObsLdsFloats = 512;
 constexpr int kStreamObsMaxCols = 64;
-constexpr size_t kStreamLdsPerWave = (size_t)kStreamRing * 64 * 16 + 64 * kStreamPx * 3 * 4 + kStreamObsLdsFloats * 4 + kStreamObsMaxCols * 4;
+constexpr size_t kStreamStageBytes = 64 * kStreamPx * 3 * 4;  // one row of 3 floats per pixel (background in / RGB out)
+constexpr size_t kStreamLdsPerWave = (size_t)kStreamRing * 64 * 16 + 2 * kStreamStageBytes + kStreamObsLdsFloats * 4 + kStreamObsMaxCols * 4;
+// workgroup-shared copy of the polynomial records of magnitude bin 0 ([id][28] floats: 24 padded to 28 so that 16 lanes with
+// distinct direction bins read 16 distinct 16-byte bank slots).  Nearly all pixels outside a contact - and there the direction
+// bin still varies from pixel to pixel - gather their record from here instead of through the vector L1, whose tag pipe was the
+// kernel's bottleneck (TCP_TOTAL_CACHE_ACCESSES: 636 per row and wave, 2/3 of them table gathers, 61 % busy).
+constexpr int kStreamPolyPitch = 28;
+constexpr int kStreamPolyMaxBins = 128;
+constexpr size_t kStreamLdsShared = (size_t)kStreamPolyMaxBins * kStreamPolyPitch * 4;
 
 template <bool GZ, int... KS>
 __global__ __launch_bounds__(64 * kStreamWaves, 2) void taxim_stream_kernel(StreamArgs a) {
@@ -119,6 +127,18 @@ __global__ __launch_bounds__(64 * kStreamWaves, 2) void taxim_stream_kernel(Stre
   const int wv_in_blk = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int per_frame = a.nstrips * a.nseg;
   const int wv = blockIdx.x * kStreamWaves + wv_in_blk;
+  float* const polyL = reinterpret_cast<float*>(smem_raw);
+  {  // magnitude-bin-0 records -> LDS (all waves of the workgroup, before any of them may leave)
+    const int nb = a.sh.nb;
+    const bool use = a.sh.rgb != nullptr && nb <= kStreamPolyMaxBins;
+    if (use)
+      for (int j = threadIdx.x; j < nb * 6; j += 64 * kStreamWaves) {  // 6 x 16 bytes per record
+        const int id = j / 6, k = j - id * 6;
+        *reinterpret_cast<v4f*>(polyL + id * kStreamPolyPitch + 4 * k) = *reinterpret_cast<const v4f*>(a.sh.poly + (size_t)id * 24 + 4 * k);
+      }
+    __syncthreads();
+  }
+  const int nb_lds = a.sh.nb <= kStreamPolyMaxBins ? a.sh.nb : 0;  // records [0, nb_lds) are LDS-resident
   if (wv >= a.B * per_frame) return;
   const int frame = wv / per_frame;
   const int rem = wv - frame * per_frame;
@@ -127,9 +147,10 @@ __global__ __launch_bounds__(64 * kStreamWaves, 2) void taxim_stream_kernel(Stre
   const int r0 = seg * a.seg_rows, r1 = min(H, r0 + a.seg_rows);  // output rows of this wave
   const int vx0 = strip * a.strip_w, vx1 = min(W, vx0 + a.strip_w);
   const int cx0 = vx0 - HL * PX;                                   // column of lane 0, pixel 0
-  char* lds = smem_raw + (size_t)wv_in_blk * kStreamLdsPerWave;
+  char* lds = smem_raw + kStreamLdsShared + (size_t)wv_in_blk * kStreamLdsPerWave;
   v4f* ring = reinterpret_cast<v4f*>(lds);
-  float* obs_row = reinterpret_cast<float*>(ring + kStreamRing * 64);
+  float* stage = reinterpret_cast<float*>(ring + kStreamRing * 64);   // [64 * PX * 3] background in / RGB out staging row
+  float* obs_row = stage + 64 * PX * 3;                               // [64 * PX * 3] observation staging row
   float* obs_wl = obs_row + 64 * PX * 3;                              // [nq][kxp] window weights
   int* obs_xb = reinterpret_cast<int*>(obs_wl + kStreamObsLdsFloats);  // [nq] first staging pixel of the window
 
@@ -155,6 +176,20 @@ __global__ __launch_bounds__(64 * kStreamWaves, 2) void taxim_stream_kernel(Stre
     valid[i] = xg[i] >= vx0 && xg[i] < vx1;
     X[i] = do_rgb ? a.sh.fx[xc[i]] : 0.0f;
   }
+  // input rows come in as ONE 12-byte load per lane; the few lanes with a pixel outside the image (reflect padding) re-load
+  // their three pixels one by one at the mirrored columns
+  const unsigned xb = (unsigned)min(max(xg[0], 0), W - PX);
+  const bool border = xg[0] < 0 || xg[PX - 1] >= W;
+  auto load_row = [&](int row, float (&zz)[PX], float (&hh)[PX]) {
+    const unsigned ro = (unsigned)row * (unsigned)W;
+    const v3f z3 = *reinterpret_cast<const v3f*>(zin + ro + xb);
+    const v3f h3 = *reinterpret_cast<const v3f*>(hm + ro + xb);
+    zz[0] = z3.x; zz[1] = z3.y; zz[2] = z3.z; hh[0] = h3.x; hh[1] = h3.y; hh[2] = h3.z;
+    if (border) {
+#pragma unroll
+      for (int i = 0; i < PX; ++i) { zz[i] = zin[ro + xo[i]]; hh[i] = hm[ro + xo[i]]; }
+    }
+  };
 
   // ---- policy observation set-up: this strip's column filters as fixed-length windows over the staging row ----
   const int q0 = do_obs ? a.obs_strip_q0[strip] : 0, nq = do_obs ? a.obs_strip_nq[strip] : 0;
@@ -244,34 +279,44 @@ __global__ __launch_bounds__(64 * kStreamWaves, 2) void taxim_stream_kernel(Stre
   // run under their latency, the polynomial + stores come last.
   const int ys = r0 - SUMR - 1, ye = r1 + SUMR + 1;
   float zc[PX], hc[PX];
-  {
-    const unsigned ro = (unsigned)row_of(ys) * (unsigned)W;
-#pragma unroll
-    for (int i = 0; i < PX; ++i) { zc[i] = zin[ro + xo[i]]; hc[i] = hm[ro + xo[i]]; }
-  }
-  // row scalars, fetched one iteration ahead: info of the row shaded next, marker ranges of the rows entering / leaving
-  StreamRowInfo ri_g = a.rows[row_of(ys - SUMR - 2)];
-  StreamRowInfo ri_y = a.rows[row_of(ys)];
-  StreamRowInfo ri_z = a.rows[row_of(ys - SUMR)];
+  load_row(row_of(ys), zc, hc);
+  // Row scalars, fetched one iteration ahead with a VECTOR load (lanes 0-7: record of the row shaded, 8-15: of the row
+  // entering, 16-23: of the row leaving the last level) and moved to scalar registers with v_readlane: scalar-memory loads
+  // share the LDS wait counter and return out of order, so every ring read would also wait for them.
+  const int* rows_i = reinterpret_cast<const int*>(a.rows);
+  auto load_info = [&](int yy) -> int {
+    const int k = lane >> 3;
+    const int r = row_of(k == 0 ? yy - SUMR - 2 : (k == 1 ? yy : yy - SUMR));
+    return lane < 24 ? rows_i[r * 8 + (lane & 7)] : 0;
+  };
+  int info = load_info(ys);
   for (int y = ys; y <= ye; ++y) {
     // ---- prefetch the next input row and the next iteration's row scalars ----
     float zn[PX], hn[PX];
-    {
-      const unsigned ro = (unsigned)row_of(y + 1) * (unsigned)W;
-#pragma unroll
-      for (int i = 0; i < PX; ++i) { zn[i] = zin[ro + xo[i]]; hn[i] = hm[ro + xo[i]]; }
-    }
-    const StreamRowInfo nri_g = a.rows[row_of(y + 1 - SUMR - 2)];
-    const StreamRowInfo nri_y = a.rows[row_of(y + 1)];
-    const StreamRowInfo nri_z = a.rows[row_of(y + 1 - SUMR)];
+    load_row(row_of(y + 1), zn, hn);
+    const int ninfo = load_info(y + 1);
+    StreamRowInfo ri_g, ri_y, ri_z;
+    ri_g.fy = __int_as_float(__builtin_amdgcn_readlane(info, 0)); ri_g.o0 = __builtin_amdgcn_readlane(info, 1);
+    ri_g.w0 = __int_as_float(__builtin_amdgcn_readlane(info, 2)); ri_g.w1 = __int_as_float(__builtin_amdgcn_readlane(info, 3));
+    ri_g.w2 = __int_as_float(__builtin_amdgcn_readlane(info, 4));
+    ri_y.mk0 = __builtin_amdgcn_readlane(info, 8 + 5); ri_y.mk1 = __builtin_amdgcn_readlane(info, 8 + 6);
+    ri_z.mk0 = __builtin_amdgcn_readlane(info, 16 + 5); ri_z.mk1 = __builtin_amdgcn_readlane(info, 16 + 6);
 
     // ---- shading, part 1 (runs between level 0 and level 1, see below): bins of row gs, table / background loads in flight.
     //      Replicate padding of the gradient maps (TT:501-502): rows 0 / H-1 take the gradient of rows 1 / H-2 and are emitted
     //      together with them; columns 0 / W-1 take the bins of columns 1 / W-2. ----
     const int gs = y - SUMR - 2;
     const bool shade_now = do_rgb && gs >= max(r0, 1) && gs <= min(r1 - 1, H - 2);
-    v4f pc[PX][5];
-    v3f bgv[PX];
+    int cc[PX] = {0, 0, 0};  // table record (bin pair) of every pixel of row gs
+    // The strip's background / RGB row is 64 x 9 floats.  A lane owns floats [9 l, 9 l + 9); read or written that way every
+    // 16-byte access instruction would touch all 36 cache lines of the row.  Instead the row moves between global memory and
+    // the wave's LDS staging row as CONTIGUOUS 16-byte pieces (lane l: floats [4 (l + 64 k), + 4), k = 0..2) and the lanes pick
+    // their own 9 floats out of LDS.
+    v4f bgq[3];
+    auto stage_chunk_ok = [&](int k, int lo_f, int hi_f) -> bool {  // chunk k of this lane inside [lo_f, hi_f) floats of the strip row?
+      const int f = 4 * (lane + 64 * k);
+      return f >= lo_f && f + 4 <= hi_f && f < 64 * PX * 3;
+    };
     auto shade_part1 = [&]() {
       if (!shade_now) return;
       const float zl = dpp_from_left(Zm[PX - 1]), zrg = dpp_from_right(Zm[0]);
@@ -286,11 +331,14 @@ __global__ __launch_bounds__(64 * kStreamWaves, 2) void taxim_stream_kernel(Stre
 #pragma unroll
       for (int i = 0; i < PX; ++i) {
         const int right = i == PX - 1 ? cr : code[i + 1], left = i == 0 ? cl : code[i - 1];
-        const int cc = xg[i] == 0 ? right : (xg[i] == W - 1 ? left : code[i]);
-        const v4f* __restrict__ pp = reinterpret_cast<const v4f*>(reinterpret_cast<const char*>(a.sh.poly) + (unsigned)cc * 96u);
-        pc[i][0] = pp[0]; pc[i][1] = pp[1]; pc[i][2] = pp[2]; pc[i][3] = pp[3]; pc[i][4] = pp[4];
-        bgv[i] = *reinterpret_cast<const v3f*>(reinterpret_cast<const char*>(a.sh.bg) + ((unsigned)gs * (unsigned)W + xc[i]) * 12u);
+        cc[i] = xg[i] == 0 ? right : (xg[i] == W - 1 ? left : code[i]);
       }
+      // background of row gs: the in-image part of the strip row, issued now, consumed after the remaining levels
+      const float* bgrow = a.sh.bg + ((size_t)gs * W + cx0) * 3;  // float 0 of the strip row (may lie left of the image)
+#pragma unroll
+      for (int k = 0; k < 3; ++k)
+        bgq[k] = stage_chunk_ok(k, -cx0 * 3 > 0 ? -cx0 * 3 : 0, (W - cx0) * 3) ? *reinterpret_cast<const v4f*>(bgrow + 4 * (lane + 64 * k))
+                                                                            : (v4f)(0.0f);
     };
 
     // ---- S of this row into the ring; contact statistics of the rows this wave owns ----
@@ -298,6 +346,12 @@ __global__ __launch_bounds__(64 * kStreamWaves, 2) void taxim_stream_kernel(Stre
 #pragma unroll
     for (int i = 0; i < PX; ++i) S[i] = (hc[i] - sa) - sb;  // TT:441
     ring[(y & (kStreamRing - 1)) * 64 + lane] = (v4f){S[0], S[1], S[2], 0.0f};
+    // S of the rows the restores of this iteration need (written 4..7 iterations ago): all ring reads issued up front
+    v4f Sring[NL > 1 ? NL - 1 : 1];
+    static_for<0, NL - 1>([&](auto lc) {
+      constexpr int l = decltype(lc)::value;
+      Sring[l] = ring[((y - C::delay(l)) & (kStreamRing - 1)) * 64 + lane];
+    });
     if (do_fots && y >= r0 && y < r1) {
       float gl[PX] = {0.f, 0.f, 0.f};
       if constexpr (!GZ) {
@@ -380,8 +434,8 @@ __global__ __launch_bounds__(64 * kStreamWaves, 2) void taxim_stream_kernel(Stre
         }
       }
       if constexpr (l < NL - 1) {  // TT:467 Z[M] = J[M]; the final blur (TT:468-471) has no restore
-        const int rr = y - C::delay(l);
-        const v4f Sv = ring[(rr & (kStreamRing - 1)) * 64 + lane];
+        [[maybe_unused]] const int rr = y - C::delay(l);
+        const v4f Sv = Sring[l];
         float gl[PX] = {0.f, 0.f, 0.f};
         if constexpr (!GZ) {
           const unsigned ro = (unsigned)row_of(rr) * (unsigned)W;
@@ -414,18 +468,41 @@ __global__ __launch_bounds__(64 * kStreamWaves, 2) void taxim_stream_kernel(Stre
         }
       }
     }
-    // ---- shading, part 2: polynomial, background, clip, store, observation ----
+    // ---- shading, part 2: table records, polynomial, background, clip, store, observation ----
     if (shade_now) {
+      // records: magnitude bin 0 (code < nb) from the workgroup's LDS copy, the others gathered from the table in L2
+      v4f pc[PX][5];
+#pragma unroll
+      for (int i = 0; i < PX; ++i) {
+        if (cc[i] < nb_lds) {
+          const v4f* pl = reinterpret_cast<const v4f*>(polyL + cc[i] * kStreamPolyPitch);
+          pc[i][0] = pl[0]; pc[i][1] = pl[1]; pc[i][2] = pl[2]; pc[i][3] = pl[3]; pc[i][4] = pl[4];
+        } else {
+          const v4f* __restrict__ pp = reinterpret_cast<const v4f*>(reinterpret_cast<const char*>(a.sh.poly) + (unsigned)cc[i] * 96u);
+          pc[i][0] = pp[0]; pc[i][1] = pp[1]; pc[i][2] = pp[2]; pc[i][3] = pp[3]; pc[i][4] = pp[4];
+        }
+      }
       const int e_lo = gs == 1 ? 0 : gs, e_hi = gs == H - 2 ? H - 1 : gs;  // rows emitted by this iteration (ascending)
       for (int e = e_lo; e <= e_hi; ++e) {
         if (e < r0 || e >= r1) continue;
         StreamRowInfo ri = ri_g;
         if (e != gs) {  // a replicated border row: its own feature / background / observation row (twice per frame)
           ri = a.rows[e];
+          const float* bgrow = a.sh.bg + ((size_t)e * W + cx0) * 3;
 #pragma unroll
-          for (int i = 0; i < PX; ++i)
-            bgv[i] = *reinterpret_cast<const v3f*>(reinterpret_cast<const char*>(a.sh.bg) + ((unsigned)e * (unsigned)W + xc[i]) * 12u);
+          for (int k = 0; k < 3; ++k)
+            bgq[k] = stage_chunk_ok(k, -cx0 * 3 > 0 ? -cx0 * 3 : 0, (W - cx0) * 3) ? *reinterpret_cast<const v4f*>(bgrow + 4 * (lane + 64 * k))
+                                                                                : (v4f)(0.0f);
         }
+        // background: contiguous pieces -> staging row -> this lane's 9 floats
+        wave_lds_fence();
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+          if (4 * (lane + 64 * k) < 64 * PX * 3) *reinterpret_cast<v4f*>(stage + 4 * (lane + 64 * k)) = bgq[k];
+        wave_lds_fence();
+        float bge[PX * 3];
+#pragma unroll
+        for (int j = 0; j < PX * 3; ++j) bge[j] = stage[lane * (PX * 3) + j];
         const float Y = ri.fy;
         float rgb[PX * 3];
 #pragma unroll
@@ -435,12 +512,21 @@ __global__ __launch_bounds__(64 * kStreamWaves, 2) void taxim_stream_kernel(Stre
           const float p0 = fmaf(f0, c0.x, fmaf(f1, c0.y, fmaf(f2, c0.z, fmaf(X[i], c0.w, fmaf(Y, c1.x, c1.y)))));
           const float p1 = fmaf(f0, c1.z, fmaf(f1, c1.w, fmaf(f2, c2.x, fmaf(X[i], c2.y, fmaf(Y, c2.z, c2.w)))));
           const float p2 = fmaf(f0, c3.x, fmaf(f1, c3.y, fmaf(f2, c3.z, fmaf(X[i], c3.w, fmaf(Y, c4.x, c4.y)))));
-          rgb[3 * i + 0] = __builtin_amdgcn_fmed3f(p0 + bgv[i].x, 0.0f, 1.0f);  // TT:257-258
-          rgb[3 * i + 1] = __builtin_amdgcn_fmed3f(p1 + bgv[i].y, 0.0f, 1.0f);
-          rgb[3 * i + 2] = __builtin_amdgcn_fmed3f(p2 + bgv[i].z, 0.0f, 1.0f);
-          if (valid[i])
-            *reinterpret_cast<v3f*>(reinterpret_cast<char*>(a.sh.rgb + fo * 3) + ((unsigned)e * (unsigned)W + xc[i]) * 12u) =
-                (v3f){rgb[3 * i], rgb[3 * i + 1], rgb[3 * i + 2]};
+          rgb[3 * i + 0] = __builtin_amdgcn_fmed3f(p0 + bge[3 * i + 0], 0.0f, 1.0f);  // TT:257-258
+          rgb[3 * i + 1] = __builtin_amdgcn_fmed3f(p1 + bge[3 * i + 1], 0.0f, 1.0f);
+          rgb[3 * i + 2] = __builtin_amdgcn_fmed3f(p2 + bge[3 * i + 2], 0.0f, 1.0f);
+        }
+        // RGB: this lane's 9 floats -> staging row -> contiguous 16-byte stores of the pieces inside the strip's own columns
+        wave_lds_fence();
+#pragma unroll
+        for (int j = 0; j < PX * 3; ++j) stage[lane * (PX * 3) + j] = rgb[j];
+        wave_lds_fence();
+        {
+          float* orow = a.sh.rgb + (fo + (size_t)e * W + cx0) * 3;
+#pragma unroll
+          for (int k = 0; k < 3; ++k)
+            if (stage_chunk_ok(k, (vx0 - cx0) * 3, (vx1 - cx0) * 3))
+              *reinterpret_cast<v4f*>(orow + 4 * (lane + 64 * k)) = *reinterpret_cast<const v4f*>(stage + 4 * (lane + 64 * k));
         }
         if (do_obs) {
           while (cur_o0 < ri.o0) {  // the oldest observation row in flight got its last frame row: reduce it horizontally
@@ -460,7 +546,7 @@ __global__ __launch_bounds__(64 * kStreamWaves, 2) void taxim_stream_kernel(Stre
     }
 #pragma unroll
     for (int i = 0; i < PX; ++i) { Zu[i] = Zm[i]; Zm[i] = Zd[i]; Zd[i] = cur[i]; zc[i] = zn[i]; hc[i] = hn[i]; }
-    ri_g = nri_g; ri_y = nri_y; ri_z = nri_z;
+    info = ninfo;
   }
   if (do_obs) {  // observation rows still in flight at the end of the segment (another segment adds its share)
     obs_flush(OA[0], cur_o0);
@@ -525,10 +611,14 @@ __global__ __launch_bounds__(256) void obs_finish_stream_kernel(const float* __r
 template <int... KS>
 static bool stream_geometry_t(int W, int* nstrips, int* strip_w) {
   using C = StreamCfg<KS...>;
-  const int ns = (W + C::VW - 1) / C::VW;
+  // strip widths are multiples of 4 columns: the 16-byte pieces of the staged RGB row then start and end on strip borders
+  static_assert((C::HL * kStreamPx * 3) % 4 == 0, "halo floats must be a multiple of 4 (staged 16-byte stores)");
+  int ns = (W + C::VW - 1) / C::VW;
+  int sw = (((W + ns - 1) / ns) + 3) & ~3;
+  if (sw > C::VW) { ++ns; sw = (((W + ns - 1) / ns) + 3) & ~3; }
   *nstrips = ns;
-  *strip_w = (W + ns - 1) / ns;
-  return true;
+  *strip_w = sw;
+  return sw <= C::VW;
 }
 
 // which fused level sets have a streaming instantiation (the same sets the tiled tail covers)
@@ -540,7 +630,7 @@ static int stream_variant(int n_fused, int k0) {
 
 bool stream_supported(int n_fused, int k0, int H, int W) {
   static const int en = getenv("TACEX_TAIL_STREAM") ? atoi(getenv("TACEX_TAIL_STREAM")) : 1;
-  return en != 0 && stream_variant(n_fused, k0) >= 0 && H >= 16 && W >= 16;
+  return en != 0 && stream_variant(n_fused, k0) >= 0 && H >= 16 && W >= 16 && W % 4 == 0;
 }
 
 bool stream_geometry(int n_fused, int k0, int W, int* nstrips, int* strip_w) {
@@ -562,14 +652,28 @@ int stream_segments(int B, int nstrips, int H, int sum_r) {
   return nseg;
 }
 
-template <int... KS>
-static hipError_t launch_stream(const StreamArgs& a, bool gel_zero, hipStream_t st) {
+template <bool GZ, int... KS>
+static hipError_t launch_stream_k(const StreamArgs& a, hipStream_t st) {
   const int waves = a.B * a.nstrips * a.nseg;
   const dim3 grid((waves + kStreamWaves - 1) / kStreamWaves);
-  const size_t lds = (size_t)kStreamWaves * kStreamLdsPerWave;
-  if (gel_zero) hipLaunchKernelGGL((taxim_stream_kernel<true, KS...>), grid, dim3(64 * kStreamWaves), lds, st, a);
-  else hipLaunchKernelGGL((taxim_stream_kernel<false, KS...>), grid, dim3(64 * kStreamWaves), lds, st, a);
+  const size_t lds = kStreamLdsShared + (size_t)kStreamWaves * kStreamLdsPerWave;
+  auto kern = taxim_stream_kernel<GZ, KS...>;
+  // > 64 KB of dynamic LDS is an opt-in per kernel AND device (one flag per device: contexts on several GPUs in one process)
+  static bool attr_done[64] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+  if (!attr_done[dev]) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    attr_done[dev] = true;
+  }
+  hipLaunchKernelGGL(kern, grid, dim3(64 * kStreamWaves), lds, st, a);
   return hipGetLastError();
+}
+
+template <int... KS>
+static hipError_t launch_stream(const StreamArgs& a, bool gel_zero, hipStream_t st) {
+  return gel_zero ? launch_stream_k<true, KS...>(a, st) : launch_stream_k<false, KS...>(a, st);
 }
 
 hipError_t run_stream_tail(const LevelDesc* lv, int n_levels, int n_fused, const float* zin, const float* hm, const float* gel,
