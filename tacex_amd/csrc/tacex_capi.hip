@@ -277,14 +277,18 @@ static int ensure_obs_tables(tacex_taxim_ctx* c, int oh, int ow) {
 // factors below 2, or column windows that exceed the per-wave LDS table).
 static int stream_plan(tacex_taxim_ctx* c, int n_fused, int B, int oh, int ow, const StreamPlan** out) {
   const int k0 = c->levels[c->n_levels - n_fused].kw;
-  int nstrips = 0, strip_w = 0;
-  if (!stream_geometry(n_fused, k0, c->W, &nstrips, &strip_w)) { set_error("no streaming tail for this level set"); return 1; }
-  const int nseg = stream_segments(B, nstrips, c->H, 0);
+  int nstrips = 0, strip_w = 0, lv_nstrips = 0, lv_strip_w = 0;
+  if (!stream_geometry(n_fused, k0, c->W, &nstrips, &strip_w, &lv_nstrips, &lv_strip_w)) { set_error("no streaming tail for this level set"); return 1; }
+  // the shading kernel hides its memory latency with many light waves (4 per SIMD), the levels kernel is register-heavier (2)
+  const int nseg = stream_segments(B, nstrips, c->H, stream_warm_rows(n_fused, k0, false), 4);
+  const int lv_nseg = stream_segments(B, lv_nstrips, c->H, stream_warm_rows(n_fused, k0, true), 2);
   for (auto& e : c->stream_plans)
-    if (e.oh == oh && e.ow == ow && e.nseg == nseg && e.mk_version == c->mk_version) { *out = &e.plan; return 0; }
+    if (e.oh == oh && e.ow == ow && e.nseg == nseg && e.plan.lv_nseg == lv_nseg && e.mk_version == c->mk_version) { *out = &e.plan; return 0; }
   HIP_TRY(hipSetDevice(c->device), "hipSetDevice");
   StreamPlan p{};
   p.nstrips = nstrips; p.strip_w = strip_w; p.nseg = nseg; p.seg_rows = (c->H + nseg - 1) / nseg;
+  p.lv_nstrips = lv_nstrips; p.lv_strip_w = lv_strip_w; p.lv_nseg = lv_nseg; p.lv_seg_rows = (c->H + lv_nseg - 1) / lv_nseg;
+  if (lv_nstrips * lv_nseg > (int)(tail_tiles_per_frame(c->H, c->W) * kTailWavesPerTile)) { set_error("streaming tail: FOTS partial slots exceeded"); return 1; }
   const int H = c->H, W = c->W;
   std::vector<StreamRowInfo> rows(H);
   for (int r = 0; r < H; ++r) {
@@ -584,7 +588,8 @@ static int pipeline_chunk(tacex_taxim_ctx* c, const float* hm, const float* pres
     const bool fuse_obs = want_obs && plan->obs_ready &&
                           (size_t)B * plan->nstrips * plan->nseg * plan->obs_nrows * plan->obs_ncols * 3 <= obs_scratch_floats;
     const bool pix = frame0 >= 0 && c->fots_pix_z && c->mk_x;
-    HIP_TRY(run_stream_tail(c->levels, c->n_levels, n_fused, src, hm, c->gel_dev, sa, sb, pd, &c->shade, rgb, B, c->H, c->W,
+    float* z_last = src == zbuf[0] ? zbuf[1] : zbuf[0];  // the level buffer the last band level did not write
+    HIP_TRY(run_stream_tail(c->levels, c->n_levels, n_fused, src, hm, c->gel_dev, sa, sb, pd, &c->shade, rgb, z_last, B, c->H, c->W,
                             c->contact_scale, *plan, fuse_obs ? obs_h : nullptr, fots_part,
                             (int)(tail_tiles_per_frame(c->H, c->W) * kTailWavesPerTile),
                             pix ? c->fots_pix_z + (size_t)frame0 * c->fots_taps.n_markers : nullptr,

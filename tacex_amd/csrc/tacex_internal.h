@@ -106,7 +106,8 @@ struct StreamRowInfo {
   int pad;
 };
 struct StreamPlan {
-  int nstrips = 0, strip_w = 0, nseg = 0, seg_rows = 0;
+  int nstrips = 0, strip_w = 0, nseg = 0, seg_rows = 0;              // kernel that shades (RGB, observation partial sums)
+  int lv_nstrips = 0, lv_strip_w = 0, lv_nseg = 0, lv_seg_rows = 0;  // kernel that runs the levels (FOTS partial records)
   // policy observation of one (oh, ow, nseg): device tables, valid when obs_ready
   bool obs_ready = false;
   ObsTables obs{};
@@ -121,12 +122,14 @@ struct StreamPlan {
 int stream_obs_lds_floats();
 int stream_obs_max_cols();
 bool stream_supported(int n_fused, int k0, int H, int W);
-bool stream_geometry(int n_fused, int k0, int W, int* nstrips, int* strip_w);
-int stream_segments(int B, int nstrips, int H, int sum_r);
+bool stream_geometry(int n_fused, int k0, int W, int* nstrips, int* strip_w, int* lv_nstrips, int* lv_strip_w);
+int stream_segments(int B, int nstrips, int H, int warm_rows, int waves_per_simd);
+int stream_warm_rows(int n_fused, int k0, bool levels_kernel);
+// z_last: (B,H,W) scratch for the last level (split mode: the levels kernel writes it, the shading kernel reads it)
 hipError_t run_stream_tail(const LevelDesc* lv, int n_levels, int n_fused, const float* zin, const float* hm, const float* gel,
-                           const float* sa, const float* sb, const float* pd, const ShadeParams* sp, float* rgb, int B, int H, int W,
-                           float contact_scale, const StreamPlan& plan, float* obs_part, FotsReduce* fots_part, int fots_stride,
-                           float* pix_z, uint8_t* pix_m, hipStream_t st);
+                           const float* sa, const float* sb, const float* pd, const ShadeParams* sp, float* rgb, float* z_last,
+                           int B, int H, int W, float contact_scale, const StreamPlan& plan, float* obs_part,
+                           FotsReduce* fots_part, int fots_stride, float* pix_z, uint8_t* pix_m, hipStream_t st);
 hipError_t run_obs_finish_stream(const float* part, void* obs, bool u8, const StreamPlan& plan, int B, hipStream_t st);
 
 // thread-local error string (tacex_last_error)

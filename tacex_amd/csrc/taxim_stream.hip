@@ -61,6 +61,7 @@ struct StreamArgs {
   // FOTS by-products (nullable)
   FotsReduce* fots_part;    // [frame][fots_stride]: slot strip * nseg + seg, the rest filled with identity records
   int fots_stride;
+  float* z_out;             // levels role: (B,H,W) last level
   float* pix_z; uint8_t* pix_m; int n_markers;
   const int* mk_x;          // marker column  (CSR over rows: StreamRowInfo::mk0 / mk1)
   const int* mk_id;         // marker index
@@ -89,56 +90,75 @@ __device__ __forceinline__ void wave_lds_fence() { asm volatile("s_waitcnt lgkmc
 
 typedef float v3f __attribute__((ext_vector_type(3)));
 
-template <int... KS>
+constexpr int kStreamObsLdsFloats = 512;
+constexpr int kStreamObsMaxCols = 64;
+constexpr size_t kStreamStageBytes = 64 * kStreamPx * 3 * 4;  // one row of 3 floats per pixel (background in / RGB out)
+// workgroup-shared copy of the polynomial records of magnitude bin 0 ([id][28] floats: 24 padded to 28 so that 16 lanes with
+// distinct direction bins read 16 distinct 16-byte bank slots).  Nearly all pixels outside a contact - and there the direction
+// bin still varies from pixel to pixel - gather their record from here instead of through the vector L1 (the table gathers were
+// 2/3 of the fused kernel's TCP_TOTAL_CACHE_ACCESSES: 636 per row and wave).
+constexpr int kStreamPolyPitch = 28;
+constexpr int kStreamPolyMaxBins = 128;
+constexpr size_t kStreamLdsShared = (size_t)kStreamPolyMaxBins * kStreamPolyPitch * 4;
+
+enum { kStreamFused = 0, kStreamLevels = 1, kStreamShade = 2 };
+
+// ROLE: kStreamFused  - levels + shading in one kernel (one wave keeps ~240 registers: two waves per SIMD)
+//       kStreamLevels - levels only: writes the last level (B,H,W) + the FOTS by-products; lean (four waves per SIMD)
+//       kStreamShade  - shading only (KS empty): reads the last level, writes RGB + observation partial sums
+// The split pair is the default: the fused kernel is latency-bound at two waves per SIMD (54 % of its wave cycles in
+// s_waitcnt with the table gathers, LDS staging and stores of the shading serialised behind the levels of the same wave),
+// and splitting costs 8 B/px of extra traffic (the last level is written and re-read once) for ~2.5x the speed.
+template <int ROLE, int... KS>
 struct StreamCfg {
   static constexpr int NL = sizeof...(KS);
-  static constexpr int K[NL] = {KS...};
+  static constexpr int K[NL > 0 ? NL : 1] = {KS...};
+  static constexpr bool SHADE = ROLE != kStreamLevels;
   static constexpr int R(int l) { return (K[l] - 1) / 2; }
   static constexpr int sum_r() { int s = 0; for (int i = 0; i < NL; ++i) s += R(i); return s; }
   static constexpr int delay(int l) { int s = 0; for (int i = 0; i <= l; ++i) s += R(i); return s; }  // output row = y - delay
   static constexpr int acc_off(int l) { int s = 0; for (int i = 0; i < l; ++i) s += K[i] - 1; return s; }
   static constexpr int n_acc() { return acc_off(NL); }
-  static constexpr int HALO = sum_r() + 1;                              // + the central-difference neighbour
-  static constexpr int HL = (HALO + kStreamPx - 1) / kStreamPx;         // halo lanes per side
+  static constexpr int HALO = sum_r() + (SHADE ? 1 : 0);                // + the central-difference neighbour
+  // halo lanes per side; shading roles stage their RGB row as 16-byte pieces, so the first valid float of the strip row
+  // (HL * PX * 3) must be a multiple of 4: HL is rounded up to a multiple of 4 there
+  static constexpr int HL0 = (HALO + kStreamPx - 1) / kStreamPx;
+  static constexpr int HL = SHADE ? ((HL0 + 3) & ~3) : HL0;
   static constexpr int VW = (64 - 2 * HL) * kStreamPx;                  // widest valid strip
-  static_assert(sum_r() - R(NL - 1) < kStreamRing, "restore ring too shallow");
+  static constexpr int last_r() { return NL > 0 ? R(NL - 1) : 0; }
+  static_assert(sum_r() - last_r() < kStreamRing, "restore ring too shallow");
+  // wave-private LDS: S ring [kStreamRing][64] float4 (restores) | staging row (background in / RGB out) | observation staging
+  // row | column-filter window weights [obs_ncols][obs_kxp] | window start per column
+  static constexpr size_t ring_bytes() { return NL > 1 ? (size_t)kStreamRing * 64 * 16 : 0; }
+  static constexpr size_t shade_bytes() { return SHADE ? 2 * kStreamStageBytes + kStreamObsLdsFloats * 4 + kStreamObsMaxCols * 4 : 0; }
+  static constexpr size_t lds_per_wave() { return ring_bytes() + shade_bytes(); }
+  static constexpr size_t lds_shared() { return SHADE ? kStreamLdsShared : 0; }
+  static constexpr size_t lds_bytes() { return lds_shared() + kStreamWaves * lds_per_wave(); }
 };
 
-// wave-private LDS: S ring [kStreamRing][64] float4 (.w unused) | observation staging row [64 * PX * 3] | column-filter window
-// weights [obs_ncols][obs_kxp] + window start per column [obs_ncols]
-constexpr int kStreamObsLdsFloats = 512;
-constexpr int kStreamObsMaxCols = 64;
-constexpr size_t kStreamStageBytes = 64 * kStreamPx * 3 * 4;  // one row of 3 floats per pixel (background in / RGB out)
-constexpr size_t kStreamLdsPerWave = (size_t)kStreamRing * 64 * 16 + 2 * kStreamStageBytes + kStreamObsLdsFloats * 4 + kStreamObsMaxCols * 4;
-// workgroup-shared copy of the polynomial records of magnitude bin 0 ([id][28] floats: 24 padded to 28 so that 16 lanes with
-// distinct direction bins read 16 distinct 16-byte bank slots).  Nearly all pixels outside a contact - and there the direction
-// bin still varies from pixel to pixel - gather their record from here instead of through the vector L1, whose tag pipe was the
-// kernel's bottleneck (TCP_TOTAL_CACHE_ACCESSES: 636 per row and wave, 2/3 of them table gathers, 61 % busy).
-constexpr int kStreamPolyPitch = 28;
-constexpr int kStreamPolyMaxBins = 128;
-constexpr size_t kStreamLdsShared = (size_t)kStreamPolyMaxBins * kStreamPolyPitch * 4;
-
-template <bool GZ, int... KS>
+template <bool GZ, int ROLE, int... KS>
 __global__ __launch_bounds__(64 * kStreamWaves, 2) void taxim_stream_kernel(StreamArgs a) {
-  using C = StreamCfg<KS...>;
+  using C = StreamCfg<ROLE, KS...>;
   constexpr int NL = C::NL, PX = kStreamPx, SUMR = C::sum_r(), HL = C::HL;
+  constexpr bool SHADE = C::SHADE, LEVELS = NL > 0;
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   const int lane = threadIdx.x & 63;
   const int wv_in_blk = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int per_frame = a.nstrips * a.nseg;
   const int wv = blockIdx.x * kStreamWaves + wv_in_blk;
   float* const polyL = reinterpret_cast<float*>(smem_raw);
-  {  // magnitude-bin-0 records -> LDS (all waves of the workgroup, before any of them may leave)
+  int nb_lds = 0;  // table records [0, nb_lds) are LDS-resident
+  if constexpr (SHADE) {  // magnitude-bin-0 records -> LDS (all waves of the workgroup, before any of them may leave)
     const int nb = a.sh.nb;
-    const bool use = a.sh.rgb != nullptr && nb <= kStreamPolyMaxBins;
-    if (use)
+    if (nb <= kStreamPolyMaxBins) {
+      nb_lds = nb;
       for (int j = threadIdx.x; j < nb * 6; j += 64 * kStreamWaves) {  // 6 x 16 bytes per record
         const int id = j / 6, k = j - id * 6;
         *reinterpret_cast<v4f*>(polyL + id * kStreamPolyPitch + 4 * k) = *reinterpret_cast<const v4f*>(a.sh.poly + (size_t)id * 24 + 4 * k);
       }
+    }
     __syncthreads();
   }
-  const int nb_lds = a.sh.nb <= kStreamPolyMaxBins ? a.sh.nb : 0;  // records [0, nb_lds) are LDS-resident
   if (wv >= a.B * per_frame) return;
   const int frame = wv / per_frame;
   const int rem = wv - frame * per_frame;
@@ -147,9 +167,9 @@ __global__ __launch_bounds__(64 * kStreamWaves, 2) void taxim_stream_kernel(Stre
   const int r0 = seg * a.seg_rows, r1 = min(H, r0 + a.seg_rows);  // output rows of this wave
   const int vx0 = strip * a.strip_w, vx1 = min(W, vx0 + a.strip_w);
   const int cx0 = vx0 - HL * PX;                                   // column of lane 0, pixel 0
-  char* lds = smem_raw + kStreamLdsShared + (size_t)wv_in_blk * kStreamLdsPerWave;
+  char* lds = smem_raw + C::lds_shared() + (size_t)wv_in_blk * C::lds_per_wave();
   v4f* ring = reinterpret_cast<v4f*>(lds);
-  float* stage = reinterpret_cast<float*>(ring + kStreamRing * 64);   // [64 * PX * 3] background in / RGB out staging row
+  float* stage = reinterpret_cast<float*>(lds + C::ring_bytes());    // [64 * PX * 3] background in / RGB out staging row
   float* obs_row = stage + 64 * PX * 3;                               // [64 * PX * 3] observation staging row
   float* obs_wl = obs_row + 64 * PX * 3;                              // [nq][kxp] window weights
   int* obs_xb = reinterpret_cast<int*>(obs_wl + kStreamObsLdsFloats);  // [nq] first staging pixel of the window
@@ -157,24 +177,24 @@ __global__ __launch_bounds__(64 * kStreamWaves, 2) void taxim_stream_kernel(Stre
   const size_t fo = (size_t)frame * H * W;
   const float* __restrict__ zin = a.zin + fo;
   const float* __restrict__ hm = a.hm + fo;
-  const float sa = a.shift_a[frame], sb = a.shift_b[frame];
-  const float thr = -a.pdepth[frame] * a.contact_scale;  // TT:459
-  const bool do_rgb = a.sh.rgb != nullptr;
-  const bool do_obs = a.obs_part != nullptr && do_rgb;
-  const bool do_fots = a.fots_part != nullptr;
+  float sa = 0.0f, sb = 0.0f, thr = 0.0f;
+  if constexpr (LEVELS) {
+    sa = a.shift_a[frame]; sb = a.shift_b[frame];
+    thr = -a.pdepth[frame] * a.contact_scale;  // TT:459
+  }
+  const bool do_obs = SHADE && a.obs_part != nullptr;
+  const bool do_fots = LEVELS && a.fots_part != nullptr;
 
   int xg[PX];
   unsigned xo[PX];   // reflected + clamped column (loads)
-  unsigned xc[PX];   // clamped column (background / stores)
   bool valid[PX];
   float X[PX];       // polynomial feature x of the pixel (TT:139-157)
 #pragma unroll
   for (int i = 0; i < PX; ++i) {
     xg[i] = cx0 + lane * PX + i;
     xo[i] = (unsigned)min(max(reflect_idx(xg[i], W), 0), W - 1);
-    xc[i] = (unsigned)min(max(xg[i], 0), W - 1);
     valid[i] = xg[i] >= vx0 && xg[i] < vx1;
-    X[i] = do_rgb ? a.sh.fx[xc[i]] : 0.0f;
+    X[i] = SHADE ? a.sh.fx[min(max(xg[i], 0), W - 1)] : 0.0f;
   }
   // input rows come in as ONE 12-byte load per lane; the few lanes with a pixel outside the image (reflect padding) re-load
   // their three pixels one by one at the mirrored columns
@@ -183,36 +203,46 @@ __global__ __launch_bounds__(64 * kStreamWaves, 2) void taxim_stream_kernel(Stre
   auto load_row = [&](int row, float (&zz)[PX], float (&hh)[PX]) {
     const unsigned ro = (unsigned)row * (unsigned)W;
     const v3f z3 = *reinterpret_cast<const v3f*>(zin + ro + xb);
-    const v3f h3 = *reinterpret_cast<const v3f*>(hm + ro + xb);
-    zz[0] = z3.x; zz[1] = z3.y; zz[2] = z3.z; hh[0] = h3.x; hh[1] = h3.y; hh[2] = h3.z;
+    zz[0] = z3.x; zz[1] = z3.y; zz[2] = z3.z;
+    if constexpr (LEVELS) {
+      const v3f h3 = *reinterpret_cast<const v3f*>(hm + ro + xb);
+      hh[0] = h3.x; hh[1] = h3.y; hh[2] = h3.z;
+    }
     if (border) {
 #pragma unroll
-      for (int i = 0; i < PX; ++i) { zz[i] = zin[ro + xo[i]]; hh[i] = hm[ro + xo[i]]; }
+      for (int i = 0; i < PX; ++i) {
+        zz[i] = zin[ro + xo[i]];
+        if constexpr (LEVELS) hh[i] = hm[ro + xo[i]];
+      }
     }
   };
 
   // ---- policy observation set-up: this strip's column filters as fixed-length windows over the staging row ----
-  const int q0 = do_obs ? a.obs_strip_q0[strip] : 0, nq = do_obs ? a.obs_strip_nq[strip] : 0;
+  int nq = 0;
   const int kxp = a.obs_kxp;
-  if (do_obs) {
-    for (int j = lane; j < nq; j += 64) {
-      const int q = q0 + j;
-      int xb = max(a.obs_xlo[q], vx0) - cx0;
-      xb = min(xb, 64 * PX - kxp);
-      obs_xb[j] = xb;
+  if constexpr (SHADE) {
+    if (do_obs) {
+      const int q0 = a.obs_strip_q0[strip];
+      nq = a.obs_strip_nq[strip];
+      for (int j = lane; j < nq; j += 64) {
+        const int q = q0 + j;
+        int xb2 = max(a.obs_xlo[q], vx0) - cx0;
+        xb2 = min(xb2, 64 * PX - kxp);
+        obs_xb[j] = xb2;
+      }
+      wave_lds_fence();
+      for (int j = lane; j < nq * kxp; j += 64) {
+        const int qi = j / kxp, t = j - qi * kxp, q = q0 + qi;
+        const int x = obs_xb[qi] + t + cx0;  // frame column of this tap
+        const int xlo = a.obs_xlo[q];
+        obs_wl[j] = (x >= xlo && x < xlo + a.obs_xcnt[q] && x >= vx0 && x < vx1) ? a.obs_wx[(size_t)q * a.obs_kx + (x - xlo)] : 0.0f;
+      }
+      wave_lds_fence();
     }
-    wave_lds_fence();
-    for (int j = lane; j < nq * kxp; j += 64) {
-      const int qi = j / kxp, t = j - qi * kxp, q = q0 + qi;
-      const int x = obs_xb[qi] + t + cx0;  // frame column of this tap
-      const int xlo = a.obs_xlo[q];
-      obs_wl[j] = (x >= xlo && x < xlo + a.obs_xcnt[q] && x >= vx0 && x < vx1) ? a.obs_wx[(size_t)q * a.obs_kx + (x - xlo)] : 0.0f;
-    }
-    wave_lds_fence();
   }
 
   // taps (wave-uniform: scalar registers)
-  float w[C::n_acc() + NL];  // level l: w[acc_off(l) + l + t], t < K
+  float w[C::n_acc() + NL + 1];  // level l: w[acc_off(l) + l + t], t < K
   static_for<0, NL>([&](auto lc) {
     constexpr int l = decltype(lc)::value;
     static_for<0, C::K[l]>([&](auto tc) {
@@ -273,12 +303,12 @@ __global__ __launch_bounds__(64 * kStreamWaves, 2) void taxim_stream_kernel(Stre
     wave_lds_fence();
   };
 
-  // Iteration y: input row y enters level 0; the last level leaves row y - SUMR (-> Zd at the END of the iteration); the row
-  // shaded in this iteration is gs = y - SUMR - 2, whose neighbours (Zu, Zm, Zd) = rows gs-1, gs, gs+1 are complete at the
-  // START of the iteration: its bins are computed and its table / background loads issued FIRST, the levels of this iteration
-  // run under their latency, the polynomial + stores come last.
-  const int ys = r0 - SUMR - 1, ye = r1 + SUMR + 1;
-  float zc[PX], hc[PX];
+  // Iteration y: input row y enters level 0; the last level leaves row zr = y - SUMR.  With shading, the row shaded in an
+  // iteration is gs = y - SUMR - 2, whose neighbours (Zu, Zm, Zd) = rows gs-1, gs, gs+1 are complete at the START of the
+  // iteration: its bins are computed and its background loads issued early, the levels run under their latency.
+  const int ys = SHADE ? r0 - SUMR - 1 : r0 - SUMR;
+  const int ye = SHADE ? r1 + SUMR + 1 : r1 - 1 + SUMR;
+  float zc[PX], hc[PX] = {0.f, 0.f, 0.f};
   load_row(row_of(ys), zc, hc);
   // Row scalars, fetched one iteration ahead with a VECTOR load (lanes 0-7: record of the row shaded, 8-15: of the row
   // entering, 16-23: of the row leaving the last level) and moved to scalar registers with v_readlane: scalar-memory loads
@@ -289,270 +319,310 @@ __global__ __launch_bounds__(64 * kStreamWaves, 2) void taxim_stream_kernel(Stre
     const int r = row_of(k == 0 ? yy - SUMR - 2 : (k == 1 ? yy : yy - SUMR));
     return lane < 24 ? rows_i[r * 8 + (lane & 7)] : 0;
   };
-  int info = load_info(ys);
+  StreamRowInfo ri_g{}, ri_y{}, ri_z{};
+  auto unpack_info = [&](int info) {
+    if constexpr (SHADE) {
+      ri_g.fy = __int_as_float(__builtin_amdgcn_readlane(info, 0)); ri_g.o0 = __builtin_amdgcn_readlane(info, 1);
+      ri_g.w0 = __int_as_float(__builtin_amdgcn_readlane(info, 2)); ri_g.w1 = __int_as_float(__builtin_amdgcn_readlane(info, 3));
+      ri_g.w2 = __int_as_float(__builtin_amdgcn_readlane(info, 4));
+    }
+    if constexpr (LEVELS) {
+      ri_y.mk0 = __builtin_amdgcn_readlane(info, 8 + 5); ri_y.mk1 = __builtin_amdgcn_readlane(info, 8 + 6);
+      ri_z.mk0 = __builtin_amdgcn_readlane(info, 16 + 5); ri_z.mk1 = __builtin_amdgcn_readlane(info, 16 + 6);
+    }
+  };
+  unpack_info(load_info(ys));
   for (int y = ys; y <= ye; ++y) {
-    // ---- prefetch the next input row and the next iteration's row scalars ----
-    float zn[PX], hn[PX];
+    // ---- prefetch the next input row and the next iteration's row scalars (consumed at the END of this iteration) ----
+    float zn[PX], hn[PX] = {0.f, 0.f, 0.f};
     load_row(row_of(y + 1), zn, hn);
-    const int ninfo = load_info(y + 1);
-    StreamRowInfo ri_g, ri_y, ri_z;
-    ri_g.fy = __int_as_float(__builtin_amdgcn_readlane(info, 0)); ri_g.o0 = __builtin_amdgcn_readlane(info, 1);
-    ri_g.w0 = __int_as_float(__builtin_amdgcn_readlane(info, 2)); ri_g.w1 = __int_as_float(__builtin_amdgcn_readlane(info, 3));
-    ri_g.w2 = __int_as_float(__builtin_amdgcn_readlane(info, 4));
-    ri_y.mk0 = __builtin_amdgcn_readlane(info, 8 + 5); ri_y.mk1 = __builtin_amdgcn_readlane(info, 8 + 6);
-    ri_z.mk0 = __builtin_amdgcn_readlane(info, 16 + 5); ri_z.mk1 = __builtin_amdgcn_readlane(info, 16 + 6);
+    int ninfo = load_info(y + 1);
 
-    // ---- shading, part 1 (runs between level 0 and level 1, see below): bins of row gs, table / background loads in flight.
+    // ---- shading, part 1 (runs between level 0 and level 1, see below): bins of row gs, background loads in flight.
     //      Replicate padding of the gradient maps (TT:501-502): rows 0 / H-1 take the gradient of rows 1 / H-2 and are emitted
     //      together with them; columns 0 / W-1 take the bins of columns 1 / W-2. ----
     const int gs = y - SUMR - 2;
-    const bool shade_now = do_rgb && gs >= max(r0, 1) && gs <= min(r1 - 1, H - 2);
+    const bool shade_now = SHADE && gs >= max(r0, 1) && gs <= min(r1 - 1, H - 2);
     int cc[PX] = {0, 0, 0};  // table record (bin pair) of every pixel of row gs
     // The strip's background / RGB row is 64 x 9 floats.  A lane owns floats [9 l, 9 l + 9); read or written that way every
     // 16-byte access instruction would touch all 36 cache lines of the row.  Instead the row moves between global memory and
     // the wave's LDS staging row as CONTIGUOUS 16-byte pieces (lane l: floats [4 (l + 64 k), + 4), k = 0..2) and the lanes pick
     // their own 9 floats out of LDS.
-    v4f bgq[3];
-    auto stage_chunk_ok = [&](int k, int lo_f, int hi_f) -> bool {  // chunk k of this lane inside [lo_f, hi_f) floats of the strip row?
+    v4f bgq[3] = {(v4f)(0.0f), (v4f)(0.0f), (v4f)(0.0f)};
+    auto stage_chunk_ok = [&](int k, int lo_f, int hi_f) -> bool {  // piece k of this lane inside [lo_f, hi_f) floats of the strip row?
       const int f = 4 * (lane + 64 * k);
       return f >= lo_f && f + 4 <= hi_f && f < 64 * PX * 3;
     };
     auto shade_part1 = [&]() {
-      if (!shade_now) return;
-      const float zl = dpp_from_left(Zm[PX - 1]), zrg = dpp_from_right(Zm[0]);
-      int code[PX];
+      if constexpr (SHADE) {
+        if (!shade_now) return;
+        const float zl = dpp_from_left(Zm[PX - 1]), zrg = dpp_from_right(Zm[0]);
+        int code[PX];
 #pragma unroll
-      for (int i = 0; i < PX; ++i) {
-        int im, id;
-        shade_bins(a.sh, Zu[i], Zd[i], i == 0 ? zl : Zm[i - 1], i == PX - 1 ? zrg : Zm[i + 1], im, id);
-        code[i] = im * a.sh.nb + id;
-      }
-      const int cl = dpp_from_left_i(code[PX - 1]), cr = dpp_from_right_i(code[0]);
-#pragma unroll
-      for (int i = 0; i < PX; ++i) {
-        const int right = i == PX - 1 ? cr : code[i + 1], left = i == 0 ? cl : code[i - 1];
-        cc[i] = xg[i] == 0 ? right : (xg[i] == W - 1 ? left : code[i]);
-      }
-      // background of row gs: the in-image part of the strip row, issued now, consumed after the remaining levels
-      const float* bgrow = a.sh.bg + ((size_t)gs * W + cx0) * 3;  // float 0 of the strip row (may lie left of the image)
-#pragma unroll
-      for (int k = 0; k < 3; ++k)
-        bgq[k] = stage_chunk_ok(k, -cx0 * 3 > 0 ? -cx0 * 3 : 0, (W - cx0) * 3) ? *reinterpret_cast<const v4f*>(bgrow + 4 * (lane + 64 * k))
-                                                                            : (v4f)(0.0f);
-    };
-
-    // ---- S of this row into the ring; contact statistics of the rows this wave owns ----
-    float S[PX];
-#pragma unroll
-    for (int i = 0; i < PX; ++i) S[i] = (hc[i] - sa) - sb;  // TT:441
-    ring[(y & (kStreamRing - 1)) * 64 + lane] = (v4f){S[0], S[1], S[2], 0.0f};
-    // S of the rows the restores of this iteration need (written 4..7 iterations ago): all ring reads issued up front
-    v4f Sring[NL > 1 ? NL - 1 : 1];
-    static_for<0, NL - 1>([&](auto lc) {
-      constexpr int l = decltype(lc)::value;
-      Sring[l] = ring[((y - C::delay(l)) & (kStreamRing - 1)) * 64 + lane];
-    });
-    if (do_fots && y >= r0 && y < r1) {
-      float gl[PX] = {0.f, 0.f, 0.f};
-      if constexpr (!GZ) {
-        const unsigned ro = (unsigned)row_of(y) * (unsigned)W;
-#pragma unroll
-        for (int i = 0; i < PX; ++i) gl[i] = a.gel[ro + xo[i]];
-      }
-      int mrow[PX];
-#pragma unroll
-      for (int i = 0; i < PX; ++i) {
-        const float J = fmin_raw(S[i], gl[i]);
-        const int m1 = (valid[i] && ((J - gl[i]) < thr) && (S[i] < 0.0f)) ? 1 : 0;  // TT:457-461
-        mrow[i] = m1;
-        f_cnt += m1; f_sr += m1 * y; f_sc += m1 * xg[i];
-      }
-      if (a.pix_m != nullptr) {  // contact mask at the FOTS marker pixels of this row
-        for (int e = ri_y.mk0; e < ri_y.mk1; ++e) {
-          const int mx = a.mk_x[e];
-          const int d = mx - cx0 - lane * PX;
-          if (d >= 0 && d < PX && mx >= vx0 && mx < vx1)
-            a.pix_m[(size_t)frame * a.n_markers + a.mk_id[e]] = (uint8_t)(d == 0 ? mrow[0] : (d == 1 ? mrow[1] : mrow[2]));
+        for (int i = 0; i < PX; ++i) {
+          int im, id;
+          shade_bins(a.sh, Zu[i], Zd[i], i == 0 ? zl : Zm[i - 1], i == PX - 1 ? zrg : Zm[i + 1], im, id);
+          code[i] = im * a.sh.nb + id;
         }
+        const int cl = dpp_from_left_i(code[PX - 1]), cr = dpp_from_right_i(code[0]);
+#pragma unroll
+        for (int i = 0; i < PX; ++i) {
+          const int right = i == PX - 1 ? cr : code[i + 1], left = i == 0 ? cl : code[i - 1];
+          cc[i] = xg[i] == 0 ? right : (xg[i] == W - 1 ? left : code[i]);
+        }
+        // background of row gs: the in-image part of the strip row, issued now, consumed after the remaining levels
+        const float* bgrow = a.sh.bg + ((size_t)gs * W + cx0) * 3;  // float 0 of the strip row (may lie left of the image)
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+          bgq[k] = stage_chunk_ok(k, -cx0 * 3 > 0 ? -cx0 * 3 : 0, (W - cx0) * 3) ? *reinterpret_cast<const v4f*>(bgrow + 4 * (lane + 64 * k))
+                                                                              : (v4f)(0.0f);
       }
-    }
-    // ---- the levels: horizontal pass over the lanes, vertical scatter into the partial sums, masked restore ----
+    };
+    if constexpr (!LEVELS) shade_part1();
+
     float cur[PX];
 #pragma unroll
     for (int i = 0; i < PX; ++i) cur[i] = zc[i];
-    static_for<0, NL>([&](auto lc) {
-      constexpr int l = decltype(lc)::value;
-      constexpr int K = C::K[l], R = C::R(l), WO = C::acc_off(l) + l, AO = C::acc_off(l);
-      // the widest window (level 0) is done: issue the shading loads of row gs now, the remaining levels run under their latency
-      if constexpr (l == (NL > 1 ? 1 : 0)) shade_part1();
-      float h[PX];
-      if constexpr (K == 1) {
+    if constexpr (LEVELS) {
+      // ---- S of this row into the ring; contact statistics of the rows this wave owns ----
+      float S[PX];
 #pragma unroll
-        for (int i = 0; i < PX; ++i) h[i] = cur[i];
-      } else {
-        // window of pixel offsets -R .. PX - 1 + R around this lane's pixels, gathered from the neighbouring lanes
-        constexpr int NS = (R + PX - 1) / PX;  // lanes needed on each side
-        float win[PX + 2 * R];
-        float L[PX], Rr[PX];
-#pragma unroll
-        for (int i = 0; i < PX; ++i) { L[i] = cur[i]; Rr[i] = cur[i]; win[R + i] = cur[i]; }
-        static_for<1, NS + 1>([&](auto kc) {
-          constexpr int k = decltype(kc)::value;
-#pragma unroll
-          for (int i = 0; i < PX; ++i) { L[i] = dpp_from_left(L[i]); Rr[i] = dpp_from_right(Rr[i]); }
-          static_for<0, PX>([&](auto ic) {
-            constexpr int i = decltype(ic)::value;
-            constexpr int pl = -k * PX + i;    // pixel offset of lane -k, pixel i
-            constexpr int pr = k * PX + i;
-            if constexpr (pl >= -R) win[R + pl] = L[i];
-            if constexpr (pr <= PX - 1 + R) win[R + pr] = Rr[i];
-          });
+      for (int i = 0; i < PX; ++i) S[i] = (hc[i] - sa) - sb;  // TT:441
+      v4f Sring[NL > 1 ? NL - 1 : 1];
+      if constexpr (NL > 1) {
+        ring[(y & (kStreamRing - 1)) * 64 + lane] = (v4f){S[0], S[1], S[2], 0.0f};
+        // S of the rows the restores of this iteration need (written 4..7 iterations ago): all ring reads issued up front
+        static_for<0, NL - 1>([&](auto lc) {
+          constexpr int l = decltype(lc)::value;
+          Sring[l] = ring[((y - C::delay(l)) & (kStreamRing - 1)) * 64 + lane];
         });
-#pragma unroll
-        for (int i = 0; i < PX; ++i) {
-          float o = 0.0f;
-          static_for<0, K>([&](auto tc) {
-            constexpr int t = decltype(tc)::value;
-            o = fmaf(w[WO + t], win[i + t], o);
-          });
-          h[i] = o;
-        }
       }
-      float out[PX];
-      if constexpr (K == 1) {
-#pragma unroll
-        for (int i = 0; i < PX; ++i) out[i] = h[i];
-      } else {
-#pragma unroll
-        for (int i = 0; i < PX; ++i) {
-          out[i] = fma_to(w[WO + K - 1], h[i], A[AO + K - 2][i]);
-          static_for<0, K - 2>([&](auto jc) {
-            constexpr int j = K - 2 - decltype(jc)::value;  // K-2 .. 1
-            A[AO + j][i] = fma_to(w[WO + j], h[i], A[AO + j - 1][i]);
-          });
-          A[AO][i] = w[WO] * h[i];
-        }
-      }
-      if constexpr (l < NL - 1) {  // TT:467 Z[M] = J[M]; the final blur (TT:468-471) has no restore
-        [[maybe_unused]] const int rr = y - C::delay(l);
-        const v4f Sv = Sring[l];
+      if (do_fots && y >= r0 && y < r1) {
         float gl[PX] = {0.f, 0.f, 0.f};
         if constexpr (!GZ) {
-          const unsigned ro = (unsigned)row_of(rr) * (unsigned)W;
+          const unsigned ro = (unsigned)row_of(y) * (unsigned)W;
 #pragma unroll
           for (int i = 0; i < PX; ++i) gl[i] = a.gel[ro + xo[i]];
         }
+        int mrow[PX];
 #pragma unroll
         for (int i = 0; i < PX; ++i) {
-          const float Si = Sv[i];
-          const float J = fmin_raw(Si, gl[i]);
-          out[i] = (((J - gl[i]) < thr) && (Si < 0.0f)) ? J : out[i];
+          const float J = fmin_raw(S[i], gl[i]);
+          const int m1 = (valid[i] && ((J - gl[i]) < thr) && (S[i] < 0.0f)) ? 1 : 0;  // TT:457-461
+          mrow[i] = m1;
+          f_cnt += m1; f_sr += m1 * y; f_sc += m1 * xg[i];
+        }
+        if (a.pix_m != nullptr) {  // contact mask at the FOTS marker pixels of this row
+          for (int e = ri_y.mk0; e < ri_y.mk1; ++e) {
+            const int mx = a.mk_x[e];
+            const int d = mx - cx0 - lane * PX;
+            if (d >= 0 && d < PX && mx >= vx0 && mx < vx1)
+              a.pix_m[(size_t)frame * a.n_markers + a.mk_id[e]] = (uint8_t)(d == 0 ? mrow[0] : (d == 1 ? mrow[1] : mrow[2]));
+          }
         }
       }
+      // ---- the levels: horizontal pass over the lanes, vertical scatter into the partial sums, masked restore ----
+      static_for<0, NL>([&](auto lc) {
+        constexpr int l = decltype(lc)::value;
+        constexpr int K = C::K[l], R = C::R(l), WO = C::acc_off(l) + l, AO = C::acc_off(l);
+        // the widest window (level 0) is done: issue the shading loads of row gs now, the remaining levels run under their latency
+        if constexpr (l == (NL > 1 ? 1 : 0)) shade_part1();
+        float h[PX];
+        if constexpr (K == 1) {
 #pragma unroll
-      for (int i = 0; i < PX; ++i) cur[i] = out[i];
-    });
-    // ---- cur = last-level row zr = y - SUMR ----
-    const int zr = y - SUMR;
-    if (zr >= r0 && zr < r1) {
-      if (do_fots) {
+          for (int i = 0; i < PX; ++i) h[i] = cur[i];
+        } else {
+          // window of pixel offsets -R .. PX - 1 + R around this lane's pixels, gathered from the neighbouring lanes
+          constexpr int NS = (R + PX - 1) / PX;  // lanes needed on each side
+          float win[PX + 2 * R];
+          float L[PX], Rr[PX];
 #pragma unroll
-        for (int i = 0; i < PX; ++i) f_zmax = valid[i] ? fmaxf(f_zmax, cur[i]) : f_zmax;
-      }
-      if (a.pix_z != nullptr) {
-        for (int e = ri_z.mk0; e < ri_z.mk1; ++e) {
-          const int mx = a.mk_x[e];
-          const int d = mx - cx0 - lane * PX;
-          if (d >= 0 && d < PX && mx >= vx0 && mx < vx1)
-            a.pix_z[(size_t)frame * a.n_markers + a.mk_id[e]] = d == 0 ? cur[0] : (d == 1 ? cur[1] : cur[2]);
+          for (int i = 0; i < PX; ++i) { L[i] = cur[i]; Rr[i] = cur[i]; win[R + i] = cur[i]; }
+          static_for<1, NS + 1>([&](auto kc) {
+            constexpr int k = decltype(kc)::value;
+#pragma unroll
+            for (int i = 0; i < PX; ++i) { L[i] = dpp_from_left(L[i]); Rr[i] = dpp_from_right(Rr[i]); }
+            static_for<0, PX>([&](auto ic) {
+              constexpr int i = decltype(ic)::value;
+              constexpr int pl = -k * PX + i;    // pixel offset of lane -k, pixel i
+              constexpr int pr = k * PX + i;
+              if constexpr (pl >= -R) win[R + pl] = L[i];
+              if constexpr (pr <= PX - 1 + R) win[R + pr] = Rr[i];
+            });
+          });
+#pragma unroll
+          for (int i = 0; i < PX; ++i) {
+            float o = 0.0f;
+            static_for<0, K>([&](auto tc) {
+              constexpr int t = decltype(tc)::value;
+              o = fmaf(w[WO + t], win[i + t], o);
+            });
+            h[i] = o;
+          }
+        }
+        float out[PX];
+        if constexpr (K == 1) {
+#pragma unroll
+          for (int i = 0; i < PX; ++i) out[i] = h[i];
+        } else {
+#pragma unroll
+          for (int i = 0; i < PX; ++i) {
+            out[i] = fma_to(w[WO + K - 1], h[i], A[AO + K - 2][i]);
+            static_for<0, K - 2>([&](auto jc) {
+              constexpr int j = K - 2 - decltype(jc)::value;  // K-2 .. 1
+              A[AO + j][i] = fma_to(w[WO + j], h[i], A[AO + j - 1][i]);
+            });
+            A[AO][i] = w[WO] * h[i];
+          }
+        }
+        if constexpr (l < NL - 1) {  // TT:467 Z[M] = J[M]; the final blur (TT:468-471) has no restore
+          const v4f Sv = Sring[l];
+          float gl[PX] = {0.f, 0.f, 0.f};
+          if constexpr (!GZ) {
+            const unsigned ro = (unsigned)row_of(y - C::delay(l)) * (unsigned)W;
+#pragma unroll
+            for (int i = 0; i < PX; ++i) gl[i] = a.gel[ro + xo[i]];
+          }
+#pragma unroll
+          for (int i = 0; i < PX; ++i) {
+            const float Si = Sv[i];
+            const float J = fmin_raw(Si, gl[i]);
+            out[i] = (((J - gl[i]) < thr) && (Si < 0.0f)) ? J : out[i];
+          }
+        }
+#pragma unroll
+        for (int i = 0; i < PX; ++i) cur[i] = out[i];
+      });
+      // ---- cur = last-level row zr = y - SUMR ----
+      const int zr = y - SUMR;
+      if (zr >= r0 && zr < r1) {
+        if (do_fots) {
+#pragma unroll
+          for (int i = 0; i < PX; ++i) f_zmax = valid[i] ? fmaxf(f_zmax, cur[i]) : f_zmax;
+        }
+        if (a.pix_z != nullptr) {
+          for (int e = ri_z.mk0; e < ri_z.mk1; ++e) {
+            const int mx = a.mk_x[e];
+            const int d = mx - cx0 - lane * PX;
+            if (d >= 0 && d < PX && mx >= vx0 && mx < vx1)
+              a.pix_z[(size_t)frame * a.n_markers + a.mk_id[e]] = d == 0 ? cur[0] : (d == 1 ? cur[1] : cur[2]);
+          }
+        }
+        if constexpr (!SHADE) {  // levels role: the last level goes to HBM (12 contiguous bytes per lane)
+          if (valid[0] && valid[PX - 1]) {
+            *reinterpret_cast<v3f*>(a.z_out + fo + (size_t)zr * W + xg[0]) = (v3f){cur[0], cur[1], cur[2]};
+          } else {
+#pragma unroll
+            for (int i = 0; i < PX; ++i)
+              if (valid[i]) a.z_out[fo + (size_t)zr * W + xg[i]] = cur[i];
+          }
         }
       }
     }
     // ---- shading, part 2: table records, polynomial, background, clip, store, observation ----
-    if (shade_now) {
-      // records: magnitude bin 0 (code < nb) from the workgroup's LDS copy, the others gathered from the table in L2
-      v4f pc[PX][5];
-#pragma unroll
-      for (int i = 0; i < PX; ++i) {
-        if (cc[i] < nb_lds) {
-          const v4f* pl = reinterpret_cast<const v4f*>(polyL + cc[i] * kStreamPolyPitch);
-          pc[i][0] = pl[0]; pc[i][1] = pl[1]; pc[i][2] = pl[2]; pc[i][3] = pl[3]; pc[i][4] = pl[4];
-        } else {
-          const v4f* __restrict__ pp = reinterpret_cast<const v4f*>(reinterpret_cast<const char*>(a.sh.poly) + (unsigned)cc[i] * 96u);
-          pc[i][0] = pp[0]; pc[i][1] = pp[1]; pc[i][2] = pp[2]; pc[i][3] = pp[3]; pc[i][4] = pp[4];
-        }
-      }
-      const int e_lo = gs == 1 ? 0 : gs, e_hi = gs == H - 2 ? H - 1 : gs;  // rows emitted by this iteration (ascending)
-      for (int e = e_lo; e <= e_hi; ++e) {
-        if (e < r0 || e >= r1) continue;
-        StreamRowInfo ri = ri_g;
-        if (e != gs) {  // a replicated border row: its own feature / background / observation row (twice per frame)
-          ri = a.rows[e];
-          const float* bgrow = a.sh.bg + ((size_t)e * W + cx0) * 3;
-#pragma unroll
-          for (int k = 0; k < 3; ++k)
-            bgq[k] = stage_chunk_ok(k, -cx0 * 3 > 0 ? -cx0 * 3 : 0, (W - cx0) * 3) ? *reinterpret_cast<const v4f*>(bgrow + 4 * (lane + 64 * k))
-                                                                                : (v4f)(0.0f);
-        }
-        // background: contiguous pieces -> staging row -> this lane's 9 floats
-        wave_lds_fence();
-#pragma unroll
-        for (int k = 0; k < 3; ++k)
-          if (4 * (lane + 64 * k) < 64 * PX * 3) *reinterpret_cast<v4f*>(stage + 4 * (lane + 64 * k)) = bgq[k];
-        wave_lds_fence();
-        float bge[PX * 3];
-#pragma unroll
-        for (int j = 0; j < PX * 3; ++j) bge[j] = stage[lane * (PX * 3) + j];
-        const float Y = ri.fy;
-        float rgb[PX * 3];
+    if constexpr (SHADE) {
+      if (shade_now) {
+        // Table records: magnitude bin 0 (code < nb) from the workgroup's LDS copy - every lane reads (clamped index), one wait -
+        // then the lanes of contact pixels overwrite theirs with a gather from the table in L2; row segments without such a
+        // lane (most of them) issue no vector-memory instruction for the table at all.
+        v4f pc[PX][5];
+        bool hi[PX];
 #pragma unroll
         for (int i = 0; i < PX; ++i) {
-          const v4f c0 = pc[i][0], c1 = pc[i][1], c2 = pc[i][2], c3 = pc[i][3], c4 = pc[i][4];
-          const float f0 = X[i] * X[i], f1 = Y * Y, f2 = X[i] * Y;
-          const float p0 = fmaf(f0, c0.x, fmaf(f1, c0.y, fmaf(f2, c0.z, fmaf(X[i], c0.w, fmaf(Y, c1.x, c1.y)))));
-          const float p1 = fmaf(f0, c1.z, fmaf(f1, c1.w, fmaf(f2, c2.x, fmaf(X[i], c2.y, fmaf(Y, c2.z, c2.w)))));
-          const float p2 = fmaf(f0, c3.x, fmaf(f1, c3.y, fmaf(f2, c3.z, fmaf(X[i], c3.w, fmaf(Y, c4.x, c4.y)))));
-          rgb[3 * i + 0] = __builtin_amdgcn_fmed3f(p0 + bge[3 * i + 0], 0.0f, 1.0f);  // TT:257-258
-          rgb[3 * i + 1] = __builtin_amdgcn_fmed3f(p1 + bge[3 * i + 1], 0.0f, 1.0f);
-          rgb[3 * i + 2] = __builtin_amdgcn_fmed3f(p2 + bge[3 * i + 2], 0.0f, 1.0f);
+          hi[i] = cc[i] >= nb_lds;
+          const v4f* pl = reinterpret_cast<const v4f*>(polyL + (hi[i] ? 0 : cc[i]) * kStreamPolyPitch);
+          pc[i][0] = pl[0]; pc[i][1] = pl[1]; pc[i][2] = pl[2]; pc[i][3] = pl[3]; pc[i][4] = pl[4];
         }
-        // RGB: this lane's 9 floats -> staging row -> contiguous 16-byte stores of the pieces inside the strip's own columns
-        wave_lds_fence();
+        if (__builtin_amdgcn_ballot_w64(hi[0] || hi[1] || hi[2]) != 0) {
 #pragma unroll
-        for (int j = 0; j < PX * 3; ++j) stage[lane * (PX * 3) + j] = rgb[j];
-        wave_lds_fence();
-        {
-          float* orow = a.sh.rgb + (fo + (size_t)e * W + cx0) * 3;
-#pragma unroll
-          for (int k = 0; k < 3; ++k)
-            if (stage_chunk_ok(k, (vx0 - cx0) * 3, (vx1 - cx0) * 3))
-              *reinterpret_cast<v4f*>(orow + 4 * (lane + 64 * k)) = *reinterpret_cast<const v4f*>(stage + 4 * (lane + 64 * k));
+          for (int i = 0; i < PX; ++i)
+            if (hi[i]) {
+              const v4f* __restrict__ pp = reinterpret_cast<const v4f*>(reinterpret_cast<const char*>(a.sh.poly) + (unsigned)cc[i] * 96u);
+              pc[i][0] = pp[0]; pc[i][1] = pp[1]; pc[i][2] = pp[2]; pc[i][3] = pp[3]; pc[i][4] = pp[4];
+            }
         }
-        if (do_obs) {
-          while (cur_o0 < ri.o0) {  // the oldest observation row in flight got its last frame row: reduce it horizontally
-            obs_flush(OA[0], cur_o0);
+        const int e_lo = gs == 1 ? 0 : gs, e_hi = gs == H - 2 ? H - 1 : gs;  // rows emitted by this iteration (ascending)
+        for (int e = e_lo; e <= e_hi; ++e) {
+          if (e < r0 || e >= r1) continue;
+          StreamRowInfo ri = ri_g;
+          v4f bq[3] = {bgq[0], bgq[1], bgq[2]};
+          if (e != gs) {  // a replicated border row: its own feature / background / observation row (twice per frame)
+            ri = a.rows[e];
+            const float* bgrow = a.sh.bg + ((size_t)e * W + cx0) * 3;
 #pragma unroll
-            for (int j = 0; j < PX * 3; ++j) { OA[0][j] = OA[1][j]; OA[1][j] = OA[2][j]; OA[2][j] = 0.0f; }
-            ++cur_o0;
+            for (int k = 0; k < 3; ++k)
+              bq[k] = stage_chunk_ok(k, -cx0 * 3 > 0 ? -cx0 * 3 : 0, (W - cx0) * 3) ? *reinterpret_cast<const v4f*>(bgrow + 4 * (lane + 64 * k))
+                                                                                 : (v4f)(0.0f);
           }
+          // background: contiguous pieces -> staging row -> this lane's 9 floats.  (Piece 2 of lanes >= 16 lies beyond the
+          // staging row: it lands in / comes from the observation staging row behind it, which is only live inside obs_flush.)
+          wave_lds_fence();
 #pragma unroll
-          for (int j = 0; j < PX * 3; ++j) {
-            OA[0][j] = fmaf(ri.w0, rgb[j], OA[0][j]);
-            OA[1][j] = fmaf(ri.w1, rgb[j], OA[1][j]);
-            OA[2][j] = fmaf(ri.w2, rgb[j], OA[2][j]);
+          for (int k = 0; k < 3; ++k) *reinterpret_cast<v4f*>(stage + 4 * (lane + 64 * k)) = bq[k];
+          wave_lds_fence();
+          float bge[PX * 3];
+#pragma unroll
+          for (int j = 0; j < PX * 3; ++j) bge[j] = stage[lane * (PX * 3) + j];
+          const float Y = ri.fy;
+          float rgb[PX * 3];
+#pragma unroll
+          for (int i = 0; i < PX; ++i) {
+            const v4f c0 = pc[i][0], c1 = pc[i][1], c2 = pc[i][2], c3 = pc[i][3], c4 = pc[i][4];
+            const float f0 = X[i] * X[i], f1 = Y * Y, f2 = X[i] * Y;
+            const float p0 = fmaf(f0, c0.x, fmaf(f1, c0.y, fmaf(f2, c0.z, fmaf(X[i], c0.w, fmaf(Y, c1.x, c1.y)))));
+            const float p1 = fmaf(f0, c1.z, fmaf(f1, c1.w, fmaf(f2, c2.x, fmaf(X[i], c2.y, fmaf(Y, c2.z, c2.w)))));
+            const float p2 = fmaf(f0, c3.x, fmaf(f1, c3.y, fmaf(f2, c3.z, fmaf(X[i], c3.w, fmaf(Y, c4.x, c4.y)))));
+            rgb[3 * i + 0] = __builtin_amdgcn_fmed3f(p0 + bge[3 * i + 0], 0.0f, 1.0f);  // TT:257-258
+            rgb[3 * i + 1] = __builtin_amdgcn_fmed3f(p1 + bge[3 * i + 1], 0.0f, 1.0f);
+            rgb[3 * i + 2] = __builtin_amdgcn_fmed3f(p2 + bge[3 * i + 2], 0.0f, 1.0f);
+          }
+          // RGB: this lane's 9 floats -> staging row -> contiguous 16-byte stores of the pieces inside the strip's own columns
+          wave_lds_fence();
+#pragma unroll
+          for (int j = 0; j < PX * 3; ++j) stage[lane * (PX * 3) + j] = rgb[j];
+          wave_lds_fence();
+          {
+            v4f piece[3];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) piece[k] = *reinterpret_cast<const v4f*>(stage + 4 * (lane + 64 * k));  // all reads first, one wait
+            float* orow = a.sh.rgb + (fo + (size_t)e * W + cx0) * 3;
+#pragma unroll
+            for (int k = 0; k < 3; ++k)
+              if (stage_chunk_ok(k, (vx0 - cx0) * 3, (vx1 - cx0) * 3)) *reinterpret_cast<v4f*>(orow + 4 * (lane + 64 * k)) = piece[k];
+          }
+          if (do_obs) {
+            while (cur_o0 < ri.o0) {  // the oldest observation row in flight got its last frame row: reduce it horizontally
+              obs_flush(OA[0], cur_o0);
+#pragma unroll
+              for (int j = 0; j < PX * 3; ++j) { OA[0][j] = OA[1][j]; OA[1][j] = OA[2][j]; OA[2][j] = 0.0f; }
+              ++cur_o0;
+            }
+#pragma unroll
+            for (int j = 0; j < PX * 3; ++j) {
+              OA[0][j] = fmaf(ri.w0, rgb[j], OA[0][j]);
+              OA[1][j] = fmaf(ri.w1, rgb[j], OA[1][j]);
+              OA[2][j] = fmaf(ri.w2, rgb[j], OA[2][j]);
+            }
           }
         }
       }
     }
+    // The prefetched row must be waited for HERE, a whole iteration after its loads were issued.  Left to the compiler, the
+    // wait lands at the first use in the NEXT iteration - behind that iteration's freshly issued loads, and the in-order
+    // vmcnt then drains those too (s_waitcnt vmcnt(2) at the loop head: the memory latency of every row was exposed).
+    if constexpr (LEVELS) asm volatile("" : "+v"(zn[0]), "+v"(zn[1]), "+v"(zn[2]), "+v"(hn[0]), "+v"(hn[1]), "+v"(hn[2]), "+v"(ninfo));
+    else asm volatile("" : "+v"(zn[0]), "+v"(zn[1]), "+v"(zn[2]), "+v"(ninfo));
+    unpack_info(ninfo);
 #pragma unroll
     for (int i = 0; i < PX; ++i) { Zu[i] = Zm[i]; Zm[i] = Zd[i]; Zd[i] = cur[i]; zc[i] = zn[i]; hc[i] = hn[i]; }
-    info = ninfo;
   }
-  if (do_obs) {  // observation rows still in flight at the end of the segment (another segment adds its share)
-    obs_flush(OA[0], cur_o0);
-    obs_flush(OA[1], cur_o0 + 1);
-    obs_flush(OA[2], cur_o0 + 2);
-    // rows of the block this segment never reached stay unwritten: the finishing kernel only reads [seg_oa, seg_ob]
+  if constexpr (SHADE) {
+    if (do_obs) {  // observation rows still in flight at the end of the segment (another segment adds its share)
+      obs_flush(OA[0], cur_o0);
+      obs_flush(OA[1], cur_o0 + 1);
+      obs_flush(OA[2], cur_o0 + 2);
+      // rows of the block this segment never reached stay unwritten: the finishing kernel only reads [seg_oa, seg_ob]
+    }
   }
   if (do_fots) {  // one record per wave: no atomics; fots_combine_kernel adds the records of an env
     f_zmax = wave_scan_max_lane63(f_zmax);
@@ -608,24 +678,31 @@ __global__ __launch_bounds__(256) void obs_finish_stream_kernel(const float* __r
 // ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
-template <int... KS>
+template <int ROLE, int... KS>
 static bool stream_geometry_t(int W, int* nstrips, int* strip_w) {
-  using C = StreamCfg<KS...>;
+  using C = StreamCfg<ROLE, KS...>;
   // strip widths are multiples of 4 columns: the 16-byte pieces of the staged RGB row then start and end on strip borders
-  static_assert((C::HL * kStreamPx * 3) % 4 == 0, "halo floats must be a multiple of 4 (staged 16-byte stores)");
+  static_assert(!C::SHADE || (C::HL * kStreamPx * 3) % 4 == 0 || true, "");
   int ns = (W + C::VW - 1) / C::VW;
   int sw = (((W + ns - 1) / ns) + 3) & ~3;
   if (sw > C::VW) { ++ns; sw = (((W + ns - 1) / ns) + 3) & ~3; }
   *nstrips = ns;
   *strip_w = sw;
+  // shading roles stage the RGB row as 16-byte pieces: the first valid float (HL * PX * 3) must be a multiple of 4
+  if (C::SHADE && (C::HL * kStreamPx * 3) % 4 != 0) return false;
   return sw <= C::VW;
 }
 
-// which fused level sets have a streaming instantiation (the same sets the tiled tail covers)
+// fused level sets with a streaming instantiation (the same sets the tiled tail covers)
 static int stream_variant(int n_fused, int k0) {
   if (n_fused == 4 && k0 == 9) return 0;   // <9,5,3,5>  320x240
   if (n_fused == 3 && k0 == 9) return 1;   // <9,5,9>    640x480 (k = 15 stays a band level)
   return -1;
+}
+
+static bool stream_split() {
+  static const int v = getenv("TACEX_STREAM_SPLIT") ? atoi(getenv("TACEX_STREAM_SPLIT")) : 1;
+  return v != 0;
 }
 
 bool stream_supported(int n_fused, int k0, int H, int W) {
@@ -633,53 +710,70 @@ bool stream_supported(int n_fused, int k0, int H, int W) {
   return en != 0 && stream_variant(n_fused, k0) >= 0 && H >= 16 && W >= 16 && W % 4 == 0;
 }
 
-bool stream_geometry(int n_fused, int k0, int W, int* nstrips, int* strip_w) {
-  switch (stream_variant(n_fused, k0)) {
-    case 0: return stream_geometry_t<9, 5, 3, 5>(W, nstrips, strip_w);
-    case 1: return stream_geometry_t<9, 5, 9>(W, nstrips, strip_w);
+// geometry of the kernel that SHADES (strip layout of the RGB / observation partial sums) and of the one that runs the LEVELS
+// (strip layout of the FOTS partial records); identical in fused mode
+bool stream_geometry(int n_fused, int k0, int W, int* nstrips, int* strip_w, int* lv_nstrips, int* lv_strip_w) {
+  const int v = stream_variant(n_fused, k0);
+  if (v < 0) return false;
+  if (stream_split()) {
+    // the shading kernel needs halo lanes whose floats are a multiple of 4 (see stream_geometry_t): HL = 4 lanes
+    if (!stream_geometry_t<kStreamShade>(W, nstrips, strip_w)) return false;
+    return v == 0 ? stream_geometry_t<kStreamLevels, 9, 5, 3, 5>(W, lv_nstrips, lv_strip_w)
+                  : stream_geometry_t<kStreamLevels, 9, 5, 9>(W, lv_nstrips, lv_strip_w);
   }
-  return false;
+  const bool ok = v == 0 ? stream_geometry_t<kStreamFused, 9, 5, 3, 5>(W, nstrips, strip_w) : stream_geometry_t<kStreamFused, 9, 5, 9>(W, nstrips, strip_w);
+  *lv_nstrips = *nstrips; *lv_strip_w = *strip_w;
+  return ok;
 }
 
-// vertical segments per strip: enough waves to give every SIMD ~2 of them, at most kStreamMaxSeg, each >= 24 rows
-int stream_segments(int B, int nstrips, int H, int sum_r) {
+// vertical segments per strip: enough waves to give every SIMD `per_simd` of them, at most kStreamMaxSeg; a segment costs
+// `warm` extra rows (the pipeline's warm-up), so it should be several times that long
+int stream_segments(int B, int nstrips, int H, int warm, int per_simd) {
   static const int forced = getenv("TACEX_STREAM_SEGS") ? atoi(getenv("TACEX_STREAM_SEGS")) : 0;
-  int nseg = forced > 0 ? forced : (2048 + B * nstrips - 1) / (B * nstrips);
+  int nseg = forced > 0 ? forced : (1024 * per_simd + B * nstrips - 1) / (B * nstrips);
   if (nseg < 1) nseg = 1;
   if (nseg > kStreamMaxSeg) nseg = kStreamMaxSeg;
-  while (nseg > 1 && (H / nseg < 24 || H - (nseg - 1) * ((H + nseg - 1) / nseg) < 4)) --nseg;
-  (void)sum_r;
+  const int min_rows = forced > 0 ? 24 : (3 * warm > 24 ? 3 * warm : 24);
+  while (nseg > 1 && (H / nseg < min_rows || H - (nseg - 1) * ((H + nseg - 1) / nseg) < 4)) --nseg;
   return nseg;
 }
+int stream_warm_rows(int n_fused, int k0, bool levels_kernel) {
+  const int v = stream_variant(n_fused, k0);
+  const int sum_r = v == 0 ? 9 : 10;
+  if (!stream_split()) return 2 * sum_r + 2;
+  return levels_kernel ? 2 * sum_r : 2;
+}
 
-template <bool GZ, int... KS>
+template <bool GZ, int ROLE, int... KS>
 static hipError_t launch_stream_k(const StreamArgs& a, hipStream_t st) {
+  using C = StreamCfg<ROLE, KS...>;
   const int waves = a.B * a.nstrips * a.nseg;
   const dim3 grid((waves + kStreamWaves - 1) / kStreamWaves);
-  const size_t lds = kStreamLdsShared + (size_t)kStreamWaves * kStreamLdsPerWave;
-  auto kern = taxim_stream_kernel<GZ, KS...>;
-  // > 64 KB of dynamic LDS is an opt-in per kernel AND device (one flag per device: contexts on several GPUs in one process)
-  static bool attr_done[64] = {};
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
-  if (!attr_done[dev]) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return e;
-    attr_done[dev] = true;
+  const size_t lds = C::lds_bytes();
+  auto kern = taxim_stream_kernel<GZ, ROLE, KS...>;
+  if (lds > 64 * 1024) {  // > 64 KB of dynamic LDS is an opt-in per kernel AND device (one flag per device)
+    static bool attr_done[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+    if (!attr_done[dev]) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (e != hipSuccess) return e;
+      attr_done[dev] = true;
+    }
   }
   hipLaunchKernelGGL(kern, grid, dim3(64 * kStreamWaves), lds, st, a);
   return hipGetLastError();
 }
 
-template <int... KS>
+template <int ROLE, int... KS>
 static hipError_t launch_stream(const StreamArgs& a, bool gel_zero, hipStream_t st) {
-  return gel_zero ? launch_stream_k<true, KS...>(a, st) : launch_stream_k<false, KS...>(a, st);
+  return gel_zero ? launch_stream_k<true, ROLE, KS...>(a, st) : launch_stream_k<false, ROLE, KS...>(a, st);
 }
 
 hipError_t run_stream_tail(const LevelDesc* lv, int n_levels, int n_fused, const float* zin, const float* hm, const float* gel,
-                           const float* sa, const float* sb, const float* pd, const ShadeParams* sp, float* rgb, int B, int H, int W,
-                           float contact_scale, const StreamPlan& plan, float* obs_part, FotsReduce* fots_part, int fots_stride,
-                           float* pix_z, uint8_t* pix_m, hipStream_t st) {
+                           const float* sa, const float* sb, const float* pd, const ShadeParams* sp, float* rgb, float* z_last,
+                           int B, int H, int W, float contact_scale, const StreamPlan& plan, float* obs_part,
+                           FotsReduce* fots_part, int fots_stride, float* pix_z, uint8_t* pix_m, hipStream_t st) {
   StreamArgs a{};
   a.zin = zin; a.hm = hm; a.gel = lv[0].gel_zero ? nullptr : gel; a.shift_a = sa; a.shift_b = sb; a.pdepth = pd;
   a.H = H; a.W = W; a.B = B; a.contact_scale = contact_scale;
@@ -689,27 +783,38 @@ hipError_t run_stream_tail(const LevelDesc* lv, int n_levels, int n_fused, const
   a.sh.calib_h = (float)sp->calib_h; a.sh.calib_w = (float)sp->calib_w; a.sh.x_binr = sp->x_binr; a.sh.y_binr = sp->y_binr;
   a.sh.gsy = (float)(0.5 * H / sp->calib_h / (double)sp->pixmm); a.sh.gsx = (float)(0.5 * W / sp->calib_w / (double)sp->pixmm);
   a.sh.inv_x_binr = (float)(1.0 / (double)sp->x_binr); a.sh.inv_y_binr = (float)(1.0 / (double)sp->y_binr);
-  a.nstrips = plan.nstrips; a.strip_w = plan.strip_w; a.nseg = plan.nseg; a.seg_rows = plan.seg_rows;
   a.rows = static_cast<const StreamRowInfo*>(plan.rows);
+  StreamArgs sh = a;  // arguments of the kernel that shades
+  sh.nstrips = plan.nstrips; sh.strip_w = plan.strip_w; sh.nseg = plan.nseg; sh.seg_rows = plan.seg_rows;
   if (obs_part && plan.obs_ready) {
-    a.obs_part = obs_part;
-    a.obs_kxp = plan.obs_kxp;
-    a.obs_xlo = plan.obs.xlo; a.obs_xcnt = plan.obs.xcnt; a.obs_wx = plan.obs.wx; a.obs_kx = plan.obs.kx;
-    a.obs_strip_q0 = plan.obs_strip_q0; a.obs_strip_nq = plan.obs_strip_nq;
-    a.obs_seg_oa = plan.obs_seg_oa; a.obs_seg_ob = plan.obs_seg_ob;
-    a.obs_nrows = plan.obs_nrows; a.obs_ncols = plan.obs_ncols;
+    sh.obs_part = obs_part;
+    sh.obs_kxp = plan.obs_kxp;
+    sh.obs_xlo = plan.obs.xlo; sh.obs_xcnt = plan.obs.xcnt; sh.obs_wx = plan.obs.wx; sh.obs_kx = plan.obs.kx;
+    sh.obs_strip_q0 = plan.obs_strip_q0; sh.obs_strip_nq = plan.obs_strip_nq;
+    sh.obs_seg_oa = plan.obs_seg_oa; sh.obs_seg_ob = plan.obs_seg_ob;
+    sh.obs_nrows = plan.obs_nrows; sh.obs_ncols = plan.obs_ncols;
   }
-  a.fots_part = fots_part; a.fots_stride = fots_stride;
+  StreamArgs lvl = a;  // ... and of the one that runs the levels (the same kernel in fused mode)
+  lvl.nstrips = plan.lv_nstrips; lvl.strip_w = plan.lv_strip_w; lvl.nseg = plan.lv_nseg; lvl.seg_rows = plan.lv_seg_rows;
+  StreamArgs& f = stream_split() ? lvl : sh;  // who writes the FOTS by-products
+  f.fots_part = fots_part; f.fots_stride = fots_stride;
   if (pix_z && pix_m && plan.mk_x) {
-    a.pix_z = pix_z; a.pix_m = pix_m; a.n_markers = plan.n_markers;
-    a.mk_x = plan.mk_x; a.mk_id = plan.mk_id;
+    f.pix_z = pix_z; f.pix_m = pix_m; f.n_markers = plan.n_markers;
+    f.mk_x = plan.mk_x; f.mk_id = plan.mk_id;
   }
-  const int k0 = lv[n_levels - n_fused].kw;
-  switch (stream_variant(n_fused, k0)) {
-    case 0: return launch_stream<9, 5, 3, 5>(a, lv[0].gel_zero, st);
-    case 1: return launch_stream<9, 5, 9>(a, lv[0].gel_zero, st);
+  const int v = stream_variant(n_fused, lv[n_levels - n_fused].kw);
+  const bool gz = lv[0].gel_zero;
+  if (!stream_split()) {
+    if (v == 0) return launch_stream<kStreamFused, 9, 5, 3, 5>(sh, gz, st);
+    if (v == 1) return launch_stream<kStreamFused, 9, 5, 9>(sh, gz, st);
+    return hipErrorInvalidValue;
   }
-  return hipErrorInvalidValue;
+  if (!z_last) return hipErrorInvalidValue;
+  lvl.z_out = z_last;
+  hipError_t e = v == 0 ? launch_stream<kStreamLevels, 9, 5, 3, 5>(lvl, gz, st) : launch_stream<kStreamLevels, 9, 5, 9>(lvl, gz, st);
+  if (e != hipSuccess) return e;
+  sh.zin = z_last;
+  return launch_stream<kStreamShade>(sh, true, st);
 }
 
 hipError_t run_obs_finish_stream(const float* part, void* obs, bool u8, const StreamPlan& plan, int B, hipStream_t st) {
