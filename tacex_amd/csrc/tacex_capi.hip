@@ -281,7 +281,7 @@ static int stream_plan(tacex_taxim_ctx* c, int n_fused, int B, int oh, int ow, c
   if (!stream_geometry(n_fused, k0, c->W, &nstrips, &strip_w, &lv_nstrips, &lv_strip_w)) { set_error("no streaming tail for this level set"); return 1; }
   // the shading kernel hides its memory latency with many light waves (4 per SIMD), the levels kernel is register-heavier (2)
   const int nseg = stream_segments(B, nstrips, c->H, stream_warm_rows(n_fused, k0, false), 4);
-  const int lv_nseg = stream_segments(B, lv_nstrips, c->H, stream_warm_rows(n_fused, k0, true), 2);
+  const int lv_nseg = stream_segments(B, lv_nstrips, c->H, stream_warm_rows(n_fused, k0, true), 4);
   for (auto& e : c->stream_plans)
     if (e.oh == oh && e.ow == ow && e.nseg == nseg && e.plan.lv_nseg == lv_nseg && e.mk_version == c->mk_version) { *out = &e.plan; return 0; }
   HIP_TRY(hipSetDevice(c->device), "hipSetDevice");

@@ -84,6 +84,14 @@ __device__ __forceinline__ float fma_to(float w, float h, float a) {
   asm volatile("v_fma_f32 %0, %1, %2, %3" : "=v"(d) : "s"(w), "v"(h), "v"(a));
   return d;
 }
+// A wave-uniform value moved into a VECTOR register on purpose: on gfx950 a v_fma_f32 with a scalar-register operand issues at
+// ~4.8 cycles per SIMD against ~3.0 with three vector operands (scripts/hip_probes/valu_occupancy.hip), and nearly every FMA of
+// the levels multiplies by a tap.  The asm hides the uniformity from hipcc, which would otherwise fold the scalar back in.
+__device__ __forceinline__ float to_vgpr(float s) {
+  float v;
+  asm volatile("v_mov_b32 %0, %1" : "=v"(v) : "s"(s));
+  return v;
+}
 
 // LDS traffic of ONE wave is executed in order; the fence only stops the compiler from moving accesses across it
 __device__ __forceinline__ void wave_lds_fence() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
@@ -120,24 +128,25 @@ struct StreamCfg {
   static constexpr int acc_off(int l) { int s = 0; for (int i = 0; i < l; ++i) s += K[i] - 1; return s; }
   static constexpr int n_acc() { return acc_off(NL); }
   static constexpr int HALO = sum_r() + (SHADE ? 1 : 0);                // + the central-difference neighbour
-  // halo lanes per side; shading roles stage their RGB row as 16-byte pieces, so the first valid float of the strip row
-  // (HL * PX * 3) must be a multiple of 4: HL is rounded up to a multiple of 4 there
-  static constexpr int HL0 = (HALO + kStreamPx - 1) / kStreamPx;
-  static constexpr int HL = SHADE ? ((HL0 + 3) & ~3) : HL0;
+  static constexpr int HL = (HALO + kStreamPx - 1) / kStreamPx;         // halo lanes per side
   static constexpr int VW = (64 - 2 * HL) * kStreamPx;                  // widest valid strip
   static constexpr int last_r() { return NL > 0 ? R(NL - 1) : 0; }
   static_assert(sum_r() - last_r() < kStreamRing, "restore ring too shallow");
-  // wave-private LDS: S ring [kStreamRing][64] float4 (restores) | staging row (background in / RGB out) | observation staging
-  // row | column-filter window weights [obs_ncols][obs_kxp] | window start per column
+  // wave-private LDS: S ring [kStreamRing][64] float4 (restores) | observation staging row | column-filter window weights
+  // [obs_ncols][obs_kxp] | window start per column
   static constexpr size_t ring_bytes() { return NL > 1 ? (size_t)kStreamRing * 64 * 16 : 0; }
-  static constexpr size_t shade_bytes() { return SHADE ? 2 * kStreamStageBytes + kStreamObsLdsFloats * 4 + kStreamObsMaxCols * 4 : 0; }
+  static constexpr size_t shade_bytes() { return SHADE ? kStreamStageBytes + kStreamObsLdsFloats * 4 + kStreamObsMaxCols * 4 : 0; }
   static constexpr size_t lds_per_wave() { return ring_bytes() + shade_bytes(); }
   static constexpr size_t lds_shared() { return SHADE ? kStreamLdsShared : 0; }
   static constexpr size_t lds_bytes() { return lds_shared() + kStreamWaves * lds_per_wave(); }
 };
 
+// register budget per role (waves per SIMD the kernel is compiled for): the lean levels kernel 4 (<= 128 VGPRs), the shading
+// kernel 3 (<= 168), the fused one 2
+constexpr int stream_min_waves(int role) { return role == kStreamLevels ? 4 : (role == kStreamShade ? 3 : 2); }
+
 template <bool GZ, int ROLE, int... KS>
-__global__ __launch_bounds__(64 * kStreamWaves, 2) void taxim_stream_kernel(StreamArgs a) {
+__global__ __launch_bounds__(64 * kStreamWaves, stream_min_waves(ROLE)) void taxim_stream_kernel(StreamArgs a) {
   using C = StreamCfg<ROLE, KS...>;
   constexpr int NL = C::NL, PX = kStreamPx, SUMR = C::sum_r(), HL = C::HL;
   constexpr bool SHADE = C::SHADE, LEVELS = NL > 0;
@@ -169,8 +178,7 @@ __global__ __launch_bounds__(64 * kStreamWaves, 2) void taxim_stream_kernel(Stre
   const int cx0 = vx0 - HL * PX;                                   // column of lane 0, pixel 0
   char* lds = smem_raw + C::lds_shared() + (size_t)wv_in_blk * C::lds_per_wave();
   v4f* ring = reinterpret_cast<v4f*>(lds);
-  float* stage = reinterpret_cast<float*>(lds + C::ring_bytes());    // [64 * PX * 3] background in / RGB out staging row
-  float* obs_row = stage + 64 * PX * 3;                               // [64 * PX * 3] observation staging row
+  float* obs_row = reinterpret_cast<float*>(lds + C::ring_bytes());  // [64 * PX * 3] observation staging row
   float* obs_wl = obs_row + 64 * PX * 3;                              // [nq][kxp] window weights
   int* obs_xb = reinterpret_cast<int*>(obs_wl + kStreamObsLdsFloats);  // [nq] first staging pixel of the window
 
@@ -200,22 +208,50 @@ __global__ __launch_bounds__(64 * kStreamWaves, 2) void taxim_stream_kernel(Stre
   // their three pixels one by one at the mirrored columns
   const unsigned xb = (unsigned)min(max(xg[0], 0), W - PX);
   const bool border = xg[0] < 0 || xg[PX - 1] >= W;
-  auto load_row = [&](int row, float (&zz)[PX], float (&hh)[PX]) {
+  // The border lanes' values go to SEPARATE registers and are merged by merge_row() only where the row is consumed: writing
+  // them over the 12-byte load's registers made hipcc wait for that load right behind its issue (s_waitcnt vmcnt(0) at the
+  // loop head - the memory latency of every row was exposed).
+  struct RowRegs { v3f z3, h3; float zb[PX], hb[PX]; };
+  auto load_row = [&](int row, RowRegs& r) {
     const unsigned ro = (unsigned)row * (unsigned)W;
-    const v3f z3 = *reinterpret_cast<const v3f*>(zin + ro + xb);
-    zz[0] = z3.x; zz[1] = z3.y; zz[2] = z3.z;
-    if constexpr (LEVELS) {
-      const v3f h3 = *reinterpret_cast<const v3f*>(hm + ro + xb);
-      hh[0] = h3.x; hh[1] = h3.y; hh[2] = h3.z;
-    }
+    r.z3 = *reinterpret_cast<const v3f*>(zin + ro + xb);
+    if constexpr (LEVELS) r.h3 = *reinterpret_cast<const v3f*>(hm + ro + xb);
+#pragma unroll
+    for (int i = 0; i < PX; ++i) { r.zb[i] = 0.0f; r.hb[i] = 0.0f; }
     if (border) {
 #pragma unroll
       for (int i = 0; i < PX; ++i) {
-        zz[i] = zin[ro + xo[i]];
-        if constexpr (LEVELS) hh[i] = hm[ro + xo[i]];
+        r.zb[i] = zin[ro + xo[i]];
+        if constexpr (LEVELS) r.hb[i] = hm[ro + xo[i]];
       }
     }
   };
+  auto consume_row = [&](RowRegs& r) {  // forces the waits for the row's loads to THIS point (see the loop tail)
+    if constexpr (LEVELS)
+      asm volatile("" : "+v"(r.z3), "+v"(r.h3), "+v"(r.zb[0]), "+v"(r.zb[1]), "+v"(r.zb[2]), "+v"(r.hb[0]), "+v"(r.hb[1]), "+v"(r.hb[2]));
+    else
+      asm volatile("" : "+v"(r.z3), "+v"(r.zb[0]), "+v"(r.zb[1]), "+v"(r.zb[2]));
+  };
+  auto merge_row = [&](const RowRegs& r, float (&zz)[PX], float (&hh)[PX]) {
+#pragma unroll
+    for (int i = 0; i < PX; ++i) {
+      zz[i] = border ? r.zb[i] : r.z3[i];
+      if constexpr (LEVELS) hh[i] = border ? r.hb[i] : r.h3[i];
+    }
+  };
+
+  // background of one row: 12 bytes per pixel straight into the lane that owns the pixel.  (Staging the row through LDS as
+  // contiguous 16-byte pieces cut the L1 tag look-ups by 40 % but added four LDS round trips to the dependency chain of every
+  // row: measured slower - the kernel is latency-, not L1-bound.)
+  unsigned xc[PX];
+#pragma unroll
+  for (int i = 0; i < PX; ++i) xc[i] = (unsigned)min(max(xg[i], 0), W - 1);
+  auto load_bg = [&](int row, v3f (&q)[PX]) {
+#pragma unroll
+    for (int i = 0; i < PX; ++i)
+      q[i] = *reinterpret_cast<const v3f*>(reinterpret_cast<const char*>(a.sh.bg) + ((unsigned)row * (unsigned)W + xc[i]) * 12u);
+  };
+  v3f bgq[PX] = {(v3f)(0.0f), (v3f)(0.0f), (v3f)(0.0f)};   // background of the row shaded in the current iteration
 
   // ---- policy observation set-up: this strip's column filters as fixed-length windows over the staging row ----
   int nq = 0;
@@ -247,7 +283,9 @@ __global__ __launch_bounds__(64 * kStreamWaves, 2) void taxim_stream_kernel(Stre
     constexpr int l = decltype(lc)::value;
     static_for<0, C::K[l]>([&](auto tc) {
       constexpr int t = decltype(tc)::value;
-      w[C::acc_off(l) + l + t] = a.taps[l][t < C::K[l] - 1 - t ? t : C::K[l] - 1 - t];
+      constexpr int ts = t < C::K[l] - 1 - t ? t : C::K[l] - 1 - t;  // symmetric taps share a register
+      if constexpr (ts == t) w[C::acc_off(l) + l + t] = a.taps[l][t];
+      else w[C::acc_off(l) + l + t] = w[C::acc_off(l) + l + ts];
     });
   });
 
@@ -309,7 +347,12 @@ __global__ __launch_bounds__(64 * kStreamWaves, 2) void taxim_stream_kernel(Stre
   const int ys = SHADE ? r0 - SUMR - 1 : r0 - SUMR;
   const int ye = SHADE ? r1 + SUMR + 1 : r1 - 1 + SUMR;
   float zc[PX], hc[PX] = {0.f, 0.f, 0.f};
-  load_row(row_of(ys), zc, hc);
+  {
+    RowRegs r0r;
+    load_row(row_of(ys), r0r);
+    consume_row(r0r);
+    merge_row(r0r, zc, hc);
+  }
   // Row scalars, fetched one iteration ahead with a VECTOR load (lanes 0-7: record of the row shaded, 8-15: of the row
   // entering, 16-23: of the row leaving the last level) and moved to scalar registers with v_readlane: scalar-memory loads
   // share the LDS wait counter and return out of order, so every ring read would also wait for them.
@@ -334,9 +377,14 @@ __global__ __launch_bounds__(64 * kStreamWaves, 2) void taxim_stream_kernel(Stre
   unpack_info(load_info(ys));
   for (int y = ys; y <= ye; ++y) {
     // ---- prefetch the next input row and the next iteration's row scalars (consumed at the END of this iteration) ----
-    float zn[PX], hn[PX] = {0.f, 0.f, 0.f};
-    load_row(row_of(y + 1), zn, hn);
+    RowRegs nrow;
+    load_row(row_of(y + 1), nrow);
     int ninfo = load_info(y + 1);
+    v3f nbg[PX] = {(v3f)(0.0f), (v3f)(0.0f), (v3f)(0.0f)};
+    if constexpr (SHADE && !LEVELS) {  // shading-only role: nothing in the iteration hides a load - fetch the background of
+      const int gn = y + 1 - SUMR - 2;   // the NEXT shaded row now (consumed at the loop tail, like the row itself)
+      if (gn >= max(r0, 1) && gn <= min(r1 - 1, H - 2)) load_bg(gn, nbg);
+    }
 
     // ---- shading, part 1 (runs between level 0 and level 1, see below): bins of row gs, background loads in flight.
     //      Replicate padding of the gradient maps (TT:501-502): rows 0 / H-1 take the gradient of rows 1 / H-2 and are emitted
@@ -344,15 +392,6 @@ __global__ __launch_bounds__(64 * kStreamWaves, 2) void taxim_stream_kernel(Stre
     const int gs = y - SUMR - 2;
     const bool shade_now = SHADE && gs >= max(r0, 1) && gs <= min(r1 - 1, H - 2);
     int cc[PX] = {0, 0, 0};  // table record (bin pair) of every pixel of row gs
-    // The strip's background / RGB row is 64 x 9 floats.  A lane owns floats [9 l, 9 l + 9); read or written that way every
-    // 16-byte access instruction would touch all 36 cache lines of the row.  Instead the row moves between global memory and
-    // the wave's LDS staging row as CONTIGUOUS 16-byte pieces (lane l: floats [4 (l + 64 k), + 4), k = 0..2) and the lanes pick
-    // their own 9 floats out of LDS.
-    v4f bgq[3] = {(v4f)(0.0f), (v4f)(0.0f), (v4f)(0.0f)};
-    auto stage_chunk_ok = [&](int k, int lo_f, int hi_f) -> bool {  // piece k of this lane inside [lo_f, hi_f) floats of the strip row?
-      const int f = 4 * (lane + 64 * k);
-      return f >= lo_f && f + 4 <= hi_f && f < 64 * PX * 3;
-    };
     auto shade_part1 = [&]() {
       if constexpr (SHADE) {
         if (!shade_now) return;
@@ -370,12 +409,7 @@ __global__ __launch_bounds__(64 * kStreamWaves, 2) void taxim_stream_kernel(Stre
           const int right = i == PX - 1 ? cr : code[i + 1], left = i == 0 ? cl : code[i - 1];
           cc[i] = xg[i] == 0 ? right : (xg[i] == W - 1 ? left : code[i]);
         }
-        // background of row gs: the in-image part of the strip row, issued now, consumed after the remaining levels
-        const float* bgrow = a.sh.bg + ((size_t)gs * W + cx0) * 3;  // float 0 of the strip row (may lie left of the image)
-#pragma unroll
-        for (int k = 0; k < 3; ++k)
-          bgq[k] = stage_chunk_ok(k, -cx0 * 3 > 0 ? -cx0 * 3 : 0, (W - cx0) * 3) ? *reinterpret_cast<const v4f*>(bgrow + 4 * (lane + 64 * k))
-                                                                              : (v4f)(0.0f);
+        if constexpr (LEVELS) load_bg(gs, bgq);  // fused role: issued here, consumed after the remaining levels
       }
     };
     if constexpr (!LEVELS) shade_part1();
@@ -529,7 +563,7 @@ __global__ __launch_bounds__(64 * kStreamWaves, 2) void taxim_stream_kernel(Stre
         bool hi[PX];
 #pragma unroll
         for (int i = 0; i < PX; ++i) {
-          hi[i] = cc[i] >= nb_lds;
+          hi[i] = valid[i] && cc[i] >= nb_lds;  // halo lanes hold garbage bins: they must not trigger the L2 gather
           const v4f* pl = reinterpret_cast<const v4f*>(polyL + (hi[i] ? 0 : cc[i]) * kStreamPolyPitch);
           pc[i][0] = pl[0]; pc[i][1] = pl[1]; pc[i][2] = pl[2]; pc[i][3] = pl[3]; pc[i][4] = pl[4];
         }
@@ -545,24 +579,11 @@ __global__ __launch_bounds__(64 * kStreamWaves, 2) void taxim_stream_kernel(Stre
         for (int e = e_lo; e <= e_hi; ++e) {
           if (e < r0 || e >= r1) continue;
           StreamRowInfo ri = ri_g;
-          v4f bq[3] = {bgq[0], bgq[1], bgq[2]};
+          v3f bq[PX] = {bgq[0], bgq[1], bgq[2]};
           if (e != gs) {  // a replicated border row: its own feature / background / observation row (twice per frame)
             ri = a.rows[e];
-            const float* bgrow = a.sh.bg + ((size_t)e * W + cx0) * 3;
-#pragma unroll
-            for (int k = 0; k < 3; ++k)
-              bq[k] = stage_chunk_ok(k, -cx0 * 3 > 0 ? -cx0 * 3 : 0, (W - cx0) * 3) ? *reinterpret_cast<const v4f*>(bgrow + 4 * (lane + 64 * k))
-                                                                                 : (v4f)(0.0f);
+            load_bg(e, bq);
           }
-          // background: contiguous pieces -> staging row -> this lane's 9 floats.  (Piece 2 of lanes >= 16 lies beyond the
-          // staging row: it lands in / comes from the observation staging row behind it, which is only live inside obs_flush.)
-          wave_lds_fence();
-#pragma unroll
-          for (int k = 0; k < 3; ++k) *reinterpret_cast<v4f*>(stage + 4 * (lane + 64 * k)) = bq[k];
-          wave_lds_fence();
-          float bge[PX * 3];
-#pragma unroll
-          for (int j = 0; j < PX * 3; ++j) bge[j] = stage[lane * (PX * 3) + j];
           const float Y = ri.fy;
           float rgb[PX * 3];
 #pragma unroll
@@ -572,23 +593,12 @@ __global__ __launch_bounds__(64 * kStreamWaves, 2) void taxim_stream_kernel(Stre
             const float p0 = fmaf(f0, c0.x, fmaf(f1, c0.y, fmaf(f2, c0.z, fmaf(X[i], c0.w, fmaf(Y, c1.x, c1.y)))));
             const float p1 = fmaf(f0, c1.z, fmaf(f1, c1.w, fmaf(f2, c2.x, fmaf(X[i], c2.y, fmaf(Y, c2.z, c2.w)))));
             const float p2 = fmaf(f0, c3.x, fmaf(f1, c3.y, fmaf(f2, c3.z, fmaf(X[i], c3.w, fmaf(Y, c4.x, c4.y)))));
-            rgb[3 * i + 0] = __builtin_amdgcn_fmed3f(p0 + bge[3 * i + 0], 0.0f, 1.0f);  // TT:257-258
-            rgb[3 * i + 1] = __builtin_amdgcn_fmed3f(p1 + bge[3 * i + 1], 0.0f, 1.0f);
-            rgb[3 * i + 2] = __builtin_amdgcn_fmed3f(p2 + bge[3 * i + 2], 0.0f, 1.0f);
-          }
-          // RGB: this lane's 9 floats -> staging row -> contiguous 16-byte stores of the pieces inside the strip's own columns
-          wave_lds_fence();
-#pragma unroll
-          for (int j = 0; j < PX * 3; ++j) stage[lane * (PX * 3) + j] = rgb[j];
-          wave_lds_fence();
-          {
-            v4f piece[3];
-#pragma unroll
-            for (int k = 0; k < 3; ++k) piece[k] = *reinterpret_cast<const v4f*>(stage + 4 * (lane + 64 * k));  // all reads first, one wait
-            float* orow = a.sh.rgb + (fo + (size_t)e * W + cx0) * 3;
-#pragma unroll
-            for (int k = 0; k < 3; ++k)
-              if (stage_chunk_ok(k, (vx0 - cx0) * 3, (vx1 - cx0) * 3)) *reinterpret_cast<v4f*>(orow + 4 * (lane + 64 * k)) = piece[k];
+            rgb[3 * i + 0] = __builtin_amdgcn_fmed3f(p0 + bq[i].x, 0.0f, 1.0f);  // TT:257-258
+            rgb[3 * i + 1] = __builtin_amdgcn_fmed3f(p1 + bq[i].y, 0.0f, 1.0f);
+            rgb[3 * i + 2] = __builtin_amdgcn_fmed3f(p2 + bq[i].z, 0.0f, 1.0f);
+            if (valid[i])
+              *reinterpret_cast<v3f*>(reinterpret_cast<char*>(a.sh.rgb + fo * 3) + ((unsigned)e * (unsigned)W + xc[i]) * 12u) =
+                  (v3f){rgb[3 * i], rgb[3 * i + 1], rgb[3 * i + 2]};
           }
           if (do_obs) {
             while (cur_o0 < ri.o0) {  // the oldest observation row in flight got its last frame row: reduce it horizontally
@@ -610,11 +620,16 @@ __global__ __launch_bounds__(64 * kStreamWaves, 2) void taxim_stream_kernel(Stre
     // The prefetched row must be waited for HERE, a whole iteration after its loads were issued.  Left to the compiler, the
     // wait lands at the first use in the NEXT iteration - behind that iteration's freshly issued loads, and the in-order
     // vmcnt then drains those too (s_waitcnt vmcnt(2) at the loop head: the memory latency of every row was exposed).
-    if constexpr (LEVELS) asm volatile("" : "+v"(zn[0]), "+v"(zn[1]), "+v"(zn[2]), "+v"(hn[0]), "+v"(hn[1]), "+v"(hn[2]), "+v"(ninfo));
-    else asm volatile("" : "+v"(zn[0]), "+v"(zn[1]), "+v"(zn[2]), "+v"(ninfo));
+    consume_row(nrow);
+    asm volatile("" : "+v"(ninfo));
+    if constexpr (SHADE && !LEVELS) {
+      asm volatile("" : "+v"(nbg[0]), "+v"(nbg[1]), "+v"(nbg[2]));
+      bgq[0] = nbg[0]; bgq[1] = nbg[1]; bgq[2] = nbg[2];
+    }
     unpack_info(ninfo);
+    merge_row(nrow, zc, hc);
 #pragma unroll
-    for (int i = 0; i < PX; ++i) { Zu[i] = Zm[i]; Zm[i] = Zd[i]; Zd[i] = cur[i]; zc[i] = zn[i]; hc[i] = hn[i]; }
+    for (int i = 0; i < PX; ++i) { Zu[i] = Zm[i]; Zm[i] = Zd[i]; Zd[i] = cur[i]; }
   }
   if constexpr (SHADE) {
     if (do_obs) {  // observation rows still in flight at the end of the segment (another segment adds its share)
@@ -681,15 +696,11 @@ __global__ __launch_bounds__(256) void obs_finish_stream_kernel(const float* __r
 template <int ROLE, int... KS>
 static bool stream_geometry_t(int W, int* nstrips, int* strip_w) {
   using C = StreamCfg<ROLE, KS...>;
-  // strip widths are multiples of 4 columns: the 16-byte pieces of the staged RGB row then start and end on strip borders
-  static_assert(!C::SHADE || (C::HL * kStreamPx * 3) % 4 == 0 || true, "");
   int ns = (W + C::VW - 1) / C::VW;
   int sw = (((W + ns - 1) / ns) + 3) & ~3;
   if (sw > C::VW) { ++ns; sw = (((W + ns - 1) / ns) + 3) & ~3; }
   *nstrips = ns;
   *strip_w = sw;
-  // shading roles stage the RGB row as 16-byte pieces: the first valid float (HL * PX * 3) must be a multiple of 4
-  if (C::SHADE && (C::HL * kStreamPx * 3) % 4 != 0) return false;
   return sw <= C::VW;
 }
 
@@ -701,7 +712,7 @@ static int stream_variant(int n_fused, int k0) {
 }
 
 static bool stream_split() {
-  static const int v = getenv("TACEX_STREAM_SPLIT") ? atoi(getenv("TACEX_STREAM_SPLIT")) : 1;
+  static const int v = getenv("TACEX_STREAM_SPLIT") ? atoi(getenv("TACEX_STREAM_SPLIT")) : 0;
   return v != 0;
 }
 
@@ -716,7 +727,6 @@ bool stream_geometry(int n_fused, int k0, int W, int* nstrips, int* strip_w, int
   const int v = stream_variant(n_fused, k0);
   if (v < 0) return false;
   if (stream_split()) {
-    // the shading kernel needs halo lanes whose floats are a multiple of 4 (see stream_geometry_t): HL = 4 lanes
     if (!stream_geometry_t<kStreamShade>(W, nstrips, strip_w)) return false;
     return v == 0 ? stream_geometry_t<kStreamLevels, 9, 5, 3, 5>(W, lv_nstrips, lv_strip_w)
                   : stream_geometry_t<kStreamLevels, 9, 5, 9>(W, lv_nstrips, lv_strip_w);
