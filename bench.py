@@ -256,7 +256,8 @@ def cpu_baseline(seconds):
         torch.set_num_threads(th)
         ts = calls(240, 320, 16, 3, 1)
         sweep_t.append({"threads": th, "frames_per_s": round(16 / statistics.median(ts), 2)})
-        if left() < seconds * 0.6:
+        # past the sweet spot the small FFTs oversubscribe and the rate collapses (64 threads: 10 frames/s on this host): stop there
+        if left() < seconds * 0.6 or sweep_t[-1]["frames_per_s"] < 0.7 * max(e["frames_per_s"] for e in sweep_t):
             break
     best_th = max(sweep_t, key=lambda e: e["frames_per_s"])["threads"]
     log(f"cpu baseline thread sweep: {sweep_t} -> {best_th}")

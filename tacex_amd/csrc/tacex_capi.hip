@@ -489,17 +489,21 @@ static int pipeline_chunk(tacex_taxim_ctx* c, const float* hm, const float* pres
                           float* z_out, uint8_t* mask_out, void* ws, int B, unsigned flags, hipStream_t st,
                           float* obs_h, void* obs, int obs_hh, int obs_w, FotsReduce* fots_part, int frame0);
 
-// Frames per pass of the pipeline: the level buffers (Z ping / pong, 4 B/px each) plus the height map of one pass should
-// stay resident in the 256 MB Infinity Cache between the kernels of the pass, so large shards are walked in chunks that
-// re-use the SAME scratch images (measured at 2048 frames 320x240: k=33 66 -> 58 us per 256 frames when chunked).
-// TACEX_CHUNK_FRAMES overrides (0 = whole batch in one pass).
+// Frames per pass of the pipeline.  With the LDS-tiled tail, large shards are walked in chunks whose level buffers (Z ping /
+// pong, 4 B/px each) plus height map stay resident in the 256 MB Infinity Cache (measured in round 1 at 2048 frames: k=33
+// 66 -> 58 us per 256 frames).  The streaming tail wants the opposite: one wave marches down a whole strip, so a pass needs
+// >= 2048 strips to fill the chip without splitting strips into short segments (each segment re-runs an 18-row warm-up), and
+// with it the band kernels measured the same chunked or not (C3: 3.95 ms chunked at 256, 3.86 ms in one pass) - passes of up
+// to 1024 frames of 320x240 there.  TACEX_CHUNK_FRAMES overrides (0 = whole batch in one pass).
 static int chunk_frames(const tacex_taxim_ctx* c, int B) {
   static const int env = getenv("TACEX_CHUNK_FRAMES") ? atoi(getenv("TACEX_CHUNK_FRAMES")) : -1;
   if (env == 0) return B;
   if (env > 0) return env < B ? env : B;
+  const bool stream = c->use_tail && c->use_stream && c->n_fused > 0 &&
+                      stream_supported(c->n_fused, c->levels[c->n_levels - c->n_fused].kw, c->H, c->W);
   const size_t per_frame = (size_t)3 * c->H * c->W * sizeof(float);
-  const size_t n = ((size_t)240 << 20) / per_frame;
-  if (n < 1 || (size_t)B < 2 * n) return B;  // a shard barely over the budget is cheaper in one pass than in two small ones
+  const size_t n = stream ? ((size_t)1024 * 240 * 320 * 12) / per_frame : ((size_t)240 << 20) / per_frame;
+  if (n < 1 || (size_t)B < (stream ? n + n / 2 : 2 * n)) return B;  // a shard barely over the budget is cheaper in one pass than in two small ones
   const size_t nchunks = ((size_t)B + n - 1) / n;
   return (int)(((size_t)B + nchunks - 1) / nchunks);  // equal chunks
 }
