@@ -32,7 +32,7 @@ extern "C" {
 #endif
 
 #define TACEX_MAX_LEVELS 8
-#define TACEX_ABI_VERSION 2
+#define TACEX_ABI_VERSION 3
 
 typedef struct tacex_taxim_ctx tacex_taxim_ctx;
 typedef struct tacex_fots_ctx tacex_fots_ctx;
@@ -110,6 +110,8 @@ typedef struct tacex_shadow_params {
   int32_t num_heights;         /* 24 */
   int32_t num_steps;           /* 51  (longest table entry; shorter ones padded with +inf, TT:118-126) */
   const float* fan_angles;     /* (num_directions, num_fan_rays): direction + linspace(-fan_angle, fan_angle), TT:103-105 */
+  const float* fan_cos;        /* (num_directions, num_fan_rays) float32 cos / sin of fan_angles as the HOST library computes them */
+  const float* fan_sin;        /*   (torch.cos / torch.sin of the float32 table, TT:299,303): the device multiplies by these bits */
   const float* table;          /* (3, num_directions, num_heights, num_steps), RGB order, already / 255, +inf padded */
   int32_t win_left, win_right, win_top, win_bottom; /* composite window of the two box-dilation rounds, TT:261-272 */
   float shadow_depth_0;        /* 0.4, TT:97 */
@@ -124,6 +126,13 @@ typedef struct tacex_shadow_params {
 int tacex_taxim_set_shadow(tacex_taxim_ctx* ctx, const tacex_shadow_params* params);
 /* extra scratch (beyond tacex_taxim_workspace_bytes) a render with TACEX_FLAG_WITH_SHADOW needs, placed right after it */
 size_t tacex_taxim_shadow_workspace_bytes(const tacex_taxim_ctx* ctx, int num_frames);
+/* The ray march of the shadow branch alone (TT:261-337): deformed gel z_dev (B,H,W) mm, shrunken contact mask mask_dev
+ * (B,H,W) uint8, gradient direction grad_dir_dev (B,H,W) -> shadow_min_dev (B,H,W,3): per pixel and channel the minimum
+ * table value over all ray samples that hit it, +inf where none does (what torch_scatter.scatter_min leaves in
+ * `shadow_img`, TT:324-336).  Ring pixels, table bins and sample coordinates are integer work in the reference's op order
+ * (float32 multiply, add, truncate - no fused multiply-add): parity tests compare this map EXACTLY. */
+int tacex_taxim_shadow_rays(tacex_taxim_ctx* ctx, const float* z_dev, const uint8_t* mask_dev, const float* grad_dir_dev,
+                            float* shadow_min_dev, int num_frames, void* stream);
 
 /* Flags for tacex_taxim_render / tacex_taxim_deform */
 #define TACEX_FLAG_NO_SHIFT      1u  /* press_depth=None: use the height map as is (TT:188-189 skipped) */
@@ -256,6 +265,19 @@ int tacex_fots_markers_partials(tacex_fots_ctx* ctx, const float* z_dev, const u
                                 const float* indent_dev, const float* theta_dev, float* traj_state_dev,
                                 float* markers_dev, void* workspace_dev, const void* partials_dev,
                                 int partials_per_env, int num_envs, void* stream);
+
+/* Marker IMAGE and RGB x marker overlay (FS:346-384 `draw_markers`, FS:265-272) for all envs:
+ *   canvas (H+24, W+24) uint8 = 255; for every marker in index order (later ones overwrite):
+ *     u = x + 0.5 + 12, v = y + 0.5 + 12 (float64); patch = table[floor(frac(u) SR)][floor(frac(v) SR)][patch_w] (12 x 12);
+ *     stamped at (floor(u) - 6, floor(v) - 6) when it lies fully inside the canvas;  image = canvas[12:-12, 12:-12].
+ *   markers_dev (B,2,M,2) f32 as written by tacex_fots_markers (the CURRENT positions, index 1, are drawn);
+ *   patch_table_dev (SR, SR, size_slots, 12, 12) uint8 - the reference draws it with cv2 (`generate_patch_array`, FS:387-446);
+ *   patch_w = floor((marker_size - base_circle_radius) * SR) (FS:370-373: 15 for marker_size 3);
+ *   img_dev (B,H,W) uint8 [nullable]; overlay_dev (B,H,W,3) uint8 = uint8(float64(rgb * 255) * marker / 255) [nullable,
+ *   needs rgb_dev (B,H,W,3) f32]. */
+int tacex_fots_marker_image(const float* markers_dev, const uint8_t* patch_table_dev, int super_resolution_ratio,
+                            int size_slots, int patch_w, const float* rgb_dev, uint8_t* img_dev, uint8_t* overlay_dev,
+                            int num_envs, int num_markers, int height, int width, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Gelpad FEM inner step (what libuipc's world.advance() runs for the StableNeoHookean gelpad,

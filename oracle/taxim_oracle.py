@@ -309,7 +309,12 @@ class TaximOracle:
         first = total // 2
         return [np.maximum(1, first), np.maximum(1, total - first)]  # each (kw, kh)
 
-    def shade_with_shadow(self, Z: np.ndarray, M: np.ndarray) -> np.ndarray:
+    def shadow_map(self, Z: np.ndarray, M: np.ndarray):
+        """(B,H,W,3) per-pixel / channel minimum of the shadow-table samples (+inf: no sample) = `shadow_img` of TT:324-336,
+        and the gradient direction map it was marched with."""
+        return self.shade_with_shadow(Z, M, _return_shadow_map=True)
+
+    def shade_with_shadow(self, Z: np.ndarray, M: np.ndarray, _return_shadow_map: bool = False) -> np.ndarray:
         """Deformed gel (B,H,W) + shrunken contact mask -> (B,H,W,3) RGB with cast shadows."""
         H, W = self.H, self.W
         B = Z.shape[0]
@@ -335,8 +340,11 @@ class TaximOracle:
         nstep = sel.shape[-1]
         steps = (np.arange(nstep) + 1).astype(F32)
         step_w, step_h = self.p.rel("shadow_step", (H, W))  # (w_val, h_val); x uses [1], y uses [0] (TT:300-305)
-        sx = (xi[:, None, None].astype(F32) + (F32(step_h) * steps)[None, None, :] * np.cos(thetas)[:, :, None]).astype(F32)
-        sy = (yi[:, None, None].astype(F32) + (F32(step_w) * steps)[None, None, :] * np.sin(thetas)[:, :, None]).astype(F32)
+        # cos / sin of the float32 fan table (TT:299,303 take them of the gathered angles; taking them of the table first and
+        # gathering is the same numbers and lets the device use the very same bits, tacex_amd/calibration.py:build_shadow_tables)
+        cos_t, sin_t = np.cos(self.fan).astype(F32)[norm_idx], np.sin(self.fan).astype(F32)[norm_idx]
+        sx = (xi[:, None, None].astype(F32) + ((F32(step_h) * steps)[None, None, :] * cos_t[:, :, None]).astype(F32)).astype(F32)
+        sy = (yi[:, None, None].astype(F32) + ((F32(step_w) * steps)[None, None, :] * sin_t[:, :, None]).astype(F32)).astype(F32)
         sx = np.trunc(sx).astype(np.int64)
         sy = np.trunc(sy).astype(np.int64)
         cx, cy = np.clip(sx, 0, W - 1), np.clip(sy, 0, H - 1)
@@ -346,6 +354,8 @@ class TaximOracle:
         flat = (bi[n_i] * H + sy[valid]) * W + sx[valid]
         for c in range(3):
             np.minimum.at(shadow[c], flat, sel[c, n_i, s_i])
+        if _return_shadow_map:
+            return np.moveaxis(shadow.reshape(3, B, H, W), 0, -1), dr
         sim = np.minimum(sim, np.moveaxis(shadow.reshape(3, B, H, W), 0, 1))
         wdt = np.float64 if self.blur_mode == "direct" else F32
         s1 = self._blur(sim.astype(wdt), self.p.rel("shadow_blur_sigma", (H, W)))

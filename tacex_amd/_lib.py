@@ -11,7 +11,7 @@ from pathlib import Path
 from ._build import LIB, build_library
 
 MAX_LEVELS = 8
-ABI_VERSION = 2  # TACEX_ABI_VERSION of include/tacex_hip.h; bumped whenever a signature or struct layout changes
+ABI_VERSION = 3  # TACEX_ABI_VERSION of include/tacex_hip.h; bumped whenever a signature or struct layout changes
 FLAG_NO_SHIFT = 1
 FLAG_HAVE_FRAME_MIN = 2
 FLAG_WITH_SHADOW = 4
@@ -46,7 +46,7 @@ class TaximParams(C.Structure):
 class ShadowParams(C.Structure):
     _fields_ = [
         ("num_directions", C.c_int32), ("num_fan_rays", C.c_int32), ("num_heights", C.c_int32), ("num_steps", C.c_int32),
-        ("fan_angles", c_float_p), ("table", c_float_p),
+        ("fan_angles", c_float_p), ("fan_cos", c_float_p), ("fan_sin", c_float_p), ("table", c_float_p),
         ("win_left", C.c_int32), ("win_right", C.c_int32), ("win_top", C.c_int32), ("win_bottom", C.c_int32),
         ("shadow_depth_0", C.c_float), ("height_precision", C.c_float), ("discretize_precision", C.c_float),
         ("step_x", C.c_float), ("step_y", C.c_float),
@@ -96,6 +96,7 @@ SIGNATURES = {
     "tacex_taxim_workspace_bytes": (_sz, [_vp, _i]),
     "tacex_taxim_set_shadow": (_i, [_vp, C.POINTER(ShadowParams)]),
     "tacex_taxim_shadow_workspace_bytes": (_sz, [_vp, _i]),
+    "tacex_taxim_shadow_rays": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _vp]),
     "tacex_height_map_from_depth": (_i, [_vp, _d, _d, _f, _f, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "tacex_indentation_depth": (_i, [_vp, _f, _f, _vp, _vp, _i, _i, _i, _vp]),
     "tacex_taxim_render": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _u, _vp]),
@@ -121,6 +122,7 @@ SIGNATURES = {
     "tacex_taxim_set_fots_partials": (_i, [_vp, _vp, _i]),
     "tacex_taxim_set_fots_taps": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _i]),
     "tacex_fots_markers_compact": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp]),
+    "tacex_fots_marker_image": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "tacex_fem_create": (_i, [_i, C.POINTER(FemParams), C.POINTER(_vp)]),
     "tacex_fem_destroy": (None, [_vp]),
     "tacex_fem_workspace_bytes": (_sz, [_vp, _i]),

@@ -271,7 +271,11 @@ def build_shadow_tables(calib_folder: Path, tables: TaximTables) -> dict:
     step_w, step_h = sim.shadow_step((H, W))
     sbw, sbh = sim.shadow_blur_sigma((H, W))
     kw, kh = gaussian_kernel_size(sbw), gaussian_kernel_size(sbh)
-    return dict(fan=np.ascontiguousarray(fan), table=np.ascontiguousarray(table), ndir=int(fan.shape[0]), nfan=int(n_fan),
+    # cos / sin of the fan angles, float32 like torch.cos / torch.sin of the float32 table (taxim_torch.py:299,303): computed
+    # HERE so that device and CPU oracle multiply by the same bits - the ray sample coordinates are then integer-exact
+    return dict(fan=np.ascontiguousarray(fan), fan_cos=np.ascontiguousarray(np.cos(fan), dtype=F32),
+                fan_sin=np.ascontiguousarray(np.sin(fan), dtype=F32),
+                table=np.ascontiguousarray(table), ndir=int(fan.shape[0]), nfan=int(n_fan),
                 nheight=int(table.shape[2]), nstep=int(nstep), win=(wl, wr, wt, wb), depth0=0.4,
                 height_precision=float(sim.height_precision), discretize_precision=float(sim.discretize_precision),
                 step_x=float(step_h), step_y=float(step_w),  # (sic) x uses shadow_step[1] = the height-scaled value

@@ -12,6 +12,8 @@
 // displacements float64, output float32.
 #include <hip/hip_runtime.h>
 #include <math.h>
+
+#include <algorithm>
 #include <stdint.h>
 
 #include "tacex_hip.h"
@@ -235,6 +237,69 @@ __global__ __launch_bounds__(128) void fots_marker_kernel(FotsArgs a) {
   out_cur[tid * 2 + 1] = (float)ny;
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Marker image (FS:346-384 `draw_markers`) + RGB x marker overlay (FS:265-272), SURVEY 8(f) n3.
+// The reference stamps one 12 x 12 patch per marker into a (H+24, W+24) uint8 canvas of 255s, the patch chosen from a
+// pre-drawn table by the sub-pixel phase of the marker centre, LATER MARKERS OVERWRITING EARLIER ONES where stamps
+// overlap, and crops the 12-pixel margin.  Here one workgroup owns a band of canvas rows of one env in LDS (the whole
+// 264 x 344 canvas of a 320 x 240 image is 90 KB), stamps the markers in index order with a barrier in between (the order
+// is the semantics; a stamp is 144 byte writes), then writes the cropped band - and, on request, the overlay
+// uint8(float64(rgb32 * 255) * float64(marker) / 255) exactly as NumPy promotes it.
+// Pure integer / byte work apart from the two floor()s of the float64 marker coordinates: bit-exact.
+// ------------------------------------------------------------------------------------------------
+struct MarkerImgArgs {
+  const float* markers;   // (B, 2, M, 2) f32: [initial | current] x (x, y); the current positions are drawn
+  const uint8_t* patches; // (SR, SR, S, 12, 12) u8
+  const float* rgb;       // (B, H, W, 3) f32 in [0,1], nullable
+  uint8_t* img;           // (B, H, W) u8, nullable when only the overlay is wanted
+  uint8_t* overlay;       // (B, H, W, 3) u8, nullable
+  int B, M, H, W, SR, S, patch_w;  // patch_w = floor((marker_size - base_radius) * SR)
+  int band_rows, nbands;
+};
+constexpr int kMkPad = 12, kMkPatch = 12;
+
+__global__ __launch_bounds__(256) void fots_marker_image_kernel(MarkerImgArgs a) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t canvas[];  // band_rows x (W + 24)
+  const int e = blockIdx.x / a.nbands, band = blockIdx.x - e * a.nbands;
+  const int CW = a.W + 2 * kMkPad, CH = a.H + 2 * kMkPad;
+  const int y0 = band * a.band_rows, y1 = min(CH, y0 + a.band_rows);  // canvas rows of this band
+  const int tid = threadIdx.x;
+  for (int i = tid * 4; i < (y1 - y0) * CW; i += 256 * 4) *reinterpret_cast<uint32_t*>(canvas + i) = 0xffffffffu;  // CW % 4 == 0
+  __syncthreads();
+  const float* cur = a.markers + ((size_t)e * 2 + 1) * a.M * 2;
+  for (int m = 0; m < a.M; ++m) {
+    // marker_uv + 0.5 (float64, FS:361) + 12 (FS:366-367)
+    const double u = ((double)cur[m * 2 + 0] + 0.5) + 12.0, v = ((double)cur[m * 2 + 1] + 0.5) + 12.0;
+    const double fu = floor(u), fv = floor(v);
+    const int pu = (int)floor((u - fu) * a.SR), pv = (int)floor((v - fv) * a.SR);  // FS:368-369
+    const int cu = (int)fu - 6, cv = (int)fv - 6;                                   // FS:375-376
+    // FS:377: canvas_w - 12 > cu >= 0 and canvas_h - 12 > cv >= 0 (a NaN / huge coordinate fails the test like in Python)
+    const bool ok = u == u && v == v && fabs(u) < 1e9 && fabs(v) < 1e9 && cu >= 0 && cu < CW - 12 && cv >= 0 && cv < CH - 12;
+    if (ok && cv + kMkPatch > y0 && cv < y1 && tid < kMkPatch * kMkPatch) {
+      const int dy = tid / kMkPatch, dx = tid - dy * kMkPatch, yy = cv + dy;
+      if (yy >= y0 && yy < y1)
+        canvas[(yy - y0) * CW + cu + dx] =
+            a.patches[((((size_t)pu * a.SR + pv) * a.S + a.patch_w) * kMkPatch + dy) * kMkPatch + dx];
+    }
+    __syncthreads();  // stamps are ordered: marker m + 1 may overwrite marker m
+  }
+  // cropped rows of this band: canvas rows [max(y0, 12), min(y1, H + 12))
+  const int r0 = max(y0, kMkPad), r1 = min(y1, a.H + kMkPad);
+  for (int i = tid; i < (r1 - r0) * a.W; i += 256) {
+    const int ry = i / a.W, x = i - ry * a.W;
+    const uint8_t mv = canvas[(r0 + ry - y0) * CW + kMkPad + x];
+    const size_t p = ((size_t)e * a.H + (r0 + ry - kMkPad)) * a.W + x;
+    if (a.img) a.img[p] = mv;
+    if (a.overlay) {
+      // FS:268-271: tactile_rgb (f32) * 255 -> f32; * (marker.astype(f64) / 255) -> f64; astype(uint8) truncates
+      const double f = (double)mv / 255.0;
+#pragma unroll
+      for (int ch = 0; ch < 3; ++ch) a.overlay[p * 3 + ch] = (uint8_t)(int)((double)(a.rgb[p * 3 + ch] * 255.0f) * f);
+    }
+  }
+}
+
 }  // namespace tacex
 
 using namespace tacex;
@@ -337,6 +402,41 @@ static int fots_markers_impl(tacex_fots_ctx* c, const float* z, const uint8_t* m
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail_hip(e, "fots kernels");
   return 0;
+}
+
+int tacex_fots_marker_image(const float* markers, const uint8_t* patches, int super_res, int size_slots, int patch_w,
+                            const float* rgb, uint8_t* img, uint8_t* overlay, int B, int M, int H, int W, void* stream) {
+  if (!markers || !patches || (!img && !overlay)) { set_error("tacex_fots_marker_image: null argument"); return 2; }
+  if (overlay && !rgb) { set_error("tacex_fots_marker_image: the overlay needs the RGB frame"); return 2; }
+  if (super_res < 1 || size_slots < 1 || patch_w < 0 || patch_w >= size_slots) {
+    set_error("tacex_fots_marker_image: patch table index %d outside [0, %d)", patch_w, size_slots);
+    return 2;
+  }
+  if (W % 4 != 0 || H <= 0 || W <= 0 || M < 0) { set_error("tacex_fots_marker_image: need W %% 4 == 0, H > 0"); return 2; }
+  if (B <= 0) return 0;
+  MarkerImgArgs a{};
+  a.markers = markers; a.patches = patches; a.rgb = rgb; a.img = img; a.overlay = overlay;
+  a.B = B; a.M = M; a.H = H; a.W = W; a.SR = super_res; a.S = size_slots; a.patch_w = patch_w;
+  const int CW = W + 2 * kMkPad, CH = H + 2 * kMkPad;
+  const size_t budget = 96 * 1024;  // canvas bytes per workgroup
+  a.band_rows = (int)std::min<size_t>((size_t)CH, budget / CW);
+  if (a.band_rows < 2 * kMkPatch) { set_error("tacex_fots_marker_image: image too wide (%d)", W); return 2; }
+  a.nbands = (CH + a.band_rows - 1) / a.band_rows;
+  const size_t lds = (size_t)a.band_rows * CW;
+  auto kern = fots_marker_image_kernel;
+  if (lds > 64 * 1024) {
+    static bool attr_done[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+    if (!attr_done[dev]) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)budget);
+      if (e != hipSuccess) return fail_hip(e, "hipFuncSetAttribute(fots_marker_image_kernel)");
+      attr_done[dev] = true;
+    }
+  }
+  hipLaunchKernelGGL(kern, dim3(B * a.nbands), dim3(256), lds, (hipStream_t)stream, a);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : fail_hip(e, "fots_marker_image_kernel");
 }
 
 }  // extern "C"

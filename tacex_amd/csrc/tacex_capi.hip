@@ -358,7 +358,7 @@ static int stream_plan(tacex_taxim_ctx* c, int n_fused, int B, int oh, int ow, c
 }
 
 int tacex_taxim_set_shadow(tacex_taxim_ctx* c, const tacex_shadow_params* p) {
-  if (!c || !p || !p->fan_angles || !p->table || !p->blur_taps_w || !p->blur_taps_h) { set_error("tacex_taxim_set_shadow: null argument"); return 2; }
+  if (!c || !p || !p->fan_angles || !p->fan_cos || !p->fan_sin || !p->table || !p->blur_taps_w || !p->blur_taps_h) { set_error("tacex_taxim_set_shadow: null argument"); return 2; }
   if (p->num_directions < 1 || p->num_fan_rays < 1 || p->num_heights < 2 || p->num_steps < 1 || p->blur_kw % 2 != 1 || p->blur_kh % 2 != 1) {
     set_error("tacex_taxim_set_shadow: bad table dimensions");
     return 2;
@@ -370,6 +370,8 @@ int tacex_taxim_set_shadow(tacex_taxim_ctx* c, const tacex_shadow_params* p) {
   s.depth0 = p->shadow_depth_0; s.height_prec = p->height_precision; s.disc_prec = p->discretize_precision;
   s.step_x = p->step_x; s.step_y = p->step_y;
   int rc = upload(c, p->fan_angles, (size_t)s.ndir * s.nfan, &s.fan_dev);
+  if (!rc) rc |= upload(c, p->fan_cos, (size_t)s.ndir * s.nfan, &s.fan_cos_dev);
+  if (!rc) rc |= upload(c, p->fan_sin, (size_t)s.ndir * s.nfan, &s.fan_sin_dev);
   if (!rc) {  // (3, ndir, nh, nstep) -> (ndir, nh, nstep, 4)
     std::vector<float> t((size_t)s.ndir * s.nheight * s.nstep * 4, 0.0f);
     for (int ch = 0; ch < 3; ++ch)
@@ -393,6 +395,15 @@ size_t tacex_taxim_shadow_workspace_bytes(const tacex_taxim_ctx* c, int B) {
   if (!c || B <= 0) return 0;
   const size_t img = align_up((size_t)B * c->H * c->W * sizeof(float), 256);
   return 12 * img;  // deformed gel 1, mask 1 (u8, one image slot), gdir 1, raw 3, shadow 3, tmp 3
+}
+
+int tacex_taxim_shadow_rays(tacex_taxim_ctx* c, const float* z, const uint8_t* mask, const float* gdir, float* shadow_min, int B,
+                            void* stream) {
+  if (!c || !z || !mask || !gdir || !shadow_min) { set_error("tacex_taxim_shadow_rays: null argument"); return 2; }
+  if (!c->shadow.ready) { set_error("tacex_taxim_shadow_rays: needs tacex_taxim_set_shadow first"); return 2; }
+  if (B <= 0) return 0;
+  HIP_TRY(run_shadow_rays(c->shadow, c->shade, z, mask, c->gel_dev, gdir, shadow_min, B, (hipStream_t)stream), "shadow_ray_kernel");
+  return 0;
 }
 
 size_t tacex_taxim_workspace_bytes(const tacex_taxim_ctx* c, int B) {

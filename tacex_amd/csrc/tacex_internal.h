@@ -63,11 +63,15 @@ struct ShadowParams {  // shadow branch tables (taxim_shadow.hip), set by tacex_
   int wl = 0, wr = 0, wt = 0, wb = 0;
   float depth0 = 0.4f, height_prec = 0.1f, disc_prec = 0.1f, step_x = 0.f, step_y = 0.f;
   float* fan_dev = nullptr;     // (ndir, nfan)
+  float* fan_cos_dev = nullptr; // (ndir, nfan) host-computed float32 cos / sin of the fan angles
+  float* fan_sin_dev = nullptr;
   float* table_dev = nullptr;   // (ndir, nheight, nstep, 4)
   int sblur_kw = 1, sblur_kh = 1, final_kw = 1, final_kh = 1;
   float* sblur_taps_w_dev = nullptr; float* sblur_taps_h_dev = nullptr;
   float* final_taps_w_dev = nullptr; float* final_taps_h_dev = nullptr;
 };
+hipError_t run_shadow_rays(const ShadowParams& sw, const ShadeParams& sp, const float* z, const uint8_t* mask, const float* gel,
+                           const float* gdir, float* shadow_min, int B, hipStream_t st);
 hipError_t run_shadow(const ShadowParams& sw, const ShadeParams& sp, const float* z, const uint8_t* mask, const float* gel,
                       float* rgb, float* ws_raw, float* ws_shadow, float* ws_gdir, float* ws_tmp, int B, hipStream_t st);
 

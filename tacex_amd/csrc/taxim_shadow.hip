@@ -61,7 +61,8 @@ struct ShadowRayArgs {
   const uint8_t* mask;    // (B,H,W) shrunken contact mask
   const float* gdir;      // (B,H,W)
   const float* gel;       // (H,W)
-  const float* fan;       // (ndir, nfan)
+  const float* fan_cos;   // (ndir, nfan) float32 cos / sin of the fan angles, computed on the host (see tacex_shadow_params)
+  const float* fan_sin;
   const float* table;     // (ndir, nheight, nstep, 4)  [r,g,b,pad], +inf padded
   float* shadow;          // (B,H,W,3) initialised to +inf
   int H, W, B, ndir, nfan, nheight, nstep;
@@ -70,6 +71,10 @@ struct ShadowRayArgs {
 };
 
 __global__ __launch_bounds__(256) void shadow_ray_kernel(ShadowRayArgs a) {
+  // Every float32 expression below feeds a floor / truncation to an integer (table bins, sample pixel): it must round where the
+  // reference's separate torch ops round.  The library is built with -ffp-contract=fast; a fused multiply-add here moved
+  // samples that sit on an integer boundary into the neighbouring pixel.
+#pragma clang fp contract(off)
   const int H = a.H, W = a.W, npix = H * W;
   const int b = blockIdx.y;
   const int p = blockIdx.x * blockDim.x + threadIdx.x;
@@ -94,14 +99,14 @@ __global__ __launch_bounds__(256) void shadow_ray_kernel(ShadowRayArgs a) {
   const float* __restrict__ tab = a.table + ((size_t)nidx * a.nheight + hidx) * a.nstep * 4;
   float* __restrict__ sh = a.shadow + (size_t)b * npix * 3;
   for (int f = 0; f < a.nfan; ++f) {
-    const float th = a.fan[nidx * a.nfan + f];
-    const float cs = cosf(th), sn = sinf(th);
+    const float cs = a.fan_cos[nidx * a.nfan + f], sn = a.fan_sin[nidx * a.nfan + f];
     for (int s = 0; s < a.nstep; ++s) {
       const v4f v = *reinterpret_cast<const v4f*>(tab + s * 4);
       if (isinf(v.x) && isinf(v.y) && isinf(v.z)) continue;  // padding
-      // float32: x + (step * (s+1)) * cos(theta), truncated toward zero like .long() (TT:300-305)
-      const float fx = (float)x + (a.step_x * (float)(s + 1)) * cs;
-      const float fy = (float)y + (a.step_y * (float)(s + 1)) * sn;
+      // float32, in the reference's order: (step * (s+1)) -> * cos(theta) -> x + ..., truncated toward zero like .long() (TT:298-305)
+      const float tx = a.step_x * (float)(s + 1), ty = a.step_y * (float)(s + 1);
+      const float ux = tx * cs, uy = ty * sn;
+      const float fx = (float)x + ux, fy = (float)y + uy;
       const int sx = (int)fx, sy = (int)fy;
       if (sx < 0 || sx >= W || sy < 0 || sy >= H) continue;
       if (!(zsrc_px < z[(size_t)sy * W + sx] / a.pixmm)) continue;  // TT:312-315: target must be higher
@@ -153,6 +158,24 @@ __global__ __launch_bounds__(256) void blur_nhwc3_kernel(Blur3Args a) {
   d[0] = acc0; d[1] = acc1; d[2] = acc2;
 }
 
+hipError_t run_shadow_rays(const ShadowParams& sw, const ShadeParams& sp, const float* z, const uint8_t* mask, const float* gel,
+                           const float* gdir, float* shadow_min, int B, hipStream_t st) {
+  const int H = sp.H, W = sp.W, npix = H * W;
+  const dim3 grid((npix + 255) / 256, B);
+  const size_t n3 = (size_t)B * npix * 3;
+  hipLaunchKernelGGL(fill_kernel, dim3((unsigned)((n3 + 255) / 256 < 65536 ? (n3 + 255) / 256 : 65536)), dim3(256), 0, st,
+                     shadow_min, INFINITY, n3);
+  ShadowRayArgs r{};
+  r.z = z; r.mask = mask; r.gdir = gdir; r.gel = gel; r.fan_cos = sw.fan_cos_dev; r.fan_sin = sw.fan_sin_dev; r.table = sw.table_dev;
+  r.shadow = shadow_min;
+  r.H = H; r.W = W; r.B = B; r.ndir = sw.ndir; r.nfan = sw.nfan; r.nheight = sw.nheight; r.nstep = sw.nstep;
+  r.wl = sw.wl; r.wr = sw.wr; r.wt = sw.wt; r.wb = sw.wb;
+  r.pixmm = sp.pixmm; r.depth0 = sw.depth0; r.height_prec = sw.height_prec; r.disc_prec = sw.disc_prec;
+  r.step_x = sw.step_x; r.step_y = sw.step_y;
+  hipLaunchKernelGGL(shadow_ray_kernel, grid, dim3(256), 0, st, r);
+  return hipGetLastError();
+}
+
 hipError_t run_shadow(const ShadowParams& sw, const ShadeParams& sp, const float* z, const uint8_t* mask, const float* gel,
                       float* rgb, float* ws_raw, float* ws_shadow, float* ws_gdir, float* ws_tmp, int B, hipStream_t st) {
   const int H = sp.H, W = sp.W, npix = H * W;
@@ -164,16 +187,7 @@ hipError_t run_shadow(const ShadowParams& sw, const ShadeParams& sp, const float
   a.inv_x_binr = (float)(1.0 / (double)sp.x_binr); a.inv_y_binr = (float)(1.0 / (double)sp.y_binr);
   const dim3 grid((npix + 255) / 256, B);
   hipLaunchKernelGGL(shade_raw_kernel, grid, dim3(256), 0, st, a, ws_raw, ws_gdir);
-  const size_t n3 = (size_t)B * npix * 3;
-  hipLaunchKernelGGL(fill_kernel, dim3((unsigned)((n3 + 255) / 256 < 65536 ? (n3 + 255) / 256 : 65536)), dim3(256), 0, st,
-                     ws_shadow, INFINITY, n3);
-  ShadowRayArgs r{};
-  r.z = z; r.mask = mask; r.gdir = ws_gdir; r.gel = gel; r.fan = sw.fan_dev; r.table = sw.table_dev; r.shadow = ws_shadow;
-  r.H = H; r.W = W; r.B = B; r.ndir = sw.ndir; r.nfan = sw.nfan; r.nheight = sw.nheight; r.nstep = sw.nstep;
-  r.wl = sw.wl; r.wr = sw.wr; r.wt = sw.wt; r.wb = sw.wb;
-  r.pixmm = sp.pixmm; r.depth0 = sw.depth0; r.height_prec = sw.height_prec; r.disc_prec = sw.disc_prec;
-  r.step_x = sw.step_x; r.step_y = sw.step_y;
-  hipLaunchKernelGGL(shadow_ray_kernel, grid, dim3(256), 0, st, r);
+  if (hipError_t e = run_shadow_rays(sw, sp, z, mask, gel, ws_gdir, ws_shadow, B, st); e != hipSuccess) return e;
   Blur3Args b1{};
   b1.src = ws_raw; b1.other = ws_shadow; b1.add = sp.bg_nhwc_dev; b1.dst = ws_tmp;
   b1.taps_w = sw.sblur_taps_w_dev; b1.taps_h = sw.sblur_taps_h_dev; b1.kw = sw.sblur_kw; b1.kh = sw.sblur_kh;

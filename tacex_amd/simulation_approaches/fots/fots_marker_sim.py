@@ -162,6 +162,57 @@ class FOTSMarkerSimulator(GelSightSimulator):
         _lib.check(rc, "tacex_fots_markers")
         return self.marker_data
 
+    # -- marker image (fots_marker_sim.py:346-384, 265-272) --------------------------------------------------
+    def set_patch_array(self, patch_array_dict: dict):
+        """The pre-drawn marker patches (`generate_patch_array()` of the reference, FS:387-446, or `marker_patches.load_patch_array`)."""
+        from .marker_patches import check_patch_array
+
+        check_patch_array(patch_array_dict)
+        self.patch_array_dict = patch_array_dict
+        self._patch_dev = torch.from_numpy(np.ascontiguousarray(patch_array_dict["patch_array"])).to(self._device)
+
+    def _patches(self):
+        if getattr(self, "_patch_dev", None) is None:
+            from .marker_patches import generate_patch_array
+
+            self.set_patch_array(generate_patch_array())  # NumPy stand-in for the OpenCV-drawn table (see marker_patches.py)
+        return self._patch_dev
+
+    def marker_images(self, marker_data: torch.Tensor | None = None, marker_size: float = 3, overlay_rgb: torch.Tensor | None = None,
+                      img_res: tuple | None = None):
+        """Marker image of EVERY env in one launch: (B, H, W) uint8, white canvas with the dot patch of each marker stamped at
+        its current position (`draw_markers`, FS:346-384).  With `overlay_rgb` (B, H, W, 3) float32 in [0,1] also the RGB x marker
+        overlay the reference shows (FS:265-272): uint8(rgb * 255 * marker / 255).  Returns (images, overlay | None)."""
+        md = self.marker_data if marker_data is None else marker_data
+        md = md.to(self._device, torch.float32).contiguous()
+        B, _, M, _ = md.shape
+        W, H = self.cfg.tactile_img_res if img_res is None else img_res
+        pt = self._patches()
+        d = self.patch_array_dict
+        sr, S = int(d["super_resolution_ratio"]), int(d["size_slot_num"])
+        import math
+
+        pw = math.floor((marker_size - d["base_circle_radius"]) * sr)  # FS:370-373
+        img = torch.empty((B, H, W), dtype=torch.uint8, device=self._device)
+        ov = None
+        if overlay_rgb is not None:
+            if tuple(overlay_rgb.shape) != (B, H, W, 3) or overlay_rgb.dtype != torch.float32:
+                raise ValueError(f"overlay_rgb must be float32 ({B}, {H}, {W}, 3)")
+            overlay_rgb = overlay_rgb.contiguous()
+            ov = torch.empty((B, H, W, 3), dtype=torch.uint8, device=self._device)
+        with torch.cuda.device(img.device):
+            rc = self._lib.tacex_fots_marker_image(_lib.ptr(md), _lib.ptr(pt), sr, S, int(pw), _lib.ptr(overlay_rgb), _lib.ptr(img),
+                                                   _lib.ptr(ov), B, M, H, W, _lib.current_stream_handle(img.device))
+        _lib.check(rc, "tacex_fots_marker_image")
+        return img, ov
+
+    def draw_markers(self, marker_uv: np.ndarray, marker_size=3, img_w=320, img_h=240) -> np.ndarray:
+        """Reference signature (FS:346): marker positions (num_markers, 2) of ONE sensor -> (img_h, img_w) uint8."""
+        uv = torch.from_numpy(np.asarray(marker_uv, dtype=np.float32)).to(self._device)
+        md = torch.stack((uv, uv), 0)[None]
+        img, _ = self.marker_images(md, marker_size, img_res=(img_w, img_h))
+        return img[0].cpu().numpy()
+
     def reset(self):
         """fots_marker_sim.py:206-208.  The trajectories are NOT cleared here (the reference does not either): an env's
         trajectory restarts when the marker simulation sees its indentation depth at 0 (FS:176-177), which the sensor's

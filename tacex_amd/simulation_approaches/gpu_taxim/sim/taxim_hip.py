@@ -147,8 +147,9 @@ class TaximHip:
         sh = build_shadow_tables(self._calib_folder, ctx.tables)
         p = _lib.ShadowParams()
         p.num_directions, p.num_fan_rays, p.num_heights, p.num_steps = sh["ndir"], sh["nfan"], sh["nheight"], sh["nstep"]
-        keep = [np.ascontiguousarray(sh[k], dtype=np.float32) for k in ("fan", "table", "blur_taps_w", "blur_taps_h")]
+        keep = [np.ascontiguousarray(sh[k], dtype=np.float32) for k in ("fan", "table", "blur_taps_w", "blur_taps_h", "fan_cos", "fan_sin")]
         p.fan_angles, p.table = keep[0].ctypes.data_as(_lib.c_float_p), keep[1].ctypes.data_as(_lib.c_float_p)
+        p.fan_cos, p.fan_sin = keep[4].ctypes.data_as(_lib.c_float_p), keep[5].ctypes.data_as(_lib.c_float_p)
         p.win_left, p.win_right, p.win_top, p.win_bottom = sh["win"]
         p.shadow_depth_0, p.height_precision, p.discretize_precision = sh["depth0"], sh["height_precision"], sh["discretize_precision"]
         p.step_x, p.step_y = sh["step_x"], sh["step_y"]
@@ -297,6 +298,22 @@ class TaximHip:
                 _lib.ptr(ws), B, flags, _lib.current_stream_handle(self._device))
         _lib.check(rc, "tacex_taxim_deform")
         return z_out, mask_out
+
+    def shadow_rays(self, deformed_gel: torch.Tensor, contact_mask: torch.Tensor, grad_dir: torch.Tensor) -> torch.Tensor:
+        """Ray march of the shadow branch alone (taxim_torch.py:261-337): (B,H,W) deformed gel [mm], uint8 shrunken contact
+        mask and gradient direction -> (B,H,W,3) per-pixel / channel minimum of the shadow-table samples (+inf: none)."""
+        z = self._check_hm(deformed_gel)
+        B, H, W = z.shape
+        ctx = self.context((H, W))
+        self._ensure_shadow(ctx)
+        m = contact_mask.to(self._device, torch.uint8).reshape(B, H, W).contiguous()
+        g = grad_dir.to(self._device, torch.float32).reshape(B, H, W).contiguous()
+        out = torch.empty((B, H, W, 3), dtype=torch.float32, device=self._device)
+        with torch.cuda.device(self._device):
+            rc = self._lib.tacex_taxim_shadow_rays(ctx.handle, _lib.ptr(z), _lib.ptr(m), _lib.ptr(g), _lib.ptr(out), B,
+                                                   _lib.current_stream_handle(self._device))
+        _lib.check(rc, "tacex_taxim_shadow_rays")
+        return out
 
     def shade(self, deformed_gel: torch.Tensor, return_bins: bool = False):
         """taxim_torch.py:237-258 on an existing deformed gel: (B,H,W) -> (B,H,W,3) [+ (B,H,W,2) uint8 bins]."""

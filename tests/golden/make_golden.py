@@ -41,7 +41,8 @@ def indentation_depth(hm_mm: torch.Tensor) -> torch.Tensor:
     return torch.where(d <= GELPAD_HEIGHT, (GELPAD_HEIGHT - d) * 1000, 0).float()
 
 
-def taxim_case(t, H, W, n, seed, levels: bool, shadow: bool, kinds=None, slim: bool = False, n_levels_frames=None):
+def taxim_case(t, H, W, n, seed, levels: bool, shadow: bool, kinds=None, slim: bool = False, n_levels_frames=None,
+               shadow_frames=None):
     kw = {} if kinds is None else {"kinds": kinds}
     hm, _ = synthetic_depth_maps(n, H, W, seed=seed, flat_fraction=0.0, **kw)
     hm[-1] = 29.0  # last frame: no contact at all
@@ -87,7 +88,8 @@ def taxim_case(t, H, W, n, seed, levels: bool, shadow: bool, kinds=None, slim: b
             out.pop(k)
     if shadow:
         rgbs = t.render_direct(hm, with_shadow=True, press_depth=indent, orig_hm_fmt=False)
-        out["rgb_shadow"] = rgbs.movedim(1, 3).contiguous().numpy()
+        rgbs = rgbs.movedim(1, 3).contiguous().numpy()
+        out["rgb_shadow"] = rgbs if shadow_frames is None else rgbs[:shadow_frames]  # frames render independently
     return out
 
 
@@ -204,7 +206,7 @@ def main():
     np.savez_compressed(HERE / "taxim_24x32.npz", **taxim_case(t, 24, 32, 3, 12, levels=True, shadow=False))
     np.savez_compressed(HERE / "taxim_48x64.npz", **taxim_case(t, 48, 64, 4, 13, levels=True, shadow=True))
     np.savez_compressed(HERE / "taxim_240x320.npz", **taxim_case(t, 240, 320, 5, 14, levels=True, shadow=True, n_levels_frames=2))
-    np.savez_compressed(HERE / "taxim_480x640.npz", **taxim_case(t, 480, 640, 2, 15, levels=False, shadow=False, slim=True))
+    np.savez_compressed(HERE / "taxim_480x640.npz", **taxim_case(t, 480, 640, 2, 15, levels=False, shadow=True, slim=True, shadow_frames=1))
     np.savez_compressed(HERE / "fots_240x320.npz", **fots_case(t, MarkerMotion, seed=21, n=4, steps=4))
     for f in sorted(HERE.glob("*.npz")):
         print(f.name, f.stat().st_size // 1024, "KiB")

@@ -139,3 +139,24 @@ def test_shadow_branch_oracle_vs_reference(golden_dir, calib_dir):
     r48 = o48.render_direct(g48["hm"], g48["indent"], with_shadow=True)
     strong = g48["grad_mag"] > 1e-3
     assert np.quantile(np.abs(r48 - g48["rgb_shadow"])[strong], 0.99) <= 1e-4
+
+
+def test_shadow_branch_oracle_vs_reference_640x480(golden_dir, calib_dir):
+    """The oracle's shadow branch at BASELINE config C5's resolution against the reference's render (frame 0)."""
+    from parity import well_conditioned_field
+
+    g = _load(golden_dir, 480, 640)
+    o = TaximOracle(calib_dir, (480, 640), "direct")
+    hm, ind = g["hm"][:1], g["indent"][:1]
+    Z, M = o.gel_pad_deformation(o.shifted_height_map(hm, ind))
+    _, mag, dr, im, idd = o.shade(Z, True)
+    rgb = o.shade_with_shadow(Z, M)
+    gg = {"idx_mag": g["idx_mag"], "idx_dir": g["idx_dir"], "grad_mag": np.where(g["idx_mag"] > 0, 1.0, 0.0)}  # slim fixture
+    ok = well_conditioned_field(im, idd, gg, frames=slice(0, 1), radius=6)
+    assert ok.sum() > 20000
+    d = np.abs(rgb - g["rgb_shadow"])
+    # a handful of the ~10^5 ray samples land in the neighbouring pixel (NumPy's and torch's float32 cos / sin differ in the last
+    # bit for some fan angles, and the product is truncated to a pixel index); the two blurs spread each over ~100 pixels
+    assert np.quantile(d[ok], 0.999) <= 1e-4, np.quantile(d[ok], 0.999)
+    assert (d[ok] > 1e-3).mean() == 0.0 and d[ok].max() <= 5e-4
+    assert np.abs(g["rgb_shadow"] - g["rgb"][:1])[ok].max() > 0.05

@@ -308,3 +308,48 @@ def test_streaming_tail_matches_tiled_tail(calib_dir, tmp_path, shape, segs):
     assert np.abs(a["obs_float32"] - b["obs_float32"]).max() <= 2e-6
     assert np.abs(a["obs_uint8"].astype(int) - b["obs_uint8"].astype(int)).max() <= 1 and (a["obs_uint8"] == b["obs_uint8"]).mean() > 0.999
     assert a["pix_m"].sum() > 0 and np.abs(a["markers"][:, 1] - a["markers"][:, 0]).max() > 0.1
+
+
+@pytest.mark.parametrize("shape", [(240, 320), (480, 640)])
+def test_shadow_ray_samples_exact_vs_oracle(taxim, golden_dir, calib_dir, shape):
+    """The ray march of the shadow branch is integer work (ring pixels, direction / height bins, truncated sample pixels,
+    TT:261-337) fed by float32 expressions in the reference's op order: given the SAME deformed gel, contact mask and gradient
+    direction, the HIP kernel's per-pixel / channel minimum map must equal the oracle's EXACTLY - every sample pixel and value."""
+    from oracle.taxim_oracle import TaximOracle
+    from parity import unpack_mask
+
+    H, W = shape
+    g = dict(np.load(golden_dir / f"taxim_{H}x{W}.npz"))
+    n = 2 if H == 480 else 4
+    Z = g["Z"][:n].astype(np.float32)
+    M = unpack_mask(g["M"], g["Z"].shape)[:n]
+    o = TaximOracle(calib_dir, (H, W), "direct")
+    ref, gdir = o.shadow_map(Z, M)
+    assert np.isfinite(ref).any(), "no shadow samples at all"
+    got = taxim.shadow_rays(torch.from_numpy(Z).cuda(), torch.from_numpy(M.astype(np.uint8)).cuda(), torch.from_numpy(gdir.astype(np.float32)).cuda())
+    got = got.cpu().numpy()
+    np.testing.assert_array_equal(np.isfinite(got), np.isfinite(ref))  # the sample index set
+    np.testing.assert_array_equal(got, ref)                            # ... and the table values that landed there
+
+
+def test_shadow_branch_640x480_vs_reference(taxim, golden_dir):
+    """with_shadow=True at BASELINE config C5's resolution against the reference's own render (frame 0 of the 480x640 fixture):
+    same protocol as at 320x240 - pixels whose receptive field of the two blurs (k = 5 and k = 9 here) is well conditioned."""
+    from parity import well_conditioned_field
+
+    g = dict(np.load(golden_dir / "taxim_480x640.npz"))
+    hm = torch.from_numpy(g["hm"][:1]).cuda()
+    indent = torch.from_numpy(g["indent"][:1]).cuda()
+    rgb = taxim.render_direct(hm, with_shadow=True, press_depth=indent).movedim(1, 3).cpu().numpy()
+    ref = g["rgb_shadow"]
+    assert rgb.shape == ref.shape == (1, 480, 640, 3)
+    Z, _ = taxim.deform(hm, indent)
+    _, idx = taxim.shade(Z, return_bins=True)
+    idx = idx.cpu().numpy().astype(np.int64)
+    gg = {"idx_mag": g["idx_mag"], "idx_dir": g["idx_dir"], "grad_mag": np.where(g["idx_mag"] > 0, 1.0, 0.0)}  # slim fixture: no grad_mag
+    ok = well_conditioned_field(idx[..., 0], idx[..., 1], gg, frames=slice(0, 1), radius=6)
+    assert ok.sum() > 20000
+    d = np.abs(rgb - ref)
+    assert np.quantile(d[ok], 0.999) <= 1e-4, np.quantile(d[ok], 0.999)
+    assert (d[ok] > 1e-3).mean() < 2e-3
+    assert np.abs(ref - g["rgb"][:1])[ok].max() > 0.05  # shadows are really cast there
