@@ -291,3 +291,123 @@ def attachment_aim_positions(offsets, body_pos, body_quat):
                   two_s * (i * k - j * r), two_s * (j * k + i * r), f(1) - two_s * (i * i + j * j)], -1).reshape(-1, 3, 3).astype(f)
     out = np.einsum("bij,aj->bai", R, np.asarray(offsets, f)).astype(f) + np.asarray(body_pos, f)[:, None, :]
     return out.astype(np.float64)
+
+
+# --------------------------------------------------------------------------------------------------
+# IPC contact of the surface vertices against one analytic indenter (first slice).  PARITY UNPINNED like the
+# rest of this file (libuipc's contact lives in the absent submodule); restates Li et al. 2020, "Incremental Potential
+# Contact", eq. 6:  b(d) = -(d - dhat)^2 ln(d / dhat) on 0 < d < dhat, here in the dimensionless gap s = d / dhat and weighted
+# per vertex:  E_c(x) = dt^2 kappa sum_v area_v b(d_v / dhat).   Known-answer tests: tests/test_fem_oracle.py.
+# --------------------------------------------------------------------------------------------------
+def contact_distance(ind, x):
+    """Signed distance d (V,) and its gradient n (V,3) of points x (V,3) to indenter [kind, cx, cy, cz, R, nx, ny, nz]."""
+    kind = int(ind[0])
+    c = np.asarray(ind[1:4], np.float64)
+    if kind == 1:
+        r = x - c
+        rho = np.linalg.norm(r, axis=-1)
+        return rho - ind[4], r / np.maximum(rho, 1e-300)[..., None]
+    if kind == 2:
+        n = np.asarray(ind[5:8], np.float64)
+        return (x - c) @ n, np.broadcast_to(n, x.shape).copy()
+    return np.full(x.shape[:-1], np.inf), np.zeros_like(x)
+
+
+def barrier(s):
+    """b(s), b'(s), b''(s) of the dimensionless IPC barrier, 0 outside (0, 1); +inf energy for s <= 0."""
+    s = np.asarray(s, np.float64)
+    act = (s > 0) & (s < 1)
+    ss = np.where(act, s, 0.5)
+    ln, q = np.log(ss), ss - 1.0
+    b = np.where(act, -q * q * ln, 0.0)
+    b = np.where(s <= 0, np.inf, b)
+    b1 = np.where(act, -2 * q * ln - q * q / ss, 0.0)
+    b2 = np.where(act, -2 * ln - 4 * q / ss + q * q / (ss * ss), 0.0)
+    return b, b1, b2
+
+
+class ContactModel:
+    """Barrier terms of one env: `area` (V,) vertex weights, indenter row, dhat [m], kappa [J/m^2], dt."""
+
+    def __init__(self, area, indenter, dhat, kappa, dt):
+        self.area, self.ind, self.dhat, self.kappa, self.dt = np.asarray(area, np.float64), np.asarray(indenter, np.float64), dhat, kappa, dt
+
+    def energy(self, x):
+        d, _ = contact_distance(self.ind, x)
+        b, _, _ = barrier(d / self.dhat)
+        with np.errstate(invalid="ignore"):
+            e = np.where(self.area > 0, self.area * b, 0.0)
+        return self.dt**2 * self.kappa * e.sum()
+
+    def gradient(self, x):
+        d, n = contact_distance(self.ind, x)
+        _, b1, _ = barrier(d / self.dhat)
+        return (self.dt**2 * self.kappa * self.area * b1 / self.dhat)[:, None] * n
+
+    def hess_blocks(self, x):
+        """(V,3,3) PSD-projected diagonal blocks b'' n n^T (the b' hess(d) part is dropped, as IPC does)."""
+        d, n = contact_distance(self.ind, x)
+        _, _, b2 = barrier(d / self.dhat)
+        return (self.dt**2 * self.kappa * self.area * b2 / self.dhat**2)[:, None, None] * n[:, :, None] * n[:, None, :]
+
+    def max_step(self, x, dx, slack=0.9):
+        """CCD filter: the largest step in [0, 1] that keeps every weighted vertex at a positive gap (1-Lipschitz bound)."""
+        d, _ = contact_distance(self.ind, x)
+        nd = np.linalg.norm(dx, axis=-1)
+        ok = (self.area > 0) & (nd > 0) & (d > 0) & np.isfinite(d)
+        return float(min(1.0, (slack * d[ok] / nd[ok]).min())) if ok.any() else 1.0
+
+
+def newton_step_contact(m: "FemModel", cm: ContactModel, x, x_tilde, constrained=None, aim=None, pcg_max_iter=64, pcg_tol_rate=1e-3,
+                        ls_max_iter=8):
+    """`FemModel.newton_step` with the barrier terms of `cm` in gradient, preconditioner, H.p and energy, and the CCD step
+    filter in front of the backtracking line search.  Returns (x_new, [E0, E1, step, pcg_iters])."""
+    g = m.gradient(x, x_tilde, constrained, aim) + cm.gradient(x)
+    Hc = cm.hess_blocks(x)
+    D = m.diag_blocks(x, constrained) + Hc
+    mdiag = m.mass * (1.0 + (m.strength * constrained if constrained is not None else 0.0))
+    Dinv = np.empty_like(D)
+    for v in range(len(m.X)):
+        try:
+            np.linalg.cholesky(D[v])
+            Dinv[v] = np.linalg.inv(D[v])
+        except np.linalg.LinAlgError:
+            Dinv[v] = np.eye(3) / mdiag[v]
+    prec = lambda r: np.einsum("vij,vj->vi", Dinv, r)
+    hv = lambda p: m.hess_vec(x, p, constrained) + np.einsum("vij,vj->vi", Hc, p)
+    energy = lambda y: m.energy(y, x_tilde, constrained, aim) + cm.energy(y)
+    d = np.zeros_like(x)
+    r = -g
+    z = prec(r)
+    p = z.copy()
+    rz = (r * z).sum()
+    rz0 = rz
+    it = 0
+    while it < pcg_max_iter and rz > pcg_tol_rate**2 * rz0 and rz0 > 0:
+        Hp = hv(p)
+        pHp = (p * Hp).sum()
+        if pHp <= 0:
+            if it == 0:
+                d = z.copy()
+            break
+        al = rz / pHp
+        d = d + al * p
+        r = r - al * Hp
+        z = prec(r)
+        rz_new = (r * z).sum()
+        p = z + (rz_new / rz) * p
+        rz = rz_new
+        it += 1
+    E0 = energy(x)
+    step = cm.max_step(x, d)
+    E1, x_new = E0, x
+    for _ in range(ls_max_iter + 1):
+        cand = x + step * d
+        Ec = energy(cand)
+        if Ec <= E0:
+            x_new, E1 = cand, Ec
+            break
+        step *= 0.5
+    else:
+        step = 0.0
+    return x_new, np.array([E0, E1, step, it])

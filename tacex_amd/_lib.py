@@ -130,6 +130,7 @@ SIGNATURES = {
     "tacex_fem_energy": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp]),
     "tacex_fem_gradient": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp]),
     "tacex_fem_newton_step": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _d, _i, _vp]),
+    "tacex_fem_set_contact": (_i, [_vp, _vp, _d, _d, _vp]),
     "tacex_fem_set_newton_early_exit": (_i, [_vp, _vp, C.c_double]),
     "tacex_fem_set_attachment_targets": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "tacex_fem_marker_uv": (_i, [_vp, _vp, _vp, _d, _d, _d, _d, _vp, _i, _i, _i, _vp]),

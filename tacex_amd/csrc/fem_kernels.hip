@@ -36,7 +36,50 @@ struct FemDev {
   const int* vt_off;      // (V+1) CSR vertex -> incident (tet*4 + local)
   const int* vt_idx;
   double mu, lam, alpha, psi_rest, dt, strength;
+  // IPC contact of the gelpad surface against one analytic indenter per env (first slice)
+  const double* area;       // (V) contact weight of a vertex = a third of the area of its surface triangles (0: interior); nullable
+  const double* indenters;  // (B,8) [kind, cx, cy, cz, radius, nx, ny, nz]: kind 0 none, 1 sphere, 2 half-space; nullable
+  double dhat, kappa;       // barrier activation distance [m], stiffness [J/m^2]
 };
+
+// ---- IPC barrier of one surface vertex against the env's analytic indenter ------------------------------------------
+// Li et al. 2020 (IPC) eq. 6 in the dimensionless gap s = d / dhat:  b(s) = -(s - 1)^2 ln s  for 0 < s < 1, 0 beyond.
+// Potential term of a vertex with weight w: dt^2 kappa w b(d / dhat); d = signed distance to the indenter surface
+// (sphere: |x - c| - R, half-space: n . (x - c)), n = grad d.  A gap <= 0 is a penetration: infinite energy (the
+// line search never accepts it; the conservative step bound below keeps the Newton direction out of it).
+struct ContactEval {
+  bool active;      // 0 < d < dhat
+  bool penetrating; // d <= 0
+  double d, n[3];
+  double e, b1, b2; // energy, dE/dd, d2E/dd2 (already times kappa w, NOT times dt^2)
+};
+__device__ __forceinline__ ContactEval contact_eval(const FemDev& m, const double* ind, double w, const double x[3]) {
+  ContactEval c;
+  c.active = false; c.penetrating = false; c.d = 1e300; c.e = 0.0; c.b1 = 0.0; c.b2 = 0.0; c.n[0] = c.n[1] = c.n[2] = 0.0;
+  if (!ind || !(w > 0.0)) return c;
+  const int kind = (int)ind[0];
+  if (kind == 1) {
+    const double r0 = x[0] - ind[1], r1 = x[1] - ind[2], r2 = x[2] - ind[3];
+    const double rho = sqrt(r0 * r0 + r1 * r1 + r2 * r2);
+    c.d = rho - ind[4];
+    const double ir = rho > 0.0 ? 1.0 / rho : 0.0;
+    c.n[0] = r0 * ir; c.n[1] = r1 * ir; c.n[2] = r2 * ir;
+  } else if (kind == 2) {
+    c.n[0] = ind[5]; c.n[1] = ind[6]; c.n[2] = ind[7];
+    c.d = c.n[0] * (x[0] - ind[1]) + c.n[1] * (x[1] - ind[2]) + c.n[2] * (x[2] - ind[3]);
+  } else {
+    return c;
+  }
+  if (c.d <= 0.0) { c.penetrating = true; c.e = INFINITY; return c; }
+  if (c.d >= m.dhat) return c;
+  c.active = true;
+  const double sg = c.d / m.dhat, ln = log(sg), q = sg - 1.0, kw = m.kappa * w;
+  c.e = -kw * q * q * ln;
+  c.b1 = kw * (-2.0 * q * ln - q * q / sg) / m.dhat;
+  c.b2 = kw * (-2.0 * ln - 4.0 * q / sg + q * q / (sg * sg)) / (m.dhat * m.dhat);
+  return c;
+}
+constexpr double kCcdSlack = 0.9;  // fraction of the conservative (1-Lipschitz) step bound d / |dx| a Newton step may use
 
 // ---- small dense helpers (row-major 3x3 in double[9]) ---------------------------------------------------
 __device__ __forceinline__ void cross3(const double* a, const double* b, double* o) {
@@ -277,7 +320,7 @@ __device__ __forceinline__ double block_sum(double v, double* sh /* >= 17 double
 }
 
 __device__ double env_energy(const FemDev& m, const double* x, const double* xt, const uint8_t* cons, const double* aim,
-                             double* sh) {
+                             double* sh, const double* ind = nullptr) {
   double e = 0.0;
   for (int t = threadIdx.x; t < m.T; t += blockDim.x) {
     int v[4];
@@ -298,6 +341,7 @@ __device__ double env_energy(const FemDev& m, const double* x, const double* xt,
       if (cons && cons[v]) { const double c = x[v * 3 + i] - aim[v * 3 + i]; qc += c * c; }
     }
     e += 0.5 * mv * q + 0.5 * m.strength * mv * qc;
+    if (ind && m.area) e += m.dt * m.dt * contact_eval(m, ind, m.area[v], x + v * 3).e;
   }
   return block_sum(e, sh);
 }
@@ -335,7 +379,8 @@ __global__ __launch_bounds__(512) void fem_energy_kernel(FemDev m, const double*
   __shared__ double sh[17];
   const int b = blockIdx.x;
   const size_t o = (size_t)b * m.V * 3;
-  const double e = env_energy(m, x + o, xt + o, cons ? cons + (size_t)b * m.V : nullptr, aim ? aim + o : nullptr, sh);
+  const double e = env_energy(m, x + o, xt + o, cons ? cons + (size_t)b * m.V : nullptr, aim ? aim + o : nullptr, sh,
+                              m.indenters ? m.indenters + (size_t)b * 8 : nullptr);
   if (threadIdx.x == 0) E[b] = e;
 }
 
@@ -357,6 +402,12 @@ __global__ __launch_bounds__(512) void fem_gradient_kernel(FemDev m, const doubl
       double gi = a[i] + mv * (x[o + v * 3 + i] - xt[o + v * 3 + i]);
       if (c) gi += m.strength * mv * (x[o + v * 3 + i] - aim[o + v * 3 + i]);
       g[o + v * 3 + i] = gi;
+    }
+    if (m.indenters && m.area) {
+      const ContactEval ce = contact_eval(m, m.indenters + (size_t)b * 8, m.area[v], x + o + v * 3);
+      if (ce.active)
+#pragma unroll
+        for (int i = 0; i < 3; ++i) g[o + v * 3 + i] += m.dt * m.dt * ce.b1 * ce.n[i];
     }
   }
 }
@@ -619,7 +670,8 @@ __device__ __forceinline__ double block_sum1(double v, double* sh2 /* 2 x 8 doub
 }
 
 __device__ __forceinline__ double env_energy_lds(const FemDev& m, const double* xl, const double x3[3], const double* xt,
-                                                 bool own, bool c, const double* aim, double* sh, int& phase) {
+                                                 bool own, bool c, const double* aim, double* sh, int& phase,
+                                                 const double* ind = nullptr, double wv = 0.0) {
   double e = 0.0;
   const double dt2 = m.dt * m.dt;
   for (int t = threadIdx.x; t < m.T; t += blockDim.x) {
@@ -642,8 +694,23 @@ __device__ __forceinline__ double env_energy_lds(const FemDev& m, const double* 
       if (c) { const double cc = x3[i] - aim[v * 3 + i]; qc += cc * cc; }
     }
     e += 0.5 * mv * q + 0.5 * m.strength * mv * qc;
+    if (ind) e += dt2 * contact_eval(m, ind, wv, x3).e;
   }
   return block_sum1(e, sh, phase);
+}
+
+// block-wide minimum, same one-barrier scheme as block_sum1
+__device__ __forceinline__ double block_min1(double v, double* sh2, int& phase) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmin(v, __shfl_xor(v, o, 64));
+  double* row = sh2 + 8 * (phase & 1);
+  ++phase;
+  if ((threadIdx.x & 63) == 0) row[threadIdx.x >> 6] = v;
+  __syncthreads();
+  double s = row[0];
+#pragma unroll
+  for (int w = 1; w < kNwtThreads / 64; ++w) s = fmin(s, row[w]);
+  return s;
 }
 
 __global__ __launch_bounds__(kNwtThreads) void fem_newton_lds_kernel(FemDev m, double* xg, const double* xtg,
@@ -675,6 +742,9 @@ __global__ __launch_bounds__(kNwtThreads) void fem_newton_lds_kernel(FemDev m, d
   const int e_begin = own ? m.vt_off[tid] : 0, e_end = own ? m.vt_off[tid + 1] : 0;
   const double mv = own ? m.mass[tid] : 0.0;
   const double md = mv * (1.0 + (c ? m.strength : 0.0));
+  // contact: this vertex's weight and the env's indenter (nullptr: contact off)
+  const double* ind = (m.indenters && m.area) ? m.indenters + (size_t)b * 8 : nullptr;
+  const double wv = (ind && own) ? m.area[tid] : 0.0;
 
   double x3[3] = {0, 0, 0};
   if (own) {
@@ -764,10 +834,22 @@ __global__ __launch_bounds__(kNwtThreads) void fem_newton_lds_kernel(FemDev m, d
       r3[i] = -gi;
     }
   }
+  // barrier of this vertex at x: gradient b1 n, curvature b2 n n^T (the b1 * hess(d) part is negative semi-definite for a
+  // convex indenter and dropped: the usual PSD projection of IPC)
+  const ContactEval ce = contact_eval(m, ind, wv, x3);
+  if (ce.active) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) r3[i] -= dt2 * ce.b1 * ce.n[i];
+  }
+  const double cb2 = ce.active ? dt2 * ce.b2 : 0.0;
   // ---- block-Jacobi preconditioner: 3x3 diagonal block of vertex tid (columns recomputed per incidence) ----
   double Dinv[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
   if (own) {
     double D[9] = {md, 0, 0, 0, md, 0, 0, 0, md};
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+      for (int k = 0; k < 3; ++k) D[i * 3 + k] += cb2 * ce.n[i] * ce.n[k];
     for (int e = e_begin; e < e_end; ++e) {
       const int code = csr[e];
       const int t = code >> 2, l = code & 3;
@@ -833,7 +915,7 @@ __global__ __launch_bounds__(kNwtThreads) void fem_newton_lds_kernel(FemDev m, d
     part = 0.0;
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
-      Hp3[i] = own ? a3[i] + md * p3[i] : 0.0;
+      Hp3[i] = own ? a3[i] + md * p3[i] + cb2 * ce.n[i] * (ce.n[0] * p3[0] + ce.n[1] * p3[1] + ce.n[2] * p3[2]) : 0.0;
       part += p3[i] * Hp3[i];
     }
     const double pHp = block_sum1(part, sh, phase);
@@ -861,8 +943,18 @@ __global__ __launch_bounds__(kNwtThreads) void fem_newton_lds_kernel(FemDev m, d
     ++it;
   }
   // ---- backtracking line search on the incremental potential (accept the first E(x + step d) <= E(x)) ----
-  const double E0 = env_energy_lds(m, xs, x3, xt, own, c, aim, sh, phase);
+  const double E0 = env_energy_lds(m, xs, x3, xt, own, c, aim, sh, phase, ind, wv);
   double step = 1.0, E1 = E0;
+  if (ind) {
+    // CCD step filter for analytic indenters: a signed distance field is 1-Lipschitz, so a vertex at gap d moving by
+    // step |dx| keeps a positive gap while step < d / |dx|; the largest step every surface vertex allows, with slack
+    double amax = 1.0;
+    if (wv > 0.0 && !ce.penetrating && ce.d < 1e299) {
+      const double nd = sqrt(d3[0] * d3[0] + d3[1] * d3[1] + d3[2] * d3[2]);
+      if (nd > 0.0) amax = fmin(1.0, kCcdSlack * ce.d / nd);
+    }
+    step = block_min1(amax, sh, phase);
+  }
   bool accepted = false;
   double xc3[3] = {0, 0, 0};
   for (int ls = 0; ls <= ls_max_iter; ++ls) {
@@ -872,7 +964,7 @@ __global__ __launch_bounds__(kNwtThreads) void fem_newton_lds_kernel(FemDev m, d
       for (int i = 0; i < 3; ++i) { xc3[i] = x3[i] + step * d3[i]; ps[tid * 3 + i] = xc3[i]; }
     }
     __syncthreads();
-    const double Ec = env_energy_lds(m, ps, xc3, xt, own, c, aim, sh, phase);
+    const double Ec = env_energy_lds(m, ps, xc3, xt, own, c, aim, sh, phase, ind, wv);
     if (Ec <= E0) { E1 = Ec; accepted = true; break; }
     step *= 0.5;
   }
@@ -1121,6 +1213,28 @@ int tacex_fem_gradient(tacex_fem_ctx* c, const double* x, const double* xt, cons
   return e == hipSuccess ? 0 : fail_hip(e, "fem_gradient_kernel");
 }
 
+int tacex_fem_set_contact(tacex_fem_ctx* c, const double* vertex_area_host, double d_hat, double stiffness, const double* indenters_dev) {
+  if (!c) { set_error("tacex_fem_set_contact: null context"); return 2; }
+  if (vertex_area_host) {
+    hipError_t e = hipSetDevice(c->device);
+    if (e != hipSuccess) return fail_hip(e, "hipSetDevice");
+    std::vector<double> a(vertex_area_host, vertex_area_host + c->dev.V);
+    for (double v : a)
+      if (!(v >= 0.0)) { set_error("tacex_fem_set_contact: vertex areas must be >= 0"); return 2; }
+    const double* d = nullptr;
+    if (int rc = fem_upload(c, a, &d)) return rc;
+    c->dev.area = d; c->dev_nwt.area = d;
+  }
+  if (indenters_dev) {
+    if (!c->dev.area) { set_error("tacex_fem_set_contact: vertex areas were never given"); return 2; }
+    if (!(d_hat > 0.0) || !(stiffness > 0.0)) { set_error("tacex_fem_set_contact: need d_hat > 0 and stiffness > 0"); return 2; }
+  }
+  c->dev.dhat = c->dev_nwt.dhat = d_hat;
+  c->dev.kappa = c->dev_nwt.kappa = stiffness;
+  c->dev.indenters = c->dev_nwt.indenters = indenters_dev;
+  return 0;
+}
+
 int tacex_fem_set_newton_early_exit(tacex_fem_ctx* c, double* dx_dev, double dx_tol) {
   if (!c) { set_error("tacex_fem_set_newton_early_exit: null context"); return 2; }
   c->dx_dev = dx_dev;
@@ -1150,6 +1264,10 @@ int tacex_fem_newton_step(tacex_fem_ctx* c, double* x, const double* xt, const u
                        stats, pcg_max_iter, pcg_tol_rate, ls_max_iter, c->dx_dev, c->dx_tol);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : fail_hip(e, "fem_newton_lds_kernel");
+  }
+  if (c->dev.indenters) {
+    set_error("tacex_fem_newton_step: contact needs the CU-resident Newton kernel (mesh with <= %d vertices, TACEX_FEM_NEWTON_LDS != 0)", kNwtThreads);
+    return 2;
   }
   hipLaunchKernelGGL(fem_newton_kernel, dim3(B), dim3(512), 0, (hipStream_t)stream, c->dev, x, xt, cons, aim, stats,
                      static_cast<double*>(ws), pcg_max_iter, pcg_tol_rate, ls_max_iter);

@@ -88,6 +88,16 @@ class UipcObject:
     def num_tets(self) -> int:
         return self.tets.shape[0]
 
+    def surface_vertex_areas(self) -> np.ndarray:
+        """(V,) a third of the rest area of the surface triangles around each vertex (0 for interior vertices): the weight of a
+        vertex in the contact barrier."""
+        tri = self.surface_triangles()
+        p = self.points
+        a = 0.5 * np.linalg.norm(np.cross(p[tri[:, 1]] - p[tri[:, 0]], p[tri[:, 2]] - p[tri[:, 0]]), axis=1)
+        w = np.zeros(self.num_verts)
+        np.add.at(w, tri.reshape(-1), np.repeat(a / 3.0, 3))
+        return w
+
     def surface_triangles(self) -> np.ndarray:
         """Boundary faces (each appears in exactly one tet), oriented outward for positively oriented tets."""
         faces = {}

@@ -61,7 +61,18 @@ class UipcSimCfg:
 
     @configclass
     class Contact:
-        enable: bool = False  # no IPC contact in this build
+        """uipc_sim.py:103-124.  First slice of IPC contact: the gelpad surface against ONE analytic indenter per env
+        (`UipcSim.set_contact_indenters`); friction (`enable_friction`, `default_friction_ratio`, `eps_velocity`) and
+        mesh-mesh contact are not implemented and the fields are kept for drop-in construction only."""
+
+        enable: bool = True
+        enable_friction: bool = True
+        default_friction_ratio: float = 0.5
+        default_contact_resistance: float = 10.0
+        """in [GPa]; the barrier stiffness is resistance * d_hat [J/m^2] per unit of surface area"""
+        constitution: str = "ipc"
+        d_hat: float = 0.001
+        eps_velocity: float = 0.01
 
     contact: Contact = Contact()
     collision_detection_method: str = "linear_bvh"
@@ -128,6 +139,39 @@ class UipcSim:
 
     def _stream(self):
         return _lib.current_stream_handle(self.device)
+
+    # -- IPC contact against analytic indenters (first slice) ------------------------------------------------------
+    def set_contact_indenters(self, indenters: torch.Tensor | None):
+        """One analytic indenter per env the gelpad surface may not penetrate: (num_envs, 8) float64
+        [kind, cx, cy, cz, radius, nx, ny, nz], kind 0 none, 1 sphere (centre c, radius), 2 half-space (unit normal n through c,
+        the solid side is n.(x - c) < 0).  None disables contact.  Needs `cfg.contact.enable`."""
+        if indenters is None:
+            _lib.check(self._lib.tacex_fem_set_contact(self._handle, 0, 0.0, 0.0, 0), "tacex_fem_set_contact")
+            self.contact_indenters = None
+            return
+        if not self.cfg.contact.enable:
+            raise RuntimeError("UipcSimCfg.contact.enable is False")
+        ind = indenters.to(self.device, torch.float64).reshape(self.num_envs, 8).contiguous()
+        area = None
+        if not getattr(self, "_contact_area_set", False):
+            area = np.ascontiguousarray(self._obj.surface_vertex_areas(), dtype=np.float64)
+            self._contact_area_set = True
+        d_hat = float(self.cfg.contact.d_hat)
+        stiffness = float(self.cfg.contact.default_contact_resistance) * 1e9 * d_hat
+        _lib.check(self._lib.tacex_fem_set_contact(self._handle, area.ctypes.data if area is not None else 0, d_hat, stiffness,
+                                                   _lib.ptr(ind)), "tacex_fem_set_contact")
+        self.contact_indenters = ind  # keeps the device buffer alive: the kernels read it on every later call
+
+    def contact_gaps(self, x=None) -> torch.Tensor:
+        """(num_envs, V) signed distance of every vertex to its env's indenter (+inf without one) - a diagnostic in torch ops."""
+        x = self.x if x is None else x
+        ind = getattr(self, "contact_indenters", None)
+        if ind is None:
+            return torch.full(x.shape[:2], float("inf"), dtype=torch.float64, device=self.device)
+        c, n, kind = ind[:, None, 1:4], ind[:, None, 5:8], ind[:, None, 0]
+        sph = (x - c).norm(dim=-1) - ind[:, None, 4]
+        pl = ((x - c) * n).sum(-1)
+        return torch.where(kind == 1, sph, torch.where(kind == 2, pl, torch.full_like(sph, float("inf"))))
 
     # -- animation targets (uipc_attachments.py:364-385) ----------------------------------------------------------
     def set_constraints(self, vertex_idx, aim_positions: torch.Tensor):

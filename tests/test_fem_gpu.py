@@ -331,3 +331,95 @@ def test_attachment_chain_aim_set_constraints_step_vs_oracle():
     d = (sim.x[:, att.attachment_points_idx] - aim).abs().amax().item()
     assert d < 2e-4
     assert (sim.x[1] - sim.x[2]).abs().max().item() > 1e-4
+
+
+def _contact_setup(B=3, strength=100.0):
+    """A gelpad-sized block whose back face (z = 0) is glued; per env a different indenter hovering over / touching the front."""
+    from oracle.fem_oracle import FemModel, box_tet_mesh
+    from tacex_amd.uipc import UipcObject, UipcObjectCfg, UipcSim, UipcSimCfg
+
+    P, Tt = box_tet_mesh(4, 5, 2)
+    sim = UipcSim(UipcSimCfg(device="cuda:0"), num_envs=B)
+    gel = UipcObject(UipcObjectCfg(mesh_points=P, mesh_tets=Tt), sim)
+    sim.setup_sim(constraint_strength_ratio=strength)
+    back = np.where(P[:, 2] < 1e-12)[0]
+    sim.set_constraints(back, torch.from_numpy(P[back]).cuda()[None].repeat(B, 1, 1))
+    top = P[:, 2].max()
+    cx, cy = P[:, 0].mean(), P[:, 1].mean()
+    ind = np.zeros((B, 8))
+    ind[0] = [1, cx, cy, top + 0.004 + 0.0004, 0.004, 0, 0, 1]              # sphere, lowest point 0.4 mm above the pad: inside d_hat
+    ind[1] = [2, cx, cy, top + 0.0006, 0, 0, 0, -1.0]                        # half-space coming down from above (solid side z > c)
+    if B > 2:
+        ind[2] = [0, 0, 0, 0, 0, 0, 0, 0]                                    # no indenter
+    m = FemModel.build(P, Tt, youngs=1e4, strength=strength)
+    return sim, gel, m, P, back, ind
+
+
+def test_contact_energy_gradient_vs_oracle():
+    from oracle.fem_oracle import ContactModel
+
+    sim, gel, m, P, back, ind = _contact_setup()
+    B = sim.num_envs
+    rng = np.random.default_rng(2)
+    x = P[None] + 2e-5 * rng.normal(size=(B,) + P.shape)
+    sim.x = torch.from_numpy(x).cuda()
+    sim.x_tilde = sim.x.clone()
+    E0 = sim.energy().cpu().numpy()
+    g0 = sim.gradient().cpu().numpy()
+    sim.set_contact_indenters(torch.from_numpy(ind))
+    E1 = sim.energy().cpu().numpy()
+    g1 = sim.gradient().cpu().numpy()
+    area = gel.surface_vertex_areas()
+    np.testing.assert_allclose(area.sum(), 2 * (20.75 * 25.25 + 20.75 * 4.5 + 25.25 * 4.5) * 1e-6, rtol=1e-12)  # the block's surface
+    kappa = sim.cfg.contact.default_contact_resistance * 1e9 * sim.cfg.contact.d_hat
+    for b in range(B):
+        cm = ContactModel(area, ind[b], sim.cfg.contact.d_hat, kappa, sim.cfg.dt)
+        ec, gc = cm.energy(x[b]), cm.gradient(x[b])
+        assert abs((E1[b] - E0[b]) - ec) <= 1e-10 * max(abs(ec), 1e-30) + 1e-12 * abs(E0[b]), b
+        assert np.abs((g1[b] - g0[b]) - gc).max() <= 1e-10 * max(np.abs(gc).max(), 1e-30) + 1e-12 * np.abs(g0[b]).max(), b
+    assert E1[0] > E0[0] and E1[1] > E0[1] and E1[2] == E0[2]  # envs 0 / 1 are inside d_hat, env 2 has no indenter
+    # penetration = infinite energy
+    xp = x.copy(); xp[1, :, 2] += 0.001
+    sim.x = torch.from_numpy(xp).cuda()
+    assert np.isinf(sim.energy().cpu().numpy()[1])
+    sim.set_contact_indenters(None)
+    np.testing.assert_array_equal(sim.energy(torch.from_numpy(x).cuda()).cpu().numpy(), E0)
+
+
+def test_contact_newton_step_vs_oracle_and_no_penetration():
+    """Indenters are pushed INTO the pad step by step (each move smaller than the current gap, as a CCD-filtered rigid motion
+    would be): Newton iterations with the barrier + CCD step filter follow the oracle, the energy never increases, and no
+    surface vertex ever crosses the indenter surface although the indenter ends up 0.8 mm below the undeformed front face."""
+    from oracle.fem_oracle import ContactModel, newton_step_contact
+
+    sim, gel, m, P, back, ind = _contact_setup(B=2)
+    sim.cfg.linear_system.max_iter, sim.cfg.linear_system.tol_rate = 300, 1e-5
+    area = gel.surface_vertex_areas()
+    dhat = sim.cfg.contact.d_hat
+    kappa = sim.cfg.contact.default_contact_resistance * 1e9 * dhat
+    cons = np.zeros(len(P)); cons[back] = 1.0
+    xo = [P.copy(), P.copy()]
+    sim.x_tilde = sim.x.clone()
+    top = P[:, 2].max()
+    for move in range(6):
+        gaps = sim.contact_gaps().amin(1).cpu().numpy() if move else np.array([4e-4, 6e-4])
+        ind[0, 3] -= 0.5 * min(gaps[0], 4e-4); ind[1, 3] -= 0.5 * min(gaps[1], 4e-4)   # never more than half the gap
+        sim.set_contact_indenters(torch.from_numpy(ind))
+        for it in range(4):
+            st = sim.newton_step().cpu().numpy().copy()
+            assert (st[:, 1] <= st[:, 0] * (1 + 1e-12) + 1e-18).all(), (move, it, st)
+            assert float(sim.contact_gaps().amin()) > 0.0, "a vertex crossed the indenter surface"
+            for b in range(2):
+                cm = ContactModel(area, ind[b], dhat, kappa, sim.cfg.dt)
+                xo[b], so = newton_step_contact(m, cm, xo[b], P, cons, P, pcg_max_iter=300, pcg_tol_rate=1e-5)
+                assert abs(st[b, 0] - so[0]) <= 1e-7 * abs(so[0]) + 1e-18, (move, it, b, st[b], so)
+                assert abs(st[b, 1] - so[1]) <= 1e-5 * abs(so[1]) + 1e-18, (move, it, b, st[b], so)
+    x = sim.x.cpu().numpy()
+    for b in range(2):
+        assert np.abs(x[b] - xo[b]).max() <= 1e-5 * np.ptp(P), b
+    # the front face is really dented, and only in front of the indenter for the sphere
+    dent = top - x[:, :, 2]
+    front = P[:, 2] > top - 1e-9
+    assert dent[0][front].max() > 1e-4 and dent[1][front].min() > 1e-4
+    r = np.hypot(P[front, 0] - ind[0, 1], P[front, 1] - ind[0, 2])
+    assert dent[0][front][r > 0.008].max() < 0.3 * dent[0][front].max()

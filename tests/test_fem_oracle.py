@@ -206,3 +206,83 @@ def test_attachment_aim_positions_closed_form():
     aim = attachment_aim_positions(off, p, q)
     np.testing.assert_allclose(aim[0], [[10, 21, 30], [8, 20, 30], [10, 20, 33]], atol=1e-5)
     np.testing.assert_allclose(aim[1], off + p[1], atol=1e-6)
+
+
+# ---- IPC contact barrier: known answers of the restatement -------------------------------------------------------
+def test_contact_barrier_known_answers():
+    """b(s) = -(s-1)^2 ln s: zero with zero slope and curvature at s = 1 (C2 at the activation distance), -> +inf as s -> 0+,
+    convex and decreasing on (0, 1); derivatives against finite differences."""
+    from oracle.fem_oracle import barrier
+
+    b, b1, b2 = barrier(np.array([1.0, 1.0 - 1e-9]))
+    assert b[0] == 0 and b1[0] == 0 and b2[0] == 0 and abs(b[1]) < 1e-25 and abs(b1[1]) < 1e-16 and abs(b2[1]) < 1e-7
+    s = np.linspace(0.02, 0.98, 49)
+    b, b1, b2 = barrier(s)
+    assert (b > 0).all() and (b1 < 0).all() and (b2 > 0).all()
+    h = 1e-6
+    np.testing.assert_allclose(b1, (barrier(s + h)[0] - barrier(s - h)[0]) / (2 * h), rtol=1e-6)
+    np.testing.assert_allclose(b2, (barrier(s + h)[1] - barrier(s - h)[1]) / (2 * h), rtol=1e-6)
+    assert barrier(np.array([1e-12]))[0][0] > 25 and np.isinf(barrier(np.array([0.0, -0.1]))[0]).all()
+    assert (barrier(np.array([1.0, 1.5, 7.0]))[0] == 0).all()
+    # closed form at s = 1/2: (1/4) ln 2
+    np.testing.assert_allclose(barrier(np.array([0.5]))[0][0], 0.25 * np.log(2.0), rtol=1e-15)
+
+
+@pytest.mark.parametrize("kind", [1, 2])
+def test_contact_gradient_hessian_finite_differences(kind):
+    """Gradient = FD of the energy; the PSD-projected Hessian b'' n n^T = FD of the gradient minus the dropped b' hess(d) part
+    (exactly the full Hessian for the half-space, whose distance has no curvature)."""
+    from oracle.fem_oracle import ContactModel, contact_distance, barrier
+
+    rng = np.random.default_rng(3)
+    dhat, kappa, dt = 1e-3, 1e7, 0.01
+    n = np.array([0.3, -0.2, 0.93]); n /= np.linalg.norm(n)
+    ind = np.array([kind, 0.001, -0.002, 0.003, 0.004, *n])
+    V = 12
+    if kind == 1:
+        dirs = rng.normal(size=(V, 3)); dirs /= np.linalg.norm(dirs, axis=1, keepdims=True)
+        x = ind[1:4] + dirs * (ind[4] + rng.uniform(0.1, 0.95, V)[:, None] * dhat)
+    else:
+        x = ind[1:4] + rng.normal(size=(V, 3)) * 0.01
+        x += ((rng.uniform(0.1, 0.95, V) * dhat) - (x - ind[1:4]) @ n)[:, None] * n
+    area = rng.uniform(0.5e-6, 2e-6, V); area[3] = 0.0  # an interior vertex carries no barrier
+    cm = ContactModel(area, ind, dhat, kappa, dt)
+    g = cm.gradient(x)
+    assert np.abs(g[3]).max() == 0.0
+    h = 1e-9
+    for v in range(V):
+        for i in range(3):
+            e = np.zeros_like(x); e[v, i] = h
+            fd = (cm.energy(x + e) - cm.energy(x - e)) / (2 * h)
+            assert abs(fd - g[v, i]) <= 1e-5 * np.abs(g).max() + 1e-12
+    H = cm.hess_blocks(x)
+    d, nn = contact_distance(ind, x)
+    _, b1, _ = barrier(d / dhat)
+    for v in (0, 5, 7):
+        fdH = np.zeros((3, 3))
+        for i in range(3):
+            e = np.zeros_like(x); e[v, i] = h
+            fdH[:, i] = (cm.gradient(x + e)[v] - cm.gradient(x - e)[v]) / (2 * h)
+        dropped = np.zeros((3, 3))
+        if kind == 1:
+            rho = d[v] + ind[4]
+            dropped = dt**2 * kappa * area[v] * b1[v] / dhat * (np.eye(3) - np.outer(nn[v], nn[v])) / rho
+            assert np.linalg.eigvalsh(dropped).max() <= 1e-9 * np.abs(H[v]).max()  # negative semi-definite: safe to drop
+        assert np.abs(fdH - dropped - H[v]).max() <= 2e-4 * np.abs(H[v]).max()
+        assert np.linalg.eigvalsh(H[v]).min() >= -1e-12 * np.abs(H[v]).max()
+
+
+def test_contact_step_filter_never_penetrates():
+    from oracle.fem_oracle import ContactModel, contact_distance
+
+    rng = np.random.default_rng(4)
+    ind = np.array([1, 0.0, 0.0, 0.0, 0.005, 0, 0, 1.0])
+    dirs = rng.normal(size=(50, 3)); dirs /= np.linalg.norm(dirs, axis=1, keepdims=True)
+    x = dirs * (0.005 + rng.uniform(1e-5, 3e-3, 50)[:, None])
+    cm = ContactModel(np.ones(50), ind, 1e-3, 1e7, 0.01)
+    for _ in range(20):
+        dx = rng.normal(size=x.shape) * 10 ** rng.uniform(-5, -2)
+        a = cm.max_step(x, dx)
+        assert 0 < a <= 1
+        assert (contact_distance(ind, x + a * dx)[0] > 0).all()
+    assert cm.max_step(x, np.zeros_like(x)) == 1.0
