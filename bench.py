@@ -171,9 +171,10 @@ class Rig:
 
 
 class FemGelpad:
-    """C4 / C5: one ~2k-tet gelpad per env (20.75 x 25.25 x 4.5 mm block, 495 vertices / 1920 tets), its back face held by the
-    sensor case and a patch of the front face driven by an attachment (UipcIsaacAttachments: aim = R(q) offset + p), stepped
-    with UipcSim.step (backward Euler, Newton + PCG + line search in one HIP launch per Newton iteration)."""
+    """C4 / C5: one ~2k-tet gelpad per env (20.75 x 25.25 x 4.5 mm block, 495 vertices / 1920 tets).  Its back face is held by
+    the sensor case through UipcIsaacAttachments (aim = R(q) offset + p, soft position constraints); a spherical indenter
+    presses into the front face through the IPC barrier (d_hat 1 mm, CCD-filtered Newton steps) and breathes in and out;
+    stepped with UipcSim.step (backward Euler: Newton + matrix-free PCG + line search in one HIP launch per Newton iteration)."""
 
     def __init__(self, B, dev):
         import numpy as np
@@ -185,28 +186,43 @@ class FemGelpad:
         self.gelpad = UipcObject(UipcObjectCfg(mesh_points=P, mesh_tets=T), self.sim)
         self.sim.setup_sim(constraint_strength_ratio=1000.0)  # benchmark env value (envs/ball_rolling_uipc.py:120-125)
         self.num_tets, self.num_verts = len(T), len(P)
-        top = np.where(P[:, 2] > P[:, 2].max() - 1e-9)[0]
-        ctr = P[top].mean(0)
-        patch = top[np.linalg.norm(P[top, :2] - ctr[:2], axis=1) < 0.006]
-        self.att = UipcIsaacAttachments(UipcIsaacAttachmentsCfg(constraint_strength_ratio=1000.0), self.gelpad, patch,
-                                        P[patch] - ctr)
-        self.ctr = torch.from_numpy(ctr).to(dev)
-        self.depth = torch.linspace(0.0002, 0.0012, B, device=dev, dtype=torch.float64)
+        size = P.max(0) - P.min(0)
+        body = np.array([size[0] / 2, size[1] / 2, -0.001])  # the sensor case: a plate hugging the back face
+        self.att = UipcIsaacAttachments(UipcIsaacAttachmentsCfg(constraint_strength_ratio=1000.0), self.gelpad,
+                                        rigid_collider=("box", (size[0] / 2 + 1e-6, size[1] / 2 + 1e-6, 0.001)), rigid_pos=body)
+        self.body = torch.from_numpy(body).to(dev)
         self.quat = torch.zeros((B, 4), device=dev, dtype=torch.float64)
         self.quat[:, 0] = 1.0
-        self.B, self.fem_ms, self.n = B, 0.0, 0
+        top = P[:, 2].max()
+        fr = np.where(P[:, 2] > top - 1e-12)[0]
+        vc = fr[np.argmin(np.hypot(P[fr, 0] - size[0] / 2, P[fr, 1] - size[1] / 2))]
+        self.R = 0.004
+        self.z_rest = top + self.R + 0.0009  # lowest point of the sphere just inside d_hat
+        ind = torch.zeros((B, 8), dtype=torch.float64, device=dev)
+        ind[:, 0] = 1.0
+        ind[:, 1], ind[:, 2], ind[:, 3], ind[:, 4] = P[vc, 0], P[vc, 1], self.z_rest, self.R
+        self.ind = ind
+        self.sim.set_contact_indenters(ind)
+        self.ind = self.sim.contact_indenters  # the device buffer the kernels read; moved in place every step
+        self.depth = torch.linspace(0.0004, 0.0014, B, device=dev, dtype=torch.float64)
+        self.B = B
         self.ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
 
     def step(self, i):
         import math
-        pos = self.ctr[None].repeat(self.B, 1)
-        pos[:, 2] -= self.depth * (0.5 + 0.5 * math.sin(0.3 * i))  # the indenter breathes in and out
-        pos[:, 0] += 0.0003 * math.sin(0.2 * i)
         self.ev[0].record()
-        self.att.apply(self.sim, pos, self.quat)  # compute_aim_positions -> set_constraints (UA:364-428)
+        pos = self.body[None].repeat(self.B, 1)
+        pos[:, 0] += 0.0002 * math.sin(0.2 * i)  # the case shears the pad a little
+        self.att.apply(self.sim, pos, self.quat)  # compute_aim_positions -> is_constrained / aim_position (UA:364-428)
+        # the indenter follows its breathing trajectory, but never moves more than half the current gap towards the pad
+        # (what a CCD-filtered rigid-body step would allow); all on the device, no host round trip
+        target = self.z_rest - self.depth * (0.5 - 0.5 * math.cos(0.3 * i))
+        gap = self.sim.contact_gaps().amin(1)
+        down = torch.clamp(self.ind[:, 3] - target, min=0.0)
+        self.ind[:, 3] -= torch.minimum(down, 0.5 * gap)
+        self.ind[:, 3] = torch.maximum(self.ind[:, 3], target) * (down > 0) + torch.where(down > 0, 0.0, 1.0) * target
         self.sim.step(max_newton_iter=8)
         self.ev[1].record()
-        self.pending = True
 
     def fem_ms_last(self):
         self.ev[1].synchronize()

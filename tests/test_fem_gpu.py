@@ -345,7 +345,9 @@ def _contact_setup(B=3, strength=100.0):
     back = np.where(P[:, 2] < 1e-12)[0]
     sim.set_constraints(back, torch.from_numpy(P[back]).cuda()[None].repeat(B, 1, 1))
     top = P[:, 2].max()
-    cx, cy = P[:, 0].mean(), P[:, 1].mean()
+    fr = np.where(P[:, 2] > top - 1e-12)[0]
+    vc = fr[np.argmin(np.hypot(P[fr, 0] - P[:, 0].mean(), P[fr, 1] - P[:, 1].mean()))]  # the barrier is per VERTEX: aim at one
+    cx, cy = P[vc, 0], P[vc, 1]
     ind = np.zeros((B, 8))
     ind[0] = [1, cx, cy, top + 0.004 + 0.0004, 0.004, 0, 0, 1]              # sphere, lowest point 0.4 mm above the pad: inside d_hat
     ind[1] = [2, cx, cy, top + 0.0006, 0, 0, 0, -1.0]                        # half-space coming down from above (solid side z > c)
