@@ -218,9 +218,8 @@ class FemGelpad:
         # (what a CCD-filtered rigid-body step would allow); all on the device, no host round trip
         target = self.z_rest - self.depth * (0.5 - 0.5 * math.cos(0.3 * i))
         gap = self.sim.contact_gaps().amin(1)
-        down = torch.clamp(self.ind[:, 3] - target, min=0.0)
-        self.ind[:, 3] -= torch.minimum(down, 0.5 * gap)
-        self.ind[:, 3] = torch.maximum(self.ind[:, 3], target) * (down > 0) + torch.where(down > 0, 0.0, 1.0) * target
+        z = self.ind[:, 3]
+        self.ind[:, 3] = torch.where(z > target, torch.maximum(target, z - 0.5 * gap), target)  # down: limited; up: free
         self.sim.step(max_newton_iter=8)
         self.ev[1].record()
 
@@ -413,9 +412,9 @@ def sweep(args, dev):
     run("C2 + FOTS markers: 256 envs x 1 sensor, RGB 320x240 + markers", 256, 240, 320, 1, True)
     run("512-env shard of the 4096-env / 8-GPU target: 512 envs x 1 sensor, RGB 320x240 + FOTS markers", 512, 240, 320, 1, True)
     run("C4 per-GPU shard: 512 envs, RGB 320x240 + FEM-driven markers + gelpad FEM step (1920 tets / env) (BASELINE configs[3] / 8)",
-        512, 240, 320, 1, False, fem=lambda: FemGelpad(512, dev), steps=max(5, args.sweep_steps // 3))
+        512, 240, 320, 1, False, fem=lambda: FemGelpad(512, dev), steps=max(12, args.sweep_steps // 3))
     run("C5 per-GPU shard: 1024 envs, RGB 640x480 + FEM-driven markers (gelpad FEM step included) (BASELINE configs[4] / 8)",
-        1024, 480, 640, 1, False, fem=lambda: FemGelpad(1024, dev), steps=max(5, args.sweep_steps // 6))
+        1024, 480, 640, 1, False, fem=lambda: FemGelpad(1024, dev), steps=max(12, args.sweep_steps // 6))
     run("C5 optical part only: 1024 envs, RGB 640x480", 1024, 480, 640, 1, False, steps=max(5, args.sweep_steps // 3))
     return out
 

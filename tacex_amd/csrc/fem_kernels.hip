@@ -1253,12 +1253,14 @@ int tacex_fem_newton_step(tacex_fem_ctx* c, double* x, const double* xt, const u
   static const int use_lds = getenv("TACEX_FEM_NEWTON_LDS") ? atoi(getenv("TACEX_FEM_NEWTON_LDS")) : 1;
   const size_t lds = ((size_t)6 * c->dev.V + (size_t)12 * kNwtChunk + 18) * sizeof(double) + (size_t)4 * c->dev.T * sizeof(int);
   if (use_lds && c->dev.V <= kNwtThreads && lds <= 160 * 1024) {
-    static size_t attr_lds = 0;
-    if (lds > attr_lds) {
-      hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void*>(fem_newton_lds_kernel),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    static size_t attr_lds[64] = {};  // per device: the attribute is per kernel AND device
+    const int dv = (c->device >= 0 && c->device < 64) ? c->device : 0;
+    if (lds > attr_lds[dv]) {
+      hipError_t ea = hipSetDevice(c->device);
+      if (ea == hipSuccess)
+        ea = hipFuncSetAttribute(reinterpret_cast<const void*>(fem_newton_lds_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       if (ea != hipSuccess) return fail_hip(ea, "hipFuncSetAttribute(fem_newton_lds_kernel)");
-      attr_lds = lds;
+      attr_lds[dv] = lds;
     }
     hipLaunchKernelGGL(fem_newton_lds_kernel, dim3(B), dim3(kNwtThreads), lds, (hipStream_t)stream, c->dev_nwt, x, xt, cons, aim,
                        stats, pcg_max_iter, pcg_tol_rate, ls_max_iter, c->dx_dev, c->dx_tol);

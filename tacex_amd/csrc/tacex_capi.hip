@@ -754,8 +754,11 @@ int tacex_taxim_render_obs(tacex_taxim_ctx* c, const float* hm, const float* pre
   if (!c || !hm || !frame_min || !rgb || !ws || !obs_scratch || !obs_out) { set_error("tacex_taxim_render_obs: null argument"); return 2; }
   if (obs_h <= 0 || obs_w <= 0 || obs_h > c->H || obs_w > c->W) { set_error("tacex_taxim_render_obs: bad observation size %dx%d", obs_w, obs_h); return 2; }
   if (!press && !(flags & TACEX_FLAG_NO_SHIFT)) { set_error("tacex_taxim_render_obs: press_dev is null"); return 2; }
-  if (flags & TACEX_FLAG_WITH_SHADOW) { set_error("tacex_taxim_render_obs: not available with TACEX_FLAG_WITH_SHADOW"); return 2; }
   if (B <= 0) return 0;
+  if (flags & TACEX_FLAG_WITH_SHADOW) {  // the shadow branch re-blurs the finished frame: its observation is a plain two-pass resize
+    if (int rc = tacex_taxim_render(c, hm, press, frame_min, rgb, z_out, mask_out, ws, B, flags & ~TACEX_FLAG_OBS_U8, stream)) return rc;
+    return resize_obs(c, rgb, obs_scratch, obs_out, (flags & TACEX_FLAG_OBS_U8) != 0, obs_h, obs_w, B, (hipStream_t)stream);
+  }
   return pipeline_impl(c, hm, press, frame_min, rgb, z_out, mask_out, ws, B, flags, (hipStream_t)stream, obs_scratch, obs_out,
                        obs_h, obs_w);
 }

@@ -606,12 +606,15 @@ static hipError_t launch_tail(const TailArgs& a0, hipStream_t st) {
   TailArgs a = a0;
   const int ntx = (a.W + C::TW - 1) / C::TW, nty = (a.H + C::TH - 1) / C::TH;
   auto kern = taxim_tail_kernel<KS...>;
-  static bool attr_done = false;
-  if (!attr_done) {
+  // > 64 KB of dynamic LDS is an opt-in per kernel AND device: one flag per device (contexts on several GPUs in one process)
+  static bool attr_done[64] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+  if (!attr_done[dev]) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int)C::lds_bytes());
     if (e != hipSuccess) return e;
-    attr_done = true;
+    attr_done[dev] = true;
   }
   hipLaunchKernelGGL(kern, dim3(ntx * nty * a.B), dim3(kTailThreads), C::lds_bytes(), st, a);
   return hipGetLastError();

@@ -249,7 +249,7 @@ class TaximHip:
         ws = self._workspace(ctx, (H, W), B, with_shadow)
         with torch.cuda.device(self._device):
             stream = _lib.current_stream_handle(self._device)
-            if obs_out is not None and not with_shadow:
+            if obs_out is not None:
                 if obs_out.dim() != 4 or obs_out.shape[0] != B or obs_out.shape[3] != 3 or not obs_out.is_contiguous():
                     raise ValueError("obs_out must be a contiguous (B, oh, ow, 3) tensor")
                 if obs_out.dtype not in (torch.float32, torch.uint8):

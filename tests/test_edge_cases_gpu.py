@@ -241,3 +241,20 @@ def test_full_baseline_batch_2048_frames_auto_chunked(calib_dir):
     assert torch.equal(mb[:, 0], ms[:, 0])
     assert float((mb[:, 1] - ms[:, 1]).abs().max()) <= 1e-4
     assert float((mb[:, 1] - mb[:, 0]).abs().max()) > 0.1
+
+
+def test_policy_observation_with_shadow(taxim):
+    """`obs_out` together with `with_shadow=True` (it used to stay all-zero silently): the observation is the antialiased
+    down-sample of the shadowed frame, float32 and uint8."""
+    hm, ind = _inputs(3, 91, flat_fraction=0.0)
+    hm, ind = hm.cuda(), ind.cuda()
+    for dt in (torch.float32, torch.uint8):
+        obs = torch.zeros((3, 32, 32, 3), dtype=dt, device="cuda")
+        rgb = taxim.render_direct(hm, True, ind, obs_out=obs)  # (3, 3, H, W) view
+        ref = torch.nn.functional.interpolate(rgb, size=[32, 32], mode="bilinear", antialias=True).movedim(1, 3)
+        if dt == torch.uint8:
+            q = torch.floor(255.0 * ref + 0.5)
+            assert float((obs.float() - q).abs().max()) <= 1.0 and float((obs.float() == q).float().mean()) > 0.99
+        else:
+            assert float((obs - ref).abs().max()) < 1e-5
+        assert float(obs.float().std()) > 0
