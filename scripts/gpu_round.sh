@@ -12,6 +12,8 @@ for s in $STEPS; do
     bench) timeout 900 python bench.py > $OUT/bench.json 2> $OUT/bench.err; echo "bench rc=$?"; tail -c 600 $OUT/bench.err; head -c 1500 $OUT/bench.json ;;
     benchq) timeout 600 python bench.py --no-sweep --no-cpu-baseline > $OUT/bench_quick.json 2> $OUT/bench_quick.err; echo "benchq rc=$?"; head -c 1200 $OUT/bench_quick.json ;;
     prof) (cd /tmp && export TMPDIR=/tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -- python3 $GRAFT_REPO_ROOT/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-sweep > $OUT/prof.log 2>&1; echo "prof rc=$?") ;;
+    prof640) (cd /tmp && export TMPDIR=/tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof640 -- python3 $GRAFT_REPO_ROOT/bench.py --steps 10 --warmup 3 --height 480 --width 640 --envs-per-gpu 1024 --sensors 1 --no-cpu-baseline --no-sweep > $OUT/prof640.log 2>&1; echo "prof640 rc=$?"; tail -c 700 $OUT/prof640.log) ;;
+    proffem) (cd /tmp && export TMPDIR=/tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/proffem -- python3 $GRAFT_REPO_ROOT/scripts/fem_bench.py > $OUT/proffem.log 2>&1; echo "proffem rc=$?"; tail -12 $OUT/proffem.log) ;;
     pmc) (cd /tmp && export TMPDIR=/tmp
           timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-sweep --no-roofline > $OUT/pmc_fetch.log 2>&1; echo "pmc fetch rc=$?"
           timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-sweep --no-roofline > $OUT/pmc_write.log 2>&1; echo "pmc write rc=$?") ;;

@@ -1,23 +1,27 @@
-"""Build profiles/pmc_traffic.json from two rocprofv3 --pmc passes (FETCH_SIZE and WRITE_SIZE in SEPARATE runs, as the
-MI355X guide prescribes) of the bench command (256 frames per launch).
+"""Build profiles/pmc_traffic_rNN.json from two rocprofv3 --pmc passes (FETCH_SIZE and WRITE_SIZE in SEPARATE runs, as the
+MI355X guide prescribes) of the bench command.
 
-On the GPU box:
+On the GPU box (scripts/gpu_round.sh <tag> pmc does exactly this):
     cd /tmp && export TMPDIR=/tmp
-    rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/pmc_fetch -- python $GRAFT_REPO_ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-roofline
-    rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/pmc_write -- python $GRAFT_REPO_ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-roofline
-then (anywhere):  python scripts/make_pmc_traffic.py gpurun_out/pmc_fetch gpurun_out/pmc_write profiles/pmc_traffic.json
+    rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 $REPO/bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-sweep --no-roofline
+    rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 $REPO/bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-sweep --no-roofline
+then (anywhere):  python scripts/make_pmc_traffic.py <pmc_fetch dir> <pmc_write dir> <out.json> [frames_per_launch=1024] [H=240] [W=320] [commit]
 """
 import csv, glob, json, os, sys
 from collections import defaultdict
 
 STAGES = {  # kernel-name substring -> bench.py stage name
-    "frame_min_kernel": "frame_min",
+    "frame_min_kernel<true>": "frame_min_from_depth", "frame_min_kernel<false>": "frame_min",
     "blur_mfma_kernel<61": "blur_l0_k61x61", "blur_band_kernel<61": "blur_l0_k61x61",
     "blur_mfma_kernel<33": "blur_l1_k33x33", "blur_band_kernel<33": "blur_l1_k33x33",
     "blur_mfma_kernel<17": "blur_l2_k17x17", "blur_band_kernel<17": "blur_l2_k17x17",
-    "taxim_tail_kernel": "tail_fused",
+    "blur_band_loop_kernel": "blur_l0_k117x117", "blur_mfma_kernel<15": "blur_l3_k15x15",
+    "taxim_stream_kernel": "tail_fused", "taxim_tail_kernel": "tail_fused_tiled",
 }
-FRAMES, NPIX = 256, 320 * 240
+FRAMES = int(sys.argv[4]) if len(sys.argv) > 4 else 1024
+H = int(sys.argv[5]) if len(sys.argv) > 5 else 240
+W = int(sys.argv[6]) if len(sys.argv) > 6 else 320
+COMMIT = sys.argv[7] if len(sys.argv) > 7 else "unknown"
 
 
 def collect(d, counter):
@@ -34,14 +38,21 @@ def collect(d, counter):
 
 
 fetch, write = collect(sys.argv[1], "FETCH_SIZE"), collect(sys.argv[2], "WRITE_SIZE")
+keys = sorted(set(fetch) | set(write))
+per_frame = {k: int((2 * fetch.get(k, 0) + write.get(k, 0)) * 1024 / FRAMES) for k in keys}
+path = [k for k in keys if k.startswith("blur_") or k == "tail_fused"]
 out = {
-    "_provenance": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (two separate passes) on `python bench.py --steps 5 --warmup 2 "
-                   "--no-cpu-baseline --no-roofline` (256 envs through GelSightSensor.update()), MI355X; built by scripts/make_pmc_traffic.py. Counter unit KiB. FETCH_SIZE is doubled "
-                   "(gfx950 reports exactly 1/2 of wide coalesced streaming reads, MI355X_MICROARCH.md HBM section; check: frame_min reads "
-                   "78.6 MB, counter 39.3 MB). Values are HBM bytes PER FRAME (320x240); bench.py multiplies by the frames per launch.",
-    "frames_per_launch_measured": FRAMES,
-    "per_frame_bytes": {k: int((2 * fetch.get(k, 0) + write.get(k, 0)) * 1024 / FRAMES) for k in sorted(set(fetch) | set(write))},
-    "raw_kib_per_launch": {k: {"FETCH_SIZE": int(fetch.get(k, 0)), "WRITE_SIZE": int(write.get(k, 0))} for k in sorted(set(fetch) | set(write))},
+    "_provenance": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (two separate passes) on `python3 bench.py --steps 3 --warmup 2 "
+                   "--no-cpu-baseline --no-sweep --no-roofline` (the driver's headline workload through GelSightSensor.update()), MI355X; built by "
+                   "scripts/make_pmc_traffic.py.  Counter unit KiB.  FETCH_SIZE is doubled (gfx950 reports exactly 1/2 of wide coalesced "
+                   "streaming reads, MI355X_MICROARCH.md HBM section; check: the depth -> height-map pass reads 4 B/px and its doubled "
+                   "counter says so).  Values are HBM bytes PER FRAME; bench.py multiplies by the frames per launch.",
+    "measured_at_commit": COMMIT,
+    "frames_per_launch_measured": FRAMES, "resolution": [W, H],
+    "per_frame_bytes": per_frame,
+    "taxim_path_sum_per_frame": sum(per_frame[k] for k in path),
+    "compulsory_per_frame_16B_per_px": 16 * H * W,
+    "raw_kib_per_launch": {k: {"FETCH_SIZE": int(fetch.get(k, 0)), "WRITE_SIZE": int(write.get(k, 0))} for k in keys},
 }
 json.dump(out, open(sys.argv[3], "w"), indent=1)
-print(json.dumps(out["per_frame_bytes"], indent=1))
+print(json.dumps({k: out[k] for k in ("per_frame_bytes", "taxim_path_sum_per_frame", "compulsory_per_frame_16B_per_px")}, indent=1))
