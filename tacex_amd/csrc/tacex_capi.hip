@@ -519,6 +519,19 @@ static int chunk_frames(const tacex_taxim_ctx* c, int B) {
   return (int)(((size_t)B + nchunks - 1) / nchunks);  // equal chunks
 }
 
+// Frames per launch of the band levels inside one pass that ends in the streaming tail (TACEX_LEVEL_CHUNK_FRAMES overrides,
+// 0 = the whole pass): 3 buffers x 4 B/px per frame against the 256 MB Infinity Cache.
+static int level_chunk_frames(const tacex_taxim_ctx* c, int B) {
+  static const int env = getenv("TACEX_LEVEL_CHUNK_FRAMES") ? atoi(getenv("TACEX_LEVEL_CHUNK_FRAMES")) : -1;
+  if (env == 0) return B;
+  if (env > 0) return env < B ? env : B;
+  const size_t per_frame = (size_t)3 * c->H * c->W * sizeof(float);
+  const size_t n = ((size_t)240 << 20) / per_frame;
+  if (n < 1 || (size_t)B < n + n / 2) return B;
+  const size_t nchunks = ((size_t)B + n - 1) / n;
+  return (int)(((size_t)B + nchunks - 1) / nchunks);
+}
+
 int tacex_taxim_chunk_frames(const tacex_taxim_ctx* c, int B) { return (c && B > 0) ? chunk_frames(c, B) : 0; }
 
 static int pipeline_impl(tacex_taxim_ctx* c, const float* hm, const float* press, float* frame_min, float* rgb,
@@ -584,16 +597,27 @@ static int pipeline_chunk(tacex_taxim_ctx* c, const float* hm, const float* pres
   const int n_fused = c->use_tail ? c->n_fused : 0;
   const int n_band = c->n_levels - n_fused;
   const float* src = nullptr;
-  for (int l = 0; l < n_band; ++l) {
-    const bool last = l == c->n_levels - 1;
-    float* dst = (last && z_out) ? z_out : zbuf[l & 1];
-    StageTimer t(c, st, 1 + l);
-    HIP_TRY(run_blur_level(c->levels[l], src, hm, c->gel_dev, sa, sb, pd, dst, tmp, last ? mask_out : nullptr, B,
-                           c->H, c->W, c->contact_scale, last ? 0 : 1, l == 0, st),
-            "blur level");
-    src = dst;
+  const bool stream_tail = n_fused > 0 && c->use_stream && rgb && !z_out && !mask_out &&
+                           stream_supported(n_fused, c->levels[c->n_levels - n_fused].kw, c->H, c->W);
+  // Band levels ahead of a streaming tail run over sub-ranges of the pass (level_chunk_frames): the tail wants >= 2048 strips
+  // per launch, the band kernels want their three frame-sized buffers (height map, Z ping, Z pong) in the Infinity Cache.
+  const int lcf = stream_tail ? level_chunk_frames(c, B) : B;
+  const size_t npix = (size_t)c->H * c->W;
+  for (int b0 = 0; b0 < B; b0 += lcf) {
+    const int nb = B - b0 < lcf ? B - b0 : lcf;
+    src = nullptr;
+    for (int l = 0; l < n_band; ++l) {
+      const bool last = l == c->n_levels - 1;
+      float* dst = (last && z_out) ? z_out : zbuf[l & 1];
+      StageTimer t(c, st, 1 + l);
+      HIP_TRY(run_blur_level(c->levels[l], src ? src + b0 * npix : nullptr, hm + b0 * npix, c->gel_dev, sa + b0, sb + b0, pd + b0,
+                             dst + b0 * npix, tmp, last && mask_out ? mask_out + b0 * npix : nullptr, nb,
+                             c->H, c->W, c->contact_scale, last ? 0 : 1, l == 0, st),
+              "blur level");
+      src = dst;
+    }
   }
-  if (n_fused > 0 && c->use_stream && rgb && !z_out && !mask_out && stream_supported(n_fused, c->levels[c->n_levels - n_fused].kw, c->H, c->W)) {
+  if (stream_tail) {
     // trailing small-kernel levels (+ restores), shading, observation and FOTS by-products: wave-autonomous streaming kernel
     StageTimer t(c, st, c->n_levels + 2);
     const bool want_obs = obs_h && obs;
