@@ -152,9 +152,21 @@ __device__ __forceinline__ void shade_bins(const ShadeArgs& a, float ztop, float
   const float mag = atan_pos(t);
   // atan2(dzdx/t, dzdy/t) == atan2(dzdx, dzdy) for t > 0; grad_dir = 0 where t == 0 (TT:494-499)
   const float dir = t != 0.0f ? atan2_fast(dzdx, dzdy) : 0.0f;
-  // floor == truncation: both arguments are >= 0 (mag >= 0, dir >= -pi)                       TT:246-247
-  im = min(max((int)(mag * a.inv_x_binr), 0), a.nb - 1);
-  id = min(max((int)((dir + 3.14159274101257324f) * a.inv_y_binr), 0), a.nb - 1);
+  // floor == truncation: both arguments are >= 0 (mag >= 0, dir >= -pi; a NaN converts to 0), so only the upper clamp
+  // of TT:246-247 can ever act (v_max_i32 / v_min_i32 issue at 2/3 rate)
+  im = min((int)(mag * a.inv_x_binr), a.nb - 1);
+  id = min((int)((dir + 3.14159274101257324f) * a.inv_y_binr), a.nb - 1);
+}
+
+// direction bin alone (the streaming tail skips the magnitude arc tangent for row segments whose gradients all fall into
+// magnitude bin 0)
+__device__ __forceinline__ int shade_dir_bin(const ShadeArgs& a, float dzdx, float dzdy, float t2) {
+  // shade_bins tests sqrt(t2) != 0, and v_sqrt_f32 returns 0 for zero AND denormal arguments: same predicate without the sqrt
+  const float dir = !(t2 < 1.17549435e-38f) ? atan2_fast(dzdx, dzdy) : 0.0f;
+  return min((int)((dir + 3.14159274101257324f) * a.inv_y_binr), a.nb - 1);
+}
+__device__ __forceinline__ int shade_mag_bin(const ShadeArgs& a, float t2) {
+  return min((int)(atan_pos(__builtin_amdgcn_sqrtf(t2)) * a.inv_x_binr), a.nb - 1);
 }
 
 // I_c = sum_k f_k(X, Y) * p_{c,k}(bin), f = [X^2, Y^2, XY, X, Y, 1]  (TT:148-157, 250-255): one FMA chain per channel.

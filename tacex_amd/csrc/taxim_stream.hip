@@ -46,6 +46,7 @@ struct StreamArgs {
   ShadeArgs sh;
   int H, W, B;
   float contact_scale;
+  float mag0_t2;         // squared gradient magnitude below which the magnitude bin is 0 for certain (see shade_part1)
   int nstrips, strip_w;  // strips per frame, valid columns per strip
   int nseg, seg_rows;    // vertical segments per strip, rows per segment
   const StreamRowInfo* rows;  // (H,)
@@ -136,7 +137,9 @@ struct StreamCfg {
   // [obs_ncols][obs_kxp] | window start per column
   static constexpr size_t ring_bytes() { return NL > 1 ? (size_t)kStreamRing * 64 * 16 : 0; }
   static constexpr size_t shade_bytes() { return SHADE ? kStreamStageBytes + kStreamObsLdsFloats * 4 + kStreamObsMaxCols * 4 : 0; }
-  static constexpr size_t lds_per_wave() { return ring_bytes() + shade_bytes(); }
+  // input rows land in a two-slot ring straight from memory (global_load_lds_dwordx3: 16-byte lane stride): [slot][z | hm][64 x 4]
+  static constexpr size_t rows_bytes() { return (size_t)2 * (NL > 0 ? 2 : 1) * 64 * 16; }
+  static constexpr size_t lds_per_wave() { return ring_bytes() + shade_bytes() + rows_bytes(); }
   static constexpr size_t lds_shared() { return SHADE ? kStreamLdsShared : 0; }
   static constexpr size_t lds_bytes() { return lds_shared() + kStreamWaves * lds_per_wave(); }
 };
@@ -181,6 +184,8 @@ __global__ __launch_bounds__(64 * kStreamWaves, stream_min_waves(ROLE)) void tax
   float* obs_row = reinterpret_cast<float*>(lds + C::ring_bytes());  // [64 * PX * 3] observation staging row
   float* obs_wl = obs_row + 64 * PX * 3;                              // [nq][kxp] window weights
   int* obs_xb = reinterpret_cast<int*>(obs_wl + kStreamObsLdsFloats);  // [nq] first staging pixel of the window
+  float* const rowbuf = reinterpret_cast<float*>(lds + C::ring_bytes() + C::shade_bytes());  // [2 slots][z | hm][64 lanes x 4]
+  constexpr int kRowArr = 64 * 4, kRowSlot = (NL > 0 ? 2 : 1) * kRowArr;                     // floats
 
   const size_t fo = (size_t)frame * H * W;
   const float* __restrict__ zin = a.zin + fo;
@@ -190,6 +195,10 @@ __global__ __launch_bounds__(64 * kStreamWaves, stream_min_waves(ROLE)) void tax
     sa = a.shift_a[frame]; sb = a.shift_b[frame];
     thr = -a.pdepth[frame] * a.contact_scale;  // TT:459
   }
+  // Zero gel map (GZ): J = min(S, 0) and the contact test (J - 0 < thr) && (S < 0) (TT:457-461) collapse to S < min(thr, 0)
+  // with J = S on the mask - one compare per pixel instead of min + two compares + and (v_min / v_cmp issue at 2/3 rate).
+  const float thr_eff = fminf(thr, 0.0f);
+  const float mag0_t2 = a.mag0_t2;
   const bool do_obs = SHADE && a.obs_part != nullptr;
   const bool do_fots = LEVELS && a.fots_part != nullptr;
 
@@ -204,39 +213,39 @@ __global__ __launch_bounds__(64 * kStreamWaves, stream_min_waves(ROLE)) void tax
     valid[i] = xg[i] >= vx0 && xg[i] < vx1;
     X[i] = SHADE ? a.sh.fx[min(max(xg[i], 0), W - 1)] : 0.0f;
   }
-  // input rows come in as ONE 12-byte load per lane; the few lanes with a pixel outside the image (reflect padding) re-load
-  // their three pixels one by one at the mirrored columns
+  // Input rows never pass through registers on their way in: each lane issues ONE 12-byte global_load_lds per array (the lanes
+  // hanging over the image edge at a clamped address), the row lands in the wave's two-slot LDS ring and is read back one
+  // iteration later - every pixel from the ring position that holds its (reflected) column, so the reflect padding costs no
+  // extra loads and no merge.  The landing zone being LDS (not 12 VGPRs per row in flight) is what lets a row be issued a full
+  // iteration ahead of the ONE vmcnt wait of the iteration (mid_point below): plain loads consumed at the loop tail were forced
+  // early by that wait (in-order vmcnt) with ~0.6 iterations to cover the HBM latency.
   const unsigned xb = (unsigned)min(max(xg[0], 0), W - PX);
-  const bool border = xg[0] < 0 || xg[PX - 1] >= W;
-  // The border lanes' values go to SEPARATE registers and are merged by merge_row() only where the row is consumed: writing
-  // them over the 12-byte load's registers made hipcc wait for that load right behind its issue (s_waitcnt vmcnt(0) at the
-  // loop head - the memory latency of every row was exposed).
-  struct RowRegs { v3f z3, h3; float zb[PX], hb[PX]; };
-  auto load_row = [&](int row, RowRegs& r) {
-    const unsigned ro = (unsigned)row * (unsigned)W;
-    r.z3 = *reinterpret_cast<const v3f*>(zin + ro + xb);
-    if constexpr (LEVELS) r.h3 = *reinterpret_cast<const v3f*>(hm + ro + xb);
+  int ridx[PX];  // ring position (float index inside one array of a slot) of this lane's pixels
 #pragma unroll
-    for (int i = 0; i < PX; ++i) { r.zb[i] = 0.0f; r.hb[i] = 0.0f; }
-    if (border) {
-#pragma unroll
-      for (int i = 0; i < PX; ++i) {
-        r.zb[i] = zin[ro + xo[i]];
-        if constexpr (LEVELS) r.hb[i] = hm[ro + xo[i]];
-      }
-    }
+  for (int i = 0; i < PX; ++i) {
+    const int c = (int)xo[i];
+    const int lc = min(max((c - cx0) / PX, 0), 63);
+    const int xbc = min(max(cx0 + lc * PX, 0), W - PX);
+    ridx[i] = lc * 4 + min(max(c - xbc, 0), PX - 1);
+  }
+  typedef __attribute__((address_space(1))) const void* gptr_t;
+  typedef __attribute__((address_space(3))) void* lptr_t;
+  auto issue_row = [&](int row, int slot) {
+#ifdef TACEX_DBG_NO_ROWLOAD
+    const unsigned ro = xb; (void)row;
+#else
+    const unsigned ro = (unsigned)row * (unsigned)W + xb;
+#endif
+    float* dst = rowbuf + slot * kRowSlot;
+    __builtin_amdgcn_global_load_lds((gptr_t)(zin + ro), (lptr_t)dst, 12, 0, 0);
+    if constexpr (LEVELS) __builtin_amdgcn_global_load_lds((gptr_t)(hm + ro), (lptr_t)(dst + kRowArr), 12, 0, 0);
   };
-  auto consume_row = [&](RowRegs& r) {  // forces the waits for the row's loads to THIS point (see the loop tail)
-    if constexpr (LEVELS)
-      asm volatile("" : "+v"(r.z3), "+v"(r.h3), "+v"(r.zb[0]), "+v"(r.zb[1]), "+v"(r.zb[2]), "+v"(r.hb[0]), "+v"(r.hb[1]), "+v"(r.hb[2]));
-    else
-      asm volatile("" : "+v"(r.z3), "+v"(r.zb[0]), "+v"(r.zb[1]), "+v"(r.zb[2]));
-  };
-  auto merge_row = [&](const RowRegs& r, float (&zz)[PX], float (&hh)[PX]) {
+  auto read_row = [&](int slot, float (&zz)[PX], float (&hh)[PX]) {
+    const float* src = rowbuf + slot * kRowSlot;
 #pragma unroll
     for (int i = 0; i < PX; ++i) {
-      zz[i] = border ? r.zb[i] : r.z3[i];
-      if constexpr (LEVELS) hh[i] = border ? r.hb[i] : r.h3[i];
+      zz[i] = src[ridx[i]];
+      if constexpr (LEVELS) hh[i] = src[kRowArr + ridx[i]];
     }
   };
 
@@ -247,6 +256,9 @@ __global__ __launch_bounds__(64 * kStreamWaves, stream_min_waves(ROLE)) void tax
 #pragma unroll
   for (int i = 0; i < PX; ++i) xc[i] = (unsigned)min(max(xg[i], 0), W - 1);
   auto load_bg = [&](int row, v3f (&q)[PX]) {
+#ifdef TACEX_DBG_NO_BG
+    if (row >= 0) return;
+#endif
 #pragma unroll
     for (int i = 0; i < PX; ++i)
       q[i] = *reinterpret_cast<const v3f*>(reinterpret_cast<const char*>(a.sh.bg) + ((unsigned)row * (unsigned)W + xc[i]) * 12u);
@@ -297,8 +309,11 @@ __global__ __launch_bounds__(64 * kStreamWaves, stream_min_waves(ROLE)) void tax
   float Zu[PX] = {0.f, 0.f, 0.f}, Zm[PX] = {0.f, 0.f, 0.f}, Zd[PX] = {0.f, 0.f, 0.f};  // last-level rows g-1, g, g+1
 
   // FOTS contact statistics of this wave's pixels
+  // (count and row sum are wave-uniform per row: scalar popcounts of the mask; the column sum needs only a per-pixel
+  //  counter per lane - sum_col = sum_i xg[i] * f_cpx[i] at the end)
   float f_zmax = -INFINITY;
-  int f_cnt = 0, f_sr = 0, f_sc = 0;
+  int f_cnt = 0, f_sr = 0;
+  int f_cpx[PX] = {0, 0, 0};
   // policy observation: vertical partial sums of the <= 3 observation rows in flight
   float OA[kStreamObsActive][PX * 3];
 #pragma unroll
@@ -347,12 +362,9 @@ __global__ __launch_bounds__(64 * kStreamWaves, stream_min_waves(ROLE)) void tax
   const int ys = SHADE ? r0 - SUMR - 1 : r0 - SUMR;
   const int ye = SHADE ? r1 + SUMR + 1 : r1 - 1 + SUMR;
   float zc[PX], hc[PX] = {0.f, 0.f, 0.f};
-  {
-    RowRegs r0r;
-    load_row(row_of(ys), r0r);
-    consume_row(r0r);
-    merge_row(r0r, zc, hc);
-  }
+  issue_row(row_of(ys), ys & 1);
+  issue_row(row_of(ys + 1), (ys + 1) & 1);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   // Row scalars, fetched one iteration ahead with a VECTOR load (lanes 0-7: record of the row shaded, 8-15: of the row
   // entering, 16-23: of the row leaving the last level) and moved to scalar registers with v_readlane: scalar-memory loads
   // share the LDS wait counter and return out of order, so every ring read would also wait for them.
@@ -376,15 +388,18 @@ __global__ __launch_bounds__(64 * kStreamWaves, stream_min_waves(ROLE)) void tax
   };
   unpack_info(load_info(ys));
   for (int y = ys; y <= ye; ++y) {
-    // ---- prefetch the next input row and the next iteration's row scalars (consumed at the END of this iteration) ----
-    RowRegs nrow;
-    load_row(row_of(y + 1), nrow);
+    // ---- row y out of the ring (it landed before the previous iteration's mid_point returned); next iteration's row scalars ----
+    read_row(y & 1, zc, hc);
     int ninfo = load_info(y + 1);
-    v3f nbg[PX] = {(v3f)(0.0f), (v3f)(0.0f), (v3f)(0.0f)};
-    if constexpr (SHADE && !LEVELS) {  // shading-only role: nothing in the iteration hides a load - fetch the background of
-      const int gn = y + 1 - SUMR - 2;   // the NEXT shaded row now (consumed at the loop tail, like the row itself)
-      if (gn >= max(r0, 1) && gn <= min(r1 - 1, H - 2)) load_bg(gn, nbg);
-    }
+    // The ONE point of the iteration where this wave waits for memory: every plain load of the iteration (row scalars,
+    // background, table gather) has been consumed by the caller, row y+1 (issued one iteration ago) is forced to have landed, and
+    // row y+2 is issued into the slot row y was read from.  Only stores follow, so they are a full iteration old at the next
+    // vmcnt(0) (on gfx9 stores count in vmcnt too, and hipcc waits vmcnt(0) at any plain load result while an LDS load is in flight).
+    auto mid_point = [&]() {
+      asm volatile("" : "+v"(ninfo));
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      issue_row(row_of(y + 2), y & 1);
+    };
 
     // ---- shading, part 1 (runs between level 0 and level 1, see below): bins of row gs, background loads in flight.
     //      Replicate padding of the gradient maps (TT:501-502): rows 0 / H-1 take the gradient of rows 1 / H-2 and are emitted
@@ -397,11 +412,20 @@ __global__ __launch_bounds__(64 * kStreamWaves, stream_min_waves(ROLE)) void tax
         if (!shade_now) return;
         const float zl = dpp_from_left(Zm[PX - 1]), zrg = dpp_from_right(Zm[0]);
         int code[PX];
+        float gx[PX], gy[PX], t2[PX];
 #pragma unroll
-        for (int i = 0; i < PX; ++i) {
-          int im, id;
-          shade_bins(a.sh, Zu[i], Zd[i], i == 0 ? zl : Zm[i - 1], i == PX - 1 ? zrg : Zm[i + 1], im, id);
-          code[i] = im * a.sh.nb + id;
+        for (int i = 0; i < PX; ++i) {  // as shade_bins (TT:475-499), split so that the magnitude part can be skipped
+          gx[i] = (Zu[i] - Zd[i]) * a.sh.gsy;
+          gy[i] = ((i == 0 ? zl : Zm[i - 1]) - (i == PX - 1 ? zrg : Zm[i + 1])) * a.sh.gsx;
+          t2[i] = fmaf(gx[i], gx[i], gy[i] * gy[i]);
+          code[i] = shade_dir_bin(a.sh, gx[i], gy[i], t2[i]);
+        }
+        // Most row segments lie outside the contact: every |gradient| is below the first magnitude-bin edge, with a margin
+        // (2e-5 relative = 2.5e-7 rad) wider than the error of the arc-tangent polynomial, so bin 0 is what the full
+        // evaluation returns and the sqrt / rcp / polynomial (a third of the bin arithmetic) is skipped for the whole wave.
+        if (__builtin_amdgcn_ballot_w64(fmaxf(fmaxf(t2[0], t2[1]), t2[2]) >= mag0_t2) != 0) {
+#pragma unroll
+          for (int i = 0; i < PX; ++i) code[i] += shade_mag_bin(a.sh, t2[i]) * a.sh.nb;
         }
         const int cl = dpp_from_left_i(code[PX - 1]), cr = dpp_from_right_i(code[0]);
 #pragma unroll
@@ -409,7 +433,7 @@ __global__ __launch_bounds__(64 * kStreamWaves, stream_min_waves(ROLE)) void tax
           const int right = i == PX - 1 ? cr : code[i + 1], left = i == 0 ? cl : code[i - 1];
           cc[i] = xg[i] == 0 ? right : (xg[i] == W - 1 ? left : code[i]);
         }
-        if constexpr (LEVELS) load_bg(gs, bgq);  // fused role: issued here, consumed after the remaining levels
+        load_bg(gs, bgq);  // issued here, consumed after the remaining levels
       }
     };
     if constexpr (!LEVELS) shade_part1();
@@ -439,13 +463,21 @@ __global__ __launch_bounds__(64 * kStreamWaves, stream_min_waves(ROLE)) void tax
           for (int i = 0; i < PX; ++i) gl[i] = a.gel[ro + xo[i]];
         }
         int mrow[PX];
+        int row_cnt = 0;
 #pragma unroll
         for (int i = 0; i < PX; ++i) {
-          const float J = fmin_raw(S[i], gl[i]);
-          const int m1 = (valid[i] && ((J - gl[i]) < thr) && (S[i] < 0.0f)) ? 1 : 0;  // TT:457-461
-          mrow[i] = m1;
-          f_cnt += m1; f_sr += m1 * y; f_sc += m1 * xg[i];
+          bool m;
+          if constexpr (GZ) {
+            m = valid[i] && S[i] < thr_eff;
+          } else {
+            const float J = fmin_raw(S[i], gl[i]);
+            m = valid[i] && ((J - gl[i]) < thr) && (S[i] < 0.0f);  // TT:457-461
+          }
+          mrow[i] = m ? 1 : 0;
+          f_cpx[i] += m ? 1 : 0;
+          row_cnt += __builtin_popcountll(__builtin_amdgcn_ballot_w64(m));
         }
+        f_cnt += row_cnt; f_sr += row_cnt * y;
         if (a.pix_m != nullptr) {  // contact mask at the FOTS marker pixels of this row
           for (int e = ri_y.mk0; e < ri_y.mk1; ++e) {
             const int mx = a.mk_x[e];
@@ -520,14 +552,19 @@ __global__ __launch_bounds__(64 * kStreamWaves, stream_min_waves(ROLE)) void tax
 #pragma unroll
           for (int i = 0; i < PX; ++i) {
             const float Si = Sv[i];
-            const float J = fmin_raw(Si, gl[i]);
-            out[i] = (((J - gl[i]) < thr) && (Si < 0.0f)) ? J : out[i];
+            if constexpr (GZ) {
+              out[i] = Si < thr_eff ? Si : out[i];
+            } else {
+              const float J = fmin_raw(Si, gl[i]);
+              out[i] = (((J - gl[i]) < thr) && (Si < 0.0f)) ? J : out[i];
+            }
           }
         }
 #pragma unroll
         for (int i = 0; i < PX; ++i) cur[i] = out[i];
       });
       // ---- cur = last-level row zr = y - SUMR ----
+      if constexpr (!SHADE) mid_point();
       const int zr = y - SUMR;
       if (zr >= r0 && zr < r1) {
         if (do_fots) {
@@ -555,15 +592,18 @@ __global__ __launch_bounds__(64 * kStreamWaves, stream_min_waves(ROLE)) void tax
     }
     // ---- shading, part 2: table records, polynomial, background, clip, store, observation ----
     if constexpr (SHADE) {
+      v4f pc[PX][5];
       if (shade_now) {
         // Table records: magnitude bin 0 (code < nb) from the workgroup's LDS copy - every lane reads (clamped index), one wait -
         // then the lanes of contact pixels overwrite theirs with a gather from the table in L2; row segments without such a
         // lane (most of them) issue no vector-memory instruction for the table at all.
-        v4f pc[PX][5];
         bool hi[PX];
 #pragma unroll
         for (int i = 0; i < PX; ++i) {
           hi[i] = valid[i] && cc[i] >= nb_lds;  // halo lanes hold garbage bins: they must not trigger the L2 gather
+#ifdef TACEX_DBG_NO_GATHER
+          hi[i] = false;
+#endif
           const v4f* pl = reinterpret_cast<const v4f*>(polyL + (hi[i] ? 0 : cc[i]) * kStreamPolyPitch);
           pc[i][0] = pl[0]; pc[i][1] = pl[1]; pc[i][2] = pl[2]; pc[i][3] = pl[3]; pc[i][4] = pl[4];
         }
@@ -575,6 +615,14 @@ __global__ __launch_bounds__(64 * kStreamWaves, stream_min_waves(ROLE)) void tax
               pc[i][0] = pp[0]; pc[i][1] = pp[1]; pc[i][2] = pp[2]; pc[i][3] = pp[3]; pc[i][4] = pp[4];
             }
         }
+        // results of the plain loads are taken HERE (see mid_point)
+        asm volatile("" : "+v"(pc[0][0]), "+v"(pc[0][1]), "+v"(pc[0][2]), "+v"(pc[0][3]), "+v"(pc[0][4]), "+v"(pc[1][0]), "+v"(pc[1][1]),
+                     "+v"(pc[1][2]), "+v"(pc[1][3]), "+v"(pc[1][4]));
+        asm volatile("" : "+v"(pc[2][0]), "+v"(pc[2][1]), "+v"(pc[2][2]), "+v"(pc[2][3]), "+v"(pc[2][4]), "+v"(bgq[0]), "+v"(bgq[1]),
+                     "+v"(bgq[2]));
+      }
+      mid_point();
+      if (shade_now) {
         const int e_lo = gs == 1 ? 0 : gs, e_hi = gs == H - 2 ? H - 1 : gs;  // rows emitted by this iteration (ascending)
         for (int e = e_lo; e <= e_hi; ++e) {
           if (e < r0 || e >= r1) continue;
@@ -596,7 +644,11 @@ __global__ __launch_bounds__(64 * kStreamWaves, stream_min_waves(ROLE)) void tax
             rgb[3 * i + 0] = __builtin_amdgcn_fmed3f(p0 + bq[i].x, 0.0f, 1.0f);  // TT:257-258
             rgb[3 * i + 1] = __builtin_amdgcn_fmed3f(p1 + bq[i].y, 0.0f, 1.0f);
             rgb[3 * i + 2] = __builtin_amdgcn_fmed3f(p2 + bq[i].z, 0.0f, 1.0f);
+#ifdef TACEX_DBG_NO_STORE
+            if (valid[i] && rgb[3 * i] == 12345.0f)
+#else
             if (valid[i])
+#endif
               *reinterpret_cast<v3f*>(reinterpret_cast<char*>(a.sh.rgb + fo * 3) + ((unsigned)e * (unsigned)W + xc[i]) * 12u) =
                   (v3f){rgb[3 * i], rgb[3 * i + 1], rgb[3 * i + 2]};
           }
@@ -617,17 +669,7 @@ __global__ __launch_bounds__(64 * kStreamWaves, stream_min_waves(ROLE)) void tax
         }
       }
     }
-    // The prefetched row must be waited for HERE, a whole iteration after its loads were issued.  Left to the compiler, the
-    // wait lands at the first use in the NEXT iteration - behind that iteration's freshly issued loads, and the in-order
-    // vmcnt then drains those too (s_waitcnt vmcnt(2) at the loop head: the memory latency of every row was exposed).
-    consume_row(nrow);
-    asm volatile("" : "+v"(ninfo));
-    if constexpr (SHADE && !LEVELS) {
-      asm volatile("" : "+v"(nbg[0]), "+v"(nbg[1]), "+v"(nbg[2]));
-      bgq[0] = nbg[0]; bgq[1] = nbg[1]; bgq[2] = nbg[2];
-    }
     unpack_info(ninfo);
-    merge_row(nrow, zc, hc);
 #pragma unroll
     for (int i = 0; i < PX; ++i) { Zu[i] = Zm[i]; Zm[i] = Zd[i]; Zd[i] = cur[i]; }
   }
@@ -641,8 +683,9 @@ __global__ __launch_bounds__(64 * kStreamWaves, stream_min_waves(ROLE)) void tax
   }
   if (do_fots) {  // one record per wave: no atomics; fots_combine_kernel adds the records of an env
     f_zmax = wave_scan_max_lane63(f_zmax);
-    f_cnt = wave_scan_add_lane63(f_cnt);
-    f_sr = wave_scan_add_lane63(f_sr);
+    int f_sc = 0;
+#pragma unroll
+    for (int i = 0; i < PX; ++i) f_sc += f_cpx[i] * xg[i];
     f_sc = wave_scan_add_lane63(f_sc);
     if (lane == 63) {
       FotsReduce r;
@@ -793,6 +836,10 @@ hipError_t run_stream_tail(const LevelDesc* lv, int n_levels, int n_fused, const
   a.sh.calib_h = (float)sp->calib_h; a.sh.calib_w = (float)sp->calib_w; a.sh.x_binr = sp->x_binr; a.sh.y_binr = sp->y_binr;
   a.sh.gsy = (float)(0.5 * H / sp->calib_h / (double)sp->pixmm); a.sh.gsx = (float)(0.5 * W / sp->calib_w / (double)sp->pixmm);
   a.sh.inv_x_binr = (float)(1.0 / (double)sp->x_binr); a.sh.inv_y_binr = (float)(1.0 / (double)sp->y_binr);
+  {
+    const double t1 = tan((double)sp->x_binr) * (1.0 - 2e-5);
+    a.mag0_t2 = (float)(t1 * t1);
+  }
   a.rows = static_cast<const StreamRowInfo*>(plan.rows);
   StreamArgs sh = a;  // arguments of the kernel that shades
   sh.nstrips = plan.nstrips; sh.strip_w = plan.strip_w; sh.nseg = plan.nseg; sh.seg_rows = plan.seg_rows;
