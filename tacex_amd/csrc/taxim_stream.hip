@@ -387,17 +387,29 @@ __global__ __launch_bounds__(64 * kStreamWaves, stream_min_waves(ROLE)) void tax
     }
   };
   unpack_info(load_info(ys));
+#ifdef TACEX_STREAM_CLOCK
+  float clk_acc[4] = {0.f, 0.f, 0.f, 0.f};
+#endif
   for (int y = ys; y <= ye; ++y) {
     // ---- row y out of the ring (it landed before the previous iteration's mid_point returned); next iteration's row scalars ----
+#ifdef TACEX_STREAM_CLOCK
+    const long long ck0 = __builtin_readcyclecounter();
+#endif
     read_row(y & 1, zc, hc);
     int ninfo = load_info(y + 1);
     // The ONE point of the iteration where this wave waits for memory: every plain load of the iteration (row scalars,
     // background, table gather) has been consumed by the caller, row y+1 (issued one iteration ago) is forced to have landed, and
     // row y+2 is issued into the slot row y was read from.  Only stores follow, so they are a full iteration old at the next
     // vmcnt(0) (on gfx9 stores count in vmcnt too, and hipcc waits vmcnt(0) at any plain load result while an LDS load is in flight).
+#ifdef TACEX_STREAM_CLOCK
+    long long ck1 = 0, ck2 = 0;
+#endif
     auto mid_point = [&]() {
       asm volatile("" : "+v"(ninfo));
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#ifdef TACEX_STREAM_CLOCK
+      ck2 = __builtin_readcyclecounter();
+#endif
       issue_row(row_of(y + 2), y & 1);
     };
 
@@ -407,6 +419,30 @@ __global__ __launch_bounds__(64 * kStreamWaves, stream_min_waves(ROLE)) void tax
     const int gs = y - SUMR - 2;
     const bool shade_now = SHADE && gs >= max(r0, 1) && gs <= min(r1 - 1, H - 2);
     int cc[PX] = {0, 0, 0};  // table record (bin pair) of every pixel of row gs
+    v4f pc[PX][5];           // its 18 polynomial coefficients (TT:250-255), fetched at the top of the iteration
+    auto fetch_table = [&]() {
+      // Table records: magnitude bin 0 (code < nb) from the workgroup's LDS copy - every lane reads (clamped index) - then the
+      // lanes of contact pixels overwrite theirs with a gather from the table in L2; row segments without such a lane (most
+      // of them) issue no vector-memory instruction for the table at all.
+      bool hi[PX];
+#pragma unroll
+      for (int i = 0; i < PX; ++i) {
+        hi[i] = valid[i] && cc[i] >= nb_lds;  // halo lanes hold garbage bins: they must not trigger the L2 gather
+#ifdef TACEX_DBG_NO_GATHER
+        hi[i] = false;
+#endif
+        const v4f* pl = reinterpret_cast<const v4f*>(polyL + (hi[i] ? 0 : cc[i]) * kStreamPolyPitch);
+        pc[i][0] = pl[0]; pc[i][1] = pl[1]; pc[i][2] = pl[2]; pc[i][3] = pl[3]; pc[i][4] = pl[4];
+      }
+      if (__builtin_amdgcn_ballot_w64(hi[0] || hi[1] || hi[2]) != 0) {
+#pragma unroll
+        for (int i = 0; i < PX; ++i)
+          if (hi[i]) {
+            const v4f* __restrict__ pp = reinterpret_cast<const v4f*>(reinterpret_cast<const char*>(a.sh.poly) + (unsigned)cc[i] * 96u);
+            pc[i][0] = pp[0]; pc[i][1] = pp[1]; pc[i][2] = pp[2]; pc[i][3] = pp[3]; pc[i][4] = pp[4];
+          }
+      }
+    };
     auto shade_part1 = [&]() {
       if constexpr (SHADE) {
         if (!shade_now) return;
@@ -433,10 +469,13 @@ __global__ __launch_bounds__(64 * kStreamWaves, stream_min_waves(ROLE)) void tax
           const int right = i == PX - 1 ? cr : code[i + 1], left = i == 0 ? cl : code[i - 1];
           cc[i] = xg[i] == 0 ? right : (xg[i] == W - 1 ? left : code[i]);
         }
-        load_bg(gs, bgq);  // issued here, consumed after the remaining levels
+#ifdef TACEX_STREAM_EARLY_TABLE  // A/B probe: table fetch ahead of the levels (measured equal: the wait below is ~6 % of the iteration either way)
+        fetch_table();
+#endif
+        load_bg(gs, bgq);
       }
     };
-    if constexpr (!LEVELS) shade_part1();
+    shade_part1();
 
     float cur[PX];
 #pragma unroll
@@ -491,8 +530,6 @@ __global__ __launch_bounds__(64 * kStreamWaves, stream_min_waves(ROLE)) void tax
       static_for<0, NL>([&](auto lc) {
         constexpr int l = decltype(lc)::value;
         constexpr int K = C::K[l], R = C::R(l), WO = C::acc_off(l) + l, AO = C::acc_off(l);
-        // the widest window (level 0) is done: issue the shading loads of row gs now, the remaining levels run under their latency
-        if constexpr (l == (NL > 1 ? 1 : 0)) shade_part1();
         float h[PX];
         if constexpr (K == 1) {
 #pragma unroll
@@ -592,29 +629,13 @@ __global__ __launch_bounds__(64 * kStreamWaves, stream_min_waves(ROLE)) void tax
     }
     // ---- shading, part 2: table records, polynomial, background, clip, store, observation ----
     if constexpr (SHADE) {
-      v4f pc[PX][5];
       if (shade_now) {
-        // Table records: magnitude bin 0 (code < nb) from the workgroup's LDS copy - every lane reads (clamped index), one wait -
-        // then the lanes of contact pixels overwrite theirs with a gather from the table in L2; row segments without such a
-        // lane (most of them) issue no vector-memory instruction for the table at all.
-        bool hi[PX];
-#pragma unroll
-        for (int i = 0; i < PX; ++i) {
-          hi[i] = valid[i] && cc[i] >= nb_lds;  // halo lanes hold garbage bins: they must not trigger the L2 gather
-#ifdef TACEX_DBG_NO_GATHER
-          hi[i] = false;
+#ifndef TACEX_STREAM_EARLY_TABLE
+        fetch_table();
 #endif
-          const v4f* pl = reinterpret_cast<const v4f*>(polyL + (hi[i] ? 0 : cc[i]) * kStreamPolyPitch);
-          pc[i][0] = pl[0]; pc[i][1] = pl[1]; pc[i][2] = pl[2]; pc[i][3] = pl[3]; pc[i][4] = pl[4];
-        }
-        if (__builtin_amdgcn_ballot_w64(hi[0] || hi[1] || hi[2]) != 0) {
-#pragma unroll
-          for (int i = 0; i < PX; ++i)
-            if (hi[i]) {
-              const v4f* __restrict__ pp = reinterpret_cast<const v4f*>(reinterpret_cast<const char*>(a.sh.poly) + (unsigned)cc[i] * 96u);
-              pc[i][0] = pp[0]; pc[i][1] = pp[1]; pc[i][2] = pp[2]; pc[i][3] = pp[3]; pc[i][4] = pp[4];
-            }
-        }
+#ifdef TACEX_STREAM_CLOCK
+        ck1 = __builtin_readcyclecounter();
+#endif
         // results of the plain loads are taken HERE (see mid_point)
         asm volatile("" : "+v"(pc[0][0]), "+v"(pc[0][1]), "+v"(pc[0][2]), "+v"(pc[0][3]), "+v"(pc[0][4]), "+v"(pc[1][0]), "+v"(pc[1][1]),
                      "+v"(pc[1][2]), "+v"(pc[1][3]), "+v"(pc[1][4]));
@@ -672,7 +693,19 @@ __global__ __launch_bounds__(64 * kStreamWaves, stream_min_waves(ROLE)) void tax
     unpack_info(ninfo);
 #pragma unroll
     for (int i = 0; i < PX; ++i) { Zu[i] = Zm[i]; Zm[i] = Zd[i]; Zd[i] = cur[i]; }
+#ifdef TACEX_STREAM_CLOCK
+    {
+      const long long ck3 = __builtin_readcyclecounter();
+      if (ck1 != 0) { clk_acc[0] += (float)(ck1 - ck0); clk_acc[1] += (float)(ck2 - ck1); clk_acc[2] += (float)(ck3 - ck2); clk_acc[3] += 1.0f; }
+    }
+#endif
   }
+#ifdef TACEX_STREAM_CLOCK
+  if (lane == 0 && SHADE) {  // probe output over the first pixels of the frame: [rem][compute before wait, wait, after wait, shaded rows]
+    float* dbg = a.sh.rgb + fo * 3 + rem * 4;
+    dbg[0] = clk_acc[0]; dbg[1] = clk_acc[1]; dbg[2] = clk_acc[2]; dbg[3] = clk_acc[3];
+  }
+#endif
   if constexpr (SHADE) {
     if (do_obs) {  // observation rows still in flight at the end of the segment (another segment adds its share)
       obs_flush(OA[0], cur_o0);
