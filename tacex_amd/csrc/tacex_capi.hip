@@ -66,6 +66,7 @@ struct tacex_taxim_ctx {
   std::vector<float> feat_y_h;                 // host copy of the polynomial feature y (per-row table of the streaming tail)
   std::vector<int> mk_row_ptr_h;               // marker CSR over frame rows (host), device columns / ids below
   const int* mk_x = nullptr; const int* mk_id = nullptr;
+  std::vector<int> mk_x_h, mk_id_h;
   int mk_version = 0;
   std::vector<void*> allocs;
   // profiling
@@ -348,10 +349,24 @@ static int stream_plan(tacex_taxim_ctx* c, int n_fused, int B, int oh, int ow, c
       for (auto& ri : rows) { ri.o0 = 0; ri.w0 = ri.w1 = ri.w2 = 0.0f; }
     }
   }
-  StreamRowInfo* d_rows = nullptr;
-  if (int rc = upload(c, rows.data(), rows.size(), &d_rows)) return rc;
+  // device table: [row][record (8 ints) | packed marker slots]
+  std::vector<int> table((size_t)H * kStreamRowInts, -1);
+  p.mk_vec = !c->mk_row_ptr_h.empty();
+  for (int r = 0; r < H; ++r) {
+    static_assert(sizeof(StreamRowInfo) == 8 * sizeof(int), "row record layout");
+    memcpy(&table[(size_t)r * kStreamRowInts], &rows[r], sizeof(StreamRowInfo));
+    if (c->mk_row_ptr_h.empty()) continue;
+    const int e0 = c->mk_row_ptr_h[r], e1 = c->mk_row_ptr_h[r + 1];
+    if (e1 - e0 > kStreamMkSlots) { p.mk_vec = false; continue; }
+    for (int e = e0; e < e1; ++e)
+      table[(size_t)r * kStreamRowInts + 8 + (e - e0)] = (int)((unsigned)c->mk_x_h[e] | ((unsigned)c->mk_id_h[e] << 16));
+  }
+  if (c->W >= 65535) p.mk_vec = false;
+  int* d_rows = nullptr;
+  if (int rc = upload(c, table.data(), table.size(), &d_rows)) return rc;
   p.rows = d_rows;
   p.mk_x = c->mk_x; p.mk_id = c->mk_id; p.n_markers = c->fots_taps.n_markers;
+  if (p.n_markers >= 65535) p.mk_vec = false;
   c->stream_plans.push_back({oh, ow, nseg, c->mk_version, p});
   *out = &c->stream_plans.back().plan;
   return 0;
@@ -720,7 +735,7 @@ int tacex_taxim_set_fots_taps(tacex_taxim_ctx* c, const int32_t* marker_x, const
   if (!c) { set_error("tacex_taxim_set_fots_taps: null context"); return 2; }
   if (!z_pix_dev || !mask_pix_dev || !marker_x || !marker_y || n_markers <= 0) {  // disable
     c->fots_pix_z = nullptr; c->fots_pix_m = nullptr; c->fots_pix_cap = 0;
-    c->mk_row_ptr_h.clear(); c->mk_x = nullptr; c->mk_id = nullptr; ++c->mk_version;
+    c->mk_row_ptr_h.clear(); c->mk_x_h.clear(); c->mk_id_h.clear(); c->mk_x = nullptr; c->mk_id = nullptr; ++c->mk_version;
     return 0;
   }
   if (n_markers > 65535) { set_error("tacex_taxim_set_fots_taps: too many markers"); return 2; }
@@ -752,7 +767,7 @@ int tacex_taxim_set_fots_taps(tacex_taxim_ctx* c, const int32_t* marker_x, const
     int *dx = nullptr, *di = nullptr;
     if (int rc = upload(c, mx.data(), mx.size(), &dx)) return rc;
     if (int rc = upload(c, mid.data(), mid.size(), &di)) return rc;
-    c->mk_row_ptr_h = ptr; c->mk_x = dx; c->mk_id = di; ++c->mk_version;
+    c->mk_row_ptr_h = ptr; c->mk_x_h = mx; c->mk_id_h = mid; c->mk_x = dx; c->mk_id = di; ++c->mk_version;
   }
   c->fots_taps.mk_tile = dt; c->fots_taps.mk_cnt = dc; c->fots_taps.n_markers = n_markers;
   c->fots_pix_z = z_pix_dev; c->fots_pix_m = mask_pix_dev; c->fots_pix_cap = capacity_frames;

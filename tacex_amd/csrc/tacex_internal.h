@@ -109,6 +109,11 @@ struct StreamRowInfo {
   int mk0, mk1;  // markers mk_x / mk_id [mk0, mk1) lie in this row
   int pad;
 };
+// the per-row table holds kStreamRowInts ints per frame row: the StreamRowInfo record (8) followed by the row's FOTS markers as
+// packed slots (column | marker index << 16, 0xffffffff = empty), so that the ONE vector load that fetches the row scalars of
+// an iteration also brings the markers of the two rows the iteration taps (lanes 24..43 / 44..63)
+constexpr int kStreamRowInts = 32;
+constexpr int kStreamMkSlots = 20;
 struct StreamPlan {
   int nstrips = 0, strip_w = 0, nseg = 0, seg_rows = 0;              // kernel that shades (RGB, observation partial sums)
   int lv_nstrips = 0, lv_strip_w = 0, lv_nseg = 0, lv_seg_rows = 0;  // kernel that runs the levels (FOTS partial records)
@@ -122,6 +127,7 @@ struct StreamPlan {
   int obs_nrows = 0, obs_ncols = 0;
   // FOTS marker pixels as a CSR over frame rows (device), nullptr when no taps are set
   const int* mk_x = nullptr; const int* mk_id = nullptr; int n_markers = 0;
+  bool mk_vec = false;  // every row's markers fit the packed slots of the row table (else the kernel walks the CSR)
 };
 int stream_obs_lds_floats();
 int stream_obs_max_cols();

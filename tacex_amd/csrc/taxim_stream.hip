@@ -49,7 +49,8 @@ struct StreamArgs {
   float mag0_t2;         // squared gradient magnitude below which the magnitude bin is 0 for certain (see shade_part1)
   int nstrips, strip_w;  // strips per frame, valid columns per strip
   int nseg, seg_rows;    // vertical segments per strip, rows per segment
-  const StreamRowInfo* rows;  // (H,)
+  const int* rows;       // (H, kStreamRowInts): StreamRowInfo record + packed marker slots per frame row
+  int mk_vec;            // marker slots usable (every row has <= kStreamMkSlots markers)
   // policy observation (nullable): per (frame, strip, segment) block of partial sums [obs_nrows][obs_ncols][3]
   float* obs_part;
   const int* obs_xlo; const int* obs_xcnt; const float* obs_wx; int obs_kx;   // column filters (ObsTables)
@@ -368,12 +369,17 @@ __global__ __launch_bounds__(64 * kStreamWaves, stream_min_waves(ROLE)) void tax
   // Row scalars, fetched one iteration ahead with a VECTOR load (lanes 0-7: record of the row shaded, 8-15: of the row
   // entering, 16-23: of the row leaving the last level) and moved to scalar registers with v_readlane: scalar-memory loads
   // share the LDS wait counter and return out of order, so every ring read would also wait for them.
-  const int* rows_i = reinterpret_cast<const int*>(a.rows);
+  // Lanes 24-43 / 44-63 of the same load bring the packed marker slots of the row entering / the row leaving the last level:
+  // the FOTS taps of a marker row then cost three ds_bpermute and one store instead of a dependent load -> wait -> store chain
+  // per marker (11 chains per marker row were ~8 % of the kernel).
+  const int* rows_i = a.rows;
   auto load_info = [&](int yy) -> int {
     const int k = lane >> 3;
-    const int r = row_of(k == 0 ? yy - SUMR - 2 : (k == 1 ? yy : yy - SUMR));
-    return lane < 24 ? rows_i[r * 8 + (lane & 7)] : 0;
+    const int r = row_of(k == 0 ? yy - SUMR - 2 : ((k == 1 || (lane >= 24 && lane < 24 + kStreamMkSlots)) ? yy : yy - SUMR));
+    const int off = lane < 24 ? (lane & 7) : 8 + (lane - 24) % kStreamMkSlots;
+    return rows_i[r * kStreamRowInts + off];
   };
+  int cinfo = 0;  // the vector the current iteration's row scalars were unpacked from (marker slots in lanes 24..63)
   StreamRowInfo ri_g{}, ri_y{}, ri_z{};
   auto unpack_info = [&](int info) {
     if constexpr (SHADE) {
@@ -386,7 +392,8 @@ __global__ __launch_bounds__(64 * kStreamWaves, stream_min_waves(ROLE)) void tax
       ri_z.mk0 = __builtin_amdgcn_readlane(info, 16 + 5); ri_z.mk1 = __builtin_amdgcn_readlane(info, 16 + 6);
     }
   };
-  unpack_info(load_info(ys));
+  cinfo = load_info(ys);
+  unpack_info(cinfo);
 #ifdef TACEX_STREAM_CLOCK
   float clk_acc[4] = {0.f, 0.f, 0.f, 0.f};
 #endif
@@ -517,7 +524,16 @@ __global__ __launch_bounds__(64 * kStreamWaves, stream_min_waves(ROLE)) void tax
           row_cnt += __builtin_popcountll(__builtin_amdgcn_ballot_w64(m));
         }
         f_cnt += row_cnt; f_sr += row_cnt * y;
-        if (a.pix_m != nullptr) {  // contact mask at the FOTS marker pixels of this row
+        if (a.pix_m != nullptr && a.mk_vec) {  // contact mask at the FOTS marker pixels of this row
+          if (ri_y.mk1 > ri_y.mk0) {
+            const unsigned mk = (lane >= 24 && lane < 24 + kStreamMkSlots) ? (unsigned)cinfo : 0xffffffffu;
+            const int mx = (int)(mk & 0xffffu), rel = mx - cx0, owner = rel / PX, d = rel - owner * PX;
+            const int v0 = __builtin_amdgcn_ds_bpermute(owner << 2, mrow[0]), v1 = __builtin_amdgcn_ds_bpermute(owner << 2, mrow[1]),
+                      v2 = __builtin_amdgcn_ds_bpermute(owner << 2, mrow[2]);
+            if (mk != 0xffffffffu && mx >= vx0 && mx < vx1)
+              a.pix_m[(size_t)frame * a.n_markers + (mk >> 16)] = (uint8_t)(d == 0 ? v0 : (d == 1 ? v1 : v2));
+          }
+        } else if (a.pix_m != nullptr) {
           for (int e = ri_y.mk0; e < ri_y.mk1; ++e) {
             const int mx = a.mk_x[e];
             const int d = mx - cx0 - lane * PX;
@@ -608,7 +624,17 @@ __global__ __launch_bounds__(64 * kStreamWaves, stream_min_waves(ROLE)) void tax
 #pragma unroll
           for (int i = 0; i < PX; ++i) f_zmax = valid[i] ? fmaxf(f_zmax, cur[i]) : f_zmax;
         }
-        if (a.pix_z != nullptr) {
+        if (a.pix_z != nullptr && a.mk_vec) {
+          if (ri_z.mk1 > ri_z.mk0) {
+            const unsigned mk = lane >= 24 + kStreamMkSlots ? (unsigned)cinfo : 0xffffffffu;
+            const int mx = (int)(mk & 0xffffu), rel = mx - cx0, owner = rel / PX, d = rel - owner * PX;
+            const int v0 = __builtin_amdgcn_ds_bpermute(owner << 2, __float_as_int(cur[0])),
+                      v1 = __builtin_amdgcn_ds_bpermute(owner << 2, __float_as_int(cur[1])),
+                      v2 = __builtin_amdgcn_ds_bpermute(owner << 2, __float_as_int(cur[2]));
+            if (mk != 0xffffffffu && mx >= vx0 && mx < vx1)
+              a.pix_z[(size_t)frame * a.n_markers + (mk >> 16)] = __int_as_float(d == 0 ? v0 : (d == 1 ? v1 : v2));
+          }
+        } else if (a.pix_z != nullptr) {
           for (int e = ri_z.mk0; e < ri_z.mk1; ++e) {
             const int mx = a.mk_x[e];
             const int d = mx - cx0 - lane * PX;
@@ -650,7 +676,7 @@ __global__ __launch_bounds__(64 * kStreamWaves, stream_min_waves(ROLE)) void tax
           StreamRowInfo ri = ri_g;
           v3f bq[PX] = {bgq[0], bgq[1], bgq[2]};
           if (e != gs) {  // a replicated border row: its own feature / background / observation row (twice per frame)
-            ri = a.rows[e];
+            ri = *reinterpret_cast<const StreamRowInfo*>(a.rows + e * kStreamRowInts);
             load_bg(e, bq);
           }
           const float Y = ri.fy;
@@ -690,6 +716,7 @@ __global__ __launch_bounds__(64 * kStreamWaves, stream_min_waves(ROLE)) void tax
         }
       }
     }
+    cinfo = ninfo;
     unpack_info(ninfo);
 #pragma unroll
     for (int i = 0; i < PX; ++i) { Zu[i] = Zm[i]; Zm[i] = Zd[i]; Zd[i] = cur[i]; }
@@ -873,7 +900,7 @@ hipError_t run_stream_tail(const LevelDesc* lv, int n_levels, int n_fused, const
     const double t1 = tan((double)sp->x_binr) * (1.0 - 2e-5);
     a.mag0_t2 = (float)(t1 * t1);
   }
-  a.rows = static_cast<const StreamRowInfo*>(plan.rows);
+  a.rows = static_cast<const int*>(plan.rows); a.mk_vec = plan.mk_vec ? 1 : 0;
   StreamArgs sh = a;  // arguments of the kernel that shades
   sh.nstrips = plan.nstrips; sh.strip_w = plan.strip_w; sh.nseg = plan.nseg; sh.seg_rows = plan.seg_rows;
   if (obs_part && plan.obs_ready) {
