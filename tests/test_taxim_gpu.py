@@ -245,13 +245,15 @@ def test_mfma_and_valu_band_kernels_agree(calib_dir, golden_dir, tmp_path):
         assert np.abs(outs[key][0] - g["Z"]).max() <= 1e-5
 
 
-@pytest.mark.parametrize("shape,segs", [((240, 320), "0"), ((240, 320), "3"), ((240, 320), "8"), ((480, 640), "0"), ((480, 640), "5")])
-def test_streaming_tail_matches_tiled_tail(calib_dir, tmp_path, shape, segs):
+@pytest.mark.parametrize("shape,segs,mcols", [((240, 320), "0", 11), ((240, 320), "3", 11), ((240, 320), "8", 11), ((480, 640), "0", 11),
+                                              ((480, 640), "5", 11), ((240, 320), "0", 26)])
+def test_streaming_tail_matches_tiled_tail(calib_dir, tmp_path, shape, segs, mcols):
     """The wave-autonomous streaming tail (taxim_stream.hip, default) against the LDS-tiled tail (taxim_tail.hip) through the
     sensor boundary: RGB bit-equal (same summation order of every level, same shading code), uint8 / float policy observation
     to round-off (different partial-sum tiling), FOTS markers bit-equal (marker-pixel values and integer contact statistics
     are the same numbers).  Vertical segmentation (TACEX_STREAM_SEGS, read once per process) must not change a bit of RGB:
-    strips / segments only differ in how much warm-up they recompute."""
+    strips / segments only differ in how much warm-up they recompute.  mcols = 26 puts more markers on a row than the packed
+    marker slots of the row table hold (the kernel then walks the marker CSR)."""
     import os
     import subprocess
     import sys
@@ -259,6 +261,7 @@ def test_streaming_tail_matches_tiled_tail(calib_dir, tmp_path, shape, segs):
     from conftest import REPO
 
     H, W = shape
+    mrows = 9 if mcols == 11 else 4  # the FOTS kernels take up to 128 markers
     script = tmp_path / "stream_run.py"
     script.write_text(
         "import sys, numpy as np, torch\n"
@@ -276,7 +279,8 @@ def test_streaming_tail_matches_tiled_tail(calib_dir, tmp_path, shape, segs):
         f"        optical_sim_cfg=TaximSimulatorCfg(calib_folder_path={str(calib_dir)!r}, gelpad_height=0.0045, gelpad_to_camera_min_distance=0.024,\n"
         "            tactile_img_res=(W, H), device='cuda:0', policy_obs_res=(32, 32), policy_obs_dtype=dt),\n"
         "        marker_motion_sim_cfg=FOTSMarkerSimulatorCfg(tactile_img_res=(W, H), device='cuda:0',\n"
-        "            marker_params=FOTSMarkerSimulatorCfg.MarkerParams(num_markers_col=11, num_markers_row=9, x0=15 * W // 320, y0=26 * H // 240)), device='cuda:0')\n"
+        f"            marker_params=FOTSMarkerSimulatorCfg.MarkerParams(num_markers_col={mcols}, num_markers_row={mrows}, num_markers={mcols * mrows}, x0=15 * W // 320, y0=26 * H // 240,\n"
+        f"                dx={26.0 * 11 / mcols}, dy=29.0)), device='cuda:0')\n"
         "    s = GelSightSensor(cfg); s.initialize()\n"
         "    s.optical_simulator._taxim.set_fused_tail((H, W), mode)\n"
         "    hm, _ = synthetic_depth_maps(n, H, W, seed=99, flat_fraction=0.17)\n"
