@@ -138,6 +138,7 @@ class VisionTactileSensorUIPC:
                         and tuple(marker_translation_range) == (0.0, 0.0) and tuple(marker_pos_shift_range) == (0.0, 0.0)
                         and marker_random_noise == 0.0 and marker_lose_tracking_probability == 0.0)
         self._cached = None
+        self._static_flow = None
         self._lib = _lib.load_library()
 
     # -- frames (VT:142-187) -----------------------------------------------------------------------------
@@ -152,6 +153,15 @@ class VisionTactileSensorUIPC:
 
     def set_reference_surface_vertices_camera(self):
         self.reference_surface_vertices_camera = self.get_surface_vertices_camera().clone()
+
+    @property
+    def reference_surface_vertices_camera(self) -> torch.Tensor:
+        return self._ref_surface
+
+    @reference_surface_vertices_camera.setter
+    def reference_surface_vertices_camera(self, v: torch.Tensor):
+        self._ref_surface = v
+        self._ref_version = getattr(self, "_ref_version", 0) + 1  # invalidates the cached initial projection / mask
 
     # -- per-call set-up, cached while nothing is random --------------------------------------------------------
     def _setup(self):
@@ -175,11 +185,45 @@ class VisionTactileSensorUIPC:
         _lib.check(rc, "tacex_fem_marker_uv")
         return uv
 
+    def _gen_marker_flow_static(self, tri, wgt, curr_uv) -> torch.Tensor:
+        """gen_marker_flow when nothing about the marker grid is random (the shipped cfgs): the initial projection and the in-image
+        mask (VT:382-387) depend only on the reference surface, so they are computed ONCE per reference surface (the boolean-mask
+        indexing costs a device sync) and every call is projection + one gather; the per-call random subset (VT:394-399) is drawn
+        on the host and travels through a small ring of pinned buffers - no host/device synchronisation per step."""
+        key = self._ref_version
+        if self._static_flow is None or self._static_flow[0] != key:
+            init_uv = self._project(self.reference_surface_vertices_camera, tri, wgt)
+            u0, v0 = init_uv[0, :, 0], init_uv[0, :, 1]
+            mask = (u0 > 5) & (u0 < self.tactile_img_height) & (v0 > 5) & (v0 < self.tactile_img_width)
+            idx = torch.nonzero(mask).reshape(-1)
+            self._static_flow = (key, init_uv, idx, idx.cpu().numpy())
+            self._sel_ring = [torch.empty(self.num_markers, dtype=torch.int64).pin_memory() for _ in range(8)]
+            self._sel_pos = 0
+        _, init_uv, idx_dev, idx_host = self._static_flow
+        n = idx_host.size
+        if n >= self.num_markers:
+            buf = self._sel_ring[self._sel_pos % len(self._sel_ring)]
+            self._sel_pos += 1
+            buf.numpy()[:] = idx_host[self._rng.choice(n, self.num_markers, replace=False)]
+            sel = buf.to(self.device, non_blocking=True)
+        elif n > 0:  # pad by repeating the last marker (VT:400-405)
+            sel = torch.cat([idx_dev, idx_dev[-1:].expand(self.num_markers - n)])
+        else:
+            self.curr_marker_uv = curr_uv
+            return torch.zeros((curr_uv.shape[0], 2, self.num_markers, 2), dtype=curr_uv.dtype, device=self.device)
+        ret = torch.stack([init_uv.index_select(1, sel), curr_uv.index_select(1, sel)], dim=1)
+        if self.normalize:
+            ret = ret / (self.tactile_img_width / 2) - 1.0
+        self.curr_marker_uv = curr_uv
+        return ret
+
     def gen_marker_flow(self) -> torch.Tensor:
         """(B, 2, num_markers, 2) float64: [initial | current] marker (u, v) pixels (VT:354-413), all envs at once."""
         tri, wgt = self._setup()
-        init_uv = self._project(self.reference_surface_vertices_camera, tri, wgt)
         curr_uv = self._project(self.get_surface_vertices_camera(), tri, wgt)
+        if self._static:
+            return self._gen_marker_flow_static(tri, wgt, curr_uv)
+        init_uv = self._project(self.reference_surface_vertices_camera, tri, wgt)
         # VT:382-387 (sic: u is compared with the image HEIGHT and v with the WIDTH); env 0 decides, like the
         # single-env reference; the reference surface is identical in every env
         u0, v0 = init_uv[0, :, 0], init_uv[0, :, 1]
