@@ -341,6 +341,8 @@ def roofline_leg(rig, markers):
         else:
             bpf = 16 * N         # shade: read deformed gel, write RGB
         avg = ms / cnt
+        if name.startswith("blur_") and cnt > 10 * max(1, B // chunk):
+            frames = B * 10 // cnt  # band levels run over Infinity-Cache-sized sub-ranges of a pass: frames per launch from the launch count
         stages[name] = {"avg_ms": round(avg, 5), "frames_per_launch": frames, "algo_bytes_per_launch": bpf * frames,
                         "GBps": round(bpf * frames / (avg * 1e-3) / 1e9, 1), "launches_per_update": round(cnt / 10, 2)}
     dom = max((k for k in stages if k != "frame_min"), key=lambda k: stages[k]["avg_ms"] * stages[k]["launches_per_update"])

@@ -34,12 +34,19 @@ def collect(d, counter):
                 if sub in row["Kernel_Name"]:
                     acc[stage] += float(row["Counter_Value"]); cnt[stage] += 1
                     break
-    return {k: acc[k] / cnt[k] for k in acc}
+    # Per-FRAME counter value.  The band levels may be launched over sub-ranges of a pass (Infinity-Cache-sized pieces), so their
+    # totals are divided by the frames the run rendered = tail launches x frames per tail launch; every other kernel processes
+    # FRAMES frames per dispatch.
+    n_pass = cnt.get("tail_fused", 0) + cnt.get("tail_fused_tiled", 0)  # every pass of FRAMES frames ends in exactly one tail launch
+    out = {}
+    for k in acc:
+        out[k] = acc[k] / (n_pass * FRAMES) if (n_pass > 0 and k.startswith("blur_")) else acc[k] / cnt[k] / FRAMES
+    return out, dict(cnt)
 
 
-fetch, write = collect(sys.argv[1], "FETCH_SIZE"), collect(sys.argv[2], "WRITE_SIZE")
+(fetch, fcnt), (write, wcnt) = collect(sys.argv[1], "FETCH_SIZE"), collect(sys.argv[2], "WRITE_SIZE")
 keys = sorted(set(fetch) | set(write))
-per_frame = {k: int((2 * fetch.get(k, 0) + write.get(k, 0)) * 1024 / FRAMES) for k in keys}
+per_frame = {k: int((2 * fetch.get(k, 0) + write.get(k, 0)) * 1024) for k in keys}
 path = [k for k in keys if k.startswith("blur_") or k == "tail_fused"]
 out = {
     "_provenance": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (two separate passes) on `python3 bench.py --steps 3 --warmup 2 "
@@ -48,11 +55,12 @@ out = {
                    "streaming reads, MI355X_MICROARCH.md HBM section; check: the depth -> height-map pass reads 4 B/px and its doubled "
                    "counter says so).  Values are HBM bytes PER FRAME; bench.py multiplies by the frames per launch.",
     "measured_at_commit": COMMIT,
-    "frames_per_launch_measured": FRAMES, "resolution": [W, H],
+    "frames_per_tail_launch_measured": FRAMES, "resolution": [W, H],
     "per_frame_bytes": per_frame,
     "taxim_path_sum_per_frame": sum(per_frame[k] for k in path),
     "compulsory_per_frame_16B_per_px": 16 * H * W,
-    "raw_kib_per_launch": {k: {"FETCH_SIZE": int(fetch.get(k, 0)), "WRITE_SIZE": int(write.get(k, 0))} for k in keys},
+    "raw_kib_per_frame": {k: {"FETCH_SIZE": round(fetch.get(k, 0), 2), "WRITE_SIZE": round(write.get(k, 0), 2)} for k in keys},
+    "dispatches": {k: {"fetch_pass": fcnt.get(k, 0), "write_pass": wcnt.get(k, 0)} for k in keys},
 }
 json.dump(out, open(sys.argv[3], "w"), indent=1)
 print(json.dumps({k: out[k] for k in ("per_frame_bytes", "taxim_path_sum_per_frame", "compulsory_per_frame_16B_per_px")}, indent=1))

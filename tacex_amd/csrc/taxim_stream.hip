@@ -241,12 +241,23 @@ __global__ __launch_bounds__(64 * kStreamWaves, stream_min_waves(ROLE)) void tax
     __builtin_amdgcn_global_load_lds((gptr_t)(zin + ro), (lptr_t)dst, 12, 0, 0);
     if constexpr (LEVELS) __builtin_amdgcn_global_load_lds((gptr_t)(hm + ro), (lptr_t)(dst + kRowArr), 12, 0, 0);
   };
+  // interior lanes read back their own 16 bytes (conflict-free b128); only the few lanes with a pixel outside the image pick
+  // their mirrored columns one by one (scattered b32 reads at a 4-dword lane stride would be 4-way bank conflicts for everyone)
+  const bool border = xg[0] < 0 || xg[PX - 1] >= W;
   auto read_row = [&](int slot, float (&zz)[PX], float (&hh)[PX]) {
     const float* src = rowbuf + slot * kRowSlot;
+    const v4f zq = *reinterpret_cast<const v4f*>(src + lane * 4);
+    zz[0] = zq.x; zz[1] = zq.y; zz[2] = zq.z;
+    if constexpr (LEVELS) {
+      const v4f hq = *reinterpret_cast<const v4f*>(src + kRowArr + lane * 4);
+      hh[0] = hq.x; hh[1] = hq.y; hh[2] = hq.z;
+    }
+    if (border) {
 #pragma unroll
-    for (int i = 0; i < PX; ++i) {
-      zz[i] = src[ridx[i]];
-      if constexpr (LEVELS) hh[i] = src[kRowArr + ridx[i]];
+      for (int i = 0; i < PX; ++i) {
+        zz[i] = src[ridx[i]];
+        if constexpr (LEVELS) hh[i] = src[kRowArr + ridx[i]];
+      }
     }
   };
 
