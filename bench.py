@@ -62,6 +62,7 @@ def parse():
                     help="payload of the per-step observation all-gather (obs32 = 32x32x3 RGB + markers + indentation)")
     ap.add_argument("--obs-dtype", choices=["u8", "f32"], default="u8",
                     help="dtype of the 32x32x3 policy image in the gather payload (u8 = what a CNN policy consumes)")
+    ap.add_argument("--no-sensor-streams", action="store_true", help="update the sensors of an env back to back on one stream")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-sweep", action="store_true", help="skip the C2 / 512-shard / C4 / C5 sweep (N = 1 only)")
@@ -104,12 +105,13 @@ def build_sensor(num_envs, H, W, markers, device, obs_res=None, obs_dtype="float
 class Rig:
     """`n_sensors` GelSightSensors over one env shard + the packed observation; step() = one update of all of them."""
 
-    def __init__(self, B, H, W, n_sensors, markers, dev, world, seed, gather="obs32", obs_dtype="u8", fem=None):
+    def __init__(self, B, H, W, n_sensors, markers, dev, world, seed, gather="obs32", obs_dtype="u8", fem=None, sensor_streams=True):
         from tacex_amd.env_shard import ObservationGather
         from tacex_amd.utils.synthetic import synthetic_depth_maps
 
         self.B, self.H, self.W, self.n, self.markers, self.fem = B, H, W, n_sensors, markers, fem
         self.sensors, self.theta = [], torch.zeros(B, device=dev)
+        self.streams = [torch.cuda.Stream(device=dev) for _ in range(n_sensors)] if (sensor_streams and n_sensors > 1) else []
         for k in range(n_sensors):
             s = build_sensor(B, H, W, markers, dev, obs_res=(32, 32) if gather == "obs32" else None,
                              obs_dtype="uint8" if obs_dtype == "u8" else "float32",
@@ -135,16 +137,25 @@ class Rig:
         if self.fem is not None:
             self.fem.step(i)
         vals = {}
+        cur = torch.cuda.current_stream()
         for k, s in enumerate(self.sensors):
-            if self.markers and self.fem is None:
-                s.marker_motion_simulator.set_indenter_yaw(self.theta)
-            s.update(dt=0.01, force_recompute=True)
+            # the sensors of an env are independent objects (left / right finger): each updates on its own HIP stream, so the
+            # drain of one sensor's kernels overlaps the next one's launch sequence; the packing kernel waits for all of them
+            st = self.streams[k] if self.streams else cur
+            if self.streams:
+                st.wait_stream(cur)
+            with torch.cuda.stream(st):
+                if self.markers and self.fem is None:
+                    s.marker_motion_simulator.set_indenter_yaw(self.theta)
+                s.update(dt=0.01, force_recompute=True)
             if self.obs is not None:
                 out = s._data.output
                 vals[f"rgb32_{k}"] = out["tactile_rgb_obs"]  # produced inside the render pass (fused into the tail kernel)
                 vals[f"indent_{k}"] = s.indentation_depth
                 if self.markers or self.fem is not None:
                     vals[f"markers_{k}"] = out["marker_motion"]
+        for st in self.streams:
+            cur.wait_stream(st)
         if self.obs is not None:
             self.obs.pack_all(vals)
             self.obs.gather_async()  # overlaps the next step's rendering; ordered before the next pack / the final sync
@@ -485,7 +496,7 @@ def main():
 
     log(f"headline: {B} envs x {args.sensors} sensors, {W}x{H}, rank {shard.rank}/{shard.world_size}")
     rig = Rig(B, H, W, args.sensors, markers, dev, shard.world_size, seed=1 + shard.rank, gather=args.gather,
-              obs_dtype=args.obs_dtype)
+              obs_dtype=args.obs_dtype, sensor_streams=not args.no_sensor_streams)
     elapsed = rig.timed(args.steps, args.warmup, barrier)
     log(f"headline timed: {elapsed / args.steps * 1e3:.3f} ms/step")
     if use_dist:
@@ -525,7 +536,8 @@ def main():
                 "envs_per_gpu": args.envs_per_gpu, "sensors_per_env": args.sensors, "frames_per_step": frames_per_step,
                 "resolution": [W, H], "markers": markers,
                 "two_sensor_batching": "two independent GelSightSensor objects (gsmini_left / gsmini_right as factory_env_cfg.py:192-213), "
-                                       "each one launch sequence over its 1024 envs on the same stream",
+                                       f"each one launch sequence over its {args.envs_per_gpu} envs"
+                                       + (", one HIP stream per sensor (joined before the observation is packed)" if rig.streams else " on the same stream"),
                 "observation_gather": None if obs_bytes is None else {
                     "payload": f"per sensor: 32x32x3 {args.obs_dtype} RGB (antialiased, produced in the render pass) + f32 indentation"
                                + (" + f32 markers (2,99,2)" if markers else ""),
