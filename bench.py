@@ -510,6 +510,7 @@ def main():
     if not args.no_roofline and shard.rank == 0:
         roofline = roofline_leg(rig, markers)
     obs_bytes = None if rig.obs is None else rig.obs.payload_bytes()
+    sensor_streams_on = bool(rig.streams)
     del rig
     torch.cuda.empty_cache()
 
@@ -537,7 +538,7 @@ def main():
                 "resolution": [W, H], "markers": markers,
                 "two_sensor_batching": "two independent GelSightSensor objects (gsmini_left / gsmini_right as factory_env_cfg.py:192-213), "
                                        f"each one launch sequence over its {args.envs_per_gpu} envs"
-                                       + (", one HIP stream per sensor (joined before the observation is packed)" if rig.streams else " on the same stream"),
+                                       + (", one HIP stream per sensor (joined before the observation is packed)" if sensor_streams_on else " on the same stream"),
                 "observation_gather": None if obs_bytes is None else {
                     "payload": f"per sensor: 32x32x3 {args.obs_dtype} RGB (antialiased, produced in the render pass) + f32 indentation"
                                + (" + f32 markers (2,99,2)" if markers else ""),
