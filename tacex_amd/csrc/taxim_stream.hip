@@ -113,12 +113,11 @@ constexpr size_t kStreamLdsShared = (size_t)kStreamPolyMaxBins * kStreamPolyPitc
 
 enum { kStreamFused = 0, kStreamLevels = 1, kStreamShade = 2 };
 
-// ROLE: kStreamFused  - levels + shading in one kernel (one wave keeps ~240 registers: two waves per SIMD)
+// ROLE: kStreamFused  - levels + shading in one kernel (one wave keeps ~240 registers: two waves per SIMD) - the default
 //       kStreamLevels - levels only: writes the last level (B,H,W) + the FOTS by-products; lean (four waves per SIMD)
 //       kStreamShade  - shading only (KS empty): reads the last level, writes RGB + observation partial sums
-// The split pair is the default: the fused kernel is latency-bound at two waves per SIMD (54 % of its wave cycles in
-// s_waitcnt with the table gathers, LDS staging and stores of the shading serialised behind the levels of the same wave),
-// and splitting costs 8 B/px of extra traffic (the last level is written and re-read once) for ~2.5x the speed.
+// The split pair (TACEX_STREAM_SPLIT=1) is an A/B path: it costs 8 B/px of extra traffic (the last level is written and re-read
+// once) and measured slower than the fused kernel (70 + 230 us vs 215 us per 256 frames).
 template <int ROLE, int... KS>
 struct StreamCfg {
   static constexpr int NL = sizeof...(KS);
