@@ -32,7 +32,7 @@ extern "C" {
 #endif
 
 #define TACEX_MAX_LEVELS 8
-#define TACEX_ABI_VERSION 3
+#define TACEX_ABI_VERSION 4
 
 typedef struct tacex_taxim_ctx tacex_taxim_ctx;
 typedef struct tacex_fots_ctx tacex_fots_ctx;
@@ -80,11 +80,16 @@ size_t tacex_taxim_workspace_bytes(const tacex_taxim_ctx* ctx, int num_frames);
  *                d = max(frame_min/1000 - gelpad_to_camera_min_distance, 0)            (B,)  [nullable]
  *   cam_u8     = uint8(((hm_mm - near_clip_m*1000) / (far_clip_m*1000)) * 255)  (sic)  (B,Hc,Wc) [nullable]
  * The clip range is passed as DOUBLES: the reference multiplies the Python doubles by 1000 and torch rounds the product once
- * to float32 (GS:573-574), so cam_u8 is bit-exact.  depth_m_dev may alias hm_mm_dev. */
+ * to float32 (GS:573-574), so cam_u8 is bit-exact.  depth_m_dev may alias hm_mm_dev.
+ *   frame_rows (B,2) int32 [nullable, needs indent_mm]: first / last frame row holding a pixel below the press plane,
+ *                i.e. with S = (hm - frame_min) - indent < 0 (TT:441) - (height, -1) when there is none.  By-product of the
+ *                same pass (per-row minima); the render uses it to skip pyramid bands that cannot be non-zero
+ *                (tacex_taxim_set_frame_rows + TACEX_FLAG_HAVE_FRAME_ROWS). */
 int tacex_height_map_from_depth(const float* depth_m_dev, double near_clip_m, double far_clip_m,
                                 float gelpad_height_m, float gelpad_to_camera_min_distance_m,
                                 float* hm_mm_dev, float* frame_min_dev, float* indent_mm_dev,
-                                uint8_t* cam_u8_dev, int num_frames, int height, int width, void* stream);
+                                uint8_t* cam_u8_dev, int32_t* frame_rows_dev, int num_frames, int height, int width,
+                                void* stream);
 
 /* Height-map SOURCE: rasterise one analytic indenter per env into the height map (mm), with the per-frame
  * minimum and the indentation depth of TS:115-131 in the same pass.  Stands in for the TiledCamera depth render
@@ -97,10 +102,12 @@ int tacex_height_map_from_indenters(const float* indenters_dev, float pixmm, flo
                                     float* frame_min_dev, float* indent_mm_dev, int num_frames, int height, int width,
                                     void* stream);
 
-/* TS:115-131 on an existing mm height map. frame_min_dev (B,) is also written (re-used by the render). */
+/* TS:115-131 on an existing mm height map. frame_min_dev (B,) is also written (re-used by the render);
+ * frame_rows_dev (B,2) int32 nullable: contact row range as in tacex_height_map_from_depth. */
 int tacex_indentation_depth(const float* hm_mm_dev, float gelpad_height_m,
                             float gelpad_to_camera_min_distance_m, float* frame_min_dev,
-                            float* indent_mm_dev, int num_frames, int height, int width, void* stream);
+                            float* indent_mm_dev, int32_t* frame_rows_dev, int num_frames, int height, int width,
+                            void* stream);
 
 /* Shadow branch tables (TaximTorch.__init__ shadow calibration TT:96-126 + the per-shape parameters of TT:260-346).
  * Optional: only needed before a render with TACEX_FLAG_WITH_SHADOW. Host pointers, copied once. */
@@ -139,6 +146,15 @@ int tacex_taxim_shadow_rays(tacex_taxim_ctx* ctx, const float* z_dev, const uint
 #define TACEX_FLAG_HAVE_FRAME_MIN 2u /* frame_min_dev already holds min(hm) per frame (skip that pass) */
 #define TACEX_FLAG_OBS_U8         8u /* render_obs only: obs_out_dev is uint8 (B,obs_h,obs_w,3) = floor(255 x + 0.5) */
 #define TACEX_FLAG_WITH_SHADOW    4u /* render only: shadow branch TT:260-346 (needs tacex_taxim_set_shadow + extra scratch) */
+#define TACEX_FLAG_HAVE_FRAME_ROWS 16u /* with HAVE_FRAME_MIN: the buffer of tacex_taxim_set_frame_rows describes THESE height maps */
+
+/* Contact row ranges of the height maps handed to the render (written by tacex_height_map_from_depth /
+ * tacex_indentation_depth into a caller-owned (capacity_frames, 2) int32 buffer).  The deformed gel of TT:443-473 is exactly
+ * zero on every pyramid band whose input window lies outside the range (zero gel map only): those bands are stored as zeros
+ * without reading or multiplying anything.  Used only by calls that pass TACEX_FLAG_HAVE_FRAME_MIN | TACEX_FLAG_HAVE_FRAME_ROWS
+ * with num_frames <= capacity_frames; without HAVE_FRAME_MIN the library computes the ranges in its own minimum pass.
+ * nullptr disables. */
+int tacex_taxim_set_frame_rows(tacex_taxim_ctx* ctx, const int32_t* frame_rows_dev, int capacity_frames);
 
 /* TaximSimulator.optical_simulation (TS:80-113) -> Taxim.render_direct (TI:153-163) ->
  * TaximTorch._render_impl / __render no-shadow branch (TT:174-258), output already NHWC (TS:109-111).

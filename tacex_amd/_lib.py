@@ -11,11 +11,12 @@ from pathlib import Path
 from ._build import LIB, build_library
 
 MAX_LEVELS = 8
-ABI_VERSION = 3  # TACEX_ABI_VERSION of include/tacex_hip.h; bumped whenever a signature or struct layout changes
+ABI_VERSION = 4  # TACEX_ABI_VERSION of include/tacex_hip.h; bumped whenever a signature or struct layout changes
 FLAG_NO_SHIFT = 1
 FLAG_HAVE_FRAME_MIN = 2
 FLAG_WITH_SHADOW = 4
 FLAG_OBS_U8 = 8
+FLAG_HAVE_FRAME_ROWS = 16
 
 c_float_p = C.POINTER(C.c_float)
 c_int32_p = C.POINTER(C.c_int32)
@@ -97,8 +98,9 @@ SIGNATURES = {
     "tacex_taxim_set_shadow": (_i, [_vp, C.POINTER(ShadowParams)]),
     "tacex_taxim_shadow_workspace_bytes": (_sz, [_vp, _i]),
     "tacex_taxim_shadow_rays": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _vp]),
-    "tacex_height_map_from_depth": (_i, [_vp, _d, _d, _f, _f, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
-    "tacex_indentation_depth": (_i, [_vp, _f, _f, _vp, _vp, _i, _i, _i, _vp]),
+    "tacex_height_map_from_depth": (_i, [_vp, _d, _d, _f, _f, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
+    "tacex_indentation_depth": (_i, [_vp, _f, _f, _vp, _vp, _vp, _i, _i, _i, _vp]),
+    "tacex_taxim_set_frame_rows": (_i, [_vp, _vp, _i]),
     "tacex_taxim_render": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _u, _vp]),
     "tacex_taxim_render_obs": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _u, _vp]),
     "tacex_taxim_deform": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _u, _vp]),

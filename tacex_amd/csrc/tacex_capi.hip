@@ -68,6 +68,7 @@ struct tacex_taxim_ctx {
   const int* mk_x = nullptr; const int* mk_id = nullptr;
   std::vector<int> mk_x_h, mk_id_h;
   int mk_version = 0;
+  const int* frame_rows = nullptr; int frame_rows_cap = 0;  // caller-owned contact row ranges (tacex_taxim_set_frame_rows)
   std::vector<void*> allocs;
   // profiling
   bool profiling = false;
@@ -425,7 +426,13 @@ size_t tacex_taxim_workspace_bytes(const tacex_taxim_ctx* c, int B) {
   if (!c || B <= 0) return 0;
   const size_t img = align_up((size_t)B * c->H * c->W * sizeof(float), 256);
   const size_t vec = align_up((size_t)B * sizeof(float), 256);
-  return 3 * img + 3 * vec;  // Z ping, Z pong, generic-path temp; shift_a, shift_b, pdepth
+  return 3 * img + 3 * vec + align_up((size_t)B * 2 * sizeof(int), 256);  // Z ping, Z pong, generic-path temp; shift_a, shift_b, pdepth; contact rows
+}
+// where the library keeps the contact row ranges it computes itself (behind everything a chunk of <= B frames lays out)
+static int* workspace_rows(const tacex_taxim_ctx* c, void* ws, int B) {
+  const size_t img = align_up((size_t)B * c->H * c->W * sizeof(float), 256);
+  const size_t vec = align_up((size_t)B * sizeof(float), 256);
+  return reinterpret_cast<int*>(static_cast<char*>(ws) + 3 * img + 3 * vec);
 }
 
 int tacex_taxim_set_profiling(tacex_taxim_ctx* c, int enabled) {
@@ -479,9 +486,17 @@ struct StageTimer {
 
 int tacex_height_map_from_depth(const float* depth_m, double near_m, double far_m, float gelpad_h,
                                 float gelpad_dmin, float* hm_mm, float* frame_min, float* indent_mm,
-                                uint8_t* cam_u8, int B, int H, int W, void* stream) {
+                                uint8_t* cam_u8, int32_t* frame_rows, int B, int H, int W, void* stream) {
   if (!depth_m || !hm_mm || !frame_min) { set_error("tacex_height_map_from_depth: null buffer"); return 2; }
+  if (frame_rows && !indent_mm) { set_error("tacex_height_map_from_depth: frame_rows needs indent_mm"); return 2; }
   if (B <= 0) return 0;
+  if (frame_rows && frame_rows_supported(H, W)) {
+    HIP_TRY(run_frame_rows(depth_m, true, hm_mm, frame_min, indent_mm, cam_u8, nullptr, frame_rows, B, H, W, (float)(near_m * 1000.0),
+                           (float)far_m, (float)(far_m * 1000.0), gelpad_h, gelpad_dmin, (hipStream_t)stream),
+            "frame_rows_kernel<depth>");
+    return 0;
+  }
+  if (frame_rows) HIP_TRY(run_fill_rows(frame_rows, B, H, (hipStream_t)stream), "fill_rows_kernel");
   // GS:573-574: `clipping_range[i] * 1000` is a Python double product; torch rounds it ONCE to float32 as the scalar operand
   HIP_TRY(run_frame_min(depth_m, true, hm_mm, frame_min, indent_mm, cam_u8, B, H * W, (float)(near_m * 1000.0), (float)far_m,
                         (float)(far_m * 1000.0), gelpad_h, gelpad_dmin, (hipStream_t)stream),
@@ -502,9 +517,16 @@ int tacex_height_map_from_indenters(const float* indenters, float pixmm, float g
 }
 
 int tacex_indentation_depth(const float* hm_mm, float gelpad_h, float gelpad_dmin, float* frame_min,
-                            float* indent_mm, int B, int H, int W, void* stream) {
+                            float* indent_mm, int32_t* frame_rows, int B, int H, int W, void* stream) {
   if (!hm_mm || !frame_min || !indent_mm) { set_error("tacex_indentation_depth: null buffer"); return 2; }
   if (B <= 0) return 0;
+  if (frame_rows && frame_rows_supported(H, W)) {
+    HIP_TRY(run_frame_rows(hm_mm, false, nullptr, frame_min, indent_mm, nullptr, nullptr, frame_rows, B, H, W, 0.f, 0.f, 0.f, gelpad_h,
+                           gelpad_dmin, (hipStream_t)stream),
+            "frame_rows_kernel");
+    return 0;
+  }
+  if (frame_rows) HIP_TRY(run_fill_rows(frame_rows, B, H, (hipStream_t)stream), "fill_rows_kernel");
   HIP_TRY(run_frame_min(hm_mm, false, nullptr, frame_min, indent_mm, nullptr, B, H * W, 0.f, 0.f, 0.f, gelpad_h,
                         gelpad_dmin, (hipStream_t)stream),
           "frame_min_kernel");
@@ -513,7 +535,8 @@ int tacex_indentation_depth(const float* hm_mm, float gelpad_h, float gelpad_dmi
 
 static int pipeline_chunk(tacex_taxim_ctx* c, const float* hm, const float* press, float* frame_min, float* rgb,
                           float* z_out, uint8_t* mask_out, void* ws, int B, unsigned flags, hipStream_t st,
-                          float* obs_h, void* obs, int obs_hh, int obs_w, FotsReduce* fots_part, int frame0);
+                          float* obs_h, void* obs, int obs_hh, int obs_w, FotsReduce* fots_part, int frame0,
+                          const int* rows = nullptr);
 
 // Frames per pass of the pipeline.  With the LDS-tiled tail, large shards are walked in chunks whose level buffers (Z ping /
 // pong, 4 B/px each) plus height map stay resident in the 256 MB Infinity Cache (measured in round 1 at 2048 frames: k=33
@@ -555,20 +578,38 @@ static int pipeline_impl(tacex_taxim_ctx* c, const float* hm, const float* press
   const int cf = chunk_frames(c, B);
   FotsReduce* fp = (c->fots_part && B <= c->fots_cap) ? c->fots_part : nullptr;
   const size_t fper = tail_tiles_per_frame(c->H, c->W) * kTailWavesPerTile;
-  if (cf >= B) return pipeline_chunk(c, hm, press, frame_min, rgb, z_out, mask_out, ws, B, flags, st, obs_h, obs, obs_hh, obs_w, fp, B <= c->fots_pix_cap ? 0 : -1);
-  if (!(flags & TACEX_FLAG_HAVE_FRAME_MIN)) {  // one reduction pass over the whole shard, then chunks
+  // Contact row ranges (zero-band skipping of the band levels, TACEX_BAND_SKIP=0 disables): from the caller's buffer when the
+  // minimum came with them, else from the library's own minimum pass (kept behind the chunk layouts of the workspace)
+  static const bool band_skip = !(getenv("TACEX_BAND_SKIP") && atoi(getenv("TACEX_BAND_SKIP")) == 0);
+  const bool can_rows = band_skip && press && !(flags & TACEX_FLAG_NO_SHIFT) && frame_rows_supported(c->H, c->W);
+  const int* rows = nullptr;
+  if (flags & TACEX_FLAG_HAVE_FRAME_MIN) {
+    if (can_rows && (flags & TACEX_FLAG_HAVE_FRAME_ROWS) && c->frame_rows && B <= c->frame_rows_cap) rows = c->frame_rows;
+  } else {  // one reduction pass over the whole shard
     StageTimer t(c, st, 0);
-    HIP_TRY(run_frame_min(hm, false, nullptr, frame_min, nullptr, nullptr, B, c->H * c->W, 0.f, 0.f, 0.f, 0.f, 0.f, st),
-            "frame_min_kernel");
+    if (can_rows) {
+      int* wr = workspace_rows(c, ws, B);
+      HIP_TRY(run_frame_rows(hm, false, nullptr, frame_min, nullptr, nullptr, press, wr, B, c->H, c->W, 0.f, 0.f, 0.f, 0.f, 0.f, st),
+              "frame_rows_kernel");
+      rows = wr;
+    } else {
+      HIP_TRY(run_frame_min(hm, false, nullptr, frame_min, nullptr, nullptr, B, c->H * c->W, 0.f, 0.f, 0.f, 0.f, 0.f, st),
+              "frame_min_kernel");
+    }
+    flags |= TACEX_FLAG_HAVE_FRAME_MIN;
   }
+  if (cf >= B)
+    return pipeline_chunk(c, hm, press, frame_min, rgb, z_out, mask_out, ws, B, flags, st, obs_h, obs, obs_hh, obs_w, fp,
+                          B <= c->fots_pix_cap ? 0 : -1, rows);
   const size_t npix = (size_t)c->H * c->W;
   for (int b0 = 0; b0 < B; b0 += cf) {
     const int n = B - b0 < cf ? B - b0 : cf;
     int rc = pipeline_chunk(c, hm + b0 * npix, press ? press + b0 : nullptr, frame_min + b0, rgb ? rgb + b0 * npix * 3 : nullptr,
                             z_out ? z_out + b0 * npix : nullptr, mask_out ? mask_out + b0 * npix : nullptr, ws, n,
-                            flags | TACEX_FLAG_HAVE_FRAME_MIN, st, obs_h,
+                            flags, st, obs_h,
                             obs ? static_cast<char*>(obs) + (size_t)b0 * obs_hh * obs_w * 3 * ((flags & TACEX_FLAG_OBS_U8) ? 1 : 4) : nullptr,
-                            obs_hh, obs_w, fp ? fp + (size_t)b0 * fper : nullptr, B <= c->fots_pix_cap ? b0 : -1);
+                            obs_hh, obs_w, fp ? fp + (size_t)b0 * fper : nullptr, B <= c->fots_pix_cap ? b0 : -1,
+                            rows ? rows + 2 * b0 : nullptr);
     if (rc) return rc;
   }
   return 0;
@@ -585,7 +626,8 @@ static int resize_obs(tacex_taxim_ctx* c, const float* rgb, float* scratch, void
 
 static int pipeline_chunk(tacex_taxim_ctx* c, const float* hm, const float* press, float* frame_min, float* rgb,
                           float* z_out, uint8_t* mask_out, void* ws, int B, unsigned flags, hipStream_t st,
-                          float* obs_h, void* obs, int obs_hh, int obs_w, FotsReduce* fots_part, int frame0) {
+                          float* obs_h, void* obs, int obs_hh, int obs_w, FotsReduce* fots_part, int frame0,
+                          const int* rows) {
   const bool obs_u8 = (flags & TACEX_FLAG_OBS_U8) != 0;
   const size_t img = align_up((size_t)B * c->H * c->W * sizeof(float), 256);
   const size_t vec = align_up((size_t)B * sizeof(float), 256);
@@ -621,14 +663,16 @@ static int pipeline_chunk(tacex_taxim_ctx* c, const float* hm, const float* pres
   for (int b0 = 0; b0 < B; b0 += lcf) {
     const int nb = B - b0 < lcf ? B - b0 : lcf;
     src = nullptr;
+    int grow = 0;  // rows by which the non-zero range of the level's input exceeds the contact rows
     for (int l = 0; l < n_band; ++l) {
       const bool last = l == c->n_levels - 1;
       float* dst = (last && z_out) ? z_out : zbuf[l & 1];
       StageTimer t(c, st, 1 + l);
       HIP_TRY(run_blur_level(c->levels[l], src ? src + b0 * npix : nullptr, hm + b0 * npix, c->gel_dev, sa + b0, sb + b0, pd + b0,
                              dst + b0 * npix, tmp, last && mask_out ? mask_out + b0 * npix : nullptr, nb,
-                             c->H, c->W, c->contact_scale, last ? 0 : 1, l == 0, st),
+                             c->H, c->W, c->contact_scale, last ? 0 : 1, l == 0, st, rows ? rows + 2 * b0 : nullptr, grow),
               "blur level");
+      grow += (c->levels[l].kh - 1) / 2;
       src = dst;
     }
   }
@@ -728,6 +772,13 @@ int tacex_taxim_render(tacex_taxim_ctx* c, const float* hm, const float* press, 
     return 0;
   }
   return pipeline_impl(c, hm, press, frame_min, rgb, z_out, mask_out, ws, B, flags, (hipStream_t)stream);
+}
+
+int tacex_taxim_set_frame_rows(tacex_taxim_ctx* c, const int32_t* frame_rows, int capacity_frames) {
+  if (!c) { set_error("tacex_taxim_set_frame_rows: null context"); return 2; }
+  c->frame_rows = (frame_rows && capacity_frames > 0) ? frame_rows : nullptr;
+  c->frame_rows_cap = c->frame_rows ? capacity_frames : 0;
+  return 0;
 }
 
 int tacex_taxim_set_fots_taps(tacex_taxim_ctx* c, const int32_t* marker_x, const int32_t* marker_y, int n_markers,

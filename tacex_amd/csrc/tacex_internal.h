@@ -51,7 +51,12 @@ hipError_t run_press_depth(const float* fmin, const float* press, float* sa, flo
 hipError_t run_blur_level(const LevelDesc& lv, const float* src, const float* hm, const float* gel,
                           const float* sa, const float* sb, const float* pd, float* dst, float* tmp,
                           uint8_t* mask_out, int B, int H, int W, float contact_scale, int restore,
-                          bool first, hipStream_t st);
+                          bool first, hipStream_t st, const int* rows_ext = nullptr, int ext_grow = 0);
+bool frame_rows_supported(int H, int W);
+hipError_t run_fill_rows(int* rows, int B, int H, hipStream_t st);
+hipError_t run_frame_rows(const float* in, bool from_depth, float* hm_out, float* fmin, float* indent, uint8_t* cam_u8,
+                          const float* press_in, int* rows_out, int B, int H, int W, float near_mm, float far_m, float far_mm,
+                          float gelpad_h, float gelpad_dmin, hipStream_t st);
 hipError_t run_shade(const ShadeParams& sp, const float* z, float* rgb, uint8_t* idx_out, int B,
                      hipStream_t st);
 hipError_t run_resize_aa(const float* src, int sh, int sw, float* dst, int dh, int dw, int B, int C, float* tmp,

@@ -93,6 +93,80 @@ __global__ __launch_bounds__(1024) void frame_min_kernel(
 }
 
 // ------------------------------------------------------------------------------------------------
+// K1 with the CONTACT ROW RANGE of every frame as a by-product (W % 4 == 0): the same pass as frame_min_kernel, walked row
+// by row (wave w takes rows w, w + 16, ...; a row is one or more float4 loads per lane), so that the per-row minima are
+// available once the frame minimum is known.  S = (hm - min) - press is monotone in hm, hence a row holds a pixel with S < 0 -
+// a non-zero input J = min(S, 0) of the pyramid (TT:441-454, zero gel map) - exactly when (rowmin - min) - press < 0, evaluated
+// with the kernels' own expression.  rows_out[2b], rows_out[2b + 1] = first / last such row, (H, -1) when the frame has no
+// contact.  The band kernels use the range to skip bands whose whole input window is zero (their output is exactly zero).
+// press: indentation depth computed here (indent_out != nullptr, TS:116-129) or given per frame (press_in).
+// ------------------------------------------------------------------------------------------------
+constexpr int kFrameRowsMaxH = 2048;
+template <bool FROM_DEPTH>
+__global__ __launch_bounds__(1024) void frame_rows_kernel(
+    const float* __restrict__ in, float* __restrict__ hm_out, float* __restrict__ fmin_out,
+    float* __restrict__ indent_out, uint8_t* __restrict__ cam_u8, const float* __restrict__ press_in,
+    int* __restrict__ rows_out, int H, int W, float nmm, float far_m, float fmm, float gelpad_h, float gelpad_dmin) {
+  __shared__ float rowmin[kFrameRowsMaxH];
+  __shared__ float bc[2];
+  const int b = blockIdx.x;
+  const size_t fo = (size_t)b * H * W;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  const int w4 = W >> 2;
+  for (int r = wave; r < H; r += nw) {
+    float m = INFINITY;
+    const size_t ro = fo + (size_t)r * W;
+    for (int c = lane; c < w4; c += 64) {
+      v4f v = reinterpret_cast<const v4f*>(in + ro)[c];
+      if (FROM_DEPTH) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          float d = v[k];
+          d = isinf(d) ? far_m : d;  // GS:585-588
+          v[k] = d * 1000.0f;        // GS:590
+        }
+        reinterpret_cast<v4f*>(hm_out + ro)[c] = v;
+        if (cam_u8) {  // GS:573-575 (see frame_min_kernel)
+          uchar4 u;
+          u.x = (uint8_t)(((v[0] - nmm) / fmm) * 255.0f);
+          u.y = (uint8_t)(((v[1] - nmm) / fmm) * 255.0f);
+          u.z = (uint8_t)(((v[2] - nmm) / fmm) * 255.0f);
+          u.w = (uint8_t)(((v[3] - nmm) / fmm) * 255.0f);
+          reinterpret_cast<uchar4*>(cam_u8 + ro)[c] = u;
+        }
+      }
+      m = fminf(m, fminf(fminf(v[0], v[1]), fminf(v[2], v[3])));
+    }
+    m = wave_min(m);
+    if (lane == 0) rowmin[r] = m;
+  }
+  __syncthreads();
+  if (wave == 0) {
+    float m = INFINITY;
+    for (int r = lane; r < H; r += 64) m = fminf(m, rowmin[r]);
+    m = wave_min(m);
+    float press = 0.0f;
+    if (indent_out) {  // TS:116-129
+      float d = m / 1000.0f - gelpad_dmin;
+      d = d < 0.0f ? 0.0f : d;
+      press = d <= gelpad_h ? (gelpad_h - d) * 1000.0f : 0.0f;
+    } else if (press_in) {
+      press = press_in[b];
+    }
+    int lo = H, hi = -1;
+    for (int r = lane; r < H; r += 64)
+      if (((rowmin[r] - m) - press) < 0.0f) { lo = min(lo, r); hi = max(hi, r); }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { lo = min(lo, __shfl_xor(lo, o, 64)); hi = max(hi, __shfl_xor(hi, o, 64)); }
+    if (lane == 0) {
+      fmin_out[b] = m;
+      if (indent_out) indent_out[b] = press;
+      rows_out[2 * b] = lo; rows_out[2 * b + 1] = hi;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // K0 (height-map source): rasterise one analytic indenter per env straight into the height map, with the
 // per-frame minimum and the indentation depth in the same pass - the input-side twin of the path.  It stands in for the
 // TiledCamera depth render (GS:229-263, 581-593) when the contact geometry is a primitive: 4 B/px written, nothing read.
@@ -812,6 +886,29 @@ static hipError_t dispatch_band(int k, bool first, const BlurArgs& a, hipStream_
   }
 }
 
+// min (+ conversion / indentation) AND the contact row range of every frame; false when the geometry is not supported
+// (the caller then runs run_frame_min and treats every row as contact)
+bool frame_rows_supported(int H, int W) { return (W % 4) == 0 && H <= kFrameRowsMaxH; }
+__global__ void fill_rows_kernel(int* rows, int B, int H) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b < B) { rows[2 * b] = 0; rows[2 * b + 1] = H - 1; }
+}
+hipError_t run_fill_rows(int* rows, int B, int H, hipStream_t st) {  // "every row may hold contact" (geometry without a row kernel)
+  hipLaunchKernelGGL(fill_rows_kernel, dim3((B + 255) / 256), dim3(256), 0, st, rows, B, H);
+  return hipGetLastError();
+}
+hipError_t run_frame_rows(const float* in, bool from_depth, float* hm_out, float* fmin, float* indent, uint8_t* cam_u8,
+                          const float* press_in, int* rows_out, int B, int H, int W, float near_mm, float far_m, float far_mm,
+                          float gelpad_h, float gelpad_dmin, hipStream_t st) {
+  if (from_depth)
+    hipLaunchKernelGGL(frame_rows_kernel<true>, dim3(B), dim3(1024), 0, st, in, hm_out, fmin, indent, cam_u8, press_in, rows_out,
+                       H, W, near_mm, far_m, far_mm, gelpad_h, gelpad_dmin);
+  else
+    hipLaunchKernelGGL(frame_rows_kernel<false>, dim3(B), dim3(1024), 0, st, in, hm_out, fmin, indent, cam_u8, press_in, rows_out,
+                       H, W, near_mm, far_m, far_mm, gelpad_h, gelpad_dmin);
+  return hipGetLastError();
+}
+
 hipError_t run_frame_min(const float* in, bool from_depth, float* hm_out, float* fmin, float* indent,
                          uint8_t* cam_u8, int B, int npix, float near_mm, float far_m, float far_mm, float gelpad_h,
                          float gelpad_dmin, hipStream_t st) {
@@ -834,10 +931,11 @@ hipError_t run_press_depth(const float* fmin, const float* press, float* sa, flo
 hipError_t run_blur_level(const LevelDesc& lv, const float* src, const float* hm, const float* gel,
                           const float* sa, const float* sb, const float* pd, float* dst, float* tmp,
                           uint8_t* mask_out, int B, int H, int W, float contact_scale, int restore,
-                          bool first, hipStream_t st) {
+                          bool first, hipStream_t st, const int* rows_ext, int ext_grow) {
   if (lv.same_taps && lv.taps_mfma_dev && mfma_supported(lv.kw, first, H, W)) {
     BlurArgs a{};
     a.src = src; a.hm = hm; a.shift_a = sa; a.shift_b = sb; a.pdepth = pd;
+    a.rows_ext = lv.gel_zero ? rows_ext : nullptr; a.ext_grow = ext_grow;  // zero-band skipping needs J = min(S, 0)
     a.gel = lv.gel_zero ? nullptr : gel;  // all-zero gel map (GelSight Mini): no gel loads - half of level 0's V-pass reads
     a.dst = dst; a.mask_out = mask_out; a.taps = lv.taps_mfma_dev; a.H = H; a.W = W; a.B = B;
     a.contact_scale = contact_scale; a.restore = restore;

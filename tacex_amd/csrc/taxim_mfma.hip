@@ -62,6 +62,24 @@ __global__ __launch_bounds__(640) void blur_mfma_kernel(BlurArgs a) {
   const float* __restrict__ src = FIRST ? a.hm + fo : a.src + fo;
   const float* __restrict__ hm = a.hm + fo;
   const float* __restrict__ gel = a.gel;
+  if constexpr (GZ) {
+    // Zero-band skipping: with a zero gel map the pyramid input J = min(S, 0) is non-zero only on the frame's contact rows
+    // [lo, hi] (frame_rows_kernel), and level l's input only within ext_grow rows of them.  A band whose whole window lies
+    // outside has an exactly zero blur and no contact pixel to restore: store zeros, read nothing.  (Reflect padding cannot
+    // bring a non-zero row in: a mirrored row index -k maps to row k, which the window contains as well.)
+    if (a.rows_ext != nullptr) {
+      const int lo = a.rows_ext[2 * frame] - a.ext_grow, hi = a.rows_ext[2 * frame + 1] + a.ext_grow;
+      if (by0 - R > hi || by0 + TH - 1 + R < lo) {
+        const int w4 = W >> 2;
+        for (int i = threadIdx.x; i < TH * w4; i += blockDim.x) {
+          const int r = i / w4, c = i - r * w4;
+          reinterpret_cast<v4f*>(a.dst + fo + (size_t)(by0 + r) * W)[c] = (v4f)(0.0f);
+          if (a.mask_out) reinterpret_cast<uchar4*>(a.mask_out + fo + (size_t)(by0 + r) * W)[c] = (uchar4){0, 0, 0, 0};
+        }
+        return;
+      }
+    }
+  }
   const float sa = a.shift_a[frame], sb = a.shift_b[frame];
   const int lane = threadIdx.x & 63;
   const int wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // one 64-column super-block per wave

@@ -293,6 +293,7 @@ class GelSightSensor(SensorBase):
         B, H, W = hm.shape
         fmin = sim._frame_min if sim is not None else self._scratch_min()
         indent = sim._indentation_depth if sim is not None else None
+        rows = getattr(sim, "_frame_rows", None) if indent is not None else None  # contact row range per frame (band skipping)
         with torch.cuda.device(hm.device):
             rc = lib.tacex_height_map_from_depth(
                 _lib.ptr(depth), float(near), float(far),
@@ -300,12 +301,15 @@ class GelSightSensor(SensorBase):
                 float(sim.cfg.gelpad_to_camera_min_distance) if sim is not None else 0.0,
                 _lib.ptr(hm), _lib.ptr(fmin), _lib.ptr(indent),
                 _lib.ptr(self._data.output["camera_depth"]) if want_u8 else 0,
+                _lib.ptr(rows) if rows is not None else 0,
                 B, H, W, _lib.current_stream_handle(hm.device))
         _lib.check(rc, "tacex_height_map_from_depth")
         self._height_map_version += 1
         if sim is not None:
             sim._frame_min_version = self._height_map_version
             sim._indent_version = self._height_map_version
+            if rows is not None:
+                sim._frame_rows_version = self._height_map_version
         self._camera_depth_version = self._height_map_version
         return hm
 

@@ -87,6 +87,7 @@ class TaximHip:
         self._ws: dict[tuple[int, int], torch.Tensor] = {}
         self._fmin: dict[tuple[int, int], torch.Tensor] = {}
         self._obs_scratch: dict[tuple[int, int], torch.Tensor] = {}
+        self._frame_rows_key: dict[tuple[int, int], tuple[int, int]] = {}
         self._bg_full = None
         self._lib = _lib.load_library()
 
@@ -211,6 +212,7 @@ class TaximHip:
         z_out: torch.Tensor | None = None,
         mask_out: torch.Tensor | None = None,
         obs_out: torch.Tensor | None = None,
+        frame_rows: torch.Tensor | None = None,
     ) -> torch.Tensor:
         """(..., H, W) mm height map -> (..., 3, H, W) RGB in [0,1] (a channel-first VIEW of an NHWC buffer).
 
@@ -218,7 +220,8 @@ class TaximHip:
         pass (fused into the tail kernel where one exists).
 
         Extra keyword arguments (not in the reference): `out` (B,H,W,3) buffer to render into,
-        `frame_min` (B,) precomputed per-frame minimum, `z_out` / `mask_out` to also return the deformed gel
+        `frame_min` (B,) precomputed per-frame minimum (+ `frame_rows` (B,2) int32, the contact row ranges produced with it),
+        `z_out` / `mask_out` to also return the deformed gel
         and the shrunken contact mask of taxim_torch.py:443-473 (the FOTS wrapper needs both).
         """
         batch_shape = tuple(height_map.shape[:-2])
@@ -237,6 +240,13 @@ class TaximHip:
         if frame_min is not None:
             flags |= _lib.FLAG_HAVE_FRAME_MIN
             fmin = frame_min
+            if frame_rows is not None and frame_rows.dtype == torch.int32 and frame_rows.is_contiguous() and frame_rows.shape[0] >= B:
+                key = (frame_rows.data_ptr(), int(frame_rows.shape[0]))
+                if self._frame_rows_key.get((H, W)) != key:  # registered once per buffer
+                    _lib.check(self._lib.tacex_taxim_set_frame_rows(ctx.handle, _lib.ptr(frame_rows), int(frame_rows.shape[0])),
+                               "tacex_taxim_set_frame_rows")
+                    self._frame_rows_key[(H, W)] = key
+                flags |= _lib.FLAG_HAVE_FRAME_ROWS
         else:
             fmin = self._frame_min_buf((H, W), B)
         if out is None:

@@ -41,6 +41,10 @@ class TaximSimulator(GelSightSimulator):
         # per-frame minimum of the current height map, shared between compute_indentation_depth and the render
         self._frame_min = torch.zeros((self._num_envs,), device=self._device)
         self._frame_min_version = -1
+        # first / last frame row with a pixel below the press plane, produced with the minimum (tacex_height_map_from_depth /
+        # tacex_indentation_depth); the render skips the pyramid bands that cannot be non-zero
+        self._frame_rows = torch.zeros((self._num_envs, 2), dtype=torch.int32, device=self._device)
+        self._frame_rows_version = -1
         self._indent_version = -1
         # deformed gel + contact mask of the latest render, kept for a marker simulator (FOTS re-uses them)
         self._keep_deformation = False
@@ -113,6 +117,7 @@ class TaximSimulator(GelSightSimulator):
             orig_hm_fmt=False,
             out=self.tactile_rgb_img,
             frame_min=self._frame_min if have_min else None,
+            frame_rows=self._frame_rows if (have_min and self._frame_rows_version == self.sensor._height_map_version) else None,
             z_out=self._deformed_gel if full else None,
             mask_out=self._contact_mask if full else None,
             obs_out=self.policy_obs,
@@ -135,10 +140,11 @@ class TaximSimulator(GelSightSimulator):
         with torch.cuda.device(hm.device):
             rc = lib.tacex_indentation_depth(
                 _lib.ptr(hm), float(self.cfg.gelpad_height), float(self.cfg.gelpad_to_camera_min_distance),
-                _lib.ptr(self._frame_min), _lib.ptr(self._indentation_depth), B, H, W,
+                _lib.ptr(self._frame_min), _lib.ptr(self._indentation_depth), _lib.ptr(self._frame_rows), B, H, W,
                 _lib.current_stream_handle(hm.device))
         _lib.check(rc, "tacex_indentation_depth")
         self._frame_min_version = self.sensor._height_map_version
+        self._frame_rows_version = self.sensor._height_map_version
         self._indent_version = self.sensor._height_map_version
         return self._indentation_depth
 

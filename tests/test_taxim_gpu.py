@@ -82,10 +82,77 @@ def test_indentation_depth_kernel(calib_dir):
     d = hm.cuda()
     fmin = torch.empty(9, device="cuda")
     ind = torch.empty(9, device="cuda")
-    _lib.check(lib.tacex_indentation_depth(d.data_ptr(), 0.0045, 0.024, fmin.data_ptr(), ind.data_ptr(), 9, 240, 320,
+    _lib.check(lib.tacex_indentation_depth(d.data_ptr(), 0.0045, 0.024, fmin.data_ptr(), ind.data_ptr(), 0, 9, 240, 320,
                                            torch.cuda.current_stream().cuda_stream), "indent")
     np.testing.assert_array_equal(_np(fmin), hm.numpy().min(axis=(1, 2)))
     np.testing.assert_array_equal(_np(ind), TaximOracle.indentation_depth(hm.numpy()))
+    # the same pass with the contact row range as a by-product (row-wise kernel): identical minimum / indentation, and
+    # rows = first / last row with S = (hm - min) - indent < 0 in float32 (TT:441), (H, -1) for frames without contact
+    fmin2, ind2 = torch.empty(9, device="cuda"), torch.empty(9, device="cuda")
+    rows = torch.full((9, 2), 77, dtype=torch.int32, device="cuda")
+    _lib.check(lib.tacex_indentation_depth(d.data_ptr(), 0.0045, 0.024, fmin2.data_ptr(), ind2.data_ptr(), rows.data_ptr(), 9, 240, 320,
+                                           torch.cuda.current_stream().cuda_stream), "indent+rows")
+    np.testing.assert_array_equal(_np(fmin2), _np(fmin))
+    np.testing.assert_array_equal(_np(ind2), _np(ind))
+    S = (hm - fmin.cpu().view(-1, 1, 1)) - ind.cpu().view(-1, 1, 1)
+    has = (S < 0).any(2).numpy()
+    want = np.array([[np.where(r)[0][0], np.where(r)[0][-1]] if r.any() else [240, -1] for r in has], dtype=np.int32)
+    np.testing.assert_array_equal(_np(rows), want)
+    assert (want[:, 1] >= 0).any() and (want[:, 1] < 0).any()
+
+
+def test_zero_band_skipping_is_exact(calib_dir, tmp_path):
+    """Bands of the band levels whose input window lies outside the contact rows are stored as zeros without being computed
+    (frame_rows_kernel + blur_mfma_kernel).  The result must not differ in a single bit from the full computation
+    (TACEX_BAND_SKIP=0, read once per process): small contacts, contact at the top / bottom border (reflect padding), frames
+    without contact, through render_direct (library-side rows) and through the sensor (rows from the depth pass)."""
+    import os
+    import subprocess
+    import sys
+
+    from conftest import REPO
+
+    script = tmp_path / "skip_run.py"
+    script.write_text(
+        "import sys, numpy as np, torch\n"
+        f"sys.path.insert(0, {str(REPO)!r})\n"
+        "from tacex_amd import GelSightSensor, GelSightSensorCfg\n"
+        "from tacex_amd.simulation_approaches.gpu_taxim import TaximSimulatorCfg\n"
+        "from tacex_amd.simulation_approaches.gpu_taxim.sim import Taxim\n"
+        "from tacex_amd.utils.synthetic import synthetic_depth_maps\n"
+        "H, W, n = 240, 320, 12\n"
+        "hm, ind = synthetic_depth_maps(n, H, W, seed=3, flat_fraction=0.25)\n"
+        "yy, xx = torch.meshgrid(torch.arange(H), torch.arange(W), indexing='ij')\n"
+        "for b, (cy, cx, r) in enumerate([(6, 40, 9.0), (H - 4, 200, 7.0), (120, 160, 5.0), (60, 300, 12.0)]):\n"
+        "    d2 = ((yy - cy) ** 2 + (xx - cx) ** 2).float()\n"
+        "    hm[b] = torch.where(d2 < r * r, 28.0 + 0.02 * d2.sqrt(), torch.full_like(d2, 29.0))\n"
+        f"t = Taxim(calib_folder={str(calib_dir)!r}, backend='hip', device='cuda:0')\n"
+        "Z, M = t.deform(hm.cuda(), torch.full((n,), 0.8).cuda())\n"
+        "rgb = t.render_direct(hm.cuda(), with_shadow=False, press_depth=torch.full((n,), 0.8).cuda())\n"
+        "cfg = GelSightSensorCfg(num_envs=n, sensor_camera_cfg=GelSightSensorCfg.SensorCameraCfg(resolution=(W, H), clipping_range=(0.024, 0.029)),\n"
+        "    data_types=['tactile_rgb', 'height_map'],\n"
+        f"    optical_sim_cfg=TaximSimulatorCfg(calib_folder_path={str(calib_dir)!r}, gelpad_height=0.0045, gelpad_to_camera_min_distance=0.024,\n"
+        "        tactile_img_res=(W, H), device='cuda:0'), marker_motion_sim_cfg=None, device='cuda:0')\n"
+        "s = GelSightSensor(cfg); s.initialize()\n"
+        "s.set_camera_depth((hm / 1000.0).cuda())\n"
+        "s.update(0.01, force_recompute=True)\n"
+        "rows = s.optical_simulator._frame_rows.cpu().numpy()\n"
+        "np.savez(sys.argv[1], Z=Z.cpu().numpy(), M=M.cpu().numpy(), rgb=rgb.cpu().numpy(), srgb=s.data.output['tactile_rgb'].cpu().numpy(), rows=rows)\n")
+    outs = {}
+    for skip in ("1", "0"):
+        out = tmp_path / f"s{skip}.npz"
+        r = subprocess.run([sys.executable, str(script), str(out)], env=dict(os.environ, TACEX_BAND_SKIP=skip), capture_output=True,
+                           text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-3000:]
+        outs[skip] = np.load(out)
+    a, b = outs["1"], outs["0"]
+    for k in ("Z", "M", "rgb", "srgb"):
+        np.testing.assert_array_equal(a[k], b[k], err_msg=k)
+    rows = a["rows"]
+    assert (rows[:, 1] < 0).any(), "a frame without contact"
+    assert ((rows[:, 1] >= 0) & (rows[:, 1] - rows[:, 0] < 40)).any(), "a small contact (most bands skipped)"
+    assert (rows[:, 0] == 0).any() and (rows[:, 1] == 239).any(), "contacts on the top and bottom border"
+    assert np.abs(a["Z"]).max() > 0.1
 
 
 def test_no_shift_render_and_numpy_entry(taxim, calib_dir):
