@@ -62,7 +62,9 @@ def parse():
                     help="payload of the per-step observation all-gather (obs32 = 32x32x3 RGB + markers + indentation)")
     ap.add_argument("--obs-dtype", choices=["u8", "f32"], default="u8",
                     help="dtype of the 32x32x3 policy image in the gather payload (u8 = what a CNN policy consumes)")
-    ap.add_argument("--no-sensor-streams", action="store_true", help="update the sensors of an env back to back on one stream")
+    ap.add_argument("--sensor-streams", action="store_true",
+                    help="update the sensors of an env on one HIP stream each (+1.5 %% measured; off by default so that the per-kernel "
+                         "durations of a profile of this command stay those of kernels running alone)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-sweep", action="store_true", help="skip the C2 / 512-shard / C4 / C5 sweep (N = 1 only)")
@@ -105,7 +107,7 @@ def build_sensor(num_envs, H, W, markers, device, obs_res=None, obs_dtype="float
 class Rig:
     """`n_sensors` GelSightSensors over one env shard + the packed observation; step() = one update of all of them."""
 
-    def __init__(self, B, H, W, n_sensors, markers, dev, world, seed, gather="obs32", obs_dtype="u8", fem=None, sensor_streams=True):
+    def __init__(self, B, H, W, n_sensors, markers, dev, world, seed, gather="obs32", obs_dtype="u8", fem=None, sensor_streams=False):
         from tacex_amd.env_shard import ObservationGather
         from tacex_amd.utils.synthetic import synthetic_depth_maps
 
@@ -496,7 +498,7 @@ def main():
 
     log(f"headline: {B} envs x {args.sensors} sensors, {W}x{H}, rank {shard.rank}/{shard.world_size}")
     rig = Rig(B, H, W, args.sensors, markers, dev, shard.world_size, seed=1 + shard.rank, gather=args.gather,
-              obs_dtype=args.obs_dtype, sensor_streams=not args.no_sensor_streams)
+              obs_dtype=args.obs_dtype, sensor_streams=args.sensor_streams)
     elapsed = rig.timed(args.steps, args.warmup, barrier)
     log(f"headline timed: {elapsed / args.steps * 1e3:.3f} ms/step")
     if use_dist:

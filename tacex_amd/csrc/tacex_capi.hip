@@ -676,6 +676,8 @@ static int pipeline_chunk(tacex_taxim_ctx* c, const float* hm, const float* pres
       src = dst;
     }
   }
+  int band_grow = 0;  // rows by which the band levels spread the non-zero range of their output beyond the contact rows
+  for (int l = 0; l < n_band; ++l) band_grow += (c->levels[l].kh - 1) / 2;
   if (stream_tail) {
     // trailing small-kernel levels (+ restores), shading, observation and FOTS by-products: wave-autonomous streaming kernel
     StageTimer t(c, st, c->n_levels + 2);
@@ -691,7 +693,7 @@ static int pipeline_chunk(tacex_taxim_ctx* c, const float* hm, const float* pres
                             c->contact_scale, *plan, fuse_obs ? obs_h : nullptr, fots_part,
                             (int)(tail_tiles_per_frame(c->H, c->W) * kTailWavesPerTile),
                             pix ? c->fots_pix_z + (size_t)frame0 * c->fots_taps.n_markers : nullptr,
-                            pix ? c->fots_pix_m + (size_t)frame0 * c->fots_taps.n_markers : nullptr, st),
+                            pix ? c->fots_pix_m + (size_t)frame0 * c->fots_taps.n_markers : nullptr, st, rows, band_grow),
             "taxim_stream_kernel");
     if (fuse_obs) {
       HIP_TRY(run_obs_finish_stream(obs_h, obs, obs_u8, *plan, B, st), "obs_finish_stream_kernel");

@@ -144,7 +144,7 @@ int stream_warm_rows(int n_fused, int k0, bool levels_kernel);
 hipError_t run_stream_tail(const LevelDesc* lv, int n_levels, int n_fused, const float* zin, const float* hm, const float* gel,
                            const float* sa, const float* sb, const float* pd, const ShadeParams* sp, float* rgb, float* z_last,
                            int B, int H, int W, float contact_scale, const StreamPlan& plan, float* obs_part,
-                           FotsReduce* fots_part, int fots_stride, float* pix_z, uint8_t* pix_m, hipStream_t st);
+                           FotsReduce* fots_part, int fots_stride, float* pix_z, uint8_t* pix_m, hipStream_t st, const int* rows_ext = nullptr, int ext_grow = 0);
 hipError_t run_obs_finish_stream(const float* part, void* obs, bool u8, const StreamPlan& plan, int B, hipStream_t st);
 
 // thread-local error string (tacex_last_error)

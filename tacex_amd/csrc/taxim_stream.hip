@@ -67,6 +67,8 @@ struct StreamArgs {
   float* pix_z; uint8_t* pix_m; int n_markers;
   const int* mk_x;          // marker column  (CSR over rows: StreamRowInfo::mk0 / mk1)
   const int* mk_id;         // marker index
+  const int* rows_ext;      // (B,2) contact row range of every frame (frame_rows_kernel), nullable
+  int ext_grow;             // rows by which the band levels have spread the non-zero range of zin beyond it
 };
 
 __device__ __forceinline__ float dpp_from_left(float v) {   // lane i receives lane i-1's value
@@ -367,15 +369,105 @@ __global__ __launch_bounds__(64 * kStreamWaves, stream_min_waves(ROLE)) void tax
     wave_lds_fence();
   };
 
+  // one finished frame row: polynomial of every pixel's table record (TT:250-255) + background + clip (TT:257-258), the RGB
+  // store and the row's share of the policy observation
+  auto emit_row = [&](int e, const StreamRowInfo& ri, const v3f (&bq)[PX], const v4f (&pc)[PX][5]) {
+    const float Y = ri.fy;
+    float rgb[PX * 3];
+#pragma unroll
+    for (int i = 0; i < PX; ++i) {
+      const v4f c0 = pc[i][0], c1 = pc[i][1], c2 = pc[i][2], c3 = pc[i][3], c4 = pc[i][4];
+      const float f0 = X[i] * X[i], f1 = Y * Y, f2 = X[i] * Y;
+      const float p0 = fmaf(f0, c0.x, fmaf(f1, c0.y, fmaf(f2, c0.z, fmaf(X[i], c0.w, fmaf(Y, c1.x, c1.y)))));
+      const float p1 = fmaf(f0, c1.z, fmaf(f1, c1.w, fmaf(f2, c2.x, fmaf(X[i], c2.y, fmaf(Y, c2.z, c2.w)))));
+      const float p2 = fmaf(f0, c3.x, fmaf(f1, c3.y, fmaf(f2, c3.z, fmaf(X[i], c3.w, fmaf(Y, c4.x, c4.y)))));
+      rgb[3 * i + 0] = __builtin_amdgcn_fmed3f(p0 + bq[i].x, 0.0f, 1.0f);  // TT:257-258
+      rgb[3 * i + 1] = __builtin_amdgcn_fmed3f(p1 + bq[i].y, 0.0f, 1.0f);
+      rgb[3 * i + 2] = __builtin_amdgcn_fmed3f(p2 + bq[i].z, 0.0f, 1.0f);
+#ifdef TACEX_DBG_NO_STORE
+      if (valid[i] && rgb[3 * i] == 12345.0f)
+#else
+      if (valid[i])
+#endif
+        *reinterpret_cast<v3f*>(reinterpret_cast<char*>(a.sh.rgb + fo * 3) + ((unsigned)e * (unsigned)W + xc[i]) * 12u) =
+            (v3f){rgb[3 * i], rgb[3 * i + 1], rgb[3 * i + 2]};
+    }
+    if (do_obs) {
+      while (cur_o0 < ri.o0) {  // the oldest observation row in flight got its last frame row: reduce it horizontally
+        obs_flush(OA[0], cur_o0);
+#pragma unroll
+        for (int j = 0; j < PX * 3; ++j) { OA[0][j] = OA[1][j]; OA[1][j] = OA[2][j]; OA[2][j] = 0.0f; }
+        ++cur_o0;
+      }
+#pragma unroll
+      for (int j = 0; j < PX * 3; ++j) {
+        OA[0][j] = fmaf(ri.w0, rgb[j], OA[0][j]);
+        OA[1][j] = fmaf(ri.w1, rgb[j], OA[1][j]);
+        OA[2][j] = fmaf(ri.w2, rgb[j], OA[2][j]);
+      }
+    }
+  };
+
   // Iteration y: input row y enters level 0; the last level leaves row zr = y - SUMR.  With shading, the row shaded in an
   // iteration is gs = y - SUMR - 2, whose neighbours (Zu, Zm, Zd) = rows gs-1, gs, gs+1 are complete at the START of the
   // iteration: its bins are computed and its background loads issued early, the levels run under their latency.
   const int ys = SHADE ? r0 - SUMR - 1 : r0 - SUMR;
   const int ye = SHADE ? r1 + SUMR + 1 : r1 - 1 + SUMR;
   float zc[PX], hc[PX] = {0.f, 0.f, 0.f};
-  issue_row(row_of(ys), ys & 1);
-  issue_row(row_of(ys + 1), (ys + 1) & 1);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  // ---- waves no contact can reach: no levels, no bins -------------------------------------------------------------------
+  // zin is non-zero only within ext_grow rows of the frame's contact rows (zero-band skipping of the band levels, same
+  // argument), S < 0 only on them: if none of the rows this wave reads (its segment + the warm-up rows) comes that close, every
+  // level of every row is exactly zero, every gradient is zero and every pixel falls into the one table record of the flat
+  // bin pair (TT:494-499: direction 0 where the gradient vanishes).  What remains is the shading of a flat gel: polynomial of
+  // that record + background + store + observation.  A frame without contact (most frames of a manipulation episode) costs a
+  // third of a frame with one.
+  bool flat = false;
+  if constexpr (ROLE == kStreamFused && GZ) {
+    if (a.rows_ext != nullptr) {
+      const int lo = a.rows_ext[2 * frame] - a.ext_grow, hi = a.rows_ext[2 * frame + 1] + a.ext_grow;
+      flat = (r0 - SUMR - 1 > hi) || (r1 + SUMR + 1 < lo);
+    }
+    if (flat) {
+      const int code = shade_dir_bin(a.sh, 0.0f, 0.0f, 0.0f);  // magnitude bin 0
+      v4f pcf[PX][5];
+      if (code < nb_lds) {
+        const v4f* pl = reinterpret_cast<const v4f*>(polyL + code * kStreamPolyPitch);
+#pragma unroll
+        for (int i = 0; i < PX; ++i) { pcf[i][0] = pl[0]; pcf[i][1] = pl[1]; pcf[i][2] = pl[2]; pcf[i][3] = pl[3]; pcf[i][4] = pl[4]; }
+      } else {
+        const v4f* pp = reinterpret_cast<const v4f*>(reinterpret_cast<const char*>(a.sh.poly) + (unsigned)code * 96u);
+#pragma unroll
+        for (int i = 0; i < PX; ++i) { pcf[i][0] = pp[0]; pcf[i][1] = pp[1]; pcf[i][2] = pp[2]; pcf[i][3] = pp[3]; pcf[i][4] = pp[4]; }
+      }
+      if (do_fots) {
+        if (a.pix_z != nullptr || a.pix_m != nullptr) {  // marker taps of this wave's rows: deformed gel 0, no contact
+          const int e0 = a.rows[r0 * kStreamRowInts + 5], e1 = a.rows[(r1 - 1) * kStreamRowInts + 6];
+          for (int e = e0 + lane; e < e1; e += 64) {
+            const int mx = a.mk_x[e];
+            if (mx >= vx0 && mx < vx1) {
+              const size_t o = (size_t)frame * a.n_markers + a.mk_id[e];
+              if (a.pix_z != nullptr) a.pix_z[o] = 0.0f;
+              if (a.pix_m != nullptr) a.pix_m[o] = 0;
+            }
+          }
+        }
+        f_zmax = (valid[0] || valid[1] || valid[2]) ? 0.0f : -INFINITY;
+      }
+      v3f bq[PX], bn[PX] = {(v3f)(0.0f), (v3f)(0.0f), (v3f)(0.0f)};
+      load_bg(r0, bq);
+      for (int e = r0; e < r1; ++e) {
+        if (e + 1 < r1) load_bg(e + 1, bn);
+        const StreamRowInfo ri = *reinterpret_cast<const StreamRowInfo*>(a.rows + e * kStreamRowInts);
+        emit_row(e, ri, bq, pcf);
+        bq[0] = bn[0]; bq[1] = bn[1]; bq[2] = bn[2];
+      }
+    }
+  }
+  if (!flat) {
+    issue_row(row_of(ys), ys & 1);
+    issue_row(row_of(ys + 1), (ys + 1) & 1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
   // Row scalars, fetched one iteration ahead with a VECTOR load (lanes 0-7: record of the row shaded, 8-15: of the row
   // entering, 16-23: of the row leaving the last level) and moved to scalar registers with v_readlane: scalar-memory loads
   // share the LDS wait counter and return out of order, so every ring read would also wait for them.
@@ -402,12 +494,14 @@ __global__ __launch_bounds__(64 * kStreamWaves, stream_min_waves(ROLE)) void tax
       ri_z.mk0 = __builtin_amdgcn_readlane(info, 16 + 5); ri_z.mk1 = __builtin_amdgcn_readlane(info, 16 + 6);
     }
   };
-  cinfo = load_info(ys);
-  unpack_info(cinfo);
+  if (!flat) {
+    cinfo = load_info(ys);
+    unpack_info(cinfo);
+  }
 #ifdef TACEX_STREAM_CLOCK
   float clk_acc[4] = {0.f, 0.f, 0.f, 0.f};
 #endif
-  for (int y = ys; y <= ye; ++y) {
+  for (int y = flat ? ye + 1 : ys; y <= ye; ++y) {
     // ---- row y out of the ring (it landed before the previous iteration's mid_point returned); next iteration's row scalars ----
 #ifdef TACEX_STREAM_CLOCK
     const long long ck0 = __builtin_readcyclecounter();
@@ -689,40 +783,7 @@ __global__ __launch_bounds__(64 * kStreamWaves, stream_min_waves(ROLE)) void tax
             ri = *reinterpret_cast<const StreamRowInfo*>(a.rows + e * kStreamRowInts);
             load_bg(e, bq);
           }
-          const float Y = ri.fy;
-          float rgb[PX * 3];
-#pragma unroll
-          for (int i = 0; i < PX; ++i) {
-            const v4f c0 = pc[i][0], c1 = pc[i][1], c2 = pc[i][2], c3 = pc[i][3], c4 = pc[i][4];
-            const float f0 = X[i] * X[i], f1 = Y * Y, f2 = X[i] * Y;
-            const float p0 = fmaf(f0, c0.x, fmaf(f1, c0.y, fmaf(f2, c0.z, fmaf(X[i], c0.w, fmaf(Y, c1.x, c1.y)))));
-            const float p1 = fmaf(f0, c1.z, fmaf(f1, c1.w, fmaf(f2, c2.x, fmaf(X[i], c2.y, fmaf(Y, c2.z, c2.w)))));
-            const float p2 = fmaf(f0, c3.x, fmaf(f1, c3.y, fmaf(f2, c3.z, fmaf(X[i], c3.w, fmaf(Y, c4.x, c4.y)))));
-            rgb[3 * i + 0] = __builtin_amdgcn_fmed3f(p0 + bq[i].x, 0.0f, 1.0f);  // TT:257-258
-            rgb[3 * i + 1] = __builtin_amdgcn_fmed3f(p1 + bq[i].y, 0.0f, 1.0f);
-            rgb[3 * i + 2] = __builtin_amdgcn_fmed3f(p2 + bq[i].z, 0.0f, 1.0f);
-#ifdef TACEX_DBG_NO_STORE
-            if (valid[i] && rgb[3 * i] == 12345.0f)
-#else
-            if (valid[i])
-#endif
-              *reinterpret_cast<v3f*>(reinterpret_cast<char*>(a.sh.rgb + fo * 3) + ((unsigned)e * (unsigned)W + xc[i]) * 12u) =
-                  (v3f){rgb[3 * i], rgb[3 * i + 1], rgb[3 * i + 2]};
-          }
-          if (do_obs) {
-            while (cur_o0 < ri.o0) {  // the oldest observation row in flight got its last frame row: reduce it horizontally
-              obs_flush(OA[0], cur_o0);
-#pragma unroll
-              for (int j = 0; j < PX * 3; ++j) { OA[0][j] = OA[1][j]; OA[1][j] = OA[2][j]; OA[2][j] = 0.0f; }
-              ++cur_o0;
-            }
-#pragma unroll
-            for (int j = 0; j < PX * 3; ++j) {
-              OA[0][j] = fmaf(ri.w0, rgb[j], OA[0][j]);
-              OA[1][j] = fmaf(ri.w1, rgb[j], OA[1][j]);
-              OA[2][j] = fmaf(ri.w2, rgb[j], OA[2][j]);
-            }
-          }
+          emit_row(e, ri, bq, pc);
         }
       }
     }
@@ -896,8 +957,10 @@ static hipError_t launch_stream(const StreamArgs& a, bool gel_zero, hipStream_t 
 hipError_t run_stream_tail(const LevelDesc* lv, int n_levels, int n_fused, const float* zin, const float* hm, const float* gel,
                            const float* sa, const float* sb, const float* pd, const ShadeParams* sp, float* rgb, float* z_last,
                            int B, int H, int W, float contact_scale, const StreamPlan& plan, float* obs_part,
-                           FotsReduce* fots_part, int fots_stride, float* pix_z, uint8_t* pix_m, hipStream_t st) {
+                           FotsReduce* fots_part, int fots_stride, float* pix_z, uint8_t* pix_m, hipStream_t st,
+                           const int* rows_ext, int ext_grow) {
   StreamArgs a{};
+  a.rows_ext = lv[0].gel_zero ? rows_ext : nullptr; a.ext_grow = ext_grow;
   a.zin = zin; a.hm = hm; a.gel = lv[0].gel_zero ? nullptr : gel; a.shift_a = sa; a.shift_b = sb; a.pdepth = pd;
   a.H = H; a.W = W; a.B = B; a.contact_scale = contact_scale;
   for (int i = 0; i < n_fused; ++i) a.taps[i] = lv[n_levels - n_fused + i].taps_w_dev;
