@@ -1,7 +1,7 @@
 """Container-only harness that imports the *reference* Taxim / FOTS kernels from /root/reference.
 
-Used ONLY by the golden-vector generators (make_golden.py, make_marker_image_golden.py) and by the container-only
-oracle-vs-reference checks in `tests/test_oracle_golden.py` (skipped when /root/reference is absent, i.e. on the GPU box).
+Used ONLY by the golden-vector generators (make_golden.py & co., run in the build container where /root/reference exists);
+the tests themselves (tests/test_oracle_golden.py, tests/test_*_gpu.py) read the committed .npz fixtures, never this module.
 Nothing here is product code; no reference source is copied - modules are loaded from where they lie.
 
 Recipe follows SURVEY.md section 8(c):
