@@ -542,6 +542,9 @@ __global__ __launch_bounds__(64 * kStreamWaves, stream_min_waves(ROLE)) void tax
 #ifdef TACEX_DBG_NO_GATHER
         hi[i] = false;
 #endif
+#ifdef TACEX_DBG_GATHER_ALL  // timing probe: every valid lane gathers (cost vs active lanes)
+        hi[i] = valid[i];
+#endif
         const v4f* pl = reinterpret_cast<const v4f*>(polyL + (hi[i] ? 0 : cc[i]) * kStreamPolyPitch);
         pc[i][0] = pl[0]; pc[i][1] = pl[1]; pc[i][2] = pl[2]; pc[i][3] = pl[3]; pc[i][4] = pl[4];
       }
@@ -550,7 +553,11 @@ __global__ __launch_bounds__(64 * kStreamWaves, stream_min_waves(ROLE)) void tax
         for (int i = 0; i < PX; ++i)
           if (hi[i]) {
             const v4f* __restrict__ pp = reinterpret_cast<const v4f*>(reinterpret_cast<const char*>(a.sh.poly) + (unsigned)cc[i] * 96u);
+#ifdef TACEX_DBG_GATHER_ONE  // timing probe (wrong colours): one 16-byte piece per contact pixel instead of five
+            pc[i][0] = pp[0];
+#else
             pc[i][0] = pp[0]; pc[i][1] = pp[1]; pc[i][2] = pp[2]; pc[i][3] = pp[3]; pc[i][4] = pp[4];
+#endif
           }
       }
     };
