@@ -2,6 +2,6 @@
 from .gelsight_sensor import GelSightSensor
 from .gelsight_sensor_cfg import GelSightSensorCfg
 from .gelsight_sensor_data import GelSightSensorData
-from .height_map_source import IndenterHeightMapSource
+from .height_map_source import IndenterHeightMapSource, MeshDepthSource
 
-__all__ = ["GelSightSensor", "GelSightSensorCfg", "GelSightSensorData", "IndenterHeightMapSource"]
+__all__ = ["GelSightSensor", "GelSightSensorCfg", "GelSightSensorData", "IndenterHeightMapSource", "MeshDepthSource"]

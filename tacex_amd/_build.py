@@ -12,13 +12,16 @@ CSRC = PKG / "csrc"
 INCLUDE = PKG.parent / "include"
 LIB = PKG / "libtacex_hip.so"
 STAMP = PKG / "libtacex_hip.so.stamp"
-SOURCES = ["taxim_kernels.hip", "taxim_mfma.hip", "taxim_tail.hip", "taxim_stream.hip", "taxim_shadow.hip", "fots_kernels.hip", "fem_kernels.hip", "tacex_capi.hip"]
+SOURCES = ["taxim_kernels.hip", "taxim_mfma.hip", "taxim_tail.hip", "taxim_stream.hip", "taxim_shadow.hip", "fots_kernels.hip", "fem_kernels.hip", "depth_raster.hip", "tacex_capi.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=fast", "-Wno-unused-result"]
 # A/B hook for kernel tuning macros, e.g. TACEX_EXTRA_HIPCC_FLAGS="-DTACEX_MFMA_CH=2" (part of the build digest)
 FLAGS += os.environ.get("TACEX_EXTRA_HIPCC_FLAGS", "").split()
 # per-file flags (part of the digest): the streaming tail is scalar f32 FMA chains - SLP packing into v_pk_fma_f32 (half rate on
 # gfx950, scripts/hip_probes/valu_rates.hip) only adds register shuffles and pushed the kernel into scratch
-FILE_FLAGS = {"taxim_stream.hip": ["-fno-slp-vectorize"]}
+FILE_FLAGS = {"taxim_stream.hip": ["-fno-slp-vectorize"],
+              # the rasteriser must round every product on its own (bit-equal to its NumPy restatement): with the global
+              # -ffp-contract=fast the backend fuses multiply-adds even under `#pragma clang fp contract(off)`
+              "depth_raster.hip": ["-ffp-contract=off"]}
 
 
 def _hipcc() -> str:

@@ -44,3 +44,53 @@ class IndenterHeightMapSource:
                 float(gelpad_to_camera_min_distance), _lib.ptr(hm), _lib.ptr(frame_min), _lib.ptr(indent), B, H, W,
                 _lib.current_stream_handle(hm.device))
         _lib.check(rc, "tacex_height_map_from_indenters")
+
+
+class MeshDepthSource:
+    """Camera depth of a rigid triangle mesh per env (arbitrary indenters): a callable for
+    `cfg.sensor_camera_cfg.depth_source` that stands in for the IsaacLab TiledCamera read-out of the reference
+    (gelsight_sensor.py:229-263): `source()` -> (num_envs, H, W) float32 "distance_to_image_plane" depth in metres, inf where
+    nothing lies inside the clipping range.  The caller updates `pos` (num_envs, 3) and `quat` (num_envs, 4, wxyz) in place -
+    the pose of the object in the CAMERA frame (x right, y down, z along the optical axis)."""
+
+    def __init__(self, verts, tris, num_envs: int, device, resolution=(320, 240), intrinsics=(340.0, 325.0, 160.0, 125.0),
+                 clipping_range=(0.024, 0.029)):
+        dev = torch.device(device)
+        if dev.type != "cuda":
+            raise _lib.TacexHipError("MeshDepthSource needs an AMD GPU device (no CPU fallback)")
+        self.verts = torch.as_tensor(verts, dtype=torch.float32).reshape(-1, 3).contiguous().to(dev)
+        self.tris = torch.as_tensor(tris, dtype=torch.int32).reshape(-1, 3).contiguous().to(dev)
+        if self.tris.numel() == 0 or int(self.tris.min()) < 0 or int(self.tris.max()) >= self.verts.shape[0]:
+            raise ValueError("MeshDepthSource: triangle indices out of range")
+        self.W, self.H = int(resolution[0]), int(resolution[1])
+        self.fx, self.fy, self.cx, self.cy = (float(v) for v in intrinsics)
+        self.near, self.far = float(clipping_range[0]), float(clipping_range[1])
+        self.pos = torch.zeros((num_envs, 3), dtype=torch.float32, device=dev)
+        self.pos[:, 2] = 1.0  # out of range until the caller places the object
+        self.quat = torch.zeros((num_envs, 4), dtype=torch.float32, device=dev)
+        self.quat[:, 0] = 1.0
+        self.depth = torch.empty((num_envs, self.H, self.W), dtype=torch.float32, device=dev)
+        self._pose = torch.empty((num_envs, 12), dtype=torch.float32, device=dev)
+        self._lib = _lib.load_library()
+
+    def pose_rows(self) -> torch.Tensor:
+        """(num_envs, 12) [rotation matrix row-major | translation], float64 arithmetic rounded once (as the oracle does)."""
+        q = self.quat.double()
+        q = q / q.norm(dim=1, keepdim=True)
+        w, x, y, z = q.unbind(1)
+        R = torch.stack([1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w),
+                         2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w),
+                         2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)], dim=1)
+        self._pose[:, :9] = R.float()
+        self._pose[:, 9:] = self.pos
+        return self._pose
+
+    def __call__(self) -> torch.Tensor:
+        pose = self.pose_rows()
+        with torch.cuda.device(self.depth.device):
+            rc = self._lib.tacex_depth_from_mesh(
+                _lib.ptr(self.verts), _lib.ptr(self.tris), int(self.verts.shape[0]), int(self.tris.shape[0]), _lib.ptr(pose),
+                self.fx, self.fy, self.cx, self.cy, self.near, self.far, _lib.ptr(self.depth), int(self.depth.shape[0]),
+                self.H, self.W, _lib.current_stream_handle(self.depth.device))
+        _lib.check(rc, "tacex_depth_from_mesh")
+        return self.depth
