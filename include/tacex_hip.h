@@ -105,13 +105,16 @@ int tacex_height_map_from_indenters(const float* indenters_dev, float pixmm, flo
 /* Height-map SOURCE for arbitrary rigid indenters: the depth image the IsaacLab TiledCamera of the reference
  * hands _get_height_map (GS:229-263, 581-593 - "distance_to_image_plane" in metres, inf where nothing is seen inside the
  * clipping range), rendered here from one shared triangle mesh and one rigid pose per env.
- *   verts_dev (V,3) f32 object frame [m]; tris_dev (T,3) int32; pose_dev (B,12) f32 = rotation matrix (row-major) + translation
- *   taking object coordinates into the CAMERA frame (x right, y down, z along the optical axis);
+ *   verts_dev (V,3) f32 object frame [m]; tris_dev (T,3) int32; pos_dev (B,3) f32 translation and quat_dev (B,4) f32 rotation
+ *   (wxyz, normalised by the kernel) taking object coordinates into the CAMERA frame (x right, y down, z along the optical axis);
  *   pinhole intrinsics fx, fy, cx, cy in pixels, pixel (i, j) sampled at its centre (j + 0.5, i + 0.5);
+ *   bounding_sphere: HOST pointer to {cx, cy, cz, r} of a sphere around the mesh in the object frame, nullable (image tiles
+ *   the sphere cannot project onto skip the triangle loop);
  *   depth_m_dev (B,H,W) f32 out.  Feed it to tacex_height_map_from_depth. */
 int tacex_depth_from_mesh(const float* verts_dev, const int32_t* tris_dev, int num_verts, int num_tris,
-                          const float* pose_dev, float fx, float fy, float cx, float cy, float near_clip_m,
-                          float far_clip_m, float* depth_m_dev, int num_envs, int height, int width, void* stream);
+                          const float* pos_dev, const float* quat_dev, float fx, float fy, float cx, float cy,
+                          float near_clip_m, float far_clip_m, const float* bounding_sphere, float* depth_m_dev, int num_envs, int height,
+                          int width, void* stream);
 
 /* TS:115-131 on an existing mm height map. frame_min_dev (B,) is also written (re-used by the render);
  * frame_rows_dev (B,2) int32 nullable: contact row range as in tacex_height_map_from_depth. */

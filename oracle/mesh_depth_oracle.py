@@ -14,14 +14,16 @@ F = np.float32
 
 
 def quat_to_matrix(q_wxyz: np.ndarray) -> np.ndarray:
-    w, x, y, z = (np.asarray(q_wxyz, dtype=np.float64) / np.linalg.norm(q_wxyz)).tolist()
+    q = np.asarray(q_wxyz, dtype=np.float64)
+    w, x, y, z = (q / np.sqrt(((q[0] * q[0] + q[1] * q[1]) + q[2] * q[2]) + q[3] * q[3])).tolist()  # float64, the kernel's order
     return np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
                      [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
                      [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
 
 
 def pose_rows(pos: np.ndarray, quat_wxyz: np.ndarray) -> np.ndarray:
-    """(B,3) positions + (B,4) quaternions -> (B,12) float32 [R row-major | t] as tacex_depth_from_mesh takes them."""
+    """(B,3) positions + (B,4) quaternions -> (B,12) float32 [R row-major | t]: the matrix the kernel builds from the quaternion
+    (float64 arithmetic, rounded once)."""
     out = np.zeros((len(pos), 12), dtype=np.float32)
     for b in range(len(pos)):
         out[b, :9] = quat_to_matrix(quat_wxyz[b]).reshape(-1)

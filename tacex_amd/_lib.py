@@ -101,7 +101,7 @@ SIGNATURES = {
     "tacex_height_map_from_depth": (_i, [_vp, _d, _d, _f, _f, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "tacex_indentation_depth": (_i, [_vp, _f, _f, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "tacex_taxim_set_frame_rows": (_i, [_vp, _vp, _i]),
-    "tacex_depth_from_mesh": (_i, [_vp, _vp, _i, _i, _vp, _f, _f, _f, _f, _f, _f, _vp, _i, _i, _i, _vp]),
+    "tacex_depth_from_mesh": (_i, [_vp, _vp, _i, _i, _vp, _vp, _f, _f, _f, _f, _f, _f, _vp, _vp, _i, _i, _i, _vp]),
     "tacex_taxim_render": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _u, _vp]),
     "tacex_taxim_render_obs": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _u, _vp]),
     "tacex_taxim_deform": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _u, _vp]),

@@ -1,7 +1,7 @@
 // Height-map SOURCE for arbitrary rigid indenters (second slice): pinhole depth image of a triangle mesh per
 // env - what the IsaacLab TiledCamera hands GelSightSensor._get_height_map (GS:229-263, 581-593: "distance_to_image_plane"
 // depth in metres, inf where the camera sees nothing inside its clipping range).  One shared mesh (object frame), one rigid pose
-// per env (rotation + translation into the camera frame: x right, y down, z along the optical axis).
+// per env (unit quaternion wxyz + translation into the camera frame: x right, y down, z along the optical axis).
 //
 // Workgroup = (env, 64 x 32 pixel tile) with the tile's z-buffer in LDS; every thread walks the triangles t = tid, tid + 256, ...:
 // transform, project, clip the bounding box to the tile, and for the covered pixel centres (j + 0.5, i + 0.5) interpolate 1/z
@@ -23,11 +23,13 @@ constexpr int kRasterTileW = 64, kRasterTileH = 32;
 struct RasterArgs {
   const float* verts;   // (V,3)
   const int* tris;      // (T,3)
-  const float* pose;    // (B,12): R row-major (9), t (3)
+  const float* pos;     // (B,3) translation into the camera frame
+  const float* quat;    // (B,4) wxyz rotation into the camera frame (normalised here, in double)
   float* depth;         // (B,H,W)
   int V, T, B, H, W;
   float fx, fy, cx, cy, near_m, far_m;
   int tiles_x, tiles_y;
+  float bs[4];          // bounding sphere of the mesh in the object frame (centre, radius); radius < 0: unknown
 };
 
 __global__ __launch_bounds__(256) void mesh_depth_kernel(RasterArgs a) {
@@ -39,10 +41,36 @@ __global__ __launch_bounds__(256) void mesh_depth_kernel(RasterArgs a) {
   const int x1 = min(x0 + kRasterTileW, a.W), y1 = min(y0 + kRasterTileH, a.H);  // exclusive
   for (int i = threadIdx.x; i < kRasterTileW * kRasterTileH; i += blockDim.x) zbuf[i] = 0x7f800000u;  // +inf
   __syncthreads();
-  const float* P = a.pose + (size_t)env * 12;
-  const float r00 = P[0], r01 = P[1], r02 = P[2], r10 = P[3], r11 = P[4], r12 = P[5], r20 = P[6], r21 = P[7], r22 = P[8];
-  const float t0 = P[9], t1 = P[10], t2 = P[11];
-  for (int t = threadIdx.x; t < a.T; t += blockDim.x) {
+  // rotation matrix of the env's quaternion: double arithmetic, rounded once to float32 (what the NumPy restatement does)
+  double qw = a.quat[4 * env], qx = a.quat[4 * env + 1], qy = a.quat[4 * env + 2], qz = a.quat[4 * env + 3];
+  const double qn = sqrt(((qw * qw + qx * qx) + qy * qy) + qz * qz);
+  qw /= qn; qx /= qn; qy /= qn; qz /= qn;
+  const float r00 = (float)(1.0 - 2.0 * (qy * qy + qz * qz)), r01 = (float)(2.0 * (qx * qy - qz * qw)), r02 = (float)(2.0 * (qx * qz + qy * qw));
+  const float r10 = (float)(2.0 * (qx * qy + qz * qw)), r11 = (float)(1.0 - 2.0 * (qx * qx + qz * qz)), r12 = (float)(2.0 * (qy * qz - qx * qw));
+  const float r20 = (float)(2.0 * (qx * qz - qy * qw)), r21 = (float)(2.0 * (qy * qz + qx * qw)), r22 = (float)(1.0 - 2.0 * (qx * qx + qy * qy));
+  const float t0 = a.pos[3 * env], t1 = a.pos[3 * env + 1], t2 = a.pos[3 * env + 2];
+  // Tiles the mesh cannot touch skip the triangle loop (a contact covers a few percent of the image): conservative screen
+  // bounds of the mesh's bounding sphere - x, y in [c -+ r] over z in [c.z - r, c.z + r] - against the tile.  Exactness is not
+  // at stake: a skipped tile holds no fragment.
+  bool tile_empty = false;
+  if (a.bs[3] >= 0.0f) {
+    const float r = a.bs[3];
+    const float bx = ((r00 * a.bs[0] + r01 * a.bs[1]) + r02 * a.bs[2]) + t0;
+    const float by = ((r10 * a.bs[0] + r11 * a.bs[1]) + r12 * a.bs[2]) + t1;
+    const float bz = ((r20 * a.bs[0] + r21 * a.bs[1]) + r22 * a.bs[2]) + t2;
+    const float zn = bz - r, zf = bz + r;
+    if (zf < a.near_m || zn > a.far_m) {
+      tile_empty = true;
+    } else if (zn > 1e-4f) {
+      const float m = 1.001f;  // slack for the rounding of the bounds themselves
+      const float ulo = fminf(a.fx * (bx - r * m) / zn, a.fx * (bx - r * m) / zf) + a.cx - 1.0f;
+      const float uhi = fmaxf(a.fx * (bx + r * m) / zn, a.fx * (bx + r * m) / zf) + a.cx + 1.0f;
+      const float vlo = fminf(a.fy * (by - r * m) / zn, a.fy * (by - r * m) / zf) + a.cy - 1.0f;
+      const float vhi = fmaxf(a.fy * (by + r * m) / zn, a.fy * (by + r * m) / zf) + a.cy + 1.0f;
+      tile_empty = uhi < (float)x0 || ulo > (float)x1 || vhi < (float)y0 || vlo > (float)y1;
+    }
+  }
+  for (int t = tile_empty ? a.T : threadIdx.x; t < a.T; t += blockDim.x) {
     float sx[3], sy[3], iz[3];
     bool ok = true;
 #pragma unroll
@@ -95,17 +123,20 @@ __global__ __launch_bounds__(256) void mesh_depth_kernel(RasterArgs a) {
 }  // namespace tacex
 
 extern "C" int tacex_depth_from_mesh(const float* verts_dev, const int32_t* tris_dev, int num_verts, int num_tris,
-                                     const float* pose_dev, float fx, float fy, float cx, float cy, float near_clip_m,
-                                     float far_clip_m, float* depth_m_dev, int num_envs, int height, int width, void* stream) {
+                                     const float* pos_dev, const float* quat_dev, float fx, float fy, float cx, float cy, float near_clip_m,
+                                     float far_clip_m, const float* bounding_sphere, float* depth_m_dev, int num_envs, int height,
+                                     int width, void* stream) {
   using namespace tacex;
-  if (!verts_dev || !tris_dev || !pose_dev || !depth_m_dev) { set_error("tacex_depth_from_mesh: null buffer"); return 2; }
+  if (!verts_dev || !tris_dev || !pos_dev || !quat_dev || !depth_m_dev) { set_error("tacex_depth_from_mesh: null buffer"); return 2; }
   if (num_verts <= 0 || num_tris <= 0 || height <= 0 || width <= 0) { set_error("tacex_depth_from_mesh: empty mesh or image"); return 2; }
   if (!(near_clip_m >= 0.0f) || !(far_clip_m > near_clip_m)) { set_error("tacex_depth_from_mesh: clipping range (%g, %g)", near_clip_m, far_clip_m); return 2; }
   if (num_envs <= 0) return 0;
   RasterArgs a{};
-  a.verts = verts_dev; a.tris = tris_dev; a.pose = pose_dev; a.depth = depth_m_dev;
+  a.verts = verts_dev; a.tris = tris_dev; a.pos = pos_dev; a.quat = quat_dev; a.depth = depth_m_dev;
   a.V = num_verts; a.T = num_tris; a.B = num_envs; a.H = height; a.W = width;
   a.fx = fx; a.fy = fy; a.cx = cx; a.cy = cy; a.near_m = near_clip_m; a.far_m = far_clip_m;
+  if (bounding_sphere) { a.bs[0] = bounding_sphere[0]; a.bs[1] = bounding_sphere[1]; a.bs[2] = bounding_sphere[2]; a.bs[3] = bounding_sphere[3]; }
+  else a.bs[3] = -1.0f;
   a.tiles_x = (width + kRasterTileW - 1) / kRasterTileW; a.tiles_y = (height + kRasterTileH - 1) / kRasterTileH;
   hipLaunchKernelGGL(mesh_depth_kernel, dim3((unsigned)(num_envs * a.tiles_x * a.tiles_y)), dim3(256), 0, (hipStream_t)stream, a);
   hipError_t e = hipGetLastError();

@@ -8,6 +8,8 @@ from the rendered depth.
 """
 from __future__ import annotations
 
+import ctypes as C
+
 import torch
 
 from . import _lib
@@ -70,27 +72,18 @@ class MeshDepthSource:
         self.quat = torch.zeros((num_envs, 4), dtype=torch.float32, device=dev)
         self.quat[:, 0] = 1.0
         self.depth = torch.empty((num_envs, self.H, self.W), dtype=torch.float32, device=dev)
-        self._pose = torch.empty((num_envs, 12), dtype=torch.float32, device=dev)
+        v = self.verts.double().cpu()
+        c = 0.5 * (v.min(0).values + v.max(0).values)
+        self._bsphere = (C.c_float * 4)(float(c[0]), float(c[1]), float(c[2]), float((v - c).norm(dim=1).max()) * 1.0001)
         self._lib = _lib.load_library()
 
-    def pose_rows(self) -> torch.Tensor:
-        """(num_envs, 12) [rotation matrix row-major | translation], float64 arithmetic rounded once (as the oracle does)."""
-        q = self.quat.double()
-        q = q / q.norm(dim=1, keepdim=True)
-        w, x, y, z = q.unbind(1)
-        R = torch.stack([1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w),
-                         2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w),
-                         2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)], dim=1)
-        self._pose[:, :9] = R.float()
-        self._pose[:, 9:] = self.pos
-        return self._pose
-
     def __call__(self) -> torch.Tensor:
-        pose = self.pose_rows()
         with torch.cuda.device(self.depth.device):
             rc = self._lib.tacex_depth_from_mesh(
-                _lib.ptr(self.verts), _lib.ptr(self.tris), int(self.verts.shape[0]), int(self.tris.shape[0]), _lib.ptr(pose),
-                self.fx, self.fy, self.cx, self.cy, self.near, self.far, _lib.ptr(self.depth), int(self.depth.shape[0]),
+                _lib.ptr(self.verts), _lib.ptr(self.tris), int(self.verts.shape[0]), int(self.tris.shape[0]),
+                _lib.ptr(self.pos), _lib.ptr(self.quat),
+                self.fx, self.fy, self.cx, self.cy, self.near, self.far, C.cast(self._bsphere, C.c_void_p), _lib.ptr(self.depth),
+                int(self.depth.shape[0]),
                 self.H, self.W, _lib.current_stream_handle(self.depth.device))
         _lib.check(rc, "tacex_depth_from_mesh")
         return self.depth

@@ -76,7 +76,7 @@ def test_hip_rasteriser_equals_oracle_and_drives_the_sensor(calib_dir):
     quat = rng.normal(size=(B, 4)); quat /= np.linalg.norm(quat, axis=1, keepdims=True)
     src.pos.copy_(torch.from_numpy(pos).float()); src.quat.copy_(torch.from_numpy(quat).float())
     depth = src().cpu().numpy()
-    want = render_depth(V, T, src.pose_rows().cpu().numpy(), H=H, W=W, near=0.024, far=0.029, **INTR)
+    want = render_depth(V, T, pose_rows(src.pos.cpu().numpy(), src.quat.cpu().numpy()), H=H, W=W, near=0.024, far=0.029, **INTR)
     np.testing.assert_array_equal(np.isfinite(depth), np.isfinite(want))
     m = np.isfinite(want)
     np.testing.assert_array_equal(depth[m], want[m])  # same float32 operations in the same order
