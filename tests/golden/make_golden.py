@@ -115,15 +115,14 @@ def kernel_tables(t, mod):
     return res
 
 
-def fots_case(t, MarkerMotion, seed: int, n: int, steps: int):
-    H, W = 240, 320
+def fots_case(t, MarkerMotion, seed: int, n: int, steps: int, H: int = 240, W: int = 320, ncol: int = 11, nrow: int = 9):
     hm0, _ = synthetic_depth_maps(n, H, W, seed=seed, flat_fraction=0.0)
     mm = MarkerMotion(
         frame0_blur=np.zeros((H, W, 3)),
         lamb=[0.00125, 0.00021, 0.00038],
         mm2pix=19.58,
-        num_markers_col=11,
-        num_markers_row=9,
+        num_markers_col=ncol,
+        num_markers_row=nrow,
         tactile_img_width=W,
         tactile_img_height=H,
         x0=15,
@@ -208,6 +207,8 @@ def main():
     np.savez_compressed(HERE / "taxim_240x320.npz", **taxim_case(t, 240, 320, 5, 14, levels=True, shadow=True, n_levels_frames=2))
     np.savez_compressed(HERE / "taxim_480x640.npz", **taxim_case(t, 480, 640, 2, 15, levels=False, shadow=True, slim=True, shadow_frames=1))
     np.savez_compressed(HERE / "fots_240x320.npz", **fots_case(t, MarkerMotion, seed=21, n=4, steps=4))
+    # the marker grid of the reference's 640x480 benchmark (ball_rolling_physx_rigid.py:172-179: 9 columns x 11 rows)
+    np.savez_compressed(HERE / "fots_480x640.npz", **fots_case(t, MarkerMotion, seed=22, n=2, steps=3, H=480, W=640, ncol=9, nrow=11))
     for f in sorted(HERE.glob("*.npz")):
         print(f.name, f.stat().st_size // 1024, "KiB")
 
