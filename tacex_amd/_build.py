@@ -46,6 +46,21 @@ def build_library(force: bool = False, verbose: bool = False) -> Path:
     dig = _digest()
     if not force and LIB.exists() and STAMP.exists() and STAMP.read_text().strip() == dig:
         return LIB
+    # several ranks of one node may get here at once (one process per GPU): one builds, the others wait and re-check
+    import fcntl
+
+    lock = open(PKG / ".build.lock", "w")
+    fcntl.flock(lock, fcntl.LOCK_EX)
+    try:
+        if not force and LIB.exists() and STAMP.exists() and STAMP.read_text().strip() == dig:
+            return LIB
+        return _build_locked(dig, verbose)
+    finally:
+        fcntl.flock(lock, fcntl.LOCK_UN)
+        lock.close()
+
+
+def _build_locked(dig: str, verbose: bool) -> Path:
     hipcc = _hipcc()
     objdir = PKG / "build"
     objdir.mkdir(exist_ok=True)
@@ -63,10 +78,12 @@ def build_library(force: bool = False, verbose: bool = False) -> Path:
         if p.returncode != 0:
             raise RuntimeError(f"hipcc failed on {s.name}:\n{out}")
         objs.append(str(obj))
-    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", str(LIB)]
+    tmp = LIB.with_suffix(".so.tmp")  # link beside, then rename: a reader never maps a half-written library
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", str(tmp)]
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"link failed:\n{r.stdout}")
+    os.replace(tmp, LIB)
     STAMP.write_text(dig)
     return LIB
 
