@@ -350,14 +350,15 @@ int tacex_fem_gradient(tacex_fem_ctx* ctx, const double* x_dev, const double* x_
 /* IPC contact of the gelpad SURFACE against one analytic indenter per env (first slice; reference cfg
  * US:103-124 `Contact`: constitution "ipc", d_hat 1e-3, resistance 10 GPa - libuipc's Compute Contact / Detect Candidates).
  * Every surface vertex v gets the barrier term  dt^2 * stiffness * area_v * b(d_v / d_hat),  b(s) = -(s-1)^2 ln s on (0,1)
- * (Li et al. 2020 eq. 6), d_v = signed distance to the indenter (sphere |x - c| - R, half-space n.(x - c)); the energy,
+ * (Li et al. 2020 eq. 6), d_v = signed distance to the indenter (sphere |x - c| - R, half-space n.(x - c), capsule: distance to the axis segment - R); the energy,
  * gradient, PSD-projected Hessian (b'' n n^T) enter tacex_fem_energy / _gradient / _newton_step, and the Newton step length is
  * first cut to 0.9 x the conservative bound min_v d_v / |dx_v| (the CCD filter of the line search: no vertex can cross the
  * indenter surface), then backtracked on the energy as before.  Friction and mesh-mesh contact are not part of this slice.
  *   vertex_area_host (V) HOST f64: a third of the area of the surface triangles around a vertex, 0 for interior vertices
  *                    (copied once; NULL keeps the previous table);
  *   indenters_dev (num_envs, 8) f64 [kind, cx, cy, cz, radius, nx, ny, nz]: kind 0 none, 1 sphere, 2 half-space (unit
- *                    normal n through c); read by every later compute call until replaced; NULL disables contact. */
+ *                    normal n through c), 3 capsule (radius around the segment c -+ (nx, ny, nz): the vector is HALF the
+ *                    axis); read by every later compute call until replaced; NULL disables contact. */
 int tacex_fem_set_contact(tacex_fem_ctx* ctx, const double* vertex_area_host, double d_hat, double stiffness,
                           const double* indenters_dev);
 

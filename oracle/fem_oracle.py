@@ -300,7 +300,8 @@ def attachment_aim_positions(offsets, body_pos, body_quat):
 # per vertex:  E_c(x) = dt^2 kappa sum_v area_v b(d_v / dhat).   Known-answer tests: tests/test_fem_oracle.py.
 # --------------------------------------------------------------------------------------------------
 def contact_distance(ind, x):
-    """Signed distance d (V,) and its gradient n (V,3) of points x (V,3) to indenter [kind, cx, cy, cz, R, nx, ny, nz]."""
+    """Signed distance d (V,) and its gradient n (V,3) of points x (V,3) to indenter [kind, cx, cy, cz, R, nx, ny, nz]
+    (kind 1 sphere, 2 half-space with unit normal n, 3 capsule with half axis vector n and radius R)."""
     kind = int(ind[0])
     c = np.asarray(ind[1:4], np.float64)
     if kind == 1:
@@ -310,6 +311,14 @@ def contact_distance(ind, x):
     if kind == 2:
         n = np.asarray(ind[5:8], np.float64)
         return (x - c) @ n, np.broadcast_to(n, x.shape).copy()
+    if kind == 3:  # capsule: (nx, ny, nz) is HALF the axis vector, R the radius
+        a = np.asarray(ind[5:8], np.float64)
+        p = x - c
+        aa = a @ a
+        t = np.clip((p @ a) / aa, -1.0, 1.0) if aa > 0 else np.zeros(x.shape[:-1])
+        r = p - t[..., None] * a
+        rho = np.linalg.norm(r, axis=-1)
+        return rho - ind[4], r / np.maximum(rho, 1e-300)[..., None]
     return np.full(x.shape[:-1], np.inf), np.zeros_like(x)
 
 

@@ -45,7 +45,7 @@ struct FemDev {
 // ---- IPC barrier of one surface vertex against the env's analytic indenter ------------------------------------------
 // Li et al. 2020 (IPC) eq. 6 in the dimensionless gap s = d / dhat:  b(s) = -(s - 1)^2 ln s  for 0 < s < 1, 0 beyond.
 // Potential term of a vertex with weight w: dt^2 kappa w b(d / dhat); d = signed distance to the indenter surface
-// (sphere: |x - c| - R, half-space: n . (x - c)), n = grad d.  A gap <= 0 is a penetration: infinite energy (the
+// (sphere: |x - c| - R, half-space: n . (x - c), capsule: distance to the axis segment - R), n = grad d.  A gap <= 0 is a penetration: infinite energy (the
 // line search never accepts it; the conservative step bound below keeps the Newton direction out of it).
 struct ContactEval {
   bool active;      // 0 < d < dhat
@@ -67,6 +67,19 @@ __device__ __forceinline__ ContactEval contact_eval(const FemDev& m, const doubl
   } else if (kind == 2) {
     c.n[0] = ind[5]; c.n[1] = ind[6]; c.n[2] = ind[7];
     c.d = c.n[0] * (x[0] - ind[1]) + c.n[1] * (x[1] - ind[2]) + c.n[2] * (x[2] - ind[3]);
+  } else if (kind == 3) {
+    // capsule (cylinder with hemispherical caps, e.g. a lying pin or a finger): centre c, radius R, the vector (nx, ny, nz) is
+    // HALF the axis (direction and half length); the closest axis point is c + clamp(p . a / |a|^2, -1, 1) a
+    const double p0 = x[0] - ind[1], p1 = x[1] - ind[2], p2 = x[2] - ind[3];
+    const double a0 = ind[5], a1 = ind[6], a2 = ind[7];
+    const double aa = a0 * a0 + a1 * a1 + a2 * a2;
+    double t = aa > 0.0 ? (p0 * a0 + p1 * a1 + p2 * a2) / aa : 0.0;
+    t = t < -1.0 ? -1.0 : (t > 1.0 ? 1.0 : t);
+    const double r0 = p0 - t * a0, r1 = p1 - t * a1, r2 = p2 - t * a2;
+    const double rho = sqrt(r0 * r0 + r1 * r1 + r2 * r2);
+    c.d = rho - ind[4];
+    const double ir = rho > 0.0 ? 1.0 / rho : 0.0;
+    c.n[0] = r0 * ir; c.n[1] = r1 * ir; c.n[2] = r2 * ir;
   } else {
     return c;
   }

@@ -144,7 +144,8 @@ class UipcSim:
     def set_contact_indenters(self, indenters: torch.Tensor | None):
         """One analytic indenter per env the gelpad surface may not penetrate: (num_envs, 8) float64
         [kind, cx, cy, cz, radius, nx, ny, nz], kind 0 none, 1 sphere (centre c, radius), 2 half-space (unit normal n through c,
-        the solid side is n.(x - c) < 0).  None disables contact.  Needs `cfg.contact.enable`."""
+        the solid side is n.(x - c) < 0), 3 capsule (centre c, radius, (nx, ny, nz) = HALF the axis vector: a lying pin, a
+        finger).  None disables contact.  Needs `cfg.contact.enable`."""
         if indenters is None:
             _lib.check(self._lib.tacex_fem_set_contact(self._handle, 0, 0.0, 0.0, 0), "tacex_fem_set_contact")
             self.contact_indenters = None
@@ -171,7 +172,11 @@ class UipcSim:
         c, n, kind = ind[:, None, 1:4], ind[:, None, 5:8], ind[:, None, 0]
         sph = (x - c).norm(dim=-1) - ind[:, None, 4]
         pl = ((x - c) * n).sum(-1)
-        return torch.where(kind == 1, sph, torch.where(kind == 2, pl, torch.full_like(sph, float("inf"))))
+        aa = (n * n).sum(-1).clamp_min(1e-300)
+        t = (pl / aa).clamp(-1.0, 1.0)
+        cap = (x - c - t[..., None] * n).norm(dim=-1) - ind[:, None, 4]
+        inf = torch.full_like(sph, float("inf"))
+        return torch.where(kind == 1, sph, torch.where(kind == 2, pl, torch.where(kind == 3, cap, inf)))
 
     # -- animation targets (uipc_attachments.py:364-385) ----------------------------------------------------------
     def set_constraints(self, vertex_idx, aim_positions: torch.Tensor):

@@ -353,6 +353,8 @@ def _contact_setup(B=3, strength=100.0):
     ind[1] = [2, cx, cy, top + 0.0006, 0, 0, 0, -1.0]                        # half-space coming down from above (solid side z > c)
     if B > 2:
         ind[2] = [0, 0, 0, 0, 0, 0, 0, 0]                                    # no indenter
+    if B > 3:  # lying capsule (a pin across the pad): radius 3 mm, half axis 8 mm along x, lowest line 0.5 mm above the pad
+        ind[3] = [3, cx, cy, top + 0.003 + 0.0005, 0.003, 0.008, 0.0, 0.0]
     m = FemModel.build(P, Tt, youngs=1e4, strength=strength)
     return sim, gel, m, P, back, ind
 
@@ -360,7 +362,7 @@ def _contact_setup(B=3, strength=100.0):
 def test_contact_energy_gradient_vs_oracle():
     from oracle.fem_oracle import ContactModel
 
-    sim, gel, m, P, back, ind = _contact_setup()
+    sim, gel, m, P, back, ind = _contact_setup(B=4)
     B = sim.num_envs
     rng = np.random.default_rng(2)
     x = P[None] + 2e-5 * rng.normal(size=(B,) + P.shape)
@@ -380,6 +382,7 @@ def test_contact_energy_gradient_vs_oracle():
         assert abs((E1[b] - E0[b]) - ec) <= 1e-10 * max(abs(ec), 1e-30) + 1e-12 * abs(E0[b]), b
         assert np.abs((g1[b] - g0[b]) - gc).max() <= 1e-10 * max(np.abs(gc).max(), 1e-30) + 1e-12 * np.abs(g0[b]).max(), b
     assert E1[0] > E0[0] and E1[1] > E0[1] and E1[2] == E0[2]  # envs 0 / 1 are inside d_hat, env 2 has no indenter
+    assert E1[3] > E0[3] and (sim.contact_gaps()[3] < sim.cfg.contact.d_hat).sum().item() >= 3  # the capsule touches a line of vertices
     # penetration = infinite energy
     xp = x.copy(); xp[1, :, 2] += 0.001
     sim.x = torch.from_numpy(xp).cuda()

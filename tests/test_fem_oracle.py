@@ -228,7 +228,7 @@ def test_contact_barrier_known_answers():
     np.testing.assert_allclose(barrier(np.array([0.5]))[0][0], 0.25 * np.log(2.0), rtol=1e-15)
 
 
-@pytest.mark.parametrize("kind", [1, 2])
+@pytest.mark.parametrize("kind", [1, 2, 3])
 def test_contact_gradient_hessian_finite_differences(kind):
     """Gradient = FD of the energy; the PSD-projected Hessian b'' n n^T = FD of the gradient minus the dropped b' hess(d) part
     (exactly the full Hessian for the half-space, whose distance has no curvature)."""
@@ -242,6 +242,19 @@ def test_contact_gradient_hessian_finite_differences(kind):
     if kind == 1:
         dirs = rng.normal(size=(V, 3)); dirs /= np.linalg.norm(dirs, axis=1, keepdims=True)
         x = ind[1:4] + dirs * (ind[4] + rng.uniform(0.1, 0.95, V)[:, None] * dhat)
+    elif kind == 3:  # capsule: half axis a = 6 mm along n, radius 4 mm; half of the points beside the cylinder, half over a cap
+        a = 0.006 * n
+        ind[5:8] = a
+        perp = np.cross(n, [1.0, 0.0, 0.0]); perp /= np.linalg.norm(perp)
+        t = np.concatenate([rng.uniform(-0.9, 0.9, V // 2), rng.choice([-1.0, 1.0], V - V // 2)])
+        dirs = rng.normal(size=(V, 3)); dirs /= np.linalg.norm(dirs, axis=1, keepdims=True)
+        side = np.cross(dirs, n); side /= np.linalg.norm(side, axis=1, keepdims=True)       # radial directions beside the cylinder
+        cap = dirs * np.sign(dirs @ n)[:, None] * np.sign(t)[:, None]                          # outward half-space of the cap
+        radial = np.where((np.abs(t) < 1.0)[:, None], side, cap)
+        x = ind[1:4] + t[:, None] * a + radial * (ind[4] + rng.uniform(0.1, 0.95, V)[:, None] * dhat)
+        d_chk, n_chk = contact_distance(ind, x)
+        np.testing.assert_allclose(n_chk, radial, atol=1e-9)  # closest axis point = the one the sample was built from
+        assert ((d_chk > 0.09 * dhat) & (d_chk < 0.96 * dhat)).all()
     else:
         x = ind[1:4] + rng.normal(size=(V, 3)) * 0.01
         x += ((rng.uniform(0.1, 0.95, V) * dhat) - (x - ind[1:4]) @ n)[:, None] * n
@@ -264,9 +277,14 @@ def test_contact_gradient_hessian_finite_differences(kind):
             e = np.zeros_like(x); e[v, i] = h
             fdH[:, i] = (cm.gradient(x + e)[v] - cm.gradient(x - e)[v]) / (2 * h)
         dropped = np.zeros((3, 3))
-        if kind == 1:
+        if kind == 1 or (kind == 3 and v >= V // 2):  # sphere, or the capsule's spherical cap
             rho = d[v] + ind[4]
             dropped = dt**2 * kappa * area[v] * b1[v] / dhat * (np.eye(3) - np.outer(nn[v], nn[v])) / rho
+            assert np.linalg.eigvalsh(dropped).max() <= 1e-9 * np.abs(H[v]).max()  # negative semi-definite: safe to drop
+        elif kind == 3:  # beside the cylinder the distance is curved around the axis only
+            rho = d[v] + ind[4]
+            ah = ind[5:8] / np.linalg.norm(ind[5:8])
+            dropped = dt**2 * kappa * area[v] * b1[v] / dhat * (np.eye(3) - np.outer(nn[v], nn[v]) - np.outer(ah, ah)) / rho
             assert np.linalg.eigvalsh(dropped).max() <= 1e-9 * np.abs(H[v]).max()  # negative semi-definite: safe to drop
         assert np.abs(fdH - dropped - H[v]).max() <= 2e-4 * np.abs(H[v]).max()
         assert np.linalg.eigvalsh(H[v]).min() >= -1e-12 * np.abs(H[v]).max()
