@@ -587,8 +587,8 @@ __global__ __launch_bounds__(64 * kStreamWaves, stream_min_waves(ROLE)) void tax
           const int right = i == PX - 1 ? cr : code[i + 1], left = i == 0 ? cl : code[i - 1];
           cc[i] = xg[i] == 0 ? right : (xg[i] == W - 1 ? left : code[i]);
         }
-#ifdef TACEX_STREAM_EARLY_TABLE  // A/B probe: table fetch ahead of the levels (measured equal: the wait below is ~6 % of the iteration either way)
-        fetch_table();
+#ifndef TACEX_STREAM_LATE_TABLE  // issued here, ahead of the levels: the gather's L2 round trip (18 % of the iteration when waited for
+        fetch_table();            // on the spot) hides behind them; -2.3 % on the kernel for six more live registers
 #endif
         load_bg(gs, bgq);
       }
@@ -767,7 +767,7 @@ __global__ __launch_bounds__(64 * kStreamWaves, stream_min_waves(ROLE)) void tax
     // ---- shading, part 2: table records, polynomial, background, clip, store, observation ----
     if constexpr (SHADE) {
       if (shade_now) {
-#ifndef TACEX_STREAM_EARLY_TABLE
+#ifdef TACEX_STREAM_LATE_TABLE  // A/B probe: table fetch on the spot
         fetch_table();
 #endif
 #ifdef TACEX_STREAM_CLOCK
