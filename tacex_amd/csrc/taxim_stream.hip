@@ -232,32 +232,54 @@ __global__ __launch_bounds__(64 * kStreamWaves, stream_min_waves(ROLE)) void tax
   }
   typedef __attribute__((address_space(1))) const void* gptr_t;
   typedef __attribute__((address_space(3))) void* lptr_t;
+  // The height map only serves S = (hm - min) - press of the masked restore and the contact statistics, and S < 0 occurs on the
+  // frame's contact rows alone (frame_rows_kernel): every other row skips its height-map load (one of the two row loads) and
+  // reads S = +inf - no restore, no contact.
+  // (-4.8 % on the kernel in alternating runs on one box.)  Likewise the previous level is zero beyond ext_grow rows of them.
+  int hm_lo = 0, hm_hi = H - 1, z_lo = 0, z_hi = H - 1;
+  if constexpr (GZ && LEVELS) {
+#ifndef TACEX_STREAM_HM_ALWAYS  // (A/B probe: load both arrays of every row)
+    if (a.rows_ext != nullptr) {
+      hm_lo = a.rows_ext[2 * frame]; hm_hi = a.rows_ext[2 * frame + 1];
+      z_lo = hm_lo - a.ext_grow; z_hi = hm_hi + a.ext_grow;
+    }
+#endif
+  }
   auto issue_row = [&](int row, int slot) {
 #ifdef TACEX_DBG_NO_ROWLOAD
-    const unsigned ro = xb; (void)row;
+    const unsigned ro = xb;
 #else
     const unsigned ro = (unsigned)row * (unsigned)W + xb;
 #endif
     float* dst = rowbuf + slot * kRowSlot;
-    __builtin_amdgcn_global_load_lds((gptr_t)(zin + ro), (lptr_t)dst, 12, 0, 0);
-    if constexpr (LEVELS) __builtin_amdgcn_global_load_lds((gptr_t)(hm + ro), (lptr_t)(dst + kRowArr), 12, 0, 0);
+    if (row >= z_lo && row <= z_hi) __builtin_amdgcn_global_load_lds((gptr_t)(zin + ro), (lptr_t)dst, 12, 0, 0);
+    if constexpr (LEVELS)
+      if (row >= hm_lo && row <= hm_hi) __builtin_amdgcn_global_load_lds((gptr_t)(hm + ro), (lptr_t)(dst + kRowArr), 12, 0, 0);
   };
   // interior lanes read back their own 16 bytes (conflict-free b128); only the few lanes with a pixel outside the image pick
   // their mirrored columns one by one (scattered b32 reads at a 4-dword lane stride would be 4-way bank conflicts for everyone)
   const bool border = xg[0] < 0 || xg[PX - 1] >= W;
-  auto read_row = [&](int slot, float (&zz)[PX], float (&hh)[PX]) {
+  auto read_row = [&](int slot, int row, float (&zz)[PX], float (&hh)[PX]) {
     const float* src = rowbuf + slot * kRowSlot;
-    const v4f zq = *reinterpret_cast<const v4f*>(src + lane * 4);
-    zz[0] = zq.x; zz[1] = zq.y; zz[2] = zq.z;
+    const bool have_hm = LEVELS && row >= hm_lo && row <= hm_hi, have_z = row >= z_lo && row <= z_hi;
+    zz[0] = zz[1] = zz[2] = 0.0f;
+    if (have_z) {
+      const v4f zq = *reinterpret_cast<const v4f*>(src + lane * 4);
+      zz[0] = zq.x; zz[1] = zq.y; zz[2] = zq.z;
+    }
     if constexpr (LEVELS) {
-      const v4f hq = *reinterpret_cast<const v4f*>(src + kRowArr + lane * 4);
-      hh[0] = hq.x; hh[1] = hq.y; hh[2] = hq.z;
+      hh[0] = hh[1] = hh[2] = INFINITY;
+      if (have_hm) {
+        const v4f hq = *reinterpret_cast<const v4f*>(src + kRowArr + lane * 4);
+        hh[0] = hq.x; hh[1] = hq.y; hh[2] = hq.z;
+      }
     }
     if (border) {
 #pragma unroll
       for (int i = 0; i < PX; ++i) {
-        zz[i] = src[ridx[i]];
-        if constexpr (LEVELS) hh[i] = src[kRowArr + ridx[i]];
+        if (have_z) zz[i] = src[ridx[i]];
+        if constexpr (LEVELS)
+          if (have_hm) hh[i] = src[kRowArr + ridx[i]];
       }
     }
   };
@@ -506,7 +528,7 @@ __global__ __launch_bounds__(64 * kStreamWaves, stream_min_waves(ROLE)) void tax
 #ifdef TACEX_STREAM_CLOCK
     const long long ck0 = __builtin_readcyclecounter();
 #endif
-    read_row(y & 1, zc, hc);
+    read_row(y & 1, row_of(y), zc, hc);
     int ninfo = load_info(y + 1);
     // The ONE point of the iteration where this wave waits for memory: every plain load of the iteration (row scalars,
     // background, table gather) has been consumed by the caller, row y+1 (issued one iteration ago) is forced to have landed, and
