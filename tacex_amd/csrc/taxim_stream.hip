@@ -13,7 +13,14 @@
 //     8-row ring per wave in LDS (wave-private: no barrier, no conflicts - every lane touches only its own 16 bytes);
 //   * level l consumes level l-1's output row of the SAME iteration, so a row entering at iteration y leaves the last level
 //     as row y - sum(R) and is shaded as row y - sum(R) - 1 (central differences need the row below).
-// HBM sees one read of the previous level + the height map and one write of RGB, as with the tiled tail; the halo is only
+//   * input rows never pass through registers: one global_load_lds per array lands a row in a two-slot LDS ring a full iteration
+//     before it is read back; the iteration has ONE vmcnt wait (mid_point), behind which only the RGB stores are issued - nothing
+//     ever waits for a young load or store (gfx9 stores count in vmcnt, and the counter retires in order);
+//   * what the frame's contact row range (frame_rows_kernel) rules out is not done: the height map is loaded on contact rows
+//     only, level rows only within the band levels' reach, and a wave no contact can reach shades a flat gel (no levels, no bins).
+// The kernel is bound by the ISSUE of its vector-memory instructions (9 + <= 15 table-gather instructions per row, ~50 % of
+// the time against a 481 us compute floor at 1024 frames) and by f32 VALU issue - see DESIGN.md section 4.2 for the probes.
+// HBM sees one read of the previous level (+ the height map on contact rows) and one write of RGB; the halo is only
 // horizontal (2 x 12 of 184 columns, those re-reads are L2 hits) plus sum(R) + 1 warm-up rows per vertical segment.
 //
 // Summation order of every level equals the band kernels / the tiled tail (taps ascending, fmaf chains), so the deformed gel
@@ -286,7 +293,7 @@ __global__ __launch_bounds__(64 * kStreamWaves, stream_min_waves(ROLE)) void tax
 
   // background of one row: 12 bytes per pixel straight into the lane that owns the pixel.  (Staging the row through LDS as
   // contiguous 16-byte pieces cut the L1 tag look-ups by 40 % but added four LDS round trips to the dependency chain of every
-  // row: measured slower - the kernel is latency-, not L1-bound.)
+  // row: measured slower; perfectly linear 768-byte loads + stores gain at most 10 %)
   unsigned xc[PX];
 #pragma unroll
   for (int i = 0; i < PX; ++i) xc[i] = (unsigned)min(max(xg[i], 0), W - 1);
