@@ -1,0 +1,34 @@
+"""The committed bench line (profiles/r02_bench_n1.json = stdout of `python bench.py` on the GPU box) follows the driver's
+contract: the headline keys, the `roofline` and `cpu_baseline` objects, the workload naming - and agrees with the kernel stats
+of the rocprofv3 run of the same command that sits beside it."""
+import csv
+import json
+from pathlib import Path
+
+REPO = Path(__file__).resolve().parent.parent
+
+
+def test_committed_bench_line_follows_the_contract():
+    d = json.loads((REPO / "profiles" / "r02_bench_n1.json").read_text())
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    base = json.loads((REPO / "BASELINE.json").read_text())
+    assert "tactile frames/sec" in base["metric"] and d["metric"] == "tactile_frames_per_sec" and d["unit"] == "frames/s"
+    assert d["n_gpus"] == 1 and d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None
+    assert d["dtype"] == "f32" and d["data"] == "synthetic" and "workload" in d["config"] and "model" not in d["config"]
+    assert abs(d["value"] - d["config"]["frames_per_step"] / (d["ms_per_step"] * 1e-3)) <= 1e-3 * d["value"]
+    r = d["roofline"]
+    assert r["bound"] in ("hbm", "mfma") and r["unit"] in ("GB/s", "TFLOP/s") and r["peak"] == 8000.0
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and (r["traffic"] is None or r["traffic"] > 0)
+    c = d["cpu_baseline"]
+    assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0 and isinstance(c["sample"], str)
+    assert {"C2", "C4", "C5"} <= {s["workload"][:2] for s in d["config"]["sweep"]}
+
+
+def test_roofline_duration_agrees_with_the_rocprof_summary():
+    d = json.loads((REPO / "profiles" / "r02_bench_n1.json").read_text())
+    stage = d["roofline"]["stages"][d["roofline"]["kernel"]]
+    rows = list(csv.DictReader(open(REPO / "profiles" / "r02_c3_kernel_stats.csv")))
+    k = next(r for r in rows if "taxim_stream_kernel" in r["Name"])
+    assert abs(float(k["AverageNs"]) * 1e-6 - stage["avg_ms"]) <= 0.05 * stage["avg_ms"]  # hipEvent vs profiler: within 5 %
