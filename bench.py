@@ -478,6 +478,14 @@ def main():
     from tacex_amd import _lib
     from tacex_amd.env_shard import init_from_env
 
+    # Native libraries write banners to the C stdout (RCCL prints its version block when the first communicator is made, and
+    # libc only flushes it at exit - after our line).  The driver parses stdout for ONE JSON line: everything before it goes to
+    # stderr instead (fd 1 -> fd 2 until the line is printed).
+    import ctypes
+    sys.stdout.flush()
+    saved_stdout = os.dup(1)
+    os.dup2(2, 1)
+
     H, W = args.height, args.width
     markers = not args.no_markers
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -556,10 +564,18 @@ def main():
             line["roofline"] = roofline
         if cpu is not None:
             line["cpu_baseline"] = cpu
-        print(json.dumps(line), flush=True)
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
+    try:
+        ctypes.CDLL(None).fflush(None)  # native buffers (the RCCL banner) land on stderr
+    except OSError:
+        pass
+    sys.stdout.flush()
+    os.dup2(saved_stdout, 1)
+    os.close(saved_stdout)
+    if shard.rank == 0:
+        print(json.dumps(line), flush=True)
 
 
 if __name__ == "__main__":
