@@ -109,7 +109,7 @@ __device__ __forceinline__ void wave_lds_fence() { asm volatile("s_waitcnt lgkmc
 
 typedef float v3f __attribute__((ext_vector_type(3)));
 
-constexpr int kStreamObsLdsFloats = 512;
+constexpr int kStreamObsLdsFloats = 448;
 constexpr int kStreamObsMaxCols = 64;
 constexpr size_t kStreamStageBytes = 64 * kStreamPx * 3 * 4;  // one row of 3 floats per pixel (background in / RGB out)
 // workgroup-shared copy of the polynomial records of magnitude bin 0 ([id][28] floats: 24 padded to 28 so that 16 lanes with
@@ -969,7 +969,8 @@ static hipError_t launch_stream_k(const StreamArgs& a, hipStream_t st) {
   using C = StreamCfg<ROLE, KS...>;
   const int waves = a.B * a.nstrips * a.nseg;
   const dim3 grid((waves + kStreamWaves - 1) / kStreamWaves);
-  const size_t lds = C::lds_bytes();
+  static const size_t lds_pad = getenv("TACEX_STREAM_LDS_PAD") ? (size_t)atoi(getenv("TACEX_STREAM_LDS_PAD")) : 0;  // occupancy A/B hook
+  const size_t lds = C::lds_bytes() + lds_pad;
   auto kern = taxim_stream_kernel<GZ, ROLE, KS...>;
   if (lds > 64 * 1024) {  // > 64 KB of dynamic LDS is an opt-in per kernel AND device (one flag per device)
     static bool attr_done[64] = {};
