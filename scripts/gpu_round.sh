@@ -17,6 +17,12 @@ for s in $STEPS; do
     pmc) (cd /tmp && export TMPDIR=/tmp
           timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-sweep --no-roofline > $OUT/pmc_fetch.log 2>&1; echo "pmc fetch rc=$?"
           timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-sweep --no-roofline > $OUT/pmc_write.log 2>&1; echo "pmc write rc=$?") ;;
+    pmc640) (cd /tmp && export TMPDIR=/tmp
+          for c in FETCH_SIZE WRITE_SIZE; do d=$(echo $c | tr A-Z a-z | sed 's/_size//')
+            timeout 600 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $OUT/pmc640_$d -- python3 $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 2 --height 480 --width 640 --envs-per-gpu 1024 --sensors 1 --no-cpu-baseline --no-sweep --no-roofline > $OUT/pmc640_$d.log 2>&1; echo "pmc640 $c rc=$?"; done) ;;
+    pmcfem) (cd /tmp && export TMPDIR=/tmp
+          for c in FETCH_SIZE WRITE_SIZE; do d=$(echo $c | tr A-Z a-z | sed 's/_size//')
+            timeout 600 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $OUT/pmcfem_$d -- python3 $GRAFT_REPO_ROOT/scripts/fem_bench.py > $OUT/pmcfem_$d.log 2>&1; echo "pmcfem $c rc=$?"; done) ;;
     pmcsq) (cd /tmp && export TMPDIR=/tmp
           timeout 600 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS --output-format csv -d $OUT/pmc_sq -- python3 $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-sweep --no-roofline > $OUT/pmc_sq.log 2>&1; echo "pmc sq rc=$?") ;;
   esac

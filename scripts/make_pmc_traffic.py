@@ -5,7 +5,7 @@ On the GPU box (scripts/gpu_round.sh <tag> pmc does exactly this):
     cd /tmp && export TMPDIR=/tmp
     rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 $REPO/bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-sweep --no-roofline
     rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 $REPO/bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-sweep --no-roofline
-then (anywhere):  python scripts/make_pmc_traffic.py <pmc_fetch dir> <pmc_write dir> <out.json> [frames_per_launch=1024] [H=240] [W=320] [commit]
+then (anywhere):  python scripts/make_pmc_traffic.py <pmc_fetch dir> <pmc_write dir> <out.json> [frames_per_tail_launch=1024] [H=240] [W=320] [commit] [frames_per_shard]
 """
 import csv, glob, json, os, sys
 from collections import defaultdict
@@ -15,13 +15,15 @@ STAGES = {  # kernel-name substring -> bench.py stage name
     "blur_mfma_kernel<61": "blur_l0_k61x61", "blur_band_kernel<61": "blur_l0_k61x61",
     "blur_mfma_kernel<33": "blur_l1_k33x33", "blur_band_kernel<33": "blur_l1_k33x33",
     "blur_mfma_kernel<17": "blur_l2_k17x17", "blur_band_kernel<17": "blur_l2_k17x17",
-    "blur_band_loop_kernel": "blur_l0_k117x117", "blur_mfma_kernel<15": "blur_l3_k15x15",
+    "blur_band_loop_kernel": "blur_l0_k117x117", "blur_mfma_kernel<117": "blur_l0_k117x117", "blur_mfma_kernel<15": "blur_l3_k15x15",
+    "frame_rows_kernel<true>": "frame_min_from_depth", "frame_rows_kernel<false>": "frame_min",
     "taxim_stream_kernel": "tail_fused", "taxim_tail_kernel": "tail_fused_tiled",
 }
 FRAMES = int(sys.argv[4]) if len(sys.argv) > 4 else 1024
 H = int(sys.argv[5]) if len(sys.argv) > 5 else 240
 W = int(sys.argv[6]) if len(sys.argv) > 6 else 320
 COMMIT = sys.argv[7] if len(sys.argv) > 7 else "unknown"
+BATCH = int(sys.argv[8]) if len(sys.argv) > 8 else FRAMES  # frames per depth -> height-map dispatch (the sensor's whole shard)
 
 
 def collect(d, counter):
@@ -40,7 +42,10 @@ def collect(d, counter):
     n_pass = cnt.get("tail_fused", 0) + cnt.get("tail_fused_tiled", 0)  # every pass of FRAMES frames ends in exactly one tail launch
     out = {}
     for k in acc:
-        out[k] = acc[k] / (n_pass * FRAMES) if (n_pass > 0 and k.startswith("blur_")) else acc[k] / cnt[k] / FRAMES
+        if n_pass > 0 and k.startswith("blur_"):
+            out[k] = acc[k] / (n_pass * FRAMES)
+        else:
+            out[k] = acc[k] / cnt[k] / (BATCH if k.startswith("frame_min") else FRAMES)
     return out, dict(cnt)
 
 
