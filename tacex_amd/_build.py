@@ -10,12 +10,20 @@ from pathlib import Path
 PKG = Path(__file__).resolve().parent
 CSRC = PKG / "csrc"
 INCLUDE = PKG.parent / "include"
-LIB = PKG / "libtacex_hip.so"
-STAMP = PKG / "libtacex_hip.so.stamp"
+# TACEX_LIB_TAG=<name>: a second, separately stamped build (libtacex_hip.<name>.so, objects under build.<name>/) whose extra
+# compiler flags are remembered in libtacex_hip.<name>.flags - kernel A/B variants are compiled in the build container, travel
+# to the GPU box next to the product library and are selected there by the tag alone (scripts/ab_*.sh); unset = the product
+_TAG = os.environ.get("TACEX_LIB_TAG", "")
+LIB = PKG / (f"libtacex_hip.{_TAG}.so" if _TAG else "libtacex_hip.so")
+STAMP = PKG / (LIB.name + ".stamp")
+_FLAGS_FILE = PKG / f"libtacex_hip.{_TAG}.flags"
 SOURCES = ["taxim_kernels.hip", "taxim_mfma.hip", "taxim_tail.hip", "taxim_stream.hip", "taxim_shadow.hip", "fots_kernels.hip", "fem_kernels.hip", "depth_raster.hip", "tacex_capi.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=fast", "-Wno-unused-result"]
 # A/B hook for kernel tuning macros, e.g. TACEX_EXTRA_HIPCC_FLAGS="-DTACEX_MFMA_CH=2" (part of the build digest)
-FLAGS += os.environ.get("TACEX_EXTRA_HIPCC_FLAGS", "").split()
+if _TAG and "TACEX_EXTRA_HIPCC_FLAGS" not in os.environ and _FLAGS_FILE.exists():
+    FLAGS += _FLAGS_FILE.read_text().split()
+else:
+    FLAGS += os.environ.get("TACEX_EXTRA_HIPCC_FLAGS", "").split()
 # per-file flags (part of the digest): the streaming tail is scalar f32 FMA chains - SLP packing into v_pk_fma_f32 (half rate on
 # gfx950, scripts/hip_probes/valu_rates.hip) only adds register shuffles and pushed the kernel into scratch
 FILE_FLAGS = {"taxim_stream.hip": ["-fno-slp-vectorize"],
@@ -62,7 +70,7 @@ def build_library(force: bool = False, verbose: bool = False) -> Path:
 
 def _build_locked(dig: str, verbose: bool) -> Path:
     hipcc = _hipcc()
-    objdir = PKG / "build"
+    objdir = PKG / (f"build.{_TAG}" if _TAG else "build")
     objdir.mkdir(exist_ok=True)
     srcs = [CSRC / s for s in SOURCES if (CSRC / s).exists()]
     procs = []
@@ -85,6 +93,8 @@ def _build_locked(dig: str, verbose: bool) -> Path:
         raise RuntimeError(f"link failed:\n{r.stdout}")
     os.replace(tmp, LIB)
     STAMP.write_text(dig)
+    if _TAG:
+        _FLAGS_FILE.write_text(os.environ.get("TACEX_EXTRA_HIPCC_FLAGS", ""))
     return LIB
 
 

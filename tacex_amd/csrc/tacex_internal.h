@@ -140,12 +140,27 @@ bool stream_supported(int n_fused, int k0, int H, int W);
 bool stream_geometry(int n_fused, int k0, int W, int* nstrips, int* strip_w, int* lv_nstrips, int* lv_strip_w);
 int stream_segments(int B, int nstrips, int H, int warm_rows, int waves_per_simd);
 int stream_warm_rows(int n_fused, int k0, bool levels_kernel);
+int stream_waves_per_simd(int n_fused, int k0);
 // z_last: (B,H,W) scratch for the last level (split mode: the levels kernel writes it, the shading kernel reads it)
 hipError_t run_stream_tail(const LevelDesc* lv, int n_levels, int n_fused, const float* zin, const float* hm, const float* gel,
                            const float* sa, const float* sb, const float* pd, const ShadeParams* sp, float* rgb, float* z_last,
                            int B, int H, int W, float contact_scale, const StreamPlan& plan, float* obs_part,
-                           FotsReduce* fots_part, int fots_stride, float* pix_z, uint8_t* pix_m, hipStream_t st, const int* rows_ext = nullptr, int ext_grow = 0);
+                           FotsReduce* fots_part, int fots_stride, float* pix_z, uint8_t* pix_m, hipStream_t st, const int* rows_ext = nullptr, int ext_grow = 0,
+                           int* order_buf = nullptr,  // (B * strips * segments) device ints for the launch's item order (nullptr: frame order)
+                           int* cost_buf = nullptr, bool cost_valid = false);  // per-item clock ticks: written by this launch, sort key of the next
 hipError_t run_obs_finish_stream(const float* part, void* obs, bool u8, const StreamPlan& plan, int B, hipStream_t st);
+
+// More than 48 KB of dynamic LDS is an opt-in per kernel AND per device (one process may drive several GPUs): `granted` is the
+// per-kernel table (a function-local static at the launch site) of the largest size already granted on every device.
+inline hipError_t ensure_dynamic_lds(const void* kern, size_t lds, size_t (&granted)[64]) {
+  if (lds <= 48 * 1024) return hipSuccess;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+  if (lds <= granted[dev]) return hipSuccess;
+  hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e == hipSuccess) granted[dev] = lds;
+  return e;
+}
 
 // thread-local error string (tacex_last_error)
 void set_error(const char* fmt, ...);

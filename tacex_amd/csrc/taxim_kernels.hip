@@ -799,13 +799,8 @@ static hipError_t launch_band_nt(const BlurArgs& a0, hipStream_t st) {
   const int nbands = (a.H + TH - 1) / TH;
   const size_t lds = (size_t)(TH / 2) * a.pitch * sizeof(v2f);
   auto kern = blur_band_kernel<K, TH, RV, RH, FIRST, NT>;
-  static bool attr_done = false;
-  if (!attr_done && lds > 48 * 1024) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return e;
-    attr_done = true;
-  }
+  static size_t granted[64] = {};
+  if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds, granted); e != hipSuccess) return e;
   hipLaunchKernelGGL(kern, dim3(nbands * a.B), dim3(NT), lds, st, a);
   return hipGetLastError();
 }
@@ -830,12 +825,8 @@ static hipError_t launch_band_loop(const BlurArgs& a0, int K, hipStream_t st) {
   const int nbands = (a.H + TH - 1) / TH;
   const size_t lds = (size_t)(TH / 2) * a.pitch * sizeof(v2f);
   auto kern = blur_band_loop_kernel<TH, RV, RH, G, FIRST, NT>;
-  static bool attr_done = false;
-  if (!attr_done && lds > 48 * 1024) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return e;
-    attr_done = true;
-  }
+  static size_t granted[64] = {};
+  if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds, granted); e != hipSuccess) return e;
   hipLaunchKernelGGL(kern, dim3(nbands * a.B), dim3(NT), lds, st, a, K);
   return hipGetLastError();
 }

@@ -244,12 +244,8 @@ static hipError_t launch_mfma_tiles(BlurArgs a, int row0, int nbands, hipStream_
   static const size_t lds_pad = getenv("TACEX_MFMA_LDS_PAD") ? (size_t)atoi(getenv("TACEX_MFMA_LDS_PAD")) * 1024 : 0;  // occupancy A/B hook
   const size_t lds = (size_t)TH * a.pitch * sizeof(float) + lds_pad;
   auto kern = blur_mfma_kernel<K, FIRST, NTILE, GZ>;
-  static size_t attr_lds = 0;
-  if (lds > 48 * 1024 && lds > attr_lds) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return e;
-    attr_lds = lds;
-  }
+  static size_t granted[64] = {};
+  if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds, granted); e != hipSuccess) return e;
   hipLaunchKernelGGL(kern, dim3(nbands * a.B), dim3(a.W), lds, st, a);
   return hipGetLastError();
 }

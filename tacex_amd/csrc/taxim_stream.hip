@@ -38,7 +38,6 @@
 namespace tacex {
 
 constexpr int kStreamPx = 3;         // pixels per lane
-constexpr int kStreamRing = 8;       // rows of S kept per wave (deepest restore looks back sum(R) - R_last rows <= 7)
 constexpr int kStreamWaves = 4;      // waves per workgroup (independent of each other)
 constexpr int kStreamObsActive = 3;  // observation rows a frame row can contribute to (down-sampling factor >= 2)
 
@@ -76,6 +75,8 @@ struct StreamArgs {
   const int* mk_id;         // marker index
   const int* rows_ext;      // (B,2) contact row range of every frame (frame_rows_kernel), nullable
   int ext_grow;             // rows by which the band levels have spread the non-zero range of zin beyond it
+  const int* order;         // (B * nstrips * nseg) item of every launched wave, heaviest first (stream_order_kernel); nullptr: identity
+  int* cost;                // (B * nstrips * nseg) clock ticks every item took in THIS launch (the next launch's sort key), nullable
 };
 
 __device__ __forceinline__ float dpp_from_left(float v) {   // lane i receives lane i-1's value
@@ -112,15 +113,18 @@ typedef float v3f __attribute__((ext_vector_type(3)));
 constexpr int kStreamObsLdsFloats = 448;
 constexpr int kStreamObsMaxCols = 64;
 constexpr size_t kStreamStageBytes = 64 * kStreamPx * 3 * 4;  // one row of 3 floats per pixel (background in / RGB out)
-// workgroup-shared copy of the polynomial records of magnitude bin 0 ([id][28] floats: 24 padded to 28 so that 16 lanes with
-// distinct direction bins read 16 distinct 16-byte bank slots).  Nearly all pixels outside a contact - and there the direction
+// workgroup-shared copy of the polynomial records of magnitude bin 0 ([id][20] floats = the five 16-byte pieces the polynomial
+// reads: an ODD number of 16-byte bank slots per record, so lanes with consecutive direction bins read distinct slots).  Nearly all pixels outside a contact - and there the direction
 // bin still varies from pixel to pixel - gather their record from here instead of through the vector L1 (the table gathers were
 // 2/3 of the fused kernel's TCP_TOTAL_CACHE_ACCESSES: 636 per row and wave).
-constexpr int kStreamPolyPitch = 28;
+constexpr int kStreamPolyPitch = 20;
 constexpr int kStreamPolyMaxBins = 128;
 constexpr size_t kStreamLdsShared = (size_t)kStreamPolyMaxBins * kStreamPolyPitch * 4;
 
 enum { kStreamFused = 0, kStreamLevels = 1, kStreamShade = 2 };
+#ifndef TACEX_STREAM3_WAVES
+#define TACEX_STREAM3_WAVES 3
+#endif
 
 // ROLE: kStreamFused  - levels + shading in one kernel (one wave keeps ~240 registers: two waves per SIMD) - the default
 //       kStreamLevels - levels only: writes the last level (B,H,W) + the FOTS by-products; lean (four waves per SIMD)
@@ -141,24 +145,52 @@ struct StreamCfg {
   static constexpr int HL = (HALO + kStreamPx - 1) / kStreamPx;         // halo lanes per side
   static constexpr int VW = (64 - 2 * HL) * kStreamPx;                  // widest valid strip
   static constexpr int last_r() { return NL > 0 ? R(NL - 1) : 0; }
-  static_assert(sum_r() - last_r() < kStreamRing, "restore ring too shallow");
-  // wave-private LDS: S ring [kStreamRing][64] float4 (restores) | observation staging row | column-filter window weights
+  // waves per SIMD the kernel is compiled for: the lean levels kernel 4 (<= 128 VGPRs), the shading kernel 3 (<= 168), the
+  // fused kernel 2 with four levels and TACEX_STREAM3_WAVES (3) with the three-level tail <5,3,5> (k = 9 left to a band level:
+  // 24 fewer partial sums, a 12-row instead of a 20-row warm-up)
+  static constexpr int min_waves() { return ROLE == kStreamLevels ? 4 : (ROLE == kStreamShade ? 3 : (sum_r() <= 5 ? TACEX_STREAM3_WAVES : 2)); }
+  // S ring of the masked restores: the deepest restore (level NL-2) looks back sum(R) - R_last rows, and an iteration READS its
+  // rows before it WRITES its own, so exactly that many rows are kept.  Two-wave kernels keep 16-byte records (one ds_read_b128
+  // per restore); the three-wave kernel packs 12-byte records (read2_b32 + b32) to fit three workgroups into a CU's 160 KB.
+  static constexpr int ring_rows() { return sum_r() - last_r() > 0 ? sum_r() - last_r() : 1; }
+  static constexpr bool ring_packed() { return min_waves() >= 3; }
+  // wave-private LDS: S ring [ring_rows][64] (restores) | observation staging row | column-filter window weights
   // [obs_ncols][obs_kxp] | window start per column
-  static constexpr size_t ring_bytes() { return NL > 1 ? (size_t)kStreamRing * 64 * 16 : 0; }
+  static constexpr size_t ring_bytes() { return NL > 1 ? (size_t)ring_rows() * 64 * (ring_packed() ? 12 : 16) : 0; }
   static constexpr size_t shade_bytes() { return SHADE ? kStreamStageBytes + kStreamObsLdsFloats * 4 + kStreamObsMaxCols * 4 : 0; }
   // input rows land in a two-slot ring straight from memory (global_load_lds_dwordx3: 16-byte lane stride): [slot][z | hm][64 x 4]
   static constexpr size_t rows_bytes() { return (size_t)2 * (NL > 0 ? 2 : 1) * 64 * 16; }
   static constexpr size_t lds_per_wave() { return ring_bytes() + shade_bytes() + rows_bytes(); }
   static constexpr size_t lds_shared() { return SHADE ? kStreamLdsShared : 0; }
   static constexpr size_t lds_bytes() { return lds_shared() + kStreamWaves * lds_per_wave(); }
+  static_assert(lds_per_wave() % 16 == 0, "wave-private LDS blocks must stay 16-byte aligned");
+  static_assert(min_waves() < 3 || 3 * lds_bytes() <= 160 * 1024, "three workgroups per CU need <= 53.3 KB of LDS each");
 };
 
-// register budget per role (waves per SIMD the kernel is compiled for): the lean levels kernel 4 (<= 128 VGPRs), the shading
-// kernel 3 (<= 168), the fused one 2
-constexpr int stream_min_waves(int role) { return role == kStreamLevels ? 4 : (role == kStreamShade ? 3 : 2); }
+struct __attribute__((packed, aligned(4))) StreamS3 { float x, y, z; };
 
-template <bool GZ, int ROLE, int... KS>
-__global__ __launch_bounds__(64 * kStreamWaves, stream_min_waves(ROLE)) void taxim_stream_kernel(StreamArgs a) {
+// the 18 coefficients of one table record: four 16-byte pieces and one 8-byte piece (18 registers, not 20)
+struct StreamRec { v4f c0, c1, c2, c3; v2f c4; };
+__device__ __forceinline__ StreamRec stream_rec_load(const float* p) {  // p 16-byte aligned (global table or the LDS copy)
+  StreamRec r;
+  const v4f* q = reinterpret_cast<const v4f*>(p);
+  r.c0 = q[0]; r.c1 = q[1]; r.c2 = q[2]; r.c3 = q[3];
+  r.c4 = *reinterpret_cast<const v2f*>(p + 16);
+  return r;
+}
+// I_c = sum_k f_k(X, Y) p_{c,k}, f = [X^2, Y^2, XY, X, Y, 1] (TT:148-157, 250-255)
+__device__ __forceinline__ void stream_poly(float X, float Y, const StreamRec& r, float& p0, float& p1, float& p2) {
+  const v4f c0 = r.c0, c1 = r.c1, c2 = r.c2, c3 = r.c3;
+  const v2f c4 = r.c4;
+  const float f0 = X * X, f1 = Y * Y, f2 = X * Y;
+  p0 = fmaf(f0, c0.x, fmaf(f1, c0.y, fmaf(f2, c0.z, fmaf(X, c0.w, fmaf(Y, c1.x, c1.y)))));
+  p1 = fmaf(f0, c1.z, fmaf(f1, c1.w, fmaf(f2, c2.x, fmaf(X, c2.y, fmaf(Y, c2.z, c2.w)))));
+  p2 = fmaf(f0, c3.x, fmaf(f1, c3.y, fmaf(f2, c3.z, fmaf(X, c3.w, fmaf(Y, c4.x, c4.y)))));
+}
+
+// MINW = StreamCfg<ROLE, KS...>::min_waves() (a pack cannot be expanded inside the launch-bounds attribute)
+template <bool GZ, int ROLE, int MINW, int... KS>
+__global__ __launch_bounds__(64 * kStreamWaves, MINW) void taxim_stream_kernel(StreamArgs a) {
   using C = StreamCfg<ROLE, KS...>;
   constexpr int NL = C::NL, PX = kStreamPx, SUMR = C::sum_r(), HL = C::HL;
   constexpr bool SHADE = C::SHADE, LEVELS = NL > 0;
@@ -166,21 +198,30 @@ __global__ __launch_bounds__(64 * kStreamWaves, stream_min_waves(ROLE)) void tax
   const int lane = threadIdx.x & 63;
   const int wv_in_blk = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int per_frame = a.nstrips * a.nseg;
-  const int wv = blockIdx.x * kStreamWaves + wv_in_blk;
   float* const polyL = reinterpret_cast<float*>(smem_raw);
   int nb_lds = 0;  // table records [0, nb_lds) are LDS-resident
   if constexpr (SHADE) {  // magnitude-bin-0 records -> LDS (all waves of the workgroup, before any of them may leave)
     const int nb = a.sh.nb;
     if (nb <= kStreamPolyMaxBins) {
       nb_lds = nb;
-      for (int j = threadIdx.x; j < nb * 6; j += 64 * kStreamWaves) {  // 6 x 16 bytes per record
-        const int id = j / 6, k = j - id * 6;
+      for (int j = threadIdx.x; j < nb * 5; j += 64 * kStreamWaves) {  // 5 x 16 bytes per record (floats 18, 19 are padding)
+        const int id = j / 5, k = j - id * 5;
         *reinterpret_cast<v4f*>(polyL + id * kStreamPolyPitch + 4 * k) = *reinterpret_cast<const v4f*>(a.sh.poly + (size_t)id * 24 + 4 * k);
       }
     }
     __syncthreads();
   }
-  if (wv >= a.B * per_frame) return;
+  // Work distribution.  An item = one (frame, strip, row segment) = one wave.  Items differ by up to 3x (flat waves; rows
+  // through a contact gather table records and run the magnitude arc tangent), a workgroup slot stays occupied until the
+  // slowest of its four waves is done, and with items in frame order 27 % of the wave-slot time of a launch was idle
+  // (SQ_WAVE_CYCLES against GRBM_GUI_ACTIVE, profiles/r03_experiments.md).  stream_order_kernel therefore sorts the items by
+  // the number of contact rows in their segment, heaviest first: the four waves of a workgroup get items of equal weight and
+  // the light ones fill the tail of the launch (longest-processing-time-first).
+  const int n_items = a.B * per_frame;
+  const int slot = blockIdx.x * kStreamWaves + wv_in_blk;
+  if (slot >= n_items) return;
+  const int wv = a.order != nullptr ? __builtin_amdgcn_readfirstlane(a.order[slot]) : slot;
+  const unsigned t_start = (unsigned)__builtin_readcyclecounter();
   const int frame = wv / per_frame;
   const int rem = wv - frame * per_frame;
   const int strip = rem / a.nseg, seg = rem - strip * a.nseg;
@@ -190,6 +231,8 @@ __global__ __launch_bounds__(64 * kStreamWaves, stream_min_waves(ROLE)) void tax
   const int cx0 = vx0 - HL * PX;                                   // column of lane 0, pixel 0
   char* lds = smem_raw + C::lds_shared() + (size_t)wv_in_blk * C::lds_per_wave();
   v4f* ring = reinterpret_cast<v4f*>(lds);
+  StreamS3* ring3 = reinterpret_cast<StreamS3*>(lds);
+  constexpr int NRING = C::ring_rows();
   float* obs_row = reinterpret_cast<float*>(lds + C::ring_bytes());  // [64 * PX * 3] observation staging row
   float* obs_wl = obs_row + 64 * PX * 3;                              // [nq][kxp] window weights
   int* obs_xb = reinterpret_cast<int*>(obs_wl + kStreamObsLdsFloats);  // [nq] first staging pixel of the window
@@ -400,16 +443,13 @@ __global__ __launch_bounds__(64 * kStreamWaves, stream_min_waves(ROLE)) void tax
 
   // one finished frame row: polynomial of every pixel's table record (TT:250-255) + background + clip (TT:257-258), the RGB
   // store and the row's share of the policy observation
-  auto emit_row = [&](int e, const StreamRowInfo& ri, const v3f (&bq)[PX], const v4f (&pc)[PX][5]) {
+  auto emit_row = [&](int e, const StreamRowInfo& ri, const v3f (&bq)[PX], const StreamRec (&pc)[PX]) {
     const float Y = ri.fy;
     float rgb[PX * 3];
 #pragma unroll
     for (int i = 0; i < PX; ++i) {
-      const v4f c0 = pc[i][0], c1 = pc[i][1], c2 = pc[i][2], c3 = pc[i][3], c4 = pc[i][4];
-      const float f0 = X[i] * X[i], f1 = Y * Y, f2 = X[i] * Y;
-      const float p0 = fmaf(f0, c0.x, fmaf(f1, c0.y, fmaf(f2, c0.z, fmaf(X[i], c0.w, fmaf(Y, c1.x, c1.y)))));
-      const float p1 = fmaf(f0, c1.z, fmaf(f1, c1.w, fmaf(f2, c2.x, fmaf(X[i], c2.y, fmaf(Y, c2.z, c2.w)))));
-      const float p2 = fmaf(f0, c3.x, fmaf(f1, c3.y, fmaf(f2, c3.z, fmaf(X[i], c3.w, fmaf(Y, c4.x, c4.y)))));
+      float p0, p1, p2;
+      stream_poly(X[i], Y, pc[i], p0, p1, p2);
       rgb[3 * i + 0] = __builtin_amdgcn_fmed3f(p0 + bq[i].x, 0.0f, 1.0f);  // TT:257-258
       rgb[3 * i + 1] = __builtin_amdgcn_fmed3f(p1 + bq[i].y, 0.0f, 1.0f);
       rgb[3 * i + 2] = __builtin_amdgcn_fmed3f(p2 + bq[i].z, 0.0f, 1.0f);
@@ -458,15 +498,11 @@ __global__ __launch_bounds__(64 * kStreamWaves, stream_min_waves(ROLE)) void tax
     }
     if (flat) {
       const int code = shade_dir_bin(a.sh, 0.0f, 0.0f, 0.0f);  // magnitude bin 0
-      v4f pcf[PX][5];
-      if (code < nb_lds) {
-        const v4f* pl = reinterpret_cast<const v4f*>(polyL + code * kStreamPolyPitch);
+      StreamRec pcf[PX];
+      {
+        const StreamRec rf = stream_rec_load(code < nb_lds ? polyL + code * kStreamPolyPitch : a.sh.poly + (size_t)code * 24);
 #pragma unroll
-        for (int i = 0; i < PX; ++i) { pcf[i][0] = pl[0]; pcf[i][1] = pl[1]; pcf[i][2] = pl[2]; pcf[i][3] = pl[3]; pcf[i][4] = pl[4]; }
-      } else {
-        const v4f* pp = reinterpret_cast<const v4f*>(reinterpret_cast<const char*>(a.sh.poly) + (unsigned)code * 96u);
-#pragma unroll
-        for (int i = 0; i < PX; ++i) { pcf[i][0] = pp[0]; pcf[i][1] = pp[1]; pcf[i][2] = pp[2]; pcf[i][3] = pp[3]; pcf[i][4] = pp[4]; }
+        for (int i = 0; i < PX; ++i) pcf[i] = rf;
       }
       if (do_fots) {
         if (a.pix_z != nullptr || a.pix_m != nullptr) {  // marker taps of this wave's rows: deformed gel 0, no contact
@@ -530,6 +566,7 @@ __global__ __launch_bounds__(64 * kStreamWaves, stream_min_waves(ROLE)) void tax
 #ifdef TACEX_STREAM_CLOCK
   float clk_acc[4] = {0.f, 0.f, 0.f, 0.f};
 #endif
+  int ring_slot = ((ys % NRING) + NRING) % NRING;  // ring slot of row y (wave-uniform, advanced once per iteration)
   for (int y = flat ? ye + 1 : ys; y <= ye; ++y) {
     // ---- row y out of the ring (it landed before the previous iteration's mid_point returned); next iteration's row scalars ----
 #ifdef TACEX_STREAM_CLOCK
@@ -559,11 +596,13 @@ __global__ __launch_bounds__(64 * kStreamWaves, stream_min_waves(ROLE)) void tax
     const int gs = y - SUMR - 2;
     const bool shade_now = SHADE && gs >= max(r0, 1) && gs <= min(r1 - 1, H - 2);
     int cc[PX] = {0, 0, 0};  // table record (bin pair) of every pixel of row gs
-    v4f pc[PX][5];           // its 18 polynomial coefficients (TT:250-255), fetched at the top of the iteration
+    StreamRec pc[PX];        // its 18 polynomial coefficients (TT:250-255), fetched at the top of the iteration
     auto fetch_table = [&]() {
       // Table records: magnitude bin 0 (code < nb) from the workgroup's LDS copy - every lane reads (clamped index) - then the
       // lanes of contact pixels overwrite theirs with a gather from the table in L2; row segments without such a lane (most
-      // of them) issue no vector-memory instruction for the table at all.
+      // of them) issue no vector-memory instruction for the table at all.  (Compacting the contact pixels of a row into one
+      // dense gather - five instructions for up to 64 pixels instead of five per pixel slot, the polynomial values handed
+      // back through LDS - was built and measured in round 3: equal within noise, profiles/r03_experiments.md; not kept.)
       bool hi[PX];
 #pragma unroll
       for (int i = 0; i < PX; ++i) {
@@ -571,23 +610,12 @@ __global__ __launch_bounds__(64 * kStreamWaves, stream_min_waves(ROLE)) void tax
 #ifdef TACEX_DBG_NO_GATHER
         hi[i] = false;
 #endif
-#ifdef TACEX_DBG_GATHER_ALL  // timing probe: every valid lane gathers (cost vs active lanes)
-        hi[i] = valid[i];
-#endif
-        const v4f* pl = reinterpret_cast<const v4f*>(polyL + (hi[i] ? 0 : cc[i]) * kStreamPolyPitch);
-        pc[i][0] = pl[0]; pc[i][1] = pl[1]; pc[i][2] = pl[2]; pc[i][3] = pl[3]; pc[i][4] = pl[4];
+        pc[i] = stream_rec_load(polyL + (hi[i] ? 0 : cc[i]) * kStreamPolyPitch);
       }
       if (__builtin_amdgcn_ballot_w64(hi[0] || hi[1] || hi[2]) != 0) {
 #pragma unroll
         for (int i = 0; i < PX; ++i)
-          if (hi[i]) {
-            const v4f* __restrict__ pp = reinterpret_cast<const v4f*>(reinterpret_cast<const char*>(a.sh.poly) + (unsigned)cc[i] * 96u);
-#ifdef TACEX_DBG_GATHER_ONE  // timing probe (wrong colours): one 16-byte piece per contact pixel instead of five
-            pc[i][0] = pp[0];
-#else
-            pc[i][0] = pp[0]; pc[i][1] = pp[1]; pc[i][2] = pp[2]; pc[i][3] = pp[3]; pc[i][4] = pp[4];
-#endif
-          }
+          if (hi[i]) pc[i] = stream_rec_load(reinterpret_cast<const float*>(reinterpret_cast<const char*>(a.sh.poly) + (unsigned)cc[i] * 96u));
       }
     };
     auto shade_part1 = [&]() {
@@ -634,12 +662,22 @@ __global__ __launch_bounds__(64 * kStreamWaves, stream_min_waves(ROLE)) void tax
       for (int i = 0; i < PX; ++i) S[i] = (hc[i] - sa) - sb;  // TT:441
       v4f Sring[NL > 1 ? NL - 1 : 1];
       if constexpr (NL > 1) {
-        ring[(y & (kStreamRing - 1)) * 64 + lane] = (v4f){S[0], S[1], S[2], 0.0f};
-        // S of the rows the restores of this iteration need (written 4..7 iterations ago): all ring reads issued up front
+        // S of the rows the restores of this iteration need (written delay(l) iterations ago): all ring reads issued up front,
+        // then this row's S takes the slot of the oldest one (LDS accesses of one wave execute in program order)
         static_for<0, NL - 1>([&](auto lc) {
           constexpr int l = decltype(lc)::value;
-          Sring[l] = ring[((y - C::delay(l)) & (kStreamRing - 1)) * 64 + lane];
+          int sl = ring_slot - C::delay(l);
+          sl += sl < 0 ? NRING : 0;
+          if constexpr (C::ring_packed()) {
+            const StreamS3 q = ring3[sl * 64 + lane];
+            Sring[l] = (v4f){q.x, q.y, q.z, 0.0f};
+          } else {
+            Sring[l] = ring[sl * 64 + lane];
+          }
         });
+        if constexpr (C::ring_packed()) ring3[ring_slot * 64 + lane] = StreamS3{S[0], S[1], S[2]};
+        else ring[ring_slot * 64 + lane] = (v4f){S[0], S[1], S[2], 0.0f};
+        ring_slot = ring_slot + 1 == NRING ? 0 : ring_slot + 1;
       }
       if (do_fots && y >= r0 && y < r1) {
         float gl[PX] = {0.f, 0.f, 0.f};
@@ -803,9 +841,9 @@ __global__ __launch_bounds__(64 * kStreamWaves, stream_min_waves(ROLE)) void tax
         ck1 = __builtin_readcyclecounter();
 #endif
         // results of the plain loads are taken HERE (see mid_point)
-        asm volatile("" : "+v"(pc[0][0]), "+v"(pc[0][1]), "+v"(pc[0][2]), "+v"(pc[0][3]), "+v"(pc[0][4]), "+v"(pc[1][0]), "+v"(pc[1][1]),
-                     "+v"(pc[1][2]), "+v"(pc[1][3]), "+v"(pc[1][4]));
-        asm volatile("" : "+v"(pc[2][0]), "+v"(pc[2][1]), "+v"(pc[2][2]), "+v"(pc[2][3]), "+v"(pc[2][4]), "+v"(bgq[0]), "+v"(bgq[1]),
+        asm volatile("" : "+v"(pc[0].c0), "+v"(pc[0].c1), "+v"(pc[0].c2), "+v"(pc[0].c3), "+v"(pc[0].c4), "+v"(pc[1].c0), "+v"(pc[1].c1),
+                     "+v"(pc[1].c2), "+v"(pc[1].c3), "+v"(pc[1].c4));
+        asm volatile("" : "+v"(pc[2].c0), "+v"(pc[2].c1), "+v"(pc[2].c2), "+v"(pc[2].c3), "+v"(pc[2].c4), "+v"(bgq[0]), "+v"(bgq[1]),
                      "+v"(bgq[2]));
       }
       mid_point();
@@ -865,6 +903,51 @@ __global__ __launch_bounds__(64 * kStreamWaves, stream_min_waves(ROLE)) void tax
       for (int s2 = per_frame + lane; s2 < a.fots_stride; s2 += 64) a.fots_part[(size_t)frame * a.fots_stride + s2] = id;
     }
   }
+  if (a.cost != nullptr && lane == 0) a.cost[wv] = (int)(((unsigned)__builtin_readcyclecounter() - t_start) >> 4);
+}
+
+// Items of a launch sorted by weight, heaviest first.  The key is what the item COST in the previous launch of the same shard
+// (clock ticks written by the kernel itself: contacts move little from one simulation step to the next, and a stale key only
+// costs balance, never correctness); the first launch of a shard uses a geometric estimate instead: the rows of the item's
+// segment that lie on (or within a few rows of) the frame's contact rows - there the shading gathers table records and runs
+// the magnitude arc tangent - 0 for a flat item (no contact within the pyramid's reach: no levels, no bins).  Counting sort by
+// one workgroup; the order inside a bucket is whatever the atomics give (every item's output is independent of where it runs).
+__global__ __launch_bounds__(1024) void stream_order_kernel(const int* __restrict__ rows_ext, const int* __restrict__ cost, int n_items,
+                                                            int per_frame, int nseg, int seg_rows, int H, int reach, int* __restrict__ order) {
+  constexpr int kKeys = 1024;
+  __shared__ int hist[kKeys], start[kKeys], red[16];
+  for (int k = threadIdx.x; k < kKeys; k += blockDim.x) hist[k] = 0;
+  // measured costs: scaled so that the longest item of the previous launch gets the last key
+  float scale = 0.0f;
+  if (cost != nullptr) {
+    int mx = 0;
+    for (int i = threadIdx.x; i < n_items; i += blockDim.x) mx = max(mx, cost[i]);
+    for (int o = 32; o > 0; o >>= 1) mx = max(mx, __shfl_xor(mx, o, 64));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mx;
+    __syncthreads();
+    mx = 0;
+    for (int w = 0; w < 16; ++w) mx = max(mx, red[w]);
+    scale = mx > 0 ? (float)(kKeys - 1) / (float)mx : 0.0f;
+  }
+  __syncthreads();
+  auto key_of = [&](int item) {
+    if (cost != nullptr) return min(kKeys - 1, max(0, (int)((float)cost[item] * scale)));
+    const int frame = item / per_frame, seg = (item - frame * per_frame) % nseg;
+    const int r0 = seg * seg_rows, r1 = min(H, r0 + seg_rows);
+    const int lo = rows_ext[2 * frame], hi = rows_ext[2 * frame + 1];
+    if ((r0 - reach > hi) || (r1 + reach < lo)) return 0;  // flat (frames without contact: lo = H, hi = -1)
+    const int pad = 4;
+    const int c = min(r1 - 1, hi + pad) - max(r0, lo - pad) + 1;
+    return min(kKeys - 1, 1 + max(c, 0));
+  };
+  for (int i = threadIdx.x; i < n_items; i += blockDim.x) atomicAdd(&hist[key_of(i)], 1);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int acc = 0;
+    for (int k = kKeys - 1; k >= 0; --k) { start[k] = acc; acc += hist[k]; }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < n_items; i += blockDim.x) order[atomicAdd(&start[key_of(i)], 1)] = i;
 }
 
 // adds the per-(strip, segment) partial sums of every observation cell in a fixed order and normalises by the weight sums
@@ -918,6 +1001,7 @@ static bool stream_geometry_t(int W, int* nstrips, int* strip_w) {
 static int stream_variant(int n_fused, int k0) {
   if (n_fused == 4 && k0 == 9) return 0;   // <9,5,3,5>  320x240
   if (n_fused == 3 && k0 == 9) return 1;   // <9,5,9>    640x480 (k = 15 stays a band level)
+  if (n_fused == 3 && k0 == 5) return 2;   // <5,3,5>    320x240 with k = 9 as a band level (three waves per SIMD)
   return -1;
 }
 
@@ -939,9 +1023,12 @@ bool stream_geometry(int n_fused, int k0, int W, int* nstrips, int* strip_w, int
   if (stream_split()) {
     if (!stream_geometry_t<kStreamShade>(W, nstrips, strip_w)) return false;
     return v == 0 ? stream_geometry_t<kStreamLevels, 9, 5, 3, 5>(W, lv_nstrips, lv_strip_w)
-                  : stream_geometry_t<kStreamLevels, 9, 5, 9>(W, lv_nstrips, lv_strip_w);
+         : v == 1 ? stream_geometry_t<kStreamLevels, 9, 5, 9>(W, lv_nstrips, lv_strip_w)
+                  : stream_geometry_t<kStreamLevels, 5, 3, 5>(W, lv_nstrips, lv_strip_w);
   }
-  const bool ok = v == 0 ? stream_geometry_t<kStreamFused, 9, 5, 3, 5>(W, nstrips, strip_w) : stream_geometry_t<kStreamFused, 9, 5, 9>(W, nstrips, strip_w);
+  const bool ok = v == 0 ? stream_geometry_t<kStreamFused, 9, 5, 3, 5>(W, nstrips, strip_w)
+                : v == 1 ? stream_geometry_t<kStreamFused, 9, 5, 9>(W, nstrips, strip_w)
+                         : stream_geometry_t<kStreamFused, 5, 3, 5>(W, nstrips, strip_w);
   *lv_nstrips = *nstrips; *lv_strip_w = *strip_w;
   return ok;
 }
@@ -957,9 +1044,12 @@ int stream_segments(int B, int nstrips, int H, int warm, int per_simd) {
   while (nseg > 1 && (H / nseg < min_rows || H - (nseg - 1) * ((H + nseg - 1) / nseg) < 4)) --nseg;
   return nseg;
 }
+// waves per SIMD the fused kernel of this level set is compiled for (sizes the segment count: a launch should bring a whole
+// number of resident rounds)
+int stream_waves_per_simd(int n_fused, int k0) { return stream_variant(n_fused, k0) == 2 ? TACEX_STREAM3_WAVES : 2; }
 int stream_warm_rows(int n_fused, int k0, bool levels_kernel) {
   const int v = stream_variant(n_fused, k0);
-  const int sum_r = v == 0 ? 9 : 10;
+  const int sum_r = v == 0 ? 9 : (v == 1 ? 10 : 5);
   if (!stream_split()) return 2 * sum_r + 2;
   return levels_kernel ? 2 * sum_r : 2;
 }
@@ -968,20 +1058,13 @@ template <bool GZ, int ROLE, int... KS>
 static hipError_t launch_stream_k(const StreamArgs& a, hipStream_t st) {
   using C = StreamCfg<ROLE, KS...>;
   const int waves = a.B * a.nstrips * a.nseg;
-  const dim3 grid((waves + kStreamWaves - 1) / kStreamWaves);
+  const int nwg = (waves + kStreamWaves - 1) / kStreamWaves;
+  const dim3 grid(nwg);
   static const size_t lds_pad = getenv("TACEX_STREAM_LDS_PAD") ? (size_t)atoi(getenv("TACEX_STREAM_LDS_PAD")) : 0;  // occupancy A/B hook
   const size_t lds = C::lds_bytes() + lds_pad;
-  auto kern = taxim_stream_kernel<GZ, ROLE, KS...>;
-  if (lds > 64 * 1024) {  // > 64 KB of dynamic LDS is an opt-in per kernel AND device (one flag per device)
-    static bool attr_done[64] = {};
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
-    if (!attr_done[dev]) {
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      if (e != hipSuccess) return e;
-      attr_done[dev] = true;
-    }
-  }
+  auto kern = taxim_stream_kernel<GZ, ROLE, C::min_waves(), KS...>;
+  static size_t granted[64] = {};  // per kernel instantiation and device
+  if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds, granted); e != hipSuccess) return e;
   hipLaunchKernelGGL(kern, grid, dim3(64 * kStreamWaves), lds, st, a);
   return hipGetLastError();
 }
@@ -995,7 +1078,9 @@ hipError_t run_stream_tail(const LevelDesc* lv, int n_levels, int n_fused, const
                            const float* sa, const float* sb, const float* pd, const ShadeParams* sp, float* rgb, float* z_last,
                            int B, int H, int W, float contact_scale, const StreamPlan& plan, float* obs_part,
                            FotsReduce* fots_part, int fots_stride, float* pix_z, uint8_t* pix_m, hipStream_t st,
-                           const int* rows_ext, int ext_grow) {
+                           const int* rows_ext, int ext_grow, int* order_buf, int* cost_buf, bool cost_valid) {
+  // TACEX_STREAM_ORDER=0: items in frame order (A/B path); the split kernels always run that way
+  static const int sorted = getenv("TACEX_STREAM_ORDER") ? atoi(getenv("TACEX_STREAM_ORDER")) : 1;
   StreamArgs a{};
   a.rows_ext = lv[0].gel_zero ? rows_ext : nullptr; a.ext_grow = ext_grow;
   a.zin = zin; a.hm = hm; a.gel = lv[0].gel_zero ? nullptr : gel; a.shift_a = sa; a.shift_b = sb; a.pdepth = pd;
@@ -1032,13 +1117,27 @@ hipError_t run_stream_tail(const LevelDesc* lv, int n_levels, int n_fused, const
   const int v = stream_variant(n_fused, lv[n_levels - n_fused].kw);
   const bool gz = lv[0].gel_zero;
   if (!stream_split()) {
+    if (sorted && order_buf && gz && rows_ext) {  // heaviest items first (see the kernel's "work distribution" note)
+      const int n_items = B * sh.nstrips * sh.nseg;
+      const int sum_r = v == 0 ? 9 : (v == 1 ? 10 : 5);
+      static const int use_cost = getenv("TACEX_STREAM_ORDER_COST") ? atoi(getenv("TACEX_STREAM_ORDER_COST")) : 1;
+      hipLaunchKernelGGL(stream_order_kernel, dim3(1), dim3(1024), 0, st, rows_ext,
+                         (use_cost && cost_buf && cost_valid) ? cost_buf : nullptr, n_items, sh.nstrips * sh.nseg, sh.nseg, sh.seg_rows, H,
+                         ext_grow + sum_r + 1, order_buf);
+      hipError_t e = hipGetLastError();
+      if (e != hipSuccess) return e;
+      sh.order = order_buf;
+      sh.cost = use_cost ? cost_buf : nullptr;
+    }
     if (v == 0) return launch_stream<kStreamFused, 9, 5, 3, 5>(sh, gz, st);
     if (v == 1) return launch_stream<kStreamFused, 9, 5, 9>(sh, gz, st);
+    if (v == 2) return launch_stream<kStreamFused, 5, 3, 5>(sh, gz, st);
     return hipErrorInvalidValue;
   }
   if (!z_last) return hipErrorInvalidValue;
   lvl.z_out = z_last;
-  hipError_t e = v == 0 ? launch_stream<kStreamLevels, 9, 5, 3, 5>(lvl, gz, st) : launch_stream<kStreamLevels, 9, 5, 9>(lvl, gz, st);
+  hipError_t e = v == 0 ? launch_stream<kStreamLevels, 9, 5, 3, 5>(lvl, gz, st)
+               : v == 1 ? launch_stream<kStreamLevels, 9, 5, 9>(lvl, gz, st) : launch_stream<kStreamLevels, 5, 3, 5>(lvl, gz, st);
   if (e != hipSuccess) return e;
   sh.zin = z_last;
   return launch_stream<kStreamShade>(sh, true, st);
