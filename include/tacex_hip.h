@@ -32,7 +32,7 @@ extern "C" {
 #endif
 
 #define TACEX_MAX_LEVELS 8
-#define TACEX_ABI_VERSION 4
+#define TACEX_ABI_VERSION 5
 
 typedef struct tacex_taxim_ctx tacex_taxim_ctx;
 typedef struct tacex_fots_ctx tacex_fots_ctx;
@@ -362,19 +362,46 @@ int tacex_fem_gradient(tacex_fem_ctx* ctx, const double* x_dev, const double* x_
 int tacex_fem_set_contact(tacex_fem_ctx* ctx, const double* vertex_area_host, double d_hat, double stiffness,
                           const double* indenters_dev);
 
-/* Device-side convergence for repeated Newton launches: dx_dev (num_envs,) f64 holds max|dx| of each env's last accepted
- * update (the caller fills it with +inf at the start of a time step); an env whose value is <= dx_tol (= velocity_tol * dt,
- * US:62-66) returns at once from the next tacex_fem_newton_step, so extra iterations cost nothing and no host round trip
- * is needed to stop them.  nullptr disables.  (CU-resident kernel only.) */
+/* Two-level preconditioner of the Newton system (CU-resident kernel): z = D^-1 r (3x3 block Jacobi, always) + P A_c^-1 P^T r.
+ * P: every vertex has 8 (coarse node, weight) pairs - the trilinear hat functions of a small grid laid over the mesh
+ * (vertex_nodes_host (V,8) int32 in [0, num_coarse), vertex_weights_host (V,8) f64 >= 0, rows summing to 1; unused slots weight 0);
+ * coarse_inverse_host (3 num_coarse, 3 num_coarse) f64 = inverse of P^T A_0 P with A_0 = M (1 + s C) + dt^2 K(rest state), built
+ * by the caller (UipcSim does it from tacex_fem_element_terms at the rest state and the constraint flags; constant per mesh
+ * and constraint set).  num_coarse <= 64; 0 switches the coarse correction off.  Tables are copied. */
+int tacex_fem_set_coarse_space(tacex_fem_ctx* ctx, int num_coarse, const int32_t* vertex_nodes_host,
+                               const double* vertex_weights_host, const double* coarse_inverse_host);
+
+/* Device-side convergence for repeated Newton launches: dx_dev (num_envs,) f64 holds, per env, max |d| of the UNSCALED Newton
+ * direction of its last iteration once that iteration was accepted at full length (no CCD truncation, no backtracking), and a
+ * value above dx_tol otherwise (the caller fills it with +inf at the start of a time step); an env whose value is <= dx_tol
+ * (= velocity_tol * dt, US:62-66) returns at once from the next tacex_fem_newton_step, so extra iterations cost nothing and
+ * no host round trip is needed to stop them.  nullptr disables. */
 int tacex_fem_set_newton_early_exit(tacex_fem_ctx* ctx, double* dx_dev, double dx_tol);
 
-/* One projected-Newton iteration per env: assemble (block-Jacobi preconditioned) system, matrix-free PCG
- * (US:70-72 tol_rate), backtracking line search on the energy (US:76: max_iter 8).  x_dev is updated in place.
+/* One projected-Newton iteration per env: assemble (block-Jacobi + coarse-grid preconditioned, tacex_fem_set_coarse_space) system, matrix-free PCG
+ * (US:70-72 tol_rate), backtracking line search on the energy (US:76: max_iter 8; when the capped search finds no decrease
+ * the step is halved further, down to 2^-32, instead of leaving the env stuck).  x_dev is updated in place.
  * stats_dev (B,4) float64 = [energy_before, energy_after, step_length, pcg_iterations]. */
 int tacex_fem_newton_step(tacex_fem_ctx* ctx, double* x_dev, const double* x_tilde_dev,
                           const uint8_t* constrained_dev, const double* aim_dev, double* stats_dev,
                           void* workspace_dev, int num_envs, int pcg_max_iter, double pcg_tol_rate,
                           int ls_max_iter, void* stream);
+
+/* One backward-Euler time step of every env - what `world.advance()` does for the gelpad (US:250-252) - with NO host round trip:
+ *   x_prev = x;  x_tilde = x + dt v + dt^2 gravity;  up to max_newton Newton iterations (as tacex_fem_newton_step), each env leaving
+ *   the loop on the device once an iteration was accepted at full length and max |d| <= velocity_tol * dt (US:62-66);
+ *   v = (x - x_prev) / dt.
+ * x_dev, v_dev (B,V,3) f64 are updated in place, x_tilde_dev (B,V,3) is written.  With the CU-resident Newton kernel (meshes of
+ * <= 512 vertices) the whole loop is ONE launch; the streaming fallback launches max_newton kernels on a fixed schedule in which
+ * converged envs return at once.  stats_dev (B,4) = [energy_before, energy_after, step_length, pcg_iterations] of the LAST iteration
+ * run; step_info_dev (B,4) f64 = [newton_iterations, max |d| of the last iteration, flags, pcg_iterations_total] (CU-resident
+ * kernel; zeros from the fallback), flags: 1 = a contact vertex was at or beyond its indenter's surface when an iteration started
+ * (the caller moved the indenter by more than the gap: that vertex gets no restoring force), 2 = a line search found no decrease.
+ * workspace_dev: tacex_fem_workspace_bytes(ctx, num_envs). */
+int tacex_fem_step(tacex_fem_ctx* ctx, double* x_dev, double* v_dev, double* x_tilde_dev, const uint8_t* constrained_dev,
+                   const double* aim_dev, double* stats_dev, double* step_info_dev, void* workspace_dev, int num_envs,
+                   const double gravity[3], int max_newton, double velocity_tol, int pcg_max_iter, double pcg_tol_rate,
+                   int ls_max_iter, void* stream);
 
 /* Attachment animation (UA:364-428: `_compute_aim_positions` + the animator callback `animate_tet` UA:365-385) for all envs:
  *   aim_position[b, idx[a]] = R(body_quat[b]) * offsets[a] + body_pos[b];  is_constrained[b, idx[a]] = 1

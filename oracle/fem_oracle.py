@@ -65,6 +65,63 @@ def box_tet_mesh(nx=6, ny=8, nz=3, size=(0.02075, 0.02525, 0.0045)):
     return P, np.array(tets, dtype=np.int32)
 
 
+# Backtracking beyond the configured cap (mirrors kLsRescue of csrc/fem_kernels.hip): when the capped line search finds no decrease
+# the step is halved further, down to 2^-32, instead of leaving the env stuck - a Newton direction computed before a vertex enters
+# the barrier zone knows nothing of the barrier it runs into.
+LS_RESCUE = 32
+
+
+def pcg_solve(hv, prec, b, max_iter, tol_rate, d0=None):
+    """Preconditioned CG on H d = b as the Newton kernels run it: stops when r^T M^-1 r <= tol_rate^2 b^T M^-1 b (or at max_iter), keeps
+    what it has on negative curvature (first iteration from a zero start: the preconditioned steepest-descent direction).  `d0`: warm
+    start (the part of the previous Newton direction that the CCD filter / the line search cut off).  Returns (d, iterations)."""
+    r = b.copy()
+    z = prec(r)
+    rz_b = (r * z).sum()
+    warm = d0 is not None and np.abs(d0).max() > 0 and rz_b > 0
+    d = d0.copy() if warm else np.zeros_like(b)
+    if warm:
+        r = r - hv(d)
+        z = prec(r)
+    p = z.copy()
+    rz = (r * z).sum()
+    it = 0
+    while it < max_iter and rz_b > 0 and rz > tol_rate**2 * rz_b:
+        Hp = hv(p)
+        pHp = (p * Hp).sum()
+        if pHp <= 0:
+            if it == 0 and not warm:
+                d = z.copy()
+            break
+        al = rz / pHp
+        d = d + al * p
+        r = r - al * Hp
+        z = prec(r)
+        rz_new = (r * z).sum()
+        p = z + (rz_new / rz) * p
+        rz = rz_new
+        it += 1
+    return d, it
+
+
+def make_preconditioner(Dinv, coarse=None):
+    """z = D^-1 r (3x3 block Jacobi) [+ P A_c^-1 P^T r: additive coarse-grid correction, `coarse` = (node (V,8), weight (V,8),
+    inverse coarse operator), the tables tacex_fem_set_coarse_space takes]."""
+    if coarse is None:
+        return lambda r: np.einsum("vij,vj->vi", Dinv, r)
+    node, w, aci = coarse
+    nc = aci.shape[0] // 3
+    V = node.shape[0]
+
+    def prec(r):
+        rc = np.zeros((nc, 3))
+        np.add.at(rc, node.reshape(-1), (w[:, :, None] * r[:, None, :]).reshape(-1, 3))
+        yc = (aci @ rc.reshape(-1)).reshape(nc, 3)
+        return np.einsum("vij,vj->vi", Dinv, r) + (w[:, :, None] * yc[node]).sum(1)
+
+    return prec
+
+
 def lame_from_youngs_poisson(E: float, nu: float):
     return E / (2 * (1 + nu)), E * nu / ((1 + nu) * (1 - 2 * nu))
 
@@ -218,8 +275,10 @@ class FemModel:
         return D
 
     # ---- one Newton iteration: truncated PCG + backtracking line search (US:70-76) ----------------------------------
-    def newton_step(self, x, x_tilde, constrained=None, aim=None, pcg_max_iter=64, pcg_tol_rate=1e-3, ls_max_iter=8):
-        """Single env (x: (V,3)).  Returns (x_new, stats=[E0, E1, step, pcg_iters])."""
+    def newton_step(self, x, x_tilde, constrained=None, aim=None, pcg_max_iter=64, pcg_tol_rate=1e-3, ls_max_iter=8, coarse=None, d0=None,
+                    return_dir=False):
+        """Single env (x: (V,3)).  Returns (x_new, stats=[E0, E1, step, pcg_iters, max |d|, ccd step]).  `coarse` = (node (V,8),
+        weight (V,8), inverse coarse operator (3 nc, 3 nc)): the additive coarse-grid correction of tacex_fem_set_coarse_space."""
         g = self.gradient(x, x_tilde, constrained, aim)
         D = self.diag_blocks(x, constrained)
         # fall back to the (always SPD) mass block where the elastic block is not positive definite
@@ -231,34 +290,13 @@ class FemModel:
                 Dinv[v] = np.linalg.inv(D[v])
             except np.linalg.LinAlgError:
                 Dinv[v] = np.eye(3) / mdiag[v]
-        prec = lambda r: np.einsum("vij,vj->vi", Dinv, r)
-        d = np.zeros_like(x)
-        r = -g
-        z = prec(r)
-        p = z.copy()
-        rz = (r * z).sum()
-        rz0 = rz
-        it = 0
-        while it < pcg_max_iter and rz > pcg_tol_rate**2 * rz0 and rz0 > 0:
-            Hp = self.hess_vec(x, p, constrained)
-            pHp = (p * Hp).sum()
-            if pHp <= 0:  # negative curvature: keep what we have (steepest-descent-like first step)
-                if it == 0:
-                    d = z.copy()
-                break
-            a = rz / pHp
-            d = d + a * p
-            r = r - a * Hp
-            z = prec(r)
-            rz_new = (r * z).sum()
-            p = z + (rz_new / rz) * p
-            rz = rz_new
-            it += 1
+        prec = make_preconditioner(Dinv, coarse)
+        d, it = pcg_solve(lambda p: self.hess_vec(x, p, constrained), prec, -g, pcg_max_iter, pcg_tol_rate, d0)
         E0 = self.energy(x, x_tilde, constrained, aim)
         step = 1.0
         E1 = E0
         x_new = x
-        for _ in range(ls_max_iter + 1):
+        for _ in range(max(ls_max_iter, LS_RESCUE) + 1):  # capped search, then the rescue halvings (see LS_RESCUE)
             cand = x + step * d
             Ec = self.energy(cand, x_tilde, constrained, aim)
             if Ec <= E0:
@@ -267,7 +305,8 @@ class FemModel:
             step *= 0.5
         else:
             step = 0.0
-        return x_new, np.array([E0, E1, step, it])
+        st = np.array([E0, E1, step, it, np.abs(d).max(), 1.0])
+        return (x_new, st, d) if return_dir else (x_new, st)
 
 
 def marker_uv(surf_pos, tri, weight, fx=340.0, fy=325.0, cx=160.0, cy=125.0):
@@ -368,7 +407,7 @@ class ContactModel:
 
 
 def newton_step_contact(m: "FemModel", cm: ContactModel, x, x_tilde, constrained=None, aim=None, pcg_max_iter=64, pcg_tol_rate=1e-3,
-                        ls_max_iter=8):
+                        ls_max_iter=8, coarse=None, d0=None, return_dir=False):
     """`FemModel.newton_step` with the barrier terms of `cm` in gradient, preconditioner, H.p and energy, and the CCD step
     filter in front of the backtracking line search.  Returns (x_new, [E0, E1, step, pcg_iters])."""
     g = m.gradient(x, x_tilde, constrained, aim) + cm.gradient(x)
@@ -382,35 +421,14 @@ def newton_step_contact(m: "FemModel", cm: ContactModel, x, x_tilde, constrained
             Dinv[v] = np.linalg.inv(D[v])
         except np.linalg.LinAlgError:
             Dinv[v] = np.eye(3) / mdiag[v]
-    prec = lambda r: np.einsum("vij,vj->vi", Dinv, r)
+    prec = make_preconditioner(Dinv, coarse)
     hv = lambda p: m.hess_vec(x, p, constrained) + np.einsum("vij,vj->vi", Hc, p)
     energy = lambda y: m.energy(y, x_tilde, constrained, aim) + cm.energy(y)
-    d = np.zeros_like(x)
-    r = -g
-    z = prec(r)
-    p = z.copy()
-    rz = (r * z).sum()
-    rz0 = rz
-    it = 0
-    while it < pcg_max_iter and rz > pcg_tol_rate**2 * rz0 and rz0 > 0:
-        Hp = hv(p)
-        pHp = (p * Hp).sum()
-        if pHp <= 0:
-            if it == 0:
-                d = z.copy()
-            break
-        al = rz / pHp
-        d = d + al * p
-        r = r - al * Hp
-        z = prec(r)
-        rz_new = (r * z).sum()
-        p = z + (rz_new / rz) * p
-        rz = rz_new
-        it += 1
+    d, it = pcg_solve(hv, prec, -g, pcg_max_iter, pcg_tol_rate, d0)
     E0 = energy(x)
-    step = cm.max_step(x, d)
+    step = step0 = cm.max_step(x, d)
     E1, x_new = E0, x
-    for _ in range(ls_max_iter + 1):
+    for _ in range(max(ls_max_iter, LS_RESCUE) + 1):
         cand = x + step * d
         Ec = energy(cand)
         if Ec <= E0:
@@ -419,4 +437,31 @@ def newton_step_contact(m: "FemModel", cm: ContactModel, x, x_tilde, constrained
         step *= 0.5
     else:
         step = 0.0
-    return x_new, np.array([E0, E1, step, it])
+    st = np.array([E0, E1, step, it, np.abs(d).max(), step0])
+    return (x_new, st, d) if return_dir else (x_new, st)
+
+
+def fem_step(m: "FemModel", cm, x, v, constrained=None, aim=None, gravity=(0.0, 0.0, -9.8), max_newton=8, velocity_tol=0.05,
+             pcg_max_iter=1024, pcg_tol_rate=1e-3, ls_max_iter=8, coarse=None):
+    """One backward-Euler step of ONE env the way `tacex_fem_step` runs it (what world.advance() does, US:250-252):
+    x_tilde = x + dt v + dt^2 g; Newton iterations until one is accepted at FULL length (no CCD truncation, no backtracking) with
+    max |d| <= velocity_tol * dt (US:62-66) or the cap; v = (x_new - x) / dt.  Returns (x_new, v_new, info) with
+    info = [newton_iterations, max |d| of the last iteration, flags (2: a line search failed), pcg_iterations_total]."""
+    x0 = x
+    xt = x + m.dt * v + m.dt**2 * np.asarray(gravity, np.float64)
+    n, flags, pcg, dmax = 0, 0, 0, np.inf
+    d0 = None
+    for _ in range(max_newton):
+        if cm is not None:
+            x, st, d = newton_step_contact(m, cm, x, xt, constrained, aim, pcg_max_iter, pcg_tol_rate, ls_max_iter, coarse, d0, True)
+        else:
+            x, st, d = m.newton_step(x, xt, constrained, aim, pcg_max_iter, pcg_tol_rate, ls_max_iter, coarse, d0, True)
+        d0 = (1.0 - st[2]) * d if 0.0 < st[2] < 1.0 else None  # warm start of the next PCG: the part of d that was cut off
+        n += 1
+        pcg += int(st[3])
+        dmax = st[4]
+        if st[2] == 0.0:
+            flags |= 2
+        if st[2] == 1.0 and st[5] == 1.0 and dmax <= velocity_tol * m.dt:
+            break
+    return x, (x - x0) / m.dt, np.array([n, dmax, flags, pcg], np.float64)

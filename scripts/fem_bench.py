@@ -47,3 +47,19 @@ def full_step():
     sim.x.copy_(x0); sim.v.zero_(); sim.step(max_newton_iter=8)
 dt = timeit(full_step, 3)
 print(f"UipcSim.step warm (8 Newton iters cap, device-side early exit): {dt*1e3:.2f} ms, iters {sim.last_newton_iters}")
+# the C4 / C5 bench scene (back face attached, sphere indenter breathing in and out): ms per FEM step and solver statistics
+from tacex_amd.uipc.gelpad_scene import FemGelpad
+fem = FemGelpad(B, "cuda:0")
+for i in range(6):
+    fem.step(i)
+torch.cuda.synchronize()
+ms, nits, pcgs = [], [], []
+for i in range(6, 30):
+    fem.step(i)
+    ms.append(fem.fem_ms_last())
+    si = fem.sim.step_info.cpu().numpy()
+    nits.append(si[:, 0].mean()); pcgs.append((si[:, 3] / np.maximum(si[:, 0], 1)).mean())
+info = fem.sim.check_step(raise_on_penetration=False)
+print(f"FemGelpad scene ({B} envs): {np.mean(ms):.3f} ms per step (min {np.min(ms):.3f}, max {np.max(ms):.3f}); Newton iterations per step mean "
+      f"{np.mean(nits):.2f}; PCG iterations per Newton iteration mean {np.mean(pcgs):.1f}; flagged envs: penetration {len(info['penetrating_envs'])}, "
+      f"line search {len(info['line_search_failed_envs'])}")

@@ -40,7 +40,16 @@ struct FemDev {
   const double* area;       // (V) contact weight of a vertex = a third of the area of its surface triangles (0: interior); nullable
   const double* indenters;  // (B,8) [kind, cx, cy, cz, radius, nx, ny, nz]: kind 0 none, 1 sphere, 2 half-space; nullable
   double dhat, kappa;       // barrier activation distance [m], stiffness [J/m^2]
+  // coarse space of the two-level preconditioner (tacex_fem_set_coarse_space); nc = 0: block Jacobi alone
+  int nc;                   // coarse nodes (<= kFemMaxCoarse)
+  const int* cv_node;       // (V,8) coarse nodes of a vertex (trilinear hats of a coarse grid over the mesh)
+  const double* cv_w;       // (V,8) their weights
+  const int* cn_off;        // (nc+1) CSR coarse node -> (vertex, weight) of its support
+  const int* cn_vtx;
+  const double* cn_w;
+  const double* ac_inv;     // (3 nc, 3 nc) inverse of P^T A_0 P, A_0 = rest-state operator incl. the constraint masses
 };
+constexpr int kFemMaxCoarse = 64;
 
 // ---- IPC barrier of one surface vertex against the env's analytic indenter ------------------------------------------
 // Li et al. 2020 (IPC) eq. 6 in the dimensionless gap s = d / dhat:  b(s) = -(s - 1)^2 ln s  for 0 < s < 1, 0 beyond.
@@ -426,7 +435,8 @@ __global__ __launch_bounds__(512) void fem_gradient_kernel(FemDev m, const doubl
 }
 
 // ---- K17b: one projected-Newton iteration per env, everything inside one workgroup -----------------------------
-// workspace per env (doubles): ge 12T | tet cache 12T (F 9, a, b, c) | hv 12T | g,r,z,p,d,Hp,xc 7*3V | Dinv 9V
+// workspace per env (doubles): ge 12T | tet cache 12T (F 9, a, b, c) | hv 12T | g,r,z,p,d,Hp,xc 7*3V | Dinv 9V; behind the B env
+// blocks: x_prev (B,V,3) and the per-env max |d| of tacex_fem_step
 __host__ __device__ inline size_t newton_ws_doubles(int V, int T) { return (size_t)36 * T + (size_t)30 * V; }
 
 __device__ __forceinline__ bool inv3_spd(const double A[9], double Ai[9]) {
@@ -449,9 +459,13 @@ __device__ __forceinline__ bool inv3_spd(const double A[9], double Ai[9]) {
 
 __global__ __launch_bounds__(512) void fem_newton_kernel(FemDev m, double* xg, const double* xtg, const uint8_t* consg,
                                                          const double* aimg, double* stats, double* wsg,
-                                                         int pcg_max_iter, double pcg_tol_rate, int ls_max_iter) {
+                                                         int pcg_max_iter, double pcg_tol_rate, int ls_max_iter, double* dxg, double dx_tol) {
   __shared__ double sh[17];
   const int b = blockIdx.x;
+  if (dxg && dxg[b] <= dx_tol) {  // converged in an earlier launch of this time step (same protocol as the CU-resident kernel)
+    if (threadIdx.x == 0) { stats[(size_t)b * 4 + 2] = 0.0; stats[(size_t)b * 4 + 3] = 0.0; }
+    return;
+  }
   const int V = m.V, T = m.T;
   const size_t o = (size_t)b * V * 3;
   double* x = xg + o;
@@ -647,6 +661,20 @@ __global__ __launch_bounds__(512) void fem_newton_kernel(FemDev m, double* xg, c
   } else {
     step = 0.0;
   }
+  if (dxg) {  // max |d| of the unscaled Newton direction; the env counts as converged only after a full accepted step
+    double md = 0.0;
+    for (int k = threadIdx.x; k < 3 * V; k += blockDim.x) md = fmax(md, fabs(vd[k]));
+#pragma unroll
+    for (int o2 = 32; o2 > 0; o2 >>= 1) md = fmax(md, __shfl_xor(md, o2, 64));
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = md;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      double v = 0.0;
+      for (int w = 0; w < (int)(blockDim.x >> 6); ++w) v = fmax(v, sh[w]);
+      dxg[b] = (accepted && step == 1.0 && v <= dx_tol) ? v : fmax(v, 2.0 * dx_tol);
+    }
+  }
   if (threadIdx.x == 0) {
     stats[(size_t)b * 4 + 0] = E0; stats[(size_t)b * 4 + 1] = E1; stats[(size_t)b * 4 + 2] = step; stats[(size_t)b * 4 + 3] = (double)it;
   }
@@ -726,10 +754,24 @@ __device__ __forceinline__ double block_min1(double v, double* sh2, int& phase) 
   return s;
 }
 
+// Backtracking beyond the configured cap: when the capped search (LineSearch.max_iter, US:96-101) finds no decrease the step is
+// halved further, down to 2^-kLsRescue - a Newton direction computed BEFORE a vertex enters the barrier zone knows nothing of
+// the barrier it runs into (soft gel, 10 GPa contact resistance: the admissible step can be 1e-3 of the CCD bound), and an env
+// whose search failed would otherwise repeat the same failing iteration until the iteration cap.
+constexpr int kLsRescue = 32;
+// flags of step_info[., 2]
+constexpr int kFemFlagPenetration = 1;  // a contact vertex was at or beyond the indenter surface when the iteration started
+constexpr int kFemFlagLsFailed = 2;     // a line search found no decrease even after the rescue halvings
+
+// One launch = up to `max_newton` Newton iterations of every env (tacex_fem_step: the whole Newton loop of world.advance(),
+// US:250-252, without a host round trip; tacex_fem_newton_step: max_newton = 1).  An env leaves the loop when an iteration was
+// accepted at full length (no CCD truncation, no backtracking) and its Newton direction moved no vertex by more than dx_tol
+// (velocity_tol * dt, US:62-66) - the criterion looks at the UNSCALED direction: a CCD- or search-shortened update says nothing
+// about convergence.
 __global__ __launch_bounds__(kNwtThreads) void fem_newton_lds_kernel(FemDev m, double* xg, const double* xtg,
                                                                      const uint8_t* consg, const double* aimg, double* stats,
                                                                      int pcg_max_iter, double pcg_tol_rate, int ls_max_iter,
-                                                                     double* dxg, double dx_tol) {
+                                                                     double* dxg, double dx_tol, int max_newton, double* step_info) {
   extern __shared__ __attribute__((aligned(16))) double nlds[];
   constexpr int CH = kNwtChunk;
   const int V = m.V, T = m.T, tid = threadIdx.x;
@@ -825,6 +867,14 @@ __global__ __launch_bounds__(kNwtThreads) void fem_newton_lds_kernel(FemDev m, d
     }
   };
 
+  int n_newton = 0, flags = 0;
+  bool done = false;
+  double pcg_total = 0.0, dmax_last = INFINITY;
+  // warm start of the next iteration's PCG: the part of this iteration's Newton direction the CCD filter / the line search cut off
+  double dprev[3] = {0, 0, 0};
+  double frac_prev = 0.0;  // (1 - accepted step) of the previous iteration, 0 when it was taken in full or rejected
+  for (int nit = 0; nit < max_newton; ++nit) {
+  if (nit > 0) __syncthreads();  // xs carries the accepted candidate of the previous iteration
   // ---- nodal gradient ----
   double r3[3], d3[3] = {0, 0, 0};
   {
@@ -850,6 +900,7 @@ __global__ __launch_bounds__(kNwtThreads) void fem_newton_lds_kernel(FemDev m, d
   // barrier of this vertex at x: gradient b1 n, curvature b2 n n^T (the b1 * hess(d) part is negative semi-definite for a
   // convex indenter and dropped: the usual PSD projection of IPC)
   const ContactEval ce = contact_eval(m, ind, wv, x3);
+  if (ce.penetrating) flags |= kFemFlagPenetration;  // (per thread; or-reduced into step_info at the end)
   if (ce.active) {
 #pragma unroll
     for (int i = 0; i < 3; ++i) r3[i] -= dt2 * ce.b1 * ce.n[i];
@@ -889,30 +940,97 @@ __global__ __launch_bounds__(kNwtThreads) void fem_newton_lds_kernel(FemDev m, d
       Dinv[0] = im; Dinv[1] = 0; Dinv[2] = 0; Dinv[3] = 0; Dinv[4] = im; Dinv[5] = 0; Dinv[6] = 0; Dinv[7] = 0; Dinv[8] = im;
     }
   }
+  // ---- preconditioner: z = D^-1 r (3x3 block Jacobi) + P A_c^-1 P^T r (additive coarse-grid correction) ----
+  // Block Jacobi alone needs 120-330 PCG iterations on the thin, nearly incompressible pad: the error it cannot reach is
+  // smooth over many elements.  The coarse space - trilinear hats of a small grid over the mesh, <= 64 nodes - carries those
+  // modes; its operator is the Galerkin product with the REST-state matrix (constant per mesh and constraint set: factored on
+  // the host once, profiles/r03_experiments.md section 4 shows it works as well as the current-state product).  Restriction is
+  // a gather per coarse dof over its support, split over G threads with the partial sums added in a fixed order (deterministic,
+  // no atomics); the sweep's LDS window is idle between two sweeps and carries r, the partial sums and the coarse vectors.
+  const int nc3 = 3 * m.nc;
+  const int G = nc3 > 0 ? kNwtThreads / nc3 : 1;
+  auto apply_prec = [&](const double (&r)[3], double (&z)[3]) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) z[i] = Dinv[i * 3 + 0] * r[0] + Dinv[i * 3 + 1] * r[1] + Dinv[i * 3 + 2] * r[2];
+    if (nc3 == 0) return;
+    double* rs = hv;                    // (V,3) residual
+    double* part_c = hv + 3 * V;        // (3 nc, G) partial sums
+    double* rc = part_c + kNwtThreads;  // (3 nc) restricted residual
+    double* yc = rc + 3 * kFemMaxCoarse;
+    __syncthreads();  // every thread is done with the window of the last sweep
+    if (own) {
+#pragma unroll
+      for (int i = 0; i < 3; ++i) rs[tid * 3 + i] = r[i];
+    }
+    __syncthreads();
+    const int dof = tid / G, j = tid - dof * G;
+    if (dof < nc3) {
+      const int node = dof / 3, comp = dof - node * 3;
+      double acc = 0.0;
+      for (int e = m.cn_off[node] + j; e < m.cn_off[node + 1]; e += G) acc += m.cn_w[e] * rs[m.cn_vtx[e] * 3 + comp];
+      part_c[dof * G + j] = acc;
+    }
+    __syncthreads();
+    if (tid < nc3) {
+      double acc = 0.0;
+      for (int q = 0; q < G; ++q) acc += part_c[tid * G + q];
+      rc[tid] = acc;
+    }
+    __syncthreads();
+    if (tid < nc3) {
+      const double* row = m.ac_inv + (size_t)tid * nc3;
+      double acc = 0.0;
+      for (int q = 0; q < nc3; ++q) acc += row[q] * rc[q];
+      yc[tid] = acc;
+    }
+    __syncthreads();
+    if (own) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const int node = m.cv_node[tid * 8 + k];
+        const double w = m.cv_w[tid * 8 + k];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) z[i] += w * yc[node * 3 + i];
+      }
+    }
+  };
   // ---- PCG ----
+  // Stops when the preconditioned residual has dropped to tol_rate times that of the right-hand side (r^T M^-1 r against
+  // b^T M^-1 b; the same test as before for a zero start).  WARM START: when the previous iteration's step was cut short (CCD
+  // bound, backtracking at the edge of the barrier zone - the release regime of a retreating indenter takes up to the iteration
+  // cap of such steps), the new system differs from the old one only around the newly pinned vertices, and the unfinished part
+  // (1 - step) d_prev is a far better start than zero: one extra H.d sweep buys most of the iterations.
   double z3[3], p3[3];
   double part = 0.0;
+  apply_prec(r3, z3);
 #pragma unroll
   for (int i = 0; i < 3; ++i) {
-    z3[i] = Dinv[i * 3 + 0] * r3[0] + Dinv[i * 3 + 1] * r3[1] + Dinv[i * 3 + 2] * r3[2];
     p3[i] = z3[i];
     part += r3[i] * z3[i];
   }
-  double rz = block_sum1(part, sh, phase);
-  const double rz0 = rz;
+  const double rz_b = block_sum1(part, sh, phase);
+  double rz = rz_b;
+  bool warm = frac_prev > 0.0 && rz_b > 0.0;
+  if (warm) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) d3[i] = frac_prev * dprev[i];
+  }
   int it = 0;
-  while (it < pcg_max_iter && rz0 > 0.0 && rz > pcg_tol_rate * pcg_tol_rate * rz0) {
+  while (warm || (it < pcg_max_iter && rz_b > 0.0 && rz > pcg_tol_rate * pcg_tol_rate * rz_b)) {
+    double q3[3];  // the vector H is applied to
+#pragma unroll
+    for (int i = 0; i < 3; ++i) q3[i] = warm ? d3[i] : p3[i];
     if (own) {
 #pragma unroll
-      for (int i = 0; i < 3; ++i) ps[tid * 3 + i] = p3[i];
+      for (int i = 0; i < 3; ++i) ps[tid * 3 + i] = q3[i];
     }
     __syncthreads();
-    // Hp = (M + s Mc + dt^2 K) p, matrix-free: per-tet dP[dF(p)] rows, gathered per vertex
+    // Hq = (M + s Mc + dt^2 K) q, matrix-free: per-tet dP[dF(q)] rows, gathered per vertex
     double a3[3];
     sweep([&](const int* v, const double* Di, double vol, double* rows) {
       double F[9], dF[9], dP[9], r[12];
       deformation_gradient(xs, v, Di, F);
-      deformation_gradient(ps, v, Di, dF);  // linear in p
+      deformation_gradient(ps, v, Di, dF);  // linear in q
       TetState s;
       tet_state(m, F, s);
       apply_dP(m, s, dF, dP);
@@ -928,12 +1046,26 @@ __global__ __launch_bounds__(kNwtThreads) void fem_newton_lds_kernel(FemDev m, d
     part = 0.0;
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
-      Hp3[i] = own ? a3[i] + md * p3[i] + cb2 * ce.n[i] * (ce.n[0] * p3[0] + ce.n[1] * p3[1] + ce.n[2] * p3[2]) : 0.0;
-      part += p3[i] * Hp3[i];
+      Hp3[i] = own ? a3[i] + md * q3[i] + cb2 * ce.n[i] * (ce.n[0] * q3[0] + ce.n[1] * q3[1] + ce.n[2] * q3[2]) : 0.0;
+      part += q3[i] * Hp3[i];
+    }
+    if (warm) {  // r = b - H d0, then the usual start from there (not counted as an iteration)
+#pragma unroll
+      for (int i = 0; i < 3; ++i) r3[i] -= Hp3[i];
+      apply_prec(r3, z3);
+      part = 0.0;
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        p3[i] = z3[i];
+        part += r3[i] * z3[i];
+      }
+      rz = block_sum1(part, sh, phase);
+      warm = false;
+      continue;
     }
     const double pHp = block_sum1(part, sh, phase);
-    if (!(pHp > 0.0)) {  // negative curvature: keep d (first iteration: preconditioned steepest descent)
-      if (it == 0) { d3[0] = z3[0]; d3[1] = z3[1]; d3[2] = z3[2]; }
+    if (!(pHp > 0.0)) {  // negative curvature: keep d (first iteration from a zero start: preconditioned steepest descent)
+      if (it == 0 && !(frac_prev > 0.0)) { d3[0] = z3[0]; d3[1] = z3[1]; d3[2] = z3[2]; }
       break;
     }
     const double al = rz / pHp;
@@ -943,11 +1075,9 @@ __global__ __launch_bounds__(kNwtThreads) void fem_newton_lds_kernel(FemDev m, d
       d3[i] += al * p3[i];
       r3[i] -= al * Hp3[i];
     }
+    apply_prec(r3, z3);
 #pragma unroll
-    for (int i = 0; i < 3; ++i) {
-      z3[i] = Dinv[i * 3 + 0] * r3[0] + Dinv[i * 3 + 1] * r3[1] + Dinv[i * 3 + 2] * r3[2];
-      part += r3[i] * z3[i];
-    }
+    for (int i = 0; i < 3; ++i) part += r3[i] * z3[i];
     const double rz_new = block_sum1(part, sh, phase);
     const double beta = rz_new / rz;
 #pragma unroll
@@ -968,9 +1098,11 @@ __global__ __launch_bounds__(kNwtThreads) void fem_newton_lds_kernel(FemDev m, d
     }
     step = block_min1(amax, sh, phase);
   }
+  const double step0 = step;  // after the CCD filter
   bool accepted = false;
   double xc3[3] = {0, 0, 0};
-  for (int ls = 0; ls <= ls_max_iter; ++ls) {
+  const int ls_cap = ls_max_iter > kLsRescue ? ls_max_iter : kLsRescue;
+  for (int ls = 0; ls <= ls_cap; ++ls) {
     __syncthreads();  // every tet is done reading ps (PCG sweep or the previous candidate)
     if (own) {
 #pragma unroll
@@ -981,31 +1113,61 @@ __global__ __launch_bounds__(kNwtThreads) void fem_newton_lds_kernel(FemDev m, d
     if (Ec <= E0) { E1 = Ec; accepted = true; break; }
     step *= 0.5;
   }
+  // max |d| of the UNSCALED Newton direction (what the convergence test looks at)
+  const double dmax = -block_min1(own ? -fmax(fabs(d3[0]), fmax(fabs(d3[1]), fabs(d3[2]))) : 0.0, sh, phase);
   if (accepted) {
     if (own) {
 #pragma unroll
-      for (int i = 0; i < 3; ++i) x[tid * 3 + i] = xc3[i];
+      for (int i = 0; i < 3; ++i) { x3[i] = xc3[i]; xs[tid * 3 + i] = xc3[i]; }
     }
   } else {
     step = 0.0;
+    flags |= kFemFlagLsFailed;
   }
-  if (dxg) {  // max |dx| of this iteration, for the early exit of the next launch
-    double mdx = 0.0;
-    if (own && accepted) mdx = fmax(fabs(xc3[0] - x3[0]), fmax(fabs(xc3[1] - x3[1]), fabs(xc3[2] - x3[2])));
+  ++n_newton;
+  pcg_total += (double)it;
+  dmax_last = dmax;
+  frac_prev = (accepted && step < 1.0) ? 1.0 - step : 0.0;
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) mdx = fmax(mdx, __shfl_xor(mdx, o, 64));
-    __syncthreads();
-    if ((tid & 63) == 0) sh[tid >> 6] = mdx;
-    __syncthreads();
-    if (tid == 0) {
-      double v = 0.0;
-      for (int w = 0; w < kNwtThreads / 64; ++w) v = fmax(v, sh[w]);
-      dxg[b] = v;
-    }
-  }
+  for (int i = 0; i < 3; ++i) dprev[i] = d3[i];
   if (tid == 0) {
     stats[(size_t)b * 4 + 0] = E0; stats[(size_t)b * 4 + 1] = E1; stats[(size_t)b * 4 + 2] = step; stats[(size_t)b * 4 + 3] = (double)it;
   }
+  const bool converged = accepted && step == 1.0 && step0 == 1.0 && dmax <= dx_tol;
+  if (converged) { done = true; break; }  // wave-uniform: every quantity above is a block reduction
+  }  // Newton loop
+  if (own) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) x[tid * 3 + i] = x3[i];
+  }
+  // what the next launch (tacex_fem_newton_step called in a loop) reads to skip this env: the direction's max |d| once the env
+  // has converged (<= dx_tol), a value above the tolerance while it has not (a shortened update must not count as convergence)
+  if (dxg && tid == 0) dxg[b] = done ? dmax_last : fmax(dmax_last, 2.0 * dx_tol);
+  if (step_info) {
+    const int any = __syncthreads_or(flags);
+    if (tid == 0) {
+      step_info[(size_t)b * 4 + 0] = (double)n_newton; step_info[(size_t)b * 4 + 1] = dmax_last;
+      step_info[(size_t)b * 4 + 2] = (double)any; step_info[(size_t)b * 4 + 3] = pcg_total;
+    }
+  }
+}
+
+// backward-Euler predictor of tacex_fem_step: x_prev = x, x_tilde = x + dt v + dt^2 g (US:250-252: what world.advance() starts from)
+__global__ __launch_bounds__(256) void fem_predict_kernel(const double* __restrict__ x, const double* __restrict__ v, double* __restrict__ xt,
+                                                          double* __restrict__ xprev, double* __restrict__ dxg, size_t n3, int B,
+                                                          double dt, double g0, double g1, double g2) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < (size_t)B && dxg) dxg[i] = INFINITY;
+  if (i >= n3) return;
+  const int k = (int)(i % 3);
+  const double xi = x[i];
+  xprev[i] = xi;
+  xt[i] = xi + dt * v[i] + dt * dt * (k == 0 ? g0 : (k == 1 ? g1 : g2));
+}
+__global__ __launch_bounds__(256) void fem_velocity_kernel(const double* __restrict__ x, const double* __restrict__ xprev,
+                                                           double* __restrict__ v, size_t n3, double inv_dt) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n3) v[i] = (x[i] - xprev[i]) * inv_dt;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1187,7 +1349,7 @@ void tacex_fem_destroy(tacex_fem_ctx* c) {
 
 size_t tacex_fem_workspace_bytes(const tacex_fem_ctx* c, int B) {
   if (!c || B <= 0) return 0;
-  return (size_t)B * newton_ws_doubles(c->dev.V, c->dev.T) * sizeof(double);
+  return ((size_t)B * newton_ws_doubles(c->dev.V, c->dev.T) + (size_t)B * 3 * c->dev.V + (size_t)B + 8) * sizeof(double);
 }
 
 int tacex_fem_element_terms(tacex_fem_ctx* c, const double* x, double* energy, double* grad, double* hess,
@@ -1248,11 +1410,81 @@ int tacex_fem_set_contact(tacex_fem_ctx* c, const double* vertex_area_host, doub
   return 0;
 }
 
+int tacex_fem_set_coarse_space(tacex_fem_ctx* c, int num_coarse, const int32_t* vertex_nodes_host, const double* vertex_weights_host,
+                               const double* coarse_inverse_host) {
+  if (!c) { set_error("tacex_fem_set_coarse_space: null context"); return 2; }
+  if (num_coarse == 0) {  // block Jacobi alone
+    c->dev.nc = c->dev_nwt.nc = 0;
+    return 0;
+  }
+  if (num_coarse < 1 || num_coarse > kFemMaxCoarse || !vertex_nodes_host || !vertex_weights_host || !coarse_inverse_host) {
+    set_error("tacex_fem_set_coarse_space: need 1 <= num_coarse <= %d and non-null tables", kFemMaxCoarse);
+    return 2;
+  }
+  const int V = c->dev.V, nc = num_coarse;
+  std::vector<int> node(vertex_nodes_host, vertex_nodes_host + (size_t)V * 8);
+  std::vector<double> w(vertex_weights_host, vertex_weights_host + (size_t)V * 8);
+  for (size_t i = 0; i < node.size(); ++i)
+    if (node[i] < 0 || node[i] >= nc || !(w[i] >= 0.0)) { set_error("tacex_fem_set_coarse_space: bad (node, weight) entry %zu", i); return 2; }
+  // coarse node -> support (vertex, weight), zero weights dropped, vertices ascending (fixed summation order)
+  std::vector<int> off(nc + 1, 0), vtx;
+  std::vector<double> cw;
+  for (int n = 0; n < nc; ++n) {
+    for (int v = 0; v < V; ++v) {
+      double ws = 0.0;
+      for (int k = 0; k < 8; ++k)
+        if (node[(size_t)v * 8 + k] == n) ws += w[(size_t)v * 8 + k];
+      if (ws > 0.0) { vtx.push_back(v); cw.push_back(ws); }
+    }
+    off[n + 1] = (int)vtx.size();
+  }
+  std::vector<double> ai(coarse_inverse_host, coarse_inverse_host + (size_t)9 * nc * nc);
+  hipError_t e = hipSetDevice(c->device);
+  if (e != hipSuccess) return fail_hip(e, "hipSetDevice");
+  FemDev& d = c->dev;
+  if (int rc = fem_upload(c, node, &d.cv_node) | fem_upload(c, w, &d.cv_w) | fem_upload(c, off, &d.cn_off) | fem_upload(c, vtx, &d.cn_vtx) |
+               fem_upload(c, cw, &d.cn_w) | fem_upload(c, ai, &d.ac_inv))
+    return rc;
+  d.nc = nc;
+  FemDev& n2 = c->dev_nwt;
+  n2.nc = nc; n2.cv_node = d.cv_node; n2.cv_w = d.cv_w; n2.cn_off = d.cn_off; n2.cn_vtx = d.cn_vtx; n2.cn_w = d.cn_w; n2.ac_inv = d.ac_inv;
+  return 0;
+}
+
 int tacex_fem_set_newton_early_exit(tacex_fem_ctx* c, double* dx_dev, double dx_tol) {
   if (!c) { set_error("tacex_fem_set_newton_early_exit: null context"); return 2; }
   c->dx_dev = dx_dev;
   c->dx_tol = dx_dev ? dx_tol : 0.0;
   return 0;
+}
+
+// one launch of the Newton kernel: up to max_newton iterations per env inside the CU-resident kernel, one iteration of the
+// streaming fallback (mesh with more vertices than a workgroup has threads; TACEX_FEM_NEWTON_LDS=0)
+static int launch_newton(tacex_fem_ctx* c, double* x, const double* xt, const uint8_t* cons, const double* aim, double* stats, void* ws,
+                         int B, int pcg_max_iter, double pcg_tol_rate, int ls_max_iter, double* dx_dev, double dx_tol, int max_newton,
+                         double* step_info, hipStream_t st, bool* resident) {
+  static const int use_lds = getenv("TACEX_FEM_NEWTON_LDS") ? atoi(getenv("TACEX_FEM_NEWTON_LDS")) : 1;
+  const size_t lds = ((size_t)6 * c->dev.V + (size_t)12 * kNwtChunk + 18) * sizeof(double) + (size_t)4 * c->dev.T * sizeof(int);
+  if (use_lds && c->dev.V <= kNwtThreads && lds <= 160 * 1024) {
+    if (resident) *resident = true;
+    static size_t granted[64] = {};  // per device: the attribute is per kernel AND device
+    hipError_t ea = hipSetDevice(c->device);
+    if (ea == hipSuccess) ea = ensure_dynamic_lds(reinterpret_cast<const void*>(fem_newton_lds_kernel), lds, granted);
+    if (ea != hipSuccess) return fail_hip(ea, "hipFuncSetAttribute(fem_newton_lds_kernel)");
+    hipLaunchKernelGGL(fem_newton_lds_kernel, dim3(B), dim3(kNwtThreads), lds, st, c->dev_nwt, x, xt, cons, aim, stats, pcg_max_iter,
+                       pcg_tol_rate, ls_max_iter, dx_dev, dx_tol, max_newton, step_info);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : fail_hip(e, "fem_newton_lds_kernel");
+  }
+  if (resident) *resident = false;
+  if (c->dev.indenters) {
+    set_error("FEM Newton: contact needs the CU-resident Newton kernel (mesh with <= %d vertices, TACEX_FEM_NEWTON_LDS != 0)", kNwtThreads);
+    return 2;
+  }
+  hipLaunchKernelGGL(fem_newton_kernel, dim3(B), dim3(512), 0, st, c->dev, x, xt, cons, aim, stats, static_cast<double*>(ws), pcg_max_iter,
+                     pcg_tol_rate, ls_max_iter, dx_dev, dx_tol);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : fail_hip(e, "fem_newton_kernel");
 }
 
 int tacex_fem_newton_step(tacex_fem_ctx* c, double* x, const double* xt, const uint8_t* cons, const double* aim,
@@ -1262,32 +1494,46 @@ int tacex_fem_newton_step(tacex_fem_ctx* c, double* x, const double* xt, const u
   if ((cons == nullptr) != (aim == nullptr)) { set_error("tacex_fem_newton_step: constrained_dev and aim_dev go together"); return 2; }
   if (pcg_max_iter < 1 || ls_max_iter < 0 || !(pcg_tol_rate > 0.0)) { set_error("tacex_fem_newton_step: bad solver parameters"); return 2; }
   if (B <= 0) return 0;
-  // TACEX_FEM_NEWTON_LDS=0 selects the streaming kernel (also used when the mesh has more vertices than a workgroup has threads)
-  static const int use_lds = getenv("TACEX_FEM_NEWTON_LDS") ? atoi(getenv("TACEX_FEM_NEWTON_LDS")) : 1;
-  const size_t lds = ((size_t)6 * c->dev.V + (size_t)12 * kNwtChunk + 18) * sizeof(double) + (size_t)4 * c->dev.T * sizeof(int);
-  if (use_lds && c->dev.V <= kNwtThreads && lds <= 160 * 1024) {
-    static size_t attr_lds[64] = {};  // per device: the attribute is per kernel AND device
-    const int dv = (c->device >= 0 && c->device < 64) ? c->device : 0;
-    if (lds > attr_lds[dv]) {
-      hipError_t ea = hipSetDevice(c->device);
-      if (ea == hipSuccess)
-        ea = hipFuncSetAttribute(reinterpret_cast<const void*>(fem_newton_lds_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      if (ea != hipSuccess) return fail_hip(ea, "hipFuncSetAttribute(fem_newton_lds_kernel)");
-      attr_lds[dv] = lds;
-    }
-    hipLaunchKernelGGL(fem_newton_lds_kernel, dim3(B), dim3(kNwtThreads), lds, (hipStream_t)stream, c->dev_nwt, x, xt, cons, aim,
-                       stats, pcg_max_iter, pcg_tol_rate, ls_max_iter, c->dx_dev, c->dx_tol);
-    hipError_t e = hipGetLastError();
-    return e == hipSuccess ? 0 : fail_hip(e, "fem_newton_lds_kernel");
-  }
-  if (c->dev.indenters) {
-    set_error("tacex_fem_newton_step: contact needs the CU-resident Newton kernel (mesh with <= %d vertices, TACEX_FEM_NEWTON_LDS != 0)", kNwtThreads);
+  return launch_newton(c, x, xt, cons, aim, stats, ws, B, pcg_max_iter, pcg_tol_rate, ls_max_iter, c->dx_dev, c->dx_tol, 1, nullptr,
+                       (hipStream_t)stream, nullptr);
+}
+
+int tacex_fem_step(tacex_fem_ctx* c, double* x, double* v, double* xt, const uint8_t* cons, const double* aim, double* stats,
+                   double* step_info, void* ws, int B, const double gravity[3], int max_newton, double velocity_tol, int pcg_max_iter,
+                   double pcg_tol_rate, int ls_max_iter, void* stream) {
+  if (!c || !x || !v || !xt || !stats || !step_info || !ws || !gravity) { set_error("tacex_fem_step: null argument"); return 2; }
+  if ((cons == nullptr) != (aim == nullptr)) { set_error("tacex_fem_step: constrained_dev and aim_dev go together"); return 2; }
+  if (max_newton < 1 || pcg_max_iter < 1 || ls_max_iter < 0 || !(pcg_tol_rate > 0.0) || !(velocity_tol >= 0.0)) {
+    set_error("tacex_fem_step: bad solver parameters");
     return 2;
   }
-  hipLaunchKernelGGL(fem_newton_kernel, dim3(B), dim3(512), 0, (hipStream_t)stream, c->dev, x, xt, cons, aim, stats,
-                     static_cast<double*>(ws), pcg_max_iter, pcg_tol_rate, ls_max_iter);
+  if (B <= 0) return 0;
+  hipStream_t st = (hipStream_t)stream;
+  const int V = c->dev.V;
+  const size_t n3 = (size_t)B * V * 3;
+  double* xprev = static_cast<double*>(ws) + (size_t)B * newton_ws_doubles(V, c->dev.T);
+  double* dx = xprev + n3;  // (B,) max |d| per env: the device-side convergence state of this time step
+  const double dt = c->dev.dt, tol = velocity_tol * dt;
+  hipLaunchKernelGGL(fem_predict_kernel, dim3((unsigned)((n3 + 255) / 256)), dim3(256), 0, st, x, v, xt, xprev, dx, n3, B, dt, gravity[0],
+                     gravity[1], gravity[2]);
   hipError_t e = hipGetLastError();
-  return e == hipSuccess ? 0 : fail_hip(e, "fem_newton_kernel");
+  if (e != hipSuccess) return fail_hip(e, "fem_predict_kernel");
+  bool resident = false;
+  if (int rc = launch_newton(c, x, xt, cons, aim, stats, ws, B, pcg_max_iter, pcg_tol_rate, ls_max_iter, dx, tol, max_newton, step_info, st,
+                             &resident))
+    return rc;
+  if (!resident) {
+    // streaming fallback: one launch per Newton iteration on a FIXED schedule; converged envs return at once (dx protocol), so the
+    // launches past convergence cost microseconds and nothing is read back.  step_info is filled from the last launch only.
+    for (int it = 1; it < max_newton; ++it)
+      if (int rc = launch_newton(c, x, xt, cons, aim, stats, ws, B, pcg_max_iter, pcg_tol_rate, ls_max_iter, dx, tol, 1, nullptr, st, nullptr))
+        return rc;
+    e = hipMemsetAsync(step_info, 0, (size_t)B * 4 * sizeof(double), st);
+    if (e != hipSuccess) return fail_hip(e, "hipMemsetAsync(step_info)");
+  }
+  hipLaunchKernelGGL(fem_velocity_kernel, dim3((unsigned)((n3 + 255) / 256)), dim3(256), 0, st, x, xprev, v, n3, 1.0 / dt);
+  e = hipGetLastError();
+  return e == hipSuccess ? 0 : fail_hip(e, "fem_velocity_kernel");
 }
 
 int tacex_fem_set_attachment_targets(const float* body_pos, const float* body_quat, const float* offsets, const int32_t* idx,

@@ -70,9 +70,6 @@ struct tacex_taxim_ctx {
   int mk_version = 0;
   const int* frame_rows = nullptr; int frame_rows_cap = 0;  // caller-owned contact row ranges (tacex_taxim_set_frame_rows)
   int* stream_order = nullptr; int stream_order_cap = 0;  // item order of a streaming-tail launch (stream_order_kernel), grown by stream_plan
-  // measured cost of every item per pass of the shard (frame0 -> buffer): what the items of that pass took in its previous launch
-  struct StreamCost { int frame0, n_items; int* buf; bool valid; };
-  std::vector<StreamCost> stream_costs;
   std::vector<void*> allocs;
   // profiling
   bool profiling = false;
@@ -549,7 +546,7 @@ int tacex_indentation_depth(const float* hm_mm, float gelpad_h, float gelpad_dmi
 static int pipeline_chunk(tacex_taxim_ctx* c, const float* hm, const float* press, float* frame_min, float* rgb,
                           float* z_out, uint8_t* mask_out, void* ws, int B, unsigned flags, hipStream_t st,
                           float* obs_h, void* obs, int obs_hh, int obs_w, FotsReduce* fots_part, int frame0,
-                          const int* rows = nullptr, int chunk0 = 0);
+                          const int* rows = nullptr);
 
 // Frames per pass of the pipeline.  With the LDS-tiled tail, large shards are walked in chunks whose level buffers (Z ping /
 // pong, 4 B/px each) plus height map stay resident in the 256 MB Infinity Cache (measured in round 1 at 2048 frames: k=33
@@ -622,7 +619,7 @@ static int pipeline_impl(tacex_taxim_ctx* c, const float* hm, const float* press
                             flags, st, obs_h,
                             obs ? static_cast<char*>(obs) + (size_t)b0 * obs_hh * obs_w * 3 * ((flags & TACEX_FLAG_OBS_U8) ? 1 : 4) : nullptr,
                             obs_hh, obs_w, fp ? fp + (size_t)b0 * fper : nullptr, B <= c->fots_pix_cap ? b0 : -1,
-                            rows ? rows + 2 * b0 : nullptr, b0);
+                            rows ? rows + 2 * b0 : nullptr);
     if (rc) return rc;
   }
   return 0;
@@ -640,7 +637,7 @@ static int resize_obs(tacex_taxim_ctx* c, const float* rgb, float* scratch, void
 static int pipeline_chunk(tacex_taxim_ctx* c, const float* hm, const float* press, float* frame_min, float* rgb,
                           float* z_out, uint8_t* mask_out, void* ws, int B, unsigned flags, hipStream_t st,
                           float* obs_h, void* obs, int obs_hh, int obs_w, FotsReduce* fots_part, int frame0,
-                          const int* rows, int chunk0) {
+                          const int* rows) {
   const bool obs_u8 = (flags & TACEX_FLAG_OBS_U8) != 0;
   const size_t img = align_up((size_t)B * c->H * c->W * sizeof(float), 256);
   const size_t vec = align_up((size_t)B * sizeof(float), 256);
@@ -702,27 +699,14 @@ static int pipeline_chunk(tacex_taxim_ctx* c, const float* hm, const float* pres
                           (size_t)B * plan->nstrips * plan->nseg * plan->obs_nrows * plan->obs_ncols * 3 <= obs_scratch_floats;
     const bool pix = frame0 >= 0 && c->fots_pix_z && c->mk_x;
     float* z_last = src == zbuf[0] ? zbuf[1] : zbuf[0];  // the level buffer the last band level did not write
-    // the pass's item costs from its previous launch (keyed by the first frame of the pass and its item count)
     const int n_items = B * plan->nstrips * plan->nseg;
-    tacex_taxim_ctx::StreamCost* sc = nullptr;
-    for (auto& e : c->stream_costs)
-      if (e.frame0 == chunk0 && e.n_items == n_items) sc = &e;
-    if (!sc && c->stream_costs.size() < 64) {
-      void* pbuf = nullptr;
-      HIP_TRY(hipSetDevice(c->device), "hipSetDevice");
-      HIP_TRY(hipMalloc(&pbuf, (size_t)n_items * sizeof(int)), "hipMalloc(stream cost)");
-      c->allocs.push_back(pbuf);
-      c->stream_costs.push_back({chunk0, n_items, static_cast<int*>(pbuf), false});
-      sc = &c->stream_costs.back();
-    }
     HIP_TRY(run_stream_tail(c->levels, c->n_levels, n_fused, src, hm, c->gel_dev, sa, sb, pd, &c->shade, rgb, z_last, B, c->H, c->W,
                             c->contact_scale, *plan, fuse_obs ? obs_h : nullptr, fots_part,
                             (int)(tail_tiles_per_frame(c->H, c->W) * kTailWavesPerTile),
                             pix ? c->fots_pix_z + (size_t)frame0 * c->fots_taps.n_markers : nullptr,
                             pix ? c->fots_pix_m + (size_t)frame0 * c->fots_taps.n_markers : nullptr, st, rows, band_grow,
-                            n_items <= c->stream_order_cap ? c->stream_order : nullptr, sc ? sc->buf : nullptr, sc && sc->valid),
+                            n_items <= c->stream_order_cap ? c->stream_order : nullptr),
             "taxim_stream_kernel");
-    if (sc) sc->valid = true;
     if (fuse_obs) {
       HIP_TRY(run_obs_finish_stream(obs_h, obs, obs_u8, *plan, B, st), "obs_finish_stream_kernel");
     } else if (want_obs) {

@@ -76,7 +76,6 @@ struct StreamArgs {
   const int* rows_ext;      // (B,2) contact row range of every frame (frame_rows_kernel), nullable
   int ext_grow;             // rows by which the band levels have spread the non-zero range of zin beyond it
   const int* order;         // (B * nstrips * nseg) item of every launched wave, heaviest first (stream_order_kernel); nullptr: identity
-  int* cost;                // (B * nstrips * nseg) clock ticks every item took in THIS launch (the next launch's sort key), nullable
 };
 
 __device__ __forceinline__ float dpp_from_left(float v) {   // lane i receives lane i-1's value
@@ -221,7 +220,6 @@ __global__ __launch_bounds__(64 * kStreamWaves, MINW) void taxim_stream_kernel(S
   const int slot = blockIdx.x * kStreamWaves + wv_in_blk;
   if (slot >= n_items) return;
   const int wv = a.order != nullptr ? __builtin_amdgcn_readfirstlane(a.order[slot]) : slot;
-  const unsigned t_start = (unsigned)__builtin_readcyclecounter();
   const int frame = wv / per_frame;
   const int rem = wv - frame * per_frame;
   const int strip = rem / a.nseg, seg = rem - strip * a.nseg;
@@ -453,6 +451,9 @@ __global__ __launch_bounds__(64 * kStreamWaves, MINW) void taxim_stream_kernel(S
       rgb[3 * i + 0] = __builtin_amdgcn_fmed3f(p0 + bq[i].x, 0.0f, 1.0f);  // TT:257-258
       rgb[3 * i + 1] = __builtin_amdgcn_fmed3f(p1 + bq[i].y, 0.0f, 1.0f);
       rgb[3 * i + 2] = __builtin_amdgcn_fmed3f(p2 + bq[i].z, 0.0f, 1.0f);
+      // (Three LINEAR stores per row - lane L of store j writing pixel 64 j + L after a transposition through the staging row -
+      //  were built and measured in round 3: a third of the L2 write requests (44.4 M of 21 bytes per 1024 frames here, the
+      //  write-through L1 forwarding every 12-byte piece on its own), the same kernel time; profiles/r03_experiments.md.)
 #ifdef TACEX_DBG_NO_STORE
       if (valid[i] && rgb[3 * i] == 12345.0f)
 #else
@@ -504,20 +505,20 @@ __global__ __launch_bounds__(64 * kStreamWaves, MINW) void taxim_stream_kernel(S
 #pragma unroll
         for (int i = 0; i < PX; ++i) pcf[i] = rf;
       }
-      if (do_fots) {
-        if (a.pix_z != nullptr || a.pix_m != nullptr) {  // marker taps of this wave's rows: deformed gel 0, no contact
-          const int e0 = a.rows[r0 * kStreamRowInts + 5], e1 = a.rows[(r1 - 1) * kStreamRowInts + 6];
-          for (int e = e0 + lane; e < e1; e += 64) {
-            const int mx = a.mk_x[e];
-            if (mx >= vx0 && mx < vx1) {
-              const size_t o = (size_t)frame * a.n_markers + a.mk_id[e];
-              if (a.pix_z != nullptr) a.pix_z[o] = 0.0f;
-              if (a.pix_m != nullptr) a.pix_m[o] = 0;
-            }
+      if (LEVELS && (a.pix_z != nullptr || a.pix_m != nullptr)) {  // marker taps of this wave's rows: deformed gel 0, no contact
+        // (registered taps are written whether or not the contact-statistics partials are: a stale tap of an earlier frame
+        //  must not survive a flat wave)
+        const int e0 = a.rows[r0 * kStreamRowInts + 5], e1 = a.rows[(r1 - 1) * kStreamRowInts + 6];
+        for (int e = e0 + lane; e < e1; e += 64) {
+          const int mx = a.mk_x[e];
+          if (mx >= vx0 && mx < vx1) {
+            const size_t o = (size_t)frame * a.n_markers + a.mk_id[e];
+            if (a.pix_z != nullptr) a.pix_z[o] = 0.0f;
+            if (a.pix_m != nullptr) a.pix_m[o] = 0;
           }
         }
-        f_zmax = (valid[0] || valid[1] || valid[2]) ? 0.0f : -INFINITY;
       }
+      if (do_fots) f_zmax = (valid[0] || valid[1] || valid[2]) ? 0.0f : -INFINITY;
       v3f bq[PX], bn[PX] = {(v3f)(0.0f), (v3f)(0.0f), (v3f)(0.0f)};
       load_bg(r0, bq);
       for (int e = r0; e < r1; ++e) {
@@ -903,35 +904,21 @@ __global__ __launch_bounds__(64 * kStreamWaves, MINW) void taxim_stream_kernel(S
       for (int s2 = per_frame + lane; s2 < a.fots_stride; s2 += 64) a.fots_part[(size_t)frame * a.fots_stride + s2] = id;
     }
   }
-  if (a.cost != nullptr && lane == 0) a.cost[wv] = (int)(((unsigned)__builtin_readcyclecounter() - t_start) >> 4);
 }
 
-// Items of a launch sorted by weight, heaviest first.  The key is what the item COST in the previous launch of the same shard
-// (clock ticks written by the kernel itself: contacts move little from one simulation step to the next, and a stale key only
-// costs balance, never correctness); the first launch of a shard uses a geometric estimate instead: the rows of the item's
-// segment that lie on (or within a few rows of) the frame's contact rows - there the shading gathers table records and runs
-// the magnitude arc tangent - 0 for a flat item (no contact within the pyramid's reach: no levels, no bins).  Counting sort by
-// one workgroup; the order inside a bucket is whatever the atomics give (every item's output is independent of where it runs).
-__global__ __launch_bounds__(1024) void stream_order_kernel(const int* __restrict__ rows_ext, const int* __restrict__ cost, int n_items,
-                                                            int per_frame, int nseg, int seg_rows, int H, int reach, int* __restrict__ order) {
+// Items of a launch sorted by weight, heaviest first: key = rows of the item's segment that lie on (or within a few rows of) the
+// frame's contact rows - there the shading gathers table records and runs the magnitude arc tangent - 0 for a flat item (no
+// contact within the pyramid's reach: no levels, no bins).  Counting sort by one workgroup; the order inside a bucket is
+// whatever the atomics give (every item's output is independent of where it runs).  (Keying on the clock ticks each item took
+// in the previous launch of the same shard was built and measured: WORSE than this geometric key - 752 vs 720 us per 1024
+// frames - the measured time of an item contains the contention it ran under; profiles/r03_experiments.md.)
+__global__ __launch_bounds__(1024) void stream_order_kernel(const int* __restrict__ rows_ext, int n_items, int per_frame, int nseg,
+                                                            int seg_rows, int H, int reach, int* __restrict__ order) {
   constexpr int kKeys = 1024;
-  __shared__ int hist[kKeys], start[kKeys], red[16];
+  __shared__ int hist[kKeys], start[kKeys];
   for (int k = threadIdx.x; k < kKeys; k += blockDim.x) hist[k] = 0;
-  // measured costs: scaled so that the longest item of the previous launch gets the last key
-  float scale = 0.0f;
-  if (cost != nullptr) {
-    int mx = 0;
-    for (int i = threadIdx.x; i < n_items; i += blockDim.x) mx = max(mx, cost[i]);
-    for (int o = 32; o > 0; o >>= 1) mx = max(mx, __shfl_xor(mx, o, 64));
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mx;
-    __syncthreads();
-    mx = 0;
-    for (int w = 0; w < 16; ++w) mx = max(mx, red[w]);
-    scale = mx > 0 ? (float)(kKeys - 1) / (float)mx : 0.0f;
-  }
   __syncthreads();
   auto key_of = [&](int item) {
-    if (cost != nullptr) return min(kKeys - 1, max(0, (int)((float)cost[item] * scale)));
     const int frame = item / per_frame, seg = (item - frame * per_frame) % nseg;
     const int r0 = seg * seg_rows, r1 = min(H, r0 + seg_rows);
     const int lo = rows_ext[2 * frame], hi = rows_ext[2 * frame + 1];
@@ -1078,7 +1065,7 @@ hipError_t run_stream_tail(const LevelDesc* lv, int n_levels, int n_fused, const
                            const float* sa, const float* sb, const float* pd, const ShadeParams* sp, float* rgb, float* z_last,
                            int B, int H, int W, float contact_scale, const StreamPlan& plan, float* obs_part,
                            FotsReduce* fots_part, int fots_stride, float* pix_z, uint8_t* pix_m, hipStream_t st,
-                           const int* rows_ext, int ext_grow, int* order_buf, int* cost_buf, bool cost_valid) {
+                           const int* rows_ext, int ext_grow, int* order_buf) {
   // TACEX_STREAM_ORDER=0: items in frame order (A/B path); the split kernels always run that way
   static const int sorted = getenv("TACEX_STREAM_ORDER") ? atoi(getenv("TACEX_STREAM_ORDER")) : 1;
   StreamArgs a{};
@@ -1120,14 +1107,11 @@ hipError_t run_stream_tail(const LevelDesc* lv, int n_levels, int n_fused, const
     if (sorted && order_buf && gz && rows_ext) {  // heaviest items first (see the kernel's "work distribution" note)
       const int n_items = B * sh.nstrips * sh.nseg;
       const int sum_r = v == 0 ? 9 : (v == 1 ? 10 : 5);
-      static const int use_cost = getenv("TACEX_STREAM_ORDER_COST") ? atoi(getenv("TACEX_STREAM_ORDER_COST")) : 1;
-      hipLaunchKernelGGL(stream_order_kernel, dim3(1), dim3(1024), 0, st, rows_ext,
-                         (use_cost && cost_buf && cost_valid) ? cost_buf : nullptr, n_items, sh.nstrips * sh.nseg, sh.nseg, sh.seg_rows, H,
+      hipLaunchKernelGGL(stream_order_kernel, dim3(1), dim3(1024), 0, st, rows_ext, n_items, sh.nstrips * sh.nseg, sh.nseg, sh.seg_rows, H,
                          ext_grow + sum_r + 1, order_buf);
       hipError_t e = hipGetLastError();
       if (e != hipSuccess) return e;
       sh.order = order_buf;
-      sh.cost = use_cost ? cost_buf : nullptr;
     }
     if (v == 0) return launch_stream<kStreamFused, 9, 5, 3, 5>(sh, gz, st);
     if (v == 1) return launch_stream<kStreamFused, 9, 5, 9>(sh, gz, st);

@@ -198,14 +198,23 @@ class VisionTactileSensorUIPC:
             idx = torch.nonzero(mask).reshape(-1)
             self._static_flow = (key, init_uv, idx, idx.cpu().numpy())
             self._sel_ring = [torch.empty(self.num_markers, dtype=torch.int64).pin_memory() for _ in range(8)]
+            self._sel_events = [None] * len(self._sel_ring)  # recorded behind each slot's H2D copy: a slot is reused only once its copy ran
             self._sel_pos = 0
         _, init_uv, idx_dev, idx_host = self._static_flow
         n = idx_host.size
         if n >= self.num_markers:
-            buf = self._sel_ring[self._sel_pos % len(self._sel_ring)]
+            slot = self._sel_pos % len(self._sel_ring)
+            buf = self._sel_ring[slot]
             self._sel_pos += 1
+            if self._sel_events[slot] is not None:
+                # the host may run more than a ring's worth of steps ahead of the device: overwriting a pinned buffer whose copy has
+                # not executed yet would hand an earlier step the wrong subset.  Waits only in that case (eight steps behind).
+                self._sel_events[slot].synchronize()
             buf.numpy()[:] = idx_host[self._rng.choice(n, self.num_markers, replace=False)]
             sel = buf.to(self.device, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(self.device))
+            self._sel_events[slot] = ev
         elif n > 0:  # pad by repeating the last marker (VT:400-405)
             sel = torch.cat([idx_dev, idx_dev[-1:].expand(self.num_markers - n)])
         else:

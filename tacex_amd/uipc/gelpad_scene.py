@@ -1,0 +1,77 @@
+"""The gelpad scene of BASELINE configs 4 / 5 (`FemGelpad`): what a tacex_uipc task assembles from UipcSim + UipcObject +
+UipcIsaacAttachments (envs/ball_rolling_uipc.py:100-140 of the reference's benchmark harness: a gelpad attached to the sensor
+case, an indenter pressing into it), with the rigid bodies replaced by prescribed trajectories.  Used by bench.py and by
+tests/test_fem_gpu.py; everything below runs on the device, no host round trip per step."""
+from __future__ import annotations
+
+import math
+
+import numpy as np
+import torch
+
+from .uipc_attachments import UipcIsaacAttachments, UipcIsaacAttachmentsCfg
+from .uipc_object import UipcObject, UipcObjectCfg, gelpad_box_mesh
+from .uipc_sim import UipcSim, UipcSimCfg
+
+
+class FemGelpad:
+    """C4 / C5: one ~2k-tet gelpad per env (20.75 x 25.25 x 4.5 mm block, 495 vertices / 1920 tets).  Its back face is held by
+    the sensor case through UipcIsaacAttachments (aim = R(q) offset + p, soft position constraints); a spherical indenter
+    presses into the front face through the IPC barrier (d_hat 1 mm, CCD-filtered Newton steps) and breathes in and out;
+    stepped with UipcSim.step (backward Euler: the whole Newton loop - matrix-free PCG, CCD filter, line search - in one HIP launch)."""
+
+    def __init__(self, B, dev, max_newton_iter: int = 8):
+        self.max_newton_iter = max_newton_iter
+        P, T = gelpad_box_mesh(8, 10, 4)
+        self.sim = UipcSim(UipcSimCfg(device=dev), num_envs=B)
+        self.gelpad = UipcObject(UipcObjectCfg(mesh_points=P, mesh_tets=T), self.sim)
+        self.sim.setup_sim(constraint_strength_ratio=1000.0)  # benchmark env value (envs/ball_rolling_uipc.py:120-125)
+        self.num_tets, self.num_verts = len(T), len(P)
+        size = P.max(0) - P.min(0)
+        body = np.array([size[0] / 2, size[1] / 2, -0.001])  # the sensor case: a plate hugging the back face
+        self.att = UipcIsaacAttachments(UipcIsaacAttachmentsCfg(constraint_strength_ratio=1000.0), self.gelpad,
+                                        rigid_collider=("box", (size[0] / 2 + 1e-6, size[1] / 2 + 1e-6, 0.001)), rigid_pos=body)
+        self.body = torch.from_numpy(body).to(dev)
+        self.quat = torch.zeros((B, 4), device=dev, dtype=torch.float64)
+        self.quat[:, 0] = 1.0
+        top = P[:, 2].max()
+        fr = np.where(P[:, 2] > top - 1e-12)[0]
+        vc = fr[np.argmin(np.hypot(P[fr, 0] - size[0] / 2, P[fr, 1] - size[1] / 2))]
+        self.R = 0.004
+        self.z_rest = top + self.R + 0.0009  # lowest point of the sphere just inside d_hat
+        ind = torch.zeros((B, 8), dtype=torch.float64, device=dev)
+        ind[:, 0] = 1.0
+        ind[:, 1], ind[:, 2], ind[:, 3], ind[:, 4] = P[vc, 0], P[vc, 1], self.z_rest, self.R
+        self.ind = ind
+        self.sim.set_contact_indenters(ind)
+        self.ind = self.sim.contact_indenters  # the device buffer the kernels read; moved in place every step
+        self.depth = torch.linspace(0.0004, 0.0014, B, device=dev, dtype=torch.float64)
+        self.B = B
+        self.ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+        self.ms_log = None    # set to [] to collect the duration of every step (hipEvents, read one step late)
+        self._pending = None
+
+    def step(self, i):
+        self.ev[0].record()
+        pos = self.body[None].repeat(self.B, 1)
+        pos[:, 0] += 0.0002 * math.sin(0.2 * i)  # the case shears the pad a little
+        self.att.apply(self.sim, pos, self.quat)  # compute_aim_positions -> is_constrained / aim_position (UA:364-428)
+        # the indenter follows its breathing trajectory, but never moves more than half the current gap towards the pad
+        # (what a CCD-filtered rigid-body step would allow); all on the device, no host round trip
+        target = self.z_rest - self.depth * (0.5 - 0.5 * math.cos(0.3 * i))
+        gap = self.sim.contact_gaps().amin(1)
+        z = self.ind[:, 3]
+        self.ind[:, 3] = torch.where(z > target, torch.maximum(target, z - 0.5 * gap), target)  # down: limited; up: free
+        self.sim.step(max_newton_iter=self.max_newton_iter)
+        self.ev[1].record()
+        if self.ms_log is not None:  # (reading the previous step's events: no sync with the step just enqueued)
+            if self._pending is not None:
+                self._pending[1].synchronize()
+                self.ms_log.append(self._pending[0].elapsed_time(self._pending[1]))
+            self._pending = self.ev
+            self.ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+
+    def fem_ms_last(self):
+        ev = self._pending if (self.ms_log is not None and self._pending is not None) else self.ev
+        ev[1].synchronize()
+        return ev[0].elapsed_time(ev[1])

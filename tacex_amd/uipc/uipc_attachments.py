@@ -107,6 +107,9 @@ class UipcIsaacAttachments:
                 _lib.ptr(uipc_sim.is_constrained), _lib.ptr(self.aim_positions), B, A, int(uipc_sim.aim_position.shape[1]),
                 _lib.current_stream_handle(dev))
         _lib.check(rc, "tacex_fem_set_attachment_targets")
+        if getattr(self, "_marked_sim", None) is not uipc_sim:  # the constraint SET changed: the sim rebuilds its coarse operator once
+            uipc_sim._precond_dirty = True
+            self._marked_sim = uipc_sim
         return self.aim_positions
 
     def _compute_aim_positions(self, uipc_sim, body_pos, body_quat):

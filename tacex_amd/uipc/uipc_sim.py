@@ -47,8 +47,11 @@ class UipcSimCfg:
         solver: str = "linear_pcg"
         tol_rate: float = 1e-3
         max_iter: int = 1024
-        """PCG iteration cap (not in the reference cfg, uipc_sim.py:86-90: libuipc stops on `tol_rate`).  The block-Jacobi PCG of
-        the 1 920-tet gelpad reaches 1e-3 in ~330 iterations, so the cap only guards against stagnation."""
+        """PCG iteration cap (not in the reference cfg, uipc_sim.py:86-90: libuipc stops on `tol_rate`); only guards against stagnation."""
+        coarse_grid: tuple | str | None = "auto"
+        """Coarse grid (cells per axis) of the additive coarse correction beside the 3x3 block Jacobi (`coarse_space.py`):
+        "auto" = 3 cells along the longest extent of the mesh, proportionally fewer along the others (2 x 3 x 1 = 24 nodes for the
+        gelpad); None = block Jacobi alone (120-330 PCG iterations on the gelpad).  Not in the reference cfg."""
 
     linear_system: LinearSystem = LinearSystem()
 
@@ -92,7 +95,6 @@ class UipcSim:
         if self.device.type != "cuda":
             raise _lib.TacexHipError("UipcSim needs an AMD GPU device (no CPU fallback)")
         self._dev_index = self.device.index if self.device.index is not None else 0
-        self.last_newton_iters = 0
 
     # -- uipc_sim.py:228-248 -------------------------------------------------------------------------------
     def setup_sim(self, constraint_strength_ratio: float | None = None):
@@ -115,6 +117,8 @@ class UipcSim:
             ac = obj.cfg.attachment_cfg
             constraint_strength_ratio = ac.constraint_strength_ratio if ac is not None else 100.0
         p.constraint_strength_ratio = constraint_strength_ratio
+        self._strength = float(constraint_strength_ratio)
+        self._precond_dirty = True
         h = C.c_void_p()
         _lib.check(lib.tacex_fem_create(self._dev_index, C.byref(p), C.byref(h)), "tacex_fem_create")
         self._handle, self._lib, self._obj = h, lib, obj
@@ -145,7 +149,11 @@ class UipcSim:
         """One analytic indenter per env the gelpad surface may not penetrate: (num_envs, 8) float64
         [kind, cx, cy, cz, radius, nx, ny, nz], kind 0 none, 1 sphere (centre c, radius), 2 half-space (unit normal n through c,
         the solid side is n.(x - c) < 0), 3 capsule (centre c, radius, (nx, ny, nz) = HALF the axis vector: a lying pin, a
-        finger).  None disables contact.  Needs `cfg.contact.enable`."""
+        finger).  None disables contact.  Needs `cfg.contact.enable`.
+
+        Contract: between two `step()` calls an indenter may approach the pad by LESS than the current gap (a rigid-body
+        integrator with CCD guarantees that; `contact_gaps()` gives the gap).  A vertex found at or beyond the surface has infinite
+        barrier energy and no gradient: the step still runs, the env is flagged in `step_info[:, 2]` and `check_step()` raises."""
         if indenters is None:
             _lib.check(self._lib.tacex_fem_set_contact(self._handle, 0, 0.0, 0.0, 0), "tacex_fem_set_contact")
             self.contact_indenters = None
@@ -184,6 +192,43 @@ class UipcSim:
         idx = torch.as_tensor(vertex_idx, device=self.device, dtype=torch.long)
         self.is_constrained[:, idx] = 1
         self.aim_position[:, idx] = aim_positions.to(self.device, torch.float64)
+        self._precond_dirty = True
+
+    def refresh_preconditioner(self):
+        """(Re)build the coarse operator of the two-level preconditioner: Galerkin product of the REST-state matrix
+        M (1 + s C) + dt^2 K_0 with the coarse space, inverted on the host (72 x 72 for the gelpad) and handed to the library.
+        C = the constraint flags of env 0 (the envs of a scene share their attachment set; a preconditioner built for another
+        set stays valid, only weaker).  Runs once - at the first step after `setup_sim` / `set_constraints` / the first
+        `UipcIsaacAttachments.apply` - and reads the flags from the device (the only synchronisation of the FEM path)."""
+        self._precond_dirty = False
+        grid = self.cfg.linear_system.coarse_grid
+        if grid is None:
+            _lib.check(self._lib.tacex_fem_set_coarse_space(self._handle, 0, 0, 0, 0), "tacex_fem_set_coarse_space")
+            return
+        from .coarse_space import build_coarse_space, coarse_grid_dims, coarse_operator_inverse
+
+        obj = self._obj
+        P, T = obj.points, obj.tets
+        dims = coarse_grid_dims(P) if grid == "auto" else tuple(int(v) for v in grid)
+        node, w, nc = build_coarse_space(P, dims)
+        if nc > 64:
+            raise ValueError(f"coarse grid {dims} has {nc} nodes (the kernel takes <= 64)")
+        rest = torch.from_numpy(np.ascontiguousarray(P))[None].to(self.device)
+        _, _, h = self.element_terms(rest, energy=False, gradient=False)
+        He = h[0].cpu().numpy().reshape(12, 12, len(T)).transpose(2, 0, 1)
+        Dm = np.stack([P[T[:, 1]] - P[T[:, 0]], P[T[:, 2]] - P[T[:, 0]], P[T[:, 3]] - P[T[:, 0]]], -1)
+        det = np.linalg.det(Dm)
+        T = T.copy()
+        T[det < 0] = T[det < 0][:, [0, 2, 1, 3]]  # the library re-orients such tets the same way (its Hessians use that vertex order)
+        vol = np.abs(det) / 6.0
+        mass = np.zeros(len(P))
+        np.add.at(mass, T.reshape(-1), np.repeat(obj.cfg.mass_density * vol / 4.0, 4))
+        cons = self.is_constrained[0].cpu().numpy().astype(np.float64)
+        aci = np.ascontiguousarray(coarse_operator_inverse(He, T, mass, cons, self._strength, self.cfg.dt, node, w, nc))
+        node, w = np.ascontiguousarray(node, np.int32), np.ascontiguousarray(w, np.float64)
+        _lib.check(self._lib.tacex_fem_set_coarse_space(self._handle, nc, node.ctypes.data, w.ctypes.data, aci.ctypes.data),
+                   "tacex_fem_set_coarse_space")
+        self.coarse_space = (node, w, aci)  # what the library was given (tests hand the same tables to the oracle)
 
     # -- low-level entry points (thin wrappers of the C ABI) -----------------------------------------------------------
     def element_terms(self, x=None, energy=True, gradient=True, hessian=True, project_psd=False):
@@ -225,6 +270,8 @@ class UipcSim:
     def newton_step(self, constrained=True, _early_exit: bool = False):
         """One Newton iteration for every env.  `_early_exit` (used by `step`) lets envs that already converged in this time
         step return at once (device-side check, see `tacex_fem_set_newton_early_exit`)."""
+        if self._precond_dirty:
+            self.refresh_preconditioner()
         dx = getattr(self, "_dx", None)
         on = bool(_early_exit and dx is not None)
         if on != getattr(self, "_early_exit_on", False):
@@ -241,29 +288,42 @@ class UipcSim:
         return self.stats
 
     # -- uipc_sim.py:250-252: world.advance(); world.retrieve() ---------------------------------------------------------
-    def step(self, max_newton_iter: int | None = None, check_every: int = 4):
-        """One backward-Euler step for all envs: x_tilde = x + dt v + dt^2 g, Newton iterations, v = (x - x_n)/dt.
-        Convergence (velocity_tol, uipc_sim.py:62-66) is decided per env on the device (converged envs return at once from later
-        launches); the host only reads the batch maximum every `check_every` iterations to stop launching."""
-        dt = self.cfg.dt
-        x_n = self.x.clone()
-        self.x_tilde = x_n + dt * self.v + (dt * dt) * self._g
-        n_max = self.cfg.newton.max_iter if max_newton_iter is None else max_newton_iter
-        # device-side convergence: an env whose last update moved less than velocity_tol * dt returns at once from further
-        # Newton launches, so the iterations between two host checks cost nothing for converged envs
-        if getattr(self, "_dx", None) is None:
-            self._dx = torch.empty((self.num_envs,), dtype=torch.float64, device=self.device)
-        self._dx.fill_(float("inf"))
-        it = 0
-        tol = float(self.cfg.newton.velocity_tol) * dt
-        while it < n_max:
-            self.newton_step(_early_exit=True)
-            it += 1
-            if it % check_every == 0 or it == n_max:
-                # max |dx| of every env's last accepted update is maintained by the kernel itself (B doubles): the host reads
-                # one scalar every `check_every` launches, no copy of the state and no per-iteration sync
-                if float(self._dx.max()) <= tol:
-                    break
-        self.last_newton_iters = it
-        self.v = (self.x - x_n) / dt
+    def step(self, max_newton_iter: int | None = None):
+        """One backward-Euler step for all envs - x_tilde = x + dt v + dt^2 g, Newton iterations, v = (x - x_n) / dt - as ONE C-ABI
+        call (`tacex_fem_step`) that never touches the host: the Newton loop runs inside the kernel, every env leaves it on the
+        device once an iteration was accepted at full length with max |d| <= velocity_tol * dt (uipc_sim.py:62-66).  Iteration
+        counts and flags land in `self.step_info` (num_envs, 4) [newton_iterations, max |d|, flags, pcg_iterations]; reading
+        `last_newton_iters` / `check_step()` is what synchronises, not the step."""
+        n_max = self.cfg.newton.max_iter if max_newton_iter is None else int(max_newton_iter)
+        if self._precond_dirty:
+            self.refresh_preconditioner()
+        if getattr(self, "step_info", None) is None:
+            self.step_info = torch.zeros((self.num_envs, 4), dtype=torch.float64, device=self.device)
+            self._g_host = (C.c_double * 3)(*[float(g) for g in self.cfg.gravity])
+        with torch.cuda.device(self.device):
+            rc = self._lib.tacex_fem_step(
+                self._handle, _lib.ptr(self.x), _lib.ptr(self.v), _lib.ptr(self.x_tilde), _lib.ptr(self.is_constrained),
+                _lib.ptr(self.aim_position), _lib.ptr(self.stats), _lib.ptr(self.step_info), _lib.ptr(self._ws), self.num_envs,
+                self._g_host, n_max, float(self.cfg.newton.velocity_tol), int(self.cfg.linear_system.max_iter),
+                float(self.cfg.linear_system.tol_rate), int(self.cfg.line_search.max_iter), self._stream())
+        _lib.check(rc, "tacex_fem_step")
         return self.x
+
+    @property
+    def last_newton_iters(self) -> int:
+        """Newton iterations of the slowest env in the last step (reads the device: synchronises)."""
+        si = getattr(self, "step_info", None)
+        return int(si[:, 0].max()) if si is not None else 0
+
+    def check_step(self, raise_on_penetration: bool = True) -> dict:
+        """Diagnostics of the last step (synchronises): flag 1 = a contact vertex was at or beyond its indenter's surface when a
+        Newton iteration started - the caller moved the indenter by more than the gap between two steps (`set_contact_indenters`
+        documents the contract) and that vertex gets no restoring force; flag 2 = a line search found no decrease."""
+        si = self.step_info.cpu().numpy()
+        flags = si[:, 2].astype(np.int64)
+        out = {"newton_iters": si[:, 0].astype(np.int64), "max_d": si[:, 1], "penetrating_envs": np.nonzero(flags & 1)[0],
+               "line_search_failed_envs": np.nonzero(flags & 2)[0], "pcg_iters": si[:, 3].astype(np.int64)}
+        if raise_on_penetration and len(out["penetrating_envs"]):
+            raise RuntimeError(f"gelpad penetrated by its indenter in envs {out['penetrating_envs'][:8].tolist()}: the indenter moved by "
+                               "more than the contact gap between two steps (see UipcSim.set_contact_indenters)")
+        return out

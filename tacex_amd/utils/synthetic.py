@@ -86,3 +86,24 @@ def synthetic_depth_maps(
         depth = torch.where(fl, torch.full_like(depth, FAR_CLIP_MM), depth)
         out[s:e] = depth
     return out, indent.to(device)
+
+
+def dense_contact_depth_maps(num_frames: int, height: int = 240, width: int = 320, seed: int = 0,
+                             device: str | torch.device = "cpu") -> tuple[torch.Tensor, torch.Tensor]:
+    """Worst-case input for the data-dependent shortcuts of the pipeline: a wavy plate pressed over the WHOLE sensor, so every
+    frame, every row and (nearly) every pixel is in contact - no zero band to skip, no flat wave, the height map is needed on
+    every row and every pixel's table record lies beyond magnitude bin 0.  Returns (depth_mm (B,H,W), indent_mm (B,))."""
+    g = torch.Generator().manual_seed(seed)
+    u = torch.rand((num_frames, 6), generator=g).to(device)
+    indent = (0.6 + 0.9 * u[:, 0]).float()
+    yy, xx = torch.meshgrid(torch.arange(height, dtype=torch.float32, device=device),
+                            torch.arange(width, dtype=torch.float32, device=device), indexing="ij")
+    s = height / 240.0
+    out = torch.empty((num_frames, height, width), dtype=torch.float32, device=device)
+    for b0 in range(0, num_frames, 256):
+        uu = u[b0:b0 + 256]
+        fx = (0.04 + 0.05 * uu[:, 1]).view(-1, 1, 1) / s
+        fy = (0.05 + 0.05 * uu[:, 2]).view(-1, 1, 1) / s
+        wav = 0.15 * (1.0 + torch.sin(fx * xx[None] + 6.28 * uu[:, 3].view(-1, 1, 1)) * torch.cos(fy * yy[None] + 6.28 * uu[:, 4].view(-1, 1, 1)))
+        out[b0:b0 + 256] = GEL_TOP_MM - indent[b0:b0 + 256].view(-1, 1, 1) + wav
+    return out, indent

@@ -10,6 +10,7 @@ def _sim(points, tets, B, strength=100.0, dt=0.01):
     from tacex_amd.uipc import UipcObject, UipcObjectCfg, UipcSim, UipcSimCfg
 
     sim = UipcSim(UipcSimCfg(device="cuda:0", dt=dt), num_envs=B)
+    sim.cfg.linear_system.coarse_grid = None  # these tests pin the block-Jacobi path; the C4 tests below run the two-level one
     UipcObject(UipcObjectCfg(mesh_points=points, mesh_tets=tets), sim)
     sim.setup_sim(constraint_strength_ratio=strength)
     return sim
@@ -133,6 +134,7 @@ def test_lds_and_streaming_newton_kernels_agree(tmp_path):
         "P, T = gelpad_box_mesh(8, 10, 4)\n"
         "B = 4\n"
         "sim = UipcSim(UipcSimCfg(device='cuda:0'), num_envs=B)\n"
+        "sim.cfg.linear_system.coarse_grid = None  # the streaming kernel has no coarse correction: compare like with like\n"
         "UipcObject(UipcObjectCfg(mesh_points=P, mesh_tets=T), sim)\n"
         "sim.setup_sim()\n"
         "sim.cfg.linear_system.max_iter = 60\n"
@@ -285,6 +287,7 @@ def test_attachment_chain_aim_set_constraints_step_vs_oracle():
     P, Tt = box_tet_mesh(4, 5, 2)
     B = 3
     sim = UipcSim(UipcSimCfg(device="cuda:0"), num_envs=B)
+    sim.cfg.linear_system.coarse_grid = None  # compared with the oracle's block-Jacobi step
     gel = UipcObject(UipcObjectCfg(mesh_points=P, mesh_tets=Tt), sim)
     sim.setup_sim(constraint_strength_ratio=100.0)
     sim.cfg.linear_system.max_iter, sim.cfg.linear_system.tol_rate = 200, 1e-4
@@ -340,6 +343,7 @@ def _contact_setup(B=3, strength=100.0):
 
     P, Tt = box_tet_mesh(4, 5, 2)
     sim = UipcSim(UipcSimCfg(device="cuda:0"), num_envs=B)
+    sim.cfg.linear_system.coarse_grid = None  # block-Jacobi path (the C4 tests run the two-level preconditioner)
     gel = UipcObject(UipcObjectCfg(mesh_points=P, mesh_tets=Tt), sim)
     sim.setup_sim(constraint_strength_ratio=strength)
     back = np.where(P[:, 2] < 1e-12)[0]
@@ -428,3 +432,143 @@ def test_contact_newton_step_vs_oracle_and_no_penetration():
     assert dent[0][front].max() > 1e-4 and dent[1][front].min() > 1e-4
     r = np.hypot(P[front, 0] - ind[0, 1], P[front, 1] - ind[0, 2])
     assert dent[0][front][r > 0.008].max() < 0.3 * dent[0][front].max()
+
+
+# ---- BASELINE config 4 size: the 8 x 10 x 4 gelpad (495 vertices / 1 920 tets) the LDS window / CSR cursor logic is sized for --------
+def _c4_scene(B, strength=1000.0):
+    """The bench's gelpad (tacex_amd/uipc/gelpad_scene.py) restated for the oracle: back face constrained (sheared a little), a
+    sphere over the middle of the front face just inside d_hat."""
+    from oracle.fem_oracle import ContactModel, FemModel
+    from tacex_amd.uipc import UipcObject, UipcObjectCfg, UipcSim, UipcSimCfg
+    from tacex_amd.uipc.uipc_object import gelpad_box_mesh
+
+    P, T = gelpad_box_mesh(8, 10, 4)
+    sim = UipcSim(UipcSimCfg(device="cuda:0"), num_envs=B)
+    gel = UipcObject(UipcObjectCfg(mesh_points=P, mesh_tets=T), sim)
+    sim.setup_sim(constraint_strength_ratio=strength)
+    m = FemModel.build(P, T, youngs=gel.cfg.constitution_cfg.youngs_modulus * 1e6, poisson=gel.cfg.constitution_cfg.poisson_rate,
+                       density=gel.cfg.mass_density, dt=sim.cfg.dt, strength=strength)
+    back = np.where(P[:, 2] < 1e-12)[0]
+    aim = np.repeat(P[None], B, 0)
+    aim[:, :, 0] += 0.0002 * (1 + np.arange(B))[:, None]  # every env sheared differently
+    sim.set_constraints(back, torch.from_numpy(aim[:, back]).cuda())
+    cons = np.zeros(len(P)); cons[back] = 1.0
+    top, size = P[:, 2].max(), P.max(0)
+    ind = np.zeros((B, 8)); ind[:, 0] = 1.0
+    ind[:, 1], ind[:, 2], ind[:, 4] = size[0] / 2, size[1] / 2, 0.004
+    ind[:, 3] = top + 0.004 + 0.0009 - 1e-4 * np.arange(B)  # gaps of 0.9, 0.8, ... mm: inside d_hat = 1 mm
+    sim.set_contact_indenters(torch.from_numpy(ind))
+    area = gel.surface_vertex_areas()
+    kappa = sim.cfg.contact.default_contact_resistance * 1e9 * sim.cfg.contact.d_hat
+    cms = [ContactModel(area, ind[b], sim.cfg.contact.d_hat, kappa, sim.cfg.dt) for b in range(B)]
+    return sim, m, P, cons, aim, cms
+
+
+def test_newton_step_c4_mesh_vs_oracle():
+    """Two Newton iterations on the C4 gelpad (four 512-tet LDS windows, 495 of 512 vertex threads), attachments + sphere contact,
+    against the oracle: energies before / after, step length, PCG iteration count and positions."""
+    from oracle.fem_oracle import newton_step_contact
+
+    B = 2
+    sim, m, P, cons, aim, cms = _c4_scene(B)
+    sim.cfg.linear_system.max_iter, sim.cfg.linear_system.tol_rate = 600, 1e-6
+    sim.x_tilde = sim.x.clone()
+    xo = [P.copy() for _ in range(B)]
+    for it in range(2):
+        st = sim.newton_step().cpu().numpy().copy()
+        for b in range(B):
+            xo[b], so = newton_step_contact(m, cms[b], xo[b], P, cons, aim[b], pcg_max_iter=600, pcg_tol_rate=1e-6, coarse=sim.coarse_space)
+            assert abs(st[b, 0] - so[0]) <= 1e-6 * abs(so[0]) + 1e-20, (it, b, st[b], so)
+            assert abs(st[b, 1] - so[1]) <= 1e-5 * abs(so[1]) + 1e-20, (it, b, st[b], so)
+            assert st[b, 2] == so[2], (it, b, st[b], so)
+            assert abs(st[b, 3] - so[3]) <= 0.05 * so[3] + 2, (it, b, st[b], so)  # PCG iterations (summation order differs)
+            assert so[3] <= 40, so  # the two-level preconditioner at work (block Jacobi alone: > 100 at this tolerance)
+    x = sim.x.cpu().numpy()
+    for b in range(B):
+        assert np.abs(x[b] - xo[b]).max() <= 1e-6 * np.ptp(P), b
+    assert np.abs(x[0] - x[1]).max() > 1e-5  # the envs really differ
+
+
+def test_step_c4_vs_oracle_step_and_convergence_rule():
+    """UipcSim.step() = ONE tacex_fem_step call (predictor, in-kernel Newton loop with device-side exit, velocity) against the
+    oracle's fem_step over three time steps with a moving indenter: same iteration counts, positions, velocities.  The
+    convergence rule: an env may only leave the loop after an iteration accepted at FULL length - here the CCD filter
+    shortens the first iterations, which must not count as converged although their update is tiny."""
+    from oracle.fem_oracle import fem_step
+
+    B = 2
+    sim, m, P, cons, aim, cms = _c4_scene(B)
+    sim.cfg.newton.velocity_tol = 2e-3  # [m/s]: 20 um per step - tight enough to need several iterations
+    sim.cfg.linear_system.max_iter, sim.cfg.linear_system.tol_rate = 600, 1e-6
+    xo = [P.copy() for _ in range(B)]
+    vo = [np.zeros_like(P) for _ in range(B)]
+    ind = sim.contact_indenters
+    saw_truncated = False
+    for k in range(3):
+        gap = sim.contact_gaps().amin(1)
+        ind[:, 3] -= 0.4 * gap  # the indenter approaches by less than the gap (the documented contract)
+        for b in range(B):
+            cms[b].ind[3] = float(ind[b, 3])
+        sim.step(max_newton_iter=12)
+        info = sim.check_step()
+        assert len(info["penetrating_envs"]) == 0 and len(info["line_search_failed_envs"]) == 0
+        x, v = sim.x.cpu().numpy(), sim.v.cpu().numpy()
+        for b in range(B):
+            xo[b], vo[b], io = fem_step(m, cms[b], xo[b], vo[b], cons, aim[b], gravity=sim.cfg.gravity, max_newton=12,
+                                        velocity_tol=2e-3, pcg_max_iter=600, pcg_tol_rate=1e-6, coarse=sim.coarse_space)
+            assert info["newton_iters"][b] == io[0], (k, b, info["newton_iters"], io)
+            # (both stop inside the Newton tolerance of 20 um; their PCG round-off differs by ~0.1 um)
+            assert np.abs(x[b] - xo[b]).max() <= 2e-5 * np.ptp(P), (k, b)
+            assert np.abs(v[b] - vo[b]).max() <= 2e-5 * np.ptp(P) / sim.cfg.dt, (k, b)
+            saw_truncated |= io[0] > 1
+        assert float(sim.contact_gaps().amin()) > 0.0
+    assert saw_truncated
+    # a penetrating indenter is reported, not swallowed
+    ind[0, 3] -= 2.0 * float(sim.contact_gaps()[0].amin())
+    sim.step(max_newton_iter=2)
+    with pytest.raises(RuntimeError, match="penetrated"):
+        sim.check_step()
+    assert 0 in sim.check_step(raise_on_penetration=False)["penetrating_envs"]
+
+
+def test_fem_gelpad_scene_through_the_sensor():
+    """The C4 / C5 scene of bench.py (tacex_amd.uipc.gelpad_scene.FemGelpad) stepped for 8 envs and read through
+    GelSightSensor.update() with the FEM-driven marker plugin: finite state, no penetration, markers move, envs differ."""
+    from tacex_amd import GelSightSensor, GelSightSensorCfg
+    from tacex_amd.calibration import CALIB_GELSIGHT_MINI
+    from tacex_amd.simulation_approaches.fem_based import ManiSkillSimulatorCfg
+    from tacex_amd.simulation_approaches.gpu_taxim import TaximSimulatorCfg
+    from tacex_amd.uipc.gelpad_scene import FemGelpad
+    from tacex_amd.utils.synthetic import synthetic_depth_maps
+
+    B, H, W = 8, 240, 320
+    fem = FemGelpad(B, "cuda:0")
+    assert fem.num_tets == 1920 and fem.num_verts == 495
+    cfg = GelSightSensorCfg(
+        num_envs=B, sensor_camera_cfg=GelSightSensorCfg.SensorCameraCfg(resolution=(W, H), clipping_range=(0.024, 0.029)),
+        data_types=["tactile_rgb", "height_map", "marker_motion"],
+        optical_sim_cfg=TaximSimulatorCfg(calib_folder_path=str(CALIB_GELSIGHT_MINI), gelpad_height=0.0045, gelpad_to_camera_min_distance=0.024,
+                                          with_shadow=False, tactile_img_res=(W, H), device="cuda:0"),
+        marker_motion_sim_cfg=ManiSkillSimulatorCfg(tactile_img_res=(W, H), device="cuda:0", camera_pos_w=(0.008, 0.012625, -0.024)),
+        device="cuda:0")
+    s = GelSightSensor(cfg, gelpad_obj=fem.gelpad)
+    s.initialize()
+    hm, _ = synthetic_depth_maps(B, H, W, seed=5)
+    s.set_camera_depth((hm / 1000.0).cuda())
+    first = None
+    for i in range(12):
+        fem.step(i)
+        s.update(dt=0.01, force_recompute=True)
+        md = s.data.output["marker_motion"]
+        if first is None:
+            first = md.clone()
+    info = fem.sim.check_step()
+    assert len(info["penetrating_envs"]) == 0
+    x = fem.sim.x
+    assert torch.isfinite(x).all() and torch.isfinite(s.data.output["tactile_rgb"]).all() and torch.isfinite(md).all()
+    assert float(fem.sim.contact_gaps().amin()) > 0.0
+    P = torch.from_numpy(fem.gelpad.points).cuda()
+    dent = (P[None, :, 2] - x[:, :, 2]).amax(1)
+    assert float(dent.min()) > 5e-5 and float((dent.max() - dent.min())) > 1e-5  # every pad is dented, by different amounts (depth ramp)
+    assert float((md - first).abs().max()) > 0.05   # markers moved [px]
+    assert float((md[0] - md[-1]).abs().max()) > 1e-3  # the envs differ
