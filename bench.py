@@ -342,7 +342,7 @@ def roofline_leg(rig, markers):
     }
     # HBM bytes of the dominant kernel per launch from the PMC passes (FETCH_SIZE x2 + WRITE_SIZE, separate `rocprofv3 --pmc` runs,
     # committed under profiles/ - counters cannot be read live from inside the process, so this is a build-time constant)
-    for cand in ("pmc_traffic_r02.json", "pmc_traffic.json"):
+    for cand in ("pmc_traffic_r03.json", "pmc_traffic_r02.json", "pmc_traffic.json"):
         pmc = REPO / "profiles" / cand
         if pmc.exists() and (H, W) == (240, 320):
             try:
