@@ -142,14 +142,15 @@ int tacex_taxim_create(int device_id, const tacex_taxim_params* p, tacex_taxim_c
     rc |= upload(c, p->taps_h[l], (size_t)p->ksize_h[l], &c->levels[l].taps_h_dev);
     if (c->levels[l].same_taps && !rc) {
       // per-lane band weights of blur_mfma_kernel (v_mfma_f32_16x16x4_f32), lane group g = lane >> 4, i = lane & 15:
-      // table 0 (V-pass): k-step ks contracts window index u = 4 ks + g; table 1 (H-pass): u = KS g + ks;
-      // weight = w[u - RA - i + R], 0 outside the band
+      // table 0 (V-pass): k-step ks contracts window index u = 4 ks + g; table 1 (H-pass): u = mfma_h_window_col(KS, g, ks)
+      // (four consecutive k-steps = four consecutive window columns = one ds_read_b128, the chunks dealt out to the lane
+      // groups so that the read is free of LDS bank conflicts); weight = w[u - RA - i + R], 0 outside the band
       const int K = p->ksize_w[l], R = (K - 1) / 2, RA = (R + 7) & ~7, ks = (16 + 2 * RA) / 4;
       std::vector<float> tl((size_t)2 * ks * 64, 0.0f);
       for (int tab = 0; tab < 2; ++tab)
         for (int kk = 0; kk < ks; ++kk)
           for (int ln = 0; ln < 64; ++ln) {
-            const int u = tab == 0 ? 4 * kk + (ln >> 4) : ks * (ln >> 4) + kk;
+            const int u = tab == 0 ? 4 * kk + (ln >> 4) : mfma_h_window_col(ks, ln >> 4, kk);
             const int t = u - RA - (ln & 15) + R;
             if (t >= 0 && t < K) tl[((size_t)tab * ks + kk) * 64 + ln] = p->taps_w[l][t];
           }

@@ -80,6 +80,20 @@ hipError_t run_shadow_rays(const ShadowParams& sw, const ShadeParams& sp, const 
 hipError_t run_shadow(const ShadowParams& sw, const ShadeParams& sp, const float* z, const uint8_t* mask, const float* gel,
                       float* rgb, float* ws_raw, float* ws_shadow, float* ws_gdir, float* ws_tmp, int B, hipStream_t st);
 
+// H-pass contraction map of blur_mfma_kernel: window column that k-step ks of lane group g (= lane >> 4) contracts.  The window
+// (KS = WIN / 4 k-steps per group, WIN / 4 = KS chunks of four columns) is dealt out in chunk PAIRS (c, c + 2): groups 0 / 1 take
+// the two chunks of the first KS / 4 pairs, groups 2 / 3 those of the rest.  A ds_read_b128 is served in four groups of 16 lanes
+// - {0-3, 12-15, 20-27}, {4-11, 16-19, 28-31} and the same + 32 (guides/MI355X_MICROARCH.md, LDS) - i.e. eight rows of lane group
+// g and the OTHER eight rows of group g + 1: with rows 0-3 / 12-15 on even and rows 4-11 on odd tile rows (mfma_h_row) and an odd
+// pitch / 4, the two halves fall on 16-byte slots of different parity when their chunks differ by 2: no bank conflict (the
+// linear map u = KS g + ks had 5 of 16 slots hit twice: LDS conflict ratio 0.42 at k = 61).
+__host__ __device__ inline int mfma_h_window_col(int KS, int g, int ks) {
+  const int p = (ks >> 2) + (g >> 1) * (KS >> 2);  // chunk pair
+  return 4 * (4 * (p >> 1) + (p & 1) + 2 * (g & 1)) + (ks & 3);
+}
+// tile row that lane i (= lane & 15) of the H-pass reads, restores and stores
+__host__ __device__ inline int mfma_h_row(int i) { return (i >= 4 && i < 12) ? 2 * (i - 4) + 1 : 2 * (i < 4 ? i : i - 8); }
+
 // fused tail (taxim_tail.hip): trailing small-kernel levels + shading in one LDS-tiled kernel
 int tail_levels(const LevelDesc* lv, int n_levels, int H, int W);
 // triangle-filter tables of the antialiased policy-observation down-sample (one entry per output row / column):

@@ -177,7 +177,8 @@ __global__ __launch_bounds__(640) void blur_mfma_kernel(BlurArgs a) {
 #pragma unroll
       for (int n = 0; n < 4; ++n) acc[n] = (f32x4)(0.0f);
       // restore operands: issued ahead of the MFMA chain so their latency hides behind it
-      const size_t p0 = (size_t)(by0 + 16 * t + li) * W + c0 + 4 * g;
+      const int hrow = TACEX_MFMA_H_CONSEC ? li : mfma_h_row(li);  // tile row of this lane (see mfma_h_window_col)
+      const size_t p0 = (size_t)(by0 + 16 * t + hrow) * W + c0 + 4 * g;
       v4f hv[4], gv[4];
 #pragma unroll
       for (int n = 0; n < 4; ++n) {
@@ -198,12 +199,13 @@ __global__ __launch_bounds__(640) void blur_mfma_kernel(BlurArgs a) {
           for (int n = 0; n < 4; ++n) acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(wl[ks], q[n], acc[n], 0, 0, 0);
         });
       } else {
-        const float* arow = mid + (16 * t + li) * pitch + KS * g + c0;  // window column KS g + ks of block n: + 16 n
+        const float* arow = mid + (16 * t + hrow) * pitch + c0;  // window column mfma_h_window_col(KS, g, 4 m ..) of block n: + 16 n
         static_for<0, KS / 4>([&](auto mc) {
           constexpr int m = decltype(mc)::value;
+          const int hcol = mfma_h_window_col(KS, g, 4 * m);
           v4f q[4];
 #pragma unroll
-          for (int n = 0; n < 4; ++n) q[n] = *reinterpret_cast<const v4f*>(arow + 16 * n + 4 * m);
+          for (int n = 0; n < 4; ++n) q[n] = *reinterpret_cast<const v4f*>(arow + 16 * n + hcol);
 #pragma unroll
           for (int n = 0; n < 4; ++n) acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(wl[4 * m], q[n].x, acc[n], 0, 0, 0);
 #pragma unroll
