@@ -307,28 +307,30 @@ __global__ __launch_bounds__(64 * kStreamWaves, MINW) void taxim_stream_kernel(S
   // interior lanes read back their own 16 bytes (conflict-free b128); only the few lanes with a pixel outside the image pick
   // their mirrored columns one by one (scattered b32 reads at a 4-dword lane stride would be 4-way bank conflicts for everyone)
   const bool border = xg[0] < 0 || xg[PX - 1] >= W;
+  const int edge_lane = (W - 1 - cx0) / PX, edge_slot = (W - 1 - cx0) - edge_lane * PX;  // lane / pixel slot of image column W - 1
   auto read_row = [&](int slot, int row, float (&zz)[PX], float (&hh)[PX]) {
     const float* src = rowbuf + slot * kRowSlot;
     const bool have_hm = LEVELS && row >= hm_lo && row <= hm_hi, have_z = row >= z_lo && row <= z_hi;
-    zz[0] = zz[1] = zz[2] = 0.0f;
-    if (have_z) {
-      const v4f zq = *reinterpret_cast<const v4f*>(src + lane * 4);
-      zz[0] = zq.x; zz[1] = zq.y; zz[2] = zq.z;
-    }
-    if constexpr (LEVELS) {
-      hh[0] = hh[1] = hh[2] = INFINITY;
-      if (have_hm) {
-        const v4f hq = *reinterpret_cast<const v4f*>(src + kRowArr + lane * 4);
-        hh[0] = hq.x; hh[1] = hq.y; hh[2] = hq.z;
-      }
-    }
+    // All LDS reads of the row are issued back to back and waited for ONCE (a slot that was not loaded for this row holds an
+    // older row: finite data, discarded by the wave-uniform selects below).  As first written - reads inside `if (have_z)` /
+    // `if (have_hm)` / per-pixel border branches - hipcc waited after every single read: 630 of the 4 600 cycles of an iteration
+    // (in-kernel clock, profiles/r03_experiments.md section 5).
+    const v4f zq = *reinterpret_cast<const v4f*>(src + lane * 4);
+    v4f hq = (v4f)(0.0f);
+    if constexpr (LEVELS) hq = *reinterpret_cast<const v4f*>(src + kRowArr + lane * 4);
+    float bz[PX] = {zq.x, zq.y, zq.z}, bh[PX] = {hq.x, hq.y, hq.z};
     if (border) {
 #pragma unroll
-      for (int i = 0; i < PX; ++i) {
-        if (have_z) zz[i] = src[ridx[i]];
-        if constexpr (LEVELS)
-          if (have_hm) hh[i] = src[kRowArr + ridx[i]];
+      for (int i = 0; i < PX; ++i) bz[i] = src[ridx[i]];
+      if constexpr (LEVELS) {
+#pragma unroll
+        for (int i = 0; i < PX; ++i) bh[i] = src[kRowArr + ridx[i]];
       }
+    }
+#pragma unroll
+    for (int i = 0; i < PX; ++i) {
+      zz[i] = have_z ? bz[i] : 0.0f;
+      if constexpr (LEVELS) hh[i] = have_hm ? bh[i] : INFINITY;
     }
   };
 
@@ -567,14 +569,29 @@ __global__ __launch_bounds__(64 * kStreamWaves, MINW) void taxim_stream_kernel(S
 #ifdef TACEX_STREAM_CLOCK
   float clk_acc[4] = {0.f, 0.f, 0.f, 0.f};
 #endif
+#ifdef TACEX_STREAM_CLOCK8  // finer probe: eight sections per shaded iteration (each tick drains the LDS queue: s_memtime returns through it)
+  float clk8[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  long long tk_prev = 0;
+  bool tk_on = false;
+#define TACEX_TICK(k) do { const long long tk_now = __builtin_readcyclecounter(); if (tk_on) clk8[k] += (float)(tk_now - tk_prev); tk_prev = tk_now; } while (0)
+#else
+#define TACEX_TICK(k) do { } while (0)
+#endif
   int ring_slot = ((ys % NRING) + NRING) % NRING;  // ring slot of row y (wave-uniform, advanced once per iteration)
   for (int y = flat ? ye + 1 : ys; y <= ye; ++y) {
     // ---- row y out of the ring (it landed before the previous iteration's mid_point returned); next iteration's row scalars ----
 #ifdef TACEX_STREAM_CLOCK
     const long long ck0 = __builtin_readcyclecounter();
 #endif
+#ifdef TACEX_STREAM_CLOCK8
+    tk_on = SHADE && (y - SUMR - 2) >= max(r0, 1) && (y - SUMR - 2) <= min(r1 - 1, H - 2);
+    tk_prev = __builtin_readcyclecounter();
+    if (tk_on) clk8[8] += 1.0f;
+#endif
     read_row(y & 1, row_of(y), zc, hc);
     int ninfo = load_info(y + 1);
+    asm volatile("" : "+v"(zc[0]), "+v"(zc[1]), "+v"(zc[2]));
+    TACEX_TICK(0);  // row read-back
     // The ONE point of the iteration where this wave waits for memory: every plain load of the iteration (row scalars,
     // background, table gather) has been consumed by the caller, row y+1 (issued one iteration ago) is forced to have landed, and
     // row y+2 is issued into the slot row y was read from.  Only stores follow, so they are a full iteration old at the next
@@ -588,6 +605,7 @@ __global__ __launch_bounds__(64 * kStreamWaves, MINW) void taxim_stream_kernel(S
 #ifdef TACEX_STREAM_CLOCK
       ck2 = __builtin_readcyclecounter();
 #endif
+      TACEX_TICK(5);  // the memory wait
       issue_row(row_of(y + 2), y & 1);
     };
 
@@ -630,7 +648,21 @@ __global__ __launch_bounds__(64 * kStreamWaves, MINW) void taxim_stream_kernel(S
           gx[i] = (Zu[i] - Zd[i]) * a.sh.gsy;
           gy[i] = ((i == 0 ? zl : Zm[i - 1]) - (i == PX - 1 ? zrg : Zm[i + 1])) * a.sh.gsx;
           t2[i] = fmaf(gx[i], gx[i], gy[i] * gy[i]);
-          code[i] = shade_dir_bin(a.sh, gx[i], gy[i], t2[i]);
+        }
+        // Direction bins (shade_dir_bin: direction 0 where sqrt(t2) == 0, TT:494-499).  ONE wave-uniform test for the row segment
+        // - where the gel is flat (most rows of most frames) no arc tangent runs at all - instead of one exec-mask branch per
+        // pixel slot: three branch sequences per iteration were a measurable part of the 1 700 cycles this block took.
+        const int flat_code = min((int)(3.14159274101257324f * a.sh.inv_y_binr), a.sh.nb - 1);
+        if (__builtin_amdgcn_ballot_w64(!(fmaxf(fmaxf(t2[0], t2[1]), t2[2]) < 1.17549435e-38f)) != 0) {
+#pragma unroll
+          for (int i = 0; i < PX; ++i) {
+            const float dir = atan2_fast(gx[i], gy[i]);  // (NaN for a zero gradient: discarded by the select)
+            const int c = min((int)((dir + 3.14159274101257324f) * a.sh.inv_y_binr), a.sh.nb - 1);
+            code[i] = !(t2[i] < 1.17549435e-38f) ? c : flat_code;
+          }
+        } else {
+#pragma unroll
+          for (int i = 0; i < PX; ++i) code[i] = flat_code;
         }
         // Most row segments lie outside the contact: every |gradient| is below the first magnitude-bin edge, with a margin
         // (2e-5 relative = 2.5e-7 rad) wider than the error of the arc-tangent polynomial, so bin 0 is what the full
@@ -639,11 +671,20 @@ __global__ __launch_bounds__(64 * kStreamWaves, MINW) void taxim_stream_kernel(S
 #pragma unroll
           for (int i = 0; i < PX; ++i) code[i] += shade_mag_bin(a.sh, t2[i]) * a.sh.nb;
         }
-        const int cl = dpp_from_left_i(code[PX - 1]), cr = dpp_from_right_i(code[0]);
+        // columns 0 / W-1 take the bins of columns 1 / W-2 (TT:501-502): one pixel of the strip at the image's left edge (lane
+        // HL, slot 0) and one of the strip at its right edge (lane / slot of column W-1), patched under wave-uniform tests
 #pragma unroll
-        for (int i = 0; i < PX; ++i) {
-          const int right = i == PX - 1 ? cr : code[i + 1], left = i == 0 ? cl : code[i - 1];
-          cc[i] = xg[i] == 0 ? right : (xg[i] == W - 1 ? left : code[i]);
+        for (int i = 0; i < PX; ++i) cc[i] = code[i];
+        if (vx0 == 0) cc[0] = lane == HL ? code[1] : code[0];
+        if (vx1 == W) {
+          if (edge_slot == 0) {
+            const int cl = dpp_from_left_i(code[PX - 1]);
+            cc[0] = lane == edge_lane ? cl : cc[0];
+          } else if (edge_slot == 1) {
+            cc[1] = lane == edge_lane ? code[0] : cc[1];
+          } else {
+            cc[2] = lane == edge_lane ? code[1] : cc[2];
+          }
         }
 #ifndef TACEX_STREAM_LATE_TABLE  // issued here, ahead of the levels: the gather's L2 round trip (18 % of the iteration when waited for
         fetch_table();            // on the spot) hides behind them; -2.3 % on the kernel for six more live registers
@@ -652,6 +693,7 @@ __global__ __launch_bounds__(64 * kStreamWaves, MINW) void taxim_stream_kernel(S
       }
     };
     shade_part1();
+    TACEX_TICK(1);  // bins, table / background fetch issue
 
     float cur[PX];
 #pragma unroll
@@ -721,6 +763,7 @@ __global__ __launch_bounds__(64 * kStreamWaves, MINW) void taxim_stream_kernel(S
           }
         }
       }
+      TACEX_TICK(2);  // S, restore ring, contact statistics, marker mask taps
       // ---- the levels: horizontal pass over the lanes, vertical scatter into the partial sums, masked restore ----
       static_for<0, NL>([&](auto lc) {
         constexpr int l = decltype(lc)::value;
@@ -795,6 +838,7 @@ __global__ __launch_bounds__(64 * kStreamWaves, MINW) void taxim_stream_kernel(S
 #pragma unroll
         for (int i = 0; i < PX; ++i) cur[i] = out[i];
       });
+      TACEX_TICK(3);  // levels
       // ---- cur = last-level row zr = y - SUMR ----
       if constexpr (!SHADE) mid_point();
       const int zr = y - SUMR;
@@ -832,6 +876,7 @@ __global__ __launch_bounds__(64 * kStreamWaves, MINW) void taxim_stream_kernel(S
         }
       }
     }
+    TACEX_TICK(4);  // last-level taps (deformed gel at the marker pixels, maximum)
     // ---- shading, part 2: table records, polynomial, background, clip, store, observation ----
     if constexpr (SHADE) {
       if (shade_now) {
@@ -862,10 +907,12 @@ __global__ __launch_bounds__(64 * kStreamWaves, MINW) void taxim_stream_kernel(S
         }
       }
     }
+    TACEX_TICK(6);  // row issue, polynomial, stores, observation
     cinfo = ninfo;
     unpack_info(ninfo);
 #pragma unroll
     for (int i = 0; i < PX; ++i) { Zu[i] = Zm[i]; Zm[i] = Zd[i]; Zd[i] = cur[i]; }
+    TACEX_TICK(7);  // row scalars of the next iteration
 #ifdef TACEX_STREAM_CLOCK
     {
       const long long ck3 = __builtin_readcyclecounter();
@@ -873,6 +920,12 @@ __global__ __launch_bounds__(64 * kStreamWaves, MINW) void taxim_stream_kernel(S
     }
 #endif
   }
+#ifdef TACEX_STREAM_CLOCK8
+  if (lane == 0 && SHADE) {
+    float* dbg = a.sh.rgb + fo * 3 + rem * 9;
+    for (int k = 0; k < 9; ++k) dbg[k] = clk8[k];
+  }
+#endif
 #ifdef TACEX_STREAM_CLOCK
   if (lane == 0 && SHADE) {  // probe output over the first pixels of the frame: [rem][compute before wait, wait, after wait, shaded rows]
     float* dbg = a.sh.rgb + fo * 3 + rem * 4;
