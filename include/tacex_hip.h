@@ -362,6 +362,14 @@ int tacex_fem_gradient(tacex_fem_ctx* ctx, const double* x_dev, const double* x_
 int tacex_fem_set_contact(tacex_fem_ctx* ctx, const double* vertex_area_host, double d_hat, double stiffness,
                           const double* indenters_dev);
 
+/* Coulomb friction of the gelpad surface against its env's indenter (US:103-124: enable_friction, default_friction_ratio,
+ * eps_velocity), the IPC way (Li et al. 2020, eq. 18-20) with normal force and contact normal lagged per Newton iteration; the
+ * tangential sliding is measured from the positions the time step starts at and relative to the indenter's own displacement
+ * since the previous tacex_fem_step (its positions are kept in the workspace), potential mu lam f0(|u|) smoothed below
+ * eps_velocity * dt.
+ * Acts inside tacex_fem_step only (tacex_fem_newton_step has no notion of the step's start).  friction_ratio 0 = off. */
+int tacex_fem_set_friction(tacex_fem_ctx* ctx, double friction_ratio, double eps_velocity);
+
 /* Two-level preconditioner of the Newton system (CU-resident kernel): z = D^-1 r (3x3 block Jacobi, always) + P A_c^-1 P^T r.
  * P: every vertex has 8 (coarse node, weight) pairs - the trilinear hat functions of a small grid laid over the mesh
  * (vertex_nodes_host (V,8) int32 in [0, num_coarse), vertex_weights_host (V,8) f64 >= 0, rows summing to 1; unused slots weight 0);

@@ -406,12 +406,77 @@ class ContactModel:
         return float(min(1.0, (slack * d[ok] / nd[ok]).min())) if ok.any() else 1.0
 
 
+def friction_f0(y, eps):
+    """IPC's smoothed friction potential per unit of normal force and friction ratio (Li et al. 2020, eq. 18-20): f0(y) =
+    -y^3/(3 eps^2) + y^2/eps + eps/3 below the stick tolerance eps, y beyond; returns (f0, f1 / y, f1') with f1 = f0'."""
+    y = np.asarray(y, np.float64)
+    st = y < eps
+    f0 = np.where(st, -y**3 / (3 * eps * eps) + y * y / eps + eps / 3, y)
+    f1_over_y = np.where(st, 2 / eps - y / (eps * eps), 1 / np.maximum(y, 1e-300))
+    f1p = np.where(st, 2 / eps - 2 * y / (eps * eps), 0.0)
+    return f0, f1_over_y, f1p
+
+
+class FrictionModel:
+    """Coulomb friction of the gelpad surface against its env's analytic indenter (uipc_sim.py:103-124: `enable_friction`,
+    `default_friction_ratio`, `eps_velocity`), the IPC way (Li et al. 2020, eq. 18-20): normal force lam = -dB/dd and contact normal n
+    are LAGGED - frozen at a given state (`update(x)`) - so the friction potential
+        D(x) = dt^2 mu lam f0(|u|),   u = (I - n n^T) (x - x_n - disp)
+    (x_n = positions the time step started from, disp = the indenter's own displacement since the previous step; u = tangential sliding
+    relative to it) is a smooth function of x with gradient dt^2 mu lam (f1 / |u|) u and the positive semi-definite Hessian
+    dt^2 mu lam [(f1 / |u|) (T - t t^T) + f1' t t^T], T = I - n n^T, t = u / |u| (both coefficients >= 0: no projection needed).
+    WHICH state the lag is taken from matters on this soft pad with its 10 GPa barrier: after the indenter has moved, the start
+    positions of the step - and every early Newton iterate - sit deep in the barrier, where lam is orders of magnitude above the
+    elastic forces (Newton directions of metres, PCG at its cap).  `fem_step` therefore solves the step in two phases: normal contact
+    alone until the Newton loop has converged, then the lag is taken from that BALANCED state and the loop continues with friction
+    (IPC's lagging iteration with the contact solve as its first pass).  eps = eps_velocity * dt."""
+
+    def __init__(self, cm: ContactModel, x_n, disp, mu, eps_velocity):
+        self.cm, self.dt, self.mu, self.eps = cm, cm.dt, float(mu), float(eps_velocity) * cm.dt
+        self.x_n = np.asarray(x_n, np.float64)
+        self.disp = np.asarray(disp, np.float64)
+        self.update(self.x_n)
+
+    def update(self, x):
+        """Freeze normal force and normal at the iterate x (the start of a Newton iteration)."""
+        cm = self.cm
+        d, n = contact_distance(cm.ind, x)
+        _, b1, _ = barrier(d / cm.dhat)
+        with np.errstate(invalid="ignore"):
+            self.lam = np.where(cm.area > 0, -cm.kappa * cm.area * b1 / cm.dhat, 0.0)  # normal force [N] per vertex, >= 0
+        self.n = np.where((self.lam > 0)[:, None], n, 0.0)
+
+    def _u(self, x):
+        r = x - self.x_n - self.disp
+        u = r - (r * self.n).sum(-1, keepdims=True) * self.n
+        return u, np.linalg.norm(u, axis=-1)
+
+    def energy(self, x):
+        _, y = self._u(x)
+        return self.dt**2 * self.mu * (self.lam * friction_f0(y, self.eps)[0])[self.lam > 0].sum()
+
+    def gradient(self, x):
+        u, y = self._u(x)
+        return (self.dt**2 * self.mu * self.lam * friction_f0(y, self.eps)[1])[:, None] * u
+
+    def hess_blocks(self, x):
+        u, y = self._u(x)
+        _, a, bq = friction_f0(y, self.eps)
+        t = u / np.maximum(y, 1e-300)[:, None]
+        T = np.eye(3)[None] - self.n[:, :, None] * self.n[:, None, :]
+        tt = t[:, :, None] * t[:, None, :]
+        return (self.dt**2 * self.mu * self.lam)[:, None, None] * (a[:, None, None] * (T - tt) + bq[:, None, None] * tt)
+
+
 def newton_step_contact(m: "FemModel", cm: ContactModel, x, x_tilde, constrained=None, aim=None, pcg_max_iter=64, pcg_tol_rate=1e-3,
-                        ls_max_iter=8, coarse=None, d0=None, return_dir=False):
+                        ls_max_iter=8, coarse=None, d0=None, return_dir=False, fr: "FrictionModel | None" = None):
     """`FemModel.newton_step` with the barrier terms of `cm` in gradient, preconditioner, H.p and energy, and the CCD step
     filter in front of the backtracking line search.  Returns (x_new, [E0, E1, step, pcg_iters])."""
     g = m.gradient(x, x_tilde, constrained, aim) + cm.gradient(x)
     Hc = cm.hess_blocks(x)
+    if fr is not None:
+        g = g + fr.gradient(x)
+        Hc = Hc + fr.hess_blocks(x)
     D = m.diag_blocks(x, constrained) + Hc
     mdiag = m.mass * (1.0 + (m.strength * constrained if constrained is not None else 0.0))
     Dinv = np.empty_like(D)
@@ -423,7 +488,7 @@ def newton_step_contact(m: "FemModel", cm: ContactModel, x, x_tilde, constrained
             Dinv[v] = np.eye(3) / mdiag[v]
     prec = make_preconditioner(Dinv, coarse)
     hv = lambda p: m.hess_vec(x, p, constrained) + np.einsum("vij,vj->vi", Hc, p)
-    energy = lambda y: m.energy(y, x_tilde, constrained, aim) + cm.energy(y)
+    energy = lambda y: m.energy(y, x_tilde, constrained, aim) + cm.energy(y) + (fr.energy(y) if fr is not None else 0.0)
     d, it = pcg_solve(hv, prec, -g, pcg_max_iter, pcg_tol_rate, d0)
     E0 = energy(x)
     step = step0 = cm.max_step(x, d)
@@ -442,18 +507,21 @@ def newton_step_contact(m: "FemModel", cm: ContactModel, x, x_tilde, constrained
 
 
 def fem_step(m: "FemModel", cm, x, v, constrained=None, aim=None, gravity=(0.0, 0.0, -9.8), max_newton=8, velocity_tol=0.05,
-             pcg_max_iter=1024, pcg_tol_rate=1e-3, ls_max_iter=8, coarse=None):
+             pcg_max_iter=1024, pcg_tol_rate=1e-3, ls_max_iter=8, coarse=None, friction=None):
     """One backward-Euler step of ONE env the way `tacex_fem_step` runs it (what world.advance() does, US:250-252):
     x_tilde = x + dt v + dt^2 g; Newton iterations until one is accepted at FULL length (no CCD truncation, no backtracking) with
     max |d| <= velocity_tol * dt (US:62-66) or the cap; v = (x_new - x) / dt.  Returns (x_new, v_new, info) with
     info = [newton_iterations, max |d| of the last iteration, flags (2: a line search failed), pcg_iterations_total]."""
     x0 = x
     xt = x + m.dt * v + m.dt**2 * np.asarray(gravity, np.float64)
+    # friction = (mu, eps_velocity, indenter displacement since the previous step): second phase, see FrictionModel
+    fric_pending = friction is not None and cm is not None
+    fr = None
     n, flags, pcg, dmax = 0, 0, 0, np.inf
     d0 = None
     for _ in range(max_newton):
         if cm is not None:
-            x, st, d = newton_step_contact(m, cm, x, xt, constrained, aim, pcg_max_iter, pcg_tol_rate, ls_max_iter, coarse, d0, True)
+            x, st, d = newton_step_contact(m, cm, x, xt, constrained, aim, pcg_max_iter, pcg_tol_rate, ls_max_iter, coarse, d0, True, fr)
         else:
             x, st, d = m.newton_step(x, xt, constrained, aim, pcg_max_iter, pcg_tol_rate, ls_max_iter, coarse, d0, True)
         d0 = (1.0 - st[2]) * d if 0.0 < st[2] < 1.0 else None  # warm start of the next PCG: the part of d that was cut off
@@ -463,5 +531,11 @@ def fem_step(m: "FemModel", cm, x, v, constrained=None, aim=None, gravity=(0.0, 
         if st[2] == 0.0:
             flags |= 2
         if st[2] == 1.0 and st[5] == 1.0 and dmax <= velocity_tol * m.dt:
+            if fric_pending:  # normal contact is balanced: take the friction lag from here and go on
+                fric_pending = False
+                fr = FrictionModel(cm, x0, friction[2], friction[0], friction[1])
+                fr.update(x)
+                if fr.lam.max() > 0.0:
+                    continue
             break
     return x, (x - x0) / m.dt, np.array([n, dmax, flags, pcg], np.float64)

@@ -40,6 +40,7 @@ struct FemDev {
   const double* area;       // (V) contact weight of a vertex = a third of the area of its surface triangles (0: interior); nullable
   const double* indenters;  // (B,8) [kind, cx, cy, cz, radius, nx, ny, nz]: kind 0 none, 1 sphere, 2 half-space; nullable
   double dhat, kappa;       // barrier activation distance [m], stiffness [J/m^2]
+  double fric_mu, fric_eps; // Coulomb friction ratio (0: off) and stick tolerance eps_velocity * dt [m] (tacex_fem_set_friction)
   // coarse space of the two-level preconditioner (tacex_fem_set_coarse_space); nc = 0: block Jacobi alone
   int nc;                   // coarse nodes (<= kFemMaxCoarse)
   const int* cv_node;       // (V,8) coarse nodes of a vertex (trilinear hats of a coarse grid over the mesh)
@@ -100,6 +101,51 @@ __device__ __forceinline__ ContactEval contact_eval(const FemDev& m, const doubl
   c.b1 = kw * (-2.0 * q * ln - q * q / sg) / m.dhat;
   c.b2 = kw * (-2.0 * ln - 4.0 * q / sg + q * q / (sg * sg)) / (m.dhat * m.dhat);
   return c;
+}
+// ---- lagged Coulomb friction of one surface vertex (IPC, Li et al. 2020 eq. 18-20; US:103-124 enable_friction / friction ratio /
+// eps_velocity).  Normal force lam = -dB/dd and contact normal n are LAGGED (frozen), which makes the potential a smooth function of
+// x.  The state the lag is taken from must be a balanced one: after the indenter has moved, the step's start positions and every
+// early Newton iterate sit deep in the 10 GPa barrier, where lam is orders of magnitude above the elastic forces of the soft pad
+// (Newton directions of metres, PCG at its cap).  The Newton loop therefore runs in TWO PHASES: normal contact alone until it has
+// converged, then lam / n are frozen at that state and the loop goes on with friction (IPC's lagging iteration with the contact
+// solve as its first pass); an env without an active contact skips the second phase.  u = (I - n n^T)(x - x_n - disp) is the tangential sliding relative to the indenter (x_n = positions the step
+// started from, disp = the indenter's own displacement since the previous step).  Potential mu lam f0(|u|), f0(y) = -y^3 / (3 eps^2) + y^2 / eps + eps / 3 below the stick
+// tolerance eps, y beyond; gradient mu lam (f1 / y) u; Hessian mu lam [(f1 / y)(T - t t^T) + f1' t t^T] (both coefficients >= 0).
+struct FricVertex {  // what a vertex keeps in LDS for the step: lam, n (4 doubles)
+  double lam, n[3];
+};
+struct FricEval {
+  double e;       // mu lam f0(y)              (NOT times dt^2)
+  double g[3];    // gradient
+  double h[6];    // Hessian, symmetric: xx xy xz yy yz zz
+};
+__device__ __forceinline__ FricEval friction_eval(double mu, double eps, const double* fv /* lam, n */, const double x[3], const double xn[3],
+                                                  const double disp[3], bool with_hessian) {
+  FricEval f;
+  f.e = 0.0; f.g[0] = f.g[1] = f.g[2] = 0.0;
+#pragma unroll
+  for (int k = 0; k < 6; ++k) f.h[k] = 0.0;
+  const double lam = fv[0];
+  if (!(lam > 0.0)) return f;
+  const double n0 = fv[1], n1 = fv[2], n2 = fv[3];
+  const double r0 = x[0] - xn[0] - disp[0], r1 = x[1] - xn[1] - disp[1], r2 = x[2] - xn[2] - disp[2];
+  const double rn = r0 * n0 + r1 * n1 + r2 * n2;
+  const double u0 = r0 - rn * n0, u1 = r1 - rn * n1, u2 = r2 - rn * n2;
+  const double y = sqrt(u0 * u0 + u1 * u1 + u2 * u2);
+  const bool stick = y < eps;
+  const double a = stick ? 2.0 / eps - y / (eps * eps) : 1.0 / y;   // f1 / y
+  const double c = mu * lam;
+  f.e = c * (stick ? -y * y * y / (3.0 * eps * eps) + y * y / eps + eps / 3.0 : y);
+  f.g[0] = c * a * u0; f.g[1] = c * a * u1; f.g[2] = c * a * u2;
+  if (with_hessian) {
+    const double bq = stick ? 2.0 / eps - 2.0 * y / (eps * eps) : 0.0;  // f1'
+    const double iy = y > 0.0 ? 1.0 / y : 0.0;
+    const double t0 = u0 * iy, t1 = u1 * iy, t2 = u2 * iy;
+    const double ca = c * a, cb = c * (bq - a);  // a (T - t t^T) + bq t t^T = a T + (bq - a) t t^T
+    f.h[0] = ca * (1.0 - n0 * n0) + cb * t0 * t0; f.h[1] = ca * (-n0 * n1) + cb * t0 * t1; f.h[2] = ca * (-n0 * n2) + cb * t0 * t2;
+    f.h[3] = ca * (1.0 - n1 * n1) + cb * t1 * t1; f.h[4] = ca * (-n1 * n2) + cb * t1 * t2; f.h[5] = ca * (1.0 - n2 * n2) + cb * t2 * t2;
+  }
+  return f;
 }
 constexpr double kCcdSlack = 0.9;  // fraction of the conservative (1-Lipschitz) step bound d / |dx| a Newton step may use
 
@@ -712,7 +758,8 @@ __device__ __forceinline__ double block_sum1(double v, double* sh2 /* 2 x 8 doub
 
 __device__ __forceinline__ double env_energy_lds(const FemDev& m, const double* xl, const double x3[3], const double* xt,
                                                  bool own, bool c, const double* aim, double* sh, int& phase,
-                                                 const double* ind = nullptr, double wv = 0.0) {
+                                                 const double* ind = nullptr, double wv = 0.0, const double* fv = nullptr,
+                                                 const double* xn = nullptr, const double* disp = nullptr) {
   double e = 0.0;
   const double dt2 = m.dt * m.dt;
   for (int t = threadIdx.x; t < m.T; t += blockDim.x) {
@@ -736,6 +783,10 @@ __device__ __forceinline__ double env_energy_lds(const FemDev& m, const double* 
     }
     e += 0.5 * mv * q + 0.5 * m.strength * mv * qc;
     if (ind) e += dt2 * contact_eval(m, ind, wv, x3).e;
+    if (fv) {
+      const double xn3[3] = {xn[v * 3], xn[v * 3 + 1], xn[v * 3 + 2]};
+      e += dt2 * friction_eval(m.fric_mu, m.fric_eps, fv + v * 4, x3, xn3, disp, false).e;
+    }
   }
   return block_sum1(e, sh, phase);
 }
@@ -771,7 +822,8 @@ constexpr int kFemFlagLsFailed = 2;     // a line search found no decrease even 
 __global__ __launch_bounds__(kNwtThreads) void fem_newton_lds_kernel(FemDev m, double* xg, const double* xtg,
                                                                      const uint8_t* consg, const double* aimg, double* stats,
                                                                      int pcg_max_iter, double pcg_tol_rate, int ls_max_iter,
-                                                                     double* dxg, double dx_tol, int max_newton, double* step_info) {
+                                                                     double* dxg, double dx_tol, int max_newton, double* step_info,
+                                                                     const double* xprevg, const double* dispg) {
   extern __shared__ __attribute__((aligned(16))) double nlds[];
   constexpr int CH = kNwtChunk;
   const int V = m.V, T = m.T, tid = threadIdx.x;
@@ -780,6 +832,8 @@ __global__ __launch_bounds__(kNwtThreads) void fem_newton_lds_kernel(FemDev m, d
   double* hv = ps + 3 * V;      // (12, CH) per-tet rows of the current window
   double* sh = hv + 12 * CH;    // 2 x 8 wave partials of block_sum1 (+2 pad)
   int* csr = reinterpret_cast<int*>(sh + 18);  // (4T) incidence codes tet * 4 + local, vertex-major: read every sweep
+  double* fl = reinterpret_cast<double*>(csr + ((4 * T + 1) & ~1));  // friction: (V,4) lagged normal force and normal | (V,6) Hessian blocks
+  double* fh = fl + 4 * V;
   int phase = 0;  // block_sum1 row toggle
   const int b = blockIdx.x;
   if (dxg && dxg[b] <= dx_tol) {  // this env's last update was below the Newton tolerance (uipc_sim.py:62-66): nothing to do
@@ -800,6 +854,11 @@ __global__ __launch_bounds__(kNwtThreads) void fem_newton_lds_kernel(FemDev m, d
   // contact: this vertex's weight and the env's indenter (nullptr: contact off)
   const double* ind = (m.indenters && m.area) ? m.indenters + (size_t)b * 8 : nullptr;
   const double wv = (ind && own) ? m.area[tid] : 0.0;
+  // friction needs the positions the step started from: tacex_fem_step only
+  const bool fric = ind && m.fric_mu > 0.0 && xprevg != nullptr && dispg != nullptr;
+  const double* xn = fric ? xprevg + o : nullptr;
+  double disp3[3] = {0, 0, 0};
+  if (fric) { disp3[0] = dispg[b * 3]; disp3[1] = dispg[b * 3 + 1]; disp3[2] = dispg[b * 3 + 2]; }
 
   double x3[3] = {0, 0, 0};
   if (own) {
@@ -873,6 +932,7 @@ __global__ __launch_bounds__(kNwtThreads) void fem_newton_lds_kernel(FemDev m, d
   // warm start of the next iteration's PCG: the part of this iteration's Newton direction the CCD filter / the line search cut off
   double dprev[3] = {0, 0, 0};
   double frac_prev = 0.0;  // (1 - accepted step) of the previous iteration, 0 when it was taken in full or rejected
+  bool fric_phase = false;  // friction terms are on (second phase of the loop, see friction_eval)
   for (int nit = 0; nit < max_newton; ++nit) {
   if (nit > 0) __syncthreads();  // xs carries the accepted candidate of the previous iteration
   // ---- nodal gradient ----
@@ -906,10 +966,23 @@ __global__ __launch_bounds__(kNwtThreads) void fem_newton_lds_kernel(FemDev m, d
     for (int i = 0; i < 3; ++i) r3[i] -= dt2 * ce.b1 * ce.n[i];
   }
   const double cb2 = ce.active ? dt2 * ce.b2 : 0.0;
+  // friction of this vertex at x: gradient into the residual, Hessian block into LDS (read back by H.p and the preconditioner)
+  if (fric_phase && own) {
+    const double xn3[3] = {xn[tid * 3], xn[tid * 3 + 1], xn[tid * 3 + 2]};
+    const FricEval fe = friction_eval(m.fric_mu, m.fric_eps, fl + tid * 4, x3, xn3, disp3, true);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) r3[i] -= dt2 * fe.g[i];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) fh[tid * 6 + k] = dt2 * fe.h[k];
+  }
   // ---- block-Jacobi preconditioner: 3x3 diagonal block of vertex tid (columns recomputed per incidence) ----
   double Dinv[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
   if (own) {
     double D[9] = {md, 0, 0, 0, md, 0, 0, 0, md};
+    if (fric_phase) {
+      const double* h = fh + tid * 6;
+      D[0] += h[0]; D[1] += h[1]; D[2] += h[2]; D[3] += h[1]; D[4] += h[3]; D[5] += h[4]; D[6] += h[2]; D[7] += h[4]; D[8] += h[5];
+    }
 #pragma unroll
     for (int i = 0; i < 3; ++i)
 #pragma unroll
@@ -1047,8 +1120,15 @@ __global__ __launch_bounds__(kNwtThreads) void fem_newton_lds_kernel(FemDev m, d
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
       Hp3[i] = own ? a3[i] + md * q3[i] + cb2 * ce.n[i] * (ce.n[0] * q3[0] + ce.n[1] * q3[1] + ce.n[2] * q3[2]) : 0.0;
-      part += q3[i] * Hp3[i];
     }
+    if (fric_phase && own) {
+      const double* h = fh + tid * 6;
+      Hp3[0] += h[0] * q3[0] + h[1] * q3[1] + h[2] * q3[2];
+      Hp3[1] += h[1] * q3[0] + h[3] * q3[1] + h[4] * q3[2];
+      Hp3[2] += h[2] * q3[0] + h[4] * q3[1] + h[5] * q3[2];
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) part += q3[i] * Hp3[i];
     if (warm) {  // r = b - H d0, then the usual start from there (not counted as an iteration)
 #pragma unroll
       for (int i = 0; i < 3; ++i) r3[i] -= Hp3[i];
@@ -1086,7 +1166,7 @@ __global__ __launch_bounds__(kNwtThreads) void fem_newton_lds_kernel(FemDev m, d
     ++it;
   }
   // ---- backtracking line search on the incremental potential (accept the first E(x + step d) <= E(x)) ----
-  const double E0 = env_energy_lds(m, xs, x3, xt, own, c, aim, sh, phase, ind, wv);
+  const double E0 = env_energy_lds(m, xs, x3, xt, own, c, aim, sh, phase, ind, wv, fric_phase ? fl : nullptr, xn, disp3);
   double step = 1.0, E1 = E0;
   if (ind) {
     // CCD step filter for analytic indenters: a signed distance field is 1-Lipschitz, so a vertex at gap d moving by
@@ -1109,7 +1189,7 @@ __global__ __launch_bounds__(kNwtThreads) void fem_newton_lds_kernel(FemDev m, d
       for (int i = 0; i < 3; ++i) { xc3[i] = x3[i] + step * d3[i]; ps[tid * 3 + i] = xc3[i]; }
     }
     __syncthreads();
-    const double Ec = env_energy_lds(m, ps, xc3, xt, own, c, aim, sh, phase, ind, wv);
+    const double Ec = env_energy_lds(m, ps, xc3, xt, own, c, aim, sh, phase, ind, wv, fric_phase ? fl : nullptr, xn, disp3);
     if (Ec <= E0) { E1 = Ec; accepted = true; break; }
     step *= 0.5;
   }
@@ -1134,7 +1214,23 @@ __global__ __launch_bounds__(kNwtThreads) void fem_newton_lds_kernel(FemDev m, d
     stats[(size_t)b * 4 + 0] = E0; stats[(size_t)b * 4 + 1] = E1; stats[(size_t)b * 4 + 2] = step; stats[(size_t)b * 4 + 3] = (double)it;
   }
   const bool converged = accepted && step == 1.0 && step0 == 1.0 && dmax <= dx_tol;
-  if (converged) { done = true; break; }  // wave-uniform: every quantity above is a block reduction
+  if (converged) {  // wave-uniform: every quantity above is a block reduction
+    if (fric && !fric_phase) {
+      // normal contact is balanced: freeze the friction lag (normal force, normal) at this state and go on, unless no vertex of
+      // the env is in contact
+      fric_phase = true;
+      double lam = 0.0;
+      if (own) {
+        const ContactEval cf = contact_eval(m, ind, wv, x3);
+        lam = cf.active ? -cf.b1 : 0.0;
+        fl[tid * 4] = lam;
+        fl[tid * 4 + 1] = cf.active ? cf.n[0] : 0.0; fl[tid * 4 + 2] = cf.active ? cf.n[1] : 0.0; fl[tid * 4 + 3] = cf.active ? cf.n[2] : 0.0;
+      }
+      if (__syncthreads_or(lam > 0.0)) { frac_prev = 0.0; continue; }
+    }
+    done = true;
+    break;
+  }
   }  // Newton loop
   if (own) {
 #pragma unroll
@@ -1144,7 +1240,9 @@ __global__ __launch_bounds__(kNwtThreads) void fem_newton_lds_kernel(FemDev m, d
   // has converged (<= dx_tol), a value above the tolerance while it has not (a shortened update must not count as convergence)
   if (dxg && tid == 0) dxg[b] = done ? dmax_last : fmax(dmax_last, 2.0 * dx_tol);
   if (step_info) {
-    const int any = __syncthreads_or(flags);
+    // (__syncthreads_or returns a truth value, not the OR of the bits: one reduction per flag)
+    const int any = (__syncthreads_or(flags & kFemFlagPenetration) ? kFemFlagPenetration : 0) |
+                    (__syncthreads_or(flags & kFemFlagLsFailed) ? kFemFlagLsFailed : 0);
     if (tid == 0) {
       step_info[(size_t)b * 4 + 0] = (double)n_newton; step_info[(size_t)b * 4 + 1] = dmax_last;
       step_info[(size_t)b * 4 + 2] = (double)any; step_info[(size_t)b * 4 + 3] = pcg_total;
@@ -1155,9 +1253,14 @@ __global__ __launch_bounds__(kNwtThreads) void fem_newton_lds_kernel(FemDev m, d
 // backward-Euler predictor of tacex_fem_step: x_prev = x, x_tilde = x + dt v + dt^2 g (US:250-252: what world.advance() starts from)
 __global__ __launch_bounds__(256) void fem_predict_kernel(const double* __restrict__ x, const double* __restrict__ v, double* __restrict__ xt,
                                                           double* __restrict__ xprev, double* __restrict__ dxg, size_t n3, int B,
-                                                          double dt, double g0, double g1, double g2) {
+                                                          double dt, double g0, double g1, double g2, const double* __restrict__ ind,
+                                                          const double* __restrict__ ind_prev, double* __restrict__ disp, int have_prev) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < (size_t)B && dxg) dxg[i] = INFINITY;
+  if (i < (size_t)B && ind && disp) {  // how far the env's indenter moved since the last step (friction slides relative to it)
+#pragma unroll
+    for (int k = 0; k < 3; ++k) disp[i * 3 + k] = have_prev ? ind[i * 8 + 1 + k] - ind_prev[i * 3 + k] : 0.0;
+  }
   if (i >= n3) return;
   const int k = (int)(i % 3);
   const double xi = x[i];
@@ -1165,9 +1268,14 @@ __global__ __launch_bounds__(256) void fem_predict_kernel(const double* __restri
   xt[i] = xi + dt * v[i] + dt * dt * (k == 0 ? g0 : (k == 1 ? g1 : g2));
 }
 __global__ __launch_bounds__(256) void fem_velocity_kernel(const double* __restrict__ x, const double* __restrict__ xprev,
-                                                           double* __restrict__ v, size_t n3, double inv_dt) {
+                                                           double* __restrict__ v, size_t n3, double inv_dt, const double* __restrict__ ind,
+                                                           double* __restrict__ ind_prev, int B) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n3) v[i] = (x[i] - xprev[i]) * inv_dt;
+  if (i < (size_t)B && ind && ind_prev) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) ind_prev[i * 3 + k] = ind[i * 8 + 1 + k];
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1229,6 +1337,7 @@ struct tacex_fem_ctx {
   int device = 0;
   FemDev dev{};
   FemDev dev_nwt{};  // same mesh with the tets renumbered for fem_newton_lds_kernel (see tacex_fem_create)
+  bool ind_prev_valid = false;  // the workspace holds the indenter positions of the previous tacex_fem_step (friction)
   double* dx_dev = nullptr;  // optional (B,) last Newton update max|dx| per env: converged envs skip further iterations
   double dx_tol = 0.0;
   std::vector<void*> allocs;
@@ -1349,7 +1458,8 @@ void tacex_fem_destroy(tacex_fem_ctx* c) {
 
 size_t tacex_fem_workspace_bytes(const tacex_fem_ctx* c, int B) {
   if (!c || B <= 0) return 0;
-  return ((size_t)B * newton_ws_doubles(c->dev.V, c->dev.T) + (size_t)B * 3 * c->dev.V + (size_t)B + 8) * sizeof(double);
+  // env blocks | x_prev (B,V,3) | max |d| (B) | indenter displacement (B,3) | previous indenter position (B,3)
+  return ((size_t)B * newton_ws_doubles(c->dev.V, c->dev.T) + (size_t)B * 3 * c->dev.V + (size_t)7 * B + 8) * sizeof(double);
 }
 
 int tacex_fem_element_terms(tacex_fem_ctx* c, const double* x, double* energy, double* grad, double* hess,
@@ -1407,6 +1517,18 @@ int tacex_fem_set_contact(tacex_fem_ctx* c, const double* vertex_area_host, doub
   c->dev.dhat = c->dev_nwt.dhat = d_hat;
   c->dev.kappa = c->dev_nwt.kappa = stiffness;
   c->dev.indenters = c->dev_nwt.indenters = indenters_dev;
+  c->ind_prev_valid = false;  // a new indenter set: the first step after it sees no indenter motion
+  return 0;
+}
+
+int tacex_fem_set_friction(tacex_fem_ctx* c, double friction_ratio, double eps_velocity) {
+  if (!c) { set_error("tacex_fem_set_friction: null context"); return 2; }
+  if (!(friction_ratio >= 0.0) || (friction_ratio > 0.0 && !(eps_velocity > 0.0))) {
+    set_error("tacex_fem_set_friction: need friction_ratio >= 0 and eps_velocity > 0");
+    return 2;
+  }
+  c->dev.fric_mu = c->dev_nwt.fric_mu = friction_ratio;
+  c->dev.fric_eps = c->dev_nwt.fric_eps = eps_velocity * c->dev.dt;
   return 0;
 }
 
@@ -1462,9 +1584,11 @@ int tacex_fem_set_newton_early_exit(tacex_fem_ctx* c, double* dx_dev, double dx_
 // streaming fallback (mesh with more vertices than a workgroup has threads; TACEX_FEM_NEWTON_LDS=0)
 static int launch_newton(tacex_fem_ctx* c, double* x, const double* xt, const uint8_t* cons, const double* aim, double* stats, void* ws,
                          int B, int pcg_max_iter, double pcg_tol_rate, int ls_max_iter, double* dx_dev, double dx_tol, int max_newton,
-                         double* step_info, hipStream_t st, bool* resident) {
+                         double* step_info, hipStream_t st, bool* resident, const double* xprev = nullptr, const double* disp = nullptr) {
   static const int use_lds = getenv("TACEX_FEM_NEWTON_LDS") ? atoi(getenv("TACEX_FEM_NEWTON_LDS")) : 1;
-  const size_t lds = ((size_t)6 * c->dev.V + (size_t)12 * kNwtChunk + 18) * sizeof(double) + (size_t)4 * c->dev.T * sizeof(int);
+  const bool fric = xprev && disp && c->dev.indenters && c->dev.fric_mu > 0.0;
+  const size_t lds = ((size_t)6 * c->dev.V + (size_t)12 * kNwtChunk + 18 + (fric ? (size_t)10 * c->dev.V : 0)) * sizeof(double) +
+                     (size_t)((4 * c->dev.T + 1) & ~1) * sizeof(int);
   if (use_lds && c->dev.V <= kNwtThreads && lds <= 160 * 1024) {
     if (resident) *resident = true;
     static size_t granted[64] = {};  // per device: the attribute is per kernel AND device
@@ -1472,7 +1596,7 @@ static int launch_newton(tacex_fem_ctx* c, double* x, const double* xt, const ui
     if (ea == hipSuccess) ea = ensure_dynamic_lds(reinterpret_cast<const void*>(fem_newton_lds_kernel), lds, granted);
     if (ea != hipSuccess) return fail_hip(ea, "hipFuncSetAttribute(fem_newton_lds_kernel)");
     hipLaunchKernelGGL(fem_newton_lds_kernel, dim3(B), dim3(kNwtThreads), lds, st, c->dev_nwt, x, xt, cons, aim, stats, pcg_max_iter,
-                       pcg_tol_rate, ls_max_iter, dx_dev, dx_tol, max_newton, step_info);
+                       pcg_tol_rate, ls_max_iter, dx_dev, dx_tol, max_newton, step_info, fric ? xprev : nullptr, fric ? disp : nullptr);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : fail_hip(e, "fem_newton_lds_kernel");
   }
@@ -1513,14 +1637,17 @@ int tacex_fem_step(tacex_fem_ctx* c, double* x, double* v, double* xt, const uin
   const size_t n3 = (size_t)B * V * 3;
   double* xprev = static_cast<double*>(ws) + (size_t)B * newton_ws_doubles(V, c->dev.T);
   double* dx = xprev + n3;  // (B,) max |d| per env: the device-side convergence state of this time step
+  double* disp = dx + B;    // (B,3) indenter displacement since the previous step | (B,3) indenter position of the previous step
+  double* ind_prev = disp + (size_t)3 * B;
+  const double* ind = c->dev.indenters;
   const double dt = c->dev.dt, tol = velocity_tol * dt;
   hipLaunchKernelGGL(fem_predict_kernel, dim3((unsigned)((n3 + 255) / 256)), dim3(256), 0, st, x, v, xt, xprev, dx, n3, B, dt, gravity[0],
-                     gravity[1], gravity[2]);
+                     gravity[1], gravity[2], ind, ind_prev, disp, c->ind_prev_valid ? 1 : 0);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail_hip(e, "fem_predict_kernel");
   bool resident = false;
   if (int rc = launch_newton(c, x, xt, cons, aim, stats, ws, B, pcg_max_iter, pcg_tol_rate, ls_max_iter, dx, tol, max_newton, step_info, st,
-                             &resident))
+                             &resident, xprev, disp))
     return rc;
   if (!resident) {
     // streaming fallback: one launch per Newton iteration on a FIXED schedule; converged envs return at once (dx protocol), so the
@@ -1531,7 +1658,8 @@ int tacex_fem_step(tacex_fem_ctx* c, double* x, double* v, double* xt, const uin
     e = hipMemsetAsync(step_info, 0, (size_t)B * 4 * sizeof(double), st);
     if (e != hipSuccess) return fail_hip(e, "hipMemsetAsync(step_info)");
   }
-  hipLaunchKernelGGL(fem_velocity_kernel, dim3((unsigned)((n3 + 255) / 256)), dim3(256), 0, st, x, xprev, v, n3, 1.0 / dt);
+  hipLaunchKernelGGL(fem_velocity_kernel, dim3((unsigned)((n3 + 255) / 256)), dim3(256), 0, st, x, xprev, v, n3, 1.0 / dt, ind, ind_prev, B);
+  if (ind) c->ind_prev_valid = true;
   e = hipGetLastError();
   return e == hipSuccess ? 0 : fail_hip(e, "fem_velocity_kernel");
 }

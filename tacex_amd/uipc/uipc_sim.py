@@ -64,9 +64,10 @@ class UipcSimCfg:
 
     @configclass
     class Contact:
-        """uipc_sim.py:103-124.  First slice of IPC contact: the gelpad surface against ONE analytic indenter per env
-        (`UipcSim.set_contact_indenters`); friction (`enable_friction`, `default_friction_ratio`, `eps_velocity`) and
-        mesh-mesh contact are not implemented and the fields are kept for drop-in construction only."""
+        """uipc_sim.py:103-124.  IPC contact of the gelpad surface against ONE analytic indenter per env
+        (`UipcSim.set_contact_indenters`): barrier + CCD step bound, and lagged Coulomb friction (`enable_friction`,
+        `default_friction_ratio`, `eps_velocity`) relative to the indenter's own motion between steps.  Mesh-mesh contact is not
+        implemented."""
 
         enable: bool = True
         enable_friction: bool = True
@@ -169,6 +170,9 @@ class UipcSim:
         stiffness = float(self.cfg.contact.default_contact_resistance) * 1e9 * d_hat
         _lib.check(self._lib.tacex_fem_set_contact(self._handle, area.ctypes.data if area is not None else 0, d_hat, stiffness,
                                                    _lib.ptr(ind)), "tacex_fem_set_contact")
+        c = self.cfg.contact
+        _lib.check(self._lib.tacex_fem_set_friction(self._handle, float(c.default_friction_ratio) if c.enable_friction else 0.0,
+                                                    float(c.eps_velocity)), "tacex_fem_set_friction")
         self.contact_indenters = ind  # keeps the device buffer alive: the kernels read it on every later call
 
     def contact_gaps(self, x=None) -> torch.Tensor:

@@ -304,3 +304,40 @@ def test_contact_step_filter_never_penetrates():
         assert 0 < a <= 1
         assert (contact_distance(ind, x + a * dx)[0] > 0).all()
     assert cm.max_step(x, np.zeros_like(x)) == 1.0
+
+
+def test_friction_potential_gradient_hessian_fd():
+    """Lagged Coulomb friction (FrictionModel): f0 is C1 at the stick tolerance with f0(eps) = eps, the gradient is the finite
+    difference of the energy, the Hessian blocks that of the gradient and positive semi-definite; no force without normal force."""
+    from oracle.fem_oracle import ContactModel, FrictionModel, friction_f0
+
+    eps = 1e-4
+    f0, a, b = friction_f0(np.array([0.0, 0.5 * eps, eps * (1 - 1e-9), eps, 3 * eps]), eps)
+    np.testing.assert_allclose(f0[[0, 3, 4]], [eps / 3, eps, 3 * eps], rtol=1e-12)
+    np.testing.assert_allclose(a[2] * eps, 1.0, rtol=1e-6)   # f1(eps) = 1: the full Coulomb force beyond the stick zone
+    assert b[3] == 0.0 and b[0] == 2 / eps
+    rng = np.random.default_rng(4)
+    V = 12
+    x_n = rng.uniform(-1e-3, 1e-3, (V, 3)); x_n[:, 2] = -rng.uniform(1e-4, 9e-4, V)  # 0.1 .. 0.9 mm below the plane z = 0
+    area = np.full(V, 2e-6); area[-2:] = 0.0
+    ind = np.array([2.0, 0, 0, 0, 0, 0, 0, -1.0])  # half-space, solid side z > 0
+    cm = ContactModel(area, ind, 1e-3, 1e7, 0.01)
+    disp = np.array([2e-5, -1e-5, 0.0])
+    fr = FrictionModel(cm, x_n, disp, 0.5, 0.01)
+    assert (fr.lam[:-2] > 0).all() and (fr.lam[-2:] == 0).all()
+    for scale in (2e-5, 4e-4):  # inside and beyond the stick tolerance eps = 1e-4 m
+        x = x_n + disp + scale * rng.normal(size=(V, 3))
+        g = fr.gradient(x)
+        H = fr.hess_blocks(x)
+        assert np.abs(g[-2:]).max() == 0.0
+        h = 1e-9
+        for v in (0, 3, 7):
+            for k in range(3):
+                xp, xm = x.copy(), x.copy()
+                xp[v, k] += h; xm[v, k] -= h
+                fd = (fr.energy(xp) - fr.energy(xm)) / (2 * h)
+                assert abs(fd - g[v, k]) <= 1e-5 * np.abs(g).max() + 1e-22, (scale, v, k, fd, g[v, k])
+                fdh = (fr.gradient(xp)[v] - fr.gradient(xm)[v]) / (2 * h)
+                assert np.abs(fdh - H[v][:, k]).max() <= 1e-4 * np.abs(H).max(), (scale, v, k)
+        assert np.linalg.eigvalsh(H).min() >= -1e-12 * np.abs(H).max()
+        assert np.abs(np.einsum("vij,vj->vi", H, fr.n)).max() <= 1e-9 * np.abs(H).max()  # no friction stiffness along the normal
