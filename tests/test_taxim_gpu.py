@@ -252,8 +252,8 @@ def test_policy_observation_downsample_matches_torch(taxim):
 
 def test_shadow_branch_vs_reference_and_oracle(taxim, golden_dir, calib_dir):
     """with_shadow=True (TT:260-346): ring detection, 4x51 ray march with float atomic-min, two image blurs.
-    vs the reference on pixels whose 7x7 receptive field is well conditioned, and vs the oracle everywhere except where
-    a single ray sample flips (float32 cos/sin + truncation sit on integer boundaries for a handful of samples)."""
+    vs the reference on EVERY pixel whose 7x7 receptive field is well conditioned, and vs the oracle on every pixel whose
+    field holds no bin flip between the two (tests/studies/shadow_outliers.py attributes the rest)."""
     from oracle.taxim_oracle import TaximOracle
     from parity import well_conditioned_field
 
@@ -267,15 +267,24 @@ def test_shadow_branch_vs_reference_and_oracle(taxim, golden_dir, calib_dir):
     idx = idx.cpu().numpy().astype(np.int64)
     ok = well_conditioned_field(idx[..., 0], idx[..., 1], g)
     assert ok.sum() > 50000
-    d = np.abs(rgb - g["rgb_shadow"])
-    assert np.quantile(d[ok], 0.999) <= 1e-4, np.quantile(d[ok], 0.999)
-    assert (d[ok] > 1e-3).mean() < 2e-3
+    # EVERY such pixel within the 1e-4 relative tolerance (measured 2.5e-6; tests/studies/shadow_outliers.py: on this fixture no
+    # shadow sample of the HIP path lands on another pixel than the reference's)
+    from parity import rgb_rel_err
+    d = rgb_rel_err(rgb, g["rgb_shadow"])
+    assert d[ok].max() <= 1e-4, d[ok].max()
     assert np.abs(g["rgb_shadow"] - g["rgb"])[ok].max() > 0.1  # shadows are really cast there
     o = TaximOracle(calib_dir, (240, 320), "direct")
     ref = o.render_direct(g["hm"], g["indent"], with_shadow=True)
     do = np.abs(rgb - ref)
-    # a bin flip (0.4 % of strong pixels) is smeared over its 7x7 neighbourhood by the two blurs
-    assert np.quantile(do, 0.99) <= 1e-4, np.quantile(do, 0.99)
+    # vs the oracle: identical to float32 round-off wherever the 7x7 field of the two blurs holds no bin flip (0.25 % of the
+    # pixels flip: flat gel, where the direction is round-off of either atan2); the flips themselves are bounded below
+    from scipy import ndimage
+    Zo, _ = o.gel_pad_deformation(o.shifted_height_map(g["hm"], g["indent"]))
+    im_o, id_o = o.bins(*o.normals(-(Zo / np.float32(o.p.pixmm))))
+    same = (idx[..., 0] == im_o) & (idx[..., 1] == id_o)
+    field = np.stack([ndimage.binary_erosion(same[b], structure=np.ones((7, 7)), border_value=1) for b in range(same.shape[0])])
+    assert field.mean() > 0.95, field.mean()
+    assert do[field].max() <= 1e-6, do[field].max()
     assert (do > 1e-3).mean() < 5e-3
     # no-contact frame: no ring -> both blurs of (flat shade + background) only
     assert do[-1].max() <= 1e-5
@@ -405,7 +414,7 @@ def test_shadow_ray_samples_exact_vs_oracle(taxim, golden_dir, calib_dir, shape)
 
 def test_shadow_branch_640x480_vs_reference(taxim, golden_dir):
     """with_shadow=True at BASELINE config C5's resolution against the reference's own render (frame 0 of the 480x640 fixture):
-    same protocol as at 320x240 - pixels whose receptive field of the two blurs (k = 5 and k = 9 here) is well conditioned."""
+    same protocol as at 320x240 - ALL pixels whose receptive field of the two blurs (k = 5 and k = 9 here) is well conditioned."""
     from parity import well_conditioned_field
 
     g = dict(np.load(golden_dir / "taxim_480x640.npz"))
@@ -420,7 +429,7 @@ def test_shadow_branch_640x480_vs_reference(taxim, golden_dir):
     gg = {"idx_mag": g["idx_mag"], "idx_dir": g["idx_dir"], "grad_mag": np.where(g["idx_mag"] > 0, 1.0, 0.0)}  # slim fixture: no grad_mag
     ok = well_conditioned_field(idx[..., 0], idx[..., 1], gg, frames=slice(0, 1), radius=6)
     assert ok.sum() > 20000
-    d = np.abs(rgb - ref)
-    assert np.quantile(d[ok], 0.999) <= 1e-4, np.quantile(d[ok], 0.999)
-    assert (d[ok] > 1e-3).mean() < 2e-3
+    from parity import rgb_rel_err
+    d = rgb_rel_err(rgb, ref)
+    assert d[ok].max() <= 1e-4, d[ok].max()  # every such pixel (measured 2.9e-6)
     assert np.abs(ref - g["rgb"][:1])[ok].max() > 0.05  # shadows are really cast there
