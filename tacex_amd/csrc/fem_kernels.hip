@@ -868,6 +868,15 @@ __global__ __launch_bounds__(kNwtThreads) void fem_newton_lds_kernel(FemDev m, d
   for (int k = tid; k < 4 * T; k += kNwtThreads) csr[k] = m.vt_idx[k];
   __syncthreads();
 
+#ifdef TACEX_FEM_CLOCK  // debug build: cycles (s_memtime) of the sections of a PCG iteration, group TACEX_FEM_CLOCK of four -> stats
+  double fclk[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  long long ftk = 0;
+#define FEM_TICK(k) do { const long long now_ = __builtin_readcyclecounter(); fclk[k] += (double)(now_ - ftk); ftk = now_; } while (0)
+#define FEM_TICK0() do { ftk = __builtin_readcyclecounter(); } while (0)
+#else
+#define FEM_TICK(k) do { } while (0)
+#define FEM_TICK0() do { } while (0)
+#endif
   // one sweep over the tets in windows of CH = kNwtTpw x 512: `make(v, Di, vol, rows)` fills the 12 rows of a tet (each thread
   // owns kNwtTpw independent tets of the window), then vertex `tid` adds the rows of its incident tets inside the window
   // (CSR entries are sorted by tet, so a cursor suffices).  The mesh constants of the NEXT window are fetched while this
@@ -875,6 +884,7 @@ __global__ __launch_bounds__(kNwtThreads) void fem_newton_lds_kernel(FemDev m, d
   auto sweep = [&](auto&& make, double acc[3]) {
     int e = e_begin;
     int code = e < e_end ? csr[e] : 0x7fffffff;
+    int code1 = e + 1 < e_end ? csr[e + 1] : 0x7fffffff;
     acc[0] = acc[1] = acc[2] = 0.0;
     int vn[kNwtTpw][4];
     double Din[kNwtTpw][9], voln[kNwtTpw];
@@ -889,6 +899,7 @@ __global__ __launch_bounds__(kNwtThreads) void fem_newton_lds_kernel(FemDev m, d
       if (t < T) { load_tet(m, t, vn[u], Din[u]); voln[u] = m.vol[t]; }
     }
     for (int j = 0; j < nchunk; ++j) {
+      FEM_TICK0();
       int v[kNwtTpw][4];
       double Di[kNwtTpw][9], vol[kNwtTpw];
 #pragma unroll
@@ -911,18 +922,36 @@ __global__ __launch_bounds__(kNwtThreads) void fem_newton_lds_kernel(FemDev m, d
           for (int k = 0; k < 12; ++k) hv[k * CH + tl] = rows[k];
         }
       }
+      FEM_TICK(8);
       __syncthreads();
+      FEM_TICK(9);
       const int tend4 = (j + 1) * CH * 4;
-      while (code < tend4) {  // `code` always holds entry e (or INT_MAX past the list): its successor is fetched while the
-        const int l = code & 3, tl = (code >> 2) - j * CH;  // rows of this entry are in flight - one LDS latency per entry
+      // `code` / `code1` always hold entries e and e + 1 (INT_MAX past the list).  Two entries of the window are gathered per
+      // round trip where there are two - their six rows are in flight together and are added in entry order - so a vertex
+      // pays one LDS latency per PAIR of incident tets (a vertex has ~4 per window)
+      while (code1 < tend4) {
+        const int l0 = code & 3, t0 = (code >> 2) - j * CH, l1 = code1 & 3, t1 = (code1 >> 2) - j * CH;
+        e += 2;
+        const int n0 = e < e_end ? csr[e] : 0x7fffffff;
+        const int n1 = e + 1 < e_end ? csr[e + 1] : 0x7fffffff;
+        const double h00 = hv[(l0 * 3 + 0) * CH + t0], h01 = hv[(l0 * 3 + 1) * CH + t0], h02 = hv[(l0 * 3 + 2) * CH + t0];
+        const double h10 = hv[(l1 * 3 + 0) * CH + t1], h11 = hv[(l1 * 3 + 1) * CH + t1], h12 = hv[(l1 * 3 + 2) * CH + t1];
+        acc[0] += h00; acc[1] += h01; acc[2] += h02;
+        acc[0] += h10; acc[1] += h11; acc[2] += h12;
+        code = n0; code1 = n1;
+      }
+      if (code < tend4) {
+        const int l = code & 3, tl = (code >> 2) - j * CH;
         ++e;
-        const int nxt = e < e_end ? csr[e] : 0x7fffffff;
         acc[0] += hv[(l * 3 + 0) * CH + tl];
         acc[1] += hv[(l * 3 + 1) * CH + tl];
         acc[2] += hv[(l * 3 + 2) * CH + tl];
-        code = nxt;
+        code = code1;
+        code1 = e + 1 < e_end ? csr[e + 1] : 0x7fffffff;
       }
-      if (j + 1 < nchunk) __syncthreads();  // the window is rewritten; after the last one the caller's next barrier suffices
+      FEM_TICK(10);
+      if (j + 1 < nchunk) __syncthreads();
+      FEM_TICK(11);  // the window is rewritten; after the last one the caller's next barrier suffices
     }
   };
 
@@ -1021,42 +1050,69 @@ __global__ __launch_bounds__(kNwtThreads) void fem_newton_lds_kernel(FemDev m, d
   // a gather per coarse dof over its support, split over G threads with the partial sums added in a fixed order (deterministic,
   // no atomics); the sweep's LDS window is idle between two sweeps and carries r, the partial sums and the coarse vectors.
   const int nc3 = 3 * m.nc;
-  const int G = nc3 > 0 ? kNwtThreads / nc3 : 1;
+  const int Gn = m.nc > 0 ? kNwtThreads / m.nc : 1;
+  const int H = nc3 > 0 ? kNwtThreads / nc3 : 1;
+  const int Q = nc3 > 0 ? (nc3 + H - 1) / H : 0;
   auto apply_prec = [&](const double (&r)[3], double (&z)[3]) {
 #pragma unroll
     for (int i = 0; i < 3; ++i) z[i] = Dinv[i * 3 + 0] * r[0] + Dinv[i * 3 + 1] * r[1] + Dinv[i * 3 + 2] * r[2];
     if (nc3 == 0) return;
+    FEM_TICK(2);
     double* rs = hv;                    // (V,3) residual
-    double* part_c = hv + 3 * V;        // (3 nc, G) partial sums
-    double* rc = part_c + kNwtThreads;  // (3 nc) restricted residual
-    double* yc = rc + 3 * kFemMaxCoarse;
+    double* part_c = hv + 3 * V;            // (3 nc, Gn) partial sums
+    double* rc = part_c + 3 * kNwtThreads;  // (3 nc) restricted residual
+    double* yc = rc + 3 * kFemMaxCoarse;      // (3 nc) coarse correction
+    double* part_y = yc + 3 * kFemMaxCoarse;  // (3 nc, H) partial sums of the coarse solve
     __syncthreads();  // every thread is done with the window of the last sweep
     if (own) {
 #pragma unroll
       for (int i = 0; i < 3; ++i) rs[tid * 3 + i] = r[i];
     }
     __syncthreads();
-    const int dof = tid / G, j = tid - dof * G;
-    if (dof < nc3) {
-      const int node = dof / 3, comp = dof - node * 3;
-      double acc = 0.0;
-      for (int e = m.cn_off[node] + j; e < m.cn_off[node + 1]; e += G) acc += m.cn_w[e] * rs[m.cn_vtx[e] * 3 + comp];
-      part_c[dof * G + j] = acc;
+    FEM_TICK(3);
+    {  // Gn threads per coarse NODE, all three components: one (vertex, weight) fetch serves three sums
+      const int node = tid / Gn, j = tid - node * Gn;
+      if (node < m.nc) {
+        double a0 = 0.0, a1 = 0.0, a2 = 0.0;
+        const int e1 = m.cn_off[node + 1];
+        for (int e = m.cn_off[node] + j; e < e1; e += Gn) {
+          const int v0 = m.cn_vtx[e];
+          const double w0 = m.cn_w[e];
+          a0 += w0 * rs[v0 * 3]; a1 += w0 * rs[v0 * 3 + 1]; a2 += w0 * rs[v0 * 3 + 2];
+        }
+        part_c[(node * 3 + 0) * Gn + j] = a0;
+        part_c[(node * 3 + 1) * Gn + j] = a1;
+        part_c[(node * 3 + 2) * Gn + j] = a2;
+      }
     }
     __syncthreads();
+    FEM_TICK(4);
     if (tid < nc3) {
       double acc = 0.0;
-      for (int q = 0; q < G; ++q) acc += part_c[tid * G + q];
+      for (int q = 0; q < Gn; ++q) acc += part_c[tid * Gn + q];
       rc[tid] = acc;
     }
     __syncthreads();
+    FEM_TICK(5);
+    {  // coarse solve y = A_c^-1 r_c: H threads per row, each over a slice of its (contiguous) row; the partial sums are
+       // added in a fixed order
+      const int dof = tid / H, h = tid - dof * H;
+      if (dof < nc3) {
+        const double* row = m.ac_inv + (size_t)dof * nc3;
+        const int q1 = min(nc3, (h + 1) * Q);
+        double acc = 0.0;
+        for (int q = h * Q; q < q1; ++q) acc += row[q] * rc[q];
+        part_y[tid] = acc;
+      }
+    }
+    __syncthreads();
     if (tid < nc3) {
-      const double* row = m.ac_inv + (size_t)tid * nc3;
       double acc = 0.0;
-      for (int q = 0; q < nc3; ++q) acc += row[q] * rc[q];
+      for (int h = 0; h < H; ++h) acc += part_y[tid * H + h];
       yc[tid] = acc;
     }
     __syncthreads();
+    FEM_TICK(6);
     if (own) {
 #pragma unroll
       for (int k = 0; k < 8; ++k) {
@@ -1066,6 +1122,7 @@ __global__ __launch_bounds__(kNwtThreads) void fem_newton_lds_kernel(FemDev m, d
         for (int i = 0; i < 3; ++i) z[i] += w * yc[node * 3 + i];
       }
     }
+    FEM_TICK(7);
   };
   // ---- PCG ----
   // Stops when the preconditioned residual has dropped to tol_rate times that of the right-hand side (r^T M^-1 r against
@@ -1091,6 +1148,7 @@ __global__ __launch_bounds__(kNwtThreads) void fem_newton_lds_kernel(FemDev m, d
   int it = 0;
   while (warm || (it < pcg_max_iter && rz_b > 0.0 && rz > pcg_tol_rate * pcg_tol_rate * rz_b)) {
     double q3[3];  // the vector H is applied to
+    FEM_TICK0();
 #pragma unroll
     for (int i = 0; i < 3; ++i) q3[i] = warm ? d3[i] : p3[i];
     if (own) {
@@ -1115,6 +1173,7 @@ __global__ __launch_bounds__(kNwtThreads) void fem_newton_lds_kernel(FemDev m, d
         for (int i = 0; i < 3; ++i)
           rows[w * 3 + i] = sc * (dP[i * 3 + 0] * r[w * 3 + 0] + dP[i * 3 + 1] * r[w * 3 + 1] + dP[i * 3 + 2] * r[w * 3 + 2]);
     }, a3);
+    FEM_TICK(0);
     double Hp3[3];
     part = 0.0;
 #pragma unroll
@@ -1144,6 +1203,7 @@ __global__ __launch_bounds__(kNwtThreads) void fem_newton_lds_kernel(FemDev m, d
       continue;
     }
     const double pHp = block_sum1(part, sh, phase);
+    FEM_TICK(1);
     if (!(pHp > 0.0)) {  // negative curvature: keep d (first iteration from a zero start: preconditioned steepest descent)
       if (it == 0 && !(frac_prev > 0.0)) { d3[0] = z3[0]; d3[1] = z3[1]; d3[2] = z3[2]; }
       break;
@@ -1212,6 +1272,9 @@ __global__ __launch_bounds__(kNwtThreads) void fem_newton_lds_kernel(FemDev m, d
   for (int i = 0; i < 3; ++i) dprev[i] = d3[i];
   if (tid == 0) {
     stats[(size_t)b * 4 + 0] = E0; stats[(size_t)b * 4 + 1] = E1; stats[(size_t)b * 4 + 2] = step; stats[(size_t)b * 4 + 3] = (double)it;
+#ifdef TACEX_FEM_CLOCK
+    for (int k = 0; k < 4; ++k) stats[(size_t)b * 4 + k] = fclk[4 * (TACEX_FEM_CLOCK) + k];
+#endif
   }
   const bool converged = accepted && step == 1.0 && step0 == 1.0 && dmax <= dx_tol;
   if (converged) {  // wave-uniform: every quantity above is a block reduction

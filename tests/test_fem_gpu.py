@@ -621,7 +621,8 @@ def test_friction_drags_the_pad_surface():
         near = top & (np.hypot(P[:, 0] - cur[0], P[:, 1] - cur[1]) < 0.004)
         res[mu] = float((x[near, 0] - P[near, 0]).mean())
         res[(mu, "oracle")] = float((xo[near, 0] - P[near, 0]).mean())
-    assert res[0.5] > 5e-5 and res[0.5] > 2 * abs(res[0.0]), res  # dragged along +x: friction more than doubles what the dent's slope alone pushes
+    assert res[0.5] > 5e-5 and res[0.5] > 1.5 * abs(res[0.0]), res  # dragged along +x: 1.77x what the dent's slope alone pushes (kernel AND oracle)
     # (step-by-step parity of the frictional step is test_step_c4_vs_oracle_step_and_convergence_rule's; the aggressive press here runs
     #  into the iteration cap, where the two paths may part within the backtracking - the drag they end with agrees)
-    assert abs(res[0.5] - res[(0.5, "oracle")]) <= 0.3 * res[0.5], res
+    assert abs(res[0.5] - res[(0.5, "oracle")]) <= 0.1 * res[0.5], res
+    assert abs(res[0.0] - res[(0.0, "oracle")]) <= 0.1 * abs(res[0.0]), res
