@@ -32,7 +32,7 @@ extern "C" {
 #endif
 
 #define TACEX_MAX_LEVELS 8
-#define TACEX_ABI_VERSION 5
+#define TACEX_ABI_VERSION 6
 
 typedef struct tacex_taxim_ctx tacex_taxim_ctx;
 typedef struct tacex_fots_ctx tacex_fots_ctx;
@@ -378,6 +378,15 @@ int tacex_fem_set_friction(tacex_fem_ctx* ctx, double friction_ratio, double eps
  * and constraint set).  num_coarse <= 64; 0 switches the coarse correction off.  Tables are copied. */
 int tacex_fem_set_coarse_space(tacex_fem_ctx* ctx, int num_coarse, const int32_t* vertex_nodes_host,
                                const double* vertex_weights_host, const double* coarse_inverse_host);
+
+/* Block part of the preconditioner: block-tridiagonal LDL^T along VERTEX CHAINS instead of one 3x3 block per vertex.  A chain is a
+ * sequence of mesh vertices, consecutive ones sharing a tet (the columns of vertices through a gelpad's thickness: the nearly
+ * incompressible material couples the layers of a thin pad most strongly; UipcSim builds them with
+ * coarse_space.build_vertex_chains).  chain_offsets_host (num_chains + 1) indexes chain_vertices_host; every vertex may appear in at
+ * most one chain, the rest are chains of one vertex (= block Jacobi).  num_chains = 0 switches chains off.  Per Newton iteration the
+ * kernel factors S_0 = D_0, G_i = S_i^-1 A(i, i+1), S_{i+1} = D_{i+1} - A(i, i+1)^T G_i and keeps S^-1 / G as floats in LDS.
+ * Tables are copied.  (CU-resident Newton kernel only.) */
+int tacex_fem_set_chains(tacex_fem_ctx* ctx, int num_chains, const int32_t* chain_offsets_host, const int32_t* chain_vertices_host);
 
 /* Device-side convergence for repeated Newton launches: dx_dev (num_envs,) f64 holds, per env, max |d| of the UNSCALED Newton
  * direction of its last iteration once that iteration was accepted at full length (no CCD truncation, no backtracking), and a

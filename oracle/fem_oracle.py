@@ -122,6 +122,91 @@ def make_preconditioner(Dinv, coarse=None):
     return prec
 
 
+def chain_tables(chains, V):
+    """chains: list of vertex-id sequences (each vertex in at most one; the rest are singletons) -> (next (V,) with -1 at a chain's
+    end, heads: first vertex of every chain, singletons included, ascending by head)."""
+    nxt = np.full(V, -1, np.int64)
+    is_member = np.zeros(V, bool)
+    heads = []
+    for ch in (chains or []):
+        ch = [int(v) for v in ch]
+        if not ch:
+            continue
+        assert not is_member[ch].any(), "a vertex belongs to two chains"
+        is_member[ch] = True
+        heads.append(ch[0])
+        for a, b in zip(ch[:-1], ch[1:]):
+            nxt[a] = b
+    heads += [v for v in range(V) if not is_member[v]]
+    return nxt, np.array(sorted(heads), np.int64)
+
+
+def _inv3_spd(A):
+    """The kernel's inv3_spd: Cholesky pivots must be positive; None otherwise."""
+    try:
+        np.linalg.cholesky(A)
+    except np.linalg.LinAlgError:
+        return None
+    return np.linalg.inv(A)
+
+
+def chain_factor(D, E, nxt, heads):
+    """Block-tridiagonal LDL^T along vertex chains - the block part of the kernel's preconditioner.  D (V,3,3): diagonal blocks of the
+    system matrix, E (V,3,3): its block (v, next(v)) (zero where v ends a chain).  Walks every chain from its head:
+        S_0 = D_0,  S_i = D_i - E_{i-1}^T G_{i-1},  G_i = S_i^-1 E_i
+    and returns (S^-1, G) ROUNDED TO float32 - the kernel keeps them in LDS as floats (6 + 9 per vertex).  Where S_i is not positive
+    definite (cannot happen in exact arithmetic with PSD-projected element Hessians) the block falls back to I / max diag S_i.  A chain
+    of one vertex is plain block Jacobi.  The operator L^-T S^-1 L^-1 is symmetric positive definite for ANY G as long as the S^-1
+    are, so rounding G costs quality, not validity."""
+    V = D.shape[0]
+    Sinv = np.zeros((V, 3, 3))
+    G = np.zeros((V, 3, 3))
+    for h in heads:
+        v, S = int(h), D[int(h)].copy()
+        while True:
+            Si = _inv3_spd(S)
+            if Si is None:
+                dmax = max(S[0, 0], S[1, 1], S[2, 2])
+                Si = np.eye(3) / (dmax if dmax > 0 else 1.0)
+            Sinv[v] = Si
+            n = int(nxt[v])
+            if n < 0:
+                break
+            G[v] = Si @ E[v]
+            S = D[n] - E[v].T @ G[v]
+            v = n
+    # symmetric part of S^-1 is what the 6 stored floats hold (upper triangle)
+    Sinv = np.triu(Sinv) + np.swapaxes(np.triu(Sinv, 1), -1, -2)
+    return Sinv.astype(np.float32).astype(np.float64), G.astype(np.float32).astype(np.float64)
+
+
+def make_chain_preconditioner(Sinv, G, nxt, heads, coarse=None):
+    """z = L^-T S^-1 L^-1 r along the chains (forward: y_i = r_i - G_{i-1}^T y_{i-1}; t_i = S_i^-1 y_i; backward: z_i = t_i - G_i z_{i+1})
+    [+ the additive coarse-grid correction of make_preconditioner]."""
+    V = Sinv.shape[0]
+    chains = []
+    for h in heads:
+        ch, v = [], int(h)
+        while v >= 0:
+            ch.append(v)
+            v = int(nxt[v])
+        chains.append(ch)
+    cpart = make_preconditioner(np.zeros((V, 3, 3)), coarse) if coarse is not None else None
+
+    def prec(r):
+        z = np.zeros_like(r)
+        for ch in chains:
+            y = np.zeros((len(ch), 3))
+            for i, v in enumerate(ch):
+                y[i] = r[v] - (G[ch[i - 1]].T @ y[i - 1] if i > 0 else 0.0)
+            for i in range(len(ch) - 1, -1, -1):
+                v = ch[i]
+                z[v] = Sinv[v] @ y[i] - (G[v] @ z[ch[i + 1]] if i + 1 < len(ch) else 0.0)
+        return z + cpart(r) if cpart is not None else z
+
+    return prec
+
+
 def lame_from_youngs_poisson(E: float, nu: float):
     return E / (2 * (1 + nu)), E * nu / ((1 + nu) * (1 - 2 * nu))
 
@@ -274,23 +359,38 @@ class FemModel:
             D = D + (self.strength * constrained * self.mass)[..., None, None] * np.eye(3)
         return D
 
+    def offdiag_blocks(self, x, nxt):
+        """(V,3,3): block (v, nxt[v]) of dt^2 K (zero where nxt[v] < 0 or the two share no tet) - the coupling the chain
+        preconditioner keeps (single env)."""
+        He = self.element_hessian(x) * self.dt**2
+        E = np.zeros((len(self.X), 3, 3))
+        for a in range(4):
+            for b in range(4):
+                if a == b:
+                    continue
+                sel = nxt[self.tets[:, a]] == self.tets[:, b]
+                if sel.any():
+                    np.add.at(E, self.tets[sel, a], He[sel][:, a * 3 : a * 3 + 3, b * 3 : b * 3 + 3])
+        return E
+
+    def block_preconditioner(self, x, D, mdiag, coarse=None, chains=None):
+        """The preconditioner of the Newton kernels from the diagonal blocks D: chain factor (chains = (next, heads) of
+        chain_tables; None: every vertex its own chain = block Jacobi, inverse blocks stored as float32) + coarse correction."""
+        V = len(self.X)
+        nxt, heads = chains if chains is not None else (np.full(V, -1, np.int64), np.arange(V))
+        E = self.offdiag_blocks(x, nxt) if (nxt >= 0).any() else np.zeros((V, 3, 3))
+        Sinv, G = chain_factor(D, E, nxt, heads)
+        return make_chain_preconditioner(Sinv, G, nxt, heads, coarse)
+
     # ---- one Newton iteration: truncated PCG + backtracking line search (US:70-76) ----------------------------------
     def newton_step(self, x, x_tilde, constrained=None, aim=None, pcg_max_iter=64, pcg_tol_rate=1e-3, ls_max_iter=8, coarse=None, d0=None,
-                    return_dir=False):
+                    return_dir=False, chains=None):
         """Single env (x: (V,3)).  Returns (x_new, stats=[E0, E1, step, pcg_iters, max |d|, ccd step]).  `coarse` = (node (V,8),
         weight (V,8), inverse coarse operator (3 nc, 3 nc)): the additive coarse-grid correction of tacex_fem_set_coarse_space."""
         g = self.gradient(x, x_tilde, constrained, aim)
         D = self.diag_blocks(x, constrained)
-        # fall back to the (always SPD) mass block where the elastic block is not positive definite
         mdiag = self.mass * (1.0 + (self.strength * constrained if constrained is not None else 0.0))
-        Dinv = np.empty_like(D)
-        for v in range(len(self.X)):
-            try:
-                np.linalg.cholesky(D[v])
-                Dinv[v] = np.linalg.inv(D[v])
-            except np.linalg.LinAlgError:
-                Dinv[v] = np.eye(3) / mdiag[v]
-        prec = make_preconditioner(Dinv, coarse)
+        prec = self.block_preconditioner(x, D, mdiag, coarse, chains)
         d, it = pcg_solve(lambda p: self.hess_vec(x, p, constrained), prec, -g, pcg_max_iter, pcg_tol_rate, d0)
         E0 = self.energy(x, x_tilde, constrained, aim)
         step = 1.0
@@ -469,24 +569,17 @@ class FrictionModel:
 
 
 def newton_step_contact(m: "FemModel", cm: ContactModel, x, x_tilde, constrained=None, aim=None, pcg_max_iter=64, pcg_tol_rate=1e-3,
-                        ls_max_iter=8, coarse=None, d0=None, return_dir=False, fr: "FrictionModel | None" = None):
+                        ls_max_iter=8, coarse=None, d0=None, return_dir=False, fr: "FrictionModel | None" = None, chains=None):
     """`FemModel.newton_step` with the barrier terms of `cm` in gradient, preconditioner, H.p and energy, and the CCD step
     filter in front of the backtracking line search.  Returns (x_new, [E0, E1, step, pcg_iters])."""
     g = m.gradient(x, x_tilde, constrained, aim) + cm.gradient(x)
     Hc = cm.hess_blocks(x)
     if fr is not None:
         g = g + fr.gradient(x)
-        Hc = Hc + fr.hess_blocks(x)
+        Hc = Hc + fr.hess_blocks(x).astype(np.float32).astype(np.float64)  # the kernel keeps these blocks in LDS as floats
     D = m.diag_blocks(x, constrained) + Hc
     mdiag = m.mass * (1.0 + (m.strength * constrained if constrained is not None else 0.0))
-    Dinv = np.empty_like(D)
-    for v in range(len(m.X)):
-        try:
-            np.linalg.cholesky(D[v])
-            Dinv[v] = np.linalg.inv(D[v])
-        except np.linalg.LinAlgError:
-            Dinv[v] = np.eye(3) / mdiag[v]
-    prec = make_preconditioner(Dinv, coarse)
+    prec = m.block_preconditioner(x, D, mdiag, coarse, chains)
     hv = lambda p: m.hess_vec(x, p, constrained) + np.einsum("vij,vj->vi", Hc, p)
     energy = lambda y: m.energy(y, x_tilde, constrained, aim) + cm.energy(y) + (fr.energy(y) if fr is not None else 0.0)
     d, it = pcg_solve(hv, prec, -g, pcg_max_iter, pcg_tol_rate, d0)
@@ -507,7 +600,7 @@ def newton_step_contact(m: "FemModel", cm: ContactModel, x, x_tilde, constrained
 
 
 def fem_step(m: "FemModel", cm, x, v, constrained=None, aim=None, gravity=(0.0, 0.0, -9.8), max_newton=8, velocity_tol=0.05,
-             pcg_max_iter=1024, pcg_tol_rate=1e-3, ls_max_iter=8, coarse=None, friction=None):
+             pcg_max_iter=1024, pcg_tol_rate=1e-3, ls_max_iter=8, coarse=None, friction=None, chains=None):
     """One backward-Euler step of ONE env the way `tacex_fem_step` runs it (what world.advance() does, US:250-252):
     x_tilde = x + dt v + dt^2 g; Newton iterations until one is accepted at FULL length (no CCD truncation, no backtracking) with
     max |d| <= velocity_tol * dt (US:62-66) or the cap; v = (x_new - x) / dt.  Returns (x_new, v_new, info) with
@@ -521,9 +614,9 @@ def fem_step(m: "FemModel", cm, x, v, constrained=None, aim=None, gravity=(0.0, 
     d0 = None
     for _ in range(max_newton):
         if cm is not None:
-            x, st, d = newton_step_contact(m, cm, x, xt, constrained, aim, pcg_max_iter, pcg_tol_rate, ls_max_iter, coarse, d0, True, fr)
+            x, st, d = newton_step_contact(m, cm, x, xt, constrained, aim, pcg_max_iter, pcg_tol_rate, ls_max_iter, coarse, d0, True, fr, chains)
         else:
-            x, st, d = m.newton_step(x, xt, constrained, aim, pcg_max_iter, pcg_tol_rate, ls_max_iter, coarse, d0, True)
+            x, st, d = m.newton_step(x, xt, constrained, aim, pcg_max_iter, pcg_tol_rate, ls_max_iter, coarse, d0, True, chains)
         d0 = (1.0 - st[2]) * d if 0.0 < st[2] < 1.0 else None  # warm start of the next PCG: the part of d that was cut off
         n += 1
         pcg += int(st[3])

@@ -11,7 +11,7 @@ from pathlib import Path
 from ._build import LIB, build_library
 
 MAX_LEVELS = 8
-ABI_VERSION = 5  # TACEX_ABI_VERSION of include/tacex_hip.h; bumped whenever a signature or struct layout changes
+ABI_VERSION = 6  # TACEX_ABI_VERSION of include/tacex_hip.h; bumped whenever a signature or struct layout changes
 FLAG_NO_SHIFT = 1
 FLAG_HAVE_FRAME_MIN = 2
 FLAG_WITH_SHADOW = 4
@@ -135,6 +135,7 @@ SIGNATURES = {
     "tacex_fem_newton_step": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _d, _i, _vp]),
     "tacex_fem_step": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, C.POINTER(C.c_double), _i, _d, _i, _d, _i, _vp]),
     "tacex_fem_set_coarse_space": (_i, [_vp, _i, _vp, _vp, _vp]),
+    "tacex_fem_set_chains": (_i, [_vp, _i, _vp, _vp]),
     "tacex_fem_set_friction": (_i, [_vp, _d, _d]),
     "tacex_fem_set_contact": (_i, [_vp, _vp, _d, _d, _vp]),
     "tacex_fem_set_newton_early_exit": (_i, [_vp, _vp, C.c_double]),

@@ -20,6 +20,7 @@
 #include <stdint.h>
 #include <stdlib.h>
 
+#include <algorithm>
 #include <vector>
 
 #include "tacex_hip.h"
@@ -49,6 +50,11 @@ struct FemDev {
   const int* cn_vtx;
   const double* cn_w;
   const double* ac_inv;     // (3 nc, 3 nc) inverse of P^T A_0 P, A_0 = rest-state operator incl. the constraint masses
+  // vertex chains of the block-tridiagonal part of the preconditioner (tacex_fem_set_chains); nullptr: every vertex its own chain
+  int nch;                  // chains, singletons included (<= V)
+  const int* ch_head;       // (nch) first vertex of every chain
+  const int* ch_next;       // (V) successor in the chain, -1 at its end
+  const int* ch_prev;       // (V) predecessor, -1 at its head
 };
 constexpr int kFemMaxCoarse = 64;
 
@@ -593,8 +599,10 @@ __global__ __launch_bounds__(512) void fem_newton_kernel(FemDev m, double* xg, c
       const double im = 1.0 / md;
       Di3[0] = im; Di3[1] = 0; Di3[2] = 0; Di3[3] = 0; Di3[4] = im; Di3[5] = 0; Di3[6] = 0; Di3[7] = 0; Di3[8] = im;
     }
+    // rounded to float like the blocks the CU-resident kernel keeps in LDS: the two kernels apply the SAME preconditioner
+    const int up[9] = {0, 1, 2, 1, 4, 5, 2, 5, 8};
 #pragma unroll
-    for (int k = 0; k < 9; ++k) Dinv[(size_t)v * 9 + k] = Di3[k];
+    for (int k = 0; k < 9; ++k) Dinv[(size_t)v * 9 + k] = (double)(float)Di3[up[k]];
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
       double gi = a3[i] + mv * (x[v * 3 + i] - xt[v * 3 + i]);
@@ -831,9 +839,14 @@ __global__ __launch_bounds__(kNwtThreads) void fem_newton_lds_kernel(FemDev m, d
   double* ps = xs + 3 * V;      // (V,3) PCG direction p, later the line-search candidate
   double* hv = ps + 3 * V;      // (12, CH) per-tet rows of the current window
   double* sh = hv + 12 * CH;    // 2 x 8 wave partials of block_sum1 (+2 pad)
-  int* csr = reinterpret_cast<int*>(sh + 18);  // (4T) incidence codes tet * 4 + local, vertex-major: read every sweep
-  double* fl = reinterpret_cast<double*>(csr + ((4 * T + 1) & ~1));  // friction: (V,4) lagged normal force and normal | (V,6) Hessian blocks
-  double* fh = fl + 4 * V;
+  // friction (tacex_fem_step with a friction ratio): (V,4) lagged normal force and normal, (V,6) Hessian blocks (floats)
+  const bool fric_lds = m.indenters && m.area && m.fric_mu > 0.0 && xprevg != nullptr && dispg != nullptr;
+  double* fl = sh + 18;
+  float* cf = reinterpret_cast<float*>(fl + (fric_lds ? 4 * V : 0));  // (V,15) chain factors: S^-1 (6, upper triangle) | G (9)
+  float* fh = cf + 15 * V;
+  unsigned short* csr = reinterpret_cast<unsigned short*>(fh + (fric_lds ? 6 * V : 0));  // (4T) incidence codes tet * 4 + local, vertex-major
+  unsigned short* cnx = csr + 4 * T;  // (V) chain successor | (V) predecessor, 0xffff = none
+  unsigned short* cpv = cnx + V;
   int phase = 0;  // block_sum1 row toggle
   const int b = blockIdx.x;
   if (dxg && dxg[b] <= dx_tol) {  // this env's last update was below the Newton tolerance (uipc_sim.py:62-66): nothing to do
@@ -865,7 +878,16 @@ __global__ __launch_bounds__(kNwtThreads) void fem_newton_lds_kernel(FemDev m, d
 #pragma unroll
     for (int i = 0; i < 3; ++i) { x3[i] = x[tid * 3 + i]; xs[tid * 3 + i] = x3[i]; }
   }
-  for (int k = tid; k < 4 * T; k += kNwtThreads) csr[k] = m.vt_idx[k];
+  for (int k = tid; k < 4 * T; k += kNwtThreads) csr[k] = (unsigned short)m.vt_idx[k];
+  if (own) {
+    cnx[tid] = (unsigned short)(m.ch_next ? m.ch_next[tid] : -1);
+    cpv[tid] = (unsigned short)(m.ch_prev ? m.ch_prev[tid] : -1);
+  }
+  const int nch = m.ch_next ? m.nch : V;
+  // the chain a thread factors and solves: chains are dealt from the TOP thread down, so that their solves overlap the coarse
+  // solve, which keeps the low threads busy
+  const int my_chain = kNwtThreads - 1 - tid;
+  const int my_head = my_chain < nch ? (m.ch_next ? m.ch_head[my_chain] : my_chain) : -1;
   __syncthreads();
 
 #ifdef TACEX_FEM_CLOCK  // debug build: cycles (s_memtime) of the sections of a PCG iteration, group TACEX_FEM_CLOCK of four -> stats
@@ -883,8 +905,8 @@ __global__ __launch_bounds__(kNwtThreads) void fem_newton_lds_kernel(FemDev m, d
   // window is computed and gathered (they are the only global reads of the sweep).
   auto sweep = [&](auto&& make, double acc[3]) {
     int e = e_begin;
-    int code = e < e_end ? csr[e] : 0x7fffffff;
-    int code1 = e + 1 < e_end ? csr[e + 1] : 0x7fffffff;
+    int code = e < e_end ? (int)csr[e] : 0x7fffffff;
+    int code1 = e + 1 < e_end ? (int)csr[e + 1] : 0x7fffffff;
     acc[0] = acc[1] = acc[2] = 0.0;
     int vn[kNwtTpw][4];
     double Din[kNwtTpw][9], voln[kNwtTpw];
@@ -932,8 +954,8 @@ __global__ __launch_bounds__(kNwtThreads) void fem_newton_lds_kernel(FemDev m, d
       while (code1 < tend4) {
         const int l0 = code & 3, t0 = (code >> 2) - j * CH, l1 = code1 & 3, t1 = (code1 >> 2) - j * CH;
         e += 2;
-        const int n0 = e < e_end ? csr[e] : 0x7fffffff;
-        const int n1 = e + 1 < e_end ? csr[e + 1] : 0x7fffffff;
+        const int n0 = e < e_end ? (int)csr[e] : 0x7fffffff;
+        const int n1 = e + 1 < e_end ? (int)csr[e + 1] : 0x7fffffff;
         const double h00 = hv[(l0 * 3 + 0) * CH + t0], h01 = hv[(l0 * 3 + 1) * CH + t0], h02 = hv[(l0 * 3 + 2) * CH + t0];
         const double h10 = hv[(l1 * 3 + 0) * CH + t1], h11 = hv[(l1 * 3 + 1) * CH + t1], h12 = hv[(l1 * 3 + 2) * CH + t1];
         acc[0] += h00; acc[1] += h01; acc[2] += h02;
@@ -947,7 +969,7 @@ __global__ __launch_bounds__(kNwtThreads) void fem_newton_lds_kernel(FemDev m, d
         acc[1] += hv[(l * 3 + 1) * CH + tl];
         acc[2] += hv[(l * 3 + 2) * CH + tl];
         code = code1;
-        code1 = e + 1 < e_end ? csr[e + 1] : 0x7fffffff;
+        code1 = e + 1 < e_end ? (int)csr[e + 1] : 0x7fffffff;
       }
       FEM_TICK(10);
       if (j + 1 < nchunk) __syncthreads();
@@ -1002,45 +1024,111 @@ __global__ __launch_bounds__(kNwtThreads) void fem_newton_lds_kernel(FemDev m, d
 #pragma unroll
     for (int i = 0; i < 3; ++i) r3[i] -= dt2 * fe.g[i];
 #pragma unroll
-    for (int k = 0; k < 6; ++k) fh[tid * 6 + k] = dt2 * fe.h[k];
+    for (int k = 0; k < 6; ++k) fh[tid * 6 + k] = (float)(dt2 * fe.h[k]);
   }
-  // ---- block-Jacobi preconditioner: 3x3 diagonal block of vertex tid (columns recomputed per incidence) ----
-  double Dinv[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-  if (own) {
+  // ---- block part of the preconditioner: block-tridiagonal LDL^T along vertex chains (tacex_fem_set_chains; a chain of one
+  //      vertex = 3x3 block Jacobi).  Every vertex assembles its diagonal block D and the block E = A(v, next(v)) towards its
+  //      chain successor (columns recomputed per incident tet), the blocks meet in LDS (the idle p / window region), and the
+  //      thread of a chain walks it:  S_0 = D_0,  G_i = S_i^-1 E_i,  S_{i+1} = D_{i+1} - E_i^T G_i.  S^-1 (6) and G (9) stay in
+  //      LDS as FLOATS: z = L^-T S^-1 L^-1 r is symmetric positive definite for any G as long as the S^-1 are, so the rounding
+  //      costs preconditioner quality only (none measurable: profiles/r03_experiments.md section 9). ----
+  {
     double D[9] = {md, 0, 0, 0, md, 0, 0, 0, md};
-    if (fric_phase) {
-      const double* h = fh + tid * 6;
-      D[0] += h[0]; D[1] += h[1]; D[2] += h[2]; D[3] += h[1]; D[4] += h[3]; D[5] += h[4]; D[6] += h[2]; D[7] += h[4]; D[8] += h[5];
-    }
+    double E[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    if (own) {
+      if (fric_phase) {
+        const float* h = fh + tid * 6;
+        D[0] += h[0]; D[1] += h[1]; D[2] += h[2]; D[3] += h[1]; D[4] += h[3]; D[5] += h[4]; D[6] += h[2]; D[7] += h[4]; D[8] += h[5];
+      }
 #pragma unroll
-    for (int i = 0; i < 3; ++i)
+      for (int i = 0; i < 3; ++i)
 #pragma unroll
-      for (int k = 0; k < 3; ++k) D[i * 3 + k] += cb2 * ce.n[i] * ce.n[k];
-    for (int e = e_begin; e < e_end; ++e) {
-      const int code = csr[e];
-      const int t = code >> 2, l = code & 3;
-      int v[4];
-      double Di[9], F[9], r[12];
-      load_tet(m, t, v, Di);
-      deformation_gradient(xs, v, Di, F);
-      TetState s;
-      tet_state(m, F, s);
-      shape_rows(Di, r);
-      const double sc = dt2 * m.vol[t];
+        for (int k = 0; k < 3; ++k) D[i * 3 + k] += cb2 * ce.n[i] * ce.n[k];
+      const int nv = cnx[tid] == 0xffff ? -1 : (int)cnx[tid];
+      for (int e = e_begin; e < e_end; ++e) {
+        const int code = csr[e];
+        const int t = code >> 2, l = code & 3;
+        int v[4];
+        double Di[9], F[9], r[12];
+        load_tet(m, t, v, Di);
+        deformation_gradient(xs, v, Di, F);
+        TetState s;
+        tet_state(m, F, s);
+        shape_rows(Di, r);
+        const double sc = dt2 * m.vol[t];
 #pragma unroll
-      for (int k = 0; k < 3; ++k) {
-        double dF[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, dP[9];
-        dF[k * 3 + 0] = r[l * 3 + 0]; dF[k * 3 + 1] = r[l * 3 + 1]; dF[k * 3 + 2] = r[l * 3 + 2];
-        apply_dP(m, s, dF, dP);
+        for (int k = 0; k < 3; ++k) {
+          double dF[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, dP[9];
+          dF[k * 3 + 0] = r[l * 3 + 0]; dF[k * 3 + 1] = r[l * 3 + 1]; dF[k * 3 + 2] = r[l * 3 + 2];
+          apply_dP(m, s, dF, dP);
 #pragma unroll
-        for (int i = 0; i < 3; ++i)
-          D[i * 3 + k] += sc * (dP[i * 3 + 0] * r[l * 3 + 0] + dP[i * 3 + 1] * r[l * 3 + 1] + dP[i * 3 + 2] * r[l * 3 + 2]);
+          for (int i = 0; i < 3; ++i)
+            D[i * 3 + k] += sc * (dP[i * 3 + 0] * r[l * 3 + 0] + dP[i * 3 + 1] * r[l * 3 + 1] + dP[i * 3 + 2] * r[l * 3 + 2]);
+        }
+        const int l2 = v[0] == nv ? 0 : (v[1] == nv ? 1 : (v[2] == nv ? 2 : (v[3] == nv ? 3 : -1)));
+        if (l2 >= 0) {  // this tet also holds the chain successor: its share of the block (v, next)
+          const double rn[3] = {r[l2 * 3 + 0], r[l2 * 3 + 1], r[l2 * 3 + 2]};
+#pragma unroll
+          for (int k = 0; k < 3; ++k) {
+            double dF[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, dP[9];
+            dF[k * 3 + 0] = rn[0]; dF[k * 3 + 1] = rn[1]; dF[k * 3 + 2] = rn[2];
+            apply_dP(m, s, dF, dP);
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+              E[i * 3 + k] += sc * (dP[i * 3 + 0] * r[l * 3 + 0] + dP[i * 3 + 1] * r[l * 3 + 1] + dP[i * 3 + 2] * r[l * 3 + 2]);
+          }
+        }
       }
     }
-    if (!inv3_spd(D, Dinv)) {  // elastic block not SPD -> mass block (always SPD)
-      const double im = 1.0 / md;
-      Dinv[0] = im; Dinv[1] = 0; Dinv[2] = 0; Dinv[3] = 0; Dinv[4] = im; Dinv[5] = 0; Dinv[6] = 0; Dinv[7] = 0; Dinv[8] = im;
+    double* xch = ps;  // (V,15) D (upper triangle) | E: p is idle until the PCG starts, the window once the gradient is gathered
+    __syncthreads();   // every vertex has gathered the last window of the gradient sweep
+    if (own) {
+      double* q = xch + tid * 15;
+      q[0] = D[0]; q[1] = D[1]; q[2] = D[2]; q[3] = D[4]; q[4] = D[5]; q[5] = D[8];
+#pragma unroll
+      for (int k = 0; k < 9; ++k) q[6 + k] = E[k];
     }
+    __syncthreads();
+    if (my_head >= 0) {
+      int v = my_head;
+      double S[9];
+      {
+        const double* q = xch + v * 15;
+        S[0] = q[0]; S[1] = q[1]; S[2] = q[2]; S[3] = q[1]; S[4] = q[3]; S[5] = q[4]; S[6] = q[2]; S[7] = q[4]; S[8] = q[5];
+      }
+      while (true) {
+        double Si[9];
+        if (!inv3_spd(S, Si)) {  // cannot happen in exact arithmetic (PSD-projected element Hessians + mass); keep the operator SPD
+          const double dm = fmax(S[0], fmax(S[4], S[8]));
+          const double im = 1.0 / (dm > 0.0 ? dm : 1.0);
+          Si[0] = im; Si[1] = 0; Si[2] = 0; Si[3] = 0; Si[4] = im; Si[5] = 0; Si[6] = 0; Si[7] = 0; Si[8] = im;
+        }
+        float* f = cf + v * 15;
+        f[0] = (float)Si[0]; f[1] = (float)Si[1]; f[2] = (float)Si[2]; f[3] = (float)Si[4]; f[4] = (float)Si[5]; f[5] = (float)Si[8];
+        const int n = cnx[v] == 0xffff ? -1 : (int)cnx[v];
+        if (n < 0) {
+#pragma unroll
+          for (int k = 0; k < 9; ++k) f[6 + k] = 0.0f;
+          break;
+        }
+        const double* Ev = xch + v * 15 + 6;
+        double G[9];
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+          for (int k = 0; k < 3; ++k) G[i * 3 + k] = Si[i * 3 + 0] * Ev[k] + Si[i * 3 + 1] * Ev[3 + k] + Si[i * 3 + 2] * Ev[6 + k];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) f[6 + k] = (float)G[k];
+        const double* q = xch + n * 15;  // S_next = D_next - E^T G
+        const double Dn[9] = {q[0], q[1], q[2], q[1], q[3], q[4], q[2], q[4], q[5]};
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+          for (int k = 0; k < 3; ++k) S[i * 3 + k] = Dn[i * 3 + k] - (Ev[i] * G[k] + Ev[3 + i] * G[3 + k] + Ev[6 + i] * G[6 + k]);
+        v = n;
+      }
+    }
+    __syncthreads();  // factors complete; the exchange region goes back to the PCG
   }
   // ---- preconditioner: z = D^-1 r (3x3 block Jacobi) + P A_c^-1 P^T r (additive coarse-grid correction) ----
   // Block Jacobi alone needs 120-330 PCG iterations on the thin, nearly incompressible pad: the error it cannot reach is
@@ -1054,15 +1142,14 @@ __global__ __launch_bounds__(kNwtThreads) void fem_newton_lds_kernel(FemDev m, d
   const int H = nc3 > 0 ? kNwtThreads / nc3 : 1;
   const int Q = nc3 > 0 ? (nc3 + H - 1) / H : 0;
   auto apply_prec = [&](const double (&r)[3], double (&z)[3]) {
-#pragma unroll
-    for (int i = 0; i < 3; ++i) z[i] = Dinv[i * 3 + 0] * r[0] + Dinv[i * 3 + 1] * r[1] + Dinv[i * 3 + 2] * r[2];
-    if (nc3 == 0) return;
-    FEM_TICK(2);
-    double* rs = hv;                    // (V,3) residual
+    double* rs = hv;                        // (V,3) residual
     double* part_c = hv + 3 * V;            // (3 nc, Gn) partial sums
     double* rc = part_c + 3 * kNwtThreads;  // (3 nc) restricted residual
     double* yc = rc + 3 * kFemMaxCoarse;      // (3 nc) coarse correction
     double* part_y = yc + 3 * kFemMaxCoarse;  // (3 nc, H) partial sums of the coarse solve
+    double* zs = part_y + kNwtThreads;        // (V,3) chain solve: y on the way down, z on the way back
+    z[0] = z[1] = z[2] = 0.0;
+    FEM_TICK(2);
     __syncthreads();  // every thread is done with the window of the last sweep
     if (own) {
 #pragma unroll
@@ -1070,6 +1157,50 @@ __global__ __launch_bounds__(kNwtThreads) void fem_newton_lds_kernel(FemDev m, d
     }
     __syncthreads();
     FEM_TICK(3);
+    // chain solve z = L^-T S^-1 L^-1 r by the chain's thread: down the chain y_i = r_i - G_{i-1}^T y_{i-1}, back up
+    // z_i = S_i^-1 y_i - G_i z_{i+1}
+    auto chain_solve = [&]() {
+      if (my_head < 0) return;
+      int v = my_head, last = my_head;
+      double y[3] = {rs[v * 3], rs[v * 3 + 1], rs[v * 3 + 2]};
+      while (true) {
+        zs[v * 3] = y[0]; zs[v * 3 + 1] = y[1]; zs[v * 3 + 2] = y[2];
+        last = v;
+        const int n = cnx[v] == 0xffff ? -1 : (int)cnx[v];
+        if (n < 0) break;
+        const float* g = cf + v * 15 + 6;
+        const double y0 = y[0], y1 = y[1], y2 = y[2];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) y[k] = rs[n * 3 + k] - ((double)g[k] * y0 + (double)g[3 + k] * y1 + (double)g[6 + k] * y2);
+        v = n;
+      }
+      v = last;
+      double zn[3] = {0, 0, 0};
+      while (true) {
+        const float* f = cf + v * 15;
+        const double y0 = zs[v * 3], y1 = zs[v * 3 + 1], y2 = zs[v * 3 + 2];
+        double zz[3];
+        zz[0] = (double)f[0] * y0 + (double)f[1] * y1 + (double)f[2] * y2;
+        zz[1] = (double)f[1] * y0 + (double)f[3] * y1 + (double)f[4] * y2;
+        zz[2] = (double)f[2] * y0 + (double)f[4] * y1 + (double)f[5] * y2;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) zz[i] -= (double)f[6 + i * 3] * zn[0] + (double)f[7 + i * 3] * zn[1] + (double)f[8 + i * 3] * zn[2];
+        zs[v * 3] = zz[0]; zs[v * 3 + 1] = zz[1]; zs[v * 3 + 2] = zz[2];
+        zn[0] = zz[0]; zn[1] = zz[1]; zn[2] = zz[2];
+        const int pv = cpv[v] == 0xffff ? -1 : (int)cpv[v];
+        if (pv < 0) break;
+        v = pv;
+      }
+    };
+    if (nc3 == 0) {
+      chain_solve();
+      __syncthreads();
+      if (own) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) z[i] = zs[tid * 3 + i];
+      }
+      return;
+    }
     {  // Gn threads per coarse NODE, all three components: one (vertex, weight) fetch serves three sums
       const int node = tid / Gn, j = tid - node * Gn;
       if (node < m.nc) {
@@ -1095,7 +1226,7 @@ __global__ __launch_bounds__(kNwtThreads) void fem_newton_lds_kernel(FemDev m, d
     __syncthreads();
     FEM_TICK(5);
     {  // coarse solve y = A_c^-1 r_c: H threads per row, each over a slice of its (contiguous) row; the partial sums are
-       // added in a fixed order
+       // added in a fixed order.  The chain solves run beside it on the threads it leaves idle (chains are dealt from the top).
       const int dof = tid / H, h = tid - dof * H;
       if (dof < nc3) {
         const double* row = m.ac_inv + (size_t)dof * nc3;
@@ -1105,6 +1236,7 @@ __global__ __launch_bounds__(kNwtThreads) void fem_newton_lds_kernel(FemDev m, d
         part_y[tid] = acc;
       }
     }
+    chain_solve();
     __syncthreads();
     if (tid < nc3) {
       double acc = 0.0;
@@ -1114,6 +1246,8 @@ __global__ __launch_bounds__(kNwtThreads) void fem_newton_lds_kernel(FemDev m, d
     __syncthreads();
     FEM_TICK(6);
     if (own) {
+#pragma unroll
+      for (int i = 0; i < 3; ++i) z[i] = zs[tid * 3 + i];
 #pragma unroll
       for (int k = 0; k < 8; ++k) {
         const int node = m.cv_node[tid * 8 + k];
@@ -1181,7 +1315,7 @@ __global__ __launch_bounds__(kNwtThreads) void fem_newton_lds_kernel(FemDev m, d
       Hp3[i] = own ? a3[i] + md * q3[i] + cb2 * ce.n[i] * (ce.n[0] * q3[0] + ce.n[1] * q3[1] + ce.n[2] * q3[2]) : 0.0;
     }
     if (fric_phase && own) {
-      const double* h = fh + tid * 6;
+      const float* h = fh + tid * 6;
       Hp3[0] += h[0] * q3[0] + h[1] * q3[1] + h[2] * q3[2];
       Hp3[1] += h[1] * q3[0] + h[3] * q3[1] + h[4] * q3[2];
       Hp3[2] += h[2] * q3[0] + h[4] * q3[1] + h[5] * q3[2];
@@ -1595,6 +1729,41 @@ int tacex_fem_set_friction(tacex_fem_ctx* c, double friction_ratio, double eps_v
   return 0;
 }
 
+int tacex_fem_set_chains(tacex_fem_ctx* c, int num_chains, const int32_t* chain_offsets_host, const int32_t* chain_vertices_host) {
+  if (!c) { set_error("tacex_fem_set_chains: null context"); return 2; }
+  FemDev& d = c->dev;
+  FemDev& n2 = c->dev_nwt;
+  if (num_chains == 0) {  // every vertex its own chain: 3x3 block Jacobi
+    d.nch = n2.nch = 0;
+    d.ch_head = n2.ch_head = nullptr; d.ch_next = n2.ch_next = nullptr; d.ch_prev = n2.ch_prev = nullptr;
+    return 0;
+  }
+  if (num_chains < 0 || !chain_offsets_host || !chain_vertices_host) { set_error("tacex_fem_set_chains: bad arguments"); return 2; }
+  const int V = d.V;
+  std::vector<int> nxt(V, -1), prv(V, -1), head;
+  std::vector<char> member(V, 0);
+  for (int ci = 0; ci < num_chains; ++ci) {
+    const int a = chain_offsets_host[ci], b = chain_offsets_host[ci + 1];
+    if (a < 0 || b < a) { set_error("tacex_fem_set_chains: offsets must ascend"); return 2; }
+    for (int k = a; k < b; ++k) {
+      const int v = chain_vertices_host[k];
+      if (v < 0 || v >= V || member[v]) { set_error("tacex_fem_set_chains: vertex %d out of range or in two chains", v); return 2; }
+      member[v] = 1;
+      if (k > a) { nxt[chain_vertices_host[k - 1]] = v; prv[v] = chain_vertices_host[k - 1]; }
+    }
+    if (b > a) head.push_back(chain_vertices_host[a]);
+  }
+  for (int v = 0; v < V; ++v)
+    if (!member[v]) head.push_back(v);  // the rest are chains of one vertex
+  std::sort(head.begin(), head.end());
+  hipError_t e = hipSetDevice(c->device);
+  if (e != hipSuccess) return fail_hip(e, "hipSetDevice");
+  if (int rc = fem_upload(c, head, &d.ch_head) | fem_upload(c, nxt, &d.ch_next) | fem_upload(c, prv, &d.ch_prev)) return rc;
+  d.nch = (int)head.size();
+  n2.nch = d.nch; n2.ch_head = d.ch_head; n2.ch_next = d.ch_next; n2.ch_prev = d.ch_prev;
+  return 0;
+}
+
 int tacex_fem_set_coarse_space(tacex_fem_ctx* c, int num_coarse, const int32_t* vertex_nodes_host, const double* vertex_weights_host,
                                const double* coarse_inverse_host) {
   if (!c) { set_error("tacex_fem_set_coarse_space: null context"); return 2; }
@@ -1650,9 +1819,11 @@ static int launch_newton(tacex_fem_ctx* c, double* x, const double* xt, const ui
                          double* step_info, hipStream_t st, bool* resident, const double* xprev = nullptr, const double* disp = nullptr) {
   static const int use_lds = getenv("TACEX_FEM_NEWTON_LDS") ? atoi(getenv("TACEX_FEM_NEWTON_LDS")) : 1;
   const bool fric = xprev && disp && c->dev.indenters && c->dev.fric_mu > 0.0;
-  const size_t lds = ((size_t)6 * c->dev.V + (size_t)12 * kNwtChunk + 18 + (fric ? (size_t)10 * c->dev.V : 0)) * sizeof(double) +
-                     (size_t)((4 * c->dev.T + 1) & ~1) * sizeof(int);
-  if (use_lds && c->dev.V <= kNwtThreads && lds <= 160 * 1024) {
+  // x, p | window | sums | [friction lag] || chain factors | [friction Hessian blocks] (floats) || incidence codes | chain links (u16)
+  const size_t lds = ((((size_t)6 * c->dev.V + (size_t)12 * kNwtChunk + 18 + (fric ? (size_t)4 * c->dev.V : 0)) * sizeof(double) +
+                       ((size_t)15 * c->dev.V + (fric ? (size_t)6 * c->dev.V : 0)) * sizeof(float) +
+                       ((size_t)4 * c->dev.T + 2 * (size_t)c->dev.V) * sizeof(unsigned short)) + 15) & ~(size_t)15;
+  if (use_lds && c->dev.V <= kNwtThreads && 4 * c->dev.T < 65535 && lds <= 160 * 1024) {
     if (resident) *resident = true;
     static size_t granted[64] = {};  // per device: the attribute is per kernel AND device
     hipError_t ea = hipSetDevice(c->device);

@@ -61,3 +61,35 @@ def coarse_operator_inverse(element_hessians: np.ndarray, tets: np.ndarray, mass
     Ac = Pm.T @ A @ Pm
     Ac = 0.5 * (Ac + Ac.T)
     return np.linalg.inv(Ac)
+
+
+def build_vertex_chains(points: np.ndarray, tets: np.ndarray, max_len: int = 16) -> list[list[int]]:
+    """Vertex chains for the block-tridiagonal part of the preconditioner (`tacex_fem_set_chains`): the columns of vertices through
+    the mesh's THIN direction (the axis of least extent - a gelpad's thickness, where the nearly incompressible material couples the
+    layers most strongly).  Vertices that share their two other coordinates form a column, ordered along the thin axis; a column is
+    cut wherever two consecutive vertices share no tet (the chain keeps only couplings the matrix has) and at `max_len`.  Works on any
+    tet mesh: an unstructured one simply yields chains of one vertex (= plain block Jacobi)."""
+    P = np.asarray(points, np.float64)
+    T = np.asarray(tets, np.int64)
+    ext = np.ptp(P, axis=0)
+    ax = int(np.argmin(ext))
+    oth = [a for a in range(3) if a != ax]
+    scale = max(float(ext.max()), 1e-300)
+    key = np.round(P[:, oth] / (1e-7 * scale)).astype(np.int64)
+    adj = set()
+    for a in range(4):
+        for b in range(a + 1, 4):
+            lo, hi = np.minimum(T[:, a], T[:, b]), np.maximum(T[:, a], T[:, b])
+            adj.update(zip(lo.tolist(), hi.tolist()))
+    order = np.lexsort((P[:, ax], key[:, 1], key[:, 0]))
+    chains, cur = [], []
+    for v in order.tolist():
+        if cur and (key[v] == key[cur[-1]]).all() and (min(v, cur[-1]), max(v, cur[-1])) in adj and len(cur) < max_len:
+            cur.append(v)
+        else:
+            if len(cur) > 1:
+                chains.append(cur)
+            cur = [v]
+    if len(cur) > 1:
+        chains.append(cur)
+    return chains

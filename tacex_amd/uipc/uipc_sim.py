@@ -52,6 +52,11 @@ class UipcSimCfg:
         """Coarse grid (cells per axis) of the additive coarse correction beside the 3x3 block Jacobi (`coarse_space.py`):
         "auto" = 3 cells along the longest extent of the mesh, proportionally fewer along the others (2 x 3 x 1 = 24 nodes for the
         gelpad); None = block Jacobi alone (120-330 PCG iterations on the gelpad).  Not in the reference cfg."""
+        vertex_chains: list | str | None = "auto"
+        """Vertex chains of the block part of the preconditioner (`tacex_fem_set_chains`): "auto" = the columns of vertices through the
+        mesh's thin direction (`coarse_space.build_vertex_chains`; an unstructured mesh yields none), a list of vertex-id lists, or
+        None = one 3x3 block per vertex.  With the coarse correction the chains take the pad's free motion from 67 to 27 PCG
+        iterations per Newton iteration.  Not in the reference cfg."""
 
     linear_system: LinearSystem = LinearSystem()
 
@@ -205,6 +210,7 @@ class UipcSim:
         set stays valid, only weaker).  Runs once - at the first step after `setup_sim` / `set_constraints` / the first
         `UipcIsaacAttachments.apply` - and reads the flags from the device (the only synchronisation of the FEM path)."""
         self._precond_dirty = False
+        self._set_chains()
         grid = self.cfg.linear_system.coarse_grid
         if grid is None:
             _lib.check(self._lib.tacex_fem_set_coarse_space(self._handle, 0, 0, 0, 0), "tacex_fem_set_coarse_space")
@@ -233,6 +239,21 @@ class UipcSim:
         _lib.check(self._lib.tacex_fem_set_coarse_space(self._handle, nc, node.ctypes.data, w.ctypes.data, aci.ctypes.data),
                    "tacex_fem_set_coarse_space")
         self.coarse_space = (node, w, aci)  # what the library was given (tests hand the same tables to the oracle)
+
+    def _set_chains(self):
+        ch = self.cfg.linear_system.vertex_chains
+        if isinstance(ch, str) and ch == "auto":
+            from .coarse_space import build_vertex_chains
+
+            ch = build_vertex_chains(self._obj.points, self._obj.tets)
+        ch = [list(map(int, c)) for c in (ch or []) if len(c) > 1]
+        self.vertex_chains = ch  # what the library was given (tests hand the same chains to the oracle)
+        if not ch:
+            _lib.check(self._lib.tacex_fem_set_chains(self._handle, 0, 0, 0), "tacex_fem_set_chains")
+            return
+        off = np.ascontiguousarray(np.concatenate([[0], np.cumsum([len(c) for c in ch])]), np.int32)
+        vtx = np.ascontiguousarray(np.concatenate(ch), np.int32)
+        _lib.check(self._lib.tacex_fem_set_chains(self._handle, len(ch), off.ctypes.data, vtx.ctypes.data), "tacex_fem_set_chains")
 
     # -- low-level entry points (thin wrappers of the C ABI) -----------------------------------------------------------
     def element_terms(self, x=None, energy=True, gradient=True, hessian=True, project_psd=False):

@@ -341,3 +341,60 @@ def test_friction_potential_gradient_hessian_fd():
                 assert np.abs(fdh - H[v][:, k]).max() <= 1e-4 * np.abs(H).max(), (scale, v, k)
         assert np.linalg.eigvalsh(H).min() >= -1e-12 * np.abs(H).max()
         assert np.abs(np.einsum("vij,vj->vi", H, fr.n)).max() <= 1e-9 * np.abs(H).max()  # no friction stiffness along the normal
+
+
+def test_chain_preconditioner_is_the_block_tridiagonal_inverse_and_cuts_pcg_iterations():
+    """The chain part of the preconditioner (tacex_fem_set_chains): along a column of vertices it must BE the inverse of the
+    block-tridiagonal part of the system matrix (up to the float32 storage of its factors), be symmetric positive definite, reduce
+    to 3x3 block Jacobi for chains of one vertex, and cut the PCG iterations of the thin pad's free motion."""
+    from oracle.fem_oracle import chain_factor, chain_tables, make_chain_preconditioner, pcg_solve
+    from tacex_amd.uipc.coarse_space import build_vertex_chains
+    from tacex_amd.uipc.uipc_object import gelpad_box_mesh
+
+    P, T = gelpad_box_mesh(3, 4, 3)
+    m = FemModel.build(P, T, youngs=1e4, poisson=0.49, density=1e3, dt=0.01, strength=1000.0)
+    V = len(P)
+    chains = build_vertex_chains(P, m.tets)
+    assert len(chains) == 4 * 5 and all(len(c) == 4 for c in chains)  # the z-columns of the 3 x 4 x 3 box
+    for c in chains:  # columns: same (x, y), ascending z
+        assert np.ptp(P[c, 0]) < 1e-12 and np.ptp(P[c, 1]) < 1e-12 and (np.diff(P[c, 2]) > 0).all()
+    rng = np.random.default_rng(3)
+    x = P + 2e-5 * rng.standard_normal(P.shape)
+    cons = (P[:, 2] < 1e-12).astype(np.float64)
+    nxt, heads = chain_tables(chains, V)
+    D = m.diag_blocks(x, cons)
+    E = m.offdiag_blocks(x, nxt)
+    Sinv, G = chain_factor(D, E, nxt, heads)
+    prec = make_chain_preconditioner(Sinv, G, nxt, heads)
+    # dense block-tridiagonal matrix of one chain vs the operator
+    He = m.element_hessian(x) * m.dt**2
+    A = np.zeros((3 * V, 3 * V))
+    dof = (m.tets[:, :, None] * 3 + np.arange(3)).reshape(len(m.tets), 12)
+    np.add.at(A, (np.repeat(dof, 12, axis=1).reshape(-1), np.tile(dof, (1, 12)).reshape(-1)), He.reshape(-1))
+    A[np.arange(3 * V), np.arange(3 * V)] += np.repeat(m.mass * (1 + m.strength * cons), 3)
+    ch = chains[7]
+    dd = (np.array(ch)[:, None] * 3 + np.arange(3)).reshape(-1)
+    Bt = A[np.ix_(dd, dd)].copy()
+    for i in range(len(ch)):  # keep the tridiagonal blocks only (what the chain factor sees)
+        for j in range(len(ch)):
+            if abs(i - j) > 1:
+                Bt[3 * i:3 * i + 3, 3 * j:3 * j + 3] = 0.0
+    r = np.zeros((V, 3))
+    r[ch] = rng.standard_normal((len(ch), 3))
+    z = prec(r)
+    ref = np.linalg.solve(Bt, r[ch].reshape(-1)).reshape(-1, 3)
+    assert np.abs(z[ch] - ref).max() <= 2e-6 * np.abs(ref).max()  # float32 factors
+    assert np.abs(np.delete(z, ch, 0)).max() == 0.0
+    # symmetric positive definite
+    r1, r2 = rng.standard_normal((V, 3)), rng.standard_normal((V, 3))
+    assert abs((r1 * prec(r2)).sum() - (r2 * prec(r1)).sum()) <= 1e-12 * abs((r1 * prec(r2)).sum()) and (r1 * prec(r1)).sum() > 0
+    # chains of one vertex = block Jacobi with float32 inverse blocks
+    n1, h1 = chain_tables(None, V)
+    S1, G1 = chain_factor(D, np.zeros_like(D), n1, h1)
+    assert np.abs(G1).max() == 0.0 and np.abs(S1 - np.linalg.inv(D)).max() <= 1e-6 * np.abs(S1).max()
+    # PCG on the free pad: fewer iterations with the chains
+    b = -m.gradient(x, P, cons, P)
+    hv = lambda p: m.hess_vec(x, p, cons)
+    _, it_bj = pcg_solve(hv, make_chain_preconditioner(S1, G1, n1, h1), b, 500, 1e-6)
+    _, it_ch = pcg_solve(hv, prec, b, 500, 1e-6)
+    assert it_ch < 0.7 * it_bj, (it_ch, it_bj)
