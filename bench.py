@@ -470,10 +470,10 @@ def fem_roofline(fem):
                              "lds_bytes_per_env_and_pcg_iteration": lds_it, "achieved_lds": round(lds_tbs, 2), "peak_lds": LDS_PEAK_TBS,
                              "lds_unit": "TB/s", "lds_frac": round(lds_tbs / LDS_PEAK_TBS, 4),
                              "envs_per_cu": round(B / 256, 2),
-                             "note": "one workgroup (512 threads, 2 waves/SIMD, 104 KB LDS) per env and CU; 256 CUs take 256 envs at a time; "
+                             "note": "one workgroup (512 threads, 2 waves/SIMD, 120-147 KB LDS) per env and CU; 256 CUs take 256 envs at a time; "
                                      "no HBM traffic inside the PCG loop (mesh constants in L2), so neither the HBM roof nor SURVEY 8(d)'s "
-                                     "304 B/tet matrix-free figure binds; latency of the ~10 barriers and dependent LDS gathers per PCG "
-                                     "iteration at 2 waves/SIMD is what the kernel waits on"},
+                                     "304 B/tet matrix-free figure binds; latency of the ~20 barriers and dependent LDS / L1 round trips per PCG "
+                                     "iteration at 2 waves/SIMD is what the kernel waits on (section clock: profiles/r03_experiments.md section 8)"},
         "element_terms": {"kernel": "fem_element_terms_kernel (NOT on the step path; assembled-Hessian entry point of the C ABI)", "bound": "hbm",
                           "ms": round(ms_el, 4), "algo_bytes": el_bytes, "achieved": round(el_bytes / (ms_el * 1e-3) / 1e9, 1),
                           "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(el_bytes / (ms_el * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),

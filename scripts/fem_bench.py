@@ -50,6 +50,10 @@ print(f"UipcSim.step warm (8 Newton iters cap, device-side early exit): {dt*1e3:
 # the C4 / C5 bench scene (back face attached, sphere indenter breathing in and out): ms per FEM step and solver statistics
 from tacex_amd.uipc.gelpad_scene import FemGelpad
 fem = FemGelpad(B, "cuda:0")
+import os
+if os.environ.get("FEM_COARSE"):  # A/B: coarse grid cells per axis, e.g. FEM_COARSE=4,5,1
+    fem.sim.cfg.linear_system.coarse_grid = tuple(int(v) for v in os.environ["FEM_COARSE"].split(","))
+    fem.sim._precond_dirty = True
 for i in range(6):
     fem.step(i)
 torch.cuda.synchronize()
