@@ -379,6 +379,18 @@ int tacex_fem_set_friction(tacex_fem_ctx* ctx, double friction_ratio, double eps
 int tacex_fem_set_coarse_space(tacex_fem_ctx* ctx, int num_coarse, const int32_t* vertex_nodes_host,
                                const double* vertex_weights_host, const double* coarse_inverse_host);
 
+/* gaps_dev (num_envs, V) f64 <- signed distance of every vertex of x_dev (num_envs, V, 3) to its env's indenter, by the solver's own
+ * distance function (+inf without an indenter): what the caller of tacex_fem_step needs to keep the "an indenter approaches by less
+ * than the current gap" contract (UipcSim.contact_gaps). */
+int tacex_fem_contact_gaps(tacex_fem_ctx* ctx, const double* x_dev, double* gaps_dev, int num_envs, void* stream);
+
+/* Rigid TRIANGLE-MESH indenter shared by all envs (indenter kind 4 of tacex_fem_set_contact's rows): vertices (num_verts,3) f64 in
+ * the mesh's own frame, triangles (num_tris,3) int32.  An env's indenter row [4, px, py, pz, offset, rx, ry, rz] places it: p =
+ * position of the mesh origin, r = rotation vector (axis * angle), offset >= 0 inflates the surface.  The barrier acts between
+ * every weighted gelpad vertex and its nearest triangle (point-triangle distance, closest feature = face / edge / vertex);
+ * the distance is unsigned.  num_tris = 0 removes the mesh.  Tables are copied. */
+int tacex_fem_set_indenter_mesh(tacex_fem_ctx* ctx, int num_verts, const double* verts_host, int num_tris, const int32_t* tris_host);
+
 /* Block part of the preconditioner: block-tridiagonal LDL^T along VERTEX CHAINS instead of one 3x3 block per vertex.  A chain is a
  * sequence of mesh vertices, consecutive ones sharing a tet (the columns of vertices through a gelpad's thickness: the nearly
  * incompressible material couples the layers of a thin pad most strongly; UipcSim builds them with

@@ -438,9 +438,64 @@ def attachment_aim_positions(offsets, body_pos, body_quat):
 # Contact", eq. 6:  b(d) = -(d - dhat)^2 ln(d / dhat) on 0 < d < dhat, here in the dimensionless gap s = d / dhat and weighted
 # per vertex:  E_c(x) = dt^2 kappa sum_v area_v b(d_v / dhat).   Known-answer tests: tests/test_fem_oracle.py.
 # --------------------------------------------------------------------------------------------------
-def contact_distance(ind, x):
+def closest_point_on_triangles(p, a, b, c):
+    """Closest points of triangles (a, b, c: (Nt,3)) to points p (Np,3) -> (Np,Nt,3): Ericson, Real-Time Collision Detection 5.1.5,
+    region by region in the book's order (vertex a, vertex b, edge ab, vertex c, edge ac, edge bc, face) - the order the kernel's
+    mesh_distance tests them in."""
+    p = np.asarray(p, np.float64)[:, None, :]
+    ab, ac = (b - a)[None], (c - a)[None]
+    ap = p - a[None]
+    d1, d2 = (ab * ap).sum(-1), (ac * ap).sum(-1)
+    bp = p - b[None]
+    d3, d4 = (ab * bp).sum(-1), (ac * bp).sum(-1)
+    cp = p - c[None]
+    d5, d6 = (ab * cp).sum(-1), (ac * cp).sum(-1)
+    vc = d1 * d4 - d3 * d2
+    vb = d5 * d2 - d1 * d6
+    va = d3 * d6 - d5 * d4
+    with np.errstate(divide="ignore", invalid="ignore"):
+        t_ab = d1 / (d1 - d3)
+        t_ac = d2 / (d2 - d6)
+        t_bc = (d4 - d3) / ((d4 - d3) + (d5 - d6))
+        den = 1.0 / (va + vb + vc)
+    conds = [
+        (d1 <= 0) & (d2 <= 0),
+        (d3 >= 0) & (d4 <= d3),
+        (vc <= 0) & (d1 >= 0) & (d3 <= 0),
+        (d6 >= 0) & (d5 <= d6),
+        (vb <= 0) & (d2 >= 0) & (d6 <= 0),
+        (va <= 0) & ((d4 - d3) >= 0) & ((d5 - d6) >= 0),
+    ]
+    A, B, C = a[None], b[None], c[None]
+    cands = [
+        np.broadcast_to(A, ap.shape),
+        np.broadcast_to(B, ap.shape),
+        A + t_ab[..., None] * ab,
+        np.broadcast_to(C, ap.shape),
+        A + t_ac[..., None] * ac,
+        B + t_bc[..., None] * (C - B),
+    ]
+    q = A + ab * (vb * den)[..., None] + ac * (vc * den)[..., None]
+    for cond, cand in reversed(list(zip(conds, cands))):  # first matching region wins
+        q = np.where(cond[..., None], cand, q)
+    return q
+
+
+def rotation_from_vector(r):
+    """Rodrigues: rotation matrix of the rotation vector r (axis * angle) - the pose a mesh indenter row carries."""
+    r = np.asarray(r, np.float64)
+    th = np.linalg.norm(r)
+    K = np.array([[0, -r[2], r[1]], [r[2], 0, -r[0]], [-r[1], r[0], 0]])
+    if th < 1e-12:
+        return np.eye(3) + K
+    return np.eye(3) + np.sin(th) / th * K + (1 - np.cos(th)) / th**2 * (K @ K)
+
+
+def contact_distance(ind, x, mesh=None):
     """Signed distance d (V,) and its gradient n (V,3) of points x (V,3) to indenter [kind, cx, cy, cz, R, nx, ny, nz]
-    (kind 1 sphere, 2 half-space with unit normal n, 3 capsule with half axis vector n and radius R)."""
+    (kind 1 sphere, 2 half-space with unit normal n, 3 capsule with half axis vector n and radius R, 4 rigid triangle mesh `mesh` =
+    (vertices (Nv,3) in its own frame, triangles (Nt,3)) placed at c with rotation vector n and inflated by R: UNSIGNED distance to
+    the nearest triangle minus R, first triangle on ties)."""
     kind = int(ind[0])
     c = np.asarray(ind[1:4], np.float64)
     if kind == 1:
@@ -458,6 +513,18 @@ def contact_distance(ind, x):
         r = p - t[..., None] * a
         rho = np.linalg.norm(r, axis=-1)
         return rho - ind[4], r / np.maximum(rho, 1e-300)[..., None]
+    if kind == 4:
+        assert mesh is not None, "indenter kind 4 needs the mesh"
+        vm, tm = np.asarray(mesh[0], np.float64), np.asarray(mesh[1], np.int64)
+        Rm = rotation_from_vector(ind[5:8])
+        pl = (x - c) @ Rm  # into the mesh frame: R^T (x - c)
+        q = closest_point_on_triangles(pl, vm[tm[:, 0]], vm[tm[:, 1]], vm[tm[:, 2]])
+        r = pl[:, None, :] - q
+        d2 = (r * r).sum(-1)
+        k = np.argmin(d2, axis=1)  # first minimum
+        rk = r[np.arange(len(pl)), k]
+        rho = np.sqrt(d2[np.arange(len(pl)), k])
+        return rho - ind[4], (rk / np.maximum(rho, 1e-300)[..., None]) @ Rm.T
     return np.full(x.shape[:-1], np.inf), np.zeros_like(x)
 
 
@@ -477,30 +544,31 @@ def barrier(s):
 class ContactModel:
     """Barrier terms of one env: `area` (V,) vertex weights, indenter row, dhat [m], kappa [J/m^2], dt."""
 
-    def __init__(self, area, indenter, dhat, kappa, dt):
+    def __init__(self, area, indenter, dhat, kappa, dt, mesh=None):
         self.area, self.ind, self.dhat, self.kappa, self.dt = np.asarray(area, np.float64), np.asarray(indenter, np.float64), dhat, kappa, dt
+        self.mesh = mesh  # (vertices, triangles) of a kind-4 indenter
 
     def energy(self, x):
-        d, _ = contact_distance(self.ind, x)
+        d, _ = contact_distance(self.ind, x, self.mesh)
         b, _, _ = barrier(d / self.dhat)
         with np.errstate(invalid="ignore"):
             e = np.where(self.area > 0, self.area * b, 0.0)
         return self.dt**2 * self.kappa * e.sum()
 
     def gradient(self, x):
-        d, n = contact_distance(self.ind, x)
+        d, n = contact_distance(self.ind, x, self.mesh)
         _, b1, _ = barrier(d / self.dhat)
         return (self.dt**2 * self.kappa * self.area * b1 / self.dhat)[:, None] * n
 
     def hess_blocks(self, x):
         """(V,3,3) PSD-projected diagonal blocks b'' n n^T (the b' hess(d) part is dropped, as IPC does)."""
-        d, n = contact_distance(self.ind, x)
+        d, n = contact_distance(self.ind, x, self.mesh)
         _, _, b2 = barrier(d / self.dhat)
         return (self.dt**2 * self.kappa * self.area * b2 / self.dhat**2)[:, None, None] * n[:, :, None] * n[:, None, :]
 
     def max_step(self, x, dx, slack=0.9):
         """CCD filter: the largest step in [0, 1] that keeps every weighted vertex at a positive gap (1-Lipschitz bound)."""
-        d, _ = contact_distance(self.ind, x)
+        d, _ = contact_distance(self.ind, x, self.mesh)
         nd = np.linalg.norm(dx, axis=-1)
         ok = (self.area > 0) & (nd > 0) & (d > 0) & np.isfinite(d)
         return float(min(1.0, (slack * d[ok] / nd[ok]).min())) if ok.any() else 1.0
@@ -540,7 +608,7 @@ class FrictionModel:
     def update(self, x):
         """Freeze normal force and normal at the iterate x (the start of a Newton iteration)."""
         cm = self.cm
-        d, n = contact_distance(cm.ind, x)
+        d, n = contact_distance(cm.ind, x, cm.mesh)
         _, b1, _ = barrier(d / cm.dhat)
         with np.errstate(invalid="ignore"):
             self.lam = np.where(cm.area > 0, -cm.kappa * cm.area * b1 / cm.dhat, 0.0)  # normal force [N] per vertex, >= 0

@@ -54,6 +54,13 @@ import os
 if os.environ.get("FEM_COARSE"):  # A/B: coarse grid cells per axis, e.g. FEM_COARSE=4,5,1
     fem.sim.cfg.linear_system.coarse_grid = tuple(int(v) for v in os.environ["FEM_COARSE"].split(","))
     fem.sim._precond_dirty = True
+if os.environ.get("FEM_MESH"):  # A/B: the sphere as a rigid triangle mesh (icosphere with FEM_MESH subdivisions), indenter kind 4
+    from tacex_amd.uipc.indenter_meshes import icosphere
+    mv, mt = icosphere(fem.R, int(os.environ["FEM_MESH"]))
+    fem.sim.set_indenter_mesh(mv, mt)
+    fem.ind[:, 0] = 4.0
+    fem.ind[:, 4] = 0.0
+    print("mesh indenter:", len(mt), "triangles")
 for i in range(6):
     fem.step(i)
 torch.cuda.synchronize()

@@ -136,6 +136,8 @@ SIGNATURES = {
     "tacex_fem_step": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, C.POINTER(C.c_double), _i, _d, _i, _d, _i, _vp]),
     "tacex_fem_set_coarse_space": (_i, [_vp, _i, _vp, _vp, _vp]),
     "tacex_fem_set_chains": (_i, [_vp, _i, _vp, _vp]),
+    "tacex_fem_set_indenter_mesh": (_i, [_vp, _i, _vp, _i, _vp]),
+    "tacex_fem_contact_gaps": (_i, [_vp, _vp, _vp, _i, _vp]),
     "tacex_fem_set_friction": (_i, [_vp, _d, _d]),
     "tacex_fem_set_contact": (_i, [_vp, _vp, _d, _d, _vp]),
     "tacex_fem_set_newton_early_exit": (_i, [_vp, _vp, C.c_double]),

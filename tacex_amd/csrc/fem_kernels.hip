@@ -50,6 +50,11 @@ struct FemDev {
   const int* cn_vtx;
   const double* cn_w;
   const double* ac_inv;     // (3 nc, 3 nc) inverse of P^T A_0 P, A_0 = rest-state operator incl. the constraint masses
+  // rigid triangle-mesh indenter shared by all envs (indenter kind 4, tacex_fem_set_indenter_mesh)
+  int im_nt;                // triangles
+  const double* im_tri;     // (nt,9) a | b - a | c - a in the mesh frame
+  const double* im_bs;      // (nt,4) bounding sphere: centroid, radius
+  const double* im_cl;      // (ceil(nt / 16),4) bounding sphere of every cluster of 16 consecutive triangles (Morton order)
   // vertex chains of the block-tridiagonal part of the preconditioner (tacex_fem_set_chains); nullptr: every vertex its own chain
   int nch;                  // chains, singletons included (<= V)
   const int* ch_head;       // (nch) first vertex of every chain
@@ -63,13 +68,105 @@ constexpr int kFemMaxCoarse = 64;
 // Potential term of a vertex with weight w: dt^2 kappa w b(d / dhat); d = signed distance to the indenter surface
 // (sphere: |x - c| - R, half-space: n . (x - c), capsule: distance to the axis segment - R), n = grad d.  A gap <= 0 is a penetration: infinite energy (the
 // line search never accepts it; the conservative step bound below keeps the Newton direction out of it).
+typedef double v4d __attribute__((ext_vector_type(4)));
 struct ContactEval {
   bool active;      // 0 < d < dhat
   bool penetrating; // d <= 0
   double d, n[3];
   double e, b1, b2; // energy, dE/dd, d2E/dd2 (already times kappa w, NOT times dt^2)
 };
-__device__ __forceinline__ ContactEval contact_eval(const FemDev& m, const double* ind, double w, const double x[3]) {
+// Unsigned distance of p (mesh frame) to the nearest triangle of the indenter mesh and the unit vector from the closest point to p.
+// Two-level culling with bounding spheres: clusters of kMeshCluster triangles (Morton order of the centroids, built on the host), then
+// the triangles of a cluster; a sphere farther than the best distance so far is skipped.  The sphere tables are fetched FOUR at a time
+// (a loop with one dependent L2 round trip per triangle took 45 ms per step for 320 triangles).  `cut2`: the search radius squared -
+// energy evaluations only need triangles within d_hat (+ offset); with nothing inside the result is sqrt(cut2), n = 0.  Closest point
+// by Ericson (Real-Time Collision Detection 5.1.5), regions in the book's order; of two triangles at exactly the same distance the
+// first visited wins (they share the closest point unless p lies on the medial axis).
+constexpr int kMeshCluster = 16;
+struct MeshDist { double d, n0, n1, n2; };
+__device__ __noinline__ MeshDist mesh_distance(int nt, const double* __restrict__ tris, const double* __restrict__ bsph,
+                                               const double* __restrict__ clus, double p0, double p1, double p2, double cut2) {
+  const double p[3] = {p0, p1, p2};
+  double best2 = cut2, best = sqrt(cut2), bq[3] = {0, 0, 0};
+  auto beyond = [&](const v4d& sp) {  // the sphere (centre, radius) lies farther than the best distance so far
+    const double c0 = p[0] - sp.x, c1 = p[1] - sp.y, c2 = p[2] - sp.z;
+    const double lim = sp.w + best;
+    return c0 * c0 + c1 * c1 + c2 * c2 >= lim * lim;
+  };
+  auto triangle = [&](int t) {
+    const double* tr = tris + (size_t)t * 9;
+    const double a[3] = {tr[0], tr[1], tr[2]}, ab[3] = {tr[3], tr[4], tr[5]}, ac[3] = {tr[6], tr[7], tr[8]};
+    const double ap[3] = {p[0] - a[0], p[1] - a[1], p[2] - a[2]};
+    const double d1 = ab[0] * ap[0] + ab[1] * ap[1] + ab[2] * ap[2], d2 = ac[0] * ap[0] + ac[1] * ap[1] + ac[2] * ap[2];
+    const double bp[3] = {ap[0] - ab[0], ap[1] - ab[1], ap[2] - ab[2]};
+    const double d3 = ab[0] * bp[0] + ab[1] * bp[1] + ab[2] * bp[2], d4 = ac[0] * bp[0] + ac[1] * bp[1] + ac[2] * bp[2];
+    const double cp[3] = {ap[0] - ac[0], ap[1] - ac[1], ap[2] - ac[2]};
+    const double d5 = ab[0] * cp[0] + ab[1] * cp[1] + ab[2] * cp[2], d6 = ac[0] * cp[0] + ac[1] * cp[1] + ac[2] * cp[2];
+    const double vc = d1 * d4 - d3 * d2, vb = d5 * d2 - d1 * d6, va = d3 * d6 - d5 * d4;
+    double s = 0.0, u = 0.0;  // closest point = a + s ab + u ac
+    if (d1 <= 0.0 && d2 <= 0.0) { s = 0.0; u = 0.0; }
+    else if (d3 >= 0.0 && d4 <= d3) { s = 1.0; u = 0.0; }
+    else if (vc <= 0.0 && d1 >= 0.0 && d3 <= 0.0) { s = d1 / (d1 - d3); u = 0.0; }
+    else if (d6 >= 0.0 && d5 <= d6) { s = 0.0; u = 1.0; }
+    else if (vb <= 0.0 && d2 >= 0.0 && d6 <= 0.0) { s = 0.0; u = d2 / (d2 - d6); }
+    else if (va <= 0.0 && (d4 - d3) >= 0.0 && (d5 - d6) >= 0.0) { u = (d4 - d3) / ((d4 - d3) + (d5 - d6)); s = 1.0 - u; }
+    else { const double den = 1.0 / (va + vb + vc); s = vb * den; u = vc * den; }
+    const double q[3] = {a[0] + s * ab[0] + u * ac[0], a[1] + s * ab[1] + u * ac[1], a[2] + s * ab[2] + u * ac[2]};
+    const double r0 = p[0] - q[0], r1 = p[1] - q[1], r2 = p[2] - q[2];
+    const double dd = r0 * r0 + r1 * r1 + r2 * r2;
+    if (dd < best2) { best2 = dd; best = sqrt(dd); bq[0] = r0; bq[1] = r1; bq[2] = r2; }
+  };
+  const v4d* cl4 = reinterpret_cast<const v4d*>(clus);
+  const v4d* bs4 = reinterpret_cast<const v4d*>(bsph);
+  const int ncl = (nt + kMeshCluster - 1) / kMeshCluster;
+  auto cluster = [&](int q) {
+    const int t0 = q * kMeshCluster, t1 = min(nt, t0 + kMeshCluster);
+    for (int tb = t0; tb < t1; tb += 4) {
+      v4d ts[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) ts[j] = bs4[min(tb + j, nt - 1)];
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (tb + j < t1 && !beyond(ts[j])) triangle(tb + j);
+    }
+  };
+  // pass 1: the cluster whose sphere comes nearest is searched first - its best distance culls nearly all of pass 2 (walking the
+  // clusters in table order the bound only tightens as fast as the order happens to approach p)
+  int first = -1;
+  {
+    double lo = 1e300;
+    for (int c0 = 0; c0 < ncl; c0 += 4) {
+      v4d cs[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) cs[k] = cl4[min(c0 + k, ncl - 1)];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const double c0x = p[0] - cs[k].x, c1x = p[1] - cs[k].y, c2x = p[2] - cs[k].z;
+        const double lb = sqrt(c0x * c0x + c1x * c1x + c2x * c2x) - cs[k].w;
+        if (c0 + k < ncl && lb < lo) { lo = lb; first = c0 + k; }
+      }
+    }
+    if (first >= 0 && lo < best) cluster(first);
+  }
+  for (int c0 = 0; c0 < ncl; c0 += 4) {
+    v4d cs[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) cs[k] = cl4[min(c0 + k, ncl - 1)];
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      if (c0 + k < ncl && c0 + k != first && !beyond(cs[k])) cluster(c0 + k);
+  }
+  MeshDist r;
+  r.d = best;
+  const double ir = best > 0.0 && best2 < cut2 ? 1.0 / best : 0.0;
+  r.n0 = bq[0] * ir; r.n1 = bq[1] * ir; r.n2 = bq[2] * ir;
+  return r;
+}
+
+// MESH = false compiles the triangle-mesh indenter (kind 4: a function call in the middle of a 256-register kernel) out: the Newton
+// kernel is instantiated both ways and the mesh-capable one is launched only when a mesh has been set.
+template <bool MESH = true>
+__device__ __forceinline__ ContactEval contact_eval(const FemDev& m, const double* ind, double w, const double x[3], bool need_distance = true) {
   ContactEval c;
   c.active = false; c.penetrating = false; c.d = 1e300; c.e = 0.0; c.b1 = 0.0; c.b2 = 0.0; c.n[0] = c.n[1] = c.n[2] = 0.0;
   if (!ind || !(w > 0.0)) return c;
@@ -96,6 +193,27 @@ __device__ __forceinline__ ContactEval contact_eval(const FemDev& m, const doubl
     c.d = rho - ind[4];
     const double ir = rho > 0.0 ? 1.0 / rho : 0.0;
     c.n[0] = r0 * ir; c.n[1] = r1 * ir; c.n[2] = r2 * ir;
+  } else if (MESH && kind == 4 && m.im_nt > 0) {
+    // rigid triangle mesh (tacex_fem_set_indenter_mesh) at position c with rotation vector (nx, ny, nz), inflated by R: UNSIGNED
+    // distance to the nearest triangle - R (the step bound keeps a vertex from crossing the surface; a vertex that starts
+    // inside the mesh is not detected)
+    const double r0 = ind[5], r1 = ind[6], r2 = ind[7];
+    const double th2 = r0 * r0 + r1 * r1 + r2 * r2, th = sqrt(th2);
+    const double ka = th < 1e-12 ? 1.0 : sin(th) / th, kb = th < 1e-12 ? 0.0 : (1.0 - cos(th)) / th2;
+    // R = I + ka K + kb K^2, K = [r]x
+    const double R[9] = {1.0 - kb * (r1 * r1 + r2 * r2), -ka * r2 + kb * r0 * r1, ka * r1 + kb * r0 * r2,
+                         ka * r2 + kb * r0 * r1, 1.0 - kb * (r0 * r0 + r2 * r2), -ka * r0 + kb * r1 * r2,
+                         -ka * r1 + kb * r0 * r2, ka * r0 + kb * r1 * r2, 1.0 - kb * (r0 * r0 + r1 * r1)};
+    const double g0 = x[0] - ind[1], g1 = x[1] - ind[2], g2 = x[2] - ind[3];
+    const double pl[3] = {R[0] * g0 + R[3] * g1 + R[6] * g2, R[1] * g0 + R[4] * g1 + R[7] * g2, R[2] * g0 + R[5] * g1 + R[8] * g2};  // R^T (x - c)
+    // need_distance = false (energy evaluations): anything at or beyond d_hat is as good as infinitely far
+    const double reach = m.dhat + ind[4];
+    const MeshDist md = mesh_distance(m.im_nt, m.im_tri, m.im_bs, m.im_cl, pl[0], pl[1], pl[2], need_distance ? 1e300 : reach * reach * (1.0 + 1e-12));
+    const double nl[3] = {md.n0, md.n1, md.n2};
+    c.d = md.d - ind[4];
+    c.n[0] = R[0] * nl[0] + R[1] * nl[1] + R[2] * nl[2];
+    c.n[1] = R[3] * nl[0] + R[4] * nl[1] + R[5] * nl[2];
+    c.n[2] = R[6] * nl[0] + R[7] * nl[1] + R[8] * nl[2];
   } else {
     return c;
   }
@@ -764,6 +882,7 @@ __device__ __forceinline__ double block_sum1(double v, double* sh2 /* 2 x 8 doub
   return s;
 }
 
+template <bool MESH>
 __device__ __forceinline__ double env_energy_lds(const FemDev& m, const double* xl, const double x3[3], const double* xt,
                                                  bool own, bool c, const double* aim, double* sh, int& phase,
                                                  const double* ind = nullptr, double wv = 0.0, const double* fv = nullptr,
@@ -790,7 +909,7 @@ __device__ __forceinline__ double env_energy_lds(const FemDev& m, const double* 
       if (c) { const double cc = x3[i] - aim[v * 3 + i]; qc += cc * cc; }
     }
     e += 0.5 * mv * q + 0.5 * m.strength * mv * qc;
-    if (ind) e += dt2 * contact_eval(m, ind, wv, x3).e;
+    if (ind) e += dt2 * contact_eval<MESH>(m, ind, wv, x3, false).e;
     if (fv) {
       const double xn3[3] = {xn[v * 3], xn[v * 3 + 1], xn[v * 3 + 2]};
       e += dt2 * friction_eval(m.fric_mu, m.fric_eps, fv + v * 4, x3, xn3, disp, false).e;
@@ -827,6 +946,7 @@ constexpr int kFemFlagLsFailed = 2;     // a line search found no decrease even 
 // accepted at full length (no CCD truncation, no backtracking) and its Newton direction moved no vertex by more than dx_tol
 // (velocity_tol * dt, US:62-66) - the criterion looks at the UNSCALED direction: a CCD- or search-shortened update says nothing
 // about convergence.
+template <bool MESH>
 __global__ __launch_bounds__(kNwtThreads) void fem_newton_lds_kernel(FemDev m, double* xg, const double* xtg,
                                                                      const uint8_t* consg, const double* aimg, double* stats,
                                                                      int pcg_max_iter, double pcg_tol_rate, int ls_max_iter,
@@ -1010,7 +1130,7 @@ __global__ __launch_bounds__(kNwtThreads) void fem_newton_lds_kernel(FemDev m, d
   }
   // barrier of this vertex at x: gradient b1 n, curvature b2 n n^T (the b1 * hess(d) part is negative semi-definite for a
   // convex indenter and dropped: the usual PSD projection of IPC)
-  const ContactEval ce = contact_eval(m, ind, wv, x3);
+  const ContactEval ce = contact_eval<MESH>(m, ind, wv, x3);
   if (ce.penetrating) flags |= kFemFlagPenetration;  // (per thread; or-reduced into step_info at the end)
   if (ce.active) {
 #pragma unroll
@@ -1360,7 +1480,7 @@ __global__ __launch_bounds__(kNwtThreads) void fem_newton_lds_kernel(FemDev m, d
     ++it;
   }
   // ---- backtracking line search on the incremental potential (accept the first E(x + step d) <= E(x)) ----
-  const double E0 = env_energy_lds(m, xs, x3, xt, own, c, aim, sh, phase, ind, wv, fric_phase ? fl : nullptr, xn, disp3);
+  const double E0 = env_energy_lds<MESH>(m, xs, x3, xt, own, c, aim, sh, phase, ind, wv, fric_phase ? fl : nullptr, xn, disp3);
   double step = 1.0, E1 = E0;
   if (ind) {
     // CCD step filter for analytic indenters: a signed distance field is 1-Lipschitz, so a vertex at gap d moving by
@@ -1383,7 +1503,7 @@ __global__ __launch_bounds__(kNwtThreads) void fem_newton_lds_kernel(FemDev m, d
       for (int i = 0; i < 3; ++i) { xc3[i] = x3[i] + step * d3[i]; ps[tid * 3 + i] = xc3[i]; }
     }
     __syncthreads();
-    const double Ec = env_energy_lds(m, ps, xc3, xt, own, c, aim, sh, phase, ind, wv, fric_phase ? fl : nullptr, xn, disp3);
+    const double Ec = env_energy_lds<MESH>(m, ps, xc3, xt, own, c, aim, sh, phase, ind, wv, fric_phase ? fl : nullptr, xn, disp3);
     if (Ec <= E0) { E1 = Ec; accepted = true; break; }
     step *= 0.5;
   }
@@ -1418,7 +1538,7 @@ __global__ __launch_bounds__(kNwtThreads) void fem_newton_lds_kernel(FemDev m, d
       fric_phase = true;
       double lam = 0.0;
       if (own) {
-        const ContactEval cf = contact_eval(m, ind, wv, x3);
+        const ContactEval cf = contact_eval<MESH>(m, ind, wv, x3);
         lam = cf.active ? -cf.b1 : 0.0;
         fl[tid * 4] = lam;
         fl[tid * 4 + 1] = cf.active ? cf.n[0] : 0.0; fl[tid * 4 + 2] = cf.active ? cf.n[1] : 0.0; fl[tid * 4 + 3] = cf.active ? cf.n[2] : 0.0;
@@ -1550,6 +1670,19 @@ static int fem_upload(tacex_fem_ctx* c, const std::vector<T>& h, const T** out) 
   if (e != hipSuccess) return fail_hip(e, "hipMemcpy(fem table)");
   *out = static_cast<const T*>(p);
   return 0;
+}
+
+// signed distance of every vertex to its env's indenter (the solver's own distance function): what a caller needs to keep the
+// "approach by less than the gap" contract of tacex_fem_step without restating the indenter geometry
+__global__ __launch_bounds__(256) void fem_contact_gaps_kernel(FemDev m, const double* xg, double* gaps) {
+  const int b = blockIdx.x;
+  const double* ind = m.indenters ? m.indenters + (size_t)b * 8 : nullptr;
+  for (int v = threadIdx.x; v < m.V; v += blockDim.x) {
+    const double* x = xg + ((size_t)b * m.V + v) * 3;
+    const double x3[3] = {x[0], x[1], x[2]};
+    const ContactEval c = contact_eval<true>(m, ind, 1.0, x3);
+    gaps[(size_t)b * m.V + v] = c.d < 1e299 ? c.d : INFINITY;
+  }
 }
 
 extern "C" {
@@ -1718,6 +1851,16 @@ int tacex_fem_set_contact(tacex_fem_ctx* c, const double* vertex_area_host, doub
   return 0;
 }
 
+int tacex_fem_contact_gaps(tacex_fem_ctx* c, const double* x_dev, double* gaps_dev, int num_envs, void* stream) {
+  if (!c || !x_dev || !gaps_dev) { set_error("tacex_fem_contact_gaps: null argument"); return 2; }
+  if (num_envs <= 0) return 0;
+  hipError_t e = hipSetDevice(c->device);
+  if (e != hipSuccess) return fail_hip(e, "hipSetDevice");
+  hipLaunchKernelGGL(fem_contact_gaps_kernel, dim3(num_envs), dim3(256), 0, (hipStream_t)stream, c->dev, x_dev, gaps_dev);
+  e = hipGetLastError();
+  return e == hipSuccess ? 0 : fail_hip(e, "fem_contact_gaps_kernel");
+}
+
 int tacex_fem_set_friction(tacex_fem_ctx* c, double friction_ratio, double eps_velocity) {
   if (!c) { set_error("tacex_fem_set_friction: null context"); return 2; }
   if (!(friction_ratio >= 0.0) || (friction_ratio > 0.0 && !(eps_velocity > 0.0))) {
@@ -1726,6 +1869,72 @@ int tacex_fem_set_friction(tacex_fem_ctx* c, double friction_ratio, double eps_v
   }
   c->dev.fric_mu = c->dev_nwt.fric_mu = friction_ratio;
   c->dev.fric_eps = c->dev_nwt.fric_eps = eps_velocity * c->dev.dt;
+  return 0;
+}
+
+int tacex_fem_set_indenter_mesh(tacex_fem_ctx* c, int num_verts, const double* verts_host, int num_tris, const int32_t* tris_host) {
+  if (!c) { set_error("tacex_fem_set_indenter_mesh: null context"); return 2; }
+  if (num_tris == 0) { c->dev.im_nt = c->dev_nwt.im_nt = 0; return 0; }
+  if (num_verts < 3 || num_tris < 1 || !verts_host || !tris_host) { set_error("tacex_fem_set_indenter_mesh: bad arguments"); return 2; }
+  for (int k = 0; k < num_tris * 3; ++k)
+    if (tris_host[k] < 0 || tris_host[k] >= num_verts) { set_error("tacex_fem_set_indenter_mesh: vertex index %d out of range", tris_host[k]); return 2; }
+  // triangles in Morton order of their centroids (10 bits per axis over the bounding box): 16 consecutive ones form a cluster
+  double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
+  for (int i = 0; i < num_verts; ++i)
+    for (int k = 0; k < 3; ++k) { lo[k] = fmin(lo[k], verts_host[(size_t)i * 3 + k]); hi[k] = fmax(hi[k], verts_host[(size_t)i * 3 + k]); }
+  std::vector<std::pair<uint32_t, int>> order(num_tris);
+  for (int t = 0; t < num_tris; ++t) {
+    uint32_t code = 0;
+    for (int k = 0; k < 3; ++k) {
+      double cen = 0.0;
+      for (int j = 0; j < 3; ++j) cen += verts_host[(size_t)tris_host[(size_t)t * 3 + j] * 3 + k] / 3.0;
+      const double ext = hi[k] - lo[k];
+      uint32_t q = ext > 0.0 ? (uint32_t)fmin(1023.0, fmax(0.0, (cen - lo[k]) / ext * 1024.0)) : 0u;
+      for (int bit = 0; bit < 10; ++bit) code |= ((q >> bit) & 1u) << (3 * bit + k);
+    }
+    order[t] = {code, t};
+  }
+  std::sort(order.begin(), order.end());
+  const int ncl = (num_tris + kMeshCluster - 1) / kMeshCluster;
+  std::vector<double> tri((size_t)num_tris * 9), bs((size_t)num_tris * 4), cl((size_t)ncl * 4);
+  for (int s = 0; s < num_tris; ++s) {
+    const int t = order[s].second;
+    const double* v[3];
+    for (int k = 0; k < 3; ++k) v[k] = verts_host + (size_t)tris_host[(size_t)t * 3 + k] * 3;
+    double cen[3];
+    for (int k = 0; k < 3; ++k) {
+      tri[(size_t)s * 9 + k] = v[0][k];
+      tri[(size_t)s * 9 + 3 + k] = v[1][k] - v[0][k];
+      tri[(size_t)s * 9 + 6 + k] = v[2][k] - v[0][k];
+      cen[k] = (v[0][k] + v[1][k] + v[2][k]) / 3.0;
+      bs[(size_t)s * 4 + k] = cen[k];
+    }
+    double r = 0.0;
+    for (int j = 0; j < 3; ++j) {
+      const double d0 = v[j][0] - cen[0], d1 = v[j][1] - cen[1], d2 = v[j][2] - cen[2];
+      r = fmax(r, sqrt(d0 * d0 + d1 * d1 + d2 * d2));
+    }
+    bs[(size_t)s * 4 + 3] = r * (1.0 + 1e-12);
+  }
+  for (int q = 0; q < ncl; ++q) {
+    const int s0 = q * kMeshCluster, s1 = std::min(num_tris, s0 + kMeshCluster);
+    double cen[3] = {0, 0, 0};
+    for (int s = s0; s < s1; ++s)
+      for (int k = 0; k < 3; ++k) cen[k] += bs[(size_t)s * 4 + k] / (s1 - s0);
+    double r = 0.0;
+    for (int s = s0; s < s1; ++s) {
+      const double d0 = bs[(size_t)s * 4] - cen[0], d1 = bs[(size_t)s * 4 + 1] - cen[1], d2 = bs[(size_t)s * 4 + 2] - cen[2];
+      r = fmax(r, sqrt(d0 * d0 + d1 * d1 + d2 * d2) + bs[(size_t)s * 4 + 3]);
+    }
+    for (int k = 0; k < 3; ++k) cl[(size_t)q * 4 + k] = cen[k];
+    cl[(size_t)q * 4 + 3] = r * (1.0 + 1e-12);
+  }
+  hipError_t e = hipSetDevice(c->device);
+  if (e != hipSuccess) return fail_hip(e, "hipSetDevice");
+  FemDev& d = c->dev;
+  if (int rc = fem_upload(c, tri, &d.im_tri) | fem_upload(c, bs, &d.im_bs) | fem_upload(c, cl, &d.im_cl)) return rc;
+  d.im_nt = num_tris;
+  c->dev_nwt.im_nt = num_tris; c->dev_nwt.im_tri = d.im_tri; c->dev_nwt.im_bs = d.im_bs; c->dev_nwt.im_cl = d.im_cl;
   return 0;
 }
 
@@ -1825,11 +2034,13 @@ static int launch_newton(tacex_fem_ctx* c, double* x, const double* xt, const ui
                        ((size_t)4 * c->dev.T + 2 * (size_t)c->dev.V) * sizeof(unsigned short)) + 15) & ~(size_t)15;
   if (use_lds && c->dev.V <= kNwtThreads && 4 * c->dev.T < 65535 && lds <= 160 * 1024) {
     if (resident) *resident = true;
-    static size_t granted[64] = {};  // per device: the attribute is per kernel AND device
+    static size_t granted[2][64] = {};  // per device: the attribute is per kernel AND device
+    const bool mesh = c->dev.indenters && c->dev.im_nt > 0;  // the mesh-capable instantiation only when a mesh indenter exists
+    auto kern = mesh ? fem_newton_lds_kernel<true> : fem_newton_lds_kernel<false>;
     hipError_t ea = hipSetDevice(c->device);
-    if (ea == hipSuccess) ea = ensure_dynamic_lds(reinterpret_cast<const void*>(fem_newton_lds_kernel), lds, granted);
+    if (ea == hipSuccess) ea = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds, granted[mesh ? 1 : 0]);
     if (ea != hipSuccess) return fail_hip(ea, "hipFuncSetAttribute(fem_newton_lds_kernel)");
-    hipLaunchKernelGGL(fem_newton_lds_kernel, dim3(B), dim3(kNwtThreads), lds, st, c->dev_nwt, x, xt, cons, aim, stats, pcg_max_iter,
+    hipLaunchKernelGGL(kern, dim3(B), dim3(kNwtThreads), lds, st, c->dev_nwt, x, xt, cons, aim, stats, pcg_max_iter,
                        pcg_tol_rate, ls_max_iter, dx_dev, dx_tol, max_newton, step_info, fric ? xprev : nullptr, fric ? disp : nullptr);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : fail_hip(e, "fem_newton_lds_kernel");

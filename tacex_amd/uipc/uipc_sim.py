@@ -180,8 +180,74 @@ class UipcSim:
                                                     float(c.eps_velocity)), "tacex_fem_set_friction")
         self.contact_indenters = ind  # keeps the device buffer alive: the kernels read it on every later call
 
+    def set_indenter_mesh(self, vertices, triangles):
+        """Rigid triangle mesh for indenter kind 4 (one mesh per scene, shared by the envs; every env places it with its indenter row):
+        vertices (Nv,3) in the mesh's own frame, triangles (Nt,3).  The barrier acts between every surface vertex of the gelpad and
+        its nearest triangle (`tacex_fem_set_indenter_mesh`).  None removes it."""
+        if vertices is None:
+            _lib.check(self._lib.tacex_fem_set_indenter_mesh(self._handle, 0, 0, 0, 0), "tacex_fem_set_indenter_mesh")
+            self.indenter_mesh = None
+            return
+        v = np.ascontiguousarray(vertices, np.float64).reshape(-1, 3)
+        t = np.ascontiguousarray(triangles, np.int32).reshape(-1, 3)
+        _lib.check(self._lib.tacex_fem_set_indenter_mesh(self._handle, len(v), v.ctypes.data, len(t), t.ctypes.data), "tacex_fem_set_indenter_mesh")
+        self.indenter_mesh = (v, t)
+
+    def _mesh_gaps(self, x, ind):
+        """torch restatement of the kernel's point-triangle distance (diagnostic; triangles in chunks to bound the memory)."""
+        v, t = self.indenter_mesh
+        vt = torch.from_numpy(v).to(self.device)
+        r = ind[:, 5:8]
+        th = r.norm(dim=-1).clamp_min(1e-300)
+        K = torch.zeros((len(r), 3, 3), dtype=torch.float64, device=self.device)
+        K[:, 0, 1], K[:, 0, 2], K[:, 1, 0], K[:, 1, 2], K[:, 2, 0], K[:, 2, 1] = -r[:, 2], r[:, 1], r[:, 2], -r[:, 0], -r[:, 1], r[:, 0]
+        ka = torch.where(th < 1e-12, torch.ones_like(th), torch.sin(th) / th)
+        kb = torch.where(th < 1e-12, torch.zeros_like(th), (1 - torch.cos(th)) / (th * th))
+        R = torch.eye(3, dtype=torch.float64, device=self.device)[None] + ka[:, None, None] * K + kb[:, None, None] * (K @ K)
+        p = torch.einsum("bvj,bji->bvi", x - ind[:, None, 1:4], R)[:, :, None, :]  # R^T (x - c): (B,V,1,3)
+        best = torch.full(x.shape[:2], float("inf"), dtype=torch.float64, device=self.device)
+        for t0 in range(0, len(t), 16):
+            tt = torch.from_numpy(t[t0:t0 + 16].astype(np.int64)).to(self.device)
+            a, b, c = vt[tt[:, 0]], vt[tt[:, 1]], vt[tt[:, 2]]
+            ab, ac = (b - a)[None, None], (c - a)[None, None]
+            ap = p - a[None, None]
+            d1, d2 = (ab * ap).sum(-1), (ac * ap).sum(-1)
+            bp = p - b[None, None]
+            d3, d4 = (ab * bp).sum(-1), (ac * bp).sum(-1)
+            cp = p - c[None, None]
+            d5, d6 = (ab * cp).sum(-1), (ac * cp).sum(-1)
+            vc, vb, va = d1 * d4 - d3 * d2, d5 * d2 - d1 * d6, d3 * d6 - d5 * d4
+            den = 1.0 / (va + vb + vc)
+            s, u = vb * den, vc * den
+            e = (va <= 0) & ((d4 - d3) >= 0) & ((d5 - d6) >= 0)
+            ue = (d4 - d3) / ((d4 - d3) + (d5 - d6))
+            s, u = torch.where(e, 1 - ue, s), torch.where(e, ue, u)
+            e = (vb <= 0) & (d2 >= 0) & (d6 <= 0)
+            s, u = torch.where(e, torch.zeros_like(s), s), torch.where(e, d2 / (d2 - d6), u)
+            e = (d6 >= 0) & (d5 <= d6)
+            s, u = torch.where(e, torch.zeros_like(s), s), torch.where(e, torch.ones_like(u), u)
+            e = (vc <= 0) & (d1 >= 0) & (d3 <= 0)
+            s, u = torch.where(e, d1 / (d1 - d3), s), torch.where(e, torch.zeros_like(u), u)
+            e = (d3 >= 0) & (d4 <= d3)
+            s, u = torch.where(e, torch.ones_like(s), s), torch.where(e, torch.zeros_like(u), u)
+            e = (d1 <= 0) & (d2 <= 0)
+            s, u = torch.where(e, torch.zeros_like(s), s), torch.where(e, torch.zeros_like(u), u)
+            q = a[None, None] + s[..., None] * ab + u[..., None] * ac
+            best = torch.minimum(best, (p - q).norm(dim=-1).amin(-1))
+        return best - ind[:, None, 4]
+
     def contact_gaps(self, x=None) -> torch.Tensor:
-        """(num_envs, V) signed distance of every vertex to its env's indenter (+inf without one) - a diagnostic in torch ops."""
+        """(num_envs, V) signed distance of every vertex to its env's indenter (+inf without one), by the solver's own distance
+        function (`tacex_fem_contact_gaps`; no host round trip)."""
+        x = self.x if x is None else x.to(self.device, torch.float64).contiguous()
+        if getattr(self, "contact_indenters", None) is None:
+            return torch.full(x.shape[:2], float("inf"), dtype=torch.float64, device=self.device)
+        gaps = torch.empty(x.shape[:2], dtype=torch.float64, device=self.device)
+        _lib.check(self._lib.tacex_fem_contact_gaps(self._handle, _lib.ptr(x), _lib.ptr(gaps), x.shape[0], self._stream()), "tacex_fem_contact_gaps")
+        return gaps
+
+    def contact_gaps_torch(self, x=None) -> torch.Tensor:
+        """The same distances restated in torch ops (tests compare the two)."""
         x = self.x if x is None else x
         ind = getattr(self, "contact_indenters", None)
         if ind is None:
@@ -193,7 +259,8 @@ class UipcSim:
         t = (pl / aa).clamp(-1.0, 1.0)
         cap = (x - c - t[..., None] * n).norm(dim=-1) - ind[:, None, 4]
         inf = torch.full_like(sph, float("inf"))
-        return torch.where(kind == 1, sph, torch.where(kind == 2, pl, torch.where(kind == 3, cap, inf)))
+        msh = self._mesh_gaps(x, ind) if getattr(self, "indenter_mesh", None) is not None and bool((ind[:, 0] == 4).any()) else inf
+        return torch.where(kind == 1, sph, torch.where(kind == 2, pl, torch.where(kind == 3, cap, torch.where(kind == 4, msh, inf))))
 
     # -- animation targets (uipc_attachments.py:364-385) ----------------------------------------------------------
     def set_constraints(self, vertex_idx, aim_positions: torch.Tensor):

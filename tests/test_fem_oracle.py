@@ -398,3 +398,45 @@ def test_chain_preconditioner_is_the_block_tridiagonal_inverse_and_cuts_pcg_iter
     _, it_bj = pcg_solve(hv, make_chain_preconditioner(S1, G1, n1, h1), b, 500, 1e-6)
     _, it_ch = pcg_solve(hv, prec, b, 500, 1e-6)
     assert it_ch < 0.7 * it_bj, (it_ch, it_bj)
+
+
+def test_mesh_indenter_distance_known_answers_and_fd():
+    """Indenter kind 4 (rigid triangle mesh): closest feature of a box (face / edge / corner) in closed form, pose (rotation vector +
+    position) and offset, an icosphere against the analytic sphere, and the gradient by finite differences."""
+    from oracle.fem_oracle import contact_distance, rotation_from_vector
+    from tacex_amd.uipc.indenter_meshes import box, icosphere
+
+    bv, bt = box((1.0, 2.0, 0.5))
+    ind = np.array([4.0, 0, 0, 0, 0.0, 0, 0, 0])
+    x = np.array([[0.3, -0.4, 1.5],    # above the +z face: distance 1.0, normal +z
+                  [2.0, 0.5, 1.5],     # beside the edge x = 1, z = 0.5: sqrt(2)
+                  [2.0, 3.0, 1.5],     # off the corner (1, 2, 0.5): sqrt(3)
+                  [-1.25, 0.0, 0.0]])  # left of the -x face
+    d, n = contact_distance(ind, x, (bv, bt))
+    np.testing.assert_allclose(d, [1.0, 2**0.5, 3**0.5, 0.25], rtol=1e-14)
+    np.testing.assert_allclose(n, [[0, 0, 1], [2**-0.5, 0, 2**-0.5], [3**-0.5] * 3, [-1, 0, 0]], atol=1e-14)
+    # pose + offset: rotate the box by 90 degrees about z, move it, inflate by 0.1
+    ind2 = np.array([4.0, 5.0, -1.0, 2.0, 0.1, 0, 0, np.pi / 2])
+    R = rotation_from_vector(ind2[5:8])
+    np.testing.assert_allclose(R @ [1, 0, 0], [0, 1, 0], atol=1e-15)
+    x2 = x @ R.T + ind2[1:4]
+    d2, n2 = contact_distance(ind2, x2, (bv, bt))
+    np.testing.assert_allclose(d2, d - 0.1, rtol=1e-13)
+    np.testing.assert_allclose(n2, n @ R.T, atol=1e-13)
+    # icosphere (vertices on the sphere, faces inside): analytic sphere distance <= mesh distance <= + the faces' sagitta
+    sv, st = icosphere(0.004, 2)
+    rng = np.random.default_rng(5)
+    p = rng.standard_normal((200, 3))
+    p = p / np.linalg.norm(p, axis=-1, keepdims=True) * rng.uniform(0.0041, 0.006, (200, 1))
+    dm, nm = contact_distance(np.array([4.0, 0, 0, 0, 0, 0, 0, 0]), p, (sv, st))
+    ds = np.linalg.norm(p, axis=-1) - 0.004
+    edge = np.linalg.norm(sv[st[:, 0]] - sv[st[:, 1]], axis=-1).max()
+    sag = 0.004 - np.sqrt(0.004**2 - (edge / 3**0.5) ** 2)
+    assert (dm >= ds - 1e-15).all() and (dm <= ds + sag + 1e-15).all()
+    assert ((nm * p).sum(-1) / np.linalg.norm(p, axis=-1) > 0.95).all()
+    # gradient of the distance = n (away from points where the closest feature changes)
+    h = 1e-8
+    for k in range(3):
+        e = np.zeros(3); e[k] = h
+        fd = (contact_distance(ind2, x2 + e, (bv, bt))[0] - contact_distance(ind2, x2 - e, (bv, bt))[0]) / (2 * h)
+        np.testing.assert_allclose(fd, n2[:, k], atol=1e-6)
