@@ -597,45 +597,52 @@ def test_fem_gelpad_scene_through_the_sensor():
 
 def test_friction_drags_the_pad_surface():
     """A sphere pressed into the pad slides sideways: with Coulomb friction (reference default, ratio 0.5) the contact patch of
-    the surface follows it, without friction it stays; kernel and oracle agree on how far."""
+    the surface follows it, without friction it stays; kernel and oracle agree on how far.  The press is gentle enough for every
+    step to converge well inside the iteration cap (9-18 Newton iterations): pressed at 0.45 of the gap per step the solver runs
+    into failing line searches and kernel and oracle part within the backtracking (profiles/r03_experiments.md section 10)."""
     from oracle.fem_oracle import fem_step
 
     res = {}
+    slide = 5e-5
     for mu in (0.5, 0.0):
         sim, m, P, cons, aim, cms = _c4_scene(1)
         sim.cfg.contact.default_friction_ratio = mu
         sim.cfg.contact.enable_friction = mu > 0
-        sim.cfg.newton.velocity_tol = 2e-3
+        sim.cfg.newton.velocity_tol = 1e-3
         sim.cfg.linear_system.max_iter, sim.cfg.linear_system.tol_rate = 600, 1e-6
         sim.set_contact_indenters(sim.contact_indenters)  # re-reads the friction settings
         ind = sim.contact_indenters
         xo, vo = P.copy(), np.zeros_like(P)
         prev = None
-        for k in range(8):
-            if k >= 4:
-                ind[:, 1] += 1e-4         # after pressing: slide along x, 0.1 mm per step (less than the gap it leaves)
+        for k in range(7):
+            if k >= 3:
+                ind[:, 1] += slide            # after pressing: slide along x, 50 um per step (less than the gap it leaves)
             gap = float(sim.contact_gaps().amin())
-            if k < 4:
-                ind[:, 3] -= 0.45 * gap   # press
-            elif gap < 2e-4:
-                ind[:, 3] += 2e-4 - gap   # (keep the contract: never closer than the sideways step)
+            if k < 3:
+                ind[:, 3] -= 0.3 * gap        # press
+            elif gap < 2 * slide:
+                ind[:, 3] += 2 * slide - gap  # (keep the contract: never closer than the sideways step)
             cur = ind[0, 1:4].cpu().numpy().copy()
             disp = cur - prev if prev is not None else np.zeros(3)
             prev = cur
             cms[0].ind[1:4] = cur
-            sim.step(max_newton_iter=100)  # (enough for every step to converge: 13-40 iterations; at a cap the two paths part within the backtracking)
-            assert len(sim.check_step()["penetrating_envs"]) == 0
+            sim.step(max_newton_iter=60)
+            info = sim.check_step()
+            assert len(info["penetrating_envs"]) == 0 and len(info["line_search_failed_envs"]) == 0 and int(sim.last_newton_iters) < 60
             if mu > 0:
-                xo, vo, io = fem_step(m, cms[0], xo, vo, cons, aim[0], gravity=sim.cfg.gravity, max_newton=100, velocity_tol=2e-3, pcg_max_iter=600,
+                xo, vo, io = fem_step(m, cms[0], xo, vo, cons, aim[0], gravity=sim.cfg.gravity, max_newton=60, velocity_tol=1e-3, pcg_max_iter=600,
                                       pcg_tol_rate=1e-6, coarse=sim.coarse_space, chains=_chains(sim), friction=(mu, sim.cfg.contact.eps_velocity, disp))
-                assert io[0] < 100 and int(sim.last_newton_iters) < 100
+                assert io[0] < 60 and io[2] == 0
+                assert np.abs(sim.x[0].cpu().numpy() - xo).max() <= 2 * 1e-3 * sim.cfg.dt, k  # both inside the Newton tolerance of the same state
         x = sim.x[0].cpu().numpy()
         top = P[:, 2] > P[:, 2].max() - 1e-9
         near = top & (np.hypot(P[:, 0] - cur[0], P[:, 1] - cur[1]) < 0.004)
         res[mu] = float((x[near, 0] - P[near, 0]).mean())
-        res[(mu, "oracle")] = float((xo[near, 0] - P[near, 0]).mean())
-    assert res[0.5] > 5e-5 and res[0.5] > 1.5 * abs(res[0.0]), res  # dragged along +x: 1.77x what the dent's slope alone pushes (kernel AND oracle)
-    assert abs(res[0.5] - res[(0.5, "oracle")]) <= 0.1 * res[0.5], res  # (measured: 3e-5 m apart at most over the eight steps)
+        if mu > 0:
+            res[(mu, "oracle")] = float((xo[near, 0] - P[near, 0]).mean())
+    print("drag [m]:", res)
+    assert res[0.5] > 5e-5 and res[0.5] > 1.25 * abs(res[0.0]), res  # dragged along +x, beyond what the dent's slope alone pushes
+    assert abs(res[0.5] - res[(0.5, "oracle")]) <= 0.01 * res[0.5], res  # (measured 1.5e-5 relative)
 
 
 def test_mesh_indenter_vs_oracle_and_analytic_sphere():
