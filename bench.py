@@ -176,11 +176,12 @@ class Rig:
         if self.obs is not None:
             self.obs.wait()  # the last step's collective is part of the timed region
 
-    def timed(self, steps, warmup, barrier=lambda: None):
+    def timed(self, steps, warmup, barrier=lambda: None, after_warmup=lambda: None):
         for i in range(warmup):
             self.step(i)
         self.finish()
         torch.cuda.synchronize()
+        after_warmup()
         barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -371,7 +372,15 @@ def sweep(args, dev):
             rig = Rig(B, H, W, n_sensors, markers, dev, 1, seed=7, gather=gather or args.gather, obs_dtype=args.obs_dtype, fem=fem, **rig_kw)
             if fem is not None:
                 fem.ms_log = []
-            el = rig.timed(steps, 3)
+            # FEM scenes: the indenter breathes with a period of 2 pi / 0.3 = 21 steps whose phases cost 1 ... 18 ms each, and the first
+            # long Newton launches of a process carry a one-time ~50 ms of runtime work (scratch set-up, seen at sync; scripts/c4_probe.py):
+            # warm up over one whole period, time exactly one period
+            if fem is not None:
+                steps = 21
+            base = []
+            if fem is not None:  # solver statistics over the timed period: device-side sums, the warm-up's share is subtracted
+                fem.info_sum = torch.zeros(4, dtype=torch.float64, device=dev)
+            el = rig.timed(steps, 24 if fem is not None else 3, after_warmup=lambda: base.append(fem.info_sum.clone()) if fem is not None else None)
             frames = B * n_sensors * steps
             e = {"workload": label, "frames_per_step": B * n_sensors, "steps": steps, "ms_per_step": round(el / steps * 1e3, 4),
                  "frames_per_s": round(frames / el, 1)}
@@ -384,7 +393,7 @@ def sweep(args, dev):
             if fem is not None:
                 # split: the FEM part alone (hipEvents around attachments + UipcSim.step), MEAN over the timed steps - the Newton
                 # / PCG iteration counts vary from step to step with the indenter's breathing
-                ms = fem.ms_log[3:] or fem.ms_log
+                ms = fem.ms_log[24:] or fem.ms_log
                 e["fem_ms_mean"] = round(sum(ms) / max(len(ms), 1), 3)
                 e["fem_ms_min_max"] = [round(min(ms), 3), round(max(ms), 3)] if ms else None
                 si = fem.sim.check_step(raise_on_penetration=False)
@@ -392,6 +401,11 @@ def sweep(args, dev):
                                       "pcg_iters_per_newton_mean": round(float((si["pcg_iters"] / np.maximum(si["newton_iters"], 1)).mean()), 1),
                                       "envs_flagged_penetration": int(len(si["penetrating_envs"])),
                                       "envs_flagged_line_search": int(len(si["line_search_failed_envs"]))}
+                tot = (fem.info_sum - base[0]).cpu().numpy()
+                e["fem_period"] = {"steps": steps, "newton_iters_per_step_mean": round(float(tot[0]) / steps, 2),
+                                   "pcg_iters_per_newton_mean": round(float(tot[3]) / max(float(tot[0]), 1e-9), 1),
+                                   "note": "means over envs and over the timed window = one period of the indenter's breathing (21 steps: about half in "
+                                           "steady contact at ~1 ms, half in the release regime at 10-18 ms)"}
                 e["fem"] = fem_roofline(fem)
             out.append(e)
             del rig
@@ -412,9 +426,9 @@ def sweep(args, dev):
     run("C2 + FOTS markers: 256 envs x 1 sensor, RGB 320x240 + markers", 256, 240, 320, 1, True)
     run("512-env shard of the 4096-env / 8-GPU target: 512 envs x 1 sensor, RGB 320x240 + FOTS markers", 512, 240, 320, 1, True)
     run("C4 per-GPU shard: 512 envs, RGB 320x240 + FEM-driven markers + gelpad FEM step (1920 tets / env) (BASELINE configs[3] / 8)",
-        512, 240, 320, 1, False, fem=lambda: FemGelpad(512, dev), steps=max(12, args.sweep_steps // 3))
+        512, 240, 320, 1, False, fem=lambda: FemGelpad(512, dev))
     run("C5 per-GPU shard: 1024 envs, RGB 640x480 + FEM-driven markers (gelpad FEM step included) (BASELINE configs[4] / 8)",
-        1024, 480, 640, 1, False, fem=lambda: FemGelpad(1024, dev), steps=max(12, args.sweep_steps // 6))
+        1024, 480, 640, 1, False, fem=lambda: FemGelpad(1024, dev))
     run("C5 optical part only: 1024 envs, RGB 640x480", 1024, 480, 640, 1, False, steps=max(5, args.sweep_steps // 3))
     return out
 

@@ -6,15 +6,11 @@ dev=torch.device("cuda:0")
 B=512
 fem=FemGelpad(B,"cuda:0")
 rig=bench.Rig(B,240,320,1,False,dev,1,seed=7,gather="obs32",obs_dtype="u8",fem=fem)
-fem.ms_log=[]
-el=rig.timed(30,3)
-ms=fem.ms_log[3:]
-print("C4 ms/step %.3f  fem mean %.3f  n %d"%(el/30*1e3, sum(ms)/len(ms), len(ms)))
-# split: sensors only
-torch.cuda.synchronize(); t0=time.perf_counter()
-for i in range(30):
+for i in range(11): rig.step(i)
+rig.finish(); torch.cuda.synchronize()
+def ev(): e=torch.cuda.Event(enable_timing=True); e.record(); return e
+for i in range(11,14):
+    t0=time.perf_counter(); e0=ev(); fem.step(i); e1=ev(); t1=time.perf_counter()
     for s in rig.sensors: s.update(dt=0.01, force_recompute=True)
-torch.cuda.synchronize(); print("sensor update only ms %.3f"%((time.perf_counter()-t0)/30*1e3))
-t0=time.perf_counter()
-for i in range(33,63): fem.step(i)
-torch.cuda.synchronize(); print("fem only wall ms %.3f"%((time.perf_counter()-t0)/30*1e3))
+    e2=ev(); t2=time.perf_counter(); torch.cuda.synchronize(); t3=time.perf_counter()
+    print(i, "host fem %.2f host sensors %.2f sync wait %.2f | gpu fem %.2f gpu sensors %.2f"%((t1-t0)*1e3,(t2-t1)*1e3,(t3-t2)*1e3,e0.elapsed_time(e1),e1.elapsed_time(e2)))

@@ -49,6 +49,7 @@ class FemGelpad:
         self.B = B
         self.ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
         self.ms_log = None    # set to [] to collect the duration of every step (hipEvents, read one step late)
+        self.info_sum = None  # with ms_log: (4,) device sums over the logged steps of [Newton iterations, -, flagged envs, PCG iterations] per env mean
         self._pending = None
 
     def step(self, i):
@@ -64,6 +65,8 @@ class FemGelpad:
         self.ind[:, 3] = torch.where(z > target, torch.maximum(target, z - 0.5 * gap), target)  # down: limited; up: free
         self.sim.step(max_newton_iter=self.max_newton_iter)
         self.ev[1].record()
+        if self.ms_log is not None and self.info_sum is not None:
+            self.info_sum += self.sim.step_info.mean(0)  # device-side, no synchronisation
         if self.ms_log is not None:  # (reading the previous step's events: no sync with the step just enqueued)
             if self._pending is not None:
                 self._pending[1].synchronize()
