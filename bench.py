@@ -406,7 +406,7 @@ def sweep(args, dev):
                                    "pcg_iters_per_newton_mean": round(float(tot[3]) / max(float(tot[0]), 1e-9), 1),
                                    "note": "means over envs and over the timed window = one period of the indenter's breathing (21 steps: about half in "
                                            "steady contact at ~1 ms, half in the release regime at 10-18 ms)"}
-                e["fem"] = fem_roofline(fem)
+                e["fem"] = fem_roofline(fem, (sum(ms) * steps / max(len(ms), 1), float(tot[0]), float(tot[3])))
             out.append(e)
             del rig
             torch.cuda.empty_cache()
@@ -433,8 +433,10 @@ def sweep(args, dev):
     return out
 
 
-def fem_roofline(fem):
-    """What bounds the FEM step.  `UipcSim.step` runs ONE kernel (fem_newton_lds_kernel: the whole Newton loop with the env's
+def fem_roofline(fem, period=None):
+    """What bounds the FEM step.  `period` = (total FEM ms, Newton iterations per env, PCG iterations per env) summed over the timed
+    period of the scene: the roofline figures are taken over THAT (the scene's own mix of regimes); without it a single Newton
+    iteration at the scene's current state is timed.  `UipcSim.step` runs ONE kernel (fem_newton_lds_kernel: the whole Newton loop with the env's
     state on the CU), so ITS roof is the one that matters: f64 vector throughput and LDS bandwidth of the CU the env sits on, not
     HBM (inside the PCG loop only the mesh constants are read, and those are shared by all envs and stay in L2).  Work per PCG
     iteration and env, counted from the kernel source (csrc/fem_kernels.hip, the `sweep` of the H.p product):
@@ -465,20 +467,26 @@ def fem_roofline(fem):
         sim.x.copy_(x0)
         sim.newton_step()
 
-    ms_nw = timeit(newton, 3)
-    st = sim.stats.cpu().numpy()
-    pcg = float(st[:, 3].mean())
-    sim.x.copy_(x0)
+    if period is None:
+        ms_nw = timeit(newton, 3)
+        st = sim.stats.cpu().numpy()
+        pcg = float(st[:, 3].mean())
+        sim.x.copy_(x0)
+        n_newton = 1.0
+    else:
+        ms_nw, n_newton, pcg = period
     # per env and PCG iteration (see the docstring); + gradient / preconditioner / line-search sweeps ~ 4 more sweeps per Newton iteration
     flop_it = 480 * T + 120 * V
     lds_it = (36 * T + 75 * V) * 8
-    sweeps = pcg + 4.0
+    sweeps = pcg + 4.0 * n_newton
     tf = flop_it * sweeps * B / (ms_nw * 1e-3) / 1e12
     lds_tbs = lds_it * sweeps * B / (ms_nw * 1e-3) / 1e12
     el_bytes = (12 * 8 + 8 + 96 + 1152) * B * T  # per env and tet: 4 vertices x 3 doubles read; energy + gradient + 12x12 Hessian written
     return {
         "newton_iteration": {"kernel": "fem_newton_lds_kernel (on the step path: 97 % of the FEM time)", "bound": "f64 VALU / LDS of one CU per env",
-                             "ms": round(ms_nw, 3), "pcg_iterations_mean": round(pcg, 1), "us_per_pcg_iteration": round(ms_nw * 1e3 / max(sweeps, 1), 2),
+                             "ms": round(ms_nw, 3), "newton_iterations": round(n_newton, 2), "pcg_iterations": round(pcg, 1),
+                             "window": "one Newton iteration at the current state" if period is None else "the timed period of the scene (sums per env)",
+                             "us_per_sweep": round(ms_nw * 1e3 / max(sweeps, 1), 2),
                              "f64_flop_per_env_and_pcg_iteration": flop_it, "achieved_f64": round(tf, 2), "peak_f64": F64_PEAK_TFLOPS, "unit": "TFLOP/s",
                              "frac": round(tf / F64_PEAK_TFLOPS, 4),
                              "lds_bytes_per_env_and_pcg_iteration": lds_it, "achieved_lds": round(lds_tbs, 2), "peak_lds": LDS_PEAK_TBS,
