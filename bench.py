@@ -427,6 +427,10 @@ def sweep(args, dev):
     run("512-env shard of the 4096-env / 8-GPU target: 512 envs x 1 sensor, RGB 320x240 + FOTS markers", 512, 240, 320, 1, True)
     run("C4 per-GPU shard: 512 envs, RGB 320x240 + FEM-driven markers + gelpad FEM step (1920 tets / env) (BASELINE configs[3] / 8)",
         512, 240, 320, 1, False, fem=lambda: FemGelpad(512, dev))
+    run("C4 shard, ROLLING CONTACT: the indenter stays on the pad like the ball of the reference's ball-rolling scene (depth 0.3-0.8 of "
+        "the maximum, sliding +-0.5 mm sideways, friction on); whenever the indenter RETREATS the pad has to follow it up the barrier and the "
+        "Newton loop runs to its cap of 8 iterations, released or not",
+        512, 240, 320, 1, False, fem=lambda: FemGelpad(512, dev, motion="rolling"))
     run("C5 per-GPU shard: 1024 envs, RGB 640x480 + FEM-driven markers (gelpad FEM step included) (BASELINE configs[4] / 8)",
         1024, 480, 640, 1, False, fem=lambda: FemGelpad(1024, dev))
     run("C5 optical part only: 1024 envs, RGB 640x480", 1024, 480, 640, 1, False, steps=max(5, args.sweep_steps // 3))

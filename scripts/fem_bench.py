@@ -48,9 +48,9 @@ def full_step():
 dt = timeit(full_step, 3)
 print(f"UipcSim.step warm (8 Newton iters cap, device-side early exit): {dt*1e3:.2f} ms, iters {sim.last_newton_iters}")
 # the C4 / C5 bench scene (back face attached, sphere indenter breathing in and out): ms per FEM step and solver statistics
-from tacex_amd.uipc.gelpad_scene import FemGelpad
-fem = FemGelpad(B, "cuda:0")
 import os
+from tacex_amd.uipc.gelpad_scene import FemGelpad
+fem = FemGelpad(B, "cuda:0", motion=os.environ.get("FEM_MOTION", "breathing"))
 if os.environ.get("FEM_COARSE"):  # A/B: coarse grid cells per axis, e.g. FEM_COARSE=4,5,1
     fem.sim.cfg.linear_system.coarse_grid = tuple(int(v) for v in os.environ["FEM_COARSE"].split(","))
     fem.sim._precond_dirty = True

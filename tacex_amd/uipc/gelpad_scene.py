@@ -20,7 +20,14 @@ class FemGelpad:
     presses into the front face through the IPC barrier (d_hat 1 mm, CCD-filtered Newton steps) and breathes in and out;
     stepped with UipcSim.step (backward Euler: the whole Newton loop - matrix-free PCG, CCD filter, line search - in one HIP launch)."""
 
-    def __init__(self, B, dev, max_newton_iter: int = 8):
+    def __init__(self, B, dev, max_newton_iter: int = 8, motion: str = "breathing"):
+        """motion: "breathing" - the indenter presses in and retreats to the edge of the barrier zone every 21 steps; "rolling" - it
+        stays on the pad like the ball of the reference's ball-rolling scenes: the depth varies between 0.3 and 0.8 of the env's
+        maximum while the sphere slides sideways by up to +-0.5 mm (friction drags the surface along).  Either way the half of the
+        period in which the indenter RETREATS is the solver's expensive regime: the pad follows it up the steeply nonlinear barrier
+        in damped Newton steps (8 iterations per step, the scene's cap), 10-17 ms per step against ~1 ms while it presses."""
+        assert motion in ("breathing", "rolling")
+        self.motion = motion
         self.max_newton_iter = max_newton_iter
         P, T = gelpad_box_mesh(8, 10, 4)
         self.sim = UipcSim(UipcSimCfg(device=dev), num_envs=B)
@@ -59,8 +66,13 @@ class FemGelpad:
         self.att.apply(self.sim, pos, self.quat)  # compute_aim_positions -> is_constrained / aim_position (UA:364-428)
         # the indenter follows its breathing trajectory, but never moves more than half the current gap towards the pad
         # (what a CCD-filtered rigid-body step would allow); all on the device, no host round trip
-        target = self.z_rest - self.depth * (0.5 - 0.5 * math.cos(0.3 * i))
         gap = self.sim.contact_gaps().amin(1)
+        if self.motion == "rolling":
+            target = self.z_rest - self.depth * (0.55 - 0.25 * math.cos(0.3 * i))
+            dx = 0.0005 * (math.sin(0.15 * (i + 1)) - math.sin(0.15 * i))  # <= 75 um per step: far below the gap the barrier keeps
+            self.ind[:, 1] += torch.clamp(torch.full_like(gap, dx), -0.25 * gap, 0.25 * gap)
+        else:
+            target = self.z_rest - self.depth * (0.5 - 0.5 * math.cos(0.3 * i))
         z = self.ind[:, 3]
         self.ind[:, 3] = torch.where(z > target, torch.maximum(target, z - 0.5 * gap), target)  # down: limited; up: free
         self.sim.step(max_newton_iter=self.max_newton_iter)
