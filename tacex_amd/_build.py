@@ -20,13 +20,20 @@ _FLAGS_FILE = PKG / f"libtacex_hip.{_TAG}.flags"
 SOURCES = ["taxim_kernels.hip", "taxim_mfma.hip", "taxim_tail.hip", "taxim_stream.hip", "taxim_shadow.hip", "fots_kernels.hip", "fem_kernels.hip", "depth_raster.hip", "tacex_capi.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=fast", "-Wno-unused-result"]
 # A/B hook for kernel tuning macros, e.g. TACEX_EXTRA_HIPCC_FLAGS="-DTACEX_MFMA_CH=2" (part of the build digest)
-if _TAG and "TACEX_EXTRA_HIPCC_FLAGS" not in os.environ and _FLAGS_FILE.exists():
-    FLAGS += _FLAGS_FILE.read_text().split()
+_STREAM_DEFAULT = "-mllvm -amdgpu-sched-strategy=max-memory-clause"
+_stream_flags = os.environ.get("TACEX_STREAM_HIPCC_FLAGS", _STREAM_DEFAULT)
+if _TAG and "TACEX_EXTRA_HIPCC_FLAGS" not in os.environ and "TACEX_STREAM_HIPCC_FLAGS" not in os.environ and _FLAGS_FILE.exists():
+    _side = _FLAGS_FILE.read_text().split("\n")  # line 1: flags of every file, line 2 (optional): flags of the streaming tail
+    FLAGS += _side[0].split()
+    if len(_side) > 1:
+        _stream_flags = _side[1]
 else:
     FLAGS += os.environ.get("TACEX_EXTRA_HIPCC_FLAGS", "").split()
 # per-file flags (part of the digest): the streaming tail is scalar f32 FMA chains - SLP packing into v_pk_fma_f32 (half rate on
 # gfx950, scripts/hip_probes/valu_rates.hip) only adds register shuffles and pushed the kernel into scratch
-FILE_FLAGS = {"taxim_stream.hip": ["-fno-slp-vectorize"],
+# TACEX_STREAM_HIPCC_FLAGS: A/B hook for flags of the streaming tail alone (scheduler strategies, profiles/r03_experiments.md section 11)
+# Scheduler: -amdgpu-sched-strategy=max-memory-clause measured -3.7 % on the streaming tail (769 vs 798 us per 1024 frames; max-ilp -1.6 %)
+FILE_FLAGS = {"taxim_stream.hip": ["-fno-slp-vectorize"] + _stream_flags.split(),
               # the rasteriser must round every product on its own (bit-equal to its NumPy restatement): with the global
               # -ffp-contract=fast the backend fuses multiply-adds even under `#pragma clang fp contract(off)`
               "depth_raster.hip": ["-ffp-contract=off"]}
@@ -94,7 +101,7 @@ def _build_locked(dig: str, verbose: bool) -> Path:
     os.replace(tmp, LIB)
     STAMP.write_text(dig)
     if _TAG:
-        _FLAGS_FILE.write_text(os.environ.get("TACEX_EXTRA_HIPCC_FLAGS", ""))
+        _FLAGS_FILE.write_text(os.environ.get("TACEX_EXTRA_HIPCC_FLAGS", "") + "\n" + _stream_flags)
     return LIB
 
 
