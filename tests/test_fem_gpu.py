@@ -711,3 +711,33 @@ def test_mesh_indenter_vs_oracle_and_analytic_sphere():
     dent = (P[:, 2] - res[1][:, 2]).max()
     assert dent > 1e-4                                                   # the pad is dented by > 0.1 mm ...
     assert np.abs(res[4] - res[1]).max() <= 0.1 * dent, (np.abs(res[4] - res[1]).max(), dent)  # ... and the mesh agrees within 10 % of it
+
+
+def test_fem_table_setters_reject_bad_input_and_gaps_without_indenter():
+    """Error behaviour of the round-3 setters (tacex_fem_set_chains / set_indenter_mesh / set_coarse_space) and the gap query."""
+    from tacex_amd.uipc import UipcObject, UipcObjectCfg, UipcSim, UipcSimCfg
+    from tacex_amd.uipc.uipc_object import gelpad_box_mesh
+
+    P, T = gelpad_box_mesh(3, 3, 2)
+    sim = UipcSim(UipcSimCfg(device="cuda:0"), num_envs=2)
+    UipcObject(UipcObjectCfg(mesh_points=P, mesh_tets=T), sim)
+    sim.setup_sim()
+    lib, h = sim._lib, sim._handle
+    assert torch.isinf(sim.contact_gaps()).all()  # no indenter yet
+    off = np.array([0, 2, 4], np.int32)
+    vtx = np.array([0, 1, 1, 2], np.int32)  # vertex 1 in two chains
+    assert lib.tacex_fem_set_chains(h, 2, off.ctypes.data, vtx.ctypes.data) != 0
+    assert b"two chains" in lib.tacex_last_error()
+    vtx = np.array([0, 1, 2, len(P)], np.int32)  # out of range
+    assert lib.tacex_fem_set_chains(h, 2, off.ctypes.data, vtx.ctypes.data) != 0
+    assert lib.tacex_fem_set_chains(h, 0, 0, 0) == 0
+    v = np.zeros((3, 3)); t = np.array([[0, 1, 3]], np.int32)  # triangle vertex out of range
+    assert lib.tacex_fem_set_indenter_mesh(h, 3, v.ctypes.data, 1, t.ctypes.data) != 0
+    assert lib.tacex_fem_set_indenter_mesh(h, 0, 0, 0, 0) == 0
+    assert lib.tacex_fem_set_coarse_space(h, 65, 0, 0, 0) != 0  # more than 64 coarse nodes
+    # a kind-4 row without a mesh is no indenter: +inf gaps, the step runs
+    ind = torch.zeros((2, 8), dtype=torch.float64); ind[:, 0] = 4.0
+    sim.set_contact_indenters(ind)
+    assert torch.isinf(sim.contact_gaps()).all()
+    sim.step(max_newton_iter=2)
+    assert torch.isfinite(sim.x).all()
