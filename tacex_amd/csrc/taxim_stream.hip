@@ -982,9 +982,9 @@ __global__ __launch_bounds__(1024) void stream_order_kernel(const int* __restric
   };
   for (int i = threadIdx.x; i < n_items; i += blockDim.x) atomicAdd(&hist[key_of(i)], 1);
   __syncthreads();
-  if (threadIdx.x == 0) {
+  if (threadIdx.x == 0) {  // keys never exceed 1 + seg_rows + 2 pad: the serial scan walks those alone (it was most of this kernel's 17 us)
     int acc = 0;
-    for (int k = kKeys - 1; k >= 0; --k) { start[k] = acc; acc += hist[k]; }
+    for (int k = min(kKeys - 1, seg_rows + 9); k >= 0; --k) { start[k] = acc; acc += hist[k]; }
   }
   __syncthreads();
   for (int i = threadIdx.x; i < n_items; i += blockDim.x) order[atomicAdd(&start[key_of(i)], 1)] = i;
