@@ -66,8 +66,9 @@ def parse():
     ap.add_argument("--obs-dtype", choices=["u8", "f32"], default="u8",
                     help="dtype of the 32x32x3 policy image in the gather payload (u8 = what a CNN policy consumes)")
     ap.add_argument("--sensor-streams", action="store_true",
-                    help="update the sensors of an env on one HIP stream each (+1.5 %% measured; off by default so that the per-kernel "
-                         "durations of a profile of this command stay those of kernels running alone)")
+                    help="update the sensors of an env on one HIP stream each (+3.3 %% measured in round 3: 660 K vs 638 K frames/s; off by "
+                         "default so that the per-kernel durations of a profile of this command stay those of kernels running alone - under "
+                         "overlap rocprofv3 reports 1084 us for a tail launch that takes 762 us alone)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-sweep", action="store_true", help="skip the C2 / 512-shard / C4 / C5 sweep (N = 1 only)")
@@ -415,6 +416,11 @@ def sweep(args, dev):
 
     run("C3 without the observation gather / pack (`--gather none`): 1024 envs x 2 sensors, RGB 320x240 + FOTS markers", args.envs_per_gpu, 240, 320,
         2, True, gather="none")
+    if not args.sensor_streams:
+        run("C3 with one HIP stream per sensor (`--sensor-streams`; the left / right finger sensors of an env are independent objects): the drain "
+            "and the small kernels of one sensor's update overlap the other's - NOT the default, because kernels that overlap have no "
+            "duration of their own for the roofline leg and a profile of the command to agree on", args.envs_per_gpu, 240, 320, 2, True,
+            sensor_streams=True)
     run("C3 DENSE CONTACT (data-independent floor: a wavy plate over the whole sensor - every frame, row and nearly every pixel in "
         "contact, so no zero band is skipped, no wave is flat and every table record is gathered): 1024 envs x 2 sensors, RGB 320x240 + "
         "FOTS markers", args.envs_per_gpu, 240, 320, 2, True, data="dense")
@@ -628,6 +634,9 @@ def main():
                 line["value_no_gather"] = ng["frames_per_s"]
             if dn:
                 line["value_dense_contact"] = dn["frames_per_s"]
+            ss = next((e for e in sw if "one HIP stream per sensor" in e.get("workload", "") and "frames_per_s" in e), None)
+            if ss:
+                line["value_sensor_streams"] = ss["frames_per_s"]
         if roofline is not None:
             line["roofline"] = roofline
         if cpu is not None:
