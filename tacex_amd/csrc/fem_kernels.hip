@@ -1258,16 +1258,18 @@ __global__ __launch_bounds__(kNwtThreads) void fem_newton_lds_kernel(FemDev m, d
   // a gather per coarse dof over its support, split over G threads with the partial sums added in a fixed order (deterministic,
   // no atomics); the sweep's LDS window is idle between two sweeps and carries r, the partial sums and the coarse vectors.
   const int nc3 = 3 * m.nc;
-  const int Gn = m.nc > 0 ? kNwtThreads / m.nc : 1;
-  const int H = nc3 > 0 ? kNwtThreads / nc3 : 1;
+  // Gn lanes per coarse NODE for the restriction, H lanes per coarse dof for the coarse solve: powers of two that divide a wave, so
+  // the partial sums of a node / dof sit in ONE wave and are added by a butterfly of lane exchanges - no LDS round trip, no barrier
+  // (a fixed tree: deterministic)
+  auto pow2_le = [](int v) { int p = 1; while (2 * p <= v && 2 * p <= 64) p *= 2; return p; };
+  const int Gn = m.nc > 0 ? pow2_le(kNwtThreads / m.nc) : 1;
+  const int H = nc3 > 0 ? pow2_le(kNwtThreads / nc3) : 1;
   const int Q = nc3 > 0 ? (nc3 + H - 1) / H : 0;
   auto apply_prec = [&](const double (&r)[3], double (&z)[3]) {
     double* rs = hv;                        // (V,3) residual
-    double* part_c = hv + 3 * V;            // (3 nc, Gn) partial sums
-    double* rc = part_c + 3 * kNwtThreads;  // (3 nc) restricted residual
-    double* yc = rc + 3 * kFemMaxCoarse;      // (3 nc) coarse correction
-    double* part_y = yc + 3 * kFemMaxCoarse;  // (3 nc, H) partial sums of the coarse solve
-    double* zs = part_y + kNwtThreads;        // (V,3) chain solve: y on the way down, z on the way back
+    double* rc = hv + 3 * V;                // (3 nc) restricted residual
+    double* yc = rc + 3 * kFemMaxCoarse;    // (3 nc) coarse correction
+    double* zs = yc + 3 * kFemMaxCoarse;    // (V,3) chain solve: y on the way down, z on the way back
     z[0] = z[1] = z[2] = 0.0;
     FEM_TICK(2);
     __syncthreads();  // every thread is done with the window of the last sweep
@@ -1321,48 +1323,37 @@ __global__ __launch_bounds__(kNwtThreads) void fem_newton_lds_kernel(FemDev m, d
       }
       return;
     }
-    {  // Gn threads per coarse NODE, all three components: one (vertex, weight) fetch serves three sums
+    {  // Gn lanes per coarse NODE, all three components: one (vertex, weight) fetch serves three sums
       const int node = tid / Gn, j = tid - node * Gn;
+      double a0 = 0.0, a1 = 0.0, a2 = 0.0;
       if (node < m.nc) {
-        double a0 = 0.0, a1 = 0.0, a2 = 0.0;
         const int e1 = m.cn_off[node + 1];
         for (int e = m.cn_off[node] + j; e < e1; e += Gn) {
           const int v0 = m.cn_vtx[e];
           const double w0 = m.cn_w[e];
           a0 += w0 * rs[v0 * 3]; a1 += w0 * rs[v0 * 3 + 1]; a2 += w0 * rs[v0 * 3 + 2];
         }
-        part_c[(node * 3 + 0) * Gn + j] = a0;
-        part_c[(node * 3 + 1) * Gn + j] = a1;
-        part_c[(node * 3 + 2) * Gn + j] = a2;
       }
-    }
-    __syncthreads();
-    FEM_TICK(4);
-    if (tid < nc3) {
-      double acc = 0.0;
-      for (int q = 0; q < Gn; ++q) acc += part_c[tid * Gn + q];
-      rc[tid] = acc;
+      for (int o = Gn >> 1; o > 0; o >>= 1) {  // (every lane of the wave takes part in the exchange)
+        a0 += __shfl_xor(a0, o, 64); a1 += __shfl_xor(a1, o, 64); a2 += __shfl_xor(a2, o, 64);
+      }
+      if (node < m.nc && j == 0) { rc[node * 3] = a0; rc[node * 3 + 1] = a1; rc[node * 3 + 2] = a2; }
     }
     __syncthreads();
     FEM_TICK(5);
-    {  // coarse solve y = A_c^-1 r_c: H threads per row, each over a slice of its (contiguous) row; the partial sums are
-       // added in a fixed order.  The chain solves run beside it on the threads it leaves idle (chains are dealt from the top).
+    {  // coarse solve y = A_c^-1 r_c: H lanes per row, each over a slice of its (contiguous) row.  The chain solves run beside it
+       // on the threads it leaves idle (chains are dealt from the top).
       const int dof = tid / H, h = tid - dof * H;
+      double acc = 0.0;
       if (dof < nc3) {
         const double* row = m.ac_inv + (size_t)dof * nc3;
         const int q1 = min(nc3, (h + 1) * Q);
-        double acc = 0.0;
         for (int q = h * Q; q < q1; ++q) acc += row[q] * rc[q];
-        part_y[tid] = acc;
       }
+      for (int o = H >> 1; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+      if (dof < nc3 && h == 0) yc[dof] = acc;
     }
     chain_solve();
-    __syncthreads();
-    if (tid < nc3) {
-      double acc = 0.0;
-      for (int h = 0; h < H; ++h) acc += part_y[tid * H + h];
-      yc[tid] = acc;
-    }
     __syncthreads();
     FEM_TICK(6);
     if (own) {
