@@ -111,13 +111,23 @@ __global__ __launch_bounds__(1024) void frame_rows_kernel(
   __shared__ float bc[2];
   const int b = blockIdx.x;
   const size_t fo = (size_t)b * H * W;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int w4 = W >> 2;
-  for (int r = wave; r < H; r += nw) {
+  // The frame is walked as ONE run of float4s (thread t takes t, t + 1024, ...): every lane of every load is busy (a wave per
+  // row left 48 of 128 lane slots idle at W = 320) and the iterations are independent, so several loads are in flight per
+  // thread.  Row minima through LDS integer atomics on the float pattern (heights are >= 0 or +inf: the patterns order like
+  // the values; a minimum does not depend on the order of its operands, so the result is the same bits as before).
+  int* rowmin_i = reinterpret_cast<int*>(rowmin);
+  for (int r = threadIdx.x; r < H; r += blockDim.x) rowmin_i[r] = 0x7f800000;  // +inf
+  __syncthreads();
+  const int n4 = H * w4;
+#pragma unroll 2
+  for (int base = 0; base < n4; base += blockDim.x) {  // (wave-uniform trip count: the wave reductions below need every lane)
+    const int q = base + threadIdx.x;
+    const bool valid = q < n4;
     float m = INFINITY;
-    const size_t ro = fo + (size_t)r * W;
-    for (int c = lane; c < w4; c += 64) {
-      v4f v = reinterpret_cast<const v4f*>(in + ro)[c];
+    if (valid) {
+      v4f v = reinterpret_cast<const v4f*>(in + fo)[q];
       if (FROM_DEPTH) {
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
@@ -125,20 +135,32 @@ __global__ __launch_bounds__(1024) void frame_rows_kernel(
           d = isinf(d) ? far_m : d;  // GS:585-588
           v[k] = d * 1000.0f;        // GS:590
         }
-        reinterpret_cast<v4f*>(hm_out + ro)[c] = v;
+        reinterpret_cast<v4f*>(hm_out + fo)[q] = v;
         if (cam_u8) {  // GS:573-575 (see frame_min_kernel)
           uchar4 u;
           u.x = (uint8_t)(((v[0] - nmm) / fmm) * 255.0f);
           u.y = (uint8_t)(((v[1] - nmm) / fmm) * 255.0f);
           u.z = (uint8_t)(((v[2] - nmm) / fmm) * 255.0f);
           u.w = (uint8_t)(((v[3] - nmm) / fmm) * 255.0f);
-          reinterpret_cast<uchar4*>(cam_u8 + ro)[c] = u;
+          reinterpret_cast<uchar4*>(cam_u8 + fo)[q] = u;
         }
       }
-      m = fminf(m, fminf(fminf(v[0], v[1]), fminf(v[2], v[3])));
+      m = fminf(fminf(v[0], v[1]), fminf(v[2], v[3]));
     }
-    m = wave_min(m);
-    if (lane == 0) rowmin[r] = m;
+    // a wave's 64 consecutive float4s lie in at most two rows when a row has >= 64 of them (a few otherwise): reduce inside the
+    // wave per row first, one atomic per row and wave
+    const int q0 = base + (threadIdx.x & ~63);
+    if (q0 < n4) {
+      const int r = valid ? q / w4 : -1;
+      const int r_first = q0 / w4, r_last = min(q0 + 63, n4 - 1) / w4;
+      for (int rr = r_first; rr <= r_last; ++rr) {
+        const float mr = wave_min(r == rr ? m : INFINITY);
+        if (lane == 0) {
+          if (mr >= 0.0f) atomicMin(&rowmin_i[rr], __float_as_int(mr + 0.0f));  // (+ 0: a -0 must not pass for INT_MIN)
+          else atomicMax(reinterpret_cast<unsigned*>(&rowmin_i[rr]), __float_as_uint(mr));
+        }
+      }
+    }
   }
   __syncthreads();
   if (wave == 0) {
