@@ -337,16 +337,17 @@ __global__ __launch_bounds__(64 * kStreamWaves, MINW) void taxim_stream_kernel(S
   // background of one row: 12 bytes per pixel straight into the lane that owns the pixel.  (Staging the row through LDS as
   // contiguous 16-byte pieces cut the L1 tag look-ups by 40 % but added four LDS round trips to the dependency chain of every
   // row: measured slower; perfectly linear 768-byte loads + stores gain at most 10 %)
-  unsigned xc[PX];
+  unsigned xc[PX];  // BYTE offset of the pixel's (clamped) column inside an RGB / background row: row * W * 12 is wave-uniform (scalar
+                    // unit), so an address costs one v_add instead of v_add + v_mul_lo (2/3 rate) per pixel slot, load and store
 #pragma unroll
-  for (int i = 0; i < PX; ++i) xc[i] = (unsigned)min(max(xg[i], 0), W - 1);
+  for (int i = 0; i < PX; ++i) xc[i] = (unsigned)min(max(xg[i], 0), W - 1) * 12u;
   auto load_bg = [&](int row, v3f (&q)[PX]) {
 #ifdef TACEX_DBG_NO_BG
     if (row >= 0) return;
 #endif
 #pragma unroll
     for (int i = 0; i < PX; ++i)
-      q[i] = *reinterpret_cast<const v3f*>(reinterpret_cast<const char*>(a.sh.bg) + ((unsigned)row * (unsigned)W + xc[i]) * 12u);
+      q[i] = *reinterpret_cast<const v3f*>(reinterpret_cast<const char*>(a.sh.bg) + ((unsigned)row * (unsigned)W * 12u + xc[i]));
   };
   v3f bgq[PX] = {(v3f)(0.0f), (v3f)(0.0f), (v3f)(0.0f)};   // background of the row shaded in the current iteration
 
@@ -461,7 +462,7 @@ __global__ __launch_bounds__(64 * kStreamWaves, MINW) void taxim_stream_kernel(S
 #else
       if (valid[i])
 #endif
-        *reinterpret_cast<v3f*>(reinterpret_cast<char*>(a.sh.rgb + fo * 3) + ((unsigned)e * (unsigned)W + xc[i]) * 12u) =
+        *reinterpret_cast<v3f*>(reinterpret_cast<char*>(a.sh.rgb + fo * 3) + ((unsigned)e * (unsigned)W * 12u + xc[i])) =
             (v3f){rgb[3 * i], rgb[3 * i + 1], rgb[3 * i + 2]};
     }
     if (do_obs) {
