@@ -339,6 +339,7 @@ __global__ __launch_bounds__(64 * kStreamWaves, MINW) void taxim_stream_kernel(S
   // row: measured slower; perfectly linear 768-byte loads + stores gain at most 10 %)
   unsigned xc[PX];  // BYTE offset of the pixel's (clamped) column inside an RGB / background row: row * W * 12 is wave-uniform (scalar
                     // unit), so an address costs one v_add instead of v_add + v_mul_lo (2/3 rate) per pixel slot, load and store
+                    // (nine v_mul_lo fewer per row; the kernel time did not move: 774-788 vs 783-789 us alternating on one box)
 #pragma unroll
   for (int i = 0; i < PX; ++i) xc[i] = (unsigned)min(max(xg[i], 0), W - 1) * 12u;
   auto load_bg = [&](int row, v3f (&q)[PX]) {
@@ -466,6 +467,8 @@ __global__ __launch_bounds__(64 * kStreamWaves, MINW) void taxim_stream_kernel(S
             (v3f){rgb[3 * i], rgb[3 * i + 1], rgb[3 * i + 2]};
     }
     if (do_obs) {
+      // (An `if` instead of this loop - at most one observation row retires per frame row - spares 26 register copies per row
+      //  in the ISA and measured 3.3 % SLOWER, 813 vs 787 us alternating on one box: left as it is.)
       while (cur_o0 < ri.o0) {  // the oldest observation row in flight got its last frame row: reduce it horizontally
         obs_flush(OA[0], cur_o0);
 #pragma unroll
