@@ -405,8 +405,8 @@ def sweep(args, dev):
                 tot = (fem.info_sum - base[0]).cpu().numpy()
                 e["fem_period"] = {"steps": steps, "newton_iters_per_step_mean": round(float(tot[0]) / steps, 2),
                                    "pcg_iters_per_newton_mean": round(float(tot[3]) / max(float(tot[0]), 1e-9), 1),
-                                   "note": "means over envs and over the timed window = one period of the indenter's breathing (21 steps: about half in "
-                                           "steady contact at ~1 ms, half in the release regime at 10-18 ms)"}
+                                   "note": "means over envs and over the timed window = one period of the indenter's motion (21 steps: about half "
+                                           "pressing at ~1 ms per step, half following the retreating indenter at 3-15 ms)"}
                 e["fem"] = fem_roofline(fem, (sum(ms) * steps / max(len(ms), 1), float(tot[0]), float(tot[3])))
             out.append(e)
             del rig

@@ -401,8 +401,8 @@ int tacex_fem_set_indenter_mesh(tacex_fem_ctx* ctx, int num_verts, const double*
 int tacex_fem_set_chains(tacex_fem_ctx* ctx, int num_chains, const int32_t* chain_offsets_host, const int32_t* chain_vertices_host);
 
 /* Device-side convergence for repeated Newton launches: dx_dev (num_envs,) f64 holds, per env, max |d| of the UNSCALED Newton
- * direction of its last iteration once that iteration was accepted at full length (no CCD truncation, no backtracking), and a
- * value above dx_tol otherwise (the caller fills it with +inf at the start of a time step); an env whose value is <= dx_tol
+ * direction of its last iteration - not of the update the CCD bound and the line search made of it (the caller fills it with
+ * +inf at the start of a time step); an env whose value is <= dx_tol
  * (= velocity_tol * dt, US:62-66) returns at once from the next tacex_fem_newton_step, so extra iterations cost nothing and
  * no host round trip is needed to stop them.  nullptr disables. */
 int tacex_fem_set_newton_early_exit(tacex_fem_ctx* ctx, double* dx_dev, double dx_tol);
@@ -418,7 +418,8 @@ int tacex_fem_newton_step(tacex_fem_ctx* ctx, double* x_dev, const double* x_til
 
 /* One backward-Euler time step of every env - what `world.advance()` does for the gelpad (US:250-252) - with NO host round trip:
  *   x_prev = x;  x_tilde = x + dt v + dt^2 gravity;  up to max_newton Newton iterations (as tacex_fem_newton_step), each env leaving
- *   the loop on the device once an iteration was accepted at full length and max |d| <= velocity_tol * dt (US:62-66);
+ *   the loop on the device once the UNSCALED Newton direction of an iteration has max |d| <= velocity_tol * dt (US:62-66; IPC's
+ *   test on the search direction, whatever the CCD bound and the line search made of the step);
  *   v = (x - x_prev) / dt.
  * x_dev, v_dev (B,V,3) f64 are updated in place, x_tilde_dev (B,V,3) is written.  With the CU-resident Newton kernel (meshes of
  * <= 512 vertices) the whole loop is ONE launch; the streaming fallback launches max_newton kernels on a fixed schedule in which

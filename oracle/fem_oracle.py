@@ -670,8 +670,8 @@ def newton_step_contact(m: "FemModel", cm: ContactModel, x, x_tilde, constrained
 def fem_step(m: "FemModel", cm, x, v, constrained=None, aim=None, gravity=(0.0, 0.0, -9.8), max_newton=8, velocity_tol=0.05,
              pcg_max_iter=1024, pcg_tol_rate=1e-3, ls_max_iter=8, coarse=None, friction=None, chains=None):
     """One backward-Euler step of ONE env the way `tacex_fem_step` runs it (what world.advance() does, US:250-252):
-    x_tilde = x + dt v + dt^2 g; Newton iterations until one is accepted at FULL length (no CCD truncation, no backtracking) with
-    max |d| <= velocity_tol * dt (US:62-66) or the cap; v = (x_new - x) / dt.  Returns (x_new, v_new, info) with
+    x_tilde = x + dt v + dt^2 g; Newton iterations until the UNSCALED Newton direction of one has max |d| <= velocity_tol * dt
+    (US:62-66; IPC's test on the search direction) or the cap; v = (x_new - x) / dt.  Returns (x_new, v_new, info) with
     info = [newton_iterations, max |d| of the last iteration, flags (2: a line search failed), pcg_iterations_total]."""
     x0 = x
     xt = x + m.dt * v + m.dt**2 * np.asarray(gravity, np.float64)
@@ -689,9 +689,9 @@ def fem_step(m: "FemModel", cm, x, v, constrained=None, aim=None, gravity=(0.0, 
         n += 1
         pcg += int(st[3])
         dmax = st[4]
-        if st[2] == 0.0:
+        if st[2] == 0.0 and not dmax <= velocity_tol * m.dt:
             flags |= 2
-        if st[2] == 1.0 and st[5] == 1.0 and dmax <= velocity_tol * m.dt:
+        if dmax <= velocity_tol * m.dt:  # IPC's test: the unscaled search direction, whatever the CCD bound / line search made of the step
             if fric_pending:  # normal contact is balanced: take the friction lag from here and go on
                 fric_pending = False
                 fr = FrictionModel(cm, x0, friction[2], friction[0], friction[1])

@@ -844,7 +844,7 @@ __global__ __launch_bounds__(512) void fem_newton_kernel(FemDev m, double* xg, c
     if (threadIdx.x == 0) {
       double v = 0.0;
       for (int w = 0; w < (int)(blockDim.x >> 6); ++w) v = fmax(v, sh[w]);
-      dxg[b] = (accepted && step == 1.0 && v <= dx_tol) ? v : fmax(v, 2.0 * dx_tol);
+      dxg[b] = v;  // max |d| of the unscaled direction: <= dx_tol = converged (same rule as the CU-resident kernel)
     }
   }
   if (threadIdx.x == 0) {
@@ -942,10 +942,9 @@ constexpr int kFemFlagPenetration = 1;  // a contact vertex was at or beyond the
 constexpr int kFemFlagLsFailed = 2;     // a line search found no decrease even after the rescue halvings
 
 // One launch = up to `max_newton` Newton iterations of every env (tacex_fem_step: the whole Newton loop of world.advance(),
-// US:250-252, without a host round trip; tacex_fem_newton_step: max_newton = 1).  An env leaves the loop when an iteration was
-// accepted at full length (no CCD truncation, no backtracking) and its Newton direction moved no vertex by more than dx_tol
-// (velocity_tol * dt, US:62-66) - the criterion looks at the UNSCALED direction: a CCD- or search-shortened update says nothing
-// about convergence.
+// US:250-252, without a host round trip; tacex_fem_newton_step: max_newton = 1).  An env leaves the loop when the Newton
+// direction of an iteration moves no vertex by more than dx_tol (velocity_tol * dt, US:62-66) - the criterion looks at the UNSCALED
+// direction (IPC's test on the search direction): a CCD- or search-shortened update says nothing about convergence.
 template <bool MESH>
 __global__ __launch_bounds__(kNwtThreads) void fem_newton_lds_kernel(FemDev m, double* xg, const double* xtg,
                                                                      const uint8_t* consg, const double* aimg, double* stats,
@@ -1507,7 +1506,7 @@ __global__ __launch_bounds__(kNwtThreads) void fem_newton_lds_kernel(FemDev m, d
     }
   } else {
     step = 0.0;
-    flags |= kFemFlagLsFailed;
+    if (!(dmax <= dx_tol)) flags |= kFemFlagLsFailed;  // (no decrease to be had at a point whose Newton step is below the tolerance: converged)
   }
   ++n_newton;
   pcg_total += (double)it;
@@ -1521,7 +1520,11 @@ __global__ __launch_bounds__(kNwtThreads) void fem_newton_lds_kernel(FemDev m, d
     for (int k = 0; k < 4; ++k) stats[(size_t)b * 4 + k] = fclk[4 * (TACEX_FEM_CLOCK) + k];
 #endif
   }
-  const bool converged = accepted && step == 1.0 && step0 == 1.0 && dmax <= dx_tol;
+  // IPC's test (Li et al. 2020, Algorithm 1: the infinity norm of the SEARCH DIRECTION over dt against the velocity tolerance): the
+  // unscaled Newton direction, whatever the CCD bound and the line search then made of the step - a shortened UPDATE says nothing
+  // about convergence, a short DIRECTION does.  (Rounds 2-3 also demanded a full-length accepted step: at the edge of
+  // the barrier zone that never happens and every retreat step ran to the iteration cap with directions 5x below the tolerance.)
+  const bool converged = dmax <= dx_tol;
   if (converged) {  // wave-uniform: every quantity above is a block reduction
     if (fric && !fric_phase) {
       // normal contact is balanced: freeze the friction lag (normal force, normal) at this state and go on, unless no vertex of
@@ -1546,7 +1549,7 @@ __global__ __launch_bounds__(kNwtThreads) void fem_newton_lds_kernel(FemDev m, d
   }
   // what the next launch (tacex_fem_newton_step called in a loop) reads to skip this env: the direction's max |d| once the env
   // has converged (<= dx_tol), a value above the tolerance while it has not (a shortened update must not count as convergence)
-  if (dxg && tid == 0) dxg[b] = done ? dmax_last : fmax(dmax_last, 2.0 * dx_tol);
+  if (dxg && tid == 0) dxg[b] = dmax_last;
   if (step_info) {
     // (__syncthreads_or returns a truth value, not the OR of the bits: one reduction per flag)
     const int any = (__syncthreads_or(flags & kFemFlagPenetration) ? kFemFlagPenetration : 0) |

@@ -383,7 +383,7 @@ class UipcSim:
     def step(self, max_newton_iter: int | None = None):
         """One backward-Euler step for all envs - x_tilde = x + dt v + dt^2 g, Newton iterations, v = (x - x_n) / dt - as ONE C-ABI
         call (`tacex_fem_step`) that never touches the host: the Newton loop runs inside the kernel, every env leaves it on the
-        device once an iteration was accepted at full length with max |d| <= velocity_tol * dt (uipc_sim.py:62-66).  Iteration
+        device once the unscaled Newton direction of an iteration has max |d| <= velocity_tol * dt (uipc_sim.py:62-66).  Iteration
         counts and flags land in `self.step_info` (num_envs, 4) [newton_iterations, max |d|, flags, pcg_iterations]; reading
         `last_newton_iters` / `check_step()` is what synchronises, not the step."""
         n_max = self.cfg.newton.max_iter if max_newton_iter is None else int(max_newton_iter)

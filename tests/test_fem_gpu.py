@@ -503,8 +503,8 @@ def test_newton_step_c4_mesh_vs_oracle():
 def test_step_c4_vs_oracle_step_and_convergence_rule():
     """UipcSim.step() = ONE tacex_fem_step call (predictor, in-kernel Newton loop with device-side exit, velocity) against the
     oracle's fem_step over three time steps with a moving indenter: same iteration counts, positions, velocities.  The
-    convergence rule: an env may only leave the loop after an iteration accepted at FULL length - here the CCD filter
-    shortens the first iterations, which must not count as converged although their update is tiny."""
+    convergence rule: the test looks at the UNSCALED Newton direction - here the CCD filter shortens the first
+    iterations, which must not count as converged although their update is tiny."""
     from oracle.fem_oracle import fem_step
 
     B = 2
