@@ -440,3 +440,31 @@ def test_mesh_indenter_distance_known_answers_and_fd():
         e = np.zeros(3); e[k] = h
         fd = (contact_distance(ind2, x2 + e, (bv, bt))[0] - contact_distance(ind2, x2 - e, (bv, bt))[0]) / (2 * h)
         np.testing.assert_allclose(fd, n2[:, k], atol=1e-6)
+
+
+def test_fem_step_stops_on_the_unscaled_direction():
+    """IPC's convergence test (Li et al. 2020, Algorithm 1; US:62-66): fem_step leaves its Newton loop as soon as the UNSCALED search
+    direction has max |d| <= velocity_tol * dt - also when the CCD bound or the line search shortened the step - and never because
+    a shortened UPDATE happened to be small."""
+    from oracle.fem_oracle import ContactModel, contact_distance, fem_step
+    from tacex_amd.uipc.uipc_object import UipcObject, UipcObjectCfg, gelpad_box_mesh
+
+    P, T = gelpad_box_mesh(3, 4, 2)
+    m = FemModel.build(P, T, youngs=1e4, poisson=0.49, density=1e3, dt=0.01, strength=1000.0)
+    cons = (P[:, 2] < 1e-12).astype(np.float64)
+    area = UipcObject(UipcObjectCfg(mesh_points=P, mesh_tets=m.tets), None).surface_vertex_areas()
+    top, size = P[:, 2].max(), P.max(0)
+    ind = np.array([1.0, size[0] / 2, size[1] / 2, top + 0.004 + 0.0004, 0.004, 0, 0, 0])  # 0.4 mm above the pad: inside d_hat = 1 mm
+    cm = ContactModel(area, ind, 1e-3, 1e7, m.dt)
+    x0, v0 = P.copy(), np.zeros_like(P)
+    # loose tolerance: one iteration whose direction is already below it ends the step, although the barrier shortens that step
+    x1, _, info = fem_step(m, cm, x0, v0, cons, P, max_newton=20, velocity_tol=1.0, pcg_max_iter=400, pcg_tol_rate=1e-6)
+    assert info[0] == 1 and info[1] <= 1.0 * m.dt
+    # tight tolerance: the loop runs on until the DIRECTION is small; the iterate it ends with is (nearly) stationary
+    x2, _, info2 = fem_step(m, cm, x0, v0, cons, P, max_newton=60, velocity_tol=1e-4, pcg_max_iter=400, pcg_tol_rate=1e-8)
+    assert 1 < info2[0] < 60 and info2[1] <= 1e-4 * m.dt and info2[2] == 0
+    xt = x0 + m.dt**2 * np.array([0, 0, -9.8])
+    g = m.gradient(x2, xt, cons, P) + cm.gradient(x2)
+    g0 = m.gradient(x0, xt, cons, P) + cm.gradient(x0)
+    assert np.abs(g).max() <= 1e-3 * np.abs(g0).max()
+    assert contact_distance(cm.ind, x2)[0][area > 0].min() > 0.0
