@@ -22,4 +22,7 @@ for _ in range(3):
 torch.cuda.synchronize()
 st = sim.stats.cpu().numpy()
 names = ["sweep", "Hp+pHp sum", "update+BJ (first call: garbage)", "rs+2 syncs", "restrict+sync", "rc sum+sync", "coarse solve+sync", "prolong", "sweep: make+hv write", "sweep: barrier", "sweep: csr gather", "sweep: 2nd barrier"]
-print("group", g, {names[4 * g + k]: float(st[:, k].mean()) for k in range(4)})
+if g == 3:
+    print("group 3 (cycles per Newton iteration):", dict(zip(["gradient + contact", "block assembly + chain factor", "PCG (%d iterations)" % 10, "line search + update"], [float(st[:, k].mean()) for k in range(4)])))
+else:
+    print("group", g, {names[4 * g + k]: float(st[:, k].mean()) for k in range(4)})

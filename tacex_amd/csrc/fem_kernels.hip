@@ -1011,6 +1011,7 @@ __global__ __launch_bounds__(kNwtThreads) void fem_newton_lds_kernel(FemDev m, d
 
 #ifdef TACEX_FEM_CLOCK  // debug build: cycles (s_memtime) of the sections of a PCG iteration, group TACEX_FEM_CLOCK of four -> stats
   double fclk[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  double fnw[4] = {0, 0, 0, 0};  // group 3: phases of a Newton iteration [gradient, block assembly + factorisation, PCG, line search]
   long long ftk = 0;
 #define FEM_TICK(k) do { const long long now_ = __builtin_readcyclecounter(); fclk[k] += (double)(now_ - ftk); ftk = now_; } while (0)
 #define FEM_TICK0() do { ftk = __builtin_readcyclecounter(); } while (0)
@@ -1105,6 +1106,12 @@ __global__ __launch_bounds__(kNwtThreads) void fem_newton_lds_kernel(FemDev m, d
   bool fric_phase = false;  // friction terms are on (second phase of the loop, see friction_eval)
   for (int nit = 0; nit < max_newton; ++nit) {
   if (nit > 0) __syncthreads();  // xs carries the accepted candidate of the previous iteration
+#ifdef TACEX_FEM_CLOCK
+  long long fph = __builtin_readcyclecounter();
+#define FEM_PHASE(k) do { const long long n_ = __builtin_readcyclecounter(); fnw[k] += (double)(n_ - fph); fph = n_; } while (0)
+#else
+#define FEM_PHASE(k) do { } while (0)
+#endif
   // ---- nodal gradient ----
   double r3[3], d3[3] = {0, 0, 0};
   {
@@ -1145,6 +1152,7 @@ __global__ __launch_bounds__(kNwtThreads) void fem_newton_lds_kernel(FemDev m, d
 #pragma unroll
     for (int k = 0; k < 6; ++k) fh[tid * 6 + k] = (float)(dt2 * fe.h[k]);
   }
+  FEM_PHASE(0);
   // ---- block part of the preconditioner: block-tridiagonal LDL^T along vertex chains (tacex_fem_set_chains; a chain of one
   //      vertex = 3x3 block Jacobi).  Every vertex assembles its diagonal block D and the block E = A(v, next(v)) towards its
   //      chain successor (columns recomputed per incident tet), the blocks meet in LDS (the idle p / window region), and the
@@ -1368,6 +1376,7 @@ __global__ __launch_bounds__(kNwtThreads) void fem_newton_lds_kernel(FemDev m, d
     }
     FEM_TICK(7);
   };
+  FEM_PHASE(1);
   // ---- PCG ----
   // Stops when the preconditioned residual has dropped to tol_rate times that of the right-hand side (r^T M^-1 r against
   // b^T M^-1 b; the same test as before for a zero start).  WARM START: when the previous iteration's step was cut short (CCD
@@ -1469,6 +1478,7 @@ __global__ __launch_bounds__(kNwtThreads) void fem_newton_lds_kernel(FemDev m, d
     rz = rz_new;
     ++it;
   }
+  FEM_PHASE(2);
   // ---- backtracking line search on the incremental potential (accept the first E(x + step d) <= E(x)) ----
   const double E0 = env_energy_lds<MESH>(m, xs, x3, xt, own, c, aim, sh, phase, ind, wv, fric_phase ? fl : nullptr, xn, disp3);
   double step = 1.0, E1 = E0;
@@ -1508,6 +1518,7 @@ __global__ __launch_bounds__(kNwtThreads) void fem_newton_lds_kernel(FemDev m, d
     step = 0.0;
     if (!(dmax <= dx_tol)) flags |= kFemFlagLsFailed;  // (no decrease to be had at a point whose Newton step is below the tolerance: converged)
   }
+  FEM_PHASE(3);
   ++n_newton;
   pcg_total += (double)it;
   dmax_last = dmax;
@@ -1517,7 +1528,7 @@ __global__ __launch_bounds__(kNwtThreads) void fem_newton_lds_kernel(FemDev m, d
   if (tid == 0) {
     stats[(size_t)b * 4 + 0] = E0; stats[(size_t)b * 4 + 1] = E1; stats[(size_t)b * 4 + 2] = step; stats[(size_t)b * 4 + 3] = (double)it;
 #ifdef TACEX_FEM_CLOCK
-    for (int k = 0; k < 4; ++k) stats[(size_t)b * 4 + k] = fclk[4 * (TACEX_FEM_CLOCK) + k];
+    for (int k = 0; k < 4; ++k) stats[(size_t)b * 4 + k] = (TACEX_FEM_CLOCK) == 3 ? fnw[k] : fclk[4 * ((TACEX_FEM_CLOCK) % 3) + k];
 #endif
   }
   // IPC's test (Li et al. 2020, Algorithm 1: the infinity norm of the SEARCH DIRECTION over dt against the velocity tolerance): the
