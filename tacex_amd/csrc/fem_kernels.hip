@@ -19,6 +19,7 @@
 #include <math.h>
 #include <stdint.h>
 #include <stdlib.h>
+#include <string.h>
 
 #include <algorithm>
 #include <vector>
@@ -33,6 +34,8 @@ struct FemDev {
   const int* tets;        // (4,T) SoA
   const double* dminv;    // (9,T) SoA, row-major 3x3 per tet
   const double* vol;      // (T)
+  const double* tet_rec;  // (T,12) AoS copy of one tet: vertex ids (4 ints in the first two doubles) | dminv (9) | vol - for loops that visit
+                          // tets in VERTEX order (every lane another tet): six 16-byte loads per tet instead of 14 scattered ones; nullable
   const double* mass;     // (V)
   const int* vt_off;      // (V+1) CSR vertex -> incident (tet*4 + local)
   const int* vt_idx;
@@ -285,6 +288,16 @@ struct TetState {
   double a, b, c;   // coefficients above
   double Ic, J;
 };
+
+// the same through the AoS record (see FemDev::tet_rec); also returns the volume
+__device__ __forceinline__ void load_tet_rec(const FemDev& m, int t, int v[4], double Di[9], double& vol) {
+  typedef double v2d __attribute__((ext_vector_type(2)));
+  const v2d* q = reinterpret_cast<const v2d*>(m.tet_rec + (size_t)t * 12);
+  const v2d q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3], q4 = q[4], q5 = q[5];
+  v[0] = __double2loint(q0.x); v[1] = __double2hiint(q0.x); v[2] = __double2loint(q0.y); v[3] = __double2hiint(q0.y);
+  Di[0] = q1.x; Di[1] = q1.y; Di[2] = q2.x; Di[3] = q2.y; Di[4] = q3.x; Di[5] = q3.y; Di[6] = q4.x; Di[7] = q4.y; Di[8] = q5.x;
+  vol = q5.y;
+}
 
 __device__ __forceinline__ void load_tet(const FemDev& m, int t, int v[4], double Di[9]) {
 #pragma unroll
@@ -1176,13 +1189,13 @@ __global__ __launch_bounds__(kNwtThreads) void fem_newton_lds_kernel(FemDev m, d
         const int code = csr[e];
         const int t = code >> 2, l = code & 3;
         int v[4];
-        double Di[9], F[9], r[12];
-        load_tet(m, t, v, Di);
+        double Di[9], F[9], r[12], vol_t;
+        load_tet_rec(m, t, v, Di, vol_t);  // (vertex order: every lane another tet - the AoS record, not 14 scattered SoA loads)
         deformation_gradient(xs, v, Di, F);
         TetState s;
         tet_state(m, F, s);
         shape_rows(Di, r);
-        const double sc = dt2 * m.vol[t];
+        const double sc = dt2 * vol_t;
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
           double dF[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, dP[9];
@@ -1765,9 +1778,17 @@ int tacex_fem_create(int device_id, const tacex_fem_params* p, tacex_fem_ctx** o
     std::vector<int> cur(off.begin(), off.end() - 1);
     for (int n = 0; n < T; ++n)
       for (int k = 0; k < 4; ++k) idx2[cur[tets2[(size_t)k * T + n]]++] = n * 4 + k;
+    std::vector<double> rec2((size_t)12 * T);
+    for (int n = 0; n < T; ++n) {
+      int ids[4];
+      for (int k = 0; k < 4; ++k) ids[k] = tets2[(size_t)k * T + n];
+      memcpy(&rec2[(size_t)n * 12], ids, sizeof(ids));  // 4 ints = the first two doubles of the record
+      for (int k = 0; k < 9; ++k) rec2[(size_t)n * 12 + 2 + k] = dminv2[(size_t)k * T + n];
+      rec2[(size_t)n * 12 + 11] = vol2[n];
+    }
     c->dev_nwt = d;
     rc = fem_upload(c, tets2, &c->dev_nwt.tets) | fem_upload(c, dminv2, &c->dev_nwt.dminv) | fem_upload(c, vol2, &c->dev_nwt.vol) |
-         fem_upload(c, idx2, &c->dev_nwt.vt_idx);
+         fem_upload(c, idx2, &c->dev_nwt.vt_idx) | fem_upload(c, rec2, &c->dev_nwt.tet_rec);
   }
   if (rc) { tacex_fem_destroy(c); return rc; }
   const double mu_l = p->youngs / (2.0 * (1.0 + p->poisson));
