@@ -255,8 +255,19 @@ static hipError_t launch_mfma_tiles(BlurArgs a, int row0, int nbands, hipStream_
 // Band height: NTILE = 1 (16 rows).  Taller bands (NTILE = 2 / 3, shared V-pass loads: 3x / 2.3x instead of 5x L2 -> L1
 // read amplification at k = 61) are supported by the kernel and were measured 3-8 % SLOWER at 256 x 320x240 (fewer,
 // longer workgroups per CU), so only NTILE = 1 is instantiated.  a.gel == nullptr selects the all-zero-gel variant.
+#ifndef TACEX_MFMA_NT117
+#define TACEX_MFMA_NT117 1  // A/B: band height (16-row tiles) of the k = 117 level (640x480: 9x L2 -> L1 read amplification at 1, 5x at 2)
+#endif
+#ifndef TACEX_MFMA_NT61
+#define TACEX_MFMA_NT61 1
+#endif
 template <int K, bool FIRST>
 static hipError_t launch_mfma(const BlurArgs& a, hipStream_t st) {
+  constexpr int NT = K == 117 ? TACEX_MFMA_NT117 : (K == 61 ? TACEX_MFMA_NT61 : 1);
+  if (NT > 1 && a.H % (16 * NT) == 0 && a.W > 320) {  // (taller bands only where the window is many times the band: the 640-wide levels)
+    if (a.gel == nullptr) return launch_mfma_tiles<K, FIRST, NT, true>(a, 0, a.H / (16 * NT), st);
+    return launch_mfma_tiles<K, FIRST, NT, false>(a, 0, a.H / (16 * NT), st);
+  }
   if (a.gel == nullptr) return launch_mfma_tiles<K, FIRST, 1, true>(a, 0, a.H / 16, st);
   return launch_mfma_tiles<K, FIRST, 1, false>(a, 0, a.H / 16, st);
 }
