@@ -47,7 +47,13 @@ __global__ __launch_bounds__(640) void blur_mfma_kernel(BlurArgs a) {
   constexpr int TH = 16 * NTILE;
   constexpr int R = (K - 1) / 2, RA = (R + 7) & ~7, WIN = 16 + 2 * RA, KS = WIN / 4;
   constexpr int KU = KS + 4 * (NTILE - 1);  // k-steps over the union window of the band's tiles
-  constexpr int CH = TACEX_MFMA_CH, NCH = KU / CH;      // k-steps per software-pipeline chunk
+#ifndef TACEX_MFMA_CH61
+#define TACEX_MFMA_CH61 TACEX_MFMA_CH
+#endif
+#ifndef TACEX_MFMA_CH117
+#define TACEX_MFMA_CH117 TACEX_MFMA_CH
+#endif
+  constexpr int CH = K == 61 ? TACEX_MFMA_CH61 : (K == 117 ? TACEX_MFMA_CH117 : TACEX_MFMA_CH), NCH = KU / CH;  // k-steps per software-pipeline chunk
   static_assert(KU % CH == 0 && KS % 4 == 0, "window");
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   float* mid = reinterpret_cast<float*>(smem_raw);  // TH x pitch, columns padded by RA on both sides
