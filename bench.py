@@ -176,6 +176,8 @@ class Rig:
     def finish(self):
         if self.obs is not None:
             self.obs.wait()  # the last step's collective is part of the timed region
+        if self.fem is not None:
+            self.fem.flush()  # the last step's hipEvent pair joins ms_log: entry k of the log IS step k
 
     def timed(self, steps, warmup, barrier=lambda: None, after_warmup=lambda: None):
         for i in range(warmup):
@@ -329,22 +331,28 @@ def roofline_leg(rig, markers):
     flops_per_frame = 2 * sum(kw + kh for kw, kh in zip(tb.ksize_w, tb.ksize_h)) * N + 100 * N
     # SURVEY 8(d) figure for the dominant kernel: 16 B/px (read height map + write RGB) x frames per launch
     survey_gbs = 16 * N * stages[dom]["frames_per_launch"] / (stages[dom]["avg_ms"] * 1e-3) / 1e9
+    # `achieved` / `frac` follow SURVEY 8(d) to the letter: ALGORITHMIC bytes = 16 B/px (read the height map, write RGB) x the pixels
+    # one launch of the dominant kernel processes, divided by that kernel's hipEvent-measured average launch duration.  The kernel's
+    # OWN reads + writes (20 B/px for the fused tail: it also reads the previous pyramid level) are kept beside it as *_own_bytes.
     roof = {
-        "bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-        "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
+        "bound": "hbm", "kernel": dom, "achieved": round(survey_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        "frac": round(survey_gbs / HBM_PEAK_GBS, 4), "traffic": None,
         "frames_per_launch": stages[dom]["frames_per_launch"],
-        "achieved_survey_16B_per_px": round(survey_gbs, 1), "frac_survey_16B_per_px": round(survey_gbs / HBM_PEAK_GBS, 4),
+        "kernel_avg_ms": stages[dom]["avg_ms"],
+        "algorithmic_bytes_per_launch": 16 * N * stages[dom]["frames_per_launch"],
+        "achieved_own_bytes": ach, "frac_own_bytes": round(ach / HBM_PEAK_GBS, 4),
         "pipeline_achieved": round(pipeline_gbs, 1), "pipeline_frac": round(pipeline_gbs / HBM_PEAK_GBS, 4),
         "valu_frac": round(flops_per_frame * B / (taxim_ms * 1e-3) / 1e12 / FP32_PEAK_TFLOPS, 4),
         "stages": stages,
-        "note": "achieved = algorithmic bytes of the dominant kernel per launch (its own reads + writes, DESIGN.md section 4) / its "
-                "hipEvent-measured duration; *_survey_16B_per_px = SURVEY 8(d)'s 16 B/px x frames per launch / the same duration; "
-                "pipeline_* = 16 B/px compulsory bytes of the whole Taxim path / sum of its kernels; valu_frac = algorithmic fp32 "
-                "flops / 157.3 TFLOP/s (the separable blur is VALU-heavy)",
+        "note": "achieved = SURVEY 8(d)'s 16 B/px x the pixels of one launch of the dominant kernel / its hipEvent-measured average "
+                "duration (frac = achieved / 8 TB/s; reproduces from profiles/r04_c3_kernel_stats.csv: 16 x 76800 x 1024 B / the tail's "
+                "average duration); *_own_bytes = the same with the kernel's own reads + writes (DESIGN.md section 4); pipeline_* = "
+                "16 B/px of the whole Taxim path / sum of its kernels; valu_frac = algorithmic fp32 flops / 157.3 TFLOP/s (the "
+                "separable blur is VALU-heavy)",
     }
     # HBM bytes of the dominant kernel per launch from the PMC passes (FETCH_SIZE x2 + WRITE_SIZE, separate `rocprofv3 --pmc` runs,
     # committed under profiles/ - counters cannot be read live from inside the process, so this is a build-time constant)
-    for cand in ("pmc_traffic_r03.json", "pmc_traffic_r02.json", "pmc_traffic.json"):
+    for cand in ("pmc_traffic_r04.json", "pmc_traffic_r03.json", "pmc_traffic_r02.json", "pmc_traffic.json"):
         pmc = REPO / "profiles" / cand
         if pmc.exists() and (H, W) == (240, 320):
             try:
@@ -394,7 +402,8 @@ def sweep(args, dev):
             if fem is not None:
                 # split: the FEM part alone (hipEvents around attachments + UipcSim.step), MEAN over the timed steps - the Newton
                 # / PCG iteration counts vary from step to step with the indenter's breathing
-                ms = fem.ms_log[24:] or fem.ms_log
+                ms = fem.ms_log[24:] or fem.ms_log  # steps 24 .. 44: exactly the timed period (Rig.finish flushes the last pair)
+                assert len(fem.ms_log) <= 24 or len(ms) == steps, (len(fem.ms_log), steps)
                 e["fem_ms_mean"] = round(sum(ms) / max(len(ms), 1), 3)
                 e["fem_ms_min_max"] = [round(min(ms), 3), round(max(ms), 3)] if ms else None
                 si = fem.sim.check_step(raise_on_penetration=False)
@@ -402,6 +411,13 @@ def sweep(args, dev):
                                       "pcg_iters_per_newton_mean": round(float((si["pcg_iters"] / np.maximum(si["newton_iters"], 1)).mean()), 1),
                                       "envs_flagged_penetration": int(len(si["penetrating_envs"])),
                                       "envs_flagged_line_search": int(len(si["line_search_failed_envs"]))}
+                # the scene caps Newton at FemGelpad.max_newton_iter where the reference's default is 1024 (uipc_sim.py Newton.max_iter): the
+                # measured rate only stands if NO env of NO logged step ran into the cap
+                e["newton_cap"] = int(fem.max_newton_iter)
+                e["newton_iters_max_over_period"] = int(fem.iters_max) if fem.iters_max is not None else None
+                e["newton_cap_hit"] = bool(e["newton_iters_max_over_period"] is not None and e["newton_iters_max_over_period"] >= fem.max_newton_iter)
+                assert not e["newton_cap_hit"] or os.environ.get("TACEX_BENCH_ALLOW_NEWTON_CAP"), \
+                    f"an env ran into the Newton cap of {fem.max_newton_iter} iterations: the FEM rate would be measured on truncated solves"
                 tot = (fem.info_sum - base[0]).cpu().numpy()
                 e["fem_period"] = {"steps": steps, "newton_iters_per_step_mean": round(float(tot[0]) / steps, 2),
                                    "pcg_iters_per_newton_mean": round(float(tot[3]) / max(float(tot[0]), 1e-9), 1),

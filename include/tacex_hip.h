@@ -358,7 +358,8 @@ int tacex_fem_gradient(tacex_fem_ctx* ctx, const double* x_dev, const double* x_
  *                    (copied once; NULL keeps the previous table);
  *   indenters_dev (num_envs, 8) f64 [kind, cx, cy, cz, radius, nx, ny, nz]: kind 0 none, 1 sphere, 2 half-space (unit
  *                    normal n through c), 3 capsule (radius around the segment c -+ (nx, ny, nz): the vector is HALF the
- *                    axis); read by every later compute call until replaced; NULL disables contact. */
+ *                    axis); read by every later compute call until replaced; NULL disables contact.
+ * Replaced tables are freed by the setter (it drains the device first: a set-up call, not a step-path call). */
 int tacex_fem_set_contact(tacex_fem_ctx* ctx, const double* vertex_area_host, double d_hat, double stiffness,
                           const double* indenters_dev);
 
@@ -366,7 +367,11 @@ int tacex_fem_set_contact(tacex_fem_ctx* ctx, const double* vertex_area_host, do
  * eps_velocity), the IPC way (Li et al. 2020, eq. 18-20) with normal force and contact normal lagged per Newton iteration; the
  * tangential sliding is measured from the positions the time step starts at and relative to the indenter's own displacement
  * since the previous tacex_fem_step (its positions are kept in the workspace), potential mu lam f0(|u|) smoothed below
- * eps_velocity * dt.
+ * eps_velocity * dt.  The displacement is the TRANSLATION of the indenter row (cx, cy, cz) between two steps: the caller may move
+ * an indenter by mutating the rows in place or by handing a new indenters_dev to tacex_fem_set_contact every step (the previous
+ * positions survive that call; they are reset when contact is disabled, enabled for the first time, or when tacex_fem_step runs
+ * with another workspace / num_envs).  A ROTATION of a capsule or mesh indenter (kinds 3 / 4: the last three row entries) between
+ * two steps is not part of the displacement - a spinning indenter drags the pad as if it only translated.
  * Acts inside tacex_fem_step only (tacex_fem_newton_step has no notion of the step's start).  friction_ratio 0 = off. */
 int tacex_fem_set_friction(tacex_fem_ctx* ctx, double friction_ratio, double eps_velocity);
 

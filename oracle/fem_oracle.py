@@ -691,6 +691,7 @@ def fem_step(m: "FemModel", cm, x, v, constrained=None, aim=None, gravity=(0.0, 
         dmax = st[4]
         if st[2] == 0.0 and not dmax <= velocity_tol * m.dt:
             flags |= 2
+            break  # a rejected search leaves x and the warm start unchanged: every further iteration would repeat this one
         if dmax <= velocity_tol * m.dt:  # IPC's test: the unscaled search direction, whatever the CCD bound / line search made of the step
             if fric_pending:  # normal contact is balanced: take the friction lag from here and go on
                 fric_pending = False

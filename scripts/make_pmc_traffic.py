@@ -5,7 +5,7 @@ On the GPU box (scripts/gpu_round.sh <tag> pmc does exactly this):
     cd /tmp && export TMPDIR=/tmp
     rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 $REPO/bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-sweep --no-roofline
     rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 $REPO/bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-sweep --no-roofline
-then (anywhere):  python scripts/make_pmc_traffic.py <pmc_fetch dir> <pmc_write dir> <out.json> [frames_per_tail_launch=1024] [H=240] [W=320] [commit] [frames_per_shard]
+then (anywhere):  python scripts/make_pmc_traffic.py <pmc_fetch dir> <pmc_write dir> <out.json> [frames_per_tail_launch=0: from the tail's WRITE_SIZE] [H=240] [W=320] [commit] [frames_per_shard]
 """
 import csv, glob, json, os, sys
 from collections import defaultdict
@@ -19,11 +19,34 @@ STAGES = {  # kernel-name substring -> bench.py stage name
     "frame_rows_kernel<true>": "frame_min_from_depth", "frame_rows_kernel<false>": "frame_min",
     "taxim_stream_kernel": "tail_fused", "taxim_tail_kernel": "tail_fused_tiled",
 }
-FRAMES = int(sys.argv[4]) if len(sys.argv) > 4 else 1024
+FRAMES = int(sys.argv[4]) if len(sys.argv) > 4 else 0  # 0 = derive from the tail's own WRITE_SIZE (12 B/px of RGB per frame)
 H = int(sys.argv[5]) if len(sys.argv) > 5 else 240
 W = int(sys.argv[6]) if len(sys.argv) > 6 else 320
 COMMIT = sys.argv[7] if len(sys.argv) > 7 else "unknown"
 BATCH = int(sys.argv[8]) if len(sys.argv) > 8 else FRAMES  # frames per depth -> height-map dispatch (the sensor's whole shard)
+
+
+def frames_per_tail_launch(write_dir):
+    """Frames one tail launch renders, from what it WROTE: RGB is 12 B/px and nothing else of size leaves the kernel, so WRITE_SIZE
+    per dispatch / (12 H W) is the frame count whatever pass policy the library chose.  (Round 3's 640x480 file was built with the
+    320x240 default of 1024 frames where the 640x480 pass launches 256: every per-frame figure in it was 4x too small.)"""
+    tot, n = 0.0, 0
+    for f in glob.glob(os.path.join(write_dir, "**", "*counter_collection.csv"), recursive=True):
+        for row in csv.DictReader(open(f)):
+            if row["Counter_Name"] == "WRITE_SIZE" and ("taxim_stream_kernel" in row["Kernel_Name"] or "taxim_tail_kernel" in row["Kernel_Name"]):
+                tot += float(row["Counter_Value"]); n += 1
+    if n == 0:
+        raise SystemExit("no tail dispatch in the WRITE_SIZE pass")
+    return tot / n * 1024 / (12.0 * H * W)
+
+
+_fpl = frames_per_tail_launch(sys.argv[2])
+if FRAMES == 0:
+    FRAMES = int(round(_fpl))
+elif abs(_fpl / FRAMES - 1.0) > 0.1:
+    raise SystemExit(f"frames_per_tail_launch={FRAMES} contradicts the tail's own writes ({_fpl:.1f} frames of {W}x{H} RGB per dispatch)")
+if len(sys.argv) <= 8:
+    BATCH = FRAMES
 
 
 def collect(d, counter):
@@ -67,5 +90,8 @@ out = {
     "raw_kib_per_frame": {k: {"FETCH_SIZE": round(fetch.get(k, 0), 2), "WRITE_SIZE": round(write.get(k, 0), 2)} for k in keys},
     "dispatches": {k: {"fetch_pass": fcnt.get(k, 0), "write_pass": wcnt.get(k, 0)} for k in keys},
 }
+out["frames_per_tail_launch_from_writes"] = round(_fpl, 2)
+if out["taxim_path_sum_per_frame"] < out["compulsory_per_frame_16B_per_px"]:
+    raise SystemExit(f"path sum {out['taxim_path_sum_per_frame']} B/frame is BELOW the compulsory {out['compulsory_per_frame_16B_per_px']}: wrong normalisation")
 json.dump(out, open(sys.argv[3], "w"), indent=1)
 print(json.dumps({k: out[k] for k in ("per_frame_bytes", "taxim_path_sum_per_frame", "compulsory_per_frame_16B_per_px")}, indent=1))

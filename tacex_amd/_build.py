@@ -75,15 +75,32 @@ def build_library(force: bool = False, verbose: bool = False) -> Path:
         lock.close()
 
 
+def _mllvm_supported(hipcc: str, flags: list, objdir: Path) -> bool:
+    """`-mllvm <opt>` names a hidden LLVM option: a hipcc / LLVM without it stops with 'Unknown command line argument' and the
+    library would not build for the sake of a 3.7 % scheduling preference.  One empty-kernel compile decides."""
+    probe = objdir / "_mllvm_probe.hip"
+    probe.write_text("#include <hip/hip_runtime.h>\n__global__ void tacex_probe() {}\n")
+    r = subprocess.run([hipcc, "--offload-arch=gfx950", "-c", *flags, str(probe), "-o", str(objdir / "_mllvm_probe.o")],
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    return r.returncode == 0
+
+
 def _build_locked(dig: str, verbose: bool) -> Path:
     hipcc = _hipcc()
     objdir = PKG / (f"build.{_TAG}" if _TAG else "build")
     objdir.mkdir(exist_ok=True)
+    file_flags = dict(FILE_FLAGS)
+    sched = _stream_flags.split()
+    if "-mllvm" in sched and "TACEX_STREAM_HIPCC_FLAGS" not in os.environ and not _mllvm_supported(hipcc, sched, objdir):
+        # the DEFAULT scheduler preference is optional (an explicitly requested flag set is passed through and may fail loudly)
+        file_flags["taxim_stream.hip"] = [f for f in file_flags["taxim_stream.hip"] if f not in sched]
+        if verbose:
+            print(f"hipcc does not know {' '.join(sched)}: building taxim_stream.hip without it")
     srcs = [CSRC / s for s in SOURCES if (CSRC / s).exists()]
     procs = []
     for s in srcs:
         obj = objdir / (s.stem + ".o")
-        cmd = [hipcc, *FLAGS, *FILE_FLAGS.get(s.name, []), f"-I{INCLUDE}", f"-I{CSRC}", "-c", str(s), "-o", str(obj)]
+        cmd = [hipcc, *FLAGS, *file_flags.get(s.name, []), f"-I{INCLUDE}", f"-I{CSRC}", "-c", str(s), "-o", str(obj)]
         if verbose:
             print(" ".join(cmd))
         procs.append((s, obj, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))

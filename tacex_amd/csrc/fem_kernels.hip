@@ -1531,6 +1531,10 @@ __global__ __launch_bounds__(kNwtThreads) void fem_newton_lds_kernel(FemDev m, d
     step = 0.0;
     if (!(dmax <= dx_tol)) flags |= kFemFlagLsFailed;  // (no decrease to be had at a point whose Newton step is below the tolerance: converged)
   }
+  // A rejected search leaves x where it was and cuts the warm start: the next iteration would be bit-identical to this one, and
+  // the one after, up to max_newton - each a full assembly, a PCG solve and up to 33 energy sweeps on a CU other envs wait for.
+  // The env stops here with the flag set (block-uniform: `accepted` and `dmax` are block reductions).
+  const bool ls_dead = !accepted && !(dmax <= dx_tol);
   FEM_PHASE(3);
   ++n_newton;
   pcg_total += (double)it;
@@ -1548,6 +1552,7 @@ __global__ __launch_bounds__(kNwtThreads) void fem_newton_lds_kernel(FemDev m, d
   // unscaled Newton direction, whatever the CCD bound and the line search then made of the step - a shortened UPDATE says nothing
   // about convergence, a short DIRECTION does.  (Rounds 2-3 also demanded a full-length accepted step: at the edge of
   // the barrier zone that never happens and every retreat step ran to the iteration cap with directions 5x below the tolerance.)
+  if (ls_dead) break;
   const bool converged = dmax <= dx_tol;
   if (converged) {  // wave-uniform: every quantity above is a block reduction
     if (fric && !fric_phase) {
@@ -1672,11 +1677,29 @@ struct tacex_fem_ctx {
   int device = 0;
   FemDev dev{};
   FemDev dev_nwt{};  // same mesh with the tets renumbered for fem_newton_lds_kernel (see tacex_fem_create)
-  bool ind_prev_valid = false;  // the workspace holds the indenter positions of the previous tacex_fem_step (friction)
+  // Friction slides relative to the indenter's displacement since the previous tacex_fem_step.  The previous positions (B,3) live
+  // in the caller's workspace (no allocation in a compute call); the context remembers WHICH workspace and env count they were
+  // written for, so another workspace or num_envs never reads stale data, and a new indenter TENSOR for the same contact (the
+  // caller animating the indenter by passing fresh tensors) keeps them: only disabling contact or its first enable resets.
+  const void* ind_prev_ws = nullptr;
+  int ind_prev_B = 0;
   double* dx_dev = nullptr;  // optional (B,) last Newton update max|dx| per env: converged envs skip further iterations
   double dx_tol = 0.0;
   std::vector<void*> allocs;
 };
+
+// Tables a setter REPLACES (coarse space, chains, indenter mesh, vertex areas) are freed once nothing can read them any more:
+// the setters are host-synchronous set-up calls, so they drain the device first (a caller who refreshed the
+// preconditioner every step grew the device memory without bound).
+template <typename T>
+static void fem_release(tacex_fem_ctx* c, const T*& ptr, bool* synced) {
+  if (!ptr) return;
+  if (!*synced) { (void)hipDeviceSynchronize(); *synced = true; }
+  void* p = const_cast<void*>(static_cast<const void*>(ptr));
+  for (size_t i = 0; i < c->allocs.size(); ++i)
+    if (c->allocs[i] == p) { c->allocs.erase(c->allocs.begin() + (long)i); (void)hipFree(p); break; }
+  ptr = nullptr;
+}
 
 template <typename T>
 static int fem_upload(tacex_fem_ctx* c, const std::vector<T>& h, const T** out) {
@@ -1864,6 +1887,8 @@ int tacex_fem_set_contact(tacex_fem_ctx* c, const double* vertex_area_host, doub
       if (!(v >= 0.0)) { set_error("tacex_fem_set_contact: vertex areas must be >= 0"); return 2; }
     const double* d = nullptr;
     if (int rc = fem_upload(c, a, &d)) return rc;
+    bool synced = false;
+    fem_release(c, c->dev.area, &synced);
     c->dev.area = d; c->dev_nwt.area = d;
   }
   if (indenters_dev) {
@@ -1872,8 +1897,9 @@ int tacex_fem_set_contact(tacex_fem_ctx* c, const double* vertex_area_host, doub
   }
   c->dev.dhat = c->dev_nwt.dhat = d_hat;
   c->dev.kappa = c->dev_nwt.kappa = stiffness;
+  if (!indenters_dev || !c->dev.indenters) { c->ind_prev_ws = nullptr; c->ind_prev_B = 0; }  // contact off, or enabled for the first time:
+                                                                                             // the next step sees no indenter motion
   c->dev.indenters = c->dev_nwt.indenters = indenters_dev;
-  c->ind_prev_valid = false;  // a new indenter set: the first step after it sees no indenter motion
   return 0;
 }
 
@@ -1900,7 +1926,14 @@ int tacex_fem_set_friction(tacex_fem_ctx* c, double friction_ratio, double eps_v
 
 int tacex_fem_set_indenter_mesh(tacex_fem_ctx* c, int num_verts, const double* verts_host, int num_tris, const int32_t* tris_host) {
   if (!c) { set_error("tacex_fem_set_indenter_mesh: null context"); return 2; }
-  if (num_tris == 0) { c->dev.im_nt = c->dev_nwt.im_nt = 0; return 0; }
+  if (num_tris == 0) {
+    bool synced = false;
+    (void)hipSetDevice(c->device);
+    fem_release(c, c->dev.im_tri, &synced); fem_release(c, c->dev.im_bs, &synced); fem_release(c, c->dev.im_cl, &synced);
+    c->dev_nwt.im_tri = nullptr; c->dev_nwt.im_bs = nullptr; c->dev_nwt.im_cl = nullptr;
+    c->dev.im_nt = c->dev_nwt.im_nt = 0;
+    return 0;
+  }
   if (num_verts < 3 || num_tris < 1 || !verts_host || !tris_host) { set_error("tacex_fem_set_indenter_mesh: bad arguments"); return 2; }
   for (int k = 0; k < num_tris * 3; ++k)
     if (tris_host[k] < 0 || tris_host[k] >= num_verts) { set_error("tacex_fem_set_indenter_mesh: vertex index %d out of range", tris_host[k]); return 2; }
@@ -1958,6 +1991,11 @@ int tacex_fem_set_indenter_mesh(tacex_fem_ctx* c, int num_verts, const double* v
   hipError_t e = hipSetDevice(c->device);
   if (e != hipSuccess) return fail_hip(e, "hipSetDevice");
   FemDev& d = c->dev;
+  {
+    bool synced = false;
+    fem_release(c, d.im_tri, &synced); fem_release(c, d.im_bs, &synced); fem_release(c, d.im_cl, &synced);
+    d.im_nt = c->dev_nwt.im_nt = 0;
+  }
   if (int rc = fem_upload(c, tri, &d.im_tri) | fem_upload(c, bs, &d.im_bs) | fem_upload(c, cl, &d.im_cl)) return rc;
   d.im_nt = num_tris;
   c->dev_nwt.im_nt = num_tris; c->dev_nwt.im_tri = d.im_tri; c->dev_nwt.im_bs = d.im_bs; c->dev_nwt.im_cl = d.im_cl;
@@ -1968,9 +2006,15 @@ int tacex_fem_set_chains(tacex_fem_ctx* c, int num_chains, const int32_t* chain_
   if (!c) { set_error("tacex_fem_set_chains: null context"); return 2; }
   FemDev& d = c->dev;
   FemDev& n2 = c->dev_nwt;
-  if (num_chains == 0) {  // every vertex its own chain: 3x3 block Jacobi
+  auto drop_chains = [&]() {
+    bool synced = false;
+    (void)hipSetDevice(c->device);
+    fem_release(c, d.ch_head, &synced); fem_release(c, d.ch_next, &synced); fem_release(c, d.ch_prev, &synced);
     d.nch = n2.nch = 0;
-    d.ch_head = n2.ch_head = nullptr; d.ch_next = n2.ch_next = nullptr; d.ch_prev = n2.ch_prev = nullptr;
+    n2.ch_head = nullptr; n2.ch_next = nullptr; n2.ch_prev = nullptr;
+  };
+  if (num_chains == 0) {  // every vertex its own chain: 3x3 block Jacobi
+    drop_chains();
     return 0;
   }
   if (num_chains < 0 || !chain_offsets_host || !chain_vertices_host) { set_error("tacex_fem_set_chains: bad arguments"); return 2; }
@@ -1993,6 +2037,7 @@ int tacex_fem_set_chains(tacex_fem_ctx* c, int num_chains, const int32_t* chain_
   std::sort(head.begin(), head.end());
   hipError_t e = hipSetDevice(c->device);
   if (e != hipSuccess) return fail_hip(e, "hipSetDevice");
+  drop_chains();
   if (int rc = fem_upload(c, head, &d.ch_head) | fem_upload(c, nxt, &d.ch_next) | fem_upload(c, prv, &d.ch_prev)) return rc;
   d.nch = (int)head.size();
   n2.nch = d.nch; n2.ch_head = d.ch_head; n2.ch_next = d.ch_next; n2.ch_prev = d.ch_prev;
@@ -2002,8 +2047,18 @@ int tacex_fem_set_chains(tacex_fem_ctx* c, int num_chains, const int32_t* chain_
 int tacex_fem_set_coarse_space(tacex_fem_ctx* c, int num_coarse, const int32_t* vertex_nodes_host, const double* vertex_weights_host,
                                const double* coarse_inverse_host) {
   if (!c) { set_error("tacex_fem_set_coarse_space: null context"); return 2; }
+  auto drop_coarse = [&]() {
+    bool synced = false;
+    (void)hipSetDevice(c->device);
+    FemDev& d0 = c->dev;
+    fem_release(c, d0.cv_node, &synced); fem_release(c, d0.cv_w, &synced); fem_release(c, d0.cn_off, &synced);
+    fem_release(c, d0.cn_vtx, &synced); fem_release(c, d0.cn_w, &synced); fem_release(c, d0.ac_inv, &synced);
+    FemDev& n0 = c->dev_nwt;
+    n0.cv_node = nullptr; n0.cv_w = nullptr; n0.cn_off = nullptr; n0.cn_vtx = nullptr; n0.cn_w = nullptr; n0.ac_inv = nullptr;
+    d0.nc = n0.nc = 0;
+  };
   if (num_coarse == 0) {  // block Jacobi alone
-    c->dev.nc = c->dev_nwt.nc = 0;
+    drop_coarse();
     return 0;
   }
   if (num_coarse < 1 || num_coarse > kFemMaxCoarse || !vertex_nodes_host || !vertex_weights_host || !coarse_inverse_host) {
@@ -2031,6 +2086,7 @@ int tacex_fem_set_coarse_space(tacex_fem_ctx* c, int num_coarse, const int32_t* 
   hipError_t e = hipSetDevice(c->device);
   if (e != hipSuccess) return fail_hip(e, "hipSetDevice");
   FemDev& d = c->dev;
+  drop_coarse();
   if (int rc = fem_upload(c, node, &d.cv_node) | fem_upload(c, w, &d.cv_w) | fem_upload(c, off, &d.cn_off) | fem_upload(c, vtx, &d.cn_vtx) |
                fem_upload(c, cw, &d.cn_w) | fem_upload(c, ai, &d.ac_inv))
     return rc;
@@ -2113,7 +2169,7 @@ int tacex_fem_step(tacex_fem_ctx* c, double* x, double* v, double* xt, const uin
   const double* ind = c->dev.indenters;
   const double dt = c->dev.dt, tol = velocity_tol * dt;
   hipLaunchKernelGGL(fem_predict_kernel, dim3((unsigned)((n3 + 255) / 256)), dim3(256), 0, st, x, v, xt, xprev, dx, n3, B, dt, gravity[0],
-                     gravity[1], gravity[2], ind, ind_prev, disp, c->ind_prev_valid ? 1 : 0);
+                     gravity[1], gravity[2], ind, ind_prev, disp, (ind && c->ind_prev_ws == ws && c->ind_prev_B == B) ? 1 : 0);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail_hip(e, "fem_predict_kernel");
   bool resident = false;
@@ -2130,7 +2186,7 @@ int tacex_fem_step(tacex_fem_ctx* c, double* x, double* v, double* xt, const uin
     if (e != hipSuccess) return fail_hip(e, "hipMemsetAsync(step_info)");
   }
   hipLaunchKernelGGL(fem_velocity_kernel, dim3((unsigned)((n3 + 255) / 256)), dim3(256), 0, st, x, xprev, v, n3, 1.0 / dt, ind, ind_prev, B);
-  if (ind) c->ind_prev_valid = true;
+  if (ind) { c->ind_prev_ws = ws; c->ind_prev_B = B; }
   e = hipGetLastError();
   return e == hipSuccess ? 0 : fail_hip(e, "fem_velocity_kernel");
 }

@@ -57,6 +57,7 @@ class FemGelpad:
         self.ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
         self.ms_log = None    # set to [] to collect the duration of every step (hipEvents, read one step late)
         self.info_sum = None  # with ms_log: (4,) device sums over the logged steps of [Newton iterations, -, flagged envs, PCG iterations] per env mean
+        self.iters_max = None  # with info_sum: device scalar, the largest Newton iteration count of any env and logged step
         self._pending = None
 
     def step(self, i):
@@ -79,6 +80,7 @@ class FemGelpad:
         self.ev[1].record()
         if self.ms_log is not None and self.info_sum is not None:
             self.info_sum += self.sim.step_info.mean(0)  # device-side, no synchronisation
+            self.iters_max = torch.maximum(self.iters_max, self.sim.step_info[:, 0].max()) if self.iters_max is not None else self.sim.step_info[:, 0].max()
         if self.ms_log is not None:  # (reading the previous step's events: no sync with the step just enqueued)
             if self._pending is not None:
                 self._pending[1].synchronize()
@@ -86,7 +88,17 @@ class FemGelpad:
             self._pending = self.ev
             self.ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
 
+    def flush(self):
+        """Appends the duration of the LAST enqueued step to `ms_log` (its events are read one step late; without this the log
+        is shifted by one step: it would hold the step before the logged window and miss its last one).  Synchronises."""
+        if self.ms_log is not None and self._pending is not None:
+            self._pending[1].synchronize()
+            self.ms_log.append(self._pending[0].elapsed_time(self._pending[1]))
+            self._pending = None
+
     def fem_ms_last(self):
+        if self.ms_log is not None and self._pending is None and self.ms_log:
+            return self.ms_log[-1]
         ev = self._pending if (self.ms_log is not None and self._pending is not None) else self.ev
         ev[1].synchronize()
         return ev[0].elapsed_time(ev[1])

@@ -108,7 +108,7 @@ class UipcIsaacAttachments:
                 _lib.current_stream_handle(dev))
         _lib.check(rc, "tacex_fem_set_attachment_targets")
         if getattr(self, "_marked_sim", None) is not uipc_sim:  # the constraint SET changed: the sim rebuilds its coarse operator once
-            uipc_sim._precond_dirty = True
+            uipc_sim._mark_constrained(np.asarray(self.attachment_points_idx, dtype=np.int64).reshape(-1))
             self._marked_sim = uipc_sim
         return self.aim_positions
 

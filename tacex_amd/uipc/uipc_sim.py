@@ -159,7 +159,12 @@ class UipcSim:
 
         Contract: between two `step()` calls an indenter may approach the pad by LESS than the current gap (a rigid-body
         integrator with CCD guarantees that; `contact_gaps()` gives the gap).  A vertex found at or beyond the surface has infinite
-        barrier energy and no gradient: the step still runs, the env is flagged in `step_info[:, 2]` and `check_step()` raises."""
+        barrier energy and no gradient: the step still runs, the env is flagged in `step_info[:, 2]` and `check_step()` raises.
+
+        Moving the indenter: mutate `sim.contact_indenters` in place, or call this again with a new tensor every step - both are
+        seen by friction as the indenter's displacement since the previous `step()` (the library keeps the previous positions
+        across this call; disabling contact resets them).  Only the TRANSLATION (cx, cy, cz) counts: a rotation of a capsule /
+        mesh indenter between two steps does not drag the pad (`tacex_fem_set_friction`, include/tacex_hip.h)."""
         if indenters is None:
             _lib.check(self._lib.tacex_fem_set_contact(self._handle, 0, 0.0, 0.0, 0), "tacex_fem_set_contact")
             self.contact_indenters = None
@@ -268,7 +273,28 @@ class UipcSim:
         idx = torch.as_tensor(vertex_idx, device=self.device, dtype=torch.long)
         self.is_constrained[:, idx] = 1
         self.aim_position[:, idx] = aim_positions.to(self.device, torch.float64)
-        self._precond_dirty = True
+        # The preconditioner depends on the constrained SET, not on the aim positions: a caller animating the targets through this
+        # method every step must not trigger a host-side rebuild (device sync, dense inverse, table re-upload) per step.  The set
+        # is mirrored on the host; an index tensor that lives on the device is read back once per distinct (tensor, version).
+        if isinstance(vertex_idx, torch.Tensor) and vertex_idx.is_cuda:
+            key = (vertex_idx.data_ptr(), vertex_idx.numel(), vertex_idx._version)
+            if key == getattr(self, "_cons_idx_seen", None):
+                return
+            self._cons_idx_seen = key
+            host_idx = vertex_idx.detach().reshape(-1).cpu().numpy().astype(np.int64)
+        else:
+            host_idx = np.asarray(vertex_idx.detach().cpu() if isinstance(vertex_idx, torch.Tensor) else vertex_idx, dtype=np.int64).reshape(-1)
+        self._mark_constrained(host_idx)
+
+    def _mark_constrained(self, host_idx):
+        """Host mirror of the constrained vertex set (env 0's flags; the envs of a scene share their attachment set): the
+        preconditioner is rebuilt only when a vertex joins it."""
+        mirror = getattr(self, "_cons_host", None)
+        if mirror is None:
+            mirror = self._cons_host = np.zeros(self._obj.num_verts, dtype=bool)
+        if not mirror[host_idx].all():
+            mirror[host_idx] = True
+            self._precond_dirty = True
 
     def refresh_preconditioner(self):
         """(Re)build the coarse operator of the two-level preconditioner: Galerkin product of the REST-state matrix

@@ -32,3 +32,24 @@ def test_roofline_duration_agrees_with_the_rocprof_summary():
     rows = list(csv.DictReader(open(REPO / "profiles" / "r02_c3_kernel_stats.csv")))
     k = next(r for r in rows if "taxim_stream_kernel" in r["Name"])
     assert abs(float(k["AverageNs"]) * 1e-6 - stage["avg_ms"]) <= 0.05 * stage["avg_ms"]  # hipEvent vs profiler: within 5 %
+
+
+def test_every_traffic_file_is_at_least_its_compulsory_bytes():
+    """A per-frame HBM traffic figure below the compulsory 16 B/px means the counters were divided by the wrong frame count
+    (round 3's 640x480 file: 1024 frames per tail launch assumed where the pass launches 256).  `scripts/make_pmc_traffic.py` now
+    takes the frame count from the tail's own WRITE_SIZE and refuses such a result; this pins the committed files."""
+    files = sorted((REPO / "profiles").glob("pmc_traffic_r*.json"))
+    assert files
+    checked = 0
+    for f in files:
+        j = json.loads(f.read_text())
+        if "taxim_path_sum_per_frame" not in j:
+            continue  # FEM files: per-dispatch figures, no per-frame path sum
+        checked += 1
+        assert j["taxim_path_sum_per_frame"] >= j["compulsory_per_frame_16B_per_px"], f.name
+        W, H = j["resolution"]
+        assert j["compulsory_per_frame_16B_per_px"] == 16 * H * W, f.name
+        tail = j["per_frame_bytes"].get("tail_fused")
+        if tail is not None:  # the tail alone writes 12 B/px of RGB and reads >= 4 B/px of the last band level
+            assert tail >= 0.95 * 16 * H * W, (f.name, tail)
+    assert checked >= 2

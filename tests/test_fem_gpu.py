@@ -741,3 +741,69 @@ def test_fem_table_setters_reject_bad_input_and_gaps_without_indenter():
     assert torch.isinf(sim.contact_gaps()).all()
     sim.step(max_newton_iter=2)
     assert torch.isfinite(sim.x).all()
+
+
+def test_animated_aims_do_not_rebuild_the_preconditioner_and_setters_free_their_tables():
+    """`set_constraints` called every step with the SAME vertex set (a caller animating the aim positions) must not
+    re-run `refresh_preconditioner` (device sync, dense inverse, six table uploads); a NEW vertex does; and the C setters free
+    the tables they replace - 40 forced refreshes leave the device memory where it was."""
+    sim, m, P, cons, aim, cms = _c4_scene(2)
+    sim.step(max_newton_iter=2)
+    assert not sim._precond_dirty
+    idx = np.nonzero(cons)[0]
+    aims = sim.aim_position[:, idx].clone()
+    calls = []
+    orig = sim.refresh_preconditioner
+    sim.refresh_preconditioner = lambda: (calls.append(1), orig())[1]
+    idx_dev = torch.as_tensor(idx, device=sim.device)
+    for k in range(5):
+        sim.set_constraints(idx.tolist() if k % 2 else idx_dev, aims + 1e-6 * k)
+        sim.step(max_newton_iter=2)
+    assert calls == [] and not sim._precond_dirty
+    free = [v for v in range(len(P)) if not cons[v]][:1]
+    sim.set_constraints(free, sim.x[:, free].clone())
+    assert sim._precond_dirty
+    sim.step(max_newton_iter=2)
+    assert calls == [1]
+    torch.cuda.synchronize()
+    sv, st = __import__("tacex_amd.uipc.indenter_meshes", fromlist=["icosphere"]).icosphere(0.004, 2)
+    for k in range(3):  # reach the allocator's steady state first
+        orig(); sim.set_indenter_mesh(sv, st)
+    torch.cuda.synchronize()
+    free0 = torch.cuda.mem_get_info()[0]
+    for k in range(40):
+        orig()
+        sim.set_indenter_mesh(sv, st)
+    torch.cuda.synchronize()
+    assert free0 - torch.cuda.mem_get_info()[0] <= (2 << 20), (free0, torch.cuda.mem_get_info()[0])  # was ~0.4 MB per refresh
+    sim.step(max_newton_iter=2)  # the replaced tables are the ones in use
+    assert torch.isfinite(sim.x).all()
+
+
+def test_friction_sees_indenter_motion_through_a_new_tensor_every_step():
+    """a caller who moves the indenter by handing `set_contact_indenters` a NEW tensor each step used to get zero
+    indenter displacement (the call reset the previous positions) and friction against the world frame.  Now the two ways of moving
+    the indenter - in-place mutation and a fresh tensor per step - give bit-identical trajectories."""
+    res = []
+    for fresh in (False, True):
+        sim, m, P, cons, aim, cms = _c4_scene(1)
+        sim.cfg.newton.velocity_tol = 1e-3
+        sim.set_contact_indenters(sim.contact_indenters)
+        row = sim.contact_indenters.clone()
+        for k in range(6):
+            gap = float(sim.contact_gaps().amin())
+            if k < 3:
+                row[:, 3] -= 0.3 * gap
+            else:
+                row[:, 1] += 5e-5
+                if gap < 1e-4:
+                    row[:, 3] += 1e-4 - gap
+            if fresh:
+                sim.set_contact_indenters(row.clone())
+            else:
+                sim.contact_indenters.copy_(row)
+            sim.step(max_newton_iter=60)
+        res.append(sim.x.cpu().numpy().copy())
+    top = P[:, 2] > P[:, 2].max() - 1e-9
+    assert (res[0][0][top, 0] - P[top, 0]).max() > 2e-5  # friction dragged the surface along +x
+    np.testing.assert_array_equal(res[0], res[1])
