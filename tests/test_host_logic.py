@@ -200,3 +200,45 @@ def test_fem_marker_setup_vs_reference(golden_dir):
     rs = np.random.RandomState(123)
     grid2 = gen_marker_grid((1.8, 2.2), 0.05, (0.5, 0.4), (0.05, 0.05), rng=rs)
     np.testing.assert_allclose(grid2, g["grid_random"], rtol=0, atol=1e-12)
+
+
+def test_uipc_cfg_defaults_and_attachment_data_vs_reference(golden_dir):
+    """Rows a18 / a20 pinned where the reference is plain Python (tests/golden/make_uipc_cfg_golden.py lifts the cfg classes and
+    `compute_attachment_data` out of the reference with `ast`): every default of UipcSimCfg (US:32-131), the gelpad constitution
+    (UO:59-88) and the attachment cfg (UA:33-66) equals the package's; the attachment set, its order, the body-frame offsets
+    (float32) and the returned positions of UA:247-346 equal `UipcIsaacAttachments.compute_attachment_data` on the same input."""
+    from tacex_amd.uipc import UipcObjectCfg, UipcSimCfg
+    from tacex_amd.uipc.uipc_attachments import UipcIsaacAttachments, UipcIsaacAttachmentsCfg
+
+    g = np.load(golden_dir / "uipc_cfg.npz")
+    ours = {"UipcSimCfg": UipcSimCfg, "UipcObjectCfg": UipcObjectCfg, "UipcIsaacAttachmentsCfg": UipcIsaacAttachmentsCfg}
+    # fields of the reference the package deliberately does not mirror: affine bodies are out of scope (DESIGN section 6), the
+    # gelpad mesh is handed over as arrays (mesh_points / mesh_tets) instead of a TetMeshCfg recipe, and the constitution defaults
+    # to the gelpad's StableNeoHookean (the reference leaves it None and every gelpad asset sets it)
+    skipped = {"UipcObjectCfg.AffineBodyConstitutionCfg.kinematic", "UipcObjectCfg.AffineBodyConstitutionCfg.m_kappa",
+               "UipcObjectCfg.mesh_cfg", "UipcObjectCfg.constitution_cfg"}
+    n = 0
+    for key in g.files:
+        if not key.startswith("cfg/"):
+            continue
+        path = key[4:]
+        if path in skipped:
+            continue
+        obj = ours[path.split(".")[0]]
+        for part in path.split(".")[1:]:
+            assert hasattr(obj, part), f"{path}: the package's cfg lacks this field of the reference"
+            obj = getattr(obj, part)
+        ref = g[key]
+        if ref.dtype.kind in "US":
+            assert (obj is None and str(ref) == "None") or obj == str(ref), (path, obj, ref)
+        else:
+            np.testing.assert_array_equal(np.asarray(obj, dtype=ref.dtype), ref, err_msg=path)
+        n += 1
+    assert n >= 34
+    off, idx, pos = UipcIsaacAttachments.compute_attachment_data(
+        ("box", tuple(g["att/box_half"])), g["att/tet_points"], rigid_pos=g["att/rigid_pos"], rigid_quat=g["att/rigid_quat"],
+        sphere_radius=float(g["att/sphere_radius"]), max_dist=float(g["att/max_dist"]))
+    np.testing.assert_array_equal(np.asarray(idx), g["att/idx"])
+    np.testing.assert_array_equal(pos, g["att/positions"])
+    assert off.dtype == np.float32 and len(idx) == 99  # the back face of the 8 x 10 x 4 pad
+    np.testing.assert_allclose(off, g["att/offsets"], rtol=0, atol=2e-9)  # float32 cross products: numpy vs torch order of the same formula

@@ -4,7 +4,7 @@ import numpy as np
 import pytest
 import torch
 
-from parity import check_against_reference, rgb_rel_err, unpack_mask
+from parity import assert_same_bin_vs_oracle, check_against_reference, rgb_rel_err, unpack_mask
 
 pytestmark = pytest.mark.gpu
 
@@ -163,12 +163,9 @@ def test_no_shift_render_and_numpy_entry(taxim, calib_dir):
     yy, xx = np.meshgrid(np.arange(48.0), np.arange(64.0), indexing="ij")
     S = (0.5 - np.sqrt(np.clip(400 - (xx - 30) ** 2 - (yy - 20) ** 2, 0, None)) * 0.05).astype(np.float32)[None]
     S = np.minimum(S, 0.6)
-    Zo, _ = o.gel_pad_deformation(S)
-    rgbo = o.shade(Zo)
     out = taxim.render(S, with_shadow=False, press_depth=None)
     assert out.shape == (1, 48, 64, 3)
-    err = rgb_rel_err(out, rgbo)
-    assert np.quantile(err, 0.99) <= 1e-4
+    assert_same_bin_vs_oracle(taxim, o, S, None, out)
 
 
 def test_resize_kernel_matches_torch():
