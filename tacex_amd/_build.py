@@ -58,6 +58,10 @@ def _digest() -> str:
 
 def build_library(force: bool = False, verbose: bool = False) -> Path:
     """Compile every HIP translation unit to an object (in parallel) and link the shared library."""
+    # TACEX_LIB_FROZEN=1 with a tag: use the tagged library as it was built, whatever the sources say now - an A/B partner built
+    # from an OLDER commit (git worktree) and carried to the GPU box beside the product library
+    if _TAG and os.environ.get("TACEX_LIB_FROZEN") == "1" and LIB.exists():
+        return LIB
     dig = _digest()
     if not force and LIB.exists() and STAMP.exists() and STAMP.read_text().strip() == dig:
         return LIB

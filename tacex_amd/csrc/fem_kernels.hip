@@ -36,6 +36,10 @@ struct FemDev {
   const double* vol;      // (T)
   const double* tet_rec;  // (T,12) AoS copy of one tet: vertex ids (4 ints in the first two doubles) | dminv (9) | vol - for loops that visit
                           // tets in VERTEX order (every lane another tet): six 16-byte loads per tet instead of 14 scattered ones; nullable
+  const double* tet_blk;  // wave-blocked SoA copy for loops that visit tets in TET order (the sweeps of fem_newton_lds_kernel): per block of
+                          // 64 tets [9][64] dminv | [64] vol | [4][64] vertex ids (int32) = kTetBlkBytes; every component of lane l sits at
+                          // block base + immediate + 8 l, so ONE 32-bit offset register addresses all 14 loads (the SoA arrays above
+                          // need 14 per-lane 64-bit addresses, which the Newton kernel spilled and re-read from scratch one by one)
   const double* mass;     // (V)
   const int* vt_off;      // (V+1) CSR vertex -> incident (tet*4 + local)
   const int* vt_idx;
@@ -297,6 +301,43 @@ __device__ __forceinline__ void load_tet_rec(const FemDev& m, int t, int v[4], d
   v[0] = __double2loint(q0.x); v[1] = __double2hiint(q0.x); v[2] = __double2loint(q0.y); v[3] = __double2hiint(q0.y);
   Di[0] = q1.x; Di[1] = q1.y; Di[2] = q2.x; Di[3] = q2.y; Di[4] = q3.x; Di[5] = q3.y; Di[6] = q4.x; Di[7] = q4.y; Di[8] = q5.x;
   vol = q5.y;
+}
+
+// table read at (uniform base) + (32-bit byte offset): selects the scalar-base form of the load (global_load v, v_off, s[base:base+1]), so
+// a loop keeps ONE 32-bit offset alive instead of a 64-bit per-lane address per table - the Newton kernel carried ~25 such addresses
+// across its PCG loop, spilled them, and read them back from scratch (which misses the L2: 512 envs x 300 KB) one dependent wait at a time
+template <typename T>
+__device__ __forceinline__ T ldg_off(const void* base, unsigned byte_off) {
+  return *reinterpret_cast<const T*>(static_cast<const char*>(base) + byte_off);
+}
+// a value the optimiser must treat as unknown: address arithmetic built on it is recomputed where it is used (a few integer
+// operations) instead of being hoisted out of the enclosing loops and kept live - or spilled - across them
+__device__ __forceinline__ unsigned opaque_u32(unsigned v) {
+  asm volatile("" : "+v"(v));
+  return v;
+}
+
+// The thread index rebuilt from nothing but the wave's index (a scalar register) and the lane counter: inside the Newton kernel the
+// register allocator spilled threadIdx.x itself - and the LDS addresses derived from it - and re-read them from scratch fourteen
+// times per PCG iteration.  volatile: every call site gets its own two-instruction copy, nothing is carried between phases.
+__device__ __forceinline__ int fresh_tid(int wave_index) {
+  int l;
+  asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+  return wave_index * 64 + l;
+}
+
+constexpr unsigned kTetBlkBytes = 9 * 512 + 512 + 4 * 256;  // 6144
+// one tet through the wave-blocked table (see FemDev::tet_blk): coalesced like the SoA arrays, one offset register
+__device__ __forceinline__ void load_tet_blk(const FemDev& m, int t, int v[4], double Di[9], double& vol) {
+  const unsigned ln = (unsigned)t & 63u;
+  const unsigned ob = ((unsigned)t >> 6) * kTetBlkBytes;
+  const char* base = reinterpret_cast<const char*>(m.tet_blk);
+  const unsigned o8 = ob + ln * 8u, o4 = ob + 5120u + ln * 4u;
+#pragma unroll
+  for (int k = 0; k < 9; ++k) Di[k] = *reinterpret_cast<const double*>(base + (o8 + (unsigned)k * 512u));
+  vol = *reinterpret_cast<const double*>(base + (o8 + 4608u));
+#pragma unroll
+  for (int k = 0; k < 4; ++k) v[k] = *reinterpret_cast<const int*>(base + (o4 + (unsigned)k * 256u));
 }
 
 __device__ __forceinline__ void load_tet(const FemDev& m, int t, int v[4], double Di[9]) {
@@ -905,11 +946,12 @@ __device__ __forceinline__ double env_energy_lds(const FemDev& m, const double* 
   for (int t = threadIdx.x; t < m.T; t += blockDim.x) {
     int v[4];
     double Di[9], F[9];
-    load_tet(m, t, v, Di);
+    double vol_t;
+    load_tet_blk(m, t, v, Di, vol_t);
     deformation_gradient(xl, v, Di, F);
     TetState s;
     tet_state(m, F, s);
-    e += dt2 * m.vol[t] * psi_of(m, s);
+    e += dt2 * vol_t * psi_of(m, s);
   }
   if (own) {
     const int v = threadIdx.x;
@@ -963,10 +1005,12 @@ __global__ __launch_bounds__(kNwtThreads) void fem_newton_lds_kernel(FemDev m, d
                                                                      const uint8_t* consg, const double* aimg, double* stats,
                                                                      int pcg_max_iter, double pcg_tol_rate, int ls_max_iter,
                                                                      double* dxg, double dx_tol, int max_newton, double* step_info,
-                                                                     const double* xprevg, const double* dispg) {
+                                                                     const double* xprevg, const double* dispg, const int* env_order) {
   extern __shared__ __attribute__((aligned(16))) double nlds[];
   constexpr int CH = kNwtChunk;
-  const int V = m.V, T = m.T, tid = threadIdx.x;
+  const int V = m.V, T = m.T;
+  const int wave_s = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int tid = fresh_tid(wave_s);
   double* xs = nlds;            // (V,3) current x
   double* ps = xs + 3 * V;      // (V,3) PCG direction p, later the line-search candidate
   double* hv = ps + 3 * V;      // (12, CH) per-tet rows of the current window
@@ -974,13 +1018,21 @@ __global__ __launch_bounds__(kNwtThreads) void fem_newton_lds_kernel(FemDev m, d
   // friction (tacex_fem_step with a friction ratio): (V,4) lagged normal force and normal, (V,6) Hessian blocks (floats)
   const bool fric_lds = m.indenters && m.area && m.fric_mu > 0.0 && xprevg != nullptr && dispg != nullptr;
   double* fl = sh + 18;
-  float* cf = reinterpret_cast<float*>(fl + (fric_lds ? 4 * V : 0));  // (V,15) chain factors: S^-1 (6, upper triangle) | G (9)
+  double* mdl = fl + (fric_lds ? 4 * V : 0);  // (V) diagonal mass term m_v (1 + s c_v): read back per PCG iteration (per-thread constants
+                                              // carried in registers across the tet arithmetic went to scratch)
+  float* cf = reinterpret_cast<float*>(mdl + V);  // (V,15) chain factors: S^-1 (6, upper triangle) | G (9)
   float* fh = cf + 15 * V;
   unsigned short* csr = reinterpret_cast<unsigned short*>(fh + (fric_lds ? 6 * V : 0));  // (4T) incidence codes tet * 4 + local, vertex-major
   unsigned short* cnx = csr + 4 * T;  // (V) chain successor | (V) predecessor, 0xffff = none
   unsigned short* cpv = cnx + V;
+  unsigned short* chd = cpv + V;      // (kNwtThreads) head vertex of the chain thread t factors and solves, 0xffff = none
+  unsigned short* vto = chd + kNwtThreads;  // (V+1) CSR offsets of the incidence codes (4 T < 65535)
   int phase = 0;  // block_sum1 row toggle
-  const int b = blockIdx.x;
+  // env_order: envs sorted by the solver work of their PREVIOUS time step, heaviest first (fem_env_order_kernel).  One env
+  // occupies one CU for its whole Newton loop and a shard brings several envs per CU, so the launch ends with whatever the
+  // last-started envs need: started in index order, the heavy envs of a scene may all come last.  Workgroups are dispatched
+  // in blockIdx order, so this is longest-processing-time-first list scheduling with last step's cost as the estimate.
+  const int b = env_order ? env_order[blockIdx.x] : (int)blockIdx.x;
   if (dxg && dxg[b] <= dx_tol) {  // this env's last update was below the Newton tolerance (uipc_sim.py:62-66): nothing to do
     if (threadIdx.x == 0) { stats[(size_t)b * 4 + 2] = 0.0; stats[(size_t)b * 4 + 3] = 0.0; }
     return;
@@ -993,7 +1045,6 @@ __global__ __launch_bounds__(kNwtThreads) void fem_newton_lds_kernel(FemDev m, d
   const bool c = own && consg && consg[(size_t)b * V + tid];
   const double dt2 = m.dt * m.dt;
   const int nchunk = (T + CH - 1) / CH;
-  const int e_begin = own ? m.vt_off[tid] : 0, e_end = own ? m.vt_off[tid + 1] : 0;
   const double mv = own ? m.mass[tid] : 0.0;
   const double md = mv * (1.0 + (c ? m.strength : 0.0));
   // contact: this vertex's weight and the env's indenter (nullptr: contact off)
@@ -1017,9 +1068,14 @@ __global__ __launch_bounds__(kNwtThreads) void fem_newton_lds_kernel(FemDev m, d
   }
   const int nch = m.ch_next ? m.nch : V;
   // the chain a thread factors and solves: chains are dealt from the TOP thread down, so that their solves overlap the coarse
-  // solve, which keeps the low threads busy
-  const int my_chain = kNwtThreads - 1 - tid;
-  const int my_head = my_chain < nch ? (m.ch_next ? m.ch_head[my_chain] : my_chain) : -1;
+  // solve, which keeps the low threads busy.  The head vertex is looked up in LDS where it is needed (chain_head).
+  {
+    const int my_chain = kNwtThreads - 1 - tid;
+    chd[tid] = (unsigned short)(my_chain < nch ? (m.ch_next ? m.ch_head[my_chain] : my_chain) : 0xffff);
+    for (int k = tid; k <= V; k += kNwtThreads) vto[k] = (unsigned short)m.vt_off[k];
+    if (own) mdl[tid] = md;
+  }
+  auto chain_head = [&](int t) -> int { const int h = chd[t]; return h == 0xffff ? -1 : h; };
   __syncthreads();
 
 #ifdef TACEX_FEM_CLOCK  // debug build: cycles (s_memtime) of the sections of a PCG iteration, group TACEX_FEM_CLOCK of four -> stats
@@ -1037,7 +1093,9 @@ __global__ __launch_bounds__(kNwtThreads) void fem_newton_lds_kernel(FemDev m, d
   // (CSR entries are sorted by tet, so a cursor suffices).  The mesh constants of the NEXT window are fetched while this
   // window is computed and gathered (they are the only global reads of the sweep).
   auto sweep = [&](auto&& make, double acc[3]) {
-    int e = e_begin;
+    const int tid_s = fresh_tid(wave_s);
+    int e = tid_s < V ? (int)vto[tid_s] : 0;
+    const int e_end = tid_s < V ? (int)vto[tid_s + 1] : 0;
     int code = e < e_end ? (int)csr[e] : 0x7fffffff;
     int code1 = e + 1 < e_end ? (int)csr[e + 1] : 0x7fffffff;
     acc[0] = acc[1] = acc[2] = 0.0;
@@ -1045,13 +1103,13 @@ __global__ __launch_bounds__(kNwtThreads) void fem_newton_lds_kernel(FemDev m, d
     double Din[kNwtTpw][9], voln[kNwtTpw];
 #pragma unroll
     for (int u = 0; u < kNwtTpw; ++u) {
-      const int t = u * kNwtThreads + tid;
+      const int t = u * kNwtThreads + tid_s;
       voln[u] = 0.0;
 #pragma unroll
       for (int k = 0; k < 4; ++k) vn[u][k] = 0;
 #pragma unroll
       for (int k = 0; k < 9; ++k) Din[u][k] = 0.0;
-      if (t < T) { load_tet(m, t, vn[u], Din[u]); voln[u] = m.vol[t]; }
+      if (t < T) load_tet_blk(m, t, vn[u], Din[u], voln[u]);
     }
     for (int j = 0; j < nchunk; ++j) {
       FEM_TICK0();
@@ -1064,8 +1122,8 @@ __global__ __launch_bounds__(kNwtThreads) void fem_newton_lds_kernel(FemDev m, d
         for (int k = 0; k < 4; ++k) v[u][k] = vn[u][k];
 #pragma unroll
         for (int k = 0; k < 9; ++k) Di[u][k] = Din[u][k];
-        const int tn = (j + 1) * CH + u * kNwtThreads + tid;
-        if (tn < T) { load_tet(m, tn, vn[u], Din[u]); voln[u] = m.vol[tn]; }
+        const int tn = (j + 1) * CH + u * kNwtThreads + tid_s;
+        if (tn < T) load_tet_blk(m, tn, vn[u], Din[u], voln[u]);
       }
 #pragma unroll
       for (int u = 0; u < kNwtTpw; ++u) {
@@ -1185,7 +1243,7 @@ __global__ __launch_bounds__(kNwtThreads) void fem_newton_lds_kernel(FemDev m, d
 #pragma unroll
         for (int k = 0; k < 3; ++k) D[i * 3 + k] += cb2 * ce.n[i] * ce.n[k];
       const int nv = cnx[tid] == 0xffff ? -1 : (int)cnx[tid];
-      for (int e = e_begin; e < e_end; ++e) {
+      for (int e = (int)vto[tid], e_end = (int)vto[tid + 1]; e < e_end; ++e) {
         const int code = csr[e];
         const int t = code >> 2, l = code & 3;
         int v[4];
@@ -1229,6 +1287,7 @@ __global__ __launch_bounds__(kNwtThreads) void fem_newton_lds_kernel(FemDev m, d
       for (int k = 0; k < 9; ++k) q[6 + k] = E[k];
     }
     __syncthreads();
+    const int my_head = chain_head(tid);
     if (my_head >= 0) {
       int v = my_head;
       double S[9];
@@ -1293,15 +1352,18 @@ __global__ __launch_bounds__(kNwtThreads) void fem_newton_lds_kernel(FemDev m, d
     z[0] = z[1] = z[2] = 0.0;
     FEM_TICK(2);
     __syncthreads();  // every thread is done with the window of the last sweep
-    if (own) {
+    const int tid_p = fresh_tid(wave_s);  // (fresh_tid: the LDS / table offsets below are rebuilt per application, never carried)
+    const bool own_p = tid_p < V;
+    if (own_p) {
 #pragma unroll
-      for (int i = 0; i < 3; ++i) rs[tid * 3 + i] = r[i];
+      for (int i = 0; i < 3; ++i) rs[tid_p * 3 + i] = r[i];
     }
     __syncthreads();
     FEM_TICK(3);
     // chain solve z = L^-T S^-1 L^-1 r by the chain's thread: down the chain y_i = r_i - G_{i-1}^T y_{i-1}, back up
     // z_i = S_i^-1 y_i - G_i z_{i+1}
     auto chain_solve = [&]() {
+      const int my_head = chain_head(tid_p);
       if (my_head < 0) return;
       int v = my_head, last = my_head;
       double y[3] = {rs[v * 3], rs[v * 3 + 1], rs[v * 3 + 2]};
@@ -1337,20 +1399,20 @@ __global__ __launch_bounds__(kNwtThreads) void fem_newton_lds_kernel(FemDev m, d
     if (nc3 == 0) {
       chain_solve();
       __syncthreads();
-      if (own) {
+      if (own_p) {
 #pragma unroll
-        for (int i = 0; i < 3; ++i) z[i] = zs[tid * 3 + i];
+        for (int i = 0; i < 3; ++i) z[i] = zs[tid_p * 3 + i];
       }
       return;
     }
     {  // Gn lanes per coarse NODE, all three components: one (vertex, weight) fetch serves three sums
-      const int node = tid / Gn, j = tid - node * Gn;
+      const int node = tid_p / Gn, j = tid_p - node * Gn;
       double a0 = 0.0, a1 = 0.0, a2 = 0.0;
       if (node < m.nc) {
-        const int e1 = m.cn_off[node + 1];
-        for (int e = m.cn_off[node] + j; e < e1; e += Gn) {
-          const int v0 = m.cn_vtx[e];
-          const double w0 = m.cn_w[e];
+        const int e1 = ldg_off<int>(m.cn_off, (unsigned)(node + 1) * 4u);
+        for (int e = ldg_off<int>(m.cn_off, (unsigned)node * 4u) + j; e < e1; e += Gn) {
+          const int v0 = ldg_off<int>(m.cn_vtx, (unsigned)e * 4u);
+          const double w0 = ldg_off<double>(m.cn_w, (unsigned)e * 8u);
           a0 += w0 * rs[v0 * 3]; a1 += w0 * rs[v0 * 3 + 1]; a2 += w0 * rs[v0 * 3 + 2];
         }
       }
@@ -1363,12 +1425,12 @@ __global__ __launch_bounds__(kNwtThreads) void fem_newton_lds_kernel(FemDev m, d
     FEM_TICK(5);
     {  // coarse solve y = A_c^-1 r_c: H lanes per row, each over a slice of its (contiguous) row.  The chain solves run beside it
        // on the threads it leaves idle (chains are dealt from the top).
-      const int dof = tid / H, h = tid - dof * H;
+      const int dof = tid_p / H, h = tid_p - dof * H;
       double acc = 0.0;
       if (dof < nc3) {
-        const double* row = m.ac_inv + (size_t)dof * nc3;
+        const unsigned row = (unsigned)(dof * nc3) * 8u;  // (3 nc)^2 doubles <= 288 KB: 32-bit byte offsets
         const int q1 = min(nc3, (h + 1) * Q);
-        for (int q = h * Q; q < q1; ++q) acc += row[q] * rc[q];
+        for (int q = h * Q; q < q1; ++q) acc += ldg_off<double>(m.ac_inv, row + (unsigned)q * 8u) * rc[q];
       }
       for (int o = H >> 1; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
       if (dof < nc3 && h == 0) yc[dof] = acc;
@@ -1376,13 +1438,13 @@ __global__ __launch_bounds__(kNwtThreads) void fem_newton_lds_kernel(FemDev m, d
     chain_solve();
     __syncthreads();
     FEM_TICK(6);
-    if (own) {
+    if (own_p) {
 #pragma unroll
-      for (int i = 0; i < 3; ++i) z[i] = zs[tid * 3 + i];
+      for (int i = 0; i < 3; ++i) z[i] = zs[tid_p * 3 + i];
 #pragma unroll
       for (int k = 0; k < 8; ++k) {
-        const int node = m.cv_node[tid * 8 + k];
-        const double w = m.cv_w[tid * 8 + k];
+        const int node = ldg_off<int>(m.cv_node, (unsigned)tid_p * 32u + (unsigned)k * 4u);
+        const double w = ldg_off<double>(m.cv_w, (unsigned)tid_p * 64u + (unsigned)k * 8u);
 #pragma unroll
         for (int i = 0; i < 3; ++i) z[i] += w * yc[node * 3 + i];
       }
@@ -1413,13 +1475,12 @@ __global__ __launch_bounds__(kNwtThreads) void fem_newton_lds_kernel(FemDev m, d
   }
   int it = 0;
   while (warm || (it < pcg_max_iter && rz_b > 0.0 && rz > pcg_tol_rate * pcg_tol_rate * rz_b)) {
-    double q3[3];  // the vector H is applied to
+    double q3[3] = {0, 0, 0};  // the vector H is applied to (d0 of the warm start, else p): lives in ps during the sweep
+    const int tid = fresh_tid(wave_s);  // (shadows the kernel-wide copy: nothing derived from it crosses an iteration)
     FEM_TICK0();
-#pragma unroll
-    for (int i = 0; i < 3; ++i) q3[i] = warm ? d3[i] : p3[i];
     if (own) {
 #pragma unroll
-      for (int i = 0; i < 3; ++i) ps[tid * 3 + i] = q3[i];
+      for (int i = 0; i < 3; ++i) ps[tid * 3 + i] = warm ? d3[i] : p3[i];
     }
     __syncthreads();
     // Hq = (M + s Mc + dt^2 K) q, matrix-free: per-tet dP[dF(q)] rows, gathered per vertex
@@ -1440,11 +1501,19 @@ __global__ __launch_bounds__(kNwtThreads) void fem_newton_lds_kernel(FemDev m, d
           rows[w * 3 + i] = sc * (dP[i * 3 + 0] * r[w * 3 + 0] + dP[i * 3 + 1] * r[w * 3 + 1] + dP[i * 3 + 2] * r[w * 3 + 2]);
     }, a3);
     FEM_TICK(0);
+    // (q is read back from LDS - the sweep leaves ps alone - rather than carried in registers across the tet arithmetic: the loop
+    //  body holds ~250 live registers there, and every value carried across it went to scratch)
+    double mdv = 0.0;
+    if (own) {
+#pragma unroll
+      for (int i = 0; i < 3; ++i) q3[i] = ps[tid * 3 + i];
+      mdv = mdl[tid];
+    }
     double Hp3[3];
     part = 0.0;
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
-      Hp3[i] = own ? a3[i] + md * q3[i] + cb2 * ce.n[i] * (ce.n[0] * q3[0] + ce.n[1] * q3[1] + ce.n[2] * q3[2]) : 0.0;
+      Hp3[i] = own ? a3[i] + mdv * q3[i] + cb2 * ce.n[i] * (ce.n[0] * q3[0] + ce.n[1] * q3[1] + ce.n[2] * q3[2]) : 0.0;
     }
     if (fric_phase && own) {
       const float* h = fh + tid * 6;
@@ -1588,6 +1657,42 @@ __global__ __launch_bounds__(kNwtThreads) void fem_newton_lds_kernel(FemDev m, d
       step_info[(size_t)b * 4 + 2] = (double)any; step_info[(size_t)b * 4 + 3] = pcg_total;
     }
   }
+}
+
+// Launch order of the envs for the next Newton launch: counting sort (descending) by the work of the env's previous step,
+// key = PCG iterations + 6 per Newton iteration (gradient, block assembly and line search cost about six sweeps), from the
+// step_info rows the previous tacex_fem_step left behind (zeros before the first step: index order).  One workgroup; the order
+// inside a bucket is whatever the atomics give - it only decides WHEN an env runs, never what it computes.
+__global__ __launch_bounds__(1024) void fem_env_order_kernel(const double* __restrict__ step_info, int B, int* __restrict__ order) {
+  constexpr int kKeys = 2048;
+  __shared__ int hist[kKeys], start[kKeys];
+  for (int k = threadIdx.x; k < kKeys; k += blockDim.x) hist[k] = 0;
+  __syncthreads();
+  auto key_of = [&](int b) {
+    const double w = step_info[(size_t)b * 4 + 3] + 6.0 * step_info[(size_t)b * 4 + 0];
+    return (w >= 0.0 && w < (double)(kKeys - 1)) ? (int)w : (w >= (double)(kKeys - 1) ? kKeys - 1 : 0);  // (NaN -> 0)
+  };
+  for (int b = threadIdx.x; b < B; b += blockDim.x) atomicAdd(&hist[key_of(b)], 1);
+  __syncthreads();
+  if (threadIdx.x < 64) {  // exclusive scan from the heaviest key down, one wave: 32 keys per lane + a lane scan
+    const int lane = threadIdx.x;
+    int loc = 0;
+    for (int k = 0; k < kKeys / 64; ++k) loc += hist[kKeys - 1 - (lane * (kKeys / 64) + k)];
+    int inc = loc;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int up = __shfl_up(inc, o, 64);
+      if (lane >= o) inc += up;
+    }
+    int acc = inc - loc;
+    for (int k = 0; k < kKeys / 64; ++k) {
+      const int key = kKeys - 1 - (lane * (kKeys / 64) + k);
+      start[key] = acc;
+      acc += hist[key];
+    }
+  }
+  __syncthreads();
+  for (int b = threadIdx.x; b < B; b += blockDim.x) order[atomicAdd(&start[key_of(b)], 1)] = b;
 }
 
 // backward-Euler predictor of tacex_fem_step: x_prev = x, x_tilde = x + dt v + dt^2 g (US:250-252: what world.advance() starts from)
@@ -1809,8 +1914,17 @@ int tacex_fem_create(int device_id, const tacex_fem_params* p, tacex_fem_ctx** o
       for (int k = 0; k < 9; ++k) rec2[(size_t)n * 12 + 2 + k] = dminv2[(size_t)k * T + n];
       rec2[(size_t)n * 12 + 11] = vol2[n];
     }
+    const int nblk = (T + 63) / 64;
+    std::vector<double> blk2((size_t)nblk * (kTetBlkBytes / 8), 0.0);
+    for (int n = 0; n < T; ++n) {
+      char* base = reinterpret_cast<char*>(blk2.data()) + (size_t)(n >> 6) * kTetBlkBytes;
+      const int ln = n & 63;
+      for (int k = 0; k < 9; ++k) memcpy(base + k * 512 + ln * 8, &dminv2[(size_t)k * T + n], 8);
+      memcpy(base + 4608 + ln * 8, &vol2[n], 8);
+      for (int k = 0; k < 4; ++k) memcpy(base + 5120 + k * 256 + ln * 4, &tets2[(size_t)k * T + n], 4);
+    }
     c->dev_nwt = d;
-    rc = fem_upload(c, tets2, &c->dev_nwt.tets) | fem_upload(c, dminv2, &c->dev_nwt.dminv) | fem_upload(c, vol2, &c->dev_nwt.vol) |
+    rc = fem_upload(c, blk2, &c->dev_nwt.tet_blk) | fem_upload(c, tets2, &c->dev_nwt.tets) | fem_upload(c, dminv2, &c->dev_nwt.dminv) | fem_upload(c, vol2, &c->dev_nwt.vol) |
          fem_upload(c, idx2, &c->dev_nwt.vt_idx) | fem_upload(c, rec2, &c->dev_nwt.tet_rec);
   }
   if (rc) { tacex_fem_destroy(c); return rc; }
@@ -1838,7 +1952,8 @@ void tacex_fem_destroy(tacex_fem_ctx* c) {
 size_t tacex_fem_workspace_bytes(const tacex_fem_ctx* c, int B) {
   if (!c || B <= 0) return 0;
   // env blocks | x_prev (B,V,3) | max |d| (B) | indenter displacement (B,3) | previous indenter position (B,3)
-  return ((size_t)B * newton_ws_doubles(c->dev.V, c->dev.T) + (size_t)B * 3 * c->dev.V + (size_t)7 * B + 8) * sizeof(double);
+  // ... | env launch order (B int32, rounded up to doubles)
+  return ((size_t)B * newton_ws_doubles(c->dev.V, c->dev.T) + (size_t)B * 3 * c->dev.V + (size_t)7 * B + 8 + ((size_t)B + 1) / 2) * sizeof(double);
 }
 
 int tacex_fem_element_terms(tacex_fem_ctx* c, const double* x, double* energy, double* grad, double* hess,
@@ -2107,13 +2222,15 @@ int tacex_fem_set_newton_early_exit(tacex_fem_ctx* c, double* dx_dev, double dx_
 // streaming fallback (mesh with more vertices than a workgroup has threads; TACEX_FEM_NEWTON_LDS=0)
 static int launch_newton(tacex_fem_ctx* c, double* x, const double* xt, const uint8_t* cons, const double* aim, double* stats, void* ws,
                          int B, int pcg_max_iter, double pcg_tol_rate, int ls_max_iter, double* dx_dev, double dx_tol, int max_newton,
-                         double* step_info, hipStream_t st, bool* resident, const double* xprev = nullptr, const double* disp = nullptr) {
+                         double* step_info, hipStream_t st, bool* resident, const double* xprev = nullptr, const double* disp = nullptr,
+                         const int* env_order = nullptr) {
   static const int use_lds = getenv("TACEX_FEM_NEWTON_LDS") ? atoi(getenv("TACEX_FEM_NEWTON_LDS")) : 1;
   const bool fric = xprev && disp && c->dev.indenters && c->dev.fric_mu > 0.0;
   // x, p | window | sums | [friction lag] || chain factors | [friction Hessian blocks] (floats) || incidence codes | chain links (u16)
-  const size_t lds = ((((size_t)6 * c->dev.V + (size_t)12 * kNwtChunk + 18 + (fric ? (size_t)4 * c->dev.V : 0)) * sizeof(double) +
+  // ... | diagonal mass term (V doubles) ... | chain heads per thread | CSR offsets (u16)
+  const size_t lds = ((((size_t)7 * c->dev.V + (size_t)12 * kNwtChunk + 18 + (fric ? (size_t)4 * c->dev.V : 0)) * sizeof(double) +
                        ((size_t)15 * c->dev.V + (fric ? (size_t)6 * c->dev.V : 0)) * sizeof(float) +
-                       ((size_t)4 * c->dev.T + 2 * (size_t)c->dev.V) * sizeof(unsigned short)) + 15) & ~(size_t)15;
+                       ((size_t)4 * c->dev.T + 3 * (size_t)c->dev.V + kNwtThreads + 1) * sizeof(unsigned short)) + 15) & ~(size_t)15;
   if (use_lds && c->dev.V <= kNwtThreads && 4 * c->dev.T < 65535 && lds <= 160 * 1024) {
     if (resident) *resident = true;
     static size_t granted[2][64] = {};  // per device: the attribute is per kernel AND device
@@ -2123,7 +2240,7 @@ static int launch_newton(tacex_fem_ctx* c, double* x, const double* xt, const ui
     if (ea == hipSuccess) ea = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds, granted[mesh ? 1 : 0]);
     if (ea != hipSuccess) return fail_hip(ea, "hipFuncSetAttribute(fem_newton_lds_kernel)");
     hipLaunchKernelGGL(kern, dim3(B), dim3(kNwtThreads), lds, st, c->dev_nwt, x, xt, cons, aim, stats, pcg_max_iter,
-                       pcg_tol_rate, ls_max_iter, dx_dev, dx_tol, max_newton, step_info, fric ? xprev : nullptr, fric ? disp : nullptr);
+                       pcg_tol_rate, ls_max_iter, dx_dev, dx_tol, max_newton, step_info, fric ? xprev : nullptr, fric ? disp : nullptr, env_order);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : fail_hip(e, "fem_newton_lds_kernel");
   }
@@ -2172,9 +2289,18 @@ int tacex_fem_step(tacex_fem_ctx* c, double* x, double* v, double* xt, const uin
                      gravity[1], gravity[2], ind, ind_prev, disp, (ind && c->ind_prev_ws == ws && c->ind_prev_B == B) ? 1 : 0);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail_hip(e, "fem_predict_kernel");
+  // heaviest envs first (see fem_newton_lds_kernel): worth it once a CU gets more than one env; TACEX_FEM_ORDER=0 = index order (A/B)
+  static const int use_order = getenv("TACEX_FEM_ORDER") ? atoi(getenv("TACEX_FEM_ORDER")) : 1;
+  int* env_order = nullptr;
+  if (use_order && B > 1) {
+    env_order = reinterpret_cast<int*>(ind_prev + (size_t)3 * B + 1);  // behind the (B,3) previous indenter positions (tacex_fem_workspace_bytes)
+    hipLaunchKernelGGL(fem_env_order_kernel, dim3(1), dim3(1024), 0, st, step_info, B, env_order);
+    e = hipGetLastError();
+    if (e != hipSuccess) return fail_hip(e, "fem_env_order_kernel");
+  }
   bool resident = false;
   if (int rc = launch_newton(c, x, xt, cons, aim, stats, ws, B, pcg_max_iter, pcg_tol_rate, ls_max_iter, dx, tol, max_newton, step_info, st,
-                             &resident, xprev, disp))
+                             &resident, xprev, disp, env_order))
     return rc;
   if (!resident) {
     // streaming fallback: one launch per Newton iteration on a FIXED schedule; converged envs return at once (dx protocol), so the
