@@ -32,7 +32,7 @@ extern "C" {
 #endif
 
 #define TACEX_MAX_LEVELS 8
-#define TACEX_ABI_VERSION 6
+#define TACEX_ABI_VERSION 7
 
 typedef struct tacex_taxim_ctx tacex_taxim_ctx;
 typedef struct tacex_fots_ctx tacex_fots_ctx;
@@ -374,6 +374,12 @@ int tacex_fem_set_contact(tacex_fem_ctx* ctx, const double* vertex_area_host, do
  * two steps is not part of the displacement - a spinning indenter drags the pad as if it only translated.
  * Acts inside tacex_fem_step only (tacex_fem_newton_step has no notion of the step's start).  friction_ratio 0 = off. */
 int tacex_fem_set_friction(tacex_fem_ctx* ctx, double friction_ratio, double eps_velocity);
+
+/* Contact-following start of tacex_fem_step's Newton loop (default on): a surface vertex inside the barrier zone of the indenter's
+ * previous position starts the iteration displaced by the indenter's translation since the previous step (its gap is what it was).
+ * An initial guess only - the step's minimiser is unchanged - but the one that lets a RETREATING indenter cost 2-3 Newton iterations
+ * like a pressing one instead of 4-30 (libuipc starts from the current positions: world.advance(), US:250-252; 0 restores that). */
+int tacex_fem_set_contact_following(tacex_fem_ctx* ctx, int enable);
 
 /* Two-level preconditioner of the Newton system (CU-resident kernel): z = D^-1 r (3x3 block Jacobi, always) + P A_c^-1 P^T r.
  * P: every vertex has 8 (coarse node, weight) pairs - the trilinear hat functions of a small grid laid over the mesh

@@ -605,13 +605,23 @@ class FrictionModel:
         self.disp = np.asarray(disp, np.float64)
         self.update(self.x_n)
 
-    def update(self, x):
-        """Freeze normal force and normal at the iterate x (the start of a Newton iteration)."""
+    def update(self, x, g_other=None):
+        """Freeze normal force and normal at the iterate x (the start of a Newton iteration).  `g_other` (V,3): gradient of the
+        step's potential WITHOUT the contact terms (inertia + elasticity + constraints) at x.  In force balance the barrier force on
+        a vertex is exactly the reaction to it, lam = (g_other . n) / dt^2; the lag takes the SMALLER of the two.  Why: the Newton
+        loop stops on its step-size tolerance (velocity_tol * dt = 0.5 mm, US:62-66), where a contact vertex may still sit at
+        0.98 d_hat - there the 10 GPa barrier pushes with 87 N on a pad whose whole reaction is below 1 N, the lagged friction force
+        is two orders of magnitude above anything the gel can oppose, the first friction iteration's direction measures 0.66 m and
+        the env needs 34 Newton iterations / 1 900 PCG iterations (scene step 11, env 442: profiles/r04_experiments.md) while the
+        launch waits for it.  At convergence both expressions agree, so the capped lag is IPC's lag wherever IPC's is meaningful."""
         cm = self.cm
         d, n = contact_distance(cm.ind, x, cm.mesh)
         _, b1, _ = barrier(d / cm.dhat)
         with np.errstate(invalid="ignore"):
             self.lam = np.where(cm.area > 0, -cm.kappa * cm.area * b1 / cm.dhat, 0.0)  # normal force [N] per vertex, >= 0
+            if g_other is not None:
+                react = np.maximum((np.asarray(g_other, np.float64) * n).sum(-1) / self.dt**2, 0.0)
+                self.lam = np.where(self.lam > 0, np.minimum(self.lam, react), self.lam)
         self.n = np.where((self.lam > 0)[:, None], n, 0.0)
 
     def _u(self, x):
@@ -668,13 +678,27 @@ def newton_step_contact(m: "FemModel", cm: ContactModel, x, x_tilde, constrained
 
 
 def fem_step(m: "FemModel", cm, x, v, constrained=None, aim=None, gravity=(0.0, 0.0, -9.8), max_newton=8, velocity_tol=0.05,
-             pcg_max_iter=1024, pcg_tol_rate=1e-3, ls_max_iter=8, coarse=None, friction=None, chains=None):
+             pcg_max_iter=1024, pcg_tol_rate=1e-3, ls_max_iter=8, coarse=None, friction=None, chains=None, indenter_disp=None):
     """One backward-Euler step of ONE env the way `tacex_fem_step` runs it (what world.advance() does, US:250-252):
     x_tilde = x + dt v + dt^2 g; Newton iterations until the UNSCALED Newton direction of one has max |d| <= velocity_tol * dt
     (US:62-66; IPC's test on the search direction) or the cap; v = (x_new - x) / dt.  Returns (x_new, v_new, info) with
     info = [newton_iterations, max |d| of the last iteration, flags (2: a line search failed), pcg_iterations_total]."""
     x0 = x
     xt = x + m.dt * v + m.dt**2 * np.asarray(gravity, np.float64)
+    # contact-following start (fem_newton_lds_kernel, `follow`): a surface vertex the indenter retreats from (disp . n < 0) and that
+    # lands inside the barrier zone when moved by that normal component starts the Newton loop at x + (disp . n) n
+    # (`indenter_disp`, default: the friction tuple's displacement).  An initial guess only.
+    if indenter_disp is None and friction is not None:
+        indenter_disp = friction[2]
+    if cm is not None and indenter_disp is not None and np.any(np.asarray(indenter_disp) != 0.0):
+        d0, n0 = contact_distance(cm.ind, x, cm.mesh)
+        dn = n0 @ np.asarray(indenter_disp, np.float64)  # < 0: the indenter's surface moves away from the vertex (retreat)
+        with np.errstate(invalid="ignore"):
+            xm = x + dn[:, None] * n0
+        cand = (cm.area > 0) & (dn < 0) & (d0 > 0) & np.isfinite(d0)
+        dm, _ = contact_distance(cm.ind, np.where(cand[:, None], xm, x), cm.mesh)
+        follow = cand & (dm > 0) & (dm < cm.dhat)
+        x = np.where(follow[:, None], xm, x)
     # friction = (mu, eps_velocity, indenter displacement since the previous step): second phase, see FrictionModel
     fric_pending = friction is not None and cm is not None
     fr = None
@@ -696,7 +720,7 @@ def fem_step(m: "FemModel", cm, x, v, constrained=None, aim=None, gravity=(0.0, 
             if fric_pending:  # normal contact is balanced: take the friction lag from here and go on
                 fric_pending = False
                 fr = FrictionModel(cm, x0, friction[2], friction[0], friction[1])
-                fr.update(x)
+                fr.update(x, m.gradient(x, xt, constrained, aim))
                 if fr.lam.max() > 0.0:
                     continue
             break

@@ -1005,7 +1005,8 @@ __global__ __launch_bounds__(kNwtThreads) void fem_newton_lds_kernel(FemDev m, d
                                                                      const uint8_t* consg, const double* aimg, double* stats,
                                                                      int pcg_max_iter, double pcg_tol_rate, int ls_max_iter,
                                                                      double* dxg, double dx_tol, int max_newton, double* step_info,
-                                                                     const double* xprevg, const double* dispg, const int* env_order) {
+                                                                     const double* xprevg, const double* dispg, const int* env_order,
+                                                                     int follow) {
   extern __shared__ __attribute__((aligned(16))) double nlds[];
   constexpr int CH = kNwtChunk;
   const int V = m.V, T = m.T;
@@ -1016,7 +1017,7 @@ __global__ __launch_bounds__(kNwtThreads) void fem_newton_lds_kernel(FemDev m, d
   double* hv = ps + 3 * V;      // (12, CH) per-tet rows of the current window
   double* sh = hv + 12 * CH;    // 2 x 8 wave partials of block_sum1 (+2 pad)
   // friction (tacex_fem_step with a friction ratio): (V,4) lagged normal force and normal, (V,6) Hessian blocks (floats)
-  const bool fric_lds = m.indenters && m.area && m.fric_mu > 0.0 && xprevg != nullptr && dispg != nullptr;
+  const bool fric_lds = m.indenters && m.area && m.fric_mu > 0.0 && xprevg != nullptr && dispg != nullptr;  // (xprevg is only handed over with friction)
   double* fl = sh + 18;
   double* mdl = fl + (fric_lds ? 4 * V : 0);  // (V) diagonal mass term m_v (1 + s c_v): read back per PCG iteration (per-thread constants
                                               // carried in registers across the tet arithmetic went to scratch)
@@ -1054,12 +1055,33 @@ __global__ __launch_bounds__(kNwtThreads) void fem_newton_lds_kernel(FemDev m, d
   const bool fric = ind && m.fric_mu > 0.0 && xprevg != nullptr && dispg != nullptr;
   const double* xn = fric ? xprevg + o : nullptr;
   double disp3[3] = {0, 0, 0};
-  if (fric) { disp3[0] = dispg[b * 3]; disp3[1] = dispg[b * 3 + 1]; disp3[2] = dispg[b * 3 + 2]; }
+  if (ind && dispg) { disp3[0] = dispg[b * 3]; disp3[1] = dispg[b * 3 + 1]; disp3[2] = dispg[b * 3 + 2]; }
 
   double x3[3] = {0, 0, 0};
   if (own) {
 #pragma unroll
-    for (int i = 0; i < 3; ++i) { x3[i] = x[tid * 3 + i]; xs[tid * 3 + i] = x3[i]; }
+    for (int i = 0; i < 3; ++i) x3[i] = x[tid * 3 + i];
+    // CONTACT-FOLLOWING START of the Newton loop (tacex_fem_step, `follow`): a surface vertex the indenter RETREATS from (its surface
+    // moves away along the vertex's contact normal: disp . n < 0) and that sat inside the barrier zone before the move starts the
+    // iteration displaced by that normal component, x += (disp . n) n - back at the gap it had.  Only the initial guess changes; the
+    // minimiser of the step's incremental potential is what it was.  Without it a retreating indenter leaves its contact vertices
+    // outside the zone, the first Newton direction springs the dent back by a millimetre into a barrier that is a hard wall for this
+    // soft gel, the line search cuts the step to 1e-3 and the contact set is rediscovered a ring of vertices per iteration: 4-5 Newton
+    // iterations of ~25 PCG iterations per env and step (stragglers: 17-32 iterations, 1 000-1 800 PCG iterations on ONE CU, and the
+    // launch waits for them) against 2 iterations of 2 while the indenter presses.  Where the indenter APPROACHES (disp . n >= 0)
+    // nothing is moved: the shrunken gap raises the barrier force and that start already converges in two iterations (following
+    // there was measured: the over-displaced surface has to come back up into the barrier and line searches fail).
+    if (follow && ind && wv > 0.0 && (disp3[0] != 0.0 || disp3[1] != 0.0 || disp3[2] != 0.0)) {
+      const ContactEval c0 = contact_eval<MESH>(m, ind, wv, x3);
+      const double dn = disp3[0] * c0.n[0] + disp3[1] * c0.n[1] + disp3[2] * c0.n[2];
+      if (dn < 0.0 && !c0.penetrating && c0.d < 1e299) {
+        const double xm[3] = {x3[0] + dn * c0.n[0], x3[1] + dn * c0.n[1], x3[2] + dn * c0.n[2]};
+        const ContactEval cf = contact_eval<MESH>(m, ind, wv, xm);
+        if (cf.active && !cf.penetrating) { x3[0] = xm[0]; x3[1] = xm[1]; x3[2] = xm[2]; }
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) xs[tid * 3 + i] = x3[i];
   }
   for (int k = tid; k < 4 * T; k += kNwtThreads) csr[k] = (unsigned short)m.vt_idx[k];
   if (own) {
@@ -1175,6 +1197,7 @@ __global__ __launch_bounds__(kNwtThreads) void fem_newton_lds_kernel(FemDev m, d
   double dprev[3] = {0, 0, 0};
   double frac_prev = 0.0;  // (1 - accepted step) of the previous iteration, 0 when it was taken in full or rejected
   bool fric_phase = false;  // friction terms are on (second phase of the loop, see friction_eval)
+  bool lag_pending = false; // the friction lag is taken in the iteration that follows the converged normal-contact solve (see below)
   for (int nit = 0; nit < max_newton; ++nit) {
   if (nit > 0) __syncthreads();  // xs carries the accepted candidate of the previous iteration
 #ifdef TACEX_FEM_CLOCK
@@ -1185,6 +1208,7 @@ __global__ __launch_bounds__(kNwtThreads) void fem_newton_lds_kernel(FemDev m, d
 #endif
   // ---- nodal gradient ----
   double r3[3], d3[3] = {0, 0, 0};
+  double go3[3] = {0, 0, 0};  // gradient WITHOUT the contact terms (inertia + elasticity + constraints): the reaction a contact balances
   {
     double a3[3];
     sweep([&](const int* v, const double* Di, double vol, double* g) {
@@ -1203,6 +1227,7 @@ __global__ __launch_bounds__(kNwtThreads) void fem_newton_lds_kernel(FemDev m, d
         if (c) gi += m.strength * mv * (x3[i] - aim[tid * 3 + i]);
       }
       r3[i] = -gi;
+      go3[i] = gi;
     }
   }
   // barrier of this vertex at x: gradient b1 n, curvature b2 n n^T (the b1 * hess(d) part is negative semi-definite for a
@@ -1214,6 +1239,27 @@ __global__ __launch_bounds__(kNwtThreads) void fem_newton_lds_kernel(FemDev m, d
     for (int i = 0; i < 3; ++i) r3[i] -= dt2 * ce.b1 * ce.n[i];
   }
   const double cb2 = ce.active ? dt2 * ce.b2 : 0.0;
+  // FRICTION LAG (normal force lam, normal n per vertex), taken once per step at the state the normal-contact solve converged to:
+  // lam = min(-dB/dd, reaction), reaction = (g_other . n) / dt^2 = the normal force that balances inertia + elasticity + constraints
+  // at this vertex.  In force balance the two agree (that IS the balance); but the Newton loop stops on its step-size tolerance
+  // (velocity_tol * dt = 0.5 mm, US:62-66), where a contact vertex may still sit at 0.98 d_hat - and there the 10 GPa barrier pushes
+  // with 87 N on a pad whose whole reaction is below 1 N.  Lagging THAT force made the first friction iteration's direction 0.66 m
+  // long and the env spend 34 Newton / 1 900 PCG iterations on one CU while the launch waited (scene step 11, env 442; replayed
+  // through the oracle in tests/studies/fem_straggler_replay.py: 38 / 2 280 -> 5 / 21 with the cap).
+  if (lag_pending) {  // (block-uniform; every thread writes and later reads its own four doubles: no barrier)
+    lag_pending = false;
+    double lam = 0.0;
+    if (own) {
+      if (ce.active) {
+        const double react = (go3[0] * ce.n[0] + go3[1] * ce.n[1] + go3[2] * ce.n[2]) / dt2;
+        lam = fmin(-ce.b1, fmax(react, 0.0));
+      }
+      const bool on = lam > 0.0;
+      fl[tid * 4] = on ? lam : 0.0;
+      fl[tid * 4 + 1] = on ? ce.n[0] : 0.0; fl[tid * 4 + 2] = on ? ce.n[1] : 0.0; fl[tid * 4 + 3] = on ? ce.n[2] : 0.0;
+    }
+    if (!__syncthreads_or(lam > 0.0)) { done = true; break; }  // no vertex carries a normal force: nothing for friction to act on
+  }
   // friction of this vertex at x: gradient into the residual, Hessian block into LDS (read back by H.p and the preconditioner)
   if (fric_phase && own) {
     const double xn3[3] = {xn[tid * 3], xn[tid * 3 + 1], xn[tid * 3 + 2]};
@@ -1628,14 +1674,14 @@ __global__ __launch_bounds__(kNwtThreads) void fem_newton_lds_kernel(FemDev m, d
       // normal contact is balanced: freeze the friction lag (normal force, normal) at this state and go on, unless no vertex of
       // the env is in contact
       fric_phase = true;
-      double lam = 0.0;
+      bool touching = false;
       if (own) {
         const ContactEval cf = contact_eval<MESH>(m, ind, wv, x3);
-        lam = cf.active ? -cf.b1 : 0.0;
-        fl[tid * 4] = lam;
-        fl[tid * 4 + 1] = cf.active ? cf.n[0] : 0.0; fl[tid * 4 + 2] = cf.active ? cf.n[1] : 0.0; fl[tid * 4 + 3] = cf.active ? cf.n[2] : 0.0;
+        touching = cf.active;
+        fl[tid * 4] = 0.0; fl[tid * 4 + 1] = 0.0; fl[tid * 4 + 2] = 0.0; fl[tid * 4 + 3] = 0.0;
       }
-      if (__syncthreads_or(lam > 0.0)) { frac_prev = 0.0; continue; }
+      // the lag itself needs the contact-free gradient at this state: the next iteration computes it first (lag_pending)
+      if (__syncthreads_or(touching)) { frac_prev = 0.0; lag_pending = true; continue; }
     }
     done = true;
     break;
@@ -1788,6 +1834,7 @@ struct tacex_fem_ctx {
   // caller animating the indenter by passing fresh tensors) keeps them: only disabling contact or its first enable resets.
   const void* ind_prev_ws = nullptr;
   int ind_prev_B = 0;
+  bool follow_indenter = true;  // contact-following start of the Newton loop (tacex_fem_set_contact_following; fem_newton_lds_kernel)
   double* dx_dev = nullptr;  // optional (B,) last Newton update max|dx| per env: converged envs skip further iterations
   double dx_tol = 0.0;
   std::vector<void*> allocs;
@@ -2028,6 +2075,12 @@ int tacex_fem_contact_gaps(tacex_fem_ctx* c, const double* x_dev, double* gaps_d
   return e == hipSuccess ? 0 : fail_hip(e, "fem_contact_gaps_kernel");
 }
 
+int tacex_fem_set_contact_following(tacex_fem_ctx* c, int enable) {
+  if (!c) { set_error("tacex_fem_set_contact_following: null context"); return 2; }
+  c->follow_indenter = enable != 0;
+  return 0;
+}
+
 int tacex_fem_set_friction(tacex_fem_ctx* c, double friction_ratio, double eps_velocity) {
   if (!c) { set_error("tacex_fem_set_friction: null context"); return 2; }
   if (!(friction_ratio >= 0.0) || (friction_ratio > 0.0 && !(eps_velocity > 0.0))) {
@@ -2240,7 +2293,8 @@ static int launch_newton(tacex_fem_ctx* c, double* x, const double* xt, const ui
     if (ea == hipSuccess) ea = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds, granted[mesh ? 1 : 0]);
     if (ea != hipSuccess) return fail_hip(ea, "hipFuncSetAttribute(fem_newton_lds_kernel)");
     hipLaunchKernelGGL(kern, dim3(B), dim3(kNwtThreads), lds, st, c->dev_nwt, x, xt, cons, aim, stats, pcg_max_iter,
-                       pcg_tol_rate, ls_max_iter, dx_dev, dx_tol, max_newton, step_info, fric ? xprev : nullptr, fric ? disp : nullptr, env_order);
+                       pcg_tol_rate, ls_max_iter, dx_dev, dx_tol, max_newton, step_info, fric ? xprev : nullptr,
+                       (xprev && disp && c->dev.indenters) ? disp : nullptr, env_order, c->follow_indenter ? 1 : 0);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : fail_hip(e, "fem_newton_lds_kernel");
   }

@@ -807,3 +807,47 @@ def test_friction_sees_indenter_motion_through_a_new_tensor_every_step():
     top = P[:, 2] > P[:, 2].max() - 1e-9
     assert (res[0][0][top, 0] - P[top, 0]).max() > 2e-5  # friction dragged the surface along +x
     np.testing.assert_array_equal(res[0], res[1])
+
+
+def test_contact_following_start_is_only_an_initial_guess_and_tames_the_retreat():
+    """The contact-following start of the Newton loop (`UipcSimCfg.contact.follow_indenter`, fem_newton_lds_kernel): vertices in the
+    barrier zone start a step displaced with the indenter.  With the indenter RETREATING the followed loop needs a fraction of the
+    Newton / PCG iterations of the loop started from the current positions (libuipc's start), and both end in the same state to the
+    Newton tolerance; kernel and oracle agree with it switched on."""
+    from oracle.fem_oracle import fem_step
+
+    res = {}
+    for follow in (True, False):
+        sim, m, P, cons, aim, cms = _c4_scene(1)
+        sim.cfg.contact.follow_indenter = follow
+        sim.cfg.contact.enable_friction = False
+        sim.cfg.newton.velocity_tol = 1e-3
+        sim.cfg.linear_system.max_iter, sim.cfg.linear_system.tol_rate = 600, 1e-6
+        sim.set_contact_indenters(sim.contact_indenters)
+        ind = sim.contact_indenters
+        xo, vo = P.copy(), np.zeros_like(P)
+        prev = None
+        its, pcg = [], []
+        for k in range(9):
+            if k < 4:
+                ind[:, 3] -= 0.35 * float(sim.contact_gaps().amin())  # press ...
+            else:
+                ind[:, 3] += 1.2e-4                                    # ... then retreat 0.12 mm per step
+            cur = ind[0, 1:4].cpu().numpy().copy()
+            disp = cur - prev if prev is not None else np.zeros(3)
+            prev = cur
+            cms[0].ind[1:4] = cur
+            sim.step(max_newton_iter=80)
+            info = sim.check_step()
+            assert len(info["penetrating_envs"]) == 0 and info["newton_iters"].max() < 80
+            if k >= 4:
+                its.append(int(info["newton_iters"][0])); pcg.append(int(info["pcg_iters"][0]))
+            if follow:
+                xo, vo, io = fem_step(m, cms[0], xo, vo, cons, aim[0], gravity=sim.cfg.gravity, max_newton=80, velocity_tol=1e-3, pcg_max_iter=600,
+                                      pcg_tol_rate=1e-6, coarse=sim.coarse_space, chains=_chains(sim), indenter_disp=disp)
+                assert abs(int(info["newton_iters"][0]) - int(io[0])) <= 1, (k, info["newton_iters"], io)
+                assert np.abs(sim.x[0].cpu().numpy() - xo).max() <= 2 * 1e-3 * sim.cfg.dt, k
+        res[follow] = (sim.x[0].cpu().numpy().copy(), sum(its), sum(pcg))
+    print("retreat: Newton / PCG iterations with following", res[True][1:], "without", res[False][1:])
+    assert np.abs(res[True][0] - res[False][0]).max() <= 4 * 1e-3 * 0.01  # the same state within the Newton tolerance of both runs
+    assert res[True][1] < res[False][1] and res[True][2] < 0.6 * res[False][2], (res[True][1:], res[False][1:])
