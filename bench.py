@@ -448,15 +448,67 @@ def sweep(args, dev):
     run("C2 + FOTS markers: 256 envs x 1 sensor, RGB 320x240 + markers", 256, 240, 320, 1, True)
     run("512-env shard of the 4096-env / 8-GPU target: 512 envs x 1 sensor, RGB 320x240 + FOTS markers", 512, 240, 320, 1, True)
     run("C4 per-GPU shard: 512 envs, RGB 320x240 + FEM-driven markers + gelpad FEM step (1920 tets / env) (BASELINE configs[3] / 8)",
-        512, 240, 320, 1, False, fem=lambda: FemGelpad(512, dev))
+        512, 240, 320, 1, False, fem=lambda: FemGelpad(512, dev, max_newton_iter=NEWTON_CAP))
     run("C4 shard, ROLLING CONTACT: the indenter stays on the pad like the ball of the reference's ball-rolling scene (depth 0.3-0.8 of "
-        "the maximum, sliding +-0.5 mm sideways, friction on); whenever the indenter RETREATS the pad has to follow it up the barrier and the "
-        "Newton loop runs to its cap of 8 iterations, released or not",
-        512, 240, 320, 1, False, fem=lambda: FemGelpad(512, dev, motion="rolling"))
+        "the maximum, sliding +-0.5 mm sideways, friction on); whenever the indenter RETREATS the pad follows it up the barrier in damped "
+        "Newton steps (every env runs to convergence: the cap of 64 iterations is asserted never to bind)",
+        512, 240, 320, 1, False, fem=lambda: FemGelpad(512, dev, motion="rolling", max_newton_iter=NEWTON_CAP))
     run("C5 per-GPU shard: 1024 envs, RGB 640x480 + FEM-driven markers (gelpad FEM step included) (BASELINE configs[4] / 8)",
-        1024, 480, 640, 1, False, fem=lambda: FemGelpad(1024, dev))
+        1024, 480, 640, 1, False, fem=lambda: FemGelpad(1024, dev, max_newton_iter=NEWTON_CAP))
+    out.append(fem_axle_entry(dev))
     run("C5 optical part only: 1024 envs, RGB 640x480", 1024, 480, 640, 1, False, steps=max(5, args.sweep_steps // 3))
     return out
+
+
+NEWTON_CAP = 64  # Newton iterations a FEM scene of the sweep may take per step (reference default 1024, uipc_sim.py Newton.max_iter):
+                 # high enough that no env of no step reaches it - asserted, a truncated solve would flatter the rate
+
+
+def fem_axle_entry(dev, B=512, steps=12):
+    """SURVEY section 8(d)'s ~2k-tet fixture simple_axle.msh (593 vertices / 2 003 tets: more vertices than the CU-resident Newton kernel
+    has threads) stepped with sphere contact on the streaming Newton kernel - FEM only, env steps per second."""
+    try:
+        from tacex_amd.uipc import UipcObject, UipcObjectCfg, UipcSim, UipcSimCfg
+
+        g = np.load(REPO / "tests" / "golden" / "fem_meshes.npz")
+        P = (g["simple_axle_points"] - g["simple_axle_points"].min(0)) * 0.01
+        T = g["simple_axle_tets"]
+        cfg = UipcSimCfg(device=dev)
+        cfg.linear_system.coarse_grid, cfg.linear_system.vertex_chains = None, None
+        cfg.contact.enable_friction = False  # friction lives in the CU-resident kernel (<= 512 vertices) only
+        sim = UipcSim(cfg, num_envs=B)
+        UipcObject(UipcObjectCfg(mesh_points=P, mesh_tets=T), sim)
+        sim.setup_sim(constraint_strength_ratio=1000.0)
+        ends = np.where((P[:, 0] < 0.002) | (P[:, 0] > P[:, 0].max() - 0.002))[0]
+        sim.set_constraints(ends, torch.from_numpy(np.repeat(P[None, ends], B, 0)).to(dev))
+        ind = torch.zeros((B, 8), dtype=torch.float64, device=dev)
+        ind[:, 0], ind[:, 1], ind[:, 2], ind[:, 4] = 1.0, P[:, 0].max() / 2, P[:, 1].max() / 2, 0.004
+        ind[:, 3] = P[:, 2].max() + 0.004 + 0.0009
+        sim.set_contact_indenters(ind)
+        ind = sim.contact_indenters
+        depth = torch.linspace(0.2, 0.4, B, device=dev, dtype=torch.float64)
+
+        def step():
+            ind[:, 3] -= depth * sim.contact_gaps().amin(1)  # press on by a fraction of the gap
+            sim.step(max_newton_iter=NEWTON_CAP)
+
+        for _ in range(3):
+            step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        its = 0
+        for _ in range(steps):
+            step()
+            its = max(its, sim.last_newton_iters)  # (synchronises: the streaming path launches one kernel per Newton iteration anyway)
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        assert its < NEWTON_CAP and bool(torch.isfinite(sim.x).all()) and float(sim.contact_gaps().amin()) > 0.0
+        return {"workload": f"FEM only: {B} envs x simple_axle.msh (593 vertices / 2003 tets, scaled to 25.8 x 3 x 3 mm), ends attached, a sphere "
+                            "pressing on through the IPC barrier (no friction): the streaming Newton kernel (meshes beyond 512 vertices)",
+                "envs": B, "steps": steps, "ms_per_step": round(el / steps * 1e3, 3), "env_steps_per_s": round(B * steps / el, 1),
+                "newton_iters_max": int(its), "newton_cap": NEWTON_CAP}
+    except Exception as ex:
+        return {"workload": "FEM only: simple_axle.msh on the streaming Newton kernel", "error": f"{type(ex).__name__}: {ex}"[:300]}
 
 
 def fem_roofline(fem, period=None):

@@ -565,6 +565,24 @@ __device__ __forceinline__ double block_sum(double v, double* sh /* >= 17 double
   return sh[16];
 }
 
+// block-wide maximum, same scheme
+__device__ __forceinline__ double block_sum_max(double v, double* sh) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o, 64));
+  const int wid = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) sh[wid] = v;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double s = sh[0];
+    for (int w = 1; w < nw; ++w) s = fmax(s, sh[w]);
+    sh[16] = s;
+  }
+  __syncthreads();
+  return sh[16];
+}
+constexpr int kLsRescueStream = 32;  // rescue halvings of the line search next to a barrier (kLsRescue of the CU-resident kernel)
+
 __device__ double env_energy(const FemDev& m, const double* x, const double* xt, const uint8_t* cons, const double* aim,
                              double* sh, const double* ind = nullptr) {
   double e = 0.0;
@@ -659,9 +677,9 @@ __global__ __launch_bounds__(512) void fem_gradient_kernel(FemDev m, const doubl
 }
 
 // ---- K17b: one projected-Newton iteration per env, everything inside one workgroup -----------------------------
-// workspace per env (doubles): ge 12T | tet cache 12T (F 9, a, b, c) | hv 12T | g,r,z,p,d,Hp,xc 7*3V | Dinv 9V; behind the B env
+// workspace per env (doubles): ge 12T | tet cache 12T (F 9, a, b, c) | hv 12T | g,r,z,p,d,Hp,xc 7*3V | Dinv 9V | contact 5V; behind the B env
 // blocks: x_prev (B,V,3) and the per-env max |d| of tacex_fem_step
-__host__ __device__ inline size_t newton_ws_doubles(int V, int T) { return (size_t)36 * T + (size_t)30 * V; }
+__host__ __device__ inline size_t newton_ws_doubles(int V, int T) { return (size_t)36 * T + (size_t)35 * V; }
 
 __device__ __forceinline__ bool inv3_spd(const double A[9], double Ai[9]) {
   // Cholesky test + inverse via adjugate
@@ -708,7 +726,12 @@ __global__ __launch_bounds__(512) void fem_newton_kernel(FemDev m, double* xg, c
   double* vHp = vd + (size_t)3 * V;
   double* xc = vHp + (size_t)3 * V;      // line-search candidate
   double* Dinv = xc + (size_t)3 * V;     // (V,9)
+  double* cdat = Dinv + (size_t)9 * V;   // (V,5) barrier of the vertex at x: dt^2 b'' | n (3) | gap d
   const double dt2 = m.dt * m.dt;
+  // IPC barrier against the env's indenter (the same terms as in the CU-resident kernel: gradient b' n, PSD curvature b'' n n^T in
+  // H.p and the block-Jacobi blocks, conservative step bound before the line search).  Friction, vertex chains and the coarse
+  // correction exist in the CU-resident kernel only - this is the path of meshes with more vertices than its workgroup has threads.
+  const double* ind = (m.indenters && m.area) ? m.indenters + (size_t)b * 8 : nullptr;
 
   // ---- element pass: cache F and coefficients, tet gradients, diagonal 3x3 blocks (into hv as (4*9? no: 12 rows)) ----
   // the four 3x3 diagonal blocks of the element Hessian need 36 doubles per tet: use ge+tc? they are needed later,
@@ -737,6 +760,23 @@ __global__ __launch_bounds__(512) void fem_newton_kernel(FemDev m, double* xg, c
     const bool c = cons && cons[v];
     const double md = mv * (1.0 + (c ? m.strength : 0.0));
     double D[9] = {md, 0, 0, 0, md, 0, 0, 0, md};
+    double cg[3] = {0, 0, 0};
+    {
+      const double xv[3] = {x[v * 3], x[v * 3 + 1], x[v * 3 + 2]};
+      const ContactEval ce = contact_eval(m, ind, ind ? m.area[v] : 0.0, xv);
+      const double cb2 = ce.active ? dt2 * ce.b2 : 0.0;
+      cdat[(size_t)v * 5] = cb2;
+      cdat[(size_t)v * 5 + 1] = ce.n[0]; cdat[(size_t)v * 5 + 2] = ce.n[1]; cdat[(size_t)v * 5 + 3] = ce.n[2];
+      cdat[(size_t)v * 5 + 4] = (ind && m.area[v] > 0.0 && !ce.penetrating) ? ce.d : 1e300;
+      if (ce.active) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+          cg[i] = dt2 * ce.b1 * ce.n[i];
+#pragma unroll
+          for (int k = 0; k < 3; ++k) D[i * 3 + k] += cb2 * ce.n[i] * ce.n[k];
+        }
+      }
+    }
     for (int e = m.vt_off[v]; e < m.vt_off[v + 1]; ++e) {
       const int code = m.vt_idx[e];
       const int t = code >> 2, l = code & 3;
@@ -777,7 +817,7 @@ __global__ __launch_bounds__(512) void fem_newton_kernel(FemDev m, double* xg, c
     for (int k = 0; k < 9; ++k) Dinv[(size_t)v * 9 + k] = (double)(float)Di3[up[k]];
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
-      double gi = a3[i] + mv * (x[v * 3 + i] - xt[v * 3 + i]);
+      double gi = a3[i] + mv * (x[v * 3 + i] - xt[v * 3 + i]) + cg[i];
       if (c) gi += m.strength * mv * (x[v * 3 + i] - aim[v * 3 + i]);
       vg[v * 3 + i] = gi;
       vr[v * 3 + i] = -gi;
@@ -833,9 +873,11 @@ __global__ __launch_bounds__(512) void fem_newton_kernel(FemDev m, double* xg, c
       double a3[3];
       gather_vertex(m, hv, v, a3);
       const double md = m.mass[v] * (1.0 + ((cons && cons[v]) ? m.strength : 0.0));
+      const double cb2 = cdat[(size_t)v * 5];
+      const double npq = cb2 * (cdat[(size_t)v * 5 + 1] * vp[v * 3] + cdat[(size_t)v * 5 + 2] * vp[v * 3 + 1] + cdat[(size_t)v * 5 + 3] * vp[v * 3 + 2]);
 #pragma unroll
       for (int i = 0; i < 3; ++i) {
-        const double h = a3[i] + md * vp[v * 3 + i];
+        const double h = a3[i] + md * vp[v * 3 + i] + npq * cdat[(size_t)v * 5 + 1 + i];
         vHp[v * 3 + i] = h;
         part += vp[v * 3 + i] * h;
       }
@@ -872,13 +914,23 @@ __global__ __launch_bounds__(512) void fem_newton_kernel(FemDev m, double* xg, c
   }
   __syncthreads();
   // ---- backtracking line search on the incremental potential (accept the first E(x + step d) <= E(x)) ----
-  const double E0 = env_energy(m, x, xt, cons, aim, sh);
+  const double E0 = env_energy(m, x, xt, cons, aim, sh, ind);
   double step = 1.0, E1 = E0;
+  if (ind) {  // conservative step bound (1-Lipschitz distance): no surface vertex may use more than kCcdSlack of its gap
+    double amax = 1.0;
+    for (int v = threadIdx.x; v < V; v += blockDim.x) {
+      const double gap = cdat[(size_t)v * 5 + 4];
+      const double nd = sqrt(vd[v * 3] * vd[v * 3] + vd[v * 3 + 1] * vd[v * 3 + 1] + vd[v * 3 + 2] * vd[v * 3 + 2]);
+      if (gap < 1e299 && nd > 0.0) amax = fmin(amax, kCcdSlack * gap / nd);
+    }
+    step = -block_sum_max(-amax, sh);
+  }
   bool accepted = false;
-  for (int ls = 0; ls <= ls_max_iter; ++ls) {
+  const int ls_cap = ind ? (ls_max_iter > kLsRescueStream ? ls_max_iter : kLsRescueStream) : ls_max_iter;
+  for (int ls = 0; ls <= ls_cap; ++ls) {
     for (int k = threadIdx.x; k < 3 * V; k += blockDim.x) xc[k] = x[k] + step * vd[k];
     __syncthreads();
-    const double Ec = env_energy(m, xc, xt, cons, aim, sh);
+    const double Ec = env_energy(m, xc, xt, cons, aim, sh, ind);
     if (Ec <= E0) { E1 = Ec; accepted = true; break; }
     step *= 0.5;
   }
@@ -1006,7 +1058,7 @@ __global__ __launch_bounds__(kNwtThreads) void fem_newton_lds_kernel(FemDev m, d
                                                                      int pcg_max_iter, double pcg_tol_rate, int ls_max_iter,
                                                                      double* dxg, double dx_tol, int max_newton, double* step_info,
                                                                      const double* xprevg, const double* dispg, const int* env_order,
-                                                                     int follow) {
+                                                                     int follow, double* lagg) {
   extern __shared__ __attribute__((aligned(16))) double nlds[];
   constexpr int CH = kNwtChunk;
   const int V = m.V, T = m.T;
@@ -1276,18 +1328,25 @@ __global__ __launch_bounds__(kNwtThreads) void fem_newton_lds_kernel(FemDev m, d
   //      thread of a chain walks it:  S_0 = D_0,  G_i = S_i^-1 E_i,  S_{i+1} = D_{i+1} - E_i^T G_i.  S^-1 (6) and G (9) stay in
   //      LDS as FLOATS: z = L^-T S^-1 L^-1 r is symmetric positive definite for any G as long as the S^-1 are, so the rounding
   //      costs preconditioner quality only (none measurable: profiles/r03_experiments.md section 9). ----
+  //      The ELASTIC part of D and E is assembled in the FIRST iteration of a launch only and kept per env in the workspace (15
+  //      doubles per vertex, SoA): between the Newton iterations of one time step the deformation gradients move by per cent, the
+  //      blocks that change by orders of magnitude - barrier curvature, friction - are added fresh every iteration, and a
+  //      preconditioner only has to stay SPD.  The assembly was 164 K of the 333 K cycles of an iteration in steady contact
+  //      (section clock, profiles/r04_experiments.md), and every step with contact runs at least two iterations (normal contact,
+  //      then friction).
   {
-    double D[9] = {md, 0, 0, 0, md, 0, 0, 0, md};
+    double D[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     double E[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-    if (own) {
-      if (fric_phase) {
-        const float* h = fh + tid * 6;
-        D[0] += h[0]; D[1] += h[1]; D[2] += h[2]; D[3] += h[1]; D[4] += h[3]; D[5] += h[4]; D[6] += h[2]; D[7] += h[4]; D[8] += h[5];
-      }
+    const bool lag_fresh = nit == 0 || lagg == nullptr;
+    double* lagw = lagg ? lagg + (size_t)b * 15 * V : nullptr;  // [15][V]: D upper triangle (6) | E (9), elastic part only
+    if (own && !lag_fresh) {
+      D[0] = lagw[0 * V + tid]; D[1] = lagw[1 * V + tid]; D[2] = lagw[2 * V + tid]; D[4] = lagw[3 * V + tid]; D[5] = lagw[4 * V + tid];
+      D[8] = lagw[5 * V + tid];
+      D[3] = D[1]; D[6] = D[2]; D[7] = D[5];
 #pragma unroll
-      for (int i = 0; i < 3; ++i)
-#pragma unroll
-        for (int k = 0; k < 3; ++k) D[i * 3 + k] += cb2 * ce.n[i] * ce.n[k];
+      for (int k = 0; k < 9; ++k) E[k] = lagw[(6 + k) * V + tid];
+    }
+    if (own && lag_fresh) {
       const int nv = cnx[tid] == 0xffff ? -1 : (int)cnx[tid];
       for (int e = (int)vto[tid], e_end = (int)vto[tid + 1]; e < e_end; ++e) {
         const int code = csr[e];
@@ -1323,6 +1382,24 @@ __global__ __launch_bounds__(kNwtThreads) void fem_newton_lds_kernel(FemDev m, d
           }
         }
       }
+    }
+    if (own) {
+      if (lag_fresh && lagw) {  // the elastic blocks of this launch (read back by its later iterations)
+        lagw[0 * V + tid] = D[0]; lagw[1 * V + tid] = D[1]; lagw[2 * V + tid] = D[2]; lagw[3 * V + tid] = D[4]; lagw[4 * V + tid] = D[5];
+        lagw[5 * V + tid] = D[8];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) lagw[(6 + k) * V + tid] = E[k];
+      }
+      // the blocks that are never lagged: mass + constraint, barrier curvature, friction
+      D[0] += md; D[4] += md; D[8] += md;
+      if (fric_phase) {
+        const float* h = fh + tid * 6;
+        D[0] += h[0]; D[1] += h[1]; D[2] += h[2]; D[3] += h[1]; D[4] += h[3]; D[5] += h[4]; D[6] += h[2]; D[7] += h[4]; D[8] += h[5];
+      }
+#pragma unroll
+      for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int k = 0; k < 3; ++k) D[i * 3 + k] += cb2 * ce.n[i] * ce.n[k];
     }
     double* xch = ps;  // (V,15) D (upper triangle) | E: p is idle until the PCG starts, the window once the gradient is gathered
     __syncthreads();   // every vertex has gathered the last window of the gradient sweep
@@ -2294,13 +2371,16 @@ static int launch_newton(tacex_fem_ctx* c, double* x, const double* xt, const ui
     if (ea != hipSuccess) return fail_hip(ea, "hipFuncSetAttribute(fem_newton_lds_kernel)");
     hipLaunchKernelGGL(kern, dim3(B), dim3(kNwtThreads), lds, st, c->dev_nwt, x, xt, cons, aim, stats, pcg_max_iter,
                        pcg_tol_rate, ls_max_iter, dx_dev, dx_tol, max_newton, step_info, fric ? xprev : nullptr,
-                       (xprev && disp && c->dev.indenters) ? disp : nullptr, env_order, c->follow_indenter ? 1 : 0);
+                       (xprev && disp && c->dev.indenters) ? disp : nullptr, env_order, c->follow_indenter ? 1 : 0,
+                       max_newton > 1 ? static_cast<double*>(ws) : nullptr);  // env blocks of the workspace: (15, V) lagged blocks per env
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : fail_hip(e, "fem_newton_lds_kernel");
   }
   if (resident) *resident = false;
-  if (c->dev.indenters) {
-    set_error("FEM Newton: contact needs the CU-resident Newton kernel (mesh with <= %d vertices, TACEX_FEM_NEWTON_LDS != 0)", kNwtThreads);
+  if (c->dev.indenters && (c->dev.fric_mu > 0.0 || c->dev.im_nt > 0)) {
+    set_error("FEM Newton: friction and mesh indenters need the CU-resident Newton kernel (mesh with <= %d vertices, TACEX_FEM_NEWTON_LDS != 0); "
+              "the streaming kernel of larger meshes handles the barrier of analytic indenters only - switch friction off",
+              kNwtThreads);
     return 2;
   }
   hipLaunchKernelGGL(fem_newton_kernel, dim3(B), dim3(512), 0, st, c->dev, x, xt, cons, aim, stats, static_cast<double*>(ws), pcg_max_iter,

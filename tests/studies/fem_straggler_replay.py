@@ -54,7 +54,7 @@ def traced(*a, **kw):
     return r
 fo.newton_step_contact = traced
 x2, v2, info = fo.fem_step(m, cm, d["x"][k].copy(), d["v"][k].copy(), cons, aim, max_newton=nmax, velocity_tol=0.05, pcg_max_iter=1024, pcg_tol_rate=1e-3,
-                           coarse=coarse, chains=chains, friction=(0.5, 0.01, disp), indenter_disp=np.zeros(3))
+                           coarse=coarse, chains=chains, friction=(0.5, 0.01, disp))
 print("fem_step with friction:", info)
 for i, t in enumerate(trace):
     print(f"  it {i:2d}: step {t[0]:.3e} (ccd {t[3]:.2e}) pcg {t[1]:3d} max|d| {t[2]:.2e} friction phase {t[4]}")

@@ -1,4 +1,6 @@
 """GPU tests of the gelpad FEM kernels against the CPU oracle (oracle/fem_oracle.py; parity with libuipc UNPINNED)."""
+from pathlib import Path
+
 import numpy as np
 import pytest
 import torch
@@ -851,3 +853,61 @@ def test_contact_following_start_is_only_an_initial_guess_and_tames_the_retreat(
     print("retreat: Newton / PCG iterations with following", res[True][1:], "without", res[False][1:])
     assert np.abs(res[True][0] - res[False][0]).max() <= 4 * 1e-3 * 0.01  # the same state within the Newton tolerance of both runs
     assert res[True][1] < res[False][1] and res[True][2] < 0.6 * res[False][2], (res[True][1:], res[False][1:])
+
+
+def test_streaming_newton_kernel_steps_simple_axle_with_sphere_contact():
+    """a mesh with MORE vertices than the CU-resident Newton kernel has threads - the reference's
+    simple_axle.msh (593 vertices / 2 003 tets, tests/golden/fem_meshes.npz) - stepped WITH contact.  Such meshes run on the streaming
+    Newton kernel (state in HBM / L2, any vertex count), which now carries the IPC barrier and the conservative step bound; friction,
+    chains and the coarse correction stay with the CU-resident kernel (asked for together with friction, the step fails loudly).
+    Against the oracle's fem_step with the same block-Jacobi preconditioner: iteration counts, positions, no penetration."""
+    from oracle.fem_oracle import ContactModel, FemModel, fem_step
+    from tacex_amd.uipc import UipcObject, UipcObjectCfg, UipcSim, UipcSimCfg
+
+    g = np.load(Path(__file__).parent / "golden" / "fem_meshes.npz")
+    P = (g["simple_axle_points"] - g["simple_axle_points"].min(0)) * 0.01  # an axle of 25.8 x 3 x 3 mm
+    T = g["simple_axle_tets"]
+    assert len(P) == 593 and len(T) == 2003
+    B = 2
+    cfg = UipcSimCfg(device="cuda:0")
+    cfg.linear_system.coarse_grid, cfg.linear_system.vertex_chains = None, None
+    cfg.linear_system.max_iter, cfg.linear_system.tol_rate = 3000, 1e-5
+    cfg.newton.velocity_tol = 2e-3
+    sim = UipcSim(cfg, num_envs=B)
+    gel = UipcObject(UipcObjectCfg(mesh_points=P, mesh_tets=T), sim)
+    sim.setup_sim(constraint_strength_ratio=1000.0)
+    ends = np.where((P[:, 0] < 0.002) | (P[:, 0] > P[:, 0].max() - 0.002))[0]
+    aim = np.repeat(P[None], B, 0)
+    sim.set_constraints(ends, torch.from_numpy(aim[:, ends]).cuda())
+    cons = np.zeros(len(P)); cons[ends] = 1.0
+    top, mid = P[:, 2].max(), P[:, 0].max() / 2
+    ind = np.zeros((B, 8)); ind[:, 0] = 1.0
+    ind[:, 1], ind[:, 2], ind[:, 4] = mid, P[:, 1].max() / 2, 0.004
+    ind[:, 3] = top + 0.004 + 0.0009 - 1e-4 * np.arange(B)
+    # friction is on by default (uipc_sim.py:103-124) and lives in the CU-resident kernel only: the step says so
+    sim.set_contact_indenters(torch.from_numpy(ind))
+    with pytest.raises(Exception, match="friction"):
+        sim.step(max_newton_iter=2)
+    sim.cfg.contact.enable_friction = False
+    sim.set_contact_indenters(torch.from_numpy(ind))
+    indd = sim.contact_indenters
+    m = FemModel.build(P, T, youngs=gel.cfg.constitution_cfg.youngs_modulus * 1e6, poisson=gel.cfg.constitution_cfg.poisson_rate,
+                       density=gel.cfg.mass_density, dt=sim.cfg.dt, strength=1000.0)
+    area = gel.surface_vertex_areas()
+    kappa = sim.cfg.contact.default_contact_resistance * 1e9 * sim.cfg.contact.d_hat
+    cms = [ContactModel(area, ind[b].copy(), sim.cfg.contact.d_hat, kappa, sim.cfg.dt) for b in range(B)]
+    xo = [P.copy() for _ in range(B)]
+    vo = [np.zeros_like(P) for _ in range(B)]
+    for k in range(3):
+        indd[:, 3] -= 0.3 * sim.contact_gaps().amin(1)
+        cur = indd[:, 1:4].cpu().numpy().copy()
+        sim.step(max_newton_iter=30)
+        x = sim.x.cpu().numpy()
+        assert np.isfinite(x).all() and float(sim.contact_gaps().amin()) > 0.0
+        for b in range(B):
+            cms[b].ind[1:4] = cur[b]
+            xo[b], vo[b], io = fem_step(m, cms[b], xo[b], vo[b], cons, aim[b], gravity=sim.cfg.gravity, max_newton=30, velocity_tol=2e-3,
+                                        pcg_max_iter=3000, pcg_tol_rate=1e-5, coarse=None, chains=None, lag_prec=False)
+            assert io[0] < 30 and io[2] == 0, (k, b, io)
+            assert np.abs(x[b] - xo[b]).max() <= 2 * 2e-3 * sim.cfg.dt, (k, b, np.abs(x[b] - xo[b]).max())  # both inside the Newton tolerance
+    assert (P[:, 2] - sim.x[0].cpu().numpy()[:, 2]).max() > 5e-5  # the axle is dented / bent by the sphere
