@@ -372,7 +372,7 @@ def sweep(args, dev):
     """The other BASELINE configurations, timed the same way (rank 0, N = 1, after the headline)."""
     out = []
 
-    def run(label, B, H, W, n_sensors, markers, fem=None, steps=None, gather=None, count_in_contact=False, **rig_kw):
+    def run(label, B, H, W, n_sensors, markers, fem=None, steps=None, gather=None, count_in_contact=False, allow_newton_cap=False, **rig_kw):
         steps = steps or args.sweep_steps
         log(f"sweep: {label}")
         try:
@@ -416,8 +416,11 @@ def sweep(args, dev):
                 e["newton_cap"] = int(fem.max_newton_iter)
                 e["newton_iters_max_over_period"] = int(fem.iters_max) if fem.iters_max is not None else None
                 e["newton_cap_hit"] = bool(e["newton_iters_max_over_period"] is not None and e["newton_iters_max_over_period"] >= fem.max_newton_iter)
-                assert not e["newton_cap_hit"] or os.environ.get("TACEX_BENCH_ALLOW_NEWTON_CAP"), \
-                    f"an env ran into the Newton cap of {fem.max_newton_iter} iterations: the FEM rate would be measured on truncated solves"
+                if allow_newton_cap:
+                    e["truncated_solves"] = e["newton_cap_hit"]  # (an entry that SAYS it caps the loop: kept for continuity with rounds 2-3)
+                else:
+                    assert not e["newton_cap_hit"], \
+                        f"an env ran into the Newton cap of {fem.max_newton_iter} iterations: the FEM rate would be measured on truncated solves"
                 tot = (fem.info_sum - base[0]).cpu().numpy()
                 e["fem_period"] = {"steps": steps, "newton_iters_per_step_mean": round(float(tot[0]) / steps, 2),
                                    "pcg_iters_per_newton_mean": round(float(tot[3]) / max(float(tot[0]), 1e-9), 1),
@@ -449,6 +452,9 @@ def sweep(args, dev):
     run("512-env shard of the 4096-env / 8-GPU target: 512 envs x 1 sensor, RGB 320x240 + FOTS markers", 512, 240, 320, 1, True)
     run("C4 per-GPU shard: 512 envs, RGB 320x240 + FEM-driven markers + gelpad FEM step (1920 tets / env) (BASELINE configs[3] / 8)",
         512, 240, 320, 1, False, fem=lambda: FemGelpad(512, dev, max_newton_iter=NEWTON_CAP))
+    run("C4 per-GPU shard with the Newton loop CAPPED at 8 iterations as in rounds 2-3 (continuity only: envs that reach the cap carry an "
+        "unconverged state into the next step - `truncated_solves` says whether any did; the entry above is the measured rate)",
+        512, 240, 320, 1, False, fem=lambda: FemGelpad(512, dev, max_newton_iter=8), allow_newton_cap=True)
     run("C4 shard, ROLLING CONTACT: the indenter stays on the pad like the ball of the reference's ball-rolling scene (depth 0.3-0.8 of "
         "the maximum, sliding +-0.5 mm sideways, friction on); whenever the indenter RETREATS the pad follows it up the barrier in damped "
         "Newton steps (every env runs to convergence: the cap of 64 iterations is asserted never to bind)",

@@ -646,12 +646,44 @@ class FrictionModel:
         return (self.dt**2 * self.mu * self.lam)[:, None, None] * (a[:, None, None] * (T - tt) + bq[:, None, None] * tt)
 
 
+def edge_snap(m, cm, x, x_tilde, constrained, aim, x_prec=None):
+    """One exact 1-D minimisation per surface vertex that is about to run into the barrier zone from outside (or sits in its outermost
+    sliver), along its contact normal - a nonlinear Gauss-Seidel sweep over the stiffest degrees of freedom, taken before the Newton
+    system of an iteration is set up (fem_newton_lds_kernel, same rule).  The barrier is C2 with b'' -> 0 at d_hat: the Newton system
+    is blind to it for such a vertex, its direction sends the vertex a millimetre deep into a wall that stops it within microns, the
+    line search cuts the step OF THE WHOLE MESH to a per cent and the next iteration repeats it (the apex vertex of a retreating
+    contact crossed the zone edge back and forth for 13 iterations; tests/studies/fem_straggler_replay.py).  Along n the vertex's
+    energy is   phi(t) = -(g.n) t + 1/2 (n.D n) t^2 + dt^2 kappa A b((gap - t) / d_hat),   g = contact-free gradient, D = diagonal
+    block: if the elastic 1-D Newton step t_el = g.n / n.D n reaches the zone, the vertex is moved to where the barrier balances
+    the force it has to carry, e = sqrt(lam d_hat / (3 kappa A)) below d_hat (b' ~ -3 e^2 near the edge, lam = g.n / dt^2) - never
+    further than t_el.  Energy decreases (a 1-D minimiser of a convex model); everything else is left to Newton."""
+    g = m.gradient(x, x_tilde, constrained, aim)
+    D = m.diag_blocks(x if x_prec is None else x_prec, constrained)
+    gap, n = contact_distance(cm.ind, x, cm.mesh)
+    with np.errstate(invalid="ignore", divide="ignore"):
+        gn = (g * n).sum(-1)
+        nDn = np.einsum("vi,vij,vj->v", n, D, n)
+        t_el = np.where(nDn > 0, gn / nDn, 0.0)
+        lam = np.maximum(gn, 0.0) / m.dt**2
+        e = np.clip(np.sqrt(lam * cm.dhat / (3.0 * cm.kappa * np.where(cm.area > 0, cm.area, 1.0))), 1e-6, 1e-2)
+        rest = gap - (1.0 - e) * cm.dhat          # distance to the balance depth (> 0: the vertex is shallower than that)
+        snap = (cm.area > 0) & np.isfinite(gap) & (gn > 0) & (rest > 0) & (t_el > gap - cm.dhat)
+        t = np.minimum(t_el, rest)
+    if not snap.any():
+        return x, 0
+    x = x.copy()
+    x[snap] -= t[snap, None] * n[snap]
+    return x, int(snap.sum())
+
+
 def newton_step_contact(m: "FemModel", cm: ContactModel, x, x_tilde, constrained=None, aim=None, pcg_max_iter=64, pcg_tol_rate=1e-3,
-                        ls_max_iter=8, coarse=None, d0=None, return_dir=False, fr: "FrictionModel | None" = None, chains=None, x_prec=None):
+                        ls_max_iter=8, coarse=None, d0=None, return_dir=False, fr: "FrictionModel | None" = None, chains=None, x_prec=None, edge=True):
     """`FemModel.newton_step` with the barrier terms of `cm` in gradient, preconditioner, H.p and energy, and the CCD step
     filter in front of the backtracking line search.  Returns (x_new, [E0, E1, step, pcg_iters]).  `x_prec`: the state the ELASTIC
     blocks of the preconditioner are taken at (tacex_fem_step lags them: assembled in the first Newton iteration of the step and
     reused by the later ones; barrier and friction blocks are always those of x)."""
+    if edge:
+        x, _ = edge_snap(m, cm, x, x_tilde, constrained, aim, x_prec)
     g = m.gradient(x, x_tilde, constrained, aim) + cm.gradient(x)
     Hc = cm.hess_blocks(x)
     if fr is not None:

@@ -1250,8 +1250,11 @@ __global__ __launch_bounds__(kNwtThreads) void fem_newton_lds_kernel(FemDev m, d
   double frac_prev = 0.0;  // (1 - accepted step) of the previous iteration, 0 when it was taken in full or rejected
   bool fric_phase = false;  // friction terms are on (second phase of the loop, see friction_eval)
   bool lag_pending = false; // the friction lag is taken in the iteration that follows the converged normal-contact solve (see below)
+  bool lag_valid = false;  // the workspace holds the elastic preconditioner blocks of this launch
   for (int nit = 0; nit < max_newton; ++nit) {
   if (nit > 0) __syncthreads();  // xs carries the accepted candidate of the previous iteration
+  bool snapped_once = false;     // the edge snap (below) restarts an iteration at most once
+restart_iteration:
 #ifdef TACEX_FEM_CLOCK
   long long fph = __builtin_readcyclecounter();
 #define FEM_PHASE(k) do { const long long n_ = __builtin_readcyclecounter(); fnw[k] += (double)(n_ - fph); fph = n_; } while (0)
@@ -1337,7 +1340,7 @@ __global__ __launch_bounds__(kNwtThreads) void fem_newton_lds_kernel(FemDev m, d
   {
     double D[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     double E[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-    const bool lag_fresh = nit == 0 || lagg == nullptr;
+    const bool lag_fresh = !lag_valid || lagg == nullptr;
     double* lagw = lagg ? lagg + (size_t)b * 15 * V : nullptr;  // [15][V]: D upper triangle (6) | E (9), elastic part only
     if (own && !lag_fresh) {
       D[0] = lagw[0 * V + tid]; D[1] = lagw[1 * V + tid]; D[2] = lagw[2 * V + tid]; D[4] = lagw[3 * V + tid]; D[5] = lagw[4 * V + tid];
@@ -1392,6 +1395,46 @@ __global__ __launch_bounds__(kNwtThreads) void fem_newton_lds_kernel(FemDev m, d
       }
       // the blocks that are never lagged: mass + constraint, barrier curvature, friction
       D[0] += md; D[4] += md; D[8] += md;
+    }
+    lag_valid = lag_valid || lagw != nullptr;
+    // EDGE SNAP: one exact 1-D minimisation per surface vertex that is about to run into the barrier zone from outside (or sits in its
+    // outermost sliver), along its contact normal - a nonlinear Gauss-Seidel sweep over the stiffest degrees of freedom, taken before
+    // the Newton system of the iteration is set up.  The barrier is C2 with b'' -> 0 at d_hat: the Newton system is blind to it for
+    // such a vertex, its direction sends the vertex a millimetre deep into a wall that stops it within microns, the line search cuts
+    // the step OF THE WHOLE MESH to a per cent and the next iteration repeats it (the apex vertex of a retreating contact crossed the
+    // zone edge back and forth for 13 iterations with max |d| 0.6-0.8 mm against a tolerance of 0.5 mm: 18 Newton / 530 PCG
+    // iterations for that env, the launch waiting; with the snap 4 / 160 - tests/studies/fem_straggler_replay.py).  Along n the
+    // vertex's energy is  phi(t) = -(g.n) t + 1/2 (n.D n) t^2 + dt^2 kappa A b((gap - t) / d_hat)  (g = contact-free gradient, D =
+    // the block above): if the elastic 1-D Newton step t_el = g.n / n.D n reaches the zone, the vertex moves to where the barrier
+    // balances the force it has to carry, e = sqrt(lam d_hat / (3 kappa A)) below d_hat (b' ~ -3 e^2 near the edge, lam = g.n / dt^2),
+    // never further than t_el.  The iteration then restarts from the moved state (gradient, contact, blocks from the lag).
+    if (ind && !snapped_once) {  // (block-uniform)
+      double tmove = 0.0;
+      if (own && wv > 0.0 && !ce.penetrating && ce.d < 1e299) {
+        const double gn = go3[0] * ce.n[0] + go3[1] * ce.n[1] + go3[2] * ce.n[2];
+        if (gn > 0.0) {
+          double nDn = 0.0;
+#pragma unroll
+          for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int k = 0; k < 3; ++k) nDn += ce.n[i] * D[i * 3 + k] * ce.n[k];
+          const double t_el = nDn > 0.0 ? gn / nDn : 0.0;
+          const double e = fmin(fmax(sqrt(gn / dt2 * m.dhat / (3.0 * m.kappa * wv)), 1e-6), 1e-2);
+          const double rest = ce.d - (1.0 - e) * m.dhat;  // distance to the balance depth
+          if (rest > 0.0 && t_el > ce.d - m.dhat) tmove = fmin(t_el, rest);
+        }
+      }
+      if (__syncthreads_or(tmove > 0.0)) {
+        if (tmove > 0.0) {
+#pragma unroll
+          for (int i = 0; i < 3; ++i) { x3[i] -= tmove * ce.n[i]; xs[tid * 3 + i] = x3[i]; }
+        }
+        snapped_once = true;
+        __syncthreads();
+        goto restart_iteration;
+      }
+    }
+    if (own) {
       if (fric_phase) {
         const float* h = fh + tid * 6;
         D[0] += h[0]; D[1] += h[1]; D[2] += h[2]; D[3] += h[1]; D[4] += h[3]; D[5] += h[4]; D[6] += h[2]; D[7] += h[4]; D[8] += h[5];

@@ -177,13 +177,6 @@ __global__ __launch_bounds__(640) void blur_mfma_kernel(BlurArgs a) {
       wl[ks] = a.taps[((TACEX_MFMA_H_CONSEC ? 0 : KS) + ks) * 64 + lane];
     });
     const float thr = -a.pdepth[frame] * a.contact_scale;  // TT:459
-    // The masked restore only touches pixels with S < 0, and those lie on the frame's contact rows [lo, hi] (frame_rows_kernel,
-    // unexpanded): a band that misses them has no pixel to restore and an all-zero mask, so it does not read the height map at all
-    // (4 of the 12 bytes per pixel this level moves; a third of the bands of a typical contact frame)
-    bool need_hm = true;
-    if constexpr (GZ) {
-      if (a.rows_ext != nullptr) need_hm = !(by0 + TH - 1 < a.rows_ext[2 * frame] || by0 > a.rows_ext[2 * frame + 1]);
-    }
 #pragma unroll
     for (int t = 0; t < NTILE; ++t) {
       f32x4 acc[4];
@@ -195,7 +188,7 @@ __global__ __launch_bounds__(640) void blur_mfma_kernel(BlurArgs a) {
       v4f hv[4], gv[4];
 #pragma unroll
       for (int n = 0; n < 4; ++n) {
-        hv[n] = need_hm ? *reinterpret_cast<const v4f*>(hm + p0 + 16 * n) : (v4f)(INFINITY);  // (S = +inf: no contact, J = gel = 0)
+        hv[n] = *reinterpret_cast<const v4f*>(hm + p0 + 16 * n);
         gv[n] = GZ ? (v4f)(0.0f) : *reinterpret_cast<const v4f*>(gel + p0 + 16 * n);
       }
       if constexpr (TACEX_MFMA_H_CONSEC) {

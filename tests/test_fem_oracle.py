@@ -468,3 +468,43 @@ def test_fem_step_stops_on_the_unscaled_direction():
     g0 = m.gradient(x0, xt, cons, P) + cm.gradient(x0)
     assert np.abs(g).max() <= 1e-3 * np.abs(g0).max()
     assert contact_distance(cm.ind, x2)[0][area > 0].min() > 0.0
+
+
+def test_edge_snap_lowers_the_energy_and_lands_at_the_balance_depth():
+    """`edge_snap` (oracle + fem_newton_lds_kernel): a surface vertex pushed towards the indenter from just outside the barrier zone is
+    moved along its contact normal to the depth where the barrier balances the force it carries - the 1-D minimiser: the step's
+    potential decreases, the vertex ends inside the zone at a gap where |barrier force - reaction| is small against the reaction, and
+    a vertex that is not pushed towards the indenter (or too far away to reach the zone) stays where it is."""
+    from oracle.fem_oracle import ContactModel, FemModel, contact_distance, edge_snap
+    from tacex_amd.uipc.uipc_object import UipcObject, UipcObjectCfg, gelpad_box_mesh
+
+    P, T = gelpad_box_mesh(4, 4, 2)
+    obj = UipcObject(UipcObjectCfg(mesh_points=P, mesh_tets=T))
+    m = FemModel.build(P, T, youngs=1e4, poisson=0.49, density=1e3, dt=0.01, strength=100.0)
+    area = obj.surface_vertex_areas()
+    dhat, kappa = 1e-3, 1e7
+    top = P[:, 2].max()
+    apex = int(np.argmin(np.hypot(P[:, 0] - P[:, 0].max() / 2, P[:, 1] - P[:, 1].max() / 2) + 1e3 * (P[:, 2] < top - 1e-12)))
+    cons = (P[:, 2] < 1e-12).astype(np.float64)
+    x = P.copy()
+    x[apex, 2] -= 4e-4  # a dent under the indenter: elasticity pushes the apex back up, towards the sphere
+    ind = np.array([1.0, P[apex, 0], P[apex, 1], x[apex, 2] + 0.004 + 1.02 * dhat, 0.004, 0, 0, 0])  # apex at 1.02 d_hat: outside the zone
+    cm = ContactModel(area, ind, dhat, kappa, m.dt)
+    E = lambda y: m.energy(y, x, cons, P) + cm.energy(y)   # x_tilde = x: no inertia pull
+    xs, n = edge_snap(m, cm, x, x, cons, P)
+    assert n >= 1 and np.abs(xs - x).max(1)[apex] > 0
+    moved = np.nonzero(np.abs(xs - x).max(1) > 0)[0]
+    assert apex in moved
+    assert E(xs) < E(x)
+    gap, nrm = contact_distance(cm.ind, xs, None)
+    assert 0.99 * dhat < gap[apex] < dhat
+    g_other = m.gradient(xs, x, cons, P)
+    react = float(g_other[apex] @ nrm[apex])
+    barrier = -float(cm.gradient(xs)[apex] @ nrm[apex])
+    assert react > 0 and abs(barrier - react) <= 0.2 * react, (barrier, react)
+    # pulled AWAY from the indenter instead: nothing to snap
+    x2 = P.copy(); x2[apex, 2] += 1e-4
+    ind2 = ind.copy(); ind2[3] = x2[apex, 2] + 0.004 + 1.02 * dhat
+    cm2 = ContactModel(area, ind2, dhat, kappa, m.dt)
+    xs2, n2 = edge_snap(m, cm2, x2, x2, cons, P)
+    assert n2 == 0 and np.array_equal(xs2, x2)
