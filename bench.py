@@ -587,6 +587,32 @@ def fem_roofline(fem, period=None):
     }
 
 
+def fem_roofline_entry(sw):
+    """`roofline.fem`: the Newton kernel of the C4 shard against BOTH roofs north_star names for it - HBM (bytes per dispatch from the
+    PMC passes of `scripts/fem_bench.py`, profiles/pmc_traffic_r04_fem.json, over the kernel's mean duration in the kernel-trace run of
+    the same command) and, live from the C4 sweep entry, the f64 vector rate and LDS rate of the CU an env sits on."""
+    c4 = next((e for e in (sw or []) if e.get("workload", "").startswith("C4 per-GPU shard:") and "fem" in e), None)
+    out = {"kernel": "fem_newton_lds_kernel<false> (one dispatch = the whole Newton loop of a time step for all envs of the shard)"}
+    try:
+        j = json.loads((REPO / "profiles" / "pmc_traffic_r04_fem.json").read_text())
+        k = next(v for n, v in j["kernels"].items() if "fem_newton_lds_kernel<false>" in n)
+        out.update({"hbm_bytes_per_dispatch": k["hbm_bytes_per_dispatch"], "mean_us_per_dispatch": k.get("mean_us_per_dispatch"),
+                    "hbm_achieved": k.get("hbm_GBps"), "hbm_peak": HBM_PEAK_GBS, "hbm_unit": "GB/s", "hbm_frac": k.get("hbm_frac_of_8TBps"),
+                    "hbm_source": "profiles/pmc_traffic_r04_fem.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE + --kernel-trace --stats of scripts/fem_bench.py)",
+                    "hbm_measured_at": j.get("measured_at_commit")})
+    except Exception:
+        out["hbm_achieved"] = None
+    if c4 is not None:
+        ni = c4["fem"]["newton_iteration"]
+        out.update({"f64_achieved": ni["achieved_f64"], "f64_peak": ni["peak_f64"], "f64_unit": "TFLOP/s", "f64_frac": ni["frac"],
+                    "lds_frac": ni["lds_frac"], "us_per_sweep": ni["us_per_sweep"], "window": ni["window"],
+                    "matrix_free_bytes_per_tet_iteration_survey": 304,
+                    "note": "the env's state lives on its CU (LDS + registers); inside the PCG loop only the mesh constants are read (shared "
+                            "by all envs, L2), so the HBM roof does not bind this kernel - its HBM bytes are spill scratch outside the PCG loop "
+                            "and the lagged preconditioner blocks"})
+    return out if (c4 is not None or out.get("hbm_achieved") is not None) else None
+
+
 def main():
     args = parse()
     from tacex_amd import _lib
@@ -713,6 +739,9 @@ def main():
                 line["value_sensor_streams"] = ss["frames_per_s"]
         if roofline is not None:
             line["roofline"] = roofline
+            fem_leg = fem_roofline_entry(sw)
+            if fem_leg is not None:
+                roofline["fem"] = fem_leg
         if cpu is not None:
             line["cpu_baseline"] = cpu
     if use_dist:

@@ -30,19 +30,26 @@ def frames_per_tail_launch(write_dir):
     """Frames one tail launch renders, from what it WROTE: RGB is 12 B/px and nothing else of size leaves the kernel, so WRITE_SIZE
     per dispatch / (12 H W) is the frame count whatever pass policy the library chose.  (Round 3's 640x480 file was built with the
     320x240 default of 1024 frames where the 640x480 pass launches 256: every per-frame figure in it was 4x too small.)"""
-    tot, n = 0.0, 0
+    vals = {"taxim_stream_kernel": [], "taxim_tail_kernel": []}
     for f in glob.glob(os.path.join(write_dir, "**", "*counter_collection.csv"), recursive=True):
         for row in csv.DictReader(open(f)):
-            if row["Counter_Name"] == "WRITE_SIZE" and ("taxim_stream_kernel" in row["Kernel_Name"] or "taxim_tail_kernel" in row["Kernel_Name"]):
-                tot += float(row["Counter_Value"]); n += 1
-    if n == 0:
+            if row["Counter_Name"] == "WRITE_SIZE":
+                for k in vals:
+                    if k in row["Kernel_Name"]:
+                        vals[k].append(float(row["Counter_Value"]))
+    v = vals["taxim_stream_kernel"] or vals["taxim_tail_kernel"]  # (the tiled tail only runs the sensors' reset renders: not the pass size)
+    if not v:
         raise SystemExit("no tail dispatch in the WRITE_SIZE pass")
-    return tot / n * 1024 / (12.0 * H * W)
+    v.sort()
+    return v[len(v) // 2] * 1024 / (12.0 * H * W)  # median dispatch
 
 
 _fpl = frames_per_tail_launch(sys.argv[2])
 if FRAMES == 0:
-    FRAMES = int(round(_fpl))
+    # the tail also writes a few KB of observation partial sums and FOTS records per frame (+2-3 %): passes are multiples of 64 frames
+    FRAMES = max(64, int(round(_fpl / 64.0)) * 64)
+    if abs(_fpl / FRAMES - 1.0) > 0.06:
+        raise SystemExit(f"cannot tell the frames per tail launch from its writes ({_fpl:.1f} frames of {W}x{H} RGB per dispatch)")
 elif abs(_fpl / FRAMES - 1.0) > 0.1:
     raise SystemExit(f"frames_per_tail_launch={FRAMES} contradicts the tail's own writes ({_fpl:.1f} frames of {W}x{H} RGB per dispatch)")
 if len(sys.argv) <= 8:
