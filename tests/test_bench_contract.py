@@ -1,6 +1,6 @@
-"""The committed bench line (profiles/r02_bench_n1.json = stdout of `python bench.py` on the GPU box) follows the driver's
+"""The committed bench line (profiles/r04_bench_n1.json = stdout of `python bench.py` on the GPU box) follows the driver's
 contract: the headline keys, the `roofline` and `cpu_baseline` objects, the workload naming - and agrees with the kernel stats
-of the rocprofv3 run of the same command that sits beside it."""
+of the rocprofv3 run of the same command that sits beside it (same gpurun call, same box)."""
 import csv
 import json
 from pathlib import Path
@@ -9,7 +9,7 @@ REPO = Path(__file__).resolve().parent.parent
 
 
 def test_committed_bench_line_follows_the_contract():
-    d = json.loads((REPO / "profiles" / "r02_bench_n1.json").read_text())
+    d = json.loads((REPO / "profiles" / "r04_bench_n1.json").read_text())
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
               "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert k in d, k
@@ -24,12 +24,23 @@ def test_committed_bench_line_follows_the_contract():
     c = d["cpu_baseline"]
     assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0 and isinstance(c["sample"], str)
     assert {"C2", "C4", "C5"} <= {s["workload"][:2] for s in d["config"]["sweep"]}
+    # roofline.achieved = 16 B/px x the pixels of one launch of the dominant kernel / its measured duration
+    W, H = d["config"]["resolution"]
+    assert r["algorithmic_bytes_per_launch"] == 16 * W * H * r["frames_per_launch"]
+    assert abs(r["achieved"] - r["algorithmic_bytes_per_launch"] / (r["kernel_avg_ms"] * 1e-3) / 1e9) <= 1e-3 * r["achieved"]
+    assert r["frac_own_bytes"] >= r["frac"]
+    # the FEM scenes run every env to convergence: the cap is reported and must not have been hit (the continuity entry says it caps)
+    for e in d["config"]["sweep"]:
+        if "newton_cap" in e and "truncated_solves" not in e and "env_steps_per_s" not in e:
+            assert e["newton_iters_max_over_period"] < e["newton_cap"] and e["newton_cap_hit"] is False, e["workload"][:40]
+    f = r["fem"]
+    assert f["hbm_achieved"] is not None and 0 < f["hbm_frac"] < 1 and 0 < f["f64_frac"] < 1
 
 
 def test_roofline_duration_agrees_with_the_rocprof_summary():
-    d = json.loads((REPO / "profiles" / "r02_bench_n1.json").read_text())
+    d = json.loads((REPO / "profiles" / "r04_bench_n1.json").read_text())
     stage = d["roofline"]["stages"][d["roofline"]["kernel"]]
-    rows = list(csv.DictReader(open(REPO / "profiles" / "r02_c3_kernel_stats.csv")))
+    rows = list(csv.DictReader(open(REPO / "profiles" / "r04_c3_kernel_stats.csv")))
     k = next(r for r in rows if "taxim_stream_kernel" in r["Name"])
     assert abs(float(k["AverageNs"]) * 1e-6 - stage["avg_ms"]) <= 0.05 * stage["avg_ms"]  # hipEvent vs profiler: within 5 %
 
