@@ -32,7 +32,7 @@ extern "C" {
 #endif
 
 #define TACEX_MAX_LEVELS 8
-#define TACEX_ABI_VERSION 7
+#define TACEX_ABI_VERSION 8
 
 typedef struct tacex_taxim_ctx tacex_taxim_ctx;
 typedef struct tacex_fots_ctx tacex_fots_ctx;
@@ -380,6 +380,12 @@ int tacex_fem_set_friction(tacex_fem_ctx* ctx, double friction_ratio, double eps
  * An initial guess only - the step's minimiser is unchanged - but the one that lets a RETREATING indenter cost 2-3 Newton iterations
  * like a pressing one instead of 4-30 (libuipc starts from the current positions: world.advance(), US:250-252; 0 restores that). */
 int tacex_fem_set_contact_following(tacex_fem_ctx* ctx, int enable);
+
+/* Summation order of the CU-resident Newton kernel's tet -> vertex sums.  0 (default): per-tet rows are added into per-vertex LDS
+ * accumulators with ds_add_f64 - the order of a vertex's ~24 contributions depends on wave timing, so two runs agree to round-off
+ * (1e-16 relative per add), not bit for bit.  1: rows travel through an exchange window and are gathered in a fixed order (bit-identical
+ * runs, ~25 % more time per PCG iteration).  No counterpart in the reference (libuipc's CUDA backend uses atomics throughout). */
+int tacex_fem_set_deterministic(tacex_fem_ctx* ctx, int enable);
 
 /* Two-level preconditioner of the Newton system (CU-resident kernel): z = D^-1 r (3x3 block Jacobi, always) + P A_c^-1 P^T r.
  * P: every vertex has 8 (coarse node, weight) pairs - the trilinear hat functions of a small grid laid over the mesh

@@ -11,7 +11,7 @@ from pathlib import Path
 from ._build import LIB, build_library
 
 MAX_LEVELS = 8
-ABI_VERSION = 7  # TACEX_ABI_VERSION of include/tacex_hip.h; bumped whenever a signature or struct layout changes
+ABI_VERSION = 8  # TACEX_ABI_VERSION of include/tacex_hip.h; bumped whenever a signature or struct layout changes
 FLAG_NO_SHIFT = 1
 FLAG_HAVE_FRAME_MIN = 2
 FLAG_WITH_SHADOW = 4
@@ -140,6 +140,7 @@ SIGNATURES = {
     "tacex_fem_contact_gaps": (_i, [_vp, _vp, _vp, _i, _vp]),
     "tacex_fem_set_friction": (_i, [_vp, _d, _d]),
     "tacex_fem_set_contact_following": (_i, [_vp, _i]),
+    "tacex_fem_set_deterministic": (_i, [_vp, _i]),
     "tacex_fem_set_contact": (_i, [_vp, _vp, _d, _d, _vp]),
     "tacex_fem_set_newton_early_exit": (_i, [_vp, _vp, C.c_double]),
     "tacex_fem_set_attachment_targets": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),

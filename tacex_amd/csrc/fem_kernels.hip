@@ -1052,7 +1052,12 @@ constexpr int kFemFlagLsFailed = 2;     // a line search found no decrease even 
 // US:250-252, without a host round trip; tacex_fem_newton_step: max_newton = 1).  An env leaves the loop when the Newton
 // direction of an iteration moves no vertex by more than dx_tol (velocity_tol * dt, US:62-66) - the criterion looks at the UNSCALED
 // direction (IPC's test on the search direction): a CCD- or search-shortened update says nothing about convergence.
-template <bool MESH>
+// ATOM: per-tet rows are ADDED into per-vertex LDS accumulators with ds_add_f64 instead of travelling through the 48 KB exchange
+// window and a CSR gather: 2 barriers per sweep instead of 8, no gather phase, and the atomics of one tet batch overlap the f64
+// arithmetic of the next (no barrier between batches: wave skew no longer costs).  The price is the summation ORDER of a vertex's
+// ~24 contributions, which then depends on the timing of the waves: results agree to round-off (1e-16 relative per add), not
+// bit for bit from run to run.  `tacex_fem_set_deterministic(ctx, 1)` selects the window path (ATOM = false).
+template <bool MESH, bool ATOM>
 __global__ __launch_bounds__(kNwtThreads) void fem_newton_lds_kernel(FemDev m, double* xg, const double* xtg,
                                                                      const uint8_t* consg, const double* aimg, double* stats,
                                                                      int pcg_max_iter, double pcg_tol_rate, int ls_max_iter,
@@ -1150,6 +1155,18 @@ __global__ __launch_bounds__(kNwtThreads) void fem_newton_lds_kernel(FemDev m, d
     if (own) mdl[tid] = md;
   }
   auto chain_head = [&](int t) -> int { const int h = chd[t]; return h == 0xffff ? -1 : h; };
+  // ATOM sweeps leave most of the 48 KB window region idle (accumulators 3V doubles, preconditioner staging 6V + 6 kFemMaxCoarse): the
+  // inverse coarse operator moves in behind them as FLOATS when it fits (72 x 72 for the gelpad's 24 nodes: 20.7 KB) - the coarse
+  // solve of every PCG iteration then reads LDS instead of L2.  The host hands over float-representable entries
+  // (UipcSim.refresh_preconditioner rounds the symmetric inverse once), so this copy is exact and both sweep variants - and the
+  // oracle - apply the same operator.
+  float* acl = reinterpret_cast<float*>(hv + 6 * V + 6 * kFemMaxCoarse);
+  bool ac_lds = false;
+  if constexpr (ATOM) {
+    const int nn = 9 * m.nc * m.nc;
+    ac_lds = m.nc > 0 && (size_t)(6 * V + 6 * kFemMaxCoarse) * sizeof(double) + (size_t)nn * sizeof(float) <= (size_t)12 * CH * sizeof(double);
+    // (filled after the block factorisation of every Newton iteration: its exchange of the 15 V block entries runs over this region)
+  }
   __syncthreads();
 
 #ifdef TACEX_FEM_CLOCK  // debug build: cycles (s_memtime) of the sections of a PCG iteration, group TACEX_FEM_CLOCK of four -> stats
@@ -1166,7 +1183,54 @@ __global__ __launch_bounds__(kNwtThreads) void fem_newton_lds_kernel(FemDev m, d
   // owns kNwtTpw independent tets of the window), then vertex `tid` adds the rows of its incident tets inside the window
   // (CSR entries are sorted by tet, so a cursor suffices).  The mesh constants of the NEXT window are fetched while this
   // window is computed and gathered (they are the only global reads of the sweep).
-  auto sweep = [&](auto&& make, double acc[3]) {
+  // pre_zeroed (ATOM only): the caller has zeroed the accumulators before a barrier of its own (saves the sweep's first barrier)
+  auto sweep = [&](auto&& make, double acc[3], bool pre_zeroed = false) {
+    if constexpr (ATOM) {
+      const int tid_a = fresh_tid(wave_s);
+      double* av = hv;  // (V,3) accumulators at the head of the (otherwise idle) window region
+      if (!pre_zeroed && tid_a < V) { av[tid_a * 3] = 0.0; av[tid_a * 3 + 1] = 0.0; av[tid_a * 3 + 2] = 0.0; }
+      int vn[kNwtTpw][4];
+      double Din[kNwtTpw][9], voln[kNwtTpw];
+#pragma unroll
+      for (int u = 0; u < kNwtTpw; ++u) {
+        const int t = u * kNwtThreads + tid_a;
+        voln[u] = 0.0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) vn[u][k] = 0;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) Din[u][k] = 0.0;
+        if (t < T) load_tet_blk(m, t, vn[u], Din[u], voln[u]);
+      }
+      if (!pre_zeroed) __syncthreads();  // accumulators zeroed (and every reader of the window region's previous content is past it)
+      for (int j = 0; j < nchunk; ++j) {
+        int v[kNwtTpw][4];
+        double Di[kNwtTpw][9], vol[kNwtTpw];
+#pragma unroll
+        for (int u = 0; u < kNwtTpw; ++u) {
+          vol[u] = voln[u];
+#pragma unroll
+          for (int k = 0; k < 4; ++k) v[u][k] = vn[u][k];
+#pragma unroll
+          for (int k = 0; k < 9; ++k) Di[u][k] = Din[u][k];
+          const int tn = (j + 1) * CH + u * kNwtThreads + tid_a;
+          if (tn < T) load_tet_blk(m, tn, vn[u], Din[u], voln[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < kNwtTpw; ++u) {
+          if (j * CH + u * kNwtThreads + tid_a < T) {
+            double rows[12];
+            make(v[u], Di[u], vol[u], rows);
+#pragma unroll
+            for (int w = 0; w < 4; ++w)
+#pragma unroll
+              for (int i = 0; i < 3; ++i) atomicAdd(&av[v[u][w] * 3 + i], rows[w * 3 + i]);
+          }
+        }
+      }
+      __syncthreads();
+      acc[0] = tid_a < V ? av[tid_a * 3] : 0.0; acc[1] = tid_a < V ? av[tid_a * 3 + 1] : 0.0; acc[2] = tid_a < V ? av[tid_a * 3 + 2] : 0.0;
+      return;
+    }
     const int tid_s = fresh_tid(wave_s);
     int e = tid_s < V ? (int)vto[tid_s] : 0;
     const int e_end = tid_s < V ? (int)vto[tid_s + 1] : 0;
@@ -1494,6 +1558,10 @@ restart_iteration:
       }
     }
     __syncthreads();  // factors complete; the exchange region goes back to the PCG
+    if (ac_lds) {  // the inverse coarse operator back into its LDS slot (41 KB of L2 reads per Newton iteration instead of per PCG iteration)
+      const int nn = 9 * m.nc * m.nc;
+      for (int k = tid; k < nn; k += kNwtThreads) acl[k] = (float)ldg_off<double>(m.ac_inv, (unsigned)k * 8u);
+    }
   }
   // ---- preconditioner: z = D^-1 r (3x3 block Jacobi) + P A_c^-1 P^T r (additive coarse-grid correction) ----
   // Block Jacobi alone needs 120-330 PCG iterations on the thin, nearly incompressible pad: the error it cannot reach is
@@ -1594,9 +1662,14 @@ restart_iteration:
       const int dof = tid_p / H, h = tid_p - dof * H;
       double acc = 0.0;
       if (dof < nc3) {
-        const unsigned row = (unsigned)(dof * nc3) * 8u;  // (3 nc)^2 doubles <= 288 KB: 32-bit byte offsets
         const int q1 = min(nc3, (h + 1) * Q);
-        for (int q = h * Q; q < q1; ++q) acc += ldg_off<double>(m.ac_inv, row + (unsigned)q * 8u) * rc[q];
+        if (ac_lds) {
+          const float* rowl = acl + dof * nc3;
+          for (int q = h * Q; q < q1; ++q) acc += (double)rowl[q] * rc[q];
+        } else {
+          const unsigned row = (unsigned)(dof * nc3) * 8u;  // (3 nc)^2 doubles <= 288 KB: 32-bit byte offsets
+          for (int q = h * Q; q < q1; ++q) acc += ldg_off<double>(m.ac_inv, row + (unsigned)q * 8u) * rc[q];
+        }
       }
       for (int o = H >> 1; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
       if (dof < nc3 && h == 0) yc[dof] = acc;
@@ -1647,6 +1720,8 @@ restart_iteration:
     if (own) {
 #pragma unroll
       for (int i = 0; i < 3; ++i) ps[tid * 3 + i] = warm ? d3[i] : p3[i];
+      if constexpr (ATOM) { hv[tid * 3] = 0.0; hv[tid * 3 + 1] = 0.0; hv[tid * 3 + 2] = 0.0; }  // the sweep's accumulators (a block reduction's
+                                                                                            // barrier lies behind the last reader of the region)
     }
     __syncthreads();
     // Hq = (M + s Mc + dt^2 K) q, matrix-free: per-tet dP[dF(q)] rows, gathered per vertex
@@ -1665,7 +1740,7 @@ restart_iteration:
 #pragma unroll
         for (int i = 0; i < 3; ++i)
           rows[w * 3 + i] = sc * (dP[i * 3 + 0] * r[w * 3 + 0] + dP[i * 3 + 1] * r[w * 3 + 1] + dP[i * 3 + 2] * r[w * 3 + 2]);
-    }, a3);
+    }, a3, ATOM);
     FEM_TICK(0);
     // (q is read back from LDS - the sweep leaves ps alone - rather than carried in registers across the tet arithmetic: the loop
     //  body holds ~250 live registers there, and every value carried across it went to scratch)
@@ -1954,6 +2029,7 @@ struct tacex_fem_ctx {
   // caller animating the indenter by passing fresh tensors) keeps them: only disabling contact or its first enable resets.
   const void* ind_prev_ws = nullptr;
   int ind_prev_B = 0;
+  bool deterministic = false;   // window + CSR-gather sweeps (fixed summation order) instead of LDS atomics (tacex_fem_set_deterministic)
   bool follow_indenter = true;  // contact-following start of the Newton loop (tacex_fem_set_contact_following; fem_newton_lds_kernel)
   double* dx_dev = nullptr;  // optional (B,) last Newton update max|dx| per env: converged envs skip further iterations
   double dx_tol = 0.0;
@@ -2195,6 +2271,12 @@ int tacex_fem_contact_gaps(tacex_fem_ctx* c, const double* x_dev, double* gaps_d
   return e == hipSuccess ? 0 : fail_hip(e, "fem_contact_gaps_kernel");
 }
 
+int tacex_fem_set_deterministic(tacex_fem_ctx* c, int enable) {
+  if (!c) { set_error("tacex_fem_set_deterministic: null context"); return 2; }
+  c->deterministic = enable != 0;
+  return 0;
+}
+
 int tacex_fem_set_contact_following(tacex_fem_ctx* c, int enable) {
   if (!c) { set_error("tacex_fem_set_contact_following: null context"); return 2; }
   c->follow_indenter = enable != 0;
@@ -2406,11 +2488,14 @@ static int launch_newton(tacex_fem_ctx* c, double* x, const double* xt, const ui
                        ((size_t)4 * c->dev.T + 3 * (size_t)c->dev.V + kNwtThreads + 1) * sizeof(unsigned short)) + 15) & ~(size_t)15;
   if (use_lds && c->dev.V <= kNwtThreads && 4 * c->dev.T < 65535 && lds <= 160 * 1024) {
     if (resident) *resident = true;
-    static size_t granted[2][64] = {};  // per device: the attribute is per kernel AND device
+    static size_t granted[4][64] = {};  // per kernel instantiation and device: the attribute is per kernel AND device
     const bool mesh = c->dev.indenters && c->dev.im_nt > 0;  // the mesh-capable instantiation only when a mesh indenter exists
-    auto kern = mesh ? fem_newton_lds_kernel<true> : fem_newton_lds_kernel<false>;
+    static const int env_atomic = getenv("TACEX_FEM_ATOMIC") ? atoi(getenv("TACEX_FEM_ATOMIC")) : 1;  // A/B hook
+    const bool atom = env_atomic != 0 && !c->deterministic;
+    auto kern = mesh ? (atom ? fem_newton_lds_kernel<true, true> : fem_newton_lds_kernel<true, false>)
+                     : (atom ? fem_newton_lds_kernel<false, true> : fem_newton_lds_kernel<false, false>);
     hipError_t ea = hipSetDevice(c->device);
-    if (ea == hipSuccess) ea = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds, granted[mesh ? 1 : 0]);
+    if (ea == hipSuccess) ea = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds, granted[(mesh ? 1 : 0) + (atom ? 2 : 0)]);
     if (ea != hipSuccess) return fail_hip(ea, "hipFuncSetAttribute(fem_newton_lds_kernel)");
     hipLaunchKernelGGL(kern, dim3(B), dim3(kNwtThreads), lds, st, c->dev_nwt, x, xt, cons, aim, stats, pcg_max_iter,
                        pcg_tol_rate, ls_max_iter, dx_dev, dx_tol, max_newton, step_info, fric ? xprev : nullptr,

@@ -48,6 +48,9 @@ class UipcSimCfg:
         tol_rate: float = 1e-3
         max_iter: int = 1024
         """PCG iteration cap (not in the reference cfg, uipc_sim.py:86-90: libuipc stops on `tol_rate`); only guards against stagnation."""
+        deterministic: bool = False
+        """True: tet -> vertex sums in a fixed order (bit-identical runs); False: LDS atomics (`tacex_fem_set_deterministic`): two runs
+        agree to round-off, a PCG iteration is ~25 % cheaper.  Not in the reference cfg."""
         coarse_grid: tuple | str | None = "auto"
         """Coarse grid (cells per axis) of the additive coarse correction beside the 3x3 block Jacobi (`coarse_space.py`):
         "auto" = 3 cells along the longest extent of the mesh, proportionally fewer along the others (2 x 3 x 1 = 24 nodes for the
@@ -132,6 +135,7 @@ class UipcSim:
         h = C.c_void_p()
         _lib.check(lib.tacex_fem_create(self._dev_index, C.byref(p), C.byref(h)), "tacex_fem_create")
         self._handle, self._lib, self._obj = h, lib, obj
+        _lib.check(lib.tacex_fem_set_deterministic(h, 1 if self.cfg.linear_system.deterministic else 0), "tacex_fem_set_deterministic")
         B, V = self.num_envs, obj.num_verts
         dev = self.device
         self.x = torch.from_numpy(obj.points).to(dev)[None].repeat(B, 1, 1).contiguous()  # (B,V,3) float64
@@ -333,7 +337,10 @@ class UipcSim:
         mass = np.zeros(len(P))
         np.add.at(mass, T.reshape(-1), np.repeat(obj.cfg.mass_density * vol / 4.0, 4))
         cons = self.is_constrained[0].cpu().numpy().astype(np.float64)
-        aci = np.ascontiguousarray(coarse_operator_inverse(He, T, mass, cons, self._strength, self.cfg.dt, node, w, nc))
+        aci = coarse_operator_inverse(He, T, mass, cons, self._strength, self.cfg.dt, node, w, nc)
+        # symmetrised and rounded to float32-representable values ONCE, here: the Newton kernel may keep the operator in LDS as floats
+        # (exactly these values), the streaming kernel and the oracle read them as doubles - one operator everywhere
+        aci = np.ascontiguousarray((0.5 * (aci + aci.T)).astype(np.float32).astype(np.float64))
         node, w = np.ascontiguousarray(node, np.int32), np.ascontiguousarray(w, np.float64)
         _lib.check(self._lib.tacex_fem_set_coarse_space(self._handle, nc, node.ctypes.data, w.ctypes.data, aci.ctypes.data),
                    "tacex_fem_set_coarse_space")
