@@ -1155,18 +1155,6 @@ __global__ __launch_bounds__(kNwtThreads) void fem_newton_lds_kernel(FemDev m, d
     if (own) mdl[tid] = md;
   }
   auto chain_head = [&](int t) -> int { const int h = chd[t]; return h == 0xffff ? -1 : h; };
-  // ATOM sweeps leave most of the 48 KB window region idle (accumulators 3V doubles, preconditioner staging 6V + 6 kFemMaxCoarse): the
-  // inverse coarse operator moves in behind them as FLOATS when it fits (72 x 72 for the gelpad's 24 nodes: 20.7 KB) - the coarse
-  // solve of every PCG iteration then reads LDS instead of L2.  The host hands over float-representable entries
-  // (UipcSim.refresh_preconditioner rounds the symmetric inverse once), so this copy is exact and both sweep variants - and the
-  // oracle - apply the same operator.
-  float* acl = reinterpret_cast<float*>(hv + 6 * V + 6 * kFemMaxCoarse);
-  bool ac_lds = false;
-  if constexpr (ATOM) {
-    const int nn = 9 * m.nc * m.nc;
-    ac_lds = m.nc > 0 && (size_t)(6 * V + 6 * kFemMaxCoarse) * sizeof(double) + (size_t)nn * sizeof(float) <= (size_t)12 * CH * sizeof(double);
-    // (filled after the block factorisation of every Newton iteration: its exchange of the 15 V block entries runs over this region)
-  }
   __syncthreads();
 
 #ifdef TACEX_FEM_CLOCK  // debug build: cycles (s_memtime) of the sections of a PCG iteration, group TACEX_FEM_CLOCK of four -> stats
@@ -1558,10 +1546,6 @@ restart_iteration:
       }
     }
     __syncthreads();  // factors complete; the exchange region goes back to the PCG
-    if (ac_lds) {  // the inverse coarse operator back into its LDS slot (41 KB of L2 reads per Newton iteration instead of per PCG iteration)
-      const int nn = 9 * m.nc * m.nc;
-      for (int k = tid; k < nn; k += kNwtThreads) acl[k] = (float)ldg_off<double>(m.ac_inv, (unsigned)k * 8u);
-    }
   }
   // ---- preconditioner: z = D^-1 r (3x3 block Jacobi) + P A_c^-1 P^T r (additive coarse-grid correction) ----
   // Block Jacobi alone needs 120-330 PCG iterations on the thin, nearly incompressible pad: the error it cannot reach is
@@ -1663,13 +1647,8 @@ restart_iteration:
       double acc = 0.0;
       if (dof < nc3) {
         const int q1 = min(nc3, (h + 1) * Q);
-        if (ac_lds) {
-          const float* rowl = acl + dof * nc3;
-          for (int q = h * Q; q < q1; ++q) acc += (double)rowl[q] * rc[q];
-        } else {
-          const unsigned row = (unsigned)(dof * nc3) * 8u;  // (3 nc)^2 doubles <= 288 KB: 32-bit byte offsets
-          for (int q = h * Q; q < q1; ++q) acc += ldg_off<double>(m.ac_inv, row + (unsigned)q * 8u) * rc[q];
-        }
+        const unsigned row = (unsigned)(dof * nc3) * 8u;  // (3 nc)^2 doubles <= 288 KB: 32-bit byte offsets
+        for (int q = h * Q; q < q1; ++q) acc += ldg_off<double>(m.ac_inv, row + (unsigned)q * 8u) * rc[q];
       }
       for (int o = H >> 1; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
       if (dof < nc3 && h == 0) yc[dof] = acc;

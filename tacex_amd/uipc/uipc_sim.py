@@ -337,10 +337,7 @@ class UipcSim:
         mass = np.zeros(len(P))
         np.add.at(mass, T.reshape(-1), np.repeat(obj.cfg.mass_density * vol / 4.0, 4))
         cons = self.is_constrained[0].cpu().numpy().astype(np.float64)
-        aci = coarse_operator_inverse(He, T, mass, cons, self._strength, self.cfg.dt, node, w, nc)
-        # symmetrised and rounded to float32-representable values ONCE, here: the Newton kernel may keep the operator in LDS as floats
-        # (exactly these values), the streaming kernel and the oracle read them as doubles - one operator everywhere
-        aci = np.ascontiguousarray((0.5 * (aci + aci.T)).astype(np.float32).astype(np.float64))
+        aci = np.ascontiguousarray(coarse_operator_inverse(He, T, mass, cons, self._strength, self.cfg.dt, node, w, nc))
         node, w = np.ascontiguousarray(node, np.int32), np.ascontiguousarray(w, np.float64)
         _lib.check(self._lib.tacex_fem_set_coarse_space(self._handle, nc, node.ctypes.data, w.ctypes.data, aci.ctypes.data),
                    "tacex_fem_set_coarse_space")

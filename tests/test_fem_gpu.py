@@ -791,6 +791,7 @@ def test_friction_sees_indenter_motion_through_a_new_tensor_every_step():
     for fresh in (False, True):
         sim, m, P, cons, aim, cms = _c4_scene(1)
         sim.cfg.newton.velocity_tol = 1e-3
+        assert sim._lib.tacex_fem_set_deterministic(sim._handle, 1) == 0  # fixed summation order: the comparison below is bit for bit
         sim.set_contact_indenters(sim.contact_indenters)
         row = sim.contact_indenters.clone()
         for k in range(6):
@@ -809,9 +810,7 @@ def test_friction_sees_indenter_motion_through_a_new_tensor_every_step():
         res.append(sim.x.cpu().numpy().copy())
     top = P[:, 2] > P[:, 2].max() - 1e-9
     assert (res[0][0][top, 0] - P[top, 0]).max() > 2e-5  # friction dragged the surface along +x
-    # (bit-identical with the deterministic sweeps; the default LDS-atomic sweeps add a vertex's tet contributions in a timing-dependent
-    #  order: round-off apart, far inside the Newton tolerance)
-    np.testing.assert_allclose(res[0], res[1], rtol=0, atol=1e-3 * 1e-3 * 0.01)
+    np.testing.assert_array_equal(res[0], res[1])  # (deterministic sweeps, see above: the two ways of moving the indenter are the SAME computation)
 
 
 def test_contact_following_start_is_only_an_initial_guess_and_tames_the_retreat():
