@@ -592,10 +592,10 @@ def fem_roofline_entry(sw):
     PMC passes of `scripts/fem_bench.py`, profiles/pmc_traffic_r04_fem.json, over the kernel's mean duration in the kernel-trace run of
     the same command) and, live from the C4 sweep entry, the f64 vector rate and LDS rate of the CU an env sits on."""
     c4 = next((e for e in (sw or []) if e.get("workload", "").startswith("C4 per-GPU shard:") and "fem" in e), None)
-    out = {"kernel": "fem_newton_lds_kernel<false> (one dispatch = the whole Newton loop of a time step for all envs of the shard)"}
+    out = {"kernel": "fem_newton_lds_kernel<MESH = false, ATOM = true> (one dispatch = the whole Newton loop of a time step for all envs of the shard)"}
     try:
         j = json.loads((REPO / "profiles" / "pmc_traffic_r04_fem.json").read_text())
-        k = next(v for n, v in j["kernels"].items() if "fem_newton_lds_kernel<false>" in n)
+        k = next(v for n, v in j["kernels"].items() if "fem_newton_lds_kernel<false" in n)  # (<MESH = false, ATOM = ...>)
         out.update({"hbm_bytes_per_dispatch": k["hbm_bytes_per_dispatch"], "mean_us_per_dispatch": k.get("mean_us_per_dispatch"),
                     "hbm_achieved": k.get("hbm_GBps"), "hbm_peak": HBM_PEAK_GBS, "hbm_unit": "GB/s", "hbm_frac": k.get("hbm_frac_of_8TBps"),
                     "hbm_source": "profiles/pmc_traffic_r04_fem.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE + --kernel-trace --stats of scripts/fem_bench.py)",
