@@ -1063,7 +1063,7 @@ __global__ __launch_bounds__(kNwtThreads) void fem_newton_lds_kernel(FemDev m, d
                                                                      int pcg_max_iter, double pcg_tol_rate, int ls_max_iter,
                                                                      double* dxg, double dx_tol, int max_newton, double* step_info,
                                                                      const double* xprevg, const double* dispg, const int* env_order,
-                                                                     int follow, double* lagg) {
+                                                                     int follow, double* lagg, const double* velg) {
   extern __shared__ __attribute__((aligned(16))) double nlds[];
   constexpr int CH = kNwtChunk;
   const int V = m.V, T = m.T;
@@ -1401,7 +1401,65 @@ restart_iteration:
 #pragma unroll
       for (int k = 0; k < 9; ++k) E[k] = lagw[(6 + k) * V + tid];
     }
-    if (own && lag_fresh) {
+    if constexpr (ATOM) {
+      // TET-CENTRIC assembly (the atomic variant of the kernel): every tet's state is computed ONCE - the vertex-centric loop below computes it
+      // once per incident vertex, four times - and its shares of the four diagonal blocks (upper triangles) and of the chain blocks
+      // (v, next(v)) are added into the (V,15) exchange array with ds_add_f64; a vertex then reads its 15 entries back.  Tets come
+      // through the wave-blocked table (coalesced) instead of one AoS record per lane.
+      if (lag_fresh) {  // (block-uniform)
+        double* xa = ps;  // the exchange array of the factorisation below
+        __syncthreads();  // the gradient sweep's accumulators (inside this region) have been read by their vertices
+        for (int k = tid; k < 15 * V; k += kNwtThreads) xa[k] = 0.0;
+        __syncthreads();
+        for (int t = tid; t < T; t += kNwtThreads) {
+          int v[4];
+          double Di[9], F[9], r[12], vol_t;
+          load_tet_blk(m, t, v, Di, vol_t);
+          deformation_gradient(xs, v, Di, F);
+          TetState s;
+          tet_state(m, F, s);
+          shape_rows(Di, r);
+          const double sc = dt2 * vol_t;
+#pragma unroll
+          for (int l = 0; l < 4; ++l) {
+            double* q = xa + v[l] * 15;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+              double dF[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, dP[9];
+              dF[k * 3 + 0] = r[l * 3 + 0]; dF[k * 3 + 1] = r[l * 3 + 1]; dF[k * 3 + 2] = r[l * 3 + 2];
+              apply_dP(m, s, dF, dP);
+#pragma unroll
+              for (int i = 0; i <= k; ++i)  // upper triangle: (0,0) (0,1) (1,1) (0,2) (1,2) (2,2) -> q[0], q[1], q[3], q[2], q[4], q[5]
+                atomicAdd(&q[i == 0 ? k : (i == 1 ? 2 + k : 5)],
+                          sc * (dP[i * 3 + 0] * r[l * 3 + 0] + dP[i * 3 + 1] * r[l * 3 + 1] + dP[i * 3 + 2] * r[l * 3 + 2]));
+            }
+            const int nv = cnx[v[l]] == 0xffff ? -1 : (int)cnx[v[l]];
+            const int l2 = nv < 0 ? -1 : (v[0] == nv ? 0 : (v[1] == nv ? 1 : (v[2] == nv ? 2 : (v[3] == nv ? 3 : -1))));
+            if (l2 >= 0) {  // this tet also holds the chain successor of vertex l: its share of the block (v_l, next(v_l))
+              const double rn[3] = {r[l2 * 3 + 0], r[l2 * 3 + 1], r[l2 * 3 + 2]};
+#pragma unroll
+              for (int k = 0; k < 3; ++k) {
+                double dF[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, dP[9];
+                dF[k * 3 + 0] = rn[0]; dF[k * 3 + 1] = rn[1]; dF[k * 3 + 2] = rn[2];
+                apply_dP(m, s, dF, dP);
+#pragma unroll
+                for (int i = 0; i < 3; ++i)
+                  atomicAdd(&q[6 + i * 3 + k], sc * (dP[i * 3 + 0] * r[l * 3 + 0] + dP[i * 3 + 1] * r[l * 3 + 1] + dP[i * 3 + 2] * r[l * 3 + 2]));
+              }
+            }
+          }
+        }
+        __syncthreads();
+        if (own) {
+          const double* q = xa + tid * 15;
+          D[0] = q[0]; D[1] = q[1]; D[2] = q[2]; D[4] = q[3]; D[5] = q[4]; D[8] = q[5];
+          D[3] = D[1]; D[6] = D[2]; D[7] = D[5];
+#pragma unroll
+          for (int k = 0; k < 9; ++k) E[k] = q[6 + k];
+        }
+      }
+    }
+    if (!ATOM && own && lag_fresh) {
       const int nv = cnx[tid] == 0xffff ? -1 : (int)cnx[tid];
       for (int e = (int)vto[tid], e_end = (int)vto[tid + 1]; e < e_end; ++e) {
         const int code = csr[e];
@@ -1690,6 +1748,22 @@ restart_iteration:
   if (warm) {
 #pragma unroll
     for (int i = 0; i < 3; ++i) d3[i] = frac_prev * dprev[i];
+  } else if (velg != nullptr && nit == 0 && rz_b > 0.0) {
+    // VELOCITY WARM START of a time step's first solve (tacex_fem_step): the pad keeps moving the way it moved in the previous step
+    // (it follows an indenter that presses on or retreats), so d0 = (x_n + dt v_n) - x - the previous step's displacement, less what the
+    // contact-following start and the edge snap already applied - is most of the Newton direction: the PCG starts from r = b - H d0
+    // (one extra H.p sweep) and stops on the same criterion (relative to the right-hand side).  A step after a reversal starts from
+    // a poor guess and converges as before.
+    double any = 0.0;
+    if (own) {
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        d3[i] = (x[tid * 3 + i] + m.dt * velg[o + tid * 3 + i]) - x3[i];  // (x: the positions the step started from, still in global memory)
+        any = fmax(any, fabs(d3[i]));
+      }
+    }
+    warm = __syncthreads_or(any > 0.0) != 0;
+    if (!warm) { d3[0] = 0.0; d3[1] = 0.0; d3[2] = 0.0; }
   }
   int it = 0;
   while (warm || (it < pcg_max_iter && rz_b > 0.0 && rz > pcg_tol_rate * pcg_tol_rate * rz_b)) {
@@ -2008,6 +2082,7 @@ struct tacex_fem_ctx {
   // caller animating the indenter by passing fresh tensors) keeps them: only disabling contact or its first enable resets.
   const void* ind_prev_ws = nullptr;
   int ind_prev_B = 0;
+  bool velocity_warm_start = true;  // first PCG of a step starts from the previous step's displacement (TACEX_FEM_VEL_WARM=0: zero start)
   bool deterministic = false;   // window + CSR-gather sweeps (fixed summation order) instead of LDS atomics (tacex_fem_set_deterministic)
   bool follow_indenter = true;  // contact-following start of the Newton loop (tacex_fem_set_contact_following; fem_newton_lds_kernel)
   double* dx_dev = nullptr;  // optional (B,) last Newton update max|dx| per env: converged envs skip further iterations
@@ -2102,6 +2177,7 @@ int tacex_fem_create(int device_id, const tacex_fem_params* p, tacex_fem_ctx** o
   hipError_t e = hipSetDevice(device_id);
   if (e != hipSuccess) return fail_hip(e, "hipSetDevice");
   auto* c = new tacex_fem_ctx();
+  if (const char* e = getenv("TACEX_FEM_VEL_WARM")) c->velocity_warm_start = atoi(e) != 0;  // A/B hook
   c->device = device_id;
   FemDev& d = c->dev;
   d.V = V; d.T = T;
@@ -2457,7 +2533,7 @@ int tacex_fem_set_newton_early_exit(tacex_fem_ctx* c, double* dx_dev, double dx_
 static int launch_newton(tacex_fem_ctx* c, double* x, const double* xt, const uint8_t* cons, const double* aim, double* stats, void* ws,
                          int B, int pcg_max_iter, double pcg_tol_rate, int ls_max_iter, double* dx_dev, double dx_tol, int max_newton,
                          double* step_info, hipStream_t st, bool* resident, const double* xprev = nullptr, const double* disp = nullptr,
-                         const int* env_order = nullptr) {
+                         const int* env_order = nullptr, const double* vel = nullptr) {
   static const int use_lds = getenv("TACEX_FEM_NEWTON_LDS") ? atoi(getenv("TACEX_FEM_NEWTON_LDS")) : 1;
   const bool fric = xprev && disp && c->dev.indenters && c->dev.fric_mu > 0.0;
   // x, p | window | sums | [friction lag] || chain factors | [friction Hessian blocks] (floats) || incidence codes | chain links (u16)
@@ -2479,7 +2555,8 @@ static int launch_newton(tacex_fem_ctx* c, double* x, const double* xt, const ui
     hipLaunchKernelGGL(kern, dim3(B), dim3(kNwtThreads), lds, st, c->dev_nwt, x, xt, cons, aim, stats, pcg_max_iter,
                        pcg_tol_rate, ls_max_iter, dx_dev, dx_tol, max_newton, step_info, fric ? xprev : nullptr,
                        (xprev && disp && c->dev.indenters) ? disp : nullptr, env_order, c->follow_indenter ? 1 : 0,
-                       max_newton > 1 ? static_cast<double*>(ws) : nullptr);  // env blocks of the workspace: (15, V) lagged blocks per env
+                       max_newton > 1 ? static_cast<double*>(ws) : nullptr,  // env blocks of the workspace: (15, V) lagged blocks per env
+                       c->velocity_warm_start ? vel : nullptr);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : fail_hip(e, "fem_newton_lds_kernel");
   }
@@ -2541,7 +2618,7 @@ int tacex_fem_step(tacex_fem_ctx* c, double* x, double* v, double* xt, const uin
   }
   bool resident = false;
   if (int rc = launch_newton(c, x, xt, cons, aim, stats, ws, B, pcg_max_iter, pcg_tol_rate, ls_max_iter, dx, tol, max_newton, step_info, st,
-                             &resident, xprev, disp, env_order))
+                             &resident, xprev, disp, env_order, v))
     return rc;
   if (!resident) {
     // streaming fallback: one launch per Newton iteration on a FIXED schedule; converged envs return at once (dx protocol), so the
