@@ -677,15 +677,13 @@ def edge_snap(m, cm, x, x_tilde, constrained, aim, x_prec=None):
 
 
 def newton_step_contact(m: "FemModel", cm: ContactModel, x, x_tilde, constrained=None, aim=None, pcg_max_iter=64, pcg_tol_rate=1e-3,
-                        ls_max_iter=8, coarse=None, d0=None, return_dir=False, fr: "FrictionModel | None" = None, chains=None, x_prec=None, edge=True, d0_target=None):
+                        ls_max_iter=8, coarse=None, d0=None, return_dir=False, fr: "FrictionModel | None" = None, chains=None, x_prec=None, edge=True):
     """`FemModel.newton_step` with the barrier terms of `cm` in gradient, preconditioner, H.p and energy, and the CCD step
     filter in front of the backtracking line search.  Returns (x_new, [E0, E1, step, pcg_iters]).  `x_prec`: the state the ELASTIC
     blocks of the preconditioner are taken at (tacex_fem_step lags them: assembled in the first Newton iteration of the step and
     reused by the later ones; barrier and friction blocks are always those of x)."""
     if edge:
         x, _ = edge_snap(m, cm, x, x_tilde, constrained, aim, x_prec)
-    if d0_target is not None:  # velocity warm start: what is left of the predicted displacement from the (snapped) iterate
-        d0 = d0_target - x
     g = m.gradient(x, x_tilde, constrained, aim) + cm.gradient(x)
     Hc = cm.hess_blocks(x)
     if fr is not None:
@@ -715,7 +713,7 @@ def newton_step_contact(m: "FemModel", cm: ContactModel, x, x_tilde, constrained
 
 
 def fem_step(m: "FemModel", cm, x, v, constrained=None, aim=None, gravity=(0.0, 0.0, -9.8), max_newton=8, velocity_tol=0.05,
-             pcg_max_iter=1024, pcg_tol_rate=1e-3, ls_max_iter=8, coarse=None, friction=None, chains=None, indenter_disp=None, lag_prec=True, vel_warm=True):
+             pcg_max_iter=1024, pcg_tol_rate=1e-3, ls_max_iter=8, coarse=None, friction=None, chains=None, indenter_disp=None, lag_prec=True):
     """One backward-Euler step of ONE env the way `tacex_fem_step` runs it (what world.advance() does, US:250-252):
     x_tilde = x + dt v + dt^2 g; Newton iterations until the UNSCALED Newton direction of one has max |d| <= velocity_tol * dt
     (US:62-66; IPC's test on the search direction) or the cap; v = (x_new - x) / dt.  Returns (x_new, v_new, info) with
@@ -740,18 +738,14 @@ def fem_step(m: "FemModel", cm, x, v, constrained=None, aim=None, gravity=(0.0, 
     fric_pending = friction is not None and cm is not None
     fr = None
     n, flags, pcg, dmax = 0, 0, 0, np.inf
-    # velocity warm start of the step's first PCG (fem_newton_lds_kernel): the previous step's displacement, less what the
-    # contact-following start already applied
     d0 = None
-    d0_target = (x0 + m.dt * v) if vel_warm else None
     # the elastic preconditioner blocks of the whole step are those of its first iteration (see newton_step_contact); lag_prec=False:
     # fresh blocks every iteration (the streaming kernel of meshes with more than 512 vertices)
     x_prec = x if lag_prec else None
     for _ in range(max_newton):
         if cm is not None:
             x, st, d = newton_step_contact(m, cm, x, xt, constrained, aim, pcg_max_iter, pcg_tol_rate, ls_max_iter, coarse, d0, True, fr, chains,
-                                           x_prec, True, d0_target)
-            d0_target = None  # (first iteration only)
+                                           x_prec)
         else:
             x, st, d = m.newton_step(x, xt, constrained, aim, pcg_max_iter, pcg_tol_rate, ls_max_iter, coarse, d0, True, chains)
         d0 = (1.0 - st[2]) * d if 0.0 < st[2] < 1.0 else None  # warm start of the next PCG: the part of d that was cut off

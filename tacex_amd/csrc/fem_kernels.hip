@@ -1063,7 +1063,7 @@ __global__ __launch_bounds__(kNwtThreads) void fem_newton_lds_kernel(FemDev m, d
                                                                      int pcg_max_iter, double pcg_tol_rate, int ls_max_iter,
                                                                      double* dxg, double dx_tol, int max_newton, double* step_info,
                                                                      const double* xprevg, const double* dispg, const int* env_order,
-                                                                     int follow, double* lagg, const double* velg) {
+                                                                     int follow, double* lagg) {
   extern __shared__ __attribute__((aligned(16))) double nlds[];
   constexpr int CH = kNwtChunk;
   const int V = m.V, T = m.T;
@@ -1748,22 +1748,6 @@ restart_iteration:
   if (warm) {
 #pragma unroll
     for (int i = 0; i < 3; ++i) d3[i] = frac_prev * dprev[i];
-  } else if (velg != nullptr && nit == 0 && rz_b > 0.0) {
-    // VELOCITY WARM START of a time step's first solve (tacex_fem_step): the pad keeps moving the way it moved in the previous step
-    // (it follows an indenter that presses on or retreats), so d0 = (x_n + dt v_n) - x - the previous step's displacement, less what the
-    // contact-following start and the edge snap already applied - is most of the Newton direction: the PCG starts from r = b - H d0
-    // (one extra H.p sweep) and stops on the same criterion (relative to the right-hand side).  A step after a reversal starts from
-    // a poor guess and converges as before.
-    double any = 0.0;
-    if (own) {
-#pragma unroll
-      for (int i = 0; i < 3; ++i) {
-        d3[i] = (x[tid * 3 + i] + m.dt * velg[o + tid * 3 + i]) - x3[i];  // (x: the positions the step started from, still in global memory)
-        any = fmax(any, fabs(d3[i]));
-      }
-    }
-    warm = __syncthreads_or(any > 0.0) != 0;
-    if (!warm) { d3[0] = 0.0; d3[1] = 0.0; d3[2] = 0.0; }
   }
   int it = 0;
   while (warm || (it < pcg_max_iter && rz_b > 0.0 && rz > pcg_tol_rate * pcg_tol_rate * rz_b)) {
@@ -2082,7 +2066,6 @@ struct tacex_fem_ctx {
   // caller animating the indenter by passing fresh tensors) keeps them: only disabling contact or its first enable resets.
   const void* ind_prev_ws = nullptr;
   int ind_prev_B = 0;
-  bool velocity_warm_start = true;  // first PCG of a step starts from the previous step's displacement (TACEX_FEM_VEL_WARM=0: zero start)
   bool deterministic = false;   // window + CSR-gather sweeps (fixed summation order) instead of LDS atomics (tacex_fem_set_deterministic)
   bool follow_indenter = true;  // contact-following start of the Newton loop (tacex_fem_set_contact_following; fem_newton_lds_kernel)
   double* dx_dev = nullptr;  // optional (B,) last Newton update max|dx| per env: converged envs skip further iterations
@@ -2177,7 +2160,6 @@ int tacex_fem_create(int device_id, const tacex_fem_params* p, tacex_fem_ctx** o
   hipError_t e = hipSetDevice(device_id);
   if (e != hipSuccess) return fail_hip(e, "hipSetDevice");
   auto* c = new tacex_fem_ctx();
-  if (const char* e = getenv("TACEX_FEM_VEL_WARM")) c->velocity_warm_start = atoi(e) != 0;  // A/B hook
   c->device = device_id;
   FemDev& d = c->dev;
   d.V = V; d.T = T;
@@ -2533,7 +2515,7 @@ int tacex_fem_set_newton_early_exit(tacex_fem_ctx* c, double* dx_dev, double dx_
 static int launch_newton(tacex_fem_ctx* c, double* x, const double* xt, const uint8_t* cons, const double* aim, double* stats, void* ws,
                          int B, int pcg_max_iter, double pcg_tol_rate, int ls_max_iter, double* dx_dev, double dx_tol, int max_newton,
                          double* step_info, hipStream_t st, bool* resident, const double* xprev = nullptr, const double* disp = nullptr,
-                         const int* env_order = nullptr, const double* vel = nullptr) {
+                         const int* env_order = nullptr) {
   static const int use_lds = getenv("TACEX_FEM_NEWTON_LDS") ? atoi(getenv("TACEX_FEM_NEWTON_LDS")) : 1;
   const bool fric = xprev && disp && c->dev.indenters && c->dev.fric_mu > 0.0;
   // x, p | window | sums | [friction lag] || chain factors | [friction Hessian blocks] (floats) || incidence codes | chain links (u16)
@@ -2555,8 +2537,7 @@ static int launch_newton(tacex_fem_ctx* c, double* x, const double* xt, const ui
     hipLaunchKernelGGL(kern, dim3(B), dim3(kNwtThreads), lds, st, c->dev_nwt, x, xt, cons, aim, stats, pcg_max_iter,
                        pcg_tol_rate, ls_max_iter, dx_dev, dx_tol, max_newton, step_info, fric ? xprev : nullptr,
                        (xprev && disp && c->dev.indenters) ? disp : nullptr, env_order, c->follow_indenter ? 1 : 0,
-                       max_newton > 1 ? static_cast<double*>(ws) : nullptr,  // env blocks of the workspace: (15, V) lagged blocks per env
-                       c->velocity_warm_start ? vel : nullptr);
+                       max_newton > 1 ? static_cast<double*>(ws) : nullptr);  // env blocks of the workspace: (15, V) lagged blocks per env
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : fail_hip(e, "fem_newton_lds_kernel");
   }
@@ -2618,7 +2599,7 @@ int tacex_fem_step(tacex_fem_ctx* c, double* x, double* v, double* xt, const uin
   }
   bool resident = false;
   if (int rc = launch_newton(c, x, xt, cons, aim, stats, ws, B, pcg_max_iter, pcg_tol_rate, ls_max_iter, dx, tol, max_newton, step_info, st,
-                             &resident, xprev, disp, env_order, v))
+                             &resident, xprev, disp, env_order))
     return rc;
   if (!resident) {
     // streaming fallback: one launch per Newton iteration on a FIXED schedule; converged envs return at once (dx protocol), so the
