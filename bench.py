@@ -462,6 +462,7 @@ def sweep(args, dev):
     run("C5 per-GPU shard: 1024 envs, RGB 640x480 + FEM-driven markers (gelpad FEM step included) (BASELINE configs[4] / 8)",
         1024, 480, 640, 1, False, fem=lambda: FemGelpad(1024, dev, max_newton_iter=NEWTON_CAP))
     out.append(fem_axle_entry(dev))
+    out.append(fem_axle_entry(dev, steps=6, streaming=True))
     run("C5 optical part only: 1024 envs, RGB 640x480", 1024, 480, 640, 1, False, steps=max(5, args.sweep_steps // 3))
     return out
 
@@ -470,9 +471,16 @@ NEWTON_CAP = 64  # Newton iterations a FEM scene of the sweep may take per step 
                  # high enough that no env of no step reaches it - asserted, a truncated solve would flatter the rate
 
 
-def fem_axle_entry(dev, B=512, steps=12):
-    """SURVEY section 8(d)'s ~2k-tet fixture simple_axle.msh (593 vertices / 2 003 tets: more vertices than the CU-resident Newton kernel
-    has threads) stepped with sphere contact on the streaming Newton kernel - FEM only, env steps per second."""
+AXLE_NEWTON_CAP = 200  # (the bent axle's iterations in PSD-safe mode converge linearly: 50 in the worst env and step measured)
+
+
+def fem_axle_entry(dev, B=512, steps=12, streaming=False):
+    """SURVEY section 8(d)'s ~2k-tet fixture simple_axle.msh (593 vertices / 2 003 tets) stepped with sphere contact - FEM only, env steps
+    per second.  Default: the 768-thread variant of the CU-resident Newton kernel with everything the gelpad scene uses (friction,
+    coarse correction on the bounding-box grid, the chains found in the mesh).  streaming=True: the streaming Newton kernel (what
+    the deterministic switch selects for a mesh of more than 512 vertices; block Jacobi, no friction)."""
+    name = "the streaming Newton kernel (deterministic switch; block Jacobi, no friction)" if streaming else \
+           "the CU-resident Newton kernel, 768 threads per env (friction, coarse correction, chains: the defaults)"
     try:
         from tacex_amd.uipc import UipcObject, UipcObjectCfg, UipcSim, UipcSimCfg
 
@@ -480,8 +488,11 @@ def fem_axle_entry(dev, B=512, steps=12):
         P = (g["simple_axle_points"] - g["simple_axle_points"].min(0)) * 0.01
         T = g["simple_axle_tets"]
         cfg = UipcSimCfg(device=dev)
-        cfg.linear_system.coarse_grid, cfg.linear_system.vertex_chains = None, None
-        cfg.contact.enable_friction = False  # friction lives in the CU-resident kernel (<= 512 vertices) only
+        cfg.newton.velocity_tol = 2e-3  # 20 um per step: the default (0.5 mm, uipc_sim.py:62-66) is a sixth of this rod's thickness
+        if streaming:
+            cfg.linear_system.coarse_grid, cfg.linear_system.vertex_chains = None, None
+            cfg.linear_system.deterministic = True
+            cfg.contact.enable_friction = False  # friction lives in the CU-resident kernel only
         sim = UipcSim(cfg, num_envs=B)
         UipcObject(UipcObjectCfg(mesh_points=P, mesh_tets=T), sim)
         sim.setup_sim(constraint_strength_ratio=1000.0)
@@ -493,28 +504,37 @@ def fem_axle_entry(dev, B=512, steps=12):
         sim.set_contact_indenters(ind)
         ind = sim.contact_indenters
         depth = torch.linspace(0.2, 0.4, B, device=dev, dtype=torch.float64)
+        its = torch.zeros((), dtype=torch.float64, device=dev)
+        flagged = torch.zeros((), dtype=torch.float64, device=dev)
 
-        def step():
-            ind[:, 3] -= depth * sim.contact_gaps().amin(1)  # press on by a fraction of the gap
-            sim.step(max_newton_iter=NEWTON_CAP)
+        def step(i):
+            ind[:, 3] -= depth * sim.contact_gaps().amin(1)  # press on by a fraction of the gap ...
+            if not streaming:
+                ind[:, 1] += 2e-5 * (1 if (i // 4) % 2 == 0 else -1)  # ... and slide back and forth (friction acts)
+            sim.step(max_newton_iter=AXLE_NEWTON_CAP)
 
-        for _ in range(3):
-            step()
+        for i in range(3):
+            step(i)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        its = 0
-        for _ in range(steps):
-            step()
-            its = max(its, sim.last_newton_iters)  # (synchronises: the streaming path launches one kernel per Newton iteration anyway)
+        for i in range(steps):
+            step(3 + i)
+            if streaming:
+                its = torch.clamp(its, min=float(sim.last_newton_iters))  # (synchronises: that path launches one kernel per Newton iteration anyway)
+            else:
+                its = torch.maximum(its, sim.step_info[:, 0].max())
+                flagged = torch.maximum(flagged, (sim.step_info[:, 2].to(torch.int64) & 3).max().to(torch.float64))  # penetration / failed line search
         torch.cuda.synchronize()
         el = time.perf_counter() - t0
-        assert its < NEWTON_CAP and bool(torch.isfinite(sim.x).all()) and float(sim.contact_gaps().amin()) > 0.0
+        finite, gap = bool(torch.isfinite(sim.x).all()), float(sim.contact_gaps().amin())
+        assert finite and gap > 0.0, f"finite {finite}, smallest gap {gap}"
+        assert float(its) < AXLE_NEWTON_CAP, f"an env ran into the Newton cap of {AXLE_NEWTON_CAP}"
         return {"workload": f"FEM only: {B} envs x simple_axle.msh (593 vertices / 2003 tets, scaled to 25.8 x 3 x 3 mm), ends attached, a sphere "
-                            "pressing on through the IPC barrier (no friction): the streaming Newton kernel (meshes beyond 512 vertices)",
+                            f"pressing on through the IPC barrier: {name}",
                 "envs": B, "steps": steps, "ms_per_step": round(el / steps * 1e3, 3), "env_steps_per_s": round(B * steps / el, 1),
-                "newton_iters_max": int(its), "newton_cap": NEWTON_CAP}
+                "newton_iters_max": int(its), "newton_cap": AXLE_NEWTON_CAP, "failure_flags_max": int(flagged), "velocity_tol": 2e-3}
     except Exception as ex:
-        return {"workload": "FEM only: simple_axle.msh on the streaming Newton kernel", "error": f"{type(ex).__name__}: {ex}"[:300]}
+        return {"workload": f"FEM only: simple_axle.msh on {name}", "error": f"{type(ex).__name__}: {ex}"[:300]}
 
 
 def fem_roofline(fem, period=None):

@@ -438,12 +438,17 @@ int tacex_fem_newton_step(tacex_fem_ctx* ctx, double* x_dev, const double* x_til
  *   the loop on the device once the UNSCALED Newton direction of an iteration has max |d| <= velocity_tol * dt (US:62-66; IPC's
  *   test on the search direction, whatever the CCD bound and the line search made of the step);
  *   v = (x - x_prev) / dt.
- * x_dev, v_dev (B,V,3) f64 are updated in place, x_tilde_dev (B,V,3) is written.  With the CU-resident Newton kernel (meshes of
- * <= 512 vertices) the whole loop is ONE launch; the streaming fallback launches max_newton kernels on a fixed schedule in which
- * converged envs return at once.  stats_dev (B,4) = [energy_before, energy_after, step_length, pcg_iterations] of the LAST iteration
+ * x_dev, v_dev (B,V,3) f64 are updated in place, x_tilde_dev (B,V,3) is written.  With the CU-resident Newton kernel (one thread per
+ * vertex: 512 threads per env for meshes of <= 512 vertices, 768 / 1024 threads for <= 768 / <= 1024 as long as the env's state fits
+ * the CU's 160 KB of LDS - simple_axle.msh, 593 vertices / 2 003 tets, does with friction; the wide variants take analytic indenters
+ * only and are not available with tacex_fem_set_deterministic) the whole loop is ONE launch; the streaming fallback launches
+ * max_newton kernels on a fixed schedule in which converged envs return at once.  stats_dev (B,4) = [energy_before, energy_after, step_length, pcg_iterations] of the LAST iteration
  * run; step_info_dev (B,4) f64 = [newton_iterations, max |d| of the last iteration, flags, pcg_iterations_total] (CU-resident
  * kernel; zeros from the fallback), flags: 1 = a contact vertex was at or beyond its indenter's surface when an iteration started
- * (the caller moved the indenter by more than the gap: that vertex gets no restoring force), 2 = a line search found no decrease.
+ * (the caller moved the indenter by more than the gap: that vertex gets no restoring force), 2 = a line search found no decrease;
+ * informational: 4 = the env dropped the coarse correction for the rest of the step (its stopping test passed with the residual's
+ * 2-norm above 0.1 |b|), 8 = its PCG met negative curvature and iterations of the step were solved with the PSD-safe Hessian
+ * (|c_J| of the Stable Neo-Hookean d2J/dF2 term clamped per element; the gradient is exact, the minimiser the same).
  * workspace_dev: tacex_fem_workspace_bytes(ctx, num_envs). */
 int tacex_fem_step(tacex_fem_ctx* ctx, double* x_dev, double* v_dev, double* x_tilde_dev, const uint8_t* constrained_dev,
                    const double* aim_dev, double* stats_dev, double* step_info_dev, void* workspace_dev, int num_envs,

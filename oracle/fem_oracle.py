@@ -71,10 +71,18 @@ def box_tet_mesh(nx=6, ny=8, nz=3, size=(0.02075, 0.02525, 0.0045)):
 LS_RESCUE = 32
 
 
-def pcg_solve(hv, prec, b, max_iter, tol_rate, d0=None):
+# Safeguard of the coarse correction (kCoarseTrust of csrc/fem_kernels.hip): the PCG's stopping test is in the M^-1 norm, and M^-1
+# contains the REST-state coarse operator - blind to the barrier / friction stiffness of the current contacts.  Where the coarse
+# space holds nearly free modes (simple_axle held at its ends) the test passes with the residual's 2-norm above that of b; if it is
+# above COARSE_TRUST |b| at exit, the coarse part is dropped for the rest of the time step and the iteration's solve starts over.
+COARSE_TRUST = 0.1
+
+
+def pcg_solve(hv, prec, b, max_iter, tol_rate, d0=None, info=None):
     """Preconditioned CG on H d = b as the Newton kernels run it: stops when r^T M^-1 r <= tol_rate^2 b^T M^-1 b (or at max_iter), keeps
     what it has on negative curvature (first iteration from a zero start: the preconditioned steepest-descent direction).  `d0`: warm
-    start (the part of the previous Newton direction that the CCD filter / the line search cut off).  Returns (d, iterations)."""
+    start (the part of the previous Newton direction that the CCD filter / the line search cut off).  Returns (d, iterations);
+    `info` (a dict) receives "res_ratio" = |r|^2 / |b|^2 of the recurrence residual at exit (None after a negative-curvature exit)."""
     r = b.copy()
     z = prec(r)
     rz_b = (r * z).sum()
@@ -86,12 +94,14 @@ def pcg_solve(hv, prec, b, max_iter, tol_rate, d0=None):
     p = z.copy()
     rz = (r * z).sum()
     it = 0
+    neg_curv = False
     while it < max_iter and rz_b > 0 and rz > tol_rate**2 * rz_b:
         Hp = hv(p)
         pHp = (p * Hp).sum()
         if pHp <= 0:
             if it == 0 and not warm:
                 d = z.copy()
+            neg_curv = True
             break
         al = rz / pHp
         d = d + al * p
@@ -101,6 +111,48 @@ def pcg_solve(hv, prec, b, max_iter, tol_rate, d0=None):
         p = z + (rz_new / rz) * p
         rz = rz_new
         it += 1
+    if info is not None:
+        info["neg_curv"] = neg_curv
+        info["warm_discard"] = neg_curv and it == 0 and warm  # a warm start alone is no descent direction: the caller starts over from zero
+        bb = (b * b).sum()
+        info["res_ratio"] = None if neg_curv else ((r * r).sum() / bb if bb > 0 else 0.0)
+    return d, it
+
+
+def direction_cap(m, d):
+    """Largest first step of a line search: no vertex moves by more than the rest mesh's bounding-box diagonal (a preconditioned
+    steepest-descent direction taken on negative curvature has no length scale: M^-1 b with a soft coarse mode was 600 m on a 26 mm
+    axle, out of reach of the 2^-40 the backtracking can do)."""
+    dm = np.abs(d).max()
+    cap = float(np.linalg.norm(np.ptp(m.X, axis=0)))
+    return min(1.0, cap / dm) if dm > 0 else 1.0
+
+
+def pcg_solve_guarded(hv, make_prec, b, max_iter, tol_rate, d0, coarse, state, model=None):
+    """pcg_solve with the two safeguards of the Newton kernel.  `state` (a dict carried over the Newton iterations of ONE time step):
+      "psd_safe"   - the PCG met negative curvature: `model` (the FemModel behind `hv`) switches to its PSD-safe Hessian (dpk1) for this
+                     Newton iteration and the solve starts over (the next iteration tries the exact Hessian again);
+      "coarse_off" - COARSE_TRUST fired: the coarse part of the preconditioner (`make_prec(coarse)` / `make_prec(None)`) is dropped for
+                     the rest of the step and the solve starts over.
+    Returns (d, iterations incl. those of discarded attempts)."""
+    use = None if (coarse is None or (state is not None and state.get("coarse_off"))) else coarse
+    info = {}
+    if model is not None:
+        model.psd_safe = False  # every Newton iteration tries the exact Hessian first: near the minimiser it is what converges quadratically
+    d, it = pcg_solve(hv, make_prec(use), b, max_iter, tol_rate, d0, info)
+    if info["neg_curv"] and state is not None and model is not None:
+        state["psd_safe"] = True  # (sticky: reported in the step's flags)
+        model.psd_safe = True
+        d, it2 = pcg_solve(hv, make_prec(use), b, max_iter, tol_rate, d0, info)
+        it += it2
+    if info["warm_discard"]:
+        d, it2 = pcg_solve(hv, make_prec(use), b, max_iter, tol_rate, None, info)
+        it += it2
+    if use is not None and info["res_ratio"] is not None and info["res_ratio"] > COARSE_TRUST**2:
+        if state is not None:
+            state["coarse_off"] = True
+        d, it2 = pcg_solve(hv, make_prec(None), b, max_iter, tol_rate, d0)
+        it += it2
     return d, it
 
 
@@ -279,8 +331,17 @@ class FemModel:
                        np.cross(d0, f1) + np.cross(f0, d1)], -1)
         FdF = (F * dF).sum((-2, -1))[..., None, None]
         CdF = (C * dF).sum((-2, -1))[..., None, None]
-        return (self.mu * (1 - 1 / (Ic + 1)) * dF + 2 * self.mu / (Ic + 1) ** 2 * FdF * F
-                + self.lam * CdF * C + self.lam * (J - self.alpha) * dC)
+        a = self.mu * (1 - 1 / (Ic + 1))
+        c = self.lam * (J - self.alpha)
+        if getattr(self, "psd_safe", False):
+            # PSD-SAFE MODE (an env switches to it for the rest of a time step once its PCG has met negative curvature): the only
+            # indefinite term of the Hessian is c d2J/dF2, whose spectral norm is <= sqrt(2 Ic) (eigenvalues +-sigma_k and those of the
+            # scaling block, bounded by two singular values); with |c| clamped to a / sqrt(2 Ic) the sum a I + c d2J/dF2 stays positive
+            # semi-definite and so does the element Hessian (the other two terms are rank-one PSD).  The gradient is untouched: Newton
+            # becomes a quasi-Newton iteration on the same minimiser.
+            lim = a / np.sqrt(2.0 * np.maximum(Ic, 1e-300))
+            c = np.clip(c, -lim, lim)
+        return a * dF + 2 * self.mu / (Ic + 1) ** 2 * FdF * F + self.lam * CdF * C + c * dC
 
     def element_energy(self, x):
         return self.vol * self.psi(self.deformation_gradient(x))  # (..., T)
@@ -305,10 +366,12 @@ class FemModel:
                 for m in range(3):
                     G[:, k * 3 + m, v * 3 + k] = r[:, v, m]
         H9 = np.zeros(shp + (9, 9))
+        safe, self.psd_safe = getattr(self, "psd_safe", False), False  # assembled blocks (preconditioner, coarse operator) are always the exact ones
         for q in range(9):
             dF = np.zeros(shp + (3, 3))
             dF[..., q // 3, q % 3] = 1.0
             H9[..., :, q] = self.dpk1(F, dF).reshape(shp + (9,))
+        self.psd_safe = safe
         if project_psd:
             w, V = np.linalg.eigh(0.5 * (H9 + np.swapaxes(H9, -1, -2)))
             H9 = (V * np.maximum(w, 0.0)[..., None, :]) @ np.swapaxes(V, -1, -2)
@@ -384,16 +447,17 @@ class FemModel:
 
     # ---- one Newton iteration: truncated PCG + backtracking line search (US:70-76) ----------------------------------
     def newton_step(self, x, x_tilde, constrained=None, aim=None, pcg_max_iter=64, pcg_tol_rate=1e-3, ls_max_iter=8, coarse=None, d0=None,
-                    return_dir=False, chains=None):
+                    return_dir=False, chains=None, state=None):
         """Single env (x: (V,3)).  Returns (x_new, stats=[E0, E1, step, pcg_iters, max |d|, ccd step]).  `coarse` = (node (V,8),
-        weight (V,8), inverse coarse operator (3 nc, 3 nc)): the additive coarse-grid correction of tacex_fem_set_coarse_space."""
+        weight (V,8), inverse coarse operator (3 nc, 3 nc)): the additive coarse-grid correction of tacex_fem_set_coarse_space.
+        `state`: see pcg_solve_guarded."""
         g = self.gradient(x, x_tilde, constrained, aim)
         D = self.diag_blocks(x, constrained)
         mdiag = self.mass * (1.0 + (self.strength * constrained if constrained is not None else 0.0))
-        prec = self.block_preconditioner(x, D, mdiag, coarse, chains)
-        d, it = pcg_solve(lambda p: self.hess_vec(x, p, constrained), prec, -g, pcg_max_iter, pcg_tol_rate, d0)
+        d, it = pcg_solve_guarded(lambda p: self.hess_vec(x, p, constrained), lambda cs: self.block_preconditioner(x, D, mdiag, cs, chains), -g,
+                                  pcg_max_iter, pcg_tol_rate, d0, coarse, state, self)
         E0 = self.energy(x, x_tilde, constrained, aim)
-        step = 1.0
+        step = direction_cap(self, d)
         E1 = E0
         x_new = x
         for _ in range(max(ls_max_iter, LS_RESCUE) + 1):  # capped search, then the rescue halvings (see LS_RESCUE)
@@ -677,7 +741,8 @@ def edge_snap(m, cm, x, x_tilde, constrained, aim, x_prec=None):
 
 
 def newton_step_contact(m: "FemModel", cm: ContactModel, x, x_tilde, constrained=None, aim=None, pcg_max_iter=64, pcg_tol_rate=1e-3,
-                        ls_max_iter=8, coarse=None, d0=None, return_dir=False, fr: "FrictionModel | None" = None, chains=None, x_prec=None, edge=True):
+                        ls_max_iter=8, coarse=None, d0=None, return_dir=False, fr: "FrictionModel | None" = None, chains=None, x_prec=None, edge=True,
+                        state=None):
     """`FemModel.newton_step` with the barrier terms of `cm` in gradient, preconditioner, H.p and energy, and the CCD step
     filter in front of the backtracking line search.  Returns (x_new, [E0, E1, step, pcg_iters]).  `x_prec`: the state the ELASTIC
     blocks of the preconditioner are taken at (tacex_fem_step lags them: assembled in the first Newton iteration of the step and
@@ -692,12 +757,11 @@ def newton_step_contact(m: "FemModel", cm: ContactModel, x, x_tilde, constrained
     xp = x if x_prec is None else x_prec
     D = m.diag_blocks(xp, constrained) + Hc
     mdiag = m.mass * (1.0 + (m.strength * constrained if constrained is not None else 0.0))
-    prec = m.block_preconditioner(xp, D, mdiag, coarse, chains)
     hv = lambda p: m.hess_vec(x, p, constrained) + np.einsum("vij,vj->vi", Hc, p)
     energy = lambda y: m.energy(y, x_tilde, constrained, aim) + cm.energy(y) + (fr.energy(y) if fr is not None else 0.0)
-    d, it = pcg_solve(hv, prec, -g, pcg_max_iter, pcg_tol_rate, d0)
+    d, it = pcg_solve_guarded(hv, lambda cs: m.block_preconditioner(xp, D, mdiag, cs, chains), -g, pcg_max_iter, pcg_tol_rate, d0, coarse, state, m)
     E0 = energy(x)
-    step = step0 = cm.max_step(x, d)
+    step = step0 = min(cm.max_step(x, d), direction_cap(m, d))
     E1, x_new = E0, x
     for _ in range(max(ls_max_iter, LS_RESCUE) + 1):
         cand = x + step * d
@@ -717,7 +781,7 @@ def fem_step(m: "FemModel", cm, x, v, constrained=None, aim=None, gravity=(0.0, 
     """One backward-Euler step of ONE env the way `tacex_fem_step` runs it (what world.advance() does, US:250-252):
     x_tilde = x + dt v + dt^2 g; Newton iterations until the UNSCALED Newton direction of one has max |d| <= velocity_tol * dt
     (US:62-66; IPC's test on the search direction) or the cap; v = (x_new - x) / dt.  Returns (x_new, v_new, info) with
-    info = [newton_iterations, max |d| of the last iteration, flags (2: a line search failed), pcg_iterations_total]."""
+    info = [newton_iterations, max |d| of the last iteration, flags (2: a line search failed, 4: the coarse correction was dropped - COARSE_TRUST), pcg_iterations_total]."""
     x0 = x
     xt = x + m.dt * v + m.dt**2 * np.asarray(gravity, np.float64)
     # contact-following start (fem_newton_lds_kernel, `follow`): a surface vertex the indenter retreats from (disp . n < 0) and that
@@ -742,19 +806,24 @@ def fem_step(m: "FemModel", cm, x, v, constrained=None, aim=None, gravity=(0.0, 
     # the elastic preconditioner blocks of the whole step are those of its first iteration (see newton_step_contact); lag_prec=False:
     # fresh blocks every iteration (the streaming kernel of meshes with more than 512 vertices)
     x_prec = x if lag_prec else None
+    guard = {}  # state of the solver safeguards (pcg_solve_guarded): once fired, they stay on for the rest of this step
+    m.psd_safe = False
     for _ in range(max_newton):
         if cm is not None:
             x, st, d = newton_step_contact(m, cm, x, xt, constrained, aim, pcg_max_iter, pcg_tol_rate, ls_max_iter, coarse, d0, True, fr, chains,
-                                           x_prec)
+                                           x_prec, state=guard)
         else:
-            x, st, d = m.newton_step(x, xt, constrained, aim, pcg_max_iter, pcg_tol_rate, ls_max_iter, coarse, d0, True, chains)
+            x, st, d = m.newton_step(x, xt, constrained, aim, pcg_max_iter, pcg_tol_rate, ls_max_iter, coarse, d0, True, chains, state=guard)
+        d0_used = d0
         d0 = (1.0 - st[2]) * d if 0.0 < st[2] < 1.0 else None  # warm start of the next PCG: the part of d that was cut off
         n += 1
         pcg += int(st[3])
         dmax = st[4]
         if st[2] == 0.0 and not dmax <= velocity_tol * m.dt:
+            if d0_used is not None:
+                continue  # the direction came from a warm start (no descent guarantee): once more from a zero start (d0 is None now)
             flags |= 2
-            break  # a rejected search leaves x and the warm start unchanged: every further iteration would repeat this one
+            break  # a rejected search leaves x unchanged: every further iteration would repeat this one
         if dmax <= velocity_tol * m.dt:  # IPC's test: the unscaled search direction, whatever the CCD bound / line search made of the step
             if fric_pending:  # normal contact is balanced: take the friction lag from here and go on
                 fric_pending = False
@@ -763,4 +832,9 @@ def fem_step(m: "FemModel", cm, x, v, constrained=None, aim=None, gravity=(0.0, 
                 if fr.lam.max() > 0.0:
                     continue
             break
+    m.psd_safe = False
+    if guard.get("coarse_off"):
+        flags |= 4
+    if guard.get("psd_safe"):
+        flags |= 8
     return x, (x - x0) / m.dt, np.array([n, dmax, flags, pcg], np.float64)

@@ -12,14 +12,14 @@ for motion in ("breathing", "rolling"):
     fem = FemGelpad(B, "cuda:0", max_newton_iter=64, motion=motion)
     fem.ms_log = []
     fem.info_sum = torch.zeros(4, dtype=torch.float64, device="cuda:0")
-    flags_or = torch.zeros(B, dtype=torch.float64, device="cuda:0")
+    flags_or = torch.zeros(B, dtype=torch.int64, device="cuda:0")
     it_max = torch.zeros((), dtype=torch.float64, device="cuda:0")
     gap_min = torch.full((), float("inf"), dtype=torch.float64, device="cuda:0")
     ls_events = torch.zeros(steps, dtype=torch.float64, device="cuda:0")
     for i in range(steps):
         fem.step(i)
         si = fem.sim.step_info
-        flags_or = torch.maximum(flags_or, si[:, 2])
+        flags_or |= si[:, 2].to(torch.int64)
         it_max = torch.maximum(it_max, si[:, 0].max())
         gap_min = torch.minimum(gap_min, fem.sim.contact_gaps().amin())
         ls_events[i] = (si[:, 2].to(torch.int64) & 2).ne(0).sum()
@@ -29,5 +29,5 @@ for motion in ("breathing", "rolling"):
     x = fem.sim.x
     fl = flags_or.cpu().numpy().astype(int)
     print(f"{motion}: {steps} steps x {B} envs: finite {bool(torch.isfinite(x).all())}, smallest gap of any step {float(gap_min) * 1e3:.4f} mm, "
-          f"envs ever flagged penetration {int((fl & 1).astype(bool).sum())}, line search {int((fl & 2).astype(bool).sum())} ({int(ls_events.sum())} env-steps of {steps * B}, steps {[int(v) for v in torch.nonzero(ls_events).flatten()[:12].cpu()]}), max Newton iterations {int(it_max)}; "
+          f"envs ever flagged penetration {int((fl & 1).astype(bool).sum())}, line search {int((fl & 2).astype(bool).sum())}, coarse correction dropped {int((fl & 4).astype(bool).sum())}, PSD-safe mode {int((fl & 8).astype(bool).sum())} ({int(ls_events.sum())} env-steps of {steps * B}, steps {[int(v) for v in torch.nonzero(ls_events).flatten()[:12].cpu()]}), max Newton iterations {int(it_max)}; "
           f"ms per step mean {ms.mean():.3f} median {np.median(ms):.3f} p90 {np.quantile(ms, 0.9):.3f} max {ms.max():.3f}", flush=True)

@@ -44,6 +44,7 @@ struct FemDev {
   const int* vt_off;      // (V+1) CSR vertex -> incident (tet*4 + local)
   const int* vt_idx;
   double mu, lam, alpha, psi_rest, dt, strength;
+  double step_cap;  // bounding-box diagonal of the rest mesh: no line search starts with a vertex moving further (fem_newton_lds_kernel)
   // IPC contact of the gelpad surface against one analytic indenter per env (first slice)
   const double* area;       // (V) contact weight of a vertex = a third of the area of its surface triangles (0: interior); nullable
   const double* indenters;  // (B,8) [kind, cx, cy, cz, radius, nx, ny, nz]: kind 0 none, 1 sphere, 2 half-space; nullable
@@ -972,23 +973,41 @@ __global__ __launch_bounds__(512) void fem_newton_kernel(FemDev m, double* xg, c
 constexpr int kNwtThreads = 512;
 constexpr int kNwtChunk = 512;  // tets per LDS exchange window (1024 = 2 per thread measured slower: 90 spilled VGPRs)
 constexpr int kNwtTpw = kNwtChunk / kNwtThreads;
+// MESHES OF MORE THAN 512 VERTICES run the same kernel with 768 or 1024 threads (thread v still owns vertex v; 3 or 4 waves per SIMD
+// instead of 2, i.e. 168 / 128 registers per lane instead of 256: more of the per-thread state goes to scratch, which is what such an
+// env pays for staying on one CU - the streaming kernel's alternative is a trip through HBM per PCG iteration).  Only the atomic
+// flavour exists there: without the exchange window and the incidence list in LDS (12 x NT doubles + 4 T shorts) a 593-vertex /
+// 2 003-tet mesh with friction fits the CU's 160 KB.  The region between p and the reduction rows then only has to hold what the
+// kernel parks in it: the 15 V block accumulators of the assembly (p + region), the preconditioner's r | r_c | y_c | z.
+__host__ __device__ constexpr int nwt_window_doubles(int V, int NT) {
+  return NT <= kNwtThreads ? 12 * kNwtChunk : (12 * V > 6 * V + 6 * kFemMaxCoarse ? 12 * V : 6 * V + 6 * kFemMaxCoarse);
+}
+// dynamic LDS of fem_newton_lds_kernel<., ., NT>: x, p | window | sums | [friction lag] | diagonal mass term (doubles) || chain factors |
+// [friction Hessian blocks] (floats) || [incidence codes] | chain links | chain heads per thread | [CSR offsets] (u16)
+static size_t nwt_lds_bytes(int V, int T, bool fric, int NT) {
+  const bool big = NT > kNwtThreads;
+  return ((((size_t)7 * V + (size_t)nwt_window_doubles(V, NT) + 2 * (NT / 64) + 2 + (fric ? (size_t)4 * V : 0)) * sizeof(double) +
+           ((size_t)15 * V + (fric ? (size_t)6 * V : 0)) * sizeof(float) +
+           ((big ? 0 : (size_t)4 * T + V + 1) + 2 * (size_t)V + NT) * sizeof(unsigned short)) + 15) & ~(size_t)15;
+}
 
 // block-wide sum with ONE barrier: wave partials go to one of two alternating LDS rows and every thread adds them in the
 // same fixed order (the row written two calls ago cannot still be read: a barrier lies in between)
-__device__ __forceinline__ double block_sum1(double v, double* sh2 /* 2 x 8 doubles */, int& phase) {
+template <int NT>
+__device__ __forceinline__ double block_sum1(double v, double* sh2 /* 2 x NT / 64 doubles */, int& phase) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  double* row = sh2 + 8 * (phase & 1);
+  double* row = sh2 + (NT / 64) * (phase & 1);
   ++phase;
   if ((threadIdx.x & 63) == 0) row[threadIdx.x >> 6] = v;
   __syncthreads();
   double s = 0.0;
 #pragma unroll
-  for (int w = 0; w < kNwtThreads / 64; ++w) s += row[w];
+  for (int w = 0; w < NT / 64; ++w) s += row[w];
   return s;
 }
 
-template <bool MESH>
+template <bool MESH, int NT>
 __device__ __forceinline__ double env_energy_lds(const FemDev& m, const double* xl, const double x3[3], const double* xt,
                                                  bool own, bool c, const double* aim, double* sh, int& phase,
                                                  const double* ind = nullptr, double wv = 0.0, const double* fv = nullptr,
@@ -1022,20 +1041,21 @@ __device__ __forceinline__ double env_energy_lds(const FemDev& m, const double* 
       e += dt2 * friction_eval(m.fric_mu, m.fric_eps, fv + v * 4, x3, xn3, disp, false).e;
     }
   }
-  return block_sum1(e, sh, phase);
+  return block_sum1<NT>(e, sh, phase);
 }
 
 // block-wide minimum, same one-barrier scheme as block_sum1
+template <int NT>
 __device__ __forceinline__ double block_min1(double v, double* sh2, int& phase) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v = fmin(v, __shfl_xor(v, o, 64));
-  double* row = sh2 + 8 * (phase & 1);
+  double* row = sh2 + (NT / 64) * (phase & 1);
   ++phase;
   if ((threadIdx.x & 63) == 0) row[threadIdx.x >> 6] = v;
   __syncthreads();
   double s = row[0];
 #pragma unroll
-  for (int w = 1; w < kNwtThreads / 64; ++w) s = fmin(s, row[w]);
+  for (int w = 1; w < NT / 64; ++w) s = fmin(s, row[w]);
   return s;
 }
 
@@ -1047,6 +1067,26 @@ constexpr int kLsRescue = 32;
 // flags of step_info[., 2]
 constexpr int kFemFlagPenetration = 1;  // a contact vertex was at or beyond the indenter surface when the iteration started
 constexpr int kFemFlagLsFailed = 2;     // a line search found no decrease even after the rescue halvings
+constexpr int kFemFlagCoarseOff = 4;    // informational: the coarse correction was switched off for the rest of the step (see kCoarseTrust)
+constexpr int kFemFlagPsdSafe = 8;      // informational: the PCG met negative curvature and the env solved iterations of the step in PSD-safe mode
+// PSD-SAFE MODE.  The Stable Neo-Hookean Hessian is applied matrix-free and unprojected: aI + b f f^T + lam c c^T + c_J d2J/dF2, whose last
+// term is indefinite (eigenvalues +-sigma_k).  On the gelpad - a thin pad held on its whole back face - the sum stays positive definite
+// along the directions the PCG visits; a slender body bent by its indenter (simple_axle held at its ends) has compressed elements with
+// negative curvature, the PCG breaks off on its first direction, and with a coarse correction in M^-1 that direction is a soft global
+// mode hundreds of metres long: the Newton loop crawls into inverted states (replayed in the oracle: 40 iterations, then 6 mm of
+// "dent" on a 3 mm rod).  IPC projects every element Hessian onto the PSD cone; here an env that MEETS negative curvature (p^T H p <= 0)
+// switches, for that Newton iteration (which starts over), to a Hessian in which |c_J| is clamped to a / sqrt(2 Ic) per element: the spectral norm of
+// d2J/dF2 is below sqrt(2 Ic) (its eigenvalues are +-sigma_k and those of the scaling block, bounded by the sum of two singular
+// values), so a I + c_J d2J/dF2 stays positive semi-definite and with it the element Hessian.  The gradient is untouched - the
+// iteration becomes a quasi-Newton one on the same minimiser - and envs that never meet negative curvature never pay.
+// The PCG stops on the M^-1 norm of the residual, and M^-1 contains the coarse operator of the REST state - without the barrier and
+// friction stiffness of the current contacts.  Where the coarse space holds nearly free modes (a slender body held at its ends:
+// simple_axle) those modes map the contact forces in b to a huge b^T M^-1 b, the relative test passes after a handful of iterations
+// with the 2-norm of the residual ABOVE that of b (measured at exit: 3.7 x |b| in the median there, against <= 0.004 x |b| on the
+// gelpad, whose back face is held), and the Newton loop crawls on such directions until a line search fails.  Safeguard: if the
+// residual's 2-norm at exit is above kCoarseTrust x |b|, the env drops the coarse correction for the rest of the time step (chains /
+// block Jacobi alone: the test is then in a norm that sees the contact blocks) and the iteration starts over.
+constexpr double kCoarseTrust = 0.1;
 
 // One launch = up to `max_newton` Newton iterations of every env (tacex_fem_step: the whole Newton loop of world.advance(),
 // US:250-252, without a host round trip; tacex_fem_newton_step: max_newton = 1).  An env leaves the loop when the Newton
@@ -1057,34 +1097,36 @@ constexpr int kFemFlagLsFailed = 2;     // a line search found no decrease even 
 // arithmetic of the next (no barrier between batches: wave skew no longer costs).  The price is the summation ORDER of a vertex's
 // ~24 contributions, which then depends on the timing of the waves: results agree to round-off (1e-16 relative per add), not
 // bit for bit from run to run.  `tacex_fem_set_deterministic(ctx, 1)` selects the window path (ATOM = false).
-template <bool MESH, bool ATOM>
-__global__ __launch_bounds__(kNwtThreads) void fem_newton_lds_kernel(FemDev m, double* xg, const double* xtg,
+template <bool MESH, bool ATOM, int NT>
+__global__ __launch_bounds__(NT) void fem_newton_lds_kernel(FemDev m, double* xg, const double* xtg,
                                                                      const uint8_t* consg, const double* aimg, double* stats,
                                                                      int pcg_max_iter, double pcg_tol_rate, int ls_max_iter,
                                                                      double* dxg, double dx_tol, int max_newton, double* step_info,
                                                                      const double* xprevg, const double* dispg, const int* env_order,
                                                                      int follow, double* lagg) {
   extern __shared__ __attribute__((aligned(16))) double nlds[];
-  constexpr int CH = kNwtChunk;
+  constexpr int CH = NT;  // tets per pass of a sweep (one per thread) = tets per exchange window
+  constexpr bool BIG = NT > kNwtThreads;  // meshes of more than 512 vertices: see nwt_lds_bytes
+  static_assert(!BIG || ATOM, "the wide variants exist in the atomic flavour only");
   const int V = m.V, T = m.T;
   const int wave_s = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int tid = fresh_tid(wave_s);
   double* xs = nlds;            // (V,3) current x
   double* ps = xs + 3 * V;      // (V,3) PCG direction p, later the line-search candidate
-  double* hv = ps + 3 * V;      // (12, CH) per-tet rows of the current window
-  double* sh = hv + 12 * CH;    // 2 x 8 wave partials of block_sum1 (+2 pad)
+  double* hv = ps + 3 * V;      // (12, CH) per-tet rows of the current window | accumulators, exchange arrays (nwt_window_doubles)
+  double* sh = hv + nwt_window_doubles(V, NT);  // 2 x NT / 64 wave partials of block_sum1 (+2 pad)
   // friction (tacex_fem_step with a friction ratio): (V,4) lagged normal force and normal, (V,6) Hessian blocks (floats)
   const bool fric_lds = m.indenters && m.area && m.fric_mu > 0.0 && xprevg != nullptr && dispg != nullptr;  // (xprevg is only handed over with friction)
-  double* fl = sh + 18;
+  double* fl = sh + 2 * (NT / 64) + 2;
   double* mdl = fl + (fric_lds ? 4 * V : 0);  // (V) diagonal mass term m_v (1 + s c_v): read back per PCG iteration (per-thread constants
                                               // carried in registers across the tet arithmetic went to scratch)
   float* cf = reinterpret_cast<float*>(mdl + V);  // (V,15) chain factors: S^-1 (6, upper triangle) | G (9)
   float* fh = cf + 15 * V;
   unsigned short* csr = reinterpret_cast<unsigned short*>(fh + (fric_lds ? 6 * V : 0));  // (4T) incidence codes tet * 4 + local, vertex-major
-  unsigned short* cnx = csr + 4 * T;  // (V) chain successor | (V) predecessor, 0xffff = none
+  unsigned short* cnx = csr + (BIG ? 0 : 4 * T);  // (V) chain successor | (V) predecessor, 0xffff = none
   unsigned short* cpv = cnx + V;
-  unsigned short* chd = cpv + V;      // (kNwtThreads) head vertex of the chain thread t factors and solves, 0xffff = none
-  unsigned short* vto = chd + kNwtThreads;  // (V+1) CSR offsets of the incidence codes (4 T < 65535)
+  unsigned short* chd = cpv + V;      // (NT) head vertex of the chain thread t factors and solves, 0xffff = none
+  unsigned short* vto = chd + NT;  // (V+1) CSR offsets of the incidence codes (4 T < 65535); like csr not there in the wide variants
   int phase = 0;  // block_sum1 row toggle
   // env_order: envs sorted by the solver work of their PREVIOUS time step, heaviest first (fem_env_order_kernel).  One env
   // occupies one CU for its whole Newton loop and a shard brings several envs per CU, so the launch ends with whatever the
@@ -1140,7 +1182,8 @@ __global__ __launch_bounds__(kNwtThreads) void fem_newton_lds_kernel(FemDev m, d
 #pragma unroll
     for (int i = 0; i < 3; ++i) xs[tid * 3 + i] = x3[i];
   }
-  for (int k = tid; k < 4 * T; k += kNwtThreads) csr[k] = (unsigned short)m.vt_idx[k];
+  if constexpr (!BIG)
+    for (int k = tid; k < 4 * T; k += NT) csr[k] = (unsigned short)m.vt_idx[k];
   if (own) {
     cnx[tid] = (unsigned short)(m.ch_next ? m.ch_next[tid] : -1);
     cpv[tid] = (unsigned short)(m.ch_prev ? m.ch_prev[tid] : -1);
@@ -1149,9 +1192,10 @@ __global__ __launch_bounds__(kNwtThreads) void fem_newton_lds_kernel(FemDev m, d
   // the chain a thread factors and solves: chains are dealt from the TOP thread down, so that their solves overlap the coarse
   // solve, which keeps the low threads busy.  The head vertex is looked up in LDS where it is needed (chain_head).
   {
-    const int my_chain = kNwtThreads - 1 - tid;
+    const int my_chain = NT - 1 - tid;
     chd[tid] = (unsigned short)(my_chain < nch ? (m.ch_next ? m.ch_head[my_chain] : my_chain) : 0xffff);
-    for (int k = tid; k <= V; k += kNwtThreads) vto[k] = (unsigned short)m.vt_off[k];
+    if constexpr (!BIG)
+      for (int k = tid; k <= V; k += NT) vto[k] = (unsigned short)m.vt_off[k];
     if (own) mdl[tid] = md;
   }
   auto chain_head = [&](int t) -> int { const int h = chd[t]; return h == 0xffff ? -1 : h; };
@@ -1181,7 +1225,7 @@ __global__ __launch_bounds__(kNwtThreads) void fem_newton_lds_kernel(FemDev m, d
       double Din[kNwtTpw][9], voln[kNwtTpw];
 #pragma unroll
       for (int u = 0; u < kNwtTpw; ++u) {
-        const int t = u * kNwtThreads + tid_a;
+        const int t = u * NT + tid_a;
         voln[u] = 0.0;
 #pragma unroll
         for (int k = 0; k < 4; ++k) vn[u][k] = 0;
@@ -1200,12 +1244,12 @@ __global__ __launch_bounds__(kNwtThreads) void fem_newton_lds_kernel(FemDev m, d
           for (int k = 0; k < 4; ++k) v[u][k] = vn[u][k];
 #pragma unroll
           for (int k = 0; k < 9; ++k) Di[u][k] = Din[u][k];
-          const int tn = (j + 1) * CH + u * kNwtThreads + tid_a;
+          const int tn = (j + 1) * CH + u * NT + tid_a;
           if (tn < T) load_tet_blk(m, tn, vn[u], Din[u], voln[u]);
         }
 #pragma unroll
         for (int u = 0; u < kNwtTpw; ++u) {
-          if (j * CH + u * kNwtThreads + tid_a < T) {
+          if (j * CH + u * NT + tid_a < T) {
             double rows[12];
             make(v[u], Di[u], vol[u], rows);
 #pragma unroll
@@ -1229,7 +1273,7 @@ __global__ __launch_bounds__(kNwtThreads) void fem_newton_lds_kernel(FemDev m, d
     double Din[kNwtTpw][9], voln[kNwtTpw];
 #pragma unroll
     for (int u = 0; u < kNwtTpw; ++u) {
-      const int t = u * kNwtThreads + tid_s;
+      const int t = u * NT + tid_s;
       voln[u] = 0.0;
 #pragma unroll
       for (int k = 0; k < 4; ++k) vn[u][k] = 0;
@@ -1248,12 +1292,12 @@ __global__ __launch_bounds__(kNwtThreads) void fem_newton_lds_kernel(FemDev m, d
         for (int k = 0; k < 4; ++k) v[u][k] = vn[u][k];
 #pragma unroll
         for (int k = 0; k < 9; ++k) Di[u][k] = Din[u][k];
-        const int tn = (j + 1) * CH + u * kNwtThreads + tid_s;
+        const int tn = (j + 1) * CH + u * NT + tid_s;
         if (tn < T) load_tet_blk(m, tn, vn[u], Din[u], voln[u]);
       }
 #pragma unroll
       for (int u = 0; u < kNwtTpw; ++u) {
-        const int tl = u * kNwtThreads + tid;
+        const int tl = u * NT + tid;
         if (j * CH + tl < T) {
           double rows[12];
           make(v[u], Di[u], vol[u], rows);
@@ -1303,9 +1347,15 @@ __global__ __launch_bounds__(kNwtThreads) void fem_newton_lds_kernel(FemDev m, d
   bool fric_phase = false;  // friction terms are on (second phase of the loop, see friction_eval)
   bool lag_pending = false; // the friction lag is taken in the iteration that follows the converged normal-contact solve (see below)
   bool lag_valid = false;  // the workspace holds the elastic preconditioner blocks of this launch
+  bool use_coarse = m.nc > 0;  // (block-uniform) false once the safeguard of kCoarseTrust has fired
+  bool psd_safe = false;       // (block-uniform) see kFemFlagPsdSafe
   for (int nit = 0; nit < max_newton; ++nit) {
   if (nit > 0) __syncthreads();  // xs carries the accepted candidate of the previous iteration
   bool snapped_once = false;     // the edge snap (below) restarts an iteration at most once
+  // every iteration tries the exact Hessian first: near the minimiser it is what converges quadratically.  (Measured against keeping
+  // the mode for the rest of the step - faster on the axle, 273 against 441 ms, but its last iterations converge linearly and stop on
+  // the tolerance 50 um from the minimiser - and against keeping it until a full step is accepted: gelpad scene 3.08 against 2.91 ms.)
+  psd_safe = false;
 restart_iteration:
 #ifdef TACEX_FEM_CLOCK
   long long fph = __builtin_readcyclecounter();
@@ -1409,9 +1459,9 @@ restart_iteration:
       if (lag_fresh) {  // (block-uniform)
         double* xa = ps;  // the exchange array of the factorisation below
         __syncthreads();  // the gradient sweep's accumulators (inside this region) have been read by their vertices
-        for (int k = tid; k < 15 * V; k += kNwtThreads) xa[k] = 0.0;
+        for (int k = tid; k < 15 * V; k += NT) xa[k] = 0.0;
         __syncthreads();
-        for (int t = tid; t < T; t += kNwtThreads) {
+        for (int t = tid; t < T; t += NT) {
           int v[4];
           double Di[9], F[9], r[12], vol_t;
           load_tet_blk(m, t, v, Di, vol_t);
@@ -1617,8 +1667,8 @@ restart_iteration:
   // the partial sums of a node / dof sit in ONE wave and are added by a butterfly of lane exchanges - no LDS round trip, no barrier
   // (a fixed tree: deterministic)
   auto pow2_le = [](int v) { int p = 1; while (2 * p <= v && 2 * p <= 64) p *= 2; return p; };
-  const int Gn = m.nc > 0 ? pow2_le(kNwtThreads / m.nc) : 1;
-  const int H = nc3 > 0 ? pow2_le(kNwtThreads / nc3) : 1;
+  const int Gn = m.nc > 0 ? pow2_le(NT / m.nc) : 1;
+  const int H = nc3 > 0 ? pow2_le(NT / nc3) : 1;
   const int Q = nc3 > 0 ? (nc3 + H - 1) / H : 0;
   auto apply_prec = [&](const double (&r)[3], double (&z)[3]) {
     double* rs = hv;                        // (V,3) residual
@@ -1672,7 +1722,7 @@ restart_iteration:
         v = pv;
       }
     };
-    if (nc3 == 0) {
+    if (nc3 == 0 || !use_coarse) {
       chain_solve();
       __syncthreads();
       if (own_p) {
@@ -1742,14 +1792,18 @@ restart_iteration:
     p3[i] = z3[i];
     part += r3[i] * z3[i];
   }
-  const double rz_b = block_sum1(part, sh, phase);
+  const double rz_b = block_sum1<NT>(part, sh, phase);
+  double bb = 0.0;  // |b|^2, for the safeguard of kCoarseTrust
+  if (use_coarse) bb = block_sum1<NT>(r3[0] * r3[0] + r3[1] * r3[1] + r3[2] * r3[2], sh, phase);
   double rz = rz_b;
   bool warm = frac_prev > 0.0 && rz_b > 0.0;
+  const bool warm_used = warm;
   if (warm) {
 #pragma unroll
     for (int i = 0; i < 3; ++i) d3[i] = frac_prev * dprev[i];
   }
   int it = 0;
+  bool neg_curv = false;
   while (warm || (it < pcg_max_iter && rz_b > 0.0 && rz > pcg_tol_rate * pcg_tol_rate * rz_b)) {
     double q3[3] = {0, 0, 0};  // the vector H is applied to (d0 of the warm start, else p): lives in ps during the sweep
     const int tid = fresh_tid(wave_s);  // (shadows the kernel-wide copy: nothing derived from it crosses an iteration)
@@ -1769,6 +1823,10 @@ restart_iteration:
       deformation_gradient(ps, v, Di, dF);  // linear in q
       TetState s;
       tet_state(m, F, s);
+      if (psd_safe) {
+        const double lim = s.a / sqrt(2.0 * fmax(s.Ic, 1e-300));
+        s.c = fmin(fmax(s.c, -lim), lim);
+      }
       apply_dP(m, s, dF, dP);
       shape_rows(Di, r);
       const double sc = dt2 * vol;
@@ -1811,14 +1869,28 @@ restart_iteration:
         p3[i] = z3[i];
         part += r3[i] * z3[i];
       }
-      rz = block_sum1(part, sh, phase);
+      rz = block_sum1<NT>(part, sh, phase);
       warm = false;
       continue;
     }
-    const double pHp = block_sum1(part, sh, phase);
+    const double pHp = block_sum1<NT>(part, sh, phase);
     FEM_TICK(1);
-    if (!(pHp > 0.0)) {  // negative curvature: keep d (first iteration from a zero start: preconditioned steepest descent)
-      if (it == 0 && !(frac_prev > 0.0)) { d3[0] = z3[0]; d3[1] = z3[1]; d3[2] = z3[2]; }
+    if (!(pHp > 0.0)) {  // negative curvature (block-uniform)
+      if (!psd_safe) {  // PSD-safe Hessian for this iteration, which starts over (same warm start)
+        psd_safe = true;
+        flags |= kFemFlagPsdSafe;
+        pcg_total += (double)it;  // (the work was done)
+        __syncthreads();
+        goto restart_iteration;
+      }
+      if (it == 0 && frac_prev > 0.0) {  // a warm start alone is no descent direction: once more from a zero start
+        frac_prev = 0.0;
+        __syncthreads();
+        goto restart_iteration;
+      }
+      // keep d (first iteration from a zero start: preconditioned steepest descent)
+      if (it == 0) { d3[0] = z3[0]; d3[1] = z3[1]; d3[2] = z3[2]; }
+      neg_curv = true;
       break;
     }
     const double al = rz / pHp;
@@ -1831,16 +1903,26 @@ restart_iteration:
     apply_prec(r3, z3);
 #pragma unroll
     for (int i = 0; i < 3; ++i) part += r3[i] * z3[i];
-    const double rz_new = block_sum1(part, sh, phase);
+    const double rz_new = block_sum1<NT>(part, sh, phase);
     const double beta = rz_new / rz;
 #pragma unroll
     for (int i = 0; i < 3; ++i) p3[i] = z3[i] + beta * p3[i];
     rz = rz_new;
     ++it;
   }
+  if (use_coarse && !neg_curv) {  // (block-uniform)
+    const double rr = block_sum1<NT>(r3[0] * r3[0] + r3[1] * r3[1] + r3[2] * r3[2], sh, phase);
+    if (rr > kCoarseTrust * kCoarseTrust * bb) {
+      use_coarse = false;
+      flags |= kFemFlagCoarseOff;
+      pcg_total += (double)it;  // (the work was done)
+      __syncthreads();
+      goto restart_iteration;
+    }
+  }
   FEM_PHASE(2);
   // ---- backtracking line search on the incremental potential (accept the first E(x + step d) <= E(x)) ----
-  const double E0 = env_energy_lds<MESH>(m, xs, x3, xt, own, c, aim, sh, phase, ind, wv, fric_phase ? fl : nullptr, xn, disp3);
+  const double E0 = env_energy_lds<MESH, NT>(m, xs, x3, xt, own, c, aim, sh, phase, ind, wv, fric_phase ? fl : nullptr, xn, disp3);
   double step = 1.0, E1 = E0;
   if (ind) {
     // CCD step filter for analytic indenters: a signed distance field is 1-Lipschitz, so a vertex at gap d moving by
@@ -1850,8 +1932,13 @@ restart_iteration:
       const double nd = sqrt(d3[0] * d3[0] + d3[1] * d3[1] + d3[2] * d3[2]);
       if (nd > 0.0) amax = fmin(1.0, kCcdSlack * ce.d / nd);
     }
-    step = block_min1(amax, sh, phase);
+    step = block_min1<NT>(amax, sh, phase);
   }
+  // max |d| of the UNSCALED Newton direction (what the convergence test looks at)
+  const double dmax = -block_min1<NT>(own ? -fmax(fabs(d3[0]), fmax(fabs(d3[1]), fabs(d3[2]))) : 0.0, sh, phase);
+  // no search starts with a vertex moving further than the body is long: a steepest-descent direction kept on negative curvature has
+  // no length scale (M^-1 b with a soft coarse mode: 600 m on the 26 mm axle, out of reach of the 2^-40 the backtracking can do)
+  if (dmax > m.step_cap) step = fmin(step, m.step_cap / dmax);
   const double step0 = step;  // after the CCD filter
   bool accepted = false;
   double xc3[3] = {0, 0, 0};
@@ -1863,12 +1950,10 @@ restart_iteration:
       for (int i = 0; i < 3; ++i) { xc3[i] = x3[i] + step * d3[i]; ps[tid * 3 + i] = xc3[i]; }
     }
     __syncthreads();
-    const double Ec = env_energy_lds<MESH>(m, ps, xc3, xt, own, c, aim, sh, phase, ind, wv, fric_phase ? fl : nullptr, xn, disp3);
+    const double Ec = env_energy_lds<MESH, NT>(m, ps, xc3, xt, own, c, aim, sh, phase, ind, wv, fric_phase ? fl : nullptr, xn, disp3);
     if (Ec <= E0) { E1 = Ec; accepted = true; break; }
     step *= 0.5;
   }
-  // max |d| of the UNSCALED Newton direction (what the convergence test looks at)
-  const double dmax = -block_min1(own ? -fmax(fabs(d3[0]), fmax(fabs(d3[1]), fabs(d3[2]))) : 0.0, sh, phase);
   if (accepted) {
     if (own) {
 #pragma unroll
@@ -1876,7 +1961,9 @@ restart_iteration:
     }
   } else {
     step = 0.0;
-    if (!(dmax <= dx_tol)) flags |= kFemFlagLsFailed;  // (no decrease to be had at a point whose Newton step is below the tolerance: converged)
+    // (no decrease to be had at a point whose Newton step is below the tolerance: converged; a direction that came from a warm start
+    //  has no descent guarantee: that iteration is repeated from a zero start, see below)
+    if (!(dmax <= dx_tol) && !warm_used) flags |= kFemFlagLsFailed;
   }
   // A rejected search leaves x where it was and cuts the warm start: the next iteration would be bit-identical to this one, and
   // the one after, up to max_newton - each a full assembly, a PCG solve and up to 33 energy sweeps on a CU other envs wait for.
@@ -1899,7 +1986,10 @@ restart_iteration:
   // unscaled Newton direction, whatever the CCD bound and the line search then made of the step - a shortened UPDATE says nothing
   // about convergence, a short DIRECTION does.  (Rounds 2-3 also demanded a full-length accepted step: at the edge of
   // the barrier zone that never happens and every retreat step ran to the iteration cap with directions 5x below the tolerance.)
-  if (ls_dead) break;
+  if (ls_dead) {
+    if (warm_used) continue;  // (frac_prev is 0 now: the next iteration solves the same system from a zero start)
+    break;
+  }
   const bool converged = dmax <= dx_tol;
   if (converged) {  // wave-uniform: every quantity above is a block reduction
     if (fric && !fric_phase) {
@@ -1929,7 +2019,8 @@ restart_iteration:
   if (step_info) {
     // (__syncthreads_or returns a truth value, not the OR of the bits: one reduction per flag)
     const int any = (__syncthreads_or(flags & kFemFlagPenetration) ? kFemFlagPenetration : 0) |
-                    (__syncthreads_or(flags & kFemFlagLsFailed) ? kFemFlagLsFailed : 0);
+                    (__syncthreads_or(flags & kFemFlagLsFailed) ? kFemFlagLsFailed : 0) |
+                    (flags & (kFemFlagCoarseOff | kFemFlagPsdSafe));  // (these two are block-uniform)
     if (tid == 0) {
       step_info[(size_t)b * 4 + 0] = (double)n_newton; step_info[(size_t)b * 4 + 1] = dmax_last;
       step_info[(size_t)b * 4 + 2] = (double)any; step_info[(size_t)b * 4 + 3] = pcg_total;
@@ -2216,6 +2307,13 @@ int tacex_fem_create(int device_id, const tacex_fem_params* p, tacex_fem_ctx** o
   d.psi_rest = 0.5 * d.lam * (1.0 - d.alpha) * (1.0 - d.alpha) - 0.5 * d.mu * log(4.0);
   d.dt = p->dt;
   d.strength = p->constraint_strength_ratio;
+  {
+    double lo[3] = {X[0], X[1], X[2]}, hi[3] = {X[0], X[1], X[2]};
+    for (int v = 1; v < V; ++v)
+      for (int i = 0; i < 3; ++i) { lo[i] = fmin(lo[i], X[v * 3 + i]); hi[i] = fmax(hi[i], X[v * 3 + i]); }
+    d.step_cap = sqrt((hi[0] - lo[0]) * (hi[0] - lo[0]) + (hi[1] - lo[1]) * (hi[1] - lo[1]) + (hi[2] - lo[2]) * (hi[2] - lo[2]));
+    c->dev_nwt.step_cap = d.step_cap;
+  }
   c->dev_nwt.mu = d.mu; c->dev_nwt.lam = d.lam; c->dev_nwt.alpha = d.alpha; c->dev_nwt.psi_rest = d.psi_rest;
   c->dev_nwt.dt = d.dt; c->dev_nwt.strength = d.strength;
   *out = c;
@@ -2518,23 +2616,35 @@ static int launch_newton(tacex_fem_ctx* c, double* x, const double* xt, const ui
                          const int* env_order = nullptr) {
   static const int use_lds = getenv("TACEX_FEM_NEWTON_LDS") ? atoi(getenv("TACEX_FEM_NEWTON_LDS")) : 1;
   const bool fric = xprev && disp && c->dev.indenters && c->dev.fric_mu > 0.0;
-  // x, p | window | sums | [friction lag] || chain factors | [friction Hessian blocks] (floats) || incidence codes | chain links (u16)
-  // ... | diagonal mass term (V doubles) ... | chain heads per thread | CSR offsets (u16)
-  const size_t lds = ((((size_t)7 * c->dev.V + (size_t)12 * kNwtChunk + 18 + (fric ? (size_t)4 * c->dev.V : 0)) * sizeof(double) +
-                       ((size_t)15 * c->dev.V + (fric ? (size_t)6 * c->dev.V : 0)) * sizeof(float) +
-                       ((size_t)4 * c->dev.T + 3 * (size_t)c->dev.V + kNwtThreads + 1) * sizeof(unsigned short)) + 15) & ~(size_t)15;
-  if (use_lds && c->dev.V <= kNwtThreads && 4 * c->dev.T < 65535 && lds <= 160 * 1024) {
+  const bool mesh = c->dev.indenters && c->dev.im_nt > 0;  // the mesh-capable instantiation only when a mesh indenter exists
+  static const int env_atomic = getenv("TACEX_FEM_ATOMIC") ? atoi(getenv("TACEX_FEM_ATOMIC")) : 1;  // A/B hook
+  const bool atom = env_atomic != 0 && !c->deterministic;
+  // threads per env: one per vertex, in steps of four waves (nwt_window_doubles); the wide variants are atomic-only and take analytic
+  // indenters only (a mesh indenter or the deterministic switch on a mesh of more than 512 vertices: streaming kernel below)
+  const int V = c->dev.V;
+  const int nt = V <= 512 ? 512 : (V <= 768 ? 768 : 1024);
+  const size_t lds = nwt_lds_bytes(V, c->dev.T, fric, nt);
+  if (use_lds && V <= 1024 && (nt == 512 ? 4 * c->dev.T < 65535 : (atom && !mesh)) && lds <= 160 * 1024) {
     if (resident) *resident = true;
-    static size_t granted[4][64] = {};  // per kernel instantiation and device: the attribute is per kernel AND device
-    const bool mesh = c->dev.indenters && c->dev.im_nt > 0;  // the mesh-capable instantiation only when a mesh indenter exists
-    static const int env_atomic = getenv("TACEX_FEM_ATOMIC") ? atoi(getenv("TACEX_FEM_ATOMIC")) : 1;  // A/B hook
-    const bool atom = env_atomic != 0 && !c->deterministic;
-    auto kern = mesh ? (atom ? fem_newton_lds_kernel<true, true> : fem_newton_lds_kernel<true, false>)
-                     : (atom ? fem_newton_lds_kernel<false, true> : fem_newton_lds_kernel<false, false>);
+    static size_t granted[6][64] = {};  // per kernel instantiation and device: the attribute is per kernel AND device
+    using kern_t = decltype(&fem_newton_lds_kernel<false, true, 512>);
+    kern_t kern;
+    int slot;
+    if (nt == 512) {
+      kern = mesh ? (atom ? fem_newton_lds_kernel<true, true, 512> : fem_newton_lds_kernel<true, false, 512>)
+                  : (atom ? fem_newton_lds_kernel<false, true, 512> : fem_newton_lds_kernel<false, false, 512>);
+      slot = (mesh ? 1 : 0) + (atom ? 2 : 0);
+    } else if (nt == 768) {
+      kern = fem_newton_lds_kernel<false, true, 768>;
+      slot = 4;
+    } else {
+      kern = fem_newton_lds_kernel<false, true, 1024>;
+      slot = 5;
+    }
     hipError_t ea = hipSetDevice(c->device);
-    if (ea == hipSuccess) ea = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds, granted[(mesh ? 1 : 0) + (atom ? 2 : 0)]);
+    if (ea == hipSuccess) ea = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds, granted[slot]);
     if (ea != hipSuccess) return fail_hip(ea, "hipFuncSetAttribute(fem_newton_lds_kernel)");
-    hipLaunchKernelGGL(kern, dim3(B), dim3(kNwtThreads), lds, st, c->dev_nwt, x, xt, cons, aim, stats, pcg_max_iter,
+    hipLaunchKernelGGL(kern, dim3(B), dim3(nt), lds, st, c->dev_nwt, x, xt, cons, aim, stats, pcg_max_iter,
                        pcg_tol_rate, ls_max_iter, dx_dev, dx_tol, max_newton, step_info, fric ? xprev : nullptr,
                        (xprev && disp && c->dev.indenters) ? disp : nullptr, env_order, c->follow_indenter ? 1 : 0,
                        max_newton > 1 ? static_cast<double*>(ws) : nullptr);  // env blocks of the workspace: (15, V) lagged blocks per env
@@ -2543,9 +2653,10 @@ static int launch_newton(tacex_fem_ctx* c, double* x, const double* xt, const ui
   }
   if (resident) *resident = false;
   if (c->dev.indenters && (c->dev.fric_mu > 0.0 || c->dev.im_nt > 0)) {
-    set_error("FEM Newton: friction and mesh indenters need the CU-resident Newton kernel (mesh with <= %d vertices, TACEX_FEM_NEWTON_LDS != 0); "
-              "the streaming kernel of larger meshes handles the barrier of analytic indenters only - switch friction off",
-              kNwtThreads);
+    set_error("FEM Newton: friction and mesh indenters need the CU-resident Newton kernel (mesh with <= 1024 vertices whose state fits the "
+              "CU's 160 KB of LDS - this one needs %zu bytes; a mesh indenter or the deterministic switch: <= 512 vertices; "
+              "TACEX_FEM_NEWTON_LDS != 0); the streaming kernel of larger meshes handles the barrier of analytic indenters only - "
+              "switch friction off", lds);
     return 2;
   }
   hipLaunchKernelGGL(fem_newton_kernel, dim3(B), dim3(512), 0, st, c->dev, x, xt, cons, aim, stats, static_cast<double*>(ws), pcg_max_iter,

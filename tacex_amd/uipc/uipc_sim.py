@@ -446,11 +446,14 @@ class UipcSim:
     def check_step(self, raise_on_penetration: bool = True) -> dict:
         """Diagnostics of the last step (synchronises): flag 1 = a contact vertex was at or beyond its indenter's surface when a
         Newton iteration started - the caller moved the indenter by more than the gap between two steps (`set_contact_indenters`
-        documents the contract) and that vertex gets no restoring force; flag 2 = a line search found no decrease."""
+        documents the contract) and that vertex gets no restoring force; flag 2 = a line search found no decrease.  Informational:
+        4 = the env dropped the coarse correction for the rest of the step, 8 = it met negative curvature and finished the step with
+        the PSD-safe Hessian (csrc/fem_kernels.hip, kFemFlagCoarseOff / kFemFlagPsdSafe)."""
         si = self.step_info.cpu().numpy()
         flags = si[:, 2].astype(np.int64)
         out = {"newton_iters": si[:, 0].astype(np.int64), "max_d": si[:, 1], "penetrating_envs": np.nonzero(flags & 1)[0],
-               "line_search_failed_envs": np.nonzero(flags & 2)[0], "pcg_iters": si[:, 3].astype(np.int64)}
+               "line_search_failed_envs": np.nonzero(flags & 2)[0], "pcg_iters": si[:, 3].astype(np.int64),
+               "coarse_dropped_envs": np.nonzero(flags & 4)[0], "psd_safe_envs": np.nonzero(flags & 8)[0]}
         if raise_on_penetration and len(out["penetrating_envs"]):
             raise RuntimeError(f"gelpad penetrated by its indenter in envs {out['penetrating_envs'][:8].tolist()}: the indenter moved by "
                                "more than the contact gap between two steps (see UipcSim.set_contact_indenters)")

@@ -635,7 +635,7 @@ def test_friction_drags_the_pad_surface():
             if mu > 0:
                 xo, vo, io = fem_step(m, cms[0], xo, vo, cons, aim[0], gravity=sim.cfg.gravity, max_newton=60, velocity_tol=1e-3, pcg_max_iter=600,
                                       pcg_tol_rate=1e-6, coarse=sim.coarse_space, chains=_chains(sim), friction=(mu, sim.cfg.contact.eps_velocity, disp))
-                assert io[0] < 60 and io[2] == 0
+                assert io[0] < 60 and int(io[2]) & 3 == 0
                 assert np.abs(sim.x[0].cpu().numpy() - xo).max() <= 2 * 1e-3 * sim.cfg.dt, k  # both inside the Newton tolerance of the same state
         x = sim.x[0].cpu().numpy()
         top = P[:, 2] > P[:, 2].max() - 1e-9
@@ -858,24 +858,21 @@ def test_contact_following_start_is_only_an_initial_guess_and_tames_the_retreat(
     assert res[True][1] < res[False][1] and res[True][2] < 0.75 * res[False][2], (res[True][1:], res[False][1:])
 
 
-def test_streaming_newton_kernel_steps_simple_axle_with_sphere_contact():
-    """a mesh with MORE vertices than the CU-resident Newton kernel has threads - the reference's
-    simple_axle.msh (593 vertices / 2 003 tets, tests/golden/fem_meshes.npz) - stepped WITH contact.  Such meshes run on the streaming
-    Newton kernel (state in HBM / L2, any vertex count), which now carries the IPC barrier and the conservative step bound; friction,
-    chains and the coarse correction stay with the CU-resident kernel (asked for together with friction, the step fails loudly).
-    Against the oracle's fem_step with the same block-Jacobi preconditioner: iteration counts, positions, no penetration."""
-    from oracle.fem_oracle import ContactModel, FemModel, fem_step
+def _axle_scene(B, deterministic=False, block_jacobi=False, velocity_tol=2e-3):
+    """simple_axle.msh (593 vertices / 2 003 tets, tests/golden/fem_meshes.npz) scaled to 25.8 x 3 x 3 mm, both ends held, a sphere over its middle."""
+    from oracle.fem_oracle import ContactModel, FemModel
     from tacex_amd.uipc import UipcObject, UipcObjectCfg, UipcSim, UipcSimCfg
 
     g = np.load(Path(__file__).parent / "golden" / "fem_meshes.npz")
-    P = (g["simple_axle_points"] - g["simple_axle_points"].min(0)) * 0.01  # an axle of 25.8 x 3 x 3 mm
+    P = (g["simple_axle_points"] - g["simple_axle_points"].min(0)) * 0.01
     T = g["simple_axle_tets"]
     assert len(P) == 593 and len(T) == 2003
-    B = 2
     cfg = UipcSimCfg(device="cuda:0")
-    cfg.linear_system.coarse_grid, cfg.linear_system.vertex_chains = None, None
+    if block_jacobi:
+        cfg.linear_system.coarse_grid, cfg.linear_system.vertex_chains = None, None
+    cfg.linear_system.deterministic = deterministic
     cfg.linear_system.max_iter, cfg.linear_system.tol_rate = 3000, 1e-5
-    cfg.newton.velocity_tol = 2e-3
+    cfg.newton.velocity_tol = velocity_tol
     sim = UipcSim(cfg, num_envs=B)
     gel = UipcObject(UipcObjectCfg(mesh_points=P, mesh_tets=T), sim)
     sim.setup_sim(constraint_strength_ratio=1000.0)
@@ -887,6 +884,73 @@ def test_streaming_newton_kernel_steps_simple_axle_with_sphere_contact():
     ind = np.zeros((B, 8)); ind[:, 0] = 1.0
     ind[:, 1], ind[:, 2], ind[:, 4] = mid, P[:, 1].max() / 2, 0.004
     ind[:, 3] = top + 0.004 + 0.0009 - 1e-4 * np.arange(B)
+    m = FemModel.build(P, T, youngs=gel.cfg.constitution_cfg.youngs_modulus * 1e6, poisson=gel.cfg.constitution_cfg.poisson_rate,
+                       density=gel.cfg.mass_density, dt=sim.cfg.dt, strength=1000.0)
+    area = gel.surface_vertex_areas()
+    kappa = sim.cfg.contact.default_contact_resistance * 1e9 * sim.cfg.contact.d_hat
+    cms = [ContactModel(area, ind[b].copy(), sim.cfg.contact.d_hat, kappa, sim.cfg.dt) for b in range(B)]
+    return sim, m, P, cons, aim, cms, ind
+
+
+def test_wide_newton_kernel_steps_simple_axle_with_contact_and_friction():
+    """a mesh with MORE vertices than 512 - the reference's simple_axle.msh - stepped by the CU-resident Newton kernel
+    (its 768-thread variant: one thread per vertex, state in LDS) with everything the gelpad scene uses: IPC barrier, CCD step bound,
+    Coulomb friction (on by default, uipc_sim.py:103-124), the coarse correction on the bounding-box grid of the unstructured mesh and
+    the vertex chains found in it.  Against the oracle's fem_step with the same tables: press for three steps, then slide.
+    The bent axle has compressed elements with negative curvature: its envs solve some iterations in PSD-safe mode (kFemFlagPsdSafe)."""
+    from oracle.fem_oracle import fem_step
+
+    B, vtol = 2, 5e-4
+    sim, m, P, cons, aim, cms, ind = _axle_scene(B, velocity_tol=vtol)
+    sim.set_contact_indenters(torch.from_numpy(ind))
+    indd = sim.contact_indenters
+    mu, slide = sim.cfg.contact.default_friction_ratio, 3e-5
+    assert sim.cfg.contact.enable_friction and mu > 0
+    xo = [P.copy() for _ in range(B)]
+    vo = [np.zeros_like(P) for _ in range(B)]
+    prev, psd_seen, gap_min = None, False, np.inf
+    for k in range(5):
+        gap = sim.contact_gaps().amin(1)
+        if k < 3:
+            indd[:, 3] -= 0.3 * gap
+        else:
+            indd[:, 1] += slide
+            indd[:, 3] += torch.clamp(2 * slide - gap, min=0.0)
+        cur = indd[:, 1:4].cpu().numpy().copy()
+        disp = cur - prev if prev is not None else np.zeros_like(cur)
+        prev = cur
+        # (every step starts the oracle from the kernel's state: the bending mode of this rod is nearly free, two runs that both stop
+        #  on the Newton tolerance drift apart along it over the steps - 0.1 mm by the fifth - and that drift is not what is compared)
+        xo, vo = list(sim.x.cpu().numpy().copy()), list(sim.v.cpu().numpy().copy())
+        sim.step(max_newton_iter=60)
+        info = sim.check_step()
+        assert len(info["penetrating_envs"]) == 0 and len(info["line_search_failed_envs"]) == 0 and int(sim.last_newton_iters) < 60, (k, info)
+        psd_seen = psd_seen or len(info["psd_safe_envs"]) > 0
+        x = sim.x.cpu().numpy()
+        assert np.isfinite(x).all() and float(sim.contact_gaps().amin()) > 0.0
+        gap_min = min(gap_min, float(sim.contact_gaps().amin()))
+        for b in range(B):
+            cms[b].ind[1:4] = cur[b]
+            xo[b], vo[b], io = fem_step(m, cms[b], xo[b], vo[b], cons, aim[b], gravity=sim.cfg.gravity, max_newton=60, velocity_tol=vtol,
+                                        pcg_max_iter=3000, pcg_tol_rate=1e-5, coarse=sim.coarse_space, chains=_chains(sim),
+                                        friction=(mu, sim.cfg.contact.eps_velocity, disp[b]))
+            assert io[0] < 60 and int(io[2]) & 3 == 0, (k, b, io)
+            assert np.abs(x[b] - xo[b]).max() <= 2 * vtol * sim.cfg.dt, (k, b, np.abs(x[b] - xo[b]).max(), io, info)  # both inside the Newton tolerance
+    assert (P[:, 2] - sim.x[0].cpu().numpy()[:, 2]).max() > 5e-5  # the axle is dented / bent by the sphere
+    assert gap_min < sim.cfg.contact.d_hat  # the barrier really acted (the soft rod is pushed away and may swing clear of the zone again)
+    assert sim.coarse_space[2].shape[0] == 3 * 16 and len(sim.vertex_chains) > 0  # 3 x 1 x 1 cells over the axle; the chains found in it
+    assert psd_seen  # (the safeguard is what this mesh needs: without it the loop crawled into inverted states, oracle and kernel alike)
+
+
+def test_streaming_newton_kernel_steps_simple_axle_with_sphere_contact():
+    """The streaming Newton kernel (state in HBM / L2, any vertex count: what a mesh of more than 1 024 vertices, or the deterministic
+    switch on one of more than 512, runs on) carries the IPC barrier and the conservative step bound; friction, chains and the coarse
+    correction stay with the CU-resident kernel (asked for together with friction, the step fails loudly).  simple_axle.msh in
+    deterministic mode against the oracle's fem_step with the same block-Jacobi preconditioner: iteration counts, positions, no penetration."""
+    from oracle.fem_oracle import fem_step
+
+    B = 2
+    sim, m, P, cons, aim, cms, ind = _axle_scene(B, deterministic=True, block_jacobi=True)
     # friction is on by default (uipc_sim.py:103-124) and lives in the CU-resident kernel only: the step says so
     sim.set_contact_indenters(torch.from_numpy(ind))
     with pytest.raises(Exception, match="friction"):
@@ -894,11 +958,6 @@ def test_streaming_newton_kernel_steps_simple_axle_with_sphere_contact():
     sim.cfg.contact.enable_friction = False
     sim.set_contact_indenters(torch.from_numpy(ind))
     indd = sim.contact_indenters
-    m = FemModel.build(P, T, youngs=gel.cfg.constitution_cfg.youngs_modulus * 1e6, poisson=gel.cfg.constitution_cfg.poisson_rate,
-                       density=gel.cfg.mass_density, dt=sim.cfg.dt, strength=1000.0)
-    area = gel.surface_vertex_areas()
-    kappa = sim.cfg.contact.default_contact_resistance * 1e9 * sim.cfg.contact.d_hat
-    cms = [ContactModel(area, ind[b].copy(), sim.cfg.contact.d_hat, kappa, sim.cfg.dt) for b in range(B)]
     xo = [P.copy() for _ in range(B)]
     vo = [np.zeros_like(P) for _ in range(B)]
     for k in range(3):
@@ -911,7 +970,7 @@ def test_streaming_newton_kernel_steps_simple_axle_with_sphere_contact():
             cms[b].ind[1:4] = cur[b]
             xo[b], vo[b], io = fem_step(m, cms[b], xo[b], vo[b], cons, aim[b], gravity=sim.cfg.gravity, max_newton=30, velocity_tol=2e-3,
                                         pcg_max_iter=3000, pcg_tol_rate=1e-5, coarse=None, chains=None, lag_prec=False)
-            assert io[0] < 30 and io[2] == 0, (k, b, io)
+            assert io[0] < 30 and int(io[2]) & 3 == 0, (k, b, io)
             assert np.abs(x[b] - xo[b]).max() <= 2 * 2e-3 * sim.cfg.dt, (k, b, np.abs(x[b] - xo[b]).max())  # both inside the Newton tolerance
     assert (P[:, 2] - sim.x[0].cpu().numpy()[:, 2]).max() > 5e-5  # the axle is dented / bent by the sphere
 

@@ -508,3 +508,76 @@ def test_edge_snap_lowers_the_energy_and_lands_at_the_balance_depth():
     cm2 = ContactModel(area, ind2, dhat, kappa, m.dt)
     xs2, n2 = edge_snap(m, cm2, x2, x2, cons, P)
     assert n2 == 0 and np.array_equal(xs2, x2)
+
+
+def test_psd_safe_hessian_is_positive_semidefinite_where_the_exact_one_is_not(meshes):
+    """PSD-safe mode (kFemFlagPsdSafe of csrc/fem_kernels.hip, `FemModel.psd_safe`): with |c_J| clamped to a / sqrt(2 Ic) per element the
+    9x9 F-space Hessian a I + b f f^T + lam c c^T + c_J d2J/dF2 is PSD for ANY deformation gradient - also strongly compressed and
+    inverted ones, where the exact Hessian has negative eigenvalues - and the bound it rests on holds: the spectral norm of d2J/dF2
+    is below sqrt(2 Ic).  Hessian-vector products in that mode are those of the clamped element matrices."""
+    m = _model(meshes, "cube")
+    rng = np.random.default_rng(3)
+    n_indef = 0
+    for trial in range(60):
+        F = np.eye(3) + rng.normal(scale=0.6, size=(3, 3))
+        if trial % 3 == 0:
+            F = F @ np.diag([0.25, 1.0, 1.4])  # compressed along one axis
+        H = {}
+        for safe in (False, True):
+            m.psd_safe = safe
+            H9 = np.zeros((9, 9))
+            for q in range(9):
+                dF = np.zeros((3, 3)); dF[q // 3, q % 3] = 1.0
+                H9[:, q] = m.dpk1(F[None], dF[None])[0].reshape(9)
+            H[safe] = 0.5 * (H9 + H9.T)
+        m.psd_safe = False
+        w_exact, w_safe = np.linalg.eigvalsh(H[False]), np.linalg.eigvalsh(H[True])
+        n_indef += w_exact[0] < -1e-9 * abs(w_exact).max()
+        assert w_safe[0] >= -1e-9 * abs(w_safe).max(), (trial, w_safe[0])
+        # the bound: HJ = d2J/dF2 as the linear map dF -> d(cofactor)
+        HJ = np.zeros((9, 9))
+        for q in range(9):
+            dF = np.zeros((3, 3)); dF[q // 3, q % 3] = 1.0
+            eps = 1e-6
+            HJ[:, q] = ((m.cofactor((F + eps * dF)[None]) - m.cofactor((F - eps * dF)[None]))[0] / (2 * eps)).reshape(9)
+        assert np.abs(np.linalg.eigvalsh(0.5 * (HJ + HJ.T))).max() <= np.sqrt(2.0 * (F * F).sum()) * (1 + 1e-6)
+    assert n_indef >= 10  # the exact Hessian really is indefinite on a good part of these states
+    # H.p in PSD-safe mode on a deformed mesh: p^T H p >= 0 for random p where the exact product goes negative for some
+    x = m.X * np.array([0.55, 1.0, 1.0]) + rng.normal(scale=0.02 * np.ptp(m.X), size=m.X.shape)
+    neg = {False: 0, True: 0}
+    for k in range(40):
+        p = rng.normal(size=m.X.shape)
+        for safe in (False, True):
+            m.psd_safe = safe
+            neg[safe] += float((p * (m.hess_vec(x, p) - m.mass[:, None] * p)).sum()) < 0.0
+    m.psd_safe = False
+    assert neg[True] == 0, neg
+
+
+def test_fem_step_on_the_bent_axle_uses_psd_safe_mode_and_converges(meshes):
+    """The scene of tests/test_fem_gpu.py::test_wide_newton_kernel_steps_simple_axle_with_contact_and_friction, first step, on the CPU:
+    the sphere bends the soft rod, compressed elements give the exact Hessian negative curvature, the PCG meets it - and the step
+    still converges (PSD-safe mode, flag 8) without a failed line search.  Without the safeguards this step ran into its iteration
+    cap and the following ones into inverted states (profiles/r04_experiments.md)."""
+    from oracle.fem_oracle import ContactModel, chain_tables, contact_distance, fem_step
+    from tacex_amd.uipc.coarse_space import build_coarse_space, build_vertex_chains, coarse_grid_dims, coarse_operator_inverse
+    from tacex_amd.uipc.uipc_object import UipcObject, UipcObjectCfg
+
+    P = (meshes["simple_axle_points"] - meshes["simple_axle_points"].min(0)) * 0.01
+    T = meshes["simple_axle_tets"]
+    obj = UipcObject(UipcObjectCfg(mesh_points=P, mesh_tets=T))
+    m = FemModel.build(P, T, youngs=obj.cfg.constitution_cfg.youngs_modulus * 1e6, poisson=obj.cfg.constitution_cfg.poisson_rate,
+                       density=obj.cfg.mass_density, dt=0.01, strength=1000.0)
+    area = obj.surface_vertex_areas()
+    cons = ((P[:, 0] < 0.002) | (P[:, 0] > P[:, 0].max() - 0.002)).astype(np.float64)
+    ind = np.array([1.0, P[:, 0].max() / 2, P[:, 1].max() / 2, P[:, 2].max() + 0.004 + 0.0009, 0.004, 0, 0, 0])
+    cm = ContactModel(area, ind, 1e-3, 10.0 * 1e9 * 1e-3, m.dt)
+    cm.ind[3] -= 0.3 * contact_distance(cm.ind, P, None)[0][area > 0].min()
+    node, w, nc = build_coarse_space(P, coarse_grid_dims(P))
+    aci = coarse_operator_inverse(m.element_hessian(P), m.tets, m.mass, cons, 1000.0, m.dt, node, w, nc)
+    chains = chain_tables([list(map(int, c)) for c in build_vertex_chains(P, T) if len(c) > 1], len(P))
+    x, v, io = fem_step(m, cm, P.copy(), np.zeros_like(P), cons, P.copy(), max_newton=40, velocity_tol=2e-3, pcg_max_iter=3000, pcg_tol_rate=1e-3,
+                        coarse=(node, w, aci), chains=chains, friction=(0.5, 0.01, np.zeros(3)))
+    assert int(io[2]) & 8 and int(io[2]) & 3 == 0 and io[0] < 40 and io[1] <= 2e-3 * m.dt, io
+    assert np.isfinite(x).all() and (np.linalg.det(m.deformation_gradient(x)) > 0.2).all()  # no inverted or crushed element
+    assert 2e-4 < (P[:, 2] - x[:, 2]).max() < 1.5e-3  # the rod gives way by about the depth the sphere reached into the barrier zone
