@@ -450,7 +450,11 @@ def sweep(args, dev):
     run("C2: 256 envs x 1 sensor, Taxim RGB 320x240 (BASELINE configs[1])", 256, 240, 320, 1, False)
     run("C2 + FOTS markers: 256 envs x 1 sensor, RGB 320x240 + markers", 256, 240, 320, 1, True)
     run("512-env shard of the 4096-env / 8-GPU target: 512 envs x 1 sensor, RGB 320x240 + FOTS markers", 512, 240, 320, 1, True)
-    run("C4 per-GPU shard: 512 envs, RGB 320x240 + FEM-driven markers + gelpad FEM step (1920 tets / env) (BASELINE configs[3] / 8)",
+    run("C4 per-GPU shard: 512 envs, RGB 320x240 + FEM-driven markers + gelpad FEM step (1920 tets / env) (BASELINE configs[3] / 8); the FEM "
+        "step runs on a HIP stream of its own, the sensor's optical pipeline overlaps its straggler tail and the FEM-driven markers wait "
+        "for its event (FemGelpad side_stream; `fem_ms_*` then include the contention with the optical kernels)",
+        512, 240, 320, 1, False, fem=lambda: FemGelpad(512, dev, max_newton_iter=NEWTON_CAP, side_stream=True))
+    run("C4 per-GPU shard on ONE stream (A/B of the side stream: FEM step, then the sensor update; `fem_ms_*` are the FEM step alone)",
         512, 240, 320, 1, False, fem=lambda: FemGelpad(512, dev, max_newton_iter=NEWTON_CAP))
     run("C4 per-GPU shard with the Newton loop CAPPED at 8 iterations as in rounds 2-3 (continuity only: envs that reach the cap carry an "
         "unconverged state into the next step - `truncated_solves` says whether any did; the entry above is the measured rate)",
@@ -458,9 +462,9 @@ def sweep(args, dev):
     run("C4 shard, ROLLING CONTACT: the indenter stays on the pad like the ball of the reference's ball-rolling scene (depth 0.3-0.8 of "
         "the maximum, sliding +-0.5 mm sideways, friction on); whenever the indenter RETREATS the pad follows it up the barrier in damped "
         "Newton steps (every env runs to convergence: the cap of 64 iterations is asserted never to bind)",
-        512, 240, 320, 1, False, fem=lambda: FemGelpad(512, dev, motion="rolling", max_newton_iter=NEWTON_CAP))
+        512, 240, 320, 1, False, fem=lambda: FemGelpad(512, dev, motion="rolling", max_newton_iter=NEWTON_CAP, side_stream=True))
     run("C5 per-GPU shard: 1024 envs, RGB 640x480 + FEM-driven markers (gelpad FEM step included) (BASELINE configs[4] / 8)",
-        1024, 480, 640, 1, False, fem=lambda: FemGelpad(1024, dev, max_newton_iter=NEWTON_CAP))
+        1024, 480, 640, 1, False, fem=lambda: FemGelpad(1024, dev, max_newton_iter=NEWTON_CAP, side_stream=True))
     out.append(fem_axle_entry(dev))
     out.append(fem_axle_entry(dev, steps=6, streaming=True))
     run("C5 optical part only: 1024 envs, RGB 640x480", 1024, 480, 640, 1, False, steps=max(5, args.sweep_steps // 3))

@@ -143,6 +143,7 @@ class VisionTactileSensorUIPC:
 
     # -- frames (VT:142-187) -----------------------------------------------------------------------------
     def get_surface_vertices_world(self) -> torch.Tensor:
+        self.uipc_sim.wait_for_step()  # (a step enqueued on a side stream: UipcSim.step_done)
         return self.uipc_sim.x[:, self._surf_ids_dev]  # (B,Vs,3) float64
 
     def transform_world_to_camera_frame(self, v: torch.Tensor) -> torch.Tensor:

@@ -5,6 +5,7 @@ tests/test_fem_gpu.py; everything below runs on the device, no host round trip p
 from __future__ import annotations
 
 import math
+import os
 
 import numpy as np
 import torch
@@ -20,7 +21,7 @@ class FemGelpad:
     presses into the front face through the IPC barrier (d_hat 1 mm, CCD-filtered Newton steps) and breathes in and out;
     stepped with UipcSim.step (backward Euler: the whole Newton loop - matrix-free PCG, CCD filter, line search - in one HIP launch)."""
 
-    def __init__(self, B, dev, max_newton_iter: int = 8, motion: str = "breathing"):
+    def __init__(self, B, dev, max_newton_iter: int = 8, motion: str = "breathing", side_stream: bool = False):
         """motion: "breathing" - the indenter presses in and retreats to the edge of the barrier zone every 21 steps; "rolling" - it
         stays on the pad like the ball of the reference's ball-rolling scenes: the depth varies between 0.3 and 0.8 of the env's
         maximum while the sphere slides sideways by up to +-0.5 mm (friction drags the surface along).  Either way the half of the
@@ -28,6 +29,12 @@ class FemGelpad:
         in damped Newton steps (8 iterations per step, the scene's cap), 10-17 ms per step against ~1 ms while it presses."""
         assert motion in ("breathing", "rolling")
         self.motion = motion
+        # side_stream: the scene driver and the FEM step run on a HIP stream of their own and `sim.step_done` marks their end, so that
+        # whatever the caller enqueues next on ITS stream - the optical pipeline of the sensors' update - overlaps the Newton launch
+        # (which ends with a few straggler envs on a mostly idle GPU); the FEM-driven markers wait for the event (UipcSim.wait_for_step)
+        # (default stream priority: a high-priority FEM stream was measured - no gain at 320x240, 640x480 a third slower; TACEX_FEM_STREAM_PRIORITY for the A/B)
+        prio = int(os.environ.get("TACEX_FEM_STREAM_PRIORITY", "0"))
+        self.stream = torch.cuda.Stream(device=dev, priority=prio) if side_stream else None
         self.max_newton_iter = max_newton_iter
         P, T = gelpad_box_mesh(8, 10, 4)
         self.sim = UipcSim(UipcSimCfg(device=dev), num_envs=B)
@@ -64,6 +71,17 @@ class FemGelpad:
         self._pending = None
 
     def step(self, i):
+        if self.stream is None:
+            return self._step(i)
+        cur = torch.cuda.current_stream(self.stream.device)
+        self.stream.wait_stream(cur)  # everything enqueued so far - the previous update's marker kernel read x - is ordered before this step
+        with torch.cuda.stream(self.stream):
+            self._step(i)
+            if self.sim.step_done is None:
+                self.sim.step_done = torch.cuda.Event()
+            self.sim.step_done.record(self.stream)
+
+    def _step(self, i):
         self.ev[0].record()
         # (the scene driver stands in for the rigid-body simulator: kept to a handful of launches - fill, attachment kernel, gap kernel +
         #  reduction, three element-wise ops - so that it does not weigh on the FEM step it is timed with)

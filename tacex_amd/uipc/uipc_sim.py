@@ -437,6 +437,18 @@ class UipcSim:
         _lib.check(rc, "tacex_fem_step")
         return self.x
 
+    # -- a step on a side stream ---------------------------------------------------------------------------------------
+    step_done = None
+    """torch.cuda.Event a caller records behind a step it enqueued on a stream of its own (gelpad_scene.FemGelpad does: the FEM step and
+    the optical pipeline of a sensor update are independent until the FEM-driven markers read the pad's surface, and a Newton launch
+    ends with a tail of straggler envs on a mostly idle GPU - exactly where the Taxim kernels fit).  Consumers of `x` on another
+    stream call `wait_for_step()` first; None: steps run on the consumers' stream."""
+
+    def wait_for_step(self):
+        """Makes the current stream wait for the last step enqueued on a side stream (no-op without one, never blocks the host)."""
+        if self.step_done is not None:
+            torch.cuda.current_stream(self.device).wait_event(self.step_done)
+
     @property
     def last_newton_iters(self) -> int:
         """Newton iterations of the slowest env in the last step (reads the device: synchronises)."""

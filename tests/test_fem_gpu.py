@@ -598,6 +598,48 @@ def test_fem_gelpad_scene_through_the_sensor(res):
     assert float((md[0] - md[-1]).abs().max()) > 1e-3  # the envs differ
 
 
+def test_fem_step_on_a_side_stream_overlaps_the_sensor_update_and_changes_nothing():
+    """`FemGelpad(side_stream=True)` (what bench.py's C4 / C5 entries run): scene driver + FEM step on a HIP stream of their own, the
+    sensor update on the caller's stream, the FEM-driven marker plugin waiting for `UipcSim.step_done`.  Same markers, frames and pad
+    state as the single-stream run, step by step (deterministic sweeps, so that the comparison is bit for bit), with a busy kernel
+    queue on the caller's stream in between - without the event the marker kernel would read the pad mid-step."""
+    from tacex_amd import GelSightSensor, GelSightSensorCfg
+    from tacex_amd.calibration import CALIB_GELSIGHT_MINI
+    from tacex_amd.simulation_approaches.fem_based import ManiSkillSimulatorCfg
+    from tacex_amd.simulation_approaches.gpu_taxim import TaximSimulatorCfg
+    from tacex_amd.uipc.gelpad_scene import FemGelpad
+    from tacex_amd.utils.synthetic import synthetic_depth_maps
+
+    B, H, W = 8, 240, 320
+    outs = {}
+    for side in (False, True):
+        fem = FemGelpad(B, "cuda:0", max_newton_iter=40, side_stream=side)
+        assert fem.sim._lib.tacex_fem_set_deterministic(fem.sim._handle, 1) == 0
+        cfg = GelSightSensorCfg(
+            num_envs=B, sensor_camera_cfg=GelSightSensorCfg.SensorCameraCfg(resolution=(W, H), clipping_range=(0.024, 0.029)),
+            data_types=["tactile_rgb", "height_map", "marker_motion"],
+            optical_sim_cfg=TaximSimulatorCfg(calib_folder_path=str(CALIB_GELSIGHT_MINI), gelpad_height=0.0045, gelpad_to_camera_min_distance=0.024,
+                                              with_shadow=False, tactile_img_res=(W, H), device="cuda:0"),
+            marker_motion_sim_cfg=ManiSkillSimulatorCfg(tactile_img_res=(W, H), device="cuda:0", camera_pos_w=(0.008, 0.012625, -0.024)),
+            device="cuda:0")
+        s = GelSightSensor(cfg, gelpad_obj=fem.gelpad)
+        s.initialize()
+        hm, _ = synthetic_depth_maps(B, H, W, seed=5)
+        s.set_camera_depth((hm / 1000.0).cuda())
+        rec = []
+        for i in range(10):
+            fem.step(i)
+            s.update(dt=0.01, force_recompute=True)
+            rec.append((s.data.output["marker_motion"].clone(), s.data.output["tactile_rgb"].clone()))
+        torch.cuda.synchronize()
+        assert (fem.sim.step_done is not None) == side
+        outs[side] = (rec, fem.sim.x.clone(), fem.sim.step_info.clone())
+    for (m0, r0), (m1, r1) in zip(outs[False][0], outs[True][0]):
+        assert torch.equal(m0, m1) and torch.equal(r0, r1)
+    assert torch.equal(outs[False][1], outs[True][1]) and torch.equal(outs[False][2], outs[True][2])
+    assert float((outs[True][0][-1][0] - outs[True][0][0][0]).abs().max()) > 0.05  # the markers moved [px]
+
+
 def test_friction_drags_the_pad_surface():
     """A sphere pressed into the pad slides sideways: with Coulomb friction (reference default, ratio 0.5) the contact patch of
     the surface follows it, without friction it stays; kernel and oracle agree on how far.  The press is gentle enough for every
