@@ -536,7 +536,8 @@ def fem_axle_entry(dev, B=512, steps=12, streaming=False):
         return {"workload": f"FEM only: {B} envs x simple_axle.msh (593 vertices / 2003 tets, scaled to 25.8 x 3 x 3 mm), ends attached, a sphere "
                             f"pressing on through the IPC barrier: {name}",
                 "envs": B, "steps": steps, "ms_per_step": round(el / steps * 1e3, 3), "env_steps_per_s": round(B * steps / el, 1),
-                "newton_iters_max": int(its), "newton_cap": AXLE_NEWTON_CAP, "failure_flags_max": int(flagged), "velocity_tol": 2e-3}
+                "newton_iters_max": None if streaming else int(its),  # (the streaming path leaves step_info zero: one launch per iteration on a fixed schedule)
+                "newton_cap": AXLE_NEWTON_CAP, "failure_flags_max": int(flagged), "velocity_tol": 2e-3}
     except Exception as ex:
         return {"workload": f"FEM only: simple_axle.msh on {name}", "error": f"{type(ex).__name__}: {ex}"[:300]}
 
