@@ -439,9 +439,9 @@ int tacex_fem_newton_step(tacex_fem_ctx* ctx, double* x_dev, const double* x_til
  *   test on the search direction, whatever the CCD bound and the line search made of the step);
  *   v = (x - x_prev) / dt.
  * x_dev, v_dev (B,V,3) f64 are updated in place, x_tilde_dev (B,V,3) is written.  With the CU-resident Newton kernel (one thread per
- * vertex: 512 threads per env for meshes of <= 512 vertices, 768 / 1024 threads for <= 768 / <= 1024 as long as the env's state fits
- * the CU's 160 KB of LDS - simple_axle.msh, 593 vertices / 2 003 tets, does with friction; the wide variants take analytic indenters
- * only and are not available with tacex_fem_set_deterministic) the whole loop is ONE launch; the streaming fallback launches
+ * vertex: 512 threads per env for meshes of <= 512 vertices, 768 threads for larger ones as long as the env's state fits the CU's
+ * 160 KB of LDS - about 600 vertices with friction, 745 without; simple_axle.msh, 593 vertices / 2 003 tets, does with friction; the
+ * wide variant takes analytic indenters only and is not available with tacex_fem_set_deterministic) the whole loop is ONE launch; the streaming fallback launches
  * max_newton kernels on a fixed schedule in which converged envs return at once.  stats_dev (B,4) = [energy_before, energy_after, step_length, pcg_iterations] of the LAST iteration
  * run; step_info_dev (B,4) f64 = [newton_iterations, max |d| of the last iteration, flags, pcg_iterations_total] (CU-resident
  * kernel; zeros from the fallback), flags: 1 = a contact vertex was at or beyond its indenter's surface when an iteration started

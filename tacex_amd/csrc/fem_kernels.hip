@@ -973,12 +973,14 @@ __global__ __launch_bounds__(512) void fem_newton_kernel(FemDev m, double* xg, c
 constexpr int kNwtThreads = 512;
 constexpr int kNwtChunk = 512;  // tets per LDS exchange window (1024 = 2 per thread measured slower: 90 spilled VGPRs)
 constexpr int kNwtTpw = kNwtChunk / kNwtThreads;
-// MESHES OF MORE THAN 512 VERTICES run the same kernel with 768 or 1024 threads (thread v still owns vertex v; 3 or 4 waves per SIMD
-// instead of 2, i.e. 168 / 128 registers per lane instead of 256: more of the per-thread state goes to scratch, which is what such an
-// env pays for staying on one CU - the streaming kernel's alternative is a trip through HBM per PCG iteration).  Only the atomic
-// flavour exists there: without the exchange window and the incidence list in LDS (12 x NT doubles + 4 T shorts) a 593-vertex /
-// 2 003-tet mesh with friction fits the CU's 160 KB.  The region between p and the reduction rows then only has to hold what the
-// kernel parks in it: the 15 V block accumulators of the assembly (p + region), the preconditioner's r | r_c | y_c | z.
+// MESHES OF MORE THAN 512 VERTICES run the same kernel with 768 threads (thread v still owns vertex v; 3 waves per SIMD instead of 2,
+// i.e. 168 registers per lane instead of 256: more of the per-thread state goes to scratch, which is what such an env pays for
+// staying on one CU - the streaming kernel's alternative is a trip through HBM per PCG iteration).  Only the atomic flavour exists
+// there: without the exchange window and the incidence list in LDS (12 x NT doubles + 4 T shorts) a 593-vertex / 2 003-tet mesh with
+// friction fits the CU's 160 KB.  The region between p and the reduction rows then only has to hold what the kernel parks in it: the
+// 15 V block accumulators of the assembly (p + region), the preconditioner's r | r_c | y_c | z.  What bounds the vertex count is the
+// LDS, not the threads: 268 bytes per vertex with friction (about 600 vertices), 212 without (about 745) - a 1 024-thread variant
+// would never be launched and is not instantiated.
 __host__ __device__ constexpr int nwt_window_doubles(int V, int NT) {
   return NT <= kNwtThreads ? 12 * kNwtChunk : (12 * V > 6 * V + 6 * kFemMaxCoarse ? 12 * V : 6 * V + 6 * kFemMaxCoarse);
 }
@@ -2622,11 +2624,11 @@ static int launch_newton(tacex_fem_ctx* c, double* x, const double* xt, const ui
   // threads per env: one per vertex, in steps of four waves (nwt_window_doubles); the wide variants are atomic-only and take analytic
   // indenters only (a mesh indenter or the deterministic switch on a mesh of more than 512 vertices: streaming kernel below)
   const int V = c->dev.V;
-  const int nt = V <= 512 ? 512 : (V <= 768 ? 768 : 1024);
+  const int nt = V <= 512 ? 512 : 768;
   const size_t lds = nwt_lds_bytes(V, c->dev.T, fric, nt);
-  if (use_lds && V <= 1024 && (nt == 512 ? 4 * c->dev.T < 65535 : (atom && !mesh)) && lds <= 160 * 1024) {
+  if (use_lds && V <= 768 && (nt == 512 ? 4 * c->dev.T < 65535 : (atom && !mesh)) && lds <= 160 * 1024) {
     if (resident) *resident = true;
-    static size_t granted[6][64] = {};  // per kernel instantiation and device: the attribute is per kernel AND device
+    static size_t granted[5][64] = {};  // per kernel instantiation and device: the attribute is per kernel AND device
     using kern_t = decltype(&fem_newton_lds_kernel<false, true, 512>);
     kern_t kern;
     int slot;
@@ -2634,12 +2636,9 @@ static int launch_newton(tacex_fem_ctx* c, double* x, const double* xt, const ui
       kern = mesh ? (atom ? fem_newton_lds_kernel<true, true, 512> : fem_newton_lds_kernel<true, false, 512>)
                   : (atom ? fem_newton_lds_kernel<false, true, 512> : fem_newton_lds_kernel<false, false, 512>);
       slot = (mesh ? 1 : 0) + (atom ? 2 : 0);
-    } else if (nt == 768) {
+    } else {
       kern = fem_newton_lds_kernel<false, true, 768>;
       slot = 4;
-    } else {
-      kern = fem_newton_lds_kernel<false, true, 1024>;
-      slot = 5;
     }
     hipError_t ea = hipSetDevice(c->device);
     if (ea == hipSuccess) ea = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds, granted[slot]);
@@ -2653,7 +2652,7 @@ static int launch_newton(tacex_fem_ctx* c, double* x, const double* xt, const ui
   }
   if (resident) *resident = false;
   if (c->dev.indenters && (c->dev.fric_mu > 0.0 || c->dev.im_nt > 0)) {
-    set_error("FEM Newton: friction and mesh indenters need the CU-resident Newton kernel (mesh with <= 1024 vertices whose state fits the "
+    set_error("FEM Newton: friction and mesh indenters need the CU-resident Newton kernel (mesh with <= 768 vertices whose state fits the "
               "CU's 160 KB of LDS - this one needs %zu bytes; a mesh indenter or the deterministic switch: <= 512 vertices; "
               "TACEX_FEM_NEWTON_LDS != 0); the streaming kernel of larger meshes handles the barrier of analytic indenters only - "
               "switch friction off", lds);

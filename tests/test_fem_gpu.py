@@ -985,7 +985,7 @@ def test_wide_newton_kernel_steps_simple_axle_with_contact_and_friction():
 
 
 def test_streaming_newton_kernel_steps_simple_axle_with_sphere_contact():
-    """The streaming Newton kernel (state in HBM / L2, any vertex count: what a mesh of more than 1 024 vertices, or the deterministic
+    """The streaming Newton kernel (state in HBM / L2, any vertex count: what a mesh too large for a CU's LDS, or the deterministic
     switch on one of more than 512, runs on) carries the IPC barrier and the conservative step bound; friction, chains and the coarse
     correction stay with the CU-resident kernel (asked for together with friction, the step fails loudly).  simple_axle.msh in
     deterministic mode against the oracle's fem_step with the same block-Jacobi preconditioner: iteration counts, positions, no penetration."""
