@@ -70,6 +70,9 @@ struct tacex_taxim_ctx {
   int mk_version = 0;
   const int* frame_rows = nullptr; int frame_rows_cap = 0;  // caller-owned contact row ranges (tacex_taxim_set_frame_rows)
   int* stream_order = nullptr; int stream_order_cap = 0;  // item order of a streaming-tail launch (stream_order_kernel), grown by stream_plan
+  // second stream of the band levels (pipeline_impl: odd chunks of a pass run beside the even ones), created on first use
+  static constexpr int kMaxLvlStreams = 4;
+  hipStream_t lvl_stream[kMaxLvlStreams - 1] = {}; hipEvent_t lvl_fork = nullptr, lvl_join[kMaxLvlStreams - 1] = {};
   std::vector<void*> allocs;
   // profiling
   bool profiling = false;
@@ -217,6 +220,11 @@ void tacex_taxim_destroy(tacex_taxim_ctx* c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
   for (auto& e : c->events) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
+  for (auto& q : c->lvl_stream)
+    if (q) { (void)hipStreamSynchronize(q); (void)hipStreamDestroy(q); }
+  if (c->lvl_fork) (void)hipEventDestroy(c->lvl_fork);
+  for (auto& e : c->lvl_join)
+    if (e) (void)hipEventDestroy(e);
   for (void* p : c->allocs) (void)hipFree(p);
   delete c;
 }
@@ -669,10 +677,36 @@ static int pipeline_chunk(tacex_taxim_ctx* c, const float* hm, const float* pres
                            stream_supported(n_fused, c->levels[c->n_levels - n_fused].kw, c->H, c->W);
   // Band levels ahead of a streaming tail run over sub-ranges of the pass (level_chunk_frames): the tail wants >= 2048 strips
   // per launch, the band kernels want their three frame-sized buffers (height map, Z ping, Z pong) in the Infinity Cache.
-  const int lcf = stream_tail ? level_chunk_frames(c, B) : B;
+  int lcf = stream_tail ? level_chunk_frames(c, B) : B;
   const size_t npix = (size_t)c->H * c->W;
-  for (int b0 = 0; b0 < B; b0 += lcf) {
+  // TWO CHUNKS IN FLIGHT: the chunks of a pass are independent until the tail, and a band-level launch of 128-256 frames spends
+  // ~14 us of its 40-77 us ramping up and draining (k = 61: 45.5 us for 128 frames, 76.9 for 256).  Chunks therefore run round-robin on the
+  // caller's stream and on streams of the context's own - at a chunk size divided by the stream count, so that the frames in flight (and
+  // their three buffers in the Infinity Cache) stay what they were.  Single-kernel (matrix-core) levels only: the two-pass
+  // fallback shares one scratch image.  Not while profiling: the stage timers bracket launches on the caller's stream.
+  static const int lvl_streams_env = getenv("TACEX_LEVEL_STREAMS") ? atoi(getenv("TACEX_LEVEL_STREAMS")) : 2;
+  const int lvl_streams = lvl_streams_env > tacex_taxim_ctx::kMaxLvlStreams ? tacex_taxim_ctx::kMaxLvlStreams : lvl_streams_env;
+  bool dual = stream_tail && lvl_streams > 1 && !c->profiling && n_band > 0 && lcf < B;
+  for (int l = 0; dual && l < n_band; ++l)
+    dual = blur_level_single_kernel(c->levels[l], l == 0, c->H, c->W);
+  if (dual) {
+    if (!c->lvl_fork) HIP_TRY(hipEventCreateWithFlags(&c->lvl_fork, hipEventDisableTiming), "hipEventCreate");
+    for (int q = 0; q < lvl_streams - 1; ++q)
+      if (!c->lvl_stream[q]) {
+        HIP_TRY(hipStreamCreateWithFlags(&c->lvl_stream[q], hipStreamNonBlocking), "hipStreamCreate(band levels)");
+        HIP_TRY(hipEventCreateWithFlags(&c->lvl_join[q], hipEventDisableTiming), "hipEventCreate");
+      }
+    static const int env_lcf = getenv("TACEX_LEVEL_CHUNK_FRAMES") ? atoi(getenv("TACEX_LEVEL_CHUNK_FRAMES")) : -1;
+    if (env_lcf < 0) lcf = (lcf + lvl_streams - 1) / lvl_streams;
+    HIP_TRY(hipEventRecord(c->lvl_fork, st), "hipEventRecord");  // the pass's inputs (height map, shifts, rows) are ready behind this
+    for (int q = 0; q < lvl_streams - 1; ++q) HIP_TRY(hipStreamWaitEvent(c->lvl_stream[q], c->lvl_fork, 0), "hipStreamWaitEvent");
+  }
+  hipStream_t const st_main = st;
+  int chunk_no = 0;
+  for (int b0 = 0; b0 < B; b0 += lcf, ++chunk_no) {
     const int nb = B - b0 < lcf ? B - b0 : lcf;
+    const int lane_q = dual ? chunk_no % lvl_streams : 0;
+    hipStream_t st = lane_q > 0 ? c->lvl_stream[lane_q - 1] : st_main;  // (shadows the pass's stream inside the chunk)
     src = nullptr;
     int grow = 0;  // rows by which the non-zero range of the level's input exceeds the contact rows
     for (int l = 0; l < n_band; ++l) {
@@ -685,6 +719,12 @@ static int pipeline_chunk(tacex_taxim_ctx* c, const float* hm, const float* pres
               "blur level");
       grow += (c->levels[l].kh - 1) / 2;
       src = dst;
+    }
+  }
+  if (dual) {  // the tail (and whatever the caller enqueues next) waits for the odd chunks
+    for (int q = 0; q < lvl_streams - 1; ++q) {
+      HIP_TRY(hipEventRecord(c->lvl_join[q], c->lvl_stream[q]), "hipEventRecord");
+      HIP_TRY(hipStreamWaitEvent(st, c->lvl_join[q], 0), "hipStreamWaitEvent");
     }
   }
   int band_grow = 0;  // rows by which the band levels spread the non-zero range of their output beyond the contact rows

@@ -48,6 +48,7 @@ hipError_t run_indenter_height_map(const float* desc, float* hm, float* fmin, fl
                                    float gel_top_mm, float far_clip_mm, float gelpad_h, float gelpad_dmin, hipStream_t st);
 hipError_t run_press_depth(const float* fmin, const float* press, float* sa, float* sb, float* pd, int B,
                            int no_shift, hipStream_t st);
+bool blur_level_single_kernel(const LevelDesc& lv, bool first, int H, int W);  // one launch, no use of the shared scratch image
 hipError_t run_blur_level(const LevelDesc& lv, const float* src, const float* hm, const float* gel,
                           const float* sa, const float* sb, const float* pd, float* dst, float* tmp,
                           uint8_t* mask_out, int B, int H, int W, float contact_scale, int restore,

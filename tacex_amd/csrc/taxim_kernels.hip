@@ -941,6 +941,11 @@ hipError_t run_press_depth(const float* fmin, const float* press, float* sa, flo
   return hipGetLastError();
 }
 
+// true: run_blur_level runs this level as ONE matrix-core launch that never touches `tmp` (launches of different frame ranges may overlap)
+bool blur_level_single_kernel(const LevelDesc& lv, bool first, int H, int W) {
+  return lv.same_taps && lv.taps_mfma_dev && mfma_supported(lv.kw, first, H, W);
+}
+
 hipError_t run_blur_level(const LevelDesc& lv, const float* src, const float* hm, const float* gel,
                           const float* sa, const float* sb, const float* pd, float* dst, float* tmp,
                           uint8_t* mask_out, int B, int H, int W, float contact_scale, int restore,
