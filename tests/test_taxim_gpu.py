@@ -155,6 +155,49 @@ def test_zero_band_skipping_is_exact(calib_dir, tmp_path):
     assert np.abs(a["Z"]).max() > 0.1
 
 
+def test_band_levels_on_two_streams_change_no_bit(calib_dir, tmp_path):
+    """The chunks of a pass alternate between the caller's stream and a stream of the context's own (TACEX_LEVEL_STREAMS, default 2,
+    read once per process; `pipeline_impl`): fork / join events order them against the pass's inputs and its tail.  A 768-frame pass
+    (three chunks per level at one stream, six at two) rendered with one and with two streams - twice in a row on the same context,
+    so that the second pass's fork meets the first one's tail - must agree bit for bit: frames (SHA-256 of the whole batch) and the
+    fused observation."""
+    import hashlib
+    import os
+    import subprocess
+    import sys
+
+    from conftest import REPO
+
+    script = tmp_path / "lvl_run.py"
+    script.write_text(
+        "import sys, hashlib, numpy as np, torch\n"
+        f"sys.path.insert(0, {str(REPO)!r})\n"
+        "from tacex_amd.simulation_approaches.gpu_taxim.sim import Taxim\n"
+        "from tacex_amd.utils.synthetic import synthetic_depth_maps\n"
+        "B, H, W = 768, 240, 320\n"
+        f"t = Taxim(calib_folder={str(calib_dir)!r}, backend='hip', device='cuda:0')\n"
+        "out = torch.empty((B, H, W, 3), device='cuda:0')\n"
+        "obs = torch.empty((B, 32, 32, 3), dtype=torch.uint8, device='cuda:0')\n"
+        "hs = []\n"
+        "for seed in (1, 2):\n"
+        "    hm, ind = synthetic_depth_maps(B, H, W, seed=seed, device='cuda:0')\n"
+        "    t.render_direct(hm, False, ind, out=out, obs_out=obs)\n"
+        "    torch.cuda.synchronize()\n"
+        "    hs.append(hashlib.sha256(out.cpu().numpy().tobytes()).hexdigest())\n"
+        "    hs.append(hashlib.sha256(obs.cpu().numpy().tobytes()).hexdigest())\n"
+        "    hs.append(str(float(out.abs().sum())))\n"
+        "open(sys.argv[1], 'w').write('\\n'.join(hs))\n")
+    outs = {}
+    for n in ("1", "2"):
+        out = tmp_path / f"l{n}.txt"
+        r = subprocess.run([sys.executable, str(script), str(out)], env=dict(os.environ, TACEX_LEVEL_STREAMS=n), capture_output=True,
+                           text=True, timeout=900)
+        assert r.returncode == 0, r.stderr[-3000:]
+        outs[n] = out.read_text().split("\n")
+    assert outs["1"] == outs["2"], (outs["1"], outs["2"])
+    assert float(outs["2"][2]) > 0.0 and outs["2"][0] != outs["2"][3]  # real frames, and the two batches differ
+
+
 def test_no_shift_render_and_numpy_entry(taxim, calib_dir):
     """press_depth=None renders the height map as is (TT:188-189 skipped); render() takes NumPy (TT:166-171)."""
     from oracle.taxim_oracle import TaximOracle
