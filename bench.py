@@ -180,21 +180,30 @@ class Rig:
             self.fem.flush()  # the last step's hipEvent pair joins ms_log: entry k of the log IS step k
 
     def timed(self, steps, warmup, barrier=lambda: None, after_warmup=lambda: None):
+        import gc
+
         for i in range(warmup):
             self.step(i)
         self.finish()
         torch.cuda.synchronize()
         after_warmup()
-        barrier()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for i in range(steps):
-            self.step(warmup + i)
-        self.finish()
-        torch.cuda.synchronize()
-        barrier()
-        torch.cuda.synchronize()
-        return time.perf_counter() - t0
+        # (no cyclic-garbage collection inside the timed region, like timeit: a full collection of this process - torch's module graph -
+        #  stalls the enqueuing thread for 60-70 ms, measured as a "76 ms step" once per few hundred steps of scripts/fem_stress.py)
+        gc.collect()
+        gc.disable()
+        try:
+            barrier()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for i in range(steps):
+                self.step(warmup + i)
+            self.finish()
+            torch.cuda.synchronize()
+            barrier()
+            torch.cuda.synchronize()
+            return time.perf_counter() - t0
+        finally:
+            gc.enable()
 
 
 from tacex_amd.uipc.gelpad_scene import FemGelpad  # noqa: E402  (C4 / C5: the gelpad scene lives in the package, tests step it too)

@@ -364,7 +364,8 @@ int tacex_fem_set_contact(tacex_fem_ctx* ctx, const double* vertex_area_host, do
                           const double* indenters_dev);
 
 /* Coulomb friction of the gelpad surface against its env's indenter (US:103-124: enable_friction, default_friction_ratio,
- * eps_velocity), the IPC way (Li et al. 2020, eq. 18-20) with normal force and contact normal lagged per Newton iteration; the
+ * eps_velocity), the IPC way (Li et al. 2020, eq. 18-20) with normal force and contact normal lagged per time step - taken at the
+ * state the step starts from, the normal force capped by the contact reaction there (= the previous step's normal force); the
  * tangential sliding is measured from the positions the time step starts at and relative to the indenter's own displacement
  * since the previous tacex_fem_step (its positions are kept in the workspace), potential mu lam f0(|u|) smoothed below
  * eps_velocity * dt.  The displacement is the TRANSLATION of the indenter row (cx, cy, cz) between two steps: the caller may move

@@ -657,11 +657,12 @@ class FrictionModel:
     (x_n = positions the time step started from, disp = the indenter's own displacement since the previous step; u = tangential sliding
     relative to it) is a smooth function of x with gradient dt^2 mu lam (f1 / |u|) u and the positive semi-definite Hessian
     dt^2 mu lam [(f1 / |u|) (T - t t^T) + f1' t t^T], T = I - n n^T, t = u / |u| (both coefficients >= 0: no projection needed).
-    WHICH state the lag is taken from matters on this soft pad with its 10 GPa barrier: after the indenter has moved, the start
-    positions of the step - and every early Newton iterate - sit deep in the barrier, where lam is orders of magnitude above the
-    elastic forces (Newton directions of metres, PCG at its cap).  `fem_step` therefore solves the step in two phases: normal contact
-    alone until the Newton loop has converged, then the lag is taken from that BALANCED state and the loop continues with friction
-    (IPC's lagging iteration with the contact solve as its first pass).  eps = eps_velocity * dt."""
+    WHICH state the lag is taken from: the one the step starts from (`fem_step(friction_lag="start")`, the kernel's default) - IPC's lag
+    "from the previous time step".  After the indenter has moved that state sits deep in the 10 GPa barrier, where -dB/dd is orders of
+    magnitude above the elastic forces (Newton directions of metres, PCG at its cap) - the reason rounds 3-4 solved the step in two
+    phases (`friction_lag="converged"`: normal contact alone until converged, then the lag from that balanced state and a friction
+    phase); `update` however takes the smaller of -dB/dd and the contact reaction, and at the start state - the previous step's
+    equilibrium - that reaction IS the previous normal force.  eps = eps_velocity * dt."""
 
     def __init__(self, cm: ContactModel, x_n, disp, mu, eps_velocity):
         self.cm, self.dt, self.mu, self.eps = cm, cm.dt, float(mu), float(eps_velocity) * cm.dt
@@ -777,7 +778,8 @@ def newton_step_contact(m: "FemModel", cm: ContactModel, x, x_tilde, constrained
 
 
 def fem_step(m: "FemModel", cm, x, v, constrained=None, aim=None, gravity=(0.0, 0.0, -9.8), max_newton=8, velocity_tol=0.05,
-             pcg_max_iter=1024, pcg_tol_rate=1e-3, ls_max_iter=8, coarse=None, friction=None, chains=None, indenter_disp=None, lag_prec=True):
+             pcg_max_iter=1024, pcg_tol_rate=1e-3, ls_max_iter=8, coarse=None, friction=None, chains=None, indenter_disp=None, lag_prec=True,
+             friction_lag="start"):
     """One backward-Euler step of ONE env the way `tacex_fem_step` runs it (what world.advance() does, US:250-252):
     x_tilde = x + dt v + dt^2 g; Newton iterations until the UNSCALED Newton direction of one has max |d| <= velocity_tol * dt
     (US:62-66; IPC's test on the search direction) or the cap; v = (x_new - x) / dt.  Returns (x_new, v_new, info) with
@@ -798,9 +800,17 @@ def fem_step(m: "FemModel", cm, x, v, constrained=None, aim=None, gravity=(0.0, 
         dm, _ = contact_distance(cm.ind, np.where(cand[:, None], xm, x), cm.mesh)
         follow = cand & (dm > 0) & (dm < cm.dhat)
         x = np.where(follow[:, None], xm, x)
-    # friction = (mu, eps_velocity, indenter displacement since the previous step): second phase, see FrictionModel
-    fric_pending = friction is not None and cm is not None
+    # friction = (mu, eps_velocity, indenter displacement since the previous step), see FrictionModel.  friction_lag = "start" (the
+    # kernel's default): normal force and normal are lagged at the state the step starts from - the previous step's equilibrium, IPC's
+    # lag "from the previous time step" - and friction acts from the first iteration on; "converged" (rounds 3-4, TACEX_FEM_FRIC_LAG=0):
+    # the lag is taken where this step's normal-contact solve converged, in a second phase of the loop
+    fric_pending = friction is not None and cm is not None and friction_lag != "start"
     fr = None
+    if friction is not None and cm is not None and friction_lag == "start":
+        fr = FrictionModel(cm, x0, friction[2], friction[0], friction[1])
+        fr.update(x, m.gradient(x, xt, constrained, aim))
+        if not fr.lam.max() > 0.0:
+            fr = None  # no vertex carries a normal force: this step runs without friction
     n, flags, pcg, dmax = 0, 0, 0, np.inf
     d0 = None
     # the elastic preconditioner blocks of the whole step are those of its first iteration (see newton_step_contact); lag_prec=False:

@@ -236,11 +236,14 @@ __device__ __forceinline__ ContactEval contact_eval(const FemDev& m, const doubl
 }
 // ---- lagged Coulomb friction of one surface vertex (IPC, Li et al. 2020 eq. 18-20; US:103-124 enable_friction / friction ratio /
 // eps_velocity).  Normal force lam = -dB/dd and contact normal n are LAGGED (frozen), which makes the potential a smooth function of
-// x.  The state the lag is taken from must be a balanced one: after the indenter has moved, the step's start positions and every
-// early Newton iterate sit deep in the 10 GPa barrier, where lam is orders of magnitude above the elastic forces of the soft pad
-// (Newton directions of metres, PCG at its cap).  The Newton loop therefore runs in TWO PHASES: normal contact alone until it has
-// converged, then lam / n are frozen at that state and the loop goes on with friction (IPC's lagging iteration with the contact
-// solve as its first pass); an env without an active contact skips the second phase.  u = (I - n n^T)(x - x_n - disp) is the tangential sliding relative to the indenter (x_n = positions the step
+// x.  WHERE the lag is taken: the state the step starts from (the default since round 4, `lag_at_start` in fem_newton_lds_kernel) - IPC's
+// lag "from the previous time step".  After the indenter has moved, that state sits deep in the 10 GPa barrier, where -dB/dd is orders of
+// magnitude above the elastic forces of the soft pad (Newton directions of metres, PCG at its cap: why rounds 3-4 ran the loop in TWO
+// PHASES - normal contact alone until converged, then the lag from that state and a friction phase); but the lag takes the SMALLER of
+// -dB/dd and the contact REACTION (g_other . n) / dt^2, and at the start state - the previous step's equilibrium - that reaction is the
+// previous step's normal force.  With the cap the start-of-step lag is well behaved, and the step saves the iteration the second phase
+// cost (a pressing step is one Newton iteration instead of two).  TACEX_FEM_FRIC_LAG=0 keeps the two-phase loop for the A/B.
+// u = (I - n n^T)(x - x_n - disp) is the tangential sliding relative to the indenter (x_n = positions the step
 // started from, disp = the indenter's own displacement since the previous step).  Potential mu lam f0(|u|), f0(y) = -y^3 / (3 eps^2) + y^2 / eps + eps / 3 below the stick
 // tolerance eps, y beyond; gradient mu lam (f1 / y) u; Hessian mu lam [(f1 / y)(T - t t^T) + f1' t t^T] (both coefficients >= 0).
 struct FricVertex {  // what a vertex keeps in LDS for the step: lam, n (4 doubles)
@@ -1172,7 +1175,7 @@ __global__ __launch_bounds__(NT) void fem_newton_lds_kernel(FemDev m, double* xg
     // launch waits for them) against 2 iterations of 2 while the indenter presses.  Where the indenter APPROACHES (disp . n >= 0)
     // nothing is moved: the shrunken gap raises the barrier force and that start already converges in two iterations (following
     // there was measured: the over-displaced surface has to come back up into the barrier and line searches fail).
-    if (follow && ind && wv > 0.0 && (disp3[0] != 0.0 || disp3[1] != 0.0 || disp3[2] != 0.0)) {
+    if ((follow & 1) && ind && wv > 0.0 && (disp3[0] != 0.0 || disp3[1] != 0.0 || disp3[2] != 0.0)) {
       const ContactEval c0 = contact_eval<MESH>(m, ind, wv, x3);
       const double dn = disp3[0] * c0.n[0] + disp3[1] * c0.n[1] + disp3[2] * c0.n[2];
       if (dn < 0.0 && !c0.penetrating && c0.d < 1e299) {
@@ -1346,8 +1349,14 @@ __global__ __launch_bounds__(NT) void fem_newton_lds_kernel(FemDev m, double* xg
   // warm start of the next iteration's PCG: the part of this iteration's Newton direction the CCD filter / the line search cut off
   double dprev[3] = {0, 0, 0};
   double frac_prev = 0.0;  // (1 - accepted step) of the previous iteration, 0 when it was taken in full or rejected
-  bool fric_phase = false;  // friction terms are on (second phase of the loop, see friction_eval)
-  bool lag_pending = false; // the friction lag is taken in the iteration that follows the converged normal-contact solve (see below)
+  // FRICTION LAG AT THE START OF THE STEP (`follow` bit 1, the default): normal force and normal are taken in the FIRST iteration, at the
+  // state the step starts from - IPC's lag "from the previous time step" (Li et al. 2020, section 5.4): that state is the previous step's
+  // equilibrium, whose contact reaction is the previous normal force - and friction acts from the first iteration on.  Bit clear: the lag is
+  // taken where the normal-contact solve of THIS step converged, in an iteration of its own (rounds 3-4: one more Newton iteration per step
+  // with contact - a pressing step is two iterations instead of one).
+  const bool lag_at_start = (follow & 2) != 0;
+  bool fric_phase = fric && lag_at_start;   // friction terms are on (see friction_eval)
+  bool lag_pending = fric && lag_at_start;  // the friction lag is taken in this iteration (behind the gradient and the contact evaluation)
   bool lag_valid = false;  // the workspace holds the elastic preconditioner blocks of this launch
   bool use_coarse = m.nc > 0;  // (block-uniform) false once the safeguard of kCoarseTrust has fired
   bool psd_safe = false;       // (block-uniform) see kFemFlagPsdSafe
@@ -1417,7 +1426,10 @@ restart_iteration:
       fl[tid * 4] = on ? lam : 0.0;
       fl[tid * 4 + 1] = on ? ce.n[0] : 0.0; fl[tid * 4 + 2] = on ? ce.n[1] : 0.0; fl[tid * 4 + 3] = on ? ce.n[2] : 0.0;
     }
-    if (!__syncthreads_or(lam > 0.0)) { done = true; break; }  // no vertex carries a normal force: nothing for friction to act on
+    if (!__syncthreads_or(lam > 0.0)) {  // no vertex carries a normal force: nothing for friction to act on
+      if (!lag_at_start) { done = true; break; }  // (two-phase mode: normal contact had converged, the step is done)
+      fric_phase = false;                         // (lag at the start: this step runs without friction)
+    }
   }
   // friction of this vertex at x: gradient into the residual, Hessian block into LDS (read back by H.p and the preconditioner)
   if (fric_phase && own) {
@@ -1994,9 +2006,9 @@ restart_iteration:
   }
   const bool converged = dmax <= dx_tol;
   if (converged) {  // wave-uniform: every quantity above is a block reduction
-    if (fric && !fric_phase) {
-      // normal contact is balanced: freeze the friction lag (normal force, normal) at this state and go on, unless no vertex of
-      // the env is in contact
+    if (fric && !fric_phase && !lag_at_start) {
+      // (two-phase mode) normal contact is balanced: freeze the friction lag (normal force, normal) at this state and go on, unless
+      // no vertex of the env is in contact
       fric_phase = true;
       bool touching = false;
       if (own) {
@@ -2621,6 +2633,7 @@ static int launch_newton(tacex_fem_ctx* c, double* x, const double* xt, const ui
   const bool mesh = c->dev.indenters && c->dev.im_nt > 0;  // the mesh-capable instantiation only when a mesh indenter exists
   static const int env_atomic = getenv("TACEX_FEM_ATOMIC") ? atoi(getenv("TACEX_FEM_ATOMIC")) : 1;  // A/B hook
   const bool atom = env_atomic != 0 && !c->deterministic;
+  static const int fric_lag_at_start = getenv("TACEX_FEM_FRIC_LAG") ? atoi(getenv("TACEX_FEM_FRIC_LAG")) : 1;  // A/B hook: 0 = lag where this step's normal contact converged
   // threads per env: one per vertex, in steps of four waves (nwt_window_doubles); the wide variants are atomic-only and take analytic
   // indenters only (a mesh indenter or the deterministic switch on a mesh of more than 512 vertices: streaming kernel below)
   const int V = c->dev.V;
@@ -2645,7 +2658,7 @@ static int launch_newton(tacex_fem_ctx* c, double* x, const double* xt, const ui
     if (ea != hipSuccess) return fail_hip(ea, "hipFuncSetAttribute(fem_newton_lds_kernel)");
     hipLaunchKernelGGL(kern, dim3(B), dim3(nt), lds, st, c->dev_nwt, x, xt, cons, aim, stats, pcg_max_iter,
                        pcg_tol_rate, ls_max_iter, dx_dev, dx_tol, max_newton, step_info, fric ? xprev : nullptr,
-                       (xprev && disp && c->dev.indenters) ? disp : nullptr, env_order, c->follow_indenter ? 1 : 0,
+                       (xprev && disp && c->dev.indenters) ? disp : nullptr, env_order, (c->follow_indenter ? 1 : 0) | (fric_lag_at_start ? 2 : 0),
                        max_newton > 1 ? static_cast<double*>(ws) : nullptr);  // env blocks of the workspace: (15, V) lagged blocks per env
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : fail_hip(e, "fem_newton_lds_kernel");

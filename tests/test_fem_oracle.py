@@ -581,3 +581,43 @@ def test_fem_step_on_the_bent_axle_uses_psd_safe_mode_and_converges(meshes):
     assert int(io[2]) & 8 and int(io[2]) & 3 == 0 and io[0] < 40 and io[1] <= 2e-3 * m.dt, io
     assert np.isfinite(x).all() and (np.linalg.det(m.deformation_gradient(x)) > 0.2).all()  # no inverted or crushed element
     assert 2e-4 < (P[:, 2] - x[:, 2]).max() < 1.5e-3  # the rod gives way by about the depth the sphere reached into the barrier zone
+
+
+def test_friction_lag_at_the_start_of_the_step_saves_the_second_phase_and_lands_on_the_same_states():
+    """`fem_step(friction_lag="start")` (the kernel's default): the friction lag - normal force capped by the contact reaction, normal -
+    is taken at the state the step starts from (IPC's lag from the previous time step) and friction acts from the first iteration on;
+    "converged" (rounds 3-4) takes it where this step's normal-contact solve converged, in a second phase.  A sphere pressed into a small
+    pad and dragged sideways: both lags drag the surface along (against a frictionless run), by amounts that agree to a few per cent -
+    the lag is one step older - and the start-of-step lag needs fewer Newton iterations."""
+    from oracle.fem_oracle import ContactModel, contact_distance, fem_step
+    from tacex_amd.uipc.uipc_object import UipcObject, UipcObjectCfg, gelpad_box_mesh
+
+    P, T = gelpad_box_mesh(4, 5, 2)
+    m = FemModel.build(P, T, youngs=1e5, poisson=0.45, density=1e3, dt=0.01, strength=1000.0)
+    cons = (P[:, 2] < 1e-12).astype(np.float64)
+    area = UipcObject(UipcObjectCfg(mesh_points=P, mesh_tets=m.tets), None).surface_vertex_areas()
+    top, size = P[:, 2].max(), P.max(0)
+    res = {}
+    for lag in ("start", "converged", None):
+        ind = np.array([1.0, size[0] / 2, size[1] / 2, top + 0.004 + 0.0009, 0.004, 0, 0, 0])
+        cm = ContactModel(area, ind, 1e-3, 1e7, m.dt)
+        x, v, prev, iters = P.copy(), np.zeros_like(P), None, 0
+        for k in range(8):
+            gap = contact_distance(cm.ind, x)[0][area > 0].min()
+            if k < 4:
+                cm.ind[3] -= 0.3 * gap
+            else:
+                cm.ind[1] += 4e-5
+            cur = cm.ind[1:4].copy()
+            disp = cur - prev if prev is not None else np.zeros(3)
+            prev = cur
+            x, v, info = fem_step(m, cm, x, v, cons, P, max_newton=40, velocity_tol=1e-3, pcg_max_iter=400, pcg_tol_rate=1e-6,
+                                  friction=None if lag is None else (0.5, 0.01, disp), **({} if lag is None else {"friction_lag": lag}))
+            assert int(info[2]) & 3 == 0 and info[0] < 40, (lag, k, info)
+            iters += int(info[0])
+        near = (P[:, 2] > top - 1e-9) & (np.hypot(P[:, 0] - cur[0], P[:, 1] - cur[1]) < 0.004)
+        res[lag] = (float((x[near, 0] - P[near, 0]).mean()), iters)
+    drag_s, drag_c, drag_0 = res["start"][0], res["converged"][0], res[None][0]
+    assert drag_s > 2e-5 and drag_c > 2e-5 and drag_0 < 0.5 * min(drag_s, drag_c), res  # friction drags the surface along (without it the dent's slope pushes it back)
+    assert abs(drag_s - drag_c) <= 0.1 * drag_c, res                                            # ... by nearly the same amount
+    assert res["start"][1] < res["converged"][1], res                                          # ... in fewer iterations
