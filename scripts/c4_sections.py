@@ -18,7 +18,7 @@ for i in range(24, 24 + N):
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(6)]
     ev[0].record()
     # scene driver (copied from FemGelpad._step)
-    fem._pos[:, 0].fill_(float(fem.body[0]) + 0.0002 * math.sin(0.2 * i))
+    fem._pos[:, 0].fill_(fem._body_x + 0.0002 * math.sin(0.2 * i))
     fem.att.apply(fem.sim, fem._pos, fem._quat32)
     gap = fem.sim.contact_gaps().amin(1)
     c = 0.5 - 0.5 * math.cos(0.3 * i)

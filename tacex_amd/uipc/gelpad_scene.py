@@ -46,6 +46,7 @@ class FemGelpad:
         self.att = UipcIsaacAttachments(UipcIsaacAttachmentsCfg(constraint_strength_ratio=1000.0), self.gelpad,
                                         rigid_collider=("box", (size[0] / 2 + 1e-6, size[1] / 2 + 1e-6, 0.001)), rigid_pos=body)
         self.body = torch.from_numpy(body).to(dev)
+        self._body_x = float(body[0])  # (host copy: reading the device tensor per step was a device-to-host sync in the middle of the step's enqueue)
         self.quat = torch.zeros((B, 4), device=dev, dtype=torch.float64)
         self.quat[:, 0] = 1.0
         self._pos = self.body[None].repeat(B, 1).to(torch.float32).contiguous()   # per-env case position, float32 like the attachment kernel's input
@@ -85,7 +86,7 @@ class FemGelpad:
         self.ev[0].record()
         # (the scene driver stands in for the rigid-body simulator: kept to a handful of launches - fill, attachment kernel, gap kernel +
         #  reduction, three element-wise ops - so that it does not weigh on the FEM step it is timed with)
-        self._pos[:, 0].fill_(float(self.body[0]) + 0.0002 * math.sin(0.2 * i))  # the case shears the pad a little
+        self._pos[:, 0].fill_(self._body_x + 0.0002 * math.sin(0.2 * i))  # the case shears the pad a little
         self.att.apply(self.sim, self._pos, self._quat32)  # compute_aim_positions -> is_constrained / aim_position (UA:364-428)
         # the indenter follows its breathing trajectory, but never moves more than half the current gap towards the pad
         # (what a CCD-filtered rigid-body step would allow); all on the device, no host round trip
