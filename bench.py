@@ -385,6 +385,12 @@ def sweep(args, dev):
         steps = steps or args.sweep_steps
         log(f"sweep: {label}")
         try:
+            # (every entry starts from a collected heap and an empty allocator cache: the previous entry's rig is garbage with
+            #  reference cycles, and its buffers are gigabytes)
+            import gc
+            gc.collect()
+            torch.cuda.synchronize()
+            torch.cuda.empty_cache()
             if callable(fem):
                 fem = fem()
             rig = Rig(B, H, W, n_sensors, markers, dev, 1, seed=7, gather=gather or args.gather, obs_dtype=args.obs_dtype, fem=fem, **rig_kw)
@@ -398,7 +404,7 @@ def sweep(args, dev):
             base = []
             if fem is not None:  # solver statistics over the timed period: device-side sums, the warm-up's share is subtracted
                 fem.info_sum = torch.zeros(4, dtype=torch.float64, device=dev)
-            el = rig.timed(steps, 24 if fem is not None else 3, after_warmup=lambda: base.append(fem.info_sum.clone()) if fem is not None else None)
+            el = rig.timed(steps, 24 if fem is not None else 8, after_warmup=lambda: base.append(fem.info_sum.clone()) if fem is not None else None)
             frames = B * n_sensors * steps
             e = {"workload": label, "frames_per_step": B * n_sensors, "steps": steps, "ms_per_step": round(el / steps * 1e3, 4),
                  "frames_per_s": round(frames / el, 1)}
