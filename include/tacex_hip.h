@@ -426,7 +426,8 @@ int tacex_fem_set_chains(tacex_fem_ctx* ctx, int num_chains, const int32_t* chai
 int tacex_fem_set_newton_early_exit(tacex_fem_ctx* ctx, double* dx_dev, double dx_tol);
 
 /* One projected-Newton iteration per env: assemble (block-Jacobi + coarse-grid preconditioned, tacex_fem_set_coarse_space) system, matrix-free PCG
- * (US:70-72 tol_rate), backtracking line search on the energy (US:76: max_iter 8; when the capped search finds no decrease
+ * (US:70-72 tol_rate: the PCG stops when r^T M^-1 r <= tol_rate x b^T M^-1 b - libuipc's own test, LinearPCG::pcg `abs(rz_new) <=
+ * global_tol_rate * rz0`: relative on r.z itself, i.e. sqrt(tol_rate) on the M^-1 norm), backtracking line search on the energy (US:76: max_iter 8; when the capped search finds no decrease
  * the step is halved further, down to 2^-32, instead of leaving the env stuck).  x_dev is updated in place.
  * stats_dev (B,4) float64 = [energy_before, energy_after, step_length, pcg_iterations]. */
 int tacex_fem_newton_step(tacex_fem_ctx* ctx, double* x_dev, const double* x_tilde_dev,
@@ -448,7 +449,7 @@ int tacex_fem_newton_step(tacex_fem_ctx* ctx, double* x_dev, const double* x_til
  * kernel; zeros from the fallback), flags: 1 = a contact vertex was at or beyond its indenter's surface when an iteration started
  * (the caller moved the indenter by more than the gap: that vertex gets no restoring force), 2 = a line search found no decrease;
  * informational: 4 = the env dropped the coarse correction for the rest of the step (its stopping test passed with the residual's
- * 2-norm above 0.1 |b|), 8 = its PCG met negative curvature and iterations of the step were solved with the PSD-safe Hessian
+ * 2-norm above |b|: no reduction at all), 8 = its PCG met negative curvature and iterations of the step were solved with the PSD-safe Hessian
  * (|c_J| of the Stable Neo-Hookean d2J/dF2 term clamped per element; the gradient is exact, the minimiser the same).
  * workspace_dev: tacex_fem_workspace_bytes(ctx, num_envs). */
 int tacex_fem_step(tacex_fem_ctx* ctx, double* x_dev, double* v_dev, double* x_tilde_dev, const uint8_t* constrained_dev,

@@ -74,12 +74,14 @@ LS_RESCUE = 32
 # Safeguard of the coarse correction (kCoarseTrust of csrc/fem_kernels.hip): the PCG's stopping test is in the M^-1 norm, and M^-1
 # contains the REST-state coarse operator - blind to the barrier / friction stiffness of the current contacts.  Where the coarse
 # space holds nearly free modes (simple_axle held at its ends) the test passes with the residual's 2-norm above that of b; if it is
-# above COARSE_TRUST |b| at exit, the coarse part is dropped for the rest of the time step and the iteration's solve starts over.
-COARSE_TRUST = 0.1
+# above COARSE_TRUST |b| at exit (no reduction at all), the coarse part is dropped for the rest of the time step and the iteration's solve starts over.
+COARSE_TRUST = 1.0
 
 
 def pcg_solve(hv, prec, b, max_iter, tol_rate, d0=None, info=None):
-    """Preconditioned CG on H d = b as the Newton kernels run it: stops when r^T M^-1 r <= tol_rate^2 b^T M^-1 b (or at max_iter), keeps
+    """Preconditioned CG on H d = b as the Newton kernels run it: stops when r^T M^-1 r <= tol_rate * b^T M^-1 b (or at max_iter) - libuipc's
+    test (LinearPCG::pcg in src/backends/cuda/linear_system/linear_pcg.cu: `abs(rz_new) <= global_tol_rate * rz0`; relative on r.z itself,
+    i.e. sqrt(tol_rate) on the M^-1 norm of the residual; source absent here, restated from the public repository) - and keeps
     what it has on negative curvature (first iteration from a zero start: the preconditioned steepest-descent direction).  `d0`: warm
     start (the part of the previous Newton direction that the CCD filter / the line search cut off).  Returns (d, iterations);
     `info` (a dict) receives "res_ratio" = |r|^2 / |b|^2 of the recurrence residual at exit (None after a negative-curvature exit)."""
@@ -95,7 +97,7 @@ def pcg_solve(hv, prec, b, max_iter, tol_rate, d0=None, info=None):
     rz = (r * z).sum()
     it = 0
     neg_curv = False
-    while it < max_iter and rz_b > 0 and rz > tol_rate**2 * rz_b:
+    while it < max_iter and rz_b > 0 and rz > tol_rate * rz_b:
         Hp = hv(p)
         pHp = (p * Hp).sum()
         if pHp <= 0:

@@ -46,6 +46,8 @@ class UipcSimCfg:
     class LinearSystem:
         solver: str = "linear_pcg"
         tol_rate: float = 1e-3
+        """The PCG of a Newton iteration stops when r^T M^-1 r <= tol_rate x its value for the right-hand side - libuipc's test (`LinearPCG::pcg`:
+        `abs(rz_new) <= global_tol_rate * rz0`), relative on r.z itself: sqrt(tol_rate) = 0.032 on the M^-1 norm of the residual."""
         max_iter: int = 1024
         """PCG iteration cap (not in the reference cfg, uipc_sim.py:86-90: libuipc stops on `tol_rate`); only guards against stagnation."""
         deterministic: bool = False

@@ -90,7 +90,7 @@ def test_newton_step_vs_oracle_and_monotone():
     top = np.where(P[:, 2] > P[:, 2].max() - 1e-9)[0]
     sim = _sim(P, Tt, B)
     sim.cfg.linear_system.max_iter = 200
-    sim.cfg.linear_system.tol_rate = 1e-4
+    sim.cfg.linear_system.tol_rate = 1e-8
     depths = [0.0004, 0.0008, 0.0012]
     aim = torch.from_numpy(P[top]).cuda()[None].repeat(B, 1, 1)
     for b, d in enumerate(depths):
@@ -109,7 +109,7 @@ def test_newton_step_vs_oracle_and_monotone():
         E_prev = st[:, 1]
         for b in range(B):
             aim_b = P.copy(); aim_b[top, 2] -= depths[b]
-            xo[b], so = m.newton_step(xo[b], xt, cons, aim_b, pcg_max_iter=200, pcg_tol_rate=1e-4)
+            xo[b], so = m.newton_step(xo[b], xt, cons, aim_b, pcg_max_iter=200, pcg_tol_rate=1e-8)
             assert abs(st[b, 0] - so[0]) <= 1e-8 * abs(so[0]) + 1e-20, (it, b)
             assert abs(st[b, 1] - so[1]) <= 1e-6 * abs(so[1]) + 1e-20, (it, b)
             if so[0] - so[1] > 1e-7 * abs(so[0]):  # at convergence accept/reject is decided by roundoff
@@ -295,7 +295,7 @@ def test_attachment_chain_aim_set_constraints_step_vs_oracle():
     sim.cfg.linear_system.vertex_chains = None
     gel = UipcObject(UipcObjectCfg(mesh_points=P, mesh_tets=Tt), sim)
     sim.setup_sim(constraint_strength_ratio=100.0)
-    sim.cfg.linear_system.max_iter, sim.cfg.linear_system.tol_rate = 200, 1e-4
+    sim.cfg.linear_system.max_iter, sim.cfg.linear_system.tol_rate = 200, 1e-8
     # the "sensor case": a box collider hugging the back face (z = 0) of the gelpad, body frame at its centre
     size = P.max(0) - P.min(0)
     body_pos0 = np.array([size[0] / 2, size[1] / 2, -0.001])
@@ -331,7 +331,7 @@ def test_attachment_chain_aim_set_constraints_step_vs_oracle():
         aim_b[att.attachment_points_idx] = aim.cpu().numpy()[b]
         xo = P.copy()
         for _ in range(3):
-            xo, _ = m.newton_step(xo, xt, c, aim_b, pcg_max_iter=200, pcg_tol_rate=1e-4)
+            xo, _ = m.newton_step(xo, xt, c, aim_b, pcg_max_iter=200, pcg_tol_rate=1e-8)
         assert np.abs(x[b] - xo).max() <= 1e-6 * np.ptp(P), b
     # and through the public step(): the attached face follows its body, envs differ
     sim.x.copy_(x_n)
@@ -408,7 +408,7 @@ def test_contact_newton_step_vs_oracle_and_no_penetration():
     from oracle.fem_oracle import ContactModel, newton_step_contact
 
     sim, gel, m, P, back, ind = _contact_setup(B=2)
-    sim.cfg.linear_system.max_iter, sim.cfg.linear_system.tol_rate = 300, 1e-5
+    sim.cfg.linear_system.max_iter, sim.cfg.linear_system.tol_rate = 300, 1e-10
     area = gel.surface_vertex_areas()
     dhat = sim.cfg.contact.d_hat
     kappa = sim.cfg.contact.default_contact_resistance * 1e9 * dhat
@@ -426,7 +426,7 @@ def test_contact_newton_step_vs_oracle_and_no_penetration():
             assert float(sim.contact_gaps().amin()) > 0.0, "a vertex crossed the indenter surface"
             for b in range(2):
                 cm = ContactModel(area, ind[b], dhat, kappa, sim.cfg.dt)
-                xo[b], so = newton_step_contact(m, cm, xo[b], P, cons, P, pcg_max_iter=300, pcg_tol_rate=1e-5)
+                xo[b], so = newton_step_contact(m, cm, xo[b], P, cons, P, pcg_max_iter=300, pcg_tol_rate=1e-10)
                 assert abs(st[b, 0] - so[0]) <= 1e-7 * abs(so[0]) + 1e-18, (move, it, b, st[b], so)
                 assert abs(st[b, 1] - so[1]) <= 1e-5 * abs(so[1]) + 1e-18, (move, it, b, st[b], so)
     x = sim.x.cpu().numpy()
@@ -484,13 +484,13 @@ def test_newton_step_c4_mesh_vs_oracle():
 
     B = 2
     sim, m, P, cons, aim, cms = _c4_scene(B)
-    sim.cfg.linear_system.max_iter, sim.cfg.linear_system.tol_rate = 600, 1e-6
+    sim.cfg.linear_system.max_iter, sim.cfg.linear_system.tol_rate = 600, 1e-12
     sim.x_tilde = sim.x.clone()
     xo = [P.copy() for _ in range(B)]
     for it in range(2):
         st = sim.newton_step().cpu().numpy().copy()
         for b in range(B):
-            xo[b], so = newton_step_contact(m, cms[b], xo[b], P, cons, aim[b], pcg_max_iter=600, pcg_tol_rate=1e-6, coarse=sim.coarse_space, chains=_chains(sim))
+            xo[b], so = newton_step_contact(m, cms[b], xo[b], P, cons, aim[b], pcg_max_iter=600, pcg_tol_rate=1e-12, coarse=sim.coarse_space, chains=_chains(sim))
             assert abs(st[b, 0] - so[0]) <= 1e-6 * abs(so[0]) + 1e-20, (it, b, st[b], so)
             assert abs(st[b, 1] - so[1]) <= 1e-5 * abs(so[1]) + 1e-20, (it, b, st[b], so)
             assert st[b, 2] == so[2], (it, b, st[b], so)
@@ -512,7 +512,7 @@ def test_step_c4_vs_oracle_step_and_convergence_rule():
     B = 2
     sim, m, P, cons, aim, cms = _c4_scene(B)
     sim.cfg.newton.velocity_tol = 2e-3  # [m/s]: 20 um per step - tight enough to need several iterations
-    sim.cfg.linear_system.max_iter, sim.cfg.linear_system.tol_rate = 600, 1e-6
+    sim.cfg.linear_system.max_iter, sim.cfg.linear_system.tol_rate = 600, 1e-12
     xo = [P.copy() for _ in range(B)]
     vo = [np.zeros_like(P) for _ in range(B)]
     ind = sim.contact_indenters
@@ -535,7 +535,7 @@ def test_step_c4_vs_oracle_step_and_convergence_rule():
         x, v = sim.x.cpu().numpy(), sim.v.cpu().numpy()
         for b in range(B):
             xo[b], vo[b], io = fem_step(m, cms[b], xo[b], vo[b], cons, aim[b], gravity=sim.cfg.gravity, max_newton=24,
-                                        velocity_tol=2e-3, pcg_max_iter=600, pcg_tol_rate=1e-6, coarse=sim.coarse_space, chains=_chains(sim),
+                                        velocity_tol=2e-3, pcg_max_iter=600, pcg_tol_rate=1e-12, coarse=sim.coarse_space, chains=_chains(sim),
                                         friction=(fric[0], fric[1], disp[b]))
             # same iteration count (a convergence test that falls within round-off of its threshold may differ by one iteration);
             # both stop inside the Newton tolerance of 20 um and their PCG round-off differs by ~0.1 um
@@ -654,7 +654,7 @@ def test_friction_drags_the_pad_surface():
         sim.cfg.contact.default_friction_ratio = mu
         sim.cfg.contact.enable_friction = mu > 0
         sim.cfg.newton.velocity_tol = 1e-3
-        sim.cfg.linear_system.max_iter, sim.cfg.linear_system.tol_rate = 600, 1e-6
+        sim.cfg.linear_system.max_iter, sim.cfg.linear_system.tol_rate = 600, 1e-12
         sim.set_contact_indenters(sim.contact_indenters)  # re-reads the friction settings
         ind = sim.contact_indenters
         xo, vo = P.copy(), np.zeros_like(P)
@@ -676,7 +676,7 @@ def test_friction_drags_the_pad_surface():
             assert len(info["penetrating_envs"]) == 0 and len(info["line_search_failed_envs"]) == 0 and int(sim.last_newton_iters) < 60
             if mu > 0:
                 xo, vo, io = fem_step(m, cms[0], xo, vo, cons, aim[0], gravity=sim.cfg.gravity, max_newton=60, velocity_tol=1e-3, pcg_max_iter=600,
-                                      pcg_tol_rate=1e-6, coarse=sim.coarse_space, chains=_chains(sim), friction=(mu, sim.cfg.contact.eps_velocity, disp))
+                                      pcg_tol_rate=1e-12, coarse=sim.coarse_space, chains=_chains(sim), friction=(mu, sim.cfg.contact.eps_velocity, disp))
                 assert io[0] < 60 and int(io[2]) & 3 == 0
                 assert np.abs(sim.x[0].cpu().numpy() - xo).max() <= 2 * 1e-3 * sim.cfg.dt, k  # both inside the Newton tolerance of the same state
         x = sim.x[0].cpu().numpy()
@@ -726,14 +726,14 @@ def test_mesh_indenter_vs_oracle_and_analytic_sphere():
     sim.set_contact_indenters(torch.from_numpy(ind))
     kappa = sim.cfg.contact.default_contact_resistance * 1e9 * sim.cfg.contact.d_hat
     cmm = [ContactModel(area, ind[b].copy(), sim.cfg.contact.d_hat, kappa, sim.cfg.dt, mesh=(sv, st)) for b in range(B)]
-    sim.cfg.linear_system.max_iter, sim.cfg.linear_system.tol_rate = 600, 1e-6
+    sim.cfg.linear_system.max_iter, sim.cfg.linear_system.tol_rate = 600, 1e-12
     sim.x_tilde = sim.x.clone()
     xo = [P.copy() for _ in range(B)]
     for it in range(2):
         stt = sim.newton_step().cpu().numpy().copy()
         x = sim.x.cpu().numpy()
         for b in range(B):
-            xo[b], so = newton_step_contact(m, cmm[b], xo[b], P, cons, aim[b], pcg_max_iter=600, pcg_tol_rate=1e-6, coarse=sim.coarse_space, chains=_chains(sim))
+            xo[b], so = newton_step_contact(m, cmm[b], xo[b], P, cons, aim[b], pcg_max_iter=600, pcg_tol_rate=1e-12, coarse=sim.coarse_space, chains=_chains(sim))
             assert abs(stt[b, 0] - so[0]) <= 1e-6 * abs(so[0]) + 1e-18 and abs(stt[b, 1] - so[1]) <= 1e-5 * abs(so[1]) + 1e-18, (it, b, stt[b], so)
             assert stt[b, 2] == so[2] and abs(stt[b, 3] - so[3]) <= 2, (it, b, stt[b], so)
             assert np.abs(x[b] - xo[b]).max() <= 1e-6 * np.ptp(P), (it, b)
@@ -743,6 +743,10 @@ def test_mesh_indenter_vs_oracle_and_analytic_sphere():
     for kind in (4, 1):
         s2, _, _, _, _, _ = _c4_scene(1)
         s2.cfg.contact.enable_friction = False
+        # (both runs solved well inside the 10 % the comparison allows: the default tolerances - 0.5 mm per step on the Newton direction,
+        #  1e-3 on r.z in the PCG - are looser than the difference between a faceted and a smooth sphere)
+        s2.cfg.newton.velocity_tol = 2e-3
+        s2.cfg.linear_system.tol_rate = 1e-8
         if kind == 4:
             s2.set_indenter_mesh(*icosphere(0.004, 3))
         row = np.array([[float(kind), size[0] / 2, size[1] / 2, top + 0.004 + 0.0009, 0.004 if kind == 1 else 0.0, 0, 0, 0]])
@@ -868,7 +872,7 @@ def test_contact_following_start_is_only_an_initial_guess_and_tames_the_retreat(
         sim.cfg.contact.follow_indenter = follow
         sim.cfg.contact.enable_friction = False
         sim.cfg.newton.velocity_tol = 1e-3
-        sim.cfg.linear_system.max_iter, sim.cfg.linear_system.tol_rate = 600, 1e-6
+        sim.cfg.linear_system.max_iter, sim.cfg.linear_system.tol_rate = 600, 1e-12
         sim.set_contact_indenters(sim.contact_indenters)
         ind = sim.contact_indenters
         xo, vo = P.copy(), np.zeros_like(P)
@@ -890,7 +894,7 @@ def test_contact_following_start_is_only_an_initial_guess_and_tames_the_retreat(
                 its.append(int(info["newton_iters"][0])); pcg.append(int(info["pcg_iters"][0]))
             if follow:
                 xo, vo, io = fem_step(m, cms[0], xo, vo, cons, aim[0], gravity=sim.cfg.gravity, max_newton=80, velocity_tol=1e-3, pcg_max_iter=600,
-                                      pcg_tol_rate=1e-6, coarse=sim.coarse_space, chains=_chains(sim), indenter_disp=disp)
+                                      pcg_tol_rate=1e-12, coarse=sim.coarse_space, chains=_chains(sim), indenter_disp=disp)
                 assert abs(int(info["newton_iters"][0]) - int(io[0])) <= 1, (k, info["newton_iters"], io)
                 assert np.abs(sim.x[0].cpu().numpy() - xo).max() <= 2 * 1e-3 * sim.cfg.dt, k
         res[follow] = (sim.x[0].cpu().numpy().copy(), sum(its), sum(pcg))
@@ -913,7 +917,7 @@ def _axle_scene(B, deterministic=False, block_jacobi=False, velocity_tol=2e-3):
     if block_jacobi:
         cfg.linear_system.coarse_grid, cfg.linear_system.vertex_chains = None, None
     cfg.linear_system.deterministic = deterministic
-    cfg.linear_system.max_iter, cfg.linear_system.tol_rate = 3000, 1e-5
+    cfg.linear_system.max_iter, cfg.linear_system.tol_rate = 3000, 1e-10
     cfg.newton.velocity_tol = velocity_tol
     sim = UipcSim(cfg, num_envs=B)
     gel = UipcObject(UipcObjectCfg(mesh_points=P, mesh_tets=T), sim)
@@ -974,7 +978,7 @@ def test_wide_newton_kernel_steps_simple_axle_with_contact_and_friction():
         for b in range(B):
             cms[b].ind[1:4] = cur[b]
             xo[b], vo[b], io = fem_step(m, cms[b], xo[b], vo[b], cons, aim[b], gravity=sim.cfg.gravity, max_newton=60, velocity_tol=vtol,
-                                        pcg_max_iter=3000, pcg_tol_rate=1e-5, coarse=sim.coarse_space, chains=_chains(sim),
+                                        pcg_max_iter=3000, pcg_tol_rate=1e-10, coarse=sim.coarse_space, chains=_chains(sim),
                                         friction=(mu, sim.cfg.contact.eps_velocity, disp[b]))
             assert io[0] < 60 and int(io[2]) & 3 == 0, (k, b, io)
             assert np.abs(x[b] - xo[b]).max() <= 2 * vtol * sim.cfg.dt, (k, b, np.abs(x[b] - xo[b]).max(), io, info)  # both inside the Newton tolerance
@@ -1011,7 +1015,7 @@ def test_streaming_newton_kernel_steps_simple_axle_with_sphere_contact():
         for b in range(B):
             cms[b].ind[1:4] = cur[b]
             xo[b], vo[b], io = fem_step(m, cms[b], xo[b], vo[b], cons, aim[b], gravity=sim.cfg.gravity, max_newton=30, velocity_tol=2e-3,
-                                        pcg_max_iter=3000, pcg_tol_rate=1e-5, coarse=None, chains=None, lag_prec=False)
+                                        pcg_max_iter=3000, pcg_tol_rate=1e-10, coarse=None, chains=None, lag_prec=False)
             assert io[0] < 30 and int(io[2]) & 3 == 0, (k, b, io)
             assert np.abs(x[b] - xo[b]).max() <= 2 * 2e-3 * sim.cfg.dt, (k, b, np.abs(x[b] - xo[b]).max())  # both inside the Newton tolerance
     assert (P[:, 2] - sim.x[0].cpu().numpy()[:, 2]).max() > 5e-5  # the axle is dented / bent by the sphere
