@@ -20,6 +20,11 @@ inside a backward-Euler incremental potential per environment
 
 and pins ITSELF with known-answer tests (tests/test_fem_oracle.py): finite-difference consistency of
 energy/gradient/Hessian, zero rest force, rigid-motion invariance, PSD projection, monotone line search.
+
+Solver conventions restated from libuipc's / IPC's published sources (unpinned like everything here): the PCG's stopping test
+`abs(r.z) <= tol_rate * abs(r0.z0)` of `LinearPCG::pcg` (libuipc, src/backends/cuda/linear_system/linear_pcg.cu; `pcg_solve`), the
+Newton loop's test on the infinity norm of the search direction over dt (Li et al. 2020, Algorithm 1; `fem_step`), the friction lag
+from the state the time step starts at (Li et al. 2020, section 5.4; `FrictionModel`, `fem_step(friction_lag="start")`).
 """
 from __future__ import annotations
 
