@@ -51,7 +51,7 @@ LDS_PEAK_TBS = 78.6      # 128 B/clk/CU x 256 CUs x 2.4 GHz (guides/MI355X_MICRO
 FP64_PEAK_TFLOPS = 78.6  # vector f64 (half the f32 vector rate)
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
@@ -74,7 +74,13 @@ def parse():
     ap.add_argument("--no-sweep", action="store_true", help="skip the C2 / 512-shard / C4 / C5 sweep (N = 1 only)")
     ap.add_argument("--sweep-steps", type=int, default=30)
     ap.add_argument("--cpu-baseline-seconds", type=float, default=30.0, help="budget of the CPU baseline leg")
-    return ap.parse_args()
+    ap.add_argument("--details-out", default=None,
+                    help="side file for everything that is not the headline (sweep entries with their descriptions, per-stage timings, CPU "
+                         "thread sweep); default gpurun_out/bench_details_n<N>.json.  stdout carries ONE compact JSON line only")
+    ap.add_argument("--cpu-dry-run", action="store_true",
+                    help="no GPU: every rank runs the launch / rendezvous / max-over-ranks timing / emitter path over gloo with a stand-in "
+                         "step (tests/test_env_shard_gloo.py); the printed line is marked data = 'dry-run' and is not a measurement")
+    return ap.parse_args(argv)
 
 
 def build_sensor(num_envs, H, W, markers, device, obs_res=None, obs_dtype="float32", fem_gelpad=None, cam_res=None, clip=(0.024, 0.029),
@@ -270,27 +276,48 @@ def cpu_baseline(seconds):
         if (H, W) == (240, 320):
             best = max(best, B / med)
         log(f"cpu baseline {W}x{H} B={B} threads={best_th}: {B / med:.1f} frames/s ({len(ts)} calls)")
-    # 3) the protocol's thread setting (all logical cores), bounded: ONE frame first; the 16-frame call only if that frame took
-    #    less than 5 s (on a 256-thread host the oversubscribed small FFTs need ~4 s per frame: the 16-frame call alone was 69 s of
-    #    the 82 s driver run of round 2)
+    # 3) the protocol's thread setting (all logical cores): ONE 320x240 frame in a child process that is ended after 5 s (on a 256-thread
+    #    host the oversubscribed small FFTs took 21 s for that frame - 30 of the 58 s of round 4's driver run)
     proto = None
     if ncpu != best_th and left() > 1.0:
-        torch.set_num_threads(ncpu)
-        t1 = calls(240, 320, 1, 1, 0)[0]
-        proto = {"threads": ncpu, "frames": 1, "frames_per_s": round(1 / t1, 3), "timed_calls": 1,
-                 "note": "torch.set_num_threads(os.cpu_count()), first call (thread-pool start-up included)"}
-        if t1 < 5.0 and left() > 16 * t1 * 1.5:
-            t16 = calls(240, 320, 16, 1, 0)[0]
-            proto.update({"frames": 16, "frames_per_s": round(16 / t16, 3), "one_frame_call_s": round(t1, 3)})
-        else:
-            proto["skipped_16_frame_call"] = f"one frame took {t1:.2f} s at {ncpu} threads (cap 5 s) or the budget is spent"
+        proto = protocol_all_cores(ncpu, cap_s=5.0)
         log(f"cpu baseline protocol all-cores: {proto}")
-        torch.set_num_threads(best_th)
     return {"value": round(best, 2), "unit": "frames/s", "cores": best_th, "logical_cores": ncpu, "physical_cores": phys, "kind": "port",
             "sample": "Taxim RGB no-shadow (reflect-pad + torch.fft correlation x7, gather + polynomial; oracle/taxim_torch_cpu.py) on the "
                       "same synthetic depth maps (seed 1); value = best 320x240 batch size of {1, 16, 64} at the best intra-op thread "
                       "count of the sweep, median of 5 calls after 2 warm-ups",
             "runs": runs, "thread_sweep_B16": sweep_t, "protocol_all_cores": proto, "wall_s": round(time.perf_counter() - t_start, 1)}
+
+
+def protocol_all_cores(ncpu, cap_s=5.0):
+    """SURVEY 8(d)'s literal thread setting, `torch.set_num_threads(os.cpu_count())`, on one 320x240 frame - in a child process
+    with a hard cap of `cap_s` seconds of compute (a call cannot be interrupted from inside)."""
+    import subprocess
+
+    code = ("import sys, time; sys.path.insert(0, %r); import torch; torch.set_num_threads(%d)\n"
+            "from oracle.taxim_torch_cpu import TaximTorchCpuPort\n"
+            "from tacex_amd.calibration import CALIB_GELSIGHT_MINI\n"
+            "from tacex_amd.utils.synthetic import synthetic_depth_maps\n"
+            "p = TaximTorchCpuPort(CALIB_GELSIGHT_MINI, (240, 320)); hm, ind = synthetic_depth_maps(1, 240, 320, seed=1, device='cpu')\n"
+            "print('READY', flush=True); t0 = time.perf_counter(); p.render_direct(hm, ind); print('T', time.perf_counter() - t0, flush=True)\n"
+            % (str(REPO), ncpu))
+    out = {"threads": ncpu, "frames": 1, "cap_s": cap_s, "note": "torch.set_num_threads(os.cpu_count()), first call (thread-pool start-up included)"}
+    try:
+        pr = subprocess.Popen([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True)
+        ready = pr.stdout.readline()  # tables loaded, the timed call starts now
+        if not ready.startswith("READY"):
+            raise RuntimeError("child did not start")
+        try:
+            rest, _ = pr.communicate(timeout=cap_s)
+            t1 = float(rest.split()[1])
+            out.update({"frames_per_s": round(1 / t1, 3), "one_frame_call_s": round(t1, 3)})
+        except subprocess.TimeoutExpired:
+            pr.kill()
+            pr.communicate()
+            out.update({"frames_per_s": None, "did_not_finish_within_cap": True, "frames_per_s_upper_bound": round(1 / cap_s, 3)})
+    except Exception as ex:
+        out["error"] = f"{type(ex).__name__}: {ex}"[:200]
+    return out
 
 
 def roofline_leg(rig, markers):
@@ -381,9 +408,9 @@ def sweep(args, dev):
     """The other BASELINE configurations, timed the same way (rank 0, N = 1, after the headline)."""
     out = []
 
-    def run(label, B, H, W, n_sensors, markers, fem=None, steps=None, gather=None, count_in_contact=False, allow_newton_cap=False, **rig_kw):
+    def run(key, label, B, H, W, n_sensors, markers, fem=None, steps=None, gather=None, count_in_contact=False, **rig_kw):
         steps = steps or args.sweep_steps
-        log(f"sweep: {label}")
+        log(f"sweep: {key}: {label}")
         try:
             # (every entry starts from a collected heap and an empty allocator cache: the previous entry's rig is garbage with
             #  reference cycles, and its buffers are gigabytes)
@@ -406,7 +433,7 @@ def sweep(args, dev):
                 fem.info_sum = torch.zeros(4, dtype=torch.float64, device=dev)
             el = rig.timed(steps, 24 if fem is not None else 8, after_warmup=lambda: base.append(fem.info_sum.clone()) if fem is not None else None)
             frames = B * n_sensors * steps
-            e = {"workload": label, "frames_per_step": B * n_sensors, "steps": steps, "ms_per_step": round(el / steps * 1e3, 4),
+            e = {"key": key, "workload": label, "frames_per_step": B * n_sensors, "steps": steps, "ms_per_step": round(el / steps * 1e3, 4),
                  "frames_per_s": round(frames / el, 1)}
             if count_in_contact:
                 # the reference's counting rule (run_ball_rolling_experiment.py:238-244): only frames with indentation_depth > 0
@@ -431,11 +458,8 @@ def sweep(args, dev):
                 e["newton_cap"] = int(fem.max_newton_iter)
                 e["newton_iters_max_over_period"] = int(fem.iters_max) if fem.iters_max is not None else None
                 e["newton_cap_hit"] = bool(e["newton_iters_max_over_period"] is not None and e["newton_iters_max_over_period"] >= fem.max_newton_iter)
-                if allow_newton_cap:
-                    e["truncated_solves"] = e["newton_cap_hit"]  # (an entry that SAYS it caps the loop: kept for continuity with rounds 2-3)
-                else:
-                    assert not e["newton_cap_hit"], \
-                        f"an env ran into the Newton cap of {fem.max_newton_iter} iterations: the FEM rate would be measured on truncated solves"
+                assert not e["newton_cap_hit"], \
+                    f"an env ran into the Newton cap of {fem.max_newton_iter} iterations: the FEM rate would be measured on truncated solves"
                 tot = (fem.info_sum - base[0]).cpu().numpy()
                 e["fem_period"] = {"steps": steps, "newton_iters_per_step_mean": round(float(tot[0]) / steps, 2),
                                    "pcg_iters_per_newton_mean": round(float(tot[3]) / max(float(tot[0]), 1e-9), 1),
@@ -446,48 +470,59 @@ def sweep(args, dev):
             del rig
             torch.cuda.empty_cache()
         except Exception as ex:  # a sweep entry must not take the headline line down with it
-            out.append({"workload": label, "error": f"{type(ex).__name__}: {ex}"[:300]})
+            out.append({"key": key, "workload": label, "error": f"{type(ex).__name__}: {ex}"[:300]})
 
-    run("C3 without the observation gather / pack (`--gather none`): 1024 envs x 2 sensors, RGB 320x240 + FOTS markers", args.envs_per_gpu, 240, 320,
-        2, True, gather="none")
+    E = args.envs_per_gpu
+    run("c3_no_gather", f"C3 without the observation gather / pack: {E} envs x 2 sensors, RGB 320x240 + FOTS markers", E, 240, 320, 2, True, gather="none")
     if not args.sensor_streams:
-        run("C3 with one HIP stream per sensor (`--sensor-streams`; the left / right finger sensors of an env are independent objects): the drain "
-            "and the small kernels of one sensor's update overlap the other's - NOT the default, because kernels that overlap have no "
-            "duration of their own for the roofline leg and a profile of the command to agree on", args.envs_per_gpu, 240, 320, 2, True,
-            sensor_streams=True)
-    run("C3 DENSE CONTACT (data-independent floor: a wavy plate over the whole sensor - every frame, row and nearly every pixel in "
-        "contact, so no zero band is skipped, no wave is flat and every table record is gathered): 1024 envs x 2 sensors, RGB 320x240 + "
-        "FOTS markers", args.envs_per_gpu, 240, 320, 2, True, data="dense")
-    run("reference benchmark scene (envs/ball_rolling_physx_rigid.py:161-199): 1024 envs x 1 sensor, camera 320x240 clip (0.024, 0.034) "
-        "up-sampled to Taxim RGB 640x480 + FOTS 9x11 markers at 640x480; frames_per_s_in_contact_only applies the reference's counting "
-        "rule (run_ball_rolling_experiment.py:238-244)", 1024, 480, 640, 1, True, steps=max(5, args.sweep_steps // 3),
-        count_in_contact=True, cam_res=(320, 240), clip=(0.024, 0.034), grid=(9, 11))
-    run("C2: 256 envs x 1 sensor, Taxim RGB 320x240 (BASELINE configs[1])", 256, 240, 320, 1, False)
-    run("C2 + FOTS markers: 256 envs x 1 sensor, RGB 320x240 + markers", 256, 240, 320, 1, True)
-    run("512-env shard of the 4096-env / 8-GPU target: 512 envs x 1 sensor, RGB 320x240 + FOTS markers", 512, 240, 320, 1, True)
-    run("C4 per-GPU shard: 512 envs, RGB 320x240 + FEM-driven markers + gelpad FEM step (1920 tets / env) (BASELINE configs[3] / 8); the FEM "
-        "step runs on a HIP stream of its own, the sensor's optical pipeline overlaps its straggler tail and the FEM-driven markers wait "
-        "for its event (FemGelpad side_stream; `fem_ms_*` then include the contention with the optical kernels)",
+        run("c3_sensor_streams", f"C3 with one HIP stream per sensor: {E} envs x 2 sensors", E, 240, 320, 2, True, sensor_streams=True)
+    run("c3_dense", f"C3 dense contact (data-independent floor): {E} envs x 2 sensors, RGB 320x240 + FOTS markers", E, 240, 320, 2, True, data="dense")
+    run("ref_scene", "reference benchmark scene: 1024 envs x 1 sensor, camera 320x240 -> Taxim RGB 640x480 + FOTS 9x11 markers", 1024, 480, 640, 1, True,
+        steps=max(5, args.sweep_steps // 3), count_in_contact=True, cam_res=(320, 240), clip=(0.024, 0.034), grid=(9, 11))
+    run("c2", "C2: 256 envs x 1 sensor, Taxim RGB 320x240 (BASELINE configs[1])", 256, 240, 320, 1, False)
+    run("c2_markers", "C2 + FOTS markers: 256 envs x 1 sensor, RGB 320x240 + markers", 256, 240, 320, 1, True)
+    run("shard512", "512-env shard of the 4096-env / 8-GPU target: 512 envs x 1 sensor, RGB 320x240 + FOTS markers", 512, 240, 320, 1, True)
+    run("c4", "C4 per-GPU shard: 512 envs, RGB 320x240 + FEM-driven markers + gelpad FEM step (1920 tets / env), FEM on a side stream",
         512, 240, 320, 1, False, fem=lambda: FemGelpad(512, dev, max_newton_iter=NEWTON_CAP, side_stream=True))
-    run("C4 per-GPU shard on ONE stream (A/B of the side stream: FEM step, then the sensor update; `fem_ms_*` are the FEM step alone)",
+    run("c4_one_stream", "C4 per-GPU shard on ONE stream (FEM step, then the sensor update)",
         512, 240, 320, 1, False, fem=lambda: FemGelpad(512, dev, max_newton_iter=NEWTON_CAP))
-    run("C4 per-GPU shard with the Newton loop CAPPED at 8 iterations as in rounds 2-3 (continuity only: envs that reach the cap carry an "
-        "unconverged state into the next step - `truncated_solves` says whether any did; the entry above is the measured rate)",
-        512, 240, 320, 1, False, fem=lambda: FemGelpad(512, dev, max_newton_iter=8), allow_newton_cap=True)
-    run("C4 shard, ROLLING CONTACT: the indenter stays on the pad like the ball of the reference's ball-rolling scene (depth 0.3-0.8 of "
-        "the maximum, sliding +-0.5 mm sideways, friction on); whenever the indenter RETREATS the pad follows it up the barrier in damped "
-        "Newton steps (every env runs to convergence: the cap of 64 iterations is asserted never to bind)",
+    run("c4_dhat5e4", "C4 per-GPU shard with the reference scenes' contact zone d_hat = 5e-4 (ball_rolling_uipc.py:71-75)",
+        512, 240, 320, 1, False, fem=lambda: FemGelpad(512, dev, max_newton_iter=NEWTON_CAP, side_stream=True, d_hat=5e-4))
+    run("c4_rolling", "C4 shard, rolling contact: the indenter stays on the pad and slides, friction on",
         512, 240, 320, 1, False, fem=lambda: FemGelpad(512, dev, motion="rolling", max_newton_iter=NEWTON_CAP, side_stream=True))
-    run("C5 per-GPU shard: 1024 envs, RGB 640x480 + FEM-driven markers (gelpad FEM step included) (BASELINE configs[4] / 8)",
+    run("c5", "C5 per-GPU shard: 1024 envs, RGB 640x480 + FEM-driven markers (gelpad FEM step included) (BASELINE configs[4] / 8)",
         1024, 480, 640, 1, False, fem=lambda: FemGelpad(1024, dev, max_newton_iter=NEWTON_CAP, side_stream=True))
-    out.append(fem_axle_entry(dev))
     # (with the coarse correction in M^-1 the reference's PCG test - 1e-3 on r.z - can pass after ONE iteration on this rod, whose coarse modes are
-    #  nearly free: states then follow the tightly solved ones within the accumulated Newton tolerance, scripts/axle_tol_check.py.  The second entry
-    #  solves to the threshold rounds 1-4 used - 1e-6 on r.z - which is also what the block-Jacobi streaming entry needs to mean the same accuracy.)
-    out.append(fem_axle_entry(dev, tol_rate=1e-6))
-    out.append(fem_axle_entry(dev, steps=6, streaming=True, tol_rate=1e-6))
-    run("C5 optical part only: 1024 envs, RGB 640x480", 1024, 480, 640, 1, False, steps=max(5, args.sweep_steps // 3))
+    #  nearly free: states then follow the tightly solved ones within the accumulated Newton tolerance.  The second entry solves to the threshold
+    #  rounds 1-4 used - 1e-6 on r.z - which is also what the block-Jacobi streaming entry needs to mean the same accuracy.)
+    out.append(fem_axle_entry(dev, key="axle"))
+    out.append(fem_axle_entry(dev, tol_rate=1e-6, key="axle_tol1e-6"))
+    out.append(fem_axle_entry(dev, steps=6, streaming=True, tol_rate=1e-6, key="axle_streaming"))
+    run("c5_optical", "C5 optical part only: 1024 envs, RGB 640x480", 1024, 480, 640, 1, False, steps=max(5, args.sweep_steps // 3))
     return out
+
+
+# What each sweep entry is, at length (goes to the details side file, never to the stdout line).
+SWEEP_NOTES = {
+    "c3_no_gather": "`--gather none`: the headline job without the 32x32 observation pack / all-gather",
+    "c3_sensor_streams": "`--sensor-streams`: the left / right finger sensors of an env are independent objects; the drain and the small kernels of one "
+                         "sensor's update overlap the other's.  NOT the default, because kernels that overlap have no duration of their own for the "
+                         "roofline leg and a profile of the command to agree on",
+    "c3_dense": "a wavy plate over the whole sensor: every frame, row and nearly every pixel in contact, so no zero band is skipped, no wave is flat "
+                "and every table record is gathered",
+    "ref_scene": "envs/ball_rolling_physx_rigid.py:161-199: camera 320x240 with clip (0.024, 0.034) up-sampled to the 640x480 tactile image; "
+                 "frames_per_s_in_contact_only applies the reference's counting rule (run_ball_rolling_experiment.py:238-244)",
+    "c4": "the FEM step runs on a HIP stream of its own, the sensor's optical pipeline overlaps its straggler tail and the FEM-driven markers wait "
+          "for its event (FemGelpad side_stream; `fem_ms_*` then include the contention with the optical kernels)",
+    "c4_one_stream": "A/B of the side stream; `fem_ms_*` are the FEM step alone",
+    "c4_dhat5e4": "half the barrier width of UipcSimCfg's default (uipc_sim.py:103-124): what both of the reference's UIPC scenes set",
+    "c4_rolling": "like the ball of the reference's ball-rolling scene (depth 0.3-0.8 of the maximum, sliding +-0.5 mm sideways); whenever the indenter "
+                  "RETREATS the pad follows it up the barrier in damped Newton steps (every env runs to convergence: the cap is asserted never to bind)",
+    "axle": "SURVEY 8(d)'s ~2k-tet fixture simple_axle.msh (593 vertices / 2003 tets, scaled to 25.8 x 3 x 3 mm), ends attached, a sphere pressing "
+            "on through the IPC barrier: the CU-resident Newton kernel, 768 threads per env (friction, coarse correction, chains: the defaults)",
+    "axle_tol1e-6": "the same with the PCG threshold of rounds 1-4 (1e-6 on r.z)",
+    "axle_streaming": "the streaming Newton kernel (deterministic switch; block Jacobi, no friction), PCG threshold 1e-6",
+}
 
 
 NEWTON_CAP = 64  # Newton iterations a FEM scene of the sweep may take per step (reference default 1024, uipc_sim.py Newton.max_iter):
@@ -497,7 +532,7 @@ NEWTON_CAP = 64  # Newton iterations a FEM scene of the sweep may take per step 
 AXLE_NEWTON_CAP = 200  # (the bent axle's iterations in PSD-safe mode converge linearly: 50 in the worst env and step measured)
 
 
-def fem_axle_entry(dev, B=512, steps=12, streaming=False, tol_rate=None):
+def fem_axle_entry(dev, B=512, steps=12, streaming=False, tol_rate=None, key="axle"):
     """SURVEY section 8(d)'s ~2k-tet fixture simple_axle.msh (593 vertices / 2 003 tets) stepped with sphere contact - FEM only, env steps
     per second.  Default: the 768-thread variant of the CU-resident Newton kernel with everything the gelpad scene uses (friction,
     coarse correction on the bounding-box grid, the chains found in the mesh).  streaming=True: the streaming Newton kernel (what
@@ -554,13 +589,12 @@ def fem_axle_entry(dev, B=512, steps=12, streaming=False, tol_rate=None):
         finite, gap = bool(torch.isfinite(sim.x).all()), float(sim.contact_gaps().amin())
         assert finite and gap > 0.0, f"finite {finite}, smallest gap {gap}"
         assert float(its) < AXLE_NEWTON_CAP, f"an env ran into the Newton cap of {AXLE_NEWTON_CAP}"
-        return {"workload": f"FEM only: {B} envs x simple_axle.msh (593 vertices / 2003 tets, scaled to 25.8 x 3 x 3 mm), ends attached, a sphere "
-                            f"pressing on through the IPC barrier: {name}",
+        return {"key": key, "workload": f"FEM only: {B} envs x simple_axle.msh, sphere contact: {name}",
                 "envs": B, "steps": steps, "ms_per_step": round(el / steps * 1e3, 3), "env_steps_per_s": round(B * steps / el, 1),
                 "newton_iters_max": None if streaming else int(its),  # (the streaming path leaves step_info zero: one launch per iteration on a fixed schedule)
                 "newton_cap": AXLE_NEWTON_CAP, "pcg_tol_rate": cfg.linear_system.tol_rate, "failure_flags_max": int(flagged), "velocity_tol": 2e-3}
     except Exception as ex:
-        return {"workload": f"FEM only: simple_axle.msh on {name}", "error": f"{type(ex).__name__}: {ex}"[:300]}
+        return {"key": key, "workload": f"FEM only: simple_axle.msh on {name}", "error": f"{type(ex).__name__}: {ex}"[:300]}
 
 
 def fem_roofline(fem, period=None):
@@ -635,50 +669,259 @@ def fem_roofline(fem, period=None):
 
 def fem_roofline_entry(sw):
     """`roofline.fem`: the Newton kernel of the C4 shard against BOTH roofs north_star names for it - HBM (bytes per dispatch from the
-    PMC passes of `scripts/fem_bench.py`, profiles/pmc_traffic_r04_fem.json, over the kernel's mean duration in the kernel-trace run of
+    PMC passes of `scripts/fem_bench.py`, profiles/pmc_traffic_r0N_fem.json, over the kernel's mean duration in the kernel-trace run of
     the same command) and, live from the C4 sweep entry, the f64 vector rate and LDS rate of the CU an env sits on."""
-    c4 = next((e for e in (sw or []) if e.get("workload", "").startswith("C4 per-GPU shard:") and "fem" in e), None)
+    c4 = next((e for e in (sw or []) if e.get("key") == "c4" and "fem" in e), None)
     out = {"kernel": "fem_newton_lds_kernel<MESH = false, ATOM = true> (one dispatch = the whole Newton loop of a time step for all envs of the shard)"}
-    try:
-        j = json.loads((REPO / "profiles" / "pmc_traffic_r04_fem.json").read_text())
-        k = next(v for n, v in j["kernels"].items() if "fem_newton_lds_kernel<false" in n)  # (<MESH = false, ATOM = ...>)
-        out.update({"hbm_bytes_per_dispatch": k["hbm_bytes_per_dispatch"], "mean_us_per_dispatch": k.get("mean_us_per_dispatch"),
-                    "hbm_achieved": k.get("hbm_GBps"), "hbm_peak": HBM_PEAK_GBS, "hbm_unit": "GB/s", "hbm_frac": k.get("hbm_frac_of_8TBps"),
-                    "hbm_source": "profiles/pmc_traffic_r04_fem.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE + --kernel-trace --stats of scripts/fem_bench.py)",
-                    "hbm_measured_at": j.get("measured_at_commit")})
-    except Exception:
-        out["hbm_achieved"] = None
+    for cand in ("pmc_traffic_r05_fem.json", "pmc_traffic_r04_fem.json"):
+        try:
+            j = json.loads((REPO / "profiles" / cand).read_text())
+            k = next(v for n, v in j["kernels"].items() if "fem_newton_lds_kernel<false" in n)  # (<MESH = false, ATOM = ...>)
+            out.update({"hbm_bytes_per_dispatch": k["hbm_bytes_per_dispatch"], "mean_us_per_dispatch": k.get("mean_us_per_dispatch"),
+                        "hbm_achieved": k.get("hbm_GBps"), "hbm_peak": HBM_PEAK_GBS, "hbm_unit": "GB/s", "hbm_frac": k.get("hbm_frac_of_8TBps"),
+                        "hbm_source": f"profiles/{cand} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE + --kernel-trace --stats of scripts/fem_bench.py)",
+                        "hbm_measured_at": j.get("measured_at_commit")})
+            asm = next((v for n, v in j["kernels"].items() if "fem_assemble" in n), None)
+            if asm is not None:
+                out["assembly"] = {"kernel": "fem_assemble_blocks_kernel", "hbm_GBps": asm.get("hbm_GBps"), "hbm_frac": asm.get("hbm_frac_of_8TBps"),
+                                   "mean_us_per_dispatch": asm.get("mean_us_per_dispatch")}
+            break
+        except Exception:
+            out["hbm_achieved"] = None
     if c4 is not None:
         ni = c4["fem"]["newton_iteration"]
+        per = c4.get("fem_period", {})
         out.update({"f64_achieved": ni["achieved_f64"], "f64_peak": ni["peak_f64"], "f64_unit": "TFLOP/s", "f64_frac": ni["frac"],
                     "lds_frac": ni["lds_frac"], "us_per_sweep": ni["us_per_sweep"], "window": ni["window"],
+                    "sweeps_per_step": round(ni["pcg_iterations"] / max(per.get("steps", 1), 1) + 4.0 * ni["newton_iterations"] / max(per.get("steps", 1), 1), 2),
+                    "newton_iters_per_step": per.get("newton_iters_per_step_mean"), "pcg_iters_per_newton": per.get("pcg_iters_per_newton_mean"),
+                    "pcg_stop": PCG_STOP_RULE,
                     "matrix_free_bytes_per_tet_iteration_survey": 304,
                     "note": "the env's state lives on its CU (LDS + registers); inside the PCG loop only the mesh constants are read (shared "
-                            "by all envs, L2), so the HBM roof does not bind this kernel - its HBM bytes are spill scratch outside the PCG loop "
-                            "and the lagged preconditioner blocks"})
+                            "by all envs, L2), so the HBM roof does not bind this kernel"})
     return out if (c4 is not None or out.get("hbm_achieved") is not None) else None
 
 
-def main():
-    args = parse()
-    from tacex_amd import _lib
-    from tacex_amd.env_shard import init_from_env
+PCG_STOP_RULE = "r.z <= tol_rate * r0.z0 (tol_rate 1e-3, uipc_sim.py linear_system default; rule restated from libuipc LinearPCG, source absent: unpinned)"
 
+
+# ------------------------------------------------------------------------------------------------------------------------------
+# The stdout line.  The driver keeps the LAST 8 KB of stdout: round 4's 20 KB line lost its head (BENCH_r04.json parsed: null).
+# Everything that is not a headline number goes to the details side file; tests/test_bench_contract.py builds a line through
+# compact_line() from a full synthetic sweep and bounds its length.
+# ------------------------------------------------------------------------------------------------------------------------------
+LINE_BUDGET = 4096  # bytes of the stdout line (asserted in emit(); the contract test allows 6000)
+
+_ROOF_KEYS = ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "kernel_avg_ms", "frames_per_launch",
+              "algorithmic_bytes_per_launch", "frac_own_bytes", "pipeline_frac", "valu_frac")
+_FEM_KEYS = ("hbm_frac", "hbm_achieved", "f64_frac", "lds_frac", "us_per_sweep", "sweeps_per_step", "newton_iters_per_step", "pcg_iters_per_newton")
+_CPU_KEYS = ("value", "unit", "cores", "kind", "logical_cores", "physical_cores")
+_SWEEP_SCALARS = {"c2": "value_c2", "c4": "value_c4", "c5": "value_c5", "c3_dense": "value_dense_contact", "c3_no_gather": "value_no_gather",
+                  "c3_sensor_streams": "value_sensor_streams", "c4_rolling": "value_c4_rolling", "c4_dhat5e4": "value_c4_dhat5e4",
+                  "c5_optical": "value_c5_optical", "shard512": "value_shard512"}
+
+
+def compact_line(full: dict, details_path: str | None) -> dict:
+    """The ONE stdout line: the driver contract's keys + compact `roofline` / `cpu_baseline` + one scalar per sweep entry."""
+    keep = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data")
+    line = {k: full[k] for k in keep}
+    cfg = full["config"]
+    line["config"] = {k: cfg[k] for k in ("workload", "envs_per_gpu", "sensors_per_env", "frames_per_step", "resolution", "markers", "gather", "arch")
+                      if k in cfg}
+    for e in cfg.get("sweep") or []:
+        name = _SWEEP_SCALARS.get(e.get("key"))
+        if name is not None:
+            line[name] = e.get("frames_per_s")  # None = the entry failed (its error is in the details file)
+        if e.get("key") == "axle":
+            line["value_axle_env_steps"] = e.get("env_steps_per_s")
+    errs = [e["key"] for e in cfg.get("sweep") or [] if "error" in e]
+    if errs:
+        line["sweep_errors"] = errs
+    r = full.get("roofline")
+    if r is not None:
+        line["roofline"] = {k: r[k] for k in _ROOF_KEYS if k in r}
+        if r.get("fem"):
+            line["roofline"]["fem"] = {k: r["fem"][k] for k in _FEM_KEYS if r["fem"].get(k) is not None}
+            line["roofline"]["fem"]["pcg_stop"] = "r.z <= tol_rate*r0.z0"
+    c = full.get("cpu_baseline")
+    if c is not None:
+        line["cpu_baseline"] = {k: c[k] for k in _CPU_KEYS if k in c}
+        line["cpu_baseline"]["sample"] = c["sample"][:200]
+    m = full.get("multi_gpu")
+    if m is not None:
+        line["multi_gpu"] = {k: m[k] for k in ("backend", "world_size", "per_rank_ms_per_step", "value_no_gather", "ms_per_step_no_gather", "launcher")
+                             if k in m}
+        line["multi_gpu"]["distinct_devices"] = len(set(m.get("rank_devices", [])))
+    if details_path:
+        line["details"] = details_path
+    return line
+
+
+def emit(full: dict, details_path: str | None) -> str:
+    """Writes the details side file (best effort) and returns the compact stdout line."""
+    if details_path:
+        try:
+            dp = Path(details_path)
+            dp.parent.mkdir(parents=True, exist_ok=True)
+            full = dict(full, sweep_notes=SWEEP_NOTES)
+            dp.write_text(json.dumps(full, indent=1))
+        except OSError as ex:
+            log(f"details file not written: {ex}")
+            details_path = None
+    if details_path:
+        try:
+            details_path = str(Path(details_path).resolve().relative_to(REPO))
+        except ValueError:
+            pass
+    text = json.dumps(compact_line(full, details_path), separators=(",", ":"))
+    assert len(text) <= LINE_BUDGET, f"stdout line of {len(text)} bytes (budget {LINE_BUDGET}): move the new field to the details file"
+    return text
+
+
+def launch_children(args, argv) -> int:
+    """`python bench.py --gpus N` with no rendezvous in the environment: this process - which has made NO GPU call - starts N fresh
+    children of this same script, one per GPU, with the torch.distributed.run environment contract (RANK / LOCAL_RANK / WORLD_SIZE /
+    MASTER_*), waits for all of them and relays rank 0's line.  Nothing that touched the GPU is ever exec'ed or forked."""
+    import socket
+    import subprocess
+
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0", TACEX_BENCH_LAUNCHER="self")
+        procs.append(subprocess.Popen([sys.executable, str(Path(__file__).resolve()), *argv], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr, stderr=sys.stderr, text=True))
+    out0 = procs[0].communicate()[0]
+    rcs = [p.wait() for p in procs]
+    if any(rcs):
+        sys.stderr.write(out0)
+        log(f"child exit codes {rcs}")
+        return next(rc for rc in rcs if rc)
+    lines = [ln for ln in out0.splitlines() if ln.startswith("{")]
+    sys.stderr.write("".join(ln + "\n" for ln in out0.splitlines() if not ln.startswith("{")))
+    print(lines[-1], flush=True)
+    return 0
+
+
+def dry_run_rank(args):
+    """--cpu-dry-run: launcher, rendezvous (gloo), barrier-bracketed timing, max over ranks, the observation all-gather and the
+    emitter, with a stand-in step on the CPU.  NOT a measurement (data = 'dry-run')."""
+    from tacex_amd.env_shard import ObservationGather, init_from_env
+
+    shard = init_from_env(args.envs_per_gpu * args.gpus, backend="gloo" if args.gpus > 1 else None)
+    use_dist = dist.is_available() and dist.is_initialized()
+    B = min(shard.num_local, 4)
+    obs = ObservationGather({"rgb32_0": (32, 32, 3), "indent_0": (1,)}, B, shard.world_size, "cpu", dtypes={"rgb32_0": torch.uint8})
+
+    def step(i):
+        obs.pack_all({"rgb32_0": torch.full((B, 32, 32, 3), (i + shard.rank) % 251, dtype=torch.uint8), "indent_0": torch.full((B, 1), float(i))})
+        obs.gather_async()
+
+    for i in range(args.warmup):
+        step(i)
+    obs.wait()
+    if use_dist:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(args.warmup + i)
+    obs.wait()
+    if use_dist:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    multi = None
+    if use_dist:
+        t = torch.tensor([elapsed], dtype=torch.float64)
+        every = [torch.zeros_like(t) for _ in range(shard.world_size)]
+        dist.all_gather(every, t)
+        elapsed = max(float(v) for v in every)
+        multi = {"backend": dist.get_backend(), "world_size": dist.get_world_size(), "rank_devices": [f"cpu-{r}" for r in range(shard.world_size)],
+                 "per_rank_ms_per_step": [round(float(v) / args.steps * 1e3, 4) for v in every],
+                 "launcher": os.environ.get("TACEX_BENCH_LAUNCHER", "torch.distributed.run")}
+        v = obs.views()
+        assert v["indent_0"].shape[0] == B * shard.world_size and float(v["indent_0"][0, 0]) == args.warmup + args.steps - 1
+    frames_per_step = args.envs_per_gpu * args.sensors * args.gpus
+    full = headline_dict(args, frames_per_step * args.steps / elapsed, elapsed, not args.no_markers, "cpu (dry run)", None)
+    full["data"] = "dry-run"
+    if multi is not None:
+        full["multi_gpu"] = multi
+    if use_dist:
+        dist.barrier()
+        dist.destroy_process_group()
+    return emit(full, args.details_out) if shard.rank == 0 else None
+
+
+def headline_dict(args, value, elapsed, markers, arch, obs_bytes, sensor_streams_on=False, use_dist=False):
+    W, H = args.width, args.height
+    frames_per_step = args.envs_per_gpu * args.sensors * args.gpus
+    return {
+        "metric": "tactile_frames_per_sec", "value": round(value, 1), "unit": "frames/s", "n_gpus": args.gpus,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {
+            "workload": f"{args.envs_per_gpu} envs x {args.sensors} GelSight Mini per GPU = {args.envs_per_gpu * args.sensors} frames/step/GPU, "
+                        f"Taxim RGB {W}x{H}" + (" + FOTS markers (99)" if markers else "")
+                        + ("; BASELINE configs[2] (C3)" if (args.envs_per_gpu, args.sensors, W, H, markers) == (1024, 2, 320, 240, True) else ""),
+            "envs_per_gpu": args.envs_per_gpu, "sensors_per_env": args.sensors, "frames_per_step": frames_per_step,
+            "resolution": [W, H], "markers": markers,
+            "gather": "none" if obs_bytes is None else f"obs32 {args.obs_dtype} ({obs_bytes} B/rank, " + ("1 all_gather/step)" if (args.gpus > 1 or use_dist) else "N=1: no collective)"),
+            "two_sensor_batching": BATCHING_NOTE + (", one HIP stream per sensor (joined before the observation is packed)" if sensor_streams_on else ""),
+            "observation_gather": None if obs_bytes is None else {
+                "payload": f"per sensor: 32x32x3 {args.obs_dtype} RGB (antialiased, produced in the render pass) + f32 indentation"
+                           + (" + f32 markers (2,99,2)" if markers else ""),
+                "bytes_per_rank": obs_bytes,
+                "collective": "all_gather_into_tensor x1 per step" if (args.gpus > 1 or use_dist) else "none (N=1: the packed buffer is the observation)"},
+            "background_frame": "synthetic f0 (real dataPack.npz absent from the reference checkout)",
+            "arch": arch,
+        },
+    }
+
+
+BATCHING_NOTE = "two independent GelSightSensor objects (gsmini_left / gsmini_right as factory_env_cfg.py:192-213)"
+
+
+def main(argv=None):
+    argv = list(sys.argv[1:] if argv is None else argv)
+    args = parse(argv)
+    if args.details_out is None:
+        args.details_out = str(REPO / "gpurun_out" / f"bench_details_n{args.gpus}.json")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(launch_children(args, argv))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     # Native libraries write banners to the C stdout (RCCL prints its version block when the first communicator is made, and
-    # libc only flushes it at exit - after our line).  The driver parses stdout for ONE JSON line: everything before it goes to
-    # stderr instead (fd 1 -> fd 2 until the line is printed).
+    # libc only flushes it at exit - after our line; gloo prints its peer count).  The driver parses stdout for ONE JSON line:
+    # everything before it goes to stderr instead (fd 1 -> fd 2 until the line is printed).
     import ctypes
     sys.stdout.flush()
     saved_stdout = os.dup(1)
     os.dup2(2, 1)
 
+    def restore_stdout():
+        try:
+            ctypes.CDLL(None).fflush(None)  # native buffers (the RCCL banner) land on stderr
+        except OSError:
+            pass
+        sys.stdout.flush()
+        os.dup2(saved_stdout, 1)
+        os.close(saved_stdout)
+
+    if args.cpu_dry_run:
+        text = dry_run_rank(args)
+        restore_stdout()
+        if text is not None:
+            print(text, flush=True)
+        return
+
+    from tacex_amd import _lib
+    from tacex_amd.env_shard import init_from_env
+
     H, W = args.height, args.width
     markers = not args.no_markers
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
-        if args.gpus > 1:
-            raise SystemExit(f"--gpus {args.gpus} needs `python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py ...` "
-                             f"(WORLD_SIZE={world})")
     shard = init_from_env(args.envs_per_gpu * args.gpus,
                           backend="nccl" if (args.gpus > 1 or os.environ.get("TACEX_FORCE_DIST") == "1") else None)
     dev = f"cuda:{shard.local_rank}"
@@ -711,7 +954,8 @@ def main():
         multi = {"backend": dist.get_backend(), "world_size": dist.get_world_size(),
                  "rank_devices": [bytes(blobs[r * 96:(r + 1) * 96].cpu().tolist()).rstrip(b"\0").decode(errors="replace")
                                   for r in range(shard.world_size)],
-                 "per_rank_ms_per_step": [round(float(v) / args.steps * 1e3, 4) for v in every.cpu().tolist()]}
+                 "per_rank_ms_per_step": [round(float(v) / args.steps * 1e3, 4) for v in every.cpu().tolist()],
+                 "launcher": os.environ.get("TACEX_BENCH_LAUNCHER", "torch.distributed.run")}
         elapsed = float(every.max().item())
     frames_per_step = args.envs_per_gpu * args.sensors * args.gpus
     value = frames_per_step * args.steps / elapsed
@@ -746,62 +990,27 @@ def main():
         cpu = cpu_baseline(args.cpu_baseline_seconds)
     log("done")
 
+    text = None
     if shard.rank == 0:
-        line = {
-            "metric": "tactile_frames_per_sec", "value": round(value, 1), "unit": "frames/s", "n_gpus": args.gpus,
-            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {
-                "workload": f"{args.envs_per_gpu} envs x {args.sensors} GelSight Mini per GPU = {args.envs_per_gpu * args.sensors} frames/step/GPU, "
-                            f"Taxim RGB {W}x{H}" + (" + FOTS markers (99)" if markers else "")
-                            + f" via {args.sensors} GelSightSensor.update() calls per step"
-                            + ("; BASELINE configs[2] (C3)" if (args.envs_per_gpu, args.sensors, W, H, markers) == (1024, 2, 320, 240, True) else ""),
-                "envs_per_gpu": args.envs_per_gpu, "sensors_per_env": args.sensors, "frames_per_step": frames_per_step,
-                "resolution": [W, H], "markers": markers,
-                "two_sensor_batching": "two independent GelSightSensor objects (gsmini_left / gsmini_right as factory_env_cfg.py:192-213), "
-                                       f"each one launch sequence over its {args.envs_per_gpu} envs"
-                                       + (", one HIP stream per sensor (joined before the observation is packed)" if sensor_streams_on else " on the same stream"),
-                "observation_gather": None if obs_bytes is None else {
-                    "payload": f"per sensor: 32x32x3 {args.obs_dtype} RGB (antialiased, produced in the render pass) + f32 indentation"
-                               + (" + f32 markers (2,99,2)" if markers else ""),
-                    "bytes_per_rank": obs_bytes,
-                    "collective": "all_gather_into_tensor x1 per step" if (args.gpus > 1 or use_dist) else "none (N=1: the packed buffer is the observation)"},
-                "background_frame": "synthetic f0 (real dataPack.npz absent from the reference checkout)",
-                "arch": _lib.require_gpu(shard.local_rank),
-            },
-        }
+        full = headline_dict(args, value, elapsed, markers, _lib.require_gpu(shard.local_rank), obs_bytes, sensor_streams_on, use_dist)
         if multi is not None:
-            line["multi_gpu"] = multi
+            full["multi_gpu"] = multi
         if sw is not None:
-            line["config"]["sweep"] = sw
-            ng = next((e for e in sw if "without the observation gather" in e.get("workload", "") and "frames_per_s" in e), None)
-            dn = next((e for e in sw if "DENSE CONTACT" in e.get("workload", "") and "frames_per_s" in e), None)
-            if ng:
-                line["value_no_gather"] = ng["frames_per_s"]
-            if dn:
-                line["value_dense_contact"] = dn["frames_per_s"]
-            ss = next((e for e in sw if "one HIP stream per sensor" in e.get("workload", "") and "frames_per_s" in e), None)
-            if ss:
-                line["value_sensor_streams"] = ss["frames_per_s"]
+            full["config"]["sweep"] = sw
         if roofline is not None:
-            line["roofline"] = roofline
+            full["roofline"] = roofline
             fem_leg = fem_roofline_entry(sw)
             if fem_leg is not None:
                 roofline["fem"] = fem_leg
         if cpu is not None:
-            line["cpu_baseline"] = cpu
+            full["cpu_baseline"] = cpu
+        text = emit(full, args.details_out)
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
-    try:
-        ctypes.CDLL(None).fflush(None)  # native buffers (the RCCL banner) land on stderr
-    except OSError:
-        pass
-    sys.stdout.flush()
-    os.dup2(saved_stdout, 1)
-    os.close(saved_stdout)
-    if shard.rank == 0:
-        print(json.dumps(line), flush=True)
+    restore_stdout()
+    if text is not None:
+        print(text, flush=True)
 
 
 if __name__ == "__main__":

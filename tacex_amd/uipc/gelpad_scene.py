@@ -21,12 +21,15 @@ class FemGelpad:
     presses into the front face through the IPC barrier (d_hat 1 mm, CCD-filtered Newton steps) and breathes in and out;
     stepped with UipcSim.step (backward Euler: the whole Newton loop - matrix-free PCG, CCD filter, line search - in one HIP launch)."""
 
-    def __init__(self, B, dev, max_newton_iter: int = 8, motion: str = "breathing", side_stream: bool = False):
+    def __init__(self, B, dev, max_newton_iter: int = 8, motion: str = "breathing", side_stream: bool = False, d_hat: float | None = None,
+                 cfg: UipcSimCfg | None = None):
         """motion: "breathing" - the indenter presses in and retreats to the edge of the barrier zone every 21 steps; "rolling" - it
         stays on the pad like the ball of the reference's ball-rolling scenes: the depth varies between 0.3 and 0.8 of the env's
-        maximum while the sphere slides sideways by up to +-0.5 mm (friction drags the surface along).  Either way the half of the
-        period in which the indenter RETREATS is the solver's expensive regime: the pad follows it up the steeply nonlinear barrier
-        in damped Newton steps (8 iterations per step, the scene's cap), 10-17 ms per step against ~1 ms while it presses."""
+        maximum while the sphere slides sideways by up to +-0.5 mm (friction drags the surface along).  The half of the period in
+        which the indenter RETREATS is the solver's harder regime: the pad follows it up the steeply nonlinear barrier.
+        d_hat: width of the barrier zone; None = UipcSimCfg's default 1e-3 (uipc_sim.py:103-124 of the reference), 5e-4 = what the
+        reference's own UIPC scenes set (ball_rolling_uipc.py:71-75, ball_rolling_tactile_rgb_uipc.py:220-224).
+        cfg: a UipcSimCfg to use instead of the defaults (tolerance studies in tests/test_fem_gpu.py)."""
         assert motion in ("breathing", "rolling")
         self.motion = motion
         # side_stream: the scene driver and the FEM step run on a HIP stream of their own and `sim.step_done` marks their end, so that
@@ -37,7 +40,11 @@ class FemGelpad:
         self.stream = torch.cuda.Stream(device=dev, priority=prio) if side_stream else None
         self.max_newton_iter = max_newton_iter
         P, T = gelpad_box_mesh(8, 10, 4)
-        self.sim = UipcSim(UipcSimCfg(device=dev), num_envs=B)
+        cfg = cfg if cfg is not None else UipcSimCfg(device=dev)
+        if d_hat is not None:
+            cfg.contact.d_hat = float(d_hat)
+        self.d_hat = float(cfg.contact.d_hat)
+        self.sim = UipcSim(cfg, num_envs=B)
         self.gelpad = UipcObject(UipcObjectCfg(mesh_points=P, mesh_tets=T), self.sim)
         self.sim.setup_sim(constraint_strength_ratio=1000.0)  # benchmark env value (envs/ball_rolling_uipc.py:120-125)
         self.num_tets, self.num_verts = len(T), len(P)
@@ -55,7 +62,7 @@ class FemGelpad:
         fr = np.where(P[:, 2] > top - 1e-12)[0]
         vc = fr[np.argmin(np.hypot(P[fr, 0] - size[0] / 2, P[fr, 1] - size[1] / 2))]
         self.R = 0.004
-        self.z_rest = top + self.R + 0.0009  # lowest point of the sphere just inside d_hat
+        self.z_rest = top + self.R + 0.9 * self.d_hat  # lowest point of the sphere just inside d_hat
         ind = torch.zeros((B, 8), dtype=torch.float64, device=dev)
         ind[:, 0] = 1.0
         ind[:, 1], ind[:, 2], ind[:, 3], ind[:, 4] = P[vc, 0], P[vc, 1], self.z_rest, self.R

@@ -59,6 +59,48 @@ def test_two_rank_gather_over_gloo(tmp_path):
         assert f"rank {rank} ok" in o
 
 
+def test_bench_gpus_2_starts_its_own_ranks_and_prints_one_compact_line(tmp_path):
+    """`python bench.py --gpus 2` with NO rendezvous in the environment (how the driver invokes it): the parent starts two fresh child
+    ranks itself, they meet over gloo (--cpu-dry-run: the launcher / barrier / max-over-ranks / all-gather / emitter path with a
+    stand-in step), and stdout is exactly ONE JSON line within the driver's 8 KB tail."""
+    import json
+
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    det = tmp_path / "details.json"
+    r = subprocess.run([sys.executable, str(REPO / "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1", "--cpu-dry-run",
+                        "--details-out", str(det)], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = r.stdout.strip().splitlines()
+    assert len(lines) == 1 and len(lines[0]) <= 6000, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 4 and d["warmup"] == 1 and d["data"] == "dry-run" and d["scaling"] == "weak"
+    m = d["multi_gpu"]
+    assert m["world_size"] == 2 and m["backend"] == "gloo" and m["launcher"] == "self" and len(m["per_rank_ms_per_step"]) == 2
+    assert abs(d["ms_per_step"] - max(m["per_rank_ms_per_step"])) < 1e-3  # MAX over ranks
+    assert abs(d["value"] - d["config"]["frames_per_step"] / (d["ms_per_step"] * 1e-3)) <= 2e-2 * d["value"]
+    assert d["config"]["frames_per_step"] == 2 * 1024 * 2
+    assert json.loads(det.read_text())["multi_gpu"]["rank_devices"] == ["cpu-0", "cpu-1"]
+
+
+def test_bench_under_torchrun_contract_env(tmp_path):
+    """The other launch form (`python -m torch.distributed.run ... bench.py --gpus 2`): RANK / WORLD_SIZE come from the environment,
+    bench.py must not start children of its own."""
+    import json
+
+    port = 29500 + (os.getpid() % 2000) + 7
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, str(REPO / "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--cpu-dry-run",
+                                       "--details-out", str(tmp_path / f"d{rank}.json")], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=300) for p in procs]
+    assert all(p.returncode == 0 for p in procs), [o[1][-1500:] for o in outs]
+    assert outs[1][0].strip() == ""  # only rank 0 prints
+    d = json.loads(outs[0][0].strip())
+    assert d["multi_gpu"]["launcher"] == "torch.distributed.run" and d["n_gpus"] == 2
+
+
 @pytest.mark.gpu
 def test_rccl_observation_gather_single_rank_child_process(tmp_path):
     """RCCL smoke on the GPU box (the 8-GPU run must not also be the first RCCL run): a FRESH child process joins a 1-rank
