@@ -69,6 +69,8 @@ def parse(argv=None):
                     help="update the sensors of an env on one HIP stream each (+3.3 %% measured in round 3: 660 K vs 638 K frames/s; off by "
                          "default so that the per-kernel durations of a profile of this command stay those of kernels running alone - under "
                          "overlap rocprofv3 reports 1084 us for a tail launch that takes 762 us alone)")
+    ap.add_argument("--no-group", action="store_true",
+                    help="update the sensors of an env one by one (two launch sequences per step) instead of as one GelSightSensorGroup")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-sweep", action="store_true", help="skip the C2 / 512-shard / C4 / C5 sweep (N = 1 only)")
@@ -84,7 +86,7 @@ def parse(argv=None):
 
 
 def build_sensor(num_envs, H, W, markers, device, obs_res=None, obs_dtype="float32", fem_gelpad=None, cam_res=None, clip=(0.024, 0.029),
-                 grid=(11, 9)):
+                 grid=(11, 9), initialize=True):
     from tacex_amd import GelSightSensor, GelSightSensorCfg
     from tacex_amd.calibration import CALIB_GELSIGHT_MINI
     from tacex_amd.simulation_approaches.fots import FOTSMarkerSimulatorCfg
@@ -112,7 +114,8 @@ def build_sensor(num_envs, H, W, markers, device, obs_res=None, obs_dtype="float
         device=device,
     )
     s = GelSightSensor(cfg, gelpad_obj=fem_gelpad)
-    s.initialize()
+    if initialize:
+        s.initialize()
     return s
 
 
@@ -120,17 +123,24 @@ class Rig:
     """`n_sensors` GelSightSensors over one env shard + the packed observation; step() = one update of all of them."""
 
     def __init__(self, B, H, W, n_sensors, markers, dev, world, seed, gather="obs32", obs_dtype="u8", fem=None, sensor_streams=False,
-                 data="contacts", cam_res=None, clip=(0.024, 0.029), grid=(11, 9)):
+                 data="contacts", cam_res=None, clip=(0.024, 0.029), grid=(11, 9), group=True):
+        from tacex_amd import GelSightSensorGroup
         from tacex_amd.env_shard import ObservationGather
         from tacex_amd.utils.synthetic import dense_contact_depth_maps, synthetic_depth_maps
 
         self.B, self.H, self.W, self.n, self.markers, self.fem = B, H, W, n_sensors, markers, fem
         self.sensors, self.theta = [], torch.zeros(B, device=dev)
         self.streams = [torch.cuda.Stream(device=dev) for _ in range(n_sensors)] if (sensor_streams and n_sensors > 1) else []
+        # the sensors of an env (left / right finger) share one configuration: grouped, their frames are ONE 2B-frame launch sequence
+        # (GelSightSensorGroup; SURVEY section 8 C3).  group=False / one stream per sensor: two independent updates per step
+        self.grouped = bool(group and n_sensors > 1 and fem is None and not self.streams)
+        built = [build_sensor(B, H, W, markers, dev, obs_res=(32, 32) if gather == "obs32" else None,
+                              obs_dtype="uint8" if obs_dtype == "u8" else "float32",
+                              fem_gelpad=fem.gelpad if fem is not None else None, cam_res=cam_res, clip=clip, grid=grid,
+                              initialize=not self.grouped) for _ in range(n_sensors)]
+        self.group = GelSightSensorGroup(built) if self.grouped else None
         for k in range(n_sensors):
-            s = build_sensor(B, H, W, markers, dev, obs_res=(32, 32) if gather == "obs32" else None,
-                             obs_dtype="uint8" if obs_dtype == "u8" else "float32",
-                             fem_gelpad=fem.gelpad if fem is not None else None, cam_res=cam_res, clip=clip, grid=grid)
+            s = built[k]
             # synthetic camera depth (metres), already resident in HBM; a different seed per shard and sensor
             Wc, Hc = cam_res or (W, H)
             gen = dense_contact_depth_maps if data == "dense" else synthetic_depth_maps
@@ -157,6 +167,9 @@ class Rig:
             self.fem.step(i)
         vals = {}
         cur = torch.cuda.current_stream()
+        if self.grouped and self.markers:  # inputs of every member first: the first member's update evaluates the whole group
+            for s in self.sensors:
+                s.marker_motion_simulator.set_indenter_yaw(self.theta)
         for k, s in enumerate(self.sensors):
             # the sensors of an env are independent objects (left / right finger): each updates on its own HIP stream, so the
             # drain of one sensor's kernels overlaps the next one's launch sequence; the packing kernel waits for all of them
@@ -164,7 +177,7 @@ class Rig:
             if self.streams:
                 st.wait_stream(cur)
             with torch.cuda.stream(st):
-                if self.markers and self.fem is None:
+                if self.markers and self.fem is None and not self.grouped:
                     s.marker_motion_simulator.set_indenter_yaw(self.theta)
                 s.update(dt=0.01, force_recompute=True)
             if self.obs is not None:
@@ -323,8 +336,8 @@ def protocol_all_cores(ncpu, cap_s=5.0):
 def roofline_leg(rig, markers):
     """Per-stage hipEvent timing on the launch stream (library-side events, tacex_taxim_set_profiling), outside the timed
     region.  Durations are per LAUNCH; a launch covers `chunk` frames (large shards are walked in Infinity-Cache-sized chunks)."""
-    s = rig.sensors[0]
-    H, W, B = rig.H, rig.W, rig.B
+    s = rig.sensors[0]  # (a grouped member: its update evaluates the group's core sensor of n x B frames)
+    H, W, B = rig.H, rig.W, (rig.group.core._num_envs if rig.grouped else rig.B)
     taxim = s.optical_simulator._taxim
     chunk = taxim.chunk_frames((H, W), B)
     taxim.set_profiling((H, W), True)
@@ -473,6 +486,7 @@ def sweep(args, dev):
             out.append({"key": key, "workload": label, "error": f"{type(ex).__name__}: {ex}"[:300]})
 
     E = args.envs_per_gpu
+    run("c3_separate", f"C3 with the two sensors updated one by one (no GelSightSensorGroup): {E} envs x 2 sensors", E, 240, 320, 2, True, group=False)
     run("c3_no_gather", f"C3 without the observation gather / pack: {E} envs x 2 sensors, RGB 320x240 + FOTS markers", E, 240, 320, 2, True, gather="none")
     if not args.sensor_streams:
         run("c3_sensor_streams", f"C3 with one HIP stream per sensor: {E} envs x 2 sensors", E, 240, 320, 2, True, sensor_streams=True)
@@ -504,6 +518,7 @@ def sweep(args, dev):
 
 # What each sweep entry is, at length (goes to the details side file, never to the stdout line).
 SWEEP_NOTES = {
+    "c3_separate": "`--no-group`: two independent GelSightSensor.update() calls per step, each one launch sequence over its envs (rounds 1-4)",
     "c3_no_gather": "`--gather none`: the headline job without the 32x32 observation pack / all-gather",
     "c3_sensor_streams": "`--sensor-streams`: the left / right finger sensors of an env are independent objects; the drain and the small kernels of one "
                          "sensor's update overlap the other's.  NOT the default, because kernels that overlap have no duration of their own for the "
@@ -716,7 +731,7 @@ _ROOF_KEYS = ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", 
               "algorithmic_bytes_per_launch", "frac_own_bytes", "pipeline_frac", "valu_frac")
 _FEM_KEYS = ("hbm_frac", "hbm_achieved", "f64_frac", "lds_frac", "us_per_sweep", "sweeps_per_step", "newton_iters_per_step", "pcg_iters_per_newton")
 _CPU_KEYS = ("value", "unit", "cores", "kind", "logical_cores", "physical_cores")
-_SWEEP_SCALARS = {"c2": "value_c2", "c4": "value_c4", "c5": "value_c5", "c3_dense": "value_dense_contact", "c3_no_gather": "value_no_gather",
+_SWEEP_SCALARS = {"c3_separate": "value_c3_separate", "c2": "value_c2", "c4": "value_c4", "c5": "value_c5", "c3_dense": "value_dense_contact", "c3_no_gather": "value_no_gather",
                   "c3_sensor_streams": "value_sensor_streams", "c4_rolling": "value_c4_rolling", "c4_dhat5e4": "value_c4_dhat5e4",
                   "c5_optical": "value_c5_optical", "shard512": "value_shard512"}
 
@@ -726,7 +741,7 @@ def compact_line(full: dict, details_path: str | None) -> dict:
     keep = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data")
     line = {k: full[k] for k in keep}
     cfg = full["config"]
-    line["config"] = {k: cfg[k] for k in ("workload", "envs_per_gpu", "sensors_per_env", "frames_per_step", "resolution", "markers", "gather", "arch")
+    line["config"] = {k: cfg[k] for k in ("workload", "envs_per_gpu", "sensors_per_env", "frames_per_step", "resolution", "markers", "sensors", "gather", "arch")
                       if k in cfg}
     for e in cfg.get("sweep") or []:
         name = _SWEEP_SCALARS.get(e.get("key"))
@@ -854,7 +869,7 @@ def dry_run_rank(args):
     return emit(full, args.details_out) if shard.rank == 0 else None
 
 
-def headline_dict(args, value, elapsed, markers, arch, obs_bytes, sensor_streams_on=False, use_dist=False):
+def headline_dict(args, value, elapsed, markers, arch, obs_bytes, sensor_streams_on=False, use_dist=False, grouped=False):
     W, H = args.width, args.height
     frames_per_step = args.envs_per_gpu * args.sensors * args.gpus
     return {
@@ -868,7 +883,10 @@ def headline_dict(args, value, elapsed, markers, arch, obs_bytes, sensor_streams
             "envs_per_gpu": args.envs_per_gpu, "sensors_per_env": args.sensors, "frames_per_step": frames_per_step,
             "resolution": [W, H], "markers": markers,
             "gather": "none" if obs_bytes is None else f"obs32 {args.obs_dtype} ({obs_bytes} B/rank, " + ("1 all_gather/step)" if (args.gpus > 1 or use_dist) else "N=1: no collective)"),
-            "two_sensor_batching": BATCHING_NOTE + (", one HIP stream per sensor (joined before the observation is packed)" if sensor_streams_on else ""),
+            "sensors": ("group" if grouped else "separate"),
+            "two_sensor_batching": BATCHING_NOTE + (", evaluated as ONE GelSightSensorGroup: one launch sequence over the frames of both" if grouped else
+                                                    ", each one launch sequence over its envs")
+                                   + (", one HIP stream per sensor (joined before the observation is packed)" if sensor_streams_on else ""),
             "observation_gather": None if obs_bytes is None else {
                 "payload": f"per sensor: 32x32x3 {args.obs_dtype} RGB (antialiased, produced in the render pass) + f32 indentation"
                            + (" + f32 markers (2,99,2)" if markers else ""),
@@ -935,7 +953,7 @@ def main(argv=None):
 
     log(f"headline: {B} envs x {args.sensors} sensors, {W}x{H}, rank {shard.rank}/{shard.world_size}")
     rig = Rig(B, H, W, args.sensors, markers, dev, shard.world_size, seed=1 + shard.rank, gather=args.gather,
-              obs_dtype=args.obs_dtype, sensor_streams=args.sensor_streams)
+              obs_dtype=args.obs_dtype, sensor_streams=args.sensor_streams, group=not args.no_group)
     elapsed = rig.timed(args.steps, args.warmup, barrier)
     log(f"headline timed: {elapsed / args.steps * 1e3:.3f} ms/step")
     multi = None
@@ -963,7 +981,7 @@ def main(argv=None):
     # the sweep carries the `--gather none` entry
     if use_dist and args.gather != "none" and args.gpus > 1:
         rig2 = Rig(B, H, W, args.sensors, markers, dev, shard.world_size, seed=1 + shard.rank, gather="none", obs_dtype=args.obs_dtype,
-                   sensor_streams=args.sensor_streams)
+                   sensor_streams=args.sensor_streams, group=not args.no_group)
         e2 = rig2.timed(max(5, args.steps // 4), 2, barrier)
         t2 = torch.tensor([e2], device=dev, dtype=torch.float64)
         dist.all_reduce(t2, op=dist.ReduceOp.MAX)
@@ -977,6 +995,7 @@ def main(argv=None):
         roofline = roofline_leg(rig, markers)
     obs_bytes = None if rig.obs is None else rig.obs.payload_bytes()
     sensor_streams_on = bool(rig.streams)
+    grouped = rig.grouped
     del rig
     torch.cuda.empty_cache()
 
@@ -992,7 +1011,7 @@ def main(argv=None):
 
     text = None
     if shard.rank == 0:
-        full = headline_dict(args, value, elapsed, markers, _lib.require_gpu(shard.local_rank), obs_bytes, sensor_streams_on, use_dist)
+        full = headline_dict(args, value, elapsed, markers, _lib.require_gpu(shard.local_rank), obs_bytes, sensor_streams_on, use_dist, grouped)
         if multi is not None:
             full["multi_gpu"] = multi
         if sw is not None:

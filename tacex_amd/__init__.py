@@ -2,6 +2,7 @@
 from .gelsight_sensor import GelSightSensor
 from .gelsight_sensor_cfg import GelSightSensorCfg
 from .gelsight_sensor_data import GelSightSensorData
+from .gelsight_sensor_group import GelSightSensorGroup
 from .height_map_source import IndenterHeightMapSource, MeshDepthSource
 
-__all__ = ["GelSightSensor", "GelSightSensorCfg", "GelSightSensorData", "IndenterHeightMapSource", "MeshDepthSource"]
+__all__ = ["GelSightSensor", "GelSightSensorCfg", "GelSightSensorData", "GelSightSensorGroup", "IndenterHeightMapSource", "MeshDepthSource"]

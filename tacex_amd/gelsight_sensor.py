@@ -38,6 +38,7 @@ class GelSightSensor(SensorBase):
         self._is_spawned = False
         self._camera_depth_m = None
         self._height_map_version = 0
+        self._group = None  # set by GelSightSensorGroup: the member's buffers are views of the group's core sensor
         # SensorBase sets _num_envs / _device, which the simulator constructors read
         super().__init__(self.cfg)
 
@@ -92,6 +93,8 @@ class GelSightSensor(SensorBase):
     # -- depth injection (replaces TiledCamera, gelsight_sensor.py:229-263) ---------------------------------
     def set_camera_depth(self, depth_m: torch.Tensor):
         """Provide the camera depth image in metres: (num_envs, Hc, Wc) or (num_envs, Hc, Wc, 1), float32."""
+        if self._group is not None:
+            return self._group._set_member_depth(self, depth_m)
         if depth_m.dim() == 4:
             depth_m = depth_m[..., 0]
         W, H = self.camera_resolution
@@ -115,8 +118,12 @@ class GelSightSensor(SensorBase):
     def mark_height_map_dirty(self):
         """Call after writing `output["height_map"]` in place."""
         self._height_map_version += 1
+        if self._group is not None:
+            self._group.core.mark_height_map_dirty()
 
     def set_height_map_source(self, source):
+        if self._group is not None:
+            raise RuntimeError("a grouped sensor takes its height map from the camera depth or set_height_map (one source per group)")
         """Fill the height map from an on-device source (e.g. `IndenterHeightMapSource`) instead of a camera depth image
         (SURVEY 8f n1).  `source.fill(hm, frame_min, indent, gelpad_height, gelpad_to_camera_min_distance)`."""
         self._height_map_source = source
@@ -129,6 +136,8 @@ class GelSightSensor(SensorBase):
 
     # -- reset (gelsight_sensor.py:147-197) -----------------------------------------------------------------
     def reset(self, env_ids: Sequence[int] | None = None):
+        if self._group is not None:
+            return self._group._member_reset(self, env_ids)
         if not self._is_initialized:
             self.initialize()
             return
@@ -228,6 +237,8 @@ class GelSightSensor(SensorBase):
 
     # -- per-step update (gelsight_sensor.py:342-378) ------------------------------------------------------------
     def _update_buffers_impl(self, env_ids: Sequence[int]):
+        if self._group is not None:  # one evaluation for all sensors of the group (gelsight_sensor_group.py)
+            return self._group._member_update(self, env_ids)
         # like the reference, env_ids only selects which frame counters advance: all envs are recomputed
         if isinstance(env_ids, slice):
             self._frame_pending += 1

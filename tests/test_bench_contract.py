@@ -61,7 +61,7 @@ def test_stdout_line_is_compact_whatever_the_sweep_holds(tmp_path):
     d = json.loads(text)
     for k in HEAD_KEYS:
         assert k in d, k
-    assert set(d["config"]) == {"workload", "envs_per_gpu", "sensors_per_env", "frames_per_step", "resolution", "markers", "gather", "arch"}
+    assert set(d["config"]) == {"workload", "envs_per_gpu", "sensors_per_env", "frames_per_step", "resolution", "markers", "sensors", "gather", "arch"}
     assert {"bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "kernel_avg_ms", "frames_per_launch", "fem"} <= set(d["roofline"])
     assert {"f64_frac", "us_per_sweep", "sweeps_per_step", "pcg_stop"} <= set(d["roofline"]["fem"])
     assert {"value", "unit", "cores", "kind", "sample"} <= set(d["cpu_baseline"])

@@ -219,7 +219,7 @@ def test_full_baseline_batch_2048_frames_auto_chunked(calib_dir):
         s.initialize()
         return s
 
-    N, lo, n = 2048, 1111, 64
+    N, lo, n = 3200, 1611, 64  # (one streaming pass holds up to 2048 frames of 320x240; 3200 are walked as two passes of 1600)
     hm, _ = synthetic_depth_maps(N, 240, 320, seed=2048, device="cuda:0")
     depth = (hm / 1000.0).contiguous()
     big = sensor(N)
