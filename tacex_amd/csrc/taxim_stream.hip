@@ -30,6 +30,7 @@
 #include <stdint.h>
 #include <stdlib.h>
 
+#include <type_traits>
 #include <vector>
 
 #include "tacex_internal.h"
@@ -553,6 +554,9 @@ __global__ __launch_bounds__(64 * kStreamWaves, MINW) void taxim_stream_kernel(S
     const int off = lane < 24 ? (lane & 7) : 8 + (lane - 24) % kStreamMkSlots;
     return rows_i[r * kStreamRowInts + off];
   };
+  // steady iterations: every lane's record row is (y + 1) + a per-lane constant, inside the image -> offset from a scalar row base
+  const int info_off = ((lane >> 3) == 0 ? -(SUMR + 2) : (((lane >> 3) == 1 || (lane >= 24 && lane < 24 + kStreamMkSlots)) ? 0 : -SUMR)) * kStreamRowInts +
+                       (lane < 24 ? (lane & 7) : 8 + (lane - 24) % kStreamMkSlots);
   int cinfo = 0;  // the vector the current iteration's row scalars were unpacked from (marker slots in lanes 24..63)
   StreamRowInfo ri_g{}, ri_y{}, ri_z{};
   auto unpack_info = [&](int info) {
@@ -582,7 +586,17 @@ __global__ __launch_bounds__(64 * kStreamWaves, MINW) void taxim_stream_kernel(S
 #define TACEX_TICK(k) do { } while (0)
 #endif
   int ring_slot = ((ys % NRING) + NRING) % NRING;  // ring slot of row y (wave-uniform, advanced once per iteration)
+  // One iteration of the pipeline.  ST (compile time) = a STEADY iteration: the row entering (y .. y + 2), the row leaving the last
+  // level and the row shaded all lie inside the image and inside this wave's segment, away from the replicated border rows - no
+  // reflection of row indices, no "does this iteration shade / emit two rows" tests, the row-scalar fetch at a per-lane constant
+  // offset from a scalar base.  87 % of the iterations of a full-height item; the generic form runs the warm-up and the drain.
+#ifdef TACEX_STREAM_STEADY
+  auto iteration = [&](const int y, auto st_c) {
+    constexpr bool ST = decltype(st_c)::value;
+#else
   for (int y = flat ? ye + 1 : ys; y <= ye; ++y) {
+    constexpr bool ST = false;
+#endif
     // ---- row y out of the ring (it landed before the previous iteration's mid_point returned); next iteration's row scalars ----
 #ifdef TACEX_STREAM_CLOCK
     const long long ck0 = __builtin_readcyclecounter();
@@ -592,8 +606,8 @@ __global__ __launch_bounds__(64 * kStreamWaves, MINW) void taxim_stream_kernel(S
     tk_prev = __builtin_readcyclecounter();
     if (tk_on) clk8[8] += 1.0f;
 #endif
-    read_row(y & 1, row_of(y), zc, hc);
-    int ninfo = load_info(y + 1);
+    read_row(y & 1, ST ? y : row_of(y), zc, hc);
+    int ninfo = ST ? (rows_i + (y + 1) * kStreamRowInts)[info_off] : load_info(y + 1);
     asm volatile("" : "+v"(zc[0]), "+v"(zc[1]), "+v"(zc[2]));
     TACEX_TICK(0);  // row read-back
     // The ONE point of the iteration where this wave waits for memory: every plain load of the iteration (row scalars,
@@ -610,14 +624,14 @@ __global__ __launch_bounds__(64 * kStreamWaves, MINW) void taxim_stream_kernel(S
       ck2 = __builtin_readcyclecounter();
 #endif
       TACEX_TICK(5);  // the memory wait
-      issue_row(row_of(y + 2), y & 1);
+      issue_row(ST ? y + 2 : row_of(y + 2), y & 1);
     };
 
     // ---- shading, part 1 (runs between level 0 and level 1, see below): bins of row gs, background loads in flight.
     //      Replicate padding of the gradient maps (TT:501-502): rows 0 / H-1 take the gradient of rows 1 / H-2 and are emitted
     //      together with them; columns 0 / W-1 take the bins of columns 1 / W-2. ----
     const int gs = y - SUMR - 2;
-    const bool shade_now = SHADE && gs >= max(r0, 1) && gs <= min(r1 - 1, H - 2);
+    const bool shade_now = SHADE && (ST || (gs >= max(r0, 1) && gs <= min(r1 - 1, H - 2)));
     int cc[PX] = {0, 0, 0};  // table record (bin pair) of every pixel of row gs
     StreamRec pc[PX];        // its 18 polynomial coefficients (TT:250-255), fetched at the top of the iteration
     auto fetch_table = [&]() {
@@ -726,7 +740,7 @@ __global__ __launch_bounds__(64 * kStreamWaves, MINW) void taxim_stream_kernel(S
         else ring[ring_slot * 64 + lane] = (v4f){S[0], S[1], S[2], 0.0f};
         ring_slot = ring_slot + 1 == NRING ? 0 : ring_slot + 1;
       }
-      if (do_fots && y >= r0 && y < r1) {
+      if (do_fots && (ST || y >= r0) && y < r1) {
         float gl[PX] = {0.f, 0.f, 0.f};
         if constexpr (!GZ) {
           const unsigned ro = (unsigned)row_of(y) * (unsigned)W;
@@ -846,7 +860,7 @@ __global__ __launch_bounds__(64 * kStreamWaves, MINW) void taxim_stream_kernel(S
       // ---- cur = last-level row zr = y - SUMR ----
       if constexpr (!SHADE) mid_point();
       const int zr = y - SUMR;
-      if (zr >= r0 && zr < r1) {
+      if ((ST || zr >= r0) && zr < r1) {
         if (do_fots) {
 #pragma unroll
           for (int i = 0; i < PX; ++i) f_zmax = valid[i] ? fmaxf(f_zmax, cur[i]) : f_zmax;
@@ -897,7 +911,9 @@ __global__ __launch_bounds__(64 * kStreamWaves, MINW) void taxim_stream_kernel(S
                      "+v"(bgq[2]));
       }
       mid_point();
-      if (shade_now) {
+      if constexpr (ST) {
+        emit_row(gs, ri_g, bgq, pc);
+      } else if (shade_now) {
         const int e_lo = gs == 1 ? 0 : gs, e_hi = gs == H - 2 ? H - 1 : gs;  // rows emitted by this iteration (ascending)
         for (int e = e_lo; e <= e_hi; ++e) {
           if (e < r0 || e >= r1) continue;
@@ -923,7 +939,23 @@ __global__ __launch_bounds__(64 * kStreamWaves, MINW) void taxim_stream_kernel(S
       if (ck1 != 0) { clk_acc[0] += (float)(ck1 - ck0); clk_acc[1] += (float)(ck2 - ck1); clk_acc[2] += (float)(ck3 - ck2); clk_acc[3] += 1.0f; }
     }
 #endif
+#ifdef TACEX_STREAM_STEADY
+  };
+  {
+    // BUILT AND MEASURED SLOWER (round 5, profiles/r05_experiments.md section 2): the steady loop is 1155 instructions against 1306 and holds
+    // 41 SGPR-spill reloads against 84, but with three loop bodies in the function the allocator spills 85 SGPRs (64 before), 20 of them
+    // beyond the spill VGPR into scratch (80 B/lane): 871 us per 1024 frames against 805.  Kept behind the macro as the A/B partner.
+    // steady range: gs = y - SUMR - 2 in [max(r0, 2), min(r1 - 1, H - 3)] (shades exactly one row), y + 2 <= H - 1 (no reflection);
+    // its lower end implies y >= r0, zr >= r0 and non-negative rows in the row-scalar fetch
+    int y = flat ? ye + 1 : ys;
+    const int st_lo = SHADE ? max(r0, 2) + SUMR + 2 : ye + 1, st_hi = SHADE ? min(min(r1 - 1, H - 3) + SUMR + 2, H - 3) : ye;
+    for (; y <= ye && y < st_lo; ++y) iteration(y, std::false_type{});
+    for (; y <= st_hi; ++y) iteration(y, std::true_type{});
+    for (; y <= ye; ++y) iteration(y, std::false_type{});
   }
+#else
+  }
+#endif
 #ifdef TACEX_STREAM_CLOCK8
   if (lane == 0 && SHADE) {
     float* dbg = a.sh.rgb + fo * 3 + rem * 9;
