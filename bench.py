@@ -502,6 +502,8 @@ def sweep(args, dev):
         512, 240, 320, 1, False, fem=lambda: FemGelpad(512, dev, max_newton_iter=NEWTON_CAP))
     run("c4_dhat5e4", "C4 per-GPU shard with the reference scenes' contact zone d_hat = 5e-4 (ball_rolling_uipc.py:71-75)",
         512, 240, 320, 1, False, fem=lambda: FemGelpad(512, dev, max_newton_iter=NEWTON_CAP, side_stream=True, d_hat=5e-4))
+    run("c4_lag_ipc", "C4 per-GPU shard with IPC's previous-configuration friction lag (cfg.contact.friction_lag = 'ipc') instead of the reaction-capped default",
+        512, 240, 320, 1, False, fem=lambda: FemGelpad(512, dev, max_newton_iter=NEWTON_CAP, side_stream=True, friction_lag="ipc"))
     run("c4_rolling", "C4 shard, rolling contact: the indenter stays on the pad and slides, friction on",
         512, 240, 320, 1, False, fem=lambda: FemGelpad(512, dev, motion="rolling", max_newton_iter=NEWTON_CAP, side_stream=True))
     run("c5", "C5 per-GPU shard: 1024 envs, RGB 640x480 + FEM-driven markers (gelpad FEM step included) (BASELINE configs[4] / 8)",
@@ -594,11 +596,8 @@ def fem_axle_entry(dev, B=512, steps=12, streaming=False, tol_rate=None, key="ax
         t0 = time.perf_counter()
         for i in range(steps):
             step(3 + i)
-            if streaming:
-                its = torch.clamp(its, min=float(sim.last_newton_iters))  # (synchronises: that path launches one kernel per Newton iteration anyway)
-            else:
-                its = torch.maximum(its, sim.step_info[:, 0].max())
-                flagged = torch.maximum(flagged, (sim.step_info[:, 2].to(torch.int64) & 3).max().to(torch.float64))  # penetration / failed line search
+            its = torch.maximum(its, sim.step_info[:, 0].max())  # (the streaming path accumulates its per-launch counts in the same row)
+            flagged = torch.maximum(flagged, (sim.step_info[:, 2].to(torch.int64) & 3).max().to(torch.float64))  # penetration / failed line search
         torch.cuda.synchronize()
         el = time.perf_counter() - t0
         finite, gap = bool(torch.isfinite(sim.x).all()), float(sim.contact_gaps().amin())
@@ -606,7 +605,7 @@ def fem_axle_entry(dev, B=512, steps=12, streaming=False, tol_rate=None, key="ax
         assert float(its) < AXLE_NEWTON_CAP, f"an env ran into the Newton cap of {AXLE_NEWTON_CAP}"
         return {"key": key, "workload": f"FEM only: {B} envs x simple_axle.msh, sphere contact: {name}",
                 "envs": B, "steps": steps, "ms_per_step": round(el / steps * 1e3, 3), "env_steps_per_s": round(B * steps / el, 1),
-                "newton_iters_max": None if streaming else int(its),  # (the streaming path leaves step_info zero: one launch per iteration on a fixed schedule)
+                "newton_iters_max": int(its),
                 "newton_cap": AXLE_NEWTON_CAP, "pcg_tol_rate": cfg.linear_system.tol_rate, "failure_flags_max": int(flagged), "velocity_tol": 2e-3}
     except Exception as ex:
         return {"key": key, "workload": f"FEM only: simple_axle.msh on {name}", "error": f"{type(ex).__name__}: {ex}"[:300]}
@@ -732,7 +731,7 @@ _ROOF_KEYS = ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", 
 _FEM_KEYS = ("hbm_frac", "hbm_achieved", "f64_frac", "lds_frac", "us_per_sweep", "sweeps_per_step", "newton_iters_per_step", "pcg_iters_per_newton")
 _CPU_KEYS = ("value", "unit", "cores", "kind", "logical_cores", "physical_cores")
 _SWEEP_SCALARS = {"c3_separate": "value_c3_separate", "c2": "value_c2", "c4": "value_c4", "c5": "value_c5", "c3_dense": "value_dense_contact", "c3_no_gather": "value_no_gather",
-                  "c3_sensor_streams": "value_sensor_streams", "c4_rolling": "value_c4_rolling", "c4_dhat5e4": "value_c4_dhat5e4",
+                  "c3_sensor_streams": "value_sensor_streams", "c4_rolling": "value_c4_rolling", "c4_lag_ipc": "value_c4_lag_ipc", "c4_dhat5e4": "value_c4_dhat5e4",
                   "c5_optical": "value_c5_optical", "shard512": "value_shard512"}
 
 

@@ -32,7 +32,7 @@ extern "C" {
 #endif
 
 #define TACEX_MAX_LEVELS 8
-#define TACEX_ABI_VERSION 8
+#define TACEX_ABI_VERSION 9
 
 typedef struct tacex_taxim_ctx tacex_taxim_ctx;
 typedef struct tacex_fots_ctx tacex_fots_ctx;
@@ -376,6 +376,16 @@ int tacex_fem_set_contact(tacex_fem_ctx* ctx, const double* vertex_area_host, do
  * Acts inside tacex_fem_step only (tacex_fem_newton_step has no notion of the step's start).  friction_ratio 0 = off. */
 int tacex_fem_set_friction(tacex_fem_ctx* ctx, double friction_ratio, double eps_velocity);
 
+/* WHERE the friction lag (normal force lam and normal n per contact vertex, frozen for the time step) is taken:
+ *   1 - IPC's rule to the letter (Li et al. 2020, section 5.4, "lagged from the previous time step"): barrier force and normal of the
+ *       PREVIOUS configuration, i.e. the positions the step starts from against the indenter where it stood at the previous step;
+ *   0 - (round 4) at the step's start positions against the indenter's NEW position, the force capped by the contact reaction there.
+ * Both are the previous step's normal force where that step converged tightly and the indenter approaches; they differ when it
+ * retreats (0 takes the smaller, already relaxed barrier force) and at loose Newton tolerances.  Only mode 1 makes the step's end
+ * state a stationary point of the plain incremental potential of IPC (tests/test_fem_physics_gpu.py); mode 0 (the default) is the
+ * one that stays bounded at the reference's default Newton tolerance, where the previous configuration is not in balance. */
+int tacex_fem_set_friction_lag(tacex_fem_ctx* ctx, int mode);
+
 /* Contact-following start of tacex_fem_step's Newton loop (default on): a surface vertex inside the barrier zone of the indenter's
  * previous position starts the iteration displaced by the indenter's translation since the previous step (its gap is what it was).
  * An initial guess only - the step's minimiser is unchanged - but the one that lets a RETREATING indenter cost 2-3 Newton iterations
@@ -456,6 +466,18 @@ int tacex_fem_step(tacex_fem_ctx* ctx, double* x_dev, double* v_dev, double* x_t
                    const double* aim_dev, double* stats_dev, double* step_info_dev, void* workspace_dev, int num_envs,
                    const double gravity[3], int max_newton, double velocity_tol, int pcg_max_iter, double pcg_tol_rate,
                    int ls_max_iter, void* stream);
+
+/* Per-env reset of the FEM state - what `UipcObject.reset(env_ids)` / `write_vertex_positions_to_sim(vertex_positions, env_ids)`
+ * (source/tacex_uipc/tacex_uipc/objects/uipc_object.py:280-370; `reset` is a TODO stub there, the write ignores env_ids) are for: an
+ * RL task puts ONE env's gelpad back while the others go on.  For every env of env_ids_dev (num_reset,) int32 (NULL: all num_envs):
+ *   x <- positions_dev (num_reset, V, 3) f64 when given, else the rest positions of tacex_fem_create;   v <- 0;
+ *   step_info row <- 0 (nullable);   the indenter position the friction displacement of the NEXT tacex_fem_step is measured from
+ *   <- none (the env's next step sees no sliding, like the first step of a fresh scene, wherever its indenter is put meanwhile).
+ * Nothing else of the solver survives a time step (friction lag, warm start, lagged preconditioner blocks and x_prev are rebuilt
+ * by every tacex_fem_step), so the next step of a reset env is bit-identical to the first step of a fresh context in deterministic
+ * mode.  workspace_dev: the workspace tacex_fem_step runs with (nullable before the first step).  Enqueued on `stream`. */
+int tacex_fem_reset_envs(tacex_fem_ctx* ctx, const int32_t* env_ids_dev, int num_reset, const double* positions_dev, double* x_dev,
+                         double* v_dev, double* step_info_dev, void* workspace_dev, int num_envs, void* stream);
 
 /* Attachment animation (UA:364-428: `_compute_aim_positions` + the animator callback `animate_tet` UA:365-385) for all envs:
  *   aim_position[b, idx[a]] = R(body_quat[b]) * offsets[a] + body_pos[b];  is_constrained[b, idx[a]] = 1

@@ -807,12 +807,20 @@ def fem_step(m: "FemModel", cm, x, v, constrained=None, aim=None, gravity=(0.0, 
         dm, _ = contact_distance(cm.ind, np.where(cand[:, None], xm, x), cm.mesh)
         follow = cand & (dm > 0) & (dm < cm.dhat)
         x = np.where(follow[:, None], xm, x)
-    # friction = (mu, eps_velocity, indenter displacement since the previous step), see FrictionModel.  friction_lag = "start" (the
-    # kernel's default): normal force and normal are lagged at the state the step starts from - the previous step's equilibrium, IPC's
+    # friction = (mu, eps_velocity, indenter displacement since the previous step), see FrictionModel.  friction_lag = "ipc": IPC's
+    # previous-configuration lag (`tacex_fem_set_friction_lag(ctx, 1)`, below); "start" (the kernel's default, mode 0): normal force and normal are lagged at the state the step starts from - the previous step's equilibrium, IPC's
     # lag "from the previous time step" - and friction acts from the first iteration on; "converged" (rounds 3-4, TACEX_FEM_FRIC_LAG=0):
     # the lag is taken where this step's normal-contact solve converged, in a second phase of the loop
-    fric_pending = friction is not None and cm is not None and friction_lag != "start"
+    fric_pending = friction is not None and cm is not None and friction_lag not in ("start", "ipc")
     fr = None
+    if friction is not None and cm is not None and friction_lag == "ipc":
+        # IPC's lag to the letter (Li et al. 2020, section 5.4): barrier force and normal of the PREVIOUS configuration - the start
+        # positions against the indenter where it stood at the previous step; no cap, nothing of the current iterate
+        ind_prev = np.array(cm.ind, np.float64)
+        ind_prev[1:4] -= np.asarray(friction[2], np.float64)
+        fr = FrictionModel(ContactModel(cm.area, ind_prev, cm.dhat, cm.kappa, cm.dt, cm.mesh), x0, friction[2], friction[0], friction[1])
+        if not fr.lam.max() > 0.0:
+            fr = None
     if friction is not None and cm is not None and friction_lag == "start":
         fr = FrictionModel(cm, x0, friction[2], friction[0], friction[1])
         fr.update(x, m.gradient(x, xt, constrained, aim))

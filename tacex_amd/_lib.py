@@ -11,7 +11,7 @@ from pathlib import Path
 from ._build import LIB, build_library
 
 MAX_LEVELS = 8
-ABI_VERSION = 8  # TACEX_ABI_VERSION of include/tacex_hip.h; bumped whenever a signature or struct layout changes
+ABI_VERSION = 9  # TACEX_ABI_VERSION of include/tacex_hip.h; bumped whenever a signature or struct layout changes
 FLAG_NO_SHIFT = 1
 FLAG_HAVE_FRAME_MIN = 2
 FLAG_WITH_SHADOW = 4
@@ -138,6 +138,8 @@ SIGNATURES = {
     "tacex_fem_set_chains": (_i, [_vp, _i, _vp, _vp]),
     "tacex_fem_set_indenter_mesh": (_i, [_vp, _i, _vp, _i, _vp]),
     "tacex_fem_contact_gaps": (_i, [_vp, _vp, _vp, _i, _vp]),
+    "tacex_fem_set_friction_lag": (_i, [_vp, _i]),
+    "tacex_fem_reset_envs": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp]),
     "tacex_fem_set_friction": (_i, [_vp, _d, _d]),
     "tacex_fem_set_contact_following": (_i, [_vp, _i]),
     "tacex_fem_set_deterministic": (_i, [_vp, _i]),

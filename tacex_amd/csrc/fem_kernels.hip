@@ -314,6 +314,7 @@ template <typename T>
 __device__ __forceinline__ T ldg_off(const void* base, unsigned byte_off) {
   return *reinterpret_cast<const T*>(static_cast<const char*>(base) + byte_off);
 }
+
 // a value the optimiser must treat as unknown: address arithmetic built on it is recomputed where it is used (a few integer
 // operations) instead of being hoisted out of the enclosing loops and kept live - or spilled - across them
 __device__ __forceinline__ unsigned opaque_u32(unsigned v) {
@@ -703,9 +704,18 @@ __device__ __forceinline__ bool inv3_spd(const double A[9], double Ai[9]) {
   return true;
 }
 
+// flags of step_info[., 2]
+constexpr int kFemFlagPenetration = 1;  // a contact vertex was at or beyond the indenter surface when the iteration started
+constexpr int kFemFlagLsFailed = 2;     // a line search found no decrease even after the rescue halvings
+constexpr int kFemFlagCoarseOff = 4;    // informational: the coarse correction was switched off for the rest of the step (see kCoarseTrust)
+constexpr int kFemFlagPsdSafe = 8;      // informational: the PCG met negative curvature and the env solved iterations of the step in PSD-safe mode
 __global__ __launch_bounds__(512) void fem_newton_kernel(FemDev m, double* xg, const double* xtg, const uint8_t* consg,
                                                          const double* aimg, double* stats, double* wsg,
-                                                         int pcg_max_iter, double pcg_tol_rate, int ls_max_iter, double* dxg, double dx_tol) {
+                                                         int pcg_max_iter, double pcg_tol_rate, int ls_max_iter, double* dxg, double dx_tol,
+                                                         double* step_info, int accumulate) {
+  // step_info (nullable): the row of this env [Newton iterations, max |d|, flags, PCG iterations] - SET by the first launch of a time
+  // step (accumulate = 0), added to / OR-ed by the later ones: tacex_fem_step runs this kernel once per Newton iteration, and
+  // UipcSim.check_step() must see a penetrating vertex or a dead line search of ANY of them (the row used to be zeroed)
   __shared__ double sh[17];
   const int b = blockIdx.x;
   if (dxg && dxg[b] <= dx_tol) {  // converged in an earlier launch of this time step (same protocol as the CU-resident kernel)
@@ -757,6 +767,7 @@ __global__ __launch_bounds__(512) void fem_newton_kernel(FemDev m, double* xg, c
   }
   __syncthreads();
   // ---- nodal gradient + block-Jacobi preconditioner (vertex gather; diagonal blocks recomputed per incidence) ----
+  int pen = 0;  // a contact vertex of this thread sits at or beyond its indenter's surface (kFemFlagPenetration)
   for (int v = threadIdx.x; v < V; v += blockDim.x) {
     double a3[3];
     gather_vertex(m, ge, v, a3);
@@ -768,6 +779,7 @@ __global__ __launch_bounds__(512) void fem_newton_kernel(FemDev m, double* xg, c
     {
       const double xv[3] = {x[v * 3], x[v * 3 + 1], x[v * 3 + 2]};
       const ContactEval ce = contact_eval(m, ind, ind ? m.area[v] : 0.0, xv);
+      if (ce.penetrating) pen = 1;
       const double cb2 = ce.active ? dt2 * ce.b2 : 0.0;
       cdat[(size_t)v * 5] = cb2;
       cdat[(size_t)v * 5 + 1] = ce.n[0]; cdat[(size_t)v * 5 + 2] = ce.n[1]; cdat[(size_t)v * 5 + 3] = ce.n[2];
@@ -828,7 +840,7 @@ __global__ __launch_bounds__(512) void fem_newton_kernel(FemDev m, double* xg, c
       vd[v * 3 + i] = 0.0;
     }
   }
-  __syncthreads();
+  const int any_pen = __syncthreads_or(pen);
   // z = Dinv r ; p = z ; rz
   double part = 0.0;
   for (int v = threadIdx.x; v < V; v += blockDim.x) {
@@ -929,6 +941,12 @@ __global__ __launch_bounds__(512) void fem_newton_kernel(FemDev m, double* xg, c
     }
     step = -block_sum_max(-amax, sh);
   }
+  // max |d| of the unscaled Newton direction (the convergence test; also caps the search: no vertex starts further than the body is long,
+  // the direction kept on negative curvature has no length scale - same rule as the CU-resident kernel)
+  double dmax = 0.0;
+  for (int k = threadIdx.x; k < 3 * V; k += blockDim.x) dmax = fmax(dmax, fabs(vd[k]));
+  dmax = block_sum_max(dmax, sh);
+  if (dmax > m.step_cap) step = fmin(step, m.step_cap / dmax);
   bool accepted = false;
   const int ls_cap = ind ? (ls_max_iter > kLsRescueStream ? ls_max_iter : kLsRescueStream) : ls_max_iter;
   for (int ls = 0; ls <= ls_cap; ++ls) {
@@ -943,22 +961,17 @@ __global__ __launch_bounds__(512) void fem_newton_kernel(FemDev m, double* xg, c
   } else {
     step = 0.0;
   }
-  if (dxg) {  // max |d| of the unscaled Newton direction; the env counts as converged only after a full accepted step
-    double md = 0.0;
-    for (int k = threadIdx.x; k < 3 * V; k += blockDim.x) md = fmax(md, fabs(vd[k]));
-#pragma unroll
-    for (int o2 = 32; o2 > 0; o2 >>= 1) md = fmax(md, __shfl_xor(md, o2, 64));
-    __syncthreads();
-    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = md;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      double v = 0.0;
-      for (int w = 0; w < (int)(blockDim.x >> 6); ++w) v = fmax(v, sh[w]);
-      dxg[b] = v;  // max |d| of the unscaled direction: <= dx_tol = converged (same rule as the CU-resident kernel)
-    }
-  }
   if (threadIdx.x == 0) {
+    if (dxg) dxg[b] = dmax;  // max |d| of the unscaled direction: <= dx_tol = converged (same rule as the CU-resident kernel)
     stats[(size_t)b * 4 + 0] = E0; stats[(size_t)b * 4 + 1] = E1; stats[(size_t)b * 4 + 2] = step; stats[(size_t)b * 4 + 3] = (double)it;
+    if (step_info) {
+      const int fl = (any_pen ? kFemFlagPenetration : 0) | ((!accepted && !(dmax <= dx_tol)) ? kFemFlagLsFailed : 0);
+      double* si = step_info + (size_t)b * 4;
+      si[0] = (accumulate ? si[0] : 0.0) + 1.0;
+      si[1] = dmax;
+      si[2] = (double)((accumulate ? (int)si[2] : 0) | fl);
+      si[3] = (accumulate ? si[3] : 0.0) + (double)it;
+    }
   }
 }
 
@@ -1069,11 +1082,6 @@ __device__ __forceinline__ double block_min1(double v, double* sh2, int& phase) 
 // the barrier it runs into (soft gel, 10 GPa contact resistance: the admissible step can be 1e-3 of the CCD bound), and an env
 // whose search failed would otherwise repeat the same failing iteration until the iteration cap.
 constexpr int kLsRescue = 32;
-// flags of step_info[., 2]
-constexpr int kFemFlagPenetration = 1;  // a contact vertex was at or beyond the indenter surface when the iteration started
-constexpr int kFemFlagLsFailed = 2;     // a line search found no decrease even after the rescue halvings
-constexpr int kFemFlagCoarseOff = 4;    // informational: the coarse correction was switched off for the rest of the step (see kCoarseTrust)
-constexpr int kFemFlagPsdSafe = 8;      // informational: the PCG met negative curvature and the env solved iterations of the step in PSD-safe mode
 // PSD-SAFE MODE.  The Stable Neo-Hookean Hessian is applied matrix-free and unprojected: aI + b f f^T + lam c c^T + c_J d2J/dF2, whose last
 // term is indefinite (eigenvalues +-sigma_k).  On the gelpad - a thin pad held on its whole back face - the sum stays positive definite
 // along the directions the PCG visits; a slender body bent by its indenter (simple_axle held at its ends) has compressed elements with
@@ -1357,7 +1365,6 @@ __global__ __launch_bounds__(NT) void fem_newton_lds_kernel(FemDev m, double* xg
   const bool lag_at_start = (follow & 2) != 0;
   bool fric_phase = fric && lag_at_start;   // friction terms are on (see friction_eval)
   bool lag_pending = fric && lag_at_start;  // the friction lag is taken in this iteration (behind the gradient and the contact evaluation)
-  bool lag_valid = false;  // the workspace holds the elastic preconditioner blocks of this launch
   bool use_coarse = m.nc > 0;  // (block-uniform) false once the safeguard of kCoarseTrust has fired
   bool psd_safe = false;       // (block-uniform) see kFemFlagPsdSafe
   for (int nit = 0; nit < max_newton; ++nit) {
@@ -1418,13 +1425,27 @@ restart_iteration:
     lag_pending = false;
     double lam = 0.0;
     if (own) {
-      if (ce.active) {
+      double ln[3] = {ce.n[0], ce.n[1], ce.n[2]};
+      if (follow & 4) {
+        // IPC's lag to the letter (Li et al. 2020, section 5.4: lam^n, T^n "from the previous time step"): the barrier force and the normal
+        // of the PREVIOUS configuration - the positions the step starts from against the indenter where it stood then (its row moved
+        // back by the displacement since the previous step).  That configuration is the previous step's equilibrium, so this IS the
+        // previous normal force; no cap, nothing of the current iterate enters (tacex_fem_set_friction_lag, mode 1).
+        double indp[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) indp[k] = ind[k];
+        indp[1] -= disp3[0]; indp[2] -= disp3[1]; indp[3] -= disp3[2];
+        const double xn3[3] = {xn[tid * 3], xn[tid * 3 + 1], xn[tid * 3 + 2]};
+        const ContactEval cp = contact_eval<MESH>(m, indp, wv, xn3);
+        lam = (cp.active && !cp.penetrating) ? -cp.b1 : 0.0;
+        ln[0] = cp.n[0]; ln[1] = cp.n[1]; ln[2] = cp.n[2];
+      } else if (ce.active) {
         const double react = (go3[0] * ce.n[0] + go3[1] * ce.n[1] + go3[2] * ce.n[2]) / dt2;
         lam = fmin(-ce.b1, fmax(react, 0.0));
       }
       const bool on = lam > 0.0;
       fl[tid * 4] = on ? lam : 0.0;
-      fl[tid * 4 + 1] = on ? ce.n[0] : 0.0; fl[tid * 4 + 2] = on ? ce.n[1] : 0.0; fl[tid * 4 + 3] = on ? ce.n[2] : 0.0;
+      fl[tid * 4 + 1] = on ? ln[0] : 0.0; fl[tid * 4 + 2] = on ? ln[1] : 0.0; fl[tid * 4 + 3] = on ? ln[2] : 0.0;
     }
     if (!__syncthreads_or(lam > 0.0)) {  // no vertex carries a normal force: nothing for friction to act on
       if (!lag_at_start) { done = true; break; }  // (two-phase mode: normal contact had converged, the step is done)
@@ -1456,121 +1477,20 @@ restart_iteration:
   {
     double D[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     double E[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-    const bool lag_fresh = !lag_valid || lagg == nullptr;
-    double* lagw = lagg ? lagg + (size_t)b * 15 * V : nullptr;  // [15][V]: D upper triangle (6) | E (9), elastic part only
-    if (own && !lag_fresh) {
-      D[0] = lagw[0 * V + tid]; D[1] = lagw[1 * V + tid]; D[2] = lagw[2 * V + tid]; D[4] = lagw[3 * V + tid]; D[5] = lagw[4 * V + tid];
-      D[8] = lagw[5 * V + tid];
+    // elastic part of D / E: assembled for ALL envs of the launch by fem_assemble_blocks_kernel ahead of this kernel, at the state the
+    // launch starts from, (V,16) per env in the workspace (round 5; rounds 3-4 assembled it here in the first iteration of a launch -
+    // 111 K of a pressing step's 268 K cycles, and the part of this kernel the register allocator spilled most for)
+    if (own) {
+      // one 128-byte record per vertex: D upper triangle (6) | E (9) | pad - ONE address (rebuilt here from a fresh thread id, never
+      // carried across the PCG loop: fifteen hoisted [15][V] row addresses were 30 of the kernel's spilled registers)
+      const double* q = lagg + ((size_t)b * V + (size_t)fresh_tid(wave_s)) * 16;
+      D[0] = q[0]; D[1] = q[1]; D[2] = q[2]; D[4] = q[3]; D[5] = q[4]; D[8] = q[5];
       D[3] = D[1]; D[6] = D[2]; D[7] = D[5];
 #pragma unroll
-      for (int k = 0; k < 9; ++k) E[k] = lagw[(6 + k) * V + tid];
-    }
-    if constexpr (ATOM) {
-      // TET-CENTRIC assembly (the atomic variant of the kernel): every tet's state is computed ONCE - the vertex-centric loop below computes it
-      // once per incident vertex, four times - and its shares of the four diagonal blocks (upper triangles) and of the chain blocks
-      // (v, next(v)) are added into the (V,15) exchange array with ds_add_f64; a vertex then reads its 15 entries back.  Tets come
-      // through the wave-blocked table (coalesced) instead of one AoS record per lane.
-      if (lag_fresh) {  // (block-uniform)
-        double* xa = ps;  // the exchange array of the factorisation below
-        __syncthreads();  // the gradient sweep's accumulators (inside this region) have been read by their vertices
-        for (int k = tid; k < 15 * V; k += NT) xa[k] = 0.0;
-        __syncthreads();
-        for (int t = tid; t < T; t += NT) {
-          int v[4];
-          double Di[9], F[9], r[12], vol_t;
-          load_tet_blk(m, t, v, Di, vol_t);
-          deformation_gradient(xs, v, Di, F);
-          TetState s;
-          tet_state(m, F, s);
-          shape_rows(Di, r);
-          const double sc = dt2 * vol_t;
-#pragma unroll
-          for (int l = 0; l < 4; ++l) {
-            double* q = xa + v[l] * 15;
-#pragma unroll
-            for (int k = 0; k < 3; ++k) {
-              double dF[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, dP[9];
-              dF[k * 3 + 0] = r[l * 3 + 0]; dF[k * 3 + 1] = r[l * 3 + 1]; dF[k * 3 + 2] = r[l * 3 + 2];
-              apply_dP(m, s, dF, dP);
-#pragma unroll
-              for (int i = 0; i <= k; ++i)  // upper triangle: (0,0) (0,1) (1,1) (0,2) (1,2) (2,2) -> q[0], q[1], q[3], q[2], q[4], q[5]
-                atomicAdd(&q[i == 0 ? k : (i == 1 ? 2 + k : 5)],
-                          sc * (dP[i * 3 + 0] * r[l * 3 + 0] + dP[i * 3 + 1] * r[l * 3 + 1] + dP[i * 3 + 2] * r[l * 3 + 2]));
-            }
-            const int nv = cnx[v[l]] == 0xffff ? -1 : (int)cnx[v[l]];
-            const int l2 = nv < 0 ? -1 : (v[0] == nv ? 0 : (v[1] == nv ? 1 : (v[2] == nv ? 2 : (v[3] == nv ? 3 : -1))));
-            if (l2 >= 0) {  // this tet also holds the chain successor of vertex l: its share of the block (v_l, next(v_l))
-              const double rn[3] = {r[l2 * 3 + 0], r[l2 * 3 + 1], r[l2 * 3 + 2]};
-#pragma unroll
-              for (int k = 0; k < 3; ++k) {
-                double dF[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, dP[9];
-                dF[k * 3 + 0] = rn[0]; dF[k * 3 + 1] = rn[1]; dF[k * 3 + 2] = rn[2];
-                apply_dP(m, s, dF, dP);
-#pragma unroll
-                for (int i = 0; i < 3; ++i)
-                  atomicAdd(&q[6 + i * 3 + k], sc * (dP[i * 3 + 0] * r[l * 3 + 0] + dP[i * 3 + 1] * r[l * 3 + 1] + dP[i * 3 + 2] * r[l * 3 + 2]));
-              }
-            }
-          }
-        }
-        __syncthreads();
-        if (own) {
-          const double* q = xa + tid * 15;
-          D[0] = q[0]; D[1] = q[1]; D[2] = q[2]; D[4] = q[3]; D[5] = q[4]; D[8] = q[5];
-          D[3] = D[1]; D[6] = D[2]; D[7] = D[5];
-#pragma unroll
-          for (int k = 0; k < 9; ++k) E[k] = q[6 + k];
-        }
-      }
-    }
-    if (!ATOM && own && lag_fresh) {
-      const int nv = cnx[tid] == 0xffff ? -1 : (int)cnx[tid];
-      for (int e = (int)vto[tid], e_end = (int)vto[tid + 1]; e < e_end; ++e) {
-        const int code = csr[e];
-        const int t = code >> 2, l = code & 3;
-        int v[4];
-        double Di[9], F[9], r[12], vol_t;
-        load_tet_rec(m, t, v, Di, vol_t);  // (vertex order: every lane another tet - the AoS record, not 14 scattered SoA loads)
-        deformation_gradient(xs, v, Di, F);
-        TetState s;
-        tet_state(m, F, s);
-        shape_rows(Di, r);
-        const double sc = dt2 * vol_t;
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-          double dF[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, dP[9];
-          dF[k * 3 + 0] = r[l * 3 + 0]; dF[k * 3 + 1] = r[l * 3 + 1]; dF[k * 3 + 2] = r[l * 3 + 2];
-          apply_dP(m, s, dF, dP);
-#pragma unroll
-          for (int i = 0; i < 3; ++i)
-            D[i * 3 + k] += sc * (dP[i * 3 + 0] * r[l * 3 + 0] + dP[i * 3 + 1] * r[l * 3 + 1] + dP[i * 3 + 2] * r[l * 3 + 2]);
-        }
-        const int l2 = v[0] == nv ? 0 : (v[1] == nv ? 1 : (v[2] == nv ? 2 : (v[3] == nv ? 3 : -1)));
-        if (l2 >= 0) {  // this tet also holds the chain successor: its share of the block (v, next)
-          const double rn[3] = {r[l2 * 3 + 0], r[l2 * 3 + 1], r[l2 * 3 + 2]};
-#pragma unroll
-          for (int k = 0; k < 3; ++k) {
-            double dF[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, dP[9];
-            dF[k * 3 + 0] = rn[0]; dF[k * 3 + 1] = rn[1]; dF[k * 3 + 2] = rn[2];
-            apply_dP(m, s, dF, dP);
-#pragma unroll
-            for (int i = 0; i < 3; ++i)
-              E[i * 3 + k] += sc * (dP[i * 3 + 0] * r[l * 3 + 0] + dP[i * 3 + 1] * r[l * 3 + 1] + dP[i * 3 + 2] * r[l * 3 + 2]);
-          }
-        }
-      }
-    }
-    if (own) {
-      if (lag_fresh && lagw) {  // the elastic blocks of this launch (read back by its later iterations)
-        lagw[0 * V + tid] = D[0]; lagw[1 * V + tid] = D[1]; lagw[2 * V + tid] = D[2]; lagw[3 * V + tid] = D[4]; lagw[4 * V + tid] = D[5];
-        lagw[5 * V + tid] = D[8];
-#pragma unroll
-        for (int k = 0; k < 9; ++k) lagw[(6 + k) * V + tid] = E[k];
-      }
+      for (int k = 0; k < 9; ++k) E[k] = q[6 + k];
       // the blocks that are never lagged: mass + constraint, barrier curvature, friction
       D[0] += md; D[4] += md; D[8] += md;
     }
-    lag_valid = lag_valid || lagw != nullptr;
     // EDGE SNAP: one exact 1-D minimisation per surface vertex that is about to run into the barrier zone from outside (or sits in its
     // outermost sliver), along its contact normal - a nonlinear Gauss-Seidel sweep over the stiffest degrees of freedom, taken before
     // the Newton system of the iteration is set up.  The barrier is C2 with b'' -> 0 at d_hat: the Newton system is blind to it for
@@ -2046,6 +1966,130 @@ restart_iteration:
   }
 }
 
+// ---- elastic preconditioner blocks of every env, ahead of the Newton launch (round 5) ------------------------------------------
+// Per vertex the 3x3 diagonal block D (upper triangle, 6) of dt^2 K at the state the launch starts from and the block E (9) towards
+// its chain successor (tacex_fem_set_chains): (V,16) doubles per env in the workspace, read by fem_newton_lds_kernel in every
+// Newton iteration of the launch (the blocks that change by orders of magnitude between iterations - barrier curvature, friction -
+// are added there, fresh).  One workgroup per env, x and the (V,15) accumulators in LDS (71 KB at 495 vertices: two envs per CU, a
+// 512-env shard in one round); rounds 3-4 ran this inside the first Newton iteration of fem_newton_lds_kernel.
+//   ATOM:  tet-centric - every tet's state is computed once, its shares of the four diagonal blocks and of the chain blocks are
+//          added with ds_add_f64 (summation order depends on wave timing: round-off level run-to-run differences);
+//   !ATOM: vertex-centric over the incidence list in a FIXED order (tacex_fem_set_deterministic) - the tet state is recomputed per
+//          incident vertex, four times the arithmetic, bit-identical runs.
+// dxg / dx_tol: envs that converged in an earlier launch of the time step are skipped (same protocol as the Newton kernels).
+template <bool ATOM>
+__global__ __launch_bounds__(512) void fem_assemble_blocks_kernel(FemDev m, const double* __restrict__ xg, double* __restrict__ lagg,
+                                                                   const double* __restrict__ dxg, double dx_tol) {
+  extern __shared__ __attribute__((aligned(16))) double alds[];
+  constexpr int NT = 512;
+  const int V = m.V, T = m.T, b = blockIdx.x, tid = threadIdx.x;
+  if (dxg && dxg[b] <= dx_tol) return;
+  double* xs = alds;           // (V,3)
+  double* xa = xs + 3 * V;     // (V,15) accumulators (ATOM)
+  const double* x = xg + (size_t)b * V * 3;
+  double* lagw = lagg + (size_t)b * 16 * V;  // (V,16): D upper triangle (6) | E (9) | pad, one 128-byte record per vertex
+  for (int k = tid; k < 3 * V; k += NT) xs[k] = x[k];
+  if constexpr (ATOM)
+    for (int k = tid; k < 15 * V; k += NT) xa[k] = 0.0;
+  __syncthreads();
+  const double dt2 = m.dt * m.dt;
+  if constexpr (ATOM) {
+    for (int t = tid; t < T; t += NT) {
+      int v[4];
+      double Di[9], F[9], r[12], vol_t;
+      load_tet_blk(m, t, v, Di, vol_t);
+      deformation_gradient(xs, v, Di, F);
+      TetState s;
+      tet_state(m, F, s);
+      shape_rows(Di, r);
+      const double sc = dt2 * vol_t;
+#pragma unroll
+      for (int l = 0; l < 4; ++l) {
+        double* q = xa + v[l] * 15;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+          double dF[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, dP[9];
+          dF[k * 3 + 0] = r[l * 3 + 0]; dF[k * 3 + 1] = r[l * 3 + 1]; dF[k * 3 + 2] = r[l * 3 + 2];
+          apply_dP(m, s, dF, dP);
+#pragma unroll
+          for (int i = 0; i <= k; ++i)  // upper triangle: (0,0) (0,1) (1,1) (0,2) (1,2) (2,2) -> q[0], q[1], q[3], q[2], q[4], q[5]
+            atomicAdd(&q[i == 0 ? k : (i == 1 ? 2 + k : 5)],
+                      sc * (dP[i * 3 + 0] * r[l * 3 + 0] + dP[i * 3 + 1] * r[l * 3 + 1] + dP[i * 3 + 2] * r[l * 3 + 2]));
+        }
+        const int nv = m.ch_next ? m.ch_next[v[l]] : -1;
+        const int l2 = nv < 0 ? -1 : (v[0] == nv ? 0 : (v[1] == nv ? 1 : (v[2] == nv ? 2 : (v[3] == nv ? 3 : -1))));
+        if (l2 >= 0) {  // this tet also holds the chain successor of vertex l: its share of the block (v_l, next(v_l))
+          // (selects, not r[l2 * 3 + j]: a runtime index sends the whole array to scratch)
+          const double rn[3] = {l2 == 0 ? r[0] : (l2 == 1 ? r[3] : (l2 == 2 ? r[6] : r[9])), l2 == 0 ? r[1] : (l2 == 1 ? r[4] : (l2 == 2 ? r[7] : r[10])),
+                                l2 == 0 ? r[2] : (l2 == 1 ? r[5] : (l2 == 2 ? r[8] : r[11]))};
+#pragma unroll
+          for (int k = 0; k < 3; ++k) {
+            double dF[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, dP[9];
+            dF[k * 3 + 0] = rn[0]; dF[k * 3 + 1] = rn[1]; dF[k * 3 + 2] = rn[2];
+            apply_dP(m, s, dF, dP);
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+              atomicAdd(&q[6 + i * 3 + k], sc * (dP[i * 3 + 0] * r[l * 3 + 0] + dP[i * 3 + 1] * r[l * 3 + 1] + dP[i * 3 + 2] * r[l * 3 + 2]));
+          }
+        }
+      }
+    }
+    __syncthreads();
+    for (int k = tid; k < 16 * V; k += NT) {  // (V,15) -> (V,16): coalesced stores
+      const int vv = k >> 4, j = k & 15;
+      lagw[k] = j < 15 ? xa[vv * 15 + j] : 0.0;
+    }
+  } else {
+    for (int vtx = tid; vtx < V; vtx += NT) {
+      double D[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+      double E[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+      const int nv = m.ch_next ? m.ch_next[vtx] : -1;
+      for (int e = m.vt_off[vtx], e_end = m.vt_off[vtx + 1]; e < e_end; ++e) {
+        const int code = m.vt_idx[e];
+        const int t = code >> 2, l = code & 3;
+        int v[4];
+        double Di[9], F[9], r[12], vol_t;
+        load_tet_rec(m, t, v, Di, vol_t);  // (vertex order: every lane another tet - the AoS record, not 14 scattered SoA loads)
+        deformation_gradient(xs, v, Di, F);
+        TetState s;
+        tet_state(m, F, s);
+        shape_rows(Di, r);
+        const double sc = dt2 * vol_t;
+        const double rl[3] = {l == 0 ? r[0] : (l == 1 ? r[3] : (l == 2 ? r[6] : r[9])), l == 0 ? r[1] : (l == 1 ? r[4] : (l == 2 ? r[7] : r[10])),
+                              l == 0 ? r[2] : (l == 1 ? r[5] : (l == 2 ? r[8] : r[11]))};
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+          double dF[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, dP[9];
+          dF[k * 3 + 0] = rl[0]; dF[k * 3 + 1] = rl[1]; dF[k * 3 + 2] = rl[2];
+          apply_dP(m, s, dF, dP);
+#pragma unroll
+          for (int i = 0; i < 3; ++i)
+            D[i * 3 + k] += sc * (dP[i * 3 + 0] * rl[0] + dP[i * 3 + 1] * rl[1] + dP[i * 3 + 2] * rl[2]);
+        }
+        const int l2 = nv < 0 ? -1 : (v[0] == nv ? 0 : (v[1] == nv ? 1 : (v[2] == nv ? 2 : (v[3] == nv ? 3 : -1))));
+        if (l2 >= 0) {  // this tet also holds the chain successor: its share of the block (v, next)
+          const double rn[3] = {l2 == 0 ? r[0] : (l2 == 1 ? r[3] : (l2 == 2 ? r[6] : r[9])), l2 == 0 ? r[1] : (l2 == 1 ? r[4] : (l2 == 2 ? r[7] : r[10])),
+                                l2 == 0 ? r[2] : (l2 == 1 ? r[5] : (l2 == 2 ? r[8] : r[11]))};
+#pragma unroll
+          for (int k = 0; k < 3; ++k) {
+            double dF[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, dP[9];
+            dF[k * 3 + 0] = rn[0]; dF[k * 3 + 1] = rn[1]; dF[k * 3 + 2] = rn[2];
+            apply_dP(m, s, dF, dP);
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+              E[i * 3 + k] += sc * (dP[i * 3 + 0] * rl[0] + dP[i * 3 + 1] * rl[1] + dP[i * 3 + 2] * rl[2]);
+          }
+        }
+      }
+      double* q = lagw + (size_t)vtx * 16;
+      q[0] = D[0]; q[1] = D[1]; q[2] = D[2]; q[3] = D[4]; q[4] = D[5]; q[5] = D[8];
+#pragma unroll
+      for (int k = 0; k < 9; ++k) q[6 + k] = E[k];
+      q[15] = 0.0;
+    }
+  }
+}
+
 // Launch order of the envs for the next Newton launch: counting sort (descending) by the work of the env's previous step,
 // key = PCG iterations + 6 per Newton iteration (gradient, block assembly and line search cost about six sweeps), from the
 // step_info rows the previous tacex_fem_step left behind (zeros before the first step: index order).  One workgroup; the order
@@ -2091,7 +2135,12 @@ __global__ __launch_bounds__(256) void fem_predict_kernel(const double* __restri
   if (i < (size_t)B && dxg) dxg[i] = INFINITY;
   if (i < (size_t)B && ind && disp) {  // how far the env's indenter moved since the last step (friction slides relative to it)
 #pragma unroll
-    for (int k = 0; k < 3; ++k) disp[i * 3 + k] = have_prev ? ind[i * 8 + 1 + k] - ind_prev[i * 3 + k] : 0.0;
+    for (int k = 0; k < 3; ++k) {
+      // (a NaN in the env's previous position = "none": tacex_fem_reset_envs marks a reset env so - wherever the caller puts its
+      //  indenter before the next step, friction sees no sliding in that step, like the first step of a fresh scene)
+      const double d = have_prev ? ind[i * 8 + 1 + k] - ind_prev[i * 3 + k] : 0.0;
+      disp[i * 3 + k] = d == d ? d : 0.0;
+    }
   }
   if (i >= n3) return;
   const int k = (int)(i % 3);
@@ -2116,6 +2165,21 @@ __global__ __launch_bounds__(256) void fem_velocity_kernel(const double* __restr
 // IsaacLab's `transform_points` in float32 on the GPU, copies it to the host and hands it to libuipc's animator callback
 // (UA:365-385).  One lane per (env, attachment point); float32 rotation like the reference, widened to float64 on store.
 // ------------------------------------------------------------------------------------------------
+// per-env reset (tacex_fem_reset_envs): one workgroup per listed env
+__global__ __launch_bounds__(256) void fem_reset_envs_kernel(const int* __restrict__ ids, const double* __restrict__ pos, const double* __restrict__ rest,
+                                                             double* __restrict__ x, double* __restrict__ v, double* __restrict__ step_info,
+                                                             double* __restrict__ ind_prev, int V, int B) {
+  const int b = ids ? ids[blockIdx.x] : (int)blockIdx.x;
+  if (b < 0 || b >= B) return;
+  const size_t o = (size_t)b * V * 3;
+  for (int k = threadIdx.x; k < 3 * V; k += blockDim.x) {
+    x[o + k] = pos ? pos[(size_t)blockIdx.x * V * 3 + k] : rest[k];
+    v[o + k] = 0.0;
+  }
+  if (threadIdx.x < 4 && step_info) step_info[(size_t)b * 4 + threadIdx.x] = 0.0;
+  if (threadIdx.x < 3 && ind_prev) ind_prev[(size_t)b * 3 + threadIdx.x] = __builtin_nan("");
+}
+
 __global__ __launch_bounds__(128) void fem_attachment_aim_kernel(const float* __restrict__ body_pos, const float* __restrict__ body_quat,
                                                                  const float* __restrict__ offsets, const int32_t* __restrict__ idx,
                                                                  double* __restrict__ aim, uint8_t* __restrict__ constrained,
@@ -2175,6 +2239,8 @@ struct tacex_fem_ctx {
   // caller animating the indenter by passing fresh tensors) keeps them: only disabling contact or its first enable resets.
   const void* ind_prev_ws = nullptr;
   int ind_prev_B = 0;
+  const double* rest = nullptr;  // (V,3) rest positions (tacex_fem_reset_envs)
+  int fric_lag_mode = 0;        // 0: lag at the step's start state, capped by the contact reaction (round 4); 1: IPC's previous-configuration lag
   bool deterministic = false;   // window + CSR-gather sweeps (fixed summation order) instead of LDS atomics (tacex_fem_set_deterministic)
   bool follow_indenter = true;  // contact-following start of the Newton loop (tacex_fem_set_contact_following; fem_newton_lds_kernel)
   double* dx_dev = nullptr;  // optional (B,) last Newton update max|dx| per env: converged envs skip further iterations
@@ -2272,6 +2338,10 @@ int tacex_fem_create(int device_id, const tacex_fem_params* p, tacex_fem_ctx** o
   c->device = device_id;
   FemDev& d = c->dev;
   d.V = V; d.T = T;
+  {
+    std::vector<double> rest(X, X + (size_t)3 * V);
+    if (int rc0 = fem_upload(c, rest, &c->rest)) { tacex_fem_destroy(c); return rc0; }
+  }
   int rc = fem_upload(c, tets, &d.tets) | fem_upload(c, dminv, &d.dminv) | fem_upload(c, vol, &d.vol) |
            fem_upload(c, mass, &d.mass) | fem_upload(c, off, &d.vt_off) | fem_upload(c, idx, &d.vt_idx);
   // Renumbered copy for the LDS Newton kernel.  Its per-window vertex gather waits, in every window, for the vertex with
@@ -2444,6 +2514,13 @@ int tacex_fem_set_friction(tacex_fem_ctx* c, double friction_ratio, double eps_v
   }
   c->dev.fric_mu = c->dev_nwt.fric_mu = friction_ratio;
   c->dev.fric_eps = c->dev_nwt.fric_eps = eps_velocity * c->dev.dt;
+  return 0;
+}
+
+int tacex_fem_set_friction_lag(tacex_fem_ctx* c, int mode) {
+  if (!c) { set_error("tacex_fem_set_friction_lag: null context"); return 2; }
+  if (mode != 0 && mode != 1) { set_error("tacex_fem_set_friction_lag: mode must be 0 (reaction-capped lag at the step's start) or 1 (IPC: previous configuration)"); return 2; }
+  c->fric_lag_mode = mode;
   return 0;
 }
 
@@ -2631,7 +2708,7 @@ int tacex_fem_set_newton_early_exit(tacex_fem_ctx* c, double* dx_dev, double dx_
 static int launch_newton(tacex_fem_ctx* c, double* x, const double* xt, const uint8_t* cons, const double* aim, double* stats, void* ws,
                          int B, int pcg_max_iter, double pcg_tol_rate, int ls_max_iter, double* dx_dev, double dx_tol, int max_newton,
                          double* step_info, hipStream_t st, bool* resident, const double* xprev = nullptr, const double* disp = nullptr,
-                         const int* env_order = nullptr) {
+                         const int* env_order = nullptr, bool stream_accumulate = false) {
   static const int use_lds = getenv("TACEX_FEM_NEWTON_LDS") ? atoi(getenv("TACEX_FEM_NEWTON_LDS")) : 1;
   const bool fric = xprev && disp && c->dev.indenters && c->dev.fric_mu > 0.0;
   const bool mesh = c->dev.indenters && c->dev.im_nt > 0;  // the mesh-capable instantiation only when a mesh indenter exists
@@ -2660,10 +2737,21 @@ static int launch_newton(tacex_fem_ctx* c, double* x, const double* xt, const ui
     hipError_t ea = hipSetDevice(c->device);
     if (ea == hipSuccess) ea = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds, granted[slot]);
     if (ea != hipSuccess) return fail_hip(ea, "hipFuncSetAttribute(fem_newton_lds_kernel)");
+    {  // elastic preconditioner blocks of all envs at the state this launch starts from -> workspace ((V,16) per env)
+      static size_t granted_a[2][64] = {};
+      const size_t lds_a = ((size_t)3 * V + (atom ? (size_t)15 * V : 0)) * sizeof(double);
+      auto ka = atom ? fem_assemble_blocks_kernel<true> : fem_assemble_blocks_kernel<false>;
+      ea = ensure_dynamic_lds(reinterpret_cast<const void*>(ka), lds_a, granted_a[atom ? 1 : 0]);
+      if (ea != hipSuccess) return fail_hip(ea, "hipFuncSetAttribute(fem_assemble_blocks_kernel)");
+      hipLaunchKernelGGL(ka, dim3(B), dim3(512), lds_a, st, c->dev_nwt, x, static_cast<double*>(ws), dx_dev, dx_tol);
+      ea = hipGetLastError();
+      if (ea != hipSuccess) return fail_hip(ea, "fem_assemble_blocks_kernel");
+    }
     hipLaunchKernelGGL(kern, dim3(B), dim3(nt), lds, st, c->dev_nwt, x, xt, cons, aim, stats, pcg_max_iter,
                        pcg_tol_rate, ls_max_iter, dx_dev, dx_tol, max_newton, step_info, fric ? xprev : nullptr,
-                       (xprev && disp && c->dev.indenters) ? disp : nullptr, env_order, (c->follow_indenter ? 1 : 0) | (fric_lag_at_start ? 2 : 0),
-                       max_newton > 1 ? static_cast<double*>(ws) : nullptr);  // env blocks of the workspace: (15, V) lagged blocks per env
+                       (xprev && disp && c->dev.indenters) ? disp : nullptr, env_order,
+                       (c->follow_indenter ? 1 : 0) | ((fric_lag_at_start || c->fric_lag_mode == 1) ? 2 : 0) | (c->fric_lag_mode == 1 ? 4 : 0),
+                       static_cast<double*>(ws));  // env blocks of the workspace: (V,16) elastic preconditioner blocks per env
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : fail_hip(e, "fem_newton_lds_kernel");
   }
@@ -2676,7 +2764,7 @@ static int launch_newton(tacex_fem_ctx* c, double* x, const double* xt, const ui
     return 2;
   }
   hipLaunchKernelGGL(fem_newton_kernel, dim3(B), dim3(512), 0, st, c->dev, x, xt, cons, aim, stats, static_cast<double*>(ws), pcg_max_iter,
-                     pcg_tol_rate, ls_max_iter, dx_dev, dx_tol);
+                     pcg_tol_rate, ls_max_iter, dx_dev, dx_tol, step_info, stream_accumulate ? 1 : 0);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : fail_hip(e, "fem_newton_kernel");
 }
@@ -2730,17 +2818,34 @@ int tacex_fem_step(tacex_fem_ctx* c, double* x, double* v, double* xt, const uin
     return rc;
   if (!resident) {
     // streaming fallback: one launch per Newton iteration on a FIXED schedule; converged envs return at once (dx protocol), so the
-    // launches past convergence cost microseconds and nothing is read back.  step_info is filled from the last launch only.
+    // launches past convergence cost microseconds and nothing is read back.  The first launch (above) SET the env's step_info row,
+    // these add their iteration / PCG counts and OR their flags into it (penetration, dead line search: check_step() sees them).
     for (int it = 1; it < max_newton; ++it)
-      if (int rc = launch_newton(c, x, xt, cons, aim, stats, ws, B, pcg_max_iter, pcg_tol_rate, ls_max_iter, dx, tol, 1, nullptr, st, nullptr))
+      if (int rc = launch_newton(c, x, xt, cons, aim, stats, ws, B, pcg_max_iter, pcg_tol_rate, ls_max_iter, dx, tol, 1, step_info, st, nullptr,
+                                 nullptr, nullptr, nullptr, true))
         return rc;
-    e = hipMemsetAsync(step_info, 0, (size_t)B * 4 * sizeof(double), st);
-    if (e != hipSuccess) return fail_hip(e, "hipMemsetAsync(step_info)");
   }
   hipLaunchKernelGGL(fem_velocity_kernel, dim3((unsigned)((n3 + 255) / 256)), dim3(256), 0, st, x, xprev, v, n3, 1.0 / dt, ind, ind_prev, B);
   if (ind) { c->ind_prev_ws = ws; c->ind_prev_B = B; }
   e = hipGetLastError();
   return e == hipSuccess ? 0 : fail_hip(e, "fem_velocity_kernel");
+}
+
+int tacex_fem_reset_envs(tacex_fem_ctx* c, const int32_t* env_ids, int num_reset, const double* positions, double* x, double* v,
+                         double* step_info, void* ws, int B, void* stream) {
+  if (!c || !x || !v) { set_error("tacex_fem_reset_envs: null argument"); return 2; }
+  if (B <= 0 || num_reset == 0) return 0;
+  if (num_reset < 0 || (!env_ids && num_reset != B)) { set_error("tacex_fem_reset_envs: without env_ids, num_reset must equal num_envs"); return 2; }
+  const int V = c->dev.V;
+  // the previous indenter positions live in the workspace the last tacex_fem_step ran with (see tacex_fem_step): another workspace or
+  // env count means the next step has no previous positions at all
+  double* ind_prev = nullptr;
+  if (ws && c->dev.indenters && c->ind_prev_ws == ws && c->ind_prev_B == B)
+    ind_prev = static_cast<double*>(ws) + (size_t)B * newton_ws_doubles(V, c->dev.T) + (size_t)B * V * 3 + B + (size_t)3 * B;
+  hipLaunchKernelGGL(fem_reset_envs_kernel, dim3(num_reset), dim3(256), 0, (hipStream_t)stream, env_ids, positions, c->rest, x, v, step_info,
+                     ind_prev, V, B);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : fail_hip(e, "fem_reset_envs_kernel");
 }
 
 int tacex_fem_set_attachment_targets(const float* body_pos, const float* body_quat, const float* offsets, const int32_t* idx,

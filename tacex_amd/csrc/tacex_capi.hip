@@ -571,8 +571,9 @@ static int chunk_frames(const tacex_taxim_ctx* c, int B) {
                       stream_supported(c->n_fused, c->levels[c->n_levels - c->n_fused].kw, c->H, c->W);
   const size_t per_frame = (size_t)3 * c->H * c->W * sizeof(float);
   // (2048 frames of 320x240 per streaming pass since round 5: a GelSightSensorGroup of two 1024-env sensors is one pass - 1571 us for the
-  //  tail's 2048 frames against 2 x 802, C3 660 K against 652 K frames/s in two passes, profiles/r05_experiments.md)
-  const size_t n = stream ? ((size_t)2048 * 240 * 320 * 12) / per_frame : ((size_t)240 << 20) / per_frame;
+  //  tail's 2048 frames against 2 x 802, C3 660 K against 652 K frames/s in two passes, profiles/r05_experiments.md.
+  //  Frames beyond 320x240 keep the 1024-frame-equivalent pass: 640x480 measured 9.28 ms per 1024 frames in passes of 512 against 7.97 ms in passes of 256.)
+  const size_t n = stream ? ((size_t)(per_frame <= (size_t)240 * 320 * 12 ? 2048 : 1024) * 240 * 320 * 12) / per_frame : ((size_t)240 << 20) / per_frame;
   if (n < 1 || (size_t)B < (stream ? n + n / 2 : 2 * n)) return B;  // a shard barely over the budget is cheaper in one pass than in two small ones
   const size_t nchunks = ((size_t)B + n - 1) / n;
   return (int)(((size_t)B + nchunks - 1) / nchunks);  // equal chunks

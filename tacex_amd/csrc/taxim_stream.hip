@@ -1227,6 +1227,19 @@ hipError_t run_obs_finish_stream(const float* part, void* obs, bool u8, const St
   return hipGetLastError();
 }
 
+#ifdef TACEX_STREAM_PROBE_DEEP
+// VERDICT r04 item 6 ("cut one HBM round trip of Z or show the build that fails"): the last BAND level (k = 17 at 320x240, k = 15 at
+// 640x480) moved into the streaming tail's level chain would save its 8 B/px write + re-read.  These instantiations are that build -
+// `hipcc -DTACEX_STREAM_PROBE_DEEP -Rpass-analysis=kernel-resource-usage` (profiles/r05_experiments.md section 4): 256 VGPRs + 61 / 52
+// spilled (ScratchSize 160 / 152 B per lane) against 242 / 245 and none; a 15-row restore ring and 34 partial sums per pixel make
+// 105 KB of LDS per workgroup (one workgroup per CU instead of two: +25 % by TACEX_STREAM_LDS_PAD, r03 section 1); the halo grows to
+// 18 columns per side (three strips of 108 columns instead of two of 160 at 320x240: 33 % instead of 15 % redundant columns) and the
+// level arithmetic from 44 to 78 FMAs per pixel on a kernel that is VALU-issue-bound.  Not wired into the runtime.
+template __global__ void taxim_stream_kernel<true, kStreamFused, 2, 17, 9, 5, 3, 5>(StreamArgs);
+template __global__ void taxim_stream_kernel<true, kStreamFused, 2, 15, 9, 5, 9>(StreamArgs);
+static_assert(StreamCfg<kStreamFused, 17, 9, 5, 3, 5>::lds_bytes() > 80 * 1024, "deep variant: one workgroup per CU");
+#endif
+
 int stream_obs_lds_floats() { return kStreamObsLdsFloats; }
 int stream_obs_max_cols() { return kStreamObsMaxCols; }
 

@@ -145,6 +145,14 @@ class GelSightSensor(SensorBase):
 
     def _reset_impl(self, env_ids):
         super().reset(env_ids)
+        # FEM gelpad (tacex_uipc): the pad of a reset env goes back to its rest shape with the sensor.  In the reference the scene resets
+        # its assets one by one and `UipcObject.reset` is a TODO stub (uipc_object.py:280-286) - its UIPC scenes hold one env; here the
+        # sensor owns the reference to the pad, so a task that resets `env_ids` of the sensor gets a consistent pad / image pair.
+        # `cfg.reset_gelpad_with_sensor = False` leaves the pad to the caller.
+        pad_sim = getattr(self.gelpad_obj, "_uipc_sim", None)
+        if pad_sim is not None and getattr(pad_sim, "_handle", None) is not None and getattr(self.cfg, "reset_gelpad_with_sensor", True) \
+                and self._is_initialized:
+            self.gelpad_obj.reset(env_ids)
         if env_ids is None:
             env_ids = self._ALL_INDICES
         self._indentation_depth[env_ids] = 0

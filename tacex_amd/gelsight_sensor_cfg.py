@@ -44,3 +44,6 @@ class GelSightSensorCfg(SensorBaseCfg):
     marker_motion_sim_cfg: GelSightSimulatorCfg = None
     compute_indentation_depth_class: Literal["optical_sim", "marker_motion_sim"] = "optical_sim"
     device: str = "cuda"
+    reset_gelpad_with_sensor: bool = True
+    """Not in the reference cfg: `GelSightSensor.reset(env_ids)` also puts the FEM gelpad (`gelpad_obj`, a tacex_uipc UipcObject) of those
+    envs back to rest (`UipcObject.reset`).  False: the caller resets the pad itself."""

@@ -22,7 +22,7 @@ class FemGelpad:
     stepped with UipcSim.step (backward Euler: the whole Newton loop - matrix-free PCG, CCD filter, line search - in one HIP launch)."""
 
     def __init__(self, B, dev, max_newton_iter: int = 8, motion: str = "breathing", side_stream: bool = False, d_hat: float | None = None,
-                 cfg: UipcSimCfg | None = None):
+                 cfg: UipcSimCfg | None = None, friction_lag: str | None = None):
         """motion: "breathing" - the indenter presses in and retreats to the edge of the barrier zone every 21 steps; "rolling" - it
         stays on the pad like the ball of the reference's ball-rolling scenes: the depth varies between 0.3 and 0.8 of the env's
         maximum while the sphere slides sideways by up to +-0.5 mm (friction drags the surface along).  The half of the period in
@@ -43,6 +43,8 @@ class FemGelpad:
         cfg = cfg if cfg is not None else UipcSimCfg(device=dev)
         if d_hat is not None:
             cfg.contact.d_hat = float(d_hat)
+        if friction_lag is not None:
+            cfg.contact.friction_lag = friction_lag
         self.d_hat = float(cfg.contact.d_hat)
         self.sim = UipcSim(cfg, num_envs=B)
         self.gelpad = UipcObject(UipcObjectCfg(mesh_points=P, mesh_tets=T), self.sim)
@@ -69,6 +71,7 @@ class FemGelpad:
         self.ind = ind
         self.sim.set_contact_indenters(ind)
         self.ind = self.sim.contact_indenters  # the device buffer the kernels read; moved in place every step
+        self.ind0 = self.ind.clone()
         self.depth = torch.linspace(0.0004, 0.0014, B, device=dev, dtype=torch.float64)
         self._z_rest_t = torch.full((B,), self.z_rest, device=dev, dtype=torch.float64)
         self.B = B
@@ -119,6 +122,10 @@ class FemGelpad:
                 self.ms_log.append(self._pending[0].elapsed_time(self._pending[1]))
             self._pending = self.ev
             self.ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+
+    def reset_indenters(self, env_ids):
+        """Indenters of `env_ids` back to where the scene started them (what a task does together with `gelpad.reset(env_ids)`)."""
+        self.ind[env_ids] = self.ind0[env_ids]
 
     def flush(self):
         """Appends the duration of the LAST enqueued step to `ms_log` (its events are read one step late; without this the log

@@ -106,3 +106,18 @@ class UipcObject:
                 key = tuple(sorted(f))
                 faces[key] = None if key in faces else f
         return np.asarray([f for f in faces.values() if f is not None], dtype=np.int32)
+
+    # -- uipc_object.py:280-370 ------------------------------------------------------------------------------------------------
+    def reset(self, env_ids=None):
+        """Rest positions and zero velocity for the envs in `env_ids` (None: all).  (A TODO stub in the reference, uipc_object.py:280-286:
+        its scenes hold one env; with hundreds of envs per GPU an RL task resets single envs every few hundred steps.)"""
+        if self._uipc_sim is None or getattr(self._uipc_sim, "_handle", None) is None:
+            raise RuntimeError("UipcObject.reset needs a UipcSim that was set up (setup_sim)")
+        self._uipc_sim.reset(env_ids)
+
+    def write_vertex_positions_to_sim(self, vertex_positions, env_ids=None):
+        """`world.write_vertex_pos_to_sim` of the reference's libuipc fork (uipc_object.py:318-370): vertex positions
+        (len(env_ids), V, 3) in the simulation frame for the listed envs (None: all), velocities zeroed."""
+        if self._uipc_sim is None or getattr(self._uipc_sim, "_handle", None) is None:
+            raise RuntimeError("UipcObject.write_vertex_positions_to_sim needs a UipcSim that was set up (setup_sim)")
+        self._uipc_sim.reset(env_ids, vertex_positions=vertex_positions)

@@ -87,6 +87,14 @@ class UipcSimCfg:
         constitution: str = "ipc"
         d_hat: float = 0.001
         eps_velocity: float = 0.01
+        friction_lag: str = "capped"
+        """Where the friction lag (normal force, normal; frozen per time step) comes from (`tacex_fem_set_friction_lag`): "ipc" = the previous
+        configuration, Li et al. 2020 section 5.4 to the letter - the step's end state is then a stationary point of IPC's plain
+        incremental potential (tests/test_fem_physics_gpu.py); "capped" (default) = start positions against the indenter's NEW position,
+        the force capped by the contact reaction there.  The two agree where the previous step converged tightly and the indenter
+        approaches; "capped" takes the smaller, already relaxed force when it retreats - and stays bounded at the reference's default
+        Newton tolerance (0.5 mm per step), where the previous configuration is far from balance: simple_axle at the defaults ran 302 K env
+        steps/s with "capped" and 8.5 K with "ipc" (profiles/r05_experiments.md).  Not in the reference cfg (libuipc's rule is not in the reference)."""
         follow_indenter: bool = True
         """Contact-following start of a step's Newton loop (`tacex_fem_set_contact_following`): vertices inside the barrier zone start
         the iteration displaced with their indenter.  An initial guess only (same minimiser); not in the reference cfg - libuipc starts
@@ -195,6 +203,10 @@ class UipcSim:
                                                     float(c.eps_velocity)), "tacex_fem_set_friction")
         _lib.check(self._lib.tacex_fem_set_contact_following(self._handle, 1 if getattr(c, "follow_indenter", True) else 0),
                    "tacex_fem_set_contact_following")
+        lag = getattr(c, "friction_lag", "capped")
+        if lag not in ("ipc", "capped"):
+            raise ValueError(f"UipcSimCfg.contact.friction_lag must be 'ipc' or 'capped', got {lag!r}")
+        _lib.check(self._lib.tacex_fem_set_friction_lag(self._handle, 1 if lag == "ipc" else 0), "tacex_fem_set_friction_lag")
         self.contact_indenters = ind  # keeps the device buffer alive: the kernels read it on every later call
 
     def set_indenter_mesh(self, vertices, triangles):
@@ -256,6 +268,8 @@ class UipcSim:
     def contact_gaps(self, x=None) -> torch.Tensor:
         """(num_envs, V) signed distance of every vertex to its env's indenter (+inf without one), by the solver's own distance
         function (`tacex_fem_contact_gaps`; no host round trip)."""
+        if x is None:
+            self.wait_for_step()  # (a step on a side stream writes self.x: the current stream reads it behind the step's event)
         x = self.x if x is None else x.to(self.device, torch.float64).contiguous()
         if getattr(self, "contact_indenters", None) is None:
             return torch.full(x.shape[:2], float("inf"), dtype=torch.float64, device=self.device)
@@ -289,10 +303,12 @@ class UipcSim:
         # method every step must not trigger a host-side rebuild (device sync, dense inverse, table re-upload) per step.  The set
         # is mirrored on the host; an index tensor that lives on the device is read back once per distinct (tensor, version).
         if isinstance(vertex_idx, torch.Tensor) and vertex_idx.is_cuda:
-            key = (vertex_idx.data_ptr(), vertex_idx.numel(), vertex_idx._version)
-            if key == getattr(self, "_cons_idx_seen", None):
+            # (identity + version of the tensor OBJECT, which is kept alive here: the caching allocator hands the address of a freed
+            #  index tensor to the next one of equal size, so a data_ptr key could take a different set for the one already mirrored)
+            seen = getattr(self, "_cons_idx_seen", None)
+            if seen is not None and seen[0] is vertex_idx and seen[1] == vertex_idx._version:
                 return
-            self._cons_idx_seen = key
+            self._cons_idx_seen = (vertex_idx, vertex_idx._version)
             host_idx = vertex_idx.detach().reshape(-1).cpu().numpy().astype(np.int64)
         else:
             host_idx = np.asarray(vertex_idx.detach().cpu() if isinstance(vertex_idx, torch.Tensor) else vertex_idx, dtype=np.int64).reshape(-1)
@@ -300,13 +316,46 @@ class UipcSim:
 
     def _mark_constrained(self, host_idx):
         """Host mirror of the constrained vertex set (env 0's flags; the envs of a scene share their attachment set): the
-        preconditioner is rebuilt only when a vertex joins it."""
+        preconditioner is rebuilt only when a vertex joins it.  A caller that CLEARS flags by writing `is_constrained` directly
+        calls `invalidate_constraints()`."""
         mirror = getattr(self, "_cons_host", None)
         if mirror is None:
             mirror = self._cons_host = np.zeros(self._obj.num_verts, dtype=bool)
         if not mirror[host_idx].all():
             mirror[host_idx] = True
             self._precond_dirty = True
+
+    def invalidate_constraints(self):
+        """After editing `is_constrained` in place (e.g. releasing vertices): the coarse operator is rebuilt from the device flags at
+        the next step and the host mirror of the set starts over."""
+        self._cons_host = None
+        self._cons_idx_seen = None
+        self._precond_dirty = True
+
+    # -- per-env reset (uipc_object.py:280-370) ----------------------------------------------------------------------------------
+    def reset(self, env_ids=None, vertex_positions: torch.Tensor | None = None):
+        """Puts the gelpads of `env_ids` (None: all) back: x = `vertex_positions` ((len(env_ids), V, 3), default the rest mesh), v = 0, the
+        env's step diagnostics and its friction reference cleared (`tacex_fem_reset_envs`).  The other envs are untouched; the next
+        step of a reset env is the first step of a fresh scene (bit for bit with `linear_system.deterministic`).  Enqueued on the
+        current stream, behind a side-stream step if there is one."""
+        self.wait_for_step()
+        B, V = self.num_envs, self._obj.num_verts
+        ids = None
+        n = B
+        if env_ids is not None:
+            ids = torch.as_tensor(env_ids, device=self.device).to(torch.int32).reshape(-1).contiguous()
+            n = int(ids.numel())
+            if n == 0:
+                return
+        pos = None
+        if vertex_positions is not None:
+            pos = vertex_positions.to(self.device, torch.float64).reshape(n, V, 3).contiguous()
+        si = getattr(self, "step_info", None)
+        with torch.cuda.device(self.device):
+            rc = self._lib.tacex_fem_reset_envs(self._handle, _lib.ptr(ids), n, _lib.ptr(pos), _lib.ptr(self.x), _lib.ptr(self.v),
+                                                _lib.ptr(si), _lib.ptr(self._ws), B, self._stream())
+        _lib.check(rc, "tacex_fem_reset_envs")
+        # (a later side-stream step is ordered behind this: FemGelpad.step makes its stream wait for the caller's before every step)
 
     def refresh_preconditioner(self):
         """(Re)build the coarse operator of the two-level preconditioner: Galerkin product of the REST-state matrix
@@ -455,6 +504,7 @@ class UipcSim:
     def last_newton_iters(self) -> int:
         """Newton iterations of the slowest env in the last step (reads the device: synchronises)."""
         si = getattr(self, "step_info", None)
+        self.wait_for_step()
         return int(si[:, 0].max()) if si is not None else 0
 
     def check_step(self, raise_on_penetration: bool = True) -> dict:
@@ -463,6 +513,7 @@ class UipcSim:
         documents the contract) and that vertex gets no restoring force; flag 2 = a line search found no decrease.  Informational:
         4 = the env dropped the coarse correction for the rest of the step, 8 = it met negative curvature and finished the step with
         the PSD-safe Hessian (csrc/fem_kernels.hip, kFemFlagCoarseOff / kFemFlagPsdSafe)."""
+        self.wait_for_step()  # a step enqueued on a side stream (FemGelpad(side_stream=True)): `.cpu()` only drains the CURRENT stream
         si = self.step_info.cpu().numpy()
         flags = si[:, 2].astype(np.int64)
         out = {"newton_iters": si[:, 0].astype(np.int64), "max_d": si[:, 1], "penetrating_envs": np.nonzero(flags & 1)[0],
