@@ -75,6 +75,7 @@ def parse(argv=None):
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-sweep", action="store_true", help="skip the C2 / 512-shard / C4 / C5 sweep (N = 1 only)")
     ap.add_argument("--sweep-steps", type=int, default=30)
+    ap.add_argument("--sweep-keys", default=None, help="comma-separated sweep entries to run (default: all), in the order given by the sweep")
     ap.add_argument("--cpu-baseline-seconds", type=float, default=30.0, help="budget of the CPU baseline leg")
     ap.add_argument("--details-out", default=None,
                     help="side file for everything that is not the headline (sweep entries with their descriptions, per-stage timings, CPU "
@@ -421,7 +422,11 @@ def sweep(args, dev):
     """The other BASELINE configurations, timed the same way (rank 0, N = 1, after the headline)."""
     out = []
 
+    only = set(args.sweep_keys.split(",")) if args.sweep_keys else None
+
     def run(key, label, B, H, W, n_sensors, markers, fem=None, steps=None, gather=None, count_in_contact=False, **rig_kw):
+        if only is not None and key not in only:
+            return
         steps = steps or args.sweep_steps
         log(f"sweep: {key}: {label}")
         try:
@@ -511,9 +516,12 @@ def sweep(args, dev):
     # (with the coarse correction in M^-1 the reference's PCG test - 1e-3 on r.z - can pass after ONE iteration on this rod, whose coarse modes are
     #  nearly free: states then follow the tightly solved ones within the accumulated Newton tolerance.  The second entry solves to the threshold
     #  rounds 1-4 used - 1e-6 on r.z - which is also what the block-Jacobi streaming entry needs to mean the same accuracy.)
-    out.append(fem_axle_entry(dev, key="axle"))
-    out.append(fem_axle_entry(dev, tol_rate=1e-6, key="axle_tol1e-6"))
-    out.append(fem_axle_entry(dev, steps=6, streaming=True, tol_rate=1e-6, key="axle_streaming"))
+    if only is None or "axle" in only:
+        out.append(fem_axle_entry(dev, key="axle"))
+    if only is None or "axle_tol1e-6" in only:
+        out.append(fem_axle_entry(dev, tol_rate=1e-6, key="axle_tol1e-6"))
+    if only is None or "axle_streaming" in only:
+        out.append(fem_axle_entry(dev, steps=6, streaming=True, tol_rate=1e-6, key="axle_streaming"))
     run("c5_optical", "C5 optical part only: 1024 envs, RGB 640x480", 1024, 480, 640, 1, False, steps=max(5, args.sweep_steps // 3))
     return out
 

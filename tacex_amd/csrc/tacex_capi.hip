@@ -7,6 +7,7 @@
 
 #include <algorithm>
 #include <string>
+#include <mutex>
 #include <vector>
 
 #include "tacex_hip.h"
@@ -221,7 +222,7 @@ void tacex_taxim_destroy(tacex_taxim_ctx* c) {
   (void)hipSetDevice(c->device);
   for (auto& e : c->events) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
   for (auto& q : c->lvl_stream)
-    if (q) { (void)hipStreamSynchronize(q); (void)hipStreamDestroy(q); }
+    if (q) (void)hipStreamSynchronize(q);  // (the streams belong to the per-device pool: level_stream())
   if (c->lvl_fork) (void)hipEventDestroy(c->lvl_fork);
   for (auto& e : c->lvl_join)
     if (e) (void)hipEventDestroy(e);
@@ -557,6 +558,24 @@ static int pipeline_chunk(tacex_taxim_ctx* c, const float* hm, const float* pres
                           float* obs_h, void* obs, int obs_hh, int obs_w, FotsReduce* fots_part, int frame0,
                           const int* rows = nullptr);
 
+// The extra streams the band levels of a pass alternate on (TWO CHUNKS IN FLIGHT, pipeline_chunk) come from ONE pool per device,
+// created at first use and kept for the life of the process.  A stream per CONTEXT (round 4) made what a context measured depend on
+// how many streams the process had created before it: HIP deals streams onto a handful of hardware queues round-robin, and a
+// context whose level stream lands on the queue of the caller's stream runs its "two chunks in flight" one after the other
+// (bench.py sweep, 640x480: 110 K frames/s as the 17th rig of a process against 128 K on its own; profiles/r05_experiments.md section 7).
+static hipError_t level_stream(int device, int q, hipStream_t* out) {
+  static std::mutex mu;
+  static hipStream_t pool[64][tacex_taxim_ctx::kMaxLvlStreams - 1] = {};
+  if (device < 0 || device >= 64 || q < 0 || q >= tacex_taxim_ctx::kMaxLvlStreams - 1) return hipErrorInvalidValue;
+  std::lock_guard<std::mutex> lock(mu);
+  if (!pool[device][q]) {
+    hipError_t e = hipStreamCreateWithFlags(&pool[device][q], hipStreamNonBlocking);
+    if (e != hipSuccess) return e;
+  }
+  *out = pool[device][q];
+  return hipSuccess;
+}
+
 // Frames per pass of the pipeline.  With the LDS-tiled tail, large shards are walked in chunks whose level buffers (Z ping /
 // pong, 4 B/px each) plus height map stay resident in the 256 MB Infinity Cache (measured in round 1 at 2048 frames: k=33
 // 66 -> 58 us per 256 frames).  The streaming tail wants the opposite: one wave marches down a whole strip, so a pass needs
@@ -699,7 +718,7 @@ static int pipeline_chunk(tacex_taxim_ctx* c, const float* hm, const float* pres
     if (!c->lvl_fork) HIP_TRY(hipEventCreateWithFlags(&c->lvl_fork, hipEventDisableTiming), "hipEventCreate");
     for (int q = 0; q < lvl_streams - 1; ++q)
       if (!c->lvl_stream[q]) {
-        HIP_TRY(hipStreamCreateWithFlags(&c->lvl_stream[q], hipStreamNonBlocking), "hipStreamCreate(band levels)");
+        if (hipError_t es = level_stream(c->device, q, &c->lvl_stream[q]); es != hipSuccess) return fail_hip(es, "hipStreamCreate(band levels)");
         HIP_TRY(hipEventCreateWithFlags(&c->lvl_join[q], hipEventDisableTiming), "hipEventCreate");
       }
     static const int env_lcf = getenv("TACEX_LEVEL_CHUNK_FRAMES") ? atoi(getenv("TACEX_LEVEL_CHUNK_FRAMES")) : -1;
