@@ -15,6 +15,21 @@ from .uipc_object import UipcObject, UipcObjectCfg, gelpad_box_mesh
 from .uipc_sim import UipcSim, UipcSimCfg
 
 
+_SIDE_STREAMS: dict = {}
+
+
+def _side_stream(dev, priority=0):
+    """ONE side stream per device and priority for every scene of the process.  HIP deals the streams a process creates onto a handful
+    of hardware queues round-robin; a side stream that lands on the queue of the caller's stream does not overlap it at all.  With a
+    stream per scene, whether a scene's FEM step overlapped the optical pipeline depended on how many streams the process had created
+    before it (bench.py sweep, round 5: the rolling-contact entry ran at the one-stream rate, 342 K against 388 K frames/s)."""
+    d = torch.device(dev)
+    key = (d.index if d.index is not None else torch.cuda.current_device(), priority)
+    if key not in _SIDE_STREAMS:
+        _SIDE_STREAMS[key] = torch.cuda.Stream(device=d, priority=priority)
+    return _SIDE_STREAMS[key]
+
+
 class FemGelpad:
     """C4 / C5: one ~2k-tet gelpad per env (20.75 x 25.25 x 4.5 mm block, 495 vertices / 1920 tets).  Its back face is held by
     the sensor case through UipcIsaacAttachments (aim = R(q) offset + p, soft position constraints); a spherical indenter
@@ -37,7 +52,7 @@ class FemGelpad:
         # (which ends with a few straggler envs on a mostly idle GPU); the FEM-driven markers wait for the event (UipcSim.wait_for_step)
         # (default stream priority: a high-priority FEM stream was measured - no gain at 320x240, 640x480 a third slower; TACEX_FEM_STREAM_PRIORITY for the A/B)
         prio = int(os.environ.get("TACEX_FEM_STREAM_PRIORITY", "0"))
-        self.stream = torch.cuda.Stream(device=dev, priority=prio) if side_stream else None
+        self.stream = _side_stream(dev, prio) if side_stream else None
         self.max_newton_iter = max_newton_iter
         P, T = gelpad_box_mesh(8, 10, 4)
         cfg = cfg if cfg is not None else UipcSimCfg(device=dev)
