@@ -1977,6 +1977,59 @@ restart_iteration:
 //   !ATOM: vertex-centric over the incidence list in a FIXED order (tacex_fem_set_deterministic) - the tet state is recomputed per
 //          incident vertex, four times the arithmetic, bit-identical runs.
 // dxg / dx_tol: envs that converged in an earlier launch of the time step are skipped (same protocol as the Newton kernels).
+// Blocks of the element Hessian in closed form.  With dF = e_k (x) r_B (row k of dF = r_B) contracted against r_A, the 9x9 Hessian
+// of the Stable Neo-Hookean density (apply_dP: a dF + b (F:dF) F + lam (C:dF) C + c dC[dF]) gives the 3x3 block
+//     B(A, B)[i][k] = a (r_A . r_B) delta_ik + b u_A[i] u_B[k] + lam w_A[i] w_B[k] + c eps_ikn g[n],
+//     u = F r,  w = C r (C = cofactor matrix),  g = F (r_A x r_B)
+// (the last term is d2J/dF2 = eps eps F contracted with r_A, r_B: antisymmetric, zero for A = B).  A diagonal block costs two
+// matrix-vector products and six entries of three FMAs instead of three apply_dP calls (~100 f64 operations each) and their
+// contractions: the assembly kernel went from 70 to 43 us per 512 envs (profiles/r05_experiments.md section 8); verified against the
+// oracle's dpk1 to 1e-16 relative.
+struct TetBlocks {
+  double u[4][3], w[4][3], n2[4];
+};
+__device__ __forceinline__ void tet_blocks(const TetState& s, const double r[12], TetBlocks& tb) {
+#pragma unroll
+  for (int l = 0; l < 4; ++l) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      tb.u[l][i] = s.F[i * 3 + 0] * r[l * 3 + 0] + s.F[i * 3 + 1] * r[l * 3 + 1] + s.F[i * 3 + 2] * r[l * 3 + 2];
+      tb.w[l][i] = s.C[i * 3 + 0] * r[l * 3 + 0] + s.C[i * 3 + 1] * r[l * 3 + 1] + s.C[i * 3 + 2] * r[l * 3 + 2];
+    }
+    tb.n2[l] = r[l * 3 + 0] * r[l * 3 + 0] + r[l * 3 + 1] * r[l * 3 + 1] + r[l * 3 + 2] * r[l * 3 + 2];
+  }
+}
+// Row `l2` of a 4-row table with a RUNTIME l2 as an exact blend (weights 1.0 / 0.0) of constant-indexed reads: a runtime index sends
+// the array to scratch, and a chain of selects is folded back into one by the optimiser (select of loads -> load of a selected address).
+#define TB_SEL(arr, l2, i) (((l2) == 0 ? 1.0 : 0.0) * arr[0][i] + ((l2) == 1 ? 1.0 : 0.0) * arr[1][i] + ((l2) == 2 ? 1.0 : 0.0) * arr[2][i] + \
+                            ((l2) == 3 ? 1.0 : 0.0) * arr[3][i])
+#define R_SEL(r, l2, j) (((l2) == 0 ? 1.0 : 0.0) * r[j] + ((l2) == 1 ? 1.0 : 0.0) * r[3 + (j)] + ((l2) == 2 ? 1.0 : 0.0) * r[6 + (j)] + \
+                         ((l2) == 3 ? 1.0 : 0.0) * r[9 + (j)])
+// the off-diagonal block (vertex l, vertex l2) of the tet: E[i * 3 + k]
+__device__ __forceinline__ void tet_block_offdiag(const FemDev& m, const TetState& s, const double r[12], const TetBlocks& tb, const double (&ul)[3],
+                                                   const double (&wl)[3], const double (&rl)[3], int l2, double E[9]) {
+  const double u2[3] = {TB_SEL(tb.u, l2, 0), TB_SEL(tb.u, l2, 1), TB_SEL(tb.u, l2, 2)};
+  const double w2[3] = {TB_SEL(tb.w, l2, 0), TB_SEL(tb.w, l2, 1), TB_SEL(tb.w, l2, 2)};
+  const double r2[3] = {R_SEL(r, l2, 0), R_SEL(r, l2, 1), R_SEL(r, l2, 2)};
+  const double dot = rl[0] * r2[0] + rl[1] * r2[1] + rl[2] * r2[2];
+  const double x3[3] = {rl[1] * r2[2] - rl[2] * r2[1], rl[2] * r2[0] - rl[0] * r2[2], rl[0] * r2[1] - rl[1] * r2[0]};
+  double g[3];
+#pragma unroll
+  for (int n = 0; n < 3; ++n) g[n] = s.c * (s.F[n * 3 + 0] * x3[0] + s.F[n * 3 + 1] * x3[1] + s.F[n * 3 + 2] * x3[2]);
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int k = 0; k < 3; ++k) E[i * 3 + k] = s.b * ul[i] * u2[k] + m.lam * wl[i] * w2[k];
+  const double ad = s.a * dot;
+  E[0] += ad; E[4] += ad; E[8] += ad;
+  E[1] += g[2]; E[2] -= g[1]; E[3] -= g[2]; E[5] += g[0]; E[6] += g[1]; E[7] -= g[0];
+}
+
+#ifdef TACEX_FEM_ASM_NOATOM  // timing probe only (racy, wrong sums): what the LDS atomics of the tet-centric assembly cost
+#define ASM_ADD(p, v) (*(p) += (v))
+#else
+#define ASM_ADD(p, v) atomicAdd((p), (v))
+#endif
 template <bool ATOM>
 __global__ __launch_bounds__(512) void fem_assemble_blocks_kernel(FemDev m, const double* __restrict__ xg, double* __restrict__ lagg,
                                                                    const double* __restrict__ dxg, double dx_tol) {
@@ -2002,35 +2055,29 @@ __global__ __launch_bounds__(512) void fem_assemble_blocks_kernel(FemDev m, cons
       TetState s;
       tet_state(m, F, s);
       shape_rows(Di, r);
+      TetBlocks tb;
+      tet_blocks(s, r, tb);
       const double sc = dt2 * vol_t;
 #pragma unroll
       for (int l = 0; l < 4; ++l) {
         double* q = xa + v[l] * 15;
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-          double dF[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, dP[9];
-          dF[k * 3 + 0] = r[l * 3 + 0]; dF[k * 3 + 1] = r[l * 3 + 1]; dF[k * 3 + 2] = r[l * 3 + 2];
-          apply_dP(m, s, dF, dP);
-#pragma unroll
-          for (int i = 0; i <= k; ++i)  // upper triangle: (0,0) (0,1) (1,1) (0,2) (1,2) (2,2) -> q[0], q[1], q[3], q[2], q[4], q[5]
-            atomicAdd(&q[i == 0 ? k : (i == 1 ? 2 + k : 5)],
-                      sc * (dP[i * 3 + 0] * r[l * 3 + 0] + dP[i * 3 + 1] * r[l * 3 + 1] + dP[i * 3 + 2] * r[l * 3 + 2]));
-        }
+        const double ul[3] = {tb.u[l][0], tb.u[l][1], tb.u[l][2]}, wl[3] = {tb.w[l][0], tb.w[l][1], tb.w[l][2]};
+        const double an = s.a * tb.n2[l];
+        // upper triangle: (0,0) (0,1) (0,2) (1,1) (1,2) (2,2) -> q[0..5]
+        ASM_ADD(&q[0], sc * (an + s.b * ul[0] * ul[0] + m.lam * wl[0] * wl[0]));
+        ASM_ADD(&q[1], sc * (s.b * ul[0] * ul[1] + m.lam * wl[0] * wl[1]));
+        ASM_ADD(&q[2], sc * (s.b * ul[0] * ul[2] + m.lam * wl[0] * wl[2]));
+        ASM_ADD(&q[3], sc * (an + s.b * ul[1] * ul[1] + m.lam * wl[1] * wl[1]));
+        ASM_ADD(&q[4], sc * (s.b * ul[1] * ul[2] + m.lam * wl[1] * wl[2]));
+        ASM_ADD(&q[5], sc * (an + s.b * ul[2] * ul[2] + m.lam * wl[2] * wl[2]));
         const int nv = m.ch_next ? m.ch_next[v[l]] : -1;
         const int l2 = nv < 0 ? -1 : (v[0] == nv ? 0 : (v[1] == nv ? 1 : (v[2] == nv ? 2 : (v[3] == nv ? 3 : -1))));
         if (l2 >= 0) {  // this tet also holds the chain successor of vertex l: its share of the block (v_l, next(v_l))
-          // (selects, not r[l2 * 3 + j]: a runtime index sends the whole array to scratch)
-          const double rn[3] = {l2 == 0 ? r[0] : (l2 == 1 ? r[3] : (l2 == 2 ? r[6] : r[9])), l2 == 0 ? r[1] : (l2 == 1 ? r[4] : (l2 == 2 ? r[7] : r[10])),
-                                l2 == 0 ? r[2] : (l2 == 1 ? r[5] : (l2 == 2 ? r[8] : r[11]))};
+          const double rl[3] = {r[l * 3 + 0], r[l * 3 + 1], r[l * 3 + 2]};
+          double E[9];
+          tet_block_offdiag(m, s, r, tb, ul, wl, rl, l2, E);
 #pragma unroll
-          for (int k = 0; k < 3; ++k) {
-            double dF[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, dP[9];
-            dF[k * 3 + 0] = rn[0]; dF[k * 3 + 1] = rn[1]; dF[k * 3 + 2] = rn[2];
-            apply_dP(m, s, dF, dP);
-#pragma unroll
-            for (int i = 0; i < 3; ++i)
-              atomicAdd(&q[6 + i * 3 + k], sc * (dP[i * 3 + 0] * r[l * 3 + 0] + dP[i * 3 + 1] * r[l * 3 + 1] + dP[i * 3 + 2] * r[l * 3 + 2]));
-          }
+          for (int k = 0; k < 9; ++k) ASM_ADD(&q[6 + k], sc * E[k]);
         }
       }
     }
@@ -2041,7 +2088,7 @@ __global__ __launch_bounds__(512) void fem_assemble_blocks_kernel(FemDev m, cons
     }
   } else {
     for (int vtx = tid; vtx < V; vtx += NT) {
-      double D[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+      double D[6] = {0, 0, 0, 0, 0, 0};
       double E[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
       const int nv = m.ch_next ? m.ch_next[vtx] : -1;
       for (int e = m.vt_off[vtx], e_end = m.vt_off[vtx + 1]; e < e_end; ++e) {
@@ -2055,34 +2102,33 @@ __global__ __launch_bounds__(512) void fem_assemble_blocks_kernel(FemDev m, cons
         tet_state(m, F, s);
         shape_rows(Di, r);
         const double sc = dt2 * vol_t;
-        const double rl[3] = {l == 0 ? r[0] : (l == 1 ? r[3] : (l == 2 ? r[6] : r[9])), l == 0 ? r[1] : (l == 1 ? r[4] : (l == 2 ? r[7] : r[10])),
-                              l == 0 ? r[2] : (l == 1 ? r[5] : (l == 2 ? r[8] : r[11]))};
+        const double rl[3] = {R_SEL(r, l, 0), R_SEL(r, l, 1), R_SEL(r, l, 2)};
+        double ul[3], wl[3];
 #pragma unroll
-        for (int k = 0; k < 3; ++k) {
-          double dF[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, dP[9];
-          dF[k * 3 + 0] = rl[0]; dF[k * 3 + 1] = rl[1]; dF[k * 3 + 2] = rl[2];
-          apply_dP(m, s, dF, dP);
-#pragma unroll
-          for (int i = 0; i < 3; ++i)
-            D[i * 3 + k] += sc * (dP[i * 3 + 0] * rl[0] + dP[i * 3 + 1] * rl[1] + dP[i * 3 + 2] * rl[2]);
+        for (int i = 0; i < 3; ++i) {
+          ul[i] = s.F[i * 3 + 0] * rl[0] + s.F[i * 3 + 1] * rl[1] + s.F[i * 3 + 2] * rl[2];
+          wl[i] = s.C[i * 3 + 0] * rl[0] + s.C[i * 3 + 1] * rl[1] + s.C[i * 3 + 2] * rl[2];
         }
+        const double an = s.a * (rl[0] * rl[0] + rl[1] * rl[1] + rl[2] * rl[2]);
+        D[0] += sc * (an + s.b * ul[0] * ul[0] + m.lam * wl[0] * wl[0]);
+        D[1] += sc * (s.b * ul[0] * ul[1] + m.lam * wl[0] * wl[1]);
+        D[2] += sc * (s.b * ul[0] * ul[2] + m.lam * wl[0] * wl[2]);
+        D[3] += sc * (an + s.b * ul[1] * ul[1] + m.lam * wl[1] * wl[1]);
+        D[4] += sc * (s.b * ul[1] * ul[2] + m.lam * wl[1] * wl[2]);
+        D[5] += sc * (an + s.b * ul[2] * ul[2] + m.lam * wl[2] * wl[2]);
         const int l2 = nv < 0 ? -1 : (v[0] == nv ? 0 : (v[1] == nv ? 1 : (v[2] == nv ? 2 : (v[3] == nv ? 3 : -1))));
         if (l2 >= 0) {  // this tet also holds the chain successor: its share of the block (v, next)
-          const double rn[3] = {l2 == 0 ? r[0] : (l2 == 1 ? r[3] : (l2 == 2 ? r[6] : r[9])), l2 == 0 ? r[1] : (l2 == 1 ? r[4] : (l2 == 2 ? r[7] : r[10])),
-                                l2 == 0 ? r[2] : (l2 == 1 ? r[5] : (l2 == 2 ? r[8] : r[11]))};
+          TetBlocks tb;
+          tet_blocks(s, r, tb);
+          double Et[9];
+          tet_block_offdiag(m, s, r, tb, ul, wl, rl, l2, Et);
 #pragma unroll
-          for (int k = 0; k < 3; ++k) {
-            double dF[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, dP[9];
-            dF[k * 3 + 0] = rn[0]; dF[k * 3 + 1] = rn[1]; dF[k * 3 + 2] = rn[2];
-            apply_dP(m, s, dF, dP);
-#pragma unroll
-            for (int i = 0; i < 3; ++i)
-              E[i * 3 + k] += sc * (dP[i * 3 + 0] * rl[0] + dP[i * 3 + 1] * rl[1] + dP[i * 3 + 2] * rl[2]);
-          }
+          for (int k = 0; k < 9; ++k) E[k] += sc * Et[k];
         }
       }
       double* q = lagw + (size_t)vtx * 16;
-      q[0] = D[0]; q[1] = D[1]; q[2] = D[2]; q[3] = D[4]; q[4] = D[5]; q[5] = D[8];
+#pragma unroll
+      for (int k = 0; k < 6; ++k) q[k] = D[k];
 #pragma unroll
       for (int k = 0; k < 9; ++k) q[6 + k] = E[k];
       q[15] = 0.0;
@@ -2739,9 +2785,12 @@ static int launch_newton(tacex_fem_ctx* c, double* x, const double* xt, const ui
     if (ea != hipSuccess) return fail_hip(ea, "hipFuncSetAttribute(fem_newton_lds_kernel)");
     {  // elastic preconditioner blocks of all envs at the state this launch starts from -> workspace ((V,16) per env)
       static size_t granted_a[2][64] = {};
-      const size_t lds_a = ((size_t)3 * V + (atom ? (size_t)15 * V : 0)) * sizeof(double);
-      auto ka = atom ? fem_assemble_blocks_kernel<true> : fem_assemble_blocks_kernel<false>;
-      ea = ensure_dynamic_lds(reinterpret_cast<const void*>(ka), lds_a, granted_a[atom ? 1 : 0]);
+      // TACEX_FEM_ASSEMBLE: 1 = tet-centric with LDS atomics, 0 = vertex-centric in a fixed order (A/B hook; default: follows the atomics switch)
+      static const int asm_env = getenv("TACEX_FEM_ASSEMBLE") ? atoi(getenv("TACEX_FEM_ASSEMBLE")) : -1;
+      const bool asm_atom = asm_env < 0 ? atom : (asm_env != 0 && !c->deterministic);
+      const size_t lds_a = ((size_t)3 * V + (asm_atom ? (size_t)15 * V : 0)) * sizeof(double);
+      auto ka = asm_atom ? fem_assemble_blocks_kernel<true> : fem_assemble_blocks_kernel<false>;
+      ea = ensure_dynamic_lds(reinterpret_cast<const void*>(ka), lds_a, granted_a[asm_atom ? 1 : 0]);
       if (ea != hipSuccess) return fail_hip(ea, "hipFuncSetAttribute(fem_assemble_blocks_kernel)");
       hipLaunchKernelGGL(ka, dim3(B), dim3(512), lds_a, st, c->dev_nwt, x, static_cast<double*>(ws), dx_dev, dx_tol);
       ea = hipGetLastError();
