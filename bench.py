@@ -395,14 +395,14 @@ def roofline_leg(rig, markers):
         "valu_frac": round(flops_per_frame * B / (taxim_ms * 1e-3) / 1e12 / FP32_PEAK_TFLOPS, 4),
         "stages": stages,
         "note": "achieved = SURVEY 8(d)'s 16 B/px x the pixels of one launch of the dominant kernel / its hipEvent-measured average "
-                "duration (frac = achieved / 8 TB/s; reproduces from profiles/r04_c3_kernel_stats.csv: 16 x 76800 x 1024 B / the tail's "
+                "duration (frac = achieved / 8 TB/s; reproduces from profiles/r05_c3_kernel_stats.csv: 16 x 76800 x frames per launch B / the tail's "
                 "average duration); *_own_bytes = the same with the kernel's own reads + writes (DESIGN.md section 4); pipeline_* = "
                 "16 B/px of the whole Taxim path / sum of its kernels; valu_frac = algorithmic fp32 flops / 157.3 TFLOP/s (the "
                 "separable blur is VALU-heavy)",
     }
     # HBM bytes of the dominant kernel per launch from the PMC passes (FETCH_SIZE x2 + WRITE_SIZE, separate `rocprofv3 --pmc` runs,
     # committed under profiles/ - counters cannot be read live from inside the process, so this is a build-time constant)
-    for cand in ("pmc_traffic_r04.json", "pmc_traffic_r03.json", "pmc_traffic_r02.json", "pmc_traffic.json"):
+    for cand in ("pmc_traffic_r05.json", "pmc_traffic_r04.json", "pmc_traffic_r03.json", "pmc_traffic_r02.json", "pmc_traffic.json"):
         pmc = REPO / "profiles" / cand
         if pmc.exists() and (H, W) == (240, 320):
             try:
@@ -913,7 +913,9 @@ def main(argv=None):
     args = parse(argv)
     if args.details_out is None:
         args.details_out = str(REPO / "gpurun_out" / f"bench_details_n{args.gpus}.json")
-    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+    # (TACEX_BENCH_FORCE_LAUNCH=1: take the self-launch path at N = 1 too - the GPU box has one device, and the launcher + RCCL
+    #  rendezvous + relay must not meet real hardware for the first time on the 8-GPU node; tests/test_env_shard_gloo.py)
+    if (args.gpus > 1 or os.environ.get("TACEX_BENCH_FORCE_LAUNCH") == "1") and "WORLD_SIZE" not in os.environ:
         raise SystemExit(launch_children(args, argv))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:

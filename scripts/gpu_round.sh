@@ -9,7 +9,7 @@ cd $GRAFT_REPO_ROOT
 for s in $STEPS; do
   case $s in
     tests) timeout 1500 python -m pytest tests -m gpu -x -q > $OUT/pytest_gpu.log 2>&1; echo "pytest rc=$?" | tee -a $OUT/pytest_gpu.log; tail -5 $OUT/pytest_gpu.log ;;
-    bench) timeout 900 python bench.py > $OUT/bench.json 2> $OUT/bench.err; echo "bench rc=$?"; tail -c 600 $OUT/bench.err; head -c 1500 $OUT/bench.json ;;
+    bench) timeout 900 python3 bench.py --gpus 1 --steps 20 --warmup 5 --details-out $OUT/bench_details.json > $OUT/bench.json 2> $OUT/bench.err; echo "bench rc=$?"; tail -c 600 $OUT/bench.err; head -c 1500 $OUT/bench.json ;;
     benchq) timeout 600 python bench.py --no-sweep --no-cpu-baseline > $OUT/bench_quick.json 2> $OUT/bench_quick.err; echo "benchq rc=$?"; head -c 1200 $OUT/bench_quick.json ;;
     prof) (cd /tmp && export TMPDIR=/tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -- python3 $GRAFT_REPO_ROOT/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-sweep > $OUT/prof.log 2>&1; echo "prof rc=$?") ;;
     prof640) (cd /tmp && export TMPDIR=/tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof640 -- python3 $GRAFT_REPO_ROOT/bench.py --steps 10 --warmup 3 --height 480 --width 640 --envs-per-gpu 1024 --sensors 1 --no-cpu-baseline --no-sweep > $OUT/prof640.log 2>&1; echo "prof640 rc=$?"; tail -c 700 $OUT/prof640.log) ;;

@@ -145,3 +145,23 @@ def test_rccl_observation_gather_single_rank_child_process(tmp_path):
                TACEX_FORCE_DIST="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     r = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "RCCL_SMOKE_OK" in r.stdout, (r.stdout[-1500:], r.stderr[-3000:])
+
+
+@pytest.mark.gpu
+def test_bench_self_launch_with_rccl_on_the_gpu_box(tmp_path):
+    """`python bench.py --gpus N` as the driver invokes it - no rendezvous in the environment - on real hardware: the parent (which never
+    touches the GPU) starts the rank(s) as fresh child processes, they form an RCCL (`nccl`) group, run the headline rig with the
+    observation all-gather, and the parent relays rank 0's ONE line.  One device here, so N = 1 through TACEX_BENCH_FORCE_LAUNCH."""
+    import json
+
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(TACEX_BENCH_FORCE_LAUNCH="1", TACEX_FORCE_DIST="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, str(REPO / "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1", "--envs-per-gpu", "64", "--no-sweep",
+                        "--no-cpu-baseline", "--details-out", str(tmp_path / "d.json")], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = r.stdout.strip().splitlines()
+    assert len(lines) == 1 and len(lines[0]) <= 6000, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 1 and d["data"] == "synthetic" and d["value"] > 0 and "roofline" in d
+    m = d["multi_gpu"]
+    assert m["backend"] == "nccl" and m["world_size"] == 1 and m["launcher"] == "self" and m["distinct_devices"] == 1
