@@ -13,7 +13,10 @@ plain Python that `ast` can lift out of the files where they lie:
     public formula) - so what is pinned is the reference's own control flow and arithmetic around them: which vertices are kept,
     in which order, `offset = quat_apply_inverse(q, v - obj_pos)` in float32, and the layout of what is returned.
 
-Writes tests/golden/uipc_cfg.npz (numbers and strings as 0-d / 1-d arrays; no source text)."""
+Writes tests/golden/uipc_cfg.npz (numbers and strings as 0-d / 1-d arrays; no source text).
+
+SECURITY: the lifted class bodies / function body are EXECUTED.  /root/reference is untrusted public content: `assert_reviewable` refuses
+imports, dunder access and process / file / introspection builtins before anything runs; run this in the sandboxed container only."""
 import ast
 import sys
 import textwrap
@@ -30,11 +33,30 @@ REF = Path("/root/reference/source/tacex_uipc/tacex_uipc")
 US, UO, UA = REF / "sim/uipc_sim.py", REF / "objects/uipc_object.py", REF / "sim/uipc_attachments.py"
 
 
+FORBIDDEN_NAMES = {"exec", "eval", "compile", "open", "__import__", "input", "breakpoint", "globals", "locals", "vars", "getattr", "setattr",
+                   "delattr", "os", "sys", "subprocess", "shutil", "socket", "importlib", "ctypes", "builtins", "exit", "quit"}
+
+
+def assert_reviewable(src: str, what: str):
+    """The reference is untrusted public content and the lifted source is EXECUTED: refuse anything a cfg class body or
+    the attachment arithmetic has no business doing - imports, dunder access, process / file / introspection builtins.  Run this
+    script in the sandboxed build container only."""
+    for node in ast.walk(ast.parse(src)):
+        if isinstance(node, (ast.Import, ast.ImportFrom, ast.Global, ast.Nonlocal, ast.AsyncFunctionDef, ast.Await, ast.Yield, ast.YieldFrom)):
+            raise RuntimeError(f"{what}: refusing to execute source containing {type(node).__name__} (line {getattr(node, 'lineno', '?')})")
+        if isinstance(node, ast.Name) and node.id in FORBIDDEN_NAMES:
+            raise RuntimeError(f"{what}: refusing to execute source that names `{node.id}` (line {node.lineno})")
+        if isinstance(node, ast.Attribute) and node.attr.startswith("__"):
+            raise RuntimeError(f"{what}: refusing to execute source with dunder attribute `{node.attr}` (line {node.lineno})")
+
+
 def class_source(path: Path, name: str) -> str:
     src = path.read_text()
     for node in ast.walk(ast.parse(src)):
         if isinstance(node, ast.ClassDef) and node.name == name:
-            return ast.get_source_segment(src, node)
+            seg = ast.get_source_segment(src, node)
+            assert_reviewable(seg, f"{path.name}:{name}")
+            return seg
     raise KeyError(name)
 
 
@@ -44,7 +66,9 @@ def function_source(path: Path, cls: str, name: str) -> str:
         if isinstance(node, ast.ClassDef) and node.name == cls:
             for f in node.body:
                 if isinstance(f, ast.FunctionDef) and f.name == name:
-                    return textwrap.dedent("\n".join(src.splitlines()[f.lineno - 1:f.end_lineno]))
+                    seg = textwrap.dedent("\n".join(src.splitlines()[f.lineno - 1:f.end_lineno]))
+                    assert_reviewable(seg, f"{path.name}:{cls}.{name}")
+                    return seg
     raise KeyError(name)
 
 
