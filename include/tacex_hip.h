@@ -32,7 +32,7 @@ extern "C" {
 #endif
 
 #define TACEX_MAX_LEVELS 8
-#define TACEX_ABI_VERSION 9
+#define TACEX_ABI_VERSION 10
 
 typedef struct tacex_taxim_ctx tacex_taxim_ctx;
 typedef struct tacex_fots_ctx tacex_fots_ctx;
@@ -81,10 +81,11 @@ size_t tacex_taxim_workspace_bytes(const tacex_taxim_ctx* ctx, int num_frames);
  *   cam_u8     = uint8(((hm_mm - near_clip_m*1000) / (far_clip_m*1000)) * 255)  (sic)  (B,Hc,Wc) [nullable]
  * The clip range is passed as DOUBLES: the reference multiplies the Python doubles by 1000 and torch rounds the product once
  * to float32 (GS:573-574), so cam_u8 is bit-exact.  depth_m_dev may alias hm_mm_dev.
- *   frame_rows (B,2) int32 [nullable, needs indent_mm]: first / last frame row holding a pixel below the press plane,
- *                i.e. with S = (hm - frame_min) - indent < 0 (TT:441) - (height, -1) when there is none.  By-product of the
- *                same pass (per-row minima); the render uses it to skip pyramid bands that cannot be non-zero
- *                (tacex_taxim_set_frame_rows + TACEX_FLAG_HAVE_FRAME_ROWS). */
+ *   frame_rows (B,4) int32 [nullable, needs indent_mm]: [0], [1] first / last frame ROW holding a pixel below the press plane,
+ *                i.e. with S = (hm - frame_min) - indent < 0 (TT:441) - (height, -1) when there is none; [2], [3] first / last
+ *                such COLUMN ((width, -1); (0, width - 1) for widths the pass cannot track).  By-product of the same pass (per-row
+ *                and per-column minima); the render uses it to skip pyramid bands and 64-column blocks that cannot be non-zero
+ *                (tacex_taxim_set_frame_rows + TACEX_FLAG_HAVE_FRAME_ROWS).  (ABI 10: two ints per frame before.) */
 int tacex_height_map_from_depth(const float* depth_m_dev, double near_clip_m, double far_clip_m,
                                 float gelpad_height_m, float gelpad_to_camera_min_distance_m,
                                 float* hm_mm_dev, float* frame_min_dev, float* indent_mm_dev,
@@ -117,7 +118,7 @@ int tacex_depth_from_mesh(const float* verts_dev, const int32_t* tris_dev, int n
                           int width, void* stream);
 
 /* TS:115-131 on an existing mm height map. frame_min_dev (B,) is also written (re-used by the render);
- * frame_rows_dev (B,2) int32 nullable: contact row range as in tacex_height_map_from_depth. */
+ * frame_rows_dev (B,4) int32 nullable: contact row / column ranges as in tacex_height_map_from_depth. */
 int tacex_indentation_depth(const float* hm_mm_dev, float gelpad_height_m,
                             float gelpad_to_camera_min_distance_m, float* frame_min_dev,
                             float* indent_mm_dev, int32_t* frame_rows_dev, int num_frames, int height, int width,
@@ -162,10 +163,10 @@ int tacex_taxim_shadow_rays(tacex_taxim_ctx* ctx, const float* z_dev, const uint
 #define TACEX_FLAG_WITH_SHADOW    4u /* render only: shadow branch TT:260-346 (needs tacex_taxim_set_shadow + extra scratch) */
 #define TACEX_FLAG_HAVE_FRAME_ROWS 16u /* with HAVE_FRAME_MIN: the buffer of tacex_taxim_set_frame_rows describes THESE height maps */
 
-/* Contact row ranges of the height maps handed to the render (written by tacex_height_map_from_depth /
- * tacex_indentation_depth into a caller-owned (capacity_frames, 2) int32 buffer).  The deformed gel of TT:443-473 is exactly
- * zero on every pyramid band whose input window lies outside the range (zero gel map only): those bands are stored as zeros
- * without reading or multiplying anything.  Used only by calls that pass TACEX_FLAG_HAVE_FRAME_MIN | TACEX_FLAG_HAVE_FRAME_ROWS
+/* Contact row / column ranges of the height maps handed to the render (written by tacex_height_map_from_depth /
+ * tacex_indentation_depth into a caller-owned (capacity_frames, 4) int32 buffer).  The deformed gel of TT:443-473 is exactly
+ * zero on every pyramid band - and every 64-column block of a band - whose input window lies outside the ranges (zero gel map
+ * only): those are stored as zeros without reading or multiplying anything.  Used only by calls that pass TACEX_FLAG_HAVE_FRAME_MIN | TACEX_FLAG_HAVE_FRAME_ROWS
  * with num_frames <= capacity_frames; without HAVE_FRAME_MIN the library computes the ranges in its own minimum pass.
  * nullptr disables. */
 int tacex_taxim_set_frame_rows(tacex_taxim_ctx* ctx, const int32_t* frame_rows_dev, int capacity_frames);

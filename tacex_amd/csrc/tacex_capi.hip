@@ -201,6 +201,16 @@ int tacex_taxim_create(int device_id, const tacex_taxim_params* p, tacex_taxim_c
   c->shade.x_binr = (float)(0.5 * 3.14159265358979323846 / (nb - 1));
   c->shade.y_binr = (float)(2.0 * 3.14159265358979323846 / (nb - 1));
   c->n_fused = tail_levels(c->levels, c->n_levels, c->H, c->W);
+  {  // RGB of the undeformed gel (flat rows / flat waves of the streaming tail copy it instead of evaluating the polynomial)
+    void* pf = nullptr;
+    hipError_t ef = hipMalloc(&pf, (size_t)c->H * c->W * 3 * sizeof(float));
+    if (ef != hipSuccess) { tacex_taxim_destroy(c); return fail_hip(ef, "hipMalloc(flat image)"); }
+    c->allocs.push_back(pf);
+    c->shade.flat_rgb_dev = static_cast<float*>(pf);
+    ef = run_stream_flat_image(&c->shade, c->H, c->W, nullptr);
+    if (ef == hipSuccess) ef = hipDeviceSynchronize();
+    if (ef != hipSuccess) { tacex_taxim_destroy(c); return fail_hip(ef, "stream_flat_image_kernel"); }
+  }
   const int ns = p->n_levels + 3;
   c->stage_ms.assign(ns, 0.0);
   c->stage_n.assign(ns, 0);
@@ -446,7 +456,7 @@ size_t tacex_taxim_workspace_bytes(const tacex_taxim_ctx* c, int B) {
   if (!c || B <= 0) return 0;
   const size_t img = align_up((size_t)B * c->H * c->W * sizeof(float), 256);
   const size_t vec = align_up((size_t)B * sizeof(float), 256);
-  return 3 * img + 3 * vec + align_up((size_t)B * 2 * sizeof(int), 256);  // Z ping, Z pong, generic-path temp; shift_a, shift_b, pdepth; contact rows
+  return 3 * img + 3 * vec + align_up((size_t)B * 4 * sizeof(int), 256);  // Z ping, Z pong, generic-path temp; shift_a, shift_b, pdepth; contact rows / columns
 }
 // where the library keeps the contact row ranges it computes itself (behind everything a chunk of <= B frames lays out)
 static int* workspace_rows(const tacex_taxim_ctx* c, void* ws, int B) {
@@ -516,7 +526,7 @@ int tacex_height_map_from_depth(const float* depth_m, double near_m, double far_
             "frame_rows_kernel<depth>");
     return 0;
   }
-  if (frame_rows) HIP_TRY(run_fill_rows(frame_rows, B, H, (hipStream_t)stream), "fill_rows_kernel");
+  if (frame_rows) HIP_TRY(run_fill_rows(frame_rows, B, H, W, (hipStream_t)stream), "fill_rows_kernel");
   // GS:573-574: `clipping_range[i] * 1000` is a Python double product; torch rounds it ONCE to float32 as the scalar operand
   HIP_TRY(run_frame_min(depth_m, true, hm_mm, frame_min, indent_mm, cam_u8, B, H * W, (float)(near_m * 1000.0), (float)far_m,
                         (float)(far_m * 1000.0), gelpad_h, gelpad_dmin, (hipStream_t)stream),
@@ -546,7 +556,7 @@ int tacex_indentation_depth(const float* hm_mm, float gelpad_h, float gelpad_dmi
             "frame_rows_kernel");
     return 0;
   }
-  if (frame_rows) HIP_TRY(run_fill_rows(frame_rows, B, H, (hipStream_t)stream), "fill_rows_kernel");
+  if (frame_rows) HIP_TRY(run_fill_rows(frame_rows, B, H, W, (hipStream_t)stream), "fill_rows_kernel");
   HIP_TRY(run_frame_min(hm_mm, false, nullptr, frame_min, indent_mm, nullptr, B, H * W, 0.f, 0.f, 0.f, gelpad_h,
                         gelpad_dmin, (hipStream_t)stream),
           "frame_min_kernel");
@@ -650,7 +660,7 @@ static int pipeline_impl(tacex_taxim_ctx* c, const float* hm, const float* press
                             flags, st, obs_h,
                             obs ? static_cast<char*>(obs) + (size_t)b0 * obs_hh * obs_w * 3 * ((flags & TACEX_FLAG_OBS_U8) ? 1 : 4) : nullptr,
                             obs_hh, obs_w, fp ? fp + (size_t)b0 * fper : nullptr, B <= c->fots_pix_cap ? b0 : -1,
-                            rows ? rows + 2 * b0 : nullptr);
+                            rows ? rows + 4 * b0 : nullptr);
     if (rc) return rc;
   }
   return 0;
@@ -733,16 +743,17 @@ static int pipeline_chunk(tacex_taxim_ctx* c, const float* hm, const float* pres
     const int lane_q = dual ? chunk_no % lvl_streams : 0;
     hipStream_t st = lane_q > 0 ? c->lvl_stream[lane_q - 1] : st_main;  // (shadows the pass's stream inside the chunk)
     src = nullptr;
-    int grow = 0;  // rows by which the non-zero range of the level's input exceeds the contact rows
+    int grow = 0, grow_x = 0;  // rows / columns by which the non-zero range of the level's input exceeds the contact rows / columns
     for (int l = 0; l < n_band; ++l) {
       const bool last = l == c->n_levels - 1;
       float* dst = (last && z_out) ? z_out : zbuf[l & 1];
       StageTimer t(c, st, 1 + l);
       HIP_TRY(run_blur_level(c->levels[l], src ? src + b0 * npix : nullptr, hm + b0 * npix, c->gel_dev, sa + b0, sb + b0, pd + b0,
                              dst + b0 * npix, tmp, last && mask_out ? mask_out + b0 * npix : nullptr, nb,
-                             c->H, c->W, c->contact_scale, last ? 0 : 1, l == 0, st, rows ? rows + 2 * b0 : nullptr, grow),
+                             c->H, c->W, c->contact_scale, last ? 0 : 1, l == 0, st, rows ? rows + 4 * b0 : nullptr, grow, grow_x),
               "blur level");
       grow += (c->levels[l].kh - 1) / 2;
+      grow_x += (c->levels[l].kw - 1) / 2;
       src = dst;
     }
   }

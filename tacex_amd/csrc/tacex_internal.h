@@ -39,6 +39,7 @@ struct ShadeParams {
   float* bg_nhwc_dev = nullptr;  // (H, W, 3)
   float* fx_dev = nullptr;       // (W,)
   float* fy_dev = nullptr;       // (H,)
+  float* flat_rgb_dev = nullptr; // (H, W, 3) RGB of the undeformed gel: clip(poly[flat bin pair](x, y) + background), run_stream_flat_image
 };
 
 hipError_t run_frame_min(const float* in, bool from_depth, float* hm_out, float* fmin, float* indent,
@@ -52,9 +53,9 @@ bool blur_level_single_kernel(const LevelDesc& lv, bool first, int H, int W);  /
 hipError_t run_blur_level(const LevelDesc& lv, const float* src, const float* hm, const float* gel,
                           const float* sa, const float* sb, const float* pd, float* dst, float* tmp,
                           uint8_t* mask_out, int B, int H, int W, float contact_scale, int restore,
-                          bool first, hipStream_t st, const int* rows_ext = nullptr, int ext_grow = 0);
+                          bool first, hipStream_t st, const int* rows_ext = nullptr, int ext_grow = 0, int ext_grow_x = 0);
 bool frame_rows_supported(int H, int W);
-hipError_t run_fill_rows(int* rows, int B, int H, hipStream_t st);
+hipError_t run_fill_rows(int* rows, int B, int H, int W, hipStream_t st);
 hipError_t run_frame_rows(const float* in, bool from_depth, float* hm_out, float* fmin, float* indent, uint8_t* cam_u8,
                           const float* press_in, int* rows_out, int B, int H, int W, float near_mm, float far_m, float far_mm,
                           float gelpad_h, float gelpad_dmin, hipStream_t st);
@@ -157,6 +158,7 @@ int stream_segments(int B, int nstrips, int H, int warm_rows, int waves_per_simd
 int stream_warm_rows(int n_fused, int k0, bool levels_kernel);
 int stream_waves_per_simd(int n_fused, int k0);
 // z_last: (B,H,W) scratch for the last level (split mode: the levels kernel writes it, the shading kernel reads it)
+hipError_t run_stream_flat_image(const ShadeParams* sp, int H, int W, hipStream_t st);  // fills sp->flat_rgb_dev
 hipError_t run_stream_tail(const LevelDesc* lv, int n_levels, int n_fused, const float* zin, const float* hm, const float* gel,
                            const float* sa, const float* sb, const float* pd, const ShadeParams* sp, float* rgb, float* z_last,
                            int B, int H, int W, float contact_scale, const StreamPlan& plan, float* obs_part,

@@ -22,8 +22,10 @@ struct BlurArgs {
   float contact_scale;
   int restore;          // apply Z[M] = J[M]
   int row0, nbands;     // MFMA kernel: first row and band count of this launch
-  const int* rows_ext;  // (B,2) first / last frame row with a non-zero level-0 input, nullable (MFMA kernel: zero-band skipping)
+  const int* rows_ext;  // (B,4) first / last frame row | first / last frame column with a non-zero level-0 input, nullable (MFMA kernel:
+                        // zero-band and zero-block skipping)
   int ext_grow;         // rows by which the non-zero range of THIS level's input has grown (sum of the previous levels' radii)
+  int ext_grow_x;       // columns, likewise
 };
 
 bool mfma_supported(int k, bool first, int H, int W);

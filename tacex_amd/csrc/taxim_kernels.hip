@@ -97,8 +97,11 @@ __global__ __launch_bounds__(1024) void frame_min_kernel(
 // by row (wave w takes rows w, w + 16, ...; a row is one or more float4 loads per lane), so that the per-row minima are
 // available once the frame minimum is known.  S = (hm - min) - press is monotone in hm, hence a row holds a pixel with S < 0 -
 // a non-zero input J = min(S, 0) of the pyramid (TT:441-454, zero gel map) - exactly when (rowmin - min) - press < 0, evaluated
-// with the kernels' own expression.  rows_out[2b], rows_out[2b + 1] = first / last such row, (H, -1) when the frame has no
-// contact.  The band kernels use the range to skip bands whose whole input window is zero (their output is exactly zero).
+// with the kernels' own expression.  rows_out[4b], rows_out[4b + 1] = first / last such row, (H, -1) when the frame has no
+// contact; rows_out[4b + 2], [4b + 3] = first / last such COLUMN (round 5; (W, -1) without contact; (0, W - 1) when the block size
+// cannot be a multiple of the row's float4 count).  The band kernels use the ranges to skip bands and 64-column blocks whose whole
+// input window is zero (their output is exactly zero).  The block runs (1024 / (W / 4)) * (W / 4) threads so that a thread always
+// meets the same four columns: their minima stay in registers and reach LDS once.
 // press: indentation depth computed here (indent_out != nullptr, TS:116-129) or given per frame (press_in).
 // ------------------------------------------------------------------------------------------------
 constexpr int kFrameRowsMaxH = 2048;
@@ -108,6 +111,7 @@ __global__ __launch_bounds__(1024) void frame_rows_kernel(
     float* __restrict__ indent_out, uint8_t* __restrict__ cam_u8, const float* __restrict__ press_in,
     int* __restrict__ rows_out, int H, int W, float nmm, float far_m, float fmm, float gelpad_h, float gelpad_dmin) {
   __shared__ float rowmin[kFrameRowsMaxH];
+  __shared__ float colmin[kFrameRowsMaxH];
   __shared__ float bc[2];
   const int b = blockIdx.x;
   const size_t fo = (size_t)b * H * W;
@@ -118,7 +122,12 @@ __global__ __launch_bounds__(1024) void frame_rows_kernel(
   // thread.  Row minima through LDS integer atomics on the float pattern (heights are >= 0 or +inf: the patterns order like
   // the values; a minimum does not depend on the order of its operands, so the result is the same bits as before).
   int* rowmin_i = reinterpret_cast<int*>(rowmin);
+  int* colmin_i = reinterpret_cast<int*>(colmin);
   for (int r = threadIdx.x; r < H; r += blockDim.x) rowmin_i[r] = 0x7f800000;  // +inf
+  const bool cols_ok = W <= kFrameRowsMaxH && (blockDim.x % w4) == 0;  // (block-uniform) a thread's float4s all lie in ONE column group
+  if (cols_ok)
+    for (int c = threadIdx.x; c < W; c += blockDim.x) colmin_i[c] = 0x7f800000;
+  float cm[4] = {INFINITY, INFINITY, INFINITY, INFINITY};
   __syncthreads();
   const int n4 = H * w4;
 #pragma unroll 2
@@ -146,6 +155,7 @@ __global__ __launch_bounds__(1024) void frame_rows_kernel(
         }
       }
       m = fminf(fminf(v[0], v[1]), fminf(v[2], v[3]));
+      cm[0] = fminf(cm[0], v[0]); cm[1] = fminf(cm[1], v[1]); cm[2] = fminf(cm[2], v[2]); cm[3] = fminf(cm[3], v[3]);
     }
     // a wave's 64 consecutive float4s lie in at most two rows when a row has >= 64 of them (a few otherwise): reduce inside the
     // wave per row first, one atomic per row and wave
@@ -160,6 +170,14 @@ __global__ __launch_bounds__(1024) void frame_rows_kernel(
           else atomicMax(reinterpret_cast<unsigned*>(&rowmin_i[rr]), __float_as_uint(mr));
         }
       }
+    }
+  }
+  if (cols_ok) {  // column minima: the same integer atomics on the float pattern as the row minima
+    const int cg = (threadIdx.x % w4) * 4;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      if (cm[k] >= 0.0f) atomicMin(&colmin_i[cg + k], __float_as_int(cm[k] + 0.0f));
+      else atomicMax(reinterpret_cast<unsigned*>(&colmin_i[cg + k]), __float_as_uint(cm[k]));
     }
   }
   __syncthreads();
@@ -180,10 +198,18 @@ __global__ __launch_bounds__(1024) void frame_rows_kernel(
       if (((rowmin[r] - m) - press) < 0.0f) { lo = min(lo, r); hi = max(hi, r); }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) { lo = min(lo, __shfl_xor(lo, o, 64)); hi = max(hi, __shfl_xor(hi, o, 64)); }
+    int clo = 0, chi = W - 1;
+    if (cols_ok) {
+      clo = W; chi = -1;
+      for (int c = lane; c < W; c += 64)
+        if (((colmin[c] - m) - press) < 0.0f) { clo = min(clo, c); chi = max(chi, c); }
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) { clo = min(clo, __shfl_xor(clo, o, 64)); chi = max(chi, __shfl_xor(chi, o, 64)); }
+    }
     if (lane == 0) {
       fmin_out[b] = m;
       if (indent_out) indent_out[b] = press;
-      rows_out[2 * b] = lo; rows_out[2 * b + 1] = hi;
+      rows_out[4 * b] = lo; rows_out[4 * b + 1] = hi; rows_out[4 * b + 2] = clo; rows_out[4 * b + 3] = chi;
     }
   }
 }
@@ -902,22 +928,25 @@ static hipError_t dispatch_band(int k, bool first, const BlurArgs& a, hipStream_
 // min (+ conversion / indentation) AND the contact row range of every frame; false when the geometry is not supported
 // (the caller then runs run_frame_min and treats every row as contact)
 bool frame_rows_supported(int H, int W) { return (W % 4) == 0 && H <= kFrameRowsMaxH; }
-__global__ void fill_rows_kernel(int* rows, int B, int H) {
+__global__ void fill_rows_kernel(int* rows, int B, int H, int W) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
-  if (b < B) { rows[2 * b] = 0; rows[2 * b + 1] = H - 1; }
+  if (b < B) { rows[4 * b] = 0; rows[4 * b + 1] = H - 1; rows[4 * b + 2] = 0; rows[4 * b + 3] = W - 1; }
 }
-hipError_t run_fill_rows(int* rows, int B, int H, hipStream_t st) {  // "every row may hold contact" (geometry without a row kernel)
-  hipLaunchKernelGGL(fill_rows_kernel, dim3((B + 255) / 256), dim3(256), 0, st, rows, B, H);
+hipError_t run_fill_rows(int* rows, int B, int H, int W, hipStream_t st) {  // "every row / column may hold contact" (geometry without a row kernel)
+  hipLaunchKernelGGL(fill_rows_kernel, dim3((B + 255) / 256), dim3(256), 0, st, rows, B, H, W);
   return hipGetLastError();
 }
 hipError_t run_frame_rows(const float* in, bool from_depth, float* hm_out, float* fmin, float* indent, uint8_t* cam_u8,
                           const float* press_in, int* rows_out, int B, int H, int W, float near_mm, float far_m, float far_mm,
                           float gelpad_h, float gelpad_dmin, hipStream_t st) {
+  const int w4 = W >> 2;
+  int nt = w4 <= 1024 ? (1024 / w4) * w4 : 1024;  // a multiple of the row's float4 count: every thread keeps to four columns
+  if (nt < 512 || (nt & 63)) nt = 1024;           // (whole waves, enough of them; else the kernel reports every column as contact)
   if (from_depth)
-    hipLaunchKernelGGL(frame_rows_kernel<true>, dim3(B), dim3(1024), 0, st, in, hm_out, fmin, indent, cam_u8, press_in, rows_out,
+    hipLaunchKernelGGL(frame_rows_kernel<true>, dim3(B), dim3(nt), 0, st, in, hm_out, fmin, indent, cam_u8, press_in, rows_out,
                        H, W, near_mm, far_m, far_mm, gelpad_h, gelpad_dmin);
   else
-    hipLaunchKernelGGL(frame_rows_kernel<false>, dim3(B), dim3(1024), 0, st, in, hm_out, fmin, indent, cam_u8, press_in, rows_out,
+    hipLaunchKernelGGL(frame_rows_kernel<false>, dim3(B), dim3(nt), 0, st, in, hm_out, fmin, indent, cam_u8, press_in, rows_out,
                        H, W, near_mm, far_m, far_mm, gelpad_h, gelpad_dmin);
   return hipGetLastError();
 }
@@ -949,11 +978,11 @@ bool blur_level_single_kernel(const LevelDesc& lv, bool first, int H, int W) {
 hipError_t run_blur_level(const LevelDesc& lv, const float* src, const float* hm, const float* gel,
                           const float* sa, const float* sb, const float* pd, float* dst, float* tmp,
                           uint8_t* mask_out, int B, int H, int W, float contact_scale, int restore,
-                          bool first, hipStream_t st, const int* rows_ext, int ext_grow) {
+                          bool first, hipStream_t st, const int* rows_ext, int ext_grow, int ext_grow_x) {
   if (lv.same_taps && lv.taps_mfma_dev && mfma_supported(lv.kw, first, H, W)) {
     BlurArgs a{};
     a.src = src; a.hm = hm; a.shift_a = sa; a.shift_b = sb; a.pdepth = pd;
-    a.rows_ext = lv.gel_zero ? rows_ext : nullptr; a.ext_grow = ext_grow;  // zero-band skipping needs J = min(S, 0)
+    a.rows_ext = lv.gel_zero ? rows_ext : nullptr; a.ext_grow = ext_grow; a.ext_grow_x = ext_grow_x;  // zero-band / zero-block skipping needs J = min(S, 0)
     a.gel = lv.gel_zero ? nullptr : gel;  // all-zero gel map (GelSight Mini): no gel loads - half of level 0's V-pass reads
     a.dst = dst; a.mask_out = mask_out; a.taps = lv.taps_mfma_dev; a.H = H; a.W = W; a.B = B;
     a.contact_scale = contact_scale; a.restore = restore;

@@ -74,7 +74,7 @@ __global__ __launch_bounds__(640) void blur_mfma_kernel(BlurArgs a) {
     // outside has an exactly zero blur and no contact pixel to restore: store zeros, read nothing.  (Reflect padding cannot
     // bring a non-zero row in: a mirrored row index -k maps to row k, which the window contains as well.)
     if (a.rows_ext != nullptr) {
-      const int lo = a.rows_ext[2 * frame] - a.ext_grow, hi = a.rows_ext[2 * frame + 1] + a.ext_grow;
+      const int lo = a.rows_ext[4 * frame] - a.ext_grow, hi = a.rows_ext[4 * frame + 1] + a.ext_grow;
       if (by0 - R > hi || by0 + TH - 1 + R < lo) {
         const int w4 = W >> 2;
         for (int i = threadIdx.x; i < TH * w4; i += blockDim.x) {
@@ -91,6 +91,23 @@ __global__ __launch_bounds__(640) void blur_mfma_kernel(BlurArgs a) {
   const int wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // one 64-column super-block per wave
   const int li = lane & 15, g = lane >> 4;
   const int c0 = wid << 6;
+  // Zero-BLOCK skipping (round 5): the same argument along x.  This level's input is non-zero only in the columns [in_lo, in_hi] =
+  // the frame's contact columns grown by the previous levels' radii: a wave whose 64 columns lie outside has an exactly zero
+  // V-pass result (it stores zeros - and zeros into the mirrored padding it owns - without loading or multiplying anything), and a
+  // wave whose columns lie more than R outside has an exactly zero H-pass result and no contact pixel to restore (stores zeros,
+  // reads neither the LDS rows nor the height map).  With a contact patch of ~90 columns two of the five waves of a 320-wide band
+  // take these paths.  (Mirrored x-padding cannot bring a non-zero column in: position -c maps to column c, inside the window too.)
+  bool v_need = true, h_need = true;
+  if constexpr (GZ) {
+    if (a.rows_ext != nullptr) {
+      const int in_lo = a.rows_ext[4 * frame + 2] - a.ext_grow_x, in_hi = a.rows_ext[4 * frame + 3] + a.ext_grow_x;
+      v_need = !(c0 + 63 < in_lo || c0 > in_hi);
+      h_need = !(c0 + 63 < in_lo - R || c0 > in_hi + R);
+#ifdef TACEX_MFMA_NO_BLOCK_SKIP  // (A/B hook)
+      v_need = h_need = true;
+#endif
+    }
+  }
 
   // ---- V-pass ----
   {
@@ -118,6 +135,7 @@ __global__ __launch_bounds__(640) void blur_mfma_kernel(BlurArgs a) {
         if constexpr (FIRST) gb[chunk & 1][c] = GZ ? (v4f)(0.0f) : *reinterpret_cast<const v4f*>(gel + off);  // GZ: gel == 0 everywhere
       });
     };
+    if (v_need) {
     issue(std::integral_constant<int, 0>{});
     static_for<0, NCH>([&](auto chunk_c) {
       constexpr int chunk = decltype(chunk_c)::value;
@@ -146,6 +164,7 @@ __global__ __launch_bounds__(640) void blur_mfma_kernel(BlurArgs a) {
         });
       });
     });
+    }
     // D layout: column (lane & 15), row 4 (lane >> 4) + reg.  The lanes next to the left / right image border also write
     // the mirrored x-padding (torch 'reflect': position -c <- c, (W-1)+c <- (W-1)-c, c = 1..RA), so one barrier suffices.
     const int cx = c0 + 4 * li;
@@ -177,6 +196,19 @@ __global__ __launch_bounds__(640) void blur_mfma_kernel(BlurArgs a) {
       wl[ks] = a.taps[((TACEX_MFMA_H_CONSEC ? 0 : KS) + ks) * 64 + lane];
     });
     const float thr = -a.pdepth[frame] * a.contact_scale;  // TT:459
+    if (!h_need) {  // (wave-uniform) exactly zero output, no contact pixel in these columns
+#pragma unroll
+      for (int t = 0; t < NTILE; ++t) {
+        const int hrow = TACEX_MFMA_H_CONSEC ? li : mfma_h_row(li);
+        const size_t p0 = (size_t)(by0 + 16 * t + hrow) * W + c0 + 4 * g;
+#pragma unroll
+        for (int n = 0; n < 4; ++n) {
+          *reinterpret_cast<v4f*>(a.dst + fo + p0 + 16 * n) = (v4f)(0.0f);
+          if (a.mask_out) *reinterpret_cast<uchar4*>(a.mask_out + fo + p0 + 16 * n) = (uchar4){0, 0, 0, 0};
+        }
+      }
+      return;
+    }
 #pragma unroll
     for (int t = 0; t < NTILE; ++t) {
       f32x4 acc[4];

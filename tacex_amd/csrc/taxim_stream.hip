@@ -74,9 +74,10 @@ struct StreamArgs {
   float* pix_z; uint8_t* pix_m; int n_markers;
   const int* mk_x;          // marker column  (CSR over rows: StreamRowInfo::mk0 / mk1)
   const int* mk_id;         // marker index
-  const int* rows_ext;      // (B,2) contact row range of every frame (frame_rows_kernel), nullable
+  const int* rows_ext;      // (B,4) contact row range | contact column range of every frame (frame_rows_kernel), nullable
   int ext_grow;             // rows by which the band levels have spread the non-zero range of zin beyond it
   const int* order;         // (B * nstrips * nseg) item of every launched wave, heaviest first (stream_order_kernel); nullptr: identity
+  const float* flat_rgb;    // (H,W,3) RGB of the undeformed gel (stream_flat_image_kernel); nullptr: flat rows evaluate the polynomial
 };
 
 __device__ __forceinline__ float dpp_from_left(float v) {   // lane i receives lane i-1's value
@@ -289,7 +290,7 @@ __global__ __launch_bounds__(64 * kStreamWaves, MINW) void taxim_stream_kernel(S
   if constexpr (GZ && LEVELS) {
 #ifndef TACEX_STREAM_HM_ALWAYS  // (A/B probe: load both arrays of every row)
     if (a.rows_ext != nullptr) {
-      hm_lo = a.rows_ext[2 * frame]; hm_hi = a.rows_ext[2 * frame + 1];
+      hm_lo = a.rows_ext[4 * frame]; hm_hi = a.rows_ext[4 * frame + 1];
       z_lo = hm_lo - a.ext_grow; z_hi = hm_hi + a.ext_grow;
     }
 #endif
@@ -501,21 +502,17 @@ __global__ __launch_bounds__(64 * kStreamWaves, MINW) void taxim_stream_kernel(S
   bool flat = false;
   if constexpr (ROLE == kStreamFused && GZ) {
     if (a.rows_ext != nullptr) {
-      const int lo = a.rows_ext[2 * frame] - a.ext_grow, hi = a.rows_ext[2 * frame + 1] + a.ext_grow;
+      const int lo = a.rows_ext[4 * frame] - a.ext_grow, hi = a.rows_ext[4 * frame + 1] + a.ext_grow;
       flat = (r0 - SUMR - 1 > hi) || (r1 + SUMR + 1 < lo);
     }
-    if (flat) {
-      const int code = shade_dir_bin(a.sh, 0.0f, 0.0f, 0.0f);  // magnitude bin 0
-      StreamRec pcf[PX];
-      {
-        const StreamRec rf = stream_rec_load(code < nb_lds ? polyL + code * kStreamPolyPitch : a.sh.poly + (size_t)code * 24);
-#pragma unroll
-        for (int i = 0; i < PX; ++i) pcf[i] = rf;
-      }
-      if (LEVELS && (a.pix_z != nullptr || a.pix_m != nullptr)) {  // marker taps of this wave's rows: deformed gel 0, no contact
-        // (registered taps are written whether or not the contact-statistics partials are: a stale tap of an earlier frame
-        //  must not survive a flat wave)
-        const int e0 = a.rows[r0 * kStreamRowInts + 5], e1 = a.rows[(r1 - 1) * kStreamRowInts + 6];
+  }
+  // rows [lo, hi) of this wave's strip as FLAT gel: polynomial of the flat bin pair's record + background + store + observation; FOTS
+  // marker taps of rows [tlo, thi): deformed gel 0, no contact (registered taps are written whether or not the contact-statistics
+  // partials are: a stale tap of an earlier frame must not survive)
+  auto flat_rows = [&](int lo, int hi, int tlo, int thi) {
+    if constexpr (ROLE == kStreamFused && GZ) {
+      if (LEVELS && (a.pix_z != nullptr || a.pix_m != nullptr) && thi > tlo) {
+        const int e0 = a.rows[tlo * kStreamRowInts + 5], e1 = a.rows[(thi - 1) * kStreamRowInts + 6];
         for (int e = e0 + lane; e < e1; e += 64) {
           const int mx = a.mk_x[e];
           if (mx >= vx0 && mx < vx1) {
@@ -525,20 +522,104 @@ __global__ __launch_bounds__(64 * kStreamWaves, MINW) void taxim_stream_kernel(S
           }
         }
       }
-      if (do_fots) f_zmax = (valid[0] || valid[1] || valid[2]) ? 0.0f : -INFINITY;
+      if (hi <= lo) return;
+      if (a.flat_rgb != nullptr) {
+        // the flat gel's RGB is a per-context constant image: a flat row is three loads, three stores and its share of the observation
+        auto load_flat = [&](int row, v3f (&q)[PX]) {
+#pragma unroll
+          for (int i = 0; i < PX; ++i)
+            q[i] = *reinterpret_cast<const v3f*>(reinterpret_cast<const char*>(a.flat_rgb) + ((unsigned)row * (unsigned)W * 12u + xc[i]));
+        };
+        v3f fq[PX], fn[PX] = {(v3f)(0.0f), (v3f)(0.0f), (v3f)(0.0f)};
+        load_flat(lo, fq);
+        for (int e = lo; e < hi; ++e) {
+          if (e + 1 < hi) load_flat(e + 1, fn);
+          const StreamRowInfo ri = *reinterpret_cast<const StreamRowInfo*>(a.rows + e * kStreamRowInts);
+          float rgb[PX * 3];
+#pragma unroll
+          for (int i = 0; i < PX; ++i) {
+            rgb[3 * i] = fq[i].x; rgb[3 * i + 1] = fq[i].y; rgb[3 * i + 2] = fq[i].z;
+            if (valid[i])
+              *reinterpret_cast<v3f*>(reinterpret_cast<char*>(a.sh.rgb + fo * 3) + ((unsigned)e * (unsigned)W * 12u + xc[i])) = fq[i];
+          }
+          if (do_obs) {
+            while (cur_o0 < ri.o0) {
+              obs_flush(OA[0], cur_o0);
+#pragma unroll
+              for (int j = 0; j < PX * 3; ++j) { OA[0][j] = OA[1][j]; OA[1][j] = OA[2][j]; OA[2][j] = 0.0f; }
+              ++cur_o0;
+            }
+#pragma unroll
+            for (int j = 0; j < PX * 3; ++j) {
+              OA[0][j] = fmaf(ri.w0, rgb[j], OA[0][j]);
+              OA[1][j] = fmaf(ri.w1, rgb[j], OA[1][j]);
+              OA[2][j] = fmaf(ri.w2, rgb[j], OA[2][j]);
+            }
+          }
+          fq[0] = fn[0]; fq[1] = fn[1]; fq[2] = fn[2];
+        }
+        return;
+      }
+      const int code = shade_dir_bin(a.sh, 0.0f, 0.0f, 0.0f);  // magnitude bin 0
+      StreamRec pcf[PX];
+      {
+        const StreamRec rf = stream_rec_load(code < nb_lds ? polyL + code * kStreamPolyPitch : a.sh.poly + (size_t)code * 24);
+#pragma unroll
+        for (int i = 0; i < PX; ++i) pcf[i] = rf;
+      }
       v3f bq[PX], bn[PX] = {(v3f)(0.0f), (v3f)(0.0f), (v3f)(0.0f)};
-      load_bg(r0, bq);
-      for (int e = r0; e < r1; ++e) {
-        if (e + 1 < r1) load_bg(e + 1, bn);
+      load_bg(lo, bq);
+      for (int e = lo; e < hi; ++e) {
+        if (e + 1 < hi) load_bg(e + 1, bn);
         const StreamRowInfo ri = *reinterpret_cast<const StreamRowInfo*>(a.rows + e * kStreamRowInts);
         emit_row(e, ri, bq, pcf);
         bq[0] = bn[0]; bq[1] = bn[1]; bq[2] = bn[2];
       }
     }
+  };
+  // ROW TRIMMING (round 5; -DTACEX_STREAM_NO_TRIM restores the full march): the last level is exactly zero farther than SUMR rows from the band levels' non-zero range
+  // [z_lo, z_hi] of the frame, so of its rows [r0, r1) this wave only MARCHES over [ra, rb) = the rows within SUMR + 1 of that range; the
+  // rows above and below are flat gel (loops before / after the march), and the march starts at the first non-zero input row with
+  // the pipeline in its zero state (partial sums 0, S ring +inf = no restore) instead of SUMR + 1 rows of warm-up above the segment.
+  int ra = r0, rb = r1, y_first = ys, y_last = ye;
+  bool trimmed = false;
+#ifndef TACEX_STREAM_NO_TRIM
+  if constexpr (ROLE == kStreamFused && GZ) {
+    if (a.rows_ext != nullptr && !flat) {
+      int aa = max(r0, z_lo - SUMR - 1), bb = min(r1, z_hi + SUMR + 2);
+      if (aa <= 1) aa = r0;        // row 0 takes the bins of row 1 (replicated border): emitted by the march whenever row 1 is
+      if (bb >= H - 1) bb = r1;    // likewise H - 1 and H - 2
+      if (bb > aa) {
+        if (z_lo > SUMR + 1) y_first = max(ys, z_lo);  // (near the top border the reflected rows above it may be non-zero: full warm-up)
+        y_last = min(ye, bb + SUMR + 1);
+        ra = aa; rb = bb;
+        trimmed = ra > r0 || rb < r1 || y_first > ys || y_last < ye;
+      }
+    }
+  }
+#endif
+  if constexpr (ROLE == kStreamFused && GZ) {
+    if (flat) {
+      if (do_fots) f_zmax = (valid[0] || valid[1] || valid[2]) ? 0.0f : -INFINITY;
+      flat_rows(r0, r1, r0, r1);
+    } else if (trimmed) {
+      // the taps of every marker row the march will not write (it overwrites the ones it visits; the wait below orders the two)
+      if (do_fots) f_zmax = (valid[0] || valid[1] || valid[2]) ? 0.0f : -INFINITY;
+      flat_rows(r0, ra, r0, r1);
+    }
+  }
+  if constexpr (NL > 1) {
+    if (!flat && y_first > ys) {  // S ring: +inf (no restore) for the rows the trimmed march never wrote
+      for (int k = 0; k < NRING; ++k) {
+        if constexpr (C::ring_packed()) ring3[k * 64 + lane] = StreamS3{INFINITY, INFINITY, INFINITY};
+        else ring[k * 64 + lane] = (v4f){INFINITY, INFINITY, INFINITY, 0.0f};
+      }
+      wave_lds_fence();
+    }
   }
   if (!flat) {
-    issue_row(row_of(ys), ys & 1);
-    issue_row(row_of(ys + 1), (ys + 1) & 1);
+    issue_row(row_of(y_first), y_first & 1);
+    issue_row(row_of(y_first + 1), (y_first + 1) & 1);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   }
   // Row scalars, fetched one iteration ahead with a VECTOR load (lanes 0-7: record of the row shaded, 8-15: of the row
@@ -571,7 +652,7 @@ __global__ __launch_bounds__(64 * kStreamWaves, MINW) void taxim_stream_kernel(S
     }
   };
   if (!flat) {
-    cinfo = load_info(ys);
+    cinfo = load_info(y_first);
     unpack_info(cinfo);
   }
 #ifdef TACEX_STREAM_CLOCK
@@ -585,7 +666,7 @@ __global__ __launch_bounds__(64 * kStreamWaves, MINW) void taxim_stream_kernel(S
 #else
 #define TACEX_TICK(k) do { } while (0)
 #endif
-  int ring_slot = ((ys % NRING) + NRING) % NRING;  // ring slot of row y (wave-uniform, advanced once per iteration)
+  int ring_slot = ((y_first % NRING) + NRING) % NRING;  // ring slot of row y (wave-uniform, advanced once per iteration)
   // One iteration of the pipeline.  ST (compile time) = a STEADY iteration: the row entering (y .. y + 2), the row leaving the last
   // level and the row shaded all lie inside the image and inside this wave's segment, away from the replicated border rows - no
   // reflection of row indices, no "does this iteration shade / emit two rows" tests, the row-scalar fetch at a per-lane constant
@@ -594,7 +675,7 @@ __global__ __launch_bounds__(64 * kStreamWaves, MINW) void taxim_stream_kernel(S
   auto iteration = [&](const int y, auto st_c) {
     constexpr bool ST = decltype(st_c)::value;
 #else
-  for (int y = flat ? ye + 1 : ys; y <= ye; ++y) {
+  for (int y = flat ? y_last + 1 : y_first; y <= y_last; ++y) {
     constexpr bool ST = false;
 #endif
     // ---- row y out of the ring (it landed before the previous iteration's mid_point returned); next iteration's row scalars ----
@@ -631,7 +712,7 @@ __global__ __launch_bounds__(64 * kStreamWaves, MINW) void taxim_stream_kernel(S
     //      Replicate padding of the gradient maps (TT:501-502): rows 0 / H-1 take the gradient of rows 1 / H-2 and are emitted
     //      together with them; columns 0 / W-1 take the bins of columns 1 / W-2. ----
     const int gs = y - SUMR - 2;
-    const bool shade_now = SHADE && (ST || (gs >= max(r0, 1) && gs <= min(r1 - 1, H - 2)));
+    const bool shade_now = SHADE && (ST || (gs >= max(ra, 1) && gs <= min(rb - 1, H - 2)));
     int cc[PX] = {0, 0, 0};  // table record (bin pair) of every pixel of row gs
     StreamRec pc[PX];        // its 18 polynomial coefficients (TT:250-255), fetched at the top of the iteration
     auto fetch_table = [&]() {
@@ -916,7 +997,7 @@ __global__ __launch_bounds__(64 * kStreamWaves, MINW) void taxim_stream_kernel(S
       } else if (shade_now) {
         const int e_lo = gs == 1 ? 0 : gs, e_hi = gs == H - 2 ? H - 1 : gs;  // rows emitted by this iteration (ascending)
         for (int e = e_lo; e <= e_hi; ++e) {
-          if (e < r0 || e >= r1) continue;
+          if (e < ra || e >= rb) continue;
           StreamRowInfo ri = ri_g;
           v3f bq[PX] = {bgq[0], bgq[1], bgq[2]};
           if (e != gs) {  // a replicated border row: its own feature / background / observation row (twice per frame)
@@ -968,6 +1049,9 @@ __global__ __launch_bounds__(64 * kStreamWaves, MINW) void taxim_stream_kernel(S
     dbg[0] = clk_acc[0]; dbg[1] = clk_acc[1]; dbg[2] = clk_acc[2]; dbg[3] = clk_acc[3];
   }
 #endif
+  if constexpr (ROLE == kStreamFused && GZ) {
+    if (trimmed && rb < r1) flat_rows(rb, r1, 0, 0);  // the flat rows below the march (ascending row order: the observation rows retire in order)
+  }
   if constexpr (SHADE) {
     if (do_obs) {  // observation rows still in flight at the end of the segment (another segment adds its share)
       obs_flush(OA[0], cur_o0);
@@ -995,6 +1079,22 @@ __global__ __launch_bounds__(64 * kStreamWaves, MINW) void taxim_stream_kernel(S
   }
 }
 
+// RGB of the undeformed gel (every gradient zero: direction 0 -> the flat bin pair's record, TT:494-499): the same arithmetic, in the same
+// order, as emit_row - what a flat row of the streaming tail would compute for every frame is a per-context constant image
+__global__ __launch_bounds__(256) void stream_flat_image_kernel(ShadeArgs sh, float* __restrict__ out) {
+  const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+  if (x >= sh.W) return;
+  const int code = shade_dir_bin(sh, 0.0f, 0.0f, 0.0f);
+  const StreamRec r = stream_rec_load(sh.poly + (size_t)code * 24);
+  float p0, p1, p2;
+  stream_poly(sh.fx[x], sh.fy[y], r, p0, p1, p2);
+  const float* bg = sh.bg + ((size_t)y * sh.W + x) * 3;
+  float* o = out + ((size_t)y * sh.W + x) * 3;
+  o[0] = __builtin_amdgcn_fmed3f(p0 + bg[0], 0.0f, 1.0f);
+  o[1] = __builtin_amdgcn_fmed3f(p1 + bg[1], 0.0f, 1.0f);
+  o[2] = __builtin_amdgcn_fmed3f(p2 + bg[2], 0.0f, 1.0f);
+}
+
 // Items of a launch sorted by weight, heaviest first: key = rows of the item's segment that lie on (or within a few rows of) the
 // frame's contact rows - there the shading gathers table records and runs the magnitude arc tangent - 0 for a flat item (no
 // contact within the pyramid's reach: no levels, no bins).  Counting sort by one workgroup; the order inside a bucket is
@@ -1010,7 +1110,7 @@ __global__ __launch_bounds__(1024) void stream_order_kernel(const int* __restric
   auto key_of = [&](int item) {
     const int frame = item / per_frame, seg = (item - frame * per_frame) % nseg;
     const int r0 = seg * seg_rows, r1 = min(H, r0 + seg_rows);
-    const int lo = rows_ext[2 * frame], hi = rows_ext[2 * frame + 1];
+    const int lo = rows_ext[4 * frame], hi = rows_ext[4 * frame + 1];
     if ((r0 - reach > hi) || (r1 + reach < lo)) return 0;  // flat (frames without contact: lo = H, hi = -1)
     const int pad = 4;
     const int c = min(r1 - 1, hi + pad) - max(r0, lo - pad) + 1;
@@ -1150,6 +1250,22 @@ static hipError_t launch_stream(const StreamArgs& a, bool gel_zero, hipStream_t 
   return gel_zero ? launch_stream_k<true, ROLE, KS...>(a, st) : launch_stream_k<false, ROLE, KS...>(a, st);
 }
 
+static void fill_shade_args(ShadeArgs& sh, const ShadeParams* sp, float* rgb, int B, int H, int W) {
+  sh.poly = sp->poly_dev; sh.bg = sp->bg_nhwc_dev; sh.fx = sp->fx_dev; sh.fy = sp->fy_dev; sh.rgb = rgb;
+  sh.idx_out = nullptr; sh.H = H; sh.W = W; sh.B = B; sh.nb = sp->nb; sh.pixmm = sp->pixmm;
+  sh.calib_h = (float)sp->calib_h; sh.calib_w = (float)sp->calib_w; sh.x_binr = sp->x_binr; sh.y_binr = sp->y_binr;
+  sh.gsy = (float)(0.5 * H / sp->calib_h / (double)sp->pixmm); sh.gsx = (float)(0.5 * W / sp->calib_w / (double)sp->pixmm);
+  sh.inv_x_binr = (float)(1.0 / (double)sp->x_binr); sh.inv_y_binr = (float)(1.0 / (double)sp->y_binr);
+}
+
+hipError_t run_stream_flat_image(const ShadeParams* sp, int H, int W, hipStream_t st) {
+  if (!sp->flat_rgb_dev) return hipErrorInvalidValue;
+  ShadeArgs sh{};
+  fill_shade_args(sh, sp, nullptr, 1, H, W);
+  hipLaunchKernelGGL(stream_flat_image_kernel, dim3((W + 255) / 256, H), dim3(256), 0, st, sh, sp->flat_rgb_dev);
+  return hipGetLastError();
+}
+
 hipError_t run_stream_tail(const LevelDesc* lv, int n_levels, int n_fused, const float* zin, const float* hm, const float* gel,
                            const float* sa, const float* sb, const float* pd, const ShadeParams* sp, float* rgb, float* z_last,
                            int B, int H, int W, float contact_scale, const StreamPlan& plan, float* obs_part,
@@ -1162,11 +1278,10 @@ hipError_t run_stream_tail(const LevelDesc* lv, int n_levels, int n_fused, const
   a.zin = zin; a.hm = hm; a.gel = lv[0].gel_zero ? nullptr : gel; a.shift_a = sa; a.shift_b = sb; a.pdepth = pd;
   a.H = H; a.W = W; a.B = B; a.contact_scale = contact_scale;
   for (int i = 0; i < n_fused; ++i) a.taps[i] = lv[n_levels - n_fused + i].taps_w_dev;
-  a.sh.poly = sp->poly_dev; a.sh.bg = sp->bg_nhwc_dev; a.sh.fx = sp->fx_dev; a.sh.fy = sp->fy_dev; a.sh.rgb = rgb;
-  a.sh.idx_out = nullptr; a.sh.H = H; a.sh.W = W; a.sh.B = B; a.sh.nb = sp->nb; a.sh.pixmm = sp->pixmm;
-  a.sh.calib_h = (float)sp->calib_h; a.sh.calib_w = (float)sp->calib_w; a.sh.x_binr = sp->x_binr; a.sh.y_binr = sp->y_binr;
-  a.sh.gsy = (float)(0.5 * H / sp->calib_h / (double)sp->pixmm); a.sh.gsx = (float)(0.5 * W / sp->calib_w / (double)sp->pixmm);
-  a.sh.inv_x_binr = (float)(1.0 / (double)sp->x_binr); a.sh.inv_y_binr = (float)(1.0 / (double)sp->y_binr);
+  fill_shade_args(a.sh, sp, rgb, B, H, W);
+#ifndef TACEX_STREAM_NO_TRIM
+  a.flat_rgb = sp->flat_rgb_dev;
+#endif
   {
     const double t1 = tan((double)sp->x_binr) * (1.0 - 2e-5);
     a.mag0_t2 = (float)(t1 * t1);

@@ -220,7 +220,7 @@ class TaximHip:
         pass (fused into the tail kernel where one exists).
 
         Extra keyword arguments (not in the reference): `out` (B,H,W,3) buffer to render into,
-        `frame_min` (B,) precomputed per-frame minimum (+ `frame_rows` (B,2) int32, the contact row ranges produced with it),
+        `frame_min` (B,) precomputed per-frame minimum (+ `frame_rows` (B,4) int32, the contact row and column ranges produced with it),
         `z_out` / `mask_out` to also return the deformed gel
         and the shrunken contact mask of taxim_torch.py:443-473 (the FOTS wrapper needs both).
         """
@@ -240,7 +240,8 @@ class TaximHip:
         if frame_min is not None:
             flags |= _lib.FLAG_HAVE_FRAME_MIN
             fmin = frame_min
-            if frame_rows is not None and frame_rows.dtype == torch.int32 and frame_rows.is_contiguous() and frame_rows.shape[0] >= B:
+            if frame_rows is not None and frame_rows.dtype == torch.int32 and frame_rows.is_contiguous() and frame_rows.shape[0] >= B \
+                    and frame_rows.dim() == 2 and frame_rows.shape[1] == 4:
                 key = (frame_rows.data_ptr(), int(frame_rows.shape[0]))
                 if self._frame_rows_key.get((H, W)) != key:  # registered once per buffer
                     _lib.check(self._lib.tacex_taxim_set_frame_rows(ctx.handle, _lib.ptr(frame_rows), int(frame_rows.shape[0])),

@@ -41,9 +41,9 @@ class TaximSimulator(GelSightSimulator):
         # per-frame minimum of the current height map, shared between compute_indentation_depth and the render
         self._frame_min = torch.zeros((self._num_envs,), device=self._device)
         self._frame_min_version = -1
-        # first / last frame row with a pixel below the press plane, produced with the minimum (tacex_height_map_from_depth /
+        # first / last frame row and first / last frame column with a pixel below the press plane, produced with the minimum (tacex_height_map_from_depth /
         # tacex_indentation_depth); the render skips the pyramid bands that cannot be non-zero
-        self._frame_rows = torch.zeros((self._num_envs, 2), dtype=torch.int32, device=self._device)
+        self._frame_rows = torch.zeros((self._num_envs, 4), dtype=torch.int32, device=self._device)  # [row lo, row hi, column lo, column hi]
         self._frame_rows_version = -1
         self._indent_version = -1
         # deformed gel + contact mask of the latest render, kept for a marker simulator (FOTS re-uses them)

@@ -87,18 +87,20 @@ def test_indentation_depth_kernel(calib_dir):
     np.testing.assert_array_equal(_np(fmin), hm.numpy().min(axis=(1, 2)))
     np.testing.assert_array_equal(_np(ind), TaximOracle.indentation_depth(hm.numpy()))
     # the same pass with the contact row range as a by-product (row-wise kernel): identical minimum / indentation, and
-    # rows = first / last row with S = (hm - min) - indent < 0 in float32 (TT:441), (H, -1) for frames without contact
+    # rows[:, 0:2] = first / last row with S = (hm - min) - indent < 0 in float32 (TT:441), (H, -1) for frames without contact
     fmin2, ind2 = torch.empty(9, device="cuda"), torch.empty(9, device="cuda")
-    rows = torch.full((9, 2), 77, dtype=torch.int32, device="cuda")
+    rows = torch.full((9, 4), 77, dtype=torch.int32, device="cuda")
     _lib.check(lib.tacex_indentation_depth(d.data_ptr(), 0.0045, 0.024, fmin2.data_ptr(), ind2.data_ptr(), rows.data_ptr(), 9, 240, 320,
                                            torch.cuda.current_stream().cuda_stream), "indent+rows")
     np.testing.assert_array_equal(_np(fmin2), _np(fmin))
     np.testing.assert_array_equal(_np(ind2), _np(ind))
     S = (hm - fmin.cpu().view(-1, 1, 1)) - ind.cpu().view(-1, 1, 1)
     has = (S < 0).any(2).numpy()
-    want = np.array([[np.where(r)[0][0], np.where(r)[0][-1]] if r.any() else [240, -1] for r in has], dtype=np.int32)
+    hasc = (S < 0).any(1).numpy()  # ... and the first / last such COLUMN, (W, -1) without contact (zero-block skipping of the band levels)
+    want = np.array([[np.where(r)[0][0], np.where(r)[0][-1], np.where(c)[0][0], np.where(c)[0][-1]] if r.any() else [240, -1, 320, -1]
+                     for r, c in zip(has, hasc)], dtype=np.int32)
     np.testing.assert_array_equal(_np(rows), want)
-    assert (want[:, 1] >= 0).any() and (want[:, 1] < 0).any()
+    assert (want[:, 1] >= 0).any() and (want[:, 1] < 0).any() and (want[:, 3] - want[:, 2] < 200).any()
 
 
 def test_zero_band_skipping_is_exact(calib_dir, tmp_path):
