@@ -1355,7 +1355,9 @@ __global__ __launch_bounds__(NT) void fem_newton_lds_kernel(FemDev m, double* xg
   bool done = false;
   double pcg_total = 0.0, dmax_last = INFINITY;
   // warm start of the next iteration's PCG: the part of this iteration's Newton direction the CCD filter / the line search cut off
-  double dprev[3] = {0, 0, 0};
+  // (the direction is parked in the env's workspace block, behind the (V,16) preconditioner blocks: it is written once and read at most
+  //  once per Newton iteration - as three more live f64 registers across the PCG loop it was part of what the allocator sent to scratch)
+  double* const dprev_g = lagg + (size_t)gridDim.x * 16 * V + ((size_t)b * V + (own ? tid : 0)) * 3;
   double frac_prev = 0.0;  // (1 - accepted step) of the previous iteration, 0 when it was taken in full or rejected
   // FRICTION LAG AT THE START OF THE STEP (`follow` bit 1, the default): normal force and normal are taken in the FIRST iteration, at the
   // state the step starts from - IPC's lag "from the previous time step" (Li et al. 2020, section 5.4): that state is the previous step's
@@ -1734,7 +1736,7 @@ restart_iteration:
   const bool warm_used = warm;
   if (warm) {
 #pragma unroll
-    for (int i = 0; i < 3; ++i) d3[i] = frac_prev * dprev[i];
+    for (int i = 0; i < 3; ++i) d3[i] = own ? frac_prev * dprev_g[i] : 0.0;
   }
   int it = 0;
   bool neg_curv = false;
@@ -1913,7 +1915,8 @@ restart_iteration:
   dmax_last = dmax;
   frac_prev = (accepted && step < 1.0) ? 1.0 - step : 0.0;
 #pragma unroll
-  for (int i = 0; i < 3; ++i) dprev[i] = d3[i];
+  for (int i = 0; i < 3; ++i)
+    if (own) dprev_g[i] = d3[i];
   if (tid == 0) {
     stats[(size_t)b * 4 + 0] = E0; stats[(size_t)b * 4 + 1] = E1; stats[(size_t)b * 4 + 2] = step; stats[(size_t)b * 4 + 3] = (double)it;
 #ifdef TACEX_FEM_CLOCK
