@@ -32,7 +32,7 @@ extern "C" {
 #endif
 
 #define TACEX_MAX_LEVELS 8
-#define TACEX_ABI_VERSION 10
+#define TACEX_ABI_VERSION 11
 
 typedef struct tacex_taxim_ctx tacex_taxim_ctx;
 typedef struct tacex_fots_ctx tacex_fots_ctx;
@@ -91,6 +91,21 @@ int tacex_height_map_from_depth(const float* depth_m_dev, double near_clip_m, do
                                 float* hm_mm_dev, float* frame_min_dev, float* indent_mm_dev,
                                 uint8_t* cam_u8_dev, int32_t* frame_rows_dev, int num_frames, int height, int width,
                                 void* stream);
+
+/* The same pass, handed to the NEXT tacex_taxim_render / _render_obs / _deform call of `ctx` instead of being launched now (ABI 11).
+ * A render whose hm_mm / frame_min / press buffers are this pass's hm_mm_dev / frame_min_dev / indent_mm_dev (same frame count,
+ * TACEX_FLAG_HAVE_FRAME_MIN, a frame-rows buffer that is this pass's) runs it INSIDE the pass: per chunk of the band levels, on the
+ * chunk's own stream, so that one chunk's depth pass (HBM-bound) overlaps the previous chunk's band levels (matrix pipe) - the
+ * reference's sequence _get_height_map -> compute_indentation_depth -> optical_simulation (GS:229-263, 581-593) as one launch
+ * sequence.  Any other render on the context, or tacex_taxim_flush_deferred, runs the pending pass in full first: the outputs are
+ * complete, in stream order, no later than the end of the next call on the context.  Frame size = the context's.  At most one
+ * pending pass per context (a second call fails). */
+int tacex_taxim_defer_height_map_from_depth(tacex_taxim_ctx* ctx, const float* depth_m_dev, double near_clip_m, double far_clip_m,
+                                            float gelpad_height_m, float gelpad_to_camera_min_distance_m,
+                                            float* hm_mm_dev, float* frame_min_dev, float* indent_mm_dev,
+                                            uint8_t* cam_u8_dev, int32_t* frame_rows_dev, int num_frames);
+/* Runs a pending deferred pass now (no-op without one). */
+int tacex_taxim_flush_deferred(tacex_taxim_ctx* ctx, void* stream);
 
 /* Height-map SOURCE: rasterise one analytic indenter per env into the height map (mm), with the per-frame
  * minimum and the indentation depth of TS:115-131 in the same pass.  Stands in for the TiledCamera depth render

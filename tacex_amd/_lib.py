@@ -11,7 +11,7 @@ from pathlib import Path
 from ._build import LIB, build_library
 
 MAX_LEVELS = 8
-ABI_VERSION = 10  # TACEX_ABI_VERSION of include/tacex_hip.h; bumped whenever a signature or struct layout changes
+ABI_VERSION = 11  # TACEX_ABI_VERSION of include/tacex_hip.h; bumped whenever a signature or struct layout changes
 FLAG_NO_SHIFT = 1
 FLAG_HAVE_FRAME_MIN = 2
 FLAG_WITH_SHADOW = 4
@@ -99,6 +99,8 @@ SIGNATURES = {
     "tacex_taxim_shadow_workspace_bytes": (_sz, [_vp, _i]),
     "tacex_taxim_shadow_rays": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _vp]),
     "tacex_height_map_from_depth": (_i, [_vp, _d, _d, _f, _f, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
+    "tacex_taxim_defer_height_map_from_depth": (_i, [_vp, _vp, _d, _d, _f, _f, _vp, _vp, _vp, _vp, _vp, _i]),
+    "tacex_taxim_flush_deferred": (_i, [_vp, _vp]),
     "tacex_indentation_depth": (_i, [_vp, _f, _f, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "tacex_taxim_set_frame_rows": (_i, [_vp, _vp, _i]),
     "tacex_depth_from_mesh": (_i, [_vp, _vp, _i, _i, _vp, _vp, _f, _f, _f, _f, _f, _f, _vp, _vp, _i, _i, _i, _vp]),

@@ -71,6 +71,14 @@ struct tacex_taxim_ctx {
   int mk_version = 0;
   const int* frame_rows = nullptr; int frame_rows_cap = 0;  // caller-owned contact row ranges (tacex_taxim_set_frame_rows)
   int* stream_order = nullptr; int stream_order_cap = 0;  // item order of a streaming-tail launch (stream_order_kernel), grown by stream_plan
+  // depth -> height map pass handed to the NEXT render of this context (tacex_taxim_defer_height_map_from_depth): the render runs it
+  // per band-level chunk on the chunk's own stream, so chunk k+1's depth pass (HBM-bound) overlaps chunk k's band levels (matrix pipe)
+  struct DepthPass {
+    bool armed = false;
+    const float* depth = nullptr; float near_mm = 0, far_m = 0, far_mm = 0, gelpad_h = 0, gelpad_dmin = 0;
+    float* hm = nullptr; float* fmin = nullptr; float* indent = nullptr; uint8_t* cam_u8 = nullptr; int* rows = nullptr;
+    int B = 0;
+  } depth_pass;
   // second stream of the band levels (pipeline_impl: odd chunks of a pass run beside the even ones), created on first use
   static constexpr int kMaxLvlStreams = 4;
   hipStream_t lvl_stream[kMaxLvlStreams - 1] = {}; hipEvent_t lvl_fork = nullptr, lvl_join[kMaxLvlStreams - 1] = {};
@@ -514,24 +522,65 @@ struct StageTimer {
   }
 };
 
-int tacex_height_map_from_depth(const float* depth_m, double near_m, double far_m, float gelpad_h,
-                                float gelpad_dmin, float* hm_mm, float* frame_min, float* indent_mm,
-                                uint8_t* cam_u8, int32_t* frame_rows, int B, int H, int W, void* stream) {
-  if (!depth_m || !hm_mm || !frame_min) { set_error("tacex_height_map_from_depth: null buffer"); return 2; }
-  if (frame_rows && !indent_mm) { set_error("tacex_height_map_from_depth: frame_rows needs indent_mm"); return 2; }
-  if (B <= 0) return 0;
-  if (frame_rows && frame_rows_supported(H, W)) {
-    HIP_TRY(run_frame_rows(depth_m, true, hm_mm, frame_min, indent_mm, cam_u8, nullptr, frame_rows, B, H, W, (float)(near_m * 1000.0),
-                           (float)far_m, (float)(far_m * 1000.0), gelpad_h, gelpad_dmin, (hipStream_t)stream),
+}  // extern "C"
+
+// frames [b0, b0 + nb) of a depth -> height map pass (GS:581-593 + TS:115-131 + contact row / column ranges)
+static int depth_pass_range(const tacex_taxim_ctx::DepthPass& d, int b0, int nb, int H, int W, hipStream_t st) {
+  const size_t o = (size_t)b0 * H * W;
+  uint8_t* u8 = d.cam_u8 ? d.cam_u8 + o : nullptr;
+  float* ind = d.indent ? d.indent + b0 : nullptr;
+  if (d.rows && frame_rows_supported(H, W)) {
+    HIP_TRY(run_frame_rows(d.depth + o, true, d.hm + o, d.fmin + b0, ind, u8, nullptr, d.rows + 4 * b0, nb, H, W, d.near_mm, d.far_m, d.far_mm,
+                           d.gelpad_h, d.gelpad_dmin, st),
             "frame_rows_kernel<depth>");
     return 0;
   }
-  if (frame_rows) HIP_TRY(run_fill_rows(frame_rows, B, H, W, (hipStream_t)stream), "fill_rows_kernel");
-  // GS:573-574: `clipping_range[i] * 1000` is a Python double product; torch rounds it ONCE to float32 as the scalar operand
-  HIP_TRY(run_frame_min(depth_m, true, hm_mm, frame_min, indent_mm, cam_u8, B, H * W, (float)(near_m * 1000.0), (float)far_m,
-                        (float)(far_m * 1000.0), gelpad_h, gelpad_dmin, (hipStream_t)stream),
+  if (d.rows) HIP_TRY(run_fill_rows(d.rows + 4 * b0, nb, H, W, st), "fill_rows_kernel");
+  HIP_TRY(run_frame_min(d.depth + o, true, d.hm + o, d.fmin + b0, ind, u8, nb, H * W, d.near_mm, d.far_m, d.far_mm, d.gelpad_h, d.gelpad_dmin, st),
           "frame_min_kernel<depth>");
   return 0;
+}
+
+static int fill_depth_pass(tacex_taxim_ctx::DepthPass* d, const char* who, const float* depth_m, double near_m, double far_m, float gelpad_h,
+                           float gelpad_dmin, float* hm_mm, float* frame_min, float* indent_mm, uint8_t* cam_u8, int32_t* frame_rows, int B) {
+  if (!depth_m || !hm_mm || !frame_min) { set_error("%s: null buffer", who); return 2; }
+  if (frame_rows && !indent_mm) { set_error("%s: frame_rows needs indent_mm", who); return 2; }
+  d->depth = depth_m;
+  // GS:573-574: `clipping_range[i] * 1000` is a Python double product; torch rounds it ONCE to float32 as the scalar operand
+  d->near_mm = (float)(near_m * 1000.0); d->far_m = (float)far_m; d->far_mm = (float)(far_m * 1000.0);
+  d->gelpad_h = gelpad_h; d->gelpad_dmin = gelpad_dmin;
+  d->hm = hm_mm; d->fmin = frame_min; d->indent = indent_mm; d->cam_u8 = cam_u8; d->rows = frame_rows; d->B = B;
+  return 0;
+}
+
+extern "C" {
+
+int tacex_height_map_from_depth(const float* depth_m, double near_m, double far_m, float gelpad_h,
+                                float gelpad_dmin, float* hm_mm, float* frame_min, float* indent_mm,
+                                uint8_t* cam_u8, int32_t* frame_rows, int B, int H, int W, void* stream) {
+  tacex_taxim_ctx::DepthPass d;
+  if (int rc = fill_depth_pass(&d, "tacex_height_map_from_depth", depth_m, near_m, far_m, gelpad_h, gelpad_dmin, hm_mm, frame_min, indent_mm,
+                               cam_u8, frame_rows, B)) return rc;
+  if (B <= 0) return 0;
+  return depth_pass_range(d, 0, B, H, W, (hipStream_t)stream);
+}
+
+int tacex_taxim_defer_height_map_from_depth(tacex_taxim_ctx* c, const float* depth_m, double near_m, double far_m, float gelpad_h,
+                                            float gelpad_dmin, float* hm_mm, float* frame_min, float* indent_mm, uint8_t* cam_u8,
+                                            int32_t* frame_rows, int B) {
+  if (!c) { set_error("tacex_taxim_defer_height_map_from_depth: null context"); return 2; }
+  if (c->depth_pass.armed) { set_error("tacex_taxim_defer_height_map_from_depth: a deferred pass is already pending on this context"); return 2; }
+  if (int rc = fill_depth_pass(&c->depth_pass, "tacex_taxim_defer_height_map_from_depth", depth_m, near_m, far_m, gelpad_h, gelpad_dmin, hm_mm,
+                               frame_min, indent_mm, cam_u8, frame_rows, B)) return rc;
+  c->depth_pass.armed = B > 0;
+  return 0;
+}
+
+int tacex_taxim_flush_deferred(tacex_taxim_ctx* c, void* stream) {
+  if (!c) { set_error("tacex_taxim_flush_deferred: null context"); return 2; }
+  if (!c->depth_pass.armed) return 0;
+  c->depth_pass.armed = false;
+  return depth_pass_range(c->depth_pass, 0, c->depth_pass.B, c->H, c->W, (hipStream_t)stream);
 }
 
 int tacex_height_map_from_indenters(const float* indenters, float pixmm, float gel_top_mm, float far_clip_mm, float gelpad_h,
@@ -566,7 +615,7 @@ int tacex_indentation_depth(const float* hm_mm, float gelpad_h, float gelpad_dmi
 static int pipeline_chunk(tacex_taxim_ctx* c, const float* hm, const float* press, float* frame_min, float* rgb,
                           float* z_out, uint8_t* mask_out, void* ws, int B, unsigned flags, hipStream_t st,
                           float* obs_h, void* obs, int obs_hh, int obs_w, FotsReduce* fots_part, int frame0,
-                          const int* rows = nullptr);
+                          const int* rows = nullptr, const tacex_taxim_ctx::DepthPass* dp = nullptr);
 
 // The extra streams the band levels of a pass alternate on (TWO CHUNKS IN FLIGHT, pipeline_chunk) come from ONE pool per device,
 // created at first use and kept for the life of the process.  A stream per CONTEXT (round 4) made what a context measured depend on
@@ -627,6 +676,19 @@ static int pipeline_impl(tacex_taxim_ctx* c, const float* hm, const float* press
                          float* z_out, uint8_t* mask_out, void* ws, int B, unsigned flags, hipStream_t st,
                          float* obs_h = nullptr, void* obs = nullptr, int obs_hh = 0, int obs_w = 0) {
   const int cf = chunk_frames(c, B);
+  // A deferred depth -> height map pass (tacex_taxim_defer_height_map_from_depth) that produces exactly this call's inputs runs inside
+  // the pass, chunk by chunk (pipeline_chunk); one that does not is run in full first - it was promised no later than this call.
+  tacex_taxim_ctx::DepthPass dpl;
+  const tacex_taxim_ctx::DepthPass* dp = nullptr;
+  if (c->depth_pass.armed) {
+    c->depth_pass.armed = false;
+    dpl = c->depth_pass;
+    const bool fits = dpl.B == B && dpl.hm == hm && dpl.fmin == frame_min && dpl.indent == press && press &&
+                      (flags & TACEX_FLAG_HAVE_FRAME_MIN) && !(flags & TACEX_FLAG_NO_SHIFT) &&
+                      (!(flags & TACEX_FLAG_HAVE_FRAME_ROWS) || dpl.rows == c->frame_rows);
+    if (fits) dp = &dpl;
+    else if (int rc = depth_pass_range(dpl, 0, dpl.B, c->H, c->W, st)) return rc;
+  }
   FotsReduce* fp = (c->fots_part && B <= c->fots_cap) ? c->fots_part : nullptr;
   const size_t fper = tail_tiles_per_frame(c->H, c->W) * kTailWavesPerTile;
   // Contact row ranges (zero-band skipping of the band levels, TACEX_BAND_SKIP=0 disables): from the caller's buffer when the
@@ -651,16 +713,23 @@ static int pipeline_impl(tacex_taxim_ctx* c, const float* hm, const float* press
   }
   if (cf >= B)
     return pipeline_chunk(c, hm, press, frame_min, rgb, z_out, mask_out, ws, B, flags, st, obs_h, obs, obs_hh, obs_w, fp,
-                          B <= c->fots_pix_cap ? 0 : -1, rows);
+                          B <= c->fots_pix_cap ? 0 : -1, rows, dp);
   const size_t npix = (size_t)c->H * c->W;
   for (int b0 = 0; b0 < B; b0 += cf) {
     const int n = B - b0 < cf ? B - b0 : cf;
+    tacex_taxim_ctx::DepthPass dpc;
+    if (dp) {  // the chunk's share of the deferred pass
+      dpc = *dp;
+      dpc.depth += b0 * npix; dpc.hm += b0 * npix; dpc.fmin += b0; dpc.indent += b0; dpc.B = n;
+      if (dpc.cam_u8) dpc.cam_u8 += b0 * npix;
+      if (dpc.rows) dpc.rows += 4 * b0;
+    }
     int rc = pipeline_chunk(c, hm + b0 * npix, press ? press + b0 : nullptr, frame_min + b0, rgb ? rgb + b0 * npix * 3 : nullptr,
                             z_out ? z_out + b0 * npix : nullptr, mask_out ? mask_out + b0 * npix : nullptr, ws, n,
                             flags, st, obs_h,
                             obs ? static_cast<char*>(obs) + (size_t)b0 * obs_hh * obs_w * 3 * ((flags & TACEX_FLAG_OBS_U8) ? 1 : 4) : nullptr,
                             obs_hh, obs_w, fp ? fp + (size_t)b0 * fper : nullptr, B <= c->fots_pix_cap ? b0 : -1,
-                            rows ? rows + 4 * b0 : nullptr);
+                            rows ? rows + 4 * b0 : nullptr, dp ? &dpc : nullptr);
     if (rc) return rc;
   }
   return 0;
@@ -678,7 +747,7 @@ static int resize_obs(tacex_taxim_ctx* c, const float* rgb, float* scratch, void
 static int pipeline_chunk(tacex_taxim_ctx* c, const float* hm, const float* press, float* frame_min, float* rgb,
                           float* z_out, uint8_t* mask_out, void* ws, int B, unsigned flags, hipStream_t st,
                           float* obs_h, void* obs, int obs_hh, int obs_w, FotsReduce* fots_part, int frame0,
-                          const int* rows) {
+                          const int* rows, const tacex_taxim_ctx::DepthPass* dp) {
   const bool obs_u8 = (flags & TACEX_FLAG_OBS_U8) != 0;
   const size_t img = align_up((size_t)B * c->H * c->W * sizeof(float), 256);
   const size_t vec = align_up((size_t)B * sizeof(float), 256);
@@ -733,6 +802,16 @@ static int pipeline_chunk(tacex_taxim_ctx* c, const float* hm, const float* pres
       }
     static const int env_lcf = getenv("TACEX_LEVEL_CHUNK_FRAMES") ? atoi(getenv("TACEX_LEVEL_CHUNK_FRAMES")) : -1;
     if (env_lcf < 0) lcf = (lcf + lvl_streams - 1) / lvl_streams;
+  }
+  // A deferred depth pass is interleaved with the band levels only where that pays: chunks alternating on two streams, and chunks of
+  // >= 128 frames (the pass runs one workgroup per frame).  Measured (profiles/r05_experiments.md section 15): 320x240 in 128-frame chunks
+  // +3.2 % on C3; 640x480 in its 32-frame chunks -11 %, in units of 128-1024 frames -0.5..-4 %.  Otherwise: in full, ahead of the levels.
+  static const int depth_min_frames = getenv("TACEX_DEPTH_INTERLEAVE_MIN_FRAMES") ? atoi(getenv("TACEX_DEPTH_INTERLEAVE_MIN_FRAMES")) : 128;
+  if (dp && (!dual || lcf < depth_min_frames)) {
+    if (int rc = depth_pass_range(*dp, 0, B, c->H, c->W, st)) return rc;
+    dp = nullptr;
+  }
+  if (dual) {
     HIP_TRY(hipEventRecord(c->lvl_fork, st), "hipEventRecord");  // the pass's inputs (height map, shifts, rows) are ready behind this
     for (int q = 0; q < lvl_streams - 1; ++q) HIP_TRY(hipStreamWaitEvent(c->lvl_stream[q], c->lvl_fork, 0), "hipStreamWaitEvent");
   }
@@ -742,6 +821,9 @@ static int pipeline_chunk(tacex_taxim_ctx* c, const float* hm, const float* pres
     const int nb = B - b0 < lcf ? B - b0 : lcf;
     const int lane_q = dual ? chunk_no % lvl_streams : 0;
     hipStream_t st = lane_q > 0 ? c->lvl_stream[lane_q - 1] : st_main;  // (shadows the pass's stream inside the chunk)
+    if (dp) {  // this chunk's height maps, minima, indentation depths and contact ranges: on the chunk's stream, ahead of its levels
+      if (int rc = depth_pass_range(*dp, b0, nb, c->H, c->W, st)) return rc;
+    }
     src = nullptr;
     int grow = 0, grow_x = 0;  // rows / columns by which the non-zero range of the level's input exceeds the contact rows / columns
     for (int l = 0; l < n_band; ++l) {

@@ -65,6 +65,10 @@ __device__ __forceinline__ int wave_scan_add_lane63(int v) {
   TACEX_DPP_SCAN(v, 0, dpp_add_int, dpp_id_int, dpp_id_int);
   return v;
 }
+__device__ __forceinline__ float wave_scan_min_lane63(float v) {
+  TACEX_DPP_SCAN(v, INFINITY, fminf, __float_as_int, __int_as_float);
+  return v;
+}
 __device__ __forceinline__ float wave_scan_max_lane63(float v) {
   TACEX_DPP_SCAN(v, -INFINITY, fmaxf, __float_as_int, __int_as_float);
   return v;

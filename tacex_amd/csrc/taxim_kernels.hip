@@ -130,45 +130,85 @@ __global__ __launch_bounds__(1024) void frame_rows_kernel(
   float cm[4] = {INFINITY, INFINITY, INFINITY, INFINITY};
   __syncthreads();
   const int n4 = H * w4;
-#pragma unroll 2
-  for (int base = 0; base < n4; base += blockDim.x) {  // (wave-uniform trip count: the wave reductions below need every lane)
-    const int q = base + threadIdx.x;
-    const bool valid = q < n4;
+  const v4f* __restrict__ in4 = reinterpret_cast<const v4f*>(in + fo);
+  // one float4 of the frame: conversion (GS:585-590), stores, the lane's minimum and its four column minima
+  auto element = [&](v4f v, int q, bool valid) -> float {
+    if (FROM_DEPTH) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        float d = v[k];
+        d = isinf(d) ? far_m : d;  // GS:585-588
+        v[k] = d * 1000.0f;        // GS:590
+      }
+    }
     float m = INFINITY;
     if (valid) {
-      v4f v = reinterpret_cast<const v4f*>(in + fo)[q];
       if (FROM_DEPTH) {
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          float d = v[k];
-          d = isinf(d) ? far_m : d;  // GS:585-588
-          v[k] = d * 1000.0f;        // GS:590
-        }
         reinterpret_cast<v4f*>(hm_out + fo)[q] = v;
         if (cam_u8) {  // GS:573-575 (see frame_min_kernel)
-          uchar4 u;
-          u.x = (uint8_t)(((v[0] - nmm) / fmm) * 255.0f);
-          u.y = (uint8_t)(((v[1] - nmm) / fmm) * 255.0f);
-          u.z = (uint8_t)(((v[2] - nmm) / fmm) * 255.0f);
-          u.w = (uint8_t)(((v[3] - nmm) / fmm) * 255.0f);
-          reinterpret_cast<uchar4*>(cam_u8 + fo)[q] = u;
+          uchar4 c;
+          c.x = (uint8_t)(((v[0] - nmm) / fmm) * 255.0f);
+          c.y = (uint8_t)(((v[1] - nmm) / fmm) * 255.0f);
+          c.z = (uint8_t)(((v[2] - nmm) / fmm) * 255.0f);
+          c.w = (uint8_t)(((v[3] - nmm) / fmm) * 255.0f);
+          reinterpret_cast<uchar4*>(cam_u8 + fo)[q] = c;
         }
       }
       m = fminf(fminf(v[0], v[1]), fminf(v[2], v[3]));
       cm[0] = fminf(cm[0], v[0]); cm[1] = fminf(cm[1], v[1]); cm[2] = fminf(cm[2], v[2]); cm[3] = fminf(cm[3], v[3]);
     }
-    // a wave's 64 consecutive float4s lie in at most two rows when a row has >= 64 of them (a few otherwise): reduce inside the
-    // wave per row first, one atomic per row and wave
-    const int q0 = base + (threadIdx.x & ~63);
-    if (q0 < n4) {
-      const int r = valid ? q / w4 : -1;
-      const int r_first = q0 / w4, r_last = min(q0 + 63, n4 - 1) / w4;
-      for (int rr = r_first; rr <= r_last; ++rr) {
-        const float mr = wave_min(r == rr ? m : INFINITY);
-        if (lane == 0) {
-          if (mr >= 0.0f) atomicMin(&rowmin_i[rr], __float_as_int(mr + 0.0f));  // (+ 0: a -0 must not pass for INT_MIN)
-          else atomicMax(reinterpret_cast<unsigned*>(&rowmin_i[rr]), __float_as_uint(mr));
-        }
+    return m;
+  };
+  // a wave's 64 consecutive float4s lie in at most two rows when a row has >= 64 of them (a few otherwise): reduce inside the wave
+  // per row (DPP scan, the minimum lands in lane 63), one LDS atomic per row and wave
+  auto row_minima = [&](float m, int r, int r_first, int r_last) {
+    for (int rr = r_first; rr <= r_last; ++rr) {
+      const float mr = wave_scan_min_lane63(r == rr ? m : INFINITY);
+      if (lane == 63) {
+        if (mr >= 0.0f) atomicMin(&rowmin_i[rr], __float_as_int(mr + 0.0f));  // (+ 0: a -0 must not pass for INT_MIN)
+        else atomicMax(reinterpret_cast<unsigned*>(&rowmin_i[rr]), __float_as_uint(mr));
+      }
+    }
+  };
+  // Batches of NB float4s per thread, their loads issued back to back (clamped index instead of a predicate: one basic block).
+#ifndef TACEX_FRAME_ROWS_NB
+#define TACEX_FRAME_ROWS_NB 4
+#endif
+  constexpr int NB = TACEX_FRAME_ROWS_NB;
+  if (cols_ok) {
+    // The block size is a multiple of the row's float4 count: float4 q = base + t of a thread lies in row base / w4 + t / w4 and the
+    // rows advance by blockDim / w4 per iteration - no division inside the loop (three of them, ~60 of its ~200 instructions
+    // before; with the ds_bpermute reductions the pass was VALU-bound at 4.6 TB/s).
+    const int rstep = blockDim.x / w4, rt = threadIdx.x / w4;
+    const int w0 = threadIdx.x & ~63;
+    const int rfw = __builtin_amdgcn_readfirstlane(w0 / w4), rlw = __builtin_amdgcn_readfirstlane((w0 + 63) / w4);
+    for (int rb0 = 0; rb0 < H; rb0 += NB * rstep) {  // (wave-uniform trip counts: the wave reductions need every lane)
+      v4f vb[NB];
+#pragma unroll
+      for (int u = 0; u < NB; ++u) vb[u] = in4[min((rb0 + u * rstep) * w4 + (int)threadIdx.x, n4 - 1)];
+#pragma unroll
+      for (int u = 0; u < NB; ++u) {
+        const int rb = rb0 + u * rstep;
+        if (rb >= H) break;  // (block-uniform)
+        const int r = rb + rt;
+        const float m = element(vb[u], rb * w4 + threadIdx.x, r < H);
+        if (rb + rfw < H) row_minima(m, r < H ? r : -1, rb + rfw, min(rb + rlw, H - 1));
+      }
+    }
+  } else {
+    for (int base0 = 0; base0 < n4; base0 += NB * blockDim.x) {
+      v4f vb[NB];
+#pragma unroll
+      for (int u = 0; u < NB; ++u) vb[u] = in4[min(base0 + u * (int)blockDim.x + (int)threadIdx.x, n4 - 1)];
+#pragma unroll
+      for (int u = 0; u < NB; ++u) {
+        const int base = base0 + u * blockDim.x;
+        if (base >= n4) break;  // (block-uniform)
+        const int q = base + threadIdx.x;
+        const bool valid = q < n4;
+        const float m = element(vb[u], q, valid);
+        const int q0 = base + (threadIdx.x & ~63);
+        if (q0 < n4) row_minima(m, valid ? q / w4 : -1, q0 / w4, min(q0 + 63, n4 - 1) / w4);
       }
     }
   }

@@ -97,8 +97,11 @@ __global__ __launch_bounds__(640) void blur_mfma_kernel(BlurArgs a) {
   // wave whose columns lie more than R outside has an exactly zero H-pass result and no contact pixel to restore (stores zeros,
   // reads neither the LDS rows nor the height map).  With a contact patch of ~90 columns two of the five waves of a 320-wide band
   // take these paths.  (Mirrored x-padding cannot bring a non-zero column in: position -c maps to column c, inside the window too.)
+#ifndef TACEX_MFMA_BLOCK_SKIP_MIN_K
+#define TACEX_MFMA_BLOCK_SKIP_MIN_K 0  // (A/B hook: levels below this kernel size are compiled without the block tests)
+#endif
   bool v_need = true, h_need = true;
-  if constexpr (GZ) {
+  if constexpr (GZ && K >= TACEX_MFMA_BLOCK_SKIP_MIN_K) {
     if (a.rows_ext != nullptr) {
       const int in_lo = a.rows_ext[4 * frame + 2] - a.ext_grow_x, in_hi = a.rows_ext[4 * frame + 3] + a.ext_grow_x;
       v_need = !(c0 + 63 < in_lo || c0 > in_hi);

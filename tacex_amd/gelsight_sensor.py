@@ -10,12 +10,16 @@ from __future__ import annotations
 from collections.abc import Sequence
 from typing import TYPE_CHECKING
 
+import os
+
 import torch
 
 from . import _lib
 from .gelsight_sensor_data import GelSightSensorData
 from .sensor_base import SensorBase
 from .simulation_approaches.gelsight_simulator import GelSightSimulator
+
+_DEFER_DEPTH = os.environ.get("TACEX_DEFER_DEPTH", "1") != "0"  # A/B switch of _can_defer_depth_pass
 
 if TYPE_CHECKING:
     from .gelsight_sensor_cfg import GelSightSensorCfg
@@ -254,7 +258,7 @@ class GelSightSensor(SensorBase):
             self._frame[env_ids.to(self._frame.device)] += 1
 
         if self.compute_indentation_depth_func is not None:
-            self._get_height_map()
+            self._get_height_map(defer=self._can_defer_depth_pass())
             res = self.compute_indentation_depth_func()
             if res.data_ptr() != self._indentation_depth.data_ptr():
                 self._indentation_depth[:] = res
@@ -282,7 +286,21 @@ class GelSightSensor(SensorBase):
             return sim
         return None
 
-    def _get_height_map(self):
+    def _can_defer_depth_pass(self) -> bool:
+        """True when the optical simulator renders in this update from exactly the buffers the depth pass fills: the pass is then handed
+        to the render (`tacex_taxim_defer_height_map_from_depth`), which runs it chunk by chunk beside the band levels of the previous
+        chunk instead of as one launch ahead of them.  `TACEX_DEFER_DEPTH=0` keeps the two launches apart (A/B)."""
+        if _DEFER_DEPTH is False:
+            return False
+        sim = self.optical_simulator
+        if sim is None or "tactile_rgb" not in self.cfg.data_types or not hasattr(sim, "defer_height_map_from_depth"):
+            return False
+        if sim is not self._fused_targets() or sim._indentation_depth.data_ptr() != self._indentation_depth.data_ptr():
+            return False
+        W, H = sim.cfg.tactile_img_res
+        return tuple(self._data.output["height_map"].shape[1:]) == (H, W)
+
+    def _get_height_map(self, defer: bool = False):
         src = getattr(self, "_height_map_source", None)
         if src is not None:  # analytic source: height map, frame minimum and indentation depth in one launch
             hm = self._data.output["height_map"]
@@ -313,16 +331,19 @@ class GelSightSensor(SensorBase):
         fmin = sim._frame_min if sim is not None else self._scratch_min()
         indent = sim._indentation_depth if sim is not None else None
         rows = getattr(sim, "_frame_rows", None) if indent is not None else None  # contact row range per frame (band skipping)
-        with torch.cuda.device(hm.device):
-            rc = lib.tacex_height_map_from_depth(
-                _lib.ptr(depth), float(near), float(far),
-                float(sim.cfg.gelpad_height) if sim is not None else 0.0,
-                float(sim.cfg.gelpad_to_camera_min_distance) if sim is not None else 0.0,
-                _lib.ptr(hm), _lib.ptr(fmin), _lib.ptr(indent),
-                _lib.ptr(self._data.output["camera_depth"]) if want_u8 else 0,
-                _lib.ptr(rows) if rows is not None else 0,
-                B, H, W, _lib.current_stream_handle(hm.device))
-        _lib.check(rc, "tacex_height_map_from_depth")
+        if defer and sim is not None and indent is not None:
+            sim.defer_height_map_from_depth(depth, near, far, hm, fmin, indent, self._data.output["camera_depth"] if want_u8 else None, rows)
+        else:
+            with torch.cuda.device(hm.device):
+                rc = lib.tacex_height_map_from_depth(
+                    _lib.ptr(depth), float(near), float(far),
+                    float(sim.cfg.gelpad_height) if sim is not None else 0.0,
+                    float(sim.cfg.gelpad_to_camera_min_distance) if sim is not None else 0.0,
+                    _lib.ptr(hm), _lib.ptr(fmin), _lib.ptr(indent),
+                    _lib.ptr(self._data.output["camera_depth"]) if want_u8 else 0,
+                    _lib.ptr(rows) if rows is not None else 0,
+                    B, H, W, _lib.current_stream_handle(hm.device))
+            _lib.check(rc, "tacex_height_map_from_depth")
         self._height_map_version += 1
         if sim is not None:
             sim._frame_min_version = self._height_map_version

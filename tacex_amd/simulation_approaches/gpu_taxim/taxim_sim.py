@@ -100,6 +100,22 @@ class TaximSimulator(GelSightSimulator):
         _lib.check(rc, "tacex_resize_bilinear_aa")
         return self._resized_hm, True
 
+    def defer_height_map_from_depth(self, depth, near, far, hm, fmin, indent, cam_u8, rows):
+        """The sensor's depth -> height map pass (GS:581-593 + TS:115-131), handed to the NEXT `optical_simulation()` instead of being
+        launched now: the render runs it chunk by chunk beside its band levels (`tacex_taxim_defer_height_map_from_depth`).  The caller
+        (GelSightSensor._get_height_map) guarantees that the render follows in the same update and reads exactly these buffers."""
+        B, H, W = hm.shape
+        lib = _lib.load_library()
+        handle = self._taxim.context((H, W)).handle
+        with torch.cuda.device(hm.device):
+            # (a pass left pending by an update that failed half way runs now, so that this one can be queued)
+            _lib.check(lib.tacex_taxim_flush_deferred(handle, _lib.current_stream_handle(hm.device)), "tacex_taxim_flush_deferred")
+            rc = lib.tacex_taxim_defer_height_map_from_depth(
+                handle, _lib.ptr(depth), float(near), float(far), float(self.cfg.gelpad_height),
+                float(self.cfg.gelpad_to_camera_min_distance), _lib.ptr(hm), _lib.ptr(fmin), _lib.ptr(indent),
+                _lib.ptr(cam_u8) if cam_u8 is not None else 0, _lib.ptr(rows) if rows is not None else 0, B)
+        _lib.check(rc, "tacex_taxim_defer_height_map_from_depth")
+
     # -- plugin interface -------------------------------------------------------------------------------
     def optical_simulation(self):
         """(num_envs, H, W, 3) float32 RGB in [0,1] (the reference docstring says 0..255, taxim_sim.py:83, wrongly)."""
