@@ -199,7 +199,9 @@ class Rig:
         if self.fem is not None:
             self.fem.flush()  # the last step's hipEvent pair joins ms_log: entry k of the log IS step k
 
-    def timed(self, steps, warmup, barrier=lambda: None, after_warmup=lambda: None):
+    def timed(self, steps, warmup, barrier=lambda: None, after_warmup=lambda: None, windows=1):
+        """Wall time of `steps` steps (after `warmup` untimed ones).  windows > 1: the steps are timed as that many consecutive windows
+        with a synchronisation between them; the per-window times land in `self.window_s` (a runtime stall inside one window shows)."""
         import gc
 
         for i in range(warmup):
@@ -215,10 +217,14 @@ class Rig:
             barrier()
             torch.cuda.synchronize()
             t0 = time.perf_counter()
-            for i in range(steps):
-                self.step(warmup + i)
-            self.finish()
-            torch.cuda.synchronize()
+            self.window_s, per = [], steps // windows
+            for w in range(windows):
+                tw = time.perf_counter()
+                for i in range(w * per, steps if w == windows - 1 else (w + 1) * per):
+                    self.step(warmup + i)
+                self.finish()
+                torch.cuda.synchronize()
+                self.window_s.append(time.perf_counter() - tw)
             barrier()
             torch.cuda.synchronize()
             return time.perf_counter() - t0
@@ -443,13 +449,16 @@ def sweep(args, dev):
                 fem.ms_log = []
             # FEM scenes: the indenter breathes with a period of 2 pi / 0.3 = 21 steps whose phases cost 1 ... 18 ms each, and the first
             # long Newton launches of a process carry a one-time ~50 ms of runtime work (scratch set-up, seen at sync; scripts/c4_probe.py):
-            # warm up over one whole period, time exactly one period
+            # warm up over one whole period, time exactly THREE periods as three windows (a single period is ~27 ms of wall time: one
+            # runtime stall of 20-50 ms - one in ~13 processes carried one, profiles/r05_experiments.md section 13 - halved the entry; the
+            # rate is still the mean over all 63 steps, the per-period times are in the entry)
             if fem is not None:
-                steps = 21
+                steps = 63
             base = []
             if fem is not None:  # solver statistics over the timed period: device-side sums, the warm-up's share is subtracted
                 fem.info_sum = torch.zeros(4, dtype=torch.float64, device=dev)
-            el = rig.timed(steps, 24 if fem is not None else 8, after_warmup=lambda: base.append(fem.info_sum.clone()) if fem is not None else None)
+            el = rig.timed(steps, 24 if fem is not None else 8, after_warmup=lambda: base.append(fem.info_sum.clone()) if fem is not None else None,
+                           windows=3 if fem is not None else 1)
             frames = B * n_sensors * steps
             e = {"key": key, "workload": label, "frames_per_step": B * n_sensors, "steps": steps, "ms_per_step": round(el / steps * 1e3, 4),
                  "frames_per_s": round(frames / el, 1)}
@@ -460,9 +469,10 @@ def sweep(args, dev):
                 e["frames_in_contact_per_step"] = inc
                 e["frames_per_s_in_contact_only"] = round(inc * steps / el, 1)
             if fem is not None:
+                e["period_ms"] = [round(w * 1e3, 2) for w in rig.window_s]  # wall time of each 21-step period of the indenter's motion
                 # split: the FEM part alone (hipEvents around attachments + UipcSim.step), MEAN over the timed steps - the Newton
                 # / PCG iteration counts vary from step to step with the indenter's breathing
-                ms = fem.ms_log[24:] or fem.ms_log  # steps 24 .. 44: exactly the timed period (Rig.finish flushes the last pair)
+                ms = fem.ms_log[24:] or fem.ms_log  # steps 24 .. 86: exactly the timed periods (Rig.finish flushes the last pair)
                 assert len(fem.ms_log) <= 24 or len(ms) == steps, (len(fem.ms_log), steps)
                 e["fem_ms_mean"] = round(sum(ms) / max(len(ms), 1), 3)
                 e["fem_ms_min_max"] = [round(min(ms), 3), round(max(ms), 3)] if ms else None
@@ -481,7 +491,7 @@ def sweep(args, dev):
                 tot = (fem.info_sum - base[0]).cpu().numpy()
                 e["fem_period"] = {"steps": steps, "newton_iters_per_step_mean": round(float(tot[0]) / steps, 2),
                                    "pcg_iters_per_newton_mean": round(float(tot[3]) / max(float(tot[0]), 1e-9), 1),
-                                   "note": "means over envs and over the timed window = one period of the indenter's motion (21 steps: about half "
+                                   "note": "means over envs and over the timed window = three periods of the indenter's motion (21 steps each: about half "
                                            "pressing at ~1 ms per step, half following the retreating indenter at 3-15 ms)"}
                 e["fem"] = fem_roofline(fem, (sum(ms) * steps / max(len(ms), 1), float(tot[0]), float(tot[3])))
             out.append(e)
@@ -519,7 +529,7 @@ def sweep(args, dev):
     if only is None or "axle" in only:
         out.append(fem_axle_entry(dev, key="axle"))
     if only is None or "axle_tol1e-6" in only:
-        out.append(fem_axle_entry(dev, tol_rate=1e-6, key="axle_tol1e-6"))
+        out.append(fem_axle_entry(dev, steps=12, tol_rate=1e-6, key="axle_tol1e-6"))
     if only is None or "axle_streaming" in only:
         out.append(fem_axle_entry(dev, steps=6, streaming=True, tol_rate=1e-6, key="axle_streaming"))
     run("c5_optical", "C5 optical part only: 1024 envs, RGB 640x480", 1024, 480, 640, 1, False, steps=max(5, args.sweep_steps // 3))
@@ -557,7 +567,7 @@ NEWTON_CAP = 64  # Newton iterations a FEM scene of the sweep may take per step 
 AXLE_NEWTON_CAP = 200  # (the bent axle's iterations in PSD-safe mode converge linearly: 50 in the worst env and step measured)
 
 
-def fem_axle_entry(dev, B=512, steps=12, streaming=False, tol_rate=None, key="axle"):
+def fem_axle_entry(dev, B=512, steps=36, streaming=False, tol_rate=None, key="axle"):
     """SURVEY section 8(d)'s ~2k-tet fixture simple_axle.msh (593 vertices / 2 003 tets) stepped with sphere contact - FEM only, env steps
     per second.  Default: the 768-thread variant of the CU-resident Newton kernel with everything the gelpad scene uses (friction,
     coarse correction on the bounding-box grid, the chains found in the mesh).  streaming=True: the streaming Newton kernel (what
@@ -602,17 +612,21 @@ def fem_axle_entry(dev, B=512, steps=12, streaming=False, tol_rate=None, key="ax
             step(i)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        for i in range(steps):
-            step(3 + i)
-            its = torch.maximum(its, sim.step_info[:, 0].max())  # (the streaming path accumulates its per-launch counts in the same row)
-            flagged = torch.maximum(flagged, (sim.step_info[:, 2].to(torch.int64) & 3).max().to(torch.float64))  # penetration / failed line search
-        torch.cuda.synchronize()
+        thirds = []  # wall time of each third of the steps (a runtime stall inside one of them shows: see the C4 entries)
+        for w in range(3):
+            tw = time.perf_counter()
+            for i in range(w * (steps // 3), steps if w == 2 else (w + 1) * (steps // 3)):
+                step(3 + i)
+                its = torch.maximum(its, sim.step_info[:, 0].max())  # (the streaming path accumulates its per-launch counts in the same row)
+                flagged = torch.maximum(flagged, (sim.step_info[:, 2].to(torch.int64) & 3).max().to(torch.float64))  # penetration / failed line search
+            torch.cuda.synchronize()
+            thirds.append(round((time.perf_counter() - tw) * 1e3, 2))
         el = time.perf_counter() - t0
         finite, gap = bool(torch.isfinite(sim.x).all()), float(sim.contact_gaps().amin())
         assert finite and gap > 0.0, f"finite {finite}, smallest gap {gap}"
         assert float(its) < AXLE_NEWTON_CAP, f"an env ran into the Newton cap of {AXLE_NEWTON_CAP}"
         return {"key": key, "workload": f"FEM only: {B} envs x simple_axle.msh, sphere contact: {name}",
-                "envs": B, "steps": steps, "ms_per_step": round(el / steps * 1e3, 3), "env_steps_per_s": round(B * steps / el, 1),
+                "envs": B, "steps": steps, "ms_per_step": round(el / steps * 1e3, 3), "env_steps_per_s": round(B * steps / el, 1), "thirds_ms": thirds,
                 "newton_iters_max": int(its),
                 "newton_cap": AXLE_NEWTON_CAP, "pcg_tol_rate": cfg.linear_system.tol_rate, "failure_flags_max": int(flagged), "velocity_tol": 2e-3}
     except Exception as ex:

@@ -74,6 +74,6 @@ for i in range(6, 30):
     si = fem.sim.step_info.cpu().numpy()
     nits.append(si[:, 0].mean()); pcgs.append((si[:, 3] / np.maximum(si[:, 0], 1)).mean())
 info = fem.sim.check_step(raise_on_penetration=False)
-print(f"FemGelpad scene ({B} envs): {np.mean(ms):.3f} ms per step (min {np.min(ms):.3f}, max {np.max(ms):.3f}); Newton iterations per step mean "
+print(f"FemGelpad scene ({B} envs): {np.mean(ms):.3f} ms per step (median {np.median(ms):.3f}, min {np.min(ms):.3f}, max {np.max(ms):.3f}); Newton iterations per step mean "
       f"{np.mean(nits):.2f}; PCG iterations per Newton iteration mean {np.mean(pcgs):.1f}; flagged envs: penetration {len(info['penetrating_envs'])}, "
       f"line search {len(info['line_search_failed_envs'])}")
