@@ -529,7 +529,7 @@ def sweep(args, dev):
     if only is None or "axle" in only:
         out.append(fem_axle_entry(dev, key="axle"))
     if only is None or "axle_tol1e-6" in only:
-        out.append(fem_axle_entry(dev, steps=12, tol_rate=1e-6, key="axle_tol1e-6"))
+        out.append(fem_axle_entry(dev, tol_rate=1e-6, key="axle_tol1e-6"))
     if only is None or "axle_streaming" in only:
         out.append(fem_axle_entry(dev, steps=6, streaming=True, tol_rate=1e-6, key="axle_streaming"))
     run("c5_optical", "C5 optical part only: 1024 envs, RGB 640x480", 1024, 480, 640, 1, False, steps=max(5, args.sweep_steps // 3))
@@ -567,7 +567,7 @@ NEWTON_CAP = 64  # Newton iterations a FEM scene of the sweep may take per step 
 AXLE_NEWTON_CAP = 200  # (the bent axle's iterations in PSD-safe mode converge linearly: 50 in the worst env and step measured)
 
 
-def fem_axle_entry(dev, B=512, steps=36, streaming=False, tol_rate=None, key="axle"):
+def fem_axle_entry(dev, B=512, steps=12, streaming=False, tol_rate=None, key="axle"):
     """SURVEY section 8(d)'s ~2k-tet fixture simple_axle.msh (593 vertices / 2 003 tets) stepped with sphere contact - FEM only, env steps
     per second.  Default: the 768-thread variant of the CU-resident Newton kernel with everything the gelpad scene uses (friction,
     coarse correction on the bounding-box grid, the chains found in the mesh).  streaming=True: the streaming Newton kernel (what
@@ -612,7 +612,10 @@ def fem_axle_entry(dev, B=512, steps=36, streaming=False, tol_rate=None, key="ax
             step(i)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        thirds = []  # wall time of each third of the steps (a runtime stall inside one of them shows: see the C4 entries)
+        # wall time of each third of the steps (a runtime stall inside one of them shows: see the C4 entries).  12 steps, not more: the
+        # scene presses on by a fraction of the gap EVERY step - past step ~15 the rod is bent far enough that steps take 50-140 Newton
+        # iterations at this tolerance (36 steps: thirds of 16 / 1 365 / 6 283 ms, profiles/r05_experiments.md section 16)
+        thirds = []
         for w in range(3):
             tw = time.perf_counter()
             for i in range(w * (steps // 3), steps if w == 2 else (w + 1) * (steps // 3)):

@@ -56,6 +56,20 @@ if len(sys.argv) <= 8:
     BATCH = FRAMES
 
 
+def depth_frames_total(write_dir):
+    """Frames the depth -> height map dispatches of the WRITE_SIZE pass converted, from what they wrote (4 B/px of height map per frame;
+    the bench does not ask for the uint8 camera image): the pass may run as one launch per shard or as one launch per band-level chunk."""
+    tot, n = 0.0, 0
+    for f in glob.glob(os.path.join(write_dir, "**", "*counter_collection.csv"), recursive=True):
+        for row in csv.DictReader(open(f)):
+            if row["Counter_Name"] == "WRITE_SIZE" and ("frame_rows_kernel<true>" in row["Kernel_Name"] or "frame_min_kernel<true>" in row["Kernel_Name"]):
+                tot += float(row["Counter_Value"]); n += 1
+    return tot * 1024 / (4.0 * H * W) if n else 0.0
+
+
+DEPTH_FRAMES_TOTAL = depth_frames_total(sys.argv[2])
+
+
 def collect(d, counter):
     acc, cnt = defaultdict(float), defaultdict(int)
     for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
@@ -74,6 +88,9 @@ def collect(d, counter):
     for k in acc:
         if n_pass > 0 and k.startswith("blur_"):
             out[k] = acc[k] / (n_pass * FRAMES)
+        elif k == "frame_min_from_depth" and DEPTH_FRAMES_TOTAL:
+            # the depth pass deferred into the render (ABI 11) runs per band-level chunk: total over the frames it converted
+            out[k] = acc[k] / DEPTH_FRAMES_TOTAL
         else:
             out[k] = acc[k] / cnt[k] / (BATCH if k.startswith("frame_min") else FRAMES)
     return out, dict(cnt)
