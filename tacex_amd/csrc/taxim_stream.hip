@@ -447,7 +447,34 @@ __global__ __launch_bounds__(64 * kStreamWaves, MINW) void taxim_stream_kernel(S
 
   // one finished frame row: polynomial of every pixel's table record (TT:250-255) + background + clip (TT:257-258), the RGB
   // store and the row's share of the policy observation
-  auto emit_row = [&](int e, const StreamRowInfo& ri, const v3f (&bq)[PX], const StreamRec (&pc)[PX]) {
+  // LATE STORES (round 5, -DTACEX_STREAM_LATE_STORE): gfx9 stores count in vmcnt and the counter retires in order, so the one wait of
+  // an iteration - for the table / background fetches issued at its top - also waited for the RGB stores of the iteration before,
+  // issued just ahead of them (knock-out build without the stores: -152 of 752 us, r04 section 9).  With this switch the RGB of the row
+  // shaded in iteration y stays in registers across the loop edge and is stored in iteration y + 1 AFTER that iteration's fetches have
+  // been issued; the wait becomes vmcnt(PX) - everything but those PX stores - so a store has a whole iteration to itself.
+#ifdef TACEX_STREAM_LATE_STORE
+  constexpr bool LATE = ROLE == kStreamFused;
+#else
+  constexpr bool LATE = false;
+#endif
+  float held[PX * 3] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  int held_row = -1;       // frame row whose RGB is in held[] (-1: none)
+  bool held_out = false;   // (wave-uniform) the PX stores of a held row were issued after this iteration's fetches
+  auto store_held = [&]() {
+    held_out = false;
+    if constexpr (LATE) {
+      if (held_row >= 0) {
+#pragma unroll
+        for (int i = 0; i < PX; ++i)
+          if (valid[i])
+            *reinterpret_cast<v3f*>(reinterpret_cast<char*>(a.sh.rgb + fo * 3) + ((unsigned)held_row * (unsigned)W * 12u + xc[i])) =
+                (v3f){held[3 * i], held[3 * i + 1], held[3 * i + 2]};
+        held_row = -1;
+        held_out = true;
+      }
+    }
+  };
+  auto emit_row = [&](int e, const StreamRowInfo& ri, const v3f (&bq)[PX], const StreamRec (&pc)[PX], bool hold = false) {
     const float Y = ri.fy;
     float rgb[PX * 3];
 #pragma unroll
@@ -463,10 +490,17 @@ __global__ __launch_bounds__(64 * kStreamWaves, MINW) void taxim_stream_kernel(S
 #ifdef TACEX_DBG_NO_STORE
       if (valid[i] && rgb[3 * i] == 12345.0f)
 #else
-      if (valid[i])
+      if (valid[i] && !(LATE && hold))
 #endif
         *reinterpret_cast<v3f*>(reinterpret_cast<char*>(a.sh.rgb + fo * 3) + ((unsigned)e * (unsigned)W * 12u + xc[i])) =
             (v3f){rgb[3 * i], rgb[3 * i + 1], rgb[3 * i + 2]};
+    }
+    if constexpr (LATE) {
+      if (hold) {
+#pragma unroll
+        for (int j = 0; j < PX * 3; ++j) held[j] = rgb[j];
+        held_row = e;
+      }
     }
     if (do_obs) {
       // (An `if` instead of this loop - at most one observation row retires per frame row - spares 26 register copies per row
@@ -700,7 +734,8 @@ __global__ __launch_bounds__(64 * kStreamWaves, MINW) void taxim_stream_kernel(S
 #endif
     auto mid_point = [&]() {
       asm volatile("" : "+v"(ninfo));
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (LATE && held_out) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");  // (PX = 3 stores of the held row may stay in flight)
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #ifdef TACEX_STREAM_CLOCK
       ck2 = __builtin_readcyclecounter();
 #endif
@@ -792,6 +827,7 @@ __global__ __launch_bounds__(64 * kStreamWaves, MINW) void taxim_stream_kernel(S
       }
     };
     shade_part1();
+    store_held();  // (LATE) the previous iteration's RGB, behind this iteration's fetches
     TACEX_TICK(1);  // bins, table / background fetch issue
 
     float cur[PX];
@@ -1004,7 +1040,7 @@ __global__ __launch_bounds__(64 * kStreamWaves, MINW) void taxim_stream_kernel(S
             ri = *reinterpret_cast<const StreamRowInfo*>(a.rows + e * kStreamRowInts);
             load_bg(e, bq);
           }
-          emit_row(e, ri, bq, pc);
+          emit_row(e, ri, bq, pc, /*hold=*/e_lo == e_hi);
         }
       }
     }
@@ -1049,6 +1085,7 @@ __global__ __launch_bounds__(64 * kStreamWaves, MINW) void taxim_stream_kernel(S
     dbg[0] = clk_acc[0]; dbg[1] = clk_acc[1]; dbg[2] = clk_acc[2]; dbg[3] = clk_acc[3];
   }
 #endif
+  store_held();  // (LATE) the last shaded row
   if constexpr (ROLE == kStreamFused && GZ) {
     if (trimmed && rb < r1) flat_rows(rb, r1, 0, 0);  // the flat rows below the march (ascending row order: the observation rows retire in order)
   }
