@@ -170,7 +170,9 @@ class Rig:
         cur = torch.cuda.current_stream()
         if self.grouped and self.markers:  # inputs of every member first: the first member's update evaluates the whole group
             for s in self.sensors:
-                s.marker_motion_simulator.set_indenter_yaw(self.theta)
+                # (the yaw, like the depth image, is resident where the sensor reads it: the member's rows of the group's yaw vector -
+                #  a producer writes there; handing over a separate tensor costs one 4 KB device copy per member and step)
+                s.marker_motion_simulator.set_indenter_yaw(s.marker_motion_simulator.indenter_yaw_buffer())
         for k, s in enumerate(self.sensors):
             # the sensors of an env are independent objects (left / right finger): each updates on its own HIP stream, so the
             # drain of one sensor's kernels overlaps the next one's launch sequence; the packing kernel waits for all of them

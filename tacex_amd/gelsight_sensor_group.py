@@ -58,12 +58,20 @@ class _MemberSimulator:
     def theta(self):
         return self._core.theta[self._sl]
 
-    def set_indenter_yaw(self, theta: torch.Tensor):
-        """Yaw of this member's indenters: written into the member's rows of the core's (n*B,) yaw vector."""
+    def indenter_yaw_buffer(self) -> torch.Tensor:
+        """(B,) float32 view of this member's rows of the core's yaw vector: a producer may write the yaw straight into it (no copy in
+        set_indenter_yaw then - the counterpart of GelSightSensorGroup.camera_depth_buffer)."""
         core = self._core
         if core.theta.shape[0] != core._num_envs or not core.theta.is_contiguous():
             core.theta = torch.zeros((core._num_envs,), device=core._device)
-        core.theta[self._sl].copy_(theta.reshape(-1))
+        return core.theta[self._sl]
+
+    def set_indenter_yaw(self, theta: torch.Tensor):
+        """Yaw of this member's indenters: written into the member's rows of the core's (n*B,) yaw vector."""
+        dst = self.indenter_yaw_buffer()
+        theta = theta.reshape(-1)
+        if not (theta.data_ptr() == dst.data_ptr() and theta.dtype == dst.dtype and theta.shape == dst.shape):  # else: already in place
+            dst.copy_(theta)
 
 
 class GelSightSensorGroup:
