@@ -1029,10 +1029,12 @@ template <bool MESH, int NT>
 __device__ __forceinline__ double env_energy_lds(const FemDev& m, const double* xl, const double x3[3], const double* xt,
                                                  bool own, bool c, const double* aim, double* sh, int& phase,
                                                  const double* ind = nullptr, double wv = 0.0, const double* fv = nullptr,
-                                                 const double* xn = nullptr, const double* disp = nullptr) {
-  double e = 0.0;
+                                                 const double* xn = nullptr, const double* disp = nullptr, const double* e_tets = nullptr) {
+  // e_tets: this thread's share of the elastic energy, already summed over the same tets in the same order by the gradient sweep of the
+  // Newton iteration (same x): the line search's E(x) then costs no tet sweep of its own - and is the same bits as with one
+  double e = e_tets ? *e_tets : 0.0;
   const double dt2 = m.dt * m.dt;
-  for (int t = threadIdx.x; t < m.T; t += blockDim.x) {
+  for (int t = threadIdx.x; t < (e_tets ? 0 : m.T); t += blockDim.x) {
     int v[4];
     double Di[9], F[9];
     double vol_t;
@@ -1386,6 +1388,7 @@ restart_iteration:
   // ---- nodal gradient ----
   double r3[3], d3[3] = {0, 0, 0};
   double go3[3] = {0, 0, 0};  // gradient WITHOUT the contact terms (inertia + elasticity + constraints): the reaction a contact balances
+  double e_tets = 0.0;  // this thread's tets' elastic energy at x: by-product of the gradient sweep, E(x) of the line search below
   {
     double a3[3];
     sweep([&](const int* v, const double* Di, double vol, double* g) {
@@ -1393,6 +1396,9 @@ restart_iteration:
       deformation_gradient(xs, v, Di, F);
       TetState s;
       tet_state(m, F, s);
+#ifndef TACEX_FEM_SEPARATE_E0
+      e_tets += dt2 * vol * psi_of(m, s);
+#endif
       shape_rows(Di, r);
       element_gradient(s, r, dt2 * vol, g);
     }, a3);
@@ -1862,7 +1868,11 @@ restart_iteration:
   }
   FEM_PHASE(2);
   // ---- backtracking line search on the incremental potential (accept the first E(x + step d) <= E(x)) ----
+#ifdef TACEX_FEM_SEPARATE_E0  // (A/B hook: E(x) by a tet sweep of its own, as before)
   const double E0 = env_energy_lds<MESH, NT>(m, xs, x3, xt, own, c, aim, sh, phase, ind, wv, fric_phase ? fl : nullptr, xn, disp3);
+#else
+  const double E0 = env_energy_lds<MESH, NT>(m, xs, x3, xt, own, c, aim, sh, phase, ind, wv, fric_phase ? fl : nullptr, xn, disp3, &e_tets);
+#endif
   double step = 1.0, E1 = E0;
   if (ind) {
     // CCD step filter for analytic indenters: a signed distance field is 1-Lipschitz, so a vertex at gap d moving by
