@@ -994,10 +994,13 @@ constexpr int kNwtTpw = kNwtChunk / kNwtThreads;
 // staying on one CU - the streaming kernel's alternative is a trip through HBM per PCG iteration).  Only the atomic flavour exists
 // there: without the exchange window and the incidence list in LDS (12 x NT doubles + 4 T shorts) a 593-vertex / 2 003-tet mesh with
 // friction fits the CU's 160 KB.  The region between p and the reduction rows then only has to hold what the kernel parks in it: the
-// 15 V block accumulators of the assembly (p + region), the preconditioner's r | r_c | y_c | z.  What bounds the vertex count is the
-// LDS, not the threads: 268 bytes per vertex with friction (about 600 vertices), 212 without (about 745) - a 1 024-thread variant
-// would never be launched and is not instantiated.
+// 15 V doubles of D | E blocks the chain factorisation exchanges (p + region), the preconditioner's r | r_c | y_c | z.  What bounds the
+// vertex count is the LDS, not the threads: 268 bytes per vertex with friction (about 600 vertices), 212 without (about 745) - a
+// 1 024-thread variant would never be launched and is not instantiated.
 __host__ __device__ constexpr int nwt_window_doubles(int V, int NT) {
+  // (wide variants: p + this region carry the (V,15) D | E blocks the chain threads exchange for the factorisation - 12 V doubles - and,
+  //  between sweeps, the preconditioner's r | r_c | y_c | z.  Shrinking it to the latter was tried in round 5: the factorisation then
+  //  overwrites the reduction rows and the friction lag - a 550-vertex pad stopped yielding to its indenter.)
   return NT <= kNwtThreads ? 12 * kNwtChunk : (12 * V > 6 * V + 6 * kFemMaxCoarse ? 12 * V : 6 * V + 6 * kFemMaxCoarse);
 }
 // dynamic LDS of fem_newton_lds_kernel<., ., NT>: x, p | window | sums | [friction lag] | diagonal mass term (doubles) || chain factors |

@@ -37,7 +37,7 @@ class FemGelpad:
     stepped with UipcSim.step (backward Euler: the whole Newton loop - matrix-free PCG, CCD filter, line search - in one HIP launch)."""
 
     def __init__(self, B, dev, max_newton_iter: int = 8, motion: str = "breathing", side_stream: bool = False, d_hat: float | None = None,
-                 cfg: UipcSimCfg | None = None, friction_lag: str | None = None):
+                 cfg: UipcSimCfg | None = None, friction_lag: str | None = None, mesh: tuple[int, int, int] = (8, 10, 4)):
         """motion: "breathing" - the indenter presses in and retreats to the edge of the barrier zone every 21 steps; "rolling" - it
         stays on the pad like the ball of the reference's ball-rolling scenes: the depth varies between 0.3 and 0.8 of the env's
         maximum while the sphere slides sideways by up to +-0.5 mm (friction drags the surface along).  The half of the period in
@@ -54,7 +54,7 @@ class FemGelpad:
         prio = int(os.environ.get("TACEX_FEM_STREAM_PRIORITY", "0"))
         self.stream = _side_stream(dev, prio) if side_stream else None
         self.max_newton_iter = max_newton_iter
-        P, T = gelpad_box_mesh(8, 10, 4)
+        P, T = gelpad_box_mesh(*mesh)  # (cells along x, y, z; the default is the 495-vertex / 1920-tet pad of C4 / C5)
         cfg = cfg if cfg is not None else UipcSimCfg(device=dev)
         if d_hat is not None:
             cfg.contact.d_hat = float(d_hat)

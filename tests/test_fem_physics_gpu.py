@@ -28,7 +28,7 @@ TIGHT_VTOL = float(os.environ.get("TACEX_TEST_VTOL", "1e-7"))
 GRAD_TOL = {1e-3: 4e-5, 5e-4: 4e-4}
 
 
-def _scene(B, d_hat=None, velocity_tol=None, tol_rate=None, motion="rolling", deterministic=False, friction_lag=None, side_stream=False):
+def _scene(B, d_hat=None, velocity_tol=None, tol_rate=None, motion="rolling", deterministic=False, friction_lag=None, side_stream=False, **kw):
     from tacex_amd.uipc.gelpad_scene import FemGelpad
     from tacex_amd.uipc.uipc_sim import UipcSimCfg
 
@@ -38,7 +38,7 @@ def _scene(B, d_hat=None, velocity_tol=None, tol_rate=None, motion="rolling", de
     if tol_rate is not None:
         cfg.linear_system.tol_rate = tol_rate
     cfg.linear_system.deterministic = deterministic
-    return FemGelpad(B, "cuda:0", max_newton_iter=200, motion=motion, d_hat=d_hat, cfg=cfg, friction_lag=friction_lag, side_stream=side_stream)
+    return FemGelpad(B, "cuda:0", max_newton_iter=200, motion=motion, d_hat=d_hat, cfg=cfg, friction_lag=friction_lag, side_stream=side_stream, **kw)
 
 
 def _plain_gradient(fem, m, area, x_end, x_n, v_n, ind_now, ind_prev, b):
@@ -144,6 +144,44 @@ def test_step_end_state_is_a_stationary_point_of_the_plain_incremental_potential
     # measured: pressing 0.02-0.08 um, retreating up to 148 um at d_hat 1 mm / 167 um at 0.5 mm (the indenter slides ~50 um per step there)
     assert REPORT or (worst_cap["pressing"] <= 5e-7 and worst_cap["retreating"] <= 2.5e-4), worst_cap
     assert REPORT or told >= 100 * GRAD_TOL[d_hat], told
+
+
+WIDE_TOL = 4e-4  # measured 1.15e-4 on the 550-vertex pad (smaller vertex areas, smaller contact force per vertex than on the C4 pad: 1.06e-5 there)
+
+
+def test_wider_pad_on_the_768_thread_kernel_is_a_stationary_point_too():
+    """A pad finer than the C4 one - 9 x 10 x 4 cells: 550 vertices / 2160 tets, what a wildmeshing `edge_length_r` a little below the
+    benchmark's gives (uipc_object.py:168-187) - with friction on.  Beyond 512 vertices the step runs the 768-thread variant of the
+    CU-resident Newton kernel (until now exercised on simple_axle.msh only).  Same property as above: with IPC's lag and tight
+    tolerances the end state of every step is a stationary point of the plain incremental potential."""
+    from oracle.fem_oracle import FemModel
+
+    B, d_hat = 3, 1e-3
+    fem = _scene(B, d_hat=d_hat, velocity_tol=TIGHT_VTOL, tol_rate=1e-12, friction_lag="ipc", mesh=(9, 10, 4))
+    sim, obj = fem.sim, fem.gelpad
+    assert obj.points.shape[0] == 550 and sim.cfg.contact.enable_friction
+    c = obj.cfg.constitution_cfg
+    m = FemModel.build(obj.points, obj.tets, youngs=c.youngs_modulus * 1e6, poisson=c.poisson_rate, density=obj.cfg.mass_density, dt=sim.cfg.dt,
+                       strength=1000.0)
+    area = obj.surface_vertex_areas()
+    ind_prev, worst, in_contact = None, 0.0, 0
+    for i in range(8):
+        x_n, v_n = sim.x.cpu().numpy().copy(), sim.v.cpu().numpy().copy()
+        fem.step(i)  # (friction on + more than 512 vertices: a step that is not CU-resident raises)
+        info = sim.check_step()
+        assert len(info["penetrating_envs"]) == 0 and len(info["line_search_failed_envs"]) == 0 and info["newton_iters"].max() < 200, (i, info)
+        x_end, ind_now = sim.x.cpu().numpy(), fem.ind.cpu().numpy().copy()
+        if ind_prev is None:
+            ind_prev = ind_now
+        for b in range(B):
+            g, scale = _plain_gradient(fem, m, area, x_end[b], x_n[b], v_n[b], ind_now[b], ind_prev[b], b)
+            if scale > 0.0:
+                in_contact += 1
+                worst = max(worst, np.abs(g).max() / scale)
+                assert REPORT or np.abs(g).max() <= WIDE_TOL * scale, (i, b, np.abs(g).max(), scale)
+        ind_prev = ind_now
+    print(f"550-vertex pad: worst |grad| / contact force {worst:.2e} over {in_contact} env-steps in contact")
+    assert in_contact >= 12 and float(np.abs(sim.x.cpu().numpy() - obj.points[None]).max()) > 1e-4
 
 
 def test_reset_of_single_envs_equals_a_fresh_scene_and_leaves_the_others_alone():
