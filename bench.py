@@ -558,7 +558,7 @@ SWEEP_NOTES = {
     "axle": "SURVEY 8(d)'s ~2k-tet fixture simple_axle.msh (593 vertices / 2003 tets, scaled to 25.8 x 3 x 3 mm), ends attached, a sphere pressing "
             "on through the IPC barrier: the CU-resident Newton kernel, 768 threads per env (friction, coarse correction, chains: the defaults)",
     "axle_tol1e-6": "the same with the PCG threshold of rounds 1-4 (1e-6 on r.z)",
-    "axle_streaming": "the streaming Newton kernel (deterministic switch; block Jacobi, no friction), PCG threshold 1e-6",
+    "axle_streaming": "the streaming Newton kernel (deterministic switch; block Jacobi, friction off as in rounds 3-4), PCG threshold 1e-6",
 }
 
 
@@ -573,8 +573,8 @@ def fem_axle_entry(dev, B=512, steps=12, streaming=False, tol_rate=None, key="ax
     """SURVEY section 8(d)'s ~2k-tet fixture simple_axle.msh (593 vertices / 2 003 tets) stepped with sphere contact - FEM only, env steps
     per second.  Default: the 768-thread variant of the CU-resident Newton kernel with everything the gelpad scene uses (friction,
     coarse correction on the bounding-box grid, the chains found in the mesh).  streaming=True: the streaming Newton kernel (what
-    the deterministic switch selects for a mesh of more than 512 vertices; block Jacobi, no friction)."""
-    name = "the streaming Newton kernel (deterministic switch; block Jacobi, no friction)" if streaming else \
+    the deterministic switch selects for a mesh of more than 512 vertices; block Jacobi; run with friction off, as in rounds 3-4)."""
+    name = "the streaming Newton kernel (deterministic switch; block Jacobi, friction off)" if streaming else \
            "the CU-resident Newton kernel, 768 threads per env (friction, coarse correction, chains: the defaults)"
     try:
         from tacex_amd.uipc import UipcObject, UipcObjectCfg, UipcSim, UipcSimCfg
@@ -589,7 +589,7 @@ def fem_axle_entry(dev, B=512, steps=12, streaming=False, tol_rate=None, key="ax
         if streaming:
             cfg.linear_system.coarse_grid, cfg.linear_system.vertex_chains = None, None
             cfg.linear_system.deterministic = True
-            cfg.contact.enable_friction = False  # friction lives in the CU-resident kernel only
+            cfg.contact.enable_friction = False  # (the entry's workload since round 3; the streaming kernel has friction since round 5)
         sim = UipcSim(cfg, num_envs=B)
         UipcObject(UipcObjectCfg(mesh_points=P, mesh_tets=T), sim)
         sim.setup_sim(constraint_strength_ratio=1000.0)

@@ -402,6 +402,10 @@ int tacex_fem_set_friction(tacex_fem_ctx* ctx, double friction_ratio, double eps
  * one that stays bounded at the reference's default Newton tolerance, where the previous configuration is not in balance. */
 int tacex_fem_set_friction_lag(tacex_fem_ctx* ctx, int mode);
 
+/* Which Newton kernel the last tacex_fem_step / tacex_fem_newton_step of the context launched: 1 = CU-resident (the env's state on one CU),
+ * 0 = the streaming fallback (larger meshes, the deterministic switch on more than 512 vertices), -1 = none yet.  (ABI 11) */
+int tacex_fem_newton_resident(const tacex_fem_ctx* ctx);
+
 /* Contact-following start of tacex_fem_step's Newton loop (default on): a surface vertex inside the barrier zone of the indenter's
  * previous position starts the iteration displaced by the indenter's translation since the previous step (its gap is what it was).
  * An initial guess only - the step's minimiser is unchanged - but the one that lets a RETREATING indenter cost 2-3 Newton iterations
@@ -469,10 +473,11 @@ int tacex_fem_newton_step(tacex_fem_ctx* ctx, double* x_dev, const double* x_til
  * x_dev, v_dev (B,V,3) f64 are updated in place, x_tilde_dev (B,V,3) is written.  With the CU-resident Newton kernel (one thread per
  * vertex: 512 threads per env for meshes of <= 512 vertices, 768 threads for larger ones as long as the env's state fits the CU's
  * 160 KB of LDS - about 600 vertices with friction, 745 without; simple_axle.msh, 593 vertices / 2 003 tets, does with friction; the
- * wide variant takes analytic indenters only and is not available with tacex_fem_set_deterministic) the whole loop is ONE launch; the streaming fallback launches
+ * wide variant takes analytic indenters only and is not available with tacex_fem_set_deterministic) the whole loop is ONE launch; the streaming fallback
+ * (any vertex count; analytic indenters with barrier, step bound and - ABI 11 - friction lagged at the step's start; block-Jacobi PCG) launches
  * max_newton kernels on a fixed schedule in which converged envs return at once.  stats_dev (B,4) = [energy_before, energy_after, step_length, pcg_iterations] of the LAST iteration
- * run; step_info_dev (B,4) f64 = [newton_iterations, max |d| of the last iteration, flags, pcg_iterations_total] (CU-resident
- * kernel; zeros from the fallback), flags: 1 = a contact vertex was at or beyond its indenter's surface when an iteration started
+ * run; step_info_dev (B,4) f64 = [newton_iterations, max |d| of the last iteration, flags, pcg_iterations_total] (both kernels: the fallback
+ * sums / ORs over its launches), flags: 1 = a contact vertex was at or beyond its indenter's surface when an iteration started
  * (the caller moved the indenter by more than the gap: that vertex gets no restoring force), 2 = a line search found no decrease;
  * informational: 4 = the env dropped the coarse correction for the rest of the step (its stopping test passed with the residual's
  * 2-norm above |b|: no reduction at all), 8 = its PCG met negative curvature and iterations of the step were solved with the PSD-safe Hessian

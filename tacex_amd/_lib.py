@@ -140,6 +140,7 @@ SIGNATURES = {
     "tacex_fem_set_chains": (_i, [_vp, _i, _vp, _vp]),
     "tacex_fem_set_indenter_mesh": (_i, [_vp, _i, _vp, _i, _vp]),
     "tacex_fem_contact_gaps": (_i, [_vp, _vp, _vp, _i, _vp]),
+    "tacex_fem_newton_resident": (_i, [_vp]),
     "tacex_fem_set_friction_lag": (_i, [_vp, _i]),
     "tacex_fem_reset_envs": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp]),
     "tacex_fem_set_friction": (_i, [_vp, _d, _d]),

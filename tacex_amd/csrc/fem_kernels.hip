@@ -589,7 +589,8 @@ __device__ __forceinline__ double block_sum_max(double v, double* sh) {
 constexpr int kLsRescueStream = 32;  // rescue halvings of the line search next to a barrier (kLsRescue of the CU-resident kernel)
 
 __device__ double env_energy(const FemDev& m, const double* x, const double* xt, const uint8_t* cons, const double* aim,
-                             double* sh, const double* ind = nullptr) {
+                             double* sh, const double* ind = nullptr, const double* fl = nullptr, const double* xn = nullptr,
+                             const double* disp = nullptr) {
   double e = 0.0;
   for (int t = threadIdx.x; t < m.T; t += blockDim.x) {
     int v[4];
@@ -611,6 +612,7 @@ __device__ double env_energy(const FemDev& m, const double* x, const double* xt,
     }
     e += 0.5 * mv * q + 0.5 * m.strength * mv * qc;
     if (ind && m.area) e += m.dt * m.dt * contact_eval(m, ind, m.area[v], x + v * 3).e;
+    if (fl) e += m.dt * m.dt * friction_eval(m.fric_mu, m.fric_eps, fl + (size_t)v * 4, x + v * 3, xn + v * 3, disp, false).e;
   }
   return block_sum(e, sh);
 }
@@ -682,9 +684,9 @@ __global__ __launch_bounds__(512) void fem_gradient_kernel(FemDev m, const doubl
 }
 
 // ---- K17b: one projected-Newton iteration per env, everything inside one workgroup -----------------------------
-// workspace per env (doubles): ge 12T | tet cache 12T (F 9, a, b, c) | hv 12T | g,r,z,p,d,Hp,xc 7*3V | Dinv 9V | contact 5V; behind the B env
+// workspace per env (doubles): ge 12T | tet cache 12T (F 9, a, b, c) | hv 12T | g,r,z,p,d,Hp,xc 7*3V | Dinv 9V | contact 5V | friction lag 4V | friction blocks 6V; behind the B env
 // blocks: x_prev (B,V,3) and the per-env max |d| of tacex_fem_step
-__host__ __device__ inline size_t newton_ws_doubles(int V, int T) { return (size_t)36 * T + (size_t)35 * V; }
+__host__ __device__ inline size_t newton_ws_doubles(int V, int T) { return (size_t)36 * T + (size_t)45 * V; }  // (+ 10 V: friction lag | Hessian blocks)
 
 __device__ __forceinline__ bool inv3_spd(const double A[9], double Ai[9]) {
   // Cholesky test + inverse via adjugate
@@ -712,7 +714,8 @@ constexpr int kFemFlagPsdSafe = 8;      // informational: the PCG met negative c
 __global__ __launch_bounds__(512) void fem_newton_kernel(FemDev m, double* xg, const double* xtg, const uint8_t* consg,
                                                          const double* aimg, double* stats, double* wsg,
                                                          int pcg_max_iter, double pcg_tol_rate, int ls_max_iter, double* dxg, double dx_tol,
-                                                         double* step_info, int accumulate) {
+                                                         double* step_info, int accumulate, const double* xprevg, const double* dispg,
+                                                         int fric_ipc) {
   // step_info (nullable): the row of this env [Newton iterations, max |d|, flags, PCG iterations] - SET by the first launch of a time
   // step (accumulate = 0), added to / OR-ed by the later ones: tacex_fem_step runs this kernel once per Newton iteration, and
   // UipcSim.check_step() must see a penetrating vertex or a dead line search of ANY of them (the row used to be zeroed)
@@ -741,11 +744,20 @@ __global__ __launch_bounds__(512) void fem_newton_kernel(FemDev m, double* xg, c
   double* xc = vHp + (size_t)3 * V;      // line-search candidate
   double* Dinv = xc + (size_t)3 * V;     // (V,9)
   double* cdat = Dinv + (size_t)9 * V;   // (V,5) barrier of the vertex at x: dt^2 b'' | n (3) | gap d
+  double* flag_ = cdat + (size_t)5 * V;  // (V,4) friction lag: normal force | normal - taken in the FIRST launch of a time step, kept for its others
+  double* fhs = flag_ + (size_t)4 * V;   // (V,6) friction Hessian block of the vertex at x (dt^2-scaled, rounded to float like the CU-resident kernel's)
   const double dt2 = m.dt * m.dt;
   // IPC barrier against the env's indenter (the same terms as in the CU-resident kernel: gradient b' n, PSD curvature b'' n n^T in
-  // H.p and the block-Jacobi blocks, conservative step bound before the line search).  Friction, vertex chains and the coarse
-  // correction exist in the CU-resident kernel only - this is the path of meshes with more vertices than its workgroup has threads.
+  // H.p and the block-Jacobi blocks, conservative step bound before the line search) and, since round 5, Coulomb friction with the lag
+  // taken at the start of the step (capped by the contact reaction, or IPC's previous-configuration lag: tacex_fem_set_friction_lag).
+  // Vertex chains, the coarse correction, the contact-following start and the edge snap exist in the CU-resident kernel only - this
+  // is the path of meshes with more vertices than its workgroup has threads.
   const double* ind = (m.indenters && m.area) ? m.indenters + (size_t)b * 8 : nullptr;
+  const bool fric = ind && m.fric_mu > 0.0 && xprevg != nullptr && dispg != nullptr;
+  const double* xn = fric ? xprevg + o : nullptr;
+  double disp3[3] = {0, 0, 0};
+  if (fric) { disp3[0] = dispg[b * 3]; disp3[1] = dispg[b * 3 + 1]; disp3[2] = dispg[b * 3 + 2]; }
+  const double* fl = fric ? flag_ : nullptr;
 
   // ---- element pass: cache F and coefficients, tet gradients, diagonal 3x3 blocks (into hv as (4*9? no: 12 rows)) ----
   // the four 3x3 diagonal blocks of the element Hessian need 36 doubles per tet: use ge+tc? they are needed later,
@@ -822,6 +834,47 @@ __global__ __launch_bounds__(512) void fem_newton_kernel(FemDev m, double* xg, c
           D[i * 3 + k] += sc * (dP[i * 3 + 0] * r[l * 3 + 0] + dP[i * 3 + 1] * r[l * 3 + 1] + dP[i * 3 + 2] * r[l * 3 + 2]);
       }
     }
+    double fg[3] = {0, 0, 0};
+    if (fric) {
+      const double xv[3] = {x[v * 3], x[v * 3 + 1], x[v * 3 + 2]};
+      if (!accumulate) {  // first launch of the time step: the lag (FrictionModel.update of the oracle; fem_newton_lds_kernel's lag_pending)
+        double lam = 0.0, ln[3] = {cdat[(size_t)v * 5 + 1], cdat[(size_t)v * 5 + 2], cdat[(size_t)v * 5 + 3]};
+        if (fric_ipc) {
+          double indp[8];
+#pragma unroll
+          for (int k = 0; k < 8; ++k) indp[k] = ind[k];
+          indp[1] -= disp3[0]; indp[2] -= disp3[1]; indp[3] -= disp3[2];
+          const double xn3[3] = {xn[v * 3], xn[v * 3 + 1], xn[v * 3 + 2]};
+          const ContactEval cp = contact_eval(m, indp, m.area[v], xn3);
+          lam = (cp.active && !cp.penetrating) ? -cp.b1 : 0.0;
+          ln[0] = cp.n[0]; ln[1] = cp.n[1]; ln[2] = cp.n[2];
+        } else {
+          const ContactEval ce = contact_eval(m, ind, m.area[v], xv);
+          if (ce.active) {
+            double go[3];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+              go[i] = a3[i] + mv * (xv[i] - xt[v * 3 + i]);
+              if (c) go[i] += m.strength * mv * (xv[i] - aim[v * 3 + i]);
+            }
+            const double react = (go[0] * ce.n[0] + go[1] * ce.n[1] + go[2] * ce.n[2]) / dt2;
+            lam = fmin(-ce.b1, fmax(react, 0.0));
+            ln[0] = ce.n[0]; ln[1] = ce.n[1]; ln[2] = ce.n[2];
+          }
+        }
+        const bool on = lam > 0.0;
+        flag_[(size_t)v * 4] = on ? lam : 0.0;
+        flag_[(size_t)v * 4 + 1] = on ? ln[0] : 0.0; flag_[(size_t)v * 4 + 2] = on ? ln[1] : 0.0; flag_[(size_t)v * 4 + 3] = on ? ln[2] : 0.0;
+      }
+      const double xn3[3] = {xn[v * 3], xn[v * 3 + 1], xn[v * 3 + 2]};
+      const FricEval fe = friction_eval(m.fric_mu, m.fric_eps, flag_ + (size_t)v * 4, xv, xn3, disp3, true);
+      double h[6];
+#pragma unroll
+      for (int k = 0; k < 6; ++k) { h[k] = (double)(float)(dt2 * fe.h[k]); fhs[(size_t)v * 6 + k] = h[k]; }
+#pragma unroll
+      for (int i = 0; i < 3; ++i) fg[i] = dt2 * fe.g[i];
+      D[0] += h[0]; D[1] += h[1]; D[2] += h[2]; D[3] += h[1]; D[4] += h[3]; D[5] += h[4]; D[6] += h[2]; D[7] += h[4]; D[8] += h[5];
+    }
     double Di3[9];
     if (!inv3_spd(D, Di3)) {  // elastic block not SPD -> mass block (always SPD)
       const double im = 1.0 / md;
@@ -833,7 +886,7 @@ __global__ __launch_bounds__(512) void fem_newton_kernel(FemDev m, double* xg, c
     for (int k = 0; k < 9; ++k) Dinv[(size_t)v * 9 + k] = (double)(float)Di3[up[k]];
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
-      double gi = a3[i] + mv * (x[v * 3 + i] - xt[v * 3 + i]) + cg[i];
+      double gi = a3[i] + mv * (x[v * 3 + i] - xt[v * 3 + i]) + cg[i] + fg[i];
       if (c) gi += m.strength * mv * (x[v * 3 + i] - aim[v * 3 + i]);
       vg[v * 3 + i] = gi;
       vr[v * 3 + i] = -gi;
@@ -891,9 +944,15 @@ __global__ __launch_bounds__(512) void fem_newton_kernel(FemDev m, double* xg, c
       const double md = m.mass[v] * (1.0 + ((cons && cons[v]) ? m.strength : 0.0));
       const double cb2 = cdat[(size_t)v * 5];
       const double npq = cb2 * (cdat[(size_t)v * 5 + 1] * vp[v * 3] + cdat[(size_t)v * 5 + 2] * vp[v * 3 + 1] + cdat[(size_t)v * 5 + 3] * vp[v * 3 + 2]);
+      double fp[3] = {0, 0, 0};
+      if (fric) {
+        const double* q = fhs + (size_t)v * 6;
+        const double p0 = vp[v * 3], p1 = vp[v * 3 + 1], p2 = vp[v * 3 + 2];
+        fp[0] = q[0] * p0 + q[1] * p1 + q[2] * p2; fp[1] = q[1] * p0 + q[3] * p1 + q[4] * p2; fp[2] = q[2] * p0 + q[4] * p1 + q[5] * p2;
+      }
 #pragma unroll
       for (int i = 0; i < 3; ++i) {
-        const double h = a3[i] + md * vp[v * 3 + i] + npq * cdat[(size_t)v * 5 + 1 + i];
+        const double h = a3[i] + md * vp[v * 3 + i] + npq * cdat[(size_t)v * 5 + 1 + i] + fp[i];
         vHp[v * 3 + i] = h;
         part += vp[v * 3 + i] * h;
       }
@@ -930,7 +989,7 @@ __global__ __launch_bounds__(512) void fem_newton_kernel(FemDev m, double* xg, c
   }
   __syncthreads();
   // ---- backtracking line search on the incremental potential (accept the first E(x + step d) <= E(x)) ----
-  const double E0 = env_energy(m, x, xt, cons, aim, sh, ind);
+  const double E0 = env_energy(m, x, xt, cons, aim, sh, ind, fl, xn, disp3);  // (lag rows: written and read by the vertex's own thread)
   double step = 1.0, E1 = E0;
   if (ind) {  // conservative step bound (1-Lipschitz distance): no surface vertex may use more than kCcdSlack of its gap
     double amax = 1.0;
@@ -952,7 +1011,7 @@ __global__ __launch_bounds__(512) void fem_newton_kernel(FemDev m, double* xg, c
   for (int ls = 0; ls <= ls_cap; ++ls) {
     for (int k = threadIdx.x; k < 3 * V; k += blockDim.x) xc[k] = x[k] + step * vd[k];
     __syncthreads();
-    const double Ec = env_energy(m, xc, xt, cons, aim, sh, ind);
+    const double Ec = env_energy(m, xc, xt, cons, aim, sh, ind, fl, xn, disp3);
     if (Ec <= E0) { E1 = Ec; accepted = true; break; }
     step *= 0.5;
   }
@@ -2302,6 +2361,7 @@ struct tacex_fem_ctx {
   const void* ind_prev_ws = nullptr;
   int ind_prev_B = 0;
   const double* rest = nullptr;  // (V,3) rest positions (tacex_fem_reset_envs)
+  int last_resident = -1;       // which Newton kernel the last launch used: 1 CU-resident, 0 streaming, -1 none yet (tacex_fem_newton_resident)
   int fric_lag_mode = 0;        // 0: lag at the step's start state, capped by the contact reaction (round 4); 1: IPC's previous-configuration lag
   bool deterministic = false;   // window + CSR-gather sweeps (fixed summation order) instead of LDS atomics (tacex_fem_set_deterministic)
   bool follow_indenter = true;  // contact-following start of the Newton loop (tacex_fem_set_contact_following; fem_newton_lds_kernel)
@@ -2586,6 +2646,8 @@ int tacex_fem_set_friction_lag(tacex_fem_ctx* c, int mode) {
   return 0;
 }
 
+int tacex_fem_newton_resident(const tacex_fem_ctx* c) { return c ? c->last_resident : -1; }
+
 int tacex_fem_set_indenter_mesh(tacex_fem_ctx* c, int num_verts, const double* verts_host, int num_tris, const int32_t* tris_host) {
   if (!c) { set_error("tacex_fem_set_indenter_mesh: null context"); return 2; }
   if (num_tris == 0) {
@@ -2784,6 +2846,7 @@ static int launch_newton(tacex_fem_ctx* c, double* x, const double* xt, const ui
   const size_t lds = nwt_lds_bytes(V, c->dev.T, fric, nt);
   if (use_lds && V <= 768 && (nt == 512 ? 4 * c->dev.T < 65535 : (atom && !mesh)) && lds <= 160 * 1024) {
     if (resident) *resident = true;
+    c->last_resident = 1;
     static size_t granted[5][64] = {};  // per kernel instantiation and device: the attribute is per kernel AND device
     using kern_t = decltype(&fem_newton_lds_kernel<false, true, 512>);
     kern_t kern;
@@ -2821,15 +2884,16 @@ static int launch_newton(tacex_fem_ctx* c, double* x, const double* xt, const ui
     return e == hipSuccess ? 0 : fail_hip(e, "fem_newton_lds_kernel");
   }
   if (resident) *resident = false;
-  if (c->dev.indenters && (c->dev.fric_mu > 0.0 || c->dev.im_nt > 0)) {
-    set_error("FEM Newton: friction and mesh indenters need the CU-resident Newton kernel (mesh with <= 768 vertices whose state fits the "
-              "CU's 160 KB of LDS - this one needs %zu bytes; a mesh indenter or the deterministic switch: <= 512 vertices; "
-              "TACEX_FEM_NEWTON_LDS != 0); the streaming kernel of larger meshes handles the barrier of analytic indenters only - "
-              "switch friction off", lds);
+  c->last_resident = 0;
+  if (c->dev.indenters && c->dev.im_nt > 0) {
+    set_error("FEM Newton: a mesh indenter needs the CU-resident Newton kernel (mesh with <= 512 vertices whose state fits the CU's 160 KB of "
+              "LDS - this one needs %zu bytes; TACEX_FEM_NEWTON_LDS != 0); the streaming kernel of larger meshes handles analytic indenters "
+              "(barrier, step bound, friction) only", lds);
     return 2;
   }
   hipLaunchKernelGGL(fem_newton_kernel, dim3(B), dim3(512), 0, st, c->dev, x, xt, cons, aim, stats, static_cast<double*>(ws), pcg_max_iter,
-                     pcg_tol_rate, ls_max_iter, dx_dev, dx_tol, step_info, stream_accumulate ? 1 : 0);
+                     pcg_tol_rate, ls_max_iter, dx_dev, dx_tol, step_info, stream_accumulate ? 1 : 0, fric ? xprev : nullptr, fric ? disp : nullptr,
+                     c->fric_lag_mode == 1 ? 1 : 0);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : fail_hip(e, "fem_newton_kernel");
 }
@@ -2887,7 +2951,7 @@ int tacex_fem_step(tacex_fem_ctx* c, double* x, double* v, double* xt, const uin
     // these add their iteration / PCG counts and OR their flags into it (penetration, dead line search: check_step() sees them).
     for (int it = 1; it < max_newton; ++it)
       if (int rc = launch_newton(c, x, xt, cons, aim, stats, ws, B, pcg_max_iter, pcg_tol_rate, ls_max_iter, dx, tol, 1, step_info, st, nullptr,
-                                 nullptr, nullptr, nullptr, true))
+                                 xprev, disp, nullptr, true))  // (xprev / disp: the friction terms of the later iterations; the lag stays the first launch's)
         return rc;
   }
   hipLaunchKernelGGL(fem_velocity_kernel, dim3((unsigned)((n3 + 255) / 256)), dim3(256), 0, st, x, xprev, v, n3, 1.0 / dt, ind, ind_prev, B);

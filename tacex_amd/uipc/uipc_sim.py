@@ -501,6 +501,13 @@ class UipcSim:
             torch.cuda.current_stream(self.device).wait_event(self.step_done)
 
     @property
+    def newton_kernel_resident(self) -> bool | None:
+        """Which Newton kernel the last step launched: True = the CU-resident one (the env's state on one CU, one launch per time step), False = the
+        streaming fallback (meshes whose state does not fit a CU's LDS, the deterministic switch on more than 512 vertices), None = no step yet."""
+        r = int(self._lib.tacex_fem_newton_resident(self._handle))
+        return None if r < 0 else bool(r)
+
+    @property
     def last_newton_iters(self) -> int:
         """Newton iterations of the slowest env in the last step (reads the device: synchronises)."""
         si = getattr(self, "step_info", None)

@@ -990,35 +990,57 @@ def test_wide_newton_kernel_steps_simple_axle_with_contact_and_friction():
 
 def test_streaming_newton_kernel_steps_simple_axle_with_sphere_contact():
     """The streaming Newton kernel (state in HBM / L2, any vertex count: what a mesh too large for a CU's LDS, or the deterministic
-    switch on one of more than 512, runs on) carries the IPC barrier and the conservative step bound; friction, chains and the coarse
-    correction stay with the CU-resident kernel (asked for together with friction, the step fails loudly).  simple_axle.msh in
-    deterministic mode against the oracle's fem_step with the same block-Jacobi preconditioner: iteration counts, positions, no penetration."""
+    switch on one of more than 512, runs on) carries the IPC barrier, the conservative step bound and - since round 5 - Coulomb friction
+    with the lag of the step's start (until then the default cfg, friction on, made such a mesh's step fail: "switch friction off");
+    chains, the coarse correction, the contact-following start and the edge snap stay with the CU-resident kernel.  simple_axle.msh in
+    deterministic mode against the oracle's fem_step with the same block-Jacobi preconditioner, without and with friction (press for
+    three steps, then slide): positions, no penetration; and friction really acts (the contact patch is dragged along)."""
     from oracle.fem_oracle import fem_step
 
-    B = 2
-    sim, m, P, cons, aim, cms, ind = _axle_scene(B, deterministic=True, block_jacobi=True)
-    # friction is on by default (uipc_sim.py:103-124) and lives in the CU-resident kernel only: the step says so
-    sim.set_contact_indenters(torch.from_numpy(ind))
-    with pytest.raises(Exception, match="friction"):
-        sim.step(max_newton_iter=2)
-    sim.cfg.contact.enable_friction = False
-    sim.set_contact_indenters(torch.from_numpy(ind))
-    indd = sim.contact_indenters
-    xo = [P.copy() for _ in range(B)]
-    vo = [np.zeros_like(P) for _ in range(B)]
-    for k in range(3):
-        indd[:, 3] -= 0.3 * sim.contact_gaps().amin(1)
-        cur = indd[:, 1:4].cpu().numpy().copy()
-        sim.step(max_newton_iter=30)
-        x = sim.x.cpu().numpy()
-        assert np.isfinite(x).all() and float(sim.contact_gaps().amin()) > 0.0
-        for b in range(B):
-            cms[b].ind[1:4] = cur[b]
-            xo[b], vo[b], io = fem_step(m, cms[b], xo[b], vo[b], cons, aim[b], gravity=sim.cfg.gravity, max_newton=30, velocity_tol=2e-3,
-                                        pcg_max_iter=3000, pcg_tol_rate=1e-10, coarse=None, chains=None, lag_prec=False)
-            assert io[0] < 30 and int(io[2]) & 3 == 0, (k, b, io)
-            assert np.abs(x[b] - xo[b]).max() <= 2 * 2e-3 * sim.cfg.dt, (k, b, np.abs(x[b] - xo[b]).max())  # both inside the Newton tolerance
-    assert (P[:, 2] - sim.x[0].cpu().numpy()[:, 2]).max() > 5e-5  # the axle is dented / bent by the sphere
+    B, slide, sep = 2, 1e-4, 0.0
+    for with_friction in (False, True):
+        sim, m, P, cons, aim, cms, ind = _axle_scene(B, deterministic=True, block_jacobi=True, velocity_tol=5e-4)
+        sim.cfg.contact.enable_friction = with_friction
+        sim.set_contact_indenters(torch.from_numpy(ind))
+        indd = sim.contact_indenters
+        mu, vtol = sim.cfg.contact.default_friction_ratio, sim.cfg.newton.velocity_tol
+        xo = [P.copy() for _ in range(B)]
+        vo = [np.zeros_like(P) for _ in range(B)]
+        prev = None
+        for k in range(5):
+            gap = sim.contact_gaps().amin(1)
+            if k < 3:
+                indd[:, 3] -= 0.3 * gap
+            else:
+                indd[:, 1] += slide
+                indd[:, 3] += torch.clamp(2 * slide - gap, min=0.0)
+            cur = indd[:, 1:4].cpu().numpy().copy()
+            disp = cur - prev if prev is not None else np.zeros_like(cur)
+            prev = cur
+            # (as in the wide-kernel test: every step starts the oracle from the kernel's state - the rod's bending mode is nearly free)
+            xo, vo = list(sim.x.cpu().numpy().copy()), list(sim.v.cpu().numpy().copy())
+            sim.step(max_newton_iter=30)
+            assert sim.newton_kernel_resident is False  # the streaming kernel
+            info = sim.check_step()
+            assert len(info["penetrating_envs"]) == 0 and len(info["line_search_failed_envs"]) == 0, (with_friction, k, info)
+            x = sim.x.cpu().numpy()
+            assert np.isfinite(x).all() and float(sim.contact_gaps().amin()) > 0.0
+            for b in range(B):
+                cms[b].ind[1:4] = cur[b]
+                if with_friction and k >= 3 and b == 0:  # what the same step looks like WITHOUT friction: the comparison below must be able to tell
+                    x_nf, _, _ = fem_step(m, cms[b], xo[b], vo[b], cons, aim[b], gravity=sim.cfg.gravity, max_newton=30, velocity_tol=vtol,
+                                          pcg_max_iter=3000, pcg_tol_rate=1e-10, coarse=None, chains=None, lag_prec=False, indenter_disp=np.zeros(3))
+                    sep = max(sep, float(np.abs(x[b] - x_nf).max()))
+                xo[b], vo[b], io = fem_step(m, cms[b], xo[b], vo[b], cons, aim[b], gravity=sim.cfg.gravity, max_newton=30, velocity_tol=vtol,
+                                            pcg_max_iter=3000, pcg_tol_rate=1e-10, coarse=None, chains=None, lag_prec=False,
+                                            friction=(mu, sim.cfg.contact.eps_velocity, disp[b]) if with_friction else None,
+                                            indenter_disp=np.zeros(3))  # (no contact-following start in the streaming kernel)
+                assert io[0] < 30 and int(io[2]) & 3 == 0, (with_friction, k, b, io)
+                assert np.abs(x[b] - xo[b]).max() <= 2 * vtol * sim.cfg.dt, (with_friction, k, b, np.abs(x[b] - xo[b]).max(), io)  # both inside the Newton tolerance
+        assert (P[:, 2] - sim.x[0].cpu().numpy()[:, 2]).max() > 5e-5  # the axle is dented / bent by the sphere
+    # friction really acted: the frictional kernel state lies further from the oracle's FRICTIONLESS solve of the same step than the tolerance
+    # it matches the frictional one to
+    assert sep > 3 * 2 * 5e-4 * 0.01, sep
 
 
 def test_deterministic_and_atomic_sweeps_agree_and_deterministic_runs_are_bit_identical():

@@ -160,6 +160,7 @@ def test_wider_pad_on_the_768_thread_kernel_is_a_stationary_point_too():
     fem = _scene(B, d_hat=d_hat, velocity_tol=TIGHT_VTOL, tol_rate=1e-12, friction_lag="ipc", mesh=(9, 10, 4))
     sim, obj = fem.sim, fem.gelpad
     assert obj.points.shape[0] == 550 and sim.cfg.contact.enable_friction
+
     c = obj.cfg.constitution_cfg
     m = FemModel.build(obj.points, obj.tets, youngs=c.youngs_modulus * 1e6, poisson=c.poisson_rate, density=obj.cfg.mass_density, dt=sim.cfg.dt,
                        strength=1000.0)
@@ -167,7 +168,8 @@ def test_wider_pad_on_the_768_thread_kernel_is_a_stationary_point_too():
     ind_prev, worst, in_contact = None, 0.0, 0
     for i in range(8):
         x_n, v_n = sim.x.cpu().numpy().copy(), sim.v.cpu().numpy().copy()
-        fem.step(i)  # (friction on + more than 512 vertices: a step that is not CU-resident raises)
+        fem.step(i)
+        assert sim.newton_kernel_resident is True  # (the 768-thread CU-resident variant, not the streaming fallback)
         info = sim.check_step()
         assert len(info["penetrating_envs"]) == 0 and len(info["line_search_failed_envs"]) == 0 and info["newton_iters"].max() < 200, (i, info)
         x_end, ind_now = sim.x.cpu().numpy(), fem.ind.cpu().numpy().copy()
@@ -273,7 +275,7 @@ def test_streaming_newton_kernel_reports_iterations_and_a_penetrating_indenter()
     from test_fem_gpu import _axle_scene
 
     sim, m, P, cons, aim, cms, ind0 = _axle_scene(2, deterministic=True, block_jacobi=True)
-    sim.cfg.contact.enable_friction = False  # (friction lives in the CU-resident kernel only)
+    sim.cfg.contact.enable_friction = False
     sim.set_contact_indenters(torch.from_numpy(ind0))
     ind = sim.contact_indenters
     ind[:, 3] -= 0.3 * sim.contact_gaps().amin(1)
