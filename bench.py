@@ -638,6 +638,9 @@ def fem_axle_entry(dev, B=512, steps=12, streaming=False, tol_rate=None, key="ax
         return {"key": key, "workload": f"FEM only: simple_axle.msh on {name}", "error": f"{type(ex).__name__}: {ex}"[:300]}
 
 
+SWEEPS_PER_NEWTON = 2.0  # tet sweeps of fem_newton_lds_kernel per Newton iteration besides the PCG's (see fem_roofline)
+
+
 def fem_roofline(fem, period=None):
     """What bounds the FEM step.  `period` = (total FEM ms, Newton iterations per env, PCG iterations per env) summed over the timed
     period of the scene: the roofline figures are taken over THAT (the scene's own mix of regimes); without it a single Newton
@@ -680,10 +683,13 @@ def fem_roofline(fem, period=None):
         n_newton = 1.0
     else:
         ms_nw, n_newton, pcg = period
-    # per env and PCG iteration (see the docstring); + gradient / preconditioner / line-search sweeps ~ 4 more sweeps per Newton iteration
+    # per env and PCG iteration (see the docstring).  Besides the PCG's H.p sweeps a Newton iteration runs SWEEPS_PER_NEWTON tet sweeps: the
+    # gradient sweep and the line search's candidate energy (round 5; rounds 3-4 counted 4: the block assembly - now a kernel of its own - and
+    # the line search's E(x) - now a by-product of the gradient sweep - were sweeps of this kernel then).  Both are priced like an H.p sweep,
+    # which overstates them (no rows, no apply_dP): the f64 fraction is an upper estimate.
     flop_it = 480 * T + 120 * V
     lds_it = (36 * T + 75 * V) * 8
-    sweeps = pcg + 4.0 * n_newton
+    sweeps = pcg + SWEEPS_PER_NEWTON * n_newton
     tf = flop_it * sweeps * B / (ms_nw * 1e-3) / 1e12
     lds_tbs = lds_it * sweeps * B / (ms_nw * 1e-3) / 1e12
     el_bytes = (12 * 8 + 8 + 96 + 1152) * B * T  # per env and tet: 4 vertices x 3 doubles read; energy + gradient + 12x12 Hessian written
@@ -734,7 +740,7 @@ def fem_roofline_entry(sw):
         per = c4.get("fem_period", {})
         out.update({"f64_achieved": ni["achieved_f64"], "f64_peak": ni["peak_f64"], "f64_unit": "TFLOP/s", "f64_frac": ni["frac"],
                     "lds_frac": ni["lds_frac"], "us_per_sweep": ni["us_per_sweep"], "window": ni["window"],
-                    "sweeps_per_step": round(ni["pcg_iterations"] / max(per.get("steps", 1), 1) + 4.0 * ni["newton_iterations"] / max(per.get("steps", 1), 1), 2),
+                    "sweeps_per_step": round(ni["pcg_iterations"] / max(per.get("steps", 1), 1) + SWEEPS_PER_NEWTON * ni["newton_iterations"] / max(per.get("steps", 1), 1), 2),
                     "newton_iters_per_step": per.get("newton_iters_per_step_mean"), "pcg_iters_per_newton": per.get("pcg_iters_per_newton_mean"),
                     "pcg_stop": PCG_STOP_RULE,
                     "matrix_free_bytes_per_tet_iteration_survey": 304,

@@ -1021,7 +1021,10 @@ __global__ __launch_bounds__(512) void fem_newton_kernel(FemDev m, double* xg, c
     step = 0.0;
   }
   if (threadIdx.x == 0) {
-    if (dxg) dxg[b] = dmax;  // max |d| of the unscaled direction: <= dx_tol = converged (same rule as the CU-resident kernel)
+    // max |d| of the unscaled direction: <= dx_tol = converged (same rule as the CU-resident kernel).  A rejected search leaves x where it
+    // was - every further launch of the step would repeat this iteration: the env is taken out of the step's remaining launches (0 = done),
+    // its flag says why (the CU-resident kernel and the oracle's fem_step break out of their loops the same way)
+    if (dxg) dxg[b] = (step_info && !accepted && !(dmax <= dx_tol)) ? 0.0 : dmax;  // (tacex_fem_step only: tacex_fem_newton_step's callers read max |d| itself)
     stats[(size_t)b * 4 + 0] = E0; stats[(size_t)b * 4 + 1] = E1; stats[(size_t)b * 4 + 2] = step; stats[(size_t)b * 4 + 3] = (double)it;
     if (step_info) {
       const int fl = (any_pen ? kFemFlagPenetration : 0) | ((!accepted && !(dmax <= dx_tol)) ? kFemFlagLsFailed : 0);
