@@ -81,7 +81,7 @@ struct tacex_taxim_ctx {
   } depth_pass;
   // second stream of the band levels (pipeline_impl: odd chunks of a pass run beside the even ones), created on first use
   static constexpr int kMaxLvlStreams = 4;
-  hipStream_t lvl_stream[kMaxLvlStreams - 1] = {}; hipEvent_t lvl_fork = nullptr, lvl_join[kMaxLvlStreams - 1] = {};
+  hipStream_t lvl_stream[kMaxLvlStreams - 1] = {}; hipEvent_t lvl_fork = nullptr, lvl_join[kMaxLvlStreams - 1] = {}, order_evt = nullptr;
   std::vector<void*> allocs;
   // profiling
   bool profiling = false;
@@ -242,6 +242,7 @@ void tacex_taxim_destroy(tacex_taxim_ctx* c) {
   for (auto& q : c->lvl_stream)
     if (q) (void)hipStreamSynchronize(q);  // (the streams belong to the per-device pool: level_stream())
   if (c->lvl_fork) (void)hipEventDestroy(c->lvl_fork);
+  if (c->order_evt) (void)hipEventDestroy(c->order_evt);
   for (auto& e : c->lvl_join)
     if (e) (void)hipEventDestroy(e);
   for (void* p : c->allocs) (void)hipFree(p);
@@ -816,6 +817,26 @@ static int pipeline_chunk(tacex_taxim_ctx* c, const float* hm, const float* pres
     for (int q = 0; q < lvl_streams - 1; ++q) HIP_TRY(hipStreamWaitEvent(c->lvl_stream[q], c->lvl_fork, 0), "hipStreamWaitEvent");
   }
   hipStream_t const st_main = st;
+  // ITEM ORDER OF THE TAIL, EARLY: stream_order_kernel needs the contact rows only.  On the two-streams path it is issued beside the band
+  // levels - right behind the fork when the caller brought the rows, behind the last two depth passes when they are this pass's own
+  // (deferred) - instead of between the levels' join and the tail (9.5 us + the join's ~12 us of queue turnaround on the critical path,
+  // profiles/r05_experiments.md section 22).  TACEX_STREAM_ORDER_EARLY=0: as before.
+  static const int order_early_env = getenv("TACEX_STREAM_ORDER_EARLY") ? atoi(getenv("TACEX_STREAM_ORDER_EARLY")) : 1;
+  const StreamPlan* tail_plan = nullptr;
+  bool order_done = false;
+  int band_grow_rows = 0;
+  for (int l = 0; l < n_band; ++l) band_grow_rows += (c->levels[l].kh - 1) / 2;
+  const int n_chunks = (B + lcf - 1) / lcf;
+  bool order_early = order_early_env != 0 && stream_tail && dual && lvl_streams == 2 && rows != nullptr && n_chunks >= 3;
+  if (order_early) {
+    const bool want_obs_p = obs_h && obs;
+    if (int rc = stream_plan(c, n_fused, B, want_obs_p ? obs_hh : 0, want_obs_p ? obs_w : 0, &tail_plan)) return rc;
+    if (B * tail_plan->nstrips * tail_plan->nseg > c->stream_order_cap) order_early = false;
+  }
+  if (order_early && !dp) {  // rows from the caller: ready behind the fork; on the second stream, ahead of its first chunk
+    HIP_TRY(run_stream_order(c->levels, c->n_levels, n_fused, *tail_plan, B, c->H, rows, band_grow_rows, c->stream_order, c->lvl_stream[0], &order_done),
+            "stream_order_kernel");
+  }
   int chunk_no = 0;
   for (int b0 = 0; b0 < B; b0 += lcf, ++chunk_no) {
     const int nb = B - b0 < lcf ? B - b0 : lcf;
@@ -823,6 +844,14 @@ static int pipeline_chunk(tacex_taxim_ctx* c, const float* hm, const float* pres
     hipStream_t st = lane_q > 0 ? c->lvl_stream[lane_q - 1] : st_main;  // (shadows the pass's stream inside the chunk)
     if (dp) {  // this chunk's height maps, minima, indentation depths and contact ranges: on the chunk's stream, ahead of its levels
       if (int rc = depth_pass_range(*dp, b0, nb, c->H, c->W, st)) return rc;
+      if (order_early && chunk_no == n_chunks - 2) {  // the last depth pass of THIS stream: the other stream's order launch waits for it
+        if (!c->order_evt) HIP_TRY(hipEventCreateWithFlags(&c->order_evt, hipEventDisableTiming), "hipEventCreate");
+        HIP_TRY(hipEventRecord(c->order_evt, st), "hipEventRecord");
+      } else if (order_early && chunk_no == n_chunks - 1) {  // every frame's rows are written once this one and the other stream's last are done
+        HIP_TRY(hipStreamWaitEvent(st, c->order_evt, 0), "hipStreamWaitEvent");
+        HIP_TRY(run_stream_order(c->levels, c->n_levels, n_fused, *tail_plan, B, c->H, rows, band_grow_rows, c->stream_order, st, &order_done),
+                "stream_order_kernel");
+      }
     }
     src = nullptr;
     int grow = 0, grow_x = 0;  // rows / columns by which the non-zero range of the level's input exceeds the contact rows / columns
@@ -864,7 +893,7 @@ static int pipeline_chunk(tacex_taxim_ctx* c, const float* hm, const float* pres
                             (int)(tail_tiles_per_frame(c->H, c->W) * kTailWavesPerTile),
                             pix ? c->fots_pix_z + (size_t)frame0 * c->fots_taps.n_markers : nullptr,
                             pix ? c->fots_pix_m + (size_t)frame0 * c->fots_taps.n_markers : nullptr, st, rows, band_grow,
-                            n_items <= c->stream_order_cap ? c->stream_order : nullptr),
+                            n_items <= c->stream_order_cap ? c->stream_order : nullptr, order_done),
             "taxim_stream_kernel");
     if (fuse_obs) {
       HIP_TRY(run_obs_finish_stream(obs_h, obs, obs_u8, *plan, B, st), "obs_finish_stream_kernel");

@@ -163,7 +163,10 @@ hipError_t run_stream_tail(const LevelDesc* lv, int n_levels, int n_fused, const
                            const float* sa, const float* sb, const float* pd, const ShadeParams* sp, float* rgb, float* z_last,
                            int B, int H, int W, float contact_scale, const StreamPlan& plan, float* obs_part,
                            FotsReduce* fots_part, int fots_stride, float* pix_z, uint8_t* pix_m, hipStream_t st, const int* rows_ext = nullptr, int ext_grow = 0,
-                           int* order_buf = nullptr);  // (B * strips * segments) device ints for the launch's item order (nullptr: frame order)
+                           int* order_buf = nullptr,  // (B * strips * segments) device ints for the launch's item order (nullptr: frame order)
+                           bool order_done = false);  // the order has been issued by run_stream_order (the tail's stream is behind it)
+hipError_t run_stream_order(const LevelDesc* lv, int n_levels, int n_fused, const StreamPlan& plan, int B, int H, const int* rows_ext, int ext_grow,
+                            int* order_buf, hipStream_t st, bool* launched);
 hipError_t run_obs_finish_stream(const float* part, void* obs, bool u8, const StreamPlan& plan, int B, hipStream_t st);
 
 // More than 48 KB of dynamic LDS is an opt-in per kernel AND per device (one process may drive several GPUs): `granted` is the

@@ -1303,13 +1303,35 @@ hipError_t run_stream_flat_image(const ShadeParams* sp, int H, int W, hipStream_
   return hipGetLastError();
 }
 
+// TACEX_STREAM_ORDER=0: items in frame order (A/B path); the split kernels always run that way
+static bool stream_sorted() {
+  static const int sorted = getenv("TACEX_STREAM_ORDER") ? atoi(getenv("TACEX_STREAM_ORDER")) : 1;
+  return sorted != 0;
+}
+
+// The item order of a fused streaming-tail launch, as a launch of its own: it depends on the contact rows alone, so the pipeline issues it
+// beside the band levels (as soon as the last depth pass has left the rows) instead of between the levels' join and the tail.
+// Returns hipSuccess and sets *launched when the order buffer will hold the launch's order.
+hipError_t run_stream_order(const LevelDesc* lv, int n_levels, int n_fused, const StreamPlan& plan, int B, int H, const int* rows_ext, int ext_grow,
+                            int* order_buf, hipStream_t st, bool* launched) {
+  *launched = false;
+  if (stream_split() || !stream_sorted() || !order_buf || !lv[0].gel_zero || !rows_ext) return hipSuccess;
+  const int v = stream_variant(n_fused, lv[n_levels - n_fused].kw);
+  const int n_items = B * plan.nstrips * plan.nseg;
+  const int sum_r = v == 0 ? 9 : (v == 1 ? 10 : 5);
+  hipLaunchKernelGGL(stream_order_kernel, dim3(1), dim3(1024), 0, st, rows_ext, n_items, plan.nstrips * plan.nseg, plan.nseg, plan.seg_rows, H,
+                     ext_grow + sum_r + 1, order_buf);
+  const hipError_t e = hipGetLastError();
+  *launched = e == hipSuccess;
+  return e;
+}
+
 hipError_t run_stream_tail(const LevelDesc* lv, int n_levels, int n_fused, const float* zin, const float* hm, const float* gel,
                            const float* sa, const float* sb, const float* pd, const ShadeParams* sp, float* rgb, float* z_last,
                            int B, int H, int W, float contact_scale, const StreamPlan& plan, float* obs_part,
                            FotsReduce* fots_part, int fots_stride, float* pix_z, uint8_t* pix_m, hipStream_t st,
-                           const int* rows_ext, int ext_grow, int* order_buf) {
-  // TACEX_STREAM_ORDER=0: items in frame order (A/B path); the split kernels always run that way
-  static const int sorted = getenv("TACEX_STREAM_ORDER") ? atoi(getenv("TACEX_STREAM_ORDER")) : 1;
+                           const int* rows_ext, int ext_grow, int* order_buf, bool order_done) {
+  const bool sorted = stream_sorted();
   StreamArgs a{};
   a.rows_ext = lv[0].gel_zero ? rows_ext : nullptr; a.ext_grow = ext_grow;
   a.zin = zin; a.hm = hm; a.gel = lv[0].gel_zero ? nullptr : gel; a.shift_a = sa; a.shift_b = sb; a.pdepth = pd;
@@ -1345,7 +1367,9 @@ hipError_t run_stream_tail(const LevelDesc* lv, int n_levels, int n_fused, const
   const int v = stream_variant(n_fused, lv[n_levels - n_fused].kw);
   const bool gz = lv[0].gel_zero;
   if (!stream_split()) {
-    if (sorted && order_buf && gz && rows_ext) {  // heaviest items first (see the kernel's "work distribution" note)
+    if (order_done) {
+      sh.order = order_buf;  // (run_stream_order has been issued for this launch)
+    } else if (sorted && order_buf && gz && rows_ext) {  // heaviest items first (see the kernel's "work distribution" note)
       const int n_items = B * sh.nstrips * sh.nseg;
       const int sum_r = v == 0 ? 9 : (v == 1 ? 10 : 5);
       hipLaunchKernelGGL(stream_order_kernel, dim3(1), dim3(1024), 0, st, rows_ext, n_items, sh.nstrips * sh.nseg, sh.nseg, sh.seg_rows, H,
