@@ -73,6 +73,7 @@ def parse(argv=None):
                     help="update the sensors of an env one by one (two launch sequences per step) instead of as one GelSightSensorGroup")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-node-leg", action="store_true", help="skip the 4096-env whole-node leg (value_node4096*)")
     ap.add_argument("--no-sweep", action="store_true", help="skip the C2 / 512-shard / C4 / C5 sweep (N = 1 only)")
     ap.add_argument("--sweep-steps", type=int, default=30)
     ap.add_argument("--sweep-keys", default=None, help="comma-separated sweep entries to run (default: all), in the order given by the sweep")
@@ -124,7 +125,7 @@ class Rig:
     """`n_sensors` GelSightSensors over one env shard + the packed observation; step() = one update of all of them."""
 
     def __init__(self, B, H, W, n_sensors, markers, dev, world, seed, gather="obs32", obs_dtype="u8", fem=None, sensor_streams=False,
-                 data="contacts", cam_res=None, clip=(0.024, 0.029), grid=(11, 9), group=True):
+                 data="contacts", cam_res=None, clip=(0.024, 0.029), grid=(11, 9), group=True, collective=None):
         from tacex_amd import GelSightSensorGroup
         from tacex_amd.env_shard import ObservationGather
         from tacex_amd.utils.synthetic import dense_contact_depth_maps, synthetic_depth_maps
@@ -161,7 +162,7 @@ class Rig:
                 pieces[f"indent_{k}"] = (1,)
                 if markers or fem is not None:
                     pieces[f"markers_{k}"] = tuple(self.sensors[k]._data.output["marker_motion"].shape[1:])
-            self.obs = ObservationGather(pieces, B, world, dev, dtypes=dtypes or None)
+            self.obs = ObservationGather(pieces, B, world, dev, dtypes=dtypes or None, collective=collective)
 
     def step(self, i=0):
         if self.fem is not None:
@@ -519,8 +520,8 @@ def sweep(args, dev):
         512, 240, 320, 1, False, fem=lambda: FemGelpad(512, dev, max_newton_iter=NEWTON_CAP))
     run("c4_dhat5e4", "C4 per-GPU shard with the reference scenes' contact zone d_hat = 5e-4 (ball_rolling_uipc.py:71-75)",
         512, 240, 320, 1, False, fem=lambda: FemGelpad(512, dev, max_newton_iter=NEWTON_CAP, side_stream=True, d_hat=5e-4))
-    run("c4_lag_ipc", "C4 per-GPU shard with IPC's previous-configuration friction lag (cfg.contact.friction_lag = 'ipc') instead of the reaction-capped default",
-        512, 240, 320, 1, False, fem=lambda: FemGelpad(512, dev, max_newton_iter=NEWTON_CAP, side_stream=True, friction_lag="ipc"))
+    run("c4_lag_capped", "C4 per-GPU shard with the opt-in reaction-capped friction lag (cfg.contact.friction_lag = 'capped') instead of IPC's previous-configuration lag (the default since round 6)",
+        512, 240, 320, 1, False, fem=lambda: FemGelpad(512, dev, max_newton_iter=NEWTON_CAP, side_stream=True, friction_lag="capped"))
     run("c4_rolling", "C4 shard, rolling contact: the indenter stays on the pad and slides, friction on",
         512, 240, 320, 1, False, fem=lambda: FemGelpad(512, dev, motion="rolling", max_newton_iter=NEWTON_CAP, side_stream=True))
     run("c5", "C5 per-GPU shard: 1024 envs, RGB 640x480 + FEM-driven markers (gelpad FEM step included) (BASELINE configs[4] / 8)",
@@ -584,6 +585,7 @@ def fem_axle_entry(dev, B=512, steps=12, streaming=False, tol_rate=None, key="ax
         T = g["simple_axle_tets"]
         cfg = UipcSimCfg(device=dev)
         cfg.newton.velocity_tol = 2e-3  # 20 um per step: the default (0.5 mm, uipc_sim.py:62-66) is a sixth of this rod's thickness
+        cfg.contact.friction_lag = "capped"  # the documented setting for slender bodies (UipcSimCfg.Contact.friction_lag); gelpad scenes run "ipc"
         if tol_rate is not None:
             cfg.linear_system.tol_rate = tol_rate
         if streaming:
@@ -764,7 +766,7 @@ _ROOF_KEYS = ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", 
 _FEM_KEYS = ("hbm_frac", "hbm_achieved", "f64_frac", "lds_frac", "us_per_sweep", "sweeps_per_step", "newton_iters_per_step", "pcg_iters_per_newton")
 _CPU_KEYS = ("value", "unit", "cores", "kind", "logical_cores", "physical_cores")
 _SWEEP_SCALARS = {"c3_separate": "value_c3_separate", "c2": "value_c2", "c4": "value_c4", "c5": "value_c5", "c3_dense": "value_dense_contact", "c3_no_gather": "value_no_gather",
-                  "c3_sensor_streams": "value_sensor_streams", "c4_rolling": "value_c4_rolling", "c4_lag_ipc": "value_c4_lag_ipc", "c4_dhat5e4": "value_c4_dhat5e4",
+                  "c3_sensor_streams": "value_sensor_streams", "c4_rolling": "value_c4_rolling", "c4_lag_capped": "value_c4_lag_capped", "c4_dhat5e4": "value_c4_dhat5e4",
                   "c5_optical": "value_c5_optical", "shard512": "value_shard512"}
 
 
@@ -779,8 +781,6 @@ def compact_line(full: dict, details_path: str | None) -> dict:
         name = _SWEEP_SCALARS.get(e.get("key"))
         if name is not None:
             line[name] = e.get("frames_per_s")  # None = the entry failed (its error is in the details file)
-        if e.get("key") == "axle":
-            line["value_axle_env_steps"] = e.get("env_steps_per_s")
     errs = [e["key"] for e in cfg.get("sweep") or [] if "error" in e]
     if errs:
         line["sweep_errors"] = errs
@@ -794,6 +794,10 @@ def compact_line(full: dict, details_path: str | None) -> dict:
     if c is not None:
         line["cpu_baseline"] = {k: c[k] for k in _CPU_KEYS if k in c}
         line["cpu_baseline"]["sample"] = c["sample"][:200]
+    nd = full.get("node4096")
+    if nd is not None:
+        for k in ("value_node4096", "value_node4096_no_gather", "value_node4096_fem", "value_node4096_fem_no_gather", "strong_scaling_base"):
+            line[k] = nd.get(k)
     m = full.get("multi_gpu")
     if m is not None:
         line["multi_gpu"] = {k: m[k] for k in ("backend", "world_size", "per_rank_ms_per_step", "value_no_gather", "ms_per_step_no_gather", "launcher")
@@ -895,10 +899,104 @@ def dry_run_rank(args):
     full["data"] = "dry-run"
     if multi is not None:
         full["multi_gpu"] = multi
+    if not args.no_node_leg:
+        full["node4096"] = node4096_leg(args, shard, "cpu", use_dist, (lambda: dist.barrier()) if use_dist else (lambda: None), dry=True)
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
     return emit(full, args.details_out) if shard.rank == 0 else None
+
+
+NODE_ENVS = 4096  # the whole-node configuration `north_star`'s target is quoted on (BASELINE.json configs[3]: 4096 envs over the GPUs of one node)
+
+
+class _DryRig:
+    """Stand-in of Rig for --cpu-dry-run: the same timed() protocol around a CPU step that packs and (when asked) gathers a tiny observation."""
+
+    def __init__(self, B, world, gather, collective=None):
+        from tacex_amd.env_shard import ObservationGather
+
+        self.B = min(B, 4)
+        self.obs = ObservationGather({"rgb32_0": (32, 32, 3), "indent_0": (1,)}, self.B, world, "cpu", dtypes={"rgb32_0": torch.uint8},
+                                     collective=collective) if gather else None
+
+    def timed(self, steps, warmup, barrier=lambda: None, windows=1):
+        def step(i):
+            if self.obs is not None:
+                self.obs.pack_all({"rgb32_0": torch.full((self.B, 32, 32, 3), i % 251, dtype=torch.uint8), "indent_0": torch.full((self.B, 1), float(i))})
+                self.obs.gather_async()
+
+        for i in range(warmup):
+            step(i)
+        if self.obs is not None:
+            self.obs.wait()
+        barrier()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            step(warmup + i)
+        if self.obs is not None:
+            self.obs.wait()
+        barrier()
+        return time.perf_counter() - t0
+
+
+def node4096_leg(args, shard, dev, use_dist, barrier, dry=False):
+    """the configuration the target names - 4096 envs over the WHOLE node, 4096 / N per GPU - on the N > 1 line (the
+    headline weak-scales C3, 16 384 frames per step at N = 8, and never contained it).  Four rates, each the frames of all ranks over the
+    MAX over ranks of the barrier-bracketed time: RGB 320x240 + FOTS markers with / without the observation all-gather, and C4-shaped
+    (RGB + FEM-driven markers + the gelpad FEM step) with / without it.  `strong_scaling_base`: the same two jobs with all 4096 envs on ONE
+    GPU (rank 0 alone, no collective, the other ranks wait at the barrier) - what the driver's per-N values of THESE keys divide by."""
+    N = shard.world_size
+    B = NODE_ENVS // N
+    reduce_dev = "cpu" if dry else dev
+
+    def make(kind, b, world, gather, collective=None):
+        if dry:
+            return _DryRig(b, world, gather, collective)
+        import gc
+        gc.collect()
+        torch.cuda.synchronize()
+        torch.cuda.empty_cache()
+        if kind == "fem":
+            return Rig(b, 240, 320, 1, False, dev, world, seed=11 + shard.rank, gather="obs32" if gather else "none", obs_dtype=args.obs_dtype,
+                       fem=FemGelpad(b, dev, max_newton_iter=NEWTON_CAP, side_stream=True), collective=collective)
+        return Rig(b, 240, 320, 1, True, dev, world, seed=11 + shard.rank, gather="obs32" if gather else "none", obs_dtype=args.obs_dtype,
+                   collective=collective)
+
+    def rate(kind, b, world, gather, collective=None, sync=True):
+        rig = make(kind, b, world, gather, collective)
+        fem = kind == "fem" and not dry
+        steps, warm = (63, 24) if fem else (max(5, args.steps // 2), max(2, args.warmup // 2))  # FEM: three periods of the indenter's motion (see sweep())
+        el = rig.timed(steps, warm, barrier if sync else (lambda: None), windows=3 if fem else 1)
+        if fem:
+            assert rig.fem.iters_max is None or int(rig.fem.iters_max) < rig.fem.max_newton_iter, "an env ran into the Newton cap"
+        if use_dist and sync:
+            t = torch.tensor([el], device=reduce_dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
+        del rig
+        return round(b * world * steps / el, 1), round(el / steps * 1e3, 4)
+
+    out = {"envs_total": B * N, "envs_per_gpu": B, "resolution": [320, 240], "sensors_per_env": 1}
+    for kind, key in (("rgb", "node4096"), ("fem", "node4096_fem")):
+        log(f"node leg: {key}: {B} envs per GPU x {N} GPUs")
+        out[f"value_{key}"], out[f"ms_per_step_{key}"] = rate(kind, B, N, True)
+        out[f"value_{key}_no_gather"], out[f"ms_per_step_{key}_no_gather"] = rate(kind, B, N, False)
+    base = {}
+    if N == 1:
+        base = {"node4096": out["value_node4096"], "node4096_fem": out["value_node4096_fem"]}
+    else:
+        if shard.rank == 0:  # all 4096 envs on one GPU, no collective; the other ranks wait
+            for kind, key in (("rgb", "node4096"), ("fem", "node4096_fem")):
+                log(f"node leg: strong-scaling base {key}: {B * N} envs on rank 0 alone")
+                base[key] = rate(kind, B * N, 1, True, collective=False, sync=False)[0]
+        barrier()
+    out["strong_scaling_base"] = base
+    out["note"] = ("value_node4096*: 4096 envs x 1 GelSight Mini over the whole node (4096 / N per GPU), RGB 320x240 + FOTS markers; *_fem: RGB + FEM-driven "
+                   "markers + gelpad FEM step (C4); each with and without the one observation all-gather per step; strong_scaling_base = the same jobs "
+                   "with all 4096 envs on one GPU")
+    return out
+
 
 
 def headline_dict(args, value, elapsed, markers, arch, obs_bytes, sensor_streams_on=False, use_dist=False, grouped=False):
@@ -1033,6 +1131,15 @@ def main(argv=None):
     del rig
     torch.cuda.empty_cache()
 
+    node = None
+    if not args.no_node_leg:
+        try:
+            node = node4096_leg(args, shard, dev, use_dist, barrier)
+        except Exception as ex:
+            if use_dist:
+                raise  # (a rank that fails alone would leave the others in a collective)
+            node = {"error": f"{type(ex).__name__}: {ex}"[:300]}
+
     sw = None
     if args.gpus == 1 and not args.no_sweep and shard.rank == 0 and not use_dist:
         sw = sweep(args, dev)
@@ -1048,6 +1155,8 @@ def main(argv=None):
         full = headline_dict(args, value, elapsed, markers, _lib.require_gpu(shard.local_rank), obs_bytes, sensor_streams_on, use_dist, grouped)
         if multi is not None:
             full["multi_gpu"] = multi
+        if node is not None:
+            full["node4096"] = node
         if sw is not None:
             full["config"]["sweep"] = sw
         if roofline is not None:

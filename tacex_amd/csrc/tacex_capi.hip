@@ -81,7 +81,7 @@ struct tacex_taxim_ctx {
   } depth_pass;
   // second stream of the band levels (pipeline_impl: odd chunks of a pass run beside the even ones), created on first use
   static constexpr int kMaxLvlStreams = 4;
-  hipStream_t lvl_stream[kMaxLvlStreams - 1] = {}; hipEvent_t lvl_fork = nullptr, lvl_join[kMaxLvlStreams - 1] = {}, order_evt = nullptr;
+  hipStream_t lvl_stream[kMaxLvlStreams - 1] = {}; hipStream_t lvl_caller = nullptr; hipEvent_t lvl_fork = nullptr, lvl_join[kMaxLvlStreams - 1] = {}, order_evt = nullptr;
   std::vector<void*> allocs;
   // profiling
   bool profiling = false;
@@ -623,16 +623,34 @@ static int pipeline_chunk(tacex_taxim_ctx* c, const float* hm, const float* pres
 // how many streams the process had created before it: HIP deals streams onto a handful of hardware queues round-robin, and a
 // context whose level stream lands on the queue of the caller's stream runs its "two chunks in flight" one after the other
 // (bench.py sweep, 640x480: 110 K frames/s as the 17th rig of a process against 128 K on its own; profiles/r05_experiments.md section 7).
-static hipError_t level_stream(int device, int q, hipStream_t* out) {
+// Round 6: the pool is keyed by (device, caller stream) - contexts driven on DIFFERENT caller streams (bench --sensor-streams, multi-threaded
+// hosts) get different side streams, so one context's fork wait does not serialise the other's chunks; all contexts on one caller stream
+// (every test, the bench default) still share lane 0, which is what made measurements independent of context creation order.
+static hipError_t level_stream(int device, hipStream_t caller, int q, hipStream_t* out) {
+  constexpr int kLanes = 4;
   static std::mutex mu;
-  static hipStream_t pool[64][tacex_taxim_ctx::kMaxLvlStreams - 1] = {};
+  static hipStream_t pool[64][kLanes][tacex_taxim_ctx::kMaxLvlStreams - 1] = {};
+  static hipStream_t owner[64][kLanes] = {};
+  static int n_owner[64] = {};
   if (device < 0 || device >= 64 || q < 0 || q >= tacex_taxim_ctx::kMaxLvlStreams - 1) return hipErrorInvalidValue;
   std::lock_guard<std::mutex> lock(mu);
-  if (!pool[device][q]) {
-    hipError_t e = hipStreamCreateWithFlags(&pool[device][q], hipStreamNonBlocking);
+  int lane = -1;
+  for (int l = 0; l < n_owner[device] && l < kLanes; ++l)
+    if (owner[device][l] == caller) { lane = l; break; }
+  if (lane < 0) {
+    lane = n_owner[device] % kLanes;  // (beyond kLanes distinct caller streams the lanes are shared round-robin)
+    if (n_owner[device] < kLanes) owner[device][lane] = caller;
+    ++n_owner[device];
+  }
+  if (!pool[device][lane][q]) {
+    int prev = -1;
+    (void)hipGetDevice(&prev);
+    if (prev != device) { if (hipError_t e = hipSetDevice(device); e != hipSuccess) return e; }
+    hipError_t e = hipStreamCreateWithFlags(&pool[device][lane][q], hipStreamNonBlocking);
+    if (prev >= 0 && prev != device) (void)hipSetDevice(prev);
     if (e != hipSuccess) return e;
   }
-  *out = pool[device][q];
+  *out = pool[device][lane][q];
   return hipSuccess;
 }
 
@@ -796,11 +814,12 @@ static int pipeline_chunk(tacex_taxim_ctx* c, const float* hm, const float* pres
     dual = blur_level_single_kernel(c->levels[l], l == 0, c->H, c->W);
   if (dual) {
     if (!c->lvl_fork) HIP_TRY(hipEventCreateWithFlags(&c->lvl_fork, hipEventDisableTiming), "hipEventCreate");
-    for (int q = 0; q < lvl_streams - 1; ++q)
-      if (!c->lvl_stream[q]) {
-        if (hipError_t es = level_stream(c->device, q, &c->lvl_stream[q]); es != hipSuccess) return fail_hip(es, "hipStreamCreate(band levels)");
-        HIP_TRY(hipEventCreateWithFlags(&c->lvl_join[q], hipEventDisableTiming), "hipEventCreate");
-      }
+    for (int q = 0; q < lvl_streams - 1; ++q) {
+      if (!c->lvl_stream[q] || c->lvl_caller != st)
+        if (hipError_t es = level_stream(c->device, st, q, &c->lvl_stream[q]); es != hipSuccess) return fail_hip(es, "hipStreamCreate(band levels)");
+      if (!c->lvl_join[q]) HIP_TRY(hipEventCreateWithFlags(&c->lvl_join[q], hipEventDisableTiming), "hipEventCreate");
+    }
+    c->lvl_caller = st;
     static const int env_lcf = getenv("TACEX_LEVEL_CHUNK_FRAMES") ? atoi(getenv("TACEX_LEVEL_CHUNK_FRAMES")) : -1;
     if (env_lcf < 0) lcf = (lcf + lvl_streams - 1) / lvl_streams;
   }

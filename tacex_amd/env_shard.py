@@ -69,10 +69,12 @@ class ObservationGather:
     (all_gather_into_tensor needs equal sizes; use num_envs_total % world_size == 0).
     dtypes: optional dict name -> torch.dtype for pieces that differ from `dtype` (e.g. a uint8 policy image next to
     float32 markers); the buffer is then a byte buffer with every piece aligned to 8 bytes, still ONE collective.
+    collective: None = a collective whenever world_size > 1 or a process group exists; False = never (a rank that works alone while
+    the other ranks of the group wait - bench.py's strong-scaling base - must not start a collective the others do not join).
     """
 
     def __init__(self, pieces: dict[str, tuple[int, ...]], num_local: int, world_size: int, device, dtype=torch.float32,
-                 dtypes: dict | None = None):
+                 dtypes: dict | None = None, collective: bool | None = None):
         self.pieces = {k: tuple(v) for k, v in pieces.items()}
         self.dtypes = {k: (dtypes or {}).get(k, dtype) for k in self.pieces}
         self.bytes_mode = len(set(self.dtypes.values())) > 1
@@ -96,7 +98,10 @@ class ObservationGather:
         self.num_local, self.world = num_local, world_size
         self.local = torch.zeros((num_local, self.row), device=device, dtype=buf_dtype)
         # one rank, no process group: the "gathered" buffer IS the send buffer (no copy); otherwise the collective fills it
-        self._alias = world_size == 1 and not (dist.is_available() and dist.is_initialized())
+        self._collective = (world_size > 1 or (dist.is_available() and dist.is_initialized())) if collective is None else bool(collective)
+        if not self._collective and world_size != 1:
+            raise ValueError("collective=False needs world_size == 1")
+        self._alias = world_size == 1 and not self._collective
         self.full = self.local if self._alias else torch.zeros((world_size * num_local, self.row), device=device, dtype=buf_dtype)
         self._pads = {w: torch.zeros((num_local, w), device=device, dtype=buf_dtype) for k, w in self._cat if k is None}
 
@@ -129,7 +134,7 @@ class ObservationGather:
         packing kernel, so it overlaps the next step's rendering.  `wait()` (called by `pack*` and `views`) orders the
         compute stream behind it before the send buffer is refilled or the result is read."""
         self.wait()
-        if self.world > 1 or (dist.is_available() and dist.is_initialized()):
+        if self._collective:
             self._work = dist.all_gather_into_tensor(self.full, self.local, async_op=True)
         elif not self._alias:
             self.full.copy_(self.local)

@@ -16,8 +16,21 @@ import torch
 
 from . import _lib
 from .gelsight_sensor_data import GelSightSensorData
-from .sensor_base import SensorBase
+from .sensor_base import SensorBase as _LocalSensorBase
 from .simulation_approaches.gelsight_simulator import GelSightSimulator
+
+# Under a real IsaacLab the sensor derives from `isaaclab.sensors.SensorBase` like the reference's (gelsight_sensor.py:31): the scene then
+# drives it through IsaacLab's own timeline / update / reset machinery.  Without IsaacLab (this repo's tests, the bench, any Isaac-free host)
+# the restatement in sensor_base.py stands in.  TACEX_SENSOR_BASE=local forces the restatement (untested against IsaacLab here: it is not
+# installable in the build container - INTEGRATION.md section 2).
+SensorBase = _LocalSensorBase
+if os.environ.get("TACEX_SENSOR_BASE", "auto") != "local":
+    try:
+        from isaaclab.sensors import SensorBase as _IsaacSensorBase  # type: ignore
+
+        SensorBase = _IsaacSensorBase
+    except Exception:  # ImportError, or Kit not running
+        pass
 
 _DEFER_DEPTH = os.environ.get("TACEX_DEFER_DEPTH", "1") != "0"  # A/B switch of _can_defer_depth_pass
 
@@ -126,10 +139,10 @@ class GelSightSensor(SensorBase):
             self._group.core.mark_height_map_dirty()
 
     def set_height_map_source(self, source):
-        if self._group is not None:
-            raise RuntimeError("a grouped sensor takes its height map from the camera depth or set_height_map (one source per group)")
         """Fill the height map from an on-device source (e.g. `IndenterHeightMapSource`) instead of a camera depth image
         (SURVEY 8f n1).  `source.fill(hm, frame_min, indent, gelpad_height, gelpad_to_camera_min_distance)`."""
+        if self._group is not None:
+            raise RuntimeError("a grouped sensor takes its height map from the camera depth or set_height_map (one source per group)")
         self._height_map_source = source
 
     def _read_camera_depth(self):
@@ -138,24 +151,34 @@ class GelSightSensor(SensorBase):
             self.set_camera_depth(src())
         return self._camera_depth_m
 
+    def initialize(self):
+        """Explicit initialisation (IsaacLab does it from its timeline-PLAY callback; both end in `_initialize_impl`)."""
+        if hasattr(super(), "initialize"):
+            return super().initialize()
+        if not self._is_initialized:
+            self._initialize_impl()
+            self._is_initialized = True
+
     # -- reset (gelsight_sensor.py:147-197) -----------------------------------------------------------------
     def reset(self, env_ids: Sequence[int] | None = None):
         if self._group is not None:
             return self._group._member_reset(self, env_ids)
         if not self._is_initialized:
+            # lazy initialisation brings the sensor's own buffers to their reset state; the reset the caller asked for (its `env_ids`, and
+            # the FEM pads of exactly those envs) then runs like any other
             self.initialize()
-            return
         self._reset_impl(env_ids)
 
-    def _reset_impl(self, env_ids):
+    def _reset_impl(self, env_ids, reset_gelpad: bool = True):
         super().reset(env_ids)
         # FEM gelpad (tacex_uipc): the pad of a reset env goes back to its rest shape with the sensor.  In the reference the scene resets
         # its assets one by one and `UipcObject.reset` is a TODO stub (uipc_object.py:280-286) - its UIPC scenes hold one env; here the
         # sensor owns the reference to the pad, so a task that resets `env_ids` of the sensor gets a consistent pad / image pair.
-        # `cfg.reset_gelpad_with_sensor = False` leaves the pad to the caller.
+        # `cfg.reset_gelpad_with_sensor = False` leaves the pad to the caller.  Only an explicit `reset()` touches the pad: initialising a
+        # sensor (`reset_gelpad=False`) must not wipe a pad that was placed with `write_vertex_positions_to_sim` or has already stepped.
         pad_sim = getattr(self.gelpad_obj, "_uipc_sim", None)
-        if pad_sim is not None and getattr(pad_sim, "_handle", None) is not None and getattr(self.cfg, "reset_gelpad_with_sensor", True) \
-                and self._is_initialized:
+        if reset_gelpad and pad_sim is not None and getattr(pad_sim, "_handle", None) is not None \
+                and getattr(self.cfg, "reset_gelpad_with_sensor", True):
             self.gelpad_obj.reset(env_ids)
         if env_ids is None:
             env_ids = self._ALL_INDICES
@@ -245,7 +268,7 @@ class GelSightSensor(SensorBase):
         if isinstance(buf, torch.Tensor) and buf.is_cuda and tuple(buf.shape) == (self._num_envs,):
             self._indentation_depth = buf
         self._is_initialized = True
-        self._reset_impl(None)
+        self._reset_impl(None, reset_gelpad=False)
 
     # -- per-step update (gelsight_sensor.py:342-378) ------------------------------------------------------------
     def _update_buffers_impl(self, env_ids: Sequence[int]):

@@ -172,7 +172,9 @@ class GelSightSensorGroup:
             ids = torch.as_tensor(env_ids, device=self.core._device, dtype=torch.long)
         self.core._reset_impl(ids + s._group_index * self.num_envs)
         s._frame[ids] = -s._frame_pending
-        self._served.discard(s._group_index)
+        # the core's outputs now hold the reset render of these envs: whichever member asks next must trigger a fresh evaluation (leaving
+        # the other members in `_served` would let the reset member "join" the evaluation that ran BEFORE its reset)
+        self._served.clear()
 
     def update(self, dt: float, force_recompute: bool = False):
         """Convenience: update every member (ONE evaluation)."""

@@ -115,6 +115,9 @@ class TaximSimulator(GelSightSimulator):
                 float(self.cfg.gelpad_to_camera_min_distance), _lib.ptr(hm), _lib.ptr(fmin), _lib.ptr(indent),
                 _lib.ptr(cam_u8) if cam_u8 is not None else 0, _lib.ptr(rows) if rows is not None else 0, B)
         _lib.check(rc, "tacex_taxim_defer_height_map_from_depth")
+        # the armed pass holds raw device pointers until the render launches it: keep every buffer it reads or fills alive until then
+        # (the depth may be a conversion copy the caller drops on return)
+        self._deferred_keepalive = (depth, hm, fmin, indent, cam_u8, rows)
 
     # -- plugin interface -------------------------------------------------------------------------------
     def optical_simulation(self):
@@ -138,6 +141,7 @@ class TaximSimulator(GelSightSimulator):
             mask_out=self._contact_mask if full else None,
             obs_out=self.policy_obs,
         )
+        self._deferred_keepalive = None  # the deferred depth pass (if any) has been enqueued; stream order protects its buffers from here on
         if self._keep_deformation:
             self._deformation_version = self.sensor._height_map_version if full else -1
             self._fots_compact_version = self.sensor._height_map_version if compact else -1

@@ -87,14 +87,16 @@ class UipcSimCfg:
         constitution: str = "ipc"
         d_hat: float = 0.001
         eps_velocity: float = 0.01
-        friction_lag: str = "capped"
-        """Where the friction lag (normal force, normal; frozen per time step) comes from (`tacex_fem_set_friction_lag`): "ipc" = the previous
-        configuration, Li et al. 2020 section 5.4 to the letter - the step's end state is then a stationary point of IPC's plain
-        incremental potential (tests/test_fem_physics_gpu.py); "capped" (default) = start positions against the indenter's NEW position,
-        the force capped by the contact reaction there.  The two agree where the previous step converged tightly and the indenter
-        approaches; "capped" takes the smaller, already relaxed force when it retreats - and stays bounded at the reference's default
-        Newton tolerance (0.5 mm per step), where the previous configuration is far from balance: simple_axle at the defaults ran 302 K env
-        steps/s with "capped" and 8.5 K with "ipc" (profiles/r05_experiments.md).  Not in the reference cfg (libuipc's rule is not in the reference)."""
+        friction_lag: str = "ipc"
+        """Where the friction lag (normal force, normal; frozen per time step) comes from (`tacex_fem_set_friction_lag`).  "ipc" (default
+        since round 6) = the previous configuration, Li et al. 2020 section 5.4 to the letter: the step's end state is a stationary point
+        of IPC's plain incremental potential (tests/test_fem_physics_gpu.py), and on the gelpad scenes `north_star` names it is also the
+        faster rule (C4: 408.9 K against 384.5 K frames/s, BENCH_r05).  "capped" (opt-in) = start positions against the indenter's NEW
+        position, the force capped by the contact reaction there: agrees with "ipc" where the previous step converged tightly and the
+        indenter approaches, takes the smaller, already relaxed force when it retreats (end state up to ~150 um off IPC's on such steps),
+        and stays bounded at the reference's default Newton tolerance on SLENDER bodies, where the previous configuration is far from
+        balance (simple_axle at the defaults: 302 K env steps/s against 8.5 K with "ipc", profiles/r05_experiments.md) - the setting for
+        those.  Not in the reference cfg (libuipc's rule is not in the reference)."""
         follow_indenter: bool = True
         """Contact-following start of a step's Newton loop (`tacex_fem_set_contact_following`): vertices inside the barrier zone start
         the iteration displaced with their indenter.  An initial guess only (same minimiser); not in the reference cfg - libuipc starts
@@ -203,7 +205,7 @@ class UipcSim:
                                                     float(c.eps_velocity)), "tacex_fem_set_friction")
         _lib.check(self._lib.tacex_fem_set_contact_following(self._handle, 1 if getattr(c, "follow_indenter", True) else 0),
                    "tacex_fem_set_contact_following")
-        lag = getattr(c, "friction_lag", "capped")
+        lag = getattr(c, "friction_lag", "ipc")
         if lag not in ("ipc", "capped"):
             raise ValueError(f"UipcSimCfg.contact.friction_lag must be 'ipc' or 'capped', got {lag!r}")
         _lib.check(self._lib.tacex_fem_set_friction_lag(self._handle, 1 if lag == "ipc" else 0), "tacex_fem_set_friction_lag")

@@ -46,6 +46,8 @@ def _synthetic_full(bench):
     full["cpu_baseline"] = {"value": 206.3, "unit": "frames/s", "cores": 16, "logical_cores": 256, "physical_cores": 128, "kind": "port", "sample": long,
                             "runs": [{"note": long}] * 4, "thread_sweep_B16": [{"threads": t, "frames_per_s": 1.0} for t in (8, 16, 32, 64, 128)],
                             "protocol_all_cores": {"note": long}}
+    full["node4096"] = {"envs_total": 4096, "envs_per_gpu": 512, "value_node4096": 5.1e6, "value_node4096_no_gather": 5.2e6, "value_node4096_fem": 3.0e6,
+                        "value_node4096_fem_no_gather": 3.1e6, "strong_scaling_base": {"node4096": 7.0e5, "node4096_fem": 3.9e5}, "note": long}
     full["multi_gpu"] = {"backend": "nccl", "world_size": 8, "rank_devices": [f"AMD Instinct MI355X|{i}" for i in range(8)],
                          "per_rank_ms_per_step": [3.1] * 8, "value_no_gather": 1.0, "ms_per_step_no_gather": 1.0, "launcher": "self"}
     return full
@@ -69,6 +71,9 @@ def test_stdout_line_is_compact_whatever_the_sweep_holds(tmp_path):
         assert d[k] == 612345.6, k
     assert d["value_c5"] is None and d["sweep_errors"] == ["c5"]  # (the failed entry is last in the list: it wins the scalar)
     assert d["multi_gpu"]["distinct_devices"] == 8
+    # the 4096-env whole-node point is on the line; the cherry-picked axle phase is not
+    assert d["value_node4096"] == 5.1e6 and d["value_node4096_fem_no_gather"] == 3.1e6 and d["strong_scaling_base"] == {"node4096": 7.0e5, "node4096_fem": 3.9e5}
+    assert "value_axle_env_steps" not in d
     # nothing is lost: the side file holds the full record
     det = json.loads((tmp_path / "details.json").read_text())
     assert len(det["config"]["sweep"]) == len(full["config"]["sweep"]) and "stages" in det["roofline"] and "sweep_notes" in det

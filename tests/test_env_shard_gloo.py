@@ -80,6 +80,13 @@ def test_bench_gpus_2_starts_its_own_ranks_and_prints_one_compact_line(tmp_path)
     assert abs(d["value"] - d["config"]["frames_per_step"] / (d["ms_per_step"] * 1e-3)) <= 2e-2 * d["value"]
     assert d["config"]["frames_per_step"] == 2 * 1024 * 2
     assert json.loads(det.read_text())["multi_gpu"]["rank_devices"] == ["cpu-0", "cpu-1"]
+    # the north-star point (4096 envs over the whole node, 2048 per rank here) rides on the same line: with / without the gather, C4-shaped
+    # with / without it, and the one-GPU base of the two jobs (rank 0 alone, no collective, the other rank waits at the barrier)
+    for k in ("value_node4096", "value_node4096_no_gather", "value_node4096_fem", "value_node4096_fem_no_gather"):
+        assert d[k] > 0, k
+    assert set(d["strong_scaling_base"]) == {"node4096", "node4096_fem"} and all(v > 0 for v in d["strong_scaling_base"].values())
+    nd = json.loads(det.read_text())["node4096"]
+    assert nd["envs_total"] == 4096 and nd["envs_per_gpu"] == 2048
 
 
 def test_bench_under_torchrun_contract_env(tmp_path):

@@ -441,6 +441,11 @@ def test_contact_newton_step_vs_oracle_and_no_penetration():
 
 
 # ---- BASELINE config 4 size: the 8 x 10 x 4 gelpad (495 vertices / 1 920 tets) the LDS window / CSR cursor logic is sized for --------
+def _lag(sim):
+    """The oracle's name for the friction lag the sim's cfg selects ("ipc" = the default since round 6; "capped" = the oracle's "start")."""
+    return {"ipc": "ipc", "capped": "start"}[sim.cfg.contact.friction_lag]
+
+
 def _chains(sim):
     """(next, heads) of the chains the library was given, for the oracle."""
     from oracle.fem_oracle import chain_tables
@@ -536,7 +541,7 @@ def test_step_c4_vs_oracle_step_and_convergence_rule():
         for b in range(B):
             xo[b], vo[b], io = fem_step(m, cms[b], xo[b], vo[b], cons, aim[b], gravity=sim.cfg.gravity, max_newton=24,
                                         velocity_tol=2e-3, pcg_max_iter=600, pcg_tol_rate=1e-12, coarse=sim.coarse_space, chains=_chains(sim),
-                                        friction=(fric[0], fric[1], disp[b]))
+                                        friction=(fric[0], fric[1], disp[b]), friction_lag=_lag(sim))
             # same iteration count (a convergence test that falls within round-off of its threshold may differ by one iteration);
             # both stop inside the Newton tolerance of 20 um and their PCG round-off differs by ~0.1 um
             assert abs(int(info["newton_iters"][b]) - int(io[0])) <= 1, (k, b, info["newton_iters"], io)
@@ -676,7 +681,7 @@ def test_friction_drags_the_pad_surface():
             assert len(info["penetrating_envs"]) == 0 and len(info["line_search_failed_envs"]) == 0 and int(sim.last_newton_iters) < 60
             if mu > 0:
                 xo, vo, io = fem_step(m, cms[0], xo, vo, cons, aim[0], gravity=sim.cfg.gravity, max_newton=60, velocity_tol=1e-3, pcg_max_iter=600,
-                                      pcg_tol_rate=1e-12, coarse=sim.coarse_space, chains=_chains(sim), friction=(mu, sim.cfg.contact.eps_velocity, disp))
+                                      pcg_tol_rate=1e-12, coarse=sim.coarse_space, chains=_chains(sim), friction=(mu, sim.cfg.contact.eps_velocity, disp), friction_lag=_lag(sim))
                 assert io[0] < 60 and int(io[2]) & 3 == 0
                 assert np.abs(sim.x[0].cpu().numpy() - xo).max() <= 2 * 1e-3 * sim.cfg.dt, k  # both inside the Newton tolerance of the same state
         x = sim.x[0].cpu().numpy()
@@ -919,6 +924,7 @@ def _axle_scene(B, deterministic=False, block_jacobi=False, velocity_tol=2e-3):
     cfg.linear_system.deterministic = deterministic
     cfg.linear_system.max_iter, cfg.linear_system.tol_rate = 3000, 1e-10
     cfg.newton.velocity_tol = velocity_tol
+    cfg.contact.friction_lag = "capped"  # the documented setting for slender bodies (UipcSimCfg.Contact.friction_lag); the gelpad scenes run the default, "ipc"
     sim = UipcSim(cfg, num_envs=B)
     gel = UipcObject(UipcObjectCfg(mesh_points=P, mesh_tets=T), sim)
     sim.setup_sim(constraint_strength_ratio=1000.0)
@@ -979,7 +985,7 @@ def test_wide_newton_kernel_steps_simple_axle_with_contact_and_friction():
             cms[b].ind[1:4] = cur[b]
             xo[b], vo[b], io = fem_step(m, cms[b], xo[b], vo[b], cons, aim[b], gravity=sim.cfg.gravity, max_newton=60, velocity_tol=vtol,
                                         pcg_max_iter=3000, pcg_tol_rate=1e-10, coarse=sim.coarse_space, chains=_chains(sim),
-                                        friction=(mu, sim.cfg.contact.eps_velocity, disp[b]))
+                                        friction=(mu, sim.cfg.contact.eps_velocity, disp[b]), friction_lag=_lag(sim))
             assert io[0] < 60 and int(io[2]) & 3 == 0, (k, b, io)
             assert np.abs(x[b] - xo[b]).max() <= 2 * vtol * sim.cfg.dt, (k, b, np.abs(x[b] - xo[b]).max(), io, info)  # both inside the Newton tolerance
     assert (P[:, 2] - sim.x[0].cpu().numpy()[:, 2]).max() > 5e-5  # the axle is dented / bent by the sphere
@@ -1034,7 +1040,7 @@ def test_streaming_newton_kernel_steps_simple_axle_with_sphere_contact():
                 xo[b], vo[b], io = fem_step(m, cms[b], xo[b], vo[b], cons, aim[b], gravity=sim.cfg.gravity, max_newton=30, velocity_tol=vtol,
                                             pcg_max_iter=3000, pcg_tol_rate=1e-10, coarse=None, chains=None, lag_prec=False,
                                             friction=(mu, sim.cfg.contact.eps_velocity, disp[b]) if with_friction else None,
-                                            indenter_disp=np.zeros(3))  # (no contact-following start in the streaming kernel)
+                                            indenter_disp=np.zeros(3), friction_lag=_lag(sim))  # (no contact-following start in the streaming kernel)
                 assert io[0] < 30 and int(io[2]) & 3 == 0, (with_friction, k, b, io)
                 assert np.abs(x[b] - xo[b]).max() <= 2 * vtol * sim.cfg.dt, (with_friction, k, b, np.abs(x[b] - xo[b]).max(), io)  # both inside the Newton tolerance
         assert (P[:, 2] - sim.x[0].cpu().numpy()[:, 2]).max() > 5e-5  # the axle is dented / bent by the sphere

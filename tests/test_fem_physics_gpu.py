@@ -70,8 +70,8 @@ def test_step_end_state_is_a_stationary_point_of_the_plain_incremental_potential
       (a) friction_lag = "ipc", solved tightly (velocity_tol 1e-8, PCG tol_rate 1e-12): the infinity norm of the plain incremental-potential
           gradient at the end state is below 1e-6 of the largest contact force on a vertex - whatever route edge snap / following start /
           PSD-safe clamp / coarse-trust took;
-      (b) the DEFAULT configuration (reaction-capped lag, velocity_tol 0.05, tol_rate 1e-3: uipc_sim.py:57-90) stops within
-          velocity_tol * dt of its own tight solve;
+      (b) the DEFAULT configuration (IPC's lag since round 6, velocity_tol 0.05, tol_rate 1e-3: uipc_sim.py:57-90) stops within
+          velocity_tol * dt of (a)'s tight solve - the default rule IS the stationary one;
       (c) the capped lag against IPC's, both tight: the same state (<= 0.5 um) where the indenter does not retreat, and a bounded difference
           (<= 250 um = half a default Newton tolerance) where it does - there the capped rule lags the smaller, already relaxed normal
           force and the surface slips further; the plain-potential gradient of THAT state is orders of magnitude above (a)'s bound.
@@ -82,7 +82,9 @@ def test_step_end_state_is_a_stationary_point_of_the_plain_incremental_potential
     ipc = _scene(B, d_hat=d_hat, velocity_tol=TIGHT_VTOL, tol_rate=1e-12, friction_lag="ipc")
     cap = _scene(B, d_hat=d_hat, velocity_tol=TIGHT_VTOL, tol_rate=1e-12, friction_lag="capped")
     dflt = _scene(B, d_hat=d_hat)
-    assert dflt.sim.cfg.contact.friction_lag == "capped" and dflt.sim.cfg.newton.velocity_tol == 0.05 and dflt.sim.cfg.linear_system.tol_rate == 1e-3
+    from tacex_amd.uipc.uipc_sim import UipcSimCfg
+    assert UipcSimCfg().contact.friction_lag == "ipc"  # the faithful rule is the default
+    assert dflt.sim.cfg.contact.friction_lag == "ipc" and dflt.sim.cfg.newton.velocity_tol == 0.05 and dflt.sim.cfg.linear_system.tol_rate == 1e-3
     sim = ipc.sim
     obj = ipc.gelpad
     c = obj.cfg.constitution_cfg
@@ -133,7 +135,7 @@ def test_step_end_state_is_a_stationary_point_of_the_plain_incremental_potential
                           f"newton ipc {int(sim.step_info[b, 0])} capped {int(cap.sim.step_info[b, 0])}")
                 key = "retreating" if dz > 0 else "pressing"
                 worst_cap[key] = max(worst_cap[key], dc)
-        gap = np.abs(x_dflt - x_cap).max()                                                # (b)
+        gap = np.abs(x_dflt - x_end).max()                                                # (b)
         worst_dflt = max(worst_dflt, gap)
         assert REPORT or gap <= dflt.sim.cfg.newton.velocity_tol * dflt.sim.cfg.dt, (i, gap)
         ind_prev = ind_now
@@ -246,6 +248,27 @@ def test_sensor_reset_puts_the_gelpad_of_those_envs_back():
     x_before = fem.sim.x.clone()
     s.reset([3])
     assert torch.equal(fem.sim.x, x_before)
+
+
+def test_initialising_a_sensor_leaves_a_stepped_gelpad_alone():
+    """`initialize()` runs the sensor's own reset (GS:147-197) but must not put the pad back to rest - a pad that has already
+    stepped (or was placed with write_vertex_positions_to_sim) keeps its state, also on the lazy path `reset(env_ids)` of a sensor that
+    was never initialised: only the listed envs' pads go back."""
+    from bench import build_sensor
+
+    fem = _scene(4)
+    for i in range(4):
+        fem.step(i)
+    rest = torch.from_numpy(fem.gelpad.points).cuda()
+    x_before = fem.sim.x.clone()
+    assert float((x_before - rest).abs().max()) > 1e-5
+    s = build_sensor(4, 240, 320, False, "cuda:0", fem_gelpad=fem.gelpad)
+    s.initialize()
+    assert torch.equal(fem.sim.x, x_before)
+    s2 = build_sensor(4, 240, 320, False, "cuda:0", fem_gelpad=fem.gelpad)
+    s2.reset([1])  # lazy initialisation + reset of env 1 only
+    assert torch.equal(fem.sim.x[1], rest)
+    assert torch.equal(fem.sim.x[[0, 2, 3]], x_before[[0, 2, 3]])
 
 
 def test_host_readers_wait_for_a_side_stream_step():
