@@ -1,0 +1,419 @@
+"""CPU oracle for the reference's own UIPC scene (TEST INFRASTRUCTURE - never imported by the product path): a FREE affine-body ball
+lying on a ground plane under the gelpad, in IPC contact with it through vertex-triangle pairs in both directions.
+
+PARITY UNPINNED, like oracle/fem_oracle.py and for the same reason: the arithmetic lives in libuipc (un-vendored submodule,
+`.gitmodules:1-4`).  What the reference shows of this scene are its call sites:
+
+  * scripts/benchmarking/tactile_sim_performance/envs/ball_rolling_uipc.py:71-92 - `UipcSimCfg(ground_height=0.001,
+    contact=Contact(d_hat=0.0005))`, the ball as `UipcObjectCfg(constitution_cfg=AffineBodyConstitutionCfg())` at z = 0.01;
+  * source/tacex_uipc/tacex_uipc/objects/uipc_object.py:62-74, 456-466 - `AffineBodyConstitution().apply_to(mesh, m_kappa * MPa,
+    mass_density)`, m_kappa = 100 MPa, density 1e3, `kinematic=False`: the body's 12 degrees of freedom are free;
+  * source/tacex_uipc/tacex_uipc/sim/uipc_sim.py:192-201 - `ground(ground_height, ground_normal)` and ONE default contact model
+    (friction rate, resistance in GPa) for every pair of surfaces.
+
+The model follows the PUBLISHED sources libuipc implements:
+
+  * Lan, Kaufman, Li, Jiang, Yang 2022, "Affine Body Dynamics": a body is x(X) = A X + p with q = (p, A) in R^12, kinetic term
+    1/2 (q - q~)^T M (q - q~) with the 12 x 12 mass matrix M = int rho J^T J dV, J = d x / d q, and the orthogonality energy
+    kappa * vol * |A A^T - I|_F^2 (eq. 7 there).  Here q is held as FOUR 3-vectors (p, c_1, c_2, c_3), c_k = column k of A, so
+    x = p + sum_k X_k c_k, J is block-scalar and M = S (x) I_3 with the 4 x 4 moment matrix S = int rho (1, X)(1, X)^T dV taken over the
+    closed surface mesh (signed tetrahedra against the origin) - the layout the kernel uses: the body is four more "vertices" of the env.
+  * Li et al. 2020 (IPC): barrier kappa * w * b(d / d_hat), b(s) = -(s - 1)^2 ln s, on every point-triangle pair closer than d_hat:
+    pad surface vertex against ball triangle (weight = the pad vertex's surface area) AND ball vertex against pad surface triangle
+    (weight = the ball vertex's area); the ground half-space against the surface vertices of both bodies.  Point-triangle distance by
+    region (Ericson 5.1.5); in every region grad_p d = n and grad_{corner j} d = -beta_j n with beta the barycentric coordinates of the
+    closest point.  Hessian: the Gauss-Newton part b'' grad d grad d^T (b' hess d is dropped: the PSD projection the analytic contact of
+    fem_oracle.py uses) and, for the orthogonality energy, 4 kappa vol [delta_mn A A^T + c_n c_m^T] (the term r_mn I of the exact
+    Hessian, r = A^T A - I, is dropped: it vanishes on rotations and is what makes the exact Hessian indefinite under compression).
+    Gradients are exact, so Newton converges to stationary points of the plain potential (tests/test_abd_oracle.py checks them by
+    finite differences).  No friction and no edge-edge pairs between the two bodies in this slice.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from .fem_oracle import LS_RESCUE, FemModel, barrier, pcg_solve
+
+
+def icosphere(radius: float, level: int = 2):
+    """(vertices (nv,3), triangles (nt,3), outward oriented): 12 / 42 / 162 / 642 vertices at level 0 / 1 / 2 / 3."""
+    t = (1.0 + 5.0**0.5) / 2.0
+    v = [(-1, t, 0), (1, t, 0), (-1, -t, 0), (1, -t, 0), (0, -1, t), (0, 1, t), (0, -1, -t), (0, 1, -t), (t, 0, -1), (t, 0, 1), (-t, 0, -1), (-t, 0, 1)]
+    f = [(0, 11, 5), (0, 5, 1), (0, 1, 7), (0, 7, 10), (0, 10, 11), (1, 5, 9), (5, 11, 4), (11, 10, 2), (10, 7, 6), (7, 1, 8),
+         (3, 9, 4), (3, 4, 2), (3, 2, 6), (3, 6, 8), (3, 8, 9), (4, 9, 5), (2, 4, 11), (6, 2, 10), (8, 6, 7), (9, 8, 1)]
+    v = [np.asarray(p, np.float64) / np.linalg.norm(p) for p in v]
+    for _ in range(level):
+        mid, nf = {}, []
+
+        def m(a, b):
+            key = (min(a, b), max(a, b))
+            if key not in mid:
+                p = v[a] + v[b]
+                v.append(p / np.linalg.norm(p))
+                mid[key] = len(v) - 1
+            return mid[key]
+
+        for a, b, c in f:
+            ab, bc, ca = m(a, b), m(b, c), m(c, a)
+            nf += [(a, ab, ca), (b, bc, ab), (c, ca, bc), (ab, bc, ca)]
+        f = nf
+    return np.asarray(v) * radius, np.asarray(f, np.int32)
+
+
+def point_triangle(p, a, b, c):
+    """Closest points of triangles (a, b, c: (Nt,3)) to points p (Np,3): barycentric coordinates (Np,Nt,3) of the closest point by
+    Ericson's regions in the book's order (the kernel's order), distance (Np,Nt) and unit vector n (Np,Nt,3) from closest point to p."""
+    p = np.asarray(p, np.float64)[:, None, :]
+    A, B, C = a[None], b[None], c[None]
+    ab, ac = B - A, C - A
+    ap = p - A
+    d1, d2 = (ab * ap).sum(-1), (ac * ap).sum(-1)
+    bp = p - B
+    d3, d4 = (ab * bp).sum(-1), (ac * bp).sum(-1)
+    cp = p - C
+    d5, d6 = (ab * cp).sum(-1), (ac * cp).sum(-1)
+    vc, vb, va = d1 * d4 - d3 * d2, d5 * d2 - d1 * d6, d3 * d6 - d5 * d4
+    with np.errstate(divide="ignore", invalid="ignore"):
+        t_ab, t_ac = d1 / (d1 - d3), d2 / (d2 - d6)
+        t_bc = (d4 - d3) / ((d4 - d3) + (d5 - d6))
+        den = 1.0 / (va + vb + vc)
+    s, u = vb * den, vc * den  # face region
+    z, o = np.zeros_like(d1), np.ones_like(d1)
+    regions = [((d1 <= 0) & (d2 <= 0), z, z), ((d3 >= 0) & (d4 <= d3), o, z), ((vc <= 0) & (d1 >= 0) & (d3 <= 0), t_ab, z),
+               ((d6 >= 0) & (d5 <= d6), z, o), ((vb <= 0) & (d2 >= 0) & (d6 <= 0), z, t_ac),
+               ((va <= 0) & ((d4 - d3) >= 0) & ((d5 - d6) >= 0), 1.0 - t_bc, t_bc)]
+    for cond, sr, ur in reversed(regions):  # first matching region wins
+        s, u = np.where(cond, sr, s), np.where(cond, ur, u)
+    beta = np.stack([1.0 - s - u, s, u], -1)
+    q = A + s[..., None] * ab + u[..., None] * ac
+    r = p - q
+    d = np.linalg.norm(r, axis=-1)
+    return beta, d, r / np.maximum(d, 1e-300)[..., None]
+
+
+def accd_point_triangle(p, tri, dp, dtri, t_max=1.0, slack=0.9, keep=0.1, max_iter=64):
+    """Additive CCD of ONE point-triangle pair (Li et al. 2021, "Codimensional IPC", Algorithm 1; no thickness): the largest t <= t_max
+    up to which the pair moving along (dp, dtri) provably keeps a gap >= keep * d(0).  p (3,), tri (3,3), dp (3,), dtri (3,3)."""
+    mean = (dp + dtri.sum(0)) / 4.0
+    dp, dtri = dp - mean, dtri - mean
+    l = np.linalg.norm(dp) + np.linalg.norm(dtri, axis=1).max()
+    if not l > 0.0:
+        return t_max
+    dist = lambda t: float(point_triangle((p + t * dp)[None], *((tri[k] + t * dtri[k])[None] for k in range(3)))[1][0, 0])
+    d0 = dist(0.0)
+    g = keep * d0
+    t, tl = 0.0, (1.0 - keep) * d0 / l
+    for _ in range(max_iter):
+        d = dist(t + tl)
+        if t > 0.0 and d < g:
+            break
+        t += tl
+        if t >= t_max:
+            return t_max
+        tl = slack * d / l
+    return t
+
+
+class AffineBody:
+    """One affine body on its closed surface mesh (body frame: the mesh's own coordinates)."""
+
+    def __init__(self, verts, tris, density=1e3, kappa=100e6):
+        self.X = np.asarray(verts, np.float64)
+        self.tris = np.asarray(tris, np.int64)
+        a, b, c = (self.X[self.tris[:, k]] for k in range(3))
+        det = np.einsum("ij,ij->i", a, np.cross(b, c))
+        assert det.sum() > 0, "surface triangles must be oriented outward"
+        vol = det / 6.0
+        self.vol = float(vol.sum())
+        S = np.zeros((4, 4))
+        S[0, 0] = self.vol
+        S[0, 1:] = S[1:, 0] = (vol[:, None] * (a + b + c) / 4.0).sum(0)
+        sm = a + b + c
+        S[1:, 1:] = (vol[:, None, None] / 20.0 * (a[:, :, None] * a[:, None] + b[:, :, None] * b[:, None] + c[:, :, None] * c[:, None]
+                                                   + sm[:, :, None] * sm[:, None])).sum(0)
+        self.S = density * S          # 4 x 4 moment matrix: M = S (x) I_3
+        self.kv = kappa * self.vol    # orthogonality stiffness kappa * vol [J]
+        ta = 0.5 * np.linalg.norm(np.cross(b - a, c - a), axis=1)
+        self.area = np.zeros(len(self.X))
+        np.add.at(self.area, self.tris.reshape(-1), np.repeat(ta / 3.0, 3))
+        self.Y = np.concatenate([np.ones((len(self.X), 1)), self.X], 1)  # (nv,4): x = Y q
+
+    @staticmethod
+    def rest_q(centre):
+        return np.concatenate([np.asarray(centre, np.float64)[None], np.eye(3)], 0)
+
+    def points(self, q):
+        return self.Y @ q  # (nv,3)
+
+    def to_q(self, f):
+        """Forces on the surface vertices (nv,3) -> generalised force (4,3)."""
+        return self.Y.T @ f
+
+    def ortho(self, q):
+        """kappa vol |A^T A - I|^2, its gradient (4,3) and r = A^T A - I."""
+        c = q[1:]
+        r = c @ c.T - np.eye(3)
+        g = np.zeros((4, 3))
+        g[1:] = 4.0 * self.kv * (r @ c)
+        return self.kv * (r * r).sum(), g
+
+    def ortho_hess_vec(self, q, pq):
+        """Gauss-Newton part 4 kappa vol [delta_mn A A^T + c_n c_m^T] applied to pq (4,3)."""
+        c, pc = q[1:], pq[1:]
+        out = np.zeros((4, 3))
+        out[1:] = 4.0 * self.kv * (pc @ (c.T @ c) + (c @ pc.T) @ c)  # row m: A A^T p_m + sum_n c_n (c_m . p_n)
+        return out
+
+    def ortho_diag_blocks(self, q):
+        c = q[1:]
+        AAt = c.T @ c
+        D = np.zeros((4, 3, 3))
+        for m in range(3):
+            D[1 + m] = 4.0 * self.kv * (AAt + np.outer(c[m], c[m]))
+        return D
+
+
+class BallScene:
+    """Gelpad (FemModel) + free affine-body ball + ground half-space z >= ground_height + IPC pairs between pad and ball.
+
+    State of one env: y (V + 4, 3) = pad vertices, then the ball's (p, c_1, c_2, c_3).  All energies are those of ONE backward-Euler
+    step (already scaled by dt^2 where they are potentials)."""
+
+    def __init__(self, pad: FemModel, pad_tris, pad_area, ball: AffineBody, dhat=5e-4, kappa=None, ground_height=0.001, resistance=10.0):
+        self.pad, self.ball = pad, ball
+        self.pad_tris = np.asarray(pad_tris, np.int64)
+        self.pad_area = np.asarray(pad_area, np.float64)
+        self.dhat = float(dhat)
+        self.kappa = resistance * 1e9 * dhat if kappa is None else float(kappa)  # as UipcSim: resistance [GPa] * d_hat [J/m^2]
+        self.gh = float(ground_height)
+        self.dt = pad.dt
+        self.V = len(pad.X)
+        self.pad_sv = np.where(self.pad_area > 0)[0]
+
+    # ---- contact terms -----------------------------------------------------------------------------------------------------------
+    def _ground(self, x, w):
+        """Ground barrier of points x (N,3) with weights w: energy, forces (N,3) = gradient, curvature b'' (N,) along z."""
+        d = x[:, 2] - self.gh
+        b, b1, b2 = barrier(d / self.dhat)
+        on = w > 0
+        with np.errstate(invalid="ignore"):
+            e = np.where(on, w * b, 0.0).sum()
+        k = self.dt**2 * self.kappa
+        return k * e, k * w * b1 / self.dhat, k * w * b2 / self.dhat**2, np.where(on, d, np.inf)
+
+    def pairs(self, y):
+        """Every point-triangle pair closer than d_hat.  Returns a list of (kind, point index, triangle row, weight, d, n (3,), beta (3,))
+        arrays: kind 0 = pad vertex vs ball triangle, kind 1 = ball vertex vs pad triangle."""
+        xb = self.ball.points(y[self.V:])
+        out = []
+        bt, pt = self.ball.tris, self.pad_tris
+        beta, d, n = point_triangle(y[self.pad_sv], xb[bt[:, 0]], xb[bt[:, 1]], xb[bt[:, 2]])
+        i, j = np.where(d < self.dhat)
+        out.append((self.pad_sv[i], j, self.pad_area[self.pad_sv[i]], d[i, j], n[i, j], beta[i, j]))
+        beta, d, n = point_triangle(xb, y[pt[:, 0]], y[pt[:, 1]], y[pt[:, 2]])
+        i, j = np.where(d < self.dhat)
+        out.append((i, j, self.ball.area[i], d[i, j], n[i, j], beta[i, j]))
+        return out
+
+    def _pair_rows(self, y):
+        """The pairs as rank-one rows: for pair k a sparse gradient of its distance over the V + 4 state rows -
+        g_k = sum_r coef[k, r] * n_k at state row rows[k, r] (r < 8; unused slots have coef 0)."""
+        memo = getattr(self, "_rows_memo", None)  # (the PCG applies the operator hundreds of times at ONE state)
+        if memo is not None and memo[0].shape == y.shape and np.array_equal(memo[0], y):
+            return memo[1]
+        V, Y, bt, pt = self.V, self.ball.Y, self.ball.tris, self.pad_tris
+        (pi, pj, pw, pd, pn, pb), (bi, bj, bw, bd, bn, bb) = self.pairs(y)
+        # kind 0: +1 on the pad vertex, -(beta . Y[tri]) on the four ball rows
+        r0 = np.concatenate([pi[:, None], np.broadcast_to(V + np.arange(4), (len(pi), 4)), np.zeros((len(pi), 3), np.int64)], 1)
+        c0 = np.concatenate([np.ones((len(pi), 1)), -np.einsum("kj,kja->ka", pb, Y[bt[pj]]), np.zeros((len(pi), 3))], 1)
+        # kind 1: +Y[b] on the four ball rows, -beta on the three pad vertices of the triangle
+        r1 = np.concatenate([np.broadcast_to(V + np.arange(4), (len(bi), 4)), pt[bj], np.zeros((len(bi), 1), np.int64)], 1)
+        c1 = np.concatenate([Y[bi], -bb, np.zeros((len(bi), 1))], 1)
+        out = (np.concatenate([r0, r1]), np.concatenate([c0, c1]), np.concatenate([pw, bw]), np.concatenate([pd, bd]), np.concatenate([pn, bn]))
+        self._rows_memo = (y.copy(), out)
+        return out
+
+    # ---- incremental potential -------------------------------------------------------------------------------------------------------
+    def energy(self, y, yt, cons=None, aim=None):
+        V = self.V
+        x, q = y[:V], y[V:]
+        dq = q - yt[V:]
+        e = self.pad.energy(x, yt[:V], cons, aim) + 0.5 * np.einsum("ab,ai,bi->", self.ball.S, dq, dq) + self.dt**2 * self.ball.ortho(q)[0]
+        e += self._ground(x, self.pad_area)[0] + self._ground(self.ball.points(q), self.ball.area)[0]
+        k = self.dt**2 * self.kappa
+        for (_, _, w, d, _, _) in self.pairs(y):
+            e += k * (w * barrier(d / self.dhat)[0]).sum()
+        return e
+
+    def gradient(self, y, yt, cons=None, aim=None):
+        V = self.V
+        x, q = y[:V], y[V:]
+        g = np.zeros_like(y)
+        g[:V] = self.pad.gradient(x, yt[:V], cons, aim)
+        g[V:] = self.ball.S @ (q - yt[V:]) + self.dt**2 * self.ball.ortho(q)[1]
+        g[:V, 2] += self._ground(x, self.pad_area)[1]
+        fb = np.zeros((len(self.ball.X), 3))
+        fb[:, 2] = self._ground(self.ball.points(q), self.ball.area)[1]
+        g[V:] += self.ball.to_q(fb)
+        rows, coef, w, d, n = self._pair_rows(y)
+        s = self.dt**2 * self.kappa * w * barrier(d / self.dhat)[1] / self.dhat
+        for r in range(8):
+            np.add.at(g, rows[:, r], (s * coef[:, r])[:, None] * n)
+        return g
+
+    def hess_vec(self, y, p, cons=None):
+        V = self.V
+        x, q = y[:V], y[V:]
+        out = np.zeros_like(y)
+        out[:V] = self.pad.hess_vec(x, p[:V], cons)
+        out[V:] = self.ball.S @ p[V:] + self.dt**2 * self.ball.ortho_hess_vec(q, p[V:])
+        out[:V, 2] += self._ground(x, self.pad_area)[2] * p[:V, 2]
+        cb = self._ground(self.ball.points(q), self.ball.area)[2]
+        fb = np.zeros((len(self.ball.X), 3))
+        fb[:, 2] = cb * (self.ball.Y @ p[V:])[:, 2]
+        out[V:] += self.ball.to_q(fb)
+        rows, coef, w, d, n = self._pair_rows(y)
+        wk = self.dt**2 * self.kappa * w * barrier(d / self.dhat)[2] / self.dhat**2
+        gp = np.zeros(len(w))
+        for r in range(8):
+            gp += coef[:, r] * (n * p[rows[:, r]]).sum(-1)
+        for r in range(8):
+            np.add.at(out, rows[:, r], (wk * gp * coef[:, r])[:, None] * n)
+        return out
+
+    def diag_blocks(self, y, cons=None):
+        """(V + 4, 3, 3) diagonal blocks of the operator hess_vec applies (block-Jacobi preconditioner)."""
+        V = self.V
+        x, q = y[:V], y[V:]
+        D = np.zeros((V + 4, 3, 3))
+        D[:V] = self.pad.diag_blocks(x, cons)
+        D[V:] = np.diag(self.ball.S)[:, None, None] * np.eye(3) + self.dt**2 * self.ball.ortho_diag_blocks(q)
+        D[:V, 2, 2] += self._ground(x, self.pad_area)[2]
+        cb = self._ground(self.ball.points(q), self.ball.area)[2]
+        D[V:, 2, 2] += (cb[:, None] * self.ball.Y**2).sum(0)
+        rows, coef, w, d, n = self._pair_rows(y)
+        wk = self.dt**2 * self.kappa * w * barrier(d / self.dhat)[2] / self.dhat**2
+        nn = n[:, :, None] * n[:, None, :]
+        for r in range(8):
+            np.add.at(D, rows[:, r], (wk * coef[:, r] ** 2)[:, None, None] * nn)
+        return D
+
+    def ball_block(self, y):
+        """(12,12) block of the operator on the ball's rows (row-major over (row a, axis i)): S (x) I + dt^2 Gauss-Newton orthogonality
+        + the ground and pair curvatures restricted to the four ball rows.  The preconditioner inverts it exactly: the 3 x 3 diagonal
+        blocks alone see the orthogonality stiffness (0.04 J) in every direction of every row, while the body's rotations - combinations
+        ACROSS the rows - are held by its inertia alone (5e-9 kg m^2): block Jacobi leaves a condition number of 1e7 on twelve unknowns."""
+        V = self.V
+        q = y[V:]
+        c = q[1:]
+        B = np.kron(self.ball.S, np.eye(3))
+        AAt = c.T @ c
+        G = np.zeros((12, 12))
+        for m in range(3):
+            for n in range(3):
+                blk = np.outer(c[n], c[m]) + (AAt if m == n else 0.0)
+                G[3 + 3 * m:6 + 3 * m, 3 + 3 * n:6 + 3 * n] = blk
+        B += self.dt**2 * 4.0 * self.ball.kv * G
+        cb = self._ground(self.ball.points(q), self.ball.area)[2]
+        YY = (cb[:, None, None] * self.ball.Y[:, :, None] * self.ball.Y[:, None, :]).sum(0)  # (4,4), acts on the z components
+        for a in range(4):
+            for b in range(4):
+                B[3 * a + 2, 3 * b + 2] += YY[a, b]
+        rows, coef, w, d, n = self._pair_rows(y)
+        wk = self.dt**2 * self.kappa * w * barrier(d / self.dhat)[2] / self.dhat**2
+        cq = np.zeros((len(w), 4))
+        for r in range(8):
+            on = rows[:, r] >= V
+            np.add.at(cq, (np.where(on)[0], rows[on, r] - V), coef[on, r])
+        for k in range(len(w)):
+            B += wk[k] * np.kron(np.outer(cq[k], cq[k]), np.outer(n[k], n[k]))
+        return B
+
+    def preconditioner(self, y, cons=None):
+        """r -> M^-1 r: 3 x 3 block Jacobi on the pad vertices, the exact inverse of the 12 x 12 ball block on the ball's rows."""
+        V = self.V
+        Dinv = np.linalg.inv(self.diag_blocks(y, cons)[:V])
+        Bc = np.linalg.cholesky(self.ball_block(y))
+
+        def prec(r):
+            z = np.empty_like(r)
+            z[:V] = np.einsum("vij,vj->vi", Dinv, r[:V])
+            z[V:] = np.linalg.solve(Bc.T, np.linalg.solve(Bc, r[V:].reshape(12))).reshape(4, 3)
+            return z
+
+        return prec
+
+    # ---- step bound: additive CCD on the candidate pairs -----------------------------------------------------------------------
+    def max_step(self, y, dy, slack=0.9, reach=2.0, keep=0.1, max_iter=64):
+        """Largest step in (0, 1] that keeps every point-triangle pair and the ground at a positive gap.
+          * ground: the gap of a surface vertex is linear in the step: slack * gap / descent;
+          * pairs within reach * d_hat: ADDITIVE CCD (Li et al. 2021, Algorithm 1) per pair - with the pair's mean displacement removed,
+            l = |dp| + max_j |dx_j| bounds the rate at which the (1-Lipschitz) distance can shrink, so t += slack * d(t) / l never
+            passes the time of impact; the march stops when the gap falls below `keep` of its start value (a pair that only slides - a
+            ball rolling under the pad - keeps its distance and reaches t = 1, where a one-shot bound d / l would cut the step to the
+            ratio of gap and sliding distance);
+          * pairs beyond cannot reach contact while no surface point moves further than slack * reach * d_hat / 2 in the step."""
+        V = self.V
+        xb = self.ball.points(y[V:])
+        db = self.ball.Y @ dy[V:]
+        nb = np.linalg.norm(db, axis=1)
+        npad = np.linalg.norm(dy[:V], axis=1)
+        a = 1.0
+        for (x, dz, w) in ((y[:V], dy[:V, 2], self.pad_area), (xb, db[:, 2], self.ball.area)):
+            gap = x[:, 2] - self.gh
+            ok = (w > 0) & (dz < 0) & (gap > 0)
+            if ok.any():
+                a = min(a, float((slack * gap[ok] / -dz[ok]).min()))
+        vmax = max(npad[self.pad_sv].max(initial=0.0), nb.max(initial=0.0))
+        R = reach * self.dhat
+        if vmax > 0:
+            a = min(a, slack * R / (2.0 * vmax))
+        bt, pt = self.ball.tris, self.pad_tris
+        for (P, dP, T0, dT0, tri) in ((y[self.pad_sv], dy[self.pad_sv], xb, db, bt), (xb, db, y[:V], dy[:V], pt)):
+            _, d, _ = point_triangle(P, T0[tri[:, 0]], T0[tri[:, 1]], T0[tri[:, 2]])
+            for i, j in zip(*np.where(d < R)):
+                a = min(a, accd_point_triangle(P[i], T0[tri[j]], dP[i], dT0[tri[j]], a, slack, keep, max_iter))
+        return a
+
+    # ---- one Newton iteration / one time step (the algorithm of fem_ball_newton_kernel) ------------------------------------------
+    def newton_step(self, y, yt, cons=None, aim=None, pcg_max_iter=1024, pcg_tol_rate=1e-3, ls_max_iter=8):
+        """PCG (block Jacobi on the pad + exact ball block) on the Gauss-Newton system, conservative step bound, backtracking line search (first E <= E0 wins).
+        Returns (y_new, [E0, E1, step, pcg iterations, max |d| over the position rows, max |d| over the ball's affine rows])."""
+        g = self.gradient(y, yt, cons, aim)
+        d, it = pcg_solve(lambda p: self.hess_vec(y, p, cons), self.preconditioner(y, cons), -g, pcg_max_iter, pcg_tol_rate)
+        E0 = self.energy(y, yt, cons, aim)
+        step = self.max_step(y, d)
+        y_new, E1 = y, E0
+        for _ in range(max(ls_max_iter, LS_RESCUE) + 1):
+            cand = y + step * d
+            Ec = self.energy(cand, yt, cons, aim)
+            if Ec <= E0:
+                y_new, E1 = cand, Ec
+                break
+            step *= 0.5
+        else:
+            step = 0.0
+        return y_new, np.array([E0, E1, step, it, np.abs(d[: self.V + 1]).max(), np.abs(d[self.V + 1:]).max()])
+
+    def step(self, y, v, cons=None, aim=None, gravity=(0.0, 0.0, -9.8), max_newton=64, velocity_tol=0.05, transrate_tol=0.1, **kw):
+        """One backward-Euler step: y~ = y + dt v + dt^2 g (gravity acts on the pad vertices and on the ball's translation p);
+        Newton until the unscaled direction has max |d| <= velocity_tol * dt on every position row (pad vertices, the ball's p) AND
+        max |d| <= transrate_tol * dt on the ball's affine rows (UipcSimCfg.newton: velocity_tol 0.05 m/s, transrate_tol 0.1 /s,
+        uipc_sim.py:62-66 - libuipc's separate test for affine bodies).  Returns (y_new, v_new, [iterations, max |d| (positions), flags, pcg])."""
+        dt = self.dt
+        yt = y + dt * v
+        g3 = dt * dt * np.asarray(gravity, np.float64)
+        yt[: self.V] += g3
+        yt[self.V] += g3
+        y0, n, pcg, dmax, flags = y, 0, 0, np.inf, 0
+        for _ in range(max_newton):
+            y, st = self.newton_step(y, yt, cons, aim, **kw)
+            n += 1
+            pcg += int(st[3])
+            dmax = st[4]
+            if dmax <= velocity_tol * dt and st[5] <= transrate_tol * dt:
+                break
+            if st[2] == 0.0:
+                flags |= 2
+                break
+        return y, (y - y0) / dt, np.array([n, dmax, flags, pcg], np.float64)
