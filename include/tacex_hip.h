@@ -32,7 +32,7 @@ extern "C" {
 #endif
 
 #define TACEX_MAX_LEVELS 8
-#define TACEX_ABI_VERSION 11
+#define TACEX_ABI_VERSION 12
 
 typedef struct tacex_taxim_ctx tacex_taxim_ctx;
 typedef struct tacex_fots_ctx tacex_fots_ctx;
@@ -487,6 +487,42 @@ int tacex_fem_step(tacex_fem_ctx* ctx, double* x_dev, double* v_dev, double* x_t
                    const double* aim_dev, double* stats_dev, double* step_info_dev, void* workspace_dev, int num_envs,
                    const double gravity[3], int max_newton, double velocity_tol, int pcg_max_iter, double pcg_tol_rate,
                    int ls_max_iter, void* stream);
+
+/* ---- The reference's own UIPC scene: a FREE affine-body ball on a ground plane under the gelpad (second slice) --------
+ * Replaces, for `UipcObjectCfg(constitution_cfg=AffineBodyConstitutionCfg())` next to the gelpad
+ * (scripts/benchmarking/tactile_sim_performance/envs/ball_rolling_uipc.py:71-92; source/tacex_uipc/tacex_uipc/objects/uipc_object.py:62-74,
+ * 456-466: `AffineBodyConstitution().apply_to(mesh, m_kappa * MPa, mass_density)`, kinematic = False) and `ground(ground_height,
+ * ground_normal)` + the default contact model (source/tacex_uipc/tacex_uipc/sim/uipc_sim.py:192-201), what libuipc's
+ * `world.advance()` does with them.  libuipc is not in the reference tree: the model is oracle/abd_oracle.py's (PARITY UNPINNED) -
+ * Lan et al. 2022 (affine body: q = (p, A), mass matrix S (x) I_3 from the surface mesh's moments, orthogonality energy
+ * kappa vol |A^T A - I|^2), Li et al. 2020 (barrier on every point-triangle pair closer than d_hat, pad vertex / ball triangle AND
+ * ball vertex / pad triangle, ground against the surface vertices of both bodies), additive CCD on the pairs.  No friction and no
+ * edge-edge pairs between the two bodies yet.
+ *
+ * tacex_fem_set_affine_body: ONE body per env, the same mesh for all envs.  verts_host (num_verts,3) f64 in the body frame, tris_host
+ * (num_tris,3) outward oriented; density [kg/m^3]; kappa [Pa] (m_kappa * 1e6); pad_vertex_area_host (V) contact weights of the gelpad's
+ * vertices (0: interior) and pad_tris_host (num_pad_tris,3) its surface triangles; d_hat [m], stiffness [J/m^2] as tacex_fem_set_contact;
+ * the ground is the half-space z >= ground_height (enable_ground = 0: none).  num_verts = 0 removes the body.  Tables are copied.
+ * State: q_dev / qv_dev (num_envs,4,3) f64 = (p, c_1, c_2, c_3) with c_k = COLUMN k of A (a surface point is p + sum_k X_k c_k) and its
+ * velocity.  tacex_fem_ball_step = one backward-Euler step of pad + ball: predictor (gravity on the pad vertices and on p), the whole
+ * Newton loop in one launch (PCG preconditioned by 3x3 blocks on the pad and the exact 12x12 ball block; an env leaves the loop once
+ * the unscaled direction has max |d| <= velocity_tol * dt on the position rows AND <= transrate_tol * dt on the affine rows,
+ * uipc_sim.py:62-66), velocities.  step_info (num_envs,4) = [Newton iterations, max |d|, flags (1 a surface vertex at / below the
+ * ground, 2 line search failed, 16 a candidate list overflowed), PCG iterations].  workspace: tacex_fem_ball_workspace_bytes.
+ * tacex_fem_ball_terms: energy (num_envs) and gradient (num_envs, V + 4, 3) of the step's incremental potential at (x, q) against the
+ * predictors (x_tilde, q_tilde) - the entry point the parity tests compare with the oracle term by term.
+ * tacex_fem_ball_moments: the 4x4 moment matrix S (row-major) and kappa * vol the library derived from the mesh. */
+int tacex_fem_set_affine_body(tacex_fem_ctx* ctx, int num_verts, const double* verts_host, int num_tris, const int32_t* tris_host, double density,
+                              double kappa, const double* pad_vertex_area_host, int num_pad_tris, const int32_t* pad_tris_host, double d_hat,
+                              double stiffness, double ground_height, int enable_ground);
+size_t tacex_fem_ball_workspace_bytes(const tacex_fem_ctx* ctx, int num_envs);
+int tacex_fem_ball_moments(const tacex_fem_ctx* ctx, double moments_out[16], double* kappa_vol_out);
+int tacex_fem_ball_terms(tacex_fem_ctx* ctx, const double* x_dev, const double* x_tilde_dev, const double* q_dev, const double* q_tilde_dev,
+                         const uint8_t* constrained_dev, const double* aim_dev, double* energy_dev, double* grad_dev, double* step_info_dev,
+                         void* workspace_dev, int num_envs, void* stream);
+int tacex_fem_ball_step(tacex_fem_ctx* ctx, double* x_dev, double* v_dev, double* q_dev, double* qv_dev, const uint8_t* constrained_dev,
+                        const double* aim_dev, double* step_info_dev, void* workspace_dev, int num_envs, const double gravity[3], int max_newton,
+                        double velocity_tol, double transrate_tol, int pcg_max_iter, double pcg_tol_rate, int ls_max_iter, void* stream);
 
 /* Per-env reset of the FEM state - what `UipcObject.reset(env_ids)` / `write_vertex_positions_to_sim(vertex_positions, env_ids)`
  * (source/tacex_uipc/tacex_uipc/objects/uipc_object.py:280-370; `reset` is a TODO stub there, the write ignores env_ids) are for: an

@@ -1,0 +1,12 @@
+"""c4_ball scene probe: per-step Newton / PCG counts, flags and time of FemBallScene (default tolerances), 64 envs."""
+import sys, time, torch
+from tacex_amd.uipc.gelpad_scene import FemBallScene
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
+sc = FemBallScene(B, "cuda:0", max_newton_iter=64)
+for i in range(30):
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    sc.step(i)
+    torch.cuda.synchronize(); ms = (time.perf_counter() - t0) * 1e3
+    si = sc.sim.step_info
+    print(f"step {i:2d} {ms:8.2f} ms newton mean {float(si[:,0].mean()):5.1f} max {int(si[:,0].max()):3d} pcg/newton {float((si[:,3]/si[:,0].clamp_min(1)).mean()):6.1f} "
+          f"flags {int(si[:,2].max())} ball z-z0 [{float((sc.sim.q[:,0,2]).min()-0.0105)*1e6:8.1f}, {float((sc.sim.q[:,0,2]).max()-0.0105)*1e6:8.1f}] um", flush=True)

@@ -1,0 +1,792 @@
+// The reference's own UIPC scene on the GPU (second slice; included by fem_kernels.hip inside namespace tacex):
+// the gelpad (Stable Neo-Hookean tets, soft position constraints) + ONE FREE AFFINE-BODY BALL per env + the ground half-space, in IPC
+// contact through point-triangle pairs in both directions.  Reference call sites: ball_rolling_uipc.py:71-92 (ground_height 0.001,
+// d_hat 5e-4, the ball as AffineBodyConstitutionCfg), uipc_object.py:62-74,456-466 (m_kappa 100 MPa, kinematic = False),
+// uipc_sim.py:192-201 (ground + one default contact model).  The arithmetic is libuipc's, which is not in the reference tree: this
+// follows oracle/abd_oracle.py (PARITY UNPINNED) term by term -
+//   * the ball's 12 degrees of freedom are FOUR MORE ROWS of the env's state: y = (x_0 .. x_{V-1}, p, c_1, c_2, c_3), a surface point
+//     of the ball is Y_b . (p, c_1, c_2, c_3) with Y_b = (1, X_b); inertia 1/2 (q - q~)^T (S (x) I) (q - q~), orthogonality energy
+//     kappa vol |A^T A - I|^2 with its Gauss-Newton Hessian 4 kappa vol [delta_mn A A^T + c_n c_m^T];
+//   * barrier kappa w b(d / d_hat) on every pair (pad surface vertex, ball triangle) and (ball vertex, pad surface triangle) closer
+//     than d_hat, and of the ground against the surface vertices of both bodies; Hessians b'' grad d grad d^T;
+//   * matrix-free PCG, preconditioned by 3 x 3 blocks on the pad vertices and by the EXACT inverse of the 12 x 12 ball block;
+//   * step bound: ground gaps (linear), additive CCD on the listed pairs, no surface point further than 0.9 d_hat per iteration;
+//   * backtracking line search on the plain incremental potential; convergence on the unscaled direction: velocity_tol * dt on the
+//     position rows AND transrate_tol * dt on the ball's affine rows (UipcSimCfg.newton, uipc_sim.py:62-66).
+// One workgroup (512 threads) per env, the whole Newton loop of a time step in ONE launch.  The pad's vectors live in the env's
+// workspace block (L2 / HBM, like fem_newton_kernel: this is the streaming form - see DESIGN.md for why the CU-resident kernel does
+// not carry the scene); pair candidates are rebuilt once per Newton iteration at reach 2.8 d_hat, which no pair outside can cross
+// into d_hat within one bounded step, so the line search's energies are exact.
+
+struct BallDev {
+  int nv = 0, nt = 0, npt = 0, nsv = 0;
+  const double* Y = nullptr;      // (nv,4) [1, X]
+  const int* tri = nullptr;       // (nt,3)
+  const double* area = nullptr;   // (nv) vertex areas
+  const int* ptri = nullptr;      // (npt,3) pad surface triangles
+  const int* psv = nullptr;       // (nsv) pad surface vertices
+  const double* parea = nullptr;  // (V) pad vertex areas (0: interior)
+  double S[16] = {};              // 4 x 4 moment matrix
+  double kv = 0.0, gh = 0.0, dhat = 0.0, kappa = 0.0;
+  int ground = 0;
+};
+
+constexpr int kBallMaxPairs = 4096;   // listed candidate pairs per env and Newton iteration
+constexpr int kBallMaxActive = 1024;  // pairs inside d_hat at the iteration's state
+constexpr int kBallRec = 14;          // doubles per active record
+constexpr int kBallMaxCand = 512;     // candidate pad vertices / pad triangles / ball vertices per env
+constexpr double kBallReach = 2.0;    // additive CCD on pairs closer than kBallReach * d_hat
+constexpr double kBallKeep = 0.1;     // ... which may keep this fraction of their gap
+constexpr int kBallFlagOverflow = 16; // step_info flag: a candidate / pair list overflowed (the scene is outside what this slice handles)
+
+// workspace of one env (doubles): ge 12T | tc 12T | hv 12T | g r z p d Hp yc: 7 x 3 (V+4) | D / Dinv 9V | ground curvature V |
+//   xb 3nv | xbc 3nv | dxb 3nv | ball triangle spheres 4nt | pair list (ints) kBallMaxPairs / 2 | active records
+__host__ __device__ inline size_t ball_ws_doubles(int V, int T, int nv, int nt) {
+  return (size_t)36 * T + (size_t)21 * (V + 4) + (size_t)10 * V + (size_t)9 * nv + (size_t)4 * nt + kBallMaxPairs / 2 + (size_t)kBallMaxActive * kBallRec;
+}
+
+// closest point of triangle (a, b, c) to p: barycentric coordinates, distance, unit vector from the closest point to p
+// (Ericson 5.1.5, regions in the book's order - oracle/abd_oracle.py point_triangle)
+__device__ __forceinline__ void pt_closest(const double p[3], const double a[3], const double b[3], const double c[3], double beta[3], double& d,
+                                           double n[3]) {
+  const double ab[3] = {b[0] - a[0], b[1] - a[1], b[2] - a[2]}, ac[3] = {c[0] - a[0], c[1] - a[1], c[2] - a[2]};
+  const double ap[3] = {p[0] - a[0], p[1] - a[1], p[2] - a[2]};
+  const double d1 = ab[0] * ap[0] + ab[1] * ap[1] + ab[2] * ap[2], d2 = ac[0] * ap[0] + ac[1] * ap[1] + ac[2] * ap[2];
+  const double bp[3] = {p[0] - b[0], p[1] - b[1], p[2] - b[2]};
+  const double d3 = ab[0] * bp[0] + ab[1] * bp[1] + ab[2] * bp[2], d4 = ac[0] * bp[0] + ac[1] * bp[1] + ac[2] * bp[2];
+  const double cp[3] = {p[0] - c[0], p[1] - c[1], p[2] - c[2]};
+  const double d5 = ab[0] * cp[0] + ab[1] * cp[1] + ab[2] * cp[2], d6 = ac[0] * cp[0] + ac[1] * cp[1] + ac[2] * cp[2];
+  const double vc = d1 * d4 - d3 * d2, vb = d5 * d2 - d1 * d6, va = d3 * d6 - d5 * d4;
+  double s, u;
+  if (d1 <= 0.0 && d2 <= 0.0) { s = 0.0; u = 0.0; }
+  else if (d3 >= 0.0 && d4 <= d3) { s = 1.0; u = 0.0; }
+  else if (vc <= 0.0 && d1 >= 0.0 && d3 <= 0.0) { s = d1 / (d1 - d3); u = 0.0; }
+  else if (d6 >= 0.0 && d5 <= d6) { s = 0.0; u = 1.0; }
+  else if (vb <= 0.0 && d2 >= 0.0 && d6 <= 0.0) { s = 0.0; u = d2 / (d2 - d6); }
+  else if (va <= 0.0 && (d4 - d3) >= 0.0 && (d5 - d6) >= 0.0) { u = (d4 - d3) / ((d4 - d3) + (d5 - d6)); s = 1.0 - u; }
+  else { const double den = 1.0 / (va + vb + vc); s = vb * den; u = vc * den; }
+  beta[0] = 1.0 - s - u; beta[1] = s; beta[2] = u;
+  const double r0 = ap[0] - s * ab[0] - u * ac[0], r1 = ap[1] - s * ab[1] - u * ac[1], r2 = ap[2] - s * ab[2] - u * ac[2];
+  d = sqrt(r0 * r0 + r1 * r1 + r2 * r2);
+  const double id = d > 0.0 ? 1.0 / d : 0.0;
+  n[0] = r0 * id; n[1] = r1 * id; n[2] = r2 * id;
+}
+
+// additive CCD of one point-triangle pair (oracle/abd_oracle.py accd_point_triangle): largest t <= t_max keeping >= keep * d(0)
+__device__ double accd_pt(const double p[3], const double tr[9], const double dp_in[3], const double dtr_in[9], double t_max) {
+  double dp[3], dtr[9], mean[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) mean[i] = (dp_in[i] + dtr_in[i] + dtr_in[3 + i] + dtr_in[6 + i]) * 0.25;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) { dp[i] = dp_in[i] - mean[i]; dtr[i] = dtr_in[i] - mean[i]; dtr[3 + i] = dtr_in[3 + i] - mean[i]; dtr[6 + i] = dtr_in[6 + i] - mean[i]; }
+  double lt = 0.0;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) lt = fmax(lt, sqrt(dtr[3 * k] * dtr[3 * k] + dtr[3 * k + 1] * dtr[3 * k + 1] + dtr[3 * k + 2] * dtr[3 * k + 2]));
+  const double l = sqrt(dp[0] * dp[0] + dp[1] * dp[1] + dp[2] * dp[2]) + lt;
+  if (!(l > 0.0)) return t_max;
+  auto dist = [&](double t) {
+    double q[3], a[3], b[3], c[3], be[3], d, n[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { q[i] = p[i] + t * dp[i]; a[i] = tr[i] + t * dtr[i]; b[i] = tr[3 + i] + t * dtr[3 + i]; c[i] = tr[6 + i] + t * dtr[6 + i]; }
+    pt_closest(q, a, b, c, be, d, n);
+    return d;
+  };
+  const double d0 = dist(0.0), g = kBallKeep * d0;
+  double t = 0.0, tl = (1.0 - kBallKeep) * d0 / l;
+  for (int it = 0; it < 64; ++it) {
+    const double d = dist(t + tl);
+    if (t > 0.0 && d < g) break;
+    t += tl;
+    if (t >= t_max) return t_max;
+    tl = kCcdSlack * d / l;
+  }
+  return t;
+}
+
+__device__ __forceinline__ void barrier3(double s, double& b, double& b1, double& b2) {  // b(s), b'(s), b''(s) of the dimensionless barrier
+  if (!(s > 0.0)) { b = INFINITY; b1 = 0.0; b2 = 0.0; return; }
+  if (s >= 1.0) { b = 0.0; b1 = 0.0; b2 = 0.0; return; }
+  const double ln = log(s), q = s - 1.0;
+  b = -q * q * ln;
+  b1 = -2.0 * q * ln - q * q / s;
+  b2 = -2.0 * ln - 4.0 * q / s + q * q / (s * s);
+}
+
+// mode 0: Newton loop of a time step; mode 1: energy and gradient at (x, q) only (terms entry point of the C ABI: tests)
+__global__ __launch_bounds__(512) void fem_ball_newton_kernel(FemDev m, BallDev bd, double* xg, const double* xtg, double* qg, const double* qtg,
+                                                              const uint8_t* consg, const double* aimg, double* wsg, int pcg_max_iter,
+                                                              double pcg_tol_rate, int ls_max_iter, int max_newton, double dx_tol, double dc_tol,
+                                                              double* step_info, int mode, double* e_out, double* g_out) {
+  __shared__ double sh[17];
+  __shared__ double gb[12], Bm[144], B0[144], Lc[144], YY[16], qs[12], qts[12], rhs12[12];
+  __shared__ int n_cpv, n_cpt, n_cbv, n_pairs, n_act, s_flags;
+  __shared__ int cpv[kBallMaxCand], cpt[kBallMaxCand], cbv[kBallMaxCand];
+  const int b = blockIdx.x, tid = threadIdx.x, NT = blockDim.x;
+  const int V = m.V, T = m.T, nv = bd.nv, nt = bd.nt, VN = V + 4;
+  const size_t o = (size_t)b * V * 3;
+  double* x = xg + o;
+  const double* xt = xtg + o;
+  double* q = qg + (size_t)b * 12;
+  const double* qt = qtg + (size_t)b * 12;
+  const uint8_t* cons = consg ? consg + (size_t)b * V : nullptr;
+  const double* aim = aimg ? aimg + o : nullptr;
+  double* ws = wsg + (size_t)b * ball_ws_doubles(V, T, nv, nt);
+  double* ge = ws;
+  double* tc = ge + (size_t)12 * T;
+  double* hv = tc + (size_t)12 * T;
+  double* vg = hv + (size_t)12 * T;
+  double* vr = vg + (size_t)3 * VN;
+  double* vz = vr + (size_t)3 * VN;
+  double* vp = vz + (size_t)3 * VN;
+  double* vd = vp + (size_t)3 * VN;
+  double* vHp = vd + (size_t)3 * VN;
+  double* yc = vHp + (size_t)3 * VN;   // line-search candidate (pad rows | ball rows)
+  double* Dinv = yc + (size_t)3 * VN;  // (V,9)
+  double* cbp = Dinv + (size_t)9 * V;  // (V) ground curvature of the pad vertices at x (dt^2-scaled)
+  double* xb = cbp + V;                // (nv,3) ball surface points at x
+  double* xbc = xb + (size_t)3 * nv;   // ... at the candidate
+  double* dxb = xbc + (size_t)3 * nv;  // ... their displacement along the Newton direction
+  double* bts = dxb + (size_t)3 * nv;  // (nt,4) bounding sphere of every ball triangle at x
+  int* plist = reinterpret_cast<int*>(bts + (size_t)4 * nt);  // (kBallMaxPairs) kind << 30 | point << 15 | triangle
+  double* arec = reinterpret_cast<double*>(plist + kBallMaxPairs);
+  const double dt2 = m.dt * m.dt, dhat = bd.dhat, kk = dt2 * bd.kappa;
+  const double L = dhat * (1.0 + kCcdSlack * kBallReach), R = kBallReach * dhat;
+
+  if (tid < 12) { qs[tid] = q[tid]; qts[tid] = qt[tid]; }
+  if (tid == 0) s_flags = 0;
+  __syncthreads();
+
+  auto ball_points = [&](const double* qq, double* out) {  // out (nv,3) = Y qq; qq in LDS
+    for (int k = tid; k < nv; k += NT) {
+      const double y0 = bd.Y[k * 4], y1 = bd.Y[k * 4 + 1], y2 = bd.Y[k * 4 + 2], y3 = bd.Y[k * 4 + 3];
+#pragma unroll
+      for (int i = 0; i < 3; ++i) out[k * 3 + i] = y0 * qq[i] + y1 * qq[3 + i] + y2 * qq[6 + i] + y3 * qq[9 + i];
+    }
+  };
+  // energy of the state (xx pad vertices in global memory, qq ball rows in LDS, xbb its surface points): every term of
+  // oracle/abd_oracle.py BallScene.energy; the pairs are those of the iteration's list
+  auto energy = [&](const double* xx, const double* qq, const double* xbb) -> double {
+    double e = 0.0;
+    for (int t = tid; t < T; t += NT) {
+      int v[4];
+      double Di[9], F[9];
+      load_tet(m, t, v, Di);
+      deformation_gradient(xx, v, Di, F);
+      TetState s;
+      tet_state(m, F, s);
+      e += dt2 * m.vol[t] * psi_of(m, s);
+    }
+    for (int v = tid; v < V; v += NT) {
+      const double mv = m.mass[v];
+      double qd = 0.0, qc = 0.0;
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        const double d = xx[v * 3 + i] - xt[v * 3 + i];
+        qd += d * d;
+        if (cons && cons[v]) { const double c = xx[v * 3 + i] - aim[v * 3 + i]; qc += c * c; }
+      }
+      e += 0.5 * mv * qd + 0.5 * m.strength * mv * qc;
+      const double w = bd.parea[v];
+      if (bd.ground && w > 0.0) {
+        double bb, b1, b2;
+        barrier3((xx[v * 3 + 2] - bd.gh) / dhat, bb, b1, b2);
+        e += kk * w * bb;
+      }
+    }
+    if (bd.ground)
+      for (int k = tid; k < nv; k += NT) {
+        double bb, b1, b2;
+        barrier3((xbb[k * 3 + 2] - bd.gh) / dhat, bb, b1, b2);
+        e += kk * bd.area[k] * bb;
+      }
+    if (tid == 0) {
+      double ei = 0.0;
+      for (int a = 0; a < 4; ++a)
+        for (int c = 0; c < 4; ++c) {
+          double dd = 0.0;
+#pragma unroll
+          for (int i = 0; i < 3; ++i) dd += (qq[a * 3 + i] - qts[a * 3 + i]) * (qq[c * 3 + i] - qts[c * 3 + i]);
+          ei += bd.S[a * 4 + c] * dd;
+        }
+      double eo = 0.0;
+      for (int k = 0; k < 3; ++k)
+        for (int l = 0; l < 3; ++l) {
+          const double r = qq[3 + k * 3] * qq[3 + l * 3] + qq[4 + k * 3] * qq[4 + l * 3] + qq[5 + k * 3] * qq[5 + l * 3] - (k == l ? 1.0 : 0.0);
+          eo += r * r;
+        }
+      e += 0.5 * ei + dt2 * bd.kv * eo;
+    }
+    const int np = n_pairs;
+    for (int k = tid; k < np; k += NT) {
+      const int code = plist[k], kind = code >> 30, pi = (code >> 15) & 0x7fff, tj = code & 0x7fff;
+      double p3[3], a[3], bq[3], c[3], be[3], d, n[3], w;
+      if (kind == 0) {
+        const int* tr = bd.tri + tj * 3;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) { p3[i] = xx[pi * 3 + i]; a[i] = xbb[tr[0] * 3 + i]; bq[i] = xbb[tr[1] * 3 + i]; c[i] = xbb[tr[2] * 3 + i]; }
+        w = bd.parea[pi];
+      } else {
+        const int* tr = bd.ptri + tj * 3;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) { p3[i] = xbb[pi * 3 + i]; a[i] = xx[tr[0] * 3 + i]; bq[i] = xx[tr[1] * 3 + i]; c[i] = xx[tr[2] * 3 + i]; }
+        w = bd.area[pi];
+      }
+      pt_closest(p3, a, bq, c, be, d, n);
+      if (d < dhat) {
+        double bb, b1, b2;
+        barrier3(d / dhat, bb, b1, b2);
+        e += kk * w * bb;
+      }
+    }
+    return block_sum(e, sh);
+  };
+  // z = M^-1 r: 3 x 3 blocks on the pad rows, the Cholesky factor of the 12 x 12 ball block on the ball rows (one thread)
+  auto precondition = [&](const double* r, double* z) -> double {
+    double part = 0.0;
+    for (int v = tid; v < V; v += NT) {
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        const double zz = Dinv[(size_t)v * 9 + i * 3] * r[v * 3] + Dinv[(size_t)v * 9 + i * 3 + 1] * r[v * 3 + 1] + Dinv[(size_t)v * 9 + i * 3 + 2] * r[v * 3 + 2];
+        z[v * 3 + i] = zz;
+        part += r[v * 3 + i] * zz;
+      }
+    }
+    if (tid == 0) {
+      double yv[12];
+      for (int i = 0; i < 12; ++i) {
+        double s = r[V * 3 + i];
+        for (int k = 0; k < i; ++k) s -= Lc[i * 12 + k] * yv[k];
+        yv[i] = s / Lc[i * 12 + i];
+      }
+      for (int i = 11; i >= 0; --i) {
+        double s = yv[i];
+        for (int k = i + 1; k < 12; ++k) s -= Lc[k * 12 + i] * yv[k];
+        yv[i] = s / Lc[i * 12 + i];
+      }
+      for (int i = 0; i < 12; ++i) { z[V * 3 + i] = yv[i]; part += r[V * 3 + i] * yv[i]; }
+    }
+    return block_sum(part, sh);
+  };
+
+  ball_points(qs, xb);
+  __syncthreads();
+  int n_newton = 0, pcg_total = 0;
+  double dmax_x = INFINITY, dmax_c = INFINITY;
+  for (int nit = 0; nit < max_newton; ++nit) {
+    // ---- element pass (as fem_newton_kernel) + bounding spheres of the ball triangles + candidate lists ----
+    for (int t = tid; t < T; t += NT) {
+      int v[4];
+      double Di[9], F[9], r[12], g[12];
+      load_tet(m, t, v, Di);
+      deformation_gradient(x, v, Di, F);
+      TetState s;
+      tet_state(m, F, s);
+      shape_rows(Di, r);
+      element_gradient(s, r, dt2 * m.vol[t], g);
+#pragma unroll
+      for (int k = 0; k < 12; ++k) ge[(size_t)k * T + t] = g[k];
+#pragma unroll
+      for (int k = 0; k < 9; ++k) tc[(size_t)k * T + t] = F[k];
+      tc[(size_t)9 * T + t] = s.a; tc[(size_t)10 * T + t] = s.b; tc[(size_t)11 * T + t] = s.c;
+    }
+    double rb = 0.0;  // bounding radius of the ball about p
+    for (int k = tid; k < nv; k += NT) {
+      const double r0 = xb[k * 3] - qs[0], r1 = xb[k * 3 + 1] - qs[1], r2 = xb[k * 3 + 2] - qs[2];
+      rb = fmax(rb, sqrt(r0 * r0 + r1 * r1 + r2 * r2));
+    }
+    for (int t = tid; t < nt; t += NT) {
+      const int* tr = bd.tri + t * 3;
+      double c3[3], rt = 0.0;
+#pragma unroll
+      for (int i = 0; i < 3; ++i) c3[i] = (xb[tr[0] * 3 + i] + xb[tr[1] * 3 + i] + xb[tr[2] * 3 + i]) * (1.0 / 3.0);
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        const double r0 = xb[tr[k] * 3] - c3[0], r1 = xb[tr[k] * 3 + 1] - c3[1], r2 = xb[tr[k] * 3 + 2] - c3[2];
+        rt = fmax(rt, sqrt(r0 * r0 + r1 * r1 + r2 * r2));
+      }
+      bts[t * 4] = c3[0]; bts[t * 4 + 1] = c3[1]; bts[t * 4 + 2] = c3[2]; bts[t * 4 + 3] = rt;
+    }
+    if (tid == 0) { n_cpv = 0; n_cpt = 0; n_cbv = 0; n_pairs = 0; n_act = 0; }
+    if (tid < 12) gb[tid] = 0.0;
+    if (tid < 16) YY[tid] = 0.0;
+    if (tid < 144) Bm[tid] = 0.0;
+    rb = block_sum_max(rb, sh);
+    // pad surface vertices / triangles within reach of the ball's bounding sphere; ball vertices within reach of ANY candidate pad triangle
+    // are found pair by pair below
+    for (int k = tid; k < bd.nsv; k += NT) {
+      const int v = bd.psv[k];
+      const double r0 = x[v * 3] - qs[0], r1 = x[v * 3 + 1] - qs[1], r2 = x[v * 3 + 2] - qs[2];
+      const double lim = rb + L;
+      if (r0 * r0 + r1 * r1 + r2 * r2 < lim * lim) {
+        const int s = atomicAdd(&n_cpv, 1);
+        if (s < kBallMaxCand) cpv[s] = v;
+      }
+    }
+    for (int k = tid; k < bd.npt; k += NT) {
+      const int* tr = bd.ptri + k * 3;
+      double c3[3], rt = 0.0;
+#pragma unroll
+      for (int i = 0; i < 3; ++i) c3[i] = (x[tr[0] * 3 + i] + x[tr[1] * 3 + i] + x[tr[2] * 3 + i]) * (1.0 / 3.0);
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        const double r0 = x[tr[j] * 3] - c3[0], r1 = x[tr[j] * 3 + 1] - c3[1], r2 = x[tr[j] * 3 + 2] - c3[2];
+        rt = fmax(rt, sqrt(r0 * r0 + r1 * r1 + r2 * r2));
+      }
+      const double r0 = c3[0] - qs[0], r1 = c3[1] - qs[1], r2 = c3[2] - qs[2];
+      const double lim = rb + L + rt;
+      if (r0 * r0 + r1 * r1 + r2 * r2 < lim * lim) {
+        const int s = atomicAdd(&n_cpt, 1);
+        if (s < kBallMaxCand) cpt[s] = k;
+      }
+    }
+    __syncthreads();
+    if (n_cpv > kBallMaxCand || n_cpt > kBallMaxCand) { if (tid == 0) s_flags |= kBallFlagOverflow; }
+    const int ncpv = min(n_cpv, kBallMaxCand), ncpt = min(n_cpt, kBallMaxCand);
+    // ball vertices near the candidate pad triangles: within L of the union of their bounding spheres - one sphere around all of them
+    // would do as well; here: within reach of the pad's candidate region = distance to p's far side is what the triangle test used, so
+    // every ball vertex is tested against the candidate triangles' spheres directly (nv x ncpt sphere tests)
+    // pairs, kind 0: candidate pad vertex x ball triangle
+    for (int k = tid; k < ncpv * nt; k += NT) {
+      const int v = cpv[k / nt], t = k - (k / nt) * nt;
+      const double r0 = x[v * 3] - bts[t * 4], r1 = x[v * 3 + 1] - bts[t * 4 + 1], r2 = x[v * 3 + 2] - bts[t * 4 + 2];
+      const double lim = L + bts[t * 4 + 3];
+      if (r0 * r0 + r1 * r1 + r2 * r2 >= lim * lim) continue;
+      const int* tr = bd.tri + t * 3;
+      double p3[3], a[3], bq[3], c[3], be[3], d, n[3];
+#pragma unroll
+      for (int i = 0; i < 3; ++i) { p3[i] = x[v * 3 + i]; a[i] = xb[tr[0] * 3 + i]; bq[i] = xb[tr[1] * 3 + i]; c[i] = xb[tr[2] * 3 + i]; }
+      pt_closest(p3, a, bq, c, be, d, n);
+      if (d < L) {
+        const int s = atomicAdd(&n_pairs, 1);
+        if (s < kBallMaxPairs) plist[s] = (0 << 30) | (v << 15) | t;
+      }
+    }
+    // pairs, kind 1: ball vertex x candidate pad triangle
+    for (int k = tid; k < nv * ncpt; k += NT) {
+      const int bv = k / ncpt, t = cpt[k - (k / ncpt) * ncpt];
+      const int* tr = bd.ptri + t * 3;
+      double p3[3], a[3], bq[3], c[3], be[3], d, n[3];
+#pragma unroll
+      for (int i = 0; i < 3; ++i) { p3[i] = xb[bv * 3 + i]; a[i] = x[tr[0] * 3 + i]; bq[i] = x[tr[1] * 3 + i]; c[i] = x[tr[2] * 3 + i]; }
+      // sphere test about the triangle's first corner (its edges are bounded by the distance test itself: cheap rejection)
+      const double r0 = p3[0] - a[0], r1 = p3[1] - a[1], r2 = p3[2] - a[2];
+      const double e0 = bq[0] - a[0], e1 = bq[1] - a[1], e2 = bq[2] - a[2], f0 = c[0] - a[0], f1 = c[1] - a[1], f2 = c[2] - a[2];
+      const double ext = sqrt(fmax(e0 * e0 + e1 * e1 + e2 * e2, f0 * f0 + f1 * f1 + f2 * f2));
+      const double lim = L + ext;
+      if (r0 * r0 + r1 * r1 + r2 * r2 >= lim * lim) continue;
+      pt_closest(p3, a, bq, c, be, d, n);
+      if (d < L) {
+        const int s = atomicAdd(&n_pairs, 1);
+        if (s < kBallMaxPairs) plist[s] = (1 << 30) | (bv << 15) | t;
+      }
+    }
+    __syncthreads();
+    if (n_pairs > kBallMaxPairs) { if (tid == 0) { s_flags |= kBallFlagOverflow; n_pairs = kBallMaxPairs; } }
+    __syncthreads();
+    // ---- nodal gradient, diagonal blocks (pad rows; pairs are added below), ground ----
+    for (int v = tid; v < V; v += NT) {
+      double a3[3];
+      gather_vertex(m, ge, v, a3);
+      const double mv = m.mass[v];
+      const bool c = cons && cons[v];
+      const double md = mv * (1.0 + (c ? m.strength : 0.0));
+      double D[9] = {md, 0, 0, 0, md, 0, 0, 0, md};
+      double gz = 0.0, cb = 0.0;
+      const double w = bd.parea[v];
+      if (bd.ground && w > 0.0) {
+        double bb, b1, b2;
+        barrier3((x[v * 3 + 2] - bd.gh) / dhat, bb, b1, b2);
+        if (!(x[v * 3 + 2] - bd.gh > 0.0)) atomicOr(&s_flags, kFemFlagPenetration);
+        gz = kk * w * b1 / dhat;
+        cb = kk * w * b2 / (dhat * dhat);
+        D[8] += cb;
+      }
+      cbp[v] = cb;
+      for (int e = m.vt_off[v]; e < m.vt_off[v + 1]; ++e) {
+        const int code = m.vt_idx[e];
+        const int t = code >> 2, l = code & 3;
+        double Di[9], r[12];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) Di[k] = m.dminv[(size_t)k * T + t];
+        shape_rows(Di, r);
+        TetState s;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) s.F[k] = tc[(size_t)k * T + t];
+        {
+          double f0[3] = {s.F[0], s.F[3], s.F[6]}, f1[3] = {s.F[1], s.F[4], s.F[7]}, f2[3] = {s.F[2], s.F[5], s.F[8]};
+          double c0[3], c1[3], c2[3];
+          cross3(f1, f2, c0); cross3(f2, f0, c1); cross3(f0, f1, c2);
+#pragma unroll
+          for (int i = 0; i < 3; ++i) { s.C[i * 3 + 0] = c0[i]; s.C[i * 3 + 1] = c1[i]; s.C[i * 3 + 2] = c2[i]; }
+        }
+        s.a = tc[(size_t)9 * T + t]; s.b = tc[(size_t)10 * T + t]; s.c = tc[(size_t)11 * T + t];
+        const double sc = dt2 * m.vol[t];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+          double dF[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, dP[9];
+          dF[k * 3 + 0] = r[l * 3 + 0]; dF[k * 3 + 1] = r[l * 3 + 1]; dF[k * 3 + 2] = r[l * 3 + 2];
+          apply_dP(m, s, dF, dP);
+#pragma unroll
+          for (int i = 0; i < 3; ++i)
+            D[i * 3 + k] += sc * (dP[i * 3 + 0] * r[l * 3 + 0] + dP[i * 3 + 1] * r[l * 3 + 1] + dP[i * 3 + 2] * r[l * 3 + 2]);
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < 9; ++k) Dinv[(size_t)v * 9 + k] = D[k];
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        double gi = a3[i] + mv * (x[v * 3 + i] - xt[v * 3 + i]);
+        if (c) gi += m.strength * mv * (x[v * 3 + i] - aim[v * 3 + i]);
+        vg[v * 3 + i] = gi + (i == 2 ? gz : 0.0);
+      }
+    }
+    if (bd.ground)
+      for (int k = tid; k < nv; k += NT) {
+        const double gap = xb[k * 3 + 2] - bd.gh;
+        if (!(gap > 0.0)) atomicOr(&s_flags, kFemFlagPenetration);
+        if (gap < dhat && gap > 0.0) {
+          double bb, b1, b2;
+          barrier3(gap / dhat, bb, b1, b2);
+          const double f = kk * bd.area[k] * b1 / dhat, cb = kk * bd.area[k] * b2 / (dhat * dhat);
+#pragma unroll
+          for (int a = 0; a < 4; ++a) {
+            atomicAdd(&gb[a * 3 + 2], f * bd.Y[k * 4 + a]);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) atomicAdd(&YY[a * 4 + c], cb * bd.Y[k * 4 + a] * bd.Y[k * 4 + c]);
+          }
+        }
+      }
+    __syncthreads();
+    // ---- pairs at x: gradient, diagonal blocks, ball block, active records ----
+    {
+      const int np = n_pairs;
+      for (int k = tid; k < np; k += NT) {
+        const int code = plist[k], kind = code >> 30, pi = (code >> 15) & 0x7fff, tj = code & 0x7fff;
+        const int* tr = (kind == 0 ? bd.tri : bd.ptri) + tj * 3;
+        const int t0 = tr[0], t1 = tr[1], t2 = tr[2];
+        double p3[3], a[3], bq[3], c[3], be[3], d, n[3], w;
+        if (kind == 0) {
+#pragma unroll
+          for (int i = 0; i < 3; ++i) { p3[i] = x[pi * 3 + i]; a[i] = xb[t0 * 3 + i]; bq[i] = xb[t1 * 3 + i]; c[i] = xb[t2 * 3 + i]; }
+          w = bd.parea[pi];
+        } else {
+#pragma unroll
+          for (int i = 0; i < 3; ++i) { p3[i] = xb[pi * 3 + i]; a[i] = x[t0 * 3 + i]; bq[i] = x[t1 * 3 + i]; c[i] = x[t2 * 3 + i]; }
+          w = bd.area[pi];
+        }
+        pt_closest(p3, a, bq, c, be, d, n);
+        if (!(d < dhat) || !(w > 0.0)) continue;
+        double bb, b1, b2;
+        barrier3(d / dhat, bb, b1, b2);
+        const double s = kk * w * b1 / dhat, wk = kk * w * b2 / (dhat * dhat);
+        double cq[4];
+        if (kind == 0) {
+#pragma unroll
+          for (int a4 = 0; a4 < 4; ++a4) cq[a4] = -(be[0] * bd.Y[t0 * 4 + a4] + be[1] * bd.Y[t1 * 4 + a4] + be[2] * bd.Y[t2 * 4 + a4]);
+        } else {
+#pragma unroll
+          for (int a4 = 0; a4 < 4; ++a4) cq[a4] = bd.Y[pi * 4 + a4];
+        }
+        // pad rows
+        const int prow[3] = {kind == 0 ? pi : t0, kind == 0 ? -1 : t1, kind == 0 ? -1 : t2};
+        const double pco[3] = {kind == 0 ? 1.0 : -be[0], kind == 0 ? 0.0 : -be[1], kind == 0 ? 0.0 : -be[2]};
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+          if (prow[r] < 0) continue;
+#pragma unroll
+          for (int i = 0; i < 3; ++i) {
+            atomicAdd(&vg[prow[r] * 3 + i], s * pco[r] * n[i]);
+#pragma unroll
+            for (int j = 0; j < 3; ++j) atomicAdd(&Dinv[(size_t)prow[r] * 9 + i * 3 + j], wk * pco[r] * pco[r] * n[i] * n[j]);
+          }
+        }
+        // ball rows
+#pragma unroll
+        for (int a4 = 0; a4 < 4; ++a4)
+#pragma unroll
+          for (int i = 0; i < 3; ++i) {
+            atomicAdd(&gb[a4 * 3 + i], s * cq[a4] * n[i]);
+#pragma unroll
+            for (int c4 = 0; c4 < 4; ++c4)
+#pragma unroll
+              for (int j = 0; j < 3; ++j) atomicAdd(&Bm[(a4 * 3 + i) * 12 + c4 * 3 + j], wk * cq[a4] * cq[c4] * n[i] * n[j]);
+          }
+        const int sl = atomicAdd(&n_act, 1);
+        if (sl < kBallMaxActive) {
+          double* rc = arec + (size_t)sl * kBallRec;
+          rc[0] = wk; rc[1] = n[0]; rc[2] = n[1]; rc[3] = n[2];
+          rc[4] = cq[0]; rc[5] = cq[1]; rc[6] = cq[2]; rc[7] = cq[3];
+          rc[8] = pco[0]; rc[9] = pco[1]; rc[10] = pco[2];
+          int* ri = reinterpret_cast<int*>(rc + 11);
+          ri[0] = prow[0]; ri[1] = prow[1]; ri[2] = prow[2];
+        }
+      }
+    }
+    __syncthreads();
+    if (n_act > kBallMaxActive) { if (tid == 0) { s_flags |= kBallFlagOverflow; n_act = kBallMaxActive; } }
+    // ---- ball rows: gradient, the block without the pairs (H.p) and with them (preconditioner, factored) ----
+    if (tid < 144) {
+      const int ra = tid / 12, ca = tid - ra * 12, a4 = ra / 3, i = ra - a4 * 3, c4 = ca / 3, j = ca - c4 * 3;
+      double v = (i == j) ? bd.S[a4 * 4 + c4] : 0.0;
+      if (a4 > 0 && c4 > 0) {  // 4 kappa vol dt^2 [delta_mn A A^T + c_n c_m^T], m = a4 - 1, n = c4 - 1
+        const int mm = a4 - 1, nn = c4 - 1;
+        double blk = qs[3 + nn * 3 + i] * qs[3 + mm * 3 + j];
+        if (mm == nn) blk += qs[3 + i] * qs[3 + j] + qs[6 + i] * qs[6 + j] + qs[9 + i] * qs[9 + j];
+        v += dt2 * 4.0 * bd.kv * blk;
+      }
+      if (i == 2 && j == 2) v += YY[a4 * 4 + c4];
+      B0[tid] = v;
+      Lc[tid] = v + Bm[tid];
+    }
+    if (tid < 12) {
+      const int a4 = tid / 3, i = tid - a4 * 3;
+      double g = 0.0;
+#pragma unroll
+      for (int c4 = 0; c4 < 4; ++c4) g += bd.S[a4 * 4 + c4] * (qs[c4 * 3 + i] - qts[c4 * 3 + i]);
+      if (a4 > 0) {
+        const int mm = a4 - 1;
+        double go = 0.0;
+        for (int l = 0; l < 3; ++l) {
+          const double r = qs[3 + mm * 3] * qs[3 + l * 3] + qs[4 + mm * 3] * qs[4 + l * 3] + qs[5 + mm * 3] * qs[5 + l * 3] - (mm == l ? 1.0 : 0.0);
+          go += r * qs[3 + l * 3 + i];
+        }
+        g += dt2 * 4.0 * bd.kv * go;
+      }
+      vg[V * 3 + tid] = g + gb[tid];
+    }
+    __syncthreads();
+    if (tid == 0) {  // Cholesky of the 12 x 12 block in place (lower triangle)
+      for (int j = 0; j < 12; ++j) {
+        double s = Lc[j * 12 + j];
+        for (int k = 0; k < j; ++k) s -= Lc[j * 12 + k] * Lc[j * 12 + k];
+        s = s > 0.0 ? sqrt(s) : sqrt(fmax(bd.S[0], 1e-300));  // (the block is SPD by construction: S (x) I is, the rest is PSD)
+        Lc[j * 12 + j] = s;
+        for (int i = j + 1; i < 12; ++i) {
+          double t = Lc[i * 12 + j];
+          for (int k = 0; k < j; ++k) t -= Lc[i * 12 + k] * Lc[j * 12 + k];
+          Lc[i * 12 + j] = t / s;
+        }
+      }
+    }
+    if (mode == 1) {  // terms only
+      __syncthreads();
+      const double E = energy(x, qs, xb);
+      if (tid == 0 && e_out) e_out[b] = E;
+      if (g_out)
+        for (int k = tid; k < 3 * VN; k += NT) g_out[(size_t)b * 3 * VN + k] = vg[k];
+      if (tid == 0 && step_info) step_info[(size_t)b * 4 + 2] = (double)s_flags;
+      return;
+    }
+    // pad blocks -> inverses
+    for (int v = tid; v < V; v += NT) {
+      double D[9], Di3[9];
+#pragma unroll
+      for (int k = 0; k < 9; ++k) D[k] = Dinv[(size_t)v * 9 + k];
+      if (!inv3_spd(D, Di3)) {
+        const double im = 1.0 / (m.mass[v] * (1.0 + ((cons && cons[v]) ? m.strength : 0.0)));
+        Di3[0] = im; Di3[1] = 0; Di3[2] = 0; Di3[3] = 0; Di3[4] = im; Di3[5] = 0; Di3[6] = 0; Di3[7] = 0; Di3[8] = im;
+      }
+#pragma unroll
+      for (int k = 0; k < 9; ++k) Dinv[(size_t)v * 9 + k] = Di3[k];
+    }
+    for (int k = tid; k < 3 * VN; k += NT) { vr[k] = -vg[k]; vd[k] = 0.0; }
+    __syncthreads();
+    // ---- PCG ----
+    double rz = precondition(vr, vz);
+    for (int k = tid; k < 3 * VN; k += NT) vp[k] = vz[k];
+    const double rz0 = rz;
+    int it = 0;
+    __syncthreads();
+    while (it < pcg_max_iter && rz0 > 0.0 && rz > pcg_tol_rate * rz0) {
+      for (int t = tid; t < T; t += NT) {
+        int v[4];
+        double Di[9], dF[9], dP[9], r[12];
+        load_tet(m, t, v, Di);
+        deformation_gradient(vp, v, Di, dF);
+        TetState s;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) s.F[k] = tc[(size_t)k * T + t];
+        {
+          double f0[3] = {s.F[0], s.F[3], s.F[6]}, f1[3] = {s.F[1], s.F[4], s.F[7]}, f2[3] = {s.F[2], s.F[5], s.F[8]};
+          double c0[3], c1[3], c2[3];
+          cross3(f1, f2, c0); cross3(f2, f0, c1); cross3(f0, f1, c2);
+#pragma unroll
+          for (int i = 0; i < 3; ++i) { s.C[i * 3 + 0] = c0[i]; s.C[i * 3 + 1] = c1[i]; s.C[i * 3 + 2] = c2[i]; }
+        }
+        s.a = tc[(size_t)9 * T + t]; s.b = tc[(size_t)10 * T + t]; s.c = tc[(size_t)11 * T + t];
+        apply_dP(m, s, dF, dP);
+        shape_rows(Di, r);
+        const double sc = dt2 * m.vol[t];
+#pragma unroll
+        for (int w4 = 0; w4 < 4; ++w4)
+#pragma unroll
+          for (int i = 0; i < 3; ++i)
+            hv[(size_t)(w4 * 3 + i) * T + t] = sc * (dP[i * 3 + 0] * r[w4 * 3 + 0] + dP[i * 3 + 1] * r[w4 * 3 + 1] + dP[i * 3 + 2] * r[w4 * 3 + 2]);
+      }
+      __syncthreads();
+      for (int v = tid; v < V; v += NT) {
+        double a3[3];
+        gather_vertex(m, hv, v, a3);
+        const double md = m.mass[v] * (1.0 + ((cons && cons[v]) ? m.strength : 0.0));
+#pragma unroll
+        for (int i = 0; i < 3; ++i) vHp[v * 3 + i] = a3[i] + md * vp[v * 3 + i] + (i == 2 ? cbp[v] * vp[v * 3 + 2] : 0.0);
+      }
+      if (tid < 12) {
+        double s = 0.0;
+        for (int k = 0; k < 12; ++k) s += B0[tid * 12 + k] * vp[V * 3 + k];
+        vHp[V * 3 + tid] = s;
+      }
+      __syncthreads();
+      {
+        const int na = n_act;
+        for (int k = tid; k < na; k += NT) {
+          const double* rc = arec + (size_t)k * kBallRec;
+          const int* ri = reinterpret_cast<const int*>(rc + 11);
+          const double n0 = rc[1], n1 = rc[2], n2 = rc[3];
+          double gp = 0.0;
+#pragma unroll
+          for (int a4 = 0; a4 < 4; ++a4) gp += rc[4 + a4] * (n0 * vp[(V + a4) * 3] + n1 * vp[(V + a4) * 3 + 1] + n2 * vp[(V + a4) * 3 + 2]);
+#pragma unroll
+          for (int r = 0; r < 3; ++r)
+            if (ri[r] >= 0) gp += rc[8 + r] * (n0 * vp[ri[r] * 3] + n1 * vp[ri[r] * 3 + 1] + n2 * vp[ri[r] * 3 + 2]);
+          const double f = rc[0] * gp;
+#pragma unroll
+          for (int a4 = 0; a4 < 4; ++a4) {
+            atomicAdd(&vHp[(V + a4) * 3], f * rc[4 + a4] * n0);
+            atomicAdd(&vHp[(V + a4) * 3 + 1], f * rc[4 + a4] * n1);
+            atomicAdd(&vHp[(V + a4) * 3 + 2], f * rc[4 + a4] * n2);
+          }
+#pragma unroll
+          for (int r = 0; r < 3; ++r)
+            if (ri[r] >= 0) {
+              atomicAdd(&vHp[ri[r] * 3], f * rc[8 + r] * n0);
+              atomicAdd(&vHp[ri[r] * 3 + 1], f * rc[8 + r] * n1);
+              atomicAdd(&vHp[ri[r] * 3 + 2], f * rc[8 + r] * n2);
+            }
+        }
+      }
+      __syncthreads();
+      double part = 0.0;
+      for (int k = tid; k < 3 * VN; k += NT) part += vp[k] * vHp[k];
+      const double pHp = block_sum(part, sh);
+      if (!(pHp > 0.0)) {
+        if (it == 0)
+          for (int k = tid; k < 3 * VN; k += NT) vd[k] = vz[k];
+        break;
+      }
+      const double al = rz / pHp;
+      for (int k = tid; k < 3 * VN; k += NT) { vd[k] += al * vp[k]; vr[k] -= al * vHp[k]; }
+      __syncthreads();
+      const double rz_new = precondition(vr, vz);
+      const double beta = rz_new / rz;
+      for (int k = tid; k < 3 * VN; k += NT) vp[k] = vz[k] + beta * vp[k];
+      rz = rz_new;
+      ++it;
+      __syncthreads();
+    }
+    __syncthreads();
+    pcg_total += it;
+    // ---- step bound ----
+    if (tid < 12) rhs12[tid] = vd[V * 3 + tid];
+    __syncthreads();
+    ball_points(rhs12, dxb);
+    __syncthreads();
+    double amax = 1.0, vmax = 0.0, dmx = 0.0, dmc = 0.0;
+    for (int v = tid; v < V; v += NT) {
+      const double d0 = vd[v * 3], d1 = vd[v * 3 + 1], d2 = vd[v * 3 + 2];
+      dmx = fmax(dmx, fmax(fabs(d0), fmax(fabs(d1), fabs(d2))));
+      if (bd.parea[v] > 0.0) {
+        vmax = fmax(vmax, sqrt(d0 * d0 + d1 * d1 + d2 * d2));
+        const double gap = x[v * 3 + 2] - bd.gh;
+        if (bd.ground && d2 < 0.0 && gap > 0.0) amax = fmin(amax, kCcdSlack * gap / -d2);
+      }
+    }
+    for (int k = tid; k < nv; k += NT) {
+      const double d0 = dxb[k * 3], d1 = dxb[k * 3 + 1], d2 = dxb[k * 3 + 2];
+      vmax = fmax(vmax, sqrt(d0 * d0 + d1 * d1 + d2 * d2));
+      const double gap = xb[k * 3 + 2] - bd.gh;
+      if (bd.ground && d2 < 0.0 && gap > 0.0) amax = fmin(amax, kCcdSlack * gap / -d2);
+    }
+    if (tid < 3) dmx = fmax(dmx, fabs(vd[V * 3 + tid]));
+    if (tid >= 3 && tid < 12) dmc = fabs(vd[V * 3 + tid]);
+    vmax = block_sum_max(vmax, sh);
+    dmx = block_sum_max(dmx, sh);
+    dmc = block_sum_max(dmc, sh);
+    if (vmax > 0.0) amax = fmin(amax, kCcdSlack * R / (2.0 * vmax));
+    amax = -block_sum_max(-amax, sh);
+    {
+      double al = amax;
+      const int np = n_pairs;
+      for (int k = tid; k < np; k += NT) {
+        const int code = plist[k], kind = code >> 30, pi = (code >> 15) & 0x7fff, tj = code & 0x7fff;
+        const int* tr = (kind == 0 ? bd.tri : bd.ptri) + tj * 3;
+        double p3[3], trx[9], dp[3], dtr[9];
+        const double* P = kind == 0 ? x : xb;
+        const double* dP_ = kind == 0 ? vd : dxb;
+        const double* Tq = kind == 0 ? xb : x;
+        const double* dT = kind == 0 ? dxb : vd;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+          p3[i] = P[pi * 3 + i]; dp[i] = dP_[pi * 3 + i];
+#pragma unroll
+          for (int j = 0; j < 3; ++j) { trx[j * 3 + i] = Tq[tr[j] * 3 + i]; dtr[j * 3 + i] = dT[tr[j] * 3 + i]; }
+        }
+        double be[3], d, n[3];
+        pt_closest(p3, trx, trx + 3, trx + 6, be, d, n);
+        if (d < R) al = fmin(al, accd_pt(p3, trx, dp, dtr, al));
+      }
+      amax = -block_sum_max(-al, sh);
+    }
+    dmax_x = dmx; dmax_c = dmc;
+    // ---- backtracking line search (first E <= E0 wins; rescue halvings as in the other Newton kernels) ----
+    const double E0 = energy(x, qs, xb);
+    double step = amax, E1 = E0;
+    bool accepted = false;
+    const int ls_cap = ls_max_iter > kLsRescueStream ? ls_max_iter : kLsRescueStream;
+    for (int ls = 0; ls <= ls_cap; ++ls) {
+      for (int k = tid; k < 3 * V; k += NT) yc[k] = x[k] + step * vd[k];
+      if (tid < 12) rhs12[tid] = qs[tid] + step * vd[V * 3 + tid];
+      __syncthreads();
+      ball_points(rhs12, xbc);
+      __syncthreads();
+      const double Ec = energy(yc, rhs12, xbc);
+      if (Ec <= E0) { E1 = Ec; accepted = true; break; }
+      step *= 0.5;
+      __syncthreads();
+    }
+    ++n_newton;
+    if (accepted) {
+      for (int k = tid; k < 3 * V; k += NT) x[k] = yc[k];
+      for (int k = tid; k < 3 * nv; k += NT) xb[k] = xbc[k];
+      __syncthreads();
+      if (tid < 12) qs[tid] = rhs12[tid];
+    } else if (!(dmx <= dx_tol && dmc <= dc_tol)) {
+      if (tid == 0) s_flags |= kFemFlagLsFailed;
+      __syncthreads();
+      break;
+    }
+    __syncthreads();
+    if (dmx <= dx_tol && dmc <= dc_tol) break;
+  }
+  if (tid < 12) q[tid] = qs[tid];
+  if (tid == 0 && step_info) {
+    double* si = step_info + (size_t)b * 4;
+    si[0] = (double)n_newton; si[1] = fmax(dmax_x, dmax_c); si[2] = (double)s_flags; si[3] = (double)pcg_total;
+  }
+}
+
+// predictor / velocity of the ball rows (the pad's go through fem_predict_kernel / fem_velocity_kernel)
+__global__ __launch_bounds__(256) void fem_ball_predict_kernel(const double* __restrict__ q, const double* __restrict__ qv, double* __restrict__ qt,
+                                                               double* __restrict__ qprev, int B, double dt, double g0, double g1, double g2) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= B * 12) return;
+  const int r = k % 12;
+  const double g = r == 0 ? g0 : (r == 1 ? g1 : (r == 2 ? g2 : 0.0));  // gravity acts on the translation row p
+  qprev[k] = q[k];
+  qt[k] = q[k] + dt * qv[k] + dt * dt * g;
+}
+__global__ __launch_bounds__(256) void fem_ball_velocity_kernel(const double* __restrict__ q, const double* __restrict__ qprev, double* __restrict__ qv,
+                                                                int B, double inv_dt) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k < B * 12) qv[k] = (q[k] - qprev[k]) * inv_dt;
+}

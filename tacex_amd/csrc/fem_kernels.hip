@@ -1037,6 +1037,8 @@ __global__ __launch_bounds__(512) void fem_newton_kernel(FemDev m, double* xg, c
   }
 }
 
+#include "fem_ball.h"
+
 // ---- K17c: the same Newton iteration with the env's state resident on the CU ------------------------------------
 // fem_newton_kernel above streams ~700 KB per env and PCG iteration through HBM / L2 (cached tet state, per-tet H*p rows,
 // seven nodal vectors): 81 us per PCG iteration for 512 envs, bandwidth-bound.  Here
@@ -2370,6 +2372,7 @@ struct tacex_fem_ctx {
   bool follow_indenter = true;  // contact-following start of the Newton loop (tacex_fem_set_contact_following; fem_newton_lds_kernel)
   double* dx_dev = nullptr;  // optional (B,) last Newton update max|dx| per env: converged envs skip further iterations
   double dx_tol = 0.0;
+  tacex::BallDev ball{};     // the env's free affine body + ground (tacex_fem_set_affine_body); nv == 0: none
   std::vector<void*> allocs;
 };
 
@@ -2961,6 +2964,128 @@ int tacex_fem_step(tacex_fem_ctx* c, double* x, double* v, double* xt, const uin
   if (ind) { c->ind_prev_ws = ws; c->ind_prev_B = B; }
   e = hipGetLastError();
   return e == hipSuccess ? 0 : fail_hip(e, "fem_velocity_kernel");
+}
+
+// ---- the reference's UIPC scene: free affine-body ball + ground (fem_ball.h) ---------------------------------------------------------
+int tacex_fem_set_affine_body(tacex_fem_ctx* c, int num_verts, const double* verts_host, int num_tris, const int32_t* tris_host, double density,
+                              double kappa, const double* pad_vertex_area_host, int num_pad_tris, const int32_t* pad_tris_host, double d_hat,
+                              double stiffness, double ground_height, int enable_ground) {
+  if (!c) { set_error("tacex_fem_set_affine_body: null context"); return 2; }
+  bool synced = false;
+  BallDev& bd = c->ball;
+  fem_release(c, bd.Y, &synced); fem_release(c, bd.tri, &synced); fem_release(c, bd.area, &synced);
+  fem_release(c, bd.ptri, &synced); fem_release(c, bd.psv, &synced); fem_release(c, bd.parea, &synced);
+  bd = BallDev{};
+  if (num_verts == 0) return 0;  // remove the body
+  if (!verts_host || !tris_host || !pad_vertex_area_host || !pad_tris_host || num_verts < 4 || num_tris < 4 || num_pad_tris < 1) {
+    set_error("tacex_fem_set_affine_body: null / too small mesh argument");
+    return 2;
+  }
+  if (num_verts >= 32768 || num_tris >= 32768 || num_pad_tris >= 32768 || c->dev.V >= 32768) {
+    set_error("tacex_fem_set_affine_body: the pair list packs indices into 15 bits (meshes of < 32768 vertices / triangles)");
+    return 2;
+  }
+  if (!(density > 0.0) || !(kappa > 0.0) || !(d_hat > 0.0) || !(stiffness > 0.0)) { set_error("tacex_fem_set_affine_body: bad material / contact parameters"); return 2; }
+  const int V = c->dev.V;
+  std::vector<double> Y((size_t)num_verts * 4), area(num_verts, 0.0), parea(pad_vertex_area_host, pad_vertex_area_host + V);
+  std::vector<int> tri(tris_host, tris_host + (size_t)num_tris * 3), ptri(pad_tris_host, pad_tris_host + (size_t)num_pad_tris * 3), psv;
+  for (int t : tri) if (t < 0 || t >= num_verts) { set_error("tacex_fem_set_affine_body: triangle index out of range"); return 2; }
+  for (int t : ptri) if (t < 0 || t >= V) { set_error("tacex_fem_set_affine_body: pad triangle index out of range"); return 2; }
+  for (int k = 0; k < num_verts; ++k) { Y[k * 4] = 1.0; for (int i = 0; i < 3; ++i) Y[k * 4 + 1 + i] = verts_host[k * 3 + i]; }
+  // moments of the closed surface (signed tetrahedra against the origin), vertex areas - oracle/abd_oracle.py AffineBody
+  double S[16] = {}, vol = 0.0;
+  for (int t = 0; t < num_tris; ++t) {
+    const double* a = verts_host + (size_t)tri[t * 3] * 3; const double* b = verts_host + (size_t)tri[t * 3 + 1] * 3; const double* cc = verts_host + (size_t)tri[t * 3 + 2] * 3;
+    const double bc[3] = {b[1] * cc[2] - b[2] * cc[1], b[2] * cc[0] - b[0] * cc[2], b[0] * cc[1] - b[1] * cc[0]};
+    const double v6 = (a[0] * bc[0] + a[1] * bc[1] + a[2] * bc[2]) / 6.0;
+    vol += v6;
+    S[0] += v6;
+    const double sm[3] = {a[0] + b[0] + cc[0], a[1] + b[1] + cc[1], a[2] + b[2] + cc[2]};
+    for (int i = 0; i < 3; ++i) {
+      S[1 + i] += v6 * sm[i] / 4.0;
+      for (int j = 0; j < 3; ++j) S[(1 + i) * 4 + 1 + j] += v6 / 20.0 * (a[i] * a[j] + b[i] * b[j] + cc[i] * cc[j] + sm[i] * sm[j]);
+    }
+    const double e1[3] = {b[0] - a[0], b[1] - a[1], b[2] - a[2]}, e2[3] = {cc[0] - a[0], cc[1] - a[1], cc[2] - a[2]};
+    const double cr[3] = {e1[1] * e2[2] - e1[2] * e2[1], e1[2] * e2[0] - e1[0] * e2[2], e1[0] * e2[1] - e1[1] * e2[0]};
+    const double ta = 0.5 * sqrt(cr[0] * cr[0] + cr[1] * cr[1] + cr[2] * cr[2]);
+    for (int k = 0; k < 3; ++k) area[tri[t * 3 + k]] += ta / 3.0;
+  }
+  if (!(vol > 0.0)) { set_error("tacex_fem_set_affine_body: the surface triangles must be oriented outward (enclosed volume %g)", vol); return 2; }
+  for (int i = 1; i < 4; ++i) S[i * 4] = S[i];
+  for (int k = 0; k < 16; ++k) bd.S[k] = density * S[k];
+  for (int v = 0; v < V; ++v) if (parea[v] > 0.0) psv.push_back(v);
+  bd.nv = num_verts; bd.nt = num_tris; bd.npt = num_pad_tris; bd.nsv = (int)psv.size();
+  bd.kv = kappa * vol; bd.gh = ground_height; bd.dhat = d_hat; bd.kappa = stiffness; bd.ground = enable_ground ? 1 : 0;
+  if (int rc = fem_upload(c, Y, &bd.Y)) return rc;
+  if (int rc = fem_upload(c, tri, &bd.tri)) return rc;
+  if (int rc = fem_upload(c, area, &bd.area)) return rc;
+  if (int rc = fem_upload(c, ptri, &bd.ptri)) return rc;
+  if (int rc = fem_upload(c, psv, &bd.psv)) return rc;
+  if (int rc = fem_upload(c, parea, &bd.parea)) return rc;
+  return 0;
+}
+
+size_t tacex_fem_ball_workspace_bytes(const tacex_fem_ctx* c, int B) {
+  if (!c || B <= 0 || c->ball.nv == 0) return 0;
+  // env blocks | x_prev (B,V,3) | q_prev (B,12) | x~ (B,V,3) | q~ (B,12)
+  return ((size_t)B * ball_ws_doubles(c->dev.V, c->dev.T, c->ball.nv, c->ball.nt) + (size_t)B * 6 * c->dev.V + (size_t)B * 24 + 8) * sizeof(double);
+}
+
+int tacex_fem_ball_moments(const tacex_fem_ctx* c, double moments_out[16], double* kappa_vol_out) {
+  if (!c || c->ball.nv == 0 || !moments_out) { set_error("tacex_fem_ball_moments: no affine body set"); return 2; }
+  for (int k = 0; k < 16; ++k) moments_out[k] = c->ball.S[k];
+  if (kappa_vol_out) *kappa_vol_out = c->ball.kv;
+  return 0;
+}
+
+static int ball_args_ok(tacex_fem_ctx* c, const void* x, const void* q, const void* ws, const uint8_t* cons, const double* aim, const char* who) {
+  if (!c || !x || !q || !ws) { set_error("%s: null argument", who); return 2; }
+  if (c->ball.nv == 0) { set_error("%s: no affine body (tacex_fem_set_affine_body)", who); return 2; }
+  if ((cons == nullptr) != (aim == nullptr)) { set_error("%s: constrained_dev and aim_dev go together", who); return 2; }
+  return 0;
+}
+
+int tacex_fem_ball_terms(tacex_fem_ctx* c, const double* x, const double* xt, const double* q, const double* qt, const uint8_t* cons, const double* aim,
+                         double* energy, double* grad, double* step_info, void* ws, int B, void* stream) {
+  if (int rc = ball_args_ok(c, x, q, ws, cons, aim, "tacex_fem_ball_terms")) return rc;
+  if (!xt || !qt) { set_error("tacex_fem_ball_terms: null argument"); return 2; }
+  if (B <= 0) return 0;
+  hipLaunchKernelGGL(fem_ball_newton_kernel, dim3(B), dim3(512), 0, (hipStream_t)stream, c->dev, c->ball, const_cast<double*>(x), xt,
+                     const_cast<double*>(q), qt, cons, aim, static_cast<double*>(ws), 1, 1.0, 0, 1, 0.0, 0.0, step_info, 1, energy, grad);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : fail_hip(e, "fem_ball_newton_kernel(terms)");
+}
+
+int tacex_fem_ball_step(tacex_fem_ctx* c, double* x, double* v, double* q, double* qv, const uint8_t* cons, const double* aim, double* step_info,
+                        void* ws, int B, const double gravity[3], int max_newton, double velocity_tol, double transrate_tol, int pcg_max_iter,
+                        double pcg_tol_rate, int ls_max_iter, void* stream) {
+  if (int rc = ball_args_ok(c, x, q, ws, cons, aim, "tacex_fem_ball_step")) return rc;
+  if (!v || !qv || !step_info || !gravity) { set_error("tacex_fem_ball_step: null argument"); return 2; }
+  if (max_newton < 1 || pcg_max_iter < 1 || ls_max_iter < 0 || !(pcg_tol_rate > 0.0) || !(velocity_tol >= 0.0) || !(transrate_tol >= 0.0)) {
+    set_error("tacex_fem_ball_step: bad solver parameters");
+    return 2;
+  }
+  if (B <= 0) return 0;
+  hipStream_t st = (hipStream_t)stream;
+  const int V = c->dev.V;
+  const size_t n3 = (size_t)B * V * 3;
+  double* xprev = static_cast<double*>(ws) + (size_t)B * ball_ws_doubles(V, c->dev.T, c->ball.nv, c->ball.nt);
+  double* qprev = xprev + n3;
+  double* xt = qprev + (size_t)B * 12;
+  double* qt = xt + n3;
+  const double dt = c->dev.dt;
+  hipLaunchKernelGGL(fem_predict_kernel, dim3((unsigned)((n3 + 255) / 256)), dim3(256), 0, st, x, v, xt, xprev, static_cast<double*>(nullptr), n3, B, dt,
+                     gravity[0], gravity[1], gravity[2], static_cast<const double*>(nullptr), static_cast<double*>(nullptr), static_cast<double*>(nullptr), 0);
+  hipLaunchKernelGGL(fem_ball_predict_kernel, dim3((unsigned)((B * 12 + 255) / 256)), dim3(256), 0, st, q, qv, qt, qprev, B, dt, gravity[0], gravity[1],
+                     gravity[2]);
+  hipLaunchKernelGGL(fem_ball_newton_kernel, dim3(B), dim3(512), 0, st, c->dev, c->ball, x, xt, q, qt, cons, aim, static_cast<double*>(ws), pcg_max_iter,
+                     pcg_tol_rate, ls_max_iter, max_newton, velocity_tol * dt, transrate_tol * dt, step_info, 0, static_cast<double*>(nullptr),
+                     static_cast<double*>(nullptr));
+  hipLaunchKernelGGL(fem_velocity_kernel, dim3((unsigned)((n3 + 255) / 256)), dim3(256), 0, st, x, xprev, v, n3, 1.0 / dt, static_cast<const double*>(nullptr),
+                     static_cast<double*>(nullptr), B);
+  hipLaunchKernelGGL(fem_ball_velocity_kernel, dim3((unsigned)((B * 12 + 255) / 256)), dim3(256), 0, st, q, qprev, qv, B, 1.0 / dt);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : fail_hip(e, "tacex_fem_ball_step");
 }
 
 int tacex_fem_reset_envs(tacex_fem_ctx* c, const int32_t* env_ids, int num_reset, const double* positions, double* x, double* v,

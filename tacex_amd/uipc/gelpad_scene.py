@@ -156,3 +156,110 @@ class FemGelpad:
         ev = self._pending if (self.ms_log is not None and self._pending is not None) else self.ev
         ev[1].synchronize()
         return ev[0].elapsed_time(ev[1])
+
+
+def icosphere(radius: float, level: int = 2):
+    """(vertices (nv,3), triangles (nt,3), outward oriented): 12 / 42 / 162 / 642 vertices at level 0 / 1 / 2 / 3; turned so that a
+    vertex (and its antipode) lies on the z axis."""
+    t = (1.0 + 5.0**0.5) / 2.0
+    v = [(-1, t, 0), (1, t, 0), (-1, -t, 0), (1, -t, 0), (0, -1, t), (0, 1, t), (0, -1, -t), (0, 1, -t), (t, 0, -1), (t, 0, 1), (-t, 0, -1), (-t, 0, 1)]
+    f = [(0, 11, 5), (0, 5, 1), (0, 1, 7), (0, 7, 10), (0, 10, 11), (1, 5, 9), (5, 11, 4), (11, 10, 2), (10, 7, 6), (7, 1, 8),
+         (3, 9, 4), (3, 4, 2), (3, 2, 6), (3, 6, 8), (3, 8, 9), (4, 9, 5), (2, 4, 11), (6, 2, 10), (8, 6, 7), (9, 8, 1)]
+    v = [np.asarray(p, np.float64) / np.linalg.norm(p) for p in v]
+    for _ in range(level):
+        mid, nf = {}, []
+
+        def m(a, b):
+            key = (min(a, b), max(a, b))
+            if key not in mid:
+                p = v[a] + v[b]
+                v.append(p / np.linalg.norm(p))
+                mid[key] = len(v) - 1
+            return mid[key]
+
+        for a, b, c in f:
+            ab, bc, ca = m(a, b), m(b, c), m(c, a)
+            nf += [(a, ab, ca), (b, bc, ab), (c, ca, bc), (ab, bc, ca)]
+        f = nf
+    v = np.asarray(v)
+    a = v[0]
+    vx = np.cross(a, [0.0, 0.0, 1.0])
+    K = np.array([[0, -vx[2], vx[1]], [vx[2], 0, -vx[0]], [-vx[1], vx[0], 0]])
+    v = v @ (np.eye(3) + K + K @ K / (1.0 + a[2])).T
+    return v * radius, np.asarray(f, np.int32)
+
+
+class FemBallScene:
+    """The reference's own UIPC scene, one per env (scripts/benchmarking/tactile_sim_performance/envs/ball_rolling_uipc.py:71-125): the gelpad
+    (contact face DOWN, its back face held by the sensor case through soft position constraints, strength ratio 1000) over a FREE
+    affine-body ball (m_kappa 100 MPa, density 1e3) that lies on the ground plane (ground_height 0.001), contact zone d_hat = 5e-4.  The case
+    moves down and up (period 21 steps, 0.2 ... 0.8 mm of press over the envs): the pad squeezes the ball against the ground through the
+    pair barriers.  Stepped by `UipcSim.step` = `tacex_fem_ball_step` (csrc/fem_ball.h).  Same driver interface as FemGelpad
+    (`gelpad`, `sim`, `step(i)`, `flush()`, `ms_log`, `info_sum`, `iters_max`)."""
+
+    def __init__(self, B, dev, max_newton_iter: int = 64, side_stream: bool = False, mesh: tuple[int, int, int] = (8, 10, 4), radius: float = 0.009,
+                 level: int = 2, d_hat: float = 5e-4, ground_height: float = 0.001, ball_density: float = 1e3, cfg: UipcSimCfg | None = None,
+                 shift=(0.0008, 0.0005)):
+        self.stream = _side_stream(dev) if side_stream else None
+        self.max_newton_iter = max_newton_iter
+        P, T = gelpad_box_mesh(*mesh)
+        size = P.max(0) - P.min(0)
+        cfg = cfg if cfg is not None else UipcSimCfg(device=dev)
+        cfg.contact.d_hat, cfg.ground_height = float(d_hat), float(ground_height)
+        self.d_hat = float(d_hat)
+        # the pad turned by pi about x (a rotation: the tets keep their orientation): its contact face (z = max of the box) looks down
+        Pw = P * np.array([1.0, -1.0, -1.0]) + np.array([-size[0] / 2 + shift[0], size[1] / 2 + shift[1], 0.0])
+        zc = ground_height + d_hat * 1.0 + radius           # the ball starts just outside the ground's barrier zone and settles into it
+        Pw[:, 2] += zc + radius + 1.02 * d_hat - Pw[:, 2].min()  # the pad's face starts just outside the ball's
+        self.sim = UipcSim(cfg, num_envs=B)
+        self.gelpad = UipcObject(UipcObjectCfg(mesh_points=Pw, mesh_tets=T), self.sim)
+        vb, tb = icosphere(radius, level)
+        self.ball = UipcObject(UipcObjectCfg(mesh_points=vb, mesh_tris=tb, mass_density=ball_density, init_pos=(0.0, 0.0, zc),
+                                             constitution_cfg=UipcObjectCfg.AffineBodyConstitutionCfg()), self.sim)
+        self.sim.setup_sim(constraint_strength_ratio=1000.0)
+        self.num_tets, self.num_verts = len(T), len(Pw)
+        back = np.where(Pw[:, 2] > Pw[:, 2].max() - 1e-12)[0]
+        self._back = torch.from_numpy(back).to(dev)
+        self._aim0 = torch.from_numpy(Pw[back]).to(dev)[None].repeat(B, 1, 1).contiguous()
+        self._aim = self._aim0.clone()
+        self.depth = torch.linspace(0.0002, 0.0008, B, device=dev, dtype=torch.float64)
+        self.B = B
+        self.ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+        self.ms_log = None
+        self.info_sum = None
+        self.iters_max = None
+        self._pending = None
+
+    def step(self, i):
+        if self.stream is None:
+            return self._step(i)
+        cur = torch.cuda.current_stream(self.stream.device)
+        self.stream.wait_stream(cur)
+        with torch.cuda.stream(self.stream):
+            self._step(i)
+            if self.sim.step_done is None:
+                self.sim.step_done = torch.cuda.Event()
+            self.sim.step_done.record(self.stream)
+
+    def _step(self, i):
+        self.ev[0].record()
+        c = 0.5 - 0.5 * math.cos(0.3 * i)
+        torch.add(self._aim0[:, :, 2], self.depth[:, None], alpha=-c, out=self._aim[:, :, 2])
+        self.sim.set_constraints(self._back, self._aim)
+        self.sim.step(max_newton_iter=self.max_newton_iter)
+        self.ev[1].record()
+        if self.ms_log is not None and self.info_sum is not None:
+            self.info_sum += self.sim.step_info.mean(0)
+            self.iters_max = torch.maximum(self.iters_max, self.sim.step_info[:, 0].max()) if self.iters_max is not None else self.sim.step_info[:, 0].max()
+        if self.ms_log is not None:
+            if self._pending is not None:
+                self._pending[1].synchronize()
+                self.ms_log.append(self._pending[0].elapsed_time(self._pending[1]))
+            self._pending = self.ev
+            self.ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+
+    def flush(self):
+        if self.ms_log is not None and self._pending is not None:
+            self._pending[1].synchronize()
+            self.ms_log.append(self._pending[0].elapsed_time(self._pending[1]))
+            self._pending = None

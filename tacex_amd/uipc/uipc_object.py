@@ -1,7 +1,8 @@
 """`UipcObject` - a (batched) deformable tet-mesh object, counterpart of
 source/tacex_uipc/tacex_uipc/objects/uipc_object.py:49-88,95-243,442-470 for the gelpad use case:
-tet mesh + StableNeoHookean(youngs_poisson) + mass density.  AffineBody (rigid) objects, USD prims,
-wildmeshing and render-mesh updates of the reference are out of scope."""
+tet mesh + StableNeoHookean(youngs_poisson) + mass density, and - since round 6 - ONE free affine body per env
+(`AffineBodyConstitutionCfg`, uipc_object.py:62-74: the ball of the reference's ball-rolling UIPC scene) given by its closed surface mesh.
+USD prims, wildmeshing and render-mesh updates of the reference are out of scope."""
 from __future__ import annotations
 
 from pathlib import Path
@@ -53,7 +54,22 @@ class UipcObjectCfg:
     """(V,3) rest positions [m] (replaces the reference's TetMeshCfg / USD mesh look-up)."""
     mesh_tets: np.ndarray = None
     """(T,4) vertex indices."""
+    mesh_tris: np.ndarray = None
+    """(Nt,3) outward-oriented surface triangles - an affine body is given by its closed surface (the reference tet-meshes it with
+    wildmeshing and libuipc takes the surface of that, uipc_object.py:168-192); derived from `mesh_tets` when absent."""
     mass_density: float = 1e3
+    init_pos: tuple = (0.0, 0.0, 0.0)
+    """World position of the object's origin in every env (`init_state.pos` of the reference's AssetBaseCfg; affine bodies only - the gelpad's
+    mesh points are world coordinates)."""
+
+    @configclass
+    class AffineBodyConstitutionCfg:
+        """uipc_object.py:62-74."""
+
+        m_kappa: float = 100.0
+        """Stiffness of the body in [MPa] (100 MPa = hard rubber): weight of the orthogonality energy kappa * vol * |A^T A - I|^2"""
+        kinematic: bool = False
+        """True: the body's degrees of freedom are fixed (not supported here: a prescribed body is `UipcSim.set_contact_indenters` / `set_indenter_mesh`)."""
 
     @configclass
     class StableNeoHookeanCfg:
@@ -69,13 +85,18 @@ class UipcObject:
     """Holds the mesh + material of one deformable object replicated over all envs of a UipcSim."""
 
     def __init__(self, cfg: UipcObjectCfg, uipc_sim=None):
-        if cfg.mesh_points is None or cfg.mesh_tets is None:
-            raise ValueError("UipcObjectCfg.mesh_points / mesh_tets are required")
+        self.is_affine_body = isinstance(cfg.constitution_cfg, UipcObjectCfg.AffineBodyConstitutionCfg)
+        if cfg.mesh_points is None or (cfg.mesh_tets is None and not (self.is_affine_body and cfg.mesh_tris is not None)):
+            raise ValueError("UipcObjectCfg.mesh_points / mesh_tets are required (an affine body may give mesh_tris instead of mesh_tets)")
         self.cfg = cfg
         self.points = np.ascontiguousarray(cfg.mesh_points, dtype=np.float64)
-        self.tets = np.ascontiguousarray(cfg.mesh_tets, dtype=np.int32)
+        self.tets = np.ascontiguousarray(cfg.mesh_tets if cfg.mesh_tets is not None else np.zeros((0, 4)), dtype=np.int32)
         if self.points.ndim != 2 or self.points.shape[1] != 3 or self.tets.ndim != 2 or self.tets.shape[1] != 4:
             raise ValueError("mesh_points must be (V,3) and mesh_tets (T,4)")
+        if self.is_affine_body:
+            if cfg.constitution_cfg.kinematic:
+                raise NotImplementedError("kinematic affine bodies: prescribe the body with UipcSim.set_contact_indenters / set_indenter_mesh instead")
+            self.tris = np.ascontiguousarray(cfg.mesh_tris if cfg.mesh_tris is not None else self.surface_triangles(), dtype=np.int32)
         self._uipc_sim = uipc_sim
         if uipc_sim is not None:
             uipc_sim.uipc_objects.append(self)

@@ -3,7 +3,9 @@
 The reference wraps libuipc (one scene, num_envs = 1 in practice, docs/source/showcases/ball_rolling.md:23) and
 calls `world.advance(); world.retrieve()` (uipc_sim.py:250-252).  Here the Newton loop of that advance - element
 gradient/Hessian work, PCG and line search - runs in HIP for `num_envs` independent copies of the gelpad.
-Contact (IPC barrier / CCD), affine bodies and the ground of libuipc are out of scope.
+IPC contact against prescribed indenters (analytic / one rigid mesh) since rounds 2-5; since round 6 also the reference's own UIPC
+scene - ONE free affine-body ball per env on the ground plane under the gelpad, point-triangle pairs in both directions
+(`UipcObjectCfg.AffineBodyConstitutionCfg`, `UipcSimCfg.ground_height`; csrc/fem_ball.h).
 """
 from __future__ import annotations
 
@@ -123,9 +125,11 @@ class UipcSim:
 
     # -- uipc_sim.py:228-248 -------------------------------------------------------------------------------
     def setup_sim(self, constraint_strength_ratio: float | None = None):
-        if len(self.uipc_objects) != 1:
-            raise RuntimeError("this build steps exactly one deformable object (the gelpad) per environment")
-        obj = self.uipc_objects[0]
+        soft = [o for o in self.uipc_objects if not getattr(o, "is_affine_body", False)]
+        body = [o for o in self.uipc_objects if getattr(o, "is_affine_body", False)]
+        if len(soft) != 1 or len(body) > 1:
+            raise RuntimeError("this build steps exactly one deformable object (the gelpad) and at most one free affine body per environment")
+        obj = soft[0]
         _lib.require_gpu(self._dev_index)
         lib = _lib.load_library()
         p = _lib.FemParams()
@@ -158,6 +162,56 @@ class UipcSim:
         self.stats = torch.zeros((B, 4), dtype=torch.float64, device=dev)
         self._ws = torch.empty(lib.tacex_fem_workspace_bytes(h, B), dtype=torch.uint8, device=dev)
         self._g = torch.tensor(self.cfg.gravity, dtype=torch.float64, device=dev)
+        self._body = None
+        if body:
+            self._setup_affine_body(body[0])
+
+    # -- the reference's UIPC scene: a free affine body + the ground (ball_rolling_uipc.py:71-92, uipc_sim.py:192-201) ----------------
+    def _setup_affine_body(self, body):
+        """One free affine body per env (`UipcObjectCfg.AffineBodyConstitutionCfg`): q (num_envs,4,3) = (p, c_1, c_2, c_3), c_k the columns
+        of A, a surface point is p + sum_k X_k c_k.  Contact: the ground half-space z >= cfg.ground_height and every point-triangle pair
+        between the gelpad's surface and the body's closer than cfg.contact.d_hat (`tacex_fem_set_affine_body`)."""
+        if tuple(float(v) for v in self.cfg.ground_normal) != (0.0, 0.0, 1.0):
+            raise NotImplementedError("the ground of a scene with an affine body is the half-space z >= ground_height (ground_normal (0, 0, 1))")
+        obj, B, dev = self._obj, self.num_envs, self.device
+        c = self.cfg.contact
+        area = np.ascontiguousarray(obj.surface_vertex_areas(), np.float64)
+        ptri = np.ascontiguousarray(obj.surface_triangles(), np.int32)
+        verts = np.ascontiguousarray(body.points, np.float64)
+        tris = np.ascontiguousarray(body.tris, np.int32)
+        d_hat = float(c.d_hat)
+        _lib.check(self._lib.tacex_fem_set_affine_body(
+            self._handle, len(verts), verts.ctypes.data, len(tris), tris.ctypes.data, float(body.cfg.mass_density),
+            float(body.cfg.constitution_cfg.m_kappa) * 1e6, area.ctypes.data, len(ptri), ptri.ctypes.data, d_hat,
+            float(c.default_contact_resistance) * 1e9 * d_hat, float(self.cfg.ground_height), 1 if c.enable else 0), "tacex_fem_set_affine_body")
+        self._body = body
+        q0 = np.concatenate([np.asarray(body.cfg.init_pos, np.float64)[None], np.eye(3)], 0)
+        self.q = torch.from_numpy(q0).to(dev)[None].repeat(B, 1, 1).contiguous()  # (B,4,3) float64
+        self.qv = torch.zeros_like(self.q)
+        self._body_Y = torch.from_numpy(np.concatenate([np.ones((len(verts), 1)), verts], 1)).to(dev)
+        self._ball_ws = torch.empty(self._lib.tacex_fem_ball_workspace_bytes(self._handle, B), dtype=torch.uint8, device=dev)
+
+    def body_points(self, q=None) -> torch.Tensor:
+        """(num_envs, nv, 3) world positions of the affine body's surface vertices."""
+        q = self.q if q is None else q
+        return torch.einsum("va,bai->bvi", self._body_Y, q)
+
+    def ball_terms(self, x=None, q=None, x_tilde=None, q_tilde=None, constrained=True):
+        """Energy (num_envs,) and gradient (num_envs, V + 4, 3) of the step's incremental potential at (x, q) (`tacex_fem_ball_terms`)."""
+        x = self.x if x is None else x
+        q = self.q if q is None else q
+        xt = x if x_tilde is None else x_tilde
+        qt = q if q_tilde is None else q_tilde
+        B, V = x.shape[0], x.shape[1]
+        E = torch.empty((B,), dtype=torch.float64, device=self.device)
+        g = torch.empty((B, V + 4, 3), dtype=torch.float64, device=self.device)
+        si = torch.zeros((B, 4), dtype=torch.float64, device=self.device)
+        with torch.cuda.device(self.device):
+            rc = self._lib.tacex_fem_ball_terms(self._handle, _lib.ptr(x), _lib.ptr(xt), _lib.ptr(q), _lib.ptr(qt),
+                                                _lib.ptr(self.is_constrained) if constrained else 0, _lib.ptr(self.aim_position) if constrained else 0,
+                                                _lib.ptr(E), _lib.ptr(g), _lib.ptr(si), _lib.ptr(self._ball_ws), B, self._stream())
+        _lib.check(rc, "tacex_fem_ball_terms")
+        return E, g, si
 
     def __del__(self):
         try:
@@ -476,11 +530,20 @@ class UipcSim:
         counts and flags land in `self.step_info` (num_envs, 4) [newton_iterations, max |d|, flags, pcg_iterations]; reading
         `last_newton_iters` / `check_step()` is what synchronises, not the step."""
         n_max = self.cfg.newton.max_iter if max_newton_iter is None else int(max_newton_iter)
-        if self._precond_dirty:
-            self.refresh_preconditioner()
         if getattr(self, "step_info", None) is None:
             self.step_info = torch.zeros((self.num_envs, 4), dtype=torch.float64, device=self.device)
             self._g_host = (C.c_double * 3)(*[float(g) for g in self.cfg.gravity])
+        if self._body is not None:  # pad + free affine body + ground: csrc/fem_ball.h (its own preconditioner: no coarse space / chains)
+            with torch.cuda.device(self.device):
+                rc = self._lib.tacex_fem_ball_step(
+                    self._handle, _lib.ptr(self.x), _lib.ptr(self.v), _lib.ptr(self.q), _lib.ptr(self.qv), _lib.ptr(self.is_constrained),
+                    _lib.ptr(self.aim_position), _lib.ptr(self.step_info), _lib.ptr(self._ball_ws), self.num_envs, self._g_host, n_max,
+                    float(self.cfg.newton.velocity_tol), float(self.cfg.newton.transrate_tol), int(self.cfg.linear_system.max_iter),
+                    float(self.cfg.linear_system.tol_rate), int(self.cfg.line_search.max_iter), self._stream())
+            _lib.check(rc, "tacex_fem_ball_step")
+            return self.x
+        if self._precond_dirty:
+            self.refresh_preconditioner()
         with torch.cuda.device(self.device):
             rc = self._lib.tacex_fem_step(
                 self._handle, _lib.ptr(self.x), _lib.ptr(self.v), _lib.ptr(self.x_tilde), _lib.ptr(self.is_constrained),
@@ -527,7 +590,8 @@ class UipcSim:
         flags = si[:, 2].astype(np.int64)
         out = {"newton_iters": si[:, 0].astype(np.int64), "max_d": si[:, 1], "penetrating_envs": np.nonzero(flags & 1)[0],
                "line_search_failed_envs": np.nonzero(flags & 2)[0], "pcg_iters": si[:, 3].astype(np.int64),
-               "coarse_dropped_envs": np.nonzero(flags & 4)[0], "psd_safe_envs": np.nonzero(flags & 8)[0]}
+               "coarse_dropped_envs": np.nonzero(flags & 4)[0], "psd_safe_envs": np.nonzero(flags & 8)[0],
+               "pair_list_overflow_envs": np.nonzero(flags & 16)[0]}  # (affine-body scenes: a candidate list of csrc/fem_ball.h overflowed)
         if raise_on_penetration and len(out["penetrating_envs"]):
             raise RuntimeError(f"gelpad penetrated by its indenter in envs {out['penetrating_envs'][:8].tolist()}: the indenter moved by "
                                "more than the contact gap between two steps (see UipcSim.set_contact_indenters)")

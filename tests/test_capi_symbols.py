@@ -69,4 +69,8 @@ def test_product_never_imports_the_oracle():
         src = f.read_text()
         assert "import oracle" not in src and "from oracle" not in src, f
     for f in (REPO / "tacex_amd" / "csrc").glob("*"):
-        assert "oracle/" not in f.read_text() or f.name.endswith(".hip") and "see oracle/" in f.read_text()
+        # native sources may CITE the oracle (which restatement a kernel follows) in comments; nothing may include, open or run it
+        for ln in f.read_text().splitlines():
+            if "oracle/" in ln:
+                code = ln.split("//")[0]
+                assert "oracle/" not in code or code.lstrip().startswith(("*", "/*")), (f.name, ln)

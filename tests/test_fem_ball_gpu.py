@@ -1,0 +1,182 @@
+"""GPU parity tests of the reference's own UIPC scene (second slice: csrc/fem_ball.h through `UipcSim` with an
+`AffineBodyConstitutionCfg` object) against oracle/abd_oracle.py - PARITY UNPINNED like every FEM row (libuipc is not in the reference
+tree); the oracle pins itself in tests/test_abd_oracle.py."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _build(B=2, mesh=(6, 8, 2), R=0.006, level=1, press=4e-4, ground_gap=0.6, density=1e3, shift=(0.0005, 0.0005), dhat=5e-4, gh=0.001,
+           velocity_tol=None, tol_rate=None, transrate_tol=None):
+    """The same scene twice: `UipcSim` (HIP) and `BallScene` (oracle).  press: how far the pad's face sits inside the ball's barrier zone
+    (negative: outside); ground_gap: the ball's lowest point above the ground in units of d_hat."""
+    from oracle.abd_oracle import AffineBody, BallScene
+    from oracle.fem_oracle import FemModel
+    from tacex_amd.uipc import UipcObject, UipcObjectCfg, UipcSim, UipcSimCfg
+    from tacex_amd.uipc.gelpad_scene import icosphere
+    from tacex_amd.uipc.uipc_object import gelpad_box_mesh
+
+    P, T = gelpad_box_mesh(*mesh)
+    size = P.max(0) - P.min(0)
+    Pw = P * np.array([1.0, -1.0, -1.0]) + np.array([-size[0] / 2 + shift[0], size[1] / 2 + shift[1], 0.0])
+    zc = gh + dhat * ground_gap + R
+    Pw[:, 2] += zc + R + (dhat - press) - Pw[:, 2].min()
+    cfg = UipcSimCfg(device="cuda:0")
+    cfg.contact.d_hat, cfg.ground_height = dhat, gh
+    if velocity_tol is not None:
+        cfg.newton.velocity_tol = velocity_tol
+    if transrate_tol is not None:
+        cfg.newton.transrate_tol = transrate_tol
+    if tol_rate is not None:
+        cfg.linear_system.tol_rate = tol_rate
+        cfg.linear_system.max_iter = 4000
+    sim = UipcSim(cfg, num_envs=B)
+    pad = UipcObject(UipcObjectCfg(mesh_points=Pw, mesh_tets=T), sim)
+    vb, tb = icosphere(R, level)
+    UipcObject(UipcObjectCfg(mesh_points=vb, mesh_tris=tb, mass_density=density, init_pos=(0.0, 0.0, zc),
+                             constitution_cfg=UipcObjectCfg.AffineBodyConstitutionCfg()), sim)
+    sim.setup_sim(constraint_strength_ratio=1000.0)
+    back = np.where(Pw[:, 2] > Pw[:, 2].max() - 1e-12)[0]
+    sim.set_constraints(back, torch.from_numpy(np.repeat(Pw[None, back], B, 0)).cuda())
+    m = FemModel.build(Pw, T, youngs=pad.cfg.constitution_cfg.youngs_modulus * 1e6, poisson=pad.cfg.constitution_cfg.poisson_rate,
+                       density=pad.cfg.mass_density, dt=cfg.dt, strength=1000.0)
+    assert np.array_equal(m.tets, T)  # (a rotation keeps the orientation: the oracle re-orients nothing)
+    sc = BallScene(m, pad.surface_triangles(), pad.surface_vertex_areas(), AffineBody(vb, tb, density=density), dhat=dhat, ground_height=gh,
+                   resistance=cfg.contact.default_contact_resistance)
+    cons = np.zeros(len(Pw))
+    cons[back] = 1.0
+    return sim, sc, cons, back
+
+
+def _y(sim, b):
+    return np.concatenate([sim.x[b].cpu().numpy(), sim.q[b].cpu().numpy()], 0)
+
+
+def test_moments_of_the_ball_mesh_vs_oracle():
+    import ctypes as C
+
+    sim, sc, cons, back = _build()
+    S = (C.c_double * 16)()
+    kv = C.c_double()
+    from tacex_amd import _lib
+    _lib.check(sim._lib.tacex_fem_ball_moments(sim._handle, S, C.byref(kv)), "moments")
+    assert np.allclose(np.array(S).reshape(4, 4), sc.ball.S, rtol=1e-12, atol=1e-22)
+    assert kv.value == pytest.approx(sc.ball.kv, rel=1e-12)
+
+
+def test_energy_and_gradient_of_the_step_potential_vs_oracle():
+    """Every term at once, in a state with pad-vertex / ball-triangle pairs, ball-vertex / pad-triangle pairs, the ground under the ball,
+    a stretched and sheared body (orthogonality energy), velocities (inertia) and constraint offsets: energy to 1e-10 relative, the
+    gradient of all V + 4 rows to 1e-9 of its largest entry; env 1 is a second, different state."""
+    sim, sc, cons, back = _build()
+    V = sc.V
+    rng = np.random.default_rng(5)
+    y = [_y(sim, b) + 2e-5 * rng.standard_normal((V + 4, 3)) for b in range(2)]
+    y[1][V + 1:] += 1e-3 * rng.standard_normal((3, 3))
+    yt = [yy + 1e-5 * rng.standard_normal(yy.shape) for yy in y]
+    aim = sim.aim_position.cpu().numpy() + 1e-5
+    sim.aim_position.copy_(torch.from_numpy(aim).cuda())
+    k0 = sc.pairs(y[0])
+    assert len(k0[0][0]) >= 1 and len(k0[1][0]) >= 1
+    x = torch.from_numpy(np.stack([yy[:V] for yy in y])).cuda()
+    q = torch.from_numpy(np.stack([yy[V:] for yy in y])).cuda()
+    xt = torch.from_numpy(np.stack([yy[:V] for yy in yt])).cuda()
+    qt = torch.from_numpy(np.stack([yy[V:] for yy in yt])).cuda()
+    E, g, si = sim.ball_terms(x, q, xt, qt)
+    assert int(si[:, 2].max()) == 0
+    for b in range(2):
+        Eo = sc.energy(y[b], yt[b], cons, aim[b])
+        go = sc.gradient(y[b], yt[b], cons, aim[b])
+        assert abs(float(E[b]) - Eo) <= 1e-10 * abs(Eo), (b, float(E[b]), Eo)
+        gk = g[b].cpu().numpy()
+        assert np.abs(gk - go).max() <= 1e-9 * np.abs(go).max(), (b, np.abs(gk - go).max(), np.abs(go).max())
+
+
+def test_step_vs_oracle_step_from_outside_every_barrier_zone():
+    """Three backward-Euler steps of the back face moving down onto the ball (denser ball: tests/test_abd_oracle.py says why), both solvers
+    run to a tight tolerance: same end states (pad vertices and the ball's twelve unknowns) step by step, no ground or pair gap closed."""
+    sim, sc, cons, back = _build(B=2, press=-2e-5, ground_gap=1.02, density=1e5, shift=(0.0008, 0.0005), velocity_tol=1e-6, transrate_tol=1e-5,
+                                 tol_rate=1e-12)
+    V = sc.V
+    yo = [_y(sim, b) for b in range(2)]
+    vo = [np.zeros_like(yo[0]) for _ in range(2)]
+    aim0 = sim.aim_position.clone()
+    depth = np.array([5e-5, 8e-5])
+    for k in range(3):
+        aim = aim0.clone()
+        aim[:, :, 2] -= torch.from_numpy(depth * (k + 1)).cuda()[:, None]
+        sim.aim_position.copy_(aim)
+        sim.step(max_newton_iter=60)
+        info = sim.check_step()
+        assert len(info["penetrating_envs"]) == 0 and len(info["line_search_failed_envs"]) == 0 and len(info["pair_list_overflow_envs"]) == 0, info
+        assert info["newton_iters"].max() < 60
+        for b in range(2):
+            yo[b], vo[b], io = sc.step(yo[b], vo[b], cons, aim[b].cpu().numpy(), gravity=sim.cfg.gravity, max_newton=60, velocity_tol=1e-6,
+                                       transrate_tol=1e-5, pcg_max_iter=4000, pcg_tol_rate=1e-12)
+            assert io[0] < 60 and int(io[2]) == 0
+            yk = _y(sim, b)
+            assert np.abs(yk[:V + 1] - yo[b][:V + 1]).max() <= 2e-8, (k, b, np.abs(yk[:V + 1] - yo[b][:V + 1]).max())  # 1e-6 m/s * dt = 1e-8 m each
+            assert np.abs(yk[V + 1:] - yo[b][V + 1:]).max() <= 2e-7, (k, b)
+            assert (sc.ball.points(yk[V:])[:, 2] > sc.gh).all()
+    assert yo[0][V, 2] < sim.cfg.ground_height + 1.02 * 5e-4 + 0.006  # the ball was pushed into the ground's barrier zone
+    kinds = sc.pairs(_y(sim, 1))
+    assert len(kinds[0][0]) + len(kinds[1][0]) >= 1
+
+
+def test_reference_scene_at_default_tolerances_runs_clean_and_ends_stationary_when_solved_tightly():
+    """`FemBallScene` (what bench.py's c4_ball entry steps): the C4 pad over the reference's ball on the ground, a press-and-release period.
+    At the reference's default tolerances (uipc_sim.py:57-101) every env converges below the iteration cap with no flag; the ball ends
+    lower while pressed and the pad's face never crosses it.  And the end state of a tightly solved step is a stationary point of the
+    plain incremental potential (oracle gradient, no solver code shared): below 1e-5 of the largest pair force."""
+    from oracle.abd_oracle import AffineBody, BallScene
+    from oracle.fem_oracle import FemModel, barrier
+    from tacex_amd.uipc.gelpad_scene import FemBallScene
+    from tacex_amd.uipc.uipc_sim import UipcSimCfg
+
+    B = 4
+    sc_d = FemBallScene(B, "cuda:0", max_newton_iter=64)
+    z0 = sc_d.sim.q[:, 0, 2].clone()
+    zmin = z0.clone()
+    for i in range(12):
+        sc_d.step(i)
+        info = sc_d.sim.check_step()
+        assert len(info["penetrating_envs"]) == 0 and len(info["pair_list_overflow_envs"]) == 0, (i, info)
+        assert len(info["line_search_failed_envs"]) == 0 and info["newton_iters"].max() < 64, (i, info)
+        zmin = torch.minimum(zmin, sc_d.sim.q[:, 0, 2])
+        assert torch.isfinite(sc_d.sim.x).all() and torch.isfinite(sc_d.sim.q).all()
+    assert float((z0 - zmin).min()) > 1e-5  # every env's ball was pushed down (0.2 ... 0.8 mm of press against a barrier zone of 0.5 mm)
+    # tight solve of one more step, checked against the oracle's plain gradient
+    cfg = UipcSimCfg(device="cuda:0")
+    cfg.newton.velocity_tol, cfg.newton.transrate_tol, cfg.linear_system.tol_rate, cfg.linear_system.max_iter = 1e-7, 1e-6, 1e-12, 4000
+    t = FemBallScene(2, "cuda:0", max_newton_iter=200, cfg=cfg, ball_density=1e5)
+    sim, pad, ball = t.sim, t.gelpad, t.ball
+    m = FemModel.build(pad.points, pad.tets, youngs=pad.cfg.constitution_cfg.youngs_modulus * 1e6, poisson=pad.cfg.constitution_cfg.poisson_rate,
+                       density=pad.cfg.mass_density, dt=cfg.dt, strength=1000.0)
+    osc = BallScene(m, pad.surface_triangles(), pad.surface_vertex_areas(), AffineBody(ball.points, ball.tris, density=1e5), dhat=cfg.contact.d_hat,
+                    ground_height=cfg.ground_height, resistance=cfg.contact.default_contact_resistance)
+    worst = 0.0
+    for i in range(8):
+        y_n = [np.concatenate([sim.x[b].cpu().numpy(), sim.q[b].cpu().numpy()]) for b in range(2)]
+        v_n = [np.concatenate([sim.v[b].cpu().numpy(), sim.qv[b].cpu().numpy()]) for b in range(2)]
+        t.step(i)
+        info = sim.check_step()
+        assert info["newton_iters"].max() < 200 and int(sim.step_info[:, 2].max()) == 0, (i, info)
+        cons = sim.is_constrained[0].cpu().numpy().astype(np.float64)
+        for b in range(2):
+            yt = y_n[b] + cfg.dt * v_n[b]
+            g3 = cfg.dt**2 * np.asarray(cfg.gravity)
+            yt[:osc.V] += g3
+            yt[osc.V] += g3
+            y = np.concatenate([sim.x[b].cpu().numpy(), sim.q[b].cpu().numpy()])
+            g = osc.gradient(y, yt, cons, sim.aim_position[b].cpu().numpy())
+            (pi, pj, pw, pd, pn, pb), (bi, bj, bw, bd, bn, bb) = osc.pairs(y)
+            w, d = np.concatenate([pw, bw]), np.concatenate([pd, bd])
+            if len(d) == 0:
+                continue
+            scale = cfg.dt**2 * osc.kappa * np.abs(w * barrier(d / osc.dhat)[1] / osc.dhat).max()
+            worst = max(worst, np.abs(g).max() / scale)
+            assert np.abs(g).max() <= 1e-5 * scale, (i, b, np.abs(g).max(), scale)
+    assert worst > 0.0  # pairs were active in the tight run
+    print(f"worst |grad| / pair force over the tight run: {worst:.2e}")
