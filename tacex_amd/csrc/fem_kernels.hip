@@ -2848,16 +2848,25 @@ static int launch_newton(tacex_fem_ctx* c, double* x, const double* xt, const ui
   // threads per env: one per vertex, in steps of four waves (nwt_window_doubles); the wide variants are atomic-only and take analytic
   // indenters only (a mesh indenter or the deterministic switch on a mesh of more than 512 vertices: streaming kernel below)
   const int V = c->dev.V;
-  const int nt = V <= 512 ? 512 : 768;
+  // Meshes of <= 256 vertices run on 256 threads (round 6): ONE wave per SIMD with the whole 512-register file per lane (256 VGPRs + 74 AGPRs,
+  // ScratchSize 0) against two waves per SIMD and 356 B/lane of scratch on 512 threads - measured on a 210-vertex / 720-tet pad, same
+  // box, alternating: 0.248 / 0.249 against 0.294 / 0.290 ms per step of 512 envs (-15 %), 0.145 / 0.151 against 0.178 / 0.174 at 256
+  // envs (profiles/r06_experiments.md section 3).  TACEX_FEM_NT256=0 keeps 512 threads (A/B).  The C4 pad (495 vertices) cannot run
+  // it: a thread OWNS a vertex.
+  static const int nt256 = getenv("TACEX_FEM_NT256") ? atoi(getenv("TACEX_FEM_NT256")) : 1;
+  const int nt = (nt256 && V <= 256 && atom && !mesh) ? 256 : (V <= 512 ? 512 : 768);
   const size_t lds = nwt_lds_bytes(V, c->dev.T, fric, nt);
-  if (use_lds && V <= 768 && (nt == 512 ? 4 * c->dev.T < 65535 : (atom && !mesh)) && lds <= 160 * 1024) {
+  if (use_lds && V <= 768 && (nt <= 512 ? 4 * c->dev.T < 65535 : (atom && !mesh)) && lds <= 160 * 1024) {
     if (resident) *resident = true;
     c->last_resident = 1;
-    static size_t granted[5][64] = {};  // per kernel instantiation and device: the attribute is per kernel AND device
+    static size_t granted[6][64] = {};  // per kernel instantiation and device: the attribute is per kernel AND device
     using kern_t = decltype(&fem_newton_lds_kernel<false, true, 512>);
     kern_t kern;
     int slot;
-    if (nt == 512) {
+    if (nt == 256) {
+      kern = fem_newton_lds_kernel<false, true, 256>;
+      slot = 5;
+    } else if (nt == 512) {
       kern = mesh ? (atom ? fem_newton_lds_kernel<true, true, 512> : fem_newton_lds_kernel<true, false, 512>)
                   : (atom ? fem_newton_lds_kernel<false, true, 512> : fem_newton_lds_kernel<false, false, 512>);
       slot = (mesh ? 1 : 0) + (atom ? 2 : 0);

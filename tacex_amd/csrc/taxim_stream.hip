@@ -857,7 +857,13 @@ __global__ __launch_bounds__(64 * kStreamWaves, MINW) void taxim_stream_kernel(S
         else ring[ring_slot * 64 + lane] = (v4f){S[0], S[1], S[2], 0.0f};
         ring_slot = ring_slot + 1 == NRING ? 0 : ring_slot + 1;
       }
+#ifdef TACEX_STREAM_NO_CONTACT_STATS  // KNOCK-OUT probe (round 6, profiles/r06_experiments.md): the contact count / row sum / column counters are
+      // not accumulated (FOTS then sees no contact: timing only) and the mask is evaluated on marker rows alone - the upper bound of what
+      // moving the contact statistics into another kernel could take off the tail
+      if (do_fots && (ST || y >= r0) && y < r1 && a.pix_m != nullptr && ri_y.mk1 > ri_y.mk0) {
+#else
       if (do_fots && (ST || y >= r0) && y < r1) {
+#endif
         float gl[PX] = {0.f, 0.f, 0.f};
         if constexpr (!GZ) {
           const unsigned ro = (unsigned)row_of(y) * (unsigned)W;
@@ -876,8 +882,10 @@ __global__ __launch_bounds__(64 * kStreamWaves, MINW) void taxim_stream_kernel(S
             m = valid[i] && ((J - gl[i]) < thr) && (S[i] < 0.0f);  // TT:457-461
           }
           mrow[i] = m ? 1 : 0;
+#ifndef TACEX_STREAM_NO_CONTACT_STATS
           f_cpx[i] += m ? 1 : 0;
           row_cnt += __builtin_popcountll(__builtin_amdgcn_ballot_w64(m));
+#endif
         }
         f_cnt += row_cnt; f_sr += row_cnt * y;
         if (a.pix_m != nullptr && a.mk_vec) {  // contact mask at the FOTS marker pixels of this row

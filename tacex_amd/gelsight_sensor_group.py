@@ -102,6 +102,7 @@ class GelSightSensorGroup:
         W, H = self.core.camera_resolution
         self._depth = None  # (n*B, Hc, Wc) camera depth of all members, allocated when a member provides one
         self._served: set[int] = set()
+        self._inputs_dirty = False  # a member's depth / yaw was handed over since the last evaluation
         for i, s in enumerate(sensors):
             self._adopt(s, i)
 
@@ -143,6 +144,9 @@ class GelSightSensorGroup:
             raise RuntimeError(f"camera depth has shape {tuple(depth_m.shape)}, expected {tuple(buf.shape)} (num_envs, camera height, camera width)")
         if depth_m.data_ptr() != buf.data_ptr():
             buf.copy_(depth_m)
+        # (a producer that writes into camera_depth_buffer() in place hands nothing over: like a plain sensor's in-place depth, it is
+        #  read by whichever update evaluates next)
+        self._inputs_dirty = True
 
     # -- evaluation -------------------------------------------------------------------------------------------------------------------
     def _member_update(self, s: GelSightSensor, env_ids):
@@ -151,7 +155,11 @@ class GelSightSensorGroup:
         else:
             s._frame[env_ids.to(s._frame.device)] += 1
         i = s._group_index
-        if self._served and i not in self._served:
+        # ONE evaluation per step when every member's inputs are in place before the first member updates (depth sources / yaw sources
+        # are read here; a task that calls set_camera_depth() hands all depths over first).  A depth handed over AFTER the step's
+        # evaluation - member 0 set and updated, then member 1 set and updated - makes the next update evaluate again: joining would
+        # serve that member the frames rendered from its PREVIOUS depth.
+        if self._served and i not in self._served and not self._inputs_dirty:
             self._served.add(i)  # this step's evaluation already covered the member
             return
         for m in self.sensors:  # every member's depth source is read before the one evaluation of the step
@@ -163,6 +171,7 @@ class GelSightSensorGroup:
                 m.marker_motion_simulator.set_indenter_yaw(mm.yaw_source())
         self.core._update_buffers_impl(slice(None))
         self._served = {i}
+        self._inputs_dirty = False
 
     def _member_reset(self, s: GelSightSensor, env_ids):
         SensorBase.reset(s, env_ids)

@@ -211,6 +211,8 @@ class FemBallScene:
         Pw = P * np.array([1.0, -1.0, -1.0]) + np.array([-size[0] / 2 + shift[0], size[1] / 2 + shift[1], 0.0])
         zc = ground_height + d_hat * 1.0 + radius           # the ball starts just outside the ground's barrier zone and settles into it
         Pw[:, 2] += zc + radius + 1.02 * d_hat - Pw[:, 2].min()  # the pad's face starts just outside the ball's
+        # world = diag(1, -1, -1) pad + offset: the sensor camera of the upright pad (24 mm behind its back face, optical axis + z) turns with it
+        self.pad_offset = Pw[0] - P[0] * np.array([1.0, -1.0, -1.0])
         self.sim = UipcSim(cfg, num_envs=B)
         self.gelpad = UipcObject(UipcObjectCfg(mesh_points=Pw, mesh_tets=T), self.sim)
         vb, tb = icosphere(radius, level)
@@ -229,6 +231,11 @@ class FemBallScene:
         self.info_sum = None
         self.iters_max = None
         self._pending = None
+
+    def camera_pose(self, cam_pos_pad=(0.008, 0.012625, -0.024)):
+        """(position, ROS quaternion wxyz) of the sensor camera in this scene's world frame, given its position in the upright pad's frame."""
+        p = np.asarray(cam_pos_pad, np.float64) * np.array([1.0, -1.0, -1.0]) + self.pad_offset
+        return tuple(float(v) for v in p), (0.0, 1.0, 0.0, 0.0)
 
     def step(self, i):
         if self.stream is None:

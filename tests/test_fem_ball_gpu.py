@@ -42,7 +42,6 @@ def _build(B=2, mesh=(6, 8, 2), R=0.006, level=1, press=4e-4, ground_gap=0.6, de
     sim.set_constraints(back, torch.from_numpy(np.repeat(Pw[None, back], B, 0)).cuda())
     m = FemModel.build(Pw, T, youngs=pad.cfg.constitution_cfg.youngs_modulus * 1e6, poisson=pad.cfg.constitution_cfg.poisson_rate,
                        density=pad.cfg.mass_density, dt=cfg.dt, strength=1000.0)
-    assert np.array_equal(m.tets, T)  # (a rotation keeps the orientation: the oracle re-orients nothing)
     sc = BallScene(m, pad.surface_triangles(), pad.surface_vertex_areas(), AffineBody(vb, tb, density=density), dhat=dhat, ground_height=gh,
                    resistance=cfg.contact.default_contact_resistance)
     cons = np.zeros(len(Pw))
@@ -156,8 +155,8 @@ def test_reference_scene_at_default_tolerances_runs_clean_and_ends_stationary_wh
                        density=pad.cfg.mass_density, dt=cfg.dt, strength=1000.0)
     osc = BallScene(m, pad.surface_triangles(), pad.surface_vertex_areas(), AffineBody(ball.points, ball.tris, density=1e5), dhat=cfg.contact.d_hat,
                     ground_height=cfg.ground_height, resistance=cfg.contact.default_contact_resistance)
-    worst = 0.0
-    for i in range(8):
+    worst, checked = 0.0, 0
+    for i in range(10):
         y_n = [np.concatenate([sim.x[b].cpu().numpy(), sim.q[b].cpu().numpy()]) for b in range(2)]
         v_n = [np.concatenate([sim.v[b].cpu().numpy(), sim.qv[b].cpu().numpy()]) for b in range(2)]
         t.step(i)
@@ -173,10 +172,12 @@ def test_reference_scene_at_default_tolerances_runs_clean_and_ends_stationary_wh
             g = osc.gradient(y, yt, cons, sim.aim_position[b].cpu().numpy())
             (pi, pj, pw, pd, pn, pb), (bi, bj, bw, bd, bn, bb) = osc.pairs(y)
             w, d = np.concatenate([pw, bw]), np.concatenate([pd, bd])
-            if len(d) == 0:
+            scale = cfg.dt**2 * osc.kappa * np.abs(w * barrier(d / osc.dhat)[1] / osc.dhat).max() if len(d) else 0.0
+            if scale < 1e-6:  # (a pair that has only just entered the zone pushes with less than the round-off of the pad's elastic forces)
+                assert np.abs(g).max() <= 1e-11, (i, b, np.abs(g).max())
                 continue
-            scale = cfg.dt**2 * osc.kappa * np.abs(w * barrier(d / osc.dhat)[1] / osc.dhat).max()
+            checked += 1
             worst = max(worst, np.abs(g).max() / scale)
             assert np.abs(g).max() <= 1e-5 * scale, (i, b, np.abs(g).max(), scale)
-    assert worst > 0.0  # pairs were active in the tight run
+    assert checked >= 2  # states with real pair forces were among them
     print(f"worst |grad| / pair force over the tight run: {worst:.2e}")
