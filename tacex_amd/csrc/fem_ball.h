@@ -41,6 +41,7 @@ constexpr int kBallFlagOverflow = 16; // step_info flag: a candidate / pair list
 
 // workspace of one env (doubles): ge 12T | tc 12T | hv 12T | g r z p d Hp yc: 7 x 3 (V+4) | D / Dinv 9V | ground curvature V |
 //   xb 3nv | xbc 3nv | dxb 3nv | ball triangle spheres 4nt | pair list (ints) kBallMaxPairs / 2 | active records
+__host__ __device__ inline size_t ball_lds_bytes(int V) { return ((size_t)9 * V + 12) * sizeof(double); }
 __host__ __device__ inline size_t ball_ws_doubles(int V, int T, int nv, int nt) {
   return (size_t)36 * T + (size_t)21 * (V + 4) + (size_t)10 * V + (size_t)9 * nv + (size_t)4 * nt + kBallMaxPairs / 2 + (size_t)kBallMaxActive * kBallRec;
 }
@@ -117,8 +118,9 @@ __global__ __launch_bounds__(512) void fem_ball_newton_kernel(FemDev m, BallDev 
                                                               const uint8_t* consg, const double* aimg, double* wsg, int pcg_max_iter,
                                                               double pcg_tol_rate, int ls_max_iter, int max_newton, double dx_tol, double dc_tol,
                                                               double* step_info, int mode, double* e_out, double* g_out) {
+  extern __shared__ __attribute__((aligned(16))) double ball_lds[];  // x (V,3) | p (V + 4,3) | H.p accumulators (V,3): ball_lds_bytes()
   __shared__ double sh[17];
-  __shared__ double gb[12], Bm[144], B0[144], Lc[144], YY[16], qs[12], qts[12], rhs12[12];
+  __shared__ double gb[12], Bm[144], B0[144], Lc[144], Bi[144], YY[16], qs[12], qts[12], rhs12[12];
   __shared__ int n_cpv, n_cpt, n_cbv, n_pairs, n_act, s_flags;
   __shared__ int cpv[kBallMaxCand], cpt[kBallMaxCand], cbv[kBallMaxCand];
   const int b = blockIdx.x, tid = threadIdx.x, NT = blockDim.x;
@@ -137,8 +139,7 @@ __global__ __launch_bounds__(512) void fem_ball_newton_kernel(FemDev m, BallDev 
   double* vg = hv + (size_t)12 * T;
   double* vr = vg + (size_t)3 * VN;
   double* vz = vr + (size_t)3 * VN;
-  double* vp = vz + (size_t)3 * VN;
-  double* vd = vp + (size_t)3 * VN;
+  double* vd = vz + (size_t)3 * VN;  // (the PCG direction p lives in LDS: every tet gathers it)
   double* vHp = vd + (size_t)3 * VN;
   double* yc = vHp + (size_t)3 * VN;   // line-search candidate (pad rows | ball rows)
   double* Dinv = yc + (size_t)3 * VN;  // (V,9)
@@ -149,6 +150,9 @@ __global__ __launch_bounds__(512) void fem_ball_newton_kernel(FemDev m, BallDev 
   double* bts = dxb + (size_t)3 * nv;  // (nt,4) bounding sphere of every ball triangle at x
   int* plist = reinterpret_cast<int*>(bts + (size_t)4 * nt);  // (kBallMaxPairs) kind << 30 | point << 15 | triangle
   double* arec = reinterpret_cast<double*>(plist + kBallMaxPairs);
+  double* xs = ball_lds;           // (V,3) x of the iteration: the tet state is recomputed from it in every H.p (no cached F in HBM)
+  double* ps = xs + 3 * V;         // (V + 4,3) PCG direction
+  double* acc = ps + 3 * VN;       // (V,3) per-vertex sums of the tets' rows (ds_add_f64)
   const double dt2 = m.dt * m.dt, dhat = bd.dhat, kk = dt2 * bd.kappa;
   const double L = dhat * (1.0 + kCcdSlack * kBallReach), R = kBallReach * dhat;
 
@@ -251,19 +255,12 @@ __global__ __launch_bounds__(512) void fem_ball_newton_kernel(FemDev m, BallDev 
         part += r[v * 3 + i] * zz;
       }
     }
-    if (tid == 0) {
-      double yv[12];
-      for (int i = 0; i < 12; ++i) {
-        double s = r[V * 3 + i];
-        for (int k = 0; k < i; ++k) s -= Lc[i * 12 + k] * yv[k];
-        yv[i] = s / Lc[i * 12 + i];
-      }
-      for (int i = 11; i >= 0; --i) {
-        double s = yv[i];
-        for (int k = i + 1; k < 12; ++k) s -= Lc[k * 12 + i] * yv[k];
-        yv[i] = s / Lc[i * 12 + i];
-      }
-      for (int i = 0; i < 12; ++i) { z[V * 3 + i] = yv[i]; part += r[V * 3 + i] * yv[i]; }
+    if (tid < 12) {
+      double zz = 0.0;
+#pragma unroll
+      for (int k = 0; k < 12; ++k) zz += Bi[tid * 12 + k] * r[V * 3 + k];
+      z[V * 3 + tid] = zz;
+      part += r[V * 3 + tid] * zz;
     }
     return block_sum(part, sh);
   };
@@ -568,6 +565,21 @@ __global__ __launch_bounds__(512) void fem_ball_newton_kernel(FemDev m, BallDev 
         }
       }
     }
+    __syncthreads();
+    if (tid < 12) {  // column tid of the inverse: L L^T z = e_tid (twelve independent solves; applied by twelve dot products per PCG iteration)
+      double yv[12];
+      for (int i = 0; i < 12; ++i) {
+        double sv = i == tid ? 1.0 : 0.0;
+        for (int k = 0; k < i; ++k) sv -= Lc[i * 12 + k] * yv[k];
+        yv[i] = sv / Lc[i * 12 + i];
+      }
+      for (int i = 11; i >= 0; --i) {
+        double sv = yv[i];
+        for (int k = i + 1; k < 12; ++k) sv -= Lc[k * 12 + i] * yv[k];
+        yv[i] = sv / Lc[i * 12 + i];
+      }
+      for (int i = 0; i < 12; ++i) Bi[i * 12 + tid] = yv[i];
+    }
     if (mode == 1) {  // terms only
       __syncthreads();
       const double E = energy(x, qs, xb);
@@ -591,29 +603,24 @@ __global__ __launch_bounds__(512) void fem_ball_newton_kernel(FemDev m, BallDev 
     }
     for (int k = tid; k < 3 * VN; k += NT) { vr[k] = -vg[k]; vd[k] = 0.0; }
     __syncthreads();
-    // ---- PCG ----
+    // ---- PCG: x and p in LDS, the tets' rows added into per-vertex LDS accumulators (no per-tet arrays through HBM) ----
+    for (int k = tid; k < 3 * V; k += NT) xs[k] = x[k];
     double rz = precondition(vr, vz);
-    for (int k = tid; k < 3 * VN; k += NT) vp[k] = vz[k];
+    for (int k = tid; k < 3 * VN; k += NT) ps[k] = vz[k];
     const double rz0 = rz;
     int it = 0;
     __syncthreads();
     while (it < pcg_max_iter && rz0 > 0.0 && rz > pcg_tol_rate * rz0) {
+      for (int k = tid; k < 3 * V; k += NT) acc[k] = 0.0;
+      __syncthreads();
       for (int t = tid; t < T; t += NT) {
         int v[4];
-        double Di[9], dF[9], dP[9], r[12];
+        double Di[9], F[9], dF[9], dP[9], r[12];
         load_tet(m, t, v, Di);
-        deformation_gradient(vp, v, Di, dF);
+        deformation_gradient(xs, v, Di, F);
         TetState s;
-#pragma unroll
-        for (int k = 0; k < 9; ++k) s.F[k] = tc[(size_t)k * T + t];
-        {
-          double f0[3] = {s.F[0], s.F[3], s.F[6]}, f1[3] = {s.F[1], s.F[4], s.F[7]}, f2[3] = {s.F[2], s.F[5], s.F[8]};
-          double c0[3], c1[3], c2[3];
-          cross3(f1, f2, c0); cross3(f2, f0, c1); cross3(f0, f1, c2);
-#pragma unroll
-          for (int i = 0; i < 3; ++i) { s.C[i * 3 + 0] = c0[i]; s.C[i * 3 + 1] = c1[i]; s.C[i * 3 + 2] = c2[i]; }
-        }
-        s.a = tc[(size_t)9 * T + t]; s.b = tc[(size_t)10 * T + t]; s.c = tc[(size_t)11 * T + t];
+        tet_state(m, F, s);
+        deformation_gradient(ps, v, Di, dF);
         apply_dP(m, s, dF, dP);
         shape_rows(Di, r);
         const double sc = dt2 * m.vol[t];
@@ -621,20 +628,18 @@ __global__ __launch_bounds__(512) void fem_ball_newton_kernel(FemDev m, BallDev 
         for (int w4 = 0; w4 < 4; ++w4)
 #pragma unroll
           for (int i = 0; i < 3; ++i)
-            hv[(size_t)(w4 * 3 + i) * T + t] = sc * (dP[i * 3 + 0] * r[w4 * 3 + 0] + dP[i * 3 + 1] * r[w4 * 3 + 1] + dP[i * 3 + 2] * r[w4 * 3 + 2]);
+            atomicAdd(&acc[v[w4] * 3 + i], sc * (dP[i * 3 + 0] * r[w4 * 3 + 0] + dP[i * 3 + 1] * r[w4 * 3 + 1] + dP[i * 3 + 2] * r[w4 * 3 + 2]));
       }
       __syncthreads();
       for (int v = tid; v < V; v += NT) {
-        double a3[3];
-        gather_vertex(m, hv, v, a3);
         const double md = m.mass[v] * (1.0 + ((cons && cons[v]) ? m.strength : 0.0));
 #pragma unroll
-        for (int i = 0; i < 3; ++i) vHp[v * 3 + i] = a3[i] + md * vp[v * 3 + i] + (i == 2 ? cbp[v] * vp[v * 3 + 2] : 0.0);
+        for (int i = 0; i < 3; ++i) vHp[v * 3 + i] = acc[v * 3 + i] + md * ps[v * 3 + i] + (i == 2 ? cbp[v] * ps[v * 3 + 2] : 0.0);
       }
       if (tid < 12) {
-        double s = 0.0;
-        for (int k = 0; k < 12; ++k) s += B0[tid * 12 + k] * vp[V * 3 + k];
-        vHp[V * 3 + tid] = s;
+        double sv = 0.0;
+        for (int k = 0; k < 12; ++k) sv += B0[tid * 12 + k] * ps[V * 3 + k];
+        vHp[V * 3 + tid] = sv;
       }
       __syncthreads();
       {
@@ -645,10 +650,10 @@ __global__ __launch_bounds__(512) void fem_ball_newton_kernel(FemDev m, BallDev 
           const double n0 = rc[1], n1 = rc[2], n2 = rc[3];
           double gp = 0.0;
 #pragma unroll
-          for (int a4 = 0; a4 < 4; ++a4) gp += rc[4 + a4] * (n0 * vp[(V + a4) * 3] + n1 * vp[(V + a4) * 3 + 1] + n2 * vp[(V + a4) * 3 + 2]);
+          for (int a4 = 0; a4 < 4; ++a4) gp += rc[4 + a4] * (n0 * ps[(V + a4) * 3] + n1 * ps[(V + a4) * 3 + 1] + n2 * ps[(V + a4) * 3 + 2]);
 #pragma unroll
           for (int r = 0; r < 3; ++r)
-            if (ri[r] >= 0) gp += rc[8 + r] * (n0 * vp[ri[r] * 3] + n1 * vp[ri[r] * 3 + 1] + n2 * vp[ri[r] * 3 + 2]);
+            if (ri[r] >= 0) gp += rc[8 + r] * (n0 * ps[ri[r] * 3] + n1 * ps[ri[r] * 3 + 1] + n2 * ps[ri[r] * 3 + 2]);
           const double f = rc[0] * gp;
 #pragma unroll
           for (int a4 = 0; a4 < 4; ++a4) {
@@ -667,7 +672,7 @@ __global__ __launch_bounds__(512) void fem_ball_newton_kernel(FemDev m, BallDev 
       }
       __syncthreads();
       double part = 0.0;
-      for (int k = tid; k < 3 * VN; k += NT) part += vp[k] * vHp[k];
+      for (int k = tid; k < 3 * VN; k += NT) part += ps[k] * vHp[k];
       const double pHp = block_sum(part, sh);
       if (!(pHp > 0.0)) {
         if (it == 0)
@@ -675,11 +680,11 @@ __global__ __launch_bounds__(512) void fem_ball_newton_kernel(FemDev m, BallDev 
         break;
       }
       const double al = rz / pHp;
-      for (int k = tid; k < 3 * VN; k += NT) { vd[k] += al * vp[k]; vr[k] -= al * vHp[k]; }
+      for (int k = tid; k < 3 * VN; k += NT) { vd[k] += al * ps[k]; vr[k] -= al * vHp[k]; }
       __syncthreads();
       const double rz_new = precondition(vr, vz);
       const double beta = rz_new / rz;
-      for (int k = tid; k < 3 * VN; k += NT) vp[k] = vz[k] + beta * vp[k];
+      for (int k = tid; k < 3 * VN; k += NT) ps[k] = vz[k] + beta * ps[k];
       rz = rz_new;
       ++it;
       __syncthreads();

@@ -3059,7 +3059,8 @@ int tacex_fem_ball_terms(tacex_fem_ctx* c, const double* x, const double* xt, co
   if (int rc = ball_args_ok(c, x, q, ws, cons, aim, "tacex_fem_ball_terms")) return rc;
   if (!xt || !qt) { set_error("tacex_fem_ball_terms: null argument"); return 2; }
   if (B <= 0) return 0;
-  hipLaunchKernelGGL(fem_ball_newton_kernel, dim3(B), dim3(512), 0, (hipStream_t)stream, c->dev, c->ball, const_cast<double*>(x), xt,
+  if (ball_lds_bytes(c->dev.V) > 48 * 1024) { set_error("tacex_fem_ball_terms: pad of %d vertices (the kernel keeps x, p and the H.p accumulators of <= 680 vertices in LDS)", c->dev.V); return 2; }
+  hipLaunchKernelGGL(fem_ball_newton_kernel, dim3(B), dim3(512), ball_lds_bytes(c->dev.V), (hipStream_t)stream, c->dev, c->ball, const_cast<double*>(x), xt,
                      const_cast<double*>(q), qt, cons, aim, static_cast<double*>(ws), 1, 1.0, 0, 1, 0.0, 0.0, step_info, 1, energy, grad);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : fail_hip(e, "fem_ball_newton_kernel(terms)");
@@ -3087,7 +3088,8 @@ int tacex_fem_ball_step(tacex_fem_ctx* c, double* x, double* v, double* q, doubl
                      gravity[0], gravity[1], gravity[2], static_cast<const double*>(nullptr), static_cast<double*>(nullptr), static_cast<double*>(nullptr), 0);
   hipLaunchKernelGGL(fem_ball_predict_kernel, dim3((unsigned)((B * 12 + 255) / 256)), dim3(256), 0, st, q, qv, qt, qprev, B, dt, gravity[0], gravity[1],
                      gravity[2]);
-  hipLaunchKernelGGL(fem_ball_newton_kernel, dim3(B), dim3(512), 0, st, c->dev, c->ball, x, xt, q, qt, cons, aim, static_cast<double*>(ws), pcg_max_iter,
+  if (ball_lds_bytes(c->dev.V) > 48 * 1024) { set_error("tacex_fem_ball_step: pad of %d vertices (the kernel keeps x, p and the H.p accumulators of <= 680 vertices in LDS)", c->dev.V); return 2; }
+  hipLaunchKernelGGL(fem_ball_newton_kernel, dim3(B), dim3(512), ball_lds_bytes(c->dev.V), st, c->dev, c->ball, x, xt, q, qt, cons, aim, static_cast<double*>(ws), pcg_max_iter,
                      pcg_tol_rate, ls_max_iter, max_newton, velocity_tol * dt, transrate_tol * dt, step_info, 0, static_cast<double*>(nullptr),
                      static_cast<double*>(nullptr));
   hipLaunchKernelGGL(fem_velocity_kernel, dim3((unsigned)((n3 + 255) / 256)), dim3(256), 0, st, x, xprev, v, n3, 1.0 / dt, static_cast<const double*>(nullptr),
