@@ -121,6 +121,7 @@ __global__ __launch_bounds__(512) void fem_ball_newton_kernel(FemDev m, BallDev 
   extern __shared__ __attribute__((aligned(16))) double ball_lds[];  // x (V,3) | p (V + 4,3) | H.p accumulators (V,3): ball_lds_bytes()
   __shared__ double sh[17];
   __shared__ double gb[12], Bm[144], B0[144], Lc[144], Bi[144], YY[16], qs[12], qts[12], rhs12[12];
+  __shared__ double crc[3 * kFemMaxCoarse], cyc[3 * kFemMaxCoarse];  // coarse residual / correction of the two-level preconditioner
   __shared__ int n_cpv, n_cpt, n_cbv, n_pairs, n_act, s_flags;
   __shared__ int cpv[kBallMaxCand], cpt[kBallMaxCand], cbv[kBallMaxCand];
   const int b = blockIdx.x, tid = threadIdx.x, NT = blockDim.x;
@@ -244,7 +245,8 @@ __global__ __launch_bounds__(512) void fem_ball_newton_kernel(FemDev m, BallDev 
     }
     return block_sum(e, sh);
   };
-  // z = M^-1 r: 3 x 3 blocks on the pad rows, the Cholesky factor of the 12 x 12 ball block on the ball rows (one thread)
+  const bool coarse = m.nc > 0 && m.cn_off && m.ac_inv && (mode & 2) == 0;  // (mode bit 1: block Jacobi alone, A/B)
+  // z = M^-1 r: 3 x 3 blocks on the pad rows (+ the coarse correction), the exact inverse of the 12 x 12 ball block on the ball rows
   auto precondition = [&](const double* r, double* z) -> double {
     double part = 0.0;
     for (int v = tid; v < V; v += NT) {
@@ -261,6 +263,42 @@ __global__ __launch_bounds__(512) void fem_ball_newton_kernel(FemDev m, BallDev 
       for (int k = 0; k < 12; ++k) zz += Bi[tid * 12 + k] * r[V * 3 + k];
       z[V * 3 + tid] = zz;
       part += r[V * 3 + tid] * zz;
+    }
+    if (coarse) {
+      // additive coarse correction on the pad rows, z += P A_c^-1 P^T r (tacex_fem_set_coarse_space: trilinear hats of a coarse grid over the
+      // pad, A_c the rest-state operator's Galerkin product - the second level of the CU-resident kernel's preconditioner; block Jacobi
+      // alone needs ~50 PCG iterations per Newton iteration on this pad, profiles/r06_experiments.md)
+      const int nc3 = 3 * m.nc;
+      int G = 1;
+      while (2 * G <= NT / m.nc && 2 * G <= 64) G *= 2;
+      const int node = tid / G, j = tid - node * G;
+      double a0 = 0.0, a1 = 0.0, a2 = 0.0;
+      if (node < m.nc) {
+        const int e1 = m.cn_off[node + 1];
+        for (int e = m.cn_off[node] + j; e < e1; e += G) {
+          const int v0 = m.cn_vtx[e];
+          const double w0 = m.cn_w[e];
+          a0 += w0 * r[v0 * 3]; a1 += w0 * r[v0 * 3 + 1]; a2 += w0 * r[v0 * 3 + 2];
+        }
+      }
+      for (int o2 = G >> 1; o2 > 0; o2 >>= 1) { a0 += __shfl_xor(a0, o2, 64); a1 += __shfl_xor(a1, o2, 64); a2 += __shfl_xor(a2, o2, 64); }
+      if (node < m.nc && j == 0) { crc[node * 3] = a0; crc[node * 3 + 1] = a1; crc[node * 3 + 2] = a2; }
+      __syncthreads();
+      if (tid < nc3) {
+        double sv = 0.0;
+        for (int k = 0; k < nc3; ++k) sv += m.ac_inv[(size_t)tid * nc3 + k] * crc[k];
+        cyc[tid] = sv;
+        part += crc[tid] * sv;
+      }
+      __syncthreads();
+      for (int v = tid; v < V; v += NT) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          const int nd = m.cv_node[v * 8 + k];
+          const double w = m.cv_w[v * 8 + k];
+          z[v * 3] += w * cyc[nd * 3]; z[v * 3 + 1] += w * cyc[nd * 3 + 1]; z[v * 3 + 2] += w * cyc[nd * 3 + 2];
+        }
+      }
     }
     return block_sum(part, sh);
   };
@@ -580,7 +618,7 @@ __global__ __launch_bounds__(512) void fem_ball_newton_kernel(FemDev m, BallDev 
       }
       for (int i = 0; i < 12; ++i) Bi[i * 12 + tid] = yv[i];
     }
-    if (mode == 1) {  // terms only
+    if (mode & 1) {  // terms only
       __syncthreads();
       const double E = energy(x, qs, xb);
       if (tid == 0 && e_out) e_out[b] = E;

@@ -3076,6 +3076,7 @@ int tacex_fem_ball_step(tacex_fem_ctx* c, double* x, double* v, double* q, doubl
     return 2;
   }
   if (B <= 0) return 0;
+  static const int ball_coarse_off = getenv("TACEX_BALL_COARSE") ? (atoi(getenv("TACEX_BALL_COARSE")) == 0) : 0;  // A/B hook: block Jacobi alone on the pad rows
   hipStream_t st = (hipStream_t)stream;
   const int V = c->dev.V;
   const size_t n3 = (size_t)B * V * 3;
@@ -3090,8 +3091,8 @@ int tacex_fem_ball_step(tacex_fem_ctx* c, double* x, double* v, double* q, doubl
                      gravity[2]);
   if (ball_lds_bytes(c->dev.V) > 48 * 1024) { set_error("tacex_fem_ball_step: pad of %d vertices (the kernel keeps x, p and the H.p accumulators of <= 680 vertices in LDS)", c->dev.V); return 2; }
   hipLaunchKernelGGL(fem_ball_newton_kernel, dim3(B), dim3(512), ball_lds_bytes(c->dev.V), st, c->dev, c->ball, x, xt, q, qt, cons, aim, static_cast<double*>(ws), pcg_max_iter,
-                     pcg_tol_rate, ls_max_iter, max_newton, velocity_tol * dt, transrate_tol * dt, step_info, 0, static_cast<double*>(nullptr),
-                     static_cast<double*>(nullptr));
+                     pcg_tol_rate, ls_max_iter, max_newton, velocity_tol * dt, transrate_tol * dt, step_info, ball_coarse_off ? 2 : 0,
+                     static_cast<double*>(nullptr), static_cast<double*>(nullptr));
   hipLaunchKernelGGL(fem_velocity_kernel, dim3((unsigned)((n3 + 255) / 256)), dim3(256), 0, st, x, xprev, v, n3, 1.0 / dt, static_cast<const double*>(nullptr),
                      static_cast<double*>(nullptr), B);
   hipLaunchKernelGGL(fem_ball_velocity_kernel, dim3((unsigned)((B * 12 + 255) / 256)), dim3(256), 0, st, q, qprev, qv, B, 1.0 / dt);

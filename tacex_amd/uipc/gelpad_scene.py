@@ -159,34 +159,16 @@ class FemGelpad:
 
 
 def icosphere(radius: float, level: int = 2):
-    """(vertices (nv,3), triangles (nt,3), outward oriented): 12 / 42 / 162 / 642 vertices at level 0 / 1 / 2 / 3; turned so that a
-    vertex (and its antipode) lies on the z axis."""
-    t = (1.0 + 5.0**0.5) / 2.0
-    v = [(-1, t, 0), (1, t, 0), (-1, -t, 0), (1, -t, 0), (0, -1, t), (0, 1, t), (0, -1, -t), (0, 1, -t), (t, 0, -1), (t, 0, 1), (-t, 0, -1), (-t, 0, 1)]
-    f = [(0, 11, 5), (0, 5, 1), (0, 1, 7), (0, 7, 10), (0, 10, 11), (1, 5, 9), (5, 11, 4), (11, 10, 2), (10, 7, 6), (7, 1, 8),
-         (3, 9, 4), (3, 4, 2), (3, 2, 6), (3, 6, 8), (3, 8, 9), (4, 9, 5), (2, 4, 11), (6, 2, 10), (8, 6, 7), (9, 8, 1)]
-    v = [np.asarray(p, np.float64) / np.linalg.norm(p) for p in v]
-    for _ in range(level):
-        mid, nf = {}, []
+    """`indenter_meshes.icosphere` (12 / 42 / 162 / 642 vertices at level 0 / 1 / 2 / 3, outward oriented) turned so that a vertex - and,
+    the mesh being point-symmetric, its antipode - lies on the z axis: a ball resting on the ground touches it with a vertex."""
+    from .indenter_meshes import icosphere as _ico
 
-        def m(a, b):
-            key = (min(a, b), max(a, b))
-            if key not in mid:
-                p = v[a] + v[b]
-                v.append(p / np.linalg.norm(p))
-                mid[key] = len(v) - 1
-            return mid[key]
-
-        for a, b, c in f:
-            ab, bc, ca = m(a, b), m(b, c), m(c, a)
-            nf += [(a, ab, ca), (b, bc, ab), (c, ca, bc), (ab, bc, ca)]
-        f = nf
-    v = np.asarray(v)
+    v, f = _ico(1.0, level)
     a = v[0]
     vx = np.cross(a, [0.0, 0.0, 1.0])
     K = np.array([[0, -vx[2], vx[1]], [vx[2], 0, -vx[0]], [-vx[1], vx[0], 0]])
     v = v @ (np.eye(3) + K + K @ K / (1.0 + a[2])).T
-    return v * radius, np.asarray(f, np.int32)
+    return v * radius, f
 
 
 class FemBallScene:

@@ -533,7 +533,9 @@ class UipcSim:
         if getattr(self, "step_info", None) is None:
             self.step_info = torch.zeros((self.num_envs, 4), dtype=torch.float64, device=self.device)
             self._g_host = (C.c_double * 3)(*[float(g) for g in self.cfg.gravity])
-        if self._body is not None:  # pad + free affine body + ground: csrc/fem_ball.h (its own preconditioner: no coarse space / chains)
+        if self._body is not None:  # pad + free affine body + ground: csrc/fem_ball.h (block Jacobi + the pad's coarse space + the exact ball block)
+            if self._precond_dirty:
+                self.refresh_preconditioner()
             with torch.cuda.device(self.device):
                 rc = self._lib.tacex_fem_ball_step(
                     self._handle, _lib.ptr(self.x), _lib.ptr(self.v), _lib.ptr(self.q), _lib.ptr(self.qv), _lib.ptr(self.is_constrained),
