@@ -32,7 +32,7 @@ from __future__ import annotations
 
 import numpy as np
 
-from .fem_oracle import LS_RESCUE, FemModel, barrier, pcg_solve
+from .fem_oracle import LS_RESCUE, FemModel, barrier, friction_f0, pcg_solve
 
 
 def icosphere(radius: float, level: int = 2):
@@ -189,6 +189,10 @@ class BallScene:
         self.dt = pad.dt
         self.V = len(pad.X)
         self.pad_sv = np.where(self.pad_area > 0)[0]
+        # lagged Coulomb friction of every contact (Li et al. 2020, eq. 18-20; US:103-124 friction ratio 0.5, eps_velocity 0.01): off until
+        # `mu` is set; the lag (normal force, normal, the pair's coefficients) is taken by step() at the state the step starts from
+        self.mu, self.eps_v = 0.0, 0.01
+        self._lag = None
 
     # ---- contact terms -----------------------------------------------------------------------------------------------------------
     def _ground(self, x, w):
@@ -233,6 +237,53 @@ class BallScene:
         self._rows_memo = (y.copy(), out)
         return out
 
+    # ---- lagged friction ---------------------------------------------------------------------------------------------------------
+    def friction_lag(self, y0):
+        """The contacts of the state y0 as friction constraints for the step that starts there: per contact the state rows and coefficients
+        of its relative displacement (pairs: point minus closest point of the triangle, the barycentric weights frozen; ground: the vertex
+        itself), the contact normal and the normal force lam = -kappa w b'(d / d_hat) / d_hat [N] - all frozen for the step (IPC's lag)."""
+        V = self.V
+        rows, coef, w, d, n = self._pair_rows(y0)
+        lam = -self.kappa * w * barrier(d / self.dhat)[1] / self.dhat
+        R, C, N, Lm = [rows], [coef], [n], [lam]
+        z = np.array([0.0, 0.0, 1.0])
+        for (x, wt, ball) in ((y0[:V], self.pad_area, False), (self.ball.points(y0[V:]), self.ball.area, True)):
+            gap = x[:, 2] - self.gh
+            on = np.where((wt > 0) & (gap > 0) & (gap < self.dhat))[0]
+            if len(on) == 0:
+                continue
+            r = np.zeros((len(on), 8), np.int64)
+            c = np.zeros((len(on), 8))
+            if ball:
+                r[:, :4] = V + np.arange(4)
+                c[:, :4] = self.ball.Y[on]
+            else:
+                r[:, 0] = on
+                c[:, 0] = 1.0
+            R.append(r); C.append(c); N.append(np.broadcast_to(z, (len(on), 3)).copy())
+            Lm.append(-self.kappa * wt[on] * barrier(gap[on] / self.dhat)[1] / self.dhat)
+        return (np.concatenate(R), np.concatenate(C), np.concatenate(N), np.concatenate(Lm), y0.copy())
+
+    def _fric(self, y):
+        """(rows, coef, lam, u (K,3) tangential relative displacement since the step's start, n) of the lagged contacts; None when off."""
+        if self._lag is None or not self.mu > 0.0 or len(self._lag[3]) == 0:
+            return None
+        rows, coef, n, lam, y0 = self._lag
+        rel = np.zeros((len(lam), 3))
+        for r in range(8):
+            rel += coef[:, r, None] * (y[rows[:, r]] - y0[rows[:, r]])
+        u = rel - (rel * n).sum(-1, keepdims=True) * n
+        return rows, coef, lam, u, n
+
+    def _fric_blocks(self, f):
+        """(K,3,3) friction Hessian of every lagged contact in its relative displacement: dt^2 mu lam [a T + (b - a) t t^T]."""
+        rows, coef, lam, u, n = f
+        yy = np.linalg.norm(u, axis=1)
+        _, a, b = friction_f0(yy, self.eps_v * self.dt)
+        t = u / np.maximum(yy, 1e-300)[:, None]
+        T = np.eye(3)[None] - n[:, :, None] * n[:, None, :]
+        return (self.dt**2 * self.mu * lam)[:, None, None] * (a[:, None, None] * T + (b - a)[:, None, None] * t[:, :, None] * t[:, None, :])
+
     # ---- incremental potential -------------------------------------------------------------------------------------------------------
     def energy(self, y, yt, cons=None, aim=None):
         V = self.V
@@ -243,6 +294,9 @@ class BallScene:
         k = self.dt**2 * self.kappa
         for (_, _, w, d, _, _) in self.pairs(y):
             e += k * (w * barrier(d / self.dhat)[0]).sum()
+        f = self._fric(y)
+        if f is not None:
+            e += self.dt**2 * self.mu * (f[2] * friction_f0(np.linalg.norm(f[3], axis=1), self.eps_v * self.dt)[0]).sum()
         return e
 
     def gradient(self, y, yt, cons=None, aim=None):
@@ -259,6 +313,12 @@ class BallScene:
         s = self.dt**2 * self.kappa * w * barrier(d / self.dhat)[1] / self.dhat
         for r in range(8):
             np.add.at(g, rows[:, r], (s * coef[:, r])[:, None] * n)
+        f = self._fric(y)
+        if f is not None:
+            frows, fcoef, lam, u, _ = f
+            a = friction_f0(np.linalg.norm(u, axis=1), self.eps_v * self.dt)[1]
+            for r in range(8):
+                np.add.at(g, frows[:, r], (self.dt**2 * self.mu * lam * a * fcoef[:, r])[:, None] * u)
         return g
 
     def hess_vec(self, y, p, cons=None):
@@ -279,6 +339,16 @@ class BallScene:
             gp += coef[:, r] * (n * p[rows[:, r]]).sum(-1)
         for r in range(8):
             np.add.at(out, rows[:, r], (wk * gp * coef[:, r])[:, None] * n)
+        f = self._fric(y)
+        if f is not None:
+            frows, fcoef = f[0], f[1]
+            M = self._fric_blocks(f)
+            wv = np.zeros((len(f[2]), 3))
+            for r in range(8):
+                wv += fcoef[:, r, None] * p[frows[:, r]]
+            Mw = np.einsum("kij,kj->ki", M, wv)
+            for r in range(8):
+                np.add.at(out, frows[:, r], fcoef[:, r, None] * Mw)
         return out
 
     def diag_blocks(self, y, cons=None):
@@ -296,6 +366,11 @@ class BallScene:
         nn = n[:, :, None] * n[:, None, :]
         for r in range(8):
             np.add.at(D, rows[:, r], (wk * coef[:, r] ** 2)[:, None, None] * nn)
+        f = self._fric(y)
+        if f is not None:
+            M = self._fric_blocks(f)
+            for r in range(8):
+                np.add.at(D, f[0][:, r], (f[1][:, r] ** 2)[:, None, None] * M)
         return D
 
     def ball_block(self, y):
@@ -327,6 +402,15 @@ class BallScene:
             np.add.at(cq, (np.where(on)[0], rows[on, r] - V), coef[on, r])
         for k in range(len(w)):
             B += wk[k] * np.kron(np.outer(cq[k], cq[k]), np.outer(n[k], n[k]))
+        f = self._fric(y)
+        if f is not None:
+            M = self._fric_blocks(f)
+            fq = np.zeros((len(f[2]), 4))
+            for r in range(8):
+                on = f[0][:, r] >= V
+                np.add.at(fq, (np.where(on)[0], f[0][on, r] - V), f[1][on, r])
+            for k in range(len(f[2])):
+                B += np.kron(np.outer(fq[k], fq[k]), M[k])
         return B
 
     def preconditioner(self, y, cons=None):
@@ -406,6 +490,7 @@ class BallScene:
         yt[: self.V] += g3
         yt[self.V] += g3
         y0, n, pcg, dmax, flags = y, 0, 0, np.inf, 0
+        self._lag = self.friction_lag(y0) if self.mu > 0.0 else None
         for _ in range(max_newton):
             y, st = self.newton_step(y, yt, cons, aim, **kw)
             n += 1

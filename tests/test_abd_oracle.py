@@ -239,3 +239,81 @@ def test_additive_ccd_known_answers():
     assert accd_point_triangle(p, tri, np.array([0, 0, -1.0]), np.tile([0, 0, -1.0], (3, 1))) == 1.0  # common translation
     t = accd_point_triangle(p, tri, np.array([0, 0, -0.6]), np.tile([0, 0, 0.4], (3, 1)))  # both move: closing speed 1
     assert abs(t - 0.45) < 1e-9
+
+
+def test_lagged_friction_terms_match_finite_differences_and_blocks():
+    """Coulomb friction of every contact (pairs of both kinds and the ground under the ball), lagged at the step's start (IPC): FD gradient
+    of the scene with friction on, the friction part of the operator against the FD derivative of the friction part of the gradient (the
+    lagged potential's Hessian is exact), symmetry, PSD, and its share of the diagonal / ball blocks; in the stick AND in the slip regime."""
+    sc, y0, cons = _scene()
+    rng = np.random.default_rng(7)
+    y0 = y0 + 2e-5 * rng.standard_normal(y0.shape)
+    sc.mu = 0.5
+    sc._lag = sc.friction_lag(y0)
+    rows, coef, n, lam, _ = sc._lag
+    assert len(lam) >= 3 and (lam > 0).all() and (rows[:, 0] >= sc.V).any() and (rows[:, 0] < sc.V).any()
+    for scale in (2e-5, 5e-4):  # |u| below / above the stick tolerance eps_v * dt = 1e-4 m
+        y = y0 + scale * rng.standard_normal(y0.shape) * (np.arange(len(y0))[:, None] >= 0)
+        y[sc.V + 1:] = y0[sc.V + 1:] + 0.02 * scale / 5e-4 * rng.standard_normal((3, 3))
+        f = sc._fric(y)
+        yy = np.linalg.norm(f[3], axis=1)
+        assert (yy < 1e-4).any() if scale < 1e-4 else (yy > 1e-4).any()
+        yt = y0.copy()
+
+        def parts(yv):
+            g1 = sc.gradient(yv, yt, cons, y0[:sc.V])
+            mu, sc.mu = sc.mu, 0.0
+            g0 = sc.gradient(yv, yt, cons, y0[:sc.V])
+            sc.mu = mu
+            return g1 - g0
+
+        def e_f(yv):
+            e1 = sc.energy(yv, yt, cons, y0[:sc.V])
+            mu, sc.mu = sc.mu, 0.0
+            e0 = sc.energy(yv, yt, cons, y0[:sc.V])
+            sc.mu = mu
+            return e1 - e0
+
+        gf = parts(y)
+        h = 1e-8
+        for r in [int(rows[0, 0]), int(rows[-1, 0]), sc.V, sc.V + 2]:
+            for i in range(3):
+                e = np.zeros_like(y); e[r, i] = h
+                fd = (e_f(y + e) - e_f(y - e)) / (2 * h)
+                assert abs(fd - gf[r, i]) <= 1e-5 * max(np.abs(gf).max(), 1e-30), (scale, r, i, fd, gf[r, i])
+        p = rng.standard_normal(y.shape)
+        mu = sc.mu
+        Hp1 = sc.hess_vec(y, p, cons); sc.mu = 0.0; Hp0 = sc.hess_vec(y, p, cons); sc.mu = mu
+        fd = (parts(y + 1e-7 * p) - parts(y - 1e-7 * p)) / 2e-7
+        assert np.abs((Hp1 - Hp0) - fd).max() <= 2e-4 * np.abs(fd).max(), (scale, np.abs((Hp1 - Hp0) - fd).max(), np.abs(fd).max())
+        assert (p * (Hp1 - Hp0)).sum() >= 0.0
+        D1 = sc.diag_blocks(y, cons); B1 = sc.ball_block(y); sc.mu = 0.0; D0 = sc.diag_blocks(y, cons); B0 = sc.ball_block(y); sc.mu = mu
+        for r in [int(rows[0, 0]), sc.V + 1]:
+            for i in range(3):
+                e = np.zeros_like(y); e[r, i] = 1.0
+                a = sc.hess_vec(y, e, cons); sc.mu = 0.0; b = sc.hess_vec(y, e, cons); sc.mu = mu
+                assert np.allclose((a - b)[r], (D1 - D0)[r][:, i], rtol=1e-9, atol=1e-18)
+        for a4 in range(4):
+            for i in range(3):
+                e = np.zeros_like(y); e[sc.V + a4, i] = 1.0
+                a = sc.hess_vec(y, e, cons); sc.mu = 0.0; b = sc.hess_vec(y, e, cons); sc.mu = mu
+                assert np.allclose((a - b)[sc.V:].reshape(12), (B1 - B0)[:, 3 * a4 + i], rtol=1e-9, atol=1e-18)
+
+
+def test_friction_keeps_the_light_ball_from_rolling_away():
+    """The reference's contact model has friction (ratio 0.5, US:103-124).  With it the reference-density ball under the pressing pad needs a
+    few Newton iterations per step at the default tolerances; without it the faceted ball rolls onto a facet and the loop runs into its cap."""
+    res = {}
+    for mu in (0.5, 0.0):
+        sc, y, cons = _scene(press=-2e-5, pole=True, shift=(0.0008, 0.0005), ground_gap=1.02)
+        sc.mu = mu
+        V = sc.V
+        aim, v, its = y[:V].copy(), np.zeros_like(y), []
+        for k in range(5 if mu > 0 else 4):
+            aim[:, 2] -= 6e-5
+            y, v, info = sc.step(y, v, cons, aim, max_newton=40)
+            assert int(info[2]) == 0
+            its.append(int(info[0]))
+        res[mu] = (its, np.abs(y[V + 1:] - np.eye(3)).max())
+    assert max(res[0.5][0]) <= 6 and res[0.5][1] < 0.02, res
+    assert max(res[0.0][0]) == 40, res  # (the frictionless ball is what runs into the cap)
