@@ -496,8 +496,10 @@ int tacex_fem_step(tacex_fem_ctx* ctx, double* x_dev, double* v_dev, double* x_t
  * `world.advance()` does with them.  libuipc is not in the reference tree: the model is oracle/abd_oracle.py's (PARITY UNPINNED) -
  * Lan et al. 2022 (affine body: q = (p, A), mass matrix S (x) I_3 from the surface mesh's moments, orthogonality energy
  * kappa vol |A^T A - I|^2), Li et al. 2020 (barrier on every point-triangle pair closer than d_hat, pad vertex / ball triangle AND
- * ball vertex / pad triangle, ground against the surface vertices of both bodies), additive CCD on the pairs.  No friction and no
- * edge-edge pairs between the two bodies yet.
+ * ball vertex / pad triangle, ground against the surface vertices of both bodies), additive CCD on the pairs, and lagged Coulomb
+ * friction of EVERY contact (pairs of both kinds and ground contacts of both bodies; ratio and stick tolerance from tacex_fem_set_friction,
+ * US:103-124: the contacts of the state the step starts from are frozen - normal force, normal, barycentric weights - and slide
+ * relative to it, Li et al. 2020 section 5.4).  No edge-edge pairs between the two bodies yet.
  *
  * tacex_fem_set_affine_body: ONE body per env, the same mesh for all envs.  verts_host (num_verts,3) f64 in the body frame, tris_host
  * (num_tris,3) outward oriented; density [kg/m^3]; kappa [Pa] (m_kappa * 1e6); pad_vertex_area_host (V) contact weights of the gelpad's
@@ -510,7 +512,8 @@ int tacex_fem_step(tacex_fem_ctx* ctx, double* x_dev, double* v_dev, double* x_t
  * uipc_sim.py:62-66), velocities.  step_info (num_envs,4) = [Newton iterations, max |d|, flags (1 a surface vertex at / below the
  * ground, 2 line search failed, 16 a candidate list overflowed), PCG iterations].  workspace: tacex_fem_ball_workspace_bytes.
  * tacex_fem_ball_terms: energy (num_envs) and gradient (num_envs, V + 4, 3) of the step's incremental potential at (x, q) against the
- * predictors (x_tilde, q_tilde) - the entry point the parity tests compare with the oracle term by term.
+ * predictors (x_tilde, q_tilde) - the entry point the parity tests compare with the oracle term by term.  x_prev_dev / q_prev_dev
+ * (both or neither): the state friction slides relative to; the friction lag (forces, normals, weights) is then taken at (x, q) itself.
  * tacex_fem_ball_moments: the 4x4 moment matrix S (row-major) and kappa * vol the library derived from the mesh. */
 int tacex_fem_set_affine_body(tacex_fem_ctx* ctx, int num_verts, const double* verts_host, int num_tris, const int32_t* tris_host, double density,
                               double kappa, const double* pad_vertex_area_host, int num_pad_tris, const int32_t* pad_tris_host, double d_hat,
@@ -518,8 +521,8 @@ int tacex_fem_set_affine_body(tacex_fem_ctx* ctx, int num_verts, const double* v
 size_t tacex_fem_ball_workspace_bytes(const tacex_fem_ctx* ctx, int num_envs);
 int tacex_fem_ball_moments(const tacex_fem_ctx* ctx, double moments_out[16], double* kappa_vol_out);
 int tacex_fem_ball_terms(tacex_fem_ctx* ctx, const double* x_dev, const double* x_tilde_dev, const double* q_dev, const double* q_tilde_dev,
-                         const uint8_t* constrained_dev, const double* aim_dev, double* energy_dev, double* grad_dev, double* step_info_dev,
-                         void* workspace_dev, int num_envs, void* stream);
+                         const uint8_t* constrained_dev, const double* aim_dev, const double* x_prev_dev, const double* q_prev_dev,
+                         double* energy_dev, double* grad_dev, double* step_info_dev, void* workspace_dev, int num_envs, void* stream);
 int tacex_fem_ball_step(tacex_fem_ctx* ctx, double* x_dev, double* v_dev, double* q_dev, double* qv_dev, const uint8_t* constrained_dev,
                         const double* aim_dev, double* step_info_dev, void* workspace_dev, int num_envs, const double gravity[3], int max_newton,
                         double velocity_tol, double transrate_tol, int pcg_max_iter, double pcg_tol_rate, int ls_max_iter, void* stream);

@@ -145,7 +145,7 @@ SIGNATURES = {
     "tacex_fem_set_affine_body": (_i, [_vp, _i, _vp, _i, _vp, _d, _d, _vp, _i, _vp, _d, _d, _d, _i]),
     "tacex_fem_ball_workspace_bytes": (_sz, [_vp, _i]),
     "tacex_fem_ball_moments": (_i, [_vp, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
-    "tacex_fem_ball_terms": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp]),
+    "tacex_fem_ball_terms": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp]),
     "tacex_fem_ball_step": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, C.POINTER(C.c_double), _i, _d, _d, _i, _d, _i, _vp]),
     "tacex_fem_reset_envs": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp]),
     "tacex_fem_set_friction": (_i, [_vp, _d, _d]),

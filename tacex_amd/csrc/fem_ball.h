@@ -37,13 +37,15 @@ constexpr int kBallRec = 14;          // doubles per active record
 constexpr int kBallMaxCand = 512;     // candidate pad vertices / pad triangles / ball vertices per env
 constexpr double kBallReach = 2.0;    // additive CCD on pairs closer than kBallReach * d_hat
 constexpr double kBallKeep = 0.1;     // ... which may keep this fraction of their gap
+constexpr int kBallMaxFric = 1024;    // lagged friction contacts per env and time step (pairs + ground)
 constexpr int kBallFlagOverflow = 16; // step_info flag: a candidate / pair list overflowed (the scene is outside what this slice handles)
 
 // workspace of one env (doubles): ge 12T | tc 12T | hv 12T | g r z p d Hp yc: 7 x 3 (V+4) | D / Dinv 9V | ground curvature V |
 //   xb 3nv | xbc 3nv | dxb 3nv | ball triangle spheres 4nt | pair list (ints) kBallMaxPairs / 2 | active records
 __host__ __device__ inline size_t ball_lds_bytes(int V) { return ((size_t)9 * V + 12) * sizeof(double); }
 __host__ __device__ inline size_t ball_ws_doubles(int V, int T, int nv, int nt) {
-  return (size_t)36 * T + (size_t)21 * (V + 4) + (size_t)10 * V + (size_t)9 * nv + (size_t)4 * nt + kBallMaxPairs / 2 + (size_t)kBallMaxActive * kBallRec;
+  return (size_t)36 * T + (size_t)21 * (V + 4) + (size_t)10 * V + (size_t)9 * nv + (size_t)4 * nt + kBallMaxPairs / 2 + (size_t)kBallMaxActive * kBallRec +
+         (size_t)kBallMaxFric * (kBallRec + 6);  // lagged friction records + their Hessians at the iteration's state
 }
 
 // closest point of triangle (a, b, c) to p: barycentric coordinates, distance, unit vector from the closest point to p
@@ -117,12 +119,14 @@ __device__ __forceinline__ void barrier3(double s, double& b, double& b1, double
 __global__ __launch_bounds__(512) void fem_ball_newton_kernel(FemDev m, BallDev bd, double* xg, const double* xtg, double* qg, const double* qtg,
                                                               const uint8_t* consg, const double* aimg, double* wsg, int pcg_max_iter,
                                                               double pcg_tol_rate, int ls_max_iter, int max_newton, double dx_tol, double dc_tol,
-                                                              double* step_info, int mode, double* e_out, double* g_out) {
+                                                              double* step_info, int mode, double* e_out, double* g_out, const double* xprevg,
+                                                              const double* qprevg) {
   extern __shared__ __attribute__((aligned(16))) double ball_lds[];  // x (V,3) | p (V + 4,3) | H.p accumulators (V,3): ball_lds_bytes()
   __shared__ double sh[17];
   __shared__ double gb[12], Bm[144], B0[144], Lc[144], Bi[144], YY[16], qs[12], qts[12], rhs12[12];
   __shared__ double crc[3 * kFemMaxCoarse], cyc[3 * kFemMaxCoarse];  // coarse residual / correction of the two-level preconditioner
-  __shared__ int n_cpv, n_cpt, n_cbv, n_pairs, n_act, s_flags;
+  __shared__ double qps[12];  // the ball rows the time step started from (friction slides relative to them)
+  __shared__ int n_cpv, n_cpt, n_cbv, n_pairs, n_act, n_fric, s_flags;
   __shared__ int cpv[kBallMaxCand], cpt[kBallMaxCand], cbv[kBallMaxCand];
   const int b = blockIdx.x, tid = threadIdx.x, NT = blockDim.x;
   const int V = m.V, T = m.T, nv = bd.nv, nt = bd.nt, VN = V + 4;
@@ -151,14 +155,22 @@ __global__ __launch_bounds__(512) void fem_ball_newton_kernel(FemDev m, BallDev 
   double* bts = dxb + (size_t)3 * nv;  // (nt,4) bounding sphere of every ball triangle at x
   int* plist = reinterpret_cast<int*>(bts + (size_t)4 * nt);  // (kBallMaxPairs) kind << 30 | point << 15 | triangle
   double* arec = reinterpret_cast<double*>(plist + kBallMaxPairs);
+  double* frec = arec + (size_t)kBallMaxActive * kBallRec;  // lagged friction contacts of the step: lam | n (3) | ball coefficients (4) | pad coefficients (3) | pad rows (3 ints)
+  double* fM = frec + (size_t)kBallMaxFric * kBallRec;      // their 3 x 3 Hessians at x (6 each, dt^2 mu lam [a T + (b - a) t t^T])
+  // LAGGED COULOMB FRICTION of every contact (Li et al. 2020 eq. 18-20; US:103-124 friction ratio / eps_velocity, tacex_fem_set_friction): the
+  // contacts of the state the step STARTS from - active pairs of both kinds, ground contacts of both bodies - are frozen as (normal force,
+  // normal, coefficients of the relative displacement) in the first Newton iteration (x = x_n there) and slide relative to that state
+  const double* xprev = xprevg ? xprevg + o : nullptr;
+  const bool fric = m.fric_mu > 0.0 && xprev != nullptr && qprevg != nullptr;
+  const double f_eps = m.fric_eps, f_mu = m.fric_mu;
   double* xs = ball_lds;           // (V,3) x of the iteration: the tet state is recomputed from it in every H.p (no cached F in HBM)
   double* ps = xs + 3 * V;         // (V + 4,3) PCG direction
   double* acc = ps + 3 * VN;       // (V,3) per-vertex sums of the tets' rows (ds_add_f64)
   const double dt2 = m.dt * m.dt, dhat = bd.dhat, kk = dt2 * bd.kappa;
   const double L = dhat * (1.0 + kCcdSlack * kBallReach), R = kBallReach * dhat;
 
-  if (tid < 12) { qs[tid] = q[tid]; qts[tid] = qt[tid]; }
-  if (tid == 0) s_flags = 0;
+  if (tid < 12) { qs[tid] = q[tid]; qts[tid] = qt[tid]; qps[tid] = fric ? qprevg[(size_t)b * 12 + tid] : 0.0; }
+  if (tid == 0) { s_flags = 0; n_fric = 0; }
   __syncthreads();
 
   auto ball_points = [&](const double* qq, double* out) {  // out (nv,3) = Y qq; qq in LDS
@@ -167,6 +179,22 @@ __global__ __launch_bounds__(512) void fem_ball_newton_kernel(FemDev m, BallDev 
 #pragma unroll
       for (int i = 0; i < 3; ++i) out[k * 3 + i] = y0 * qq[i] + y1 * qq[3 + i] + y2 * qq[6 + i] + y3 * qq[9 + i];
     }
+  };
+  auto fric_u = [&](const double* rc, const double* xx, const double* qq, double u[3]) {  // tangential relative displacement since the step's start
+    const int* ri = reinterpret_cast<const int*>(rc + 11);
+    double rel[3] = {0.0, 0.0, 0.0};
+#pragma unroll
+    for (int a4 = 0; a4 < 4; ++a4)
+#pragma unroll
+      for (int i = 0; i < 3; ++i) rel[i] += rc[4 + a4] * (qq[a4 * 3 + i] - qps[a4 * 3 + i]);
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+      if (ri[r] >= 0)
+#pragma unroll
+        for (int i = 0; i < 3; ++i) rel[i] += rc[8 + r] * (xx[ri[r] * 3 + i] - xprev[ri[r] * 3 + i]);
+    const double rn = rel[0] * rc[1] + rel[1] * rc[2] + rel[2] * rc[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) u[i] = rel[i] - rn * rc[1 + i];
   };
   // energy of the state (xx pad vertices in global memory, qq ball rows in LDS, xbb its surface points): every term of
   // oracle/abd_oracle.py BallScene.energy; the pairs are those of the iteration's list
@@ -243,6 +271,16 @@ __global__ __launch_bounds__(512) void fem_ball_newton_kernel(FemDev m, BallDev 
         e += kk * w * bb;
       }
     }
+    if (fric) {
+      const int nf = n_fric;
+      for (int k = tid; k < nf; k += NT) {
+        const double* rc = frec + (size_t)k * kBallRec;
+        double u[3];
+        fric_u(rc, xx, qq, u);
+        const double yv = sqrt(u[0] * u[0] + u[1] * u[1] + u[2] * u[2]);
+        e += dt2 * f_mu * rc[0] * (yv < f_eps ? -yv * yv * yv / (3.0 * f_eps * f_eps) + yv * yv / f_eps + f_eps / 3.0 : yv);
+      }
+    }
     return block_sum(e, sh);
   };
   const bool coarse = m.nc > 0 && m.cn_off && m.ac_inv && (mode & 2) == 0;  // (mode bit 1: block Jacobi alone, A/B)
@@ -308,6 +346,7 @@ __global__ __launch_bounds__(512) void fem_ball_newton_kernel(FemDev m, BallDev 
   int n_newton = 0, pcg_total = 0;
   double dmax_x = INFINITY, dmax_c = INFINITY;
   for (int nit = 0; nit < max_newton; ++nit) {
+    const bool take_lag = fric && (nit == 0);  // (the first iteration stands at the state the step starts from)
     // ---- element pass (as fem_newton_kernel) + bounding spheres of the ball triangles + candidate lists ----
     for (int t = tid; t < T; t += NT) {
       int v[4];
@@ -435,6 +474,16 @@ __global__ __launch_bounds__(512) void fem_ball_newton_kernel(FemDev m, BallDev 
         gz = kk * w * b1 / dhat;
         cb = kk * w * b2 / (dhat * dhat);
         D[8] += cb;
+        if (fric && take_lag && b1 < 0.0) {  // (inside the ground's barrier zone)
+          const int sl = atomicAdd(&n_fric, 1);
+          if (sl < kBallMaxFric) {
+            double* rc = frec + (size_t)sl * kBallRec;
+            rc[0] = -bd.kappa * w * b1 / dhat; rc[1] = 0.0; rc[2] = 0.0; rc[3] = 1.0;
+            rc[4] = rc[5] = rc[6] = rc[7] = 0.0; rc[8] = 1.0; rc[9] = 0.0; rc[10] = 0.0;
+            int* ri = reinterpret_cast<int*>(rc + 11);
+            ri[0] = v; ri[1] = -1; ri[2] = -1;
+          }
+        }
       }
       cbp[v] = cb;
       for (int e = m.vt_off[v]; e < m.vt_off[v + 1]; ++e) {
@@ -483,6 +532,18 @@ __global__ __launch_bounds__(512) void fem_ball_newton_kernel(FemDev m, BallDev 
           double bb, b1, b2;
           barrier3(gap / dhat, bb, b1, b2);
           const double f = kk * bd.area[k] * b1 / dhat, cb = kk * bd.area[k] * b2 / (dhat * dhat);
+          if (fric && take_lag) {
+            const int sl = atomicAdd(&n_fric, 1);
+            if (sl < kBallMaxFric) {
+              double* rc = frec + (size_t)sl * kBallRec;
+              rc[0] = -bd.kappa * bd.area[k] * b1 / dhat; rc[1] = 0.0; rc[2] = 0.0; rc[3] = 1.0;
+#pragma unroll
+              for (int a4 = 0; a4 < 4; ++a4) rc[4 + a4] = bd.Y[k * 4 + a4];
+              rc[8] = rc[9] = rc[10] = 0.0;
+              int* ri = reinterpret_cast<int*>(rc + 11);
+              ri[0] = -1; ri[1] = -1; ri[2] = -1;
+            }
+          }
 #pragma unroll
           for (int a = 0; a < 4; ++a) {
             atomicAdd(&gb[a * 3 + 2], f * bd.Y[k * 4 + a]);
@@ -546,6 +607,17 @@ __global__ __launch_bounds__(512) void fem_ball_newton_kernel(FemDev m, BallDev 
 #pragma unroll
               for (int j = 0; j < 3; ++j) atomicAdd(&Bm[(a4 * 3 + i) * 12 + c4 * 3 + j], wk * cq[a4] * cq[c4] * n[i] * n[j]);
           }
+        if (take_lag) {
+          const int sf = atomicAdd(&n_fric, 1);
+          if (sf < kBallMaxFric) {
+            double* rc = frec + (size_t)sf * kBallRec;
+            rc[0] = -bd.kappa * w * b1 / dhat; rc[1] = n[0]; rc[2] = n[1]; rc[3] = n[2];
+            rc[4] = cq[0]; rc[5] = cq[1]; rc[6] = cq[2]; rc[7] = cq[3];
+            rc[8] = pco[0]; rc[9] = pco[1]; rc[10] = pco[2];
+            int* ri = reinterpret_cast<int*>(rc + 11);
+            ri[0] = prow[0]; ri[1] = prow[1]; ri[2] = prow[2];
+          }
+        }
         const int sl = atomicAdd(&n_act, 1);
         if (sl < kBallMaxActive) {
           double* rc = arec + (size_t)sl * kBallRec;
@@ -559,6 +631,61 @@ __global__ __launch_bounds__(512) void fem_ball_newton_kernel(FemDev m, BallDev 
     }
     __syncthreads();
     if (n_act > kBallMaxActive) { if (tid == 0) { s_flags |= kBallFlagOverflow; n_act = kBallMaxActive; } }
+    if (n_fric > kBallMaxFric) { if (tid == 0) { s_flags |= kBallFlagOverflow; n_fric = kBallMaxFric; } }
+    if (fric) {  // friction of the lagged contacts at x: gradient, Hessians (kept for H.p), diagonal / ball blocks
+      __syncthreads();
+      const int nf = n_fric;
+      for (int k = tid; k < nf; k += NT) {
+        const double* rc = frec + (size_t)k * kBallRec;
+        const int* ri = reinterpret_cast<const int*>(rc + 11);
+        double u[3];
+        fric_u(rc, x, qs, u);
+        const double yv = sqrt(u[0] * u[0] + u[1] * u[1] + u[2] * u[2]);
+        const bool stick = yv < f_eps;
+        const double fa = stick ? 2.0 / f_eps - yv / (f_eps * f_eps) : 1.0 / yv;
+        const double fb = stick ? 2.0 / f_eps - 2.0 * yv / (f_eps * f_eps) : 0.0;
+        const double cf = dt2 * f_mu * rc[0];
+        const double iy = yv > 0.0 ? 1.0 / yv : 0.0;
+        const double t3[3] = {u[0] * iy, u[1] * iy, u[2] * iy}, n3[3] = {rc[1], rc[2], rc[3]};
+        double M[6];  // xx xy xz yy yz zz of cf [fa (I - n n^T) + (fb - fa) t t^T]
+        {
+          int kq = 0;
+#pragma unroll
+          for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int j = i; j < 3; ++j) M[kq++] = cf * (fa * ((i == j ? 1.0 : 0.0) - n3[i] * n3[j]) + (fb - fa) * t3[i] * t3[j]);
+        }
+#pragma unroll
+        for (int kq = 0; kq < 6; ++kq) fM[(size_t)k * 6 + kq] = M[kq];
+        const double Mf[9] = {M[0], M[1], M[2], M[1], M[3], M[4], M[2], M[4], M[5]};
+        const double g3[3] = {cf * fa * u[0], cf * fa * u[1], cf * fa * u[2]};
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+          if (ri[r] < 0) continue;
+          const double pc = rc[8 + r];
+#pragma unroll
+          for (int i = 0; i < 3; ++i) {
+            atomicAdd(&vg[ri[r] * 3 + i], pc * g3[i]);
+#pragma unroll
+            for (int j = 0; j < 3; ++j) atomicAdd(&Dinv[(size_t)ri[r] * 9 + i * 3 + j], pc * pc * Mf[i * 3 + j]);
+          }
+        }
+#pragma unroll
+        for (int a4 = 0; a4 < 4; ++a4) {
+          const double ca = rc[4 + a4];
+          if (ca == 0.0) continue;
+#pragma unroll
+          for (int i = 0; i < 3; ++i) {
+            atomicAdd(&gb[a4 * 3 + i], ca * g3[i]);
+#pragma unroll
+            for (int c4 = 0; c4 < 4; ++c4)
+#pragma unroll
+              for (int j = 0; j < 3; ++j) atomicAdd(&Bm[(a4 * 3 + i) * 12 + c4 * 3 + j], ca * rc[4 + c4] * Mf[i * 3 + j]);
+          }
+        }
+      }
+      __syncthreads();
+    }
     // ---- ball rows: gradient, the block without the pairs (H.p) and with them (preconditioner, factored) ----
     if (tid < 144) {
       const int ra = tid / 12, ca = tid - ra * 12, a4 = ra / 3, i = ra - a4 * 3, c4 = ca / 3, j = ca - c4 * 3;
@@ -706,6 +833,36 @@ __global__ __launch_bounds__(512) void fem_ball_newton_kernel(FemDev m, BallDev 
               atomicAdd(&vHp[ri[r] * 3 + 1], f * rc[8 + r] * n1);
               atomicAdd(&vHp[ri[r] * 3 + 2], f * rc[8 + r] * n2);
             }
+        }
+      }
+      if (fric) {
+        const int nf = n_fric;
+        for (int k = tid; k < nf; k += NT) {
+          const double* rc = frec + (size_t)k * kBallRec;
+          const int* ri = reinterpret_cast<const int*>(rc + 11);
+          const double* M = fM + (size_t)k * 6;
+          double w3[3] = {0.0, 0.0, 0.0};
+#pragma unroll
+          for (int a4 = 0; a4 < 4; ++a4)
+#pragma unroll
+            for (int i = 0; i < 3; ++i) w3[i] += rc[4 + a4] * ps[(V + a4) * 3 + i];
+#pragma unroll
+          for (int r = 0; r < 3; ++r)
+            if (ri[r] >= 0)
+#pragma unroll
+              for (int i = 0; i < 3; ++i) w3[i] += rc[8 + r] * ps[ri[r] * 3 + i];
+          const double mw[3] = {M[0] * w3[0] + M[1] * w3[1] + M[2] * w3[2], M[1] * w3[0] + M[3] * w3[1] + M[4] * w3[2],
+                                M[2] * w3[0] + M[4] * w3[1] + M[5] * w3[2]};
+#pragma unroll
+          for (int a4 = 0; a4 < 4; ++a4)
+            if (rc[4 + a4] != 0.0)
+#pragma unroll
+              for (int i = 0; i < 3; ++i) atomicAdd(&vHp[(V + a4) * 3 + i], rc[4 + a4] * mw[i]);
+#pragma unroll
+          for (int r = 0; r < 3; ++r)
+            if (ri[r] >= 0)
+#pragma unroll
+              for (int i = 0; i < 3; ++i) atomicAdd(&vHp[ri[r] * 3 + i], rc[8 + r] * mw[i]);
         }
       }
       __syncthreads();

@@ -3055,13 +3055,14 @@ static int ball_args_ok(tacex_fem_ctx* c, const void* x, const void* q, const vo
 }
 
 int tacex_fem_ball_terms(tacex_fem_ctx* c, const double* x, const double* xt, const double* q, const double* qt, const uint8_t* cons, const double* aim,
-                         double* energy, double* grad, double* step_info, void* ws, int B, void* stream) {
+                         const double* x_prev, const double* q_prev, double* energy, double* grad, double* step_info, void* ws, int B, void* stream) {
   if (int rc = ball_args_ok(c, x, q, ws, cons, aim, "tacex_fem_ball_terms")) return rc;
   if (!xt || !qt) { set_error("tacex_fem_ball_terms: null argument"); return 2; }
   if (B <= 0) return 0;
   if (ball_lds_bytes(c->dev.V) > 48 * 1024) { set_error("tacex_fem_ball_terms: pad of %d vertices (the kernel keeps x, p and the H.p accumulators of <= 680 vertices in LDS)", c->dev.V); return 2; }
   hipLaunchKernelGGL(fem_ball_newton_kernel, dim3(B), dim3(512), ball_lds_bytes(c->dev.V), (hipStream_t)stream, c->dev, c->ball, const_cast<double*>(x), xt,
-                     const_cast<double*>(q), qt, cons, aim, static_cast<double*>(ws), 1, 1.0, 0, 1, 0.0, 0.0, step_info, 1, energy, grad);
+                     const_cast<double*>(q), qt, cons, aim, static_cast<double*>(ws), 1, 1.0, 0, 1, 0.0, 0.0, step_info, 1, energy, grad,
+                     (x_prev && q_prev) ? x_prev : nullptr, (x_prev && q_prev) ? q_prev : nullptr);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : fail_hip(e, "fem_ball_newton_kernel(terms)");
 }
@@ -3092,7 +3093,7 @@ int tacex_fem_ball_step(tacex_fem_ctx* c, double* x, double* v, double* q, doubl
   if (ball_lds_bytes(c->dev.V) > 48 * 1024) { set_error("tacex_fem_ball_step: pad of %d vertices (the kernel keeps x, p and the H.p accumulators of <= 680 vertices in LDS)", c->dev.V); return 2; }
   hipLaunchKernelGGL(fem_ball_newton_kernel, dim3(B), dim3(512), ball_lds_bytes(c->dev.V), st, c->dev, c->ball, x, xt, q, qt, cons, aim, static_cast<double*>(ws), pcg_max_iter,
                      pcg_tol_rate, ls_max_iter, max_newton, velocity_tol * dt, transrate_tol * dt, step_info, ball_coarse_off ? 2 : 0,
-                     static_cast<double*>(nullptr), static_cast<double*>(nullptr));
+                     static_cast<double*>(nullptr), static_cast<double*>(nullptr), static_cast<const double*>(xprev), static_cast<const double*>(qprev));
   hipLaunchKernelGGL(fem_velocity_kernel, dim3((unsigned)((n3 + 255) / 256)), dim3(256), 0, st, x, xprev, v, n3, 1.0 / dt, static_cast<const double*>(nullptr),
                      static_cast<double*>(nullptr), B);
   hipLaunchKernelGGL(fem_ball_velocity_kernel, dim3((unsigned)((B * 12 + 255) / 256)), dim3(256), 0, st, q, qprev, qv, B, 1.0 / dt);

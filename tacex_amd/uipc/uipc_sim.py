@@ -184,6 +184,9 @@ class UipcSim:
             self._handle, len(verts), verts.ctypes.data, len(tris), tris.ctypes.data, float(body.cfg.mass_density),
             float(body.cfg.constitution_cfg.m_kappa) * 1e6, area.ctypes.data, len(ptri), ptri.ctypes.data, d_hat,
             float(c.default_contact_resistance) * 1e9 * d_hat, float(self.cfg.ground_height), 1 if c.enable else 0), "tacex_fem_set_affine_body")
+        # one default contact model for every pair of surfaces (US:192-201): friction ratio / eps_velocity of the cfg act on the pairs and the ground
+        _lib.check(self._lib.tacex_fem_set_friction(self._handle, float(c.default_friction_ratio) if c.enable_friction else 0.0,
+                                                    float(c.eps_velocity)), "tacex_fem_set_friction")
         self._body = body
         q0 = np.concatenate([np.asarray(body.cfg.init_pos, np.float64)[None], np.eye(3)], 0)
         self.q = torch.from_numpy(q0).to(dev)[None].repeat(B, 1, 1).contiguous()  # (B,4,3) float64
@@ -196,8 +199,9 @@ class UipcSim:
         q = self.q if q is None else q
         return torch.einsum("va,bai->bvi", self._body_Y, q)
 
-    def ball_terms(self, x=None, q=None, x_tilde=None, q_tilde=None, constrained=True):
-        """Energy (num_envs,) and gradient (num_envs, V + 4, 3) of the step's incremental potential at (x, q) (`tacex_fem_ball_terms`)."""
+    def ball_terms(self, x=None, q=None, x_tilde=None, q_tilde=None, constrained=True, x_prev=None, q_prev=None):
+        """Energy (num_envs,) and gradient (num_envs, V + 4, 3) of the step's incremental potential at (x, q) (`tacex_fem_ball_terms`).
+        x_prev / q_prev: the state friction slides relative to (None: friction off in this evaluation)."""
         x = self.x if x is None else x
         q = self.q if q is None else q
         xt = x if x_tilde is None else x_tilde
@@ -209,6 +213,7 @@ class UipcSim:
         with torch.cuda.device(self.device):
             rc = self._lib.tacex_fem_ball_terms(self._handle, _lib.ptr(x), _lib.ptr(xt), _lib.ptr(q), _lib.ptr(qt),
                                                 _lib.ptr(self.is_constrained) if constrained else 0, _lib.ptr(self.aim_position) if constrained else 0,
+                                                _lib.ptr(x_prev) if x_prev is not None else 0, _lib.ptr(q_prev) if q_prev is not None else 0,
                                                 _lib.ptr(E), _lib.ptr(g), _lib.ptr(si), _lib.ptr(self._ball_ws), B, self._stream())
         _lib.check(rc, "tacex_fem_ball_terms")
         return E, g, si
