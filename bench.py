@@ -532,9 +532,9 @@ def sweep(args, dev):
     run("c4_rolling", "C4 shard, rolling contact: the indenter stays on the pad and slides, friction on",
         512, 240, 320, 1, False, fem=lambda: FemGelpad(512, dev, motion="rolling", max_newton_iter=NEWTON_CAP, side_stream=True))
     # the reference's own UIPC scene (ball_rolling_uipc.py:71-125): free affine-body ball on the ground under the pad, pairs both ways, d_hat 5e-4.
-    # Stepped by the streaming-form kernel of csrc/fem_ball.h (pad vectors through HBM): 128 envs, and a cap that MAY bind - reported, not asserted
-    run("c4_ball", "C4-shaped, the reference's UIPC scene: 128 envs, RGB 320x240 + FEM-driven markers + gelpad FEM step against a FREE affine-body ball on the ground (point-triangle pairs both ways, d_hat 5e-4)",
-        128, 240, 320, 1, False, fem=lambda: FemBallScene(128, dev, max_newton_iter=NEWTON_CAP, side_stream=True), cap_may_bind=True)
+    # with friction on every contact (the cfg's default contact model); stepped by csrc/fem_ball.h (one launch per time step)
+    run("c4_ball", "C4 per-GPU shard on the reference's UIPC scene: 512 envs, RGB 320x240 + FEM-driven markers + gelpad FEM step against a FREE affine-body ball on the ground (point-triangle pairs both ways + friction, d_hat 5e-4)",
+        512, 240, 320, 1, False, fem=lambda: FemBallScene(512, dev, max_newton_iter=NEWTON_CAP, side_stream=True))
     run("c5", "C5 per-GPU shard: 1024 envs, RGB 640x480 + FEM-driven markers (gelpad FEM step included) (BASELINE configs[4] / 8)",
         1024, 480, 640, 1, False, fem=lambda: FemGelpad(1024, dev, max_newton_iter=NEWTON_CAP, side_stream=True))
     # (with the coarse correction in M^-1 the reference's PCG test - 1e-3 on r.z - can pass after ONE iteration on this rod, whose coarse modes are

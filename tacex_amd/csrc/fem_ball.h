@@ -116,7 +116,10 @@ __device__ __forceinline__ void barrier3(double s, double& b, double& b1, double
 }
 
 // mode 0: Newton loop of a time step; mode 1: energy and gradient at (x, q) only (terms entry point of the C ABI: tests)
-__global__ __launch_bounds__(512) void fem_ball_newton_kernel(FemDev m, BallDev bd, double* xg, const double* xtg, double* qg, const double* qtg,
+#ifndef TACEX_BALL_WG_PER_CU
+#define TACEX_BALL_WG_PER_CU 2  // waves per SIMD the kernel is compiled for (2 = one env per CU; A/B: 4 = two envs co-resident at <= 128 VGPRs, profiles/r06_experiments.md section 5)
+#endif
+__global__ __launch_bounds__(512, TACEX_BALL_WG_PER_CU) void fem_ball_newton_kernel(FemDev m, BallDev bd, double* xg, const double* xtg, double* qg, const double* qtg,
                                                               const uint8_t* consg, const double* aimg, double* wsg, int pcg_max_iter,
                                                               double pcg_tol_rate, int ls_max_iter, int max_newton, double dx_tol, double dc_tol,
                                                               double* step_info, int mode, double* e_out, double* g_out, const double* xprevg,
