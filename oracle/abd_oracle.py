@@ -26,7 +26,10 @@ The model follows the PUBLISHED sources libuipc implements:
     fem_oracle.py uses) and, for the orthogonality energy, 4 kappa vol [delta_mn A A^T + c_n c_m^T] (the term r_mn I of the exact
     Hessian, r = A^T A - I, is dropped: it vanishes on rotations and is what makes the exact Hessian indefinite under compression).
     Gradients are exact, so Newton converges to stationary points of the plain potential (tests/test_abd_oracle.py checks them by
-    finite differences).  No friction and no edge-edge pairs between the two bodies in this slice.
+    finite differences).  Lagged Coulomb friction (Li et al. 2020 eq. 18-20, section 5.4: normal force, normal and barycentric weights
+    of every contact frozen at the state the step starts from) acts on the pairs of both kinds and on the ground contacts of both
+    bodies once `BallScene.mu` is set - the reference's one default contact model (US:103-124, 192-201: ratio 0.5, eps_velocity 0.01).
+    No edge-edge pairs between the two bodies in this slice.
 """
 from __future__ import annotations
 

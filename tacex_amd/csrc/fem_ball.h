@@ -9,14 +9,18 @@
 //     kappa vol |A^T A - I|^2 with its Gauss-Newton Hessian 4 kappa vol [delta_mn A A^T + c_n c_m^T];
 //   * barrier kappa w b(d / d_hat) on every pair (pad surface vertex, ball triangle) and (ball vertex, pad surface triangle) closer
 //     than d_hat, and of the ground against the surface vertices of both bodies; Hessians b'' grad d grad d^T;
-//   * matrix-free PCG, preconditioned by 3 x 3 blocks on the pad vertices and by the EXACT inverse of the 12 x 12 ball block;
+//   * lagged Coulomb friction of every one of those contacts (the cfg's one default contact model, US:103-124 / 192-201): normal force,
+//     normal and barycentric weights frozen at the state the step starts from, sliding measured relative to it (IPC's lag);
+//   * matrix-free PCG: x, p and the per-vertex H.p accumulators in LDS (tet rows by ds_add_f64, the tet state recomputed from x);
+//     preconditioner = 3 x 3 blocks on the pad vertices + the additive coarse correction of the pad's coarse space
+//     (tacex_fem_set_coarse_space) + the EXACT inverse of the 12 x 12 ball block;
 //   * step bound: ground gaps (linear), additive CCD on the listed pairs, no surface point further than 0.9 d_hat per iteration;
 //   * backtracking line search on the plain incremental potential; convergence on the unscaled direction: velocity_tol * dt on the
 //     position rows AND transrate_tol * dt on the ball's affine rows (UipcSimCfg.newton, uipc_sim.py:62-66).
-// One workgroup (512 threads) per env, the whole Newton loop of a time step in ONE launch.  The pad's vectors live in the env's
-// workspace block (L2 / HBM, like fem_newton_kernel: this is the streaming form - see DESIGN.md for why the CU-resident kernel does
-// not carry the scene); pair candidates are rebuilt once per Newton iteration at reach 2.8 d_hat, which no pair outside can cross
-// into d_hat within one bounded step, so the line search's energies are exact.
+// One workgroup (512 threads) per env, the whole Newton loop of a time step in ONE launch.  The pad's r, z, d, H.p and blocks live in
+// the env's workspace block (L2 / HBM); pair candidates are rebuilt once per Newton iteration at reach 2.8 d_hat, which no pair
+// outside can cross into d_hat within one bounded step, so the line search's energies are exact.  (The CU-resident kernel of the
+// prescribed-indenter scenes keeps ALL per-vertex state in registers and is at its register limit: this scene got a kernel of its own.)
 
 struct BallDev {
   int nv = 0, nt = 0, npt = 0, nsv = 0;
