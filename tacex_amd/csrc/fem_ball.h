@@ -127,15 +127,18 @@ __global__ __launch_bounds__(512, TACEX_BALL_WG_PER_CU) void fem_ball_newton_ker
                                                               const uint8_t* consg, const double* aimg, double* wsg, int pcg_max_iter,
                                                               double pcg_tol_rate, int ls_max_iter, int max_newton, double dx_tol, double dc_tol,
                                                               double* step_info, int mode, double* e_out, double* g_out, const double* xprevg,
-                                                              const double* qprevg) {
+                                                              const double* qprevg, const int* env_order) {
   extern __shared__ __attribute__((aligned(16))) double ball_lds[];  // x (V,3) | p (V + 4,3) | H.p accumulators (V,3): ball_lds_bytes()
-  __shared__ double sh[17];
+  __shared__ double sh[17], sh2[16];
   __shared__ double gb[12], Bm[144], B0[144], Lc[144], Bi[144], YY[16], qs[12], qts[12], rhs12[12];
   __shared__ double crc[3 * kFemMaxCoarse], cyc[3 * kFemMaxCoarse];  // coarse residual / correction of the two-level preconditioner
   __shared__ double qps[12];  // the ball rows the time step started from (friction slides relative to them)
   __shared__ int n_cpv, n_cpt, n_cbv, n_pairs, n_act, n_fric, s_flags;
   __shared__ int cpv[kBallMaxCand], cpt[kBallMaxCand], cbv[kBallMaxCand];
-  const int b = blockIdx.x, tid = threadIdx.x, NT = blockDim.x;
+  // env_order: envs sorted by the solver work of their previous step, heaviest first (fem_env_order_kernel): a shard brings two envs
+  // per CU, the launch ends with whatever the last-started ones need
+  const int b = env_order ? env_order[blockIdx.x] : (int)blockIdx.x;
+  const int tid = threadIdx.x, NT = blockDim.x;
   const int V = m.V, T = m.T, nv = bd.nv, nt = bd.nt, VN = V + 4;
   const size_t o = (size_t)b * V * 3;
   double* x = xg + o;
@@ -290,6 +293,21 @@ __global__ __launch_bounds__(512, TACEX_BALL_WG_PER_CU) void fem_ball_newton_ker
     }
     return block_sum(e, sh);
   };
+  // block-wide sum with ONE barrier (two alternating rows of wave partials: the row written two calls ago cannot still be read, a
+  // barrier lies in between) - the PCG loop runs two of these per iteration
+  int bphase = 0;
+  auto bsum = [&](double v) -> double {
+#pragma unroll
+    for (int o2 = 32; o2 > 0; o2 >>= 1) v += __shfl_xor(v, o2, 64);
+    double* row = sh2 + 8 * (bphase & 1);
+    ++bphase;
+    if ((tid & 63) == 0) row[tid >> 6] = v;
+    __syncthreads();
+    double sv = 0.0;
+#pragma unroll
+    for (int w8 = 0; w8 < 8; ++w8) sv += row[w8];
+    return sv;
+  };
   const bool coarse = m.nc > 0 && m.cn_off && m.ac_inv && (mode & 2) == 0;  // (mode bit 1: block Jacobi alone, A/B)
   // z = M^-1 r: 3 x 3 blocks on the pad rows (+ the coarse correction), the exact inverse of the 12 x 12 ball block on the ball rows
   auto precondition = [&](const double* r, double* z) -> double {
@@ -345,7 +363,7 @@ __global__ __launch_bounds__(512, TACEX_BALL_WG_PER_CU) void fem_ball_newton_ker
         }
       }
     }
-    return block_sum(part, sh);
+    return bsum(part);
   };
 
   ball_points(qs, xb);
@@ -782,9 +800,9 @@ __global__ __launch_bounds__(512, TACEX_BALL_WG_PER_CU) void fem_ball_newton_ker
     const double rz0 = rz;
     int it = 0;
     __syncthreads();
+    for (int k = tid; k < 3 * V; k += NT) acc[k] = 0.0;
+    __syncthreads();
     while (it < pcg_max_iter && rz0 > 0.0 && rz > pcg_tol_rate * rz0) {
-      for (int k = tid; k < 3 * V; k += NT) acc[k] = 0.0;
-      __syncthreads();
       for (int t = tid; t < T; t += NT) {
         int v[4];
         double Di[9], F[9], dF[9], dP[9], r[12];
@@ -806,7 +824,10 @@ __global__ __launch_bounds__(512, TACEX_BALL_WG_PER_CU) void fem_ball_newton_ker
       for (int v = tid; v < V; v += NT) {
         const double md = m.mass[v] * (1.0 + ((cons && cons[v]) ? m.strength : 0.0));
 #pragma unroll
-        for (int i = 0; i < 3; ++i) vHp[v * 3 + i] = acc[v * 3 + i] + md * ps[v * 3 + i] + (i == 2 ? cbp[v] * ps[v * 3 + 2] : 0.0);
+        for (int i = 0; i < 3; ++i) {
+          vHp[v * 3 + i] = acc[v * 3 + i] + md * ps[v * 3 + i] + (i == 2 ? cbp[v] * ps[v * 3 + 2] : 0.0);
+          acc[v * 3 + i] = 0.0;  // (for the next iteration's sweep: the same thread read it, barriers lie before the next atomics)
+        }
       }
       if (tid < 12) {
         double sv = 0.0;
@@ -875,7 +896,7 @@ __global__ __launch_bounds__(512, TACEX_BALL_WG_PER_CU) void fem_ball_newton_ker
       __syncthreads();
       double part = 0.0;
       for (int k = tid; k < 3 * VN; k += NT) part += ps[k] * vHp[k];
-      const double pHp = block_sum(part, sh);
+      const double pHp = bsum(part);
       if (!(pHp > 0.0)) {
         if (it == 0)
           for (int k = tid; k < 3 * VN; k += NT) vd[k] = vz[k];

@@ -3036,8 +3036,8 @@ int tacex_fem_set_affine_body(tacex_fem_ctx* c, int num_verts, const double* ver
 
 size_t tacex_fem_ball_workspace_bytes(const tacex_fem_ctx* c, int B) {
   if (!c || B <= 0 || c->ball.nv == 0) return 0;
-  // env blocks | x_prev (B,V,3) | q_prev (B,12) | x~ (B,V,3) | q~ (B,12)
-  return ((size_t)B * ball_ws_doubles(c->dev.V, c->dev.T, c->ball.nv, c->ball.nt) + (size_t)B * 6 * c->dev.V + (size_t)B * 24 + 8) * sizeof(double);
+  // env blocks | x_prev (B,V,3) | q_prev (B,12) | x~ (B,V,3) | q~ (B,12) | env launch order (B int32)
+  return ((size_t)B * ball_ws_doubles(c->dev.V, c->dev.T, c->ball.nv, c->ball.nt) + (size_t)B * 6 * c->dev.V + (size_t)B * 24 + 8 + ((size_t)B + 1) / 2) * sizeof(double);
 }
 
 int tacex_fem_ball_moments(const tacex_fem_ctx* c, double moments_out[16], double* kappa_vol_out) {
@@ -3062,7 +3062,7 @@ int tacex_fem_ball_terms(tacex_fem_ctx* c, const double* x, const double* xt, co
   if (ball_lds_bytes(c->dev.V) > 48 * 1024) { set_error("tacex_fem_ball_terms: pad of %d vertices (the kernel keeps x, p and the H.p accumulators of <= 680 vertices in LDS)", c->dev.V); return 2; }
   hipLaunchKernelGGL(fem_ball_newton_kernel, dim3(B), dim3(512), ball_lds_bytes(c->dev.V), (hipStream_t)stream, c->dev, c->ball, const_cast<double*>(x), xt,
                      const_cast<double*>(q), qt, cons, aim, static_cast<double*>(ws), 1, 1.0, 0, 1, 0.0, 0.0, step_info, 1, energy, grad,
-                     (x_prev && q_prev) ? x_prev : nullptr, (x_prev && q_prev) ? q_prev : nullptr);
+                     (x_prev && q_prev) ? x_prev : nullptr, (x_prev && q_prev) ? q_prev : nullptr, static_cast<const int*>(nullptr));
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : fail_hip(e, "fem_ball_newton_kernel(terms)");
 }
@@ -3090,10 +3090,17 @@ int tacex_fem_ball_step(tacex_fem_ctx* c, double* x, double* v, double* q, doubl
                      gravity[0], gravity[1], gravity[2], static_cast<const double*>(nullptr), static_cast<double*>(nullptr), static_cast<double*>(nullptr), 0);
   hipLaunchKernelGGL(fem_ball_predict_kernel, dim3((unsigned)((B * 12 + 255) / 256)), dim3(256), 0, st, q, qv, qt, qprev, B, dt, gravity[0], gravity[1],
                      gravity[2]);
+  int* env_order = nullptr;
+  static const int use_order = getenv("TACEX_FEM_ORDER") ? atoi(getenv("TACEX_FEM_ORDER")) : 1;
+  if (use_order && B > 256) {  // (step_info still holds the previous step's counts; a first step sorts zeros = index order)
+    env_order = reinterpret_cast<int*>(qt + (size_t)B * 12 + 1);
+    hipLaunchKernelGGL(fem_env_order_kernel, dim3(1), dim3(1024), 0, st, step_info, B, env_order);
+  }
   if (ball_lds_bytes(c->dev.V) > 48 * 1024) { set_error("tacex_fem_ball_step: pad of %d vertices (the kernel keeps x, p and the H.p accumulators of <= 680 vertices in LDS)", c->dev.V); return 2; }
   hipLaunchKernelGGL(fem_ball_newton_kernel, dim3(B), dim3(512), ball_lds_bytes(c->dev.V), st, c->dev, c->ball, x, xt, q, qt, cons, aim, static_cast<double*>(ws), pcg_max_iter,
                      pcg_tol_rate, ls_max_iter, max_newton, velocity_tol * dt, transrate_tol * dt, step_info, ball_coarse_off ? 2 : 0,
-                     static_cast<double*>(nullptr), static_cast<double*>(nullptr), static_cast<const double*>(xprev), static_cast<const double*>(qprev));
+                     static_cast<double*>(nullptr), static_cast<double*>(nullptr), static_cast<const double*>(xprev), static_cast<const double*>(qprev),
+                     static_cast<const int*>(env_order));
   hipLaunchKernelGGL(fem_velocity_kernel, dim3((unsigned)((n3 + 255) / 256)), dim3(256), 0, st, x, xprev, v, n3, 1.0 / dt, static_cast<const double*>(nullptr),
                      static_cast<double*>(nullptr), B);
   hipLaunchKernelGGL(fem_ball_velocity_kernel, dim3((unsigned)((B * 12 + 255) / 256)), dim3(256), 0, st, q, qprev, qv, B, 1.0 / dt);
