@@ -546,6 +546,8 @@ def sweep(args, dev):
         out.append(fem_axle_entry(dev, tol_rate=1e-6, key="axle_tol1e-6"))
     if only is None or "axle_streaming" in only:
         out.append(fem_axle_entry(dev, steps=6, streaming=True, tol_rate=1e-6, key="axle_streaming"))
+    if only is None or "axle_streaming_2level" in only:
+        out.append(fem_axle_entry(dev, steps=6, streaming=True, tol_rate=1e-6, key="axle_streaming_2level", two_level=True))
     run("c5_optical", "C5 optical part only: 1024 envs, RGB 640x480", 1024, 480, 640, 1, False, steps=max(5, args.sweep_steps // 3))
     return out
 
@@ -571,6 +573,7 @@ SWEEP_NOTES = {
             "on through the IPC barrier: the CU-resident Newton kernel, 768 threads per env (friction, coarse correction, chains: the defaults)",
     "axle_tol1e-6": "the same with the PCG threshold of rounds 1-4 (1e-6 on r.z)",
     "axle_streaming": "the streaming Newton kernel (deterministic switch; block Jacobi, friction off as in rounds 3-4), PCG threshold 1e-6",
+    "axle_streaming_2level": "the same with the coarse correction on the bounding-box grid (round 6: the streaming kernel's two-level preconditioner)",
 }
 
 
@@ -581,7 +584,7 @@ NEWTON_CAP = 64  # Newton iterations a FEM scene of the sweep may take per step 
 AXLE_NEWTON_CAP = 200  # (the bent axle's iterations in PSD-safe mode converge linearly: 50 in the worst env and step measured)
 
 
-def fem_axle_entry(dev, B=512, steps=12, streaming=False, tol_rate=None, key="axle"):
+def fem_axle_entry(dev, B=512, steps=12, streaming=False, tol_rate=None, key="axle", two_level=False):
     """SURVEY section 8(d)'s ~2k-tet fixture simple_axle.msh (593 vertices / 2 003 tets) stepped with sphere contact - FEM only, env steps
     per second.  Default: the 768-thread variant of the CU-resident Newton kernel with everything the gelpad scene uses (friction,
     coarse correction on the bounding-box grid, the chains found in the mesh).  streaming=True: the streaming Newton kernel (what
@@ -600,7 +603,7 @@ def fem_axle_entry(dev, B=512, steps=12, streaming=False, tol_rate=None, key="ax
         if tol_rate is not None:
             cfg.linear_system.tol_rate = tol_rate
         if streaming:
-            cfg.linear_system.coarse_grid, cfg.linear_system.vertex_chains = None, None
+            cfg.linear_system.coarse_grid, cfg.linear_system.vertex_chains = ("auto" if two_level else None), None  # (round 6: the streaming kernel takes the coarse space)
             cfg.linear_system.deterministic = True
             cfg.contact.enable_friction = False  # (the entry's workload since round 3; the streaming kernel has friction since round 5)
         sim = UipcSim(cfg, num_envs=B)

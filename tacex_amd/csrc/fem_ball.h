@@ -328,40 +328,10 @@ __global__ __launch_bounds__(512, TACEX_BALL_WG_PER_CU) void fem_ball_newton_ker
       part += r[V * 3 + tid] * zz;
     }
     if (coarse) {
-      // additive coarse correction on the pad rows, z += P A_c^-1 P^T r (tacex_fem_set_coarse_space: trilinear hats of a coarse grid over the
-      // pad, A_c the rest-state operator's Galerkin product - the second level of the CU-resident kernel's preconditioner; block Jacobi
-      // alone needs ~50 PCG iterations per Newton iteration on this pad, profiles/r06_experiments.md)
-      const int nc3 = 3 * m.nc;
-      int G = 1;
-      while (2 * G <= NT / m.nc && 2 * G <= 64) G *= 2;
-      const int node = tid / G, j = tid - node * G;
-      double a0 = 0.0, a1 = 0.0, a2 = 0.0;
-      if (node < m.nc) {
-        const int e1 = m.cn_off[node + 1];
-        for (int e = m.cn_off[node] + j; e < e1; e += G) {
-          const int v0 = m.cn_vtx[e];
-          const double w0 = m.cn_w[e];
-          a0 += w0 * r[v0 * 3]; a1 += w0 * r[v0 * 3 + 1]; a2 += w0 * r[v0 * 3 + 2];
-        }
-      }
-      for (int o2 = G >> 1; o2 > 0; o2 >>= 1) { a0 += __shfl_xor(a0, o2, 64); a1 += __shfl_xor(a1, o2, 64); a2 += __shfl_xor(a2, o2, 64); }
-      if (node < m.nc && j == 0) { crc[node * 3] = a0; crc[node * 3 + 1] = a1; crc[node * 3 + 2] = a2; }
+      // additive coarse correction on the pad rows (coarse_correct, fem_kernels.hip: the second level of the CU-resident kernel's
+      // preconditioner; block Jacobi alone needs ~48 PCG iterations per Newton iteration on this pad, with it 14-24, r06 section 5)
       __syncthreads();
-      if (tid < nc3) {
-        double sv = 0.0;
-        for (int k = 0; k < nc3; ++k) sv += m.ac_inv[(size_t)tid * nc3 + k] * crc[k];
-        cyc[tid] = sv;
-        part += crc[tid] * sv;
-      }
-      __syncthreads();
-      for (int v = tid; v < V; v += NT) {
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-          const int nd = m.cv_node[v * 8 + k];
-          const double w = m.cv_w[v * 8 + k];
-          z[v * 3] += w * cyc[nd * 3]; z[v * 3 + 1] += w * cyc[nd * 3 + 1]; z[v * 3 + 2] += w * cyc[nd * 3 + 2];
-        }
-      }
+      part += coarse_correct(m, r, z, crc, cyc);
     }
     return bsum(part);
   };

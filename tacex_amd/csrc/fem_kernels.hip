@@ -706,6 +706,46 @@ __device__ __forceinline__ bool inv3_spd(const double A[9], double Ai[9]) {
   return true;
 }
 
+// Additive coarse correction of the two-level preconditioner for kernels whose vectors live in memory (fem_newton_kernel, fem_ball_newton_kernel):
+// z += P A_c^-1 P^T r over the (V,3) rows of one env (tacex_fem_set_coarse_space: trilinear hats of a coarse grid, A_c the rest-state
+// operator's Galerkin product).  Every thread of the workgroup calls it; rc / yc: 3 * kFemMaxCoarse doubles of LDS each.  Returns this
+// thread's share of r . (P A_c^-1 P^T r) (add it to the partial sum of r . z before the block reduction).  Fixed summation order.
+__device__ __forceinline__ double coarse_correct(const FemDev& m, const double* r, double* z, double* rc, double* yc) {
+  const int nc3 = 3 * m.nc, NT = (int)blockDim.x, tid = (int)threadIdx.x;
+  int G = 1;
+  while (2 * G <= NT / m.nc && 2 * G <= 64) G *= 2;
+  const int node = tid / G, j = tid - node * G;
+  double a0 = 0.0, a1 = 0.0, a2 = 0.0;
+  if (node < m.nc) {
+    const int e1 = m.cn_off[node + 1];
+    for (int e = m.cn_off[node] + j; e < e1; e += G) {
+      const int v0 = m.cn_vtx[e];
+      const double w0 = m.cn_w[e];
+      a0 += w0 * r[v0 * 3]; a1 += w0 * r[v0 * 3 + 1]; a2 += w0 * r[v0 * 3 + 2];
+    }
+  }
+  for (int o2 = G >> 1; o2 > 0; o2 >>= 1) { a0 += __shfl_xor(a0, o2, 64); a1 += __shfl_xor(a1, o2, 64); a2 += __shfl_xor(a2, o2, 64); }
+  if (node < m.nc && j == 0) { rc[node * 3] = a0; rc[node * 3 + 1] = a1; rc[node * 3 + 2] = a2; }
+  __syncthreads();
+  double part = 0.0;
+  if (tid < nc3) {
+    double sv = 0.0;
+    for (int k = 0; k < nc3; ++k) sv += m.ac_inv[(size_t)tid * nc3 + k] * rc[k];
+    yc[tid] = sv;
+    part = rc[tid] * sv;
+  }
+  __syncthreads();
+  for (int v = tid; v < m.V; v += NT) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int nd = m.cv_node[v * 8 + k];
+      const double w = m.cv_w[v * 8 + k];
+      z[v * 3] += w * yc[nd * 3]; z[v * 3 + 1] += w * yc[nd * 3 + 1]; z[v * 3 + 2] += w * yc[nd * 3 + 2];
+    }
+  }
+  return part;
+}
+
 // flags of step_info[., 2]
 constexpr int kFemFlagPenetration = 1;  // a contact vertex was at or beyond the indenter surface when the iteration started
 constexpr int kFemFlagLsFailed = 2;     // a line search found no decrease even after the rescue halvings
@@ -720,6 +760,7 @@ __global__ __launch_bounds__(512) void fem_newton_kernel(FemDev m, double* xg, c
   // step (accumulate = 0), added to / OR-ed by the later ones: tacex_fem_step runs this kernel once per Newton iteration, and
   // UipcSim.check_step() must see a penetrating vertex or a dead line search of ANY of them (the row used to be zeroed)
   __shared__ double sh[17];
+  __shared__ double crc[3 * kFemMaxCoarse], cyc[3 * kFemMaxCoarse];
   const int b = blockIdx.x;
   if (dxg && dxg[b] <= dx_tol) {  // converged in an earlier launch of this time step (same protocol as the CU-resident kernel)
     if (threadIdx.x == 0) { stats[(size_t)b * 4 + 2] = 0.0; stats[(size_t)b * 4 + 3] = 0.0; }
@@ -902,10 +943,19 @@ __global__ __launch_bounds__(512) void fem_newton_kernel(FemDev m, double* xg, c
       const double z = Dinv[(size_t)v * 9 + i * 3 + 0] * vr[v * 3 + 0] + Dinv[(size_t)v * 9 + i * 3 + 1] * vr[v * 3 + 1] +
                        Dinv[(size_t)v * 9 + i * 3 + 2] * vr[v * 3 + 2];
       vz[v * 3 + i] = z;
-      vp[v * 3 + i] = z;
       part += vr[v * 3 + i] * z;
     }
   }
+  // two-level preconditioner (round 6): block Jacobi + the additive coarse correction of tacex_fem_set_coarse_space - what the CU-resident
+  // kernel applies minus its vertex chains; meshes beyond its reach (> 768 vertices, or the deterministic switch) no longer pay block
+  // Jacobi's iteration counts.  The summation order is fixed: deterministic runs stay bit-identical.
+  const bool two_level = m.nc > 0 && m.cn_off && m.ac_inv;
+  if (two_level) {
+    __syncthreads();
+    part += coarse_correct(m, vr, vz, crc, cyc);
+  }
+  __syncthreads();
+  for (int k = threadIdx.x; k < 3 * V; k += blockDim.x) vp[k] = vz[k];
   double rz = block_sum(part, sh);
   const double rz0 = rz;
   int it = 0;
@@ -979,6 +1029,11 @@ __global__ __launch_bounds__(512) void fem_newton_kernel(FemDev m, double* xg, c
         vz[v * 3 + i] = z;
         part += rr[i] * z;
       }
+    }
+    if (two_level) {
+      __syncthreads();
+      part += coarse_correct(m, vr, vz, crc, cyc);
+      __syncthreads();
     }
     const double rz_new = block_sum(part, sh);
     const double beta = rz_new / rz;
