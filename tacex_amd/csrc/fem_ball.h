@@ -339,6 +339,8 @@ __global__ __launch_bounds__(512, TACEX_BALL_WG_PER_CU) void fem_ball_newton_ker
   ball_points(qs, xb);
   __syncthreads();
   int n_newton = 0, pcg_total = 0;
+  double e_carry = 0.0;
+  bool have_e = false;
   double dmax_x = INFINITY, dmax_c = INFINITY;
   for (int nit = 0; nit < max_newton; ++nit) {
     const bool take_lag = fric && (nit == 0);  // (the first iteration stands at the state the step starts from)
@@ -481,7 +483,17 @@ __global__ __launch_bounds__(512, TACEX_BALL_WG_PER_CU) void fem_ball_newton_ker
         }
       }
       cbp[v] = cb;
-      for (int e = m.vt_off[v]; e < m.vt_off[v + 1]; ++e) {
+      // ELASTIC part of the block: assembled in the first iteration of the step and kept (hv: idle since the PCG's rows go through LDS) -
+      // between the Newton iterations of one step the deformation gradients move by per cent, the blocks that change by orders of
+      // magnitude (barriers, friction) are added fresh, and a preconditioner only has to stay SPD (the CU-resident kernel does the same);
+      // 72 applications of the element Hessian per vertex otherwise, the largest fixed cost of an iteration
+      double* Del = hv + (size_t)v * 9;
+      if (nit > 0) {
+#pragma unroll
+        for (int k = 0; k < 9; ++k) D[k] += Del[k];
+      }
+      double De[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+      for (int e = m.vt_off[v]; nit == 0 && e < m.vt_off[v + 1]; ++e) {
         const int code = m.vt_idx[e];
         const int t = code >> 2, l = code & 3;
         double Di[9], r[12];
@@ -507,8 +519,12 @@ __global__ __launch_bounds__(512, TACEX_BALL_WG_PER_CU) void fem_ball_newton_ker
           apply_dP(m, s, dF, dP);
 #pragma unroll
           for (int i = 0; i < 3; ++i)
-            D[i * 3 + k] += sc * (dP[i * 3 + 0] * r[l * 3 + 0] + dP[i * 3 + 1] * r[l * 3 + 1] + dP[i * 3 + 2] * r[l * 3 + 2]);
+            De[i * 3 + k] += sc * (dP[i * 3 + 0] * r[l * 3 + 0] + dP[i * 3 + 1] * r[l * 3 + 1] + dP[i * 3 + 2] * r[l * 3 + 2]);
         }
+      }
+      if (nit == 0) {
+#pragma unroll
+        for (int k = 0; k < 9; ++k) { Del[k] = De[k]; D[k] += De[k]; }
       }
 #pragma unroll
       for (int k = 0; k < 9; ++k) Dinv[(size_t)v * 9 + k] = D[k];
@@ -937,7 +953,8 @@ __global__ __launch_bounds__(512, TACEX_BALL_WG_PER_CU) void fem_ball_newton_ker
     }
     dmax_x = dmx; dmax_c = dmc;
     // ---- backtracking line search (first E <= E0 wins; rescue halvings as in the other Newton kernels) ----
-    const double E0 = energy(x, qs, xb);
+    // E(x): the accepted candidate's energy of the previous iteration IS this iteration's (every pair inside d_hat is in both lists)
+    const double E0 = have_e ? e_carry : energy(x, qs, xb);
     double step = amax, E1 = E0;
     bool accepted = false;
     const int ls_cap = ls_max_iter > kLsRescueStream ? ls_max_iter : kLsRescueStream;
@@ -948,7 +965,7 @@ __global__ __launch_bounds__(512, TACEX_BALL_WG_PER_CU) void fem_ball_newton_ker
       ball_points(rhs12, xbc);
       __syncthreads();
       const double Ec = energy(yc, rhs12, xbc);
-      if (Ec <= E0) { E1 = Ec; accepted = true; break; }
+      if (Ec <= E0) { E1 = Ec; accepted = true; e_carry = Ec; have_e = true; break; }
       step *= 0.5;
       __syncthreads();
     }

@@ -3105,6 +3105,7 @@ int tacex_fem_ball_moments(const tacex_fem_ctx* c, double moments_out[16], doubl
 static int ball_args_ok(tacex_fem_ctx* c, const void* x, const void* q, const void* ws, const uint8_t* cons, const double* aim, const char* who) {
   if (!c || !x || !q || !ws) { set_error("%s: null argument", who); return 2; }
   if (c->ball.nv == 0) { set_error("%s: no affine body (tacex_fem_set_affine_body)", who); return 2; }
+  if ((size_t)9 * c->dev.V > (size_t)12 * c->dev.T) { set_error("%s: mesh with more than 4/3 vertices per tet (the lagged blocks share a per-tet array)", who); return 2; }
   if ((cons == nullptr) != (aim == nullptr)) { set_error("%s: constrained_dev and aim_dev go together", who); return 2; }
   return 0;
 }

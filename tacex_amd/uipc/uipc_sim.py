@@ -189,7 +189,8 @@ class UipcSim:
                                                     float(c.eps_velocity)), "tacex_fem_set_friction")
         self._body = body
         q0 = np.concatenate([np.asarray(body.cfg.init_pos, np.float64)[None], np.eye(3)], 0)
-        self.q = torch.from_numpy(q0).to(dev)[None].repeat(B, 1, 1).contiguous()  # (B,4,3) float64
+        self._q0 = torch.from_numpy(q0).to(dev)
+        self.q = self._q0[None].repeat(B, 1, 1).contiguous()  # (B,4,3) float64
         self.qv = torch.zeros_like(self.q)
         self._body_Y = torch.from_numpy(np.concatenate([np.ones((len(verts), 1)), verts], 1)).to(dev)
         self._ball_ws = torch.empty(self._lib.tacex_fem_ball_workspace_bytes(self._handle, B), dtype=torch.uint8, device=dev)
@@ -416,6 +417,10 @@ class UipcSim:
             rc = self._lib.tacex_fem_reset_envs(self._handle, _lib.ptr(ids), n, _lib.ptr(pos), _lib.ptr(self.x), _lib.ptr(self.v),
                                                 _lib.ptr(si), _lib.ptr(self._ws), B, self._stream())
         _lib.check(rc, "tacex_fem_reset_envs")
+        if self._body is not None:  # the env's free affine body goes back to where the scene placed it, at rest
+            rows = slice(None) if ids is None else ids.long()
+            self.q[rows] = self._q0
+            self.qv[rows] = 0.0
         # (a later side-stream step is ordered behind this: FemGelpad.step makes its stream wait for the caller's before every step)
 
     def refresh_preconditioner(self):

@@ -207,3 +207,26 @@ def test_reference_scene_at_default_tolerances_runs_clean_and_ends_stationary_wh
             assert np.abs(g).max() <= 1e-5 * scale, (i, b, np.abs(g).max(), scale)
     assert checked >= 2  # states with real pair forces were among them
     print(f"worst |grad| / pair force over the tight run: {worst:.2e}")
+
+
+def test_reset_of_single_envs_puts_pad_and_ball_back():
+    """`UipcSim.reset(env_ids)` in a scene with an affine body (uipc_object.py:280-370): the listed envs' pads AND balls return to where the scene
+    placed them, at rest; the others keep their state; the next steps run clean."""
+    from tacex_amd.uipc.gelpad_scene import FemBallScene
+
+    B = 4
+    sc = FemBallScene(B, "cuda:0", max_newton_iter=64)
+    for i in range(8):
+        sc.step(i)
+    rest = torch.from_numpy(sc.gelpad.points).cuda()
+    q0 = sc.sim._q0
+    xb, qb = sc.sim.x.clone(), sc.sim.q.clone()
+    assert float((xb[3] - rest).abs().max()) > 1e-5 and float((qb[3] - q0).abs().max()) > 1e-8
+    sc.sim.reset([1, 3])
+    assert torch.equal(sc.sim.x[[1, 3]], rest[None].expand(2, -1, -1)) and torch.equal(sc.sim.q[[1, 3]], q0[None].expand(2, -1, -1))
+    assert float(sc.sim.v[[1, 3]].abs().max()) == 0.0 and float(sc.sim.qv[[1, 3]].abs().max()) == 0.0
+    assert torch.equal(sc.sim.x[[0, 2]], xb[[0, 2]]) and torch.equal(sc.sim.q[[0, 2]], qb[[0, 2]])
+    for i in range(8, 11):
+        sc.step(i)
+        info = sc.sim.check_step()
+        assert len(info["line_search_failed_envs"]) == 0 and len(info["pair_list_overflow_envs"]) == 0 and info["newton_iters"].max() < 64, (i, info)
