@@ -407,14 +407,14 @@ def roofline_leg(rig, markers):
         "valu_frac": round(flops_per_frame * B / (taxim_ms * 1e-3) / 1e12 / FP32_PEAK_TFLOPS, 4),
         "stages": stages,
         "note": "achieved = SURVEY 8(d)'s 16 B/px x the pixels of one launch of the dominant kernel / its hipEvent-measured average "
-                "duration (frac = achieved / 8 TB/s; reproduces from profiles/r05_c3_kernel_stats.csv: 16 x 76800 x frames per launch B / the tail's "
+                "duration (frac = achieved / 8 TB/s; reproduces from profiles/r06_c3_kernel_stats.csv: 16 x 76800 x frames per launch B / the tail's "
                 "average duration); *_own_bytes = the same with the kernel's own reads + writes (DESIGN.md section 4); pipeline_* = "
                 "16 B/px of the whole Taxim path / sum of its kernels; valu_frac = algorithmic fp32 flops / 157.3 TFLOP/s (the "
                 "separable blur is VALU-heavy)",
     }
     # HBM bytes of the dominant kernel per launch from the PMC passes (FETCH_SIZE x2 + WRITE_SIZE, separate `rocprofv3 --pmc` runs,
     # committed under profiles/ - counters cannot be read live from inside the process, so this is a build-time constant)
-    for cand in ("pmc_traffic_r05.json", "pmc_traffic_r04.json", "pmc_traffic_r03.json", "pmc_traffic_r02.json", "pmc_traffic.json"):
+    for cand in ("pmc_traffic_r06.json", "pmc_traffic_r05.json", "pmc_traffic_r04.json", "pmc_traffic_r03.json", "pmc_traffic_r02.json", "pmc_traffic.json"):
         pmc = REPO / "profiles" / cand
         if pmc.exists() and (H, W) == (240, 320):
             try:
@@ -736,7 +736,7 @@ def fem_roofline_entry(sw):
     the same command) and, live from the C4 sweep entry, the f64 vector rate and LDS rate of the CU an env sits on."""
     c4 = next((e for e in (sw or []) if e.get("key") == "c4" and "fem" in e), None)
     out = {"kernel": "fem_newton_lds_kernel<MESH = false, ATOM = true> (one dispatch = the whole Newton loop of a time step for all envs of the shard)"}
-    for cand in ("pmc_traffic_r05_fem.json", "pmc_traffic_r04_fem.json"):
+    for cand in ("pmc_traffic_r06_fem.json", "pmc_traffic_r05_fem.json", "pmc_traffic_r04_fem.json"):
         try:
             j = json.loads((REPO / "profiles" / cand).read_text())
             k = next(v for n, v in j["kernels"].items() if "fem_newton_lds_kernel<false" in n)  # (<MESH = false, ATOM = ...>)

@@ -755,12 +755,17 @@ __global__ __launch_bounds__(512) void fem_newton_kernel(FemDev m, double* xg, c
                                                          const double* aimg, double* stats, double* wsg,
                                                          int pcg_max_iter, double pcg_tol_rate, int ls_max_iter, double* dxg, double dx_tol,
                                                          double* step_info, int accumulate, const double* xprevg, const double* dispg,
-                                                         int fric_ipc) {
+                                                         int fric_ipc, int lds_sweep) {
   // step_info (nullable): the row of this env [Newton iterations, max |d|, flags, PCG iterations] - SET by the first launch of a time
   // step (accumulate = 0), added to / OR-ed by the later ones: tacex_fem_step runs this kernel once per Newton iteration, and
   // UipcSim.check_step() must see a penetrating vertex or a dead line search of ANY of them (the row used to be zeroed)
   __shared__ double sh[17];
   __shared__ double crc[3 * kFemMaxCoarse], cyc[3 * kFemMaxCoarse];
+  // lds_sweep (round 6; atomic mode only, 9 V doubles of dynamic LDS): x, the PCG direction p and per-vertex H.p accumulators live in LDS - a
+  // tet recomputes its state from x, gathers p from LDS and ADDS its rows with ds_add_f64, instead of reading a cached state (96 B) and
+  // writing rows (96 B) through HBM and a CSR gather afterwards: what made this kernel 4x slower per iteration than the CU-resident one.
+  // The deterministic switch keeps the fixed-order gather (lds_sweep = 0).
+  extern __shared__ __attribute__((aligned(16))) double nws_lds[];
   const int b = blockIdx.x;
   if (dxg && dxg[b] <= dx_tol) {  // converged in an earlier launch of this time step (same protocol as the CU-resident kernel)
     if (threadIdx.x == 0) { stats[(size_t)b * 4 + 2] = 0.0; stats[(size_t)b * 4 + 3] = 0.0; }
@@ -779,8 +784,10 @@ __global__ __launch_bounds__(512) void fem_newton_kernel(FemDev m, double* xg, c
   double* vg = ws + (size_t)36 * T;      // g
   double* vr = vg + (size_t)3 * V;
   double* vz = vr + (size_t)3 * V;
-  double* vp = vz + (size_t)3 * V;
-  double* vd = vp + (size_t)3 * V;
+  double* vp = lds_sweep ? nws_lds + 3 * V : vz + (size_t)3 * V;  // (the workspace slot stays where it is: the layout is one)
+  double* xs_l = nws_lds;                   // (V,3) x
+  double* acc_l = nws_lds + 6 * V;          // (V,3) accumulators
+  double* vd = vz + (size_t)6 * V;
   double* vHp = vd + (size_t)3 * V;
   double* xc = vHp + (size_t)3 * V;      // line-search candidate
   double* Dinv = xc + (size_t)3 * V;     // (V,9)
@@ -959,9 +966,30 @@ __global__ __launch_bounds__(512) void fem_newton_kernel(FemDev m, double* xg, c
   double rz = block_sum(part, sh);
   const double rz0 = rz;
   int it = 0;
+  if (lds_sweep) {
+    for (int k = threadIdx.x; k < 3 * V; k += blockDim.x) { xs_l[k] = x[k]; acc_l[k] = 0.0; }
+    __syncthreads();
+  }
   while (it < pcg_max_iter && rz0 > 0.0 && rz > pcg_tol_rate * rz0) {  // (libuipc's test: on r.z itself, see fem_newton_lds_kernel)
     // ---- Hp = (M + s Mc + dt^2 K) p, matrix-free: per-tet dP[dF(p)] then vertex gather ----
-    for (int t = threadIdx.x; t < T; t += blockDim.x) {
+    for (int t = threadIdx.x; lds_sweep && t < T; t += blockDim.x) {
+      int v[4];
+      double Di[9], F[9], dF[9], dP[9], r[12];
+      load_tet(m, t, v, Di);
+      deformation_gradient(xs_l, v, Di, F);
+      TetState s;
+      tet_state(m, F, s);
+      deformation_gradient(vp, v, Di, dF);
+      apply_dP(m, s, dF, dP);
+      shape_rows(Di, r);
+      const double sc = dt2 * m.vol[t];
+#pragma unroll
+      for (int w = 0; w < 4; ++w)
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+          atomicAdd(&acc_l[v[w] * 3 + i], sc * (dP[i * 3 + 0] * r[w * 3 + 0] + dP[i * 3 + 1] * r[w * 3 + 1] + dP[i * 3 + 2] * r[w * 3 + 2]));
+    }
+    for (int t = threadIdx.x; !lds_sweep && t < T; t += blockDim.x) {
       int v[4];
       double Di[9], dF[9], dP[9], r[12];
       load_tet(m, t, v, Di);
@@ -990,7 +1018,12 @@ __global__ __launch_bounds__(512) void fem_newton_kernel(FemDev m, double* xg, c
     part = 0.0;
     for (int v = threadIdx.x; v < V; v += blockDim.x) {
       double a3[3];
-      gather_vertex(m, hv, v, a3);
+      if (lds_sweep) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) { a3[i] = acc_l[v * 3 + i]; acc_l[v * 3 + i] = 0.0; }  // (zeroed for the next sweep by the thread that read it)
+      } else {
+        gather_vertex(m, hv, v, a3);
+      }
       const double md = m.mass[v] * (1.0 + ((cons && cons[v]) ? m.strength : 0.0));
       const double cb2 = cdat[(size_t)v * 5];
       const double npq = cb2 * (cdat[(size_t)v * 5 + 1] * vp[v * 3] + cdat[(size_t)v * 5 + 2] * vp[v * 3 + 1] + cdat[(size_t)v * 5 + 3] * vp[v * 3 + 2]);
@@ -2961,9 +2994,19 @@ static int launch_newton(tacex_fem_ctx* c, double* x, const double* xt, const ui
               "(barrier, step bound, friction) only", lds);
     return 2;
   }
-  hipLaunchKernelGGL(fem_newton_kernel, dim3(B), dim3(512), 0, st, c->dev, x, xt, cons, aim, stats, static_cast<double*>(ws), pcg_max_iter,
+  // x, p and the H.p accumulators in LDS when the summation order is free (atomic mode) and they fit (9 V doubles: ~2 200 vertices)
+  static const int stream_lds = getenv("TACEX_FEM_STREAM_LDS") ? atoi(getenv("TACEX_FEM_STREAM_LDS")) : 1;  // A/B hook
+  const size_t lds_s = (size_t)9 * V * sizeof(double);
+  const bool lds_sweep = stream_lds != 0 && atom && lds_s <= 160 * 1024;
+  if (lds_sweep) {
+    static size_t granted_s[64] = {};
+    hipError_t es = hipSetDevice(c->device);
+    if (es == hipSuccess) es = ensure_dynamic_lds(reinterpret_cast<const void*>(fem_newton_kernel), lds_s, granted_s);
+    if (es != hipSuccess) return fail_hip(es, "hipFuncSetAttribute(fem_newton_kernel)");
+  }
+  hipLaunchKernelGGL(fem_newton_kernel, dim3(B), dim3(512), lds_sweep ? lds_s : 0, st, c->dev, x, xt, cons, aim, stats, static_cast<double*>(ws), pcg_max_iter,
                      pcg_tol_rate, ls_max_iter, dx_dev, dx_tol, step_info, stream_accumulate ? 1 : 0, fric ? xprev : nullptr, fric ? disp : nullptr,
-                     c->fric_lag_mode == 1 ? 1 : 0);
+                     c->fric_lag_mode == 1 ? 1 : 0, lds_sweep ? 1 : 0);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : fail_hip(e, "fem_newton_kernel");
 }

@@ -88,9 +88,9 @@ def _committed(name):
 
 
 def test_committed_bench_line_follows_the_contract():
-    """profiles/r05_bench_n1.json = the stdout line of `python bench.py` on the GPU box; r05_bench_details_n1.json = its side file."""
-    raw = (REPO / "profiles" / "r05_bench_n1.json")
-    d = _committed("r05_bench_n1.json")
+    """profiles/r06_bench_n1.json = the stdout line of `python bench.py` on the GPU box; r06_bench_details_n1.json = its side file."""
+    raw = (REPO / "profiles" / "r06_bench_n1.json")
+    d = _committed("r06_bench_n1.json")
     assert len(raw.read_text().strip()) <= 6000
     for k in HEAD_KEYS:
         assert k in d, k
@@ -113,18 +113,18 @@ def test_committed_bench_line_follows_the_contract():
     f = r["fem"]
     assert 0 < f["f64_frac"] < 1 and f["us_per_sweep"] > 0 and f["sweeps_per_step"] > 0
     # the FEM scenes run every env to convergence: the cap is reported in the details file and must not have been hit
-    det = _committed("r05_bench_details_n1.json")
+    det = _committed("r06_bench_details_n1.json")
     for e in det["config"]["sweep"]:
         if "newton_cap" in e and "env_steps_per_s" not in e:
             assert e["newton_iters_max_over_period"] < e["newton_cap"] and e["newton_cap_hit"] is False, e["key"]
 
 
 def test_roofline_duration_agrees_with_the_rocprof_summary():
-    d = _committed("r05_bench_n1.json")
-    f = REPO / "profiles" / "r05_c3_kernel_stats.csv"
+    d = _committed("r06_bench_n1.json")
+    f = REPO / "profiles" / "r06_c3_kernel_stats.csv"
     if not f.exists():
         import pytest
-        pytest.skip("r05 kernel stats not committed yet")
+        pytest.skip("r06 kernel stats not committed yet")
     rows = list(csv.DictReader(open(f)))
     k = next(r for r in rows if "taxim_stream_kernel" in r["Name"])
     avg = d["roofline"]["kernel_avg_ms"]
