@@ -499,10 +499,12 @@ def sweep(args, dev):
                                    "pcg_iters_per_newton_mean": round(float(tot[3]) / max(float(tot[0]), 1e-9), 1),
                                    "note": "means over envs and over the timed window = three periods of the indenter's motion (21 steps each: about half "
                                            "pressing at ~1 ms per step, half following the retreating indenter at 3-15 ms)"}
-                if hasattr(fem, "ind"):  # (the analytic-indenter scenes: roofline of the CU-resident Newton kernel)
+                if hasattr(fem, "ind") and fem.sim.newton_kernel_resident:  # (the analytic-indenter scenes on the CU-resident Newton kernel: its roofline)
                     e["fem"] = fem_roofline(fem, (sum(ms) * steps / max(len(ms), 1), float(tot[0]), float(tot[3])))
+                elif hasattr(fem, "ind"):
+                    e["fem_kernel"] = "fem_newton_kernel (streaming form: one launch per Newton iteration; x, p, H.p accumulators in LDS)"
                 else:
-                    e["fem_kernel"] = "fem_ball_newton_kernel (csrc/fem_ball.h: streaming form, one launch per time step)"
+                    e["fem_kernel"] = "fem_ball_newton_kernel (csrc/fem_ball.h: one launch per time step)"
                     e["envs_flagged_overflow"] = int(len(si.get("pair_list_overflow_envs", [])))
             out.append(e)
             del rig
@@ -535,6 +537,8 @@ def sweep(args, dev):
     # with friction on every contact (the cfg's default contact model); stepped by csrc/fem_ball.h (one launch per time step)
     run("c4_ball", "C4 per-GPU shard on the reference's UIPC scene: 512 envs, RGB 320x240 + FEM-driven markers + gelpad FEM step against a FREE affine-body ball on the ground (point-triangle pairs both ways + friction, d_hat 5e-4)",
         512, 240, 320, 1, False, fem=lambda: FemBallScene(512, dev, max_newton_iter=NEWTON_CAP, side_stream=True))
+    run("c4_pad715", "C4 per-GPU shard with a pad the reference's mesher could just as well produce - 715 vertices / 2880 tets: beyond a CU's LDS, the streaming Newton kernel",
+        512, 240, 320, 1, False, fem=lambda: FemGelpad(512, dev, max_newton_iter=NEWTON_CAP, side_stream=True, mesh=(10, 12, 4)))
     run("c5", "C5 per-GPU shard: 1024 envs, RGB 640x480 + FEM-driven markers (gelpad FEM step included) (BASELINE configs[4] / 8)",
         1024, 480, 640, 1, False, fem=lambda: FemGelpad(1024, dev, max_newton_iter=NEWTON_CAP, side_stream=True))
     # (with the coarse correction in M^-1 the reference's PCG test - 1e-3 on r.z - can pass after ONE iteration on this rod, whose coarse modes are
@@ -781,7 +785,7 @@ _FEM_KEYS = ("hbm_frac", "hbm_achieved", "f64_frac", "lds_frac", "us_per_sweep",
 _CPU_KEYS = ("value", "unit", "cores", "kind", "logical_cores", "physical_cores")
 _SWEEP_SCALARS = {"c3_separate": "value_c3_separate", "c2": "value_c2", "c4": "value_c4", "c5": "value_c5", "c3_dense": "value_dense_contact", "c3_no_gather": "value_no_gather",
                   "c3_sensor_streams": "value_sensor_streams", "c4_rolling": "value_c4_rolling", "c4_lag_capped": "value_c4_lag_capped", "c4_dhat5e4": "value_c4_dhat5e4",
-                  "c5_optical": "value_c5_optical", "shard512": "value_shard512", "c4_ball": "value_c4_ball"}
+                  "c5_optical": "value_c5_optical", "shard512": "value_shard512", "c4_ball": "value_c4_ball", "c4_pad715": "value_c4_pad715"}
 
 
 def compact_line(full: dict, details_path: str | None) -> dict:
