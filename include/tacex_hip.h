@@ -504,7 +504,9 @@ int tacex_fem_step(tacex_fem_ctx* ctx, double* x_dev, double* v_dev, double* x_t
  * tacex_fem_set_affine_body: ONE body per env, the same mesh for all envs.  verts_host (num_verts,3) f64 in the body frame, tris_host
  * (num_tris,3) outward oriented; density [kg/m^3]; kappa [Pa] (m_kappa * 1e6); pad_vertex_area_host (V) contact weights of the gelpad's
  * vertices (0: interior) and pad_tris_host (num_pad_tris,3) its surface triangles; d_hat [m], stiffness [J/m^2] as tacex_fem_set_contact;
- * the ground is the half-space z >= ground_height (enable_ground = 0: none).  num_verts = 0 removes the body.  Tables are copied.
+ * the ground is the half-space z >= ground_height (enable_ground = 0: none); kinematic = 1 (`AffineBodyConstitutionCfg.kinematic`,
+ * uipc_object.py:70-73, 463-466 `is_fixed`): the body's twelve unknowns are FIXED within a step - the caller moves q_dev between steps
+ * and the pad feels the body through the pairs and their friction.  num_verts = 0 removes the body.  Tables are copied.
  * State: q_dev / qv_dev (num_envs,4,3) f64 = (p, c_1, c_2, c_3) with c_k = COLUMN k of A (a surface point is p + sum_k X_k c_k) and its
  * velocity.  tacex_fem_ball_step = one backward-Euler step of pad + ball: predictor (gravity on the pad vertices and on p), the whole
  * Newton loop in one launch (PCG preconditioned by 3x3 blocks on the pad and the exact 12x12 ball block; an env leaves the loop once
@@ -517,7 +519,7 @@ int tacex_fem_step(tacex_fem_ctx* ctx, double* x_dev, double* v_dev, double* x_t
  * tacex_fem_ball_moments: the 4x4 moment matrix S (row-major) and kappa * vol the library derived from the mesh. */
 int tacex_fem_set_affine_body(tacex_fem_ctx* ctx, int num_verts, const double* verts_host, int num_tris, const int32_t* tris_host, double density,
                               double kappa, const double* pad_vertex_area_host, int num_pad_tris, const int32_t* pad_tris_host, double d_hat,
-                              double stiffness, double ground_height, int enable_ground);
+                              double stiffness, double ground_height, int enable_ground, int kinematic);
 size_t tacex_fem_ball_workspace_bytes(const tacex_fem_ctx* ctx, int num_envs);
 int tacex_fem_ball_moments(const tacex_fem_ctx* ctx, double moments_out[16], double* kappa_vol_out);
 int tacex_fem_ball_terms(tacex_fem_ctx* ctx, const double* x_dev, const double* x_tilde_dev, const double* q_dev, const double* q_tilde_dev,

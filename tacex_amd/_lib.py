@@ -142,7 +142,7 @@ SIGNATURES = {
     "tacex_fem_contact_gaps": (_i, [_vp, _vp, _vp, _i, _vp]),
     "tacex_fem_newton_resident": (_i, [_vp]),
     "tacex_fem_set_friction_lag": (_i, [_vp, _i]),
-    "tacex_fem_set_affine_body": (_i, [_vp, _i, _vp, _i, _vp, _d, _d, _vp, _i, _vp, _d, _d, _d, _i]),
+    "tacex_fem_set_affine_body": (_i, [_vp, _i, _vp, _i, _vp, _d, _d, _vp, _i, _vp, _d, _d, _d, _i, _i]),
     "tacex_fem_ball_workspace_bytes": (_sz, [_vp, _i]),
     "tacex_fem_ball_moments": (_i, [_vp, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "tacex_fem_ball_terms": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp]),

@@ -33,6 +33,8 @@ struct BallDev {
   double S[16] = {};              // 4 x 4 moment matrix
   double kv = 0.0, gh = 0.0, dhat = 0.0, kappa = 0.0;
   int ground = 0;
+  int kinematic = 0;  // AffineBodyConstitutionCfg.kinematic (uipc_object.py:70-73, 463-466: `is_fixed`): the body's rows are not unknowns - the
+                      // caller moves q between steps, the pad sees it through the pairs (both ways) and their friction
 };
 
 constexpr int kBallMaxPairs = 4096;   // listed candidate pairs per env and Newton iteration
@@ -777,7 +779,7 @@ __global__ __launch_bounds__(512, TACEX_BALL_WG_PER_CU) void fem_ball_newton_ker
 #pragma unroll
       for (int k = 0; k < 9; ++k) Dinv[(size_t)v * 9 + k] = Di3[k];
     }
-    for (int k = tid; k < 3 * VN; k += NT) { vr[k] = -vg[k]; vd[k] = 0.0; }
+    for (int k = tid; k < 3 * VN; k += NT) { vr[k] = (bd.kinematic && k >= 3 * V) ? 0.0 : -vg[k]; vd[k] = 0.0; }  // (a fixed body: zero residual rows stay zero through the PCG)
     __syncthreads();
     // ---- PCG: x and p in LDS, the tets' rows added into per-vertex LDS accumulators (no per-tet arrays through HBM) ----
     for (int k = tid; k < 3 * V; k += NT) xs[k] = x[k];

@@ -2461,6 +2461,8 @@ struct tacex_fem_ctx {
   double* dx_dev = nullptr;  // optional (B,) last Newton update max|dx| per env: converged envs skip further iterations
   double dx_tol = 0.0;
   tacex::BallDev ball{};     // the env's free affine body + ground (tacex_fem_set_affine_body); nv == 0: none
+  const void* ball_last_ws = nullptr;  // workspace / env count whose "q at the end of the previous step" rows are valid (kinematic bodies)
+  int ball_last_B = 0;
   std::vector<void*> allocs;
 };
 
@@ -3076,7 +3078,7 @@ int tacex_fem_step(tacex_fem_ctx* c, double* x, double* v, double* xt, const uin
 // ---- the reference's UIPC scene: free affine-body ball + ground (fem_ball.h) ---------------------------------------------------------
 int tacex_fem_set_affine_body(tacex_fem_ctx* c, int num_verts, const double* verts_host, int num_tris, const int32_t* tris_host, double density,
                               double kappa, const double* pad_vertex_area_host, int num_pad_tris, const int32_t* pad_tris_host, double d_hat,
-                              double stiffness, double ground_height, int enable_ground) {
+                              double stiffness, double ground_height, int enable_ground, int kinematic) {
   if (!c) { set_error("tacex_fem_set_affine_body: null context"); return 2; }
   bool synced = false;
   BallDev& bd = c->ball;
@@ -3122,7 +3124,7 @@ int tacex_fem_set_affine_body(tacex_fem_ctx* c, int num_verts, const double* ver
   for (int k = 0; k < 16; ++k) bd.S[k] = density * S[k];
   for (int v = 0; v < V; ++v) if (parea[v] > 0.0) psv.push_back(v);
   bd.nv = num_verts; bd.nt = num_tris; bd.npt = num_pad_tris; bd.nsv = (int)psv.size();
-  bd.kv = kappa * vol; bd.gh = ground_height; bd.dhat = d_hat; bd.kappa = stiffness; bd.ground = enable_ground ? 1 : 0;
+  bd.kv = kappa * vol; bd.gh = ground_height; bd.dhat = d_hat; bd.kappa = stiffness; bd.ground = enable_ground ? 1 : 0; bd.kinematic = kinematic ? 1 : 0;
   if (int rc = fem_upload(c, Y, &bd.Y)) return rc;
   if (int rc = fem_upload(c, tri, &bd.tri)) return rc;
   if (int rc = fem_upload(c, area, &bd.area)) return rc;
@@ -3134,8 +3136,8 @@ int tacex_fem_set_affine_body(tacex_fem_ctx* c, int num_verts, const double* ver
 
 size_t tacex_fem_ball_workspace_bytes(const tacex_fem_ctx* c, int B) {
   if (!c || B <= 0 || c->ball.nv == 0) return 0;
-  // env blocks | x_prev (B,V,3) | q_prev (B,12) | x~ (B,V,3) | q~ (B,12) | env launch order (B int32)
-  return ((size_t)B * ball_ws_doubles(c->dev.V, c->dev.T, c->ball.nv, c->ball.nt) + (size_t)B * 6 * c->dev.V + (size_t)B * 24 + 8 + ((size_t)B + 1) / 2) * sizeof(double);
+  // env blocks | x_prev (B,V,3) | q_prev (B,12) | x~ (B,V,3) | q~ (B,12) | q at the end of the previous step (B,12) | env launch order (B int32)
+  return ((size_t)B * ball_ws_doubles(c->dev.V, c->dev.T, c->ball.nv, c->ball.nt) + (size_t)B * 6 * c->dev.V + (size_t)B * 36 + 8 + ((size_t)B + 1) / 2) * sizeof(double);
 }
 
 int tacex_fem_ball_moments(const tacex_fem_ctx* c, double moments_out[16], double* kappa_vol_out) {
@@ -3184,6 +3186,10 @@ int tacex_fem_ball_step(tacex_fem_ctx* c, double* x, double* v, double* q, doubl
   double* qprev = xprev + n3;
   double* xt = qprev + (size_t)B * 12;
   double* qt = xt + n3;
+  // A KINEMATIC body is moved by the caller between steps: friction then slides relative to where the body stood at the END of the previous
+  // step (kept here; the first step with this workspace sees no body motion), like the analytic indenters' displacement in tacex_fem_step
+  double* qlast = qt + (size_t)B * 12;
+  const bool have_last = c->ball.kinematic && c->ball_last_ws == ws && c->ball_last_B == B;
   const double dt = c->dev.dt;
   hipLaunchKernelGGL(fem_predict_kernel, dim3((unsigned)((n3 + 255) / 256)), dim3(256), 0, st, x, v, xt, xprev, static_cast<double*>(nullptr), n3, B, dt,
                      gravity[0], gravity[1], gravity[2], static_cast<const double*>(nullptr), static_cast<double*>(nullptr), static_cast<double*>(nullptr), 0);
@@ -3192,17 +3198,21 @@ int tacex_fem_ball_step(tacex_fem_ctx* c, double* x, double* v, double* q, doubl
   int* env_order = nullptr;
   static const int use_order = getenv("TACEX_FEM_ORDER") ? atoi(getenv("TACEX_FEM_ORDER")) : 1;
   if (use_order && B > 256) {  // (step_info still holds the previous step's counts; a first step sorts zeros = index order)
-    env_order = reinterpret_cast<int*>(qt + (size_t)B * 12 + 1);
+    env_order = reinterpret_cast<int*>(qlast + (size_t)B * 12 + 1);
     hipLaunchKernelGGL(fem_env_order_kernel, dim3(1), dim3(1024), 0, st, step_info, B, env_order);
   }
   if (ball_lds_bytes(c->dev.V) > 48 * 1024) { set_error("tacex_fem_ball_step: pad of %d vertices (the kernel keeps x, p and the H.p accumulators of <= 680 vertices in LDS)", c->dev.V); return 2; }
   hipLaunchKernelGGL(fem_ball_newton_kernel, dim3(B), dim3(512), ball_lds_bytes(c->dev.V), st, c->dev, c->ball, x, xt, q, qt, cons, aim, static_cast<double*>(ws), pcg_max_iter,
                      pcg_tol_rate, ls_max_iter, max_newton, velocity_tol * dt, transrate_tol * dt, step_info, ball_coarse_off ? 2 : 0,
-                     static_cast<double*>(nullptr), static_cast<double*>(nullptr), static_cast<const double*>(xprev), static_cast<const double*>(qprev),
-                     static_cast<const int*>(env_order));
+                     static_cast<double*>(nullptr), static_cast<double*>(nullptr), static_cast<const double*>(xprev),
+                     static_cast<const double*>(have_last ? qlast : qprev), static_cast<const int*>(env_order));
   hipLaunchKernelGGL(fem_velocity_kernel, dim3((unsigned)((n3 + 255) / 256)), dim3(256), 0, st, x, xprev, v, n3, 1.0 / dt, static_cast<const double*>(nullptr),
                      static_cast<double*>(nullptr), B);
   hipLaunchKernelGGL(fem_ball_velocity_kernel, dim3((unsigned)((B * 12 + 255) / 256)), dim3(256), 0, st, q, qprev, qv, B, 1.0 / dt);
+  if (c->ball.kinematic) {
+    (void)hipMemcpyAsync(qlast, q, (size_t)B * 12 * sizeof(double), hipMemcpyDeviceToDevice, st);
+    c->ball_last_ws = ws; c->ball_last_B = B;
+  }
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : fail_hip(e, "tacex_fem_ball_step");
 }

@@ -69,7 +69,8 @@ class UipcObjectCfg:
         m_kappa: float = 100.0
         """Stiffness of the body in [MPa] (100 MPa = hard rubber): weight of the orthogonality energy kappa * vol * |A^T A - I|^2"""
         kinematic: bool = False
-        """True: the body's degrees of freedom are fixed (not supported here: a prescribed body is `UipcSim.set_contact_indenters` / `set_indenter_mesh`)."""
+        """True: the body's degrees of freedom are fixed within a step (uipc_object.py:463-466 `is_fixed`): the caller moves `UipcSim.q` between
+        steps (the velocity `UipcSim.qv` then only feeds the inertia term, which a fixed body does not use)."""
 
     @configclass
     class StableNeoHookeanCfg:
@@ -94,8 +95,6 @@ class UipcObject:
         if self.points.ndim != 2 or self.points.shape[1] != 3 or self.tets.ndim != 2 or self.tets.shape[1] != 4:
             raise ValueError("mesh_points must be (V,3) and mesh_tets (T,4)")
         if self.is_affine_body:
-            if cfg.constitution_cfg.kinematic:
-                raise NotImplementedError("kinematic affine bodies: prescribe the body with UipcSim.set_contact_indenters / set_indenter_mesh instead")
             self.tris = np.ascontiguousarray(cfg.mesh_tris if cfg.mesh_tris is not None else self.surface_triangles(), dtype=np.int32)
         self._uipc_sim = uipc_sim
         if uipc_sim is not None:

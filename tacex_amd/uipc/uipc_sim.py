@@ -183,7 +183,8 @@ class UipcSim:
         _lib.check(self._lib.tacex_fem_set_affine_body(
             self._handle, len(verts), verts.ctypes.data, len(tris), tris.ctypes.data, float(body.cfg.mass_density),
             float(body.cfg.constitution_cfg.m_kappa) * 1e6, area.ctypes.data, len(ptri), ptri.ctypes.data, d_hat,
-            float(c.default_contact_resistance) * 1e9 * d_hat, float(self.cfg.ground_height), 1 if c.enable else 0), "tacex_fem_set_affine_body")
+            float(c.default_contact_resistance) * 1e9 * d_hat, float(self.cfg.ground_height), 1 if c.enable else 0,
+            1 if body.cfg.constitution_cfg.kinematic else 0), "tacex_fem_set_affine_body")
         # one default contact model for every pair of surfaces (US:192-201): friction ratio / eps_velocity of the cfg act on the pairs and the ground
         _lib.check(self._lib.tacex_fem_set_friction(self._handle, float(c.default_friction_ratio) if c.enable_friction else 0.0,
                                                     float(c.eps_velocity)), "tacex_fem_set_friction")

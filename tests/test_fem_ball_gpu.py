@@ -230,3 +230,42 @@ def test_reset_of_single_envs_puts_pad_and_ball_back():
         sc.step(i)
         info = sc.sim.check_step()
         assert len(info["line_search_failed_envs"]) == 0 and len(info["pair_list_overflow_envs"]) == 0 and info["newton_iters"].max() < 64, (i, info)
+
+
+def test_kinematic_body_is_fixed_within_a_step_and_dents_the_pad():
+    """`AffineBodyConstitutionCfg(kinematic=True)` (uipc_object.py:70-73, 463-466): the ball's twelve unknowns do not move in a step whatever
+    pushes it - no gravity fall, no yielding to the pad - and a ball the caller lifts into the pad dents it (pairs both ways act on the pad)."""
+    from tacex_amd.uipc import UipcObject, UipcObjectCfg, UipcSim, UipcSimCfg
+    from tacex_amd.uipc.gelpad_scene import icosphere
+    from tacex_amd.uipc.uipc_object import gelpad_box_mesh
+
+    B, R, dhat, gh = 2, 0.006, 5e-4, 0.001
+    P, T = gelpad_box_mesh(6, 8, 2)
+    size = P.max(0) - P.min(0)
+    Pw = P * np.array([1.0, -1.0, -1.0]) + np.array([-size[0] / 2 + 0.0008, size[1] / 2 + 0.0005, 0.0])
+    zc = gh + 0.002 + R
+    Pw[:, 2] += zc + R + 1.02 * dhat - Pw[:, 2].min()
+    cfg = UipcSimCfg(device="cuda:0")
+    cfg.contact.d_hat, cfg.ground_height = dhat, gh
+    sim = UipcSim(cfg, num_envs=B)
+    pad = UipcObject(UipcObjectCfg(mesh_points=Pw, mesh_tets=T), sim)
+    vb, tb = icosphere(R, 1)
+    UipcObject(UipcObjectCfg(mesh_points=vb, mesh_tris=tb, init_pos=(0.0, 0.0, zc),
+                             constitution_cfg=UipcObjectCfg.AffineBodyConstitutionCfg(kinematic=True)), sim)
+    sim.setup_sim(constraint_strength_ratio=1000.0)
+    back = np.where(Pw[:, 2] > Pw[:, 2].max() - 1e-12)[0]
+    sim.set_constraints(back, torch.from_numpy(np.repeat(Pw[None, back], B, 0)).cuda())
+    q0 = sim.q.clone()
+    face = int(np.argmin(np.hypot(Pw[:, 0], Pw[:, 1]) + 1e3 * (Pw[:, 2] > Pw[:, 2].min() + 1e-12)))  # contact-face vertex nearest the ball's axis
+    z_face0 = float(sim.x[0, face, 2])
+    for k in range(8):
+        sim.q[:, 0, 2] += 1e-4 * torch.tensor([1.0, 0.5], device="cuda", dtype=torch.float64)  # the caller lifts the ball: 0.8 / 0.4 mm in all
+        q_before = sim.q.clone()
+        sim.step(max_newton_iter=64)
+        info = sim.check_step()
+        assert len(info["line_search_failed_envs"]) == 0 and len(info["pair_list_overflow_envs"]) == 0 and info["newton_iters"].max() < 64, (k, info)
+        assert torch.equal(sim.q, q_before)  # fixed within the step: no fall, no yielding
+    lift = sim.x[:, face, 2].cpu().numpy() - z_face0
+    assert lift[0] > 1.5e-4 and lift[0] > lift[1] > 0.0, lift  # the pad's face was pushed up, more where the ball rose further
+    gaps = sim.x[:, face, 2].cpu().numpy() - (sim.q[:, 0, 2].cpu().numpy() + R)
+    assert (gaps > 0).all()
