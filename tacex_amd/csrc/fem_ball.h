@@ -338,6 +338,12 @@ __global__ __launch_bounds__(512, TACEX_BALL_WG_PER_CU) void fem_ball_newton_ker
     return bsum(part);
   };
 
+#ifdef TACEX_BALL_CLOCK  // debug build: cycles of the phases of a step, printed by env 0 (scripts/r06/ball_clock.sh)
+  long long bck[8] = {0, 0, 0, 0, 0, 0, 0, 0}, bt0 = __builtin_readcyclecounter();
+#define BALL_TICK(k) do { const long long n_ = __builtin_readcyclecounter(); bck[k] += n_ - bt0; bt0 = n_; } while (0)
+#else
+#define BALL_TICK(k) do { } while (0)
+#endif
   ball_points(qs, xb);
   __syncthreads();
   int n_newton = 0, pcg_total = 0;
@@ -379,6 +385,7 @@ __global__ __launch_bounds__(512, TACEX_BALL_WG_PER_CU) void fem_ball_newton_ker
       }
       bts[t * 4] = c3[0]; bts[t * 4 + 1] = c3[1]; bts[t * 4 + 2] = c3[2]; bts[t * 4 + 3] = rt;
     }
+    BALL_TICK(0);  // element pass, ball triangle spheres
     if (tid == 0) { n_cpv = 0; n_cpt = 0; n_cbv = 0; n_pairs = 0; n_act = 0; }
     if (tid < 12) gb[tid] = 0.0;
     if (tid < 16) YY[tid] = 0.0;
@@ -456,6 +463,7 @@ __global__ __launch_bounds__(512, TACEX_BALL_WG_PER_CU) void fem_ball_newton_ker
     __syncthreads();
     if (n_pairs > kBallMaxPairs) { if (tid == 0) { s_flags |= kBallFlagOverflow; n_pairs = kBallMaxPairs; } }
     __syncthreads();
+    BALL_TICK(1);  // candidates, pair list
     // ---- nodal gradient, diagonal blocks (pad rows; pairs are added below), ground ----
     for (int v = tid; v < V; v += NT) {
       double a3[3];
@@ -566,6 +574,7 @@ __global__ __launch_bounds__(512, TACEX_BALL_WG_PER_CU) void fem_ball_newton_ker
         }
       }
     __syncthreads();
+    BALL_TICK(2);  // gradient, elastic blocks, ground
     // ---- pairs at x: gradient, diagonal blocks, ball block, active records ----
     {
       const int np = n_pairs;
@@ -781,6 +790,7 @@ __global__ __launch_bounds__(512, TACEX_BALL_WG_PER_CU) void fem_ball_newton_ker
     }
     for (int k = tid; k < 3 * VN; k += NT) { vr[k] = (bd.kinematic && k >= 3 * V) ? 0.0 : -vg[k]; vd[k] = 0.0; }  // (a fixed body: zero residual rows stay zero through the PCG)
     __syncthreads();
+    BALL_TICK(3);  // pairs, friction, ball blocks, factorisation, pad block inverses
     // ---- PCG: x and p in LDS, the tets' rows added into per-vertex LDS accumulators (no per-tet arrays through HBM) ----
     for (int k = tid; k < 3 * V; k += NT) xs[k] = x[k];
     double rz = precondition(vr, vz);
@@ -902,6 +912,7 @@ __global__ __launch_bounds__(512, TACEX_BALL_WG_PER_CU) void fem_ball_newton_ker
     }
     __syncthreads();
     pcg_total += it;
+    BALL_TICK(4);  // PCG
     // ---- step bound ----
     if (tid < 12) rhs12[tid] = vd[V * 3 + tid];
     __syncthreads();
@@ -955,6 +966,7 @@ __global__ __launch_bounds__(512, TACEX_BALL_WG_PER_CU) void fem_ball_newton_ker
     }
     dmax_x = dmx; dmax_c = dmc;
     // ---- backtracking line search (first E <= E0 wins; rescue halvings as in the other Newton kernels) ----
+    BALL_TICK(5);  // step bound (ground, additive CCD)
     // E(x): the accepted candidate's energy of the previous iteration IS this iteration's (every pair inside d_hat is in both lists)
     const double E0 = have_e ? e_carry : energy(x, qs, xb);
     double step = amax, E1 = E0;
@@ -972,6 +984,7 @@ __global__ __launch_bounds__(512, TACEX_BALL_WG_PER_CU) void fem_ball_newton_ker
       __syncthreads();
     }
     ++n_newton;
+    BALL_TICK(6);  // line search
     if (accepted) {
       for (int k = tid; k < 3 * V; k += NT) x[k] = yc[k];
       for (int k = tid; k < 3 * nv; k += NT) xb[k] = xbc[k];
@@ -985,6 +998,11 @@ __global__ __launch_bounds__(512, TACEX_BALL_WG_PER_CU) void fem_ball_newton_ker
     __syncthreads();
     if (dmx <= dx_tol && dmc <= dc_tol) break;
   }
+#ifdef TACEX_BALL_CLOCK
+  if (tid == 0 && (b == 0 || b == (int)gridDim.x - 1))
+    printf("ball clock env %d: newton %d pcg %d | kcycles: element %lld candidates %lld gradient+blocks %lld pairs+factor %lld PCG %lld stepbound %lld linesearch %lld\n", b,
+           n_newton, pcg_total, bck[0] / 1000, bck[1] / 1000, bck[2] / 1000, bck[3] / 1000, bck[4] / 1000, bck[5] / 1000, bck[6] / 1000);
+#endif
   if (tid < 12) q[tid] = qs[tid];
   if (tid == 0 && step_info) {
     double* si = step_info + (size_t)b * 4;

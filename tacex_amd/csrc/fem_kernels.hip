@@ -3085,6 +3085,7 @@ int tacex_fem_set_affine_body(tacex_fem_ctx* c, int num_verts, const double* ver
   fem_release(c, bd.Y, &synced); fem_release(c, bd.tri, &synced); fem_release(c, bd.area, &synced);
   fem_release(c, bd.ptri, &synced); fem_release(c, bd.psv, &synced); fem_release(c, bd.parea, &synced);
   bd = BallDev{};
+  c->ball_last_ws = nullptr; c->ball_last_B = 0;
   if (num_verts == 0) return 0;  // remove the body
   if (!verts_host || !tris_host || !pad_vertex_area_host || !pad_tris_host || num_verts < 4 || num_tris < 4 || num_pad_tris < 1) {
     set_error("tacex_fem_set_affine_body: null / too small mesh argument");
