@@ -892,6 +892,10 @@ __global__ __launch_bounds__(512, TACEX_BALL_WG_PER_CU) void fem_ball_newton_ker
         }
       }
       __syncthreads();
+      if (bd.kinematic) {  // a fixed body: its rows of the operator are eliminated (the residual rows stay zero, p_q stays zero)
+        if (tid < 12) vHp[V * 3 + tid] = 0.0;
+        __syncthreads();
+      }
       double part = 0.0;
       for (int k = tid; k < 3 * VN; k += NT) part += ps[k] * vHp[k];
       const double pHp = bsum(part);
