@@ -48,7 +48,11 @@ constexpr int kBallFlagOverflow = 16; // step_info flag: a candidate / pair list
 
 // workspace of one env (doubles): ge 12T | tc 12T | hv 12T | g r z p d Hp yc: 7 x 3 (V+4) | D / Dinv 9V | ground curvature V |
 //   xb 3nv | xbc 3nv | dxb 3nv | ball triangle spheres 4nt | pair list (ints) kBallMaxPairs / 2 | active records
-__host__ __device__ inline size_t ball_lds_bytes(int V) { return ((size_t)9 * V + 12) * sizeof(double); }
+// dynamic LDS: x (V,3) | p (V + 4,3) | H.p accumulators (V,3) | r / z of the chain solve (V,3) (doubles) || chain factors (V,15) (floats) ||
+// chain successor / predecessor (V each, u16)
+__host__ __device__ inline size_t ball_lds_bytes(int V) {
+  return ((((size_t)12 * V + 12) * sizeof(double) + (size_t)15 * V * sizeof(float) + (size_t)2 * V * sizeof(unsigned short)) + 15) & ~(size_t)15;
+}
 __host__ __device__ inline size_t ball_ws_doubles(int V, int T, int nv, int nt) {
   return (size_t)36 * T + (size_t)21 * (V + 4) + (size_t)10 * V + (size_t)9 * nv + (size_t)4 * nt + kBallMaxPairs / 2 + (size_t)kBallMaxActive * kBallRec +
          (size_t)kBallMaxFric * (kBallRec + 6);  // lagged friction records + their Hessians at the iteration's state
@@ -129,7 +133,7 @@ __global__ __launch_bounds__(512, TACEX_BALL_WG_PER_CU) void fem_ball_newton_ker
                                                               const uint8_t* consg, const double* aimg, double* wsg, int pcg_max_iter,
                                                               double pcg_tol_rate, int ls_max_iter, int max_newton, double dx_tol, double dc_tol,
                                                               double* step_info, int mode, double* e_out, double* g_out, const double* xprevg,
-                                                              const double* qprevg, const int* env_order) {
+                                                              const double* qprevg, const int* env_order, const double* blkg) {
   extern __shared__ __attribute__((aligned(16))) double ball_lds[];  // x (V,3) | p (V + 4,3) | H.p accumulators (V,3): ball_lds_bytes()
   __shared__ double sh[17], sh2[16];
   __shared__ double gb[12], Bm[144], B0[144], Lc[144], Bi[144], YY[16], qs[12], qts[12], rhs12[12];
@@ -178,6 +182,18 @@ __global__ __launch_bounds__(512, TACEX_BALL_WG_PER_CU) void fem_ball_newton_ker
   double* xs = ball_lds;           // (V,3) x of the iteration: the tet state is recomputed from it in every H.p (no cached F in HBM)
   double* ps = xs + 3 * V;         // (V + 4,3) PCG direction
   double* acc = ps + 3 * VN;       // (V,3) per-vertex sums of the tets' rows (ds_add_f64)
+  double* rsl = acc + 3 * V;       // (V,3) the chain solve's r, then y, then z (in place)
+  float* cf = reinterpret_cast<float*>(rsl + 3 * V);                      // (V,15) chain factors: S^-1 (upper triangle, 6) | G (9)
+  unsigned short* cnx = reinterpret_cast<unsigned short*>(cf + 15 * V);   // (V) chain successor, 0xffff = none
+  unsigned short* cpr = cnx + V;                                           // (V) predecessor
+  // elastic preconditioner blocks of the step: D (upper triangle) | E = A(v, next(v)) per vertex, assembled for all envs by
+  // fem_assemble_blocks_kernel ahead of this launch at the state the step starts from ((V,16) per env; nullptr: mass blocks only)
+  const double* blk = blkg ? blkg + (size_t)b * 16 * V : nullptr;
+  const int nch = m.ch_next ? m.nch : V;
+  for (int v = tid; v < V; v += NT) {
+    cnx[v] = (unsigned short)(m.ch_next ? m.ch_next[v] : -1);
+    cpr[v] = (unsigned short)(m.ch_prev ? m.ch_prev[v] : -1);
+  }
   const double dt2 = m.dt * m.dt, dhat = bd.dhat, kk = dt2 * bd.kappa;
   const double L = dhat * (1.0 + kCcdSlack * kBallReach), R = kBallReach * dhat;
 
@@ -314,13 +330,46 @@ __global__ __launch_bounds__(512, TACEX_BALL_WG_PER_CU) void fem_ball_newton_ker
   // z = M^-1 r: 3 x 3 blocks on the pad rows (+ the coarse correction), the exact inverse of the 12 x 12 ball block on the ball rows
   auto precondition = [&](const double* r, double* z) -> double {
     double part = 0.0;
-    for (int v = tid; v < V; v += NT) {
+    // chain solve z = L^-T S^-1 L^-1 r in LDS, in place: down the chain y_i = r_i - G_{i-1}^T y_{i-1}, back up z_i = S_i^-1 y_i - G_i z_{i+1}
+    for (int k = tid; k < 3 * V; k += NT) rsl[k] = r[k];
+    __syncthreads();
+    for (int ch = tid; ch < nch; ch += NT) {
+      int v = m.ch_next ? m.ch_head[ch] : ch, last = v;
+      double y[3] = {rsl[v * 3], rsl[v * 3 + 1], rsl[v * 3 + 2]};
+      while (true) {
+        last = v;
+        const int n = cnx[v] == 0xffff ? -1 : (int)cnx[v];
+        if (n < 0) break;
+        const float* g = cf + v * 15 + 6;
+        const double y0 = y[0], y1 = y[1], y2 = y[2];
 #pragma unroll
-      for (int i = 0; i < 3; ++i) {
-        const double zz = Dinv[(size_t)v * 9 + i * 3] * r[v * 3] + Dinv[(size_t)v * 9 + i * 3 + 1] * r[v * 3 + 1] + Dinv[(size_t)v * 9 + i * 3 + 2] * r[v * 3 + 2];
-        z[v * 3 + i] = zz;
-        part += r[v * 3 + i] * zz;
+        for (int k = 0; k < 3; ++k) y[k] = rsl[n * 3 + k] - ((double)g[k] * y0 + (double)g[3 + k] * y1 + (double)g[6 + k] * y2);
+        rsl[n * 3] = y[0]; rsl[n * 3 + 1] = y[1]; rsl[n * 3 + 2] = y[2];
+        v = n;
       }
+      v = last;
+      double zn[3] = {0, 0, 0};
+      while (true) {
+        const float* f = cf + v * 15;
+        const double y0 = rsl[v * 3], y1 = rsl[v * 3 + 1], y2 = rsl[v * 3 + 2];
+        double zz[3];
+        zz[0] = (double)f[0] * y0 + (double)f[1] * y1 + (double)f[2] * y2;
+        zz[1] = (double)f[1] * y0 + (double)f[3] * y1 + (double)f[4] * y2;
+        zz[2] = (double)f[2] * y0 + (double)f[4] * y1 + (double)f[5] * y2;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) zz[i] -= (double)f[6 + i * 3] * zn[0] + (double)f[7 + i * 3] * zn[1] + (double)f[8 + i * 3] * zn[2];
+        rsl[v * 3] = zz[0]; rsl[v * 3 + 1] = zz[1]; rsl[v * 3 + 2] = zz[2];
+        zn[0] = zz[0]; zn[1] = zz[1]; zn[2] = zz[2];
+        const int pv = cpr[v] == 0xffff ? -1 : (int)cpr[v];
+        if (pv < 0) break;
+        v = pv;
+      }
+    }
+    __syncthreads();
+    for (int k = tid; k < 3 * V; k += NT) {
+      const double zz = rsl[k];
+      z[k] = zz;
+      part += r[k] * zz;
     }
     if (tid < 12) {
       double zz = 0.0;
@@ -364,9 +413,6 @@ __global__ __launch_bounds__(512, TACEX_BALL_WG_PER_CU) void fem_ball_newton_ker
       element_gradient(s, r, dt2 * m.vol[t], g);
 #pragma unroll
       for (int k = 0; k < 12; ++k) ge[(size_t)k * T + t] = g[k];
-#pragma unroll
-      for (int k = 0; k < 9; ++k) tc[(size_t)k * T + t] = F[k];
-      tc[(size_t)9 * T + t] = s.a; tc[(size_t)10 * T + t] = s.b; tc[(size_t)11 * T + t] = s.c;
     }
     double rb = 0.0;  // bounding radius of the ball about p
     for (int k = tid; k < nv; k += NT) {
@@ -493,48 +539,9 @@ __global__ __launch_bounds__(512, TACEX_BALL_WG_PER_CU) void fem_ball_newton_ker
         }
       }
       cbp[v] = cb;
-      // ELASTIC part of the block: assembled in the first iteration of the step and kept (hv: idle since the PCG's rows go through LDS) -
-      // between the Newton iterations of one step the deformation gradients move by per cent, the blocks that change by orders of
-      // magnitude (barriers, friction) are added fresh, and a preconditioner only has to stay SPD (the CU-resident kernel does the same);
-      // 72 applications of the element Hessian per vertex otherwise, the largest fixed cost of an iteration
-      double* Del = hv + (size_t)v * 9;
-      if (nit > 0) {
-#pragma unroll
-        for (int k = 0; k < 9; ++k) D[k] += Del[k];
-      }
-      double De[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-      for (int e = m.vt_off[v]; nit == 0 && e < m.vt_off[v + 1]; ++e) {
-        const int code = m.vt_idx[e];
-        const int t = code >> 2, l = code & 3;
-        double Di[9], r[12];
-#pragma unroll
-        for (int k = 0; k < 9; ++k) Di[k] = m.dminv[(size_t)k * T + t];
-        shape_rows(Di, r);
-        TetState s;
-#pragma unroll
-        for (int k = 0; k < 9; ++k) s.F[k] = tc[(size_t)k * T + t];
-        {
-          double f0[3] = {s.F[0], s.F[3], s.F[6]}, f1[3] = {s.F[1], s.F[4], s.F[7]}, f2[3] = {s.F[2], s.F[5], s.F[8]};
-          double c0[3], c1[3], c2[3];
-          cross3(f1, f2, c0); cross3(f2, f0, c1); cross3(f0, f1, c2);
-#pragma unroll
-          for (int i = 0; i < 3; ++i) { s.C[i * 3 + 0] = c0[i]; s.C[i * 3 + 1] = c1[i]; s.C[i * 3 + 2] = c2[i]; }
-        }
-        s.a = tc[(size_t)9 * T + t]; s.b = tc[(size_t)10 * T + t]; s.c = tc[(size_t)11 * T + t];
-        const double sc = dt2 * m.vol[t];
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-          double dF[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, dP[9];
-          dF[k * 3 + 0] = r[l * 3 + 0]; dF[k * 3 + 1] = r[l * 3 + 1]; dF[k * 3 + 2] = r[l * 3 + 2];
-          apply_dP(m, s, dF, dP);
-#pragma unroll
-          for (int i = 0; i < 3; ++i)
-            De[i * 3 + k] += sc * (dP[i * 3 + 0] * r[l * 3 + 0] + dP[i * 3 + 1] * r[l * 3 + 1] + dP[i * 3 + 2] * r[l * 3 + 2]);
-        }
-      }
-      if (nit == 0) {
-#pragma unroll
-        for (int k = 0; k < 9; ++k) { Del[k] = De[k]; D[k] += De[k]; }
+      if (blk) {  // elastic part: the step's lagged blocks (see blk above)
+        const double* qb = blk + (size_t)v * 16;
+        D[0] += qb[0]; D[1] += qb[1]; D[2] += qb[2]; D[3] += qb[1]; D[4] += qb[3]; D[5] += qb[4]; D[6] += qb[2]; D[7] += qb[4]; D[8] += qb[5];
       }
 #pragma unroll
       for (int k = 0; k < 9; ++k) Dinv[(size_t)v * 9 + k] = D[k];
@@ -776,17 +783,48 @@ __global__ __launch_bounds__(512, TACEX_BALL_WG_PER_CU) void fem_ball_newton_ker
       if (tid == 0 && step_info) step_info[(size_t)b * 4 + 2] = (double)s_flags;
       return;
     }
-    // pad blocks -> inverses
-    for (int v = tid; v < V; v += NT) {
-      double D[9], Di3[9];
+    // block part of the pad's preconditioner: block-tridiagonal LDL^T along the vertex chains of tacex_fem_set_chains (the columns of
+    // vertices through the pad's thickness; a chain of one vertex = 3 x 3 block Jacobi) - S_0 = D_0, G_i = S_i^-1 E_i,
+    // S_{i+1} = D_{i+1} - E_i^T G_i, the thread of a chain walks it (fem_newton_lds_kernel does the same); S^-1 | G as floats in LDS
+    for (int ch = tid; ch < nch; ch += NT) {
+      int v = m.ch_next ? m.ch_head[ch] : ch;
+      double S[9];
 #pragma unroll
-      for (int k = 0; k < 9; ++k) D[k] = Dinv[(size_t)v * 9 + k];
-      if (!inv3_spd(D, Di3)) {
-        const double im = 1.0 / (m.mass[v] * (1.0 + ((cons && cons[v]) ? m.strength : 0.0)));
-        Di3[0] = im; Di3[1] = 0; Di3[2] = 0; Di3[3] = 0; Di3[4] = im; Di3[5] = 0; Di3[6] = 0; Di3[7] = 0; Di3[8] = im;
+      for (int k = 0; k < 9; ++k) S[k] = Dinv[(size_t)v * 9 + k];
+      while (true) {
+        double Si[9];
+        if (!inv3_spd(S, Si)) {
+          const double dm = fmax(S[0], fmax(S[4], S[8]));
+          const double im = 1.0 / (dm > 0.0 ? dm : 1.0);
+          Si[0] = im; Si[1] = 0; Si[2] = 0; Si[3] = 0; Si[4] = im; Si[5] = 0; Si[6] = 0; Si[7] = 0; Si[8] = im;
+        }
+        float* f = cf + v * 15;
+        f[0] = (float)Si[0]; f[1] = (float)Si[1]; f[2] = (float)Si[2]; f[3] = (float)Si[4]; f[4] = (float)Si[5]; f[5] = (float)Si[8];
+        const int n = cnx[v] == 0xffff ? -1 : (int)cnx[v];
+        if (n < 0 || !blk) {
+#pragma unroll
+          for (int k = 0; k < 9; ++k) f[6 + k] = 0.0f;
+          if (n < 0) break;
+#pragma unroll
+          for (int k = 0; k < 9; ++k) S[k] = Dinv[(size_t)n * 9 + k];
+          v = n;
+          continue;
+        }
+        const double* Ev = blk + (size_t)v * 16 + 6;
+        double G[9];
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+          for (int k = 0; k < 3; ++k) G[i * 3 + k] = Si[i * 3 + 0] * Ev[k] + Si[i * 3 + 1] * Ev[3 + k] + Si[i * 3 + 2] * Ev[6 + k];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) f[6 + k] = (float)G[k];
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+          for (int k = 0; k < 3; ++k)
+            S[i * 3 + k] = Dinv[(size_t)n * 9 + i * 3 + k] - (Ev[i] * G[k] + Ev[3 + i] * G[3 + k] + Ev[6 + i] * G[6 + k]);
+        v = n;
       }
-#pragma unroll
-      for (int k = 0; k < 9; ++k) Dinv[(size_t)v * 9 + k] = Di3[k];
     }
     for (int k = tid; k < 3 * VN; k += NT) { vr[k] = (bd.kinematic && k >= 3 * V) ? 0.0 : -vg[k]; vd[k] = 0.0; }  // (a fixed body: zero residual rows stay zero through the PCG)
     __syncthreads();

@@ -3138,7 +3138,9 @@ int tacex_fem_set_affine_body(tacex_fem_ctx* c, int num_verts, const double* ver
 size_t tacex_fem_ball_workspace_bytes(const tacex_fem_ctx* c, int B) {
   if (!c || B <= 0 || c->ball.nv == 0) return 0;
   // env blocks | x_prev (B,V,3) | q_prev (B,12) | x~ (B,V,3) | q~ (B,12) | q at the end of the previous step (B,12) | env launch order (B int32)
-  return ((size_t)B * ball_ws_doubles(c->dev.V, c->dev.T, c->ball.nv, c->ball.nt) + (size_t)B * 6 * c->dev.V + (size_t)B * 36 + 8 + ((size_t)B + 1) / 2) * sizeof(double);
+  // | elastic preconditioner blocks (B,V,16)
+  return ((size_t)B * ball_ws_doubles(c->dev.V, c->dev.T, c->ball.nv, c->ball.nt) + (size_t)B * 6 * c->dev.V + (size_t)B * 36 + 8 + ((size_t)B + 1) / 2 + 2 +
+          (size_t)B * 16 * c->dev.V) * sizeof(double);
 }
 
 int tacex_fem_ball_moments(const tacex_fem_ctx* c, double moments_out[16], double* kappa_vol_out) {
@@ -3146,6 +3148,15 @@ int tacex_fem_ball_moments(const tacex_fem_ctx* c, double moments_out[16], doubl
   for (int k = 0; k < 16; ++k) moments_out[k] = c->ball.S[k];
   if (kappa_vol_out) *kappa_vol_out = c->ball.kv;
   return 0;
+}
+
+static int ball_lds_ok(tacex_fem_ctx* c, const char* who) {
+  const size_t lds = ball_lds_bytes(c->dev.V);
+  if (lds > 160 * 1024) { set_error("%s: pad of %d vertices (x, p, accumulators and chain factors of one env must fit a CU's 160 KB of LDS)", who, c->dev.V); return 2; }
+  static size_t granted[64] = {};
+  hipError_t e = hipSetDevice(c->device);
+  if (e == hipSuccess) e = ensure_dynamic_lds(reinterpret_cast<const void*>(fem_ball_newton_kernel), lds, granted);
+  return e == hipSuccess ? 0 : fail_hip(e, "hipFuncSetAttribute(fem_ball_newton_kernel)");
 }
 
 static int ball_args_ok(tacex_fem_ctx* c, const void* x, const void* q, const void* ws, const uint8_t* cons, const double* aim, const char* who) {
@@ -3161,10 +3172,11 @@ int tacex_fem_ball_terms(tacex_fem_ctx* c, const double* x, const double* xt, co
   if (int rc = ball_args_ok(c, x, q, ws, cons, aim, "tacex_fem_ball_terms")) return rc;
   if (!xt || !qt) { set_error("tacex_fem_ball_terms: null argument"); return 2; }
   if (B <= 0) return 0;
-  if (ball_lds_bytes(c->dev.V) > 48 * 1024) { set_error("tacex_fem_ball_terms: pad of %d vertices (the kernel keeps x, p and the H.p accumulators of <= 680 vertices in LDS)", c->dev.V); return 2; }
+  if (int rc = ball_lds_ok(c, "tacex_fem_ball_terms")) return rc;
   hipLaunchKernelGGL(fem_ball_newton_kernel, dim3(B), dim3(512), ball_lds_bytes(c->dev.V), (hipStream_t)stream, c->dev, c->ball, const_cast<double*>(x), xt,
                      const_cast<double*>(q), qt, cons, aim, static_cast<double*>(ws), 1, 1.0, 0, 1, 0.0, 0.0, step_info, 1, energy, grad,
-                     (x_prev && q_prev) ? x_prev : nullptr, (x_prev && q_prev) ? q_prev : nullptr, static_cast<const int*>(nullptr));
+                     (x_prev && q_prev) ? x_prev : nullptr, (x_prev && q_prev) ? q_prev : nullptr, static_cast<const int*>(nullptr),
+                     static_cast<const double*>(nullptr));
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : fail_hip(e, "fem_ball_newton_kernel(terms)");
 }
@@ -3202,11 +3214,23 @@ int tacex_fem_ball_step(tacex_fem_ctx* c, double* x, double* v, double* q, doubl
     env_order = reinterpret_cast<int*>(qlast + (size_t)B * 12 + 1);
     hipLaunchKernelGGL(fem_env_order_kernel, dim3(1), dim3(1024), 0, st, step_info, B, env_order);
   }
-  if (ball_lds_bytes(c->dev.V) > 48 * 1024) { set_error("tacex_fem_ball_step: pad of %d vertices (the kernel keeps x, p and the H.p accumulators of <= 680 vertices in LDS)", c->dev.V); return 2; }
+  if (int rc = ball_lds_ok(c, "tacex_fem_ball_step")) return rc;
+  // elastic preconditioner blocks D | E of every env at the state the step starts from (what fem_newton_lds_kernel's launch does too)
+  double* blk = reinterpret_cast<double*>(reinterpret_cast<char*>(qlast + (size_t)B * 12) + (((size_t)B + 1) / 2 + 2) * sizeof(double));
+  {
+    static size_t granted_a[2][64] = {};
+    const bool asm_atom = !c->deterministic;
+    const size_t lds_a = ((size_t)3 * V + (asm_atom ? (size_t)15 * V : 0)) * sizeof(double);
+    auto ka = asm_atom ? fem_assemble_blocks_kernel<true> : fem_assemble_blocks_kernel<false>;
+    hipError_t ea = hipSetDevice(c->device);
+    if (ea == hipSuccess) ea = ensure_dynamic_lds(reinterpret_cast<const void*>(ka), lds_a, granted_a[asm_atom ? 1 : 0]);
+    if (ea != hipSuccess) return fail_hip(ea, "hipFuncSetAttribute(fem_assemble_blocks_kernel)");
+    hipLaunchKernelGGL(ka, dim3(B), dim3(512), lds_a, st, c->dev_nwt, x, blk, static_cast<const double*>(nullptr), 0.0);
+  }
   hipLaunchKernelGGL(fem_ball_newton_kernel, dim3(B), dim3(512), ball_lds_bytes(c->dev.V), st, c->dev, c->ball, x, xt, q, qt, cons, aim, static_cast<double*>(ws), pcg_max_iter,
                      pcg_tol_rate, ls_max_iter, max_newton, velocity_tol * dt, transrate_tol * dt, step_info, ball_coarse_off ? 2 : 0,
                      static_cast<double*>(nullptr), static_cast<double*>(nullptr), static_cast<const double*>(xprev),
-                     static_cast<const double*>(have_last ? qlast : qprev), static_cast<const int*>(env_order));
+                     static_cast<const double*>(have_last ? qlast : qprev), static_cast<const int*>(env_order), static_cast<const double*>(blk));
   hipLaunchKernelGGL(fem_velocity_kernel, dim3((unsigned)((n3 + 255) / 256)), dim3(256), 0, st, x, xprev, v, n3, 1.0 / dt, static_cast<const double*>(nullptr),
                      static_cast<double*>(nullptr), B);
   hipLaunchKernelGGL(fem_ball_velocity_kernel, dim3((unsigned)((B * 12 + 255) / 256)), dim3(256), 0, st, q, qprev, qv, B, 1.0 / dt);
