@@ -48,10 +48,10 @@ constexpr int kBallFlagOverflow = 16; // step_info flag: a candidate / pair list
 
 // workspace of one env (doubles): ge 12T | tc 12T | hv 12T | g r z p d Hp yc: 7 x 3 (V+4) | D / Dinv 9V | ground curvature V |
 //   xb 3nv | xbc 3nv | dxb 3nv | ball triangle spheres 4nt | pair list (ints) kBallMaxPairs / 2 | active records
-// dynamic LDS: x (V,3) | p (V + 4,3) | H.p accumulators (V,3) | r / z of the chain solve (V,3) (doubles) || chain factors (V,15) (floats) ||
-// chain successor / predecessor (V each, u16)
+// dynamic LDS: x (V,3) | p (V + 4,3) | H.p accumulators = H.p (V,3) | z (V,3) | r (V + 4,3) | d (V + 4,3) (doubles) || chain factors (V,15)
+// (floats) || chain successor / predecessor (V each, u16): every vector of the PCG loop, 104 KB at 495 vertices
 __host__ __device__ inline size_t ball_lds_bytes(int V) {
-  return ((((size_t)12 * V + 12) * sizeof(double) + (size_t)15 * V * sizeof(float) + (size_t)2 * V * sizeof(unsigned short)) + 15) & ~(size_t)15;
+  return ((((size_t)18 * V + 36) * sizeof(double) + (size_t)15 * V * sizeof(float) + (size_t)2 * V * sizeof(unsigned short)) + 15) & ~(size_t)15;
 }
 __host__ __device__ inline size_t ball_ws_doubles(int V, int T, int nv, int nt) {
   return (size_t)36 * T + (size_t)21 * (V + 4) + (size_t)10 * V + (size_t)9 * nv + (size_t)4 * nt + kBallMaxPairs / 2 + (size_t)kBallMaxActive * kBallRec +
@@ -138,7 +138,7 @@ __global__ __launch_bounds__(512, TACEX_BALL_WG_PER_CU) void fem_ball_newton_ker
   __shared__ double sh[17], sh2[16];
   __shared__ double gb[12], Bm[144], B0[144], Lc[144], Bi[144], YY[16], qs[12], qts[12], rhs12[12];
   __shared__ double crc[3 * kFemMaxCoarse], cyc[3 * kFemMaxCoarse];  // coarse residual / correction of the two-level preconditioner
-  __shared__ double qps[12];  // the ball rows the time step started from (friction slides relative to them)
+  __shared__ double qps[12], Hpq[12], zq[12];  // ... | the ball rows of H.p and of z  // the ball rows the time step started from (friction slides relative to them)
   __shared__ int n_cpv, n_cpt, n_cbv, n_pairs, n_act, n_fric, s_flags;
   __shared__ int cpv[kBallMaxCand], cpt[kBallMaxCand], cbv[kBallMaxCand];
   // env_order: envs sorted by the solver work of their previous step, heaviest first (fem_env_order_kernel): a shard brings two envs
@@ -182,8 +182,10 @@ __global__ __launch_bounds__(512, TACEX_BALL_WG_PER_CU) void fem_ball_newton_ker
   double* xs = ball_lds;           // (V,3) x of the iteration: the tet state is recomputed from it in every H.p (no cached F in HBM)
   double* ps = xs + 3 * V;         // (V + 4,3) PCG direction
   double* acc = ps + 3 * VN;       // (V,3) per-vertex sums of the tets' rows (ds_add_f64)
-  double* rsl = acc + 3 * V;       // (V,3) the chain solve's r, then y, then z (in place)
-  float* cf = reinterpret_cast<float*>(rsl + 3 * V);                      // (V,15) chain factors: S^-1 (upper triangle, 6) | G (9)
+  double* rsl = acc + 3 * V;       // (V,3) z: the chain solve's r, then y, then z (in place), + the coarse correction
+  double* rL = rsl + 3 * V;        // (V + 4,3) PCG residual
+  double* dL = rL + 3 * VN;        // (V + 4,3) PCG solution (the Newton direction)
+  float* cf = reinterpret_cast<float*>(dL + 3 * VN);                      // (V,15) chain factors: S^-1 (upper triangle, 6) | G (9)
   unsigned short* cnx = reinterpret_cast<unsigned short*>(cf + 15 * V);   // (V) chain successor, 0xffff = none
   unsigned short* cpr = cnx + V;                                           // (V) predecessor
   // elastic preconditioner blocks of the step: D (upper triangle) | E = A(v, next(v)) per vertex, assembled for all envs by
@@ -327,12 +329,26 @@ __global__ __launch_bounds__(512, TACEX_BALL_WG_PER_CU) void fem_ball_newton_ker
     return sv;
   };
   const bool coarse = m.nc > 0 && m.cn_off && m.ac_inv && (mode & 2) == 0;  // (mode bit 1: block Jacobi alone, A/B)
-  // z = M^-1 r: 3 x 3 blocks on the pad rows (+ the coarse correction), the exact inverse of the 12 x 12 ball block on the ball rows
-  auto precondition = [&](const double* r, double* z) -> double {
-    double part = 0.0;
-    // chain solve z = L^-T S^-1 L^-1 r in LDS, in place: down the chain y_i = r_i - G_{i-1}^T y_{i-1}, back up z_i = S_i^-1 y_i - G_i z_{i+1}
-    for (int k = tid; k < 3 * V; k += NT) rsl[k] = r[k];
+  // z = M^-1 r, everything in LDS (r = rL; z = rsl on the pad rows, zq on the ball rows): chain solve z = L^-T S^-1 L^-1 r in place (down the
+  // chain y_i = r_i - G_{i-1}^T y_{i-1}, back up z_i = S_i^-1 y_i - G_i z_{i+1}) + the additive coarse correction P A_c^-1 P^T r of the
+  // pad's coarse space (restriction by ds_add_f64 from the vertices' own 8 (node, weight) pairs) + the exact inverse of the ball block.
+  // Returns r . z.
+  auto precondition = [&]() -> double {
+    const int nc3 = 3 * m.nc;
+    for (int k = tid; k < 3 * V; k += NT) rsl[k] = rL[k];
+    if (coarse && tid < nc3) crc[tid] = 0.0;
     __syncthreads();
+    if (coarse) {
+      for (int v = tid; v < V; v += NT) {
+        const double r0 = rL[v * 3], r1 = rL[v * 3 + 1], r2 = rL[v * 3 + 2];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          const int nd = m.cv_node[v * 8 + k];
+          const double w = m.cv_w[v * 8 + k];
+          if (w != 0.0) { atomicAdd(&crc[nd * 3], w * r0); atomicAdd(&crc[nd * 3 + 1], w * r1); atomicAdd(&crc[nd * 3 + 2], w * r2); }
+        }
+      }
+    }
     for (int ch = tid; ch < nch; ch += NT) {
       int v = m.ch_next ? m.ch_head[ch] : ch, last = v;
       double y[3] = {rsl[v * 3], rsl[v * 3 + 1], rsl[v * 3 + 2]};
@@ -365,24 +381,36 @@ __global__ __launch_bounds__(512, TACEX_BALL_WG_PER_CU) void fem_ball_newton_ker
         v = pv;
       }
     }
-    __syncthreads();
-    for (int k = tid; k < 3 * V; k += NT) {
-      const double zz = rsl[k];
-      z[k] = zz;
-      part += r[k] * zz;
-    }
+    double part = 0.0;
     if (tid < 12) {
       double zz = 0.0;
 #pragma unroll
-      for (int k = 0; k < 12; ++k) zz += Bi[tid * 12 + k] * r[V * 3 + k];
-      z[V * 3 + tid] = zz;
-      part += r[V * 3 + tid] * zz;
+      for (int k = 0; k < 12; ++k) zz += Bi[tid * 12 + k] * rL[V * 3 + k];
+      zq[tid] = zz;
+      part += rL[V * 3 + tid] * zz;
     }
+    __syncthreads();
     if (coarse) {
-      // additive coarse correction on the pad rows (coarse_correct, fem_kernels.hip: the second level of the CU-resident kernel's
-      // preconditioner; block Jacobi alone needs ~48 PCG iterations per Newton iteration on this pad, with it 14-24, r06 section 5)
+      if (tid < nc3) {
+        double sv = 0.0;
+        for (int k = 0; k < nc3; ++k) sv += m.ac_inv[(size_t)tid * nc3 + k] * crc[k];
+        cyc[tid] = sv;
+        part += crc[tid] * sv;
+      }
       __syncthreads();
-      part += coarse_correct(m, r, z, crc, cyc);
+    }
+    for (int v = tid; v < V; v += NT) {
+      double z0 = rsl[v * 3], z1 = rsl[v * 3 + 1], z2 = rsl[v * 3 + 2];
+      part += rL[v * 3] * z0 + rL[v * 3 + 1] * z1 + rL[v * 3 + 2] * z2;  // (the chain part; the coarse part of r . z is crc . cyc above)
+      if (coarse) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          const int nd = m.cv_node[v * 8 + k];
+          const double w = m.cv_w[v * 8 + k];
+          z0 += w * cyc[nd * 3]; z1 += w * cyc[nd * 3 + 1]; z2 += w * cyc[nd * 3 + 2];
+        }
+        rsl[v * 3] = z0; rsl[v * 3 + 1] = z1; rsl[v * 3 + 2] = z2;
+      }
     }
     return bsum(part);
   };
@@ -826,17 +854,18 @@ __global__ __launch_bounds__(512, TACEX_BALL_WG_PER_CU) void fem_ball_newton_ker
         v = n;
       }
     }
-    for (int k = tid; k < 3 * VN; k += NT) { vr[k] = (bd.kinematic && k >= 3 * V) ? 0.0 : -vg[k]; vd[k] = 0.0; }  // (a fixed body: zero residual rows stay zero through the PCG)
+    for (int k = tid; k < 3 * VN; k += NT) { rL[k] = (bd.kinematic && k >= 3 * V) ? 0.0 : -vg[k]; dL[k] = 0.0; }  // (a fixed body: zero residual rows stay zero through the PCG)
     __syncthreads();
     BALL_TICK(3);  // pairs, friction, ball blocks, factorisation, pad block inverses
-    // ---- PCG: x and p in LDS, the tets' rows added into per-vertex LDS accumulators (no per-tet arrays through HBM) ----
-    for (int k = tid; k < 3 * V; k += NT) xs[k] = x[k];
-    double rz = precondition(vr, vz);
-    for (int k = tid; k < 3 * VN; k += NT) ps[k] = vz[k];
+    // ---- PCG: every vector in LDS (x, p, H.p = the accumulators of the tets' rows, z, r, d); the mesh constants, the blocks' tables and
+    //      the pair records are what it reads from memory ----
+    for (int k = tid; k < 3 * V; k += NT) { xs[k] = x[k]; acc[k] = 0.0; }
+    __syncthreads();
+    double rz = precondition();
+    for (int k = tid; k < 3 * V; k += NT) ps[k] = rsl[k];
+    if (tid < 12) ps[V * 3 + tid] = zq[tid];
     const double rz0 = rz;
     int it = 0;
-    __syncthreads();
-    for (int k = tid; k < 3 * V; k += NT) acc[k] = 0.0;
     __syncthreads();
     while (it < pcg_max_iter && rz0 > 0.0 && rz > pcg_tol_rate * rz0) {
       for (int t = tid; t < T; t += NT) {
@@ -860,15 +889,12 @@ __global__ __launch_bounds__(512, TACEX_BALL_WG_PER_CU) void fem_ball_newton_ker
       for (int v = tid; v < V; v += NT) {
         const double md = m.mass[v] * (1.0 + ((cons && cons[v]) ? m.strength : 0.0));
 #pragma unroll
-        for (int i = 0; i < 3; ++i) {
-          vHp[v * 3 + i] = acc[v * 3 + i] + md * ps[v * 3 + i] + (i == 2 ? cbp[v] * ps[v * 3 + 2] : 0.0);
-          acc[v * 3 + i] = 0.0;  // (for the next iteration's sweep: the same thread read it, barriers lie before the next atomics)
-        }
+        for (int i = 0; i < 3; ++i) acc[v * 3 + i] += md * ps[v * 3 + i] + (i == 2 ? cbp[v] * ps[v * 3 + 2] : 0.0);  // acc IS H.p from here on
       }
       if (tid < 12) {
         double sv = 0.0;
         for (int k = 0; k < 12; ++k) sv += B0[tid * 12 + k] * ps[V * 3 + k];
-        vHp[V * 3 + tid] = sv;
+        Hpq[tid] = sv;
       }
       __syncthreads();
       {
@@ -886,16 +912,16 @@ __global__ __launch_bounds__(512, TACEX_BALL_WG_PER_CU) void fem_ball_newton_ker
           const double f = rc[0] * gp;
 #pragma unroll
           for (int a4 = 0; a4 < 4; ++a4) {
-            atomicAdd(&vHp[(V + a4) * 3], f * rc[4 + a4] * n0);
-            atomicAdd(&vHp[(V + a4) * 3 + 1], f * rc[4 + a4] * n1);
-            atomicAdd(&vHp[(V + a4) * 3 + 2], f * rc[4 + a4] * n2);
+            atomicAdd(&Hpq[a4 * 3], f * rc[4 + a4] * n0);
+            atomicAdd(&Hpq[a4 * 3 + 1], f * rc[4 + a4] * n1);
+            atomicAdd(&Hpq[a4 * 3 + 2], f * rc[4 + a4] * n2);
           }
 #pragma unroll
           for (int r = 0; r < 3; ++r)
             if (ri[r] >= 0) {
-              atomicAdd(&vHp[ri[r] * 3], f * rc[8 + r] * n0);
-              atomicAdd(&vHp[ri[r] * 3 + 1], f * rc[8 + r] * n1);
-              atomicAdd(&vHp[ri[r] * 3 + 2], f * rc[8 + r] * n2);
+              atomicAdd(&acc[ri[r] * 3], f * rc[8 + r] * n0);
+              atomicAdd(&acc[ri[r] * 3 + 1], f * rc[8 + r] * n1);
+              atomicAdd(&acc[ri[r] * 3 + 2], f * rc[8 + r] * n2);
             }
         }
       }
@@ -921,37 +947,43 @@ __global__ __launch_bounds__(512, TACEX_BALL_WG_PER_CU) void fem_ball_newton_ker
           for (int a4 = 0; a4 < 4; ++a4)
             if (rc[4 + a4] != 0.0)
 #pragma unroll
-              for (int i = 0; i < 3; ++i) atomicAdd(&vHp[(V + a4) * 3 + i], rc[4 + a4] * mw[i]);
+              for (int i = 0; i < 3; ++i) atomicAdd(&Hpq[a4 * 3 + i], rc[4 + a4] * mw[i]);
 #pragma unroll
           for (int r = 0; r < 3; ++r)
             if (ri[r] >= 0)
 #pragma unroll
-              for (int i = 0; i < 3; ++i) atomicAdd(&vHp[ri[r] * 3 + i], rc[8 + r] * mw[i]);
+              for (int i = 0; i < 3; ++i) atomicAdd(&acc[ri[r] * 3 + i], rc[8 + r] * mw[i]);
         }
       }
       __syncthreads();
-      if (bd.kinematic) {  // a fixed body: its rows of the operator are eliminated (the residual rows stay zero, p_q stays zero)
-        if (tid < 12) vHp[V * 3 + tid] = 0.0;
-        __syncthreads();
-      }
       double part = 0.0;
-      for (int k = tid; k < 3 * VN; k += NT) part += ps[k] * vHp[k];
+      for (int k = tid; k < 3 * V; k += NT) part += ps[k] * acc[k];
+      if (tid < 12) {
+        if (bd.kinematic) Hpq[tid] = 0.0;  // a fixed body: its rows of the operator are eliminated (only thread tid reads Hpq[tid] below)
+        part += ps[V * 3 + tid] * Hpq[tid];
+      }
       const double pHp = bsum(part);
       if (!(pHp > 0.0)) {
-        if (it == 0)
-          for (int k = tid; k < 3 * VN; k += NT) vd[k] = vz[k];
+        if (it == 0) {
+          for (int k = tid; k < 3 * V; k += NT) dL[k] = rsl[k];
+          if (tid < 12) dL[V * 3 + tid] = zq[tid];
+        }
         break;
       }
       const double al = rz / pHp;
-      for (int k = tid; k < 3 * VN; k += NT) { vd[k] += al * ps[k]; vr[k] -= al * vHp[k]; }
+      for (int k = tid; k < 3 * V; k += NT) { dL[k] += al * ps[k]; rL[k] -= al * acc[k]; acc[k] = 0.0; }  // (acc: zero for the next sweep)
+      if (tid < 12) { dL[V * 3 + tid] += al * ps[V * 3 + tid]; rL[V * 3 + tid] -= al * Hpq[tid]; }
       __syncthreads();
-      const double rz_new = precondition(vr, vz);
+      const double rz_new = precondition();
       const double beta = rz_new / rz;
-      for (int k = tid; k < 3 * VN; k += NT) ps[k] = vz[k] + beta * ps[k];
+      for (int k = tid; k < 3 * V; k += NT) ps[k] = rsl[k] + beta * ps[k];
+      if (tid < 12) ps[V * 3 + tid] = zq[tid] + beta * ps[V * 3 + tid];
       rz = rz_new;
       ++it;
       __syncthreads();
     }
+    __syncthreads();
+    for (int k = tid; k < 3 * VN; k += NT) vd[k] = dL[k];  // the direction goes to memory for the step bound and the line search
     __syncthreads();
     pcg_total += it;
     BALL_TICK(4);  // PCG
