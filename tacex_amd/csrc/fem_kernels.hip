@@ -782,14 +782,17 @@ __global__ __launch_bounds__(512) void fem_newton_kernel(FemDev m, double* xg, c
   double* tc = ws + (size_t)12 * T;      // (12,T) F(9), a, b, c
   double* hv = ws + (size_t)24 * T;      // (12,T) per-tet H*p contributions
   double* vg = ws + (size_t)36 * T;      // g
-  double* vr = vg + (size_t)3 * V;
-  double* vz = vr + (size_t)3 * V;
-  double* vp = lds_sweep ? nws_lds + 3 * V : vz + (size_t)3 * V;  // (the workspace slot stays where it is: the layout is one)
+  // lds_sweep = 2: the PCG's r, z, d and H.p live in LDS as well (21 V doubles: 120 KB at 715 vertices) - the direction is computed and
+  // consumed (step bound, line search) inside this launch, so nothing of the loop has to pass through memory (the workspace slots stay
+  // where they are: the layout is one)
+  double* vr = lds_sweep == 2 ? nws_lds + 9 * V : vg + (size_t)3 * V;
+  double* vz = lds_sweep == 2 ? nws_lds + 12 * V : vg + (size_t)6 * V;
+  double* vp = lds_sweep ? nws_lds + 3 * V : vg + (size_t)9 * V;
   double* xs_l = nws_lds;                   // (V,3) x
   double* acc_l = nws_lds + 6 * V;          // (V,3) accumulators
-  double* vd = vz + (size_t)6 * V;
-  double* vHp = vd + (size_t)3 * V;
-  double* xc = vHp + (size_t)3 * V;      // line-search candidate
+  double* vd = lds_sweep == 2 ? nws_lds + 15 * V : vg + (size_t)12 * V;
+  double* vHp = lds_sweep == 2 ? nws_lds + 18 * V : vg + (size_t)15 * V;
+  double* xc = vg + (size_t)18 * V;      // line-search candidate
   double* Dinv = xc + (size_t)3 * V;     // (V,9)
   double* cdat = Dinv + (size_t)9 * V;   // (V,5) barrier of the vertex at x: dt^2 b'' | n (3) | gap d
   double* flag_ = cdat + (size_t)5 * V;  // (V,4) friction lag: normal force | normal - taken in the FIRST launch of a time step, kept for its others
@@ -2997,8 +3000,9 @@ static int launch_newton(tacex_fem_ctx* c, double* x, const double* xt, const ui
     return 2;
   }
   // x, p and the H.p accumulators in LDS when the summation order is free (atomic mode) and they fit (9 V doubles: ~2 200 vertices)
-  static const int stream_lds = getenv("TACEX_FEM_STREAM_LDS") ? atoi(getenv("TACEX_FEM_STREAM_LDS")) : 1;  // A/B hook
-  const size_t lds_s = (size_t)9 * V * sizeof(double);
+  static const int stream_lds = getenv("TACEX_FEM_STREAM_LDS") ? atoi(getenv("TACEX_FEM_STREAM_LDS")) : 2;  // A/B hook: 0 none, 1 x / p / accumulators, 2 all PCG vectors
+  const bool lds_all = stream_lds != 1 && (size_t)21 * V * sizeof(double) <= 160 * 1024;  // (TACEX_FEM_STREAM_LDS=1: x, p, accumulators only)
+  const size_t lds_s = (size_t)(lds_all ? 21 : 9) * V * sizeof(double);
   const bool lds_sweep = stream_lds != 0 && atom && lds_s <= 160 * 1024;
   if (lds_sweep) {
     static size_t granted_s[64] = {};
@@ -3008,7 +3012,7 @@ static int launch_newton(tacex_fem_ctx* c, double* x, const double* xt, const ui
   }
   hipLaunchKernelGGL(fem_newton_kernel, dim3(B), dim3(512), lds_sweep ? lds_s : 0, st, c->dev, x, xt, cons, aim, stats, static_cast<double*>(ws), pcg_max_iter,
                      pcg_tol_rate, ls_max_iter, dx_dev, dx_tol, step_info, stream_accumulate ? 1 : 0, fric ? xprev : nullptr, fric ? disp : nullptr,
-                     c->fric_lag_mode == 1 ? 1 : 0, lds_sweep ? 1 : 0);
+                     c->fric_lag_mode == 1 ? 1 : 0, lds_sweep ? (lds_all ? 2 : 1) : 0);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : fail_hip(e, "fem_newton_kernel");
 }
