@@ -96,6 +96,9 @@ class UipcObject:
             raise ValueError("mesh_points must be (V,3) and mesh_tets (T,4)")
         if self.is_affine_body:
             self.tris = np.ascontiguousarray(cfg.mesh_tris if cfg.mesh_tris is not None else self.surface_triangles(), dtype=np.int32)
+            a, b, c = (self.points[self.tris[:, k]] for k in range(3))
+            if np.einsum("ij,ij->i", a, np.cross(b, c)).sum() < 0.0:  # (boundary faces of negatively oriented tets look inward)
+                self.tris = np.ascontiguousarray(self.tris[:, [0, 2, 1]])
         self._uipc_sim = uipc_sim
         if uipc_sim is not None:
             uipc_sim.uipc_objects.append(self)

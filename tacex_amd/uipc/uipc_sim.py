@@ -175,6 +175,10 @@ class UipcSim:
             raise NotImplementedError("the ground of a scene with an affine body is the half-space z >= ground_height (ground_normal (0, 0, 1))")
         obj, B, dev = self._obj, self.num_envs, self.device
         c = self.cfg.contact
+        if not c.enable:
+            raise NotImplementedError("a scene with an affine body needs contact (UipcSimCfg.contact.enable): nothing else holds the free body")
+        if self.cfg.linear_system.deterministic:
+            raise NotImplementedError("linear_system.deterministic is not available with an affine body (csrc/fem_ball.h adds its tet / pair rows with LDS atomics)")
         area = np.ascontiguousarray(obj.surface_vertex_areas(), np.float64)
         ptri = np.ascontiguousarray(obj.surface_triangles(), np.int32)
         verts = np.ascontiguousarray(body.points, np.float64)
@@ -252,6 +256,9 @@ class UipcSim:
             return
         if not self.cfg.contact.enable:
             raise RuntimeError("UipcSimCfg.contact.enable is False")
+        if getattr(self, "_body", None) is not None:
+            raise NotImplementedError("a scene with an affine body takes its contact from the body, the ground and the gelpad (pairs); prescribed "
+                                      "indenters are the other kind of scene (or make the body kinematic: AffineBodyConstitutionCfg.kinematic)")
         ind = indenters.to(self.device, torch.float64).reshape(self.num_envs, 8).contiguous()
         area = None
         if not getattr(self, "_contact_area_set", False):

@@ -269,3 +269,44 @@ def test_kinematic_body_is_fixed_within_a_step_and_dents_the_pad():
     assert lift[0] > 1.5e-4 and lift[0] > lift[1] > 0.0, lift  # the pad's face was pushed up, more where the ball rose further
     gaps = sim.x[:, face, 2].cpu().numpy() - (sim.q[:, 0, 2].cpu().numpy() + R)
     assert (gaps > 0).all()
+
+
+def test_scene_guards_of_the_affine_body_path():
+    """What the ball path does not do is refused loudly: prescribed indenters next to a body, the deterministic switch, a body without contact,
+    a second body; a body given by tets takes their surface."""
+    from tacex_amd.uipc import UipcObject, UipcObjectCfg, UipcSim, UipcSimCfg
+    from tacex_amd.uipc.gelpad_scene import FemBallScene, icosphere
+    from tacex_amd.uipc.uipc_object import gelpad_box_mesh
+
+    sc = FemBallScene(2, "cuda:0")
+    with pytest.raises(NotImplementedError):
+        sc.sim.set_contact_indenters(torch.zeros((2, 8), dtype=torch.float64, device="cuda"))
+    P, T = gelpad_box_mesh(4, 5, 2)
+    vb, tb = icosphere(0.005, 1)
+    for bad in ("deterministic", "no_contact", "two_bodies"):
+        cfg = UipcSimCfg(device="cuda:0")
+        if bad == "deterministic":
+            cfg.linear_system.deterministic = True
+        if bad == "no_contact":
+            cfg.contact.enable = False
+        sim = UipcSim(cfg, num_envs=1)
+        UipcObject(UipcObjectCfg(mesh_points=P + np.array([0, 0, 0.02]), mesh_tets=T), sim)
+        UipcObject(UipcObjectCfg(mesh_points=vb, mesh_tris=tb, init_pos=(0.01, 0.012, 0.007), constitution_cfg=UipcObjectCfg.AffineBodyConstitutionCfg()), sim)
+        if bad == "two_bodies":
+            UipcObject(UipcObjectCfg(mesh_points=vb, mesh_tris=tb, constitution_cfg=UipcObjectCfg.AffineBodyConstitutionCfg()), sim)
+        with pytest.raises((NotImplementedError, RuntimeError)):
+            sim.setup_sim()
+    # a body given as a tet mesh: its boundary faces are the surface
+    Pb, Tb = gelpad_box_mesh(2, 2, 2, size=(0.006, 0.006, 0.006))
+    sim = UipcSim(UipcSimCfg(device="cuda:0", ground_height=0.001), num_envs=1)
+    UipcObject(UipcObjectCfg(mesh_points=P + np.array([0, 0, 0.02]), mesh_tets=T), sim)
+    body = UipcObject(UipcObjectCfg(mesh_points=Pb - 0.003, mesh_tets=Tb, init_pos=(0.01, 0.012, 0.0045),
+                                    constitution_cfg=UipcObjectCfg.AffineBodyConstitutionCfg()), sim)
+    assert body.tris.shape == (48, 3)
+    sim.setup_sim()
+    import ctypes as C
+    S = (C.c_double * 16)()
+    sim._lib.tacex_fem_ball_moments(sim._handle, S, None)
+    assert np.array(S)[0] == pytest.approx(1e3 * 0.006**3, rel=1e-9)  # mass of the cube
+    sim.step(max_newton_iter=30)  # falls into the ground's barrier zone and is held
+    assert len(sim.check_step()["line_search_failed_envs"]) == 0 and float(sim.q[0, 0, 2]) > 0.001 + 0.003
