@@ -117,6 +117,72 @@ def accd_point_triangle(p, tri, dp, dtri, t_max=1.0, slack=0.9, keep=0.1, max_it
     return t
 
 
+def segment_segment(a0, a1, b0, b1):
+    """Closest points of segments a (Na,3)+(Na,3) and b (Nb,3)+(Nb,3), every a against every b (Ericson, Real-Time Collision Detection
+    5.1.9, in the book's order - the kernel's order): parameters s, t in [0,1] (Na,Nb), distance (Na,Nb), unit vector n (Na,Nb,3) from the
+    point on b to the point on a.  The gradient of the distance is (1-s) n, s n on a's end points and -(1-t) n, -t n on b's (envelope)."""
+    a0, a1, b0, b1 = (np.asarray(v, np.float64) for v in (a0, a1, b0, b1))
+    d1, d2 = (a1 - a0)[:, None, :], (b1 - b0)[None, :, :]
+    r = a0[:, None, :] - b0[None, :, :]
+    a, e = (d1 * d1).sum(-1), (d2 * d2).sum(-1)
+    f, c, b = (d2 * r).sum(-1), (d1 * r).sum(-1), (d1 * d2).sum(-1)
+    a, e = np.broadcast_to(a, b.shape), np.broadcast_to(e, b.shape)
+    den = a * e - b * b
+    with np.errstate(divide="ignore", invalid="ignore"):
+        s = np.where(den > 0.0, np.clip((b * f - c * e) / den, 0.0, 1.0), 0.0)
+        t = (b * s + f) / e
+        s = np.where(t < 0.0, np.clip(-c / a, 0.0, 1.0), np.where(t > 1.0, np.clip((b - c) / a, 0.0, 1.0), s))
+    t = np.clip(t, 0.0, 1.0)
+    w = r + s[..., None] * d1 - t[..., None] * d2
+    d = np.linalg.norm(w, axis=-1)
+    return s, t, d, w / np.maximum(d, 1e-300)[..., None]
+
+
+def edge_mollifier(c, eps):
+    """IPC's mollifier of nearly parallel edge pairs (Li et al. 2020, eq. 24) in c = |e_a x e_b|^2: m = (2 - c/eps) c/eps below eps, 1 above;
+    returns (m, dm/dc)."""
+    r = c / eps
+    lo = r < 1.0
+    return np.where(lo, (2.0 - r) * r, 1.0), np.where(lo, 2.0 * (1.0 - r) / eps, 0.0)
+
+
+def accd_edge_edge(ea, eb, dea, deb, t_max=1.0, slack=0.9, keep=0.1, max_iter=64):
+    """Additive CCD of ONE edge-edge pair (as accd_point_triangle; l = max |d a_k| + max |d b_k|).  ea, eb, dea, deb (2,3)."""
+    mean = (dea.sum(0) + deb.sum(0)) / 4.0
+    dea, deb = dea - mean, deb - mean
+    l = np.linalg.norm(dea, axis=1).max() + np.linalg.norm(deb, axis=1).max()
+    if not l > 0.0:
+        return t_max
+    dist = lambda t: float(segment_segment((ea[0] + t * dea[0])[None], (ea[1] + t * dea[1])[None], (eb[0] + t * deb[0])[None], (eb[1] + t * deb[1])[None])[2][0, 0])
+    d0 = dist(0.0)
+    g = keep * d0
+    t, tl = 0.0, (1.0 - keep) * d0 / l
+    for _ in range(max_iter):
+        d = dist(t + tl)
+        if t > 0.0 and d < g:
+            break
+        t += tl
+        if t >= t_max:
+            return t_max
+        tl = slack * d / l
+    return t
+
+
+def surface_edges(tris, X):
+    """Unique edges (E,2) (lower index first, sorted) of a triangle mesh, the area each stands for (a third of its triangles' rest areas - the
+    edge areas sum to the surface area) and its squared rest length."""
+    tris = np.asarray(tris, np.int64)
+    ta = 0.5 * np.linalg.norm(np.cross(X[tris[:, 1]] - X[tris[:, 0]], X[tris[:, 2]] - X[tris[:, 0]]), axis=1)
+    e = np.concatenate([tris[:, [0, 1]], tris[:, [1, 2]], tris[:, [2, 0]]])
+    e.sort(axis=1)
+    key = e[:, 0] * (int(tris.max()) + 1) + e[:, 1]
+    uk, inv = np.unique(key, return_inverse=True)
+    area = np.zeros(len(uk))
+    np.add.at(area, inv, np.tile(ta / 3.0, 3))
+    edges = np.stack([uk // (int(tris.max()) + 1), uk % (int(tris.max()) + 1)], 1)
+    return edges, area, ((X[edges[:, 1]] - X[edges[:, 0]]) ** 2).sum(-1)
+
+
 class AffineBody:
     """One affine body on its closed surface mesh (body frame: the mesh's own coordinates)."""
 
@@ -182,8 +248,10 @@ class BallScene:
     State of one env: y (V + 4, 3) = pad vertices, then the ball's (p, c_1, c_2, c_3).  All energies are those of ONE backward-Euler
     step (already scaled by dt^2 where they are potentials)."""
 
-    def __init__(self, pad: FemModel, pad_tris, pad_area, ball: AffineBody, dhat=5e-4, kappa=None, ground_height=0.001, resistance=10.0):
+    def __init__(self, pad: FemModel, pad_tris, pad_area, ball: AffineBody, dhat=5e-4, kappa=None, ground_height=0.001, resistance=10.0,
+                 edge_edge=True):
         self.pad, self.ball = pad, ball
+        self.edge_edge = bool(edge_edge)
         self.pad_tris = np.asarray(pad_tris, np.int64)
         self.pad_area = np.asarray(pad_area, np.float64)
         self.dhat = float(dhat)
@@ -192,6 +260,9 @@ class BallScene:
         self.dt = pad.dt
         self.V = len(pad.X)
         self.pad_sv = np.where(self.pad_area > 0)[0]
+        # edge-edge pairs (pad surface edge x ball edge): weight = the mean of the two edge areas; mollifier threshold 1e-3 |e_a|^2 |e_b|^2 (rest)
+        self.pad_edges, self.pad_earea, self.pad_elen2 = surface_edges(self.pad_tris, pad.X)
+        self.ball_edges, self.ball_earea, self.ball_elen2 = surface_edges(ball.tris, ball.X)
         # lagged Coulomb friction of every contact (Li et al. 2020, eq. 18-20; US:103-124 friction ratio 0.5, eps_velocity 0.01): off until
         # `mu` is set; the lag (normal force, normal, the pair's coefficients) is taken by step() at the state the step starts from
         self.mu, self.eps_v = 0.0, 0.01
@@ -209,8 +280,8 @@ class BallScene:
         return k * e, k * w * b1 / self.dhat, k * w * b2 / self.dhat**2, np.where(on, d, np.inf)
 
     def pairs(self, y):
-        """Every point-triangle pair closer than d_hat.  Returns a list of (kind, point index, triangle row, weight, d, n (3,), beta (3,))
-        arrays: kind 0 = pad vertex vs ball triangle, kind 1 = ball vertex vs pad triangle."""
+        """Every point-triangle pair closer than d_hat as [kind 0, kind 1] = (point index, triangle row, weight, d, n (3,), beta (3,)) arrays:
+        kind 0 = pad vertex vs ball triangle, kind 1 = ball vertex vs pad triangle; and, with edge_edge, the edge-edge pairs (below)."""
         xb = self.ball.points(y[self.V:])
         out = []
         bt, pt = self.ball.tris, self.pad_tris
@@ -220,23 +291,49 @@ class BallScene:
         beta, d, n = point_triangle(xb, y[pt[:, 0]], y[pt[:, 1]], y[pt[:, 2]])
         i, j = np.where(d < self.dhat)
         out.append((i, j, self.ball.area[i], d[i, j], n[i, j], beta[i, j]))
+        if self.edge_edge:  # third entry: (pad edge, ball edge, weight, d, n, s, t, m, m' grad c on (a0, a1, b0, b1) (K,4,3))
+            pe, be = self.pad_edges, self.ball_edges
+            a0, a1, b0, b1 = y[pe[:, 0]], y[pe[:, 1]], xb[be[:, 0]], xb[be[:, 1]]
+            s, t, d, n = segment_segment(a0, a1, b0, b1)
+            i, j = np.where(d < self.dhat)
+            e1, e2 = (a1 - a0)[i], (b1 - b0)[j]
+            u = np.cross(e1, e2)
+            m, dm = edge_mollifier((u * u).sum(-1), 1e-3 * self.pad_elen2[i] * self.ball_elen2[j])
+            ga, gb = 2.0 * np.cross(e2, u), 2.0 * np.cross(u, e1)
+            dc = dm[:, None, None] * np.stack([-ga, ga, -gb, gb], 1)
+            out.append((i, j, 0.5 * (self.pad_earea[i] + self.ball_earea[j]), d[i, j], n[i, j], s[i, j], t[i, j], m, dc))
         return out
 
     def _pair_rows(self, y):
         """The pairs as rank-one rows: for pair k a sparse gradient of its distance over the V + 4 state rows -
-        g_k = sum_r coef[k, r] * n_k at state row rows[k, r] (r < 8; unused slots have coef 0)."""
+        g_k = sum_r coef[k, r] * n_k at state row rows[k, r] (r < 8; unused slots have coef 0).  Returns (rows, coef, w, d, n, m, X): m the
+        mollifier of the pair (1 for point-triangle pairs), X = None or (pair index, rows (K,6), m'(c) grad c (K,6,3)) of the mollified pairs."""
         memo = getattr(self, "_rows_memo", None)  # (the PCG applies the operator hundreds of times at ONE state)
         if memo is not None and memo[0].shape == y.shape and np.array_equal(memo[0], y):
             return memo[1]
         V, Y, bt, pt = self.V, self.ball.Y, self.ball.tris, self.pad_tris
-        (pi, pj, pw, pd, pn, pb), (bi, bj, bw, bd, bn, bb) = self.pairs(y)
+        pr = self.pairs(y)
+        (pi, pj, pw, pd, pn, pb), (bi, bj, bw, bd, bn, bb) = pr[0], pr[1]
         # kind 0: +1 on the pad vertex, -(beta . Y[tri]) on the four ball rows
         r0 = np.concatenate([pi[:, None], np.broadcast_to(V + np.arange(4), (len(pi), 4)), np.zeros((len(pi), 3), np.int64)], 1)
         c0 = np.concatenate([np.ones((len(pi), 1)), -np.einsum("kj,kja->ka", pb, Y[bt[pj]]), np.zeros((len(pi), 3))], 1)
         # kind 1: +Y[b] on the four ball rows, -beta on the three pad vertices of the triangle
         r1 = np.concatenate([np.broadcast_to(V + np.arange(4), (len(bi), 4)), pt[bj], np.zeros((len(bi), 1), np.int64)], 1)
         c1 = np.concatenate([Y[bi], -bb, np.zeros((len(bi), 1))], 1)
-        out = (np.concatenate([r0, r1]), np.concatenate([c0, c1]), np.concatenate([pw, bw]), np.concatenate([pd, bd]), np.concatenate([pn, bn]))
+        R, C, W, D, N = [r0, r1], [c0, c1], [pw, bw], [pd, bd], [pn, bn]
+        M, X = [np.ones(len(pw) + len(bw))], None
+        if self.edge_edge:
+            ei, ej, ew, ed, en, es, et, em, dc = pr[2]
+            pe, be = self.pad_edges[ei], self.ball_edges[ej]
+            # kind 2: (1-s), s on the pad edge's end points, -((1-t) Y[b0] + t Y[b1]) on the four ball rows
+            r2 = np.concatenate([pe, np.broadcast_to(V + np.arange(4), (len(ei), 4)), np.zeros((len(ei), 2), np.int64)], 1)
+            c2 = np.concatenate([(1.0 - es)[:, None], es[:, None], -((1.0 - et)[:, None] * Y[be[:, 0]] + et[:, None] * Y[be[:, 1]]), np.zeros((len(ei), 2))], 1)
+            R.append(r2); C.append(c2); W.append(ew); D.append(ed); N.append(en); M.append(em)
+            lo = np.where(em < 1.0)[0]
+            if len(lo):  # the mollifier's own gradient m'(c) grad c, over the same six state rows (index into the full pair list)
+                gq = Y[be[lo, 0]][:, :, None] * dc[lo, 2][:, None, :] + Y[be[lo, 1]][:, :, None] * dc[lo, 3][:, None, :]  # (K,4,3)
+                X = (len(pw) + len(bw) + lo, r2[lo, :6], np.concatenate([dc[lo, :2], gq], 1))
+        out = (np.concatenate(R), np.concatenate(C), np.concatenate(W), np.concatenate(D), np.concatenate(N), np.concatenate(M), X)
         self._rows_memo = (y.copy(), out)
         return out
 
@@ -246,8 +343,8 @@ class BallScene:
         of its relative displacement (pairs: point minus closest point of the triangle, the barycentric weights frozen; ground: the vertex
         itself), the contact normal and the normal force lam = -kappa w b'(d / d_hat) / d_hat [N] - all frozen for the step (IPC's lag)."""
         V = self.V
-        rows, coef, w, d, n = self._pair_rows(y0)
-        lam = -self.kappa * w * barrier(d / self.dhat)[1] / self.dhat
+        rows, coef, w, d, n, mol, _ = self._pair_rows(y0)
+        lam = -self.kappa * w * mol * barrier(d / self.dhat)[1] / self.dhat
         R, C, N, Lm = [rows], [coef], [n], [lam]
         z = np.array([0.0, 0.0, 1.0])
         for (x, wt, ball) in ((y0[:V], self.pad_area, False), (self.ball.points(y0[V:]), self.ball.area, True)):
@@ -295,8 +392,8 @@ class BallScene:
         e = self.pad.energy(x, yt[:V], cons, aim) + 0.5 * np.einsum("ab,ai,bi->", self.ball.S, dq, dq) + self.dt**2 * self.ball.ortho(q)[0]
         e += self._ground(x, self.pad_area)[0] + self._ground(self.ball.points(q), self.ball.area)[0]
         k = self.dt**2 * self.kappa
-        for (_, _, w, d, _, _) in self.pairs(y):
-            e += k * (w * barrier(d / self.dhat)[0]).sum()
+        _, _, w, d, _, mol, _ = self._pair_rows(y)
+        e += k * (w * mol * barrier(d / self.dhat)[0]).sum()
         f = self._fric(y)
         if f is not None:
             e += self.dt**2 * self.mu * (f[2] * friction_f0(np.linalg.norm(f[3], axis=1), self.eps_v * self.dt)[0]).sum()
@@ -312,10 +409,15 @@ class BallScene:
         fb = np.zeros((len(self.ball.X), 3))
         fb[:, 2] = self._ground(self.ball.points(q), self.ball.area)[1]
         g[V:] += self.ball.to_q(fb)
-        rows, coef, w, d, n = self._pair_rows(y)
-        s = self.dt**2 * self.kappa * w * barrier(d / self.dhat)[1] / self.dhat
+        rows, coef, w, d, n, mol, X = self._pair_rows(y)
+        s = self.dt**2 * self.kappa * w * mol * barrier(d / self.dhat)[1] / self.dhat
         for r in range(8):
             np.add.at(g, rows[:, r], (s * coef[:, r])[:, None] * n)
+        if X is not None:
+            k, xr, xv = X
+            sb = self.dt**2 * self.kappa * w[k] * barrier(d[k] / self.dhat)[0]
+            for r in range(6):
+                np.add.at(g, xr[:, r], sb[:, None] * xv[:, r])
         f = self._fric(y)
         if f is not None:
             frows, fcoef, lam, u, _ = f
@@ -335,8 +437,8 @@ class BallScene:
         fb = np.zeros((len(self.ball.X), 3))
         fb[:, 2] = cb * (self.ball.Y @ p[V:])[:, 2]
         out[V:] += self.ball.to_q(fb)
-        rows, coef, w, d, n = self._pair_rows(y)
-        wk = self.dt**2 * self.kappa * w * barrier(d / self.dhat)[2] / self.dhat**2
+        rows, coef, w, d, n, mol, _ = self._pair_rows(y)
+        wk = self.dt**2 * self.kappa * w * mol * barrier(d / self.dhat)[2] / self.dhat**2
         gp = np.zeros(len(w))
         for r in range(8):
             gp += coef[:, r] * (n * p[rows[:, r]]).sum(-1)
@@ -364,8 +466,8 @@ class BallScene:
         D[:V, 2, 2] += self._ground(x, self.pad_area)[2]
         cb = self._ground(self.ball.points(q), self.ball.area)[2]
         D[V:, 2, 2] += (cb[:, None] * self.ball.Y**2).sum(0)
-        rows, coef, w, d, n = self._pair_rows(y)
-        wk = self.dt**2 * self.kappa * w * barrier(d / self.dhat)[2] / self.dhat**2
+        rows, coef, w, d, n, mol, _ = self._pair_rows(y)
+        wk = self.dt**2 * self.kappa * w * mol * barrier(d / self.dhat)[2] / self.dhat**2
         nn = n[:, :, None] * n[:, None, :]
         for r in range(8):
             np.add.at(D, rows[:, r], (wk * coef[:, r] ** 2)[:, None, None] * nn)
@@ -397,8 +499,8 @@ class BallScene:
         for a in range(4):
             for b in range(4):
                 B[3 * a + 2, 3 * b + 2] += YY[a, b]
-        rows, coef, w, d, n = self._pair_rows(y)
-        wk = self.dt**2 * self.kappa * w * barrier(d / self.dhat)[2] / self.dhat**2
+        rows, coef, w, d, n, mol, _ = self._pair_rows(y)
+        wk = self.dt**2 * self.kappa * w * mol * barrier(d / self.dhat)[2] / self.dhat**2
         cq = np.zeros((len(w), 4))
         for r in range(8):
             on = rows[:, r] >= V
@@ -460,6 +562,11 @@ class BallScene:
             _, d, _ = point_triangle(P, T0[tri[:, 0]], T0[tri[:, 1]], T0[tri[:, 2]])
             for i, j in zip(*np.where(d < R)):
                 a = min(a, accd_point_triangle(P[i], T0[tri[j]], dP[i], dT0[tri[j]], a, slack, keep, max_iter))
+        if self.edge_edge:
+            pe, be = self.pad_edges, self.ball_edges
+            _, _, d, _ = segment_segment(y[pe[:, 0]], y[pe[:, 1]], xb[be[:, 0]], xb[be[:, 1]])
+            for i, j in zip(*np.where(d < R)):
+                a = min(a, accd_edge_edge(y[pe[i]], xb[be[j]], dy[pe[i]], db[be[j]], a, slack, keep, max_iter))
         return a
 
     # ---- one Newton iteration / one time step (the algorithm of fem_ball_newton_kernel) ------------------------------------------

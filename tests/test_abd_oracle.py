@@ -163,7 +163,8 @@ def test_pair_forces_are_action_and_reaction():
     """The pair energy is invariant under a common translation of pad and ball: the pair forces on the pad vertices and on the ball's
     translation p sum to zero (the rows of every pair's distance gradient sum to zero)."""
     sc, y, cons = _scene()
-    rows, coef, w, d, n = sc._pair_rows(y)
+    rows, coef, w, d, n, mol, _ = sc._pair_rows(y)
+    assert (mol[len(w) - len(sc.pairs(y)[2][0]):] <= 1.0).all() and len(sc.pairs(y)[2][0]) > 0  # edge-edge pairs are in the list
     tr = np.zeros(len(w))
     for r in range(8):
         on_p_or_pad = (rows[:, r] < sc.V) | (rows[:, r] == sc.V)
@@ -218,7 +219,7 @@ def test_pressed_pad_converges_to_a_stationary_point_without_penetration():
             if st[4] < 1e-9 and st[5] < 1e-7:
                 break
         assert it < 24, (k, st)
-        (pi, pj, pw, pd, pn, pb), (bi, bj, bw, bd, bn, bb) = sc.pairs(y)
+        (pi, pj, pw, pd, pn, pb), (bi, bj, bw, bd, bn, bb) = sc.pairs(y)[:2]
         w, d = np.concatenate([pw, bw]), np.concatenate([pd, bd])
         assert len(d) > 0 and d.min() > 0
         scale = sc.dt**2 * sc.kappa * np.abs(w * barrier(d / sc.dhat)[1] / sc.dhat).max()
@@ -317,3 +318,92 @@ def test_friction_keeps_the_light_ball_from_rolling_away():
         res[mu] = (its, np.abs(y[V + 1:] - np.eye(3)).max())
     assert max(res[0.5][0]) <= 6 and res[0.5][1] < 0.02, res
     assert max(res[0.0][0]) == 40, res  # (the frictionless ball is what runs into the cap)
+
+
+def test_segment_segment_regions_and_derivatives():
+    """Distance of two segments in all nine parameter regions; its gradient on the four end points is the envelope formula."""
+    from oracle.abd_oracle import segment_segment
+    rng = np.random.default_rng(3)
+    seen = set()
+    h = 1e-7
+    for _ in range(300):
+        P = rng.uniform(-1.0, 1.0, (4, 3))
+        s, t, d, n = segment_segment(P[0:1], P[1:2], P[2:3], P[3:4])
+        s, t, d, n = s[0, 0], t[0, 0], d[0, 0], n[0, 0]
+        # brute force over a grid of both parameters bounds the minimum from above
+        ss, tt = np.meshgrid(np.linspace(0, 1, 41), np.linspace(0, 1, 41), indexing="ij")
+        dd = np.linalg.norm((P[0] + ss[..., None] * (P[1] - P[0])) - (P[2] + tt[..., None] * (P[3] - P[2])), axis=-1)
+        assert d <= dd.min() + 1e-12 and d >= dd.min() - 0.05
+        seen.add((0 if s <= 0 else 2 if s >= 1 else 1, 0 if t <= 0 else 2 if t >= 1 else 1))
+        if min(abs(s), abs(1 - s), abs(t), abs(1 - t)) < 1e-4 and 0 < s < 1 and 0 < t < 1:
+            continue
+        coef = [(1 - s), s, -(1 - t), -t]
+        for k in range(4):
+            for i in range(3):
+                Pp, Pm = P.copy(), P.copy()
+                Pp[k, i] += h; Pm[k, i] -= h
+                fd = (segment_segment(Pp[0:1], Pp[1:2], Pp[2:3], Pp[3:4])[2][0, 0] - segment_segment(Pm[0:1], Pm[1:2], Pm[2:3], Pm[3:4])[2][0, 0]) / (2 * h)
+                assert abs(fd - coef[k] * n[i]) < 2e-6, (k, i, s, t)
+    assert len(seen) >= 8  # interior-interior, the four edges of the parameter square, corners
+
+
+def test_parallel_segments_have_a_finite_distance():
+    from oracle.abd_oracle import segment_segment
+    a0, a1 = np.array([[0.0, 0, 0]]), np.array([[1.0, 0, 0]])
+    b0, b1 = np.array([[0.2, 0, 0.3]]), np.array([[0.7, 0, 0.3]])
+    s, t, d, n = segment_segment(a0, a1, b0, b1)
+    assert d[0, 0] == pytest.approx(0.3) and np.allclose(n[0, 0], [0, 0, -1.0])
+
+
+def test_edge_edge_pairs_energy_gradient_match_finite_differences():
+    """The scene with edge-edge pairs: (i) they exist at the usual press; (ii) gradient = FD of the energy on rows an edge-edge pair touches;
+    (iii) a pad edge turned parallel to a ball edge is mollified (m < 1) and the mollifier's own gradient term is in the gradient."""
+    sc, y, cons = _scene(press=3.5e-4)
+    ee = sc.pairs(y)[2]
+    assert len(ee[0]) > 0 and (ee[7] <= 1.0).all()
+    yt = y + 1e-5
+    g = sc.gradient(y, yt, cons, y[: sc.V])
+    rows = sorted({int(r) for r in sc.pad_edges[ee[0]].reshape(-1)})[:6] + [sc.V, sc.V + 2]
+    h = 1e-9
+    for r in rows:
+        for i in range(3):
+            yp, ym = y.copy(), y.copy()
+            yp[r, i] += h; ym[r, i] -= h
+            fd = (sc.energy(yp, yt, cons, y[: sc.V]) - sc.energy(ym, yt, cons, y[: sc.V])) / (2 * h)
+            assert abs(fd - g[r, i]) <= 2e-5 * max(abs(g[r, i]), np.abs(g).max() * 1e-3), (r, i, fd, g[r, i])
+    # (iii) lay one close pad edge nearly parallel over its partner ball edge, 0.4 d_hat away along the pair's normal
+    k = int(np.argmin(ee[3]))
+    pe, be = sc.pad_edges[ee[0][k]], sc.ball_edges[ee[1][k]]
+    xb = sc.ball.points(y[sc.V:])
+    e2 = xb[be[1]] - xb[be[0]]
+    u2 = e2 / np.linalg.norm(e2)
+    nn = ee[4][k] - (ee[4][k] @ u2) * u2
+    nn /= np.linalg.norm(nn)
+    mid = xb[be[0]] + 0.5 * e2 + 0.4 * sc.dhat * nn
+    L = np.linalg.norm(y[pe[1]] - y[pe[0]])
+    skew = 0.01 * L * np.cross(u2, nn)
+    y2 = y.copy()
+    y2[pe[0]] = mid - 0.3 * L * u2 - skew
+    y2[pe[1]] = mid + 0.3 * L * u2 + skew
+    _, _, w, d, _, mol, X = sc._pair_rows(y2)
+    assert X is not None and (mol < 1.0).any() and d.min() > 1e-5
+    g2 = sc.gradient(y2, yt, cons, y[: sc.V])
+    for r in (int(pe[0]), int(pe[1]), sc.V + 1):
+        for i in range(3):
+            yp, ym = y2.copy(), y2.copy()
+            yp[r, i] += h; ym[r, i] -= h
+            fd = (sc.energy(yp, yt, cons, y[: sc.V]) - sc.energy(ym, yt, cons, y[: sc.V])) / (2 * h)
+            assert abs(fd - g2[r, i]) <= 1e-4 * max(abs(g2[r, i]), np.abs(g2).max() * 1e-3), (r, i, fd, g2[r, i])
+
+
+def test_accd_edge_edge_is_conservative():
+    from oracle.abd_oracle import accd_edge_edge, segment_segment
+    ea = np.array([[0.0, 0, 0], [1.0, 0, 0]])
+    eb = np.array([[0.5, -0.5, 0.2], [0.5, 0.5, 0.2]])
+    dea = np.zeros((2, 3))
+    deb = np.array([[0.0, 0, -1.0], [0.0, 0, -1.0]])  # b falls onto a: impact at t = 0.2
+    t = accd_edge_edge(ea, eb, dea, deb, 1.0)
+    assert 0.17 < t < 0.2
+    d = segment_segment(ea[0:1], ea[1:2], (eb[0] + t * deb[0])[None], (eb[1] + t * deb[1])[None])[2][0, 0]
+    assert d >= 0.1 * 0.2 - 1e-12
+    assert accd_edge_edge(ea, eb, dea, np.array([[1.0, 0, 0], [1.0, 0, 0]]), 1.0) == 1.0  # sliding keeps the gap
