@@ -32,7 +32,7 @@ extern "C" {
 #endif
 
 #define TACEX_MAX_LEVELS 8
-#define TACEX_ABI_VERSION 12
+#define TACEX_ABI_VERSION 13
 
 typedef struct tacex_taxim_ctx tacex_taxim_ctx;
 typedef struct tacex_fots_ctx tacex_fots_ctx;
@@ -499,7 +499,10 @@ int tacex_fem_step(tacex_fem_ctx* ctx, double* x_dev, double* v_dev, double* x_t
  * ball vertex / pad triangle, ground against the surface vertices of both bodies), additive CCD on the pairs, and lagged Coulomb
  * friction of EVERY contact (pairs of both kinds and ground contacts of both bodies; ratio and stick tolerance from tacex_fem_set_friction,
  * US:103-124: the contacts of the state the step starts from are frozen - normal force, normal, barycentric weights - and slide
- * relative to it, Li et al. 2020 section 5.4).  No edge-edge pairs between the two bodies yet.
+ * relative to it, Li et al. 2020 section 5.4).  EDGE-EDGE pairs (every pad surface edge against every ball edge closer than d_hat:
+ * segment-segment distance, weight = the mean of the two edges' areas, IPC's mollifier m(|e_a x e_b|^2) with threshold
+ * 1e-3 |e_a|^2 |e_b|^2 at rest, Li et al. 2020 eq. 24) complete IPC's contact set; tacex_fem_set_edge_edge(ctx, 0) switches that pair kind
+ * off (on after tacex_fem_set_affine_body).
  *
  * tacex_fem_set_affine_body: ONE body per env, the same mesh for all envs.  verts_host (num_verts,3) f64 in the body frame, tris_host
  * (num_tris,3) outward oriented; density [kg/m^3]; kappa [Pa] (m_kappa * 1e6); pad_vertex_area_host (V) contact weights of the gelpad's
@@ -520,6 +523,7 @@ int tacex_fem_step(tacex_fem_ctx* ctx, double* x_dev, double* v_dev, double* x_t
 int tacex_fem_set_affine_body(tacex_fem_ctx* ctx, int num_verts, const double* verts_host, int num_tris, const int32_t* tris_host, double density,
                               double kappa, const double* pad_vertex_area_host, int num_pad_tris, const int32_t* pad_tris_host, double d_hat,
                               double stiffness, double ground_height, int enable_ground, int kinematic);
+int tacex_fem_set_edge_edge(tacex_fem_ctx* ctx, int enable);
 size_t tacex_fem_ball_workspace_bytes(const tacex_fem_ctx* ctx, int num_envs);
 int tacex_fem_ball_moments(const tacex_fem_ctx* ctx, double moments_out[16], double* kappa_vol_out);
 int tacex_fem_ball_terms(tacex_fem_ctx* ctx, const double* x_dev, const double* x_tilde_dev, const double* q_dev, const double* q_tilde_dev,

@@ -309,7 +309,7 @@ class BallScene:
         g_k = sum_r coef[k, r] * n_k at state row rows[k, r] (r < 8; unused slots have coef 0).  Returns (rows, coef, w, d, n, m, X): m the
         mollifier of the pair (1 for point-triangle pairs), X = None or (pair index, rows (K,6), m'(c) grad c (K,6,3)) of the mollified pairs."""
         memo = getattr(self, "_rows_memo", None)  # (the PCG applies the operator hundreds of times at ONE state)
-        if memo is not None and memo[0].shape == y.shape and np.array_equal(memo[0], y):
+        if memo is not None and memo[2] == self.edge_edge and memo[0].shape == y.shape and np.array_equal(memo[0], y):
             return memo[1]
         V, Y, bt, pt = self.V, self.ball.Y, self.ball.tris, self.pad_tris
         pr = self.pairs(y)
@@ -334,7 +334,7 @@ class BallScene:
                 gq = Y[be[lo, 0]][:, :, None] * dc[lo, 2][:, None, :] + Y[be[lo, 1]][:, :, None] * dc[lo, 3][:, None, :]  # (K,4,3)
                 X = (len(pw) + len(bw) + lo, r2[lo, :6], np.concatenate([dc[lo, :2], gq], 1))
         out = (np.concatenate(R), np.concatenate(C), np.concatenate(W), np.concatenate(D), np.concatenate(N), np.concatenate(M), X)
-        self._rows_memo = (y.copy(), out)
+        self._rows_memo = (y.copy(), out, self.edge_edge)
         return out
 
     # ---- lagged friction ---------------------------------------------------------------------------------------------------------

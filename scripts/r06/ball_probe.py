@@ -2,7 +2,13 @@
 import sys, time, torch
 from tacex_amd.uipc.gelpad_scene import FemBallScene
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
-sc = FemBallScene(B, "cuda:0", max_newton_iter=64)
+import os
+from tacex_amd.uipc.uipc_sim import UipcSimCfg
+cfg = None
+if os.environ.get("TACEX_BALL_EDGE_EDGE") == "0":  # A/B: point-triangle pairs alone
+    cfg = UipcSimCfg(device="cuda:0")
+    cfg.contact.edge_edge = False
+sc = FemBallScene(B, "cuda:0", max_newton_iter=64, cfg=cfg)
 for i in range(30):
     torch.cuda.synchronize(); t0 = time.perf_counter()
     sc.step(i)

@@ -32,6 +32,15 @@ struct BallDev {
   const double* parea = nullptr;  // (V) pad vertex areas (0: interior)
   double S[16] = {};              // 4 x 4 moment matrix
   double kv = 0.0, gh = 0.0, dhat = 0.0, kappa = 0.0;
+  // edge-edge pairs: pad surface edges x ball edges (unique edges of the two triangle lists), the area each edge stands for (a third of its
+  // triangles' rest areas) and its squared rest length (the mollifier's threshold); ee = 0 switches the pair kind off
+  int npe = 0, nbe = 0, ee = 0;
+  const int* pedge = nullptr;      // (npe,2)
+  const double* pearea = nullptr;  // (npe)
+  const double* pelen2 = nullptr;  // (npe)
+  const int* bedge = nullptr;      // (nbe,2)
+  const double* bearea = nullptr;  // (nbe)
+  const double* belen2 = nullptr;  // (nbe)
   int ground = 0;
   int kinematic = 0;  // AffineBodyConstitutionCfg.kinematic (uipc_object.py:70-73, 463-466: `is_fixed`): the body's rows are not unknowns - the
                       // caller moves q between steps, the pad sees it through the pairs (both ways) and their friction
@@ -116,6 +125,67 @@ __device__ double accd_pt(const double p[3], const double tr[9], const double dp
   return t;
 }
 
+// closest points of segments a0-a1 and b0-b1 (Ericson 5.1.9 - oracle/abd_oracle.py segment_segment): parameters, distance, unit vector from
+// the point on b to the point on a; the distance's gradient is (1-s) n, s n on a's end points and -(1-t) n, -t n on b's
+__device__ __forceinline__ void ee_closest(const double a0[3], const double a1[3], const double b0[3], const double b1[3], double& s, double& t, double& d,
+                                           double n[3]) {
+  const double d1[3] = {a1[0] - a0[0], a1[1] - a0[1], a1[2] - a0[2]}, d2[3] = {b1[0] - b0[0], b1[1] - b0[1], b1[2] - b0[2]};
+  const double r[3] = {a0[0] - b0[0], a0[1] - b0[1], a0[2] - b0[2]};
+  const double a = d1[0] * d1[0] + d1[1] * d1[1] + d1[2] * d1[2], e = d2[0] * d2[0] + d2[1] * d2[1] + d2[2] * d2[2];
+  const double f = d2[0] * r[0] + d2[1] * r[1] + d2[2] * r[2], c = d1[0] * r[0] + d1[1] * r[1] + d1[2] * r[2];
+  const double bq = d1[0] * d2[0] + d1[1] * d2[1] + d1[2] * d2[2];
+  const double den = a * e - bq * bq;
+  s = den > 0.0 ? fmin(fmax((bq * f - c * e) / den, 0.0), 1.0) : 0.0;
+  t = (bq * s + f) / e;
+  if (t < 0.0) { t = 0.0; s = fmin(fmax(-c / a, 0.0), 1.0); }
+  else if (t > 1.0) { t = 1.0; s = fmin(fmax((bq - c) / a, 0.0), 1.0); }
+  const double w0 = r[0] + s * d1[0] - t * d2[0], w1 = r[1] + s * d1[1] - t * d2[1], w2 = r[2] + s * d1[2] - t * d2[2];
+  d = sqrt(w0 * w0 + w1 * w1 + w2 * w2);
+  const double id = d > 0.0 ? 1.0 / d : 0.0;
+  n[0] = w0 * id; n[1] = w1 * id; n[2] = w2 * id;
+}
+
+// IPC's mollifier of nearly parallel edge pairs in c = |e_a x e_b|^2 (Li et al. 2020 eq. 24 - oracle edge_mollifier): m, dm/dc; u = e_a x e_b
+__device__ __forceinline__ void ee_mollifier(const double a0[3], const double a1[3], const double b0[3], const double b1[3], double eps, double& mol, double& dm,
+                                             double e1[3], double e2[3], double u[3]) {
+#pragma unroll
+  for (int i = 0; i < 3; ++i) { e1[i] = a1[i] - a0[i]; e2[i] = b1[i] - b0[i]; }
+  u[0] = e1[1] * e2[2] - e1[2] * e2[1]; u[1] = e1[2] * e2[0] - e1[0] * e2[2]; u[2] = e1[0] * e2[1] - e1[1] * e2[0];
+  const double r = (u[0] * u[0] + u[1] * u[1] + u[2] * u[2]) / eps;
+  if (r < 1.0) { mol = (2.0 - r) * r; dm = 2.0 * (1.0 - r) / eps; }
+  else { mol = 1.0; dm = 0.0; }
+}
+
+// additive CCD of one edge-edge pair (oracle accd_edge_edge); ea, eb, dea, deb: the two end points of each edge, row-major (2,3)
+__device__ double accd_ee(const double ea[6], const double eb[6], const double dea_in[6], const double deb_in[6], double t_max) {
+  double da[6], db[6], mean[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) mean[i] = (dea_in[i] + dea_in[3 + i] + deb_in[i] + deb_in[3 + i]) * 0.25;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) { da[i] = dea_in[i] - mean[i]; da[3 + i] = dea_in[3 + i] - mean[i]; db[i] = deb_in[i] - mean[i]; db[3 + i] = deb_in[3 + i] - mean[i]; }
+  const double la = fmax(sqrt(da[0] * da[0] + da[1] * da[1] + da[2] * da[2]), sqrt(da[3] * da[3] + da[4] * da[4] + da[5] * da[5]));
+  const double lb = fmax(sqrt(db[0] * db[0] + db[1] * db[1] + db[2] * db[2]), sqrt(db[3] * db[3] + db[4] * db[4] + db[5] * db[5]));
+  const double l = la + lb;
+  if (!(l > 0.0)) return t_max;
+  auto dist = [&](double t) {
+    double a0[3], a1[3], b0[3], b1[3], s, u, d, n[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { a0[i] = ea[i] + t * da[i]; a1[i] = ea[3 + i] + t * da[3 + i]; b0[i] = eb[i] + t * db[i]; b1[i] = eb[3 + i] + t * db[3 + i]; }
+    ee_closest(a0, a1, b0, b1, s, u, d, n);
+    return d;
+  };
+  const double d0 = dist(0.0), g = kBallKeep * d0;
+  double t = 0.0, tl = (1.0 - kBallKeep) * d0 / l;
+  for (int it = 0; it < 64; ++it) {
+    const double d = dist(t + tl);
+    if (t > 0.0 && d < g) break;
+    t += tl;
+    if (t >= t_max) return t_max;
+    tl = kCcdSlack * d / l;
+  }
+  return t;
+}
+
 __device__ __forceinline__ void barrier3(double s, double& b, double& b1, double& b2) {  // b(s), b'(s), b''(s) of the dimensionless barrier
   if (!(s > 0.0)) { b = INFINITY; b1 = 0.0; b2 = 0.0; return; }
   if (s >= 1.0) { b = 0.0; b1 = 0.0; b2 = 0.0; return; }
@@ -139,8 +209,8 @@ __global__ __launch_bounds__(512, TACEX_BALL_WG_PER_CU) void fem_ball_newton_ker
   __shared__ double gb[12], Bm[144], B0[144], Lc[144], Bi[144], YY[16], qs[12], qts[12], rhs12[12];
   __shared__ double crc[3 * kFemMaxCoarse], cyc[3 * kFemMaxCoarse];  // coarse residual / correction of the two-level preconditioner
   __shared__ double qps[12], Hpq[12], zq[12];  // ... | the ball rows of H.p and of z  // the ball rows the time step started from (friction slides relative to them)
-  __shared__ int n_cpv, n_cpt, n_cbv, n_pairs, n_act, n_fric, s_flags;
-  __shared__ int cpv[kBallMaxCand], cpt[kBallMaxCand], cbv[kBallMaxCand];
+  __shared__ int n_cpv, n_cpt, n_cpe, n_pairs, n_act, n_fric, s_flags;
+  __shared__ int cpv[kBallMaxCand], cpt[kBallMaxCand], cpe[kBallMaxCand];
   // env_order: envs sorted by the solver work of their previous step, heaviest first (fem_env_order_kernel): a shard brings two envs
   // per CU, the launch ends with whatever the last-started ones need
   const int b = env_order ? env_order[blockIdx.x] : (int)blockIdx.x;
@@ -281,24 +351,37 @@ __global__ __launch_bounds__(512, TACEX_BALL_WG_PER_CU) void fem_ball_newton_ker
     }
     const int np = n_pairs;
     for (int k = tid; k < np; k += NT) {
-      const int code = plist[k], kind = code >> 30, pi = (code >> 15) & 0x7fff, tj = code & 0x7fff;
-      double p3[3], a[3], bq[3], c[3], be[3], d, n[3], w;
-      if (kind == 0) {
-        const int* tr = bd.tri + tj * 3;
+      const unsigned code = (unsigned)plist[k];
+      const int kind = (int)(code >> 30), pi = (int)((code >> 15) & 0x7fff), tj = (int)(code & 0x7fff);
+      double d, w;
+      if (kind == 2) {
+        const int* ea = bd.pedge + pi * 2;
+        const int* eb = bd.bedge + tj * 2;
+        double a0[3], a1[3], b0[3], b1[3], s, t, n[3], mol, dm, e1[3], e2[3], u[3];
 #pragma unroll
-        for (int i = 0; i < 3; ++i) { p3[i] = xx[pi * 3 + i]; a[i] = xbb[tr[0] * 3 + i]; bq[i] = xbb[tr[1] * 3 + i]; c[i] = xbb[tr[2] * 3 + i]; }
-        w = bd.parea[pi];
+        for (int i = 0; i < 3; ++i) { a0[i] = xx[ea[0] * 3 + i]; a1[i] = xx[ea[1] * 3 + i]; b0[i] = xbb[eb[0] * 3 + i]; b1[i] = xbb[eb[1] * 3 + i]; }
+        ee_closest(a0, a1, b0, b1, s, t, d, n);
+        ee_mollifier(a0, a1, b0, b1, 1e-3 * bd.pelen2[pi] * bd.belen2[tj], mol, dm, e1, e2, u);
+        w = 0.5 * (bd.pearea[pi] + bd.bearea[tj]) * mol;
       } else {
-        const int* tr = bd.ptri + tj * 3;
+        double p3[3], a[3], bq[3], c[3], be[3], n[3];
+        if (kind == 0) {
+          const int* tr = bd.tri + tj * 3;
 #pragma unroll
-        for (int i = 0; i < 3; ++i) { p3[i] = xbb[pi * 3 + i]; a[i] = xx[tr[0] * 3 + i]; bq[i] = xx[tr[1] * 3 + i]; c[i] = xx[tr[2] * 3 + i]; }
-        w = bd.area[pi];
+          for (int i = 0; i < 3; ++i) { p3[i] = xx[pi * 3 + i]; a[i] = xbb[tr[0] * 3 + i]; bq[i] = xbb[tr[1] * 3 + i]; c[i] = xbb[tr[2] * 3 + i]; }
+          w = bd.parea[pi];
+        } else {
+          const int* tr = bd.ptri + tj * 3;
+#pragma unroll
+          for (int i = 0; i < 3; ++i) { p3[i] = xbb[pi * 3 + i]; a[i] = xx[tr[0] * 3 + i]; bq[i] = xx[tr[1] * 3 + i]; c[i] = xx[tr[2] * 3 + i]; }
+          w = bd.area[pi];
+        }
+        pt_closest(p3, a, bq, c, be, d, n);
       }
-      pt_closest(p3, a, bq, c, be, d, n);
       if (d < dhat) {
         double bb, b1, b2;
         barrier3(d / dhat, bb, b1, b2);
-        e += kk * w * bb;
+        if (w > 0.0) e += kk * w * bb;  // (w = 0: an exactly parallel edge pair - mollified away, whatever its distance)
       }
     }
     if (fric) {
@@ -460,7 +543,7 @@ __global__ __launch_bounds__(512, TACEX_BALL_WG_PER_CU) void fem_ball_newton_ker
       bts[t * 4] = c3[0]; bts[t * 4 + 1] = c3[1]; bts[t * 4 + 2] = c3[2]; bts[t * 4 + 3] = rt;
     }
     BALL_TICK(0);  // element pass, ball triangle spheres
-    if (tid == 0) { n_cpv = 0; n_cpt = 0; n_cbv = 0; n_pairs = 0; n_act = 0; }
+    if (tid == 0) { n_cpv = 0; n_cpt = 0; n_cpe = 0; n_pairs = 0; n_act = 0; }
     if (tid < 12) gb[tid] = 0.0;
     if (tid < 16) YY[tid] = 0.0;
     if (tid < 144) Bm[tid] = 0.0;
@@ -493,9 +576,24 @@ __global__ __launch_bounds__(512, TACEX_BALL_WG_PER_CU) void fem_ball_newton_ker
         if (s < kBallMaxCand) cpt[s] = k;
       }
     }
+    if (bd.ee)
+      for (int k = tid; k < bd.npe; k += NT) {
+        const int* ed = bd.pedge + k * 2;
+        double r2 = 0.0, h2 = 0.0;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+          const double mi = 0.5 * (x[ed[0] * 3 + i] + x[ed[1] * 3 + i]) - qs[i], hi = 0.5 * (x[ed[1] * 3 + i] - x[ed[0] * 3 + i]);
+          r2 += mi * mi; h2 += hi * hi;
+        }
+        const double lim = rb + L + sqrt(h2);
+        if (r2 < lim * lim) {
+          const int s = atomicAdd(&n_cpe, 1);
+          if (s < kBallMaxCand) cpe[s] = k;
+        }
+      }
     __syncthreads();
-    if (n_cpv > kBallMaxCand || n_cpt > kBallMaxCand) { if (tid == 0) s_flags |= kBallFlagOverflow; }
-    const int ncpv = min(n_cpv, kBallMaxCand), ncpt = min(n_cpt, kBallMaxCand);
+    if (n_cpv > kBallMaxCand || n_cpt > kBallMaxCand || n_cpe > kBallMaxCand) { if (tid == 0) s_flags |= kBallFlagOverflow; }
+    const int ncpv = min(n_cpv, kBallMaxCand), ncpt = min(n_cpt, kBallMaxCand), ncpe = min(n_cpe, kBallMaxCand);
     // ball vertices near the candidate pad triangles: within L of the union of their bounding spheres - one sphere around all of them
     // would do as well; here: within reach of the pad's candidate region = distance to p's far side is what the triangle test used, so
     // every ball vertex is tested against the candidate triangles' spheres directly (nv x ncpt sphere tests)
@@ -532,6 +630,28 @@ __global__ __launch_bounds__(512, TACEX_BALL_WG_PER_CU) void fem_ball_newton_ker
       if (d < L) {
         const int s = atomicAdd(&n_pairs, 1);
         if (s < kBallMaxPairs) plist[s] = (1 << 30) | (bv << 15) | t;
+      }
+    }
+    // pairs, kind 2: candidate pad edge x ball edge
+    for (int k = tid; k < ncpe * bd.nbe; k += NT) {
+      const int pe = cpe[k / bd.nbe], be_ = k - (k / bd.nbe) * bd.nbe;
+      const int* ea = bd.pedge + pe * 2;
+      const int* eb = bd.bedge + be_ * 2;
+      double a0[3], a1[3], b0[3], b1[3];
+      double r2 = 0.0, ha = 0.0, hb = 0.0;
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        a0[i] = x[ea[0] * 3 + i]; a1[i] = x[ea[1] * 3 + i]; b0[i] = xb[eb[0] * 3 + i]; b1[i] = xb[eb[1] * 3 + i];
+        const double mi = 0.5 * ((a0[i] + a1[i]) - (b0[i] + b1[i])), hai = 0.5 * (a1[i] - a0[i]), hbi = 0.5 * (b1[i] - b0[i]);
+        r2 += mi * mi; ha += hai * hai; hb += hbi * hbi;
+      }
+      const double lim = L + sqrt(ha) + sqrt(hb);
+      if (r2 >= lim * lim) continue;
+      double sa, tb, d, n[3];
+      ee_closest(a0, a1, b0, b1, sa, tb, d, n);
+      if (d < L) {
+        const int s = atomicAdd(&n_pairs, 1);
+        if (s < kBallMaxPairs) plist[s] = (int)((2u << 30) | ((unsigned)pe << 15) | (unsigned)be_);
       }
     }
     __syncthreads();
@@ -614,35 +734,75 @@ __global__ __launch_bounds__(512, TACEX_BALL_WG_PER_CU) void fem_ball_newton_ker
     {
       const int np = n_pairs;
       for (int k = tid; k < np; k += NT) {
-        const int code = plist[k], kind = code >> 30, pi = (code >> 15) & 0x7fff, tj = code & 0x7fff;
-        const int* tr = (kind == 0 ? bd.tri : bd.ptri) + tj * 3;
-        const int t0 = tr[0], t1 = tr[1], t2 = tr[2];
-        double p3[3], a[3], bq[3], c[3], be[3], d, n[3], w;
-        if (kind == 0) {
+        const unsigned code = (unsigned)plist[k];
+        const int kind = (int)(code >> 30), pi = (int)((code >> 15) & 0x7fff), tj = (int)(code & 0x7fff);
+        double d, n[3], w, cq[4], pco[3];
+        int prow[3];
+        double molg = 0.0, ga[3] = {0.0, 0.0, 0.0}, gbq[3] = {0.0, 0.0, 0.0}, yd[4] = {0.0, 0.0, 0.0, 0.0};  // mollifier's own gradient (edge-edge pairs below the threshold)
+        if (kind == 2) {
+          const int* ea = bd.pedge + pi * 2;
+          const int* eb = bd.bedge + tj * 2;
+          double a0[3], a1[3], b0[3], b1[3], sa, tb, mol, dm, e1[3], e2[3], u[3];
 #pragma unroll
-          for (int i = 0; i < 3; ++i) { p3[i] = x[pi * 3 + i]; a[i] = xb[t0 * 3 + i]; bq[i] = xb[t1 * 3 + i]; c[i] = xb[t2 * 3 + i]; }
-          w = bd.parea[pi];
+          for (int i = 0; i < 3; ++i) { a0[i] = x[ea[0] * 3 + i]; a1[i] = x[ea[1] * 3 + i]; b0[i] = xb[eb[0] * 3 + i]; b1[i] = xb[eb[1] * 3 + i]; }
+          ee_closest(a0, a1, b0, b1, sa, tb, d, n);
+          if (!(d < dhat)) continue;
+          ee_mollifier(a0, a1, b0, b1, 1e-3 * bd.pelen2[pi] * bd.belen2[tj], mol, dm, e1, e2, u);
+          const double w0 = 0.5 * (bd.pearea[pi] + bd.bearea[tj]);
+          w = w0 * mol;
+#pragma unroll
+          for (int a4 = 0; a4 < 4; ++a4) {
+            cq[a4] = -((1.0 - tb) * bd.Y[eb[0] * 4 + a4] + tb * bd.Y[eb[1] * 4 + a4]);
+            yd[a4] = bd.Y[eb[1] * 4 + a4] - bd.Y[eb[0] * 4 + a4];
+          }
+          prow[0] = ea[0]; prow[1] = ea[1]; prow[2] = -1;
+          pco[0] = 1.0 - sa; pco[1] = sa; pco[2] = 0.0;
+          if (dm > 0.0) {  // grad c = 2 (e2 x u) on a1 (minus on a0), 2 (u x e1) on b1 (minus on b0)
+            molg = w0 * dm;
+            ga[0] = 2.0 * (e2[1] * u[2] - e2[2] * u[1]); ga[1] = 2.0 * (e2[2] * u[0] - e2[0] * u[2]); ga[2] = 2.0 * (e2[0] * u[1] - e2[1] * u[0]);
+            gbq[0] = 2.0 * (u[1] * e1[2] - u[2] * e1[1]); gbq[1] = 2.0 * (u[2] * e1[0] - u[0] * e1[2]); gbq[2] = 2.0 * (u[0] * e1[1] - u[1] * e1[0]);
+          }
         } else {
+          const int* tr = (kind == 0 ? bd.tri : bd.ptri) + tj * 3;
+          const int t0 = tr[0], t1 = tr[1], t2 = tr[2];
+          double p3[3], a[3], bq[3], c[3], be[3];
+          if (kind == 0) {
 #pragma unroll
-          for (int i = 0; i < 3; ++i) { p3[i] = xb[pi * 3 + i]; a[i] = x[t0 * 3 + i]; bq[i] = x[t1 * 3 + i]; c[i] = x[t2 * 3 + i]; }
-          w = bd.area[pi];
+            for (int i = 0; i < 3; ++i) { p3[i] = x[pi * 3 + i]; a[i] = xb[t0 * 3 + i]; bq[i] = xb[t1 * 3 + i]; c[i] = xb[t2 * 3 + i]; }
+            w = bd.parea[pi];
+          } else {
+#pragma unroll
+            for (int i = 0; i < 3; ++i) { p3[i] = xb[pi * 3 + i]; a[i] = x[t0 * 3 + i]; bq[i] = x[t1 * 3 + i]; c[i] = x[t2 * 3 + i]; }
+            w = bd.area[pi];
+          }
+          pt_closest(p3, a, bq, c, be, d, n);
+          if (kind == 0) {
+#pragma unroll
+            for (int a4 = 0; a4 < 4; ++a4) cq[a4] = -(be[0] * bd.Y[t0 * 4 + a4] + be[1] * bd.Y[t1 * 4 + a4] + be[2] * bd.Y[t2 * 4 + a4]);
+            prow[0] = pi; prow[1] = -1; prow[2] = -1;
+            pco[0] = 1.0; pco[1] = 0.0; pco[2] = 0.0;
+          } else {
+#pragma unroll
+            for (int a4 = 0; a4 < 4; ++a4) cq[a4] = bd.Y[pi * 4 + a4];
+            prow[0] = t0; prow[1] = t1; prow[2] = t2;
+            pco[0] = -be[0]; pco[1] = -be[1]; pco[2] = -be[2];
+          }
         }
-        pt_closest(p3, a, bq, c, be, d, n);
         if (!(d < dhat) || !(w > 0.0)) continue;
         double bb, b1, b2;
         barrier3(d / dhat, bb, b1, b2);
         const double s = kk * w * b1 / dhat, wk = kk * w * b2 / (dhat * dhat);
-        double cq[4];
-        if (kind == 0) {
+        if (molg > 0.0) {
+          const double f = kk * molg * bb;
 #pragma unroll
-          for (int a4 = 0; a4 < 4; ++a4) cq[a4] = -(be[0] * bd.Y[t0 * 4 + a4] + be[1] * bd.Y[t1 * 4 + a4] + be[2] * bd.Y[t2 * 4 + a4]);
-        } else {
+          for (int i = 0; i < 3; ++i) {
+            atomicAdd(&vg[prow[0] * 3 + i], -f * ga[i]);
+            atomicAdd(&vg[prow[1] * 3 + i], f * ga[i]);
 #pragma unroll
-          for (int a4 = 0; a4 < 4; ++a4) cq[a4] = bd.Y[pi * 4 + a4];
+            for (int a4 = 0; a4 < 4; ++a4) atomicAdd(&gb[a4 * 3 + i], f * yd[a4] * gbq[i]);
+          }
         }
         // pad rows
-        const int prow[3] = {kind == 0 ? pi : t0, kind == 0 ? -1 : t1, kind == 0 ? -1 : t2};
-        const double pco[3] = {kind == 0 ? 1.0 : -be[0], kind == 0 ? 0.0 : -be[1], kind == 0 ? 0.0 : -be[2]};
 #pragma unroll
         for (int r = 0; r < 3; ++r) {
           if (prow[r] < 0) continue;
@@ -1019,7 +1179,24 @@ __global__ __launch_bounds__(512, TACEX_BALL_WG_PER_CU) void fem_ball_newton_ker
       double al = amax;
       const int np = n_pairs;
       for (int k = tid; k < np; k += NT) {
-        const int code = plist[k], kind = code >> 30, pi = (code >> 15) & 0x7fff, tj = code & 0x7fff;
+        const unsigned code = (unsigned)plist[k];
+        const int kind = (int)(code >> 30), pi = (int)((code >> 15) & 0x7fff), tj = (int)(code & 0x7fff);
+        if (kind == 2) {
+          const int* ea = bd.pedge + pi * 2;
+          const int* eb = bd.bedge + tj * 2;
+          double pa[6], pb[6], da[6], db[6];
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+              pa[j * 3 + i] = x[ea[j] * 3 + i]; da[j * 3 + i] = vd[ea[j] * 3 + i];
+              pb[j * 3 + i] = xb[eb[j] * 3 + i]; db[j * 3 + i] = dxb[eb[j] * 3 + i];
+            }
+          double sa, tb, d, n[3];
+          ee_closest(pa, pa + 3, pb, pb + 3, sa, tb, d, n);
+          if (d < R) al = fmin(al, accd_ee(pa, pb, da, db, al));
+          continue;
+        }
         const int* tr = (kind == 0 ? bd.tri : bd.ptri) + tj * 3;
         double p3[3], trx[9], dp[3], dtr[9];
         const double* P = kind == 0 ? x : xb;

@@ -22,6 +22,8 @@
 #include <string.h>
 
 #include <algorithm>
+#include <map>
+#include <utility>
 #include <vector>
 
 #include "tacex_hip.h"
@@ -2507,6 +2509,31 @@ __global__ __launch_bounds__(256) void fem_contact_gaps_kernel(FemDev m, const d
   }
 }
 
+// unique edges (lower index first) of a triangle list, the area each stands for (a third of its triangles' rest areas: the edge areas sum
+// to the surface area) and its squared rest length - oracle/abd_oracle.py surface_edges
+static void surface_edges(const std::vector<int>& tri, const double* X, std::vector<int>& edges, std::vector<double>& earea, std::vector<double>& elen2) {
+  std::map<std::pair<int, int>, double> acc;
+  for (size_t t = 0; t + 2 < tri.size(); t += 3) {
+    const double* a = X + (size_t)tri[t] * 3; const double* b = X + (size_t)tri[t + 1] * 3; const double* cc = X + (size_t)tri[t + 2] * 3;
+    const double e1[3] = {b[0] - a[0], b[1] - a[1], b[2] - a[2]}, e2[3] = {cc[0] - a[0], cc[1] - a[1], cc[2] - a[2]};
+    const double cr[3] = {e1[1] * e2[2] - e1[2] * e2[1], e1[2] * e2[0] - e1[0] * e2[2], e1[0] * e2[1] - e1[1] * e2[0]};
+    const double ta = 0.5 * sqrt(cr[0] * cr[0] + cr[1] * cr[1] + cr[2] * cr[2]);
+    for (int k = 0; k < 3; ++k) {
+      const int u = tri[t + k], v = tri[t + (k + 1) % 3];
+      acc[{u < v ? u : v, u < v ? v : u}] += ta / 3.0;
+    }
+  }
+  edges.clear(); earea.clear(); elen2.clear();
+  for (const auto& kv : acc) {
+    const int u = kv.first.first, v = kv.first.second;
+    edges.push_back(u); edges.push_back(v);
+    earea.push_back(kv.second);
+    double l2 = 0.0;
+    for (int i = 0; i < 3; ++i) { const double dd = X[(size_t)v * 3 + i] - X[(size_t)u * 3 + i]; l2 += dd * dd; }
+    elen2.push_back(l2);
+  }
+}
+
 extern "C" {
 
 int tacex_fem_create(int device_id, const tacex_fem_params* p, tacex_fem_ctx** out) {
@@ -3088,6 +3115,8 @@ int tacex_fem_set_affine_body(tacex_fem_ctx* c, int num_verts, const double* ver
   BallDev& bd = c->ball;
   fem_release(c, bd.Y, &synced); fem_release(c, bd.tri, &synced); fem_release(c, bd.area, &synced);
   fem_release(c, bd.ptri, &synced); fem_release(c, bd.psv, &synced); fem_release(c, bd.parea, &synced);
+  fem_release(c, bd.pedge, &synced); fem_release(c, bd.pearea, &synced); fem_release(c, bd.pelen2, &synced);
+  fem_release(c, bd.bedge, &synced); fem_release(c, bd.bearea, &synced); fem_release(c, bd.belen2, &synced);
   bd = BallDev{};
   c->ball_last_ws = nullptr; c->ball_last_B = 0;
   if (num_verts == 0) return 0;  // remove the body
@@ -3136,6 +3165,30 @@ int tacex_fem_set_affine_body(tacex_fem_ctx* c, int num_verts, const double* ver
   if (int rc = fem_upload(c, ptri, &bd.ptri)) return rc;
   if (int rc = fem_upload(c, psv, &bd.psv)) return rc;
   if (int rc = fem_upload(c, parea, &bd.parea)) return rc;
+  // edge-edge pairs: the unique edges of both surfaces (oracle/abd_oracle.py surface_edges); the pad's rest positions come back from the device
+  {
+    std::vector<double> rest((size_t)3 * V);
+    hipError_t e = hipMemcpy(rest.data(), c->rest, rest.size() * sizeof(double), hipMemcpyDeviceToHost);
+    if (e != hipSuccess) return fail_hip(e, "hipMemcpy(pad rest positions)");
+    std::vector<int> pe, be;
+    std::vector<double> pa, pl, ba, bl;
+    surface_edges(ptri, rest.data(), pe, pa, pl);
+    surface_edges(tri, verts_host, be, ba, bl);
+    if (pe.size() / 2 >= 32768 || be.size() / 2 >= 32768) { set_error("tacex_fem_set_affine_body: more than 32767 surface edges"); return 2; }
+    bd.npe = (int)(pe.size() / 2); bd.nbe = (int)(be.size() / 2); bd.ee = 1;
+    if (int rc = fem_upload(c, pe, &bd.pedge)) return rc;
+    if (int rc = fem_upload(c, pa, &bd.pearea)) return rc;
+    if (int rc = fem_upload(c, pl, &bd.pelen2)) return rc;
+    if (int rc = fem_upload(c, be, &bd.bedge)) return rc;
+    if (int rc = fem_upload(c, ba, &bd.bearea)) return rc;
+    if (int rc = fem_upload(c, bl, &bd.belen2)) return rc;
+  }
+  return 0;
+}
+
+int tacex_fem_set_edge_edge(tacex_fem_ctx* c, int enable) {
+  if (!c || c->ball.nv == 0) { set_error("tacex_fem_set_edge_edge: no affine body set"); return 2; }
+  c->ball.ee = enable ? 1 : 0;
   return 0;
 }
 

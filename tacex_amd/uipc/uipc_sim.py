@@ -99,6 +99,11 @@ class UipcSimCfg:
         and stays bounded at the reference's default Newton tolerance on SLENDER bodies, where the previous configuration is far from
         balance (simple_axle at the defaults: 302 K env steps/s against 8.5 K with "ipc", profiles/r05_experiments.md) - the setting for
         those.  Not in the reference cfg (libuipc's rule is not in the reference)."""
+        edge_edge: bool = True
+        """Edge-edge pairs between the gelpad's surface and an affine body's (`tacex_fem_set_edge_edge`): IPC's contact set is point-triangle
+        AND edge-edge pairs (Li et al. 2020); False leaves the point-triangle pairs of both directions alone (the first cut of this scene -
+        between a pad of ~1.5 mm triangles and a ball of 2.7 mm edges at d_hat 0.5 mm the point-triangle pairs already keep the surfaces
+        apart; the switch is there to compare).  Not a field of the reference's cfg: libuipc has no such switch."""
         follow_indenter: bool = True
         """Contact-following start of a step's Newton loop (`tacex_fem_set_contact_following`): vertices inside the barrier zone start
         the iteration displaced with their indenter.  An initial guess only (same minimiser); not in the reference cfg - libuipc starts
@@ -169,8 +174,8 @@ class UipcSim:
     # -- the reference's UIPC scene: a free affine body + the ground (ball_rolling_uipc.py:71-92, uipc_sim.py:192-201) ----------------
     def _setup_affine_body(self, body):
         """One free affine body per env (`UipcObjectCfg.AffineBodyConstitutionCfg`): q (num_envs,4,3) = (p, c_1, c_2, c_3), c_k the columns
-        of A, a surface point is p + sum_k X_k c_k.  Contact: the ground half-space z >= cfg.ground_height and every point-triangle pair
-        between the gelpad's surface and the body's closer than cfg.contact.d_hat (`tacex_fem_set_affine_body`)."""
+        of A, a surface point is p + sum_k X_k c_k.  Contact: the ground half-space z >= cfg.ground_height and every point-triangle and
+        edge-edge pair between the gelpad's surface and the body's closer than cfg.contact.d_hat (`tacex_fem_set_affine_body`)."""
         if tuple(float(v) for v in self.cfg.ground_normal) != (0.0, 0.0, 1.0):
             raise NotImplementedError("the ground of a scene with an affine body is the half-space z >= ground_height (ground_normal (0, 0, 1))")
         obj, B, dev = self._obj, self.num_envs, self.device
@@ -189,6 +194,7 @@ class UipcSim:
             float(body.cfg.constitution_cfg.m_kappa) * 1e6, area.ctypes.data, len(ptri), ptri.ctypes.data, d_hat,
             float(c.default_contact_resistance) * 1e9 * d_hat, float(self.cfg.ground_height), 1 if c.enable else 0,
             1 if body.cfg.constitution_cfg.kinematic else 0), "tacex_fem_set_affine_body")
+        _lib.check(self._lib.tacex_fem_set_edge_edge(self._handle, 1 if getattr(c, "edge_edge", True) else 0), "tacex_fem_set_edge_edge")
         # one default contact model for every pair of surfaces (US:192-201): friction ratio / eps_velocity of the cfg act on the pairs and the ground
         _lib.check(self._lib.tacex_fem_set_friction(self._handle, float(c.default_friction_ratio) if c.enable_friction else 0.0,
                                                     float(c.eps_velocity)), "tacex_fem_set_friction")

@@ -81,7 +81,7 @@ def test_energy_and_gradient_of_the_step_potential_vs_oracle():
     aim = sim.aim_position.cpu().numpy() + 1e-5
     sim.aim_position.copy_(torch.from_numpy(aim).cuda())
     k0 = sc.pairs(y[0])
-    assert len(k0[0][0]) >= 1 and len(k0[1][0]) >= 1
+    assert len(k0[0][0]) >= 1 and len(k0[1][0]) >= 1 and len(k0[2][0]) >= 1  # both point-triangle kinds and edge-edge pairs
     x = torch.from_numpy(np.stack([yy[:V] for yy in y])).cuda()
     q = torch.from_numpy(np.stack([yy[V:] for yy in y])).cuda()
     xt = torch.from_numpy(np.stack([yy[:V] for yy in yt])).cuda()
@@ -105,6 +105,60 @@ def test_energy_and_gradient_of_the_step_potential_vs_oracle():
     eps = sc.eps_v * sc.dt
     assert (slid[0] < eps).any() and (slid[1] > eps).any()  # both branches of the friction potential were in play
     sc._lag = None
+
+
+def test_edge_edge_pairs_mollified_and_switched_off_vs_oracle():
+    """Edge-edge pairs on their own: (i) env 0 holds a pad edge laid nearly parallel over a ball edge - the pair is mollified (m < 1) and the
+    mollifier's own gradient is in play; (ii) with `tacex_fem_set_edge_edge(ctx, 0)` the kernel's terms are the oracle's without that pair
+    kind, and differ from (i)."""
+    from tacex_amd import _lib
+
+    sim, sc, cons, back = _build(press=3.5e-4)
+    V = sc.V
+    y = [_y(sim, b) for b in range(2)]
+    ee = sc.pairs(y[0])[2]
+    assert len(ee[0]) > 0
+    k = int(np.argmin(ee[3]))
+    pe, be = sc.pad_edges[ee[0][k]], sc.ball_edges[ee[1][k]]
+    xb = sc.ball.points(y[0][V:])
+    e2 = xb[be[1]] - xb[be[0]]
+    u2 = e2 / np.linalg.norm(e2)
+    nn = ee[4][k] - (ee[4][k] @ u2) * u2
+    nn /= np.linalg.norm(nn)
+    mid = xb[be[0]] + 0.5 * e2 + 0.4 * sc.dhat * nn
+    L = np.linalg.norm(y[0][pe[1]] - y[0][pe[0]])
+    skew = 0.01 * L * np.cross(u2, nn)
+    y[0][pe[0]] = mid - 0.3 * L * u2 - skew
+    y[0][pe[1]] = mid + 0.3 * L * u2 + skew
+    mol = sc._pair_rows(y[0])[5]
+    assert (mol < 1.0).any() and sc._pair_rows(y[0])[6] is not None
+    yt = [yy + 1e-5 for yy in y]
+    aim = sim.aim_position.cpu().numpy()
+    x = torch.from_numpy(np.stack([yy[:V] for yy in y])).cuda()
+    q = torch.from_numpy(np.stack([yy[V:] for yy in y])).cuda()
+    xt = torch.from_numpy(np.stack([yy[:V] for yy in yt])).cuda()
+    qt = torch.from_numpy(np.stack([yy[V:] for yy in yt])).cuda()
+    mu = sc.mu
+    sc.mu = 0.0  # (no x_prev / q_prev handed over: the kernel's terms are frictionless)
+    try:
+        E, g, si = sim.ball_terms(x, q, xt, qt)
+        assert int(si[:, 2].max()) == 0
+        on = []
+        for b in range(2):
+            Eo, go = sc.energy(y[b], yt[b], cons, aim[b]), sc.gradient(y[b], yt[b], cons, aim[b])
+            on.append(Eo)
+            assert abs(float(E[b]) - Eo) <= 1e-10 * abs(Eo), (b, float(E[b]), Eo)
+            assert np.abs(g[b].cpu().numpy() - go).max() <= 1e-9 * np.abs(go).max(), b
+        _lib.check(sim._lib.tacex_fem_set_edge_edge(sim._handle, 0), "tacex_fem_set_edge_edge")
+        sc.edge_edge = False
+        E, g, si = sim.ball_terms(x, q, xt, qt)
+        for b in range(2):
+            Eo, go = sc.energy(y[b], yt[b], cons, aim[b]), sc.gradient(y[b], yt[b], cons, aim[b])
+            assert Eo < on[b] * (1 - 1e-6)  # the edge-edge barrier energy is gone
+            assert abs(float(E[b]) - Eo) <= 1e-10 * abs(Eo), (b, float(E[b]), Eo)
+            assert np.abs(g[b].cpu().numpy() - go).max() <= 1e-9 * np.abs(go).max(), b
+    finally:
+        sc.mu, sc.edge_edge = mu, True
 
 
 def test_step_vs_oracle_step_from_outside_every_barrier_zone():
@@ -196,8 +250,8 @@ def test_reference_scene_at_default_tolerances_runs_clean_and_ends_stationary_wh
             y = np.concatenate([sim.x[b].cpu().numpy(), sim.q[b].cpu().numpy()])
             osc._lag = osc.friction_lag(y_n[b])  # IPC's lag: the contacts of the state the step started from
             g = osc.gradient(y, yt, cons, sim.aim_position[b].cpu().numpy())
-            (pi, pj, pw, pd, pn, pb), (bi, bj, bw, bd, bn, bb) = osc.pairs(y)
-            w, d = np.concatenate([pw, bw]), np.concatenate([pd, bd])
+            _, _, w, d, _, mol, _ = osc._pair_rows(y)  # point-triangle pairs of both kinds and edge-edge pairs
+            w = w * mol
             scale = cfg.dt**2 * osc.kappa * np.abs(w * barrier(d / osc.dhat)[1] / osc.dhat).max() if len(d) else 0.0
             if scale < 1e-6:  # (a pair that has only just entered the zone pushes with less than the round-off of the pad's elastic forces)
                 assert np.abs(g).max() <= 1e-11, (i, b, np.abs(g).max())
