@@ -29,7 +29,12 @@ The model follows the PUBLISHED sources libuipc implements:
     finite differences).  Lagged Coulomb friction (Li et al. 2020 eq. 18-20, section 5.4: normal force, normal and barycentric weights
     of every contact frozen at the state the step starts from) acts on the pairs of both kinds and on the ground contacts of both
     bodies once `BallScene.mu` is set - the reference's one default contact model (US:103-124, 192-201: ratio 0.5, eps_velocity 0.01).
-    No edge-edge pairs between the two bodies in this slice.
+    EDGE-EDGE pairs (BallScene(edge_edge=True), the default) complete IPC's contact set: every pad surface edge against every ball edge closer
+    than d_hat by the segment-segment distance (Ericson 5.1.9; gradient (1-s) n, s n, -(1-t) n, -t n on the four end points), weighted with
+    the mean of the two edges' areas (an edge stands for a third of its triangles' rest areas) and IPC's mollifier m(c) = (2 - c/eps) c/eps
+    below eps = 1e-3 |e_a|^2 |e_b|^2 (rest lengths), c = |e_a x e_b|^2 (Li et al. 2020 eq. 24), whose own gradient b m'(c) grad c is part of
+    the gradient; Hessian m b'' grad d grad d^T; the pair slides with friction like the others; additive CCD with
+    l = max |d a_k| + max |d b_k|.
 """
 from __future__ import annotations
 

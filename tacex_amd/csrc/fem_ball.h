@@ -1,6 +1,6 @@
 // The reference's own UIPC scene on the GPU (second slice; included by fem_kernels.hip inside namespace tacex):
 // the gelpad (Stable Neo-Hookean tets, soft position constraints) + ONE FREE AFFINE-BODY BALL per env + the ground half-space, in IPC
-// contact through point-triangle pairs in both directions.  Reference call sites: ball_rolling_uipc.py:71-92 (ground_height 0.001,
+// contact through point-triangle pairs in both directions and edge-edge pairs.  Reference call sites: ball_rolling_uipc.py:71-92 (ground_height 0.001,
 // d_hat 5e-4, the ball as AffineBodyConstitutionCfg), uipc_object.py:62-74,456-466 (m_kappa 100 MPa, kinematic = False),
 // uipc_sim.py:192-201 (ground + one default contact model).  The arithmetic is libuipc's, which is not in the reference tree: this
 // follows oracle/abd_oracle.py (PARITY UNPINNED) term by term -
@@ -8,7 +8,9 @@
 //     of the ball is Y_b . (p, c_1, c_2, c_3) with Y_b = (1, X_b); inertia 1/2 (q - q~)^T (S (x) I) (q - q~), orthogonality energy
 //     kappa vol |A^T A - I|^2 with its Gauss-Newton Hessian 4 kappa vol [delta_mn A A^T + c_n c_m^T];
 //   * barrier kappa w b(d / d_hat) on every pair (pad surface vertex, ball triangle) and (ball vertex, pad surface triangle) closer
-//     than d_hat, and of the ground against the surface vertices of both bodies; Hessians b'' grad d grad d^T;
+//     than d_hat, on every EDGE-EDGE pair (pad surface edge, ball edge) closer than d_hat (segment-segment distance, weight = the mean
+//     of the two edge areas, IPC's mollifier of nearly parallel pairs), and of the ground against the surface vertices of both bodies;
+//     Hessians b'' grad d grad d^T;
 //   * lagged Coulomb friction of every one of those contacts (the cfg's one default contact model, US:103-124 / 192-201): normal force,
 //     normal and barycentric weights frozen at the state the step starts from, sliding measured relative to it (IPC's lag);
 //   * matrix-free PCG: x, p and the per-vertex H.p accumulators in LDS (tet rows by ds_add_f64, the tet state recomputed from x);
