@@ -535,8 +535,10 @@ def sweep(args, dev):
         512, 240, 320, 1, False, fem=lambda: FemGelpad(512, dev, motion="rolling", max_newton_iter=NEWTON_CAP, side_stream=True))
     # the reference's own UIPC scene (ball_rolling_uipc.py:71-125): free affine-body ball on the ground under the pad, pairs both ways, d_hat 5e-4.
     # with friction on every contact (the cfg's default contact model); stepped by csrc/fem_ball.h (one launch per time step)
-    run("c4_ball", "C4 per-GPU shard on the reference's UIPC scene: 512 envs, RGB 320x240 + FEM-driven markers + gelpad FEM step against a FREE affine-body ball on the ground (point-triangle pairs both ways + friction, d_hat 5e-4)",
+    run("c4_ball", "C4 per-GPU shard on the reference's UIPC scene: 512 envs, RGB 320x240 + FEM-driven markers + gelpad FEM step against a FREE affine-body ball on the ground (point-triangle pairs both ways + edge-edge pairs + friction, d_hat 5e-4)",
         512, 240, 320, 1, False, fem=lambda: FemBallScene(512, dev, max_newton_iter=NEWTON_CAP, side_stream=True))
+    run("c4_ball4096", "the reference's UIPC scene with the whole 4096-env job on ONE GPU (16 envs per CU instead of 2: the launch no longer ends with its slowest envs)",
+        4096, 240, 320, 1, False, fem=lambda: FemBallScene(4096, dev, max_newton_iter=NEWTON_CAP, side_stream=True))
     run("c4_pad715", "C4 per-GPU shard with a pad the reference's mesher could just as well produce - 715 vertices / 2880 tets: beyond a CU's LDS, the streaming Newton kernel",
         512, 240, 320, 1, False, fem=lambda: FemGelpad(512, dev, max_newton_iter=NEWTON_CAP, side_stream=True, mesh=(10, 12, 4)))
     run("c5", "C5 per-GPU shard: 1024 envs, RGB 640x480 + FEM-driven markers (gelpad FEM step included) (BASELINE configs[4] / 8)",
@@ -573,6 +575,9 @@ SWEEP_NOTES = {
     "c4_dhat5e4": "half the barrier width of UipcSimCfg's default (uipc_sim.py:103-124): what both of the reference's UIPC scenes set",
     "c4_rolling": "like the ball of the reference's ball-rolling scene (depth 0.3-0.8 of the maximum, sliding +-0.5 mm sideways); whenever the indenter "
                   "RETREATS the pad follows it up the barrier in damped Newton steps (every env runs to convergence: the cap is asserted never to bind)",
+    "c4_ball": "every env converges at the reference's default tolerances (asserted: no env at the Newton cap, no flag); with 512 envs on 256 CUs the launch "
+               "lasts as long as its slowest envs (6-9 Newton iterations where the mean is 1.4: envs whose ball has just been touched off-centre and turns)",
+    "c4_ball4096": "the same scene, eight times the envs: what one GPU does with the north star's whole job; per-env cost = mean work, not the stragglers'",
     "axle": "SURVEY 8(d)'s ~2k-tet fixture simple_axle.msh (593 vertices / 2003 tets, scaled to 25.8 x 3 x 3 mm), ends attached, a sphere pressing "
             "on through the IPC barrier: the CU-resident Newton kernel, 768 threads per env (friction, coarse correction, chains: the defaults)",
     "axle_tol1e-6": "the same with the PCG threshold of rounds 1-4 (1e-6 on r.z)",
@@ -785,7 +790,8 @@ _FEM_KEYS = ("hbm_frac", "hbm_achieved", "f64_frac", "lds_frac", "us_per_sweep",
 _CPU_KEYS = ("value", "unit", "cores", "kind", "logical_cores", "physical_cores")
 _SWEEP_SCALARS = {"c3_separate": "value_c3_separate", "c2": "value_c2", "c4": "value_c4", "c5": "value_c5", "c3_dense": "value_dense_contact", "c3_no_gather": "value_no_gather",
                   "c3_sensor_streams": "value_sensor_streams", "c4_rolling": "value_c4_rolling", "c4_lag_capped": "value_c4_lag_capped", "c4_dhat5e4": "value_c4_dhat5e4",
-                  "c5_optical": "value_c5_optical", "shard512": "value_shard512", "c4_ball": "value_c4_ball", "c4_pad715": "value_c4_pad715"}
+                  "c5_optical": "value_c5_optical", "shard512": "value_shard512", "c4_ball": "value_c4_ball", "c4_ball4096": "value_c4_ball4096",
+                  "c4_pad715": "value_c4_pad715"}
 
 
 def compact_line(full: dict, details_path: str | None) -> dict:
