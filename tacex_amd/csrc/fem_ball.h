@@ -1239,7 +1239,7 @@ __global__ __launch_bounds__(512, TACEX_BALL_WG_PER_CU) void fem_ball_newton_ker
     ++n_newton;
     BALL_TICK(6);  // line search
 #ifdef TACEX_BALL_TRACE  // debug build: the late Newton iterations of the envs that need them (scripts/r06/ball_trace.py)
-    if (tid == 0 && nit >= 2)
+    if (tid == 0 && (nit >= 2 || it >= 20))
       printf("trace env %d newton %d: pcg %d amax %.3e step %.3e E0 %.12e dE %.3e dmx %.3e (tol %.1e) dmc %.3e (tol %.1e) pairs %d act %d fric %d\n", b, nit, it, amax, step,
              E0, E1 - E0, dmx, dx_tol, dmc, dc_tol, n_pairs, n_act, n_fric);
 #endif
