@@ -58,7 +58,12 @@ class UipcSimCfg:
         coarse_grid: tuple | str | None = "auto"
         """Coarse grid (cells per axis) of the additive coarse correction beside the 3x3 block Jacobi (`coarse_space.py`):
         "auto" = 3 cells along the longest extent of the mesh, proportionally fewer along the others (2 x 3 x 1 = 24 nodes for the
-        gelpad); None = block Jacobi alone (120-330 PCG iterations on the gelpad).  Not in the reference cfg."""
+        gelpad); None = block Jacobi alone (120-330 PCG iterations on the gelpad).  Not in the reference cfg.
+        A grid NESTED in a structured mesh (nodes on mesh vertices: (4, 5, 1) on the 8 x 10 x 4 pad) is the better coarse space where the
+        right-hand side is smooth - the affine-body scene, `FemBallScene`: 12.9 -> 9.6 PCG iterations per Newton iteration - but NOT a
+        safe choice for the prescribed-indenter scenes on the CU-resident kernel: on C4's breathing press one env of 512 met negative
+        curvature, lost its coarse correction and ran into the Newton cap with a penetrated state (flags 13;
+        profiles/r06_experiments.md section 10, scripts/r06/c4_grid451_probe.py).  `check_step()` reports such envs."""
         vertex_chains: list | str | None = "auto"
         """Vertex chains of the block part of the preconditioner (`tacex_fem_set_chains`): "auto" = the columns of vertices through the
         mesh's thin direction (`coarse_space.build_vertex_chains`; an unstructured mesh yields none), a list of vertex-id lists, or
