@@ -32,7 +32,7 @@ extern "C" {
 #endif
 
 #define TACEX_MAX_LEVELS 8
-#define TACEX_ABI_VERSION 13
+#define TACEX_ABI_VERSION 14
 
 typedef struct tacex_taxim_ctx tacex_taxim_ctx;
 typedef struct tacex_fots_ctx tacex_fots_ctx;
@@ -562,6 +562,20 @@ int tacex_fem_set_attachment_targets(const float* body_pos_dev, const float* bod
 int tacex_fem_marker_uv(const double* surf_pos_dev, const int32_t* tri_dev, const double* weight_dev,
                         double fx, double fy, double cx, double cy, double* uv_dev, int num_envs,
                         int num_surf_verts, int num_markers, void* stream);
+
+/* gen_marker_flow's per-step part for a static marker grid (VT:354-413: no random rotation / translation / shift / noise / lost
+ * tracking - the shipped cfgs) in ONE launch: the FEM state's surface vertices -> camera frame (VT:142-187) -> barycentric point ->
+ * pinhole projection of all markers, then the step's subset next to its initial projection.
+ *   x_dev (B,V,3) f64 world positions (the FEM state itself); surf_ids_dev (Vs) int64: global vertex id of every surface vertex;
+ *   cam_pos_dev (B,3), cam_rot_inv_dev (B,3,3) row-major: camera-frame point = cam_rot_inv (x - cam_pos); tri_dev (M,3) int32 SURFACE-local
+ *   vertex ids and weight_dev (M,3) f64 per marker; init_uv_dev (B,M,2) the projections of the reference surface; select_dev (K) int64: the
+ *   markers of this step's subset (VT:394-399, drawn by the caller); normalize_div > 0: values / normalize_div - 1 (VT:407-409), 0: pixels.
+ *   Outputs: curr_uv_dev (B,M,2) f64 (nullable) all current projections; flow_dev (B,2,K,2) f64 and / or flow_f32_dev (B,2,K,2) f32:
+ *   [initial | current] (u, v) of the subset. */
+int tacex_fem_marker_flow(const double* x_dev, const int64_t* surf_ids_dev, const double* cam_pos_dev, const double* cam_rot_inv_dev,
+                          const int32_t* tri_dev, const double* weight_dev, double fx, double fy, double cx, double cy,
+                          const double* init_uv_dev, const int64_t* select_dev, double normalize_div, double* curr_uv_dev, double* flow_dev,
+                          float* flow_f32_dev, int num_envs, int num_verts, int num_markers, int num_selected, void* stream);
 
 #ifdef __cplusplus
 }

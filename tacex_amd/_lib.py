@@ -11,7 +11,7 @@ from pathlib import Path
 from ._build import LIB, build_library
 
 MAX_LEVELS = 8
-ABI_VERSION = 13  # TACEX_ABI_VERSION of include/tacex_hip.h; bumped whenever a signature or struct layout changes
+ABI_VERSION = 14  # TACEX_ABI_VERSION of include/tacex_hip.h; bumped whenever a signature or struct layout changes
 FLAG_NO_SHIFT = 1
 FLAG_HAVE_FRAME_MIN = 2
 FLAG_WITH_SHADOW = 4
@@ -156,6 +156,7 @@ SIGNATURES = {
     "tacex_fem_set_newton_early_exit": (_i, [_vp, _vp, C.c_double]),
     "tacex_fem_set_attachment_targets": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "tacex_fem_marker_uv": (_i, [_vp, _vp, _vp, _d, _d, _d, _d, _vp, _i, _i, _i, _vp]),
+    "tacex_fem_marker_flow": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _d, _d, _d, _d, _vp, _vp, _d, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
 }
 
 _lib = None

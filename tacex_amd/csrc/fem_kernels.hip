@@ -2444,6 +2444,51 @@ __global__ __launch_bounds__(128) void fem_marker_uv_kernel(const double* __rest
   uv[((size_t)b * M + mi) * 2 + 1] = fy * q[1] / q[2] + cy;
 }
 
+// The whole of gen_marker_flow's per-step part (VT:354-413, the static marker grid of the shipped cfgs) in ONE launch, one workgroup per env:
+// surface vertices out of the FEM state -> camera frame (VT:142-187: R_inv (x - cam_pos)) -> barycentric point -> pinhole projection of ALL
+// M markers (kept: `curr_marker_uv`), then the step's subset: flow[b, 0, k] = init_uv[b, sel[k]], flow[b, 1, k] = uv[b, sel[k]], optionally
+// normalised (VT:407-409: / (W / 2) - 1), as float64 and / or float32 (the plugin's marker_data).  Replaces thirteen launches (index, subtract,
+// batched GEMM, contiguous copy, projection, two gathers, stack, normalise, cast; 120 us of C4's 1.27 ms step: profiles/r06_experiments.md 11).
+__global__ __launch_bounds__(256) void fem_marker_flow_kernel(const double* __restrict__ xg, const long long* __restrict__ surf_ids,
+                                                              const double* __restrict__ cam_pos, const double* __restrict__ cam_rot_inv,
+                                                              const int* __restrict__ tri, const double* __restrict__ wgt, double fx, double fy,
+                                                              double cx, double cy, const double* __restrict__ init_uv,
+                                                              const long long* __restrict__ sel, double norm_div, double* __restrict__ curr_uv,
+                                                              double* __restrict__ flow, float* __restrict__ flow32, int V, int M, int K) {
+  extern __shared__ double muv[];  // (M,2) this env's projections
+  const int b = blockIdx.x;
+  const double* x = xg + (size_t)b * V * 3;
+  const double* cp = cam_pos + (size_t)b * 3;
+  const double* R = cam_rot_inv + (size_t)b * 9;
+  for (int mi = threadIdx.x; mi < M; mi += blockDim.x) {
+    double q[3] = {0.0, 0.0, 0.0};
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const long long v = surf_ids[tri[mi * 3 + k]];
+      const double w = wgt[mi * 3 + k];
+      const double d0 = x[v * 3] - cp[0], d1 = x[v * 3 + 1] - cp[1], d2 = x[v * 3 + 2] - cp[2];
+#pragma unroll
+      for (int i = 0; i < 3; ++i) q[i] += w * (R[i * 3] * d0 + R[i * 3 + 1] * d1 + R[i * 3 + 2] * d2);
+    }
+    const double u = fx * q[0] / q[2] + cx, vv = fy * q[1] / q[2] + cy;
+    muv[mi * 2] = u; muv[mi * 2 + 1] = vv;
+    if (curr_uv) { curr_uv[((size_t)b * M + mi) * 2] = u; curr_uv[((size_t)b * M + mi) * 2 + 1] = vv; }
+  }
+  __syncthreads();
+  for (int k = threadIdx.x; k < 2 * K; k += blockDim.x) {
+    const int which = k / K, kk = k - which * K;  // 0: initial, 1: current
+    const long long s = sel[kk];
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      double val = which == 0 ? init_uv[((size_t)b * M + s) * 2 + c] : muv[s * 2 + c];
+      if (norm_div > 0.0) val = val / norm_div - 1.0;
+      const size_t o = (((size_t)b * 2 + which) * K + kk) * 2 + c;
+      if (flow) flow[o] = val;
+      if (flow32) flow32[o] = (float)val;
+    }
+  }
+}
+
 }  // namespace tacex
 
 using namespace tacex;
@@ -3334,6 +3379,22 @@ int tacex_fem_marker_uv(const double* pos, const int32_t* tri, const double* wgt
                      cx, cy, uv, Vs, M);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : fail_hip(e, "fem_marker_uv_kernel");
+}
+
+int tacex_fem_marker_flow(const double* x, const int64_t* surf_ids, const double* cam_pos, const double* cam_rot_inv, const int32_t* tri,
+                          const double* wgt, double fx, double fy, double cx, double cy, const double* init_uv, const int64_t* select,
+                          double normalize_div, double* curr_uv, double* flow, float* flow_f32, int B, int V, int M, int K, void* stream) {
+  if (!x || !surf_ids || !cam_pos || !cam_rot_inv || !tri || !wgt || !init_uv || !select || (!flow && !flow_f32)) {
+    set_error("tacex_fem_marker_flow: null argument");
+    return 2;
+  }
+  if (B <= 0 || M <= 0 || K <= 0) return 0;
+  if ((size_t)M * 2 * sizeof(double) > 64 * 1024) { set_error("tacex_fem_marker_flow: %d markers (the env's projections are staged in 64 KB of LDS)", M); return 2; }
+  hipLaunchKernelGGL(fem_marker_flow_kernel, dim3(B), dim3(256), (size_t)M * 2 * sizeof(double), (hipStream_t)stream, x,
+                     reinterpret_cast<const long long*>(surf_ids), cam_pos, cam_rot_inv, tri, wgt, fx, fy, cx, cy, init_uv,
+                     reinterpret_cast<const long long*>(select), normalize_div, curr_uv, flow, flow_f32, V, M, K);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : fail_hip(e, "fem_marker_flow_kernel");
 }
 
 }  // extern "C"

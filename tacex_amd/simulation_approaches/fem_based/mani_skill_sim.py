@@ -46,6 +46,9 @@ class ManiSkillSimulator(GelSightSimulator):
         self.marker_data = torch.zeros((self._num_envs, 2, self.cfg.marker_params.num_markers, 2), device=self._device)
 
     def marker_motion_simulation(self):
+        # static marker grid (the shipped cfgs): one launch from the FEM state straight into marker_data; otherwise the general path
+        if self.marker_data.dtype == torch.float32 and self.marker_motion_sim.gen_marker_flow_fused(out_f32=self.marker_data) is not None:
+            return self.marker_data
         self.marker_data[:] = self.marker_motion_sim.gen_marker_flow().to(self.marker_data.dtype)
         return self.marker_data
 

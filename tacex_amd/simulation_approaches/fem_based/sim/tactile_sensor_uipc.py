@@ -132,6 +132,7 @@ class VisionTactileSensorUIPC:
         remap[self.surf_vertex_ids] = np.arange(len(self.surf_vertex_ids))
         self.surf_triangles = remap[tri_global].astype(np.int32)
         self._surf_ids_dev = torch.from_numpy(self.surf_vertex_ids).to(dev)
+        self._surf_ids64 = self._surf_ids_dev.to(torch.int64).contiguous()  # (tacex_fem_marker_flow reads the FEM state through them)
         self.init_surface_vertices_camera = self.get_surface_vertices_camera().clone()
         self.reference_surface_vertices_camera = self.init_surface_vertices_camera.clone()
         self._static = (marker_interval_range[0] == marker_interval_range[1] and marker_rotation_range == 0.0
@@ -191,31 +192,10 @@ class VisionTactileSensorUIPC:
         mask (VT:382-387) depend only on the reference surface, so they are computed ONCE per reference surface (the boolean-mask
         indexing costs a device sync) and every call is projection + one gather; the per-call random subset (VT:394-399) is drawn
         on the host and travels through a small ring of pinned buffers - no host/device synchronisation per step."""
-        key = self._ref_version
-        if self._static_flow is None or self._static_flow[0] != key:
-            init_uv = self._project(self.reference_surface_vertices_camera, tri, wgt)
-            u0, v0 = init_uv[0, :, 0], init_uv[0, :, 1]
-            mask = (u0 > 5) & (u0 < self.tactile_img_height) & (v0 > 5) & (v0 < self.tactile_img_width)
-            idx = torch.nonzero(mask).reshape(-1)
-            self._static_flow = (key, init_uv, idx, idx.cpu().numpy())
-            self._sel_ring = [torch.empty(self.num_markers, dtype=torch.int64).pin_memory() for _ in range(8)]
-            self._sel_events = [None] * len(self._sel_ring)  # recorded behind each slot's H2D copy: a slot is reused only once its copy ran
-            self._sel_pos = 0
-        _, init_uv, idx_dev, idx_host = self._static_flow
+        init_uv, idx_dev, idx_host = self._static_tables(tri, wgt)
         n = idx_host.size
         if n >= self.num_markers:
-            slot = self._sel_pos % len(self._sel_ring)
-            buf = self._sel_ring[slot]
-            self._sel_pos += 1
-            if self._sel_events[slot] is not None:
-                # the host may run more than a ring's worth of steps ahead of the device: overwriting a pinned buffer whose copy has
-                # not executed yet would hand an earlier step the wrong subset.  Waits only in that case (eight steps behind).
-                self._sel_events[slot].synchronize()
-            buf.numpy()[:] = idx_host[self._rng.choice(n, self.num_markers, replace=False)]
-            sel = buf.to(self.device, non_blocking=True)
-            ev = torch.cuda.Event()
-            ev.record(torch.cuda.current_stream(self.device))
-            self._sel_events[slot] = ev
+            sel = self._draw_subset(idx_host)
         elif n > 0:  # pad by repeating the last marker (VT:400-405)
             sel = torch.cat([idx_dev, idx_dev[-1:].expand(self.num_markers - n)])
         else:
@@ -227,8 +207,80 @@ class VisionTactileSensorUIPC:
         self.curr_marker_uv = curr_uv
         return ret
 
+    def _draw_subset(self, idx_host):
+        """This step's random subset of the in-image markers (VT:394-399) as a device tensor: drawn on the host, through a small ring of pinned
+        buffers - no host/device synchronisation per step."""
+        slot = self._sel_pos % len(self._sel_ring)
+        buf = self._sel_ring[slot]
+        self._sel_pos += 1
+        if self._sel_events[slot] is not None:
+            # the host may run more than a ring's worth of steps ahead of the device: overwriting a pinned buffer whose copy has
+            # not executed yet would hand an earlier step the wrong subset.  Waits only in that case (eight steps behind).
+            self._sel_events[slot].synchronize()
+        buf.numpy()[:] = idx_host[self._rng.choice(idx_host.size, self.num_markers, replace=False)]
+        sel = buf.to(self.device, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(self.device))
+        self._sel_events[slot] = ev
+        return sel
+
+    def _static_tables(self, tri, wgt):
+        """(initial projections (B,M,2), in-image marker ids on the device / host) of the current reference surface (VT:382-387)."""
+        key = self._ref_version
+        if self._static_flow is None or self._static_flow[0] != key:
+            init_uv = self._project(self.reference_surface_vertices_camera, tri, wgt)
+            u0, v0 = init_uv[0, :, 0], init_uv[0, :, 1]
+            mask = (u0 > 5) & (u0 < self.tactile_img_height) & (v0 > 5) & (v0 < self.tactile_img_width)
+            idx = torch.nonzero(mask).reshape(-1)
+            self._static_flow = (key, init_uv, idx, idx.cpu().numpy())
+            self._sel_ring = [torch.empty(self.num_markers, dtype=torch.int64).pin_memory() for _ in range(8)]
+            self._sel_events = [None] * len(self._sel_ring)  # recorded behind each slot's H2D copy: a slot is reused only once its copy ran
+            self._sel_pos = 0
+        return self._static_flow[1:]
+
+    def gen_marker_flow_fused(self, out_f32: torch.Tensor | None = None) -> torch.Tensor | None:
+        """gen_marker_flow for a static marker grid with enough in-image markers, as ONE launch on the FEM state (`tacex_fem_marker_flow`):
+        returns the (B,2,num_markers,2) float64 flow - or, with `out_f32` (B,2,num_markers,2) float32 contiguous, writes that and returns it.
+        None when this path does not apply (random grid, no marker in the image): the caller takes gen_marker_flow()."""
+        if not self._static:
+            return None
+        tri, wgt = self._setup()
+        init_uv, idx_dev, idx_host = self._static_tables(tri, wgt)
+        if idx_host.size >= self.num_markers:
+            sel = self._draw_subset(idx_host)
+        elif idx_host.size > 0:  # fewer in-image markers than asked for: all of them, padded by repeating the last one (VT:400-405) - a fixed list
+            pad = getattr(self, "_pad_sel", None)
+            if pad is None or pad[0] != self._ref_version:
+                pad = (self._ref_version, torch.cat([idx_dev, idx_dev[-1:].expand(self.num_markers - idx_host.size)]).contiguous())
+                self._pad_sel = pad
+            sel = pad[1]
+        else:
+            return None
+        self.uipc_sim.wait_for_step()
+        x = self.uipc_sim.x
+        B, V, M, K = x.shape[0], x.shape[1], tri.shape[0], self.num_markers
+        if getattr(self, "_curr_uv_buf", None) is None or self._curr_uv_buf.shape != (B, M, 2):
+            self._curr_uv_buf = torch.empty((B, M, 2), dtype=torch.float64, device=self.device)
+        flow = None
+        if out_f32 is None:
+            flow = torch.empty((B, 2, K, 2), dtype=torch.float64, device=self.device)
+        elif out_f32.dtype != torch.float32 or not out_f32.is_contiguous() or tuple(out_f32.shape) != (B, 2, K, 2):
+            raise ValueError("gen_marker_flow_fused: out_f32 must be a contiguous float32 (B, 2, num_markers, 2) tensor")
+        with torch.cuda.device(self.device):
+            rc = self._lib.tacex_fem_marker_flow(
+                _lib.ptr(x), _lib.ptr(self._surf_ids64), _lib.ptr(self.cam_pos_w), _lib.ptr(self.cam_rot_inv), _lib.ptr(tri), _lib.ptr(wgt),
+                self.fx, self.fy, self.cx, self.cy, _lib.ptr(init_uv), _lib.ptr(sel), float(self.tactile_img_width / 2) if self.normalize else 0.0,
+                _lib.ptr(self._curr_uv_buf), _lib.ptr(flow) if flow is not None else None, _lib.ptr(out_f32) if out_f32 is not None else None,
+                B, V, M, K, _lib.current_stream_handle(self.device))
+        _lib.check(rc, "tacex_fem_marker_flow")
+        self.curr_marker_uv = self._curr_uv_buf
+        return flow if out_f32 is None else out_f32
+
     def gen_marker_flow(self) -> torch.Tensor:
         """(B, 2, num_markers, 2) float64: [initial | current] marker (u, v) pixels (VT:354-413), all envs at once."""
+        fused = self.gen_marker_flow_fused()
+        if fused is not None:
+            return fused
         tri, wgt = self._setup()
         curr_uv = self._project(self.get_surface_vertices_camera(), tri, wgt)
         if self._static:

@@ -247,6 +247,78 @@ def test_mani_skill_marker_flow_plugin():
     assert np.abs(flow[0] - flow[2]).max() > 0.5         # per-env flows differ (the reference fills env 0 only)
 
 
+def test_marker_flow_in_one_launch_vs_oracle_and_vs_the_general_path():
+    """`tacex_fem_marker_flow` (static marker grid, more in-image markers than num_markers: VT:354-413 with the random subset of VT:394-399):
+    the plugin's float32 output and the float64 flow against the NumPy oracle with the same RandomState draws, pixels and normalised; the
+    projections of all markers (`curr_marker_uv`) against the oracle; and the general (multi-launch) path gives the same numbers."""
+    from oracle.fem_oracle import marker_uv
+    from tacex_amd.simulation_approaches.fem_based.sim.tactile_sensor_uipc import VisionTactileSensorUIPC, gen_marker_grid, gen_marker_weight
+    from tacex_amd.uipc import UipcObject, UipcObjectCfg, UipcSim, UipcSimCfg
+    from tacex_amd.uipc.uipc_object import gelpad_box_mesh
+
+    B, K = 3, 40
+    P, Tt = gelpad_box_mesh(10, 8, 3, size=(0.030, 0.018, 0.0045))
+    P = P - np.array([0.011, 0.009, 0.0])
+    sim = UipcSim(UipcSimCfg(device="cuda:0"), num_envs=B)
+    gel = UipcObject(UipcObjectCfg(mesh_points=P, mesh_tets=Tt), sim)
+    sim.setup_sim()
+    cam_pos = torch.tensor([0.0005, -0.0003, -0.024], dtype=torch.float64)
+    quat = torch.tensor([0.9990482, 0.0, 0.0, 0.0436194], dtype=torch.float64)  # 5 degrees about the optical axis (w, x, y, z)
+    mk = lambda norm, seed: VisionTactileSensorUIPC(gel, sim, cam_pos, quat, num_markers=K, normalize=norm, seed=seed)
+    x = sim.x.clone()
+    for b in range(B):
+        x[b, :, 0] += 0.0004 * (b + 1) * torch.sin(300 * x[b, :, 1])
+        x[b, :, 2] += 0.0003 * (b + 1) * torch.cos(200 * x[b, :, 0])
+    made = {(norm, role): mk(norm, 3) for norm in (False, True) for role in ("fused", "general", "again")}  # (reference surface and marker
+    ms = made[(False, "fused")]                                                                              #  weights: the rest shape, at construction)
+    many = VisionTactileSensorUIPC(gel, sim, cam_pos, quat, num_markers=4096)
+    sim.x = x
+    # oracle: camera frame = R^T (x - pos), R from the quaternion
+    w_, x_, y_, z_ = quat.numpy()
+    R = np.array([[1 - 2 * (y_**2 + z_**2), 2 * (x_ * y_ - z_ * w_), 2 * (x_ * z_ + y_ * w_)],
+                  [2 * (x_ * y_ + z_ * w_), 1 - 2 * (x_**2 + z_**2), 2 * (y_ * z_ - x_ * w_)],
+                  [2 * (x_ * z_ - y_ * w_), 2 * (y_ * z_ + x_ * w_), 1 - 2 * (x_**2 + y_**2)]])
+    cam = lambda v: (v - cam_pos.numpy()) @ R
+    surf = ms.surf_vertex_ids
+    tri, wgt = gen_marker_weight(gen_marker_grid(), cam(P[surf]), ms.surf_triangles)
+    init_uv = marker_uv(cam(P[surf])[None].repeat(B, 0), tri, wgt)
+    curr_uv = marker_uv(cam(x.cpu().numpy()[:, surf]), tri, wgt)
+    mask = (init_uv[0, :, 0] > 5) & (init_uv[0, :, 0] < 240) & (init_uv[0, :, 1] > 5) & (init_uv[0, :, 1] < 320)
+    ids = np.where(mask)[0]
+    assert ids.size > K
+    for norm in (False, True):
+        ms = made[(norm, "fused")]
+        rng = np.random.RandomState(3)
+        gen_marker_grid(rng=rng)  # (the grid is drawn first, VT:189-247: a static grid consumes the same draws as a random one)
+        out32 = torch.zeros((B, 2, K, 2), dtype=torch.float32, device="cuda:0")
+        for call in range(2):  # two steps: two draws
+            chosen = ids[rng.choice(ids.size, K, replace=False)]
+            ref = np.stack([init_uv[:, chosen], curr_uv[:, chosen]], 1)
+            if norm:
+                ref = ref / 160.0 - 1.0
+            if call == 0:
+                flow = ms.gen_marker_flow()
+                assert flow.dtype == torch.float64
+                np.testing.assert_allclose(flow.cpu().numpy(), ref, rtol=1e-11, atol=1e-11)
+            else:
+                assert ms.gen_marker_flow_fused(out_f32=out32) is out32
+                np.testing.assert_allclose(out32.cpu().numpy(), ref, rtol=0, atol=3e-5 if not norm else 2e-7)
+            np.testing.assert_allclose(ms.curr_marker_uv.cpu().numpy(), curr_uv, rtol=1e-11)
+        # the general path with the same draws
+        gen = made[(norm, "general")]
+        tri_d, wgt_d = gen._setup()
+        a = gen._gen_marker_flow_static(tri_d, wgt_d, gen._project(gen.get_surface_vertices_camera(), tri_d, wgt_d))
+        b_ = made[(norm, "again")]
+        np.testing.assert_allclose(a.cpu().numpy(), b_.gen_marker_flow().cpu().numpy(), rtol=1e-12, atol=1e-12)
+    # fewer in-image markers than asked for: all of them, padded by repeating the last (VT:400-405) - the same launch with a fixed list
+    f = many.gen_marker_flow_fused().cpu().numpy()
+    n = ids.size
+    assert f.shape == (B, 2, 4096, 2)
+    np.testing.assert_allclose(f[:, 0, :n], init_uv[:, ids], rtol=1e-11)
+    np.testing.assert_allclose(f[:, 1, :n], curr_uv[:, ids], rtol=1e-11)
+    assert (f[:, :, n:] == f[:, :, n - 1:n]).all()
+
+
 @pytest.mark.parametrize("nu", [0.3, 0.49])
 def test_hip_element_gradient_uniaxial_closed_form(nu):
     """The HIP element kernel against a CLOSED FORM (not the oracle): F = diag(s,1,1) on the unit right tet gives
