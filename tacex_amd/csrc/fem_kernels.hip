@@ -3000,6 +3000,22 @@ int tacex_fem_set_newton_early_exit(tacex_fem_ctx* c, double* dx_dev, double dx_
 
 // one launch of the Newton kernel: up to max_newton iterations per env inside the CU-resident kernel, one iteration of the
 // streaming fallback (mesh with more vertices than a workgroup has threads; TACEX_FEM_NEWTON_LDS=0)
+// elastic preconditioner blocks of all envs at x -> the env blocks of the workspace ((V,16) per env); dx_dev / dx_tol: envs already converged are skipped
+static int launch_assemble(tacex_fem_ctx* c, const double* x, void* ws, int B, const double* dx_dev, double dx_tol, hipStream_t st, bool atom) {
+  static size_t granted_a[2][64] = {};
+  // TACEX_FEM_ASSEMBLE: 1 = tet-centric with LDS atomics, 0 = vertex-centric in a fixed order (A/B hook; default: follows the atomics switch)
+  static const int asm_env = getenv("TACEX_FEM_ASSEMBLE") ? atoi(getenv("TACEX_FEM_ASSEMBLE")) : -1;
+  const bool asm_atom = asm_env < 0 ? atom : (asm_env != 0 && !c->deterministic);
+  const int V = c->dev.V;
+  const size_t lds_a = ((size_t)3 * V + (asm_atom ? (size_t)15 * V : 0)) * sizeof(double);
+  auto ka = asm_atom ? fem_assemble_blocks_kernel<true> : fem_assemble_blocks_kernel<false>;
+  hipError_t ea = ensure_dynamic_lds(reinterpret_cast<const void*>(ka), lds_a, granted_a[asm_atom ? 1 : 0]);
+  if (ea != hipSuccess) return fail_hip(ea, "hipFuncSetAttribute(fem_assemble_blocks_kernel)");
+  hipLaunchKernelGGL(ka, dim3(B), dim3(512), lds_a, st, c->dev_nwt, x, static_cast<double*>(ws), dx_dev, dx_tol);
+  ea = hipGetLastError();
+  return ea == hipSuccess ? 0 : fail_hip(ea, "fem_assemble_blocks_kernel");
+}
+
 static int launch_newton(tacex_fem_ctx* c, double* x, const double* xt, const uint8_t* cons, const double* aim, double* stats, void* ws,
                          int B, int pcg_max_iter, double pcg_tol_rate, int ls_max_iter, double* dx_dev, double dx_tol, int max_newton,
                          double* step_info, hipStream_t st, bool* resident, const double* xprev = nullptr, const double* disp = nullptr,
@@ -3042,19 +3058,8 @@ static int launch_newton(tacex_fem_ctx* c, double* x, const double* xt, const ui
     hipError_t ea = hipSetDevice(c->device);
     if (ea == hipSuccess) ea = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds, granted[slot]);
     if (ea != hipSuccess) return fail_hip(ea, "hipFuncSetAttribute(fem_newton_lds_kernel)");
-    {  // elastic preconditioner blocks of all envs at the state this launch starts from -> workspace ((V,16) per env)
-      static size_t granted_a[2][64] = {};
-      // TACEX_FEM_ASSEMBLE: 1 = tet-centric with LDS atomics, 0 = vertex-centric in a fixed order (A/B hook; default: follows the atomics switch)
-      static const int asm_env = getenv("TACEX_FEM_ASSEMBLE") ? atoi(getenv("TACEX_FEM_ASSEMBLE")) : -1;
-      const bool asm_atom = asm_env < 0 ? atom : (asm_env != 0 && !c->deterministic);
-      const size_t lds_a = ((size_t)3 * V + (asm_atom ? (size_t)15 * V : 0)) * sizeof(double);
-      auto ka = asm_atom ? fem_assemble_blocks_kernel<true> : fem_assemble_blocks_kernel<false>;
-      ea = ensure_dynamic_lds(reinterpret_cast<const void*>(ka), lds_a, granted_a[asm_atom ? 1 : 0]);
-      if (ea != hipSuccess) return fail_hip(ea, "hipFuncSetAttribute(fem_assemble_blocks_kernel)");
-      hipLaunchKernelGGL(ka, dim3(B), dim3(512), lds_a, st, c->dev_nwt, x, static_cast<double*>(ws), dx_dev, dx_tol);
-      ea = hipGetLastError();
-      if (ea != hipSuccess) return fail_hip(ea, "fem_assemble_blocks_kernel");
-    }
+    // elastic preconditioner blocks of all envs at the state this launch starts from -> workspace ((V,16) per env)
+    if (int rc = launch_assemble(c, x, ws, B, dx_dev, dx_tol, st, atom)) return rc;
     hipLaunchKernelGGL(kern, dim3(B), dim3(nt), lds, st, c->dev_nwt, x, xt, cons, aim, stats, pcg_max_iter,
                        pcg_tol_rate, ls_max_iter, dx_dev, dx_tol, max_newton, step_info, fric ? xprev : nullptr,
                        (xprev && disp && c->dev.indenters) ? disp : nullptr, env_order,

@@ -103,9 +103,14 @@ class FemGelpad:
         self.stream.wait_stream(cur)  # everything enqueued so far - the previous update's marker kernel read x - is ordered before this step
         with torch.cuda.stream(self.stream):
             self._step(i)
-            if self.sim.step_done is None:
-                self.sim.step_done = torch.cuda.Event()
-            self.sim.step_done.record(self.stream)
+
+    def _after_step(self):
+        """Side stream: the event the consumers of x wait for goes right behind the step - ahead of this class's own bookkeeping kernels."""
+        if self.stream is None:
+            return
+        if self.sim.step_done is None:
+            self.sim.step_done = torch.cuda.Event()
+        self.sim.step_done.record(self.stream)
 
     def _step(self, i):
         self.ev[0].record()
@@ -128,6 +133,7 @@ class FemGelpad:
         torch.maximum(target, torch.add(z, gap, alpha=-0.5), out=z)
         self.sim.step(max_newton_iter=self.max_newton_iter)
         self.ev[1].record()
+        self._after_step()
         if self.ms_log is not None and self.info_sum is not None:
             self.info_sum += self.sim.step_info.mean(0)  # device-side, no synchronisation
             self.iters_max = torch.maximum(self.iters_max, self.sim.step_info[:, 0].max()) if self.iters_max is not None else self.sim.step_info[:, 0].max()
@@ -234,9 +240,6 @@ class FemBallScene:
         self.stream.wait_stream(cur)
         with torch.cuda.stream(self.stream):
             self._step(i)
-            if self.sim.step_done is None:
-                self.sim.step_done = torch.cuda.Event()
-            self.sim.step_done.record(self.stream)
 
     def _step(self, i):
         self.ev[0].record()
@@ -245,6 +248,10 @@ class FemBallScene:
         self.sim.set_constraints(self._back, self._aim)
         self.sim.step(max_newton_iter=self.max_newton_iter)
         self.ev[1].record()
+        if self.stream is not None:  # (the consumers of x wait for this event: ahead of the bookkeeping kernels below)
+            if self.sim.step_done is None:
+                self.sim.step_done = torch.cuda.Event()
+            self.sim.step_done.record(self.stream)
         if self.ms_log is not None and self.info_sum is not None:
             self.info_sum += self.sim.step_info.mean(0)
             self.iters_max = torch.maximum(self.iters_max, self.sim.step_info[:, 0].max()) if self.iters_max is not None else self.sim.step_info[:, 0].max()
