@@ -2,7 +2,8 @@
 `rocprofv3 --kernel-trace --output-format csv -d gpurun_out/prof_c4 -- python3 scripts/r06/c4_timeline.py`; scripts/r06/timeline_of.py turns the trace into one
 steady step, kernel by kernel."""
 import sys
-sys.path.insert(0, ".")
+import os
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
 import torch, bench
 from tacex_amd.uipc.gelpad_scene import FemGelpad
 dev = "cuda:0"

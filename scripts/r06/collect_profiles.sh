@@ -11,5 +11,6 @@ grep -v "rocprofv3\|^[EW]2026" $T/proffem.log > $P/r06_fem_bench.log
 python scripts/make_pmc_traffic.py $T/pmc_fetch $T/pmc_write $P/pmc_traffic_r06.json 0 240 320 $C 2048
 python scripts/make_pmc_traffic.py $T/pmc640_fetch $T/pmc640_write $P/pmc_traffic_r06_640x480.json 0 480 640 $C 1024
 python scripts/make_pmc_traffic_fem.py $T/pmcfem_fetch $T/pmcfem_write $T/proffem $P/pmc_traffic_r06_fem.json $C
+for t in c3 c4; do [ -s $T/${t}_step_timeline.txt ] && sed "s#^\# .*kernel_trace.csv#\# one steady step at commit $C#" $T/${t}_step_timeline.txt > $P/r06_${t}_step_timeline.txt; done
 python scripts/pmc_sq_report.py $T/pmc_sq $P/r06_pmc_sq_summary.md $C
 ls -la $P/r06_* $P/pmc_traffic_r06*

@@ -3,7 +3,7 @@ substring of its name), taken `argv[3]` anchors before the last; start / duratio
 import csv, glob, sys
 root, anchor = sys.argv[1], sys.argv[2]
 back = int(sys.argv[3]) if len(sys.argv) > 3 else 4
-f = sorted(glob.glob(root + "/**/*kernel_trace.csv", recursive=True))[-1]
+f = sorted(glob.glob(root + "/**/*kernel_trace.csv", recursive=True))[-1]  # (prof keeps its trace: the "timeline" step of gpu_round.sh runs after "prof")
 rows = []
 for r in csv.DictReader(open(f)):
     rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Queue_Id"], r["Kernel_Name"]))
