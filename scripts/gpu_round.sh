@@ -26,7 +26,7 @@ for s in $STEPS; do
     timeline) (cd /tmp && export TMPDIR=/tmp
           timeout 600 rocprofv3 --kernel-trace --output-format csv -d $OUT/prof_c4 -- python3 $GRAFT_REPO_ROOT/scripts/r06/c4_timeline.py > $OUT/c4_timeline_run.log 2>&1; echo "timeline c4 rc=$?"; grep "C4:" $OUT/c4_timeline_run.log
           python3 $GRAFT_REPO_ROOT/scripts/r06/timeline_of.py $OUT/prof_c4 fem_newton_lds_kernel 4 > $OUT/c4_step_timeline.txt; rm -rf $OUT/prof_c4
-          python3 $GRAFT_REPO_ROOT/scripts/r06/timeline_of.py $OUT/prof taxim_stream_kernel 4 > $OUT/c3_step_timeline.txt) ;;
+          python3 $GRAFT_REPO_ROOT/scripts/r06/timeline_of.py $OUT/prof taxim_stream_kernel 12 > $OUT/c3_step_timeline.txt) ;;
     pmcsq) (cd /tmp && export TMPDIR=/tmp
           timeout 600 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS --output-format csv -d $OUT/pmc_sq -- python3 $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-sweep --no-node-leg --no-roofline > $OUT/pmc_sq.log 2>&1; echo "pmc sq rc=$?") ;;
   esac
