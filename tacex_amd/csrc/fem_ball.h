@@ -211,8 +211,9 @@ __global__ __launch_bounds__(512, TACEX_BALL_WG_PER_CU) void fem_ball_newton_ker
   __shared__ double gb[12], Bm[144], B0[144], Lc[144], Bi[144], YY[16], qs[12], qts[12], rhs12[12];
   __shared__ double crc[3 * kFemMaxCoarse], cyc[3 * kFemMaxCoarse];  // coarse residual / correction of the two-level preconditioner
   __shared__ double qps[12], Hpq[12], zq[12];  // ... | the ball rows of H.p and of z  // the ball rows the time step started from (friction slides relative to them)
-  __shared__ int n_cpv, n_cpt, n_cpe, n_pairs, n_act, n_fric, s_flags;
-  __shared__ int cpv[kBallMaxCand], cpt[kBallMaxCand], cpe[kBallMaxCand];
+  __shared__ int n_cpv, n_cpt, n_cpe, n_cbv, n_cbt, n_cbe, n_pairs, n_act, n_fric, s_flags;
+  __shared__ unsigned short cpv[kBallMaxCand], cpt[kBallMaxCand], cpe[kBallMaxCand];  // candidate pad vertices / triangles / edges (indices < 32768)
+  __shared__ unsigned short cbv[kBallMaxCand], cbt[kBallMaxCand], cbe[kBallMaxCand];  // candidate ball vertices / triangles / edges
   // env_order: envs sorted by the solver work of their previous step, heaviest first (fem_env_order_kernel): a shard brings two envs
   // per CU, the launch ends with whatever the last-started ones need
   const int b = env_order ? env_order[blockIdx.x] : (int)blockIdx.x;
@@ -545,7 +546,7 @@ __global__ __launch_bounds__(512, TACEX_BALL_WG_PER_CU) void fem_ball_newton_ker
       bts[t * 4] = c3[0]; bts[t * 4 + 1] = c3[1]; bts[t * 4 + 2] = c3[2]; bts[t * 4 + 3] = rt;
     }
     BALL_TICK(0);  // element pass, ball triangle spheres
-    if (tid == 0) { n_cpv = 0; n_cpt = 0; n_cpe = 0; n_pairs = 0; n_act = 0; }
+    if (tid == 0) { n_cpv = 0; n_cpt = 0; n_cpe = 0; n_cbv = 0; n_cbt = 0; n_cbe = 0; n_pairs = 0; n_act = 0; }
     if (tid < 12) gb[tid] = 0.0;
     if (tid < 16) YY[tid] = 0.0;
     if (tid < 144) Bm[tid] = 0.0;
@@ -558,7 +559,7 @@ __global__ __launch_bounds__(512, TACEX_BALL_WG_PER_CU) void fem_ball_newton_ker
       const double lim = rb + L;
       if (r0 * r0 + r1 * r1 + r2 * r2 < lim * lim) {
         const int s = atomicAdd(&n_cpv, 1);
-        if (s < kBallMaxCand) cpv[s] = v;
+        if (s < kBallMaxCand) cpv[s] = (unsigned short)v;
       }
     }
     for (int k = tid; k < bd.npt; k += NT) {
@@ -575,7 +576,7 @@ __global__ __launch_bounds__(512, TACEX_BALL_WG_PER_CU) void fem_ball_newton_ker
       const double lim = rb + L + rt;
       if (r0 * r0 + r1 * r1 + r2 * r2 < lim * lim) {
         const int s = atomicAdd(&n_cpt, 1);
-        if (s < kBallMaxCand) cpt[s] = k;
+        if (s < kBallMaxCand) cpt[s] = (unsigned short)k;
       }
     }
     if (bd.ee)
@@ -590,18 +591,61 @@ __global__ __launch_bounds__(512, TACEX_BALL_WG_PER_CU) void fem_ball_newton_ker
         const double lim = rb + L + sqrt(h2);
         if (r2 < lim * lim) {
           const int s = atomicAdd(&n_cpe, 1);
-          if (s < kBallMaxCand) cpe[s] = k;
+          if (s < kBallMaxCand) cpe[s] = (unsigned short)k;
         }
       }
     __syncthreads();
     if (n_cpv > kBallMaxCand || n_cpt > kBallMaxCand || n_cpe > kBallMaxCand) { if (tid == 0) s_flags |= kBallFlagOverflow; }
     const int ncpv = min(n_cpv, kBallMaxCand), ncpt = min(n_cpt, kBallMaxCand), ncpe = min(n_cpe, kBallMaxCand);
-    // ball vertices near the candidate pad triangles: within L of the union of their bounding spheres - one sphere around all of them
-    // would do as well; here: within reach of the pad's candidate region = distance to p's far side is what the triangle test used, so
-    // every ball vertex is tested against the candidate triangles' spheres directly (nv x ncpt sphere tests)
-    // pairs, kind 0: candidate pad vertex x ball triangle
-    for (int k = tid; k < ncpv * nt; k += NT) {
-      const int v = cpv[k / nt], t = k - (k / nt) * nt;
+    // the ball's side of the lists: what lies within L of the bounding box of the pad's candidates (a ball of 320 triangles / 480 edges / 162
+    // vertices touches the pad with a few dozen of each: the pair tests below shrink accordingly)
+    double lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    auto grow = [&](int v) {
+#pragma unroll
+      for (int i = 0; i < 3; ++i) { lo[i] = fmin(lo[i], x[v * 3 + i]); hi[i] = fmax(hi[i], x[v * 3 + i]); }
+    };
+    for (int k = tid; k < ncpv; k += NT) grow(cpv[k]);
+    for (int k = tid; k < ncpt; k += NT) { const int* tr = bd.ptri + cpt[k] * 3; grow(tr[0]); grow(tr[1]); grow(tr[2]); }
+    for (int k = tid; k < ncpe; k += NT) { const int* ed = bd.pedge + cpe[k] * 2; grow(ed[0]); grow(ed[1]); }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { lo[i] = -block_sum_max(-lo[i], sh) - L; hi[i] = block_sum_max(hi[i], sh) + L; }
+    for (int k = tid; k < nv; k += NT) {
+      const double p0 = xb[k * 3], p1 = xb[k * 3 + 1], p2 = xb[k * 3 + 2];
+      if (p0 >= lo[0] && p0 <= hi[0] && p1 >= lo[1] && p1 <= hi[1] && p2 >= lo[2] && p2 <= hi[2]) {
+        const int sl = atomicAdd(&n_cbv, 1);
+        if (sl < kBallMaxCand) cbv[sl] = (unsigned short)k;
+      }
+    }
+    for (int t = tid; t < nt; t += NT) {
+      const double rt = bts[t * 4 + 3];
+      bool in = true;
+#pragma unroll
+      for (int i = 0; i < 3; ++i) in = in && bts[t * 4 + i] + rt >= lo[i] && bts[t * 4 + i] - rt <= hi[i];
+      if (in) {
+        const int sl = atomicAdd(&n_cbt, 1);
+        if (sl < kBallMaxCand) cbt[sl] = (unsigned short)t;
+      }
+    }
+    if (bd.ee)
+      for (int k = tid; k < bd.nbe; k += NT) {
+        const int* eb = bd.bedge + k * 2;
+        bool in = true;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+          const double a = xb[eb[0] * 3 + i], b2 = xb[eb[1] * 3 + i];
+          in = in && fmax(a, b2) >= lo[i] && fmin(a, b2) <= hi[i];
+        }
+        if (in) {
+          const int sl = atomicAdd(&n_cbe, 1);
+          if (sl < kBallMaxCand) cbe[sl] = (unsigned short)k;
+        }
+      }
+    __syncthreads();
+    if (n_cbv > kBallMaxCand || n_cbt > kBallMaxCand || n_cbe > kBallMaxCand) { if (tid == 0) s_flags |= kBallFlagOverflow; }
+    const int ncbv = min(n_cbv, kBallMaxCand), ncbt = min(n_cbt, kBallMaxCand), ncbe = min(n_cbe, kBallMaxCand);
+    // pairs, kind 0: candidate pad vertex x candidate ball triangle
+    for (int k = tid; k < ncpv * ncbt; k += NT) {
+      const int v = cpv[k / ncbt], t = cbt[k - (k / ncbt) * ncbt];
       const double r0 = x[v * 3] - bts[t * 4], r1 = x[v * 3 + 1] - bts[t * 4 + 1], r2 = x[v * 3 + 2] - bts[t * 4 + 2];
       const double lim = L + bts[t * 4 + 3];
       if (r0 * r0 + r1 * r1 + r2 * r2 >= lim * lim) continue;
@@ -615,9 +659,9 @@ __global__ __launch_bounds__(512, TACEX_BALL_WG_PER_CU) void fem_ball_newton_ker
         if (s < kBallMaxPairs) plist[s] = (0 << 30) | (v << 15) | t;
       }
     }
-    // pairs, kind 1: ball vertex x candidate pad triangle
-    for (int k = tid; k < nv * ncpt; k += NT) {
-      const int bv = k / ncpt, t = cpt[k - (k / ncpt) * ncpt];
+    // pairs, kind 1: candidate ball vertex x candidate pad triangle
+    for (int k = tid; k < ncbv * ncpt; k += NT) {
+      const int bv = cbv[k / ncpt], t = cpt[k - (k / ncpt) * ncpt];
       const int* tr = bd.ptri + t * 3;
       double p3[3], a[3], bq[3], c[3], be[3], d, n[3];
 #pragma unroll
@@ -634,9 +678,9 @@ __global__ __launch_bounds__(512, TACEX_BALL_WG_PER_CU) void fem_ball_newton_ker
         if (s < kBallMaxPairs) plist[s] = (1 << 30) | (bv << 15) | t;
       }
     }
-    // pairs, kind 2: candidate pad edge x ball edge
-    for (int k = tid; k < ncpe * bd.nbe; k += NT) {
-      const int pe = cpe[k / bd.nbe], be_ = k - (k / bd.nbe) * bd.nbe;
+    // pairs, kind 2: candidate pad edge x candidate ball edge
+    for (int k = tid; k < ncpe * ncbe; k += NT) {
+      const int pe = cpe[k / ncbe], be_ = cbe[k - (k / ncbe) * ncbe];
       const int* ea = bd.pedge + pe * 2;
       const int* eb = bd.bedge + be_ * 2;
       double a0[3], a1[3], b0[3], b1[3];
