@@ -210,6 +210,7 @@ __global__ __launch_bounds__(512, TACEX_BALL_WG_PER_CU) void fem_ball_newton_ker
   __shared__ double sh[17], sh2[16];
   __shared__ double gb[12], Bm[144], B0[144], Lc[144], Bi[144], YY[16], qs[12], qts[12], rhs12[12];
   __shared__ double crc[3 * kFemMaxCoarse], cyc[3 * kFemMaxCoarse];  // coarse residual / correction of the two-level preconditioner
+  __shared__ double cpart[6 * kFemMaxCoarse];                        // ... the two halves of the coarse solve's sums
   __shared__ double qps[12], Hpq[12], zq[12];  // ... | the ball rows of H.p and of z  // the ball rows the time step started from (friction slides relative to them)
   __shared__ int n_cpv, n_cpt, n_cpe, n_cbv, n_cbt, n_cbe, n_pairs, n_act, n_fric, s_flags;
   __shared__ unsigned short cpv[kBallMaxCand], cpt[kBallMaxCand], cpe[kBallMaxCand];  // candidate pad vertices / triangles / edges (indices < 32768)
@@ -419,23 +420,37 @@ __global__ __launch_bounds__(512, TACEX_BALL_WG_PER_CU) void fem_ball_newton_ker
   // chain y_i = r_i - G_{i-1}^T y_{i-1}, back up z_i = S_i^-1 y_i - G_i z_{i+1}) + the additive coarse correction P A_c^-1 P^T r of the
   // pad's coarse space (restriction by ds_add_f64 from the vertices' own 8 (node, weight) pairs) + the exact inverse of the ball block.
   // Returns r . z.
+#ifdef TACEX_BALL_CLOCK  // debug build: cycles inside the PCG loop (sweep | vertex + records | dot + update | restriction + chains | coarse solve | prolongation + sum)
+  long long pck[6] = {0, 0, 0, 0, 0, 0}, pt0 = 0;
+#define PCG_TICK0() do { pt0 = __builtin_readcyclecounter(); } while (0)
+#define PCG_TICK(k) do { const long long n_ = __builtin_readcyclecounter(); pck[k] += n_ - pt0; pt0 = n_; } while (0)
+#else
+#define PCG_TICK0() do { } while (0)
+#define PCG_TICK(k) do { } while (0)
+#endif
   auto precondition = [&]() -> double {
     const int nc3 = 3 * m.nc;
+    PCG_TICK0();
     for (int k = tid; k < 3 * V; k += NT) rsl[k] = rL[k];
-    if (coarse && tid < nc3) crc[tid] = 0.0;
     __syncthreads();
-    if (coarse) {
-      for (int v = tid; v < V; v += NT) {
-        const double r0 = rL[v * 3], r1 = rL[v * 3 + 1], r2 = rL[v * 3 + 2];
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-          const int nd = m.cv_node[v * 8 + k];
-          const double w = m.cv_w[v * 8 + k];
-          if (w != 0.0) { atomicAdd(&crc[nd * 3], w * r0); atomicAdd(&crc[nd * 3 + 1], w * r1); atomicAdd(&crc[nd * 3 + 2], w * r2); }
+    if (coarse) {  // restriction r_c = P^T r, node by node over the node's vertex list (G lanes per node, as coarse_correct(); the first cut added
+                   // 12 000 LDS atomics onto 180 addresses per application)
+      int G = 1;
+      while (2 * G <= NT / m.nc && 2 * G <= 64) G *= 2;
+      const int node = tid / G, jn = tid - node * G;
+      double a0 = 0.0, a1 = 0.0, a2 = 0.0;
+      if (node < m.nc) {
+        const int e1 = m.cn_off[node + 1];
+        for (int e = m.cn_off[node] + jn; e < e1; e += G) {
+          const int v0 = m.cn_vtx[e];
+          const double w0 = m.cn_w[e];
+          a0 += w0 * rL[v0 * 3]; a1 += w0 * rL[v0 * 3 + 1]; a2 += w0 * rL[v0 * 3 + 2];
         }
       }
+      for (int o2 = G >> 1; o2 > 0; o2 >>= 1) { a0 += __shfl_xor(a0, o2, 64); a1 += __shfl_xor(a1, o2, 64); a2 += __shfl_xor(a2, o2, 64); }
+      if (node < m.nc && jn == 0) { crc[node * 3] = a0; crc[node * 3 + 1] = a1; crc[node * 3 + 2] = a2; }
     }
-    for (int ch = tid; ch < nch; ch += NT) {
+    for (int ch = NT - 1 - tid; ch < nch; ch += NT) {  // (the chains go to the LAST threads: the restriction above keeps the first nc * G busy)
       int v = m.ch_next ? m.ch_head[ch] : ch, last = v;
       double y[3] = {rsl[v * 3], rsl[v * 3 + 1], rsl[v * 3 + 2]};
       while (true) {
@@ -476,15 +491,38 @@ __global__ __launch_bounds__(512, TACEX_BALL_WG_PER_CU) void fem_ball_newton_ker
       part += rL[V * 3 + tid] * zz;
     }
     __syncthreads();
+    PCG_TICK(3);
     if (coarse) {
-      if (tid < nc3) {
-        double sv = 0.0;
-        for (int k = 0; k < nc3; ++k) sv += m.ac_inv[(size_t)tid * nc3 + k] * crc[k];
-        cyc[tid] = sv;
-        part += crc[tid] * sv;
+      // y_c = A_c^-1 r_c, a (3 nc)^2 <= 192^2 f64 matrix in L2.  The matrix is symmetric: lane = OUTPUT index, the loop runs down a COLUMN
+      // block - every load instruction reads 512 contiguous bytes, eight of them in flight, no cross-lane reduction.  Six waves: three
+      // output chunks of 64 x two halves of the sum.  (A thread walking its own row: 32 of a PCG iteration's 110 kcycles with the 60-node
+      // grid - 180 dependent steps, 64 cache lines per load instruction; a wave per row with shuffles: 36.)
+      const int lane = tid & 63, wave = tid >> 6;
+      if (wave < 6) {
+        const int r = (wave % 3) * 64 + lane, jp = wave / 3;
+        const int j0 = jp * 96, j1 = min(nc3, j0 + 96);
+        double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+        if (r < nc3) {
+          int jj = j0;
+          for (; jj + 8 <= j1; jj += 8) {
+            double a[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) a[u] = m.ac_inv[(size_t)(jj + u) * nc3 + r];
+            s0 += a[0] * crc[jj] + a[4] * crc[jj + 4];
+            s1 += a[1] * crc[jj + 1] + a[5] * crc[jj + 5];
+            s2 += a[2] * crc[jj + 2] + a[6] * crc[jj + 6];
+            s3 += a[3] * crc[jj + 3] + a[7] * crc[jj + 7];
+          }
+          for (; jj < j1; ++jj) s0 += m.ac_inv[(size_t)jj * nc3 + r] * crc[jj];
+          cpart[jp * 3 * kFemMaxCoarse + r] = (s0 + s1) + (s2 + s3);
+        }
       }
       __syncthreads();
+      if (tid < nc3) cyc[tid] = cpart[tid] + cpart[3 * kFemMaxCoarse + tid];
+      __syncthreads();
+      if (tid < nc3) part += crc[tid] * cyc[tid];
     }
+    PCG_TICK(4);
     for (int v = tid; v < V; v += NT) {
       double z0 = rsl[v * 3], z1 = rsl[v * 3 + 1], z2 = rsl[v * 3 + 2];
       part += rL[v * 3] * z0 + rL[v * 3 + 1] * z1 + rL[v * 3 + 2] * z2;  // (the chain part; the coarse part of r . z is crc . cyc above)
@@ -498,7 +536,9 @@ __global__ __launch_bounds__(512, TACEX_BALL_WG_PER_CU) void fem_ball_newton_ker
         rsl[v * 3] = z0; rsl[v * 3 + 1] = z1; rsl[v * 3 + 2] = z2;
       }
     }
-    return bsum(part);
+    const double rzv = bsum(part);
+    PCG_TICK(5);
+    return rzv;
   };
 
 #ifdef TACEX_BALL_CLOCK  // debug build: cycles of the phases of a step, printed by env 0 (scripts/r06/ball_clock.sh)
@@ -1074,6 +1114,7 @@ __global__ __launch_bounds__(512, TACEX_BALL_WG_PER_CU) void fem_ball_newton_ker
     int it = 0;
     __syncthreads();
     while (it < pcg_max_iter && rz0 > 0.0 && rz > pcg_tol_rate * rz0) {
+      PCG_TICK0();
       for (int t = tid; t < T; t += NT) {
         int v[4];
         double Di[9], F[9], dF[9], dP[9], r[12];
@@ -1092,6 +1133,7 @@ __global__ __launch_bounds__(512, TACEX_BALL_WG_PER_CU) void fem_ball_newton_ker
             atomicAdd(&acc[v[w4] * 3 + i], sc * (dP[i * 3 + 0] * r[w4 * 3 + 0] + dP[i * 3 + 1] * r[w4 * 3 + 1] + dP[i * 3 + 2] * r[w4 * 3 + 2]));
       }
       __syncthreads();
+      PCG_TICK(0);
       for (int v = tid; v < V; v += NT) {
         const double md = m.mass[v] * (1.0 + ((cons && cons[v]) ? m.strength : 0.0));
 #pragma unroll
@@ -1162,6 +1204,7 @@ __global__ __launch_bounds__(512, TACEX_BALL_WG_PER_CU) void fem_ball_newton_ker
         }
       }
       __syncthreads();
+      PCG_TICK(1);
       double part = 0.0;
       for (int k = tid; k < 3 * V; k += NT) part += ps[k] * acc[k];
       if (tid < 12) {
@@ -1180,6 +1223,7 @@ __global__ __launch_bounds__(512, TACEX_BALL_WG_PER_CU) void fem_ball_newton_ker
       for (int k = tid; k < 3 * V; k += NT) { dL[k] += al * ps[k]; rL[k] -= al * acc[k]; acc[k] = 0.0; }  // (acc: zero for the next sweep)
       if (tid < 12) { dL[V * 3 + tid] += al * ps[V * 3 + tid]; rL[V * 3 + tid] -= al * Hpq[tid]; }
       __syncthreads();
+      PCG_TICK(2);
       const double rz_new = precondition();
       const double beta = rz_new / rz;
       for (int k = tid; k < 3 * V; k += NT) ps[k] = rsl[k] + beta * ps[k];
@@ -1302,8 +1346,9 @@ __global__ __launch_bounds__(512, TACEX_BALL_WG_PER_CU) void fem_ball_newton_ker
   }
 #ifdef TACEX_BALL_CLOCK
   if (tid == 0 && (b == 0 || b == (int)gridDim.x - 1))
-    printf("ball clock env %d: newton %d pcg %d | kcycles: element %lld candidates %lld gradient+blocks %lld pairs+factor %lld PCG %lld stepbound %lld linesearch %lld\n", b,
-           n_newton, pcg_total, bck[0] / 1000, bck[1] / 1000, bck[2] / 1000, bck[3] / 1000, bck[4] / 1000, bck[5] / 1000, bck[6] / 1000);
+    printf("ball clock env %d: newton %d pcg %d | kcycles: element %lld candidates %lld gradient+blocks %lld pairs+factor %lld PCG %lld stepbound %lld linesearch %lld | inside PCG: sweep %lld vertex+records %lld dot+update %lld restrict+chains %lld coarse %lld prolong+sum %lld\n", b,
+           n_newton, pcg_total, bck[0] / 1000, bck[1] / 1000, bck[2] / 1000, bck[3] / 1000, bck[4] / 1000, bck[5] / 1000, bck[6] / 1000, pck[0] / 1000, pck[1] / 1000,
+           pck[2] / 1000, pck[3] / 1000, pck[4] / 1000, pck[5] / 1000);
 #endif
   if (tid < 12) q[tid] = qs[tid];
   if (tid == 0 && step_info) {
