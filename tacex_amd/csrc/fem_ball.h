@@ -428,13 +428,47 @@ __global__ __launch_bounds__(512, TACEX_BALL_WG_PER_CU) void fem_ball_newton_ker
 #define PCG_TICK0() do { } while (0)
 #define PCG_TICK(k) do { } while (0)
 #endif
+  auto chain_solve = [&](int ch) {  // block-tridiagonal L D L^T solve along one vertex chain, in place in rsl (factors cf in LDS)
+    int v = m.ch_next ? m.ch_head[ch] : ch, last = v;
+    double y[3] = {rsl[v * 3], rsl[v * 3 + 1], rsl[v * 3 + 2]};
+    while (true) {
+      last = v;
+      const int n = cnx[v] == 0xffff ? -1 : (int)cnx[v];
+      if (n < 0) break;
+      const float* g = cf + v * 15 + 6;
+      const double y0 = y[0], y1 = y[1], y2 = y[2];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) y[k] = rsl[n * 3 + k] - ((double)g[k] * y0 + (double)g[3 + k] * y1 + (double)g[6 + k] * y2);
+      rsl[n * 3] = y[0]; rsl[n * 3 + 1] = y[1]; rsl[n * 3 + 2] = y[2];
+      v = n;
+    }
+    v = last;
+    double zn[3] = {0, 0, 0};
+    while (true) {
+      const float* f = cf + v * 15;
+      const double y0 = rsl[v * 3], y1 = rsl[v * 3 + 1], y2 = rsl[v * 3 + 2];
+      double zz[3];
+      zz[0] = (double)f[0] * y0 + (double)f[1] * y1 + (double)f[2] * y2;
+      zz[1] = (double)f[1] * y0 + (double)f[3] * y1 + (double)f[4] * y2;
+      zz[2] = (double)f[2] * y0 + (double)f[4] * y1 + (double)f[5] * y2;
+#pragma unroll
+      for (int i = 0; i < 3; ++i) zz[i] -= (double)f[6 + i * 3] * zn[0] + (double)f[7 + i * 3] * zn[1] + (double)f[8 + i * 3] * zn[2];
+      rsl[v * 3] = zz[0]; rsl[v * 3 + 1] = zz[1]; rsl[v * 3 + 2] = zz[2];
+      zn[0] = zz[0]; zn[1] = zz[1]; zn[2] = zz[2];
+      const int pv = cpr[v] == 0xffff ? -1 : (int)cpr[v];
+      if (pv < 0) break;
+      v = pv;
+    }
+  };
+  // z = M^-1 r (r in rL, z in rsl | zq); returns r . z.  Phases: (A) copy + restriction r_c = P^T r; (B) coarse solve on waves 0-5 WHILE waves 6-7
+  // solve the chains; (C) the coarse solve's two halves; (D) prolongation + r . z.
   auto precondition = [&]() -> double {
     const int nc3 = 3 * m.nc;
+    const int lane = tid & 63, wave = tid >> 6;
     PCG_TICK0();
     for (int k = tid; k < 3 * V; k += NT) rsl[k] = rL[k];
-    __syncthreads();
-    if (coarse) {  // restriction r_c = P^T r, node by node over the node's vertex list (G lanes per node, as coarse_correct(); the first cut added
-                   // 12 000 LDS atomics onto 180 addresses per application)
+    if (coarse) {  // restriction, node by node over the node's vertex list (G lanes per node, as coarse_correct(); the first cut added 12 000 LDS
+                   // atomics onto 180 addresses per application)
       int G = 1;
       while (2 * G <= NT / m.nc && 2 * G <= 64) G *= 2;
       const int node = tid / G, jn = tid - node * G;
@@ -450,38 +484,8 @@ __global__ __launch_bounds__(512, TACEX_BALL_WG_PER_CU) void fem_ball_newton_ker
       for (int o2 = G >> 1; o2 > 0; o2 >>= 1) { a0 += __shfl_xor(a0, o2, 64); a1 += __shfl_xor(a1, o2, 64); a2 += __shfl_xor(a2, o2, 64); }
       if (node < m.nc && jn == 0) { crc[node * 3] = a0; crc[node * 3 + 1] = a1; crc[node * 3 + 2] = a2; }
     }
-    for (int ch = NT - 1 - tid; ch < nch; ch += NT) {  // (the chains go to the LAST threads: the restriction above keeps the first nc * G busy)
-      int v = m.ch_next ? m.ch_head[ch] : ch, last = v;
-      double y[3] = {rsl[v * 3], rsl[v * 3 + 1], rsl[v * 3 + 2]};
-      while (true) {
-        last = v;
-        const int n = cnx[v] == 0xffff ? -1 : (int)cnx[v];
-        if (n < 0) break;
-        const float* g = cf + v * 15 + 6;
-        const double y0 = y[0], y1 = y[1], y2 = y[2];
-#pragma unroll
-        for (int k = 0; k < 3; ++k) y[k] = rsl[n * 3 + k] - ((double)g[k] * y0 + (double)g[3 + k] * y1 + (double)g[6 + k] * y2);
-        rsl[n * 3] = y[0]; rsl[n * 3 + 1] = y[1]; rsl[n * 3 + 2] = y[2];
-        v = n;
-      }
-      v = last;
-      double zn[3] = {0, 0, 0};
-      while (true) {
-        const float* f = cf + v * 15;
-        const double y0 = rsl[v * 3], y1 = rsl[v * 3 + 1], y2 = rsl[v * 3 + 2];
-        double zz[3];
-        zz[0] = (double)f[0] * y0 + (double)f[1] * y1 + (double)f[2] * y2;
-        zz[1] = (double)f[1] * y0 + (double)f[3] * y1 + (double)f[4] * y2;
-        zz[2] = (double)f[2] * y0 + (double)f[4] * y1 + (double)f[5] * y2;
-#pragma unroll
-        for (int i = 0; i < 3; ++i) zz[i] -= (double)f[6 + i * 3] * zn[0] + (double)f[7 + i * 3] * zn[1] + (double)f[8 + i * 3] * zn[2];
-        rsl[v * 3] = zz[0]; rsl[v * 3 + 1] = zz[1]; rsl[v * 3 + 2] = zz[2];
-        zn[0] = zz[0]; zn[1] = zz[1]; zn[2] = zz[2];
-        const int pv = cpr[v] == 0xffff ? -1 : (int)cpr[v];
-        if (pv < 0) break;
-        v = pv;
-      }
-    }
+    __syncthreads();
+    PCG_TICK(3);
     double part = 0.0;
     if (tid < 12) {
       double zz = 0.0;
@@ -490,14 +494,11 @@ __global__ __launch_bounds__(512, TACEX_BALL_WG_PER_CU) void fem_ball_newton_ker
       zq[tid] = zz;
       part += rL[V * 3 + tid] * zz;
     }
-    __syncthreads();
-    PCG_TICK(3);
-    if (coarse) {
+    if (coarse && NT >= 512) {
       // y_c = A_c^-1 r_c, a (3 nc)^2 <= 192^2 f64 matrix in L2.  The matrix is symmetric: lane = OUTPUT index, the loop runs down a COLUMN
       // block - every load instruction reads 512 contiguous bytes, eight of them in flight, no cross-lane reduction.  Six waves: three
       // output chunks of 64 x two halves of the sum.  (A thread walking its own row: 32 of a PCG iteration's 110 kcycles with the 60-node
       // grid - 180 dependent steps, 64 cache lines per load instruction; a wave per row with shuffles: 36.)
-      const int lane = tid & 63, wave = tid >> 6;
       if (wave < 6) {
         const int r = (wave % 3) * 64 + lane, jp = wave / 3;
         const int j0 = jp * 96, j1 = min(nc3, j0 + 96);
@@ -516,11 +517,16 @@ __global__ __launch_bounds__(512, TACEX_BALL_WG_PER_CU) void fem_ball_newton_ker
           for (; jj < j1; ++jj) s0 += m.ac_inv[(size_t)jj * nc3 + r] * crc[jj];
           cpart[jp * 3 * kFemMaxCoarse + r] = (s0 + s1) + (s2 + s3);
         }
+      } else {  // ... while the last two waves solve the chains
+        for (int ch = tid - 384; ch < nch; ch += NT - 384) chain_solve(ch);
       }
       __syncthreads();
       if (tid < nc3) cyc[tid] = cpart[tid] + cpart[3 * kFemMaxCoarse + tid];
       __syncthreads();
       if (tid < nc3) part += crc[tid] * cyc[tid];
+    } else {
+      for (int ch = tid; ch < nch; ch += NT) chain_solve(ch);
+      __syncthreads();
     }
     PCG_TICK(4);
     for (int v = tid; v < V; v += NT) {
@@ -1107,6 +1113,13 @@ __global__ __launch_bounds__(512, TACEX_BALL_WG_PER_CU) void fem_ball_newton_ker
     //      the pair records are what it reads from memory ----
     for (int k = tid; k < 3 * V; k += NT) { xs[k] = x[k]; acc[k] = 0.0; }
     __syncthreads();
+    double md_r[2], cb_r[2];  // this thread's vertices: mass (+ constraint) diagonal and ground curvature, constant through the PCG loop
+#pragma unroll
+    for (int sl = 0; sl < 2; ++sl) {
+      const int v = tid + sl * NT;
+      md_r[sl] = v < V ? m.mass[v] * (1.0 + ((cons && cons[v]) ? m.strength : 0.0)) : 0.0;
+      cb_r[sl] = v < V ? cbp[v] : 0.0;
+    }
     double rz = precondition();
     for (int k = tid; k < 3 * V; k += NT) ps[k] = rsl[k];
     if (tid < 12) ps[V * 3 + tid] = zq[tid];
@@ -1134,10 +1147,13 @@ __global__ __launch_bounds__(512, TACEX_BALL_WG_PER_CU) void fem_ball_newton_ker
       }
       __syncthreads();
       PCG_TICK(0);
-      for (int v = tid; v < V; v += NT) {
-        const double md = m.mass[v] * (1.0 + ((cons && cons[v]) ? m.strength : 0.0));
 #pragma unroll
-        for (int i = 0; i < 3; ++i) acc[v * 3 + i] += md * ps[v * 3 + i] + (i == 2 ? cbp[v] * ps[v * 3 + 2] : 0.0);  // acc IS H.p from here on
+      for (int sl = 0; sl < 2; ++sl) {  // (V <= 2 NT: ball_lds_ok)
+        const int v = tid + sl * NT;
+        if (v < V) {
+#pragma unroll
+          for (int i = 0; i < 3; ++i) acc[v * 3 + i] += md_r[sl] * ps[v * 3 + i] + (i == 2 ? cb_r[sl] * ps[v * 3 + 2] : 0.0);  // acc IS H.p from here on
+        }
       }
       if (tid < 12) {
         double sv = 0.0;
