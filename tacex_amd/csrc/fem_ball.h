@@ -210,6 +210,7 @@ __global__ __launch_bounds__(512, TACEX_BALL_WG_PER_CU) void fem_ball_newton_ker
   __shared__ double sh[17], sh2[16];
   __shared__ double gb[12], Bm[144], B0[144], Lc[144], Bi[144], YY[16], qs[12], qts[12], rhs12[12];
   __shared__ double crc[3 * kFemMaxCoarse], cyc[3 * kFemMaxCoarse];  // coarse residual / correction of the two-level preconditioner
+  __shared__ double Hw[8 * 12];  // per-wave partial sums of the ball rows of H.p over the pair / friction records (one copy: 61 records x 12 atomic adds on 12 addresses)
   __shared__ double cpart[6 * kFemMaxCoarse];                        // ... the two halves of the coarse solve's sums
   __shared__ double qps[12], Hpq[12], zq[12];  // ... | the ball rows of H.p and of z  // the ball rows the time step started from (friction slides relative to them)
   __shared__ int n_cpv, n_cpt, n_cpe, n_cbv, n_cbt, n_cbe, n_pairs, n_act, n_fric, s_flags;
@@ -421,7 +422,7 @@ __global__ __launch_bounds__(512, TACEX_BALL_WG_PER_CU) void fem_ball_newton_ker
   // pad's coarse space (restriction by ds_add_f64 from the vertices' own 8 (node, weight) pairs) + the exact inverse of the ball block.
   // Returns r . z.
 #ifdef TACEX_BALL_CLOCK  // debug build: cycles inside the PCG loop (sweep | vertex + records | dot + update | restriction + chains | coarse solve | prolongation + sum)
-  long long pck[6] = {0, 0, 0, 0, 0, 0}, pt0 = 0;
+  long long pck[7] = {0, 0, 0, 0, 0, 0, 0}, pt0 = 0;
 #define PCG_TICK0() do { pt0 = __builtin_readcyclecounter(); } while (0)
 #define PCG_TICK(k) do { const long long n_ = __builtin_readcyclecounter(); pck[k] += n_ - pt0; pt0 = n_; } while (0)
 #else
@@ -944,7 +945,9 @@ __global__ __launch_bounds__(512, TACEX_BALL_WG_PER_CU) void fem_ball_newton_ker
     if (fric) {  // friction of the lagged contacts at x: gradient, Hessians (kept for H.p), diagonal / ball blocks
       __syncthreads();
       const int nf = n_fric;
-      for (int k = tid; k < nf; k += NT) {
+      // (records dealt to the waves round-robin: the ball rows of every record go to the SAME 12 + 144 LDS addresses, and lanes of one wave
+      //  that add to one address are served one after the other - 60 records in wave 0 were 45 kcycles of this phase)
+      for (int k = (tid & 63) * 8 + (tid >> 6); k < nf; k += NT) {
         const double* rc = frec + (size_t)k * kBallRec;
         const int* ri = reinterpret_cast<const int*>(rc + 11);
         double u[3];
@@ -1160,10 +1163,14 @@ __global__ __launch_bounds__(512, TACEX_BALL_WG_PER_CU) void fem_ball_newton_ker
         for (int k = 0; k < 12; ++k) sv += B0[tid * 12 + k] * ps[V * 3 + k];
         Hpq[tid] = sv;
       }
+      if (tid >= 64 && tid < 64 + 96) Hw[tid - 64] = 0.0;
       __syncthreads();
+      PCG_TICK(6);
+      // records are dealt to the waves round-robin (record k -> wave k % 8, lane k / 8) and each wave adds the ball rows into its own copy
+      double* const hw = Hw + 12 * (tid >> 6);
       {
         const int na = n_act;
-        for (int k = tid; k < na; k += NT) {
+        for (int k = (tid & 63) * 8 + (tid >> 6); k < na; k += NT) {
           const double* rc = arec + (size_t)k * kBallRec;
           const int* ri = reinterpret_cast<const int*>(rc + 11);
           const double n0 = rc[1], n1 = rc[2], n2 = rc[3];
@@ -1176,9 +1183,9 @@ __global__ __launch_bounds__(512, TACEX_BALL_WG_PER_CU) void fem_ball_newton_ker
           const double f = rc[0] * gp;
 #pragma unroll
           for (int a4 = 0; a4 < 4; ++a4) {
-            atomicAdd(&Hpq[a4 * 3], f * rc[4 + a4] * n0);
-            atomicAdd(&Hpq[a4 * 3 + 1], f * rc[4 + a4] * n1);
-            atomicAdd(&Hpq[a4 * 3 + 2], f * rc[4 + a4] * n2);
+            atomicAdd(&hw[a4 * 3], f * rc[4 + a4] * n0);
+            atomicAdd(&hw[a4 * 3 + 1], f * rc[4 + a4] * n1);
+            atomicAdd(&hw[a4 * 3 + 2], f * rc[4 + a4] * n2);
           }
 #pragma unroll
           for (int r = 0; r < 3; ++r)
@@ -1191,7 +1198,7 @@ __global__ __launch_bounds__(512, TACEX_BALL_WG_PER_CU) void fem_ball_newton_ker
       }
       if (fric) {
         const int nf = n_fric;
-        for (int k = tid; k < nf; k += NT) {
+        for (int k = (tid & 63) * 8 + (tid >> 6); k < nf; k += NT) {
           const double* rc = frec + (size_t)k * kBallRec;
           const int* ri = reinterpret_cast<const int*>(rc + 11);
           const double* M = fM + (size_t)k * 6;
@@ -1211,7 +1218,7 @@ __global__ __launch_bounds__(512, TACEX_BALL_WG_PER_CU) void fem_ball_newton_ker
           for (int a4 = 0; a4 < 4; ++a4)
             if (rc[4 + a4] != 0.0)
 #pragma unroll
-              for (int i = 0; i < 3; ++i) atomicAdd(&Hpq[a4 * 3 + i], rc[4 + a4] * mw[i]);
+              for (int i = 0; i < 3; ++i) atomicAdd(&hw[a4 * 3 + i], rc[4 + a4] * mw[i]);
 #pragma unroll
           for (int r = 0; r < 3; ++r)
             if (ri[r] >= 0)
@@ -1224,6 +1231,8 @@ __global__ __launch_bounds__(512, TACEX_BALL_WG_PER_CU) void fem_ball_newton_ker
       double part = 0.0;
       for (int k = tid; k < 3 * V; k += NT) part += ps[k] * acc[k];
       if (tid < 12) {
+#pragma unroll
+        for (int w8 = 0; w8 < 8; ++w8) Hpq[tid] += Hw[w8 * 12 + tid];
         if (bd.kinematic) Hpq[tid] = 0.0;  // a fixed body: its rows of the operator are eliminated (only thread tid reads Hpq[tid] below)
         part += ps[V * 3 + tid] * Hpq[tid];
       }
@@ -1362,8 +1371,8 @@ __global__ __launch_bounds__(512, TACEX_BALL_WG_PER_CU) void fem_ball_newton_ker
   }
 #ifdef TACEX_BALL_CLOCK
   if (tid == 0 && (b == 0 || b == (int)gridDim.x - 1))
-    printf("ball clock env %d: newton %d pcg %d | kcycles: element %lld candidates %lld gradient+blocks %lld pairs+factor %lld PCG %lld stepbound %lld linesearch %lld | inside PCG: sweep %lld vertex+records %lld dot+update %lld restrict+chains %lld coarse %lld prolong+sum %lld\n", b,
-           n_newton, pcg_total, bck[0] / 1000, bck[1] / 1000, bck[2] / 1000, bck[3] / 1000, bck[4] / 1000, bck[5] / 1000, bck[6] / 1000, pck[0] / 1000, pck[1] / 1000,
+    printf("ball clock env %d: newton %d pcg %d | kcycles: element %lld candidates %lld gradient+blocks %lld pairs+factor %lld PCG %lld stepbound %lld linesearch %lld | inside PCG: sweep %lld vertex %lld records %lld dot+update %lld restrict+chains %lld coarse %lld prolong+sum %lld\n", b,
+           n_newton, pcg_total, bck[0] / 1000, bck[1] / 1000, bck[2] / 1000, bck[3] / 1000, bck[4] / 1000, bck[5] / 1000, bck[6] / 1000, pck[0] / 1000, pck[6] / 1000, pck[1] / 1000,
            pck[2] / 1000, pck[3] / 1000, pck[4] / 1000, pck[5] / 1000);
 #endif
   if (tid < 12) q[tid] = qs[tid];
