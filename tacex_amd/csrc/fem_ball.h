@@ -232,14 +232,14 @@ __global__ __launch_bounds__(512, TACEX_BALL_WG_PER_CU) void fem_ball_newton_ker
   double* ge = ws;
   double* tc = ge + (size_t)12 * T;
   double* hv = tc + (size_t)12 * T;
-  double* vg = hv + (size_t)12 * T;
-  double* vr = vg + (size_t)3 * VN;
+  double* vg_ws = hv + (size_t)12 * T;  // (gradient: lives in LDS, see vg below; the slot keeps the workspace layout)
+  double* vr = vg_ws + (size_t)3 * VN;
   double* vz = vr + (size_t)3 * VN;
   double* vd = vz + (size_t)3 * VN;  // (the PCG direction p lives in LDS: every tet gathers it)
   double* vHp = vd + (size_t)3 * VN;
   double* yc = vHp + (size_t)3 * VN;   // line-search candidate (pad rows | ball rows)
-  double* Dinv = yc + (size_t)3 * VN;  // (V,9)
-  double* cbp = Dinv + (size_t)9 * V;  // (V) ground curvature of the pad vertices at x (dt^2-scaled)
+  double* Dinv_ws = yc + (size_t)3 * VN;  // ((V,9) diagonal blocks: in LDS, see Dinv below)
+  double* cbp = Dinv_ws + (size_t)9 * V;  // (V) ground curvature of the pad vertices at x (dt^2-scaled)
   double* xb = cbp + V;                // (nv,3) ball surface points at x
   double* xbc = xb + (size_t)3 * nv;   // ... at the candidate
   double* dxb = xbc + (size_t)3 * nv;  // ... their displacement along the Newton direction
@@ -260,6 +260,12 @@ __global__ __launch_bounds__(512, TACEX_BALL_WG_PER_CU) void fem_ball_newton_ker
   double* rsl = acc + 3 * V;       // (V,3) z: the chain solve's r, then y, then z (in place), + the coarse correction
   double* rL = rsl + 3 * V;        // (V + 4,3) PCG residual
   double* dL = rL + 3 * VN;        // (V + 4,3) PCG solution (the Newton direction)
+  // While an iteration's system is SET UP the PCG vectors are idle: the gradient (3 (V + 4)) and the pad's diagonal blocks (V,9) are built in
+  // their place - hundreds of f64 atomic adds per iteration (pair / friction rows) then hit LDS instead of memory, and the chain
+  // factorisation reads its blocks from LDS.  vg = dL's slot (rL = -vg, dL = 0 is the hand-over, element by element); Dinv = acc | z | the pad
+  // rows of r, all read for the last time by the chain factorisation, one barrier before r is written.
+  double* const vg = dL;
+  double* const Dinv = acc;
   float* cf = reinterpret_cast<float*>(dL + 3 * VN);                      // (V,15) chain factors: S^-1 (upper triangle, 6) | G (9)
   unsigned short* cnx = reinterpret_cast<unsigned short*>(cf + 15 * V);   // (V) chain successor, 0xffff = none
   unsigned short* cpr = cnx + V;                                           // (V) predecessor
@@ -550,9 +556,14 @@ __global__ __launch_bounds__(512, TACEX_BALL_WG_PER_CU) void fem_ball_newton_ker
 
 #ifdef TACEX_BALL_CLOCK  // debug build: cycles of the phases of a step, printed by env 0 (scripts/r06/ball_clock.sh)
   long long bck[8] = {0, 0, 0, 0, 0, 0, 0, 0}, bt0 = __builtin_readcyclecounter();
+  long long sck[4] = {0, 0, 0, 0}, st0 = 0;
+#define SUB_TICK0() do { st0 = __builtin_readcyclecounter(); } while (0)
+#define SUB_TICK(k) do { const long long n_ = __builtin_readcyclecounter(); sck[k] += n_ - st0; st0 = n_; } while (0)
 #define BALL_TICK(k) do { const long long n_ = __builtin_readcyclecounter(); bck[k] += n_ - bt0; bt0 = n_; } while (0)
 #else
 #define BALL_TICK(k) do { } while (0)
+#define SUB_TICK0() do { } while (0)
+#define SUB_TICK(k) do { } while (0)
 #endif
   ball_points(qs, xb);
   __syncthreads();
@@ -824,6 +835,7 @@ __global__ __launch_bounds__(512, TACEX_BALL_WG_PER_CU) void fem_ball_newton_ker
     __syncthreads();
     BALL_TICK(2);  // gradient, elastic blocks, ground
     // ---- pairs at x: gradient, diagonal blocks, ball block, active records ----
+    SUB_TICK0();
     {
       const int np = n_pairs;
       for (int k = tid; k < np; k += NT) {
@@ -942,6 +954,7 @@ __global__ __launch_bounds__(512, TACEX_BALL_WG_PER_CU) void fem_ball_newton_ker
     __syncthreads();
     if (n_act > kBallMaxActive) { if (tid == 0) { s_flags |= kBallFlagOverflow; n_act = kBallMaxActive; } }
     if (n_fric > kBallMaxFric) { if (tid == 0) { s_flags |= kBallFlagOverflow; n_fric = kBallMaxFric; } }
+    SUB_TICK(0);
     if (fric) {  // friction of the lagged contacts at x: gradient, Hessians (kept for H.p), diagonal / ball blocks
       __syncthreads();
       const int nf = n_fric;
@@ -998,6 +1011,7 @@ __global__ __launch_bounds__(512, TACEX_BALL_WG_PER_CU) void fem_ball_newton_ker
       }
       __syncthreads();
     }
+    SUB_TICK(1);
     // ---- ball rows: gradient, the block without the pairs (H.p) and with them (preconditioner, factored) ----
     if (tid < 144) {
       const int ra = tid / 12, ca = tid - ra * 12, a4 = ra / 3, i = ra - a4 * 3, c4 = ca / 3, j = ca - c4 * 3;
@@ -1066,6 +1080,7 @@ __global__ __launch_bounds__(512, TACEX_BALL_WG_PER_CU) void fem_ball_newton_ker
       if (tid == 0 && step_info) step_info[(size_t)b * 4 + 2] = (double)s_flags;
       return;
     }
+    SUB_TICK(2);
     // block part of the pad's preconditioner: block-tridiagonal LDL^T along the vertex chains of tacex_fem_set_chains (the columns of
     // vertices through the pad's thickness; a chain of one vertex = 3 x 3 block Jacobi) - S_0 = D_0, G_i = S_i^-1 E_i,
     // S_{i+1} = D_{i+1} - E_i^T G_i, the thread of a chain walks it (fem_newton_lds_kernel does the same); S^-1 | G as floats in LDS
@@ -1109,8 +1124,10 @@ __global__ __launch_bounds__(512, TACEX_BALL_WG_PER_CU) void fem_ball_newton_ker
         v = n;
       }
     }
+    __syncthreads();  // (the chains have read their blocks: r may take over the tail of their slot)
     for (int k = tid; k < 3 * VN; k += NT) { rL[k] = (bd.kinematic && k >= 3 * V) ? 0.0 : -vg[k]; dL[k] = 0.0; }  // (a fixed body: zero residual rows stay zero through the PCG)
     __syncthreads();
+    SUB_TICK(3);
     BALL_TICK(3);  // pairs, friction, ball blocks, factorisation, pad block inverses
     // ---- PCG: every vector in LDS (x, p, H.p = the accumulators of the tets' rows, z, r, d); the mesh constants, the blocks' tables and
     //      the pair records are what it reads from memory ----
@@ -1371,9 +1388,9 @@ __global__ __launch_bounds__(512, TACEX_BALL_WG_PER_CU) void fem_ball_newton_ker
   }
 #ifdef TACEX_BALL_CLOCK
   if (tid == 0 && (b == 0 || b == (int)gridDim.x - 1))
-    printf("ball clock env %d: newton %d pcg %d | kcycles: element %lld candidates %lld gradient+blocks %lld pairs+factor %lld PCG %lld stepbound %lld linesearch %lld | inside PCG: sweep %lld vertex %lld records %lld dot+update %lld restrict+chains %lld coarse %lld prolong+sum %lld\n", b,
+    printf("ball clock env %d: newton %d pcg %d | kcycles: element %lld candidates %lld gradient+blocks %lld pairs+factor %lld PCG %lld stepbound %lld linesearch %lld | inside PCG: sweep %lld vertex %lld records %lld dot+update %lld restrict+chains %lld coarse %lld prolong+sum %lld | phase 3: pairs %lld friction %lld ball block %lld chains %lld\n", b,
            n_newton, pcg_total, bck[0] / 1000, bck[1] / 1000, bck[2] / 1000, bck[3] / 1000, bck[4] / 1000, bck[5] / 1000, bck[6] / 1000, pck[0] / 1000, pck[6] / 1000, pck[1] / 1000,
-           pck[2] / 1000, pck[3] / 1000, pck[4] / 1000, pck[5] / 1000);
+           pck[2] / 1000, pck[3] / 1000, pck[4] / 1000, pck[5] / 1000, sck[0] / 1000, sck[1] / 1000, sck[2] / 1000, sck[3] / 1000);
 #endif
   if (tid < 12) q[tid] = qs[tid];
   if (tid == 0 && step_info) {
