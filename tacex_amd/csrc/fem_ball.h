@@ -566,6 +566,7 @@ __global__ __launch_bounds__(512, TACEX_BALL_WG_PER_CU) void fem_ball_newton_ker
 #define SUB_TICK(k) do { } while (0)
 #endif
   ball_points(qs, xb);
+  for (int k = tid; k < 3 * V; k += NT) xs[k] = x[k];
   __syncthreads();
   int n_newton = 0, pcg_total = 0;
   double e_carry = 0.0;
@@ -574,17 +575,21 @@ __global__ __launch_bounds__(512, TACEX_BALL_WG_PER_CU) void fem_ball_newton_ker
   for (int nit = 0; nit < max_newton; ++nit) {
     const bool take_lag = fric && (nit == 0);  // (the first iteration stands at the state the step starts from)
     // ---- element pass (as fem_newton_kernel) + bounding spheres of the ball triangles + candidate lists ----
-    for (int t = tid; t < T; t += NT) {
+    for (int k = tid; k < 3 * VN; k += NT) vg[k] = 0.0;
+    __syncthreads();
+    for (int t = tid; t < T; t += NT) {  // (the tets' rows go straight into the LDS gradient: no (12,T) array through memory, no gather)
       int v[4];
       double Di[9], F[9], r[12], g[12];
       load_tet(m, t, v, Di);
-      deformation_gradient(x, v, Di, F);
+      deformation_gradient(xs, v, Di, F);
       TetState s;
       tet_state(m, F, s);
       shape_rows(Di, r);
       element_gradient(s, r, dt2 * m.vol[t], g);
 #pragma unroll
-      for (int k = 0; k < 12; ++k) ge[(size_t)k * T + t] = g[k];
+      for (int w4 = 0; w4 < 4; ++w4)
+#pragma unroll
+        for (int i = 0; i < 3; ++i) atomicAdd(&vg[v[w4] * 3 + i], g[w4 * 3 + i]);
     }
     double rb = 0.0;  // bounding radius of the ball about p
     for (int k = tid; k < nv; k += NT) {
@@ -764,8 +769,7 @@ __global__ __launch_bounds__(512, TACEX_BALL_WG_PER_CU) void fem_ball_newton_ker
     BALL_TICK(1);  // candidates, pair list
     // ---- nodal gradient, diagonal blocks (pad rows; pairs are added below), ground ----
     for (int v = tid; v < V; v += NT) {
-      double a3[3];
-      gather_vertex(m, ge, v, a3);
+      const double a3[3] = {vg[v * 3], vg[v * 3 + 1], vg[v * 3 + 2]};  // (the element pass's sums)
       const double mv = m.mass[v];
       const bool c = cons && cons[v];
       const double md = mv * (1.0 + (c ? m.strength : 0.0));
@@ -1131,7 +1135,7 @@ __global__ __launch_bounds__(512, TACEX_BALL_WG_PER_CU) void fem_ball_newton_ker
     BALL_TICK(3);  // pairs, friction, ball blocks, factorisation, pad block inverses
     // ---- PCG: every vector in LDS (x, p, H.p = the accumulators of the tets' rows, z, r, d); the mesh constants, the blocks' tables and
     //      the pair records are what it reads from memory ----
-    for (int k = tid; k < 3 * V; k += NT) { xs[k] = x[k]; acc[k] = 0.0; }
+    for (int k = tid; k < 3 * V; k += NT) acc[k] = 0.0;  // (xs holds x since the kernel's start / the last accepted step)
     __syncthreads();
     double md_r[2], cb_r[2];  // this thread's vertices: mass (+ constraint) diagonal and ground curvature, constant through the PCG loop
 #pragma unroll
@@ -1374,7 +1378,7 @@ __global__ __launch_bounds__(512, TACEX_BALL_WG_PER_CU) void fem_ball_newton_ker
              E0, E1 - E0, dmx, dx_tol, dmc, dc_tol, n_pairs, n_act, n_fric);
 #endif
     if (accepted) {
-      for (int k = tid; k < 3 * V; k += NT) x[k] = yc[k];
+      for (int k = tid; k < 3 * V; k += NT) { x[k] = yc[k]; xs[k] = yc[k]; }
       for (int k = tid; k < 3 * nv; k += NT) xb[k] = xbc[k];
       __syncthreads();
       if (tid < 12) qs[tid] = rhs12[tid];
