@@ -265,6 +265,7 @@ __global__ __launch_bounds__(512, TACEX_BALL_WG_PER_CU) void fem_ball_newton_ker
   // factorisation reads its blocks from LDS.  vg = dL's slot (rL = -vg, dL = 0 is the hand-over, element by element); Dinv = acc | z | the pad
   // rows of r, all read for the last time by the chain factorisation, one barrier before r is written.
   double* const vg = dL;
+  double* const ycl = ps;  // line-search candidate (pad rows): the PCG direction's slot, idle between the PCG loop and the next one
   double* const Dinv = acc;
   float* cf = reinterpret_cast<float*>(dL + 3 * VN);                      // (V,15) chain factors: S^-1 (upper triangle, 6) | G (9)
   unsigned short* cnx = reinterpret_cast<unsigned short*>(cf + 15 * V);   // (V) chain successor, 0xffff = none
@@ -618,7 +619,7 @@ __global__ __launch_bounds__(512, TACEX_BALL_WG_PER_CU) void fem_ball_newton_ker
     // are found pair by pair below
     for (int k = tid; k < bd.nsv; k += NT) {
       const int v = bd.psv[k];
-      const double r0 = x[v * 3] - qs[0], r1 = x[v * 3 + 1] - qs[1], r2 = x[v * 3 + 2] - qs[2];
+      const double r0 = xs[v * 3] - qs[0], r1 = xs[v * 3 + 1] - qs[1], r2 = xs[v * 3 + 2] - qs[2];
       const double lim = rb + L;
       if (r0 * r0 + r1 * r1 + r2 * r2 < lim * lim) {
         const int s = atomicAdd(&n_cpv, 1);
@@ -629,10 +630,10 @@ __global__ __launch_bounds__(512, TACEX_BALL_WG_PER_CU) void fem_ball_newton_ker
       const int* tr = bd.ptri + k * 3;
       double c3[3], rt = 0.0;
 #pragma unroll
-      for (int i = 0; i < 3; ++i) c3[i] = (x[tr[0] * 3 + i] + x[tr[1] * 3 + i] + x[tr[2] * 3 + i]) * (1.0 / 3.0);
+      for (int i = 0; i < 3; ++i) c3[i] = (xs[tr[0] * 3 + i] + xs[tr[1] * 3 + i] + xs[tr[2] * 3 + i]) * (1.0 / 3.0);
 #pragma unroll
       for (int j = 0; j < 3; ++j) {
-        const double r0 = x[tr[j] * 3] - c3[0], r1 = x[tr[j] * 3 + 1] - c3[1], r2 = x[tr[j] * 3 + 2] - c3[2];
+        const double r0 = xs[tr[j] * 3] - c3[0], r1 = xs[tr[j] * 3 + 1] - c3[1], r2 = xs[tr[j] * 3 + 2] - c3[2];
         rt = fmax(rt, sqrt(r0 * r0 + r1 * r1 + r2 * r2));
       }
       const double r0 = c3[0] - qs[0], r1 = c3[1] - qs[1], r2 = c3[2] - qs[2];
@@ -648,7 +649,7 @@ __global__ __launch_bounds__(512, TACEX_BALL_WG_PER_CU) void fem_ball_newton_ker
         double r2 = 0.0, h2 = 0.0;
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
-          const double mi = 0.5 * (x[ed[0] * 3 + i] + x[ed[1] * 3 + i]) - qs[i], hi = 0.5 * (x[ed[1] * 3 + i] - x[ed[0] * 3 + i]);
+          const double mi = 0.5 * (xs[ed[0] * 3 + i] + xs[ed[1] * 3 + i]) - qs[i], hi = 0.5 * (xs[ed[1] * 3 + i] - xs[ed[0] * 3 + i]);
           r2 += mi * mi; h2 += hi * hi;
         }
         const double lim = rb + L + sqrt(h2);
@@ -665,7 +666,7 @@ __global__ __launch_bounds__(512, TACEX_BALL_WG_PER_CU) void fem_ball_newton_ker
     double lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
     auto grow = [&](int v) {
 #pragma unroll
-      for (int i = 0; i < 3; ++i) { lo[i] = fmin(lo[i], x[v * 3 + i]); hi[i] = fmax(hi[i], x[v * 3 + i]); }
+      for (int i = 0; i < 3; ++i) { lo[i] = fmin(lo[i], xs[v * 3 + i]); hi[i] = fmax(hi[i], xs[v * 3 + i]); }
     };
     for (int k = tid; k < ncpv; k += NT) grow(cpv[k]);
     for (int k = tid; k < ncpt; k += NT) { const int* tr = bd.ptri + cpt[k] * 3; grow(tr[0]); grow(tr[1]); grow(tr[2]); }
@@ -709,13 +710,13 @@ __global__ __launch_bounds__(512, TACEX_BALL_WG_PER_CU) void fem_ball_newton_ker
     // pairs, kind 0: candidate pad vertex x candidate ball triangle
     for (int k = tid; k < ncpv * ncbt; k += NT) {
       const int v = cpv[k / ncbt], t = cbt[k - (k / ncbt) * ncbt];
-      const double r0 = x[v * 3] - bts[t * 4], r1 = x[v * 3 + 1] - bts[t * 4 + 1], r2 = x[v * 3 + 2] - bts[t * 4 + 2];
+      const double r0 = xs[v * 3] - bts[t * 4], r1 = xs[v * 3 + 1] - bts[t * 4 + 1], r2 = xs[v * 3 + 2] - bts[t * 4 + 2];
       const double lim = L + bts[t * 4 + 3];
       if (r0 * r0 + r1 * r1 + r2 * r2 >= lim * lim) continue;
       const int* tr = bd.tri + t * 3;
       double p3[3], a[3], bq[3], c[3], be[3], d, n[3];
 #pragma unroll
-      for (int i = 0; i < 3; ++i) { p3[i] = x[v * 3 + i]; a[i] = xb[tr[0] * 3 + i]; bq[i] = xb[tr[1] * 3 + i]; c[i] = xb[tr[2] * 3 + i]; }
+      for (int i = 0; i < 3; ++i) { p3[i] = xs[v * 3 + i]; a[i] = xb[tr[0] * 3 + i]; bq[i] = xb[tr[1] * 3 + i]; c[i] = xb[tr[2] * 3 + i]; }
       pt_closest(p3, a, bq, c, be, d, n);
       if (d < L) {
         const int s = atomicAdd(&n_pairs, 1);
@@ -728,7 +729,7 @@ __global__ __launch_bounds__(512, TACEX_BALL_WG_PER_CU) void fem_ball_newton_ker
       const int* tr = bd.ptri + t * 3;
       double p3[3], a[3], bq[3], c[3], be[3], d, n[3];
 #pragma unroll
-      for (int i = 0; i < 3; ++i) { p3[i] = xb[bv * 3 + i]; a[i] = x[tr[0] * 3 + i]; bq[i] = x[tr[1] * 3 + i]; c[i] = x[tr[2] * 3 + i]; }
+      for (int i = 0; i < 3; ++i) { p3[i] = xb[bv * 3 + i]; a[i] = xs[tr[0] * 3 + i]; bq[i] = xs[tr[1] * 3 + i]; c[i] = xs[tr[2] * 3 + i]; }
       // sphere test about the triangle's first corner (its edges are bounded by the distance test itself: cheap rejection)
       const double r0 = p3[0] - a[0], r1 = p3[1] - a[1], r2 = p3[2] - a[2];
       const double e0 = bq[0] - a[0], e1 = bq[1] - a[1], e2 = bq[2] - a[2], f0 = c[0] - a[0], f1 = c[1] - a[1], f2 = c[2] - a[2];
@@ -750,7 +751,7 @@ __global__ __launch_bounds__(512, TACEX_BALL_WG_PER_CU) void fem_ball_newton_ker
       double r2 = 0.0, ha = 0.0, hb = 0.0;
 #pragma unroll
       for (int i = 0; i < 3; ++i) {
-        a0[i] = x[ea[0] * 3 + i]; a1[i] = x[ea[1] * 3 + i]; b0[i] = xb[eb[0] * 3 + i]; b1[i] = xb[eb[1] * 3 + i];
+        a0[i] = xs[ea[0] * 3 + i]; a1[i] = xs[ea[1] * 3 + i]; b0[i] = xb[eb[0] * 3 + i]; b1[i] = xb[eb[1] * 3 + i];
         const double mi = 0.5 * ((a0[i] + a1[i]) - (b0[i] + b1[i])), hai = 0.5 * (a1[i] - a0[i]), hbi = 0.5 * (b1[i] - b0[i]);
         r2 += mi * mi; ha += hai * hai; hb += hbi * hbi;
       }
@@ -778,8 +779,8 @@ __global__ __launch_bounds__(512, TACEX_BALL_WG_PER_CU) void fem_ball_newton_ker
       const double w = bd.parea[v];
       if (bd.ground && w > 0.0) {
         double bb, b1, b2;
-        barrier3((x[v * 3 + 2] - bd.gh) / dhat, bb, b1, b2);
-        if (!(x[v * 3 + 2] - bd.gh > 0.0)) atomicOr(&s_flags, kFemFlagPenetration);
+        barrier3((xs[v * 3 + 2] - bd.gh) / dhat, bb, b1, b2);
+        if (!(xs[v * 3 + 2] - bd.gh > 0.0)) atomicOr(&s_flags, kFemFlagPenetration);
         gz = kk * w * b1 / dhat;
         cb = kk * w * b2 / (dhat * dhat);
         D[8] += cb;
@@ -803,8 +804,8 @@ __global__ __launch_bounds__(512, TACEX_BALL_WG_PER_CU) void fem_ball_newton_ker
       for (int k = 0; k < 9; ++k) Dinv[(size_t)v * 9 + k] = D[k];
 #pragma unroll
       for (int i = 0; i < 3; ++i) {
-        double gi = a3[i] + mv * (x[v * 3 + i] - xt[v * 3 + i]);
-        if (c) gi += m.strength * mv * (x[v * 3 + i] - aim[v * 3 + i]);
+        double gi = a3[i] + mv * (xs[v * 3 + i] - xt[v * 3 + i]);
+        if (c) gi += m.strength * mv * (xs[v * 3 + i] - aim[v * 3 + i]);
         vg[v * 3 + i] = gi + (i == 2 ? gz : 0.0);
       }
     }
@@ -853,7 +854,7 @@ __global__ __launch_bounds__(512, TACEX_BALL_WG_PER_CU) void fem_ball_newton_ker
           const int* eb = bd.bedge + tj * 2;
           double a0[3], a1[3], b0[3], b1[3], sa, tb, mol, dm, e1[3], e2[3], u[3];
 #pragma unroll
-          for (int i = 0; i < 3; ++i) { a0[i] = x[ea[0] * 3 + i]; a1[i] = x[ea[1] * 3 + i]; b0[i] = xb[eb[0] * 3 + i]; b1[i] = xb[eb[1] * 3 + i]; }
+          for (int i = 0; i < 3; ++i) { a0[i] = xs[ea[0] * 3 + i]; a1[i] = xs[ea[1] * 3 + i]; b0[i] = xb[eb[0] * 3 + i]; b1[i] = xb[eb[1] * 3 + i]; }
           ee_closest(a0, a1, b0, b1, sa, tb, d, n);
           if (!(d < dhat)) continue;
           ee_mollifier(a0, a1, b0, b1, 1e-3 * bd.pelen2[pi] * bd.belen2[tj], mol, dm, e1, e2, u);
@@ -877,11 +878,11 @@ __global__ __launch_bounds__(512, TACEX_BALL_WG_PER_CU) void fem_ball_newton_ker
           double p3[3], a[3], bq[3], c[3], be[3];
           if (kind == 0) {
 #pragma unroll
-            for (int i = 0; i < 3; ++i) { p3[i] = x[pi * 3 + i]; a[i] = xb[t0 * 3 + i]; bq[i] = xb[t1 * 3 + i]; c[i] = xb[t2 * 3 + i]; }
+            for (int i = 0; i < 3; ++i) { p3[i] = xs[pi * 3 + i]; a[i] = xb[t0 * 3 + i]; bq[i] = xb[t1 * 3 + i]; c[i] = xb[t2 * 3 + i]; }
             w = bd.parea[pi];
           } else {
 #pragma unroll
-            for (int i = 0; i < 3; ++i) { p3[i] = xb[pi * 3 + i]; a[i] = x[t0 * 3 + i]; bq[i] = x[t1 * 3 + i]; c[i] = x[t2 * 3 + i]; }
+            for (int i = 0; i < 3; ++i) { p3[i] = xb[pi * 3 + i]; a[i] = xs[t0 * 3 + i]; bq[i] = xs[t1 * 3 + i]; c[i] = xs[t2 * 3 + i]; }
             w = bd.area[pi];
           }
           pt_closest(p3, a, bq, c, be, d, n);
@@ -968,7 +969,7 @@ __global__ __launch_bounds__(512, TACEX_BALL_WG_PER_CU) void fem_ball_newton_ker
         const double* rc = frec + (size_t)k * kBallRec;
         const int* ri = reinterpret_cast<const int*>(rc + 11);
         double u[3];
-        fric_u(rc, x, qs, u);
+        fric_u(rc, xs, qs, u);
         const double yv = sqrt(u[0] * u[0] + u[1] * u[1] + u[2] * u[2]);
         const bool stick = yv < f_eps;
         const double fa = stick ? 2.0 / f_eps - yv / (f_eps * f_eps) : 1.0 / yv;
@@ -1294,7 +1295,7 @@ __global__ __launch_bounds__(512, TACEX_BALL_WG_PER_CU) void fem_ball_newton_ker
       dmx = fmax(dmx, fmax(fabs(d0), fmax(fabs(d1), fabs(d2))));
       if (bd.parea[v] > 0.0) {
         vmax = fmax(vmax, sqrt(d0 * d0 + d1 * d1 + d2 * d2));
-        const double gap = x[v * 3 + 2] - bd.gh;
+        const double gap = xs[v * 3 + 2] - bd.gh;
         if (bd.ground && d2 < 0.0 && gap > 0.0) amax = fmin(amax, kCcdSlack * gap / -d2);
       }
     }
@@ -1325,7 +1326,7 @@ __global__ __launch_bounds__(512, TACEX_BALL_WG_PER_CU) void fem_ball_newton_ker
           for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int i = 0; i < 3; ++i) {
-              pa[j * 3 + i] = x[ea[j] * 3 + i]; da[j * 3 + i] = vd[ea[j] * 3 + i];
+              pa[j * 3 + i] = xs[ea[j] * 3 + i]; da[j * 3 + i] = vd[ea[j] * 3 + i];
               pb[j * 3 + i] = xb[eb[j] * 3 + i]; db[j * 3 + i] = dxb[eb[j] * 3 + i];
             }
           double sa, tb, d, n[3];
@@ -1335,9 +1336,9 @@ __global__ __launch_bounds__(512, TACEX_BALL_WG_PER_CU) void fem_ball_newton_ker
         }
         const int* tr = (kind == 0 ? bd.tri : bd.ptri) + tj * 3;
         double p3[3], trx[9], dp[3], dtr[9];
-        const double* P = kind == 0 ? x : xb;
+        const double* P = kind == 0 ? xs : xb;
         const double* dP_ = kind == 0 ? vd : dxb;
-        const double* Tq = kind == 0 ? xb : x;
+        const double* Tq = kind == 0 ? xb : xs;
         const double* dT = kind == 0 ? dxb : vd;
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
@@ -1355,17 +1356,17 @@ __global__ __launch_bounds__(512, TACEX_BALL_WG_PER_CU) void fem_ball_newton_ker
     // ---- backtracking line search (first E <= E0 wins; rescue halvings as in the other Newton kernels) ----
     BALL_TICK(5);  // step bound (ground, additive CCD)
     // E(x): the accepted candidate's energy of the previous iteration IS this iteration's (every pair inside d_hat is in both lists)
-    const double E0 = have_e ? e_carry : energy(x, qs, xb);
+    const double E0 = have_e ? e_carry : energy(xs, qs, xb);
     double step = amax, E1 = E0;
     bool accepted = false;
     const int ls_cap = ls_max_iter > kLsRescueStream ? ls_max_iter : kLsRescueStream;
     for (int ls = 0; ls <= ls_cap; ++ls) {
-      for (int k = tid; k < 3 * V; k += NT) yc[k] = x[k] + step * vd[k];
-      if (tid < 12) rhs12[tid] = qs[tid] + step * vd[V * 3 + tid];
+      for (int k = tid; k < 3 * V; k += NT) ycl[k] = xs[k] + step * dL[k];  // (the candidate in the idle PCG direction's slot; dL still holds d)
+      if (tid < 12) rhs12[tid] = qs[tid] + step * dL[V * 3 + tid];
       __syncthreads();
       ball_points(rhs12, xbc);
       __syncthreads();
-      const double Ec = energy(yc, rhs12, xbc);
+      const double Ec = energy(ycl, rhs12, xbc);
       if (Ec <= E0) { E1 = Ec; accepted = true; e_carry = Ec; have_e = true; break; }
       step *= 0.5;
       __syncthreads();
@@ -1378,7 +1379,7 @@ __global__ __launch_bounds__(512, TACEX_BALL_WG_PER_CU) void fem_ball_newton_ker
              E0, E1 - E0, dmx, dx_tol, dmc, dc_tol, n_pairs, n_act, n_fric);
 #endif
     if (accepted) {
-      for (int k = tid; k < 3 * V; k += NT) { x[k] = yc[k]; xs[k] = yc[k]; }
+      for (int k = tid; k < 3 * V; k += NT) { const double v_ = ycl[k]; x[k] = v_; xs[k] = v_; }
       for (int k = tid; k < 3 * nv; k += NT) xb[k] = xbc[k];
       __syncthreads();
       if (tid < 12) qs[tid] = rhs12[tid];
