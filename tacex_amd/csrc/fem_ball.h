@@ -13,14 +13,16 @@
 //     Hessians b'' grad d grad d^T;
 //   * lagged Coulomb friction of every one of those contacts (the cfg's one default contact model, US:103-124 / 192-201): normal force,
 //     normal and barycentric weights frozen at the state the step starts from, sliding measured relative to it (IPC's lag);
-//   * matrix-free PCG: x, p and the per-vertex H.p accumulators in LDS (tet rows by ds_add_f64, the tet state recomputed from x);
-//     preconditioner = 3 x 3 blocks on the pad vertices + the additive coarse correction of the pad's coarse space
-//     (tacex_fem_set_coarse_space) + the EXACT inverse of the 12 x 12 ball block;
+//   * matrix-free PCG, every vector in LDS (tet rows by ds_add_f64, the tet state recomputed from x); preconditioner = the pad's vertex
+//     chains (block-tridiagonal LDL^T through the thickness; a chain of one vertex = a 3 x 3 block) + the additive coarse correction of
+//     the pad's coarse space (tacex_fem_set_coarse_space) + the EXACT inverse of the 12 x 12 ball block;
 //   * step bound: ground gaps (linear), additive CCD on the listed pairs, no surface point further than 0.9 d_hat per iteration;
 //   * backtracking line search on the plain incremental potential; convergence on the unscaled direction: velocity_tol * dt on the
 //     position rows AND transrate_tol * dt on the ball's affine rows (UipcSimCfg.newton, uipc_sim.py:62-66).
-// One workgroup (512 threads) per env, the whole Newton loop of a time step in ONE launch.  The pad's r, z, d, H.p and blocks live in
-// the env's workspace block (L2 / HBM); pair candidates are rebuilt once per Newton iteration at reach 2.8 d_hat, which no pair
+// One workgroup (512 threads) per env, the whole Newton loop of a time step in ONE launch.  x and the six PCG vectors live in LDS for the
+// whole launch; while an iteration's system is set up the idle PCG vectors hold the gradient, the pad's 3 x 3 blocks and, in the line
+// search, the candidate; the workspace block (L2 / HBM) keeps the pair list and records, the ball's surface points and the direction for
+// the step bound.  Pair candidates are rebuilt once per Newton iteration at reach 2.8 d_hat, which no pair
 // outside can cross into d_hat within one bounded step, so the line search's energies are exact.  (The CU-resident kernel of the
 // prescribed-indenter scenes keeps ALL per-vertex state in registers and is at its register limit: this scene got a kernel of its own.)
 
@@ -58,7 +60,9 @@ constexpr int kBallMaxFric = 1024;    // lagged friction contacts per env and ti
 constexpr int kBallFlagOverflow = 16; // step_info flag: a candidate / pair list overflowed (the scene is outside what this slice handles)
 
 // workspace of one env (doubles): ge 12T | tc 12T | hv 12T | g r z p d Hp yc: 7 x 3 (V+4) | D / Dinv 9V | ground curvature V |
-//   xb 3nv | xbc 3nv | dxb 3nv | ball triangle spheres 4nt | pair list (ints) kBallMaxPairs / 2 | active records
+//   xb 3nv | xbc 3nv | dxb 3nv | ball triangle spheres 4nt | pair list (ints) kBallMaxPairs / 2 | active records | friction records
+//   (the layout of the first cut; of the first three rows only d (direction for the step bound) and the ground curvature are still used -
+//    the rest moved to LDS - and stay allocated)
 // dynamic LDS: x (V,3) | p (V + 4,3) | H.p accumulators = H.p (V,3) | z (V,3) | r (V + 4,3) | d (V + 4,3) (doubles) || chain factors (V,15)
 // (floats) || chain successor / predecessor (V each, u16): every vector of the PCG loop, 104 KB at 495 vertices
 __host__ __device__ inline size_t ball_lds_bytes(int V) {
