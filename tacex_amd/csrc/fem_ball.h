@@ -59,17 +59,16 @@ constexpr double kBallKeep = 0.1;     // ... which may keep this fraction of the
 constexpr int kBallMaxFric = 1024;    // lagged friction contacts per env and time step (pairs + ground)
 constexpr int kBallFlagOverflow = 16; // step_info flag: a candidate / pair list overflowed (the scene is outside what this slice handles)
 
-// workspace of one env (doubles): ge 12T | tc 12T | hv 12T | g r z p d Hp yc: 7 x 3 (V+4) | D / Dinv 9V | ground curvature V |
-//   xb 3nv | xbc 3nv | dxb 3nv | ball triangle spheres 4nt | pair list (ints) kBallMaxPairs / 2 | active records | friction records
-//   (the layout of the first cut; of the first three rows only d (direction for the step bound) and the ground curvature are still used -
-//    the rest moved to LDS - and stay allocated)
+// workspace of one env (doubles): ground curvature V | xb 3nv | xbc 3nv | dxb 3nv | ball triangle spheres 4nt | pair list (ints)
+//   kBallMaxPairs / 2 | active records | friction records + their Hessians.  (Everything per-vertex lives in LDS.)
 // dynamic LDS: x (V,3) | p (V + 4,3) | H.p accumulators = H.p (V,3) | z (V,3) | r (V + 4,3) | d (V + 4,3) (doubles) || chain factors (V,15)
 // (floats) || chain successor / predecessor (V each, u16): every vector of the PCG loop, 104 KB at 495 vertices
 __host__ __device__ inline size_t ball_lds_bytes(int V) {
   return ((((size_t)18 * V + 36) * sizeof(double) + (size_t)15 * V * sizeof(float) + (size_t)2 * V * sizeof(unsigned short)) + 15) & ~(size_t)15;
 }
 __host__ __device__ inline size_t ball_ws_doubles(int V, int T, int nv, int nt) {
-  return (size_t)36 * T + (size_t)21 * (V + 4) + (size_t)10 * V + (size_t)9 * nv + (size_t)4 * nt + kBallMaxPairs / 2 + (size_t)kBallMaxActive * kBallRec +
+  (void)T;
+  return (size_t)V + (size_t)9 * nv + (size_t)4 * nt + kBallMaxPairs / 2 + (size_t)kBallMaxActive * kBallRec +
          (size_t)kBallMaxFric * (kBallRec + 6);  // lagged friction records + their Hessians at the iteration's state
 }
 
@@ -233,17 +232,7 @@ __global__ __launch_bounds__(512, TACEX_BALL_WG_PER_CU) void fem_ball_newton_ker
   const uint8_t* cons = consg ? consg + (size_t)b * V : nullptr;
   const double* aim = aimg ? aimg + o : nullptr;
   double* ws = wsg + (size_t)b * ball_ws_doubles(V, T, nv, nt);
-  double* ge = ws;
-  double* tc = ge + (size_t)12 * T;
-  double* hv = tc + (size_t)12 * T;
-  double* vg_ws = hv + (size_t)12 * T;  // (gradient: lives in LDS, see vg below; the slot keeps the workspace layout)
-  double* vr = vg_ws + (size_t)3 * VN;
-  double* vz = vr + (size_t)3 * VN;
-  double* vd = vz + (size_t)3 * VN;  // (the PCG direction p lives in LDS: every tet gathers it)
-  double* vHp = vd + (size_t)3 * VN;
-  double* yc = vHp + (size_t)3 * VN;   // line-search candidate (pad rows | ball rows)
-  double* Dinv_ws = yc + (size_t)3 * VN;  // ((V,9) diagonal blocks: in LDS, see Dinv below)
-  double* cbp = Dinv_ws + (size_t)9 * V;  // (V) ground curvature of the pad vertices at x (dt^2-scaled)
+  double* cbp = ws;                    // (V) ground curvature of the pad vertices at x (dt^2-scaled)
   double* xb = cbp + V;                // (nv,3) ball surface points at x
   double* xbc = xb + (size_t)3 * nv;   // ... at the candidate
   double* dxb = xbc + (size_t)3 * nv;  // ... their displacement along the Newton direction
@@ -1284,18 +1273,16 @@ __global__ __launch_bounds__(512, TACEX_BALL_WG_PER_CU) void fem_ball_newton_ker
       __syncthreads();
     }
     __syncthreads();
-    for (int k = tid; k < 3 * VN; k += NT) vd[k] = dL[k];  // the direction goes to memory for the step bound and the line search
-    __syncthreads();
     pcg_total += it;
     BALL_TICK(4);  // PCG
     // ---- step bound ----
-    if (tid < 12) rhs12[tid] = vd[V * 3 + tid];
+    if (tid < 12) rhs12[tid] = dL[V * 3 + tid];
     __syncthreads();
     ball_points(rhs12, dxb);
     __syncthreads();
     double amax = 1.0, vmax = 0.0, dmx = 0.0, dmc = 0.0;
     for (int v = tid; v < V; v += NT) {
-      const double d0 = vd[v * 3], d1 = vd[v * 3 + 1], d2 = vd[v * 3 + 2];
+      const double d0 = dL[v * 3], d1 = dL[v * 3 + 1], d2 = dL[v * 3 + 2];
       dmx = fmax(dmx, fmax(fabs(d0), fmax(fabs(d1), fabs(d2))));
       if (bd.parea[v] > 0.0) {
         vmax = fmax(vmax, sqrt(d0 * d0 + d1 * d1 + d2 * d2));
@@ -1309,8 +1296,8 @@ __global__ __launch_bounds__(512, TACEX_BALL_WG_PER_CU) void fem_ball_newton_ker
       const double gap = xb[k * 3 + 2] - bd.gh;
       if (bd.ground && d2 < 0.0 && gap > 0.0) amax = fmin(amax, kCcdSlack * gap / -d2);
     }
-    if (tid < 3) dmx = fmax(dmx, fabs(vd[V * 3 + tid]));
-    if (tid >= 3 && tid < 12) dmc = fabs(vd[V * 3 + tid]);
+    if (tid < 3) dmx = fmax(dmx, fabs(dL[V * 3 + tid]));
+    if (tid >= 3 && tid < 12) dmc = fabs(dL[V * 3 + tid]);
     vmax = block_sum_max(vmax, sh);
     dmx = block_sum_max(dmx, sh);
     dmc = block_sum_max(dmc, sh);
@@ -1330,7 +1317,7 @@ __global__ __launch_bounds__(512, TACEX_BALL_WG_PER_CU) void fem_ball_newton_ker
           for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int i = 0; i < 3; ++i) {
-              pa[j * 3 + i] = xs[ea[j] * 3 + i]; da[j * 3 + i] = vd[ea[j] * 3 + i];
+              pa[j * 3 + i] = xs[ea[j] * 3 + i]; da[j * 3 + i] = dL[ea[j] * 3 + i];
               pb[j * 3 + i] = xb[eb[j] * 3 + i]; db[j * 3 + i] = dxb[eb[j] * 3 + i];
             }
           double sa, tb, d, n[3];
@@ -1341,9 +1328,9 @@ __global__ __launch_bounds__(512, TACEX_BALL_WG_PER_CU) void fem_ball_newton_ker
         const int* tr = (kind == 0 ? bd.tri : bd.ptri) + tj * 3;
         double p3[3], trx[9], dp[3], dtr[9];
         const double* P = kind == 0 ? xs : xb;
-        const double* dP_ = kind == 0 ? vd : dxb;
+        const double* dP_ = kind == 0 ? dL : dxb;
         const double* Tq = kind == 0 ? xb : xs;
-        const double* dT = kind == 0 ? dxb : vd;
+        const double* dT = kind == 0 ? dxb : dL;
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
           p3[i] = P[pi * 3 + i]; dp[i] = dP_[pi * 3 + i];
