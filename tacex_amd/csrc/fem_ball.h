@@ -204,7 +204,8 @@ __device__ __forceinline__ void barrier3(double s, double& b, double& b1, double
 #ifndef TACEX_BALL_WG_PER_CU
 #define TACEX_BALL_WG_PER_CU 2  // waves per SIMD the kernel is compiled for (2 = one env per CU; A/B: 4 = two envs co-resident at <= 128 VGPRs, profiles/r06_experiments.md section 5)
 #endif
-__global__ __launch_bounds__(512, TACEX_BALL_WG_PER_CU) void fem_ball_newton_kernel(FemDev m, BallDev bd, double* xg, const double* xtg, double* qg, const double* qtg,
+template <int NT_>
+__global__ __launch_bounds__(NT_, NT_ >= 512 ? TACEX_BALL_WG_PER_CU : 1) void fem_ball_newton_kernel(FemDev m, BallDev bd, double* xg, const double* xtg, double* qg, const double* qtg,
                                                               const uint8_t* consg, const double* aimg, double* wsg, int pcg_max_iter,
                                                               double pcg_tol_rate, int ls_max_iter, int max_newton, double dx_tol, double dc_tol,
                                                               double* step_info, int mode, double* e_out, double* g_out, const double* xprevg,
@@ -213,7 +214,7 @@ __global__ __launch_bounds__(512, TACEX_BALL_WG_PER_CU) void fem_ball_newton_ker
   __shared__ double sh[17], sh2[16];
   __shared__ double gb[12], Bm[144], B0[144], Lc[144], Bi[144], YY[16], qs[12], qts[12], rhs12[12];
   __shared__ double crc[3 * kFemMaxCoarse], cyc[3 * kFemMaxCoarse];  // coarse residual / correction of the two-level preconditioner
-  __shared__ double Hw[8 * 12];  // per-wave partial sums of the ball rows of H.p over the pair / friction records (one copy: 61 records x 12 atomic adds on 12 addresses)
+  __shared__ double Hw[NT_ / 64 * 12];  // per-wave partial sums of the ball rows of H.p over the pair / friction records (one copy: 61 records x 12 atomic adds on 12 addresses)
   __shared__ double cpart[6 * kFemMaxCoarse];                        // ... the two halves of the coarse solve's sums
   __shared__ double qps[12], Hpq[12], zq[12];  // ... | the ball rows of H.p and of z  // the ball rows the time step started from (friction slides relative to them)
   __shared__ int n_cpv, n_cpt, n_cpe, n_cbv, n_cbt, n_cbe, n_pairs, n_act, n_fric, s_flags;
@@ -222,7 +223,8 @@ __global__ __launch_bounds__(512, TACEX_BALL_WG_PER_CU) void fem_ball_newton_ker
   // env_order: envs sorted by the solver work of their previous step, heaviest first (fem_env_order_kernel): a shard brings two envs
   // per CU, the launch ends with whatever the last-started ones need
   const int b = env_order ? env_order[blockIdx.x] : (int)blockIdx.x;
-  const int tid = threadIdx.x, NT = blockDim.x;
+  constexpr int NT = NT_, NWV = NT_ / 64;  // threads / waves per env: 512 / 8 (two waves per SIMD, 256 VGPRs each) or 256 / 4 (one wave per SIMD with the whole register file)
+  const int tid = threadIdx.x;
   const int V = m.V, T = m.T, nv = bd.nv, nt = bd.nt, VN = V + 4;
   const size_t o = (size_t)b * V * 3;
   double* x = xg + o;
@@ -413,7 +415,7 @@ __global__ __launch_bounds__(512, TACEX_BALL_WG_PER_CU) void fem_ball_newton_ker
     __syncthreads();
     double sv = 0.0;
 #pragma unroll
-    for (int w8 = 0; w8 < 8; ++w8) sv += row[w8];
+    for (int w8 = 0; w8 < NWV; ++w8) sv += row[w8];
     return sv;
   };
   const bool coarse = m.nc > 0 && m.cn_off && m.ac_inv && (mode & 2) == 0;  // (mode bit 1: block Jacobi alone, A/B)
@@ -495,14 +497,15 @@ __global__ __launch_bounds__(512, TACEX_BALL_WG_PER_CU) void fem_ball_newton_ker
       zq[tid] = zz;
       part += rL[V * 3 + tid] * zz;
     }
-    if (coarse && NT >= 512) {
+    constexpr int MW = NWV >= 8 ? 6 : 3, HALVES = MW / 3;  // waves of the coarse solve (three output chunks x one or two halves of the sum); the rest solve the chains
+    if (coarse && NWV > MW) {
       // y_c = A_c^-1 r_c, a (3 nc)^2 <= 192^2 f64 matrix in L2.  The matrix is symmetric: lane = OUTPUT index, the loop runs down a COLUMN
       // block - every load instruction reads 512 contiguous bytes, eight of them in flight, no cross-lane reduction.  Six waves: three
       // output chunks of 64 x two halves of the sum.  (A thread walking its own row: 32 of a PCG iteration's 110 kcycles with the 60-node
       // grid - 180 dependent steps, 64 cache lines per load instruction; a wave per row with shuffles: 36.)
-      if (wave < 6) {
+      if (wave < MW) {
         const int r = (wave % 3) * 64 + lane, jp = wave / 3;
-        const int j0 = jp * 96, j1 = min(nc3, j0 + 96);
+        const int j0 = jp * (192 / HALVES), j1 = min(nc3, j0 + 192 / HALVES);
         double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
         if (r < nc3) {
           int jj = j0;
@@ -519,12 +522,12 @@ __global__ __launch_bounds__(512, TACEX_BALL_WG_PER_CU) void fem_ball_newton_ker
           cpart[jp * 3 * kFemMaxCoarse + r] = (s0 + s1) + (s2 + s3);
         }
       } else {  // ... while the last two waves solve the chains
-        for (int ch = tid - 384; ch < nch; ch += NT - 384) chain_solve(ch);
+        for (int ch = tid - MW * 64; ch < nch; ch += NT - MW * 64) chain_solve(ch);
       }
       __syncthreads();
-      if (tid < nc3) cyc[tid] = cpart[tid] + cpart[3 * kFemMaxCoarse + tid];
+      for (int k = tid; k < nc3; k += NT) cyc[k] = cpart[k] + (HALVES > 1 ? cpart[3 * kFemMaxCoarse + k] : 0.0);
       __syncthreads();
-      if (tid < nc3) part += crc[tid] * cyc[tid];
+      for (int k = tid; k < nc3; k += NT) part += crc[k] * cyc[k];
     } else {
       for (int ch = tid; ch < nch; ch += NT) chain_solve(ch);
       __syncthreads();
@@ -958,7 +961,7 @@ __global__ __launch_bounds__(512, TACEX_BALL_WG_PER_CU) void fem_ball_newton_ker
       const int nf = n_fric;
       // (records dealt to the waves round-robin: the ball rows of every record go to the SAME 12 + 144 LDS addresses, and lanes of one wave
       //  that add to one address are served one after the other - 60 records in wave 0 were 45 kcycles of this phase)
-      for (int k = (tid & 63) * 8 + (tid >> 6); k < nf; k += NT) {
+      for (int k = (tid & 63) * NWV + (tid >> 6); k < nf; k += NT) {
         const double* rc = frec + (size_t)k * kBallRec;
         const int* ri = reinterpret_cast<const int*>(rc + 11);
         double u[3];
@@ -1131,9 +1134,10 @@ __global__ __launch_bounds__(512, TACEX_BALL_WG_PER_CU) void fem_ball_newton_ker
     //      the pair records are what it reads from memory ----
     for (int k = tid; k < 3 * V; k += NT) acc[k] = 0.0;  // (xs holds x since the kernel's start / the last accepted step)
     __syncthreads();
-    double md_r[2], cb_r[2];  // this thread's vertices: mass (+ constraint) diagonal and ground curvature, constant through the PCG loop
+    constexpr int VS = 1024 / NT;  // vertices per thread (V <= 780: ball_lds_ok)
+    double md_r[VS], cb_r[VS];  // this thread's vertices: mass (+ constraint) diagonal and ground curvature, constant through the PCG loop
 #pragma unroll
-    for (int sl = 0; sl < 2; ++sl) {
+    for (int sl = 0; sl < VS; ++sl) {
       const int v = tid + sl * NT;
       md_r[sl] = v < V ? m.mass[v] * (1.0 + ((cons && cons[v]) ? m.strength : 0.0)) : 0.0;
       cb_r[sl] = v < V ? cbp[v] : 0.0;
@@ -1166,7 +1170,7 @@ __global__ __launch_bounds__(512, TACEX_BALL_WG_PER_CU) void fem_ball_newton_ker
       __syncthreads();
       PCG_TICK(0);
 #pragma unroll
-      for (int sl = 0; sl < 2; ++sl) {  // (V <= 2 NT: ball_lds_ok)
+      for (int sl = 0; sl < VS; ++sl) {
         const int v = tid + sl * NT;
         if (v < V) {
 #pragma unroll
@@ -1178,14 +1182,14 @@ __global__ __launch_bounds__(512, TACEX_BALL_WG_PER_CU) void fem_ball_newton_ker
         for (int k = 0; k < 12; ++k) sv += B0[tid * 12 + k] * ps[V * 3 + k];
         Hpq[tid] = sv;
       }
-      if (tid >= 64 && tid < 64 + 96) Hw[tid - 64] = 0.0;
+      if (tid >= 64 && tid < 64 + NWV * 12) Hw[tid - 64] = 0.0;
       __syncthreads();
       PCG_TICK(6);
       // records are dealt to the waves round-robin (record k -> wave k % 8, lane k / 8) and each wave adds the ball rows into its own copy
       double* const hw = Hw + 12 * (tid >> 6);
       {
         const int na = n_act;
-        for (int k = (tid & 63) * 8 + (tid >> 6); k < na; k += NT) {
+        for (int k = (tid & 63) * NWV + (tid >> 6); k < na; k += NT) {
           const double* rc = arec + (size_t)k * kBallRec;
           const int* ri = reinterpret_cast<const int*>(rc + 11);
           const double n0 = rc[1], n1 = rc[2], n2 = rc[3];
@@ -1213,7 +1217,7 @@ __global__ __launch_bounds__(512, TACEX_BALL_WG_PER_CU) void fem_ball_newton_ker
       }
       if (fric) {
         const int nf = n_fric;
-        for (int k = (tid & 63) * 8 + (tid >> 6); k < nf; k += NT) {
+        for (int k = (tid & 63) * NWV + (tid >> 6); k < nf; k += NT) {
           const double* rc = frec + (size_t)k * kBallRec;
           const int* ri = reinterpret_cast<const int*>(rc + 11);
           const double* M = fM + (size_t)k * 6;
@@ -1247,7 +1251,7 @@ __global__ __launch_bounds__(512, TACEX_BALL_WG_PER_CU) void fem_ball_newton_ker
       for (int k = tid; k < 3 * V; k += NT) part += ps[k] * acc[k];
       if (tid < 12) {
 #pragma unroll
-        for (int w8 = 0; w8 < 8; ++w8) Hpq[tid] += Hw[w8 * 12 + tid];
+        for (int w8 = 0; w8 < NWV; ++w8) Hpq[tid] += Hw[w8 * 12 + tid];
         if (bd.kinematic) Hpq[tid] = 0.0;  // a fixed body: its rows of the operator are eliminated (only thread tid reads Hpq[tid] below)
         part += ps[V * 3 + tid] * Hpq[tid];
       }

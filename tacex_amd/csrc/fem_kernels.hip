@@ -3257,12 +3257,21 @@ int tacex_fem_ball_moments(const tacex_fem_ctx* c, double moments_out[16], doubl
   return 0;
 }
 
+// threads per env of fem_ball_newton_kernel: 512 (two waves per SIMD at 256 VGPRs: 358 of them spilled) or 256 (one wave per SIMD with the whole
+// register file); TACEX_BALL_NT picks (A/B, profiles/r06_experiments.md section 13)
+static int ball_threads() {
+  static const int nt = getenv("TACEX_BALL_NT") ? atoi(getenv("TACEX_BALL_NT")) : 512;
+  return nt == 256 ? 256 : 512;
+}
+
 static int ball_lds_ok(tacex_fem_ctx* c, const char* who) {
   const size_t lds = ball_lds_bytes(c->dev.V);
   if (lds > 160 * 1024) { set_error("%s: pad of %d vertices (x, p, accumulators and chain factors of one env must fit a CU's 160 KB of LDS)", who, c->dev.V); return 2; }
-  static size_t granted[64] = {};
+  static size_t granted[2][64] = {};
   hipError_t e = hipSetDevice(c->device);
-  if (e == hipSuccess) e = ensure_dynamic_lds(reinterpret_cast<const void*>(fem_ball_newton_kernel), lds, granted);
+  if (e == hipSuccess)
+    e = ball_threads() == 256 ? ensure_dynamic_lds(reinterpret_cast<const void*>(fem_ball_newton_kernel<256>), lds, granted[0])
+                              : ensure_dynamic_lds(reinterpret_cast<const void*>(fem_ball_newton_kernel<512>), lds, granted[1]);
   return e == hipSuccess ? 0 : fail_hip(e, "hipFuncSetAttribute(fem_ball_newton_kernel)");
 }
 
@@ -3280,7 +3289,8 @@ int tacex_fem_ball_terms(tacex_fem_ctx* c, const double* x, const double* xt, co
   if (!xt || !qt) { set_error("tacex_fem_ball_terms: null argument"); return 2; }
   if (B <= 0) return 0;
   if (int rc = ball_lds_ok(c, "tacex_fem_ball_terms")) return rc;
-  hipLaunchKernelGGL(fem_ball_newton_kernel, dim3(B), dim3(512), ball_lds_bytes(c->dev.V), (hipStream_t)stream, c->dev, c->ball, const_cast<double*>(x), xt,
+  auto kern = ball_threads() == 256 ? fem_ball_newton_kernel<256> : fem_ball_newton_kernel<512>;
+  hipLaunchKernelGGL(kern, dim3(B), dim3(ball_threads()), ball_lds_bytes(c->dev.V), (hipStream_t)stream, c->dev, c->ball, const_cast<double*>(x), xt,
                      const_cast<double*>(q), qt, cons, aim, static_cast<double*>(ws), 1, 1.0, 0, 1, 0.0, 0.0, step_info, 1, energy, grad,
                      (x_prev && q_prev) ? x_prev : nullptr, (x_prev && q_prev) ? q_prev : nullptr, static_cast<const int*>(nullptr),
                      static_cast<const double*>(nullptr));
@@ -3334,7 +3344,8 @@ int tacex_fem_ball_step(tacex_fem_ctx* c, double* x, double* v, double* q, doubl
     if (ea != hipSuccess) return fail_hip(ea, "hipFuncSetAttribute(fem_assemble_blocks_kernel)");
     hipLaunchKernelGGL(ka, dim3(B), dim3(512), lds_a, st, c->dev_nwt, x, blk, static_cast<const double*>(nullptr), 0.0);
   }
-  hipLaunchKernelGGL(fem_ball_newton_kernel, dim3(B), dim3(512), ball_lds_bytes(c->dev.V), st, c->dev, c->ball, x, xt, q, qt, cons, aim, static_cast<double*>(ws), pcg_max_iter,
+  auto kern = ball_threads() == 256 ? fem_ball_newton_kernel<256> : fem_ball_newton_kernel<512>;
+  hipLaunchKernelGGL(kern, dim3(B), dim3(ball_threads()), ball_lds_bytes(c->dev.V), st, c->dev, c->ball, x, xt, q, qt, cons, aim, static_cast<double*>(ws), pcg_max_iter,
                      pcg_tol_rate, ls_max_iter, max_newton, velocity_tol * dt, transrate_tol * dt, step_info, ball_coarse_off ? 2 : 0,
                      static_cast<double*>(nullptr), static_cast<double*>(nullptr), static_cast<const double*>(xprev),
                      static_cast<const double*>(have_last ? qlast : qprev), static_cast<const int*>(env_order), static_cast<const double*>(blk));
