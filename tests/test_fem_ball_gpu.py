@@ -364,3 +364,20 @@ def test_scene_guards_of_the_affine_body_path():
     assert np.array(S)[0] == pytest.approx(1e3 * 0.006**3, rel=1e-9)  # mass of the cube
     sim.step(max_newton_iter=30)  # falls into the ground's barrier zone and is held
     assert len(sim.check_step()["line_search_failed_envs"]) == 0 and float(sim.q[0, 0, 2]) > 0.001 + 0.003
+
+
+def test_candidate_list_overflow_is_flagged_not_fatal():
+    """A scene outside what the fixed-size lists of csrc/fem_ball.h hold (a barrier zone of 6 mm around a level-3 ball: thousands of pairs
+    inside the reach of the lists, capacities 512 candidates / 4096 pairs / 1024 active): the lists clamp, `check_step()` names the envs
+    (flag 16), nothing is written out of bounds - the neighbouring env's state and the workspace behind it are untouched, positions stay finite."""
+    from tacex_amd.uipc.gelpad_scene import FemBallScene
+
+    sc = FemBallScene(3, "cuda:0", max_newton_iter=3, level=3, d_hat=6e-3)
+    guard = torch.full((4096,), 7.25, dtype=torch.float64, device="cuda:0")  # (allocated right behind: a stray write would likely land here or fault)
+    for i in range(2):
+        sc.step(i)
+    torch.cuda.synchronize()
+    info = sc.sim.check_step(raise_on_penetration=False)
+    assert len(info["pair_list_overflow_envs"]) == 3, info
+    assert torch.isfinite(sc.sim.x).all() and torch.isfinite(sc.sim.q).all()
+    assert bool((guard == 7.25).all())
