@@ -259,8 +259,7 @@ class VisionTactileSensorUIPC:
         self.uipc_sim.wait_for_step()
         x = self.uipc_sim.x
         B, V, M, K = x.shape[0], x.shape[1], tri.shape[0], self.num_markers
-        if getattr(self, "_curr_uv_buf", None) is None or self._curr_uv_buf.shape != (B, M, 2):
-            self._curr_uv_buf = torch.empty((B, M, 2), dtype=torch.float64, device=self.device)
+        curr_uv = torch.empty((B, M, 2), dtype=torch.float64, device=self.device)  # (a fresh tensor per call, like the general path: callers may keep the last one)
         flow = None
         if out_f32 is None:
             flow = torch.empty((B, 2, K, 2), dtype=torch.float64, device=self.device)
@@ -270,10 +269,10 @@ class VisionTactileSensorUIPC:
             rc = self._lib.tacex_fem_marker_flow(
                 _lib.ptr(x), _lib.ptr(self._surf_ids64), _lib.ptr(self.cam_pos_w), _lib.ptr(self.cam_rot_inv), _lib.ptr(tri), _lib.ptr(wgt),
                 self.fx, self.fy, self.cx, self.cy, _lib.ptr(init_uv), _lib.ptr(sel), float(self.tactile_img_width / 2) if self.normalize else 0.0,
-                _lib.ptr(self._curr_uv_buf), _lib.ptr(flow) if flow is not None else None, _lib.ptr(out_f32) if out_f32 is not None else None,
+                _lib.ptr(curr_uv), _lib.ptr(flow) if flow is not None else None, _lib.ptr(out_f32) if out_f32 is not None else None,
                 B, V, M, K, _lib.current_stream_handle(self.device))
         _lib.check(rc, "tacex_fem_marker_flow")
-        self.curr_marker_uv = self._curr_uv_buf
+        self.curr_marker_uv = curr_uv
         return flow if out_f32 is None else out_f32
 
     def gen_marker_flow(self) -> torch.Tensor:
