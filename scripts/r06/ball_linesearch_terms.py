@@ -1,4 +1,5 @@
-"""Which term of the incremental potential rejects the full Newton step in the dumped light-contact states (scripts/r06/ball_dump.py)?  Oracle\noperators on the CPU: the direction of the first Newton iteration, then every term of E along it."""
+"""Which term of the incremental potential rejects the full Newton step in the dumped light-contact states (scripts/r06/ball_dump.py)?  Oracle
+operators on the CPU: the direction of the first Newton iteration, then every term of E along it."""
 import sys, numpy as np
 sys.path.insert(0, "."); sys.path.insert(0, "tests")
 from oracle.abd_oracle import AffineBody, BallScene
