@@ -575,13 +575,15 @@ class BallScene:
         return a
 
     # ---- one Newton iteration / one time step (the algorithm of fem_ball_newton_kernel) ------------------------------------------
-    def newton_step(self, y, yt, cons=None, aim=None, pcg_max_iter=1024, pcg_tol_rate=1e-3, ls_max_iter=8):
-        """PCG (block Jacobi on the pad + exact ball block) on the Gauss-Newton system, conservative step bound, backtracking line search (first E <= E0 wins).
+    def newton_step(self, y, yt, cons=None, aim=None, pcg_max_iter=1024, pcg_tol_rate=1e-3, ls_max_iter=8, ls_refine=4):
+        """PCG (block Jacobi on the pad + exact ball block) on the Gauss-Newton system, conservative step bound, backtracking line search (first E <= E0 wins,
+        then `ls_refine` bisections towards the last rejected step when the step was cut).
         Returns (y_new, [E0, E1, step, pcg iterations, max |d| over the position rows, max |d| over the ball's affine rows])."""
         g = self.gradient(y, yt, cons, aim)
         d, it = pcg_solve(lambda p: self.hess_vec(y, p, cons), self.preconditioner(y, cons), -g, pcg_max_iter, pcg_tol_rate)
         E0 = self.energy(y, yt, cons, aim)
         step = self.max_step(y, d)
+        step_full = step
         y_new, E1 = y, E0
         for _ in range(max(ls_max_iter, LS_RESCUE) + 1):
             cand = y + step * d
@@ -592,6 +594,18 @@ class BallScene:
             step *= 0.5
         else:
             step = 0.0
+        if step > 0.0 and step < step_full:
+            # a step that had to be cut: `ls_refine` bisections between it and the last rejected one keep the largest step that still does
+            # not increase E - the pair that cut it ends INSIDE the barrier zone, in the next Hessian (csrc/fem_ball.h does the same)
+            lo, hi = step, 2.0 * step
+            for _ in range(ls_refine):
+                mid = 0.5 * (lo + hi)
+                Ec = self.energy(y + mid * d, yt, cons, aim)
+                if Ec <= E0:
+                    lo, y_new, E1 = mid, y + mid * d, Ec
+                else:
+                    hi = mid
+            step = lo
         return y_new, np.array([E0, E1, step, it, np.abs(d[: self.V + 1]).max(), np.abs(d[self.V + 1:]).max()])
 
     def step(self, y, v, cons=None, aim=None, gravity=(0.0, 0.0, -9.8), max_newton=64, velocity_tol=0.05, transrate_tol=0.1, **kw):

@@ -8,6 +8,10 @@ cfg = None
 if os.environ.get("TACEX_BALL_EDGE_EDGE") == "0":  # A/B: point-triangle pairs alone
     cfg = UipcSimCfg(device="cuda:0")
     cfg.contact.edge_edge = False
+if "TACEX_BALL_LS_REFINE" in os.environ:  # A/B: bisections after a cut line search (cfg.line_search.refine, default 4)
+    cfg = cfg or UipcSimCfg(device="cuda:0")
+    cfg.linear_system.coarse_grid = (4, 5, 1)  # (what FemBallScene sets when it builds its own cfg)
+    cfg.line_search.refine = int(os.environ["TACEX_BALL_LS_REFINE"])
 sc = FemBallScene(B, "cuda:0", max_newton_iter=64, cfg=cfg)
 for i in range(30):
     torch.cuda.synchronize(); t0 = time.perf_counter()

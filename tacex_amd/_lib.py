@@ -11,7 +11,7 @@ from pathlib import Path
 from ._build import LIB, build_library
 
 MAX_LEVELS = 8
-ABI_VERSION = 14  # TACEX_ABI_VERSION of include/tacex_hip.h; bumped whenever a signature or struct layout changes
+ABI_VERSION = 15  # TACEX_ABI_VERSION of include/tacex_hip.h; bumped whenever a signature or struct layout changes
 FLAG_NO_SHIFT = 1
 FLAG_HAVE_FRAME_MIN = 2
 FLAG_WITH_SHADOW = 4
@@ -145,6 +145,7 @@ SIGNATURES = {
     "tacex_fem_set_affine_body": (_i, [_vp, _i, _vp, _i, _vp, _d, _d, _vp, _i, _vp, _d, _d, _d, _i, _i]),
     "tacex_fem_ball_workspace_bytes": (_sz, [_vp, _i]),
     "tacex_fem_set_edge_edge": (_i, [_vp, _i]),
+    "tacex_fem_set_line_search_refine": (_i, [_vp, _i]),
     "tacex_fem_ball_moments": (_i, [_vp, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "tacex_fem_ball_terms": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp]),
     "tacex_fem_ball_step": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, C.POINTER(C.c_double), _i, _d, _d, _i, _d, _i, _vp]),

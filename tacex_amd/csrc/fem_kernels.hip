@@ -2505,6 +2505,7 @@ struct tacex_fem_ctx {
   int ind_prev_B = 0;
   const double* rest = nullptr;  // (V,3) rest positions (tacex_fem_reset_envs)
   int last_resident = -1;       // which Newton kernel the last launch used: 1 CU-resident, 0 streaming, -1 none yet (tacex_fem_newton_resident)
+  int ls_refine = 4;            // bisections after a cut line search in fem_ball_newton_kernel (tacex_fem_set_line_search_refine)
   int fric_lag_mode = 0;        // 0: lag at the step's start state, capped by the contact reaction (round 4); 1: IPC's previous-configuration lag
   bool deterministic = false;   // window + CSR-gather sweeps (fixed summation order) instead of LDS atomics (tacex_fem_set_deterministic)
   bool follow_indenter = true;  // contact-following start of the Newton loop (tacex_fem_set_contact_following; fem_newton_lds_kernel)
@@ -2807,6 +2808,12 @@ int tacex_fem_set_friction(tacex_fem_ctx* c, double friction_ratio, double eps_v
   }
   c->dev.fric_mu = c->dev_nwt.fric_mu = friction_ratio;
   c->dev.fric_eps = c->dev_nwt.fric_eps = eps_velocity * c->dev.dt;
+  return 0;
+}
+
+int tacex_fem_set_line_search_refine(tacex_fem_ctx* c, int bisections) {
+  if (!c || bisections < 0 || bisections > 15) { set_error("tacex_fem_set_line_search_refine: need a context and 0 <= bisections <= 15"); return 2; }
+  c->ls_refine = bisections;
   return 0;
 }
 
@@ -3346,7 +3353,7 @@ int tacex_fem_ball_step(tacex_fem_ctx* c, double* x, double* v, double* q, doubl
   }
   auto kern = ball_threads() == 256 ? fem_ball_newton_kernel<256> : fem_ball_newton_kernel<512>;
   hipLaunchKernelGGL(kern, dim3(B), dim3(ball_threads()), ball_lds_bytes(c->dev.V), st, c->dev, c->ball, x, xt, q, qt, cons, aim, static_cast<double*>(ws), pcg_max_iter,
-                     pcg_tol_rate, ls_max_iter, max_newton, velocity_tol * dt, transrate_tol * dt, step_info, ball_coarse_off ? 2 : 0,
+                     pcg_tol_rate, ls_max_iter, max_newton, velocity_tol * dt, transrate_tol * dt, step_info, (ball_coarse_off ? 2 : 0) | ((c->ls_refine & 15) << 8),
                      static_cast<double*>(nullptr), static_cast<double*>(nullptr), static_cast<const double*>(xprev),
                      static_cast<const double*>(have_last ? qlast : qprev), static_cast<const int*>(env_order), static_cast<const double*>(blk));
   hipLaunchKernelGGL(fem_velocity_kernel, dim3((unsigned)((n3 + 255) / 256)), dim3(256), 0, st, x, xprev, v, n3, 1.0 / dt, static_cast<const double*>(nullptr),

@@ -76,6 +76,11 @@ class UipcSimCfg:
     class LineSearch:
         max_iter: int = 8
         report_energy: bool = False
+        refine: int = 4
+        """Scenes with an affine body (`tacex_fem_set_line_search_refine`): bisections between the accepted and the last rejected step of a
+        backtracking search that had to cut the step - the largest step that still does not increase the potential takes the pair that cut it
+        INSIDE the barrier zone, where the next iteration's Hessian sees it (profiles/r06_experiments.md sections 15-16).  0 = plain halving.
+        Not in the reference cfg (uipc_sim.py:96-101)."""
 
     line_search: LineSearch = LineSearch()
 
@@ -200,6 +205,7 @@ class UipcSim:
             float(c.default_contact_resistance) * 1e9 * d_hat, float(self.cfg.ground_height), 1 if c.enable else 0,
             1 if body.cfg.constitution_cfg.kinematic else 0), "tacex_fem_set_affine_body")
         _lib.check(self._lib.tacex_fem_set_edge_edge(self._handle, 1 if getattr(c, "edge_edge", True) else 0), "tacex_fem_set_edge_edge")
+        _lib.check(self._lib.tacex_fem_set_line_search_refine(self._handle, int(getattr(self.cfg.line_search, "refine", 4))), "tacex_fem_set_line_search_refine")
         # one default contact model for every pair of surfaces (US:192-201): friction ratio / eps_velocity of the cfg act on the pairs and the ground
         _lib.check(self._lib.tacex_fem_set_friction(self._handle, float(c.default_friction_ratio) if c.enable_friction else 0.0,
                                                     float(c.eps_velocity)), "tacex_fem_set_friction")
