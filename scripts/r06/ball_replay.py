@@ -89,3 +89,45 @@ print("mean constraint offset", shift, " max |x~ - x| pad", np.abs(d_pred[:V]).m
 for name, d0 in (("zero", np.zeros(n)), ("pad follows its constraints rigidly", d_rigid.reshape(-1)), ("x~ - x (all rows)", d_pred.reshape(-1)), ("x~ - x (pad rows)", d_pred_pad.reshape(-1))):
     d, it = pcg_warm(lambda p: H @ p, Mb, -g, d0, 1e-3)
     print(f"   warm start {name:40s}: {it} iterations")
+
+# ---- line preconditioners on the last sample: exact inverses of H restricted to the vertex lines of the structured pad along z (what the kernel's
+#      chains are), and additionally along x and y; always + ball block + the nested (4, 5, 1) coarse correction ----
+from oracle.fem_oracle import box_tet_mesh  # noqa
+Xr = m.X
+def lines_along(axis):
+    other = [a for a in range(3) if a != axis]
+    key = np.round(Xr[:, other] * 1e7).astype(np.int64)
+    groups = {}
+    for v in range(V):
+        groups.setdefault(tuple(key[v]), []).append(v)
+    return [sorted(g, key=lambda v: Xr[v, axis]) for g in groups.values()]
+def line_inverse(lines):
+    blocks = []
+    for ln in lines:
+        idx = np.concatenate([[3 * v, 3 * v + 1, 3 * v + 2] for v in ln])
+        blocks.append((idx, np.linalg.inv(H[np.ix_(idx, idx)])))
+    def app(r):
+        z = np.zeros_like(r)
+        for idx, Bi_ in blocks:
+            z[idx] = Bi_ @ r[idx]
+        return z
+    return app
+nd, ww, ncc = build_coarse_space(m.X, (4, 5, 1))
+Pv = prolongation_matrix(nd, ww, ncc)
+Ai = np.linalg.inv(Pv.T @ A0 @ Pv)
+Lz, Lx, Ly = (line_inverse(lines_along(a)) for a in (2, 0, 1))
+print("lines:", [len(lines_along(a)) for a in (2, 0, 1)], "of lengths", [len(lines_along(a)[0]) for a in (2, 0, 1)])
+def mk(parts, scale=1.0):
+    def M(r):
+        z = np.zeros_like(r)
+        for p_ in parts:
+            z += scale * p_(r)
+        z[3 * V:] = np.linalg.solve(Bfull, r[3 * V:])
+        z[:3 * V] += Pv @ (Ai @ (Pv.T @ r[:3 * V]))
+        return z
+    return M
+for name, M in (("z lines (the kernel's chains) + coarse", mk([Lz])), ("z + x + y lines + coarse", mk([Lz, Lx, Ly])), ("(z + x + y) / 3 + coarse", mk([Lz, Lx, Ly], 1 / 3)),
+                ("z + x lines + coarse", mk([Lz, Lx])), ("z + y lines + coarse", mk([Lz, Ly]))):
+    for tol in (1e-3,):
+        d, it = pcg_solve(lambda p: H @ p, M, -g, 4000, tol)
+        print(f"   {name:45s}: {it} iterations")
