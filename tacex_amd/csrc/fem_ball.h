@@ -1366,7 +1366,7 @@ __global__ __launch_bounds__(NT_, NT_ >= 512 ? TACEX_BALL_WG_PER_CU : 1) void fe
       step *= 0.5;
       __syncthreads();
     }
-    // REFINEMENT (mode bits 8-11 = bisections, A/B): a step the halving had to cut was cut by a pair ENTERING the barrier zone (10 GPa against a
+    // REFINEMENT (mode bits 8-11 = bisections: tacex_fem_set_line_search_refine): a step the halving had to cut was cut by a pair ENTERING the barrier zone (10 GPa against a
     // 0.1 MPa gel: a few um inside cost more than the step gains, r06 section 15), and the accepted half usually leaves that pair just
     // OUTSIDE - where it has no curvature for the next iteration either, which is then cut again.  A few bisections between the accepted and
     // the last rejected step find a larger one that still decreases E and has the pair inside, active in the next Hessian.
@@ -1384,15 +1384,14 @@ __global__ __launch_bounds__(NT_, NT_ >= 512 ? TACEX_BALL_WG_PER_CU : 1) void fe
         const double Ec = energy(ycl, rhs12, xbc);
         if (Ec <= E0) { lo_s = mid; E1 = Ec; e_carry = Ec; } else { hi_s = mid; }
       }
-      if (lo_s != step || true) {  // the candidate buffers hold the LAST trial: rebuild them at the accepted step
-        step = lo_s;
-        __syncthreads();
-        for (int k = tid; k < 3 * V; k += NT) ycl[k] = xs[k] + step * dL[k];
-        if (tid < 12) rhs12[tid] = qs[tid] + step * dL[V * 3 + tid];
-        __syncthreads();
-        ball_points(rhs12, xbc);
-        __syncthreads();
-      }
+      // (the candidate buffers hold the LAST trial: rebuild them at the accepted step)
+      step = lo_s;
+      __syncthreads();
+      for (int k = tid; k < 3 * V; k += NT) ycl[k] = xs[k] + step * dL[k];
+      if (tid < 12) rhs12[tid] = qs[tid] + step * dL[V * 3 + tid];
+      __syncthreads();
+      ball_points(rhs12, xbc);
+      __syncthreads();
     }
     ++n_newton;
     BALL_TICK(6);  // line search
